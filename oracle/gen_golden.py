@@ -1,0 +1,285 @@
+"""Generate tests/golden/*.npz by running the REAL reference on closed-form data.
+
+Runs only in the build container (needs /root/reference, read-only).  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+What it does:
+  * puts our two import shims (oracle/_shims: timm, mmcv) and /root/reference on
+    sys.path; mocks the data-pipeline-only imports of diffusion_trainer
+    (cv2, torchvision, torchaudio, ...) which are absent here;
+  * builds the reference ``SalUNet`` and loads ``synth_state_dict`` into it
+    (the same closed-form fill the tests regenerate on the GPU box);
+  * runs reference forward passes with hooks for intermediate taps, the
+    reference ``NoiseScheduleVP`` / ``DPM_Solver`` and the reference trainer's
+    ``sample_ddim``;
+  * stores inputs' checksums, outputs and (strided) taps as small .npz files.
+
+The fixtures are data only; no reference source is copied.  Test infrastructure.
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(HERE, "_shims"), REF, REPO]
+sys.dont_write_bytecode = True
+
+from oracle import salunet_oracle as orc  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+TAP_SAMPLES = 4096  # large taps are stored as ~4096 strided samples + statistics
+
+
+def ref_kwargs(cfg: orc.SalUNetConfig):
+    n = cfg.num_stages
+    planes = {0: cfg.down_embed_dim, 1: 192, 2: 384, 3: cfg.ori_embed_dim}
+    return dict(
+        image_based=True, img_size=tuple(cfg.img_size), frames_len=1, tasks=["futr"], in_index=[0, 1, 2, 3],
+        idx_to_planes=planes, mid_num_stages=n, temporal_size=9, temporal_list=list(cfg.temporal_list),
+        keep_max_len=5, exclude_layers=[], futr_num_stages=0, ori_embed_dim=cfg.ori_embed_dim,
+        down_embed_dim=cfg.down_embed_dim, patch_size=[0] + [3] * (n - 1), patch_stride=[0] + [1] * (n - 1),
+        patch_padding=list(cfg.dilation), up_channel=list(cfg.up_channel), num_heads=list(cfg.num_heads),
+        mlp_ratio=[2.0] * n, drop_path_rate=[0.15] * n, qkv_bias=[True] * n, kv_proj_method=["avg"] * n,
+        kernel_kv=list(cfg.kernel_kv), padding_kv=[0] * n, stride_kv=list(cfg.kernel_kv),
+        q_proj_method=["dw_bn"] * n, kernel_q=[3] * n, padding_q=[1] * n, stride_q=[1] * n,
+    )
+
+
+def build_reference(cfg):
+    from models.saliency_decoder.sal_unet import SalUNet
+
+    net = SalUNet(**ref_kwargs(cfg)).eval()
+    ref_sd = net.state_dict()
+    tmpl = orc.state_dict_template(cfg)
+    assert list(ref_sd.keys()) == list(tmpl.keys()) or set(ref_sd) == set(tmpl), (
+        set(ref_sd) ^ set(tmpl)
+    )
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(tmpl[k].shape), (k, ref_sd[k].shape, tmpl[k].shape)
+    sd = orc.synth_state_dict(tmpl)
+    net.load_state_dict(sd, strict=True)
+    return net, sd
+
+
+def run_reference(net, x, t, feats, audio):
+    taps = {}
+    hooks = []
+
+    def grab(name, sel=lambda o: o):
+        def fn(_m, _i, o):
+            taps[name] = sel(o).detach().clone()
+
+        return fn
+
+    hooks.append(net.temb.dense[1].register_forward_hook(grab("temb")))
+    hooks.append(net.down1.register_forward_hook(grab("down1")))
+    nlev = len(net.res_encoder)
+    for i, blk in enumerate(net.res_encoder):
+        hooks.append(blk[0].register_forward_hook(grab(f"res{i}")))
+        hooks.append(blk[1].register_forward_hook(grab(f"noise{nlev - 1 - i}", lambda o: o.unsqueeze(2))))
+    for i, st in enumerate(net.invpt_decoder.mid_stages):
+        hooks.append(st.register_forward_hook(grab(f"stage{i}", lambda o: o[0])))
+    hooks.append(net.invpt_decoder.mt_proj.register_forward_pre_hook(
+        lambda _m, i: taps.__setitem__("multi_scale", i[0].detach().clone())))
+    with torch.no_grad():
+        out = net(x, t, [f.clone() for f in feats], audio)  # fresh list: reference mutates it (D4)
+    for h in hooks:
+        h.remove()
+    return out, taps
+
+
+def pack_taps(taps):
+    out = {}
+    for k, v in taps.items():
+        flat = v.reshape(-1).double()
+        out[f"tap.{k}.shape"] = np.array(v.shape, dtype=np.int64)
+        out[f"tap.{k}.stats"] = np.array([flat.mean().item(), flat.std().item(), flat.abs().max().item()])
+        stride = 1 if flat.numel() <= 2 * TAP_SAMPLES else (flat.numel() // TAP_SAMPLES) | 1
+        out[f"tap.{k}.stride"] = np.array(stride, dtype=np.int64)
+        out[f"tap.{k}.sample"] = v.reshape(-1)[::stride].numpy().copy()
+    return out
+
+
+def checksum(sd):
+    s = 0.0
+    for k in sorted(sd):
+        if sd[k].dtype.is_floating_point:
+            s += float(sd[k].double().abs().sum())
+    return s
+
+
+CASES = {
+    # name: (cfg, batch, audio, t)
+    "small_av": (orc.SalUNetConfig(img_size=(64, 128)), 2, True, torch.tensor([3, 977], dtype=torch.int64)),
+    "small_vis": (orc.SalUNetConfig(img_size=(64, 128)), 2, False, torch.tensor([998.996, 0.46], dtype=torch.float32)),
+    "tiny_av": (
+        orc.SalUNetConfig(img_size=(64, 128), up_channel=(256, 128, 64, 32), ori_embed_dim=256, down_embed_dim=32),
+        2, True, torch.tensor([250, 750], dtype=torch.int64)),
+    "tiny_vis": (
+        orc.SalUNetConfig(img_size=(64, 128), up_channel=(256, 128, 64, 32), ori_embed_dim=256, down_embed_dim=32),
+        1, False, torch.tensor([17.25], dtype=torch.float32)),
+    "full_av_b1": (orc.SalUNetConfig(), 1, True, torch.tensor([500], dtype=torch.int64)),
+    "full_vis_b1": (orc.SalUNetConfig(), 1, False, torch.tensor([998.07], dtype=torch.float32)),
+}
+
+
+def gen_forward_cases():
+    for name, (cfg, B, av, t) in CASES.items():
+        net, sd = build_reference(cfg)
+        x, feats, audio = orc.synth_inputs(cfg, B, av, tag=name)
+        out, taps = run_reference(net, x, t, feats, audio)
+        # restatement must agree with the reference before anything is written
+        otaps = {}
+        with torch.no_grad():
+            mine = orc.salunet_forward(sd, cfg, x, t, feats, audio, taps=otaps)
+        err = (mine - out).abs().max().item()
+        print(f"[{name}] ref-vs-restatement max|d| = {err:.3e}; out range {out.min():.4f}..{out.max():.4f}")
+        assert err < 2e-5, err
+        for k in taps:
+            e = (otaps[k] - taps[k]).abs().max().item() / (taps[k].abs().max().item() + 1e-12)
+            assert e < 2e-5, (k, e)
+        d = dict(output=out.numpy(), t=t.numpy(), batch=np.array(B), audio=np.array(int(av)),
+                 weights_checksum=np.array(checksum(sd)),
+                 inputs_checksum=np.array(float(x.double().abs().sum() + sum(f.double().abs().sum() for f in feats))))
+        d.update(pack_taps(taps))
+        np.savez_compressed(os.path.join(GOLD, f"salunet_{name}.npz"), **d)
+
+
+def gen_f1_property():
+    """F1: visual-only eval output is independent of (x, t) -- record it as a fixture fact."""
+    cfg, B, _, _ = CASES["tiny_vis"]
+    net, _ = build_reference(cfg)
+    x, feats, _ = orc.synth_inputs(cfg, B, False, tag="f1")
+    o1, _ = run_reference(net, x, torch.tensor([10]), feats, None)
+    o2, _ = run_reference(net, x * -2 + 1, torch.tensor([900]), feats, None)
+    print("F1 visual-only max|d| =", (o1 - o2).abs().max().item())
+    assert (o1 - o2).abs().max().item() == 0.0
+
+
+def gen_sampler_cases():
+    from models.diffusion_decoder.diffusion_utils import get_beta_schedule, to_torch
+    from models.dpm_solver.sampler import DPM_Solver, NoiseScheduleVP, model_wrapper
+
+    betas64 = get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)
+    betas = to_torch(betas64)
+    ns = NoiseScheduleVP("discrete", betas=betas)
+    tg = torch.linspace(1.0 / ns.total_N, 1.0, 41)
+    lam = ns.marginal_lambda(tg)
+    d = dict(
+        betas=betas64, total_N=np.array(ns.total_N), t_grid=tg.numpy(),
+        log_alpha=ns.marginal_log_mean_coeff(tg).numpy(), std=ns.marginal_std(tg).numpy(), lam=lam.numpy(),
+        inv_lam=ns.inverse_lambda(lam).numpy(),
+    )
+
+    def toy(x, t_in, img, **kw):  # x0-predicting stand-in, smooth in x and t
+        return torch.sigmoid(0.7 * x + 0.001 * t_in.view(-1, 1, 1, 1) + img[0])
+
+    for algo in ("dpmsolver", "dpmsolver++"):
+        for skip in ("logSNR", "time_uniform"):
+            fn = model_wrapper(toy, ns, model_type="x_start", model_kwargs={}, guidance_type="uncond")
+            solver = DPM_Solver(fn, ns, algorithm_type=algo)
+            d[f"ts.{algo}.{skip}"] = solver.get_time_steps(skip, 1.0, 1.0 / ns.total_N, 49, "cpu").numpy()
+            # batch 1: the reference's x_start branch (sampler.py:290-292) omits expand_dims on
+            # alpha_t/sigma_t, so it only broadcasts correctly for B == 1 (defect D6)
+            x = orc.synth_tensor("dpm.xT", (1, 1, 8, 12))
+            img = [orc.synth_tensor("dpm.img", (1, 1, 8, 12), 0.3)]
+            xe, inter = solver.sample(x, img, steps=49, order=2, skip_type=skip, method="multistep",
+                                      lower_order_final=False, denoise_to_zero=True, solver_type="dpmsolver",
+                                      return_intermediate=True)
+            d[f"x0.{algo}.{skip}"] = xe.numpy()
+            d[f"inter.{algo}.{skip}"] = torch.stack(inter)[[0, 1, 2, 10, 25, 48, 49, 50]].numpy()
+    # few-step run exercising lower_order_final and the noise-model branch
+    fn = model_wrapper(lambda x, t, img, **kw: torch.tanh(0.5 * x + img[0]), ns, model_type="noise",
+                       model_kwargs={}, guidance_type="uncond")
+    solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+    x = orc.synth_tensor("dpm.xT", (2, 1, 8, 12))
+    img = [orc.synth_tensor("dpm.img", (2, 1, 8, 12), 0.3)]
+    d["x0.few"] = solver.sample(x, img, steps=6, order=2, skip_type="time_uniform", method="multistep",
+                                lower_order_final=True, denoise_to_zero=False).numpy()
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), **d)
+    print("sampler: total_N", ns.total_N, "first ts", d["ts.dpmsolver.logSNR"][:3])
+
+
+def gen_trainer_ddim():
+    """Drive the reference trainer's own sample_ddim (R/diffusion_trainer.py:440-480) on CPU."""
+    for m in ("cv2", "torchvision", "torchvision.transforms", "torchaudio", "torchaudio.functional", "soundfile",
+              "resampy", "wandb", "skimage", "skimage.transform", "matplotlib", "matplotlib.pylab", "pandas",
+              "matplotlib.pyplot", "torchvision.transforms.functional", "skimage.io"):
+        sys.modules.setdefault(m, mock.MagicMock())
+    import yaml
+
+    import diffusion_trainer as dt
+
+    cfg, _, _, _ = CASES["tiny_av"]
+    net, sd = build_reference(cfg)
+
+    class Top(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.decoder_net = net
+            self.audio_net = None
+            self.visual_net = None
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.module = Top()
+
+    dt.generate_av_model = lambda opt: (Wrap().eval(), None)
+
+    def ns(dct):
+        o = types.SimpleNamespace()
+        for k, v in dct.items():
+            setattr(o, k, ns(v) if isinstance(v, dict) else v)
+        return o
+
+    with open(os.path.join(REF, "cfgs", "diffusion.yml")) as f:
+        conf = ns(yaml.safe_load(f))
+    conf.sampling.timesteps = 10
+    tr = dt.DiffusionTrainer(types.SimpleNamespace(), conf, device=torch.device("cpu"))
+    x, feats, audio = orc.synth_inputs(cfg, 1, True, tag="ddim")
+    out = tr.sample_ddim(x, feats, audio)
+    np.savez_compressed(
+        os.path.join(GOLD, "ddim_tiny_av.npz"), output=out.numpy(), alphas_hat=tr.alphas_hat.numpy(),
+        sqrt_recip=tr.sqrt_recip_alphas_hat.numpy(), sqrt_recipm1=tr.sqrt_recipm1_alphas_hat.numpy())
+    print("ddim: out range", out.min().item(), out.max().item())
+
+    # the same net through the reference DPM-Solver (multistep-2, 50 NFE, x_start) with a
+    # non-mutating model_fn (the trainer's own DPM branch is broken as shipped: D1-D4)
+    from models.dpm_solver.sampler import DPM_Solver, NoiseScheduleVP, model_wrapper
+
+    nsched = NoiseScheduleVP("discrete", betas=tr.betas)
+
+    def model_fn(x, t, vis, **kw):
+        return net(x, t, [v.clone() for v in vis], audio)
+
+    fn = model_wrapper(model_fn, nsched, model_type="x_start", model_kwargs={}, guidance_type="uncond")
+    solver = DPM_Solver(fn, nsched, algorithm_type="dpmsolver")
+    x, feats, audio = orc.synth_inputs(cfg, 1, True, tag="ddim")
+    with torch.no_grad():
+        xe = solver.sample(x, feats, steps=49, order=2, skip_type="logSNR", method="multistep",
+                           lower_order_final=False, denoise_to_zero=True, solver_type="dpmsolver")
+    np.savez_compressed(os.path.join(GOLD, "dpm50_tiny_av.npz"), output=xe.numpy())
+    print("dpm50: out range", xe.min().item(), xe.max().item())
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer"]
+    if "forward" in which:
+        gen_forward_cases()
+    if "f1" in which:
+        gen_f1_property()
+    if "sampler" in which:
+        gen_sampler_cases()
+    if "trainer" in which:
+        gen_trainer_ddim()
