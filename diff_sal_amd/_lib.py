@@ -1,0 +1,85 @@
+"""ctypes binding of libdiffsal_hip.so (the C ABI declared in include/diffsal.h).
+
+The library is the product path: if it is missing or does not load, importing the ops fails
+loudly -- there is no PyTorch/CPU fallback.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_f = C.c_void_p  # device pointers travel as integers
+c_i = C.c_int
+c_fl = C.c_float
+c_sz = C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """struct diffsal_conv_desc (include/diffsal.h)."""
+
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride_h", "stride_w", "pad_t", "pad_l",
+        "dil_h", "dil_w", "act", "rowvec_ld")]
+
+
+SIGNATURES = {
+    "diffsal_version": (c_i, []),
+    "diffsal_last_error": (C.c_char_p, []),
+    "diffsal_temb_mlp": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "diffsal_dense_small": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f]),
+    "diffsal_conv_in": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_groupnorm_ws_bytes": (c_sz, [c_i, c_i]),
+    "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_f]),
+    "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_audio_fuse": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),
+    "diffsal_dwconv3_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f]),
+    "diffsal_dwpool_ln_kv": (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
+    "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
+    "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
+}
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the HIP library (building it first if sources are newer); raises if impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path) or (_build.needs_build() and os.environ.get("DIFFSAL_NO_REBUILD") != "1"):
+        try:
+            _build.build_library()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    f"libdiffsal_hip.so is missing and could not be built ({e}); run `python -m diff_sal_amd.build`"
+                ) from e
+    # PyTorch bundles its own libamdhip64 (same soname as /opt/rocm's).  Import it first so that ONE HIP
+    # runtime lives in the process and streams / device pointers are shared with torch.
+    import torch  # noqa: F401
+
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().diffsal_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdiffsal_hip {what} failed (code {rc}): {msg}")

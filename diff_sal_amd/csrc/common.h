@@ -1,0 +1,67 @@
+// Shared helpers for the gfx950 kernels of libdiffsal_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/diffsal.h"
+
+namespace diffsal {
+
+void set_error(const char* fmt, ...);
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return DIFFSAL_E_LAUNCH;
+  }
+  return DIFFSAL_OK;
+}
+
+#define DS_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      diffsal::set_error(__VA_ARGS__); \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Butterfly all-reduce over `width` (power of two <= 64) consecutive lanes.
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+__device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Source coordinate of a bilinear resize with align_corners=False (PyTorch area_pixel_compute_source_index).
+__device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float s = (static_cast<float>(dst) + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = static_cast<int>(s);
+  i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - static_cast<float>(i0);
+}
+
+}  // namespace diffsal

@@ -1,0 +1,360 @@
+// Normalisation-family kernels (HBM-bound): GroupNorm+swish on NHWC images, LayerNorm over C on
+// tokens, and the depthwise q/k/v projections fused with their LayerNorm.
+//
+// Layout rule: channels are the fastest dimension everywhere, so a group of G = pow2 lanes owns one
+// token/pixel and reads it with coalesced float4 loads; reductions over C are xor-butterflies inside
+// that lane group (64-wide wavefronts hold 64/G tokens at once).
+#include "common.h"
+
+namespace diffsal {
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32, eps) + swish.   R/models/saliency_decoder/sal_unet.py:36-44
+// pass 1: per (image, pixel-chunk) partial sums per group  -> ws[B][chunks][groups][2] (double)
+// pass 2: finalise mean/rstd per (image, group), normalise, affine, swish.
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_CHUNKS = 32;
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ ws,
+                                                       int HW, int C, int groups) {
+  extern __shared__ double sh[];  // [C][2]
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int c4n = C >> 2;                     // float4 per pixel
+  const int pix_per_pass = 256 / c4n > 0 ? 256 / c4n : 1;
+  const int my_c4 = threadIdx.x % c4n;
+  const int my_p = threadIdx.x / c4n;
+  const bool active = threadIdx.x < pix_per_pass * c4n;
+  const int p_begin = static_cast<long>(HW) * chunk / GN_CHUNKS;
+  const int p_end = static_cast<long>(HW) * (chunk + 1) / GN_CHUNKS;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (active) {
+    const float* base = x + (static_cast<long>(b) * HW) * C + my_c4 * 4;
+    for (int p = p_begin + my_p; p < p_end; p += pix_per_pass) {
+      const float4 v = ld4(base + static_cast<long>(p) * C);
+      s[0] += v.x; q[0] += v.x * v.x;
+      s[1] += v.y; q[1] += v.y * v.y;
+      s[2] += v.z; q[2] += v.z * v.z;
+      s[3] += v.w; q[3] += v.w * v.w;
+    }
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.0;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      atomicAdd(&sh[(my_c4 * 4 + i) * 2 + 0], static_cast<double>(s[i]));
+      atomicAdd(&sh[(my_c4 * 4 + i) * 2 + 1], static_cast<double>(q[i]));
+    }
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    double a = 0, bq = 0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sh[c * 2]; bq += sh[c * 2 + 1]; }
+    double* o = ws + ((static_cast<long>(b) * GN_CHUNKS + chunk) * groups + g) * 2;
+    o[0] = a; o[1] = bq;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ ws,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int HW, int C, int groups, float eps) {
+  extern __shared__ float shf[];  // [C] scale, [C] shift
+  const int b = blockIdx.y;
+  const int cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    double s = 0, q = 0;
+    for (int k = 0; k < GN_CHUNKS; ++k) {
+      const double* o = ws + ((static_cast<long>(b) * GN_CHUNKS + k) * groups + g) * 2;
+      s += o[0]; q += o[1];
+    }
+    const double n = static_cast<double>(HW) * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    const float sc = rstd * gamma[c];
+    shf[c] = sc;
+    shf[C + c] = beta[c] - static_cast<float>(mean) * sc;
+  }
+  __syncthreads();
+  const int c4n = C >> 2;
+  const long total4 = static_cast<long>(HW) * c4n;
+  const float* xb = x + static_cast<long>(b) * HW * C;
+  float* ob = out + static_cast<long>(b) * HW * C;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    float4 v = ld4(xb + i * 4);
+    v.x = swishf(v.x * shf[c + 0] + shf[C + c + 0]);
+    v.y = swishf(v.y * shf[c + 1] + shf[C + c + 1]);
+    v.z = swishf(v.z * shf[c + 2] + shf[C + c + 2]);
+    v.w = swishf(v.w * shf[c + 3] + shf[C + c + 3]);
+    st4(ob + i * 4, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row helpers: a lane group of G lanes owns one token of C channels (C % 4 == 0), NV = ceil(C/4/G)
+// float4 per lane.  Two-pass (mean, then centred variance) in registers.
+// ------------------------------------------------------------------------------------------------
+template <int G, int NV>
+__device__ __forceinline__ void ln_rows_finish(float4 (&v)[NV], int gl, int C, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps, float* __restrict__ orow) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  s = group_sum<G>(s);
+  const float mean = s / static_cast<float>(C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  q = group_sum<G>(q);
+  const float rstd = 1.0f / sqrtf(q / static_cast<float>(C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) {
+      const float4 g = ld4(gamma + c), b = ld4(beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      st4(orow + c, o);
+    }
+  }
+}
+
+// LayerNorm over C.  R/.../transformer.py:110,121; sal_unet.py:447,473
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out,
+                                                        int M, int C, float eps) {
+  constexpr int ROWS = 256 / G;
+  const int gl = threadIdx.x % G;
+  const int gr = threadIdx.x / G;
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < M; row += static_cast<long>(gridDim.x) * ROWS) {
+    const float* xr = x + row * C;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      v[i] = c < C ? ld4(xr + c) : make_float4(0, 0, 0, 0);
+    }
+    ln_rows_finish<G, NV>(v, gl, C, gamma, beta, eps, out + row * C);
+  }
+}
+
+// depthwise 3x3 (pad 1, stride 1) + LayerNorm.  R/.../attention.py:36-47,94 (quirk Q8: centre slice)
+template <int G, int NV>
+__global__ __launch_bounds__(256) void dwconv3_ln_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ out, int N, int H, int W, int C, float eps) {
+  constexpr int ROWS = 256 / G;
+  const int gl = threadIdx.x % G;
+  const int gr = threadIdx.x / G;
+  const long M = static_cast<long>(N) * H * W;
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < M; row += static_cast<long>(gridDim.x) * ROWS) {
+    const int xw = static_cast<int>(row % W);
+    const int yh = static_cast<int>((row / W) % H);
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = yh + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = xw + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const float* xr = x + (row + static_cast<long>(ky - 1) * W + (kx - 1)) * C;
+        const float* wr = w9 + (ky * 3 + kx) * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c = (gl + i * G) * 4;
+          if (c < C) {
+            const float4 a = ld4(xr + c), ww = ld4(wr + c);
+            v[i].x = fmaf(a.x, ww.x, v[i].x);
+            v[i].y = fmaf(a.y, ww.y, v[i].y);
+            v[i].z = fmaf(a.z, ww.z, v[i].z);
+            v[i].w = fmaf(a.w, ww.w, v[i].w);
+          }
+        }
+      }
+    }
+    ln_rows_finish<G, NV>(v, gl, C, gamma, beta, eps, out + row * C);
+  }
+}
+
+// depthwise k x k, stride k, no padding, + LayerNorm, for K and V at once: one workgroup per pooled token.
+// R/.../attention.py:49-76,88-95.  Threads = (256/G position lanes) x (G channel lanes).
+template <int G, int NV>
+__global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const float* __restrict__ xk, const float* __restrict__ xv,
+                                                           const float* __restrict__ wk, const float* __restrict__ wv,
+                                                           const float* __restrict__ gk, const float* __restrict__ bk,
+                                                           const float* __restrict__ gv, const float* __restrict__ bv,
+                                                           float* __restrict__ ok, float* __restrict__ ov, int H, int W,
+                                                           int C, int k, int gh, int gw, float eps) {
+  constexpr int PL = 256 / G;
+  extern __shared__ float shp[];  // [2][PL][C]
+  const int gl = threadIdx.x % G;
+  const int pl = threadIdx.x / G;
+  const int tok = blockIdx.x;  // n * gh*gw + gy*gw + gx
+  const int n = tok / (gh * gw);
+  const int g = tok - n * gh * gw;
+  const int gy = g / gw, gx = g - gy * gw;
+  float4 ak[NV], av[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { ak[i] = make_float4(0, 0, 0, 0); av[i] = make_float4(0, 0, 0, 0); }
+  const long img = static_cast<long>(n) * H * W;
+  for (int pos = pl; pos < k * k; pos += PL) {
+    const int dy = pos / k, dx = pos - dy * k;
+    const long off = (img + static_cast<long>(gy * k + dy) * W + (gx * k + dx)) * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      if (c < C) {
+        const float4 a = ld4(xk + off + c), w1 = ld4(wk + static_cast<long>(pos) * C + c);
+        ak[i].x = fmaf(a.x, w1.x, ak[i].x); ak[i].y = fmaf(a.y, w1.y, ak[i].y);
+        ak[i].z = fmaf(a.z, w1.z, ak[i].z); ak[i].w = fmaf(a.w, w1.w, ak[i].w);
+        const float4 b = ld4(xv + off + c), w2 = ld4(wv + static_cast<long>(pos) * C + c);
+        av[i].x = fmaf(b.x, w2.x, av[i].x); av[i].y = fmaf(b.y, w2.y, av[i].y);
+        av[i].z = fmaf(b.z, w2.z, av[i].z); av[i].w = fmaf(b.w, w2.w, av[i].w);
+      }
+    }
+  }
+  // cross position-lane reduction through LDS (fixed order => deterministic)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) {
+      st4(&shp[(0 * PL + pl) * C + c], ak[i]);
+      st4(&shp[(1 * PL + pl) * C + c], av[i]);
+    }
+  }
+  __syncthreads();
+  if (pl < 2) {  // lane group 0 finishes K, lane group 1 finishes V
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      v[i] = make_float4(0, 0, 0, 0);
+      if (c < C) {
+        for (int j = 0; j < PL; ++j) {
+          const float4 t = ld4(&shp[(pl * PL + j) * C + c]);
+          v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        }
+      }
+    }
+    if (pl == 0) ln_rows_finish<G, NV>(v, gl, C, gk, bk, eps, ok + static_cast<long>(tok) * C);
+    else ln_rows_finish<G, NV>(v, gl, C, gv, bv, eps, ov + static_cast<long>(tok) * C);
+  }
+}
+
+// Dispatch on C: lane-group width G = min(64, pow2 >= C/4), NV = ceil(C/4/G).
+#define DS_ROW_DISPATCH(C, CALL)                                  \
+  do {                                                            \
+    const int c4 = (C) / 4;                                       \
+    if (c4 <= 8) { CALL(8, 1); }                                  \
+    else if (c4 <= 16) { CALL(16, 1); }                           \
+    else if (c4 <= 32) { CALL(32, 1); }                           \
+    else if (c4 <= 64) { CALL(64, 1); }                           \
+    else if (c4 <= 128) { CALL(64, 2); }                          \
+    else if (c4 <= 192) { CALL(64, 3); }                          \
+    else if (c4 <= 256) { CALL(64, 4); }                          \
+    else { set_error("channel count %d > 1024 unsupported", (C)); return DIFFSAL_E_SHAPE; } \
+  } while (0)
+
+}  // namespace diffsal
+
+using namespace diffsal;
+
+extern "C" size_t diffsal_groupnorm_ws_bytes(int B, int groups) {
+  return static_cast<size_t>(B) * GN_CHUNKS * groups * 2 * sizeof(double);
+}
+
+extern "C" int diffsal_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* out, int B,
+                                       int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+                                       diffsal_stream_t stream) {
+  DS_REQUIRE(x && gamma && beta && out && ws, DIFFSAL_E_ARG, "groupnorm_swish: null argument");
+  DS_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 1024, DIFFSAL_E_SHAPE,
+             "groupnorm_swish: bad shape B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
+  DS_REQUIRE(ws_bytes >= diffsal_groupnorm_ws_bytes(B, groups), DIFFSAL_E_ARG, "groupnorm_swish: workspace too small");
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(ws), DIFFSAL_E_ALIGN, "groupnorm_swish: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(GN_CHUNKS, B), dim3(256), 2 * C * sizeof(double), s, x,
+                     static_cast<double*>(ws), HW, C, groups);
+  int rc = check_launch("groupnorm_swish(stats)");
+  if (rc) return rc;
+  const long total4 = static_cast<long>(HW) * (C / 4);
+  int gx = static_cast<int>((total4 + 255) / 256);
+  gx = gx > 512 ? 512 : gx;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x,
+                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps);
+  return check_launch("groupnorm_swish(apply)");
+}
+
+static int row_grid(long rows, int rows_per_block) {
+  long g = (rows + rows_per_block - 1) / rows_per_block;
+  return static_cast<int>(g > 8192 ? 8192 : g);
+}
+
+extern "C" int diffsal_layernorm(const float* x, const float* gamma, const float* beta, float* out, int M, int C,
+                                 float eps, diffsal_stream_t stream) {
+  DS_REQUIRE(x && gamma && beta && out, DIFFSAL_E_ARG, "layernorm: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm: bad shape M=%d C=%d", M, C);
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), DIFFSAL_E_ALIGN,
+             "layernorm: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(G, NV) \
+  hipLaunchKernelGGL((layernorm_kernel<G, NV>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, gamma, beta, out, M, C, eps)
+  DS_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("layernorm");
+}
+
+extern "C" int diffsal_dwconv3_ln(const float* x, const float* w9, const float* gamma, const float* beta, float* out,
+                                  int N, int H, int W, int C, float eps, diffsal_stream_t stream) {
+  DS_REQUIRE(x && w9 && gamma && beta && out, DIFFSAL_E_ARG, "dwconv3_ln: null argument");
+  DS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "dwconv3_ln: bad shape");
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(w9) && aligned16(gamma) && aligned16(beta), DIFFSAL_E_ALIGN,
+             "dwconv3_ln: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long M = static_cast<long>(N) * H * W;
+#define CALL(G, NV)                                                                                              \
+  hipLaunchKernelGGL((dwconv3_ln_kernel<G, NV>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, w9, gamma, beta, \
+                     out, N, H, W, C, eps)
+  DS_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("dwconv3_ln");
+}
+
+extern "C" int diffsal_dwpool_ln_kv(const float* xk, const float* xv, const float* wk, const float* wv,
+                                    const float* gk, const float* bk, const float* gv, const float* bv, float* out_k,
+                                    float* out_v, int N, int H, int W, int C, int k, float eps,
+                                    diffsal_stream_t stream) {
+  DS_REQUIRE(xk && xv && wk && wv && gk && bk && gv && bv && out_k && out_v, DIFFSAL_E_ARG, "dwpool_ln_kv: null argument");
+  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && H >= k && W >= k, DIFFSAL_E_SHAPE,
+             "dwpool_ln_kv: bad shape H=%d W=%d C=%d k=%d", H, W, C, k);
+  DS_REQUIRE(aligned16(xk) && aligned16(xv) && aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v),
+             DIFFSAL_E_ALIGN, "dwpool_ln_kv: misaligned pointer");
+  const int gh = (H - k) / k + 1, gw = (W - k) / k + 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(G, NV)                                                                                             \
+  hipLaunchKernelGGL((dwpool_ln_kv_kernel<G, NV>), dim3(N * gh * gw), dim3(256), 2 * (256 / G) * C * sizeof(float), s, \
+                     xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, H, W, C, k, gh, gw, eps)
+  DS_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("dwpool_ln_kv");
+}

@@ -1,0 +1,224 @@
+"""Tensor-level wrappers over the C ABI of libdiffsal_hip.so.
+
+PyTorch is used for device memory and streams only: each function hands raw device pointers and
+the current HIP stream to a hand-written gfx950 kernel.  Activations are fp32 and channels-last
+(images [N,H,W,C], tokens [M,C]).  There is no CPU / PyTorch fallback: a missing library or a
+non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"diff_sal_amd ops need contiguous fp32 GPU tensors, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def temb_mlp(t: Tensor, freq: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
+    """K1. t: [B] int64 or float32 -> temb [B, 4*ch]."""
+    lib = _lib.load()
+    B, ch = t.shape[0], w0.shape[1]
+    if t.dtype == torch.int64:
+        is_f32 = 0
+    elif t.dtype == torch.float32:
+        is_f32 = 1
+    else:
+        t, is_f32 = t.to(torch.float32), 1
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("t must be a contiguous GPU tensor")
+    out = torch.empty((B, 4 * ch), device=t.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_temb_mlp(t.data_ptr(), is_f32, B, ch, _p(freq), _p(w0), _p(b0), _p(w1), _p(b1),
+                                    _p(out), _stream()), "temb_mlp")
+    return out
+
+
+def dense_small(x: Tensor, w: Tensor, bias: Optional[Tensor], swish_in: bool) -> Tensor:
+    lib = _lib.load()
+    B, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_dense_small(_p(x), B, K, int(swish_in), _p(w), _p(bias), N, _p(out), _stream()),
+               "dense_small")
+    return out
+
+
+def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0) -> Tensor:
+    """K2. x [B,1,H,W] -> NHWC [B,H,W,C]; with skip_mod=4 the pixels a stride-4 3x3 consumer never
+    reads are left unwritten."""
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    Cc = w9.shape[0]
+    out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), _p(out), B, H, W, Cc, skip_mod, _stream()), "conv_in")
+    return out
+
+
+def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
+    """K3 on NHWC [B,H,W,C]."""
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    nbytes = lib.diffsal_groupnorm_ws_bytes(B, groups)
+    ws = torch.empty((nbytes // 8,), device=x.device, dtype=torch.float64)
+    _lib.check(lib.diffsal_groupnorm_swish(_p(x), _p(gamma), _p(beta), _p(out), B, H * W, Cc, groups, eps,
+                                           ws.data_ptr(), nbytes, _stream()), "groupnorm_swish")
+    return out
+
+
+def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
+               out_hw: Optional[Sequence[int]] = None, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
+               shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+               act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """Implicit-GEMM conv on NHWC x [N,H,W,Cin] with packed weight [Cout, kh*kw*Cin] -> [N,Ho,Wo,Cout].
+
+    ``pad`` is (top, left); bottom/right padding is implied by ``out_hw`` (zero fill outside)."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    assert w_packed.shape[1] == kh * kw * Cin, (w_packed.shape, kh, kw, Cin)
+    if out_hw is None:
+        Ho = (H + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride[0] + 1
+        Wo = (W + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride[1] + 1
+    else:
+        Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], act,
+                 rowvec.shape[-1] if rowvec is not None else 0)
+    if rowvec is not None:
+        assert rowvec.stride(-1) == 1 and rowvec.dtype == torch.float32 and rowvec.is_cuda
+        d.rowvec_ld = rowvec.stride(0)
+        rv = rowvec.data_ptr()
+    else:
+        rv = None
+    _lib.check(lib.diffsal_conv_igemm(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(scale), _p(shift), rv,
+                                      _p(residual), _p(out), _stream()), "conv_igemm")
+    return out
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
+           residual: Optional[Tensor] = None) -> Tensor:
+    """Token GEMM: x [..., K] @ w[N, K]^T (+bias, act, +residual) through the same MFMA kernel."""
+    lead = x.shape[:-1]
+    M = 1
+    for s in lead:
+        M *= s
+    y = conv_igemm(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act,
+                   residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
+    return y.reshape(*lead, w.shape[0])
+
+
+def pack_frames(vis: Tensor, noise: Optional[Tensor], t_out: Optional[int] = None) -> Tensor:
+    """K6. vis [B,C,Tv,h,w] (NCTHW) + noise [B,h,w,C] -> [B,Tv+1,h,w,C]."""
+    lib = _lib.load()
+    B, Cc, Tv, h, w = vis.shape
+    Tout = t_out if t_out is not None else Tv + (1 if noise is not None else 0)
+    out = torch.empty((B, Tout, h, w, Cc), device=vis.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_pack_frames(_p(vis), _p(noise), _p(out), B, Cc, Tv, Tout, h * w, _stream()), "pack_frames")
+    return out
+
+
+def resize_bilinear(x: Tensor, H: int, W: int) -> Tensor:
+    lib = _lib.load()
+    N, h, w, Cc = x.shape
+    out = torch.empty((N, H, W, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_resize_bilinear(_p(x), _p(out), N, h, w, H, W, Cc, _stream()), "resize_bilinear")
+    return out
+
+
+def resize_sum(xs: Sequence[Tensor], H: int, W: int) -> Tensor:
+    """sum_i bilinear(xs[i] -> (H, W)), NHWC, accumulated in list order."""
+    lib = _lib.load()
+    n = len(xs)
+    N, _, _, Cc = xs[0].shape
+    ptrs = (C.c_void_p * n)(*[_p(x) for x in xs])
+    hs = (C.c_int * n)(*[x.shape[1] for x in xs])
+    ws = (C.c_int * n)(*[x.shape[2] for x in xs])
+    out = torch.empty((N, H, W, Cc), device=xs[0].device, dtype=torch.float32)
+    _lib.check(lib.diffsal_resize_sum(ptrs, hs, ws, n, _p(out), N, H, W, Cc, _stream()), "resize_sum")
+    return out
+
+
+def audio_fuse(a_small: Tensor, x: Tensor, h: int, w: int) -> Tensor:
+    """K7. a_small [B*T, h*w, C], x [B,T,H,W,C] -> fused audio in the reference's [B,C,T,H,W] order."""
+    lib = _lib.load()
+    B, T, H, W, Cc = x.shape
+    out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_audio_fuse(_p(a_small), _p(x), _p(out), B, T, H, W, Cc, h, w, _stream()), "audio_fuse")
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    out = torch.empty_like(x)
+    _lib.check(lib.diffsal_layernorm(_p(x), _p(gamma), _p(beta), _p(out), M, Cc, eps, _stream()), "layernorm")
+    return out
+
+
+def dwconv3_ln(x: Tensor, w9: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tensor:
+    """x NHWC [N,H,W,C] -> tokens [N, H*W, C]."""
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, H * W, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_dwconv3_ln(_p(x), _p(w9), _p(gamma), _p(beta), _p(out), N, H, W, Cc, eps, _stream()),
+               "dwconv3_ln")
+    return out
+
+
+def dwpool_ln_kv(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tensor, gv: Tensor, bv: Tensor,
+                 k: int, eps: float = 1e-5):
+    lib = _lib.load()
+    N, H, W, Cc = xv.shape
+    gh, gw = (H - k) // k + 1, (W - k) // k + 1
+    ok = torch.empty((N, gh * gw, Cc), device=xv.device, dtype=torch.float32)
+    ov = torch.empty_like(ok)
+    _lib.check(lib.diffsal_dwpool_ln_kv(_p(xk), _p(xv), _p(wk), _p(wv), _p(gk), _p(bk), _p(gv), _p(bv), _p(ok),
+                                        _p(ov), N, H, W, Cc, k, eps, _stream()), "dwpool_ln_kv")
+    return ok, ov
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tensor:
+    lib = _lib.load()
+    N, Lq, Cc = q.shape
+    Lk = k.shape[1]
+    o = torch.empty_like(q)
+    _lib.check(lib.diffsal_attention(_p(q), _p(k), _p(v), _p(o), N, Lq, Lk, Cc, heads, scale, _stream()), "attention")
+    return o
+
+
+def head_sigmoid(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
+    """x NHWC [N,H,W,C] -> [N,H,W,1]."""
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, H, W, 1), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_head_sigmoid(_p(x), _p(w), _p(bias), _p(out), N * H * W, Cc, _stream()), "head_sigmoid")
+    return out
+
+
+def axpbypcz(x: Tensor, a: float, y: Optional[Tensor] = None, b: float = 0.0, z: Optional[Tensor] = None,
+             c: float = 0.0, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.diffsal_axpbypcz(_p(x), _p(y), _p(z), float(a), float(b), float(c), _p(out), x.numel(), _stream()),
+               "axpbypcz")
+    return out

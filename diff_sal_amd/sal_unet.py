@@ -1,0 +1,421 @@
+"""SalUNet -- DiffSal's per-step denoiser, MI355X-native.
+
+Drop-in for the reference module ``models/saliency_decoder/sal_unet.py::SalUNet``
+(R/models/saliency_decoder/sal_unet.py:146-328):
+
+  * same constructor keywords (R/cfgs/audio_visual.py:50-82),
+  * same ``forward(x, t, feat_list, audio_feat_list=None)`` contract,
+  * same ``state_dict`` names and shapes, so reference checkpoints load,
+
+but the forward pass is a sequence of hand-written gfx950 kernels reached through the C ABI of
+``libdiffsal_hip.so`` (see ``ops.py`` / ``include/diffsal.h``).  Internally everything is
+channels-last: frames [B,T,H,W,C] double as token matrices [B*T*H*W, C], so none of the
+reference's ``rearrange(...).contiguous()`` copies exist; the only layout changes are one
+transpose of each visual feature map per call (NCTHW is the module's input contract).
+
+Unlike the reference, ``forward`` never mutates ``feat_list`` (reference defect D4).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU
+
+Tensor = torch.Tensor
+
+
+def _holder(**children) -> nn.Module:
+    m = nn.Module()
+    for k, v in children.items():
+        setattr(m, k, v)
+    return m
+
+
+def _seq_named(pairs) -> nn.Sequential:
+    from collections import OrderedDict
+
+    return nn.Sequential(OrderedDict(pairs))
+
+
+class _ParamTree:
+    """Builders for the parameter containers.  The nn layers below are *storage only* (names,
+    shapes, init, state_dict, .to(), optimizers); their own forward() is never called."""
+
+    @staticmethod
+    def res_block(cin: int, cout: int, temb_ch: int) -> nn.Module:
+        m = nn.Module()
+        m.norm1 = nn.GroupNorm(32, cin, eps=1e-6)
+        m.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        m.temb_proj = nn.Linear(temb_ch, cout)
+        m.norm2 = nn.GroupNorm(32, cout, eps=1e-6)
+        m.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        if cin != cout:
+            m.nin_shortcut = nn.Conv2d(cin, cout, 1)
+        return m
+
+    @staticmethod
+    def up_embed(cin: int, cout: int, dil: int) -> nn.Module:
+        # indices 1,2,4,5 carry parameters (0 = upsample, 3/6 = ReLU): common_block.py:196-216
+        return _holder(proj=nn.Sequential(
+            nn.Identity(),
+            nn.Conv2d(cin, cout, 3, padding=dil, dilation=dil, bias=False), nn.BatchNorm2d(cout), nn.Identity(),
+            nn.Conv2d(cout, cout, 3, padding=dil, dilation=dil, bias=False), nn.BatchNorm2d(cout), nn.Identity()))
+
+    @staticmethod
+    def dw_proj(c: int, k3) -> nn.Sequential:
+        return _seq_named([("conv", nn.Conv3d(c, c, k3, groups=c, bias=False)), ("bn", nn.LayerNorm(c))])
+
+    @classmethod
+    def block(cls, c: int, mlp_ratio: float, kq: int, kkv: int, qkv_bias: bool) -> nn.Module:
+        hid = int(c * mlp_ratio)
+        attn = _holder(
+            conv_proj_q=cls.dw_proj(c, (kq, kq, kq)),
+            conv_proj_k=cls.dw_proj(c, (1, kkv, kkv)),
+            conv_proj_v=cls.dw_proj(c, (1, kkv, kkv)),
+            proj_q=nn.Linear(c, c, bias=qkv_bias), proj_k=nn.Linear(c, c, bias=qkv_bias),
+            proj_v=nn.Linear(c, c, bias=qkv_bias), proj=nn.Linear(c, c))
+        return _holder(mlp=_holder(fc1=nn.Linear(c, hid), fc2=nn.Linear(hid, c)), norm=nn.LayerNorm(c), attn=attn,
+                       norm2=nn.LayerNorm(c), align_conv=nn.Conv2d(512, c, 1))
+
+
+class SalUNet(nn.Module):
+    """See module docstring.  Keyword names follow R/models/saliency_decoder/sal_unet.py:147-179."""
+
+    def __init__(
+        self,
+        image_based=False,
+        img_size=(224, 384),
+        frames_len=2,
+        tasks=("futr",),
+        in_index=(0, 1, 2, 3),
+        idx_to_planes=None,
+        temporal_size=5,
+        mid_num_stages=3,
+        futr_num_stages=1,
+        ori_embed_dim=768,
+        down_embed_dim=96,
+        keep_max_len=5,
+        exclude_layers=(),
+        temporal_list=(1, 9, 9),
+        patch_size=(0, 3, 3),
+        patch_stride=(0, 1, 1),
+        patch_padding=(0, 2, 2),
+        up_channel=(768, 384, 192),
+        num_heads=(2, 2, 2),
+        mlp_ratio=(4.0, 4.0, 4.0),
+        drop_path_rate=(0.15, 0.15, 0.15),
+        qkv_bias=(True, True, True),
+        kv_proj_method=("avg", "avg", "avg"),
+        kernel_kv=(2, 4, 8),
+        padding_kv=(0, 0, 0),
+        stride_kv=(2, 4, 8),
+        q_proj_method=("dw_bn", "dw_bn", "dw_bn"),
+        kernel_q=(3, 3, 3),
+        padding_q=(1, 1, 1),
+        stride_q=(1, 1, 1),
+    ):
+        super().__init__()
+        idx_to_planes = dict(idx_to_planes or {0: 96, 1: 192, 2: 384, 3: 768})
+        ns = int(mid_num_stages)
+        if int(frames_len) != 1:
+            # the reference derives len(tasks) from str(range(frames_len))[0], i.e. always one task (quirk Q1)
+            pass
+        for name, seq in (("patch_size", patch_size), ("patch_padding", patch_padding), ("up_channel", up_channel),
+                          ("num_heads", num_heads), ("mlp_ratio", mlp_ratio), ("kernel_kv", kernel_kv),
+                          ("stride_kv", stride_kv), ("temporal_list", temporal_list), ("qkv_bias", qkv_bias),
+                          ("kernel_q", kernel_q), ("padding_q", padding_q), ("stride_q", stride_q),
+                          ("padding_kv", padding_kv)):
+            if len(seq) < ns:
+                raise ValueError(f"{name} needs {ns} entries, got {len(seq)}")
+        if any(k != 3 for k in kernel_q[:ns]) or any(p != 1 for p in padding_q[:ns]) or any(s != 1 for s in stride_q[:ns]):
+            raise NotImplementedError("q projection: only depthwise 3x3x3 / pad 1 / stride 1 is built")
+        if list(kernel_kv[:ns]) != list(stride_kv[:ns]) or any(p != 0 for p in padding_kv[:ns]):
+            raise NotImplementedError("k/v projection: only kernel == stride, padding 0 is built")
+        if any(ps not in (0, 3) for ps in patch_size[:ns]) or any(s not in (0, 1) for s in patch_stride[:ns]):
+            raise NotImplementedError("UpEmbed: only 3x3 stride-1 dilated convolutions are built")
+
+        self.img_size = (int(img_size[0]), int(img_size[1]))
+        self.image_based = bool(image_based)
+        self.frame_len = frames_len
+        self.num_stages = ns
+        self.up_channels = [int(c) for c in up_channel[:ns]]
+        self.heads = [int(h) for h in num_heads[:ns]]
+        self.kernel_kv = [int(k) for k in kernel_kv[:ns]]
+        self.temporal_list = [int(k) for k in temporal_list[:ns]]
+        self.dilation = [int(p) if int(ps) != 0 else 0 for p, ps in zip(patch_padding[:ns], patch_size[:ns])]
+        self.ori_embed_dim = int(ori_embed_dim)
+        self.down_channel = int(idx_to_planes[0])
+        self.ch = 96  # sal_unet.py:228
+        self.temb_ch = self.ch * 4
+
+        # ---- decoder parameters (names: SURVEY Appendix B) ----
+        dec = nn.Module()
+        dec.norm_mts = nn.ModuleList()
+        dec.redu_chan_up = nn.ModuleList()
+        dec.mid_stages = nn.ModuleList()
+        prev = self.ori_embed_dim
+        for i, c in enumerate(self.up_channels):
+            st = nn.Module()
+            st.patch_embed = (nn.ModuleList([_ParamTree.up_embed(prev, c, self.dilation[i])])
+                              if self.dilation[i] != 0 else None)
+            st.blocks = nn.ModuleList([_ParamTree.block(c, float(mlp_ratio[i]), int(kernel_q[i]),
+                                                        self.kernel_kv[i], bool(qkv_bias[i]))])
+            dec.mid_stages.append(st)
+            dec.norm_mts.append(nn.LayerNorm(c))
+            kt = self.temporal_list[i]
+            dec.redu_chan_up.append(_holder(proj=nn.Sequential(
+                nn.Conv3d(c, self.ori_embed_dim, (kt, 1, 1), stride=(kt, 1, 1), bias=False), nn.Identity())))
+            prev = c
+        dec.mt_proj = nn.Sequential(nn.Conv2d(self.ori_embed_dim, int(down_embed_dim), 3, padding=1),
+                                    nn.BatchNorm2d(int(down_embed_dim)), nn.Identity())
+        self.invpt_decoder = dec
+        self.logits = _holder(linear_pred=nn.Conv2d(self.down_channel, 1, 1))
+
+        # ---- noise encoder parameters ----
+        self.temb = _holder(dense=nn.ModuleList([nn.Linear(self.ch, self.temb_ch),
+                                                 nn.Linear(self.temb_ch, self.temb_ch)]))
+        self.conv_in = nn.Conv2d(1, self.ch, 3, padding=1)
+        self.down1 = _holder(conv=nn.Conv2d(self.ch, self.ch, 3, stride=4))
+        self.res_encoder = nn.ModuleList()
+        cin = self.ch
+        for cout in self.up_channels[:-1][::-1]:
+            self.res_encoder.append(nn.Sequential(_ParamTree.res_block(cin, cout, self.temb_ch),
+                                                  _holder(conv=nn.Conv2d(cout, cout, 3, stride=2))))
+            cin = cout
+
+        self._pack_cache: Optional[Dict[str, Tensor]] = None
+        self._pack_key = None
+        self.init_weights()
+
+    # ------------------------------------------------------------------ init (quirk Q15)
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.Linear)):
+                nn.init.normal_(m.weight, 0.0, 0.01)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, (nn.LayerNorm, nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        for st in self.invpt_decoder.mid_stages:  # transformer.py:236-248 re-initialises the stage's Linears
+            for m in st.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.trunc_normal_(m.weight, std=0.02)
+        nn.init.trunc_normal_(self.invpt_decoder.mt_proj[0].weight, std=0.02)  # sal_unet.py:408
+
+    # ------------------------------------------------------------------ weight packing
+    def _cache_key(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    @staticmethod
+    def _pack_conv(w: Tensor) -> Tensor:
+        """[Cout,Cin,KH,KW] -> [Cout, KH*KW*Cin] (tap-major, channel fastest = the im2col K order)."""
+        return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+    @staticmethod
+    def _bn_affine(bn: nn.BatchNorm2d):
+        scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).contiguous()
+        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+        return scale, shift
+
+    def packed(self) -> Dict[str, Tensor]:
+        """Kernel-layout copies of the parameters, rebuilt only when a parameter changes."""
+        key = self._cache_key()
+        if self._pack_cache is not None and key == self._pack_key:
+            return self._pack_cache
+        dev = self.conv_in.weight.device
+        pk: Dict[str, Tensor] = {}
+        half = self.ch // 2
+        # same fp32 arithmetic as the reference table, sal_unet.py:25-27
+        pk["freq"] = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(dev)
+        pk["conv_in.w"] = self.conv_in.weight.detach().reshape(self.ch, 9).contiguous()
+        pk["down1.w"] = self._pack_conv(self.down1.conv.weight)
+        tw, tb = [], []
+        for i, blk in enumerate(self.res_encoder):
+            rb, dn = blk[0], blk[1]
+            pk[f"res{i}.conv1.w"] = self._pack_conv(rb.conv1.weight)
+            pk[f"res{i}.conv2.w"] = self._pack_conv(rb.conv2.weight)
+            if hasattr(rb, "nin_shortcut"):
+                pk[f"res{i}.nin.w"] = self._pack_conv(rb.nin_shortcut.weight)
+            pk[f"res{i}.down.w"] = self._pack_conv(dn.conv.weight)
+            tw.append(rb.temb_proj.weight.detach())
+            tb.append(rb.temb_proj.bias.detach())
+        pk["tproj.w"] = torch.cat(tw, 0).contiguous()
+        pk["tproj.b"] = torch.cat(tb, 0).contiguous()
+        dec = self.invpt_decoder
+        for i, st in enumerate(dec.mid_stages):
+            if st.patch_embed is not None:
+                pe = st.patch_embed[0].proj
+                pk[f"s{i}.pe1.w"] = self._pack_conv(pe[1].weight)
+                pk[f"s{i}.pe1.scale"], pk[f"s{i}.pe1.shift"] = self._bn_affine(pe[2])
+                pk[f"s{i}.pe2.w"] = self._pack_conv(pe[4].weight)
+                pk[f"s{i}.pe2.scale"], pk[f"s{i}.pe2.shift"] = self._bn_affine(pe[5])
+            a = st.blocks[0].attn
+            c = self.up_channels[i]
+            k = self.kernel_kv[i]
+            pk[f"s{i}.wq9"] = a.conv_proj_q.conv.weight.detach()[:, 0, 1].reshape(c, 9).t().contiguous()  # Q8
+            pk[f"s{i}.wk"] = a.conv_proj_k.conv.weight.detach().reshape(c, k * k).t().contiguous()
+            pk[f"s{i}.wv"] = a.conv_proj_v.conv.weight.detach().reshape(c, k * k).t().contiguous()
+            pk[f"s{i}.align.w"] = st.blocks[0].align_conv.weight.detach().reshape(c, 512).contiguous()
+            w3 = dec.redu_chan_up[i].proj[0].weight.detach()  # [Co, C, kt, 1, 1] -> [Co, kt*C]
+            pk[f"s{i}.redu.w"] = w3[:, :, :, 0, 0].permute(0, 2, 1).reshape(w3.shape[0], -1).contiguous()
+        pk["mt.w"] = self._pack_conv(dec.mt_proj[0].weight)
+        pk["mt.scale"], pk["mt.shift"] = self._bn_affine(dec.mt_proj[1])
+        pk["head.w"] = self.logits.linear_pred.weight.detach().reshape(-1).contiguous()
+        self._pack_cache, self._pack_key = pk, key
+        return pk
+
+    # ------------------------------------------------------------------ forward pieces
+    def _noise_encoder(self, x: Tensor, t: Tensor, pk, taps=None) -> List[Tensor]:
+        """K1-K5 (sal_unet.py:279-307): returns NHWC noise maps, coarsest first."""
+        d0, d1 = self.temb.dense[0], self.temb.dense[1]
+        temb = ops.temb_mlp(t, pk["freq"], d0.weight, d0.bias, d1.weight, d1.bias)
+        tproj = ops.dense_small(temb, pk["tproj.w"], pk["tproj.b"], swish_in=True)
+        B, _, H, W = x.shape
+        f = ops.conv_in(x, pk["conv_in.w"], self.conv_in.bias, skip_mod=4)
+        f = ops.conv_igemm(f, pk["down1.w"], kh=3, kw=3, stride=(4, 4), out_hw=((H - 2) // 4 + 1, (W - 2) // 4 + 1),
+                           bias=self.down1.conv.bias)
+        if taps is not None:
+            taps["temb"], taps["down1"] = temb, f
+        outs, off = [], 0
+        for i, blk in enumerate(self.res_encoder):
+            rb, dn = blk[0], blk[1]
+            co = rb.conv1.out_channels
+            h = ops.groupnorm_swish(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
+            h = ops.conv_igemm(h, pk[f"res{i}.conv1.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv1.bias,
+                               rowvec=tproj[:, off:off + co])
+            off += co
+            h = ops.groupnorm_swish(h, rb.norm2.weight, rb.norm2.bias, 32, rb.norm2.eps)
+            sc = f
+            if hasattr(rb, "nin_shortcut"):
+                sc = ops.conv_igemm(f, pk[f"res{i}.nin.w"], bias=rb.nin_shortcut.bias)
+            f = ops.conv_igemm(h, pk[f"res{i}.conv2.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc)
+            if taps is not None:
+                taps[f"res{i}"] = f
+            hh, ww = f.shape[1:3]
+            f = ops.conv_igemm(f, pk[f"res{i}.down.w"], kh=3, kw=3, stride=(2, 2),
+                               out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1), bias=dn.conv.bias)
+            outs.append(f)
+        return outs[::-1]
+
+    def _block(self, i: int, x: Tensor, pk, audio_tok: Optional[Tensor], audio_hw) -> Tensor:
+        """TransformerBlock on frames x [B,T,H,W,C] (transformer.py:124-159, attention.py:86-113)."""
+        B, T, H, W, C = x.shape
+        blk = self.invpt_decoder.mid_stages[i].blocks[0]
+        a = blk.attn
+        n9 = B * T
+        xn = ops.layernorm(x, blk.norm.weight, blk.norm.bias, blk.norm.eps)
+        k_src = xn
+        if audio_tok is not None:
+            a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias)  # [B*T, ha*wa, C]
+            k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
+        q = ops.dwconv3_ln(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
+                           a.conv_proj_q.bn.eps)
+        kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+                                  a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
+                                  a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
+        q = ops.linear(q, a.proj_q.weight, a.proj_q.bias)
+        kk = ops.linear(kk, a.proj_k.weight, a.proj_k.bias)
+        vv = ops.linear(vv, a.proj_v.weight, a.proj_v.bias)
+        o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
+        xt = x.view(n9, H * W, C)
+        x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=xt)
+        y = ops.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        y = ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ACT_GELU)
+        x2 = ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1)
+        return x2.view(B, T, H, W, C)
+
+    def forward(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor] = None,
+                taps: Optional[dict] = None) -> Tensor:
+        """x [B,1,H,W], t [B] (int64 or float), feat_list: 4 x [B,C_i,Tv,h_i,w_i] coarsest first,
+        audio_feat_list: [B,512,Tv+1,h_0,w_0] or None  ->  [B,1,img_H,img_W] in (0,1)."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("diff_sal_amd.SalUNet: the HIP path implements the eval-mode forward only "
+                               "(BatchNorm running statistics, no dropout); call .eval() / torch.no_grad()")
+        if not x.is_cuda:
+            raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
+        pk = self.packed()
+        x = x.contiguous().float()
+        t = t.contiguous()
+        B = x.shape[0]
+        ns = self.num_stages
+        dec = self.invpt_decoder
+
+        noise = self._noise_encoder(x, t, pk, taps)
+        frames: List[Optional[Tensor]] = []
+        for i in range(ns):
+            f = feat_list[i].contiguous().float() if i < len(feat_list) else None
+            if f is None:
+                frames.append(None)
+                continue
+            nz = None
+            if self.image_based and i < len(noise) and tuple(f.shape[-2:]) == tuple(noise[i].shape[1:3]):
+                nz = noise[i]
+            # stage-3 features are never read by the decoder (quirk Q2): skip their transpose
+            frames.append(ops.pack_frames(f, nz) if i < 3 else None)
+        if taps is not None:
+            for i, nzt in enumerate(noise):
+                taps[f"noise{i}"] = nzt
+
+        audio_tok, audio_hw = None, None
+        if audio_feat_list is not None:
+            a = audio_feat_list.contiguous().float()
+            ap = ops.pack_frames(a, None)  # [B,Ta,ha,wa,512]
+            if ap.shape[1] != frames[0].shape[1]:
+                raise RuntimeError(f"audio has {ap.shape[1]} frames but the decoder input has {frames[0].shape[1]}")
+            audio_hw = (ap.shape[2], ap.shape[3])
+            audio_tok = ap.view(B * ap.shape[1], audio_hw[0] * audio_hw[1], ap.shape[4])
+
+        xcur = frames[0]
+        h0, w0 = xcur.shape[2:4]
+        th, tw = h0 * 2 ** (ns - 1) * 2, w0 * 2 ** (ns - 1) * 2
+        zs = []
+        for i in range(ns):
+            C = self.up_channels[i]
+            if self.dilation[i] != 0:
+                Bn, T, h, w, Cp = xcur.shape
+                d = self.dilation[i]
+                u = ops.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
+                u = ops.conv_igemm(u, pk[f"s{i}.pe1.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
+                                   scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU)
+                skip = frames[i] if i in (1, 2) else None  # transformer.py:265-270
+                u = ops.conv_igemm(u, pk[f"s{i}.pe2.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
+                                   scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU,
+                                   residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C))
+                xcur = u.view(Bn, T, 2 * h, 2 * w, C)
+            xcur = self._block(i, xcur, pk, audio_tok, audio_hw)
+            if taps is not None:
+                taps[f"stage{i}"] = xcur
+            Bn, T, H, W, _ = xcur.shape
+            nm = dec.norm_mts[i]
+            z = ops.layernorm(xcur, nm.weight, nm.bias, nm.eps)
+            kt = self.temporal_list[i]
+            if (T - kt) // kt + 1 != 1:
+                raise RuntimeError(f"ReduceTemp: T={T}, kernel/stride {kt} must give exactly one frame")
+            z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU)
+            zs.append(z.view(Bn, H, W, self.ori_embed_dim))
+        acc = ops.resize_sum(zs, th, tw)
+        if taps is not None:
+            taps["multi_scale"] = acc
+        mt = dec.mt_proj
+        y = ops.conv_igemm(acc, pk["mt.w"], kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, scale=pk["mt.scale"],
+                           shift=pk["mt.shift"], act=ACT_RELU)
+        s = ops.head_sigmoid(y, pk["head.w"], self.logits.linear_pred.bias)
+        out = ops.resize_bilinear(s, self.img_size[0], self.img_size[1])
+        return out.view(B, 1, self.img_size[0], self.img_size[1])
+
+    # taps come back channels-last; helpers for tests that compare with NCHW / NCTHW fixtures
+    @staticmethod
+    def tap_to_reference_layout(name: str, v: Tensor) -> Tensor:
+        if name.startswith("stage"):
+            return v.permute(0, 4, 1, 2, 3)
+        if name.startswith("noise"):
+            return v.permute(0, 3, 1, 2).unsqueeze(2)
+        if name in ("down1", "multi_scale") or name.startswith("res"):
+            return v.permute(0, 3, 1, 2)
+        return v

@@ -1,0 +1,148 @@
+/*
+ * diffsal.h -- C ABI of libdiffsal_hip.so: the MI355X (gfx950) operator library for
+ * DiffSal's per-step denoiser (SalUNet) hot path.
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise;
+ *   - activations are fp32, channels-last: images [N,H,W,C], tokens [M,C];
+ *   - every entry point enqueues work on `stream` (a hipStream_t) and returns immediately:
+ *       0 on success, a negative DIFFSAL_E_* code on failure (diffsal_last_error() has the text);
+ *   - no allocation, no synchronisation, no host-visible side effect inside an entry point,
+ *     so every call is legal under HIP-graph capture;
+ *   - re-entrant; the only global state is a thread-local error string.
+ *
+ * Each entry point cites the reference interface it replaces (R/ = junwenxiong/diff_sal).
+ */
+#ifndef DIFFSAL_H
+#define DIFFSAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* diffsal_stream_t; /* hipStream_t */
+
+enum {
+  DIFFSAL_OK = 0,
+  DIFFSAL_E_SHAPE = -1,   /* unsupported / inconsistent dimensions */
+  DIFFSAL_E_ALIGN = -2,   /* pointer not 16-byte aligned */
+  DIFFSAL_E_LAUNCH = -3,  /* hipGetLastError() after launch */
+  DIFFSAL_E_ARG = -4      /* null pointer / bad enum */
+};
+
+enum { DIFFSAL_ACT_NONE = 0, DIFFSAL_ACT_RELU = 1, DIFFSAL_ACT_GELU_ERF = 2, DIFFSAL_ACT_SIGMOID = 3 };
+
+int diffsal_version(void);
+const char* diffsal_last_error(void);
+
+/* ---- K1: timestep embedding + MLP ------------------------------------------------------
+ * R/models/saliency_decoder/sal_unet.py:15-33 (get_timestep_embedding) and :304-307.
+ * t: [B] int64 (t_is_f32 == 0) or float (t_is_f32 == 1); freq: [ch/2] table exp(-j*ln(1e4)/(ch/2-1)).
+ * temb_out[B,4ch] = W1 * swish(W0 * [sin(t f), cos(t f)] + b0) + b1 */
+int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq,
+                     const float* w0, const float* b0, const float* w1, const float* b1,
+                     float* temb_out, diffsal_stream_t stream);
+
+/* out[B,N] = W[N,K] * f(in[B,K]) + bias, f = swish if swish_in.  ResnetBlock.temb_proj of all
+ * blocks in one call (weights concatenated along N).  R/.../sal_unet.py:107,129. */
+int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float* w, const float* bias,
+                        int N, float* out, diffsal_stream_t stream);
+
+/* ---- K2: conv_in (1 -> C, 3x3, pad 1), NCHW[B,1,H,W] -> NHWC[B,H,W,C] -----------------
+ * R/.../sal_unet.py:240,292.  Only pixels with (y % skip_mod != skip_mod-1 && x % skip_mod != skip_mod-1)
+ * are written when skip_mod > 0 (the stride-4 consumer never reads the others, sal_unet.py:67-84). */
+int diffsal_conv_in(const float* x, const float* w /*[C,9]*/, const float* bias, float* out,
+                    int B, int H, int W, int C, int skip_mod, diffsal_stream_t stream);
+
+/* ---- K3: GroupNorm(groups, eps) + swish on NHWC ----------------------------------------
+ * R/.../sal_unet.py:36-44.  ws: >= diffsal_groupnorm_ws_bytes(B, groups) bytes of scratch. */
+size_t diffsal_groupnorm_ws_bytes(int B, int groups);
+int diffsal_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* out,
+                            int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+                            diffsal_stream_t stream);
+
+/* ---- K4/K5/K10/K12/K13/K14: implicit-GEMM convolution / linear on fp32 MFMA -------------
+ * out[m, co] = act( ((sum_k A[m,k] * w[co,k]) + bias[co]) * scale[co] + shift[co] + rowvec[img(m), co] )
+ *              + residual[m, co]
+ * A is the im2col view of in[N,H,W,Cin] (never materialised): m = (n, oy, ox), k = (ky, kx, ci),
+ * iy = oy*stride_h - pad_t + ky*dil_h, ix = ox*stride_w - pad_l + kx*dil_w, zero outside.
+ * w: packed [Cout][KH*KW*Cin].  bias/scale/shift: [Cout] or NULL.  rowvec: [N, rowvec_ld] or NULL.
+ * residual: [M, Cout] or NULL.  Cin % 32 == 0.  A plain linear layer is KH=KW=1, H=1, W=rows.
+ * Replaces torch.nn.Conv2d / Conv3d(k,1,1) / Linear call sites:
+ *   R/.../sal_unet.py:104-142 (ResnetBlock), :47-84 (Downsample*), common_block.py:33-36,150-223,
+ *   attention.py:78-83, common_block.py:125-147, transformer.py:122,131. */
+typedef struct diffsal_conv_desc {
+  int N, H, W, Cin;
+  int Ho, Wo, Cout;
+  int KH, KW, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
+  int act;        /* DIFFSAL_ACT_* */
+  int rowvec_ld;  /* leading dimension of rowvec (>= Cout) */
+} diffsal_conv_desc;
+
+int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, const float* w,
+                       const float* bias, const float* scale, const float* shift, const float* rowvec,
+                       const float* residual, float* out, diffsal_stream_t stream);
+
+/* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
+ * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
+ * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,
+ * transformer.py:273-279. noise may be NULL (then only Tv frames of a [B,Tout,...] buffer are written). */
+int diffsal_pack_frames(const float* vis, const float* noise, float* out, int B, int C, int Tv, int Tout,
+                        int hw, diffsal_stream_t stream);
+
+/* ---- bilinear resize, align_corners=False, NHWC ----------------------------------------
+ * R/.../common_block.py:197 (nn.Upsample x2), sal_unet.py:325-327. */
+int diffsal_resize_bilinear(const float* in, float* out, int N, int h, int w, int H, int W, int C,
+                            diffsal_stream_t stream);
+
+/* out[n,Y,X,c] = sum_i bilinear(in_i[n, h_i, w_i, c] -> (H,W)), summed in order i = 0..n_in-1.
+ * Replaces the per-stage F.interpolate + "+=" of R/.../sal_unet.py:482-487. n_in <= 4. */
+int diffsal_resize_sum(const float* const* ins /*host array of device ptrs*/, const int* hs, const int* ws,
+                       int n_in, float* out, int N, int H, int W, int C, diffsal_stream_t stream);
+
+/* ---- K7: audio fusion (after the align 1x1 conv) ----------------------------------------
+ * R/.../transformer.py:133-146.  a_small: [B*T, h*w, C] tokens; x: NHWC frames [B,T,H,W,C];
+ * out: contiguous [B,C,T,H,W] (the reference layout, which the caller then *reinterprets* as
+ * [B*T, H*W, C] tokens -- quirk Q5).  up = H / h (nearest), 1 when no upsample. */
+int diffsal_audio_fuse(const float* a_small, const float* x, float* out, int B, int T, int H, int W, int C,
+                       int h, int w, diffsal_stream_t stream);
+
+/* ---- K8: LayerNorm over C on tokens [M,C] ------------------------------------------------ */
+int diffsal_layernorm(const float* x, const float* gamma, const float* beta, float* out, int M, int C,
+                      float eps, diffsal_stream_t stream);
+
+/* ---- K9: depthwise projections + LayerNorm ----------------------------------------------
+ * q: depthwise 3x3 (pad 1) on NHWC [N,H,W,C] then LN  -> [N, H*W, C].   R/.../attention.py:36-47,94
+ * w9: [9][C] (centre temporal slice of the Conv3d weight, quirk Q8). */
+int diffsal_dwconv3_ln(const float* x, const float* w9, const float* gamma, const float* beta, float* out,
+                       int N, int H, int W, int C, float eps, diffsal_stream_t stream);
+/* k and v: depthwise kxk stride k (no pad) then LN -> [N, gh*gw, C] each; xk may differ from xv
+ * (audio-fused K, attention.py:88-92).  wk, wv: [k*k][C]. */
+int diffsal_dwpool_ln_kv(const float* xk, const float* xv, const float* wk, const float* wv,
+                         const float* gk, const float* bk, const float* gv, const float* bv,
+                         float* out_k, float* out_v, int N, int H, int W, int C, int k, float eps,
+                         diffsal_stream_t stream);
+
+/* ---- K11: attention core ------------------------------------------------------------------
+ * o[n,l,:] = concat_h softmax_t( q[n,l,h,:] . k[n,t,h,:] * scale ) v[n,t,h,:],  Lk <= 32.
+ * R/.../attention.py:97-108 (scale = C^-0.5, quirk Q6). */
+int diffsal_attention(const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk,
+                      int C, int heads, float scale, diffsal_stream_t stream);
+
+/* ---- K14 tail: 1x1 conv C->1 + sigmoid on NHWC -> [N,H,W] --------------------------------
+ * R/.../common_block.py:111-122. */
+int diffsal_head_sigmoid(const float* x, const float* w /*[C]*/, const float* bias /*[1]*/, float* out,
+                         int NHW, int C, diffsal_stream_t stream);
+
+/* ---- K15: sampler elementwise update  out = a*x + b*y + c*z  (y, z may be NULL) -----------
+ * scalar-coefficient axpys of R/diffusion_trainer.py:459-478 and R/models/dpm_solver/sampler.py:548-593,816-853. */
+int diffsal_axpbypcz(const float* x, const float* y, const float* z, float a, float b, float c, float* out,
+                     size_t n, diffsal_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSAL_H */
