@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoise-steps/s of the DiffSal sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): visual-only, batch 4 clips per GPU, 224x384, 50-NFE
+DPM-Solver trajectories (49 multistep-2 steps, logSNR grid, + denoise-to-zero, model_type x_start), fp32,
+faithful full graph (all 9 frames every step, no cross-step caching), synthetic N(0,1) inputs of the
+shapes in R/models/diff_model.py:105-111, closed-form random weights (no checkpoints offline).
+
+One "step" = one denoising step of the sampler on one batch: one SalUNet evaluation + its solver update.
+Trajectories run back to back; exactly K steps are timed (a trailing partial trajectory is cut after its
+last needed evaluation).  value = n_gpus * batch * K / max-over-ranks(wall time), inputs resident in HBM.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (fp32-MFMA implicit GEMM): algorithmic FLOPs of the launches of one
+                  timed step / their HIP-event durations, vs the 157.3 TFLOP/s dense fp32 matrix peak.
+  cpu_baseline -- the CPU oracle (oracle/salunet_oracle.py, "port") timed on this box's host cores on a
+                  bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+NFE_PER_TRAJECTORY = 50
+
+
+class _Stop(Exception):
+    pass
+
+
+def build_net(cfg, device):
+    from diff_sal_amd.sal_unet import SalUNet
+    from oracle import salunet_oracle as orc
+
+    n = cfg.num_stages
+    net = SalUNet(
+        image_based=True, img_size=cfg.img_size, frames_len=1, mid_num_stages=n, temporal_size=9,
+        temporal_list=list(cfg.temporal_list), futr_num_stages=0, ori_embed_dim=cfg.ori_embed_dim,
+        down_embed_dim=cfg.down_embed_dim, patch_size=[0, 3, 3, 3], patch_stride=[0, 1, 1, 1],
+        patch_padding=list(cfg.dilation), up_channel=list(cfg.up_channel), num_heads=list(cfg.num_heads),
+        mlp_ratio=[2.0] * n, drop_path_rate=[0.15] * n, qkv_bias=[True] * n, kv_proj_method=["avg"] * n,
+        kernel_kv=list(cfg.kernel_kv), padding_kv=[0] * n, stride_kv=list(cfg.kernel_kv),
+        q_proj_method=["dw_bn"] * n, kernel_q=[3] * n, padding_q=[1] * n, stride_q=[1] * n)
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    net.load_state_dict(sd)
+    return net.to(device).eval(), sd
+
+
+class Top(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.decoder_net, self.audio_net, self.visual_net = net, None, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--mode", choices=["vis", "av"], default="vis", help="vis = BASELINE configs[1]; av = configs[2]")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", init_method="env://")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from diff_sal_amd import ops
+    from diff_sal_amd.sampling import DiffusionSampler
+    from oracle import salunet_oracle as orc  # only for the closed-form weights/inputs and the CPU baseline
+
+    cfg = orc.SalUNetConfig()
+    B, av = args.batch, args.mode == "av"
+    net, sd = build_net(cfg, dev)
+
+    # synthetic clips, resident in HBM before the timed region; rank-dependent seed (each rank owns its clips)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    H, W = cfg.img_size
+    x_T = torch.randn((B, 1, H, W), generator=g).to(dev)
+    feats = [torch.randn((B, c, 8, H // s, W // s), generator=g).to(dev)
+             for c, s in zip(cfg.up_channel, (32, 16, 8, 4))]
+    audio = torch.randn((B, 512, 9, H // 32, W // 32), generator=g).to(dev) if av else None
+
+    sampler = DiffusionSampler(Top(net), timesteps=NFE_PER_TRAJECTORY, sample_type="dpmsolver", skip_type="logSNR",
+                               denoise=True, training_target="x0")
+
+    state = {"budget": 0, "profile_last": False}
+    inner = net.forward
+
+    def counted(x, t, f, a=None):
+        if state["budget"] <= 0:
+            raise _Stop
+        state["budget"] -= 1
+        if state["budget"] == 0 and state["profile_last"]:
+            ops.PROFILE = []
+            try:
+                return inner(x, t, f, a)
+            finally:
+                state["events"], ops.PROFILE = ops.PROFILE, None
+        return inner(x, t, f, a)
+
+    net.forward = counted
+
+    def run_steps(n, profile_last=False):
+        state["budget"], state["profile_last"] = n, profile_last
+        while state["budget"] > 0:
+            try:
+                sampler.sample_dpm_solver(x_T, feats, audio)
+            except _Stop:
+                pass
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+
+    run_steps(max(args.warmup, 1))
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, profile_last=True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
+    ev = state.get("events") or []
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+    k_flops = sum(f for _, _, f in ev)
+    n_launch = max(len(ev), 1)
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "igemm_hbm_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = {
+        "kernel": "diffsal::igemm_kernel (fp32 MFMA implicit GEMM: 3x3 convs, token GEMMs, ReduceTemp)",
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),
+        "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3),
+    }
+
+    result = {
+        "metric": "denoise-steps/sec (batch x NFE / wall time), 16x224x384 clip, 50-step DPM-Solver",
+        "value": round(world * B * args.steps / elapsed, 3),
+        "unit": "denoise-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE configs[1]: DHF1k visual-only" if not av else "BASELINE configs[2]: AVAD audio-visual")
+            + f", batch={B}/GPU, 224x384, 50-NFE DPM-Solver (multistep-2, logSNR, denoise-to-zero), faithful full graph",
+            "batch_per_gpu": B, "nfe_per_trajectory": NFE_PER_TRAJECTORY, "sharding": "clips by rank, no collective",
+            "step": "one SalUNet evaluation + DPM-Solver update on one batch",
+            "gflop_per_clip_step": 151.61 if not av else 152.73,
+        },
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample: a few B-clip oracle evaluations (the per-step network cost dominates a trajectory)
+        nthreads = os.cpu_count() or 1
+        torch.set_num_threads(nthreads)
+        xc, fc = x_T.cpu(), [f.cpu() for f in feats]
+        ac = audio.cpu() if av else None
+        tcpu = torch.full((B,), 500.0)
+        with torch.no_grad():
+            orc.salunet_forward(sd, cfg, xc[:1], tcpu[:1], [f[:1] for f in fc], None if ac is None else ac[:1])
+            c0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                orc.salunet_forward(sd, cfg, xc, tcpu, fc, ac)
+            cdt = time.perf_counter() - c0
+        result["cpu_baseline"] = {
+            "value": round(B * args.cpu_steps / cdt, 4), "unit": "denoise-steps/s", "cores": nthreads, "kind": "port",
+            "sample": f"{args.cpu_steps} SalUNet evaluations at batch {B} (fp32, eval, torch CPU oracle), "
+                      f"{cdt:.1f} s; solver update excluded (negligible)",
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,12 +27,13 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "diffsal_version": (c_i, []),
     "diffsal_last_error": (C.c_char_p, []),
-    "diffsal_temb_mlp": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "diffsal_temb_mlp": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "diffsal_dense_small": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f]),
     "diffsal_conv_in": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_groupnorm_ws_bytes": (c_sz, [c_i, c_i]),
     "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_f]),
-    "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "diffsal_conv_igemm_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
+    "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),

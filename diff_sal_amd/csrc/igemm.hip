@@ -3,8 +3,11 @@
 //   out[m, co] = epilogue( sum_k A[m, k] * Wt[co, k] )
 //
 // A is the im2col view of a channels-last image (never materialised): m = (n, oy, ox),
-// k = (ky, kx, ci) with ci fastest, so a 32-wide K slice is one contiguous 128-byte run of
-// one input pixel.  Wt is the weight packed as [Cout][K]: both operands are K-contiguous
+// k = (ci_chunk, ky, kx, ci % 32): a 32-wide K slice is one contiguous 128-byte run of one input
+// pixel, and the KH*KW taps of one 32-channel chunk are consecutive K slices, so a workgroup
+// sweeps all taps over the same few KB of input while they are still in L1/L2 (tap-major order
+// re-streams the whole channel depth once per tap and overflows the 4 MiB per-XCD L2).
+// Wt is the weight packed as [Cout][K] in the same k order: both operands are K-contiguous
 // ("NT" GEMM), both are staged through LDS with a 36-dword row pitch (conflict-free for
 // ds_read_b128 on the 64-bank LDS), and each lane reads 4 consecutive k of its row at once.
 // v_mfma_f32_32x32x2_f32 consumes k pairs {j, j+4} of an 8-wide group (lane half h supplies
@@ -32,9 +35,11 @@ struct IgemmArgs {
   float* out;
   int M, K;
   int H, W, Cin, Ho, Wo, Cout;
-  int KW, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
+  int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int act, rowvec_ld;
   int n_tiles_n, n_tiles;  // tiles along N, total tiles
+  int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
+  float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
 };
 
 constexpr int BK = 32;
@@ -46,11 +51,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int BN = WN * TN * 32;
   constexpr int A_PASSES = BM / 32;
   constexpr int B_PASSES = BN / 32;
+  constexpr int STAGE = (BM + BN) * PITCH;  // floats per LDS stage
   static_assert(WM * WN == 4, "4 waves per workgroup");
 
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * PITCH];
-  float* As = smem;
-  float* Bs = smem + BM * PITCH;
+  // Two LDS stages: while the MFMAs consume stage `cur`, the same wave parks the next K slice
+  // (already in registers) into stage `cur ^ 1` and issues the global loads of the slice after
+  // that.  One barrier per K slice; no phase in which the matrix pipe has nothing to do.
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
   // contiguous run of tiles (same-M tiles share their A rows in one L2).  Bijective for any count.
   int tile;
+  const int split = blockIdx.y;
   {
     const int nwg = p.n_tiles;
     const int b = blockIdx.x;
@@ -78,61 +86,61 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   const int lcol = (tid & 7) * 4;
 
   int a_iy0[A_PASSES], a_ix0[A_PASSES];
-  long a_base[A_PASSES];
+  long a_off[A_PASSES];  // element offset of (n, iy0, ix0, lcol); may point before the image, only used when in bounds
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int j = 0; j < A_PASSES; ++j) {
-    const int m = m0 + lrow + 32 * j;
-    if (m < p.M) {
-      const int n = m / HoWo;
-      const int rem = m - n * HoWo;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
-      a_iy0[j] = oy * p.stride_h - p.pad_t;
-      a_ix0[j] = ox * p.stride_w - p.pad_l;
-      a_base[j] = static_cast<long>(n) * p.H * p.W * p.Cin + lcol;
-    } else {
-      a_iy0[j] = -(1 << 28);  // forces the bounds test to fail for every tap
-      a_ix0[j] = 0;
-      a_base[j] = 0;
-    }
+    int m = m0 + lrow + 32 * j;
+    m = m < p.M ? m : p.M - 1;  // rows past M compute garbage that is never stored
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    a_iy0[j] = oy * p.stride_h - p.pad_t;
+    a_ix0[j] = ox * p.stride_w - p.pad_l;
+    a_off[j] = (static_cast<long>(n) * p.H * p.W + static_cast<long>(a_iy0[j]) * p.W + a_ix0[j]) * p.Cin + lcol;
   }
   long b_off[B_PASSES];
-  bool b_ok[B_PASSES];
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
-    const int n = n0 + lrow + 32 * j;
-    b_ok[j] = n < p.Cout;
-    b_off[j] = static_cast<long>(b_ok[j] ? n : 0) * p.K + lcol;
+    int n = n0 + lrow + 32 * j;
+    n = n < p.Cout ? n : p.Cout - 1;  // columns past Cout are never stored
+    b_off[j] = static_cast<long>(n) * p.K + lcol;
   }
 
   float4 ra[A_PASSES], rb[B_PASSES];
-  const int KT = p.K / BK;
+  unsigned a_mask = 0;  // bit j: ra[j] is a real (in-bounds) pixel, else it must read as zero
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(p.K / BK, kt_begin + p.kt_per_split);
+  const int nkt = kt_end - kt_begin;
 
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / p.Cin;  // wave-uniform
-    const int ci0 = k0 - tap * p.Cin;
+  // Branch-free: out-of-image taps and slices past the end read element 0 (always mapped) and are
+  // zeroed / ignored later, so the whole K loop stays one basic block the scheduler can interleave.
+  auto issue_loads = [&](int kt, bool live) {
+    const int chunk = kt / p.taps;  // wave-uniform
+    const int tap = kt - chunk * p.taps;
     const int ky = tap / p.KW;
     const int kx = tap - ky * p.KW;
     const int dy = ky * p.dil_h, dx = kx * p.dil_w;
+    const long delta = (static_cast<long>(dy) * p.W + dx) * p.Cin + chunk * BK;
+    a_mask = 0;
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
       const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-      const bool ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-      const long off = a_base[j] + (static_cast<long>(iy) * p.W + ix) * p.Cin + ci0;
-      ra[j] = ok ? ld4(p.in + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = live & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+      a_mask |= (ok ? 1u : 0u) << j;
+      ra[j] = ld4(p.in + (ok ? a_off[j] + delta : 0L));
     }
+    const long kofs = live ? static_cast<long>(kt) * BK : 0L;
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) {
-      rb[j] = b_ok[j] ? ld4(p.w + b_off[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < B_PASSES; ++j) rb[j] = ld4(p.w + (live ? b_off[j] : 0L) + kofs);
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](float* stage) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < A_PASSES; ++j) st4(&As[(lrow + 32 * j) * PITCH + lcol], ra[j]);
+    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH + lcol], ((a_mask >> j) & 1u) ? ra[j] : z);
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) st4(&Bs[(lrow + 32 * j) * PITCH + lcol], rb[j]);
+    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
   };
 
   f32x16 acc[TM][TN];
@@ -145,40 +153,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 
   const int frow = lane & 31;
   const int fk = (lane >> 5) * 4;
-  const float* a_frag = As + (wm * TM * 32 + frow) * PITCH + fk;
-  const float* b_frag = Bs + (wn * TN * 32 + frow) * PITCH + fk;
+  const int a_frag = (wm * TM * 32 + frow) * PITCH + fk;
+  const int b_frag = (BM + wn * TN * 32 + frow) * PITCH + fk;
 
-  load_tile(0);
-  for (int kt = 0; kt < KT; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < KT) load_tile(kt + 1);  // global loads fly under the MFMAs below
+  auto mfma_group = [&](const float* stage, int kk) {
+    float4 af[TM], bf[TN];
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) af[i] = ld4(stage + a_frag + i * 32 * PITCH + kk * 8);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ld4(a_frag + i * 32 * PITCH + kk * 8);
+    for (int j = 0; j < TN; ++j) bf[j] = ld4(stage + b_frag + j * 32 * PITCH + kk * 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = ld4(b_frag + j * 32 * PITCH + kk * 8);
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int i = 0; i < TM; ++i) {
+        const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-          }
+        for (int j = 0; j < TN; ++j) {
+          const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
         }
       }
     }
+  };
+
+  issue_loads(kt_begin, true);
+  store_tile(smem);
+  issue_loads(kt_begin + 1, nkt > 1);
+  __syncthreads();
+  for (int it = 0; it < nkt; ++it) {
+    float* cur = smem + (it & 1) * STAGE;
+    float* nxt = smem + ((it & 1) ^ 1) * STAGE;
+    mfma_group(cur, 0);
+    store_tile(nxt);                                    // slice it+1: registers -> other stage
+    issue_loads(kt_begin + it + 2, it + 2 < nkt);        // slice it+2: global -> registers
+    mfma_group(cur, 1);
+    mfma_group(cur, 2);
+    mfma_group(cur, 3);
     __syncthreads();
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
+  if (p.splits > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
+    float* part = p.partial + static_cast<long>(split) * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + col_l;
+      if (n >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + (wm * TM + i) * 32 + row_h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) part[static_cast<long>(m) * p.Cout + n] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + col_l;
@@ -208,34 +242,121 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   }
 }
 
+// Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue; float4 over Cout.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs p) {
+  const int n4 = p.Cout >> 2;
+  const long total = static_cast<long>(p.M) * n4;
+  const long slab = static_cast<long>(p.M) * p.Cout;
+  const int HoWo = p.Ho * p.Wo;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int n = static_cast<int>(i % n4) * 4;
+    const long m = i / n4;
+    const long o = m * p.Cout + n;
+    float4 a = ld4(p.partial + o);
+    for (int s = 1; s < p.splits; ++s) {
+      const float4 b = ld4(p.partial + s * slab + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j];
+      if (p.bias) x += p.bias[n + j];
+      if (p.scale) x = x * p.scale[n + j] + p.shift[n + j];
+      if (p.rowvec) x += p.rowvec[(m / HoWo) * p.rowvec_ld + n + j];
+      if (p.act == DIFFSAL_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (p.act == DIFFSAL_ACT_GELU_ERF) x = gelu_erf(x);
+      else if (p.act == DIFFSAL_ACT_SIGMOID) x = sigmoidf_(x);
+      if (p.residual) x += p.residual[o + j];
+      v[j] = x;
+    }
+    st4(p.out + o, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
+struct TileCfg { int bm, bn; float eff; };
+// order must match the dispatch switch in run()
+static const TileCfg kCfgs[] = {{128, 192, 0.95f}, {128, 128, 0.95f}, {128, 96, 0.95f},
+                                {64, 128, 0.90f},  {128, 64, 0.90f},  {64, 64, 0.85f}};
+constexpr int kNumCfgs = 6;
+constexpr int kCUs = 256;
+
+struct Plan { int cfg, splits; };
+
+// Pick tile shape and split-K factor with a small analytic model of an MFMA-bound grid:
+// the 256 CUs each retire whole workgroups, so time ~ ceil(workgroups / 256) * work-per-workgroup
+// (wave quantisation), plus a fixed per-workgroup cost and, for split-K, the slab round trip.
+static Plan choose_plan(long M, int Cout, int K) {
+  const double mac_per_s_cu = 157.3e12 / 2.0 / kCUs;
+  const int KT = K / BK;
+  Plan best{5, 1};
+  double best_t = 1e30;
+  for (int c = 0; c < kNumCfgs; ++c) {
+    const TileCfg& t = kCfgs[c];
+    if (Cout % 32 == 0 && t.bn > Cout && t.bn - Cout >= 32 && c != 5) continue;  // mostly-empty N tile
+    const long tiles = ((M + t.bm - 1) / t.bm) * ((Cout + t.bn - 1) / t.bn);
+    for (int S = 1; S <= 16; S *= 2) {
+      if (S > 1 && (KT / S < 6 || Cout % 4 != 0)) break;
+      const long wgs = tiles * S;
+      const double rounds = static_cast<double>((wgs + kCUs - 1) / kCUs);
+      const int kt_per = (KT + S - 1) / S;
+      double tt = rounds * (static_cast<double>(t.bm) * t.bn * (kt_per * BK) / (mac_per_s_cu * t.eff) + 1.5e-6);
+      if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6;
+      if (tt < best_t) { best_t = tt; best = Plan{c, S}; }
+    }
+  }
+  return best;
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch(IgemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), dim3(a.n_tiles), dim3(256), 0, s, a);
-  return check_launch("diffsal_conv_igemm");
+  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  int rc = check_launch("diffsal_conv_igemm");
+  if (rc || a.splits == 1) return rc;
+  const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
+  long g = (total4 + 255) / 256;
+  g = g > 2048 ? 2048 : g;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<int>(g)), dim3(256), 0, s, a);
+  return check_launch("diffsal_conv_igemm(split-K reduce)");
 }
 
 }  // namespace diffsal
 
 using namespace diffsal;
 
-extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, const float* w,
-                                  const float* bias, const float* scale, const float* shift,
-                                  const float* rowvec, const float* residual, float* out,
-                                  diffsal_stream_t stream) {
-  DS_REQUIRE(d && in && w && out, DIFFSAL_E_ARG, "conv_igemm: null argument");
+static int validate(const diffsal_conv_desc* d) {
+  DS_REQUIRE(d, DIFFSAL_E_ARG, "conv_igemm: null descriptor");
   DS_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, DIFFSAL_E_SHAPE, "conv_igemm: Cin=%d must be a multiple of 32", d->Cin);
   DS_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride_h > 0 &&
                  d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0,
              DIFFSAL_E_SHAPE, "conv_igemm: non-positive dimension");
   DS_REQUIRE(d->Ho > 0 && d->Wo > 0, DIFFSAL_E_SHAPE, "conv_igemm: empty output %dx%d", d->Ho, d->Wo);
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  DS_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), DIFFSAL_E_SHAPE, "conv_igemm: problem too large");
+  return DIFFSAL_OK;
+}
+
+extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
+  if (validate(d) != DIFFSAL_OK) return 0;
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  const Plan pl = choose_plan(M, d->Cout, d->KH * d->KW * d->Cin);
+  return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
+}
+
+extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, const float* w,
+                                  const float* bias, const float* scale, const float* shift,
+                                  const float* rowvec, const float* residual, float* out, void* ws,
+                                  size_t ws_bytes, diffsal_stream_t stream) {
+  int rc = validate(d);
+  if (rc) return rc;
+  DS_REQUIRE(in && w && out, DIFFSAL_E_ARG, "conv_igemm: null argument");
   DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "conv_igemm: scale and shift go together");
   DS_REQUIRE(aligned16(in) && aligned16(w), DIFFSAL_E_ALIGN, "conv_igemm: in/w must be 16-byte aligned");
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
-  DS_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), DIFFSAL_E_SHAPE, "conv_igemm: problem too large");
 
   IgemmArgs a;
   a.in = in; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec;
@@ -243,18 +364,28 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.M = static_cast<int>(M);
   a.K = d->KH * d->KW * d->Cin;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
-  a.KW = d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
-  a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
+  a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
+  a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
   hipStream_t s = static_cast<hipStream_t>(stream);
 
-  // Tile choice: the widest tile whose grid still fills the 256 CUs a few times over.
-  const int Cout = d->Cout;
-  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-  const bool n96 = (Cout % 96 == 0) && (Cout % 128 != 0);
-  if (n96 && Cout % 192 == 0 && blocks(128, 192) >= 768) return launch<2, 2, 2, 3>(a, s);
-  if (n96 && blocks(128, 96) >= 192) return launch<4, 1, 1, 3>(a, s);
-  if (!n96 && blocks(128, 128) >= 512) return launch<2, 2, 2, 2>(a, s);
-  if (blocks(64, 128) >= 384 && Cout % 128 == 0) return launch<2, 2, 1, 2>(a, s);
-  return launch<2, 2, 1, 1>(a, s);
+  const Plan pl = choose_plan(M, d->Cout, a.K);
+  a.splits = pl.splits;
+  a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;
+  a.partial = nullptr;
+  if (pl.splits > 1) {
+    const size_t need = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
+    DS_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && aligned16(out), DIFFSAL_E_ARG,
+               "conv_igemm: split-K needs %zu bytes of 16-byte aligned workspace (diffsal_conv_igemm_ws_bytes), got %zu",
+               need, ws_bytes);
+    a.partial = static_cast<float*>(ws);
+  }
+  switch (pl.cfg) {
+    case 0: return launch<2, 2, 2, 3>(a, s);
+    case 1: return launch<2, 2, 2, 2>(a, s);
+    case 2: return launch<4, 1, 1, 3>(a, s);
+    case 3: return launch<2, 2, 1, 2>(a, s);
+    case 4: return launch<2, 2, 2, 1>(a, s);
+    default: return launch<2, 2, 1, 1>(a, s);
+  }
 }

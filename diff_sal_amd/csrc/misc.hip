@@ -13,41 +13,33 @@ void set_error(const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: sinusoidal embedding + dense0 + swish + dense1, one workgroup per batch element.
-// R/models/saliency_decoder/sal_unet.py:15-33, :304-307.  A wavefront computes one output row at a
-// time: coalesced weight-row read + 64-lane butterfly.
+// K1: sinusoidal embedding + dense0 + swish (this kernel), then dense1 through dense_small_kernel.
+// R/models/saliency_decoder/sal_unet.py:15-33, :304-307.  One wavefront per output row: coalesced
+// weight-row read + 64-lane butterfly; every workgroup rebuilds the tiny [B, ch] embedding in LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void temb_kernel(const void* __restrict__ t, int t_is_f32, int ch,
-                                                   const float* __restrict__ freq, const float* __restrict__ w0,
-                                                   const float* __restrict__ b0, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, float* __restrict__ out) {
-  extern __shared__ float sh[];  // emb[ch] | hidden[4ch]
-  float* emb = sh;
-  float* hid = sh + ch;
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void temb_dense0_kernel(const void* __restrict__ t, int t_is_f32, int B, int ch,
+                                                          const float* __restrict__ freq, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, float* __restrict__ hid) {
+  extern __shared__ float sh[];  // emb[B][ch]
   const int half = ch / 2, tc = 4 * ch;
-  const float tv = t_is_f32 ? static_cast<const float*>(t)[b]
-                            : static_cast<float>(static_cast<const long long*>(t)[b]);
-  for (int j = threadIdx.x; j < half; j += 256) {
+  for (int i = threadIdx.x; i < B * half; i += 256) {
+    const int b = i / half, j = i - b * half;
+    const float tv = t_is_f32 ? static_cast<const float*>(t)[b]
+                              : static_cast<float>(static_cast<const long long*>(t)[b]);
     const float a = tv * freq[j];
-    emb[j] = sinf(a);
-    emb[half + j] = cosf(a);
+    sh[b * ch + j] = sinf(a);
+    sh[b * ch + half + j] = cosf(a);
   }
-  if ((ch & 1) && threadIdx.x == 0) emb[ch - 1] = 0.f;
+  if ((ch & 1) && threadIdx.x < B) sh[threadIdx.x * ch + ch - 1] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < tc; r += 4) {
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= tc) return;
+  for (int b = 0; b < B; ++b) {
     float s = 0.f;
-    for (int k = lane; k < ch; k += 64) s = fmaf(w0[r * ch + k], emb[k], s);
+    for (int k = lane; k < ch; k += 64) s = fmaf(w0[r * ch + k], sh[b * ch + k], s);
     s = group_sum<64>(s);
-    if (lane == 0) hid[r] = swishf(s + b0[r]);
-  }
-  __syncthreads();
-  for (int r = wave; r < tc; r += 4) {
-    float s = 0.f;
-    for (int k = lane; k < tc; k += 64) s = fmaf(w1[static_cast<long>(r) * tc + k], hid[k], s);
-    s = group_sum<64>(s);
-    if (lane == 0) out[static_cast<long>(b) * tc + r] = s + b1[r];
+    if (lane == 0) hid[static_cast<long>(b) * tc + r] = swishf(s + b0[r]);
   }
 }
 
@@ -71,35 +63,49 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // K2: conv_in 1 -> C, 3x3, pad 1; NCHW (C=1) in, NHWC out.  R/.../sal_unet.py:240,292
-// thread = (pixel, 4 channels).
+// A thread owns 4 output channels (its 36 weights stay in registers) and walks over pixels; the
+// C/4 lanes of a pixel read the same 9 inputs (broadcast) and write one contiguous C-float row.
+// With skip_mod = s only rows/columns with index % s != s-1 are produced (the stride-s 3x3 consumer
+// never reads the others).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                      int H, int W, int C, int skip_mod) {
+                                                      int H, int W, int C, int skip_mod, int Hn, int Wn) {
   const int c4n = C >> 2;
-  const long total = static_cast<long>(B) * H * W * c4n;
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
-    const int c = static_cast<int>(i % c4n) * 4;
-    const long pix = i / c4n;
-    const int xw = static_cast<int>(pix % W);
-    const int yh = static_cast<int>((pix / W) % H);
-    if (skip_mod > 0 && ((yh % skip_mod) == skip_mod - 1 || (xw % skip_mod) == skip_mod - 1)) continue;
-    const float* img = x + (pix / (static_cast<long>(H) * W)) * H * W;
-    float o[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
+  const int ppb = 256 / c4n;  // pixels per pass
+  const int c4 = threadIdx.x % c4n, ps = threadIdx.x / c4n;
+  if (ps >= ppb) return;
+  const int c = c4 * 4;
+  float wr[4][9], bi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bi[j] = bias[c + j];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[j][k] = w[(c + j) * 9 + k];
+  }
+  const int keep = skip_mod > 0 ? skip_mod - 1 : 1;
+  const long total = static_cast<long>(B) * Hn * Wn;
+  for (long i = static_cast<long>(blockIdx.x) * ppb + ps; i < total; i += static_cast<long>(gridDim.x) * ppb) {
+    const int xn = static_cast<int>(i % Wn);
+    const int yn = static_cast<int>((i / Wn) % Hn);
+    const int b = static_cast<int>(i / (static_cast<long>(Wn) * Hn));
+    const int xw = skip_mod > 0 ? (xn / keep) * skip_mod + xn % keep : xn;
+    const int yh = skip_mod > 0 ? (yn / keep) * skip_mod + yn % keep : yn;
+    const float* img = x + static_cast<long>(b) * H * W;
+    float o[4] = {bi[0], bi[1], bi[2], bi[3]};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = yh + ky - 1;
-      if (iy < 0 || iy >= H) continue;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = xw + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        const float v = img[static_cast<long>(iy) * W + ix];
+        const bool ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+        const float v = ok ? img[static_cast<long>(iy) * W + ix] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaf(v, w[(c + j) * 9 + ky * 3 + kx], o[j]);
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(v, wr[j][ky * 3 + kx], o[j]);
       }
     }
-    st4(out + pix * C + c, make_float4(o[0], o[1], o[2], o[3]));
+    st4(out + ((static_cast<long>(b) * H + yh) * W + xw) * C + c, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -185,37 +191,49 @@ struct ResizeSumArgs {
 };
 
 // out = ((in0^ + in1^) + in2^) + in3^, x^ = bilinear resize of x to (H, W): one write of the big map.
-__global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float* __restrict__ out, int N, int H, int W,
-                                                         int C) {
-  const int cv = C >> 2;
-  const long total = static_cast<long>(N) * H * W * cv;
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
-    const int c = static_cast<int>(i % cv) * 4;
-    long pix = i / cv;
-    const int X = static_cast<int>(pix % W);
-    pix /= W;
-    const int Y = static_cast<int>(pix % H);
-    const int n = static_cast<int>(pix / H);
+// One workgroup = 4 neighbouring output pixels of one row, one wavefront per pixel: all source
+// coordinates and weights are wave-uniform (scalar registers), lanes stride the channels with float4.
+__global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float* __restrict__ out, int H, int W, int C,
+                                                         int w_tiles) {
+  int bid = blockIdx.x;
+  const int xt = bid % w_tiles; bid /= w_tiles;
+  const int Y = bid % H;
+  const int n = bid / H;
+  const int lane = threadIdx.x & 63;
+  const int X = __builtin_amdgcn_readfirstlane(xt * 4 + (threadIdx.x >> 6));
+  if (X >= W) return;
+  const float* p00[4]; const float* p01[4]; const float* p10[4]; const float* p11[4];
+  float w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < a.n_in) {
+      const int h = a.h[s], w = a.w[s];
+      int y0, y1, x0, x1;
+      float ly, lx;
+      bilin_coord(Y, a.sy[s], h, y0, y1, ly);
+      bilin_coord(X, a.sx[s], w, x0, x1, lx);
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      const float* b = a.in[s] + static_cast<long>(n) * h * w * C;
+      p00[s] = b + (static_cast<long>(y0) * w + x0) * C; p01[s] = b + (static_cast<long>(y0) * w + x1) * C;
+      p10[s] = b + (static_cast<long>(y1) * w + x0) * C; p11[s] = b + (static_cast<long>(y1) * w + x1) * C;
+      w00[s] = hx; w01[s] = lx; w10[s] = hy; w11[s] = ly;
+    }
+  }
+  float* orow = out + ((static_cast<long>(n) * H + Y) * W + X) * C;
+  for (int c = lane * 4; c < C; c += 256) {
     float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s < a.n_in) {
-        const int h = a.h[s], w = a.w[s];
-        int y0, y1, x0, x1;
-        float ly, lx;
-        bilin_coord(Y, a.sy[s], h, y0, y1, ly);
-        bilin_coord(X, a.sx[s], w, x0, x1, lx);
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* b = a.in[s] + static_cast<long>(n) * h * w * C + c;
-        const float4 v00 = ld4(b + (static_cast<long>(y0) * w + x0) * C), v01 = ld4(b + (static_cast<long>(y0) * w + x1) * C);
-        const float4 v10 = ld4(b + (static_cast<long>(y1) * w + x0) * C), v11 = ld4(b + (static_cast<long>(y1) * w + x1) * C);
+        const float4 v00 = ld4(p00[s] + c), v01 = ld4(p01[s] + c), v10 = ld4(p10[s] + c), v11 = ld4(p11[s] + c);
+        const float hx = w00[s], lx = w01[s], hy = w10[s], ly = w11[s];
         acc.x += hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
         acc.y += hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
         acc.z += hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
         acc.w += hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
       }
     }
-    st4(out + ((static_cast<long>(n) * H + Y) * W + X) * C + c, acc);
+    st4(orow + c, acc);
   }
 }
 
@@ -285,58 +303,74 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // K11: attention core with a short pooled K/V (Lk <= 32).  R/.../attention.py:97-108
-// One workgroup = one image n and a run of queries; K and V rows of that image live in LDS.
-// One wavefront per query: lanes stride the C channels; per (head, key) partial dot products are
-// reduced with 64-lane butterflies; softmax over Lk in registers (every lane holds all scores).
+// G lanes share one (query, head): lane g owns the float4 pieces g, g+G, ... of the head's d channels,
+// so the G lanes read/write 16*G contiguous bytes of the q / o rows, the Lk partial scores are
+// combined with log2(G) xor-shuffles, and the softmax runs redundantly in registers (no LDS, no
+// cross-wave traffic).  K and V of the image sit in LDS; lanes with the same g read the same
+// address (broadcast), different g read neighbouring 16-byte slots (conflict-free).
+// FLOPs are 0.4 % of a step: the kernel is bound by the q / o traffic.
 // ------------------------------------------------------------------------------------------------
-template <int LK_MAX>
+template <int LK, int G>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* __restrict__ o, int Lq,
-                                                        int Lk, int C, int heads, float scale, int q_per_block) {
+                                                        int Lk, int C, int heads, float scale) {
   extern __shared__ float sh[];  // K[Lk][C] | V[Lk][C]
   float* Ks = sh;
   float* Vs = sh + Lk * C;
   const int n = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < Lk * C / 4; i += 256) {
     st4(Ks + i * 4, ld4(k + static_cast<long>(n) * Lk * C + i * 4));
     st4(Vs + i * 4, ld4(v + static_cast<long>(n) * Lk * C + i * 4));
   }
   __syncthreads();
-  const int d = C / heads;
-  const int q_begin = blockIdx.x * q_per_block;
-  const int q_end = min(Lq, q_begin + q_per_block);
-  for (int l = q_begin + wave; l < q_end; l += 4) {
-    const float* qr = q + (static_cast<long>(n) * Lq + l) * C;
-    float* orow = o + (static_cast<long>(n) * Lq + l) * C;
-    for (int hd = 0; hd < heads; ++hd) {
-      const int cb = hd * d;
-      float sc[LK_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wph = 4 / heads;       // wavefronts per head; the head is wave-uniform
+  const int hd = wave / wph;
+  constexpr int QPW = 64 / G;      // queries per wavefront
+  const int g = lane % G;
+  const int l = blockIdx.x * (wph * QPW) + (wave - hd * wph) * QPW + lane / G;
+  const bool valid = l < Lq;
+  const int lc = valid ? l : Lq - 1;  // out-of-range lanes stay alive for the shuffles
+  const int d = C / heads, nf4 = d >> 2;
+  const int cb = hd * d;
+  const float* qr = q + (static_cast<long>(n) * Lq + lc) * C + cb;
+  float* orow = o + (static_cast<long>(n) * Lq + lc) * C + cb;
+  float sc[LK];
 #pragma unroll
-      for (int t = 0; t < LK_MAX; ++t) sc[t] = 0.f;
-      for (int cc = lane; cc < d; cc += 64) {
-        const float qv = qr[cb + cc];
+  for (int t = 0; t < LK; ++t) sc[t] = 0.f;
+  for (int i = g; i < nf4; i += G) {
+    const float4 qv = ld4(qr + 4 * i);
 #pragma unroll
-        for (int t = 0; t < LK_MAX; ++t)
-          if (t < Lk) sc[t] = fmaf(qv, Ks[t * C + cb + cc], sc[t]);
-      }
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int t = 0; t < LK_MAX; ++t)
-        if (t < Lk) { sc[t] = group_sum<64>(sc[t]) * scale; mx = fmaxf(mx, sc[t]); }
-      float sum = 0.f;
-#pragma unroll
-      for (int t = 0; t < LK_MAX; ++t)
-        if (t < Lk) { sc[t] = expf(sc[t] - mx); sum += sc[t]; }
-      const float inv = 1.0f / sum;
-      for (int cc = lane; cc < d; cc += 64) {
-        float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < LK_MAX; ++t)
-          if (t < Lk) acc = fmaf(sc[t] * inv, Vs[t * C + cb + cc], acc);
-        orow[cb + cc] = acc;
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) {
+        const float4 kv = ld4(Ks + t * C + cb + 4 * i);
+        sc[t] = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, sc[t]))));
       }
     }
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < LK; ++t) {
+    if (t < Lk) { sc[t] = group_sum<G>(sc[t]) * scale; mx = fmaxf(mx, sc[t]); }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < LK; ++t) {
+    if (t < Lk) { sc[t] = expf(sc[t] - mx); sum += sc[t]; }
+  }
+  const float inv = 1.0f / sum;
+  for (int i = g; i < nf4; i += G) {
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) {
+        const float4 vv = ld4(Vs + t * C + cb + 4 * i);
+        const float pw = sc[t] * inv;
+        acc.x = fmaf(pw, vv.x, acc.x); acc.y = fmaf(pw, vv.y, acc.y);
+        acc.z = fmaf(pw, vv.z, acc.z); acc.w = fmaf(pw, vv.w, acc.w);
+      }
+    }
+    if (valid) st4(orow + 4 * i, acc);
   }
 }
 
@@ -380,13 +414,20 @@ extern "C" int diffsal_version(void) { return 1; }
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
-                                const float* b0, const float* w1, const float* b1, float* temb_out,
+                                const float* b0, const float* w1, const float* b1, float* hidden_ws, float* temb_out,
                                 diffsal_stream_t stream) {
-  DS_REQUIRE(t && freq && w0 && b0 && w1 && b1 && temb_out, DIFFSAL_E_ARG, "temb_mlp: null argument");
-  DS_REQUIRE(B > 0 && ch >= 4 && ch <= 1024, DIFFSAL_E_SHAPE, "temb_mlp: bad shape B=%d ch=%d", B, ch);
-  hipLaunchKernelGGL(temb_kernel, dim3(B), dim3(256), 5 * ch * sizeof(float), static_cast<hipStream_t>(stream), t,
-                     t_is_f32, ch, freq, w0, b0, w1, b1, temb_out);
-  return check_launch("temb_mlp");
+  DS_REQUIRE(t && freq && w0 && b0 && w1 && b1 && hidden_ws && temb_out, DIFFSAL_E_ARG, "temb_mlp: null argument");
+  DS_REQUIRE(B > 0 && ch >= 4 && ch <= 1024 && static_cast<long>(B) * ch * 16 <= 64 * 1024, DIFFSAL_E_SHAPE,
+             "temb_mlp: bad shape B=%d ch=%d", B, ch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tc = 4 * ch;
+  hipLaunchKernelGGL(temb_dense0_kernel, dim3((tc + 3) / 4), dim3(256), static_cast<size_t>(B) * ch * sizeof(float), s,
+                     t, t_is_f32, B, ch, freq, w0, b0, hidden_ws);
+  int rc = check_launch("temb_mlp(dense0)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dense_small_kernel, dim3((tc + 3) / 4), dim3(256), static_cast<size_t>(B) * tc * sizeof(float), s,
+                     hidden_ws, B, tc, 0, w1, b1, tc, temb_out);
+  return check_launch("temb_mlp(dense1)");
 }
 
 extern "C" int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float* w, const float* bias,
@@ -404,9 +445,15 @@ extern "C" int diffsal_conv_in(const float* x, const float* w, const float* bias
   DS_REQUIRE(x && w && bias && out, DIFFSAL_E_ARG, "conv_in: null argument");
   DS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "conv_in: bad shape");
   DS_REQUIRE(aligned16(out), DIFFSAL_E_ALIGN, "conv_in: misaligned output");
-  const long total = static_cast<long>(B) * H * W * (C / 4);
-  hipLaunchKernelGGL(conv_in_kernel, dim3(ew_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias,
-                     out, B, H, W, C, skip_mod);
+  DS_REQUIRE(C <= 1024 && skip_mod != 1, DIFFSAL_E_SHAPE, "conv_in: C=%d skip_mod=%d unsupported", C, skip_mod);
+  const int keep = skip_mod > 0 ? skip_mod - 1 : 1;
+  const int Hn = skip_mod > 0 ? (H / skip_mod) * keep + (H % skip_mod < keep ? H % skip_mod : keep) : H;
+  const int Wn = skip_mod > 0 ? (W / skip_mod) * keep + (W % skip_mod < keep ? W % skip_mod : keep) : W;
+  const int ppb = 256 / (C / 4);
+  long g = (static_cast<long>(B) * Hn * Wn + ppb - 1) / ppb;
+  g = g > 8192 ? 8192 : g;
+  hipLaunchKernelGGL(conv_in_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w,
+                     bias, out, B, H, W, C, skip_mod, Hn, Wn);
   return check_launch("conv_in");
 }
 
@@ -457,9 +504,11 @@ extern "C" int diffsal_resize_sum(const float* const* ins, const int* hs, const 
     if (i < n_in) DS_REQUIRE(ins[i] && aligned16(ins[i]) && hs[i] > 0 && ws[i] > 0, DIFFSAL_E_ARG, "resize_sum: bad input %d", i);
   }
   DS_REQUIRE(aligned16(out), DIFFSAL_E_ALIGN, "resize_sum: misaligned output");
-  const long total = static_cast<long>(N) * H * W * (C / 4);
-  hipLaunchKernelGGL(resize_sum_kernel, dim3(ew_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), a, out,
-                     N, H, W, C);
+  const int w_tiles = (W + 3) / 4;
+  const long blocks = static_cast<long>(N) * H * w_tiles;
+  DS_REQUIRE(blocks < (1L << 31), DIFFSAL_E_SHAPE, "resize_sum: output too large");
+  hipLaunchKernelGGL(resize_sum_kernel, dim3(static_cast<int>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     out, H, W, C, w_tiles);
   return check_launch("resize_sum");
 }
 
@@ -482,30 +531,53 @@ extern "C" int diffsal_audio_fuse(const float* a_small, const float* x, float* o
   return check_launch("audio_fuse");
 }
 
+template <int LK, int G>
+static void launch_attention(const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk, int C,
+                             int heads, float scale, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(2) * Lk * C * sizeof(float);
+  static bool raised = false;
+  if (lds > 64 * 1024 && !raised) {  // opt in to > 64 KiB of dynamic LDS (host-side attribute, not a stream op)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<LK, G>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  const int qpb = (4 / heads) * (64 / G);  // queries per workgroup
+  hipLaunchKernelGGL((attention_kernel<LK, G>), dim3((Lq + qpb - 1) / qpb, N), dim3(256), lds, s, q, k, v, o, Lq, Lk,
+                     C, heads, scale);
+}
+
+template <int LK>
+static void launch_attention_g(int G, const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk,
+                               int C, int heads, float scale, hipStream_t s) {
+  switch (G) {
+    case 16: launch_attention<LK, 16>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    case 8: launch_attention<LK, 8>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    case 4: launch_attention<LK, 4>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    default: launch_attention<LK, 1>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+  }
+}
+
 extern "C" int diffsal_attention(const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk,
                                  int C, int heads, float scale, diffsal_stream_t stream) {
   DS_REQUIRE(q && k && v && o, DIFFSAL_E_ARG, "attention: null argument");
-  DS_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && Lk <= 32 && heads > 0 && C % heads == 0 && C % 4 == 0, DIFFSAL_E_SHAPE,
-             "attention: bad shape Lq=%d Lk=%d C=%d heads=%d", Lq, Lk, C, heads);
-  const size_t lds = static_cast<size_t>(2) * Lk * C * sizeof(float);
-  DS_REQUIRE(lds <= 160 * 1024, DIFFSAL_E_SHAPE, "attention: K/V tile (%zu B) exceeds LDS", lds);
-  DS_REQUIRE(aligned16(k) && aligned16(v), DIFFSAL_E_ALIGN, "attention: misaligned K/V");
+  DS_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && Lk <= 32, DIFFSAL_E_SHAPE, "attention: bad shape Lq=%d Lk=%d", Lq, Lk);
+  DS_REQUIRE(heads == 1 || heads == 2 || heads == 4, DIFFSAL_E_SHAPE, "attention: heads=%d (1, 2 or 4 are built)", heads);
+  DS_REQUIRE(C % heads == 0 && (C / heads) % 4 == 0, DIFFSAL_E_SHAPE,
+             "attention: C=%d heads=%d: head dim must be a multiple of 4", C, heads);
+  DS_REQUIRE(static_cast<size_t>(2) * Lk * C * sizeof(float) <= 160 * 1024, DIFFSAL_E_SHAPE,
+             "attention: K/V tile exceeds LDS (Lk=%d C=%d)", Lk, C);
+  DS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), DIFFSAL_E_ALIGN,
+             "attention: misaligned pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // enough workgroups to fill the chip, but >= 16 queries each so the K/V staging amortises
-  int qpb = (Lq * N + 1023) / 1024;
-  qpb = qpb < 16 ? 16 : qpb;
-  qpb = (qpb + 3) & ~3;
-  const dim3 grid((Lq + qpb - 1) / qpb, N);
-  if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (host-side attribute, not a stream op)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<18>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
-  if (Lk <= 18)
-    hipLaunchKernelGGL((attention_kernel<18>), grid, dim3(256), lds, s, q, k, v, o, Lq, Lk, C, heads, scale, qpb);
-  else
-    hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), lds, s, q, k, v, o, Lq, Lk, C, heads, scale, qpb);
+  // lanes per (query, head): about 3 float4 pieces of the head dim per lane, at most 16 lanes
+  const int nf4 = C / heads / 4;
+  int G = 1;
+  while (G < 16 && nf4 / (2 * G) >= 3) G *= 2;
+  if (G == 2) G = 4;
+  if (Lk <= 4) launch_attention_g<4>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+  else if (Lk <= 8) launch_attention_g<8>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+  else if (Lk <= 18) launch_attention_g<18>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+  else launch_attention_g<32>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
   return check_launch("attention");
 }
 

@@ -17,6 +17,10 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc  # noqa: F
 
 Tensor = torch.Tensor
 
+# When set to a list (bench.py, one step inside its timed region), every implicit-GEMM launch is bracketed
+# by HIP events on the launching stream and (start, end, algorithmic_flops) is appended.
+PROFILE = None
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -43,9 +47,10 @@ def temb_mlp(t: Tensor, freq: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Te
         t, is_f32 = t.to(torch.float32), 1
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("t must be a contiguous GPU tensor")
-    out = torch.empty((B, 4 * ch), device=t.device, dtype=torch.float32)
+    out = torch.empty((2, B, 4 * ch), device=t.device, dtype=torch.float32)  # [0] = hidden scratch, [1] = temb
     _lib.check(lib.diffsal_temb_mlp(t.data_ptr(), is_f32, B, ch, _p(freq), _p(w0), _p(b0), _p(w1), _p(b1),
-                                    _p(out), _stream()), "temb_mlp")
+                                    _p(out[0]), _p(out[1]), _stream()), "temb_mlp")
+    out = out[1]
     return out
 
 
@@ -82,6 +87,17 @@ def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, ep
     return out
 
 
+def pack_conv_weight(w: Tensor) -> Tensor:
+    """[Cout, Cin, KH, KW] (or Conv3d [Cout, Cin, KT, 1, 1]) -> [Cout, K] in the kernel's k order
+    (ci // 32, tap, ci % 32); see include/diffsal.h."""
+    w = w.detach()
+    if w.dim() == 5:
+        w = w[:, :, :, 0, 0].unsqueeze(-1)  # [Cout, Cin, KT, 1]
+    co, ci, kh, kw = w.shape
+    return (w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3)
+            .reshape(co, kh * kw * ci).contiguous())
+
+
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
                out_hw: Optional[Sequence[int]] = None, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None,
@@ -108,8 +124,16 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         rv = rowvec.data_ptr()
     else:
         rv = None
+    ws_bytes = lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
+    ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32) if ws_bytes else None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.diffsal_conv_igemm(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(scale), _p(shift), rv,
-                                      _p(residual), _p(out), _stream()), "conv_igemm")
+                                      _p(residual), _p(out), _p(ws), ws_bytes, _stream()), "conv_igemm")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin))
     return out
 
 

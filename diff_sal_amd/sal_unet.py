@@ -214,8 +214,8 @@ class SalUNet(nn.Module):
 
     @staticmethod
     def _pack_conv(w: Tensor) -> Tensor:
-        """[Cout,Cin,KH,KW] -> [Cout, KH*KW*Cin] (tap-major, channel fastest = the im2col K order)."""
-        return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+        """[Cout,Cin,KH,KW] -> [Cout, K] in the implicit-GEMM k order (channel chunk, tap, channel)."""
+        return ops.pack_conv_weight(w)
 
     @staticmethod
     def _bn_affine(bn: nn.BatchNorm2d):
@@ -262,8 +262,7 @@ class SalUNet(nn.Module):
             pk[f"s{i}.wk"] = a.conv_proj_k.conv.weight.detach().reshape(c, k * k).t().contiguous()
             pk[f"s{i}.wv"] = a.conv_proj_v.conv.weight.detach().reshape(c, k * k).t().contiguous()
             pk[f"s{i}.align.w"] = st.blocks[0].align_conv.weight.detach().reshape(c, 512).contiguous()
-            w3 = dec.redu_chan_up[i].proj[0].weight.detach()  # [Co, C, kt, 1, 1] -> [Co, kt*C]
-            pk[f"s{i}.redu.w"] = w3[:, :, :, 0, 0].permute(0, 2, 1).reshape(w3.shape[0], -1).contiguous()
+            pk[f"s{i}.redu.w"] = ops.pack_conv_weight(dec.redu_chan_up[i].proj[0].weight)  # [Co, C, kt, 1, 1]
         pk["mt.w"] = self._pack_conv(dec.mt_proj[0].weight)
         pk["mt.scale"], pk["mt.shift"] = self._bn_affine(dec.mt_proj[1])
         pk["head.w"] = self.logits.linear_pred.weight.detach().reshape(-1).contiguous()

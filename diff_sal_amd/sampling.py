@@ -1,0 +1,159 @@
+"""Sampling loops of the DiffSal trainer, re-built around a non-mutating denoiser.
+
+Call-surface parity:
+  * ``DiffusionSampler`` carries the schedule constants of ``DiffusionTrainer.__init__``
+    (R/diffusion_trainer.py:47-76) and its sampling methods ``q_sample`` (:122), ``predict_noise_from_start``
+    (:434), ``sample_ddim`` (:440-480), ``sample_image`` (:546-640);
+  * ``generalized_steps`` keeps the signature of the legacy helper R/util/denoising.py:9-33.
+
+Differences, on purpose: no ``copy.deepcopy`` of the feature list per step (the denoiser does not mutate
+it, D4); the DPM-Solver branch actually runs (D1), wraps the x0-predicting net as ``model_type="x_start"``
+(D2) and forwards the audio conditioning (D3); alpha-bar look-ups are host scalars, so a sampling loop has
+no device->host synchronisation.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .diffusion_utils import get_beta_schedule, to_torch
+from .dpm_solver import DPM_Solver, NoiseScheduleVP, _lincomb, model_wrapper
+
+Tensor = torch.Tensor
+
+
+class DiffusionSampler:
+    def __init__(self, model, *, beta_schedule="cosine", beta_start=1e-4, beta_end=0.02,
+                 num_diffusion_timesteps=1000, training_target="x0", sample_type="ddim", timesteps=1, eta=0.0,
+                 skip_type="logSNR", dpm_solver_order=2, dpm_solver_method="multistep", dpm_solver_type="dpmsolver",
+                 lower_order_final=False, denoise=True, thresholding=False, device=None):
+        """``model`` exposes ``decoder_net`` and optionally ``visual_net`` / ``audio_net`` / ``forward_vggish``
+        (a ``VideoSaliencyModel``; a DDP/DataParallel wrapper is unwrapped through ``.module``).
+        Keyword names = the YAML fields the trainer reads (R/cfgs/diffusion.yml:24-28, 37, 63-78)."""
+        assert training_target in ("x0", "noise")
+        self.model = getattr(model, "module", model)
+        self.training_target = training_target
+        self.sample_type, self.timesteps, self.eta = sample_type, int(timesteps), float(eta)
+        self.skip_type, self.dpm_solver_order = skip_type, int(dpm_solver_order)
+        self.dpm_solver_method, self.dpm_solver_type = dpm_solver_method, dpm_solver_type
+        self.lower_order_final, self.denoise, self.thresholding = bool(lower_order_final), bool(denoise), bool(thresholding)
+        betas = to_torch(get_beta_schedule(beta_schedule, beta_start=beta_start, beta_end=beta_end,
+                                           num_diffusion_timesteps=num_diffusion_timesteps))
+        alphas_hat = (1.0 - betas).cumprod(dim=0)  # host tables; same fp32 arithmetic as the trainer
+        self.betas = betas
+        self.alphas_hat = alphas_hat
+        self.alphas_hat_prev = torch.cat([torch.ones(1), alphas_hat[:-1]], dim=0)
+        self.sqrt_alphas_hat = torch.sqrt(alphas_hat)
+        self.sqrt_one_minus_alphas_hat = torch.sqrt(1.0 - alphas_hat)
+        self.sqrt_recip_alphas_hat = torch.sqrt(1.0 / alphas_hat)
+        self.sqrt_recipm1_alphas_hat = torch.sqrt(1.0 / alphas_hat - 1)
+        self.num_timesteps = betas.shape[0]
+        self.device = device
+
+    # ---- forward process (training side, K16) ----
+    def q_sample(self, x_start: Tensor, t: int, noise: Optional[Tensor] = None) -> Tensor:
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return _lincomb(x_start, self.sqrt_alphas_hat[t], noise, self.sqrt_one_minus_alphas_hat[t])
+
+    def predict_noise_from_start(self, x_t: Tensor, t: int, x0: Tensor) -> Tensor:
+        r, rm1 = float(self.sqrt_recip_alphas_hat[t]), float(self.sqrt_recipm1_alphas_hat[t])
+        return _lincomb(x_t, r / rm1, x0, -1.0 / rm1)
+
+    # ---- DDIM (the reference's live sampler) ----
+    @torch.no_grad()
+    def sample_ddim(self, x: Tensor, img: Optional[Sequence[Tensor]] = None, audio_cond: Optional[Tensor] = None) -> Tensor:
+        skip = self.num_timesteps // self.timesteps
+        seq = list(range(0, self.num_timesteps, skip))
+        seq_next = [-1] + seq[:-1]
+        n = x.size(0)
+        net = self.model.decoder_net
+        for time, time_next in zip(reversed(seq), reversed(seq_next)):
+            t_tensor = torch.full((n,), time, dtype=torch.int64, device=x.device)
+            alpha = float(self.alphas_hat[time])
+            out = net(x, t_tensor, img, audio_cond)
+            if self.training_target == "x0":
+                x_start = out
+                pred_noise = None if time_next < 0 else self.predict_noise_from_start(x, time, x_start)
+            else:
+                pred_noise = out
+                x_start = _lincomb(x, alpha ** -0.5, pred_noise, -((1 - alpha) ** 0.5) / alpha ** 0.5)
+            if time_next < 0:
+                x = x_start
+                continue
+            alpha_next = float(self.alphas_hat[time_next])
+            c1 = self.eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)) ** 0.5
+            c2 = ((1 - alpha_next) - c1 ** 2) ** 0.5
+            if c1 != 0.0:
+                x = _lincomb(x_start, float(self.sqrt_alphas_hat[time_next]), torch.randn_like(x), c1, pred_noise, c2)
+            else:  # eta = 0 (the shipped config): deterministic, no RNG launch
+                x = _lincomb(x_start, float(self.sqrt_alphas_hat[time_next]), pred_noise, c2)
+        return x
+
+    # ---- DPM-Solver (the path the reference intended, with D1-D4 fixed) ----
+    @torch.no_grad()
+    def sample_dpm_solver(self, x: Tensor, img=None, audio_cond: Optional[Tensor] = None) -> Tensor:
+        net = self.model.decoder_net
+
+        def model_fn(x, t, vis_feat, **kw):
+            return net(x, t, vis_feat, audio_cond)
+
+        noise_schedule = NoiseScheduleVP(schedule="discrete", betas=self.betas)
+        fn = model_wrapper(model_fn, noise_schedule,
+                           model_type="x_start" if self.training_target == "x0" else "noise", guidance_type="uncond")
+        solver = DPM_Solver(fn, noise_schedule, algorithm_type=self.sample_type,
+                            correcting_x0_fn="dynamic_thresholding" if self.thresholding else None)
+        return solver.sample(x, img, steps=self.timesteps - 1 if self.denoise else self.timesteps,
+                             order=self.dpm_solver_order, skip_type=self.skip_type, method=self.dpm_solver_method,
+                             lower_order_final=self.lower_order_final, denoise_to_zero=self.denoise,
+                             solver_type=self.dpm_solver_type)
+
+    @torch.no_grad()
+    def sample_image(self, x: Tensor, img: Optional[Tensor] = None, audio: Optional[Tensor] = None) -> Tensor:
+        """Encoders once per clip, then the per-step loop (R/diffusion_trainer.py:546-640)."""
+        m = self.model
+        audio_embed = None
+        if getattr(m, "audio_net", None):
+            _, audio_embed = m.forward_vggish(audio)
+        if getattr(m, "visual_net", None):
+            vis_list = m.visual_net(img)
+        else:  # same synthetic fall-back shapes as the reference (:564-569)
+            b, dev = x.shape[0], x.device
+            vis_list = [torch.randn((b, c, 8, h, w), device=dev)
+                        for c, h, w in ((768, 7, 12), (384, 14, 24), (192, 28, 48), (96, 56, 96))]
+        if self.sample_type == "ddim":
+            return self.sample_ddim(x, vis_list, audio_embed)
+        if self.sample_type in ("dpmsolver", "dpmsolver++"):
+            return self.sample_dpm_solver(x, vis_list, audio_embed)
+        raise NotImplementedError(self.sample_type)
+
+
+def compute_alpha(beta: Tensor, t: Tensor) -> Tensor:
+    """R/util/denoising.py:3-6."""
+    beta = torch.cat([torch.zeros(1).to(beta.device), beta], dim=0)
+    return (1 - beta).cumprod(dim=0).index_select(0, t + 1).view(-1, 1, 1, 1)
+
+
+def generalized_steps(x, seq, model, b, img=None, **kwargs):
+    """Legacy DDIM loop with the reference signature (R/util/denoising.py:9-33): ``model(data, t)`` predicts
+    noise; returns (xs, x0_preds).  Runs on whatever device ``x`` is on (the reference hard-codes 'cuda')."""
+    with torch.no_grad():
+        n = x.size(0)
+        seq = list(seq)
+        seq_next = [-1] + seq[:-1]
+        x0_preds, xs = [], [x]
+        eta = kwargs.get("eta", 0)
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            t = (torch.ones(n) * i).to(x.device)
+            next_t = (torch.ones(n) * j).to(x.device)
+            at = compute_alpha(b, t.long())
+            at_next = compute_alpha(b, next_t.long())
+            xt = xs[-1].to(x.device)
+            et = model({"img": img, "input": xt}, t)
+            x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+            x0_preds.append(x0_t.to("cpu"))
+            c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+            c2 = ((1 - at_next) - c1 ** 2).sqrt()
+            xs.append((at_next.sqrt() * x0_t + c1 * torch.randn_like(x) + c2 * et).to("cpu"))
+    return xs, x0_preds

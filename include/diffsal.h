@@ -44,7 +44,7 @@ const char* diffsal_last_error(void);
  * temb_out[B,4ch] = W1 * swish(W0 * [sin(t f), cos(t f)] + b0) + b1 */
 int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq,
                      const float* w0, const float* b0, const float* w1, const float* b1,
-                     float* temb_out, diffsal_stream_t stream);
+                     float* hidden_ws /* scratch [B,4ch] */, float* temb_out, diffsal_stream_t stream);
 
 /* out[B,N] = W[N,K] * f(in[B,K]) + bias, f = swish if swish_in.  ResnetBlock.temb_proj of all
  * blocks in one call (weights concatenated along N).  R/.../sal_unet.py:107,129. */
@@ -67,9 +67,9 @@ int diffsal_groupnorm_swish(const float* x, const float* gamma, const float* bet
 /* ---- K4/K5/K10/K12/K13/K14: implicit-GEMM convolution / linear on fp32 MFMA -------------
  * out[m, co] = act( ((sum_k A[m,k] * w[co,k]) + bias[co]) * scale[co] + shift[co] + rowvec[img(m), co] )
  *              + residual[m, co]
- * A is the im2col view of in[N,H,W,Cin] (never materialised): m = (n, oy, ox), k = (ky, kx, ci),
+ * A is the im2col view of in[N,H,W,Cin] (never materialised): m = (n, oy, ox), k = (ci / 32, ky, kx, ci % 32),
  * iy = oy*stride_h - pad_t + ky*dil_h, ix = ox*stride_w - pad_l + kx*dil_w, zero outside.
- * w: packed [Cout][KH*KW*Cin].  bias/scale/shift: [Cout] or NULL.  rowvec: [N, rowvec_ld] or NULL.
+ * w: packed [Cout][Cin/32][KH*KW][32] (= [Cout][K] in that k order).  bias/scale/shift: [Cout] or NULL.  rowvec: [N, rowvec_ld] or NULL.
  * residual: [M, Cout] or NULL.  Cin % 32 == 0.  A plain linear layer is KH=KW=1, H=1, W=rows.
  * Replaces torch.nn.Conv2d / Conv3d(k,1,1) / Linear call sites:
  *   R/.../sal_unet.py:104-142 (ResnetBlock), :47-84 (Downsample*), common_block.py:33-36,150-223,
@@ -82,9 +82,12 @@ typedef struct diffsal_conv_desc {
   int rowvec_ld;  /* leading dimension of rowvec (>= Cout) */
 } diffsal_conv_desc;
 
+/* Bytes of scratch the call below needs for this shape (0 unless the planner picks split-K, which it does
+ * when the M x Cout grid alone cannot fill the 256 CUs). */
+size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, const float* w,
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
-                       const float* residual, float* out, diffsal_stream_t stream);
+                       const float* residual, float* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).

@@ -30,7 +30,9 @@ def nhwc(x):
 
 
 def pack_conv(w):
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    from diff_sal_amd.ops import pack_conv_weight
+
+    return pack_conv_weight(w)
 
 
 @pytest.fixture(scope="module")
@@ -103,7 +105,7 @@ def test_conv_igemm_reduce_temp_view(ops):
     w = rnd("rtw", Co, C, 5, 1, 1, scale=0.05)
     ref = F.relu(F.conv3d(x5, w, stride=(5, 1, 1))).squeeze(2)  # [B,Co,H,W]
     xf = x5.permute(0, 2, 3, 4, 1).reshape(B, T, H * W, C).contiguous()
-    wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(Co, -1).contiguous()
+    wp = pack_conv(w)
     got = ops.conv_igemm(xf.to(DEV), wp.to(DEV), kh=5, kw=1, stride=(5, 1), act=ops.ACT_RELU)
     assert got.shape == (B, 1, H * W, Co)
     assert rel_err(got.view(B, H, W, Co), nhwc(ref)) < 2e-5

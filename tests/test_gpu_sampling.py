@@ -1,0 +1,69 @@
+"""Sampling loops on the GPU against trajectories produced by the reference trainer / reference DPM-Solver."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import salunet_oracle as orc
+from tests._cases import CASES
+from tests.test_gpu_salunet import build
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class Top(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.decoder_net = net
+        self.audio_net = None
+        self.visual_net = None
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    x, feats, audio = orc.synth_inputs(cfg, 1, True, tag="ddim")
+    return Top(build(cfg, sd)), x.to(DEV), [f.to(DEV) for f in feats], audio.to(DEV)
+
+
+def test_sample_ddim_10_steps_matches_reference_trainer(golden_dir, tiny):
+    """Config 1 plumbing: the reference trainer's own sample_ddim, 10 steps, eta 0 (R/diffusion_trainer.py:440-480)."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    top, x, feats, audio = tiny
+    g = np.load(f"{golden_dir}/ddim_tiny_av.npz")
+    out = DiffusionSampler(top, timesteps=10, sample_type="ddim").sample_ddim(x, feats, audio)
+    ref = torch.from_numpy(g["output"])
+    assert (out.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+    assert len(feats) == 4 and feats[0].shape[2] == 8  # caller's list untouched, no deep copies needed
+
+
+def test_dpm_solver_50_nfe_matches_reference_sampler(golden_dir, tiny):
+    """49 multistep-2 steps + denoise-to-zero through the real reference sampler with the same net."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    top, x, feats, audio = tiny
+    g = np.load(f"{golden_dir}/dpm50_tiny_av.npz")
+    s = DiffusionSampler(top, timesteps=50, sample_type="dpmsolver", skip_type="logSNR", denoise=True)
+    out = s.sample_dpm_solver(x, feats, audio)
+    ref = torch.from_numpy(g["output"])
+    assert (out.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+def test_sampling_loop_has_no_host_sync(tiny):
+    """The loop must be enqueue-only: run it under a stream capture-like check by timing enqueue vs completion."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    top, x, feats, audio = tiny
+    s = DiffusionSampler(top, timesteps=10, sample_type="dpmsolver")
+    s.sample_dpm_solver(x, feats, audio)  # warm-up (weight packing, library load)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):  # capture fails on any synchronising call or host read-back
+            y = s.sample_dpm_solver(x, feats, audio)
+    g.replay()
+    torch.cuda.synchronize()
+    eager = s.sample_dpm_solver(x, feats, audio)
+    assert torch.equal(y, eager)

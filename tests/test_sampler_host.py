@@ -1,0 +1,137 @@
+"""Host-side sampler logic against vectors produced by the reference sampler (tests/golden/sampler.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from diff_sal_amd.diffusion_utils import get_beta_schedule, to_torch
+from diff_sal_amd.dpm_solver import DPM_Solver, NoiseScheduleVP, interpolate_fn, model_wrapper
+from oracle import salunet_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(f"{golden_dir}/sampler.npz")
+
+
+@pytest.fixture(scope="module")
+def ns(gold):
+    return NoiseScheduleVP("discrete", betas=to_torch(gold["betas"]))
+
+
+def test_cosine_betas_match_reference(gold):
+    b = get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)
+    assert np.array_equal(b, gold["betas"])
+    assert abs(b[0] - 4.1284e-5) < 1e-8 and b[-1] == 0.999
+    for kind in ("linear", "quad", "const", "jsd", "sigmoid"):
+        assert get_beta_schedule(kind, beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=10).shape == (10,)
+
+
+def test_noise_schedule_tables(gold, ns):
+    assert ns.total_N == int(gold["total_N"]) == 996
+    t = torch.from_numpy(gold["t_grid"])
+    assert np.allclose(ns.marginal_log_mean_coeff(t).numpy(), gold["log_alpha"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(ns.marginal_std(t).numpy(), gold["std"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(ns.marginal_lambda(t).numpy(), gold["lam"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(ns.inverse_lambda(torch.from_numpy(gold["lam"])).numpy(), gold["inv_lam"], rtol=1e-5, atol=1e-6)
+
+
+def test_interpolate_fn_extrapolates_with_outer_segments():
+    xp, yp = torch.tensor([[0.0, 1.0, 3.0]]), torch.tensor([[0.0, 2.0, 0.0]])
+    x = torch.tensor([[-1.0], [0.5], [2.0], [4.0], [1.0]])
+    assert torch.allclose(interpolate_fn(x, xp, yp).reshape(-1), torch.tensor([-2.0, 1.0, 1.0, -1.0, 2.0]))
+
+
+def toy(x, t_in, img, **kw):
+    return torch.sigmoid(0.7 * x + 0.001 * t_in.view(-1, 1, 1, 1) + img[0])
+
+
+@pytest.mark.parametrize("algo", ["dpmsolver", "dpmsolver++"])
+@pytest.mark.parametrize("skip", ["logSNR", "time_uniform"])
+def test_multistep_trajectory_matches_reference(gold, ns, algo, skip):
+    fn = model_wrapper(toy, ns, model_type="x_start", model_kwargs={}, guidance_type="uncond")
+    solver = DPM_Solver(fn, ns, algorithm_type=algo)
+    ts = solver.get_time_steps(skip, 1.0, 1.0 / ns.total_N, 49, "cpu")
+    assert np.allclose(ts.numpy(), gold[f"ts.{algo}.{skip}"], rtol=2e-5, atol=2e-6)
+    x = orc.synth_tensor("dpm.xT", (1, 1, 8, 12))
+    img = [orc.synth_tensor("dpm.img", (1, 1, 8, 12), 0.3)]
+    xe, inter = solver.sample(x, img, steps=49, order=2, skip_type=skip, method="multistep", lower_order_final=False,
+                              denoise_to_zero=True, solver_type="dpmsolver", return_intermediate=True)
+    assert len(inter) == 51  # 49 steps + initial + denoise-to-zero = 50 network evaluations (F2)
+    ref_inter = gold[f"inter.{algo}.{skip}"]
+    got = torch.stack(inter)[[0, 1, 2, 10, 25, 48, 49, 50]].numpy()
+    assert np.abs(got - ref_inter).max() < 2e-4 * np.abs(ref_inter).max()
+    assert np.abs(xe.numpy() - gold[f"x0.{algo}.{skip}"]).max() < 1e-4
+
+
+def test_nfe_count_is_50_for_49_steps(ns):
+    calls = []
+
+    def counting(x, t_in, img, **kw):
+        calls.append(float(t_in[0]))
+        return torch.zeros_like(x)
+
+    fn = model_wrapper(counting, ns, model_type="x_start")
+    DPM_Solver(fn, ns, algorithm_type="dpmsolver").sample(
+        torch.zeros(2, 1, 4, 4), None, steps=49, order=2, skip_type="logSNR", method="multistep",
+        lower_order_final=False, denoise_to_zero=True)
+    assert len(calls) == 50
+    assert abs(calls[0] - 998.996) < 1e-2 and calls[-1] == 0.0  # fractional float timesteps (F3)
+
+
+def test_few_steps_lower_order_final_noise_model(gold, ns):
+    fn = model_wrapper(lambda x, t, img, **kw: torch.tanh(0.5 * x + img[0]), ns, model_type="noise")
+    solver = DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+    x = orc.synth_tensor("dpm.xT", (2, 1, 8, 12))
+    img = [orc.synth_tensor("dpm.img", (2, 1, 8, 12), 0.3)]
+    out = solver.sample(x, img, steps=6, order=2, skip_type="time_uniform", method="multistep",
+                        lower_order_final=True, denoise_to_zero=False)
+    assert np.abs(out.numpy() - gold["x0.few"]).max() < 1e-4
+
+
+def test_x_start_wrapper_broadcasts_over_batch(ns):
+    """Reference defect D6: its x_start branch only broadcasts for batch 1; ours handles per-sample t."""
+    fn = model_wrapper(lambda x, t, img, **kw: 0.5 * x, ns, model_type="x_start")
+    x = torch.randn(3, 1, 4, 5)
+    t = torch.tensor([0.9, 0.5, 0.1])
+    out = fn(x, t, None)
+    a, s = ns.marginal_alpha(t), ns.marginal_std(t)
+    ref = (x - a.view(-1, 1, 1, 1) * 0.5 * x) / s.view(-1, 1, 1, 1)
+    assert torch.allclose(out, ref, atol=1e-6)
+
+
+def test_unbuilt_methods_raise(ns):
+    solver = DPM_Solver(lambda x, t, img=None: x, ns)
+    with pytest.raises(NotImplementedError):
+        solver.sample(torch.zeros(1, 1, 2, 2), steps=4, method="singlestep")
+
+
+def test_diffusion_sampler_tables_match_trainer(golden_dir):
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    g = np.load(f"{golden_dir}/ddim_tiny_av.npz")
+    s = DiffusionSampler(model=type("M", (), {"decoder_net": None})())
+    assert np.allclose(s.alphas_hat.numpy(), g["alphas_hat"], rtol=1e-6)
+    assert np.allclose(s.sqrt_recip_alphas_hat.numpy(), g["sqrt_recip"], rtol=1e-6)
+    assert np.allclose(s.sqrt_recipm1_alphas_hat.numpy(), g["sqrt_recipm1"], rtol=1e-5)
+    assert abs(float(s.alphas_hat[500]) - 0.49229) < 1e-4
+
+
+def test_ddim_loop_host_logic_with_toy_net():
+    """sample_ddim on CPU tensors with a closed-form x0-predictor: compare with the textbook recursion."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    net = lambda x, t, img, a: torch.sigmoid(x + 0.001 * t.float().view(-1, 1, 1, 1))  # noqa: E731
+    s = DiffusionSampler(model=type("M", (), {"decoder_net": staticmethod(net)})(), timesteps=10)
+    x = orc.synth_tensor("ddim.toy", (2, 1, 4, 6))
+    out = s.sample_ddim(x.clone(), None, None)
+    ah = s.alphas_hat
+    ref = x.clone()
+    seq = list(range(0, 1000, 100))
+    for time, nxt in zip(reversed(seq), reversed([-1] + seq[:-1])):
+        x0 = net(ref, torch.full((2,), time), None, None)
+        if nxt < 0:
+            ref = x0
+            break
+        eps = (torch.sqrt(1 / ah[time]) * ref - x0) / torch.sqrt(1 / ah[time] - 1)
+        ref = torch.sqrt(ah[nxt]) * x0 + torch.sqrt(1 - ah[nxt]) * eps
+    assert torch.allclose(out, ref, atol=1e-5)
