@@ -18,6 +18,8 @@
 //
 // Replaces the cuDNN/cuBLAS call sites behind torch.nn.Conv2d / Linear / Conv3d(k,1,1) in
 // R/models/saliency_decoder/{sal_unet,common_block,attention,transformer}.py (see diffsal.h).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace diffsal {
@@ -38,6 +40,7 @@ struct IgemmArgs {
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int act, rowvec_ld;
   int n_tiles_n, n_tiles;  // tiles along N, total tiles
+  unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
   int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
 };
@@ -45,7 +48,7 @@ struct IgemmArgs {
 constexpr int BK = 32;
 constexpr int PITCH = BK + 4;  // dwords; 36*r mod 64 hits 16 distinct 4-bank slots for 16 rows
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DBG = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -82,11 +85,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   const int n0 = tile_n * BN;
 
   // ---- loader mapping: 8 lanes cover one 32-float K slice of a row; 32 rows per pass ----
+  // Loads go through buffer descriptors: a 32-bit byte offset per row, the per-slice displacement
+  // added as a scalar, and padding taps / rows handled by the hardware range check (an offset of
+  // 0xFFFFFFFF is out of range => the load returns 0 and touches no memory).  No branches, no selects
+  // on the data: ~4 VALU per load, so the loader hides completely under the MFMAs.
   const int lrow = tid >> 3;
   const int lcol = (tid & 7) * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, static_cast<int>(p.w_bytes), 0x00020000);
 
-  int a_iy0[A_PASSES], a_ix0[A_PASSES];
-  long a_off[A_PASSES];  // element offset of (n, iy0, ix0, lcol); may point before the image, only used when in bounds
+  unsigned a_voff[A_PASSES];   // byte offset of (n, iy0, ix0, lcol); wraps for negative iy0/ix0, only used when valid
+  unsigned a_valid[A_PASSES];  // bit t: tap t of this row lies inside the image
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int j = 0; j < A_PASSES; ++j) {
@@ -96,49 +107,51 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     const int rem = m - n * HoWo;
     const int oy = rem / p.Wo;
     const int ox = rem - oy * p.Wo;
-    a_iy0[j] = oy * p.stride_h - p.pad_t;
-    a_ix0[j] = ox * p.stride_w - p.pad_l;
-    a_off[j] = (static_cast<long>(n) * p.H * p.W + static_cast<long>(a_iy0[j]) * p.W + a_ix0[j]) * p.Cin + lcol;
+    const int iy0 = oy * p.stride_h - p.pad_t;
+    const int ix0 = ox * p.stride_w - p.pad_l;
+    a_voff[j] = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + lcol) * 4u;
+    unsigned bits = 0;
+    for (int t = 0; t < p.taps; ++t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      const int iy = iy0 + ky * p.dil_h, ix = ix0 + kx * p.dil_w;
+      bits |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) ? (1u << t) : 0u;
+    }
+    a_valid[j] = bits;
   }
-  long b_off[B_PASSES];
+  unsigned b_voff[B_PASSES];
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
     int n = n0 + lrow + 32 * j;
     n = n < p.Cout ? n : p.Cout - 1;  // columns past Cout are never stored
-    b_off[j] = static_cast<long>(n) * p.K + lcol;
+    b_voff[j] = static_cast<unsigned>(n * p.K + lcol) * 4u;
   }
 
   float4 ra[A_PASSES], rb[B_PASSES];
-  unsigned a_mask = 0;  // bit j: ra[j] is a real (in-bounds) pixel, else it must read as zero
   const int kt_begin = split * p.kt_per_split;
   const int kt_end = min(p.K / BK, kt_begin + p.kt_per_split);
   const int nkt = kt_end - kt_begin;
 
-  // Branch-free: out-of-image taps and slices past the end read element 0 (always mapped) and are
-  // zeroed / ignored later, so the whole K loop stays one basic block the scheduler can interleave.
   auto issue_loads = [&](int kt, bool live) {
-    const int chunk = kt / p.taps;  // wave-uniform
+    const int chunk = kt / p.taps;  // wave-uniform (scalar unit)
     const int tap = kt - chunk * p.taps;
     const int ky = tap / p.KW;
     const int kx = tap - ky * p.KW;
-    const int dy = ky * p.dil_h, dx = kx * p.dil_w;
-    const long delta = (static_cast<long>(dy) * p.W + dx) * p.Cin + chunk * BK;
-    a_mask = 0;
+    const unsigned delta = static_cast<unsigned>((ky * p.dil_h * p.W + kx * p.dil_w) * p.Cin + chunk * BK) * 4u;
+    const unsigned dead = live ? 0u : 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
-      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-      const bool ok = live & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-      a_mask |= (ok ? 1u : 0u) << j;
-      ra[j] = ld4(p.in + (ok ? a_off[j] + delta : 0L));
+      const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;  // 0 when the tap is inside, else all ones
+      const unsigned off = (a_voff[j] + delta) | oob | dead;
+      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
     }
-    const long kofs = live ? static_cast<long>(kt) * BK : 0L;
+    const unsigned kofs = static_cast<unsigned>(kt * BK) * 4u;
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) rb[j] = ld4(p.w + (live ? b_off[j] : 0L) + kofs);
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
   };
   auto store_tile = [&](float* stage) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH + lcol], ((a_mask >> j) & 1u) ? ra[j] : z);
+    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH + lcol], ra[j]);
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
   };
@@ -156,20 +169,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   const int a_frag = (wm * TM * 32 + frow) * PITCH + fk;
   const int b_frag = (BM + wn * TN * 32 + frow) * PITCH + fk;
 
-  auto mfma_group = [&](const float* stage, int kk) {
-    float4 af[TM], bf[TN];
+  // Fragment registers are double-buffered: the ds_reads of group kk+1 are issued before the MFMAs of
+  // group kk, and the first group of the NEXT K slice is fetched behind the barrier while the last
+  // group of this slice still runs, so the matrix pipe never waits for LDS latency.
+  float4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](const float* stage, int kk, int set) {
+    if constexpr (DBG & 4) { if (kk != 0 || stage != smem) return; }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = ld4(stage + a_frag + i * 32 * PITCH + kk * 8);
+    for (int i = 0; i < TM; ++i) fa[set][i] = ld4(stage + a_frag + i * 32 * PITCH + kk * 8);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = ld4(stage + b_frag + j * 32 * PITCH + kk * 8);
+    for (int j = 0; j < TN; ++j) fb[set][j] = ld4(stage + b_frag + j * 32 * PITCH + kk * 8);
+  };
+  auto do_mfmas = [&](int set) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+        const float av = s == 0 ? fa[set][i].x : s == 1 ? fa[set][i].y : s == 2 ? fa[set][i].z : fa[set][i].w;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+          const float bv = s == 0 ? fb[set][j].x : s == 1 ? fb[set][j].y : s == 2 ? fb[set][j].z : fb[set][j].w;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
         }
       }
@@ -180,16 +199,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   store_tile(smem);
   issue_loads(kt_begin + 1, nkt > 1);
   __syncthreads();
+  load_frags(smem, 0, 0);
   for (int it = 0; it < nkt; ++it) {
     float* cur = smem + (it & 1) * STAGE;
     float* nxt = smem + ((it & 1) ^ 1) * STAGE;
-    mfma_group(cur, 0);
-    store_tile(nxt);                                    // slice it+1: registers -> other stage
-    issue_loads(kt_begin + it + 2, it + 2 < nkt);        // slice it+2: global -> registers
-    mfma_group(cur, 1);
-    mfma_group(cur, 2);
-    mfma_group(cur, 3);
+    // group 0: MFMAs on set 0; meanwhile fetch group 1, park slice it+1 in the other stage
+    load_frags(cur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    if constexpr (!(DBG & 2)) store_tile(nxt);
+    // the registers are free again: slice it+2 starts its trip now and has a whole K slice of MFMAs to land
+    if constexpr (!(DBG & 1)) issue_loads(kt_begin + it + 2, it + 2 < nkt);
+    {  // spread the LDS writes over the first half of this group's MFMAs and the buffer loads over the second
+      constexpr int NM = 4 * TM * TN, NW = A_PASSES + B_PASSES, H1 = NM / 2, PER = (NW + H1 - 1) / H1;
+#pragma unroll
+      for (int i = 0; i < H1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x200, PER, 0);  // then LDS writes
+      }
+#pragma unroll
+      for (int i = H1; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);  // then buffer loads
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // group 1: meanwhile fetch group 2
+    load_frags(cur, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // group 2: meanwhile fetch group 3
+    load_frags(cur, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // every read of `cur` and every write of `nxt` has been issued: one barrier per K slice
     __syncthreads();
+    // group 3: meanwhile fetch group 0 of the next slice
+    load_frags(nxt, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -308,13 +359,13 @@ static Plan choose_plan(long M, int Cout, int K) {
   return best;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DBG = 0>
 static int launch(IgemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, DBG>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
   int rc = check_launch("diffsal_conv_igemm");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
@@ -337,6 +388,12 @@ static int validate(const diffsal_conv_desc* d) {
   DS_REQUIRE(d->Ho > 0 && d->Wo > 0, DIFFSAL_E_SHAPE, "conv_igemm: empty output %dx%d", d->Ho, d->Wo);
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   DS_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), DIFFSAL_E_SHAPE, "conv_igemm: problem too large");
+  DS_REQUIRE(d->KH * d->KW <= 32, DIFFSAL_E_SHAPE, "conv_igemm: at most 32 taps (KH*KW=%d)", d->KH * d->KW);
+  const long in_bytes = static_cast<long>(d->N) * d->H * d->W * d->Cin * 4;
+  const long w_bytes = static_cast<long>(d->Cout) * d->KH * d->KW * d->Cin * 4;
+  DS_REQUIRE(in_bytes < (1L << 32) - 16 && w_bytes < (1L << 32) - 16, DIFFSAL_E_SHAPE,
+             "conv_igemm: input (%ld B) and weight (%ld B) must each stay below 4 GiB (32-bit buffer offsets); "
+             "split the batch", in_bytes, w_bytes);
   return DIFFSAL_OK;
 }
 
@@ -367,6 +424,8 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
+  a.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
+  a.w_bytes = static_cast<unsigned>(static_cast<long>(d->Cout) * a.K * 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   const Plan pl = choose_plan(M, d->Cout, a.K);
@@ -380,6 +439,15 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
                need, ws_bytes);
     a.partial = static_cast<float*>(ws);
   }
+#ifdef DIFFSAL_IGEMM_ABLATE
+  if (const char* e = getenv("DIFFSAL_IGEMM_DBG")) {
+    const int v = atoi(e);
+    if (pl.cfg == 2 && v == 1) return launch<4, 1, 1, 3, 1>(a, s);
+    if (pl.cfg == 2 && v == 2) return launch<4, 1, 1, 3, 2>(a, s);
+    if (pl.cfg == 2 && v == 3) return launch<4, 1, 1, 3, 3>(a, s);
+    if (pl.cfg == 2 && v == 7) return launch<4, 1, 1, 3, 7>(a, s);
+  }
+#endif
   switch (pl.cfg) {
     case 0: return launch<2, 2, 2, 3>(a, s);
     case 1: return launch<2, 2, 2, 2>(a, s);
