@@ -264,6 +264,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     }
     return;
   }
+  // Fetch every residual value of this thread's outputs BEFORE the arithmetic and the stores: they are
+  // independent loads that fly together (out must not alias residual / rowvec).
+  float res[TM][TN][16];
+  const float* __restrict__ resid = p.residual;
+  const float* __restrict__ rowv = p.rowvec;
+  float* __restrict__ outp = p.out;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + col_l;
+    const int nc = n < p.Cout ? n : p.Cout - 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + (wm * TM + i) * 32 + row_h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = mb + (r & 3) + 8 * (r >> 2);
+        m = m < p.M ? m : p.M - 1;
+        res[i][j][r] = resid ? resid[static_cast<long>(m) * p.Cout + nc] : 0.f;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + col_l;
@@ -281,13 +302,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
         float v = acc[i][j][r];
         v += bi;
         if (p.scale) v = v * sc + sh;
-        if (p.rowvec) v += p.rowvec[static_cast<long>(m / HoWo) * p.rowvec_ld + n];
+        if (rowv) v += rowv[static_cast<long>(m / HoWo) * p.rowvec_ld + n];
         if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
         else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
         else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
-        const long o = static_cast<long>(m) * p.Cout + n;
-        if (p.residual) v += p.residual[o];
-        p.out[o] = v;
+        v += res[i][j][r];
+        outp[static_cast<long>(m) * p.Cout + n] = v;
       }
     }
   }
