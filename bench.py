@@ -69,7 +69,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--mode", choices=["vis", "av"], default="vis", help="vis = BASELINE configs[1]; av = configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="host threads for the CPU baseline (32 is the fastest setting measured on the 256-core box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,7 +197,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: a few B-clip oracle evaluations (the per-step network cost dominates a trajectory)
-        nthreads = os.cpu_count() or 1
+        nthreads = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
         torch.set_num_threads(nthreads)
         xc, fc = x_T.cpu(), [f.cpu() for f in feats]
         ac = audio.cpu() if av else None
@@ -208,7 +210,8 @@ def main():
             cdt = time.perf_counter() - c0
         result["cpu_baseline"] = {
             "value": round(B * args.cpu_steps / cdt, 4), "unit": "denoise-steps/s", "cores": nthreads, "kind": "port",
-            "sample": f"{args.cpu_steps} SalUNet evaluations at batch {B} (fp32, eval, torch CPU oracle), "
+            "sample": f"{args.cpu_steps} SalUNet evaluations at batch {B} (fp32, eval, torch CPU oracle, "
+                      f"{nthreads} of {os.cpu_count()} host threads: more threads are slower), "
                       f"{cdt:.1f} s; solver update excluded (negligible)",
         }
     if rank == 0:
