@@ -195,9 +195,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     }
   };
 
+  // prologue: the loads of slices 0 and 1 are in flight together (slice 1 borrows a second register set)
+  issue_loads(kt_begin + 1, nkt > 1);
+  float4 ta[A_PASSES], tb[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) ta[j] = ra[j];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) tb[j] = rb[j];
   issue_loads(kt_begin, true);
   store_tile(smem);
-  issue_loads(kt_begin + 1, nkt > 1);
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) ra[j] = ta[j];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) rb[j] = tb[j];
   __syncthreads();
   load_frags(smem, 0, 0);
   for (int it = 0; it < nkt; ++it) {
@@ -345,33 +355,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs p) {
   }
 }
 
-struct TileCfg { int bm, bn; float eff; };
-// order must match the dispatch switch in run()
-static const TileCfg kCfgs[] = {{128, 192, 0.95f}, {128, 128, 0.95f}, {128, 96, 0.95f},
-                                {64, 128, 0.90f},  {128, 64, 0.90f},  {64, 64, 0.85f}};
+struct TileCfg { int bm, bn, occ; float eff; };  // occ = co-resident workgroups per CU (registers / LDS)
+// order must match the dispatch switch in diffsal_conv_igemm
+static const TileCfg kCfgs[] = {{128, 192, 1, 0.95f}, {128, 128, 2, 0.95f}, {128, 96, 2, 0.95f},
+                                {64, 128, 2, 0.90f},  {128, 64, 2, 0.90f},  {64, 64, 4, 0.85f}};
 constexpr int kNumCfgs = 6;
 constexpr int kCUs = 256;
 
 struct Plan { int cfg, splits; };
 
-// Pick tile shape and split-K factor with a small analytic model of an MFMA-bound grid:
-// the 256 CUs each retire whole workgroups, so time ~ ceil(workgroups / 256) * work-per-workgroup
-// (wave quantisation), plus a fixed per-workgroup cost and, for split-K, the slab round trip.
+// Pick tile shape and split-K factor with a small analytic model.  The 256 CUs each hold `occ`
+// workgroups; co-resident workgroups share the CU's matrix pipes, and every workgroup also has a
+// fixed, pipe-idle latency (prologue loads, store tail) that only the other residents can cover:
+//   round = max(occ * t_mfma, t_mfma + t_fixed),  time = ceil(workgroups / (256 occ)) * round
+// (+ the slab round trip for split-K).  Short-K GEMMs therefore prefer more, smaller residents;
+// long-K convolutions prefer the widest tile that still fills the chip.
 static Plan choose_plan(long M, int Cout, int K) {
   const double mac_per_s_cu = 157.3e12 / 2.0 / kCUs;
+  const double t_fixed = 10e-6;
   const int KT = K / BK;
   Plan best{5, 1};
   double best_t = 1e30;
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];
-    if (Cout % 32 == 0 && t.bn > Cout && t.bn - Cout >= 32 && c != 5) continue;  // mostly-empty N tile
+    if (t.bn > Cout && t.bn - Cout >= 32 && c != 5) continue;  // mostly-empty N tile
     const long tiles = ((M + t.bm - 1) / t.bm) * ((Cout + t.bn - 1) / t.bn);
     for (int S = 1; S <= 16; S *= 2) {
       if (S > 1 && (KT / S < 6 || Cout % 4 != 0)) break;
       const long wgs = tiles * S;
-      const double rounds = static_cast<double>((wgs + kCUs - 1) / kCUs);
+      const long slots = static_cast<long>(kCUs) * t.occ;
+      const double rounds = static_cast<double>((wgs + slots - 1) / slots);
       const int kt_per = (KT + S - 1) / S;
-      double tt = rounds * (static_cast<double>(t.bm) * t.bn * (kt_per * BK) / (mac_per_s_cu * t.eff) + 1.5e-6);
+      const double t_mfma = static_cast<double>(t.bm) * t.bn * (kt_per * BK) / (mac_per_s_cu * t.eff);
+      const double resident = static_cast<double>(wgs < slots ? (wgs + kCUs - 1) / kCUs : t.occ);
+      const double round = resident * t_mfma > t_mfma + t_fixed ? resident * t_mfma : t_mfma + t_fixed;
+      double tt = rounds * round;
       if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6;
       if (tt < best_t) { best_t = tt; best = Plan{c, S}; }
     }

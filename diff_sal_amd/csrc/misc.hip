@@ -190,11 +190,106 @@ struct ResizeSumArgs {
   int n_in;
 };
 
+// Patch form of the bilinear resize for integer up-scaling (the only case on the hot path: x2 in UpEmbed,
+// x2..x16 in the 4-scale sum).  One wavefront owns a 4x4 patch of output pixels (aligned to 4), lanes stride
+// the channels with float4.  A 4-aligned run of 4 outputs touches only NR = 2 (factor >= 8), 3 (factor 4) or
+// 4 (factor 2) source rows/columns, so the NR x NR source window is loaded ONCE and reused for all 16 outputs:
+// 2 loads per output instead of 16 -- the naive form is bound by L1/L2 request rate, not by HBM.
+// All coordinates / weights are wave-uniform scalars.
+template <int NR>
+__device__ __forceinline__ void patch_accumulate(const float* __restrict__ in, int n, int h, int w, int C, int Y0,
+                                                 int X0, float sy, float sx, int c, float4 (&acc)[4][4]) {
+  float wy[4][NR], wx[4][NR];
+  int ry0 = 0, rx0 = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_coord(Y0 + d, sy, h, y0, y1, ly);
+    bilin_coord(X0 + d, sx, w, x0, x1, lx);
+    if (d == 0) { ry0 = y0; rx0 = x0; }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      wy[d][i] = (ry0 + i == y0 ? 1.f - ly : 0.f) + (ry0 + i == y1 ? ly : 0.f);
+      wx[d][i] = (rx0 + i == x0 ? 1.f - lx : 0.f) + (rx0 + i == x1 ? lx : 0.f);
+    }
+  }
+  float4 win[NR][NR];
+  const float* base = in + static_cast<long>(n) * h * w * C + c;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int yy = min(ry0 + i, h - 1);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int xx = min(rx0 + k, w - 1);
+      win[i][k] = ld4(base + (static_cast<long>(yy) * w + xx) * C);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float4 tmp[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      float4 t = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        t.x = fmaf(wy[d][i], win[i][k].x, t.x); t.y = fmaf(wy[d][i], win[i][k].y, t.y);
+        t.z = fmaf(wy[d][i], win[i][k].z, t.z); t.w = fmaf(wy[d][i], win[i][k].w, t.w);
+      }
+      tmp[k] = t;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float4 r = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        r.x = fmaf(wx[e][k], tmp[k].x, r.x); r.y = fmaf(wx[e][k], tmp[k].y, r.y);
+        r.z = fmaf(wx[e][k], tmp[k].z, r.z); r.w = fmaf(wx[e][k], tmp[k].w, r.w);
+      }
+      acc[d][e].x += r.x; acc[d][e].y += r.y; acc[d][e].z += r.z; acc[d][e].w += r.w;
+    }
+  }
+}
+
 // out = ((in0^ + in1^) + in2^) + in3^, x^ = bilinear resize of x to (H, W): one write of the big map.
-// One workgroup = 4 neighbouring output pixels of one row, one wavefront per pixel: all source
-// coordinates and weights are wave-uniform (scalar registers), lanes stride the channels with float4.
+// Requires H, W multiples of 4 and every input an integer factor (2, 4, 8, ...) smaller; n_in = 1 is the
+// plain resize.  R/.../sal_unet.py:482-487, common_block.py:197.
 __global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float* __restrict__ out, int H, int W, int C,
-                                                         int w_tiles) {
+                                                         int w_patches, long n_patches) {
+  const int lane = threadIdx.x & 63;
+  const long patch = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (patch >= n_patches) return;
+  const int px = static_cast<int>(patch % w_patches);
+  const long t = patch / w_patches;
+  const int py = static_cast<int>(t % (H >> 2));
+  const int n = static_cast<int>(t / (H >> 2));
+  const int Y0 = __builtin_amdgcn_readfirstlane(py * 4), X0 = __builtin_amdgcn_readfirstlane(px * 4);
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 acc[4][4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[d][e] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < a.n_in) {
+        const int f = H / a.h[s];  // wave-uniform
+        if (f >= 8) patch_accumulate<2>(a.in[s], n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
+        else if (f == 4) patch_accumulate<3>(a.in[s], n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
+        else patch_accumulate<4>(a.in[s], n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        st4(out + ((static_cast<long>(n) * H + Y0 + d) * W + X0 + e) * C + c, acc[d][e]);
+  }
+}
+
+// General fallback (any sizes): one wavefront per output pixel.
+__global__ __launch_bounds__(256) void resize_sum_generic_kernel(ResizeSumArgs a, float* __restrict__ out, int H, int W,
+                                                                 int C, int w_tiles) {
   int bid = blockIdx.x;
   const int xt = bid % w_tiles; bid /= w_tiles;
   const int Y = bid % H;
@@ -202,38 +297,27 @@ __global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float*
   const int lane = threadIdx.x & 63;
   const int X = __builtin_amdgcn_readfirstlane(xt * 4 + (threadIdx.x >> 6));
   if (X >= W) return;
-  const float* p00[4]; const float* p01[4]; const float* p10[4]; const float* p11[4];
-  float w00[4], w01[4], w10[4], w11[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s < a.n_in) {
-      const int h = a.h[s], w = a.w[s];
-      int y0, y1, x0, x1;
-      float ly, lx;
-      bilin_coord(Y, a.sy[s], h, y0, y1, ly);
-      bilin_coord(X, a.sx[s], w, x0, x1, lx);
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      const float* b = a.in[s] + static_cast<long>(n) * h * w * C;
-      p00[s] = b + (static_cast<long>(y0) * w + x0) * C; p01[s] = b + (static_cast<long>(y0) * w + x1) * C;
-      p10[s] = b + (static_cast<long>(y1) * w + x0) * C; p11[s] = b + (static_cast<long>(y1) * w + x1) * C;
-      w00[s] = hx; w01[s] = lx; w10[s] = hy; w11[s] = ly;
-    }
-  }
-  float* orow = out + ((static_cast<long>(n) * H + Y) * W + X) * C;
   for (int c = lane * 4; c < C; c += 256) {
     float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s < a.n_in) {
-        const float4 v00 = ld4(p00[s] + c), v01 = ld4(p01[s] + c), v10 = ld4(p10[s] + c), v11 = ld4(p11[s] + c);
-        const float hx = w00[s], lx = w01[s], hy = w10[s], ly = w11[s];
+        const int h = a.h[s], w = a.w[s];
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_coord(Y, a.sy[s], h, y0, y1, ly);
+        bilin_coord(X, a.sx[s], w, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* b = a.in[s] + static_cast<long>(n) * h * w * C + c;
+        const float4 v00 = ld4(b + (static_cast<long>(y0) * w + x0) * C), v01 = ld4(b + (static_cast<long>(y0) * w + x1) * C);
+        const float4 v10 = ld4(b + (static_cast<long>(y1) * w + x0) * C), v11 = ld4(b + (static_cast<long>(y1) * w + x1) * C);
         acc.x += hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
         acc.y += hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
         acc.z += hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
         acc.w += hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
       }
     }
-    st4(orow + c, acc);
+    st4(out + ((static_cast<long>(n) * H + Y) * W + X) * C + c, acc);
   }
 }
 
@@ -478,7 +562,17 @@ extern "C" int diffsal_resize_bilinear(const float* in, float* out, int N, int h
   DS_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, DIFFSAL_E_SHAPE, "resize_bilinear: bad shape");
   const float sy = static_cast<float>(h) / static_cast<float>(H), sx = static_cast<float>(w) / static_cast<float>(W);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (C % 4 == 0 && aligned16(in) && aligned16(out)) {
+  const int f = H / h;
+  // x2 is cheaper with one thread per output (4 loads, mostly L1 hits); the patch form pays from x4 up
+  if (C % 4 == 0 && aligned16(in) && aligned16(out) && H % 4 == 0 && W % 4 == 0 && f >= 4 && (f & (f - 1)) == 0 &&
+      h * f == H && w * f == W) {
+    ResizeSumArgs a;
+    a.n_in = 1;
+    for (int i = 0; i < 4; ++i) { a.in[i] = in; a.h[i] = h; a.w[i] = w; a.sy[i] = sy; a.sx[i] = sx; }
+    const long n_patches = static_cast<long>(N) * (H / 4) * (W / 4);
+    hipLaunchKernelGGL(resize_sum_kernel, dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a, out, H, W, C,
+                       W / 4, n_patches);
+  } else if (C % 4 == 0 && aligned16(in) && aligned16(out)) {
     const long total = static_cast<long>(N) * H * W * (C / 4);
     hipLaunchKernelGGL((resize_kernel<4>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
   } else {
@@ -504,11 +598,23 @@ extern "C" int diffsal_resize_sum(const float* const* ins, const int* hs, const 
     if (i < n_in) DS_REQUIRE(ins[i] && aligned16(ins[i]) && hs[i] > 0 && ws[i] > 0, DIFFSAL_E_ARG, "resize_sum: bad input %d", i);
   }
   DS_REQUIRE(aligned16(out), DIFFSAL_E_ALIGN, "resize_sum: misaligned output");
-  const int w_tiles = (W + 3) / 4;
-  const long blocks = static_cast<long>(N) * H * w_tiles;
-  DS_REQUIRE(blocks < (1L << 31), DIFFSAL_E_SHAPE, "resize_sum: output too large");
-  hipLaunchKernelGGL(resize_sum_kernel, dim3(static_cast<int>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
-                     out, H, W, C, w_tiles);
+  bool patchable = (H % 4 == 0) && (W % 4 == 0);
+  for (int i = 0; i < n_in; ++i) {
+    const int f = H / hs[i];
+    patchable = patchable && f >= 2 && (f & (f - 1)) == 0 && hs[i] * f == H && ws[i] * f == W;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (patchable) {
+    const long n_patches = static_cast<long>(N) * (H / 4) * (W / 4);
+    hipLaunchKernelGGL(resize_sum_kernel, dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a, out, H, W, C,
+                       W / 4, n_patches);
+  } else {
+    const int w_tiles = (W + 3) / 4;
+    const long blocks = static_cast<long>(N) * H * w_tiles;
+    DS_REQUIRE(blocks < (1L << 31), DIFFSAL_E_SHAPE, "resize_sum: output too large");
+    hipLaunchKernelGGL(resize_sum_generic_kernel, dim3(static_cast<int>(blocks)), dim3(256), 0, s, a, out, H, W, C,
+                       w_tiles);
+  }
   return check_launch("resize_sum");
 }
 
