@@ -43,6 +43,7 @@ struct IgemmArgs {
   unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
   int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
+  int dbg;                   // ablation switches (env DIFFSAL_IGEMM_DBG), 0 in production
 };
 
 constexpr int BK = 32;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     const int ky = tap / p.KW;
     const int kx = tap - ky * p.KW;
     const unsigned delta = static_cast<unsigned>((ky * p.dil_h * p.W + kx * p.dil_w) * p.Cin + chunk * BK) * 4u;
-    const unsigned dead = live ? 0u : 0xFFFFFFFFu;
+    const unsigned dead = (live && !(p.dbg & 1)) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
       const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;  // 0 when the tap is inside, else all ones
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
         else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
         else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
         v += res[i][j][r];
-        outp[static_cast<long>(m) * p.Cout + n] = v;
+        if (!(p.dbg & 2)) outp[static_cast<long>(m) * p.Cout + n] = v;
       }
     }
   }
@@ -470,6 +471,7 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.splits = pl.splits;
   a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;
   a.partial = nullptr;
+  { const char* e = getenv("DIFFSAL_IGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   if (pl.splits > 1) {
     const size_t need = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
     DS_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && aligned16(out), DIFFSAL_E_ARG,

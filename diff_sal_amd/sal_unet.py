@@ -329,10 +329,29 @@ class SalUNet(nn.Module):
         x2 = ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1)
         return x2.view(B, T, H, W, C)
 
+    # Largest batch evaluated in one pass.  The 4-scale sum [B,112,192,768] fp32 is 66 MB per clip and the
+    # implicit-GEMM loader addresses each operand with 32-bit byte offsets (< 4 GiB): larger batches
+    # (BASELINE config 5 uses 64 clips per GPU) are evaluated in chunks; clips are independent in eval mode.
+    max_clips_per_pass = 16
+
     def forward(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor] = None,
                 taps: Optional[dict] = None) -> Tensor:
         """x [B,1,H,W], t [B] (int64 or float), feat_list: 4 x [B,C_i,Tv,h_i,w_i] coarsest first,
         audio_feat_list: [B,512,Tv+1,h_0,w_0] or None  ->  [B,1,img_H,img_W] in (0,1)."""
+        B = x.shape[0]
+        if B == 0:
+            return x.new_empty((0, 1, self.img_size[0], self.img_size[1]))
+        if B > self.max_clips_per_pass and taps is None:
+            outs = []
+            for s in range(0, B, self.max_clips_per_pass):
+                e = min(B, s + self.max_clips_per_pass)
+                outs.append(self._forward_pass(x[s:e], t[s:e], [f[s:e] for f in feat_list],
+                                               None if audio_feat_list is None else audio_feat_list[s:e], None))
+            return torch.cat(outs, dim=0)
+        return self._forward_pass(x, t, feat_list, audio_feat_list, taps)
+
+    def _forward_pass(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor],
+                      taps: Optional[dict]) -> Tensor:
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("diff_sal_amd.SalUNet: the HIP path implements the eval-mode forward only "
                                "(BatchNorm running statistics, no dropout); call .eval() / torch.no_grad()")

@@ -92,3 +92,44 @@ def test_cpu_input_is_rejected():
     x, feats, _ = orc.synth_inputs(cfg, 1, False)
     with pytest.raises(RuntimeError, match="GPU only"):
         net(x, torch.tensor([1]), feats)
+
+
+def test_ragged_and_chunked_batches():
+    """Batches that are not a multiple of the internal pass size are split and re-joined; empty batch -> empty."""
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    net = build(cfg, sd)
+    x, feats, audio = orc.synth_inputs(cfg, 5, True, tag="ragged")
+    xd, fd, ad = x.to(DEV), [f.to(DEV) for f in feats], audio.to(DEV)
+    t = torch.tensor([1, 200, 400, 600, 999], device=DEV)
+    with torch.no_grad():
+        whole = net(xd, t, fd, ad)
+        net.max_clips_per_pass = 2  # force 2 + 2 + 1
+        chunked = net(xd, t, fd, ad)
+        empty = net(xd[:0], t[:0], [f[:0] for f in fd], ad[:0])
+    assert chunked.shape == whole.shape and (chunked - whole).abs().max().item() < 1e-5
+    assert empty.shape == (0, 1, 64, 128)
+
+
+def test_image_based_false_uses_eight_frames():
+    """image_based=False (the class default): the noise maps are not appended, T stays 8 (sal_unet.py:311)."""
+    from diff_sal_amd.sal_unet import SalUNet
+
+    cfg = CASES["tiny_vis"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    kw = dict(img_size=cfg.img_size, frames_len=1, mid_num_stages=4, temporal_size=9, temporal_list=[5] * 4,
+              futr_num_stages=0, ori_embed_dim=256, down_embed_dim=32, idx_to_planes={0: 32, 1: 192, 2: 384, 3: 256},
+              patch_size=[0, 3, 3, 3], patch_stride=[0, 1, 1, 1], patch_padding=[0, 2, 2, 2],
+              up_channel=[256, 128, 64, 32], num_heads=[2] * 4, mlp_ratio=[2.0] * 4, drop_path_rate=[0.15] * 4,
+              qkv_bias=[True] * 4, kv_proj_method=["avg"] * 4, kernel_kv=[2, 4, 8, 16], padding_kv=[0] * 4,
+              stride_kv=[2, 4, 8, 16], q_proj_method=["dw_bn"] * 4, kernel_q=[3] * 4, padding_q=[1] * 4,
+              stride_q=[1] * 4)
+    net = SalUNet(image_based=False, **kw)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    x, feats, _ = orc.synth_inputs(cfg, 2, False, tag="ib0")
+    cfg0 = orc.SalUNetConfig(**{**cfg.__dict__, "image_based": False})
+    with torch.no_grad():
+        ref = orc.salunet_forward(sd, cfg0, x, torch.tensor([5, 50]), feats, None)
+        out = net(x.to(DEV), torch.tensor([5, 50], device=DEV), [f.to(DEV) for f in feats], None)
+    assert (out.cpu() - ref).abs().max().item() < RTOL * ref.abs().max().item()
