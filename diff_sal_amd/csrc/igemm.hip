@@ -24,6 +24,10 @@
 
 namespace diffsal {
 
+// lin_stream.hip: barrier-free streaming kernel for short-K, huge-M linear layers
+int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
+                      int K, int N, int act, hipStream_t s);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct IgemmArgs {
@@ -467,6 +471,12 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.w_bytes = static_cast<unsigned>(static_cast<long>(d->Cout) * a.K * 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
+  if (d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
+      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) &&
+      !getenv("DIFFSAL_NO_STREAM")) {
+    const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
+    if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+  }
   const Plan pl = choose_plan(M, d->Cout, a.K);
   a.splits = pl.splits;
   a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;

@@ -98,6 +98,22 @@ def test_linear_matches_torch(ops, M, K, N, act):
     assert rel_err(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("K,N,act,res", [(96, 96, 0, True), (96, 96, 0, False), (96, 192, 2, False), (192, 96, 0, True),
+                                         (96, 192, 1, True)])
+def test_streaming_short_k_linear(ops, K, N, act, res):
+    """M >= 16384 rows with K, N in {96, 192} take the barrier-free streaming kernel (lin_stream.hip);
+    M is deliberately not a multiple of the 32-row wave tile."""
+    M = 20011
+    x, w, b = rnd("sx%d" % K, M, K), rnd("sw%d%d" % (K, N), N, K, scale=K ** -0.5), rnd("sb", N, scale=0.1)
+    r = rnd("sr", M, N) if res else None
+    ref = F.linear(x, w, b)
+    ref = F.gelu(ref) if act == 2 else (F.relu(ref) if act == 1 else ref)
+    if res:
+        ref = ref + r
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act, residual=None if r is None else r.to(DEV))
+    assert rel_err(got, ref) < 2e-5
+
+
 def test_conv_igemm_reduce_temp_view(ops):
     """Conv3d (5,1,1)/5 over frames == a (5x1)-tap conv on the [B, T, H*W, C] view (quirk Q10)."""
     B, T, H, W, C, Co = 2, 9, 6, 10, 64, 96
