@@ -18,8 +18,6 @@
 //
 // Replaces the cuDNN/cuBLAS call sites behind torch.nn.Conv2d / Linear / Conv3d(k,1,1) in
 // R/models/saliency_decoder/{sal_unet,common_block,attention,transformer}.py (see diffsal.h).
-#include <cstdlib>
-
 #include "common.h"
 
 namespace diffsal {
@@ -47,13 +45,12 @@ struct IgemmArgs {
   unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
   int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
-  int dbg;                   // ablation switches (env DIFFSAL_IGEMM_DBG), 0 in production
 };
 
 constexpr int BK = 32;
 constexpr int PITCH = BK + 4;  // dwords; 36*r mod 64 hits 16 distinct 4-bank slots for 16 rows
 
-template <int WM, int WN, int TM, int TN, int DBG = 0>
+template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -142,7 +139,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     const int ky = tap / p.KW;
     const int kx = tap - ky * p.KW;
     const unsigned delta = static_cast<unsigned>((ky * p.dil_h * p.W + kx * p.dil_w) * p.Cin + chunk * BK) * 4u;
-    const unsigned dead = (live && !(p.dbg & 1)) ? 0u : 0xFFFFFFFFu;
+    const unsigned dead = live ? 0u : 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
       const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;  // 0 when the tap is inside, else all ones
@@ -179,7 +176,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   // group of this slice still runs, so the matrix pipe never waits for LDS latency.
   float4 fa[2][TM], fb[2][TN];
   auto load_frags = [&](const float* stage, int kk, int set) {
-    if constexpr (DBG & 4) { if (kk != 0 || stage != smem) return; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[set][i] = ld4(stage + a_frag + i * 32 * PITCH + kk * 8);
 #pragma unroll
@@ -222,9 +218,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     load_frags(cur, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     do_mfmas(0);
-    if constexpr (!(DBG & 2)) store_tile(nxt);
+    store_tile(nxt);
     // the registers are free again: slice it+2 starts its trip now and has a whole K slice of MFMAs to land
-    if constexpr (!(DBG & 1)) issue_loads(kt_begin + it + 2, it + 2 < nkt);
+    issue_loads(kt_begin + it + 2, it + 2 < nkt);
     {  // spread the LDS writes over the first half of this group's MFMAs and the buffer loads over the second
       constexpr int NM = 4 * TM * TN, NW = A_PASSES + B_PASSES, H1 = NM / 2, PER = (NW + H1 - 1) / H1;
 #pragma unroll
@@ -322,7 +318,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
         else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
         else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
         v += res[i][j][r];
-        if (!(p.dbg & 2)) outp[static_cast<long>(m) * p.Cout + n] = v;
+        outp[static_cast<long>(m) * p.Cout + n] = v;
       }
     }
   }
@@ -364,7 +360,7 @@ struct TileCfg { int bm, bn, occ; float eff; };  // occ = co-resident workgroups
 // order must match the dispatch switch in diffsal_conv_igemm
 static const TileCfg kCfgs[] = {{128, 192, 1, 0.95f}, {128, 128, 2, 0.95f}, {128, 96, 2, 0.95f},
                                 {64, 128, 2, 0.90f},  {128, 64, 2, 0.90f},  {64, 64, 4, 0.85f}};
-constexpr int kNumCfgs = 6;
+constexpr int kNumCfgs = 6;  // (a 256x96 tile with 64x96 per wave and one wave per SIMD measured 5-20 % slower)
 constexpr int kCUs = 256;
 
 struct Plan { int cfg, splits; };
@@ -402,13 +398,13 @@ static Plan choose_plan(long M, int Cout, int K) {
   return best;
 }
 
-template <int WM, int WN, int TM, int TN, int DBG = 0>
+template <int WM, int WN, int TM, int TN>
 static int launch(IgemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, DBG>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
   int rc = check_launch("diffsal_conv_igemm");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
@@ -472,8 +468,7 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   if (d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
-      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) &&
-      !getenv("DIFFSAL_NO_STREAM")) {
+      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual))) {
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
@@ -481,7 +476,6 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.splits = pl.splits;
   a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;
   a.partial = nullptr;
-  { const char* e = getenv("DIFFSAL_IGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   if (pl.splits > 1) {
     const size_t need = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
     DS_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && aligned16(out), DIFFSAL_E_ARG,
@@ -489,15 +483,6 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
                need, ws_bytes);
     a.partial = static_cast<float*>(ws);
   }
-#ifdef DIFFSAL_IGEMM_ABLATE
-  if (const char* e = getenv("DIFFSAL_IGEMM_DBG")) {
-    const int v = atoi(e);
-    if (pl.cfg == 2 && v == 1) return launch<4, 1, 1, 3, 1>(a, s);
-    if (pl.cfg == 2 && v == 2) return launch<4, 1, 1, 3, 2>(a, s);
-    if (pl.cfg == 2 && v == 3) return launch<4, 1, 1, 3, 3>(a, s);
-    if (pl.cfg == 2 && v == 7) return launch<4, 1, 1, 3, 7>(a, s);
-  }
-#endif
   switch (pl.cfg) {
     case 0: return launch<2, 2, 2, 3>(a, s);
     case 1: return launch<2, 2, 2, 2>(a, s);

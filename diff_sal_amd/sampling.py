@@ -27,7 +27,8 @@ class DiffusionSampler:
     def __init__(self, model, *, beta_schedule="cosine", beta_start=1e-4, beta_end=0.02,
                  num_diffusion_timesteps=1000, training_target="x0", sample_type="ddim", timesteps=1, eta=0.0,
                  skip_type="logSNR", dpm_solver_order=2, dpm_solver_method="multistep", dpm_solver_type="dpmsolver",
-                 lower_order_final=False, denoise=True, thresholding=False, device=None):
+                 lower_order_final=False, denoise=True, thresholding=False, device=None, hip_graph=False,
+                 step_invariant_shortcut=False):
         """``model`` exposes ``decoder_net`` and optionally ``visual_net`` / ``audio_net`` / ``forward_vggish``
         (a ``VideoSaliencyModel``; a DDP/DataParallel wrapper is unwrapped through ``.module``).
         Keyword names = the YAML fields the trainer reads (R/cfgs/diffusion.yml:24-28, 37, 63-78)."""
@@ -50,6 +51,15 @@ class DiffusionSampler:
         self.sqrt_recipm1_alphas_hat = torch.sqrt(1.0 / alphas_hat - 1)
         self.num_timesteps = betas.shape[0]
         self.device = device
+        # Optional modes, both OFF by default and reported separately from the headline metric:
+        #  hip_graph: capture one whole sampling trajectory per input shape in a HIP graph and replay it
+        #    (the loop is enqueue-only, so it is capturable); removes host launch cost at small batch.
+        #  step_invariant_shortcut: in visual-only eval mode the denoiser output does not depend on (x, t)
+        #    (the noise map is frame 8 of 9, ReduceTemp reads frames 0-4), so every step of a
+        #    trajectory returns the same x0 and the sample equals ONE network evaluation.
+        self.hip_graph = bool(hip_graph)
+        self.step_invariant_shortcut = bool(step_invariant_shortcut)
+        self._graphs = {}
 
     # ---- forward process (training side, K16) ----
     def q_sample(self, x_start: Tensor, t: int, noise: Optional[Tensor] = None) -> Tensor:
@@ -62,8 +72,43 @@ class DiffusionSampler:
         return _lincomb(x_t, r / rm1, x0, -1.0 / rm1)
 
     # ---- DDIM (the reference's live sampler) ----
+    def _shortcut(self, x, img, audio_cond):
+        net = self.model.decoder_net
+        t = torch.full((x.size(0),), self.num_timesteps - 1, dtype=torch.int64, device=x.device)
+        return net(x, t, img, None)
+
+    def _graphed(self, fn, x, img, audio_cond):
+        """Replay (capturing on first use) ``fn(x, img, audio_cond)`` as one HIP graph per input signature."""
+        key = (fn.__name__, tuple(x.shape), tuple(tuple(f.shape) for f in img), None if audio_cond is None else tuple(audio_cond.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx, simg = x.clone(), [f.clone() for f in img]
+            sa = None if audio_cond is None else audio_cond.clone()
+            fn(sx, simg, sa)  # warm-up outside capture: library load, weight packing, allocator pools
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn(sx, simg, sa)
+            ent = (g, sx, simg, sa, out)
+            self._graphs[key] = ent
+        g, sx, simg, sa, out = ent
+        sx.copy_(x)
+        for d, s_ in zip(simg, img):
+            d.copy_(s_)
+        if sa is not None:
+            sa.copy_(audio_cond)
+        g.replay()
+        return out.clone()
+
     @torch.no_grad()
     def sample_ddim(self, x: Tensor, img: Optional[Sequence[Tensor]] = None, audio_cond: Optional[Tensor] = None) -> Tensor:
+        if self.step_invariant_shortcut and audio_cond is None:
+            return self._shortcut(x, img, audio_cond)
+        if self.hip_graph and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            return self._graphed(self._sample_ddim, x, img, audio_cond)
+        return self._sample_ddim(x, img, audio_cond)
+
+    def _sample_ddim(self, x, img, audio_cond):
         skip = self.num_timesteps // self.timesteps
         seq = list(range(0, self.num_timesteps, skip))
         seq_next = [-1] + seq[:-1]
@@ -94,6 +139,13 @@ class DiffusionSampler:
     # ---- DPM-Solver (the path the reference intended, with D1-D4 fixed) ----
     @torch.no_grad()
     def sample_dpm_solver(self, x: Tensor, img=None, audio_cond: Optional[Tensor] = None) -> Tensor:
+        if self.step_invariant_shortcut and audio_cond is None:
+            return self._shortcut(x, img, audio_cond)
+        if self.hip_graph and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            return self._graphed(self._sample_dpm_solver, x, img, audio_cond)
+        return self._sample_dpm_solver(x, img, audio_cond)
+
+    def _sample_dpm_solver(self, x, img, audio_cond):
         net = self.model.decoder_net
 
         def model_fn(x, t, vis_feat, **kw):

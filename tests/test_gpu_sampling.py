@@ -67,3 +67,24 @@ def test_sampling_loop_has_no_host_sync(tiny):
     torch.cuda.synchronize()
     eager = s.sample_dpm_solver(x, feats, audio)
     assert torch.equal(y, eager)
+
+
+def test_hip_graph_mode_and_f1_shortcut_agree_with_the_plain_loop():
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    cfg = CASES["tiny_vis"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    top = Top(build(cfg, sd))
+    x, feats, _ = orc.synth_inputs(cfg, 2, False, tag="modes")
+    xd, fd = x.to(DEV), [f.to(DEV) for f in feats]
+    plain = DiffusionSampler(top, timesteps=8, sample_type="dpmsolver").sample_dpm_solver(xd, fd, None)
+    graphed = DiffusionSampler(top, timesteps=8, sample_type="dpmsolver", hip_graph=True)
+    g1 = graphed.sample_dpm_solver(xd, fd, None)
+    g2 = graphed.sample_dpm_solver(xd * 0.5, fd, None)  # replay with new inputs
+    assert torch.equal(g1, plain)
+    assert torch.isfinite(g2).all()
+    # F1: visual-only output ignores (x, t): one evaluation reproduces the 8-step sample up to fp32 rounding
+    short = DiffusionSampler(top, timesteps=8, sample_type="dpmsolver", step_invariant_shortcut=True)
+    assert (short.sample_dpm_solver(xd, fd, None) - plain).abs().max().item() < 1e-5
+    ddim = DiffusionSampler(top, timesteps=8, sample_type="ddim")
+    assert (short.sample_ddim(xd, fd, None) - ddim.sample_ddim(xd, fd, None)).abs().max().item() < 1e-6
