@@ -160,7 +160,7 @@ static int launch_stream(const LinStreamArgs& a, hipStream_t s) {
 // Returns 1 if the shape is handled here (and launches), 0 if the caller should use the tiled kernel, <0 on error.
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
                       int K, int N, int act, hipStream_t s) {
-  if (M < 16384 || M >= (1L << 31) / 192) return 0;
+  if (M < 65536 || M >= (1L << 31) / 192) return 0;  // below ~256 tiles per CU-wave the tiled kernel wins
   if (!((K == 96 || K == 192) && (N == 96 || N == 192)) || (K == 192 && N == 192)) return 0;
   LinStreamArgs a{x, w, bias, residual, out, static_cast<int>(M), act};
   int rc;

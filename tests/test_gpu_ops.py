@@ -101,9 +101,9 @@ def test_linear_matches_torch(ops, M, K, N, act):
 @pytest.mark.parametrize("K,N,act,res", [(96, 96, 0, True), (96, 96, 0, False), (96, 192, 2, False), (192, 96, 0, True),
                                          (96, 192, 1, True)])
 def test_streaming_short_k_linear(ops, K, N, act, res):
-    """M >= 16384 rows with K, N in {96, 192} take the barrier-free streaming kernel (lin_stream.hip);
+    """M >= 65536 rows with K, N in {96, 192} take the barrier-free streaming kernel (lin_stream.hip);
     M is deliberately not a multiple of the 32-row wave tile."""
-    M = 20011
+    M = 70003
     x, w, b = rnd("sx%d" % K, M, K), rnd("sw%d%d" % (K, N), N, K, scale=K ** -0.5), rnd("sb", N, scale=0.1)
     r = rnd("sr", M, N) if res else None
     ref = F.linear(x, w, b)
