@@ -34,6 +34,10 @@ SIGNATURES = {
     "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_f]),
     "diffsal_conv_igemm_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
+    "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
+    "diffsal_colsum": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
+    "diffsal_act_bwd": (c_i, [c_f, c_f, c_f, c_sz, c_i, c_f]),
     "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -98,6 +98,15 @@ def pack_conv_weight(w: Tensor) -> Tensor:
             .reshape(co, kh * kw * ci).contiguous())
 
 
+def pack_conv_weight_diff(w: Tensor) -> Tensor:
+    """pack_conv_weight that stays on the autograd tape (pure permutes/reshapes): dW flows back to ``w``."""
+    if w.dim() == 5:
+        w = w[:, :, :, 0, 0].unsqueeze(-1)
+    co, ci, kh, kw = w.shape
+    return (w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3)
+            .reshape(co, kh * kw * ci).contiguous())
+
+
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
                out_hw: Optional[Sequence[int]] = None, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None,
@@ -246,3 +255,44 @@ def axpbypcz(x: Tensor, a: float, y: Optional[Tensor] = None, b: float = 0.0, z:
     _lib.check(lib.diffsal_axpbypcz(_p(x), _p(y), _p(z), float(a), float(b), float(c), _p(out), x.numel(), _stream()),
                "axpbypcz")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# training-side kernels
+# ------------------------------------------------------------------------------------------------
+def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1)) -> Tensor:
+    """dW in the packed layout [Cout, kh*kw*Cin] for the conv  y = conv_igemm(x, w_packed, ...).  x NHWC, dy NHWC."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 0, 0)
+    nws = lib.diffsal_conv_wgrad_ws_bytes(C.byref(d))
+    ws = torch.empty((nws // 4,), device=x.device, dtype=torch.float32)
+    dw = torch.empty((Cout, kh * kw * Cin), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), nws, _stream()), "conv_wgrad")
+    return dw
+
+
+def colsum(dy: Tensor, seg_rows: Optional[int] = None) -> Tensor:
+    """Column sums of dy [M, C] per segment of seg_rows rows -> [M // seg_rows, C] (one segment: [1, C])."""
+    lib = _lib.load()
+    Cc = dy.shape[-1]
+    M = dy.numel() // Cc
+    seg = M if seg_rows is None else seg_rows
+    out = torch.empty((M // seg, Cc), device=dy.device, dtype=torch.float32)
+    nws = (M // seg) * 64 * Cc * 4
+    ws = torch.empty((nws // 4,), device=dy.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_colsum(_p(dy), _p(out), M, Cc, seg, _p(ws), nws, _stream()), "colsum")
+    return out
+
+
+def act_bwd(dy: Tensor, ref: Tensor, mode: int) -> Tensor:
+    """dy * act'(.): mode 1 ReLU (ref = y), 2 GELU (ref = pre-activation), 3 sigmoid (ref = y)."""
+    lib = _lib.load()
+    dx = torch.empty_like(dy)
+    _lib.check(lib.diffsal_act_bwd(_p(dy), _p(ref), _p(dx), dy.numel(), mode, _stream()), "act_bwd")
+    return dx
+
+
+def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
+    return act_bwd(dy, y, 1)

@@ -89,6 +89,21 @@ int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, con
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
                        const float* residual, float* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 
+/* ---- K16 (training): weight gradient of the layer above, in the SAME packed layout as `w`:
+ * dw[co, k] = sum_m dy[m, co] * A[m, k].  Replaces the wgrad of autograd's conv / linear backward.
+ * ws: >= diffsal_conv_wgrad_ws_bytes(d) bytes (partial slabs, summed in a fixed order).  Cout % 4 == 0. */
+size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d /*host*/);
+int diffsal_conv_wgrad(const diffsal_conv_desc* d /*host*/, const float* in, const float* dy, float* dw_packed,
+                       void* ws, size_t ws_bytes, diffsal_stream_t stream);
+/* out[g, c] = sum of dy[m, c] over the rows of segment g (M / seg_rows segments): bias gradients (one segment)
+ * and per-image vector gradients (one segment per image).  ws: >= (M/seg_rows) * 64 * C * 4 bytes. */
+int diffsal_colsum(const float* dy, float* out, int M, int C, int seg_rows, void* ws, size_t ws_bytes,
+                   diffsal_stream_t stream);
+
+/* dx = dy * act'(.): mode 1 ReLU (ref = output y), 2 GELU-erf (ref = pre-activation), 3 sigmoid (ref = output y).
+ * Backward of the activations fused into the forward epilogues / nn.GELU (common_block.py:137). n % 4 == 0. */
+int diffsal_act_bwd(const float* dy, const float* ref, float* dx, size_t n, int mode, diffsal_stream_t stream);
+
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
  * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,
