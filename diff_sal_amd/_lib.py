@@ -38,6 +38,13 @@ SIGNATURES = {
     "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_colsum": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "diffsal_act_bwd": (c_i, [c_f, c_f, c_f, c_sz, c_i, c_f]),
+    "diffsal_rowstats_chunks": (c_i, [c_i, c_i]),
+    "diffsal_rowstats": (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_affine_act": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_norm_bwd_apply": (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_layernorm_bwd_blocks": (c_i, [c_i, c_i]),
+    "diffsal_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),
+    "diffsal_dropout": (c_i, [c_f, c_f, c_sz, c_fl, C.c_uint64, c_f]),
     "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -87,3 +87,165 @@ def linear(x, w, bias=None, *, residual=None, act=ACT_NONE):
     y = conv(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, w_dgrad=wd,
              residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
     return y.reshape(*lead, w.shape[0])
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dim; backward recomputes the row statistics in registers."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma)
+        return ops.layernorm(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps)
+        return dx, dg, db, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class GroupNormSwishFn(torch.autograd.Function):
+    """swish(GroupNorm(x)) on NHWC [B,H,W,C] (sal_unet.py:36-44), statistics kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        B, H, W, C = x.shape
+        hw, cpg = H * W, C // groups
+        st = ops.rowstats(x, hw, 0)                                  # [B, 2, C] float64
+        n = float(hw * cpg)
+        gs = st.reshape(B, 2, groups, cpg).sum(-1)                   # [B, 2, G]
+        mean = gs[:, 0] / n
+        var = (gs[:, 1] / n - mean * mean).clamp_min(0.0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        mu_c = mean.repeat_interleave(cpg, dim=1).float().contiguous()   # [B, C]
+        rs_c = rstd.repeat_interleave(cpg, dim=1).float().contiguous()
+        scale = (rs_c * gamma).contiguous()
+        shift = (beta - mu_c * scale).contiguous()
+        ctx.groups = groups
+        ctx.save_for_backward(x, gamma, beta, mu_c, rs_c)
+        return ops.affine_act(x, scale, shift, hw, 4)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mu_c, rs_c = ctx.saved_tensors
+        B, H, W, C = x.shape
+        hw, G = H * W, ctx.groups
+        cpg = C // G
+        dy = dy.contiguous()
+        t = ops.rowstats(x, hw, 2, dy=dy, mu=mu_c, rs=rs_c, gamma=gamma, beta=beta, stat_per_seg=True)  # [B,2,C]
+        dbeta, dgamma = t[:, 0].sum(0).float(), t[:, 1].sum(0).float()
+        gd = gamma.double()
+        n = float(hw * cpg)
+        A = (t[:, 0] * gd).reshape(B, G, cpg).sum(-1).repeat_interleave(cpg, dim=1) / n   # [B, C]
+        Bq = (t[:, 1] * gd).reshape(B, G, cpg).sum(-1).repeat_interleave(cpg, dim=1) / n
+        k1 = (rs_c * gamma).contiguous()
+        k2 = (rs_c.double() * A).float().contiguous()
+        k3 = (rs_c.double() * Bq).float().contiguous()
+        dx = ops.norm_bwd_apply(x, dy, None, mu_c, rs_c, gamma, beta, k1, k2, k3, hw, 2)
+        return dx, dgamma, dbeta, None, None
+
+
+def groupnorm_swish(x, gamma, beta, groups=32, eps=1e-6):
+    return GroupNormSwishFn.apply(x, gamma, beta, groups, eps)
+
+
+class BatchNormReLUFn(torch.autograd.Function):
+    """relu(BatchNorm2d(x)) in TRAIN mode on channels-last rows [M, C]: batch statistics over all rows (per rank,
+    unsynchronised -- exactly what the reference's DDP does); returns (y, batch_mean, biased_var)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        C = x.shape[-1]
+        M = x.numel() // C
+        st = ops.rowstats(x, M, 0)[0]                  # [2, C] float64
+        mean = st[0] / M
+        var = (st[1] / M - mean * mean).clamp_min(0.0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        mu = mean.float().reshape(1, C).contiguous()
+        rs = rstd.float().reshape(1, C).contiguous()
+        scale = (rs * gamma).contiguous()
+        shift = (beta - mu * scale).contiguous()
+        y = ops.affine_act(x, scale, shift, M, ACT_RELU if relu else ACT_NONE)
+        ctx.relu = relu
+        ctx.save_for_backward(x, y if relu else x.new_empty(0), gamma, mu, rs)
+        ctx.mark_non_differentiable(mu, rs)
+        return y, mean.float(), var.float()
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, y, gamma, mu, rs = ctx.saved_tensors
+        C = x.shape[-1]
+        M = x.numel() // C
+        dy = dy.contiguous()
+        mode = 1 if ctx.relu else 3
+        t = ops.rowstats(x, M, mode, dy=dy, y=y if ctx.relu else None, mu=mu, rs=rs)[0]   # [2, C]
+        dbeta, dgamma = t[0].float(), t[1].float()
+        k1 = (gamma * rs).contiguous()                                  # [1, C]
+        k2 = (k1.double() * t[0] / M).float().contiguous()
+        k3 = (k1.double() * t[1] / M).float().contiguous()
+        dx = ops.norm_bwd_apply(x, dy, y if ctx.relu else None, mu, rs, None, None, k1, k2, k3, M, mode)
+        return dx, dgamma, dbeta, None, None
+
+
+def batchnorm_relu_train(x, bn: "torch.nn.BatchNorm2d", relu=True):
+    """Functional train-mode BatchNorm(+ReLU) that also updates the module's running statistics like nn.BatchNorm2d."""
+    y, mean, var = BatchNormReLUFn.apply(x, bn.weight, bn.bias, bn.eps, relu)
+    with torch.no_grad():
+        M = x.numel() // x.shape[-1]
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+        bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+        bn.num_batches_tracked += 1
+    return y
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, seed):
+    return DropoutFn.apply(x, p, seed) if p > 0 else x
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(dy.contiguous(), x, 2)
+
+
+def gelu(x):
+    return GeluFn.apply(x)
+
+
+class AddFn(torch.autograd.Function):
+    """a + b through the axpy kernel (skip connections of the training graph)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpbypcz(a, 1.0, b, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)

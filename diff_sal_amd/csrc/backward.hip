@@ -30,6 +30,248 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-channel dual sums over rows, the reduction half of every normalisation layer's forward/backward.
+//   mode 0: (x, x^2)                                   BatchNorm / GroupNorm forward statistics
+//   mode 1: (dz, dz*xhat), dz = dy * [y > 0]           BatchNorm+ReLU backward   (mu, rs: [1][C])
+//   mode 2: (dz, dz*xhat), dz = dy * swish'(z)         GroupNorm+swish backward  (mu, rs: [seg][C], z = xhat*gamma+beta)
+//   mode 3: (dy, dy*xhat)                              plain normalisation backward
+// part: [segments][chunks][2][C]; rows of segment g are [g*seg_rows, (g+1)*seg_rows).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float swish_grad(float z) {
+  const float sg = 1.0f / (1.0f + expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ y, const float* __restrict__ mu,
+                                                       const float* __restrict__ rs, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ part, int M,
+                                                       int C, int seg_rows, int chunks, int mode, int stat_per_seg) {
+  extern __shared__ float sh[];  // [2][C]
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const int c4n = C >> 2;
+  const int rpp = 256 / c4n > 0 ? 256 / c4n : 1;
+  const int c4 = threadIdx.x % c4n, rsub = threadIdx.x / c4n;
+  const int c = c4 * 4;
+  const long r0 = static_cast<long>(seg) * seg_rows;
+  const long rb = r0 + static_cast<long>(seg_rows) * chunk / chunks;
+  const long re = r0 + static_cast<long>(seg_rows) * (chunk + 1) / chunks;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (rsub < rpp) {
+    float m4[4] = {0, 0, 0, 0}, r4[4] = {1, 1, 1, 1}, g4[4] = {1, 1, 1, 1}, b4[4] = {0, 0, 0, 0};
+    if (mode != 0) {
+      const long so = (stat_per_seg ? static_cast<long>(seg) * C : 0) + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { m4[k] = mu[so + k]; r4[k] = rs[so + k]; }
+      if (mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g4[k] = gamma[c + k]; b4[k] = beta[c + k]; }
+      }
+    }
+    for (long m = rb + rsub; m < re; m += rpp) {
+      const float4 xv = ld4(x + m * C + c);
+      const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (mode == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s1[k] += xa[k]; s2[k] += xa[k] * xa[k]; }
+      } else {
+        const float4 gv = ld4(dy + m * C + c);
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+        float ya[4] = {1, 1, 1, 1};
+        if (mode == 1) { const float4 yv = ld4(y + m * C + c); ya[0] = yv.x; ya[1] = yv.y; ya[2] = yv.z; ya[3] = yv.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xa[k] - m4[k]) * r4[k];
+          float dz = ga[k];
+          if (mode == 1) dz = ya[k] > 0.f ? dz : 0.f;
+          else if (mode == 2) dz *= swish_grad(xh * g4[k] + b4[k]);
+          s1[k] += dz;
+          s2[k] += dz * xh;
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  if (rsub < rpp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(&sh[c + k], s1[k]); atomicAdd(&sh[C + c + k], s2[k]); }
+  }
+  __syncthreads();
+  float* o = part + (static_cast<long>(seg) * chunks + chunk) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) o[i] = sh[i];
+}
+
+// y = act(x * s[seg, c] + t[seg, c])   (BatchNorm / GroupNorm forward once the statistics are folded into s, t)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                         const float* __restrict__ sh_, float* __restrict__ out, long M,
+                                                         int C, int seg_rows, int act) {
+  const int c4n = C >> 2;
+  const long total = M * c4n;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    const long m = i / c4n;
+    const long so = (m / seg_rows) * C + c;
+    const float4 v = ld4(x + m * C + c), s4 = ld4(sc + so), t4 = ld4(sh_ + so);
+    float o[4] = {v.x * s4.x + t4.x, v.y * s4.y + t4.y, v.z * s4.z + t4.z, v.w * s4.w + t4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (act == DIFFSAL_ACT_RELU) o[k] = fmaxf(o[k], 0.f);
+      else if (act == DIFFSAL_ACT_GELU_ERF) o[k] = gelu_erf(o[k]);
+      else if (act == 4) o[k] = swishf(o[k]);
+    }
+    st4(out + m * C + c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// dx = k1*dz - k2 - k3*xhat with per-(segment, channel) coefficients; dz as in rowstats (same modes 1..3)
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ y, const float* __restrict__ mu,
+                                                             const float* __restrict__ rs, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ k1,
+                                                             const float* __restrict__ k2, const float* __restrict__ k3,
+                                                             float* __restrict__ dx, long M, int C, int seg_rows,
+                                                             int mode) {
+  const int c4n = C >> 2;
+  const long total = M * c4n;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    const long m = i / c4n;
+    const long so = (m / seg_rows) * C + c;
+    const float4 xv = ld4(x + m * C + c), gv = ld4(dy + m * C + c);
+    const float4 m4 = ld4(mu + so), r4 = ld4(rs + so), a4 = ld4(k1 + so), b4 = ld4(k2 + so), c4v = ld4(k3 + so);
+    const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float ma[4] = {m4.x, m4.y, m4.z, m4.w}, ra[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float ka[4] = {a4.x, a4.y, a4.z, a4.w}, kb[4] = {b4.x, b4.y, b4.z, b4.w}, kc[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+    float ya[4] = {1, 1, 1, 1}, gm[4] = {1, 1, 1, 1}, bt[4] = {0, 0, 0, 0};
+    if (mode == 1) { const float4 yv = ld4(y + m * C + c); ya[0] = yv.x; ya[1] = yv.y; ya[2] = yv.z; ya[3] = yv.w; }
+    if (mode == 2) {
+      const float4 g4 = ld4(gamma + c), be = ld4(beta + c);
+      gm[0] = g4.x; gm[1] = g4.y; gm[2] = g4.z; gm[3] = g4.w; bt[0] = be.x; bt[1] = be.y; bt[2] = be.z; bt[3] = be.w;
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (xa[k] - ma[k]) * ra[k];
+      float dz = ga[k];
+      if (mode == 1) dz = ya[k] > 0.f ? dz : 0.f;
+      else if (mode == 2) dz *= swish_grad(xh * gm[k] + bt[k]);
+      o[k] = ka[k] * dz - kb[k] - kc[k] * xh;
+    }
+    st4(dx + m * C + c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// LayerNorm backward over C (rows in registers, statistics recomputed): dx, and per-block partial dgamma / dbeta.
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ part, int M, int C, float eps) {
+  constexpr int ROWS = 256 / G;
+  extern __shared__ float sh[];  // [2][C]
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  float4 dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); }
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < M; row += static_cast<long>(gridDim.x) * ROWS) {
+    float4 xv[NV], gv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      xv[i] = c < C ? ld4(x + row * C + c) : make_float4(0, 0, 0, 0);
+      gv[i] = c < C ? ld4(dy + row * C + c) : make_float4(0, 0, 0, 0);
+      s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    }
+    s = group_sum<G>(s);
+    const float mean = s / static_cast<float>(C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      if (c < C) {
+        const float a = xv[i].x - mean, b = xv[i].y - mean, cc = xv[i].z - mean, d = xv[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    q = group_sum<G>(q);
+    const float rstd = 1.0f / sqrtf(q / static_cast<float>(C) + eps);
+    float a1 = 0.f, a2 = 0.f;  // sum(dxhat), sum(dxhat * xhat)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      if (c < C) {
+        const float4 gm = ld4(gamma + c);
+        const float xh[4] = {(xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd};
+        const float gy[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
+        const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a1 += gy[k] * gg[k]; a2 += gy[k] * gg[k] * xh[k]; }
+        dg[i].x += gy[0] * xh[0]; dg[i].y += gy[1] * xh[1]; dg[i].z += gy[2] * xh[2]; dg[i].w += gy[3] * xh[3];
+        db[i].x += gy[0]; db[i].y += gy[1]; db[i].z += gy[2]; db[i].w += gy[3];
+      }
+    }
+    a1 = group_sum<G>(a1) / static_cast<float>(C);
+    a2 = group_sum<G>(a2) / static_cast<float>(C);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      if (c < C) {
+        const float4 gm = ld4(gamma + c);
+        float4 o;
+        o.x = rstd * (gv[i].x * gm.x - a1 - (xv[i].x - mean) * rstd * a2);
+        o.y = rstd * (gv[i].y * gm.y - a1 - (xv[i].y - mean) * rstd * a2);
+        o.z = rstd * (gv[i].z * gm.z - a1 - (xv[i].z - mean) * rstd * a2);
+        o.w = rstd * (gv[i].w * gm.w - a1 - (xv[i].w - mean) * rstd * a2);
+        st4(dx + row * C + c, o);
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) {
+      atomicAdd(&sh[c + 0], dg[i].x); atomicAdd(&sh[c + 1], dg[i].y); atomicAdd(&sh[c + 2], dg[i].z); atomicAdd(&sh[c + 3], dg[i].w);
+      atomicAdd(&sh[C + c + 0], db[i].x); atomicAdd(&sh[C + c + 1], db[i].y); atomicAdd(&sh[C + c + 2], db[i].z); atomicAdd(&sh[C + c + 3], db[i].w);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) part[static_cast<long>(blockIdx.x) * 2 * C + i] = sh[i];
+}
+
+// y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter-based hash of (seed, element index): the same call
+// with the same seed is the backward (R/models/saliency_decoder/sal_unet.py:109,133, Dropout(0.1) in train mode).
+__device__ __forceinline__ unsigned hash_u32(unsigned a, unsigned b) {
+  unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
+                                                      float p, unsigned seed_lo, unsigned seed_hi) {
+  const float scale = 1.0f / (1.0f - p);
+  const unsigned thr = static_cast<unsigned>(p * 4294967296.0);
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * 256) {
+    const unsigned h = hash_u32(hash_u32(static_cast<unsigned>(i), seed_lo), static_cast<unsigned>(i >> 32) ^ seed_hi);
+    out[i] = h >= thr ? x[i] * scale : 0.f;
+  }
+}
+
+#define DS_ROW_DISPATCH_B(C, CALL)                                \
+  do {                                                            \
+    const int c4 = (C) / 4;                                       \
+    if (c4 <= 8) { CALL(8, 1); }                                  \
+    else if (c4 <= 16) { CALL(16, 1); }                           \
+    else if (c4 <= 32) { CALL(32, 1); }                           \
+    else if (c4 <= 64) { CALL(64, 1); }                           \
+    else if (c4 <= 128) { CALL(64, 2); }                          \
+    else if (c4 <= 192) { CALL(64, 3); }                          \
+    else if (c4 <= 256) { CALL(64, 4); }                          \
+    else { set_error("channel count %d > 1024 unsupported", (C)); return DIFFSAL_E_SHAPE; } \
+  } while (0)
+
 }  // namespace diffsal
 
 using namespace diffsal;
@@ -43,4 +285,83 @@ extern "C" int diffsal_act_bwd(const float* dy, const float* ref, float* dx, siz
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid_b(static_cast<long>(n / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dy, ref, dx, static_cast<long>(n / 4), mode);
   return check_launch("act_bwd");
+}
+
+extern "C" int diffsal_rowstats_chunks(int M, int seg_rows) {
+  const int segs = M / seg_rows;
+  int chunks = 1024 / (segs > 0 ? segs : 1);
+  chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+  while (chunks > 1 && seg_rows / chunks < 16) chunks >>= 1;
+  return chunks;
+}
+
+extern "C" int diffsal_rowstats(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
+                                const float* gamma, const float* beta, float* part, int M, int C, int seg_rows,
+                                int mode, int stat_per_seg, diffsal_stream_t stream) {
+  DS_REQUIRE(x && part, DIFFSAL_E_ARG, "rowstats: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 2048 && seg_rows > 0 && M % seg_rows == 0 && mode >= 0 && mode <= 3,
+             DIFFSAL_E_SHAPE, "rowstats: bad shape M=%d C=%d seg_rows=%d mode=%d", M, C, seg_rows, mode);
+  DS_REQUIRE(mode == 0 || (dy && mu && rs), DIFFSAL_E_ARG, "rowstats: backward modes need dy, mu, rs");
+  DS_REQUIRE(mode != 1 || y, DIFFSAL_E_ARG, "rowstats: mode 1 needs y");
+  DS_REQUIRE(mode != 2 || (gamma && beta), DIFFSAL_E_ARG, "rowstats: mode 2 needs gamma, beta");
+  const int chunks = diffsal_rowstats_chunks(M, seg_rows);
+  hipLaunchKernelGGL(rowstats_kernel, dim3(chunks, M / seg_rows), dim3(256), 2 * C * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, dy, y, mu, rs, gamma, beta, part, M, C, seg_rows, chunks, mode,
+                     stat_per_seg);
+  return check_launch("rowstats");
+}
+
+extern "C" int diffsal_affine_act(const float* x, const float* scale, const float* shift, float* out, int M, int C,
+                                  int seg_rows, int act, diffsal_stream_t stream) {
+  DS_REQUIRE(x && scale && shift && out, DIFFSAL_E_ARG, "affine_act: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && seg_rows > 0, DIFFSAL_E_SHAPE, "affine_act: bad shape");
+  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid_b(static_cast<long>(M) * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, scale, shift, out, static_cast<long>(M), C, seg_rows, act);
+  return check_launch("affine_act");
+}
+
+extern "C" int diffsal_norm_bwd_apply(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
+                                      const float* gamma, const float* beta, const float* k1, const float* k2,
+                                      const float* k3, float* dx, int M, int C, int seg_rows, int mode,
+                                      diffsal_stream_t stream) {
+  DS_REQUIRE(x && dy && mu && rs && k1 && k2 && k3 && dx, DIFFSAL_E_ARG, "norm_bwd_apply: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && seg_rows > 0 && mode >= 1 && mode <= 3, DIFFSAL_E_SHAPE,
+             "norm_bwd_apply: bad shape");
+  DS_REQUIRE(mode != 1 || y, DIFFSAL_E_ARG, "norm_bwd_apply: mode 1 needs y");
+  DS_REQUIRE(mode != 2 || (gamma && beta), DIFFSAL_E_ARG, "norm_bwd_apply: mode 2 needs gamma, beta");
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid_b(static_cast<long>(M) * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, dy, y, mu, rs, gamma, beta, k1, k2, k3, dx,
+                     static_cast<long>(M), C, seg_rows, mode);
+  return check_launch("norm_bwd_apply");
+}
+
+extern "C" int diffsal_layernorm_bwd_blocks(int M, int C) {
+  const int c4 = C / 4;
+  const int G = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : (c4 <= 32 ? 32 : 64));
+  long g = (static_cast<long>(M) + 256 / G - 1) / (256 / G);
+  return static_cast<int>(g > 1024 ? 1024 : g);
+}
+
+extern "C" int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* part,
+                                     int M, int C, float eps, diffsal_stream_t stream) {
+  DS_REQUIRE(x && dy && gamma && dx && part, DIFFSAL_E_ARG, "layernorm_bwd: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm_bwd: bad shape M=%d C=%d", M, C);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int blocks = diffsal_layernorm_bwd_blocks(M, C);
+#define CALL(G, NV)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<G, NV>), dim3(blocks), dim3(256), 2 * C * sizeof(float), s, x, dy, gamma, dx, \
+                     part, M, C, eps)
+  DS_ROW_DISPATCH_B(C, CALL);
+#undef CALL
+  return check_launch("layernorm_bwd");
+}
+
+extern "C" int diffsal_dropout(const float* x, float* out, size_t n, float p, uint64_t seed, diffsal_stream_t stream) {
+  DS_REQUIRE(x && out, DIFFSAL_E_ARG, "dropout: null argument");
+  DS_REQUIRE(p >= 0.f && p < 1.f, DIFFSAL_E_SHAPE, "dropout: p=%f out of [0,1)", p);
+  if (n == 0) return DIFFSAL_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid_b(static_cast<long>(n))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, out, static_cast<long>(n), p,
+                     static_cast<unsigned>(seed & 0xFFFFFFFFu), static_cast<unsigned>(seed >> 32));
+  return check_launch("dropout");
 }

@@ -296,3 +296,64 @@ def act_bwd(dy: Tensor, ref: Tensor, mode: int) -> Tensor:
 
 def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
     return act_bwd(dy, y, 1)
+
+
+def rowstats(x: Tensor, seg_rows: int, mode: int = 0, dy=None, y=None, mu=None, rs=None, gamma=None, beta=None,
+             stat_per_seg: bool = False) -> Tensor:
+    """Per-channel dual sums over the rows of each segment -> [segs, 2, C] (float64, chunk partials already summed)."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    chunks = lib.diffsal_rowstats_chunks(M, seg_rows)
+    part = torch.empty((M // seg_rows, chunks, 2, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_rowstats(_p(x), _p(dy), _p(y), _p(mu), _p(rs), _p(gamma), _p(beta), _p(part), M, Cc, seg_rows,
+                                    mode, int(stat_per_seg), _stream()), "rowstats")
+    return part.double().sum(dim=1)
+
+
+def affine_act(x: Tensor, scale: Tensor, shift: Tensor, seg_rows: int, act: int) -> Tensor:
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(lib.diffsal_affine_act(_p(x), _p(scale), _p(shift), _p(out), x.numel() // Cc, Cc, seg_rows, act,
+                                      _stream()), "affine_act")
+    return out
+
+
+def norm_bwd_apply(x, dy, y, mu, rs, gamma, beta, k1, k2, k3, seg_rows: int, mode: int) -> Tensor:
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(lib.diffsal_norm_bwd_apply(_p(x), _p(dy), _p(y), _p(mu), _p(rs), _p(gamma), _p(beta), _p(k1), _p(k2),
+                                          _p(k3), _p(dx), x.numel() // Cc, Cc, seg_rows, mode, _stream()),
+               "norm_bwd_apply")
+    return dx
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5):
+    """-> (dx, dgamma, dbeta)."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    blocks = lib.diffsal_layernorm_bwd_blocks(M, Cc)
+    part = torch.empty((blocks, 2, Cc), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    _lib.check(lib.diffsal_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(dx), _p(part), M, Cc, eps, _stream()),
+               "layernorm_bwd")
+    s = part.double().sum(dim=0).float()
+    return dx, s[0], s[1]
+
+
+def dropout(x: Tensor, p: float, seed: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    _lib.check(lib.diffsal_dropout(_p(x), _p(out), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _stream()), "dropout")
+    return out
+
+
+def gelu(x: Tensor) -> Tensor:
+    """Stand-alone erf-GELU (training path keeps the pre-activation for the backward)."""
+    Cc = x.shape[-1]
+    one = torch.ones((1, Cc), device=x.device, dtype=torch.float32)
+    zero = torch.zeros((1, Cc), device=x.device, dtype=torch.float32)
+    return affine_act(x, one, zero, x.numel() // Cc, ACT_GELU)

@@ -104,6 +104,31 @@ int diffsal_colsum(const float* dy, float* out, int M, int C, int seg_rows, void
  * Backward of the activations fused into the forward epilogues / nn.GELU (common_block.py:137). n % 4 == 0. */
 int diffsal_act_bwd(const float* dy, const float* ref, float* dx, size_t n, int mode, diffsal_stream_t stream);
 
+/* ---- K16 (training): normalisation layers ------------------------------------------------------
+ * Per-channel dual sums over the rows of each segment -> part[segs][chunks][2][C], chunks = diffsal_rowstats_chunks():
+ *   mode 0 (x, x^2): BatchNorm (train) / GroupNorm statistics;  mode 1/2/3: (dz, dz*xhat) for BN+ReLU, GN+swish, plain.
+ * The caller folds the partials into per-(segment, channel) vectors (tiny) and calls the element-wise kernels below.
+ * Replace the forward / backward of nn.BatchNorm2d (train), nn.GroupNorm + swish (sal_unet.py:36-44,
+ * common_block.py:33-36,196-216). */
+int diffsal_rowstats_chunks(int M, int seg_rows);
+int diffsal_rowstats(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
+                     const float* gamma, const float* beta, float* part, int M, int C, int seg_rows, int mode,
+                     int stat_per_seg, diffsal_stream_t stream);
+/* out = act(x * scale[seg, c] + shift[seg, c]); act: DIFFSAL_ACT_NONE / RELU, or 4 = swish */
+int diffsal_affine_act(const float* x, const float* scale, const float* shift, float* out, int M, int C, int seg_rows,
+                       int act, diffsal_stream_t stream);
+/* dx = k1*dz - k2 - k3*xhat with [seg, C] coefficient tables (dz, xhat as in rowstats modes 1..3) */
+int diffsal_norm_bwd_apply(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
+                           const float* gamma, const float* beta, const float* k1, const float* k2, const float* k3,
+                           float* dx, int M, int C, int seg_rows, int mode, diffsal_stream_t stream);
+/* LayerNorm backward: dx and per-block partial (dgamma, dbeta) -> part[blocks][2][C], blocks = diffsal_layernorm_bwd_blocks() */
+int diffsal_layernorm_bwd_blocks(int M, int C);
+int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* part, int M, int C,
+                          float eps, diffsal_stream_t stream);
+/* out = x * keep / (1-p), keep from a counter-based hash of (seed, index); same call = its own backward.
+ * Replaces nn.Dropout(0.1) of ResnetBlock in train mode (sal_unet.py:109,133). */
+int diffsal_dropout(const float* x, float* out, size_t n, float p, uint64_t seed, diffsal_stream_t stream);
+
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
  * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,

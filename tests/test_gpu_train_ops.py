@@ -84,3 +84,85 @@ def test_linear_backward_with_residual(ag):
     yd.backward(gy.to(DEV))
     for got, ref in ((xd.grad, x.grad), (wd.grad, w.grad), (bd.grad, b.grad), (rd.grad, r.grad)):
         assert rel(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("C", [96, 192, 768, 32])
+def test_layernorm_backward(ag, C):
+    agops, _ = ag
+    x = (rnd("lnx%d" % C, 4, 57, C) * 1.7 + 0.2).requires_grad_(True)
+    g = (rnd("lng", C, scale=0.2) + 1.0).requires_grad_(True)
+    b = rnd("lnb", C, scale=0.2).requires_grad_(True)
+    gy = rnd("lngy", 4, 57, C)
+    F.layer_norm(x, (C,), g, b, 1e-5).backward(gy)
+    xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, g, b))
+    y = agops.layernorm(xd, gd, bd, 1e-5)
+    y.backward(gy.to(DEV))
+    assert rel(xd.grad, x.grad) < 2e-5 and rel(gd.grad, g.grad) < 2e-5 and rel(bd.grad, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("C,HW", [(96, (14, 24)), (192, (7, 9)), (768, (5, 6))])
+def test_groupnorm_swish_backward(ag, C, HW):
+    agops, _ = ag
+    x = (rnd("gnx%d" % C, 3, C, *HW) * 2.0 + 0.7).requires_grad_(True)
+    g = (rnd("gng", C, scale=0.2) + 1.0).requires_grad_(True)
+    b = rnd("gnb", C, scale=0.2).requires_grad_(True)
+    y = orc.group_norm_swish(x, g, b)
+    gy = rnd("gngy", *y.shape)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(DEV).requires_grad_(True)
+    gd, bd = g.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    yd = agops.groupnorm_swish(xd, gd, bd, 32, 1e-6)
+    assert rel(yd, nhwc(y)) < 2e-5
+    yd.backward(nhwc(gy).to(DEV))
+    assert rel(xd.grad, nhwc(x.grad)) < 5e-5 and rel(gd.grad, g.grad) < 5e-5 and rel(bd.grad, b.grad) < 5e-5
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_train_forward_backward_and_running_stats(ag, relu):
+    agops, _ = ag
+    N, C, H, W = 5, 96, 9, 11
+    x = (rnd("bnx", N, C, H, W) * 1.3 + 0.4).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(rnd("bnw", C, scale=0.2) + 1.0)
+        bn.bias.copy_(rnd("bnb", C, scale=0.2))
+    bn.train()
+    y = bn(x)
+    y = F.relu(y) if relu else y
+    gy = rnd("bngy", *y.shape)
+    y.backward(gy)
+    bnd = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bnd.weight.copy_(bn.weight.detach())
+        bnd.bias.copy_(bn.bias.detach())
+    xd = nhwc(x.detach()).to(DEV).requires_grad_(True)
+    yd = agops.batchnorm_relu_train(xd, bnd, relu=relu)
+    assert rel(yd, nhwc(y)) < 2e-5
+    yd.backward(nhwc(gy).to(DEV))
+    assert rel(xd.grad, nhwc(x.grad)) < 5e-5
+    assert rel(bnd.weight.grad, bn.weight.grad) < 5e-5 and rel(bnd.bias.grad, bn.bias.grad) < 5e-5
+    assert rel(bnd.running_mean, bn.running_mean) < 1e-5 and rel(bnd.running_var, bn.running_var) < 1e-5
+    assert int(bnd.num_batches_tracked) == 1
+
+
+def test_dropout_is_its_own_backward_and_unbiased(ag):
+    agops, _ = ag
+    x = torch.ones(1 << 20, device=DEV, requires_grad=True)
+    y = agops.dropout(x, 0.1, seed=1234)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3 and abs(y.mean().item() - 1.0) < 3e-3
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, y.detach())
+    y2 = agops.dropout(x, 0.1, seed=1235)
+    assert not torch.equal(y2, y)
+
+
+def test_gelu_and_add_backward(ag):
+    agops, _ = ag
+    x = rnd("gex", 7, 33, 96).requires_grad_(True)
+    z = rnd("gez", 7, 33, 96).requires_grad_(True)
+    gy = rnd("gegy", 7, 33, 96)
+    (F.gelu(x) + z).backward(gy)
+    xd, zd = x.detach().to(DEV).requires_grad_(True), z.detach().to(DEV).requires_grad_(True)
+    agops.add(agops.gelu(xd), zd).backward(gy.to(DEV))
+    assert rel(xd.grad, x.grad) < 2e-5 and rel(zd.grad, z.grad) < 1e-6
