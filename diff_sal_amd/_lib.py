@@ -45,6 +45,12 @@ SIGNATURES = {
     "diffsal_layernorm_bwd_blocks": (c_i, [c_i, c_i]),
     "diffsal_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),
     "diffsal_dropout": (c_i, [c_f, c_f, c_sz, c_fl, C.c_uint64, c_f]),
+    "diffsal_dwconv": (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f]),
+    "diffsal_dwconv_bwd_data": (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f]),
+    "diffsal_dwconv_bwd_weight_chunks": (c_i, [c_i] * 6),
+    "diffsal_dwconv_bwd_weight": (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f]),
+    "diffsal_attention_bwd_blocks": (c_i, [c_i, c_i, c_i]),
+    "diffsal_attention_bwd": (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl, c_f]),
     "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),

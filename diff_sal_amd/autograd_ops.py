@@ -249,3 +249,43 @@ class AddFn(torch.autograd.Function):
 
 def add(a, b):
     return AddFn.apply(a, b)
+
+
+class DwConvFn(torch.autograd.Function):
+    """Depthwise k x k convolution on NHWC; w: [k*k, C]."""
+
+    @staticmethod
+    def forward(ctx, x, w, k, stride, pad):
+        ctx.cfg = (k, stride, pad)
+        ctx.save_for_backward(x, w)
+        return ops.dwconv(x, w, k, stride, pad)
+
+    @staticmethod
+    def backward(ctx, du):
+        x, w = ctx.saved_tensors
+        k, stride, pad = ctx.cfg
+        dx, dw = ops.dwconv_bwd(x, w, du.contiguous(), k, stride, pad, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, None, None, None
+
+
+def dwconv(x, w, k, stride, pad):
+    return DwConvFn.apply(x, w, k, stride, pad)
+
+
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        ctx.cfg = (heads, scale)
+        ctx.save_for_backward(q, k, v)
+        return ops.attention(q, k, v, heads, scale)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        dq, dk, dv = ops.attention_bwd(q, k, v, do.contiguous(), heads, scale)
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, heads, scale):
+    return AttentionFn.apply(q, k, v, heads, scale)

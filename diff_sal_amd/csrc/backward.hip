@@ -259,6 +259,199 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Depthwise convolution on NHWC (training path of the q / k / v token projections, attention.py:36-76):
+// forward, data gradient and weight gradient.  w: [taps][C].  thread = (output element, 4 channels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ out, int N, int H, int W, int C, int Ho,
+                                                         int Wo, int k, int stride, int pad) {
+  const int c4n = C >> 2;
+  const long total = static_cast<long>(N) * Ho * Wo * c4n;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    long pix = i / c4n;
+    const int ox = static_cast<int>(pix % Wo); pix /= Wo;
+    const int oy = static_cast<int>(pix % Ho);
+    const int n = static_cast<int>(pix / Ho);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 a = ld4(x + ((static_cast<long>(n) * H + iy) * W + ix) * C + c);
+        const float4 ww = ld4(w + static_cast<long>(ky * k + kx) * C + c);
+        acc.x = fmaf(a.x, ww.x, acc.x); acc.y = fmaf(a.y, ww.y, acc.y);
+        acc.z = fmaf(a.z, ww.z, acc.z); acc.w = fmaf(a.w, ww.w, acc.w);
+      }
+    }
+    st4(out + i * 4, acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __restrict__ du, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                              int Wo, int k, int stride, int pad) {
+  const int c4n = C >> 2;
+  const long total = static_cast<long>(N) * H * W * c4n;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    long pix = i / c4n;
+    const int ix = static_cast<int>(pix % W); pix /= W;
+    const int iy = static_cast<int>(pix % H);
+    const int n = static_cast<int>(pix / H);
+    float4 acc = make_float4(0, 0, 0, 0);
+    // taps with (iy + pad - ky) divisible by stride and the quotient inside the output
+    for (int ky = (iy + pad) % stride; ky < k; ky += stride) {
+      const int oy = (iy + pad - ky) / stride;
+      if (iy + pad - ky < 0 || oy >= Ho) continue;
+      for (int kx = (ix + pad) % stride; kx < k; kx += stride) {
+        const int ox = (ix + pad - kx) / stride;
+        if (ix + pad - kx < 0 || ox >= Wo) continue;
+        const float4 g = ld4(du + ((static_cast<long>(n) * Ho + oy) * Wo + ox) * C + c);
+        const float4 ww = ld4(w + static_cast<long>(ky * k + kx) * C + c);
+        acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
+        acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+      }
+    }
+    st4(dx + i * 4, acc);
+  }
+}
+
+// part[tap][chunk][C]: one workgroup = one tap and one chunk of output pixels; threads = (pixel lane, 4 channels)
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                                                float* __restrict__ part, int N, int H, int W, int C,
+                                                                int Ho, int Wo, int k, int stride, int pad, int chunks) {
+  extern __shared__ float sh[];  // [C]
+  const int tap = blockIdx.y, chunk = blockIdx.x;
+  const int ky = tap / k, kx = tap - ky * k;
+  const int c4n = C >> 2;
+  const int ppp = 256 / c4n > 0 ? 256 / c4n : 1;
+  const int c4 = threadIdx.x % c4n, ps = threadIdx.x / c4n;
+  const long P = static_cast<long>(N) * Ho * Wo;
+  const long pb = P * chunk / chunks, pe = P * (chunk + 1) / chunks;
+  float4 s = make_float4(0, 0, 0, 0);
+  if (ps < ppp)
+    for (long pix = pb + ps; pix < pe; pix += ppp) {
+      long t = pix;
+      const int ox = static_cast<int>(t % Wo); t /= Wo;
+      const int oy = static_cast<int>(t % Ho);
+      const int n = static_cast<int>(t / Ho);
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const float4 a = ld4(x + ((static_cast<long>(n) * H + iy) * W + ix) * C + c4 * 4);
+      const float4 g = ld4(du + pix * C + c4 * 4);
+      s.x = fmaf(a.x, g.x, s.x); s.y = fmaf(a.y, g.y, s.y); s.z = fmaf(a.z, g.z, s.z); s.w = fmaf(a.w, g.w, s.w);
+    }
+  for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  if (ps < ppp) {
+    atomicAdd(&sh[c4 * 4 + 0], s.x); atomicAdd(&sh[c4 * 4 + 1], s.y);
+    atomicAdd(&sh[c4 * 4 + 2], s.z); atomicAdd(&sh[c4 * 4 + 3], s.w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(tap) * chunks + chunk) * C + i] = sh[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention backward (pooled K/V, Lk <= 32): dq directly; dk, dv accumulated per workgroup in LDS and
+// written as partials part[n][block][2][Lk][C] (summed by the caller).  Same lane mapping as the forward.
+// ------------------------------------------------------------------------------------------------
+template <int LK, int G>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ dout,
+                                                            float* __restrict__ dq, float* __restrict__ part, int Lq,
+                                                            int Lk, int C, int heads, float scale) {
+  // one workgroup = one image, one HEAD (blockIdx.z) and a run of queries: K | V | dK | dV of that head, [Lk][d] each
+  extern __shared__ float sh[];
+  const int d = C / heads, nf4 = d >> 2;
+  const int hd = blockIdx.z;
+  const int cb = hd * d;
+  float* Ks = sh;
+  float* Vs = sh + Lk * d;
+  float* dKs = sh + 2 * Lk * d;
+  float* dVs = sh + 3 * Lk * d;
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < Lk * nf4; i += 256) {
+    const int t = i / nf4, j = (i - t * nf4) * 4;
+    st4(Ks + t * d + j, ld4(k + (static_cast<long>(n) * Lk + t) * C + cb + j));
+    st4(Vs + t * d + j, ld4(v + (static_cast<long>(n) * Lk + t) * C + cb + j));
+    st4(dKs + t * d + j, make_float4(0, 0, 0, 0));
+    st4(dVs + t * d + j, make_float4(0, 0, 0, 0));
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int QPW = 64 / G;
+  const int g = lane % G;
+  const int l = blockIdx.x * (4 * QPW) + wave * QPW + lane / G;
+  const bool valid = l < Lq;
+  const int lc = valid ? l : Lq - 1;
+  const float* qr = q + (static_cast<long>(n) * Lq + lc) * C + cb;
+  const float* gr = dout + (static_cast<long>(n) * Lq + lc) * C + cb;
+  float sc[LK], dp[LK];
+#pragma unroll
+  for (int t = 0; t < LK; ++t) { sc[t] = 0.f; dp[t] = 0.f; }
+  for (int i = g; i < nf4; i += G) {
+    const float4 qv = ld4(qr + 4 * i), gv = ld4(gr + 4 * i);
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) {
+        const float4 kv = ld4(Ks + t * d + 4 * i), vv = ld4(Vs + t * d + 4 * i);
+        sc[t] = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, sc[t]))));
+        dp[t] = fmaf(gv.x, vv.x, fmaf(gv.y, vv.y, fmaf(gv.z, vv.z, fmaf(gv.w, vv.w, dp[t]))));
+      }
+    }
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < LK; ++t)
+    if (t < Lk) { sc[t] = group_sum<G>(sc[t]) * scale; dp[t] = group_sum<G>(dp[t]); mx = fmaxf(mx, sc[t]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < LK; ++t)
+    if (t < Lk) { sc[t] = expf(sc[t] - mx); sum += sc[t]; }
+  const float inv = 1.0f / sum;
+  float dot = 0.f;
+#pragma unroll
+  for (int t = 0; t < LK; ++t)
+    if (t < Lk) { sc[t] *= inv; dot += sc[t] * dp[t]; }       // sc = P
+  float ds[LK];
+#pragma unroll
+  for (int t = 0; t < LK; ++t) ds[t] = t < Lk ? sc[t] * (dp[t] - dot) * scale : 0.f;   // dS * scale
+  float* dqr = dq + (static_cast<long>(n) * Lq + lc) * C + cb;
+  for (int i = g; i < nf4; i += G) {
+    const float4 qv = ld4(qr + 4 * i), gv = ld4(gr + 4 * i);
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) {
+        const float4 kv = ld4(Ks + t * d + 4 * i);
+        acc.x = fmaf(ds[t], kv.x, acc.x); acc.y = fmaf(ds[t], kv.y, acc.y);
+        acc.z = fmaf(ds[t], kv.z, acc.z); acc.w = fmaf(ds[t], kv.w, acc.w);
+        if (valid) {
+          float* dk = dKs + t * d + 4 * i;
+          float* dv = dVs + t * d + 4 * i;
+          atomicAdd(dk + 0, ds[t] * qv.x); atomicAdd(dk + 1, ds[t] * qv.y);
+          atomicAdd(dk + 2, ds[t] * qv.z); atomicAdd(dk + 3, ds[t] * qv.w);
+          atomicAdd(dv + 0, sc[t] * gv.x); atomicAdd(dv + 1, sc[t] * gv.y);
+          atomicAdd(dv + 2, sc[t] * gv.z); atomicAdd(dv + 3, sc[t] * gv.w);
+        }
+      }
+    }
+    if (valid) st4(dqr + 4 * i, acc);
+  }
+  __syncthreads();
+  // part[n][block][{dK, dV}][Lk][C]: this head's d columns
+  float* o = part + (static_cast<long>(n) * gridDim.x + blockIdx.x) * 2 * Lk * C;
+  for (int i = threadIdx.x; i < 2 * Lk * nf4; i += 256) {
+    const int which = i / (Lk * nf4), r = i - which * Lk * nf4;
+    const int t = r / nf4, j = (r - t * nf4) * 4;
+    st4(o + (static_cast<long>(which) * Lk + t) * C + cb + j, ld4((which ? dVs : dKs) + t * d + j));
+  }
+}
+
 #define DS_ROW_DISPATCH_B(C, CALL)                                \
   do {                                                            \
     const int c4 = (C) / 4;                                       \
@@ -364,4 +557,97 @@ extern "C" int diffsal_dropout(const float* x, float* out, size_t n, float p, ui
                      static_cast<hipStream_t>(stream), x, out, static_cast<long>(n), p,
                      static_cast<unsigned>(seed & 0xFFFFFFFFu), static_cast<unsigned>(seed >> 32));
   return check_launch("dropout");
+}
+
+extern "C" int diffsal_dwconv(const float* x, const float* w, float* out, int N, int H, int W, int C, int k, int stride,
+                              int pad, diffsal_stream_t stream) {
+  DS_REQUIRE(x && w && out, DIFFSAL_E_ARG, "dwconv: null argument");
+  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0, DIFFSAL_E_SHAPE, "dwconv: bad shape");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  DS_REQUIRE(Ho > 0 && Wo > 0, DIFFSAL_E_SHAPE, "dwconv: empty output");
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_grid_b(static_cast<long>(N) * Ho * Wo * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, w, out, N, H, W, C, Ho, Wo, k, stride, pad);
+  return check_launch("dwconv");
+}
+
+extern "C" int diffsal_dwconv_bwd_data(const float* du, const float* w, float* dx, int N, int H, int W, int C, int k,
+                                       int stride, int pad, diffsal_stream_t stream) {
+  DS_REQUIRE(du && w && dx, DIFFSAL_E_ARG, "dwconv_bwd_data: null argument");
+  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0, DIFFSAL_E_SHAPE, "dwconv_bwd_data: bad shape");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(ew_grid_b(static_cast<long>(N) * H * W * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), du, w, dx, N, H, W, C, Ho, Wo, k, stride, pad);
+  return check_launch("dwconv_bwd_data");
+}
+
+extern "C" int diffsal_dwconv_bwd_weight_chunks(int N, int H, int W, int k, int stride, int pad) {
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const long P = static_cast<long>(N) * Ho * Wo;
+  long chunks = 2048 / (k * k);
+  chunks = chunks < 1 ? 1 : chunks;
+  while (chunks > 1 && P / chunks < 32) chunks >>= 1;
+  return static_cast<int>(chunks > 256 ? 256 : chunks);
+}
+
+extern "C" int diffsal_dwconv_bwd_weight(const float* x, const float* du, float* part, int N, int H, int W, int C, int k,
+                                         int stride, int pad, diffsal_stream_t stream) {
+  DS_REQUIRE(x && du && part, DIFFSAL_E_ARG, "dwconv_bwd_weight: null argument");
+  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && C <= 4096 && k > 0 && stride > 0 && pad >= 0, DIFFSAL_E_SHAPE,
+             "dwconv_bwd_weight: bad shape");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int chunks = diffsal_dwconv_bwd_weight_chunks(N, H, W, k, stride, pad);
+  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(chunks, k * k), dim3(256), C * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, du, part, N, H, W, C, Ho, Wo, k, stride, pad, chunks);
+  return check_launch("dwconv_bwd_weight");
+}
+
+template <int LK, int G>
+static void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq,
+                                 float* part, int N, int Lq, int Lk, int C, int heads, float scale, int blocks,
+                                 hipStream_t s) {
+  const size_t lds = static_cast<size_t>(4) * Lk * (C / heads) * sizeof(float);
+  static bool raised = false;
+  if (lds > 64 * 1024 && !raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<LK, G>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  hipLaunchKernelGGL((attention_bwd_kernel<LK, G>), dim3(blocks, N, heads), dim3(256), lds, s, q, k, v, dout, dq, part, Lq, Lk,
+                     C, heads, scale);
+}
+
+static int attention_g(int C, int heads) {
+  const int nf4 = C / heads / 4;
+  int G = 1;
+  while (G < 16 && nf4 / (2 * G) >= 3) G *= 2;
+  return G == 2 ? 4 : G;
+}
+
+extern "C" int diffsal_attention_bwd_blocks(int Lq, int C, int heads) {
+  const int qpb = 4 * (64 / attention_g(C, heads));  // one head per workgroup: all four waves take queries
+  return (Lq + qpb - 1) / qpb;
+}
+
+extern "C" int diffsal_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq,
+                                     float* part, int N, int Lq, int Lk, int C, int heads, float scale,
+                                     diffsal_stream_t stream) {
+  DS_REQUIRE(q && k && v && dout && dq && part, DIFFSAL_E_ARG, "attention_bwd: null argument");
+  DS_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && Lk <= 32 && (heads == 1 || heads == 2 || heads == 4) && C % heads == 0 &&
+                 (C / heads) % 4 == 0,
+             DIFFSAL_E_SHAPE, "attention_bwd: bad shape");
+  DS_REQUIRE(static_cast<size_t>(4) * Lk * (C / heads) * sizeof(float) <= 160 * 1024, DIFFSAL_E_SHAPE,
+             "attention_bwd: K/V + gradients of one head exceed LDS (Lk=%d d=%d)", Lk, C / heads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int G = attention_g(C, heads);
+  const int blocks = diffsal_attention_bwd_blocks(Lq, C, heads);
+#define ABW(L)                                                                                                        \
+  switch (G) {                                                                                                        \
+    case 16: launch_attention_bwd<L, 16>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;      \
+    case 8: launch_attention_bwd<L, 8>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;        \
+    case 4: launch_attention_bwd<L, 4>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;        \
+    default: launch_attention_bwd<L, 1>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;       \
+  }
+  if (Lk <= 4) { ABW(4) } else if (Lk <= 8) { ABW(8) } else if (Lk <= 18) { ABW(18) } else { ABW(32) }
+#undef ABW
+  return check_launch("attention_bwd");
 }

@@ -357,3 +357,44 @@ def gelu(x: Tensor) -> Tensor:
     one = torch.ones((1, Cc), device=x.device, dtype=torch.float32)
     zero = torch.zeros((1, Cc), device=x.device, dtype=torch.float32)
     return affine_act(x, one, zero, x.numel() // Cc, ACT_GELU)
+
+
+def dwconv(x: Tensor, w: Tensor, k: int, stride: int, pad: int) -> Tensor:
+    """Depthwise k x k conv on NHWC x with w [k*k, C]."""
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_dwconv(_p(x), _p(w), _p(out), N, H, W, Cc, k, stride, pad, _stream()), "dwconv")
+    return out
+
+
+def dwconv_bwd(x: Tensor, w: Tensor, du: Tensor, k: int, stride: int, pad: int, need_dx=True, need_dw=True):
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    dx = dw = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        _lib.check(lib.diffsal_dwconv_bwd_data(_p(du), _p(w), _p(dx), N, H, W, Cc, k, stride, pad, _stream()),
+                   "dwconv_bwd_data")
+    if need_dw:
+        chunks = lib.diffsal_dwconv_bwd_weight_chunks(N, H, W, k, stride, pad)
+        part = torch.empty((k * k, chunks, Cc), device=x.device, dtype=torch.float32)
+        _lib.check(lib.diffsal_dwconv_bwd_weight(_p(x), _p(du), _p(part), N, H, W, Cc, k, stride, pad, _stream()),
+                   "dwconv_bwd_weight")
+        dw = part.double().sum(dim=1).float()
+    return dx, dw
+
+
+def attention_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, heads: int, scale: float):
+    """-> (dq, dk, dv)."""
+    lib = _lib.load()
+    N, Lq, Cc = q.shape
+    Lk = k.shape[1]
+    blocks = lib.diffsal_attention_bwd_blocks(Lq, Cc, heads)
+    part = torch.empty((N, blocks, 2, Lk, Cc), device=q.device, dtype=torch.float32)
+    dq = torch.empty_like(q)
+    _lib.check(lib.diffsal_attention_bwd(_p(q), _p(k), _p(v), _p(dout), _p(dq), _p(part), N, Lq, Lk, Cc, heads, scale,
+                                         _stream()), "attention_bwd")
+    s = part.sum(dim=1)
+    return dq, s[:, 0].contiguous(), s[:, 1].contiguous()

@@ -129,6 +129,23 @@ int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, f
  * Replaces nn.Dropout(0.1) of ResnetBlock in train mode (sal_unet.py:109,133). */
 int diffsal_dropout(const float* x, float* out, size_t n, float p, uint64_t seed, diffsal_stream_t stream);
 
+/* ---- K16 (training): depthwise projections and attention ---------------------------------------------
+ * Plain depthwise k x k convolution on NHWC (w: [k*k][C]) and its two gradients; the training path runs
+ * conv_proj_q/k/v (attention.py:36-76) as dwconv + LayerNorm so each half has an exact backward.
+ * bwd_weight writes part[k*k][chunks][C], chunks = diffsal_dwconv_bwd_weight_chunks(); the caller sums the chunks. */
+int diffsal_dwconv(const float* x, const float* w, float* out, int N, int H, int W, int C, int k, int stride, int pad,
+                   diffsal_stream_t stream);
+int diffsal_dwconv_bwd_data(const float* du, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
+                            int pad, diffsal_stream_t stream);
+int diffsal_dwconv_bwd_weight_chunks(int N, int H, int W, int k, int stride, int pad);
+int diffsal_dwconv_bwd_weight(const float* x, const float* du, float* part, int N, int H, int W, int C, int k,
+                              int stride, int pad, diffsal_stream_t stream);
+/* Backward of diffsal_attention: dq [N,Lq,C]; dk, dv as per-workgroup partials part[N][blocks][2][Lk][C],
+ * blocks = diffsal_attention_bwd_blocks(); the caller sums over blocks. */
+int diffsal_attention_bwd_blocks(int Lq, int C, int heads);
+int diffsal_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* part,
+                          int N, int Lq, int Lk, int C, int heads, float scale, diffsal_stream_t stream);
+
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
  * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,

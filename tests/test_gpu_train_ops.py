@@ -166,3 +166,36 @@ def test_gelu_and_add_backward(ag):
     xd, zd = x.detach().to(DEV).requires_grad_(True), z.detach().to(DEV).requires_grad_(True)
     agops.add(agops.gelu(xd), zd).backward(gy.to(DEV))
     assert rel(xd.grad, x.grad) < 2e-5 and rel(zd.grad, z.grad) < 1e-6
+
+
+@pytest.mark.parametrize("C,H,W,k,stride,pad", [(96, 16, 32, 16, 16, 0), (192, 9, 13, 4, 4, 0), (64, 11, 7, 3, 1, 1), (768, 7, 12, 2, 2, 0)])
+def test_depthwise_conv_backward(ag, C, H, W, k, stride, pad):
+    agops, _ = ag
+    x = rnd("dwx%d" % C, 2, C, H, W).requires_grad_(True)
+    w = rnd("dww%d" % C, C, 1, k, k, scale=1.0 / k).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad, groups=C)
+    gy = rnd("dwgy", *y.shape)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(DEV).requires_grad_(True)
+    wd = w.detach().reshape(C, k * k).t().contiguous().to(DEV).requires_grad_(True)
+    yd = agops.dwconv(xd, wd, k, stride, pad)
+    assert rel(yd, nhwc(y)) < 2e-5
+    yd.backward(nhwc(gy).to(DEV))
+    assert rel(xd.grad, nhwc(x.grad)) < 2e-5
+    assert rel(wd.grad, w.grad.reshape(C, k * k).t()) < 2e-5
+
+
+@pytest.mark.parametrize("C,Lq,Lk,heads", [(96, 200, 18, 2), (768, 84, 18, 2), (32, 64, 2, 2)])
+def test_attention_backward(ag, C, Lq, Lk, heads):
+    agops, _ = ag
+    n = 3
+    q, k, v = (rnd(nm, n, L, C).requires_grad_(True) for nm, L in (("abq", Lq), ("abk", Lk), ("abv", Lk)))
+    d = C // heads
+    qh, kh, vh = (t.reshape(n, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = (F.softmax(qh @ kh.transpose(-1, -2) * C ** -0.5, -1) @ vh).transpose(1, 2).reshape(n, Lq, C)
+    go = rnd("abgo", n, Lq, C)
+    o.backward(go)
+    qd, kd, vd = (t.detach().to(DEV).requires_grad_(True) for t in (q, k, v))
+    od = agops.attention(qd, kd, vd, heads, C ** -0.5)
+    od.backward(go.to(DEV))
+    assert rel(qd.grad, q.grad) < 5e-5 and rel(kd.grad, k.grad) < 5e-5 and rel(vd.grad, v.grad) < 5e-5
