@@ -289,3 +289,110 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(q, k, v, heads, scale):
     return AttentionFn.apply(q, k, v, heads, scale)
+
+
+class ResizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        ctx.hw = x.shape[1:3]
+        return ops.resize_bilinear(x, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.resize_bilinear_bwd(dy.contiguous(), ctx.hw[0], ctx.hw[1]), None, None
+
+
+def resize_bilinear(x, H, W):
+    return ResizeFn.apply(x, H, W)
+
+
+class ResizeSumFn(torch.autograd.Function):
+    """sum_i bilinear(x_i -> (H, W)); the adjoint is one gather-form resize backward per input."""
+
+    @staticmethod
+    def forward(ctx, H, W, *xs):
+        ctx.shapes = [x.shape[1:3] for x in xs]
+        return ops.resize_sum(list(xs), H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return (None, None) + tuple(ops.resize_bilinear_bwd(dy, h, w) for h, w in ctx.shapes)
+
+
+def resize_sum(xs, H, W):
+    return ResizeSumFn.apply(H, W, *xs)
+
+
+class PackFramesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vis, noise):
+        ctx.tv = vis.shape[2]
+        ctx.has_noise = noise is not None
+        return ops.pack_frames(vis, noise)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dvis = ops.unpack_frames(dout, ctx.tv) if ctx.needs_input_grad[0] else None
+        dnoise = dout[:, ctx.tv].contiguous() if (ctx.has_noise and ctx.needs_input_grad[1]) else None
+        return dvis, dnoise
+
+
+def pack_frames(vis, noise):
+    return PackFramesFn.apply(vis, noise)
+
+
+class HeadSigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, w, b):
+        s = ops.head_sigmoid(y, w, b)
+        ctx.save_for_backward(y, w, s)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        y, w, s = ctx.saved_tensors
+        dy, dw, db = ops.head_bwd(y, w, s, ds.contiguous())
+        return dy, dw, db
+
+
+def head_sigmoid(y, w, b):
+    return HeadSigmoidFn.apply(y, w, b)
+
+
+class ConvInFn(torch.autograd.Function):
+    """conv_in (1 -> C); the noisy map x carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w9, bias, skip_mod):
+        ctx.save_for_backward(x)
+        return ops.conv_in(x, w9, bias, skip_mod)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dw, db = ops.conv_in_bwd(x, dy.contiguous())
+        return None, dw, db, None
+
+
+def conv_in(x, w9, bias, skip_mod=0):
+    return ConvInFn.apply(x, w9, bias, skip_mod)
+
+
+class DenseSmallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, swish_in):
+        ctx.swish_in = swish_in
+        ctx.save_for_backward(x, w)
+        return ops.dense_small(x, w, b, swish_in)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.dense_small_bwd(x, w, dout.contiguous(), ctx.swish_in)
+        return dx, dw, db, None
+
+
+def dense_small(x, w, b, swish_in):
+    return DenseSmallFn.apply(x, w, b, swish_in)

@@ -452,6 +452,179 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the bilinear resize (align_corners=False), gather form (deterministic, no atomics):
+// dx[n, iy, ix, :] = sum over the outputs (Y, X) whose two taps per axis include (iy, ix) of wy * wx * dy[n, Y, X, :].
+// Backward of nn.Upsample(x2) / F.interpolate (common_block.py:197, sal_unet.py:325-327,482-484).
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                         int h, int w, int H, int W, int C, float sy, float sx) {
+  const int cv = C / VEC;
+  const long total = static_cast<long>(N) * h * w * cv;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % cv) * VEC;
+    long pix = i / cv;
+    const int ix = static_cast<int>(pix % w); pix /= w;
+    const int iy = static_cast<int>(pix % h);
+    const int n = static_cast<int>(pix / h);
+    const int Ylo = max(0, static_cast<int>(floorf((iy - 0.5f) / sy - 0.5f)) - 1);
+    const int Yhi = min(H - 1, static_cast<int>(ceilf((iy + 1.5f) / sy - 0.5f)) + 1);
+    const int Xlo = max(0, static_cast<int>(floorf((ix - 0.5f) / sx - 0.5f)) - 1);
+    const int Xhi = min(W - 1, static_cast<int>(ceilf((ix + 1.5f) / sx - 0.5f)) + 1);
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+      int y0, y1; float ly;
+      bilin_coord(Y, sy, h, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = Xlo; X <= Xhi; ++X) {
+        int x0, x1; float lx;
+        bilin_coord(X, sx, w, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const float* g = dy + ((static_cast<long>(n) * H + Y) * W + X) * C + c;
+        const float ww = wy * wx;
+        if constexpr (VEC == 4) {
+          const float4 v = ld4(g);
+          acc[0] = fmaf(ww, v.x, acc[0]); acc[1] = fmaf(ww, v.y, acc[1]);
+          acc[2] = fmaf(ww, v.z, acc[2]); acc[3] = fmaf(ww, v.w, acc[3]);
+        } else {
+          acc[0] = fmaf(ww, g[0], acc[0]);
+        }
+      }
+    }
+    float* o = dx + i * VEC;
+    if constexpr (VEC == 4) st4(o, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    else o[0] = acc[0];
+  }
+}
+
+// frames [B][Tin*hw][C] (first Q = Tv*hw rows) -> NCTHW [B][C][Q]: backward of pack_frames for the visual features
+__global__ __launch_bounds__(256) void unpack_frames_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                            int Q, long in_batch_stride, int tiles_q) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y;
+  const int tq = blockIdx.x % tiles_q, tcx = blockIdx.x / tiles_q;
+  const int q0 = tq * 64, c0 = tcx * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* src = in + static_cast<long>(b) * in_batch_stride;
+  for (int r = ty; r < 64; r += 4) {  // r: q in tile, tx: channel (contiguous reads)
+    const int q = q0 + r, c = c0 + tx;
+    tile[r][tx] = (q < Q && c < C) ? src[static_cast<long>(q) * C + c] : 0.f;
+  }
+  __syncthreads();
+  float* dst = out + static_cast<long>(b) * C * Q;
+  for (int r = ty; r < 64; r += 4) {  // r: channel in tile, tx: q (contiguous writes)
+    const int c = c0 + r, q = q0 + tx;
+    if (c < C && q < Q) dst[static_cast<long>(c) * Q + q] = tile[tx][r];
+  }
+}
+
+// head (1x1 conv C -> 1 + sigmoid) backward: dpre[m] = ds[m] * s[m] (1 - s[m]);
+// dy[m, c] = dpre[m] w[c];  part[block][C+1] = (sum_m dpre[m] y[m, c], sum_m dpre[m])
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                       const float* __restrict__ s_out, const float* __restrict__ ds,
+                                                       float* __restrict__ dy, float* __restrict__ part, long M, int C) {
+  extern __shared__ float sh[];  // [C + 1]
+  const int c4n = C >> 2;
+  const int rpp = 256 / c4n > 0 ? 256 / c4n : 1;
+  const int c4 = threadIdx.x % c4n, rs = threadIdx.x / c4n;
+  float4 acc = make_float4(0, 0, 0, 0);
+  float accb = 0.f;
+  if (rs < rpp) {
+    const float4 wv = ld4(w + c4 * 4);
+    for (long m = static_cast<long>(blockIdx.x) * rpp + rs; m < M; m += static_cast<long>(gridDim.x) * rpp) {
+      const float sv = s_out[m];
+      const float dp = ds[m] * sv * (1.f - sv);
+      const float4 yv = ld4(y + m * C + c4 * 4);
+      st4(dy + m * C + c4 * 4, make_float4(dp * wv.x, dp * wv.y, dp * wv.z, dp * wv.w));
+      acc.x = fmaf(dp, yv.x, acc.x); acc.y = fmaf(dp, yv.y, acc.y); acc.z = fmaf(dp, yv.z, acc.z); acc.w = fmaf(dp, yv.w, acc.w);
+      if (c4 == 0) accb += dp;
+    }
+  }
+  for (int i = threadIdx.x; i <= C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  if (rs < rpp) {
+    atomicAdd(&sh[c4 * 4 + 0], acc.x); atomicAdd(&sh[c4 * 4 + 1], acc.y);
+    atomicAdd(&sh[c4 * 4 + 2], acc.z); atomicAdd(&sh[c4 * 4 + 3], acc.w);
+    if (c4 == 0) atomicAdd(&sh[C], accb);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= C; i += 256) part[static_cast<long>(blockIdx.x) * (C + 1) + i] = sh[i];
+}
+
+// conv_in (1 -> C, 3x3, pad 1) parameter gradients: part[tap 0..8 | bias][chunk][C]
+__global__ __launch_bounds__(256) void conv_in_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ part, int B, int H, int W, int C,
+                                                          int chunks) {
+  extern __shared__ float sh[];  // [C]
+  const int tap = blockIdx.y, chunk = blockIdx.x;  // tap 9 = bias
+  const int ky = tap / 3, kx = tap - ky * 3;
+  const int c4n = C >> 2;
+  const int ppp = 256 / c4n > 0 ? 256 / c4n : 1;
+  const int c4 = threadIdx.x % c4n, ps = threadIdx.x / c4n;
+  const long P = static_cast<long>(B) * H * W;
+  const long pb = P * chunk / chunks, pe = P * (chunk + 1) / chunks;
+  float4 s = make_float4(0, 0, 0, 0);
+  if (ps < ppp)
+    for (long pix = pb + ps; pix < pe; pix += ppp) {
+      float xv = 1.f;
+      if (tap < 9) {
+        long t = pix;
+        const int xw = static_cast<int>(t % W); t /= W;
+        const int yh = static_cast<int>(t % H);
+        const long n = t / H;
+        const int iy = yh + ky - 1, ix = xw + kx - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        xv = x[(n * H + iy) * W + ix];
+      }
+      const float4 g = ld4(dy + pix * C + c4 * 4);
+      s.x = fmaf(xv, g.x, s.x); s.y = fmaf(xv, g.y, s.y); s.z = fmaf(xv, g.z, s.z); s.w = fmaf(xv, g.w, s.w);
+    }
+  for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  if (ps < ppp) {
+    atomicAdd(&sh[c4 * 4 + 0], s.x); atomicAdd(&sh[c4 * 4 + 1], s.y);
+    atomicAdd(&sh[c4 * 4 + 2], s.z); atomicAdd(&sh[c4 * 4 + 3], s.w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(tap) * chunks + chunk) * C + i] = sh[i];
+}
+
+// dense_small backward: out = W f(in) + b  (f = swish if swish_in).  One thread per output entry, tiny sizes.
+//   dW[n,k] = sum_b dout[b,n] f(in[b,k]);  db[n] = sum_b dout[b,n];  din[b,k] = f'(in[b,k]) sum_n dout[b,n] W[n,k]
+__global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ dout, float* __restrict__ dw,
+                                                              float* __restrict__ db, float* __restrict__ din, int B,
+                                                              int K, int N, int swish_in) {
+  const long nw = static_cast<long>(N) * K, nd = static_cast<long>(B) * K;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < nw + N + nd; i += static_cast<long>(gridDim.x) * 256) {
+    if (i < nw) {
+      const int n = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<long>(n) * K);
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float v = in[b * K + k];
+        s = fmaf(dout[b * N + n], swish_in ? swishf(v) : v, s);
+      }
+      dw[i] = s;
+    } else if (i < nw + N) {
+      const int n = static_cast<int>(i - nw);
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dout[b * N + n];
+      db[n] = s;
+    } else {
+      const long j = i - nw - N;
+      const int b = static_cast<int>(j / K), k = static_cast<int>(j - static_cast<long>(b) * K);
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s = fmaf(dout[b * N + n], w[static_cast<long>(n) * K + k], s);
+      din[j] = swish_in ? s * swish_grad(in[j]) : s;
+    }
+  }
+}
+
 #define DS_ROW_DISPATCH_B(C, CALL)                                \
   do {                                                            \
     const int c4 = (C) / 4;                                       \
@@ -650,4 +823,58 @@ extern "C" int diffsal_attention_bwd(const float* q, const float* k, const float
   if (Lk <= 4) { ABW(4) } else if (Lk <= 8) { ABW(8) } else if (Lk <= 18) { ABW(18) } else { ABW(32) }
 #undef ABW
   return check_launch("attention_bwd");
+}
+
+extern "C" int diffsal_resize_bilinear_bwd(const float* dy, float* dx, int N, int h, int w, int H, int W, int C,
+                                           diffsal_stream_t stream) {
+  DS_REQUIRE(dy && dx, DIFFSAL_E_ARG, "resize_bilinear_bwd: null argument");
+  DS_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, DIFFSAL_E_SHAPE, "resize_bilinear_bwd: bad shape");
+  const float sy = static_cast<float>(h) / static_cast<float>(H), sx = static_cast<float>(w) / static_cast<float>(W);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (C % 4 == 0 && aligned16(dy) && aligned16(dx))
+    hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(ew_grid_b(static_cast<long>(N) * h * w * (C / 4))), dim3(256), 0, s,
+                       dy, dx, N, h, w, H, W, C, sy, sx);
+  else
+    hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(ew_grid_b(static_cast<long>(N) * h * w * C)), dim3(256), 0, s, dy, dx,
+                       N, h, w, H, W, C, sy, sx);
+  return check_launch("resize_bilinear_bwd");
+}
+
+extern "C" int diffsal_unpack_frames(const float* frames, float* vis_grad, int B, int C, int Tv, int Tin, int hw,
+                                     diffsal_stream_t stream) {
+  DS_REQUIRE(frames && vis_grad, DIFFSAL_E_ARG, "unpack_frames: null argument");
+  DS_REQUIRE(B > 0 && C > 0 && Tv > 0 && Tin >= Tv && hw > 0, DIFFSAL_E_SHAPE, "unpack_frames: bad shape");
+  const int Q = Tv * hw, tiles_q = (Q + 63) / 64, tiles_c = (C + 63) / 64;
+  hipLaunchKernelGGL(unpack_frames_kernel, dim3(tiles_q * tiles_c, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     frames, vis_grad, C, Q, static_cast<long>(Tin) * hw * C, tiles_q);
+  return check_launch("unpack_frames");
+}
+
+extern "C" int diffsal_head_bwd(const float* y, const float* w, const float* s_out, const float* ds, float* dy,
+                                float* part, int blocks, int M, int C, diffsal_stream_t stream) {
+  DS_REQUIRE(y && w && s_out && ds && dy && part, DIFFSAL_E_ARG, "head_bwd: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && blocks > 0, DIFFSAL_E_SHAPE, "head_bwd: bad shape");
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), (C + 1) * sizeof(float),
+                     static_cast<hipStream_t>(stream), y, w, s_out, ds, dy, part, static_cast<long>(M), C);
+  return check_launch("head_bwd");
+}
+
+extern "C" int diffsal_conv_in_bwd(const float* x, const float* dy, float* part, int B, int H, int W, int C, int chunks,
+                                   diffsal_stream_t stream) {
+  DS_REQUIRE(x && dy && part, DIFFSAL_E_ARG, "conv_in_bwd: null argument");
+  DS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && chunks > 0, DIFFSAL_E_SHAPE,
+             "conv_in_bwd: bad shape");
+  hipLaunchKernelGGL(conv_in_bwd_kernel, dim3(chunks, 10), dim3(256), C * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, dy, part, B, H, W, C, chunks);
+  return check_launch("conv_in_bwd");
+}
+
+extern "C" int diffsal_dense_small_bwd(const float* in, const float* w, const float* dout, float* dw, float* db,
+                                       float* din, int B, int K, int N, int swish_in, diffsal_stream_t stream) {
+  DS_REQUIRE(in && w && dout && dw && db && din, DIFFSAL_E_ARG, "dense_small_bwd: null argument");
+  DS_REQUIRE(B > 0 && K > 0 && N > 0, DIFFSAL_E_SHAPE, "dense_small_bwd: bad shape");
+  const long total = static_cast<long>(N) * K + N + static_cast<long>(B) * K;
+  hipLaunchKernelGGL(dense_small_bwd_kernel, dim3(ew_grid_b(total)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     w, dout, dw, db, din, B, K, N, swish_in);
+  return check_launch("dense_small_bwd");
 }

@@ -398,3 +398,57 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, heads: int, sca
                                          _stream()), "attention_bwd")
     s = part.sum(dim=1)
     return dq, s[:, 0].contiguous(), s[:, 1].contiguous()
+
+
+def resize_bilinear_bwd(dy: Tensor, h: int, w: int) -> Tensor:
+    lib = _lib.load()
+    N, H, W, Cc = dy.shape
+    dx = torch.empty((N, h, w, Cc), device=dy.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_resize_bilinear_bwd(_p(dy), _p(dx), N, h, w, H, W, Cc, _stream()), "resize_bilinear_bwd")
+    return dx
+
+
+def unpack_frames(frames_grad: Tensor, Tv: int) -> Tensor:
+    """[B,Tin,h,w,C] -> gradient of the NCTHW visual features [B,C,Tv,h,w]."""
+    lib = _lib.load()
+    B, Tin, h, w, Cc = frames_grad.shape
+    out = torch.empty((B, Cc, Tv, h, w), device=frames_grad.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_unpack_frames(_p(frames_grad), _p(out), B, Cc, Tv, Tin, h * w, _stream()), "unpack_frames")
+    return out
+
+
+def head_bwd(y: Tensor, w: Tensor, s_out: Tensor, ds: Tensor):
+    """-> (dy, dw [C], db [1])."""
+    lib = _lib.load()
+    Cc = y.shape[-1]
+    M = y.numel() // Cc
+    blocks = min(1024, max(1, M // 64))
+    part = torch.empty((blocks, Cc + 1), device=y.device, dtype=torch.float32)
+    dy = torch.empty_like(y)
+    _lib.check(lib.diffsal_head_bwd(_p(y), _p(w), _p(s_out), _p(ds), _p(dy), _p(part), blocks, M, Cc, _stream()),
+               "head_bwd")
+    s = part.double().sum(dim=0).float()
+    return dy, s[:Cc].contiguous(), s[Cc:].contiguous()
+
+
+def conv_in_bwd(x: Tensor, dy: Tensor):
+    """-> (dw [C, 9], db [C]) of conv_in."""
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    Cc = dy.shape[-1]
+    chunks = 128
+    part = torch.empty((10, chunks, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_conv_in_bwd(_p(x), _p(dy), _p(part), B, H, W, Cc, chunks, _stream()), "conv_in_bwd")
+    s = part.double().sum(dim=1).float()
+    return s[:9].t().contiguous(), s[9].contiguous()
+
+
+def dense_small_bwd(x: Tensor, w: Tensor, dout: Tensor, swish_in: bool):
+    """-> (dx, dw, db)."""
+    lib = _lib.load()
+    B, K = x.shape
+    N = w.shape[0]
+    dw, db, dx = torch.empty_like(w), torch.empty((N,), device=x.device), torch.empty_like(x)
+    _lib.check(lib.diffsal_dense_small_bwd(_p(x), _p(w), _p(dout), _p(dw), _p(db), _p(dx), B, K, N, int(swish_in),
+                                           _stream()), "dense_small_bwd")
+    return dx, dw, db

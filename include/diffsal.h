@@ -146,6 +146,21 @@ int diffsal_attention_bwd_blocks(int Lq, int C, int heads);
 int diffsal_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* part,
                           int N, int Lq, int Lk, int C, int heads, float scale, diffsal_stream_t stream);
 
+/* ---- K16 (training): remaining backward kernels ----------------------------------------------------
+ * adjoint of diffsal_resize_bilinear (dy [N,H,W,C] -> dx [N,h,w,C]); backward of pack_frames for the visual
+ * features (frames [B,Tin,hw,C] -> NCTHW [B,C,Tv,hw]); head backward (dy = dpre w, part[blocks][C+1] holds
+ * sum dpre*y and sum dpre); conv_in parameter gradients (part[10][chunks][C]: 9 taps + bias); dense_small backward. */
+int diffsal_resize_bilinear_bwd(const float* dy, float* dx, int N, int h, int w, int H, int W, int C,
+                                diffsal_stream_t stream);
+int diffsal_unpack_frames(const float* frames, float* vis_grad, int B, int C, int Tv, int Tin, int hw,
+                          diffsal_stream_t stream);
+int diffsal_head_bwd(const float* y, const float* w, const float* s_out, const float* ds, float* dy, float* part,
+                     int blocks, int M, int C, diffsal_stream_t stream);
+int diffsal_conv_in_bwd(const float* x, const float* dy, float* part, int B, int H, int W, int C, int chunks,
+                        diffsal_stream_t stream);
+int diffsal_dense_small_bwd(const float* in, const float* w, const float* dout, float* dw, float* db, float* din,
+                            int B, int K, int N, int swish_in, diffsal_stream_t stream);
+
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
  * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,

@@ -199,3 +199,68 @@ def test_attention_backward(ag, C, Lq, Lk, heads):
     od = agops.attention(qd, kd, vd, heads, C ** -0.5)
     od.backward(go.to(DEV))
     assert rel(qd.grad, q.grad) < 5e-5 and rel(kd.grad, k.grad) < 5e-5 and rel(vd.grad, v.grad) < 5e-5
+
+
+@pytest.mark.parametrize("hw,HW,C", [((7, 12), (14, 24), 96), ((3, 5), (48, 80), 32), ((56, 96), (112, 192), 1)])
+def test_resize_backward_is_the_adjoint(ag, hw, HW, C):
+    agops, _ = ag
+    x = rnd("rbx", 2, C, *hw).requires_grad_(True)
+    y = F.interpolate(x, size=HW, mode="bilinear", align_corners=False)
+    gy = rnd("rbgy", *y.shape)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(DEV).requires_grad_(True)
+    agops.resize_bilinear(xd, *HW).backward(nhwc(gy).to(DEV))
+    assert rel(xd.grad, nhwc(x.grad)) < 2e-5
+
+
+def test_resize_sum_backward(ag):
+    agops, _ = ag
+    xs = [rnd("rsb%d" % i, 2, 64, 3 * 2 ** i, 5 * 2 ** i).requires_grad_(True) for i in range(4)]
+    y = sum(F.interpolate(x, size=(48, 80), mode="bilinear", align_corners=False) for x in xs)
+    gy = rnd("rsbgy", *y.shape)
+    y.backward(gy)
+    xd = [nhwc(x.detach()).to(DEV).requires_grad_(True) for x in xs]
+    agops.resize_sum(xd, 48, 80).backward(nhwc(gy).to(DEV))
+    for a, b in zip(xd, xs):
+        assert rel(a.grad, nhwc(b.grad)) < 2e-5
+
+
+def test_pack_frames_backward(ag):
+    agops, _ = ag
+    vis = rnd("pbv", 2, 96, 8, 7, 12).requires_grad_(True)
+    nz = rnd("pbn", 2, 7, 12, 96).requires_grad_(True)
+    out = torch.cat([vis, nz.permute(0, 3, 1, 2).unsqueeze(2)], dim=2).permute(0, 2, 3, 4, 1)
+    g = rnd("pbg", *out.shape)
+    out.backward(g)
+    vd, nd = vis.detach().to(DEV).requires_grad_(True), nz.detach().to(DEV).requires_grad_(True)
+    agops.pack_frames(vd, nd).backward(g.to(DEV))
+    assert torch.equal(vd.grad.cpu(), vis.grad) and torch.equal(nd.grad.cpu(), nz.grad)
+
+
+def test_head_conv_in_and_dense_small_backward(ag):
+    agops, _ = ag
+    y, w, b = rnd("hby", 2, 96, 10, 12).requires_grad_(True), rnd("hbw", 1, 96, 1, 1, scale=0.2).requires_grad_(True), rnd("hbb", 1).requires_grad_(True)
+    s = torch.sigmoid(F.conv2d(y, w, b))
+    gs = rnd("hbg", *s.shape)
+    s.backward(gs)
+    yd = nhwc(y.detach()).to(DEV).requires_grad_(True)
+    wd, bd = w.detach().reshape(-1).to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    agops.head_sigmoid(yd, wd, bd).backward(nhwc(gs).to(DEV))
+    assert rel(yd.grad, nhwc(y.grad)) < 2e-5 and rel(wd.grad, w.grad.reshape(-1)) < 2e-5 and rel(bd.grad, b.grad) < 2e-5
+
+    x = rnd("cibx", 2, 1, 24, 40)
+    w2, b2 = rnd("cibw", 96, 1, 3, 3, scale=0.3).requires_grad_(True), rnd("cibb", 96, scale=0.1).requires_grad_(True)
+    o = F.conv2d(x, w2, b2, padding=1)
+    go = rnd("cibg", *o.shape)
+    o.backward(go)
+    w2d, b2d = w2.detach().reshape(96, 9).to(DEV).requires_grad_(True), b2.detach().to(DEV).requires_grad_(True)
+    agops.conv_in(x.to(DEV), w2d, b2d, 0).backward(nhwc(go).to(DEV))
+    assert rel(w2d.grad, w2.grad.reshape(96, 9)) < 2e-5 and rel(b2d.grad, b2.grad) < 2e-5
+
+    xi, w3, b3 = rnd("dsx", 4, 384).requires_grad_(True), rnd("dsw", 1344, 384, scale=0.05).requires_grad_(True), rnd("dsb", 1344, scale=0.1).requires_grad_(True)
+    z = F.linear(orc.swish(xi), w3, b3)
+    gz = rnd("dsg", *z.shape)
+    z.backward(gz)
+    xid, w3d, b3d = (t.detach().to(DEV).requires_grad_(True) for t in (xi, w3, b3))
+    agops.dense_small(xid, w3d, b3d, True).backward(gz.to(DEV))
+    assert rel(xid.grad, xi.grad) < 2e-5 and rel(w3d.grad, w3.grad) < 2e-5 and rel(b3d.grad, b3.grad) < 2e-5
