@@ -56,6 +56,7 @@ SIGNATURES = {
     "diffsal_head_bwd": (c_i, [c_f] * 6 + [c_i, c_i, c_i, c_f]),
     "diffsal_conv_in_bwd": (c_i, [c_f, c_f, c_f] + [c_i] * 5 + [c_f]),
     "diffsal_dense_small_bwd": (c_i, [c_f] * 6 + [c_i] * 4 + [c_f]),
+    "diffsal_audio_fuse_bwd": (c_i, [c_f] * 5 + [c_i] * 7 + [c_f]),
     "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -396,3 +396,21 @@ class DenseSmallFn(torch.autograd.Function):
 
 def dense_small(x, w, b, swish_in):
     return DenseSmallFn.apply(x, w, b, swish_in)
+
+
+class AudioFuseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a_small, x, h, w):
+        ctx.hw = (h, w)
+        ctx.save_for_backward(a_small, x)
+        return ops.audio_fuse(a_small, x, h, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a_small, x = ctx.saved_tensors
+        dx, da = ops.audio_fuse_bwd(a_small, x, dout.contiguous(), ctx.hw[0], ctx.hw[1])
+        return da, dx, None, None
+
+
+def audio_fuse(a_small, x, h, w):
+    return AudioFuseFn.apply(a_small, x, h, w)

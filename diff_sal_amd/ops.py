@@ -452,3 +452,14 @@ def dense_small_bwd(x: Tensor, w: Tensor, dout: Tensor, swish_in: bool):
     _lib.check(lib.diffsal_dense_small_bwd(_p(x), _p(w), _p(dout), _p(dw), _p(db), _p(dx), B, K, N, int(swish_in),
                                            _stream()), "dense_small_bwd")
     return dx, dw, db
+
+
+def audio_fuse_bwd(a_small: Tensor, x: Tensor, dout: Tensor, h: int, w: int):
+    """-> (dx [B,T,H,W,C], da_small [B*T, h*w, C])."""
+    lib = _lib.load()
+    B, T, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    da = torch.empty_like(a_small)
+    _lib.check(lib.diffsal_audio_fuse_bwd(_p(a_small), _p(x), _p(dout), _p(dx), _p(da), B, T, H, W, Cc, h, w, _stream()),
+               "audio_fuse_bwd")
+    return dx, da

@@ -161,6 +161,10 @@ int diffsal_conv_in_bwd(const float* x, const float* dy, float* part, int B, int
 int diffsal_dense_small_bwd(const float* in, const float* w, const float* dout, float* dw, float* db, float* din,
                             int B, int K, int N, int swish_in, diffsal_stream_t stream);
 
+/* backward of diffsal_audio_fuse: dout [B,C,T,H,W] -> dx [B,T,H,W,C] (frames layout) and da_small [B*T, h*w, C] */
+int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* dout, float* dx, float* da_small, int B,
+                           int T, int H, int W, int C, int h, int w, diffsal_stream_t stream);
+
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
  * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,

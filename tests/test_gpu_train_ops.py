@@ -264,3 +264,27 @@ def test_head_conv_in_and_dense_small_backward(ag):
     xid, w3d, b3d = (t.detach().to(DEV).requires_grad_(True) for t in (xi, w3, b3))
     agops.dense_small(xid, w3d, b3d, True).backward(gz.to(DEV))
     assert rel(xid.grad, xi.grad) < 2e-5 and rel(w3d.grad, w3.grad) < 2e-5 and rel(b3d.grad, b3.grad) < 2e-5
+
+
+@pytest.mark.parametrize("stage", [0, 1, 3])
+def test_audio_fuse_backward(ag, stage):
+    agops, ops = ag
+    B, T, C, ha, wa = 2, 9, 64, 2, 4
+    H, W = ha * 2 ** stage, wa * 2 ** stage
+    x5 = rnd("abx", B, C, T, H, W).requires_grad_(True)
+    a_small = rnd("aba", B * T, ha * wa, C).requires_grad_(True)
+    # reference: same math as oracle.audio_fusion after the 1x1 conv
+    a = a_small.reshape(B, T, ha, wa, C).permute(0, 4, 1, 2, 3)
+    if ha != H and wa != W:
+        a = F.interpolate(a.reshape(B, C * T, ha, wa), scale_factor=H // ha, mode="nearest").reshape(B, C, T, H, W)
+    m = F.softmax((a * x5).mean(dim=2, keepdim=True), dim=-1)
+    out = a * m
+    g = rnd("abg", *out.shape)
+    out.backward(g)
+    xd = x5.detach().permute(0, 2, 3, 4, 1).contiguous().to(DEV).requires_grad_(True)
+    ad = a_small.detach().to(DEV).requires_grad_(True)
+    od = agops.audio_fuse(ad, xd, ha, wa)
+    assert rel(od, out) < 2e-5
+    od.backward(g.to(DEV))
+    assert rel(xd.grad, x5.grad.permute(0, 2, 3, 4, 1)) < 5e-5
+    assert rel(ad.grad, a_small.grad) < 5e-5
