@@ -46,9 +46,11 @@ __device__ __forceinline__ float swish_grad(float z) {
 __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ y, const float* __restrict__ mu,
                                                        const float* __restrict__ rs, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ part, int M,
+                                                       const float* __restrict__ beta, double* __restrict__ part, int M,
                                                        int C, int seg_rows, int chunks, int mode, int stat_per_seg) {
-  extern __shared__ float sh[];  // [2][C]
+  // per-thread partial sums are fp32 over a handful of rows; everything across threads / workgroups is fp64:
+  // gradient sums such as d(beta) cancel heavily (sum << sum of magnitudes) and must not depend on atomics order
+  extern __shared__ double shd[];  // [2][C]
   const int seg = blockIdx.y, chunk = blockIdx.x;
   const int c4n = C >> 2;
   const int rpp = 256 / c4n > 0 ? 256 / c4n : 1;
@@ -92,15 +94,18 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
       }
     }
   }
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) shd[i] = 0.0;
   __syncthreads();
   if (rsub < rpp) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { atomicAdd(&sh[c + k], s1[k]); atomicAdd(&sh[C + c + k], s2[k]); }
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&shd[c + k], static_cast<double>(s1[k]));
+      atomicAdd(&shd[C + c + k], static_cast<double>(s2[k]));
+    }
   }
   __syncthreads();
-  float* o = part + (static_cast<long>(seg) * chunks + chunk) * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) o[i] = sh[i];
+  double* o = part + (static_cast<long>(seg) * chunks + chunk) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) o[i] = shd[i];
 }
 
 // y = act(x * s[seg, c] + t[seg, c])   (BatchNorm / GroupNorm forward once the statistics are folded into s, t)
@@ -167,9 +172,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 template <int G, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            float* __restrict__ part, int M, int C, float eps) {
+                                                            double* __restrict__ part, int M, int C, float eps) {
   constexpr int ROWS = 256 / G;
-  extern __shared__ float sh[];  // [2][C]
+  extern __shared__ double shd[];  // [2][C]
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   float4 dg[NV], db[NV];
 #pragma unroll
@@ -228,18 +233,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) shd[i] = 0.0;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (gl + i * G) * 4;
     if (c < C) {
-      atomicAdd(&sh[c + 0], dg[i].x); atomicAdd(&sh[c + 1], dg[i].y); atomicAdd(&sh[c + 2], dg[i].z); atomicAdd(&sh[c + 3], dg[i].w);
-      atomicAdd(&sh[C + c + 0], db[i].x); atomicAdd(&sh[C + c + 1], db[i].y); atomicAdd(&sh[C + c + 2], db[i].z); atomicAdd(&sh[C + c + 3], db[i].w);
+      const float dgv[4] = {dg[i].x, dg[i].y, dg[i].z, dg[i].w}, dbv[4] = {db[i].x, db[i].y, db[i].z, db[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&shd[c + k], static_cast<double>(dgv[k]));
+        atomicAdd(&shd[C + c + k], static_cast<double>(dbv[k]));
+      }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) part[static_cast<long>(blockIdx.x) * 2 * C + i] = sh[i];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) part[static_cast<long>(blockIdx.x) * 2 * C + i] = shd[i];
 }
 
 // y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter-based hash of (seed, element index): the same call
@@ -322,9 +331,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
 
 // part[tap][chunk][C]: one workgroup = one tap and one chunk of output pixels; threads = (pixel lane, 4 channels)
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ du,
-                                                                float* __restrict__ part, int N, int H, int W, int C,
+                                                                double* __restrict__ part, int N, int H, int W, int C,
                                                                 int Ho, int Wo, int k, int stride, int pad, int chunks) {
-  extern __shared__ float sh[];  // [C]
+  extern __shared__ double shd[];  // [C]
   const int tap = blockIdx.y, chunk = blockIdx.x;
   const int ky = tap / k, kx = tap - ky * k;
   const int c4n = C >> 2;
@@ -345,14 +354,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __r
       const float4 g = ld4(du + pix * C + c4 * 4);
       s.x = fmaf(a.x, g.x, s.x); s.y = fmaf(a.y, g.y, s.y); s.z = fmaf(a.z, g.z, s.z); s.w = fmaf(a.w, g.w, s.w);
     }
-  for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) shd[i] = 0.0;
   __syncthreads();
   if (ps < ppp) {
-    atomicAdd(&sh[c4 * 4 + 0], s.x); atomicAdd(&sh[c4 * 4 + 1], s.y);
-    atomicAdd(&sh[c4 * 4 + 2], s.z); atomicAdd(&sh[c4 * 4 + 3], s.w);
+    atomicAdd(&shd[c4 * 4 + 0], static_cast<double>(s.x)); atomicAdd(&shd[c4 * 4 + 1], static_cast<double>(s.y));
+    atomicAdd(&shd[c4 * 4 + 2], static_cast<double>(s.z)); atomicAdd(&shd[c4 * 4 + 3], static_cast<double>(s.w));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(tap) * chunks + chunk) * C + i] = sh[i];
+  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(tap) * chunks + chunk) * C + i] = shd[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,8 +536,8 @@ __global__ __launch_bounds__(256) void unpack_frames_kernel(const float* __restr
 // dy[m, c] = dpre[m] w[c];  part[block][C+1] = (sum_m dpre[m] y[m, c], sum_m dpre[m])
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ w,
                                                        const float* __restrict__ s_out, const float* __restrict__ ds,
-                                                       float* __restrict__ dy, float* __restrict__ part, long M, int C) {
-  extern __shared__ float sh[];  // [C + 1]
+                                                       float* __restrict__ dy, double* __restrict__ part, long M, int C) {
+  extern __shared__ double shd[];  // [C + 1]
   const int c4n = C >> 2;
   const int rpp = 256 / c4n > 0 ? 256 / c4n : 1;
   const int c4 = threadIdx.x % c4n, rs = threadIdx.x / c4n;
@@ -545,22 +554,22 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       if (c4 == 0) accb += dp;
     }
   }
-  for (int i = threadIdx.x; i <= C; i += 256) sh[i] = 0.f;
+  for (int i = threadIdx.x; i <= C; i += 256) shd[i] = 0.0;
   __syncthreads();
   if (rs < rpp) {
-    atomicAdd(&sh[c4 * 4 + 0], acc.x); atomicAdd(&sh[c4 * 4 + 1], acc.y);
-    atomicAdd(&sh[c4 * 4 + 2], acc.z); atomicAdd(&sh[c4 * 4 + 3], acc.w);
-    if (c4 == 0) atomicAdd(&sh[C], accb);
+    atomicAdd(&shd[c4 * 4 + 0], static_cast<double>(acc.x)); atomicAdd(&shd[c4 * 4 + 1], static_cast<double>(acc.y));
+    atomicAdd(&shd[c4 * 4 + 2], static_cast<double>(acc.z)); atomicAdd(&shd[c4 * 4 + 3], static_cast<double>(acc.w));
+    if (c4 == 0) atomicAdd(&shd[C], static_cast<double>(accb));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i <= C; i += 256) part[static_cast<long>(blockIdx.x) * (C + 1) + i] = sh[i];
+  for (int i = threadIdx.x; i <= C; i += 256) part[static_cast<long>(blockIdx.x) * (C + 1) + i] = shd[i];
 }
 
 // conv_in (1 -> C, 3x3, pad 1) parameter gradients: part[tap 0..8 | bias][chunk][C]
 __global__ __launch_bounds__(256) void conv_in_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ part, int B, int H, int W, int C,
+                                                          double* __restrict__ part, int B, int H, int W, int C,
                                                           int chunks) {
-  extern __shared__ float sh[];  // [C]
+  extern __shared__ double shd[];  // [C]
   const int tap = blockIdx.y, chunk = blockIdx.x;  // tap 9 = bias
   const int ky = tap / 3, kx = tap - ky * 3;
   const int c4n = C >> 2;
@@ -584,14 +593,14 @@ __global__ __launch_bounds__(256) void conv_in_bwd_kernel(const float* __restric
       const float4 g = ld4(dy + pix * C + c4 * 4);
       s.x = fmaf(xv, g.x, s.x); s.y = fmaf(xv, g.y, s.y); s.z = fmaf(xv, g.z, s.z); s.w = fmaf(xv, g.w, s.w);
     }
-  for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) shd[i] = 0.0;
   __syncthreads();
   if (ps < ppp) {
-    atomicAdd(&sh[c4 * 4 + 0], s.x); atomicAdd(&sh[c4 * 4 + 1], s.y);
-    atomicAdd(&sh[c4 * 4 + 2], s.z); atomicAdd(&sh[c4 * 4 + 3], s.w);
+    atomicAdd(&shd[c4 * 4 + 0], static_cast<double>(s.x)); atomicAdd(&shd[c4 * 4 + 1], static_cast<double>(s.y));
+    atomicAdd(&shd[c4 * 4 + 2], static_cast<double>(s.z)); atomicAdd(&shd[c4 * 4 + 3], static_cast<double>(s.w));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(tap) * chunks + chunk) * C + i] = sh[i];
+  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(tap) * chunks + chunk) * C + i] = shd[i];
 }
 
 // dense_small backward: out = W f(in) + b  (f = swish if swish_in).  One thread per output entry, tiny sizes.
@@ -757,7 +766,7 @@ extern "C" int diffsal_rowstats_chunks(int M, int seg_rows) {
 }
 
 extern "C" int diffsal_rowstats(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
-                                const float* gamma, const float* beta, float* part, int M, int C, int seg_rows,
+                                const float* gamma, const float* beta, double* part, int M, int C, int seg_rows,
                                 int mode, int stat_per_seg, diffsal_stream_t stream) {
   DS_REQUIRE(x && part, DIFFSAL_E_ARG, "rowstats: null argument");
   DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 2048 && seg_rows > 0 && M % seg_rows == 0 && mode >= 0 && mode <= 3,
@@ -766,7 +775,7 @@ extern "C" int diffsal_rowstats(const float* x, const float* dy, const float* y,
   DS_REQUIRE(mode != 1 || y, DIFFSAL_E_ARG, "rowstats: mode 1 needs y");
   DS_REQUIRE(mode != 2 || (gamma && beta), DIFFSAL_E_ARG, "rowstats: mode 2 needs gamma, beta");
   const int chunks = diffsal_rowstats_chunks(M, seg_rows);
-  hipLaunchKernelGGL(rowstats_kernel, dim3(chunks, M / seg_rows), dim3(256), 2 * C * sizeof(float),
+  hipLaunchKernelGGL(rowstats_kernel, dim3(chunks, M / seg_rows), dim3(256), 2 * C * sizeof(double),
                      static_cast<hipStream_t>(stream), x, dy, y, mu, rs, gamma, beta, part, M, C, seg_rows, chunks, mode,
                      stat_per_seg);
   return check_launch("rowstats");
@@ -803,14 +812,14 @@ extern "C" int diffsal_layernorm_bwd_blocks(int M, int C) {
   return static_cast<int>(g > 1024 ? 1024 : g);
 }
 
-extern "C" int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* part,
+extern "C" int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, double* part,
                                      int M, int C, float eps, diffsal_stream_t stream) {
   DS_REQUIRE(x && dy && gamma && dx && part, DIFFSAL_E_ARG, "layernorm_bwd: null argument");
   DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm_bwd: bad shape M=%d C=%d", M, C);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int blocks = diffsal_layernorm_bwd_blocks(M, C);
 #define CALL(G, NV)                                                                                                  \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<G, NV>), dim3(blocks), dim3(256), 2 * C * sizeof(float), s, x, dy, gamma, dx, \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<G, NV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), s, x, dy, gamma, dx, \
                      part, M, C, eps)
   DS_ROW_DISPATCH_B(C, CALL);
 #undef CALL
@@ -857,14 +866,14 @@ extern "C" int diffsal_dwconv_bwd_weight_chunks(int N, int H, int W, int k, int 
   return static_cast<int>(chunks > 256 ? 256 : chunks);
 }
 
-extern "C" int diffsal_dwconv_bwd_weight(const float* x, const float* du, float* part, int N, int H, int W, int C, int k,
+extern "C" int diffsal_dwconv_bwd_weight(const float* x, const float* du, double* part, int N, int H, int W, int C, int k,
                                          int stride, int pad, diffsal_stream_t stream) {
   DS_REQUIRE(x && du && part, DIFFSAL_E_ARG, "dwconv_bwd_weight: null argument");
   DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && C <= 4096 && k > 0 && stride > 0 && pad >= 0, DIFFSAL_E_SHAPE,
              "dwconv_bwd_weight: bad shape");
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int chunks = diffsal_dwconv_bwd_weight_chunks(N, H, W, k, stride, pad);
-  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(chunks, k * k), dim3(256), C * sizeof(float),
+  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(chunks, k * k), dim3(256), C * sizeof(double),
                      static_cast<hipStream_t>(stream), x, du, part, N, H, W, C, Ho, Wo, k, stride, pad, chunks);
   return check_launch("dwconv_bwd_weight");
 }
@@ -946,20 +955,20 @@ extern "C" int diffsal_unpack_frames(const float* frames, float* vis_grad, int B
 }
 
 extern "C" int diffsal_head_bwd(const float* y, const float* w, const float* s_out, const float* ds, float* dy,
-                                float* part, int blocks, int M, int C, diffsal_stream_t stream) {
+                                double* part, int blocks, int M, int C, diffsal_stream_t stream) {
   DS_REQUIRE(y && w && s_out && ds && dy && part, DIFFSAL_E_ARG, "head_bwd: null argument");
   DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && blocks > 0, DIFFSAL_E_SHAPE, "head_bwd: bad shape");
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), (C + 1) * sizeof(float),
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), (C + 1) * sizeof(double),
                      static_cast<hipStream_t>(stream), y, w, s_out, ds, dy, part, static_cast<long>(M), C);
   return check_launch("head_bwd");
 }
 
-extern "C" int diffsal_conv_in_bwd(const float* x, const float* dy, float* part, int B, int H, int W, int C, int chunks,
+extern "C" int diffsal_conv_in_bwd(const float* x, const float* dy, double* part, int B, int H, int W, int C, int chunks,
                                    diffsal_stream_t stream) {
   DS_REQUIRE(x && dy && part, DIFFSAL_E_ARG, "conv_in_bwd: null argument");
   DS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && chunks > 0, DIFFSAL_E_SHAPE,
              "conv_in_bwd: bad shape");
-  hipLaunchKernelGGL(conv_in_bwd_kernel, dim3(chunks, 10), dim3(256), C * sizeof(float),
+  hipLaunchKernelGGL(conv_in_bwd_kernel, dim3(chunks, 10), dim3(256), C * sizeof(double),
                      static_cast<hipStream_t>(stream), x, dy, part, B, H, W, C, chunks);
   return check_launch("conv_in_bwd");
 }

@@ -139,10 +139,11 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 }
 
 // out[g, c] = sum over rows m in segment g (seg_rows rows each) of act'(y[m,c]) * dy[m, c]  (bias / per-image grads)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, float* __restrict__ part, int M,
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, double* __restrict__ part, int M,
                                                      int C, int seg_rows, int chunks) {
-  // grid: (chunks, segments); block covers a row chunk of one segment; threads stride (row, c4)
-  extern __shared__ float sh[];  // [C]
+  // grid: (chunks, segments); block covers a row chunk of one segment; threads stride (row, c4).
+  // fp32 per thread over a few rows, fp64 across threads and workgroups (bias gradients cancel heavily).
+  extern __shared__ double shd[];  // [C]
   const int seg = blockIdx.y, chunk = blockIdx.x;
   const int c4n = C >> 2;
   const int rpp = 256 / c4n > 0 ? 256 / c4n : 1;
@@ -156,14 +157,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
       const float4 v = ld4(dy + m * C + c4 * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-  for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) shd[i] = 0.0;
   __syncthreads();
   if (rs < rpp) {
-    atomicAdd(&sh[c4 * 4 + 0], s.x); atomicAdd(&sh[c4 * 4 + 1], s.y);
-    atomicAdd(&sh[c4 * 4 + 2], s.z); atomicAdd(&sh[c4 * 4 + 3], s.w);
+    atomicAdd(&shd[c4 * 4 + 0], static_cast<double>(s.x)); atomicAdd(&shd[c4 * 4 + 1], static_cast<double>(s.y));
+    atomicAdd(&shd[c4 * 4 + 2], static_cast<double>(s.z)); atomicAdd(&shd[c4 * 4 + 3], static_cast<double>(s.w));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(seg) * chunks + chunk) * C + i] = sh[i];
+  for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(seg) * chunks + chunk) * C + i] = shd[i];
+}
+
+// out[g][c] (fp32) = sum over chunks of part[g][chunk][c] (fp64)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out,
+                                                           int segs, int chunks, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= segs * C) return;
+  const int g = i / C, c = i - g * C;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += part[(static_cast<long>(g) * chunks + k) * C + c];
+  out[i] = static_cast<float>(s);
 }
 
 }  // namespace diffsal
@@ -226,17 +238,14 @@ extern "C" int diffsal_colsum(const float* dy, float* out, int M, int C, int seg
   int chunks = 2048 / segs;
   chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
   while (chunks > 1 && seg_rows / chunks < 8) chunks >>= 1;
-  DS_REQUIRE(ws_bytes >= static_cast<size_t>(segs) * chunks * C * 4, DIFFSAL_E_ARG, "colsum: workspace too small");
+  DS_REQUIRE(ws_bytes >= static_cast<size_t>(segs) * chunks * C * sizeof(double), DIFFSAL_E_ARG,
+             "colsum: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(colsum_kernel, dim3(chunks, segs), dim3(256), C * sizeof(float), s, dy, static_cast<float*>(ws), M,
+  hipLaunchKernelGGL(colsum_kernel, dim3(chunks, segs), dim3(256), C * sizeof(double), s, dy, static_cast<double*>(ws), M,
                      C, seg_rows, chunks);
   int rc = check_launch("colsum");
   if (rc) return rc;
-  // second stage: sum the chunk partials of each segment; [segs][chunks][C] -> [segs][C]
-  for (int g = 0; g < segs; ++g) {  // segs is small (1 for a bias, N images for a per-image vector)
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
-                       static_cast<const float*>(ws) + static_cast<long>(g) * chunks * C, out + static_cast<long>(g) * C,
-                       static_cast<long>(C), chunks);
-  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((segs * C + 255) / 256), dim3(256), 0, s,
+                     static_cast<const double*>(ws), out, segs, chunks, C);
   return check_launch("colsum(sum)");
 }

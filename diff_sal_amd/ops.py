@@ -280,9 +280,9 @@ def colsum(dy: Tensor, seg_rows: Optional[int] = None) -> Tensor:
     M = dy.numel() // Cc
     seg = M if seg_rows is None else seg_rows
     out = torch.empty((M // seg, Cc), device=dy.device, dtype=torch.float32)
-    nws = (M // seg) * 64 * Cc * 4
-    ws = torch.empty((nws // 4,), device=dy.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_colsum(_p(dy), _p(out), M, Cc, seg, _p(ws), nws, _stream()), "colsum")
+    nws = (M // seg) * 64 * Cc * 8
+    ws = torch.empty((nws // 8,), device=dy.device, dtype=torch.float64)
+    _lib.check(lib.diffsal_colsum(_p(dy), _p(out), M, Cc, seg, ws.data_ptr(), nws, _stream()), "colsum")
     return out
 
 
@@ -305,10 +305,10 @@ def rowstats(x: Tensor, seg_rows: int, mode: int = 0, dy=None, y=None, mu=None, 
     Cc = x.shape[-1]
     M = x.numel() // Cc
     chunks = lib.diffsal_rowstats_chunks(M, seg_rows)
-    part = torch.empty((M // seg_rows, chunks, 2, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_rowstats(_p(x), _p(dy), _p(y), _p(mu), _p(rs), _p(gamma), _p(beta), _p(part), M, Cc, seg_rows,
+    part = torch.empty((M // seg_rows, chunks, 2, Cc), device=x.device, dtype=torch.float64)
+    _lib.check(lib.diffsal_rowstats(_p(x), _p(dy), _p(y), _p(mu), _p(rs), _p(gamma), _p(beta), part.data_ptr(), M, Cc, seg_rows,
                                     mode, int(stat_per_seg), _stream()), "rowstats")
-    return part.double().sum(dim=1)
+    return part.sum(dim=1)
 
 
 def affine_act(x: Tensor, scale: Tensor, shift: Tensor, seg_rows: int, act: int) -> Tensor:
@@ -336,11 +336,11 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5):
     Cc = x.shape[-1]
     M = x.numel() // Cc
     blocks = lib.diffsal_layernorm_bwd_blocks(M, Cc)
-    part = torch.empty((blocks, 2, Cc), device=x.device, dtype=torch.float32)
+    part = torch.empty((blocks, 2, Cc), device=x.device, dtype=torch.float64)
     dx = torch.empty_like(x)
-    _lib.check(lib.diffsal_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(dx), _p(part), M, Cc, eps, _stream()),
+    _lib.check(lib.diffsal_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(dx), part.data_ptr(), M, Cc, eps, _stream()),
                "layernorm_bwd")
-    s = part.double().sum(dim=0).float()
+    s = part.sum(dim=0).float()
     return dx, s[0], s[1]
 
 
@@ -379,10 +379,10 @@ def dwconv_bwd(x: Tensor, w: Tensor, du: Tensor, k: int, stride: int, pad: int, 
                    "dwconv_bwd_data")
     if need_dw:
         chunks = lib.diffsal_dwconv_bwd_weight_chunks(N, H, W, k, stride, pad)
-        part = torch.empty((k * k, chunks, Cc), device=x.device, dtype=torch.float32)
-        _lib.check(lib.diffsal_dwconv_bwd_weight(_p(x), _p(du), _p(part), N, H, W, Cc, k, stride, pad, _stream()),
+        part = torch.empty((k * k, chunks, Cc), device=x.device, dtype=torch.float64)
+        _lib.check(lib.diffsal_dwconv_bwd_weight(_p(x), _p(du), part.data_ptr(), N, H, W, Cc, k, stride, pad, _stream()),
                    "dwconv_bwd_weight")
-        dw = part.double().sum(dim=1).float()
+        dw = part.sum(dim=1).float()
     return dx, dw
 
 
@@ -396,7 +396,7 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, heads: int, sca
     dq = torch.empty_like(q)
     _lib.check(lib.diffsal_attention_bwd(_p(q), _p(k), _p(v), _p(dout), _p(dq), _p(part), N, Lq, Lk, Cc, heads, scale,
                                          _stream()), "attention_bwd")
-    s = part.sum(dim=1)
+    s = part.double().sum(dim=1).float()
     return dq, s[:, 0].contiguous(), s[:, 1].contiguous()
 
 
@@ -423,11 +423,11 @@ def head_bwd(y: Tensor, w: Tensor, s_out: Tensor, ds: Tensor):
     Cc = y.shape[-1]
     M = y.numel() // Cc
     blocks = min(1024, max(1, M // 64))
-    part = torch.empty((blocks, Cc + 1), device=y.device, dtype=torch.float32)
+    part = torch.empty((blocks, Cc + 1), device=y.device, dtype=torch.float64)
     dy = torch.empty_like(y)
-    _lib.check(lib.diffsal_head_bwd(_p(y), _p(w), _p(s_out), _p(ds), _p(dy), _p(part), blocks, M, Cc, _stream()),
+    _lib.check(lib.diffsal_head_bwd(_p(y), _p(w), _p(s_out), _p(ds), _p(dy), part.data_ptr(), blocks, M, Cc, _stream()),
                "head_bwd")
-    s = part.double().sum(dim=0).float()
+    s = part.sum(dim=0).float()
     return dy, s[:Cc].contiguous(), s[Cc:].contiguous()
 
 
@@ -437,9 +437,9 @@ def conv_in_bwd(x: Tensor, dy: Tensor):
     B, _, H, W = x.shape
     Cc = dy.shape[-1]
     chunks = 128
-    part = torch.empty((10, chunks, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_conv_in_bwd(_p(x), _p(dy), _p(part), B, H, W, Cc, chunks, _stream()), "conv_in_bwd")
-    s = part.double().sum(dim=1).float()
+    part = torch.empty((10, chunks, Cc), device=x.device, dtype=torch.float64)
+    _lib.check(lib.diffsal_conv_in_bwd(_p(x), _p(dy), part.data_ptr(), B, H, W, Cc, chunks, _stream()), "conv_in_bwd")
+    s = part.sum(dim=1).float()
     return s[:9].t().contiguous(), s[9].contiguous()
 
 

@@ -352,9 +352,8 @@ class SalUNet(nn.Module):
 
     def _forward_pass(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor],
                       taps: Optional[dict]) -> Tensor:
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("diff_sal_amd.SalUNet: the HIP path implements the eval-mode forward only "
-                               "(BatchNorm running statistics, no dropout); call .eval() / torch.no_grad()")
+        if self.training:
+            return self.forward_train(x, t, feat_list, audio_feat_list)
         if not x.is_cuda:
             raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
         pk = self.packed()
@@ -425,6 +424,145 @@ class SalUNet(nn.Module):
                            shift=pk["mt.shift"], act=ACT_RELU)
         s = ops.head_sigmoid(y, pk["head.w"], self.logits.linear_pred.bias)
         out = ops.resize_bilinear(s, self.img_size[0], self.img_size[1])
+        return out.view(B, 1, self.img_size[0], self.img_size[1])
+
+    # ------------------------------------------------------------------ training forward
+    dropout_p = 0.1          # ResnetBlock dropout (sal_unet.py:229); set to 0 for gradient-parity tests
+    _dropout_calls = 0
+
+    def forward_train(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor] = None,
+                      dropout_seed: Optional[int] = None) -> Tensor:
+        """Train-mode forward on the autograd tape: BatchNorm uses (per-rank) batch statistics and updates its
+        running buffers, ResnetBlock dropout is active, every op is a torch.autograd.Function whose forward AND
+        backward are HIP kernels (autograd_ops.py).  Same graph as ``forward``; less epilogue fusion because the
+        backward needs the pre-activation tensors."""
+        from . import autograd_ops as ag
+
+        if not x.is_cuda:
+            raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        ns, dec = self.num_stages, self.invpt_decoder
+        if dropout_seed is None:
+            SalUNet._dropout_calls += 1
+            dropout_seed = (torch.initial_seed() * 1000003 + SalUNet._dropout_calls) & (2 ** 63 - 1)
+        pw = ops.pack_conv_weight_diff
+        dgw = ag.dgrad_weight
+
+        # K1: embedding table lookup (no parameters) + three small dense layers
+        half = self.ch // 2
+        freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(x.device)
+        arg = t.to(torch.float32)[:, None] * freq[None, :]
+        emb = torch.cat([arg.sin(), arg.cos()], dim=1).contiguous()
+        d0, d1 = self.temb.dense[0], self.temb.dense[1]
+        temb = ag.dense_small(ag.dense_small(emb, d0.weight, d0.bias, False), d1.weight, d1.bias, True)
+        tw = torch.cat([blk[0].temb_proj.weight for blk in self.res_encoder], 0)
+        tb = torch.cat([blk[0].temb_proj.bias for blk in self.res_encoder], 0)
+        tproj = ag.dense_small(temb, tw, tb, True)
+
+        f = ag.conv_in(x, self.conv_in.weight.reshape(self.ch, 9), self.conv_in.bias, 0)
+        f = ag.conv(f, pw(self.down1.conv.weight), kh=3, kw=3, stride=(4, 4), out_hw=((H - 2) // 4 + 1, (W - 2) // 4 + 1),
+                    bias=self.down1.conv.bias, w_dgrad=dgw(self.down1.conv.weight))
+        noise, off = [], 0
+        for i, blk in enumerate(self.res_encoder):
+            rb, dn = blk[0], blk[1]
+            co = rb.conv1.out_channels
+            h = ag.groupnorm_swish(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
+            h = ag.conv(h, pw(rb.conv1.weight), kh=3, kw=3, pad=(1, 1), bias=rb.conv1.bias,
+                        rowvec=tproj[:, off:off + co], w_dgrad=dgw(rb.conv1.weight))
+            off += co
+            h = ag.groupnorm_swish(h, rb.norm2.weight, rb.norm2.bias, 32, rb.norm2.eps)
+            h = ag.dropout(h, self.dropout_p, dropout_seed + 7919 * i)
+            sc = f
+            if hasattr(rb, "nin_shortcut"):
+                sc = ag.conv(f, pw(rb.nin_shortcut.weight), bias=rb.nin_shortcut.bias, w_dgrad=dgw(rb.nin_shortcut.weight))
+            f = ag.conv(h, pw(rb.conv2.weight), kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc,
+                        w_dgrad=dgw(rb.conv2.weight))
+            hh, ww = f.shape[1:3]
+            f = ag.conv(f, pw(dn.conv.weight), kh=3, kw=3, stride=(2, 2), out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1),
+                        bias=dn.conv.bias, w_dgrad=dgw(dn.conv.weight))
+            noise.append(f)
+        noise = noise[::-1]
+
+        frames: List[Optional[Tensor]] = []
+        for i in range(ns):
+            fi = feat_list[i].contiguous().float() if (i < len(feat_list) and i < 3) else None
+            if fi is None:
+                frames.append(None)
+                continue
+            nz = noise[i] if (self.image_based and i < len(noise) and tuple(fi.shape[-2:]) == tuple(noise[i].shape[1:3])) else None
+            frames.append(ag.pack_frames(fi, nz))
+
+        audio_tok, audio_hw = None, None
+        if audio_feat_list is not None:
+            ap = ag.pack_frames(audio_feat_list.contiguous().float(), None)
+            audio_hw = (ap.shape[2], ap.shape[3])
+            audio_tok = ap.view(B * ap.shape[1], audio_hw[0] * audio_hw[1], ap.shape[4])
+
+        xcur = frames[0]
+        h0, w0 = xcur.shape[2:4]
+        th, tw_ = h0 * 2 ** (ns - 1) * 2, w0 * 2 ** (ns - 1) * 2
+        zs = []
+        for i in range(ns):
+            C = self.up_channels[i]
+            st = dec.mid_stages[i]
+            if self.dilation[i] != 0:
+                Bn, T, h, w, Cp = xcur.shape
+                d = self.dilation[i]
+                pe = st.patch_embed[0].proj
+                u = ag.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
+                u = ag.conv(u, pw(pe[1].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[1].weight))
+                u = ag.batchnorm_relu_train(u, pe[2])
+                u = ag.conv(u, pw(pe[4].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[4].weight))
+                u = ag.batchnorm_relu_train(u, pe[5])
+                if i in (1, 2):
+                    u = ag.add(u, frames[i].view(Bn * T, 2 * h, 2 * w, C))
+                xcur = u.view(Bn, T, 2 * h, 2 * w, C)
+            # ---- transformer block
+            Bn, T, Hs, Ws, _ = xcur.shape
+            n9 = Bn * T
+            blk = st.blocks[0]
+            a = blk.attn
+            xn = ag.layernorm(xcur, blk.norm.weight, blk.norm.bias, blk.norm.eps)
+            k_src = xn.view(n9, Hs, Ws, C)
+            if audio_tok is not None:
+                a_small = ag.linear(audio_tok, blk.align_conv.weight.reshape(C, 512), blk.align_conv.bias)
+                k_src = ag.audio_fuse(a_small, xcur, audio_hw[0], audio_hw[1]).view(n9, Hs, Ws, C)
+            kk_ = self.kernel_kv[i]
+            wq9 = a.conv_proj_q.conv.weight[:, 0, 1].reshape(C, 9).t().contiguous()
+            wk = a.conv_proj_k.conv.weight.reshape(C, kk_ * kk_).t().contiguous()
+            wv = a.conv_proj_v.conv.weight.reshape(C, kk_ * kk_).t().contiguous()
+            q = ag.layernorm(ag.dwconv(xn.view(n9, Hs, Ws, C), wq9, 3, 1, 1).view(n9, Hs * Ws, C),
+                             a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias, a.conv_proj_q.bn.eps)
+            kt_ = ag.dwconv(k_src, wk, kk_, kk_, 0)
+            vt_ = ag.dwconv(xn.view(n9, Hs, Ws, C), wv, kk_, kk_, 0)
+            kk = ag.layernorm(kt_.view(n9, -1, C), a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_k.bn.eps)
+            vv = ag.layernorm(vt_.view(n9, -1, C), a.conv_proj_v.bn.weight, a.conv_proj_v.bn.bias, a.conv_proj_v.bn.eps)
+            q = ag.linear(q, a.proj_q.weight, a.proj_q.bias)
+            kk = ag.linear(kk, a.proj_k.weight, a.proj_k.bias)
+            vv = ag.linear(vv, a.proj_v.weight, a.proj_v.bias)
+            o = ag.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)
+            x1 = ag.linear(o, a.proj.weight, a.proj.bias, residual=xcur.view(n9, Hs * Ws, C))
+            y = ag.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            y = ag.gelu(ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+            x2 = ag.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1)
+            xcur = x2.view(Bn, T, Hs, Ws, C)
+            # ---- norm + ReduceTemp
+            nm = dec.norm_mts[i]
+            z = ag.layernorm(xcur, nm.weight, nm.bias, nm.eps)
+            kt = self.temporal_list[i]
+            if (T - kt) // kt + 1 != 1:
+                raise RuntimeError(f"ReduceTemp: T={T}, kernel/stride {kt} must give exactly one frame")
+            w3 = dec.redu_chan_up[i].proj[0].weight
+            z = ag.conv(z.view(Bn, T, Hs * Ws, C), pw(w3), kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
+                        w_dgrad=dgw(w3[:, :, :, 0, 0].unsqueeze(-1)))
+            zs.append(z.view(Bn, Hs, Ws, self.ori_embed_dim))
+        acc = ag.resize_sum(zs, th, tw_)
+        mt = dec.mt_proj
+        y = ag.conv(acc, pw(mt[0].weight), kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, w_dgrad=dgw(mt[0].weight))
+        y = ag.batchnorm_relu_train(y, mt[1])
+        s_ = ag.head_sigmoid(y, self.logits.linear_pred.weight.reshape(-1), self.logits.linear_pred.bias)
+        out = ag.resize_bilinear(s_, self.img_size[0], self.img_size[1])
         return out.view(B, 1, self.img_size[0], self.img_size[1])
 
     # taps come back channels-last; helpers for tests that compare with NCHW / NCTHW fixtures

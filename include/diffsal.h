@@ -96,7 +96,8 @@ size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wgrad(const diffsal_conv_desc* d /*host*/, const float* in, const float* dy, float* dw_packed,
                        void* ws, size_t ws_bytes, diffsal_stream_t stream);
 /* out[g, c] = sum of dy[m, c] over the rows of segment g (M / seg_rows segments): bias gradients (one segment)
- * and per-image vector gradients (one segment per image).  ws: >= (M/seg_rows) * 64 * C * 4 bytes. */
+ * and per-image vector gradients (one segment per image).  ws: >= (M/seg_rows) * 64 * C * 8 bytes (fp64 partials:
+ * reductions across threads run in double so that heavily cancelling sums do not depend on the atomics order). */
 int diffsal_colsum(const float* dy, float* out, int M, int C, int seg_rows, void* ws, size_t ws_bytes,
                    diffsal_stream_t stream);
 
@@ -105,14 +106,14 @@ int diffsal_colsum(const float* dy, float* out, int M, int C, int seg_rows, void
 int diffsal_act_bwd(const float* dy, const float* ref, float* dx, size_t n, int mode, diffsal_stream_t stream);
 
 /* ---- K16 (training): normalisation layers ------------------------------------------------------
- * Per-channel dual sums over the rows of each segment -> part[segs][chunks][2][C], chunks = diffsal_rowstats_chunks():
+ * Per-channel dual sums over the rows of each segment -> part[segs][chunks][2][C] (fp64), chunks = diffsal_rowstats_chunks():
  *   mode 0 (x, x^2): BatchNorm (train) / GroupNorm statistics;  mode 1/2/3: (dz, dz*xhat) for BN+ReLU, GN+swish, plain.
  * The caller folds the partials into per-(segment, channel) vectors (tiny) and calls the element-wise kernels below.
  * Replace the forward / backward of nn.BatchNorm2d (train), nn.GroupNorm + swish (sal_unet.py:36-44,
  * common_block.py:33-36,196-216). */
 int diffsal_rowstats_chunks(int M, int seg_rows);
 int diffsal_rowstats(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
-                     const float* gamma, const float* beta, float* part, int M, int C, int seg_rows, int mode,
+                     const float* gamma, const float* beta, double* part, int M, int C, int seg_rows, int mode,
                      int stat_per_seg, diffsal_stream_t stream);
 /* out = act(x * scale[seg, c] + shift[seg, c]); act: DIFFSAL_ACT_NONE / RELU, or 4 = swish */
 int diffsal_affine_act(const float* x, const float* scale, const float* shift, float* out, int M, int C, int seg_rows,
@@ -123,7 +124,7 @@ int diffsal_norm_bwd_apply(const float* x, const float* dy, const float* y, cons
                            float* dx, int M, int C, int seg_rows, int mode, diffsal_stream_t stream);
 /* LayerNorm backward: dx and per-block partial (dgamma, dbeta) -> part[blocks][2][C], blocks = diffsal_layernorm_bwd_blocks() */
 int diffsal_layernorm_bwd_blocks(int M, int C);
-int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* part, int M, int C,
+int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, double* part, int M, int C,
                           float eps, diffsal_stream_t stream);
 /* out = x * keep / (1-p), keep from a counter-based hash of (seed, index); same call = its own backward.
  * Replaces nn.Dropout(0.1) of ResnetBlock in train mode (sal_unet.py:109,133). */
@@ -138,7 +139,7 @@ int diffsal_dwconv(const float* x, const float* w, float* out, int N, int H, int
 int diffsal_dwconv_bwd_data(const float* du, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
                             int pad, diffsal_stream_t stream);
 int diffsal_dwconv_bwd_weight_chunks(int N, int H, int W, int k, int stride, int pad);
-int diffsal_dwconv_bwd_weight(const float* x, const float* du, float* part, int N, int H, int W, int C, int k,
+int diffsal_dwconv_bwd_weight(const float* x, const float* du, double* part, int N, int H, int W, int C, int k,
                               int stride, int pad, diffsal_stream_t stream);
 /* Backward of diffsal_attention: dq [N,Lq,C]; dk, dv as per-workgroup partials part[N][blocks][2][Lk][C],
  * blocks = diffsal_attention_bwd_blocks(); the caller sums over blocks. */
@@ -154,9 +155,9 @@ int diffsal_resize_bilinear_bwd(const float* dy, float* dx, int N, int h, int w,
                                 diffsal_stream_t stream);
 int diffsal_unpack_frames(const float* frames, float* vis_grad, int B, int C, int Tv, int Tin, int hw,
                           diffsal_stream_t stream);
-int diffsal_head_bwd(const float* y, const float* w, const float* s_out, const float* ds, float* dy, float* part,
+int diffsal_head_bwd(const float* y, const float* w, const float* s_out, const float* ds, float* dy, double* part,
                      int blocks, int M, int C, diffsal_stream_t stream);
-int diffsal_conv_in_bwd(const float* x, const float* dy, float* part, int B, int H, int W, int C, int chunks,
+int diffsal_conv_in_bwd(const float* x, const float* dy, double* part, int B, int H, int W, int C, int chunks,
                         diffsal_stream_t stream);
 int diffsal_dense_small_bwd(const float* in, const float* w, const float* dout, float* dw, float* db, float* din,
                             int B, int K, int N, int swish_in, diffsal_stream_t stream);

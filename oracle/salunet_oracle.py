@@ -127,7 +127,12 @@ def noise_downsample(sd: Dict[str, Tensor], x: Tensor, temb: Tensor, taps=None) 
 # --------------------------------------------------------------------------
 # K12: UpEmbed
 # --------------------------------------------------------------------------
+BN_TRAIN = False  # tests of the training step flip this: batch statistics, as nn.BatchNorm2d in train mode
+
+
 def _bn_eval(x: Tensor, sd: Dict[str, Tensor], p: str) -> Tensor:
+    if BN_TRAIN:
+        return F.batch_norm(x, None, None, sd[p + "weight"], sd[p + "bias"], True, 0.0, 1e-5)
     return F.batch_norm(
         x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5
     )
