@@ -67,6 +67,11 @@ SIGNATURES = {
     "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
+    "diffsal_reduce_blocks": (c_i, []),
+    "diffsal_scale_by": (c_i, [c_f, c_f, c_f, C.c_long, c_f]),
+    "diffsal_mse_loss": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_long, c_fl, c_f]),
+    "diffsal_grad_norm": (c_i, [c_f, C.c_long, c_fl, c_f, c_f, c_f]),
+    "diffsal_adam_step": (c_i, [c_f] * 4 + [C.c_long] + [C.c_double] * 5 + [c_i, c_fl, c_f, c_fl, c_i, c_f]),
 }
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3

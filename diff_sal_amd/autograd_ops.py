@@ -414,3 +414,23 @@ class AudioFuseFn(torch.autograd.Function):
 
 def audio_fuse(a_small, x, h, w):
     return AudioFuseFn.apply(a_small, x, h, w)
+
+
+class MseLossFn(torch.autograd.Function):
+    """loss = loss_scale * sum (pred - target)^2 (R/models/sal_losses.py:189-192); one kernel produces the loss
+    and d(loss)/d(pred), the backward only applies the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, target, loss_scale):
+        loss, dpred = ops.mse_loss(pred.contiguous(), target.contiguous(), loss_scale, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dpred,) = ctx.saved_tensors
+        return ops.scale_by(dpred, dloss.contiguous()), None, None
+
+
+def mse_loss(pred, target, loss_scale):
+    return MseLossFn.apply(pred, target, loss_scale)

@@ -463,3 +463,53 @@ def audio_fuse_bwd(a_small: Tensor, x: Tensor, dout: Tensor, h: int, w: int):
     _lib.check(lib.diffsal_audio_fuse_bwd(_p(a_small), _p(x), _p(dout), _p(dx), _p(da), B, T, H, W, Cc, h, w, _stream()),
                "audio_fuse_bwd")
     return dx, da
+
+
+# ---- K16 tail: loss, clip, optimizer on flat buffers (csrc/optim.hip) --------------------------------
+def _reduce_scratch(dev) -> Tensor:
+    return torch.empty((_lib.load().diffsal_reduce_blocks(),), device=dev, dtype=torch.float64)
+
+
+def mse_loss(pred: Tensor, target: Tensor, loss_scale: float, want_grad: bool = True):
+    """-> (loss [1], dpred or None): loss = loss_scale * sum (pred-target)^2 (R/models/sal_losses.py:189-192)."""
+    lib = _lib.load()
+    if pred.shape != target.shape:
+        raise RuntimeError(f"mse_loss: shapes differ: {tuple(pred.shape)} vs {tuple(target.shape)}")
+    loss = torch.empty((1,), device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    part = _reduce_scratch(pred.device)
+    _lib.check(lib.diffsal_mse_loss(_p(pred), _p(target), _p(dpred) if want_grad else None, _p(loss), part.data_ptr(),
+                                    pred.numel(), float(loss_scale), _stream()), "mse_loss")
+    return loss, dpred
+
+
+def grad_norm(flat_grad: Tensor, gscale: float = 1.0) -> Tensor:
+    """-> [1] tensor gscale * ||flat_grad||_2 (stays on the device)."""
+    lib = _lib.load()
+    norm = torch.empty((1,), device=flat_grad.device)
+    part = _reduce_scratch(flat_grad.device)
+    _lib.check(lib.diffsal_grad_norm(_p(flat_grad), flat_grad.numel(), float(gscale), _p(norm), part.data_ptr(), _stream()),
+               "grad_norm")
+    return norm
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+              weight_decay: float = 0.0, gscale: float = 1.0, norm: Optional[Tensor] = None, max_norm: float = 0.0,
+              store_clipped_grad: bool = False) -> None:
+    """In-place torch.optim.Adam update of the flat buffers (p, m, v), gradient pre-scaled by
+    gscale * min(1, max_norm / (norm + 1e-6))."""
+    lib = _lib.load()
+    n = p.numel()
+    if not (g.numel() == n and m.numel() == n and v.numel() == n):
+        raise RuntimeError("adam_step: p, g, m, v must have the same number of elements")
+    _lib.check(lib.diffsal_adam_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                     float(weight_decay), int(step), float(gscale), _p(norm) if norm is not None else None,
+                                     float(max_norm), int(store_clipped_grad), _stream()), "adam_step")
+
+
+def scale_by(x: Tensor, s: Tensor) -> Tensor:
+    """x * s[0] with s a one-element device tensor."""
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    _lib.check(lib.diffsal_scale_by(_p(x), _p(s.reshape(1)), _p(out), x.numel(), _stream()), "scale_by")
+    return out

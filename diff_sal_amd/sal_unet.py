@@ -190,6 +190,7 @@ class SalUNet(nn.Module):
 
         self._pack_cache: Optional[Dict[str, Tensor]] = None
         self._pack_key = None
+        self._pack_epoch = 0
         self.init_weights()
 
     # ------------------------------------------------------------------ init (quirk Q15)
@@ -210,7 +211,12 @@ class SalUNet(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _cache_key(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (self._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def parameters_updated(self) -> None:
+        """Tell the module its parameters were rewritten behind autograd's version counters (the fused Adam kernel
+        writes through raw pointers): the eval-mode packed-weight cache is rebuilt on next use."""
+        self._pack_epoch += 1
 
     @staticmethod
     def _pack_conv(w: Tensor) -> Tensor:

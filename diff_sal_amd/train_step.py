@@ -1,0 +1,269 @@
+"""The diffusion training step of the denoiser (BASELINE configs[3]).
+
+What one step does, and the reference lines it mirrors:
+
+    prepare_data   x0 = sal_map + 0.01 randn;  t0 = ONE integer in [0, T) for the whole rank-batch;
+                   x_t = sqrt(a_hat[t0]) x0 + sqrt(1 - a_hat[t0]) randn         R/diffusion_trainer.py:106-117, 122-137,
+                                                                                R/datasets/__init__.py:8-25
+    forward        pred = model(x_t, t, conditioning)  (train-mode BN with per-rank statistics, dropout 0.1)
+    loss           mse_weight * sum_{chw}(pred - x0)^2 .mean(batch)              R/models/sal_losses.py:189-192
+    backward       hand-written HIP backward of every operator (autograd_ops.py)
+    exchange       gradient MEAN over ranks -- the one collective of the path    (DDP, R/model.py:15)
+    clip + Adam    clip_grad_norm_(1.0); Adam(lr 1e-4, (0.9, 0.999), eps 1e-8)   R/diffusion_trainer.py:228-235,
+                                                                                R/util/utils.py:116-123
+
+MI355X design.  Parameters, gradients and both Adam moments live in four flat fp32 buffers; every
+``nn.Parameter`` (and its ``.grad``) is a view into them, so state_dict()/load_state_dict() keep working and
+the reference's per-tensor loops collapse into three streaming kernels (csrc/optim.hip) -- norm, then a fused
+clip+Adam that reads the norm from device memory (no host sync anywhere in the step).  Parameters are laid out
+in REVERSE registration order, so gradients become final roughly front-to-back in the flat buffer during
+backward; the buffer is cut into a few large buckets (default 32 MB: xGMI is point-to-point, a ring all-reduce
+is per-link bound, so few large messages beat DDP's 25 MB x many) and each bucket's all-reduce (RCCL) is
+launched asynchronously from a post-accumulate hook as soon as its last gradient lands, overlapping the rest of
+backward.  Only parameters that can receive a gradient are exchanged (the reference buckets 72 M dead ones).
+The DDP mean is not a separate pass: 1/world is folded into the norm and Adam kernels.
+BatchNorm running statistics follow DDP's ``broadcast_buffers=True``: rank 0's buffers are broadcast (one flat
+message) at the start of each step.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .diffusion_utils import get_beta_schedule, to_torch
+
+
+def _aligned(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """Flat fp32 storage for the trainable parameters of ``module`` (+ grads and optimizer moments).
+
+    Layout: reverse registration order, each tensor padded to 64 elements (256 B) so every view is 16-byte aligned
+    for the vectorised kernels.  Padding stays zero in all four buffers (Adam maps 0 -> 0)."""
+
+    def __init__(self, module: nn.Module, bucket_bytes: int = 32 << 20):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("FlatParams: module has no trainable parameters")
+        dev, dt = params[0].device, params[0].dtype
+        if dt != torch.float32 or any(p.dtype != dt or p.device != dev for p in params):
+            raise ValueError("FlatParams: all trainable parameters must be fp32 on one device")
+        self.params: List[nn.Parameter] = params[::-1]
+        self.offsets: List[int] = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += _aligned(p.numel())
+        self.numel = off
+        self.live_numel = sum(p.numel() for p in self.params)
+        self.flat_p = torch.zeros(off, device=dev)
+        self.flat_g = torch.zeros(off, device=dev)
+        self.exp_avg = torch.zeros(off, device=dev)
+        self.exp_avg_sq = torch.zeros(off, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat_p[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        # buckets: contiguous ranges of whole tensors, closed once they reach bucket_bytes
+        self.buckets: List[range] = []       # element ranges of the flat buffer
+        self.bucket_of: List[int] = []       # parameter index -> bucket
+        start, cap = 0, max(1, bucket_bytes // 4)
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            self.bucket_of.append(len(self.buckets))
+            end = o + _aligned(p.numel())
+            if end - start >= cap or i == len(self.params) - 1:
+                self.buckets.append(range(start, end))
+                start = end
+        self.bucket_size = [0] * len(self.buckets)
+        for b in self.bucket_of:
+            self.bucket_size[b] += 1
+
+    def zero_grad(self) -> None:
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):  # a caller may have set p.grad = None
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+
+class GradReducer:
+    """Bucketed asynchronous gradient SUM over the ranks of ``group`` (the mean's 1/world is applied by the consumer).
+
+    ``arm()`` before backward; the per-parameter hooks launch a bucket's all-reduce when its last gradient has
+    been accumulated; ``finish()`` launches whatever is left (buckets holding parameters that received no
+    gradient this step) and waits for all of them."""
+
+    def __init__(self, flat: FlatParams, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._pending: List[int] = []
+        self._launched: List[bool] = []
+        self._work = []
+        self._armed = False
+        self.launch_order: List[int] = []
+        if self.world > 1:
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i: int) -> Callable:
+        def hook(_param):
+            if not self._armed:
+                return
+            b = self.flat.bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int) -> None:
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        r = self.flat.buckets[b]
+        self.launch_order.append(b)
+        self._work.append(dist.all_reduce(self.flat.flat_g[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group,
+                                          async_op=True))
+
+    def arm(self) -> None:
+        self._pending = list(self.flat.bucket_size)
+        self._launched = [False] * len(self.flat.buckets)
+        self._work, self.launch_order = [], []
+        self._armed = self.world > 1
+
+    def finish(self) -> None:
+        if self.world <= 1:
+            return
+        for b in range(len(self.flat.buckets)):
+            self._launch(b)
+        for w in self._work:
+            w.wait()
+        self._work, self._armed = [], False
+
+
+class DiffusionTrainStep:
+    """prepare_data -> forward -> MSE -> backward -> gradient mean -> clip -> Adam, for ``model``.
+
+    ``model`` is a ``diff_sal_amd.SalUNet`` (called as ``model(x_t, t, feat_list, audio)``) or a
+    ``VideoSaliencyModel`` (called as ``model({"img", "input", "audio"}, t)``, R/diffusion_trainer.py:212-218).
+    Keyword names follow the YAML fields the reference trainer reads (R/cfgs/diffusion.yml:24-28, 39-60)."""
+
+    def __init__(self, model: nn.Module, *, lr: float = 1e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                 weight_decay: float = 0.0, grad_clip: float = 1.0, mse_weight: float = 1.0,
+                 beta_schedule: str = "cosine", beta_start: float = 1e-4, beta_end: float = 0.02,
+                 num_diffusion_timesteps: int = 1000, gaussian_dequantization: bool = True,
+                 bucket_mb: float = 32.0, process_group=None, broadcast_buffers: bool = True,
+                 store_clipped_grad: bool = False):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(beta1), float(beta2)), float(eps), float(weight_decay)
+        self.grad_clip, self.mse_weight = float(grad_clip), float(mse_weight)
+        self.gaussian_dequantization = bool(gaussian_dequantization)
+        self.store_clipped_grad = bool(store_clipped_grad)
+        betas = to_torch(get_beta_schedule(beta_schedule, beta_start=beta_start, beta_end=beta_end,
+                                           num_diffusion_timesteps=num_diffusion_timesteps))
+        alphas_hat = (1.0 - betas).cumprod(dim=0)
+        self.sqrt_alphas_hat = torch.sqrt(alphas_hat)
+        self.sqrt_one_minus_alphas_hat = torch.sqrt(1.0 - alphas_hat)
+        self.num_timesteps = int(betas.shape[0])
+        self.flat = FlatParams(model, int(bucket_mb * (1 << 20)))
+        self.group = process_group
+        self.reducer = GradReducer(self.flat, process_group)
+        self.world = self.reducer.world
+        self.broadcast_buffers = bool(broadcast_buffers) and self.world > 1
+        self.step_count = 0
+        self.last_norm: Optional[Tensor] = None
+        self._rng = np.random  # the reference draws t0 from numpy's global generator (diffusion_trainer.py:111)
+
+    # ---- R/diffusion_trainer.py:78-120 (training branch) ----
+    def prepare_data(self, sal_maps: Tensor, *, t0: Optional[int] = None, noise: Optional[Tensor] = None,
+                     dequant_noise: Optional[Tensor] = None):
+        """sal_maps [B,1,H,W] in [0,1] -> (x0, x_t, t [B] int64, noise)."""
+        from . import ops
+
+        x = sal_maps.contiguous().float()
+        if self.gaussian_dequantization:
+            dq = torch.randn_like(x) if dequant_noise is None else dequant_noise
+            x = ops.axpbypcz(x, 1.0, dq, 0.01)
+        if noise is None:
+            noise = torch.randn_like(x)
+        if t0 is None:
+            t0 = int(self._rng.randint(0, self.num_timesteps))
+        t = torch.full((x.shape[0],), t0, dtype=torch.int64, device=x.device)
+        x_t = ops.axpbypcz(x, float(self.sqrt_alphas_hat[t0]), noise, float(self.sqrt_one_minus_alphas_hat[t0]))
+        return x, x_t, t, noise
+
+    def _forward(self, x_t: Tensor, t: Tensor, cond: Dict) -> Tensor:
+        from .sal_unet import SalUNet
+
+        if isinstance(self.model, SalUNet):
+            return self.model(x_t, t, cond["feat_list"], cond.get("audio_feat"))
+        data = dict(cond)
+        data["input"] = x_t
+        return self.model(data, t)
+
+    def _sync_buffers(self) -> None:
+        bufs = [b for b in self.model.buffers() if b.dtype.is_floating_point]
+        if not bufs:
+            return
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view(b.shape))
+            off += b.numel()
+
+    def loss_and_backward(self, x0: Tensor, x_t: Tensor, t: Tensor, cond: Dict) -> Tensor:
+        """Forward + MSE + backward + gradient exchange; leaves the rank-SUMMED gradient in ``flat.flat_g``."""
+        from . import autograd_ops as ag
+
+        self.model.train()
+        if self.broadcast_buffers:
+            self._sync_buffers()
+        self.flat.zero_grad()
+        self.reducer.arm()
+        pred = self._forward(x_t, t, cond)
+        loss = ag.mse_loss(pred, x0, self.mse_weight / x0.shape[0])
+        loss.backward()
+        self.reducer.finish()
+        return loss.detach()
+
+    def optimizer_step(self) -> None:
+        from . import ops
+
+        self.step_count += 1
+        gscale = 1.0 / self.world
+        norm = ops.grad_norm(self.flat.flat_g, gscale) if self.grad_clip > 0 else None
+        self.last_norm = norm
+        ops.adam_step(self.flat.flat_p, self.flat.flat_g, self.flat.exp_avg, self.flat.exp_avg_sq, step=self.step_count,
+                      lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, gscale=gscale, norm=norm,
+                      max_norm=self.grad_clip, store_clipped_grad=self.store_clipped_grad)
+        bump = getattr(self.model, "parameters_updated", None)
+        if bump is not None:
+            bump()
+        for m in self.model.modules():  # nested denoiser inside a VideoSaliencyModel
+            if m is not self.model and hasattr(m, "parameters_updated"):
+                m.parameters_updated()
+
+    def step(self, sal_maps: Tensor, cond: Dict, *, t0: Optional[int] = None, noise: Optional[Tensor] = None,
+             dequant_noise: Optional[Tensor] = None) -> Tensor:
+        """One training step on this rank's clips; returns the (detached, device-resident) loss."""
+        x0, x_t, t, _ = self.prepare_data(sal_maps, t0=t0, noise=noise, dequant_noise=dequant_noise)
+        loss = self.loss_and_backward(x0, x_t, t, cond)
+        self.optimizer_step()
+        return loss
+
+    # ---- checkpoint surface of torch.optim.Adam (R/diffusion_trainer.py:263-280: "optim_dict") ----
+    def state_dict(self) -> Dict:
+        return {"step": self.step_count, "exp_avg": self.flat.exp_avg.clone(), "exp_avg_sq": self.flat.exp_avg_sq.clone(),
+                "lr": self.lr}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        self.step_count = int(sd["step"])
+        self.flat.exp_avg.copy_(sd["exp_avg"])
+        self.flat.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.lr = float(sd.get("lr", self.lr))

@@ -222,6 +222,29 @@ int diffsal_head_sigmoid(const float* x, const float* w /*[C]*/, const float* bi
 int diffsal_axpbypcz(const float* x, const float* y, const float* z, float a, float b, float c, float* out,
                      size_t n, diffsal_stream_t stream);
 
+/* ---- K16 tail: loss, gradient clipping and the optimizer, on flat fp32 buffers -------------
+ * diffsal_reduce_blocks(): number of doubles the `part` scratch of the two reductions below must hold.
+ *
+ * mse_loss: loss[0] = loss_scale * sum (pred - target)^2 and, if dpred != NULL, dpred = 2 loss_scale (pred - target).
+ *   With loss_scale = mse_weight / batch this is `mse_weight * (pred-gt).square().sum(dim=(1,2,3)).mean(dim=0)`
+ *   (R/models/sal_losses.py:189-192) and its gradient.  n % 4 == 0.
+ * grad_norm: norm[0] = gscale * ||g||_2 over the flat gradient buffer -- total_norm of
+ *   torch.nn.utils.clip_grad_norm_ (R/diffusion_trainer.py:228-233); gscale = 1/world_size folds in the DDP mean.
+ * adam_step: torch.optim.Adam.step (R/util/utils.py:116-123, R/diffusion_trainer.py:235; amsgrad=false) on
+ *   p, m (exp_avg), v (exp_avg_sq), with the gradient first multiplied by
+ *   gscale * min(1, max_norm / (norm[0] + 1e-6)) (norm may be NULL or max_norm <= 0: no clipping).  `step` counts
+ *   from 1.  store_clipped_grad != 0 writes the scaled gradient back into g as clip_grad_norm_ does.
+ * scale_by: out = x * s[0] with s a device scalar (the incoming d(loss) of the MSE backward).  n % 4 == 0.
+ * Reductions are fp64 with a fixed order: a step is bit-reproducible.  No host synchronisation. */
+int diffsal_reduce_blocks(void);
+int diffsal_scale_by(const float* x, const float* s, float* out, long n, diffsal_stream_t stream);
+int diffsal_mse_loss(const float* pred, const float* target, float* dpred, float* loss, double* part, long n,
+                     float loss_scale, diffsal_stream_t stream);
+int diffsal_grad_norm(const float* g, long n, float gscale, float* norm, double* part, diffsal_stream_t stream);
+int diffsal_adam_step(float* p, float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int step, float gscale, const float* norm, float max_norm,
+                      int store_clipped_grad, diffsal_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

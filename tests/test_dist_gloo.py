@@ -60,3 +60,69 @@ def test_shard_range_covers_everything_once(n, world):
     assert seen == list(range(n))
     sizes = [len(dsd.shard_range(n, r, world)) for r in range(world)]
     assert max(sizes) - min(sizes) <= 1
+
+
+# ---- training exchange (K16 / BASELINE configs[3]): flat gradient buckets + asynchronous all-reduce ----
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.unused = torch.nn.Linear(5, 5)  # never called: its gradient stays zero, its bucket is launched by finish()
+        self.body = torch.nn.Sequential(torch.nn.Linear(6, 50), torch.nn.ReLU(), torch.nn.Linear(50, 70), torch.nn.ReLU(),
+                                        torch.nn.Linear(70, 3))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _toy_trainable():
+    torch.manual_seed(3)
+    return _Toy()
+
+
+def _train_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from diff_sal_amd.train_step import FlatParams, GradReducer
+
+    dsd.init_from_env("gloo")
+    m = _toy_trainable()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = FlatParams(m, bucket_bytes=1024)  # several buckets
+    red = GradReducer(flat)
+    same_values = all(torch.equal(before[k], v) for k, v in m.state_dict().items())
+    views = all(p.data_ptr() == flat.flat_p.data_ptr() + 4 * o and p.grad.data_ptr() == flat.flat_g.data_ptr() + 4 * o
+                for p, o in zip(flat.params, flat.offsets))
+    ok_steps = []
+    for it in range(2):  # two steps: arm()/finish() are reusable and zero_grad() really clears
+        g = torch.Generator().manual_seed(100 * it + rank)
+        x = torch.randn(4, 6, generator=g)
+        flat.zero_grad()
+        red.arm()
+        m(x).square().sum().backward()
+        red.finish()
+        # expected: sum over ranks of the single-process gradients
+        exp = torch.zeros_like(flat.flat_g)
+        for r in range(world):
+            m2 = _toy_trainable()
+            f2 = FlatParams(m2, bucket_bytes=1024)
+            xr = torch.randn(4, 6, generator=torch.Generator().manual_seed(100 * it + r))
+            m2(xr).square().sum().backward()
+            exp += f2.flat_g
+        ok_steps.append(bool(torch.allclose(flat.flat_g, exp, rtol=1e-6, atol=1e-6)))
+    ret[rank] = dict(same_values=same_values, views=views, ok=ok_steps, nb=len(flat.buckets), order=list(red.launch_order),
+                     cover=sum(len(b) for b in flat.buckets) == flat.numel,
+                     first_is_last_layer=flat.params[0] is list(m.parameters())[-1])
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bucketed_gradient_allreduce():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r]["same_values"] and ret[r]["views"] and ret[r]["cover"] and ret[r]["first_is_last_layer"]
+        assert ret[r]["ok"] == [True, True]
+        assert ret[r]["nb"] >= 3
+        assert sorted(ret[r]["order"]) == list(range(ret[r]["nb"]))   # every bucket exchanged exactly once
+    assert ret[0]["order"] == ret[1]["order"]                          # same collective order on every rank

@@ -288,3 +288,59 @@ def test_audio_fuse_backward(ag, stage):
     od.backward(g.to(DEV))
     assert rel(xd.grad, x5.grad.permute(0, 2, 3, 4, 1)) < 5e-5
     assert rel(ad.grad, a_small.grad) < 5e-5
+
+
+# ---- loss / clip / optimizer kernels (csrc/optim.hip) ----
+def test_mse_loss_value_and_gradient(ag):
+    A, _ = ag
+    torch.manual_seed(11)
+    pred = torch.rand(3, 1, 28, 48)
+    tgt = torch.rand(3, 1, 28, 48)
+    p = pred.clone().requires_grad_(True)
+    ref = 0.7 * (p - tgt).square().sum(dim=(1, 2, 3)).mean(dim=0)   # R/models/sal_losses.py:189-192
+    (3.0 * ref).backward()
+    q = pred.to(DEV).requires_grad_(True)
+    loss = A.mse_loss(q, tgt.to(DEV), 0.7 / 3)
+    (3.0 * loss).backward()
+    assert loss.shape == ()
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item())
+    assert (q.grad.cpu() - p.grad).abs().max().item() < 1e-6 * p.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("n", [4, 1000, 1 << 20, (1 << 22) + 3])
+def test_grad_norm_matches_fp64(ag, n):
+    _, ops = ag
+    torch.manual_seed(n)
+    g = torch.randn(n)
+    got = ops.grad_norm(g.to(DEV), 0.5).item()
+    ref = 0.5 * g.double().norm().item()
+    assert abs(got - ref) < 1e-6 * ref
+
+
+@pytest.mark.parametrize("max_norm,world", [(1.0, 1), (1.0, 4), (0.0, 1)])
+def test_adam_step_matches_torch_adam_with_clipping(ag, max_norm, world):
+    """3 steps of clip_grad_norm_ + torch.optim.Adam (R/diffusion_trainer.py:228-235, R/util/utils.py:116-123) on CPU vs
+    grad_norm + adam_step on flat buffers; gradients arrive as rank SUMS, the mean is folded into gscale."""
+    _, ops = ag
+    torch.manual_seed(5)
+    n = 70003
+    p0 = torch.randn(n)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gsum = torch.randn(n) * (10.0 if step == 2 else 0.001) * world   # step 2 is clipped, the others are not
+        ref_p.grad = gsum / world
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([ref_p], max_norm)
+        opt.step()
+        g = gsum.to(DEV)
+        norm = ops.grad_norm(g, 1.0 / world) if max_norm > 0 else None
+        ops.adam_step(p, g, m, v, step=step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, gscale=1.0 / world, norm=norm,
+                      max_norm=max_norm, store_clipped_grad=True)
+        assert (g.cpu() - ref_p.grad).abs().max().item() <= 2e-6 * ref_p.grad.abs().max().item()   # clipped grad written back
+        st = opt.state[ref_p]
+        assert (m.cpu() - st["exp_avg"]).abs().max().item() <= 1e-6 * st["exp_avg"].abs().max().item()
+        assert (v.cpu() - st["exp_avg_sq"]).abs().max().item() <= 2e-6 * st["exp_avg_sq"].abs().max().item()
+        # the update is ~lr * m / sqrt(v): compare the step taken, not the parameter (|p| ~ 1 hides it)
+        assert (p.cpu() - ref_p.detach()).abs().max().item() <= 1e-4 * 1e-4 * step + 1.2e-7 * 4

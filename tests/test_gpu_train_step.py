@@ -1,5 +1,13 @@
 """Whole-network training forward/backward: HIP autograd path vs PyTorch autograd through the
-CPU oracle, train-mode BatchNorm, dropout disabled (masks cannot match by construction)."""
+CPU oracle, train-mode BatchNorm, dropout disabled (masks cannot match by construction).
+
+Tolerances.  Every backward kernel is pinned to ~1e-6 against autograd of the same op in test_gpu_train_ops.py.  A
+whole-network gradient cannot be compared that tightly: the decoder has 11 ReLUs over ~1.5 M pre-activations, a few
+of which land within 1e-6 of zero on any input, and two correct fp32 evaluations (different summation order) put such
+an element on different sides of the kink.  One flipped element changes the local gradient by O(1e-2) of its layer's
+maximum and everything upstream by ~1e-3 (measured: tools/relu_flip_census.py counts the flips against an fp64 run,
+tools/grad_trace.py shows the error entering exactly at the flipped layer; with no flip the HIP gradients are
+within 2e-6 of fp64).  Hence 5e-3 here."""
 import pytest
 import torch
 
@@ -58,3 +66,94 @@ def test_train_forward_and_all_parameter_gradients_match_oracle_autograd(av):
     print("median fraction:", worst[len(worst) // 2][0])
     assert checked > 150
     assert worst[-1][0] < 1.0, worst[-1]
+
+
+def _oracle_train_steps(cfg, sd, batches, av, n_steps, lr):
+    """The reference's step restated on the CPU: q_sample, train-mode forward, MSE, clip 1.0, torch Adam."""
+    from diff_sal_amd.diffusion_utils import get_beta_schedule, to_torch
+
+    betas = to_torch(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000))
+    a_hat = (1.0 - betas).cumprod(dim=0)
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    leaf = {k: (torch.nn.Parameter(v.clone()) if k in names else v.clone()) for k, v in sd.items()}
+    opt = torch.optim.Adam([leaf[k] for k in names], lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    losses, grads = [], None
+    for it in range(n_steps):
+        sal, dq, noise, t0, feats, audio = batches[it]
+        x0 = sal + 0.01 * dq
+        x_t = a_hat[t0].sqrt() * x0 + (1 - a_hat[t0]).sqrt() * noise
+        orc.BN_TRAIN = True
+        try:
+            pred = orc.salunet_forward(leaf, cfg, x_t, torch.full((sal.shape[0],), t0), feats, audio)
+        finally:
+            orc.BN_TRAIN = False
+        loss = (pred - x0).square().sum(dim=(1, 2, 3)).mean(dim=0)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([leaf[k] for k in names], 1.0)
+        if it == 0:
+            grads = {k: (None if leaf[k].grad is None else leaf[k].grad.clone()) for k in names}
+        opt.step()
+        losses.append(loss.item())
+    return losses, {k: leaf[k].detach() for k in names}, grads
+
+
+@pytest.mark.parametrize("av", [False, True])
+def test_training_steps_match_oracle_adam(av):
+    """Three full steps (prepare_data -> forward -> MSE -> backward -> clip -> Adam) of DiffusionTrainStep against
+    the oracle + torch.optim.Adam.  lr = the reference value 1e-4 (R/cfgs/diffusion.yml:56)."""
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    B, n_steps, lr = 2, 3, 1e-4
+    batches = []
+    for it in range(n_steps):
+        x, feats, audio = orc.synth_inputs(cfg, B, av, tag=f"ts{it}")
+        sal = torch.sigmoid(orc.synth_tensor(f"ts{it}.sal", (B, 1, *cfg.img_size)))
+        batches.append((sal, orc.synth_tensor(f"ts{it}.dq", tuple(sal.shape)), x, (137 * (it + 1)) % 1000, feats, audio))
+    ref_losses, ref_params, ref_grads = _oracle_train_steps(cfg, sd, batches, av, n_steps, lr)
+
+    net = build(cfg, sd)
+    net.dropout_p = 0.0
+    ts = DiffusionTrainStep(net, lr=lr, grad_clip=1.0)
+    assert ts.flat.live_numel == sum(p.numel() for p in net.parameters())
+    losses = []
+    for it in range(n_steps):
+        sal, dq, noise, t0, feats, audio = batches[it]
+        cond = {"feat_list": [f.to(DEV) for f in feats], "audio_feat": None if audio is None else audio.to(DEV)}
+        loss = ts.step(sal.to(DEV), cond, t0=t0, noise=noise.to(DEV), dequant_noise=dq.to(DEV))
+        losses.append(loss.item())
+    print("losses", losses, "ref", ref_losses, "grad norm (last)", ts.last_norm.item())
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 1e-3 * abs(b), (losses, ref_losses)
+    # parameters after three Adam steps: the step is ~lr * sign-like, so compare displacement in units of lr; parameters
+    # whose gradient is rounding noise (zero by symmetry) may move in either direction and are skipped
+    gscale = torch.stack([g.abs().max() for g in ref_grads.values() if g is not None]).median().item()
+    # Why the bounds are loose: after clipping by a norm of ~6e3 most gradient entries are ~1e-8 = Adam's eps, where the
+    # update lr*g/(|g|+eps) is linear in g, so a 1e-3-of-max gradient difference (fp32 order of summation, and the odd
+    # ReLU whose pre-activation of ~1e-7 falls on the other side of zero) becomes a few % of one step.  The Adam kernel
+    # itself is pinned to 1e-6 against torch.optim.Adam in test_gpu_train_ops.py.
+    errs = []
+    for name, p in net.named_parameters():
+        g = ref_grads[name]
+        if g is None or g.abs().max().item() < 1e-3 * gscale:
+            continue
+        mask = g.abs() > 1e-2 * g.abs().max()
+        d_got = (p.detach().cpu() - sd[name])[mask]
+        d_ref = (ref_params[name] - sd[name])[mask]
+        errs.append(((d_got - d_ref).abs().max().item() / (n_steps * lr), name))
+    errs.sort()
+    print("displacement error / (steps*lr): median %.4f, worst %s" % (errs[len(errs) // 2][0], errs[-3:]))
+    assert len(errs) > 100
+    assert errs[len(errs) // 2][0] < 0.15 and errs[-1][0] < 1.0, errs[-3:]
+    # eval-mode forward after training uses the UPDATED weights (packed-weight cache invalidated by the optimizer)
+    net.eval()
+    sal, dq, noise, t0, feats, audio = batches[0]
+    with torch.no_grad():
+        out = net(noise.to(DEV), torch.full((B,), t0, device=DEV), [f.to(DEV) for f in feats],
+                  None if audio is None else audio.to(DEV))
+    full_sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.salunet_forward(full_sd, cfg, noise, torch.full((B,), t0), feats, audio)
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
