@@ -50,7 +50,9 @@ SIGNATURES = {
     "diffsal_dwconv_bwd_weight_chunks": (c_i, [c_i] * 6),
     "diffsal_dwconv_bwd_weight": (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f]),
     "diffsal_attention_bwd_blocks": (c_i, [c_i, c_i, c_i]),
-    "diffsal_attention_bwd": (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl, c_f]),
+    "diffsal_attention_bwd": (c_i, [c_f] * 7 + [c_i] * 6 + [c_fl, c_f]),
+    "diffsal_wgrad_segmented_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "diffsal_wgrad_segmented": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "diffsal_resize_bilinear_bwd": (c_i, [c_f, c_f] + [c_i] * 6 + [c_f]),
     "diffsal_unpack_frames": (c_i, [c_f, c_f] + [c_i] * 5 + [c_f]),
     "diffsal_head_bwd": (c_i, [c_f] * 6 + [c_i, c_i, c_i, c_f]),

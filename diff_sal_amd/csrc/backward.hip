@@ -365,30 +365,30 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention backward (pooled K/V, Lk <= 32): dq directly; dk, dv accumulated per workgroup in LDS and
-// written as partials part[n][block][2][Lk][C] (summed by the caller).  Same lane mapping as the forward.
+// Attention backward (pooled K/V, Lk <= 32), pass 1 of 2: per query, recompute P = softmax(q K^T scale), form
+// dS = P (dP - <P, dP>) scale with dP = dO V^T, write dq = dS K and store P and dS as [N*Lq][ld] rows
+// (column = head * Lk + t).  Pass 2 is two segmented weight-gradient GEMMs on the matrix cores
+// (wgrad.hip: dK = dS^T Q, dV = P^T dO, one segment per image) -- no atomics anywhere, so the result is
+// deterministic.  Same lane mapping as the forward kernel.
 // ------------------------------------------------------------------------------------------------
 template <int LK, int G>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, const float* __restrict__ dout,
-                                                            float* __restrict__ dq, float* __restrict__ part, int Lq,
-                                                            int Lk, int C, int heads, float scale) {
-  // one workgroup = one image, one HEAD (blockIdx.z) and a run of queries: K | V | dK | dV of that head, [Lk][d] each
+                                                            float* __restrict__ dq, float* __restrict__ p_out,
+                                                            float* __restrict__ ds_out, int Lq, int Lk, int C, int heads,
+                                                            int ld, float scale) {
+  // one workgroup = one image, one HEAD (blockIdx.z) and a run of queries: K | V of that head in LDS, [Lk][d] each
   extern __shared__ float sh[];
   const int d = C / heads, nf4 = d >> 2;
   const int hd = blockIdx.z;
   const int cb = hd * d;
   float* Ks = sh;
   float* Vs = sh + Lk * d;
-  float* dKs = sh + 2 * Lk * d;
-  float* dVs = sh + 3 * Lk * d;
   const int n = blockIdx.y;
   for (int i = threadIdx.x; i < Lk * nf4; i += 256) {
     const int t = i / nf4, j = (i - t * nf4) * 4;
     st4(Ks + t * d + j, ld4(k + (static_cast<long>(n) * Lk + t) * C + cb + j));
     st4(Vs + t * d + j, ld4(v + (static_cast<long>(n) * Lk + t) * C + cb + j));
-    st4(dKs + t * d + j, make_float4(0, 0, 0, 0));
-    st4(dVs + t * d + j, make_float4(0, 0, 0, 0));
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -431,7 +431,6 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
   for (int t = 0; t < LK; ++t) ds[t] = t < Lk ? sc[t] * (dp[t] - dot) * scale : 0.f;   // dS * scale
   float* dqr = dq + (static_cast<long>(n) * Lq + lc) * C + cb;
   for (int i = g; i < nf4; i += G) {
-    const float4 qv = ld4(qr + 4 * i), gv = ld4(gr + 4 * i);
     float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < LK; ++t) {
@@ -439,25 +438,17 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         const float4 kv = ld4(Ks + t * d + 4 * i);
         acc.x = fmaf(ds[t], kv.x, acc.x); acc.y = fmaf(ds[t], kv.y, acc.y);
         acc.z = fmaf(ds[t], kv.z, acc.z); acc.w = fmaf(ds[t], kv.w, acc.w);
-        if (valid) {
-          float* dk = dKs + t * d + 4 * i;
-          float* dv = dVs + t * d + 4 * i;
-          atomicAdd(dk + 0, ds[t] * qv.x); atomicAdd(dk + 1, ds[t] * qv.y);
-          atomicAdd(dk + 2, ds[t] * qv.z); atomicAdd(dk + 3, ds[t] * qv.w);
-          atomicAdd(dv + 0, sc[t] * gv.x); atomicAdd(dv + 1, sc[t] * gv.y);
-          atomicAdd(dv + 2, sc[t] * gv.z); atomicAdd(dv + 3, sc[t] * gv.w);
-        }
       }
     }
     if (valid) st4(dqr + 4 * i, acc);
   }
-  __syncthreads();
-  // part[n][block][{dK, dV}][Lk][C]: this head's d columns
-  float* o = part + (static_cast<long>(n) * gridDim.x + blockIdx.x) * 2 * Lk * C;
-  for (int i = threadIdx.x; i < 2 * Lk * nf4; i += 256) {
-    const int which = i / (Lk * nf4), r = i - which * Lk * nf4;
-    const int t = r / nf4, j = (r - t * nf4) * 4;
-    st4(o + (static_cast<long>(which) * Lk + t) * C + cb + j, ld4((which ? dVs : dKs) + t * d + j));
+  // every lane of a query group holds the same P / dS after the butterfly reductions: lane t % G writes column t
+  if (valid) {
+    float* pr = p_out + (static_cast<long>(n) * Lq + l) * ld + hd * Lk;
+    float* sr = ds_out + (static_cast<long>(n) * Lq + l) * ld + hd * Lk;
+#pragma unroll
+    for (int t = 0; t < LK; ++t)
+      if (t < Lk && (t % G) == g) { pr[t] = sc[t]; sr[t] = ds[t]; }
   }
 }
 
@@ -880,17 +871,17 @@ extern "C" int diffsal_dwconv_bwd_weight(const float* x, const float* du, double
 
 template <int LK, int G>
 static void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq,
-                                 float* part, int N, int Lq, int Lk, int C, int heads, float scale, int blocks,
-                                 hipStream_t s) {
-  const size_t lds = static_cast<size_t>(4) * Lk * (C / heads) * sizeof(float);
+                                 float* p_out, float* ds_out, int N, int Lq, int Lk, int C, int heads, int ld, float scale,
+                                 int blocks, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(2) * Lk * (C / heads) * sizeof(float);
   static bool raised = false;
   if (lds > 64 * 1024 && !raised) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<LK, G>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = true;
   }
-  hipLaunchKernelGGL((attention_bwd_kernel<LK, G>), dim3(blocks, N, heads), dim3(256), lds, s, q, k, v, dout, dq, part, Lq, Lk,
-                     C, heads, scale);
+  hipLaunchKernelGGL((attention_bwd_kernel<LK, G>), dim3(blocks, N, heads), dim3(256), lds, s, q, k, v, dout, dq, p_out,
+                     ds_out, Lq, Lk, C, heads, ld, scale);
 }
 
 static int attention_g(int C, int heads) {
@@ -906,23 +897,24 @@ extern "C" int diffsal_attention_bwd_blocks(int Lq, int C, int heads) {
 }
 
 extern "C" int diffsal_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq,
-                                     float* part, int N, int Lq, int Lk, int C, int heads, float scale,
-                                     diffsal_stream_t stream) {
-  DS_REQUIRE(q && k && v && dout && dq && part, DIFFSAL_E_ARG, "attention_bwd: null argument");
+                                     float* p_out, float* ds_out, int N, int Lq, int Lk, int C, int heads, int ld,
+                                     float scale, diffsal_stream_t stream) {
+  DS_REQUIRE(q && k && v && dout && dq && p_out && ds_out, DIFFSAL_E_ARG, "attention_bwd: null argument");
+  DS_REQUIRE(ld >= heads * Lk, DIFFSAL_E_SHAPE, "attention_bwd: ld=%d < heads*Lk=%d", ld, heads * Lk);
   DS_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && Lk <= 32 && (heads == 1 || heads == 2 || heads == 4) && C % heads == 0 &&
                  (C / heads) % 4 == 0,
              DIFFSAL_E_SHAPE, "attention_bwd: bad shape");
-  DS_REQUIRE(static_cast<size_t>(4) * Lk * (C / heads) * sizeof(float) <= 160 * 1024, DIFFSAL_E_SHAPE,
-             "attention_bwd: K/V + gradients of one head exceed LDS (Lk=%d d=%d)", Lk, C / heads);
+  DS_REQUIRE(static_cast<size_t>(2) * Lk * (C / heads) * sizeof(float) <= 160 * 1024, DIFFSAL_E_SHAPE,
+             "attention_bwd: K/V of one head exceed LDS (Lk=%d d=%d)", Lk, C / heads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int G = attention_g(C, heads);
   const int blocks = diffsal_attention_bwd_blocks(Lq, C, heads);
 #define ABW(L)                                                                                                        \
   switch (G) {                                                                                                        \
-    case 16: launch_attention_bwd<L, 16>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;      \
-    case 8: launch_attention_bwd<L, 8>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;        \
-    case 4: launch_attention_bwd<L, 4>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;        \
-    default: launch_attention_bwd<L, 1>(q, k, v, dout, dq, part, N, Lq, Lk, C, heads, scale, blocks, s); break;       \
+    case 16: launch_attention_bwd<L, 16>(q, k, v, dout, dq, p_out, ds_out, N, Lq, Lk, C, heads, ld, scale, blocks, s); break;      \
+    case 8: launch_attention_bwd<L, 8>(q, k, v, dout, dq, p_out, ds_out, N, Lq, Lk, C, heads, ld, scale, blocks, s); break;        \
+    case 4: launch_attention_bwd<L, 4>(q, k, v, dout, dq, p_out, ds_out, N, Lq, Lk, C, heads, ld, scale, blocks, s); break;        \
+    default: launch_attention_bwd<L, 1>(q, k, v, dout, dq, p_out, ds_out, N, Lq, Lk, C, heads, ld, scale, blocks, s); break;       \
   }
   if (Lk <= 4) { ABW(4) } else if (Lk <= 8) { ABW(8) } else if (Lk <= 18) { ABW(18) } else { ABW(32) }
 #undef ABW

@@ -9,6 +9,8 @@
 // wave: conflict-free).  The M range is split over gridDim.z; partial tiles go to slabs that a second kernel
 // sums in a fixed order (deterministic, no atomics).  Replaces the wgrad half of autograd's conv/linear
 // backward for every call site listed in diffsal.h (training step).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace diffsal {
@@ -18,123 +20,152 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct WgradArgs {
   const float* in;   // layer input, NHWC
   const float* dy;   // [M][Cout]
-  float* slabs;      // [splits][Cout][K]
+  float* slabs;      // [segments * splits][Cout][K]
   int M, K, Cout;
   int H, W, Cin, Ho, Wo;
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
-  int rows_per_split;
+  int seg_rows, splits, rows_per_split;   // blockIdx.z = segment * splits + split
   unsigned in_bytes;
 };
 
-constexpr int WG_BCO = 128;   // co tile (2 waves x 2 MFMA tiles)
-constexpr int WG_SL = 6;      // K slices of 32 per tile (2 waves x 3 MFMA tiles)
-constexpr int WG_BKI = WG_SL * 32;
 constexpr int WG_BM = 32;     // pixels per reduction step
-constexpr int WG_PA = WG_BCO + 4;
-constexpr int WG_PB = WG_BKI + 4;
 
+// Tile = (WCO*CT*32 output channels) x (WK*ST K-slices of 32); the 4 waves form a WCO x WK grid and each owns
+// CT x ST MFMA 32x32 accumulators.  Global loads of step i+1 are issued into registers before the MFMA loop of
+// step i, so HBM/L2 latency hides behind 16 * CT * ST MFMAs per wave.
+template <int CT, int WCO, int WK, int ST>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float dYs[WG_BM * WG_PA];
-  __shared__ __attribute__((aligned(16))) float Xs[WG_BM * WG_PB];
+  static_assert(WCO * WK == 4, "four waves");
+  constexpr int BCO = WCO * CT * 32, SL = WK * ST, BKI = SL * 32;
+  constexpr int PA = BCO + 4, PB = BKI + 4;      // ds_read_b32 of 32 consecutive floats per half wave: conflict-free
+  constexpr int NA = BCO / 32, NB = BKI / 32;    // float4 loads per thread per step
+  __shared__ __attribute__((aligned(16))) float dYs[WG_BM * PA];
+  __shared__ __attribute__((aligned(16))) float Xs[WG_BM * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves over (co, k)
-  const int co0 = blockIdx.x * WG_BCO;
-  const int sl0 = blockIdx.y * WG_SL;       // first K slice of this tile
+  const int wm = wave / WK, wn = wave % WK;
+  const int co0 = blockIdx.x * BCO;
+  const int sl0 = blockIdx.y * SL;          // first K slice of this tile
   const int n_slices = p.K / 32;
-  const int m_begin = blockIdx.z * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int seg = blockIdx.z / p.splits, sp = blockIdx.z - seg * p.splits;
+  const int m_begin = seg * p.seg_rows + sp * p.rows_per_split;
+  const int m_end = min(min(p.M, (seg + 1) * p.seg_rows), m_begin + p.rows_per_split);
   const int HoWo = p.Ho * p.Wo;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
 
-  // per-slice tap displacement (wave-uniform)
-  int sl_dy[WG_SL], sl_dx[WG_SL];
-  unsigned sl_delta[WG_SL];
+  f32x16 acc[CT][ST];
 #pragma unroll
-  for (int s = 0; s < WG_SL; ++s) {
-    const int kt = min(sl0 + s, n_slices - 1);
-    const int chunk = kt / p.taps, tap = kt - chunk * p.taps;
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    sl_dy[s] = ky * p.dil_h;
-    sl_dx[s] = kx * p.dil_w;
-    sl_delta[s] = static_cast<unsigned>((sl_dy[s] * p.W + sl_dx[s]) * p.Cin + chunk * 32) * 4u;
-  }
-
-  f32x16 acc[2][3];
+  for (int i = 0; i < CT; ++i)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < ST; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // loader mapping: dY tile 32 x 128 floats = 1024 float4 (4 per thread); X tile 32 x 192 = 1536 float4 (6 per thread)
-  for (int mb = m_begin; mb < m_end; mb += WG_BM) {
+  // loader mapping: dY tile 32 x BCO floats (NA float4 per thread); X tile 32 x BKI floats (NB float4 per thread).
+  // Per-load constants that do not depend on the step: tile row, K slice -> tap displacement.
+  int xr[NB], xdy[NB], xdx[NB];
+  unsigned xdelta[NB];
+  bool xok[NB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;        // 0..1023
-      const int r = idx >> 5, c4 = (idx & 31) * 4;
+  for (int q = 0; q < NB; ++q) {
+    const int idx = tid + 256 * q;
+    const int r = idx / (BKI / 4), rem = idx - r * (BKI / 4);
+    const int s = rem >> 3, c4 = (rem & 7) * 4;
+    const int kt = min(sl0 + s, n_slices - 1);
+    const int chunk = kt / p.taps, tap = kt - chunk * p.taps;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    xr[q] = r;
+    xdy[q] = ky * p.dil_h;
+    xdx[q] = kx * p.dil_w;
+    xdelta[q] = static_cast<unsigned>((xdy[q] * p.W + xdx[q]) * p.Cin + chunk * 32 + c4) * 4u;
+    xok[q] = sl0 + s < n_slices;
+  }
+  float4 ra[NA], rb[NB];
+  auto prefetch = [&](int mb) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int idx = tid + 256 * q;
+      const int r = idx / (BCO / 4), c4 = (idx - r * (BCO / 4)) * 4;
       const int m = mb + r, co = co0 + c4;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (m < m_end && co < p.Cout) v = ld4(p.dy + static_cast<long>(m) * p.Cout + co);  // Cout % 4 == 0
-      st4(&dYs[r * WG_PA + c4], v);
+      ra[q] = make_float4(0, 0, 0, 0);
+      if (m < m_end && co < p.Cout) ra[q] = ld4(p.dy + static_cast<long>(m) * p.Cout + co);  // Cout % 4 == 0
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int idx = tid + 256 * q;        // 0..1535
-      const int r = idx / 48, rem = idx - r * 48;
-      const int s = rem >> 3, c4 = (rem & 7) * 4;
-      const int m = mb + r;
+    for (int q = 0; q < NB; ++q) {
+      const int m = mb + xr[q];
       unsigned off = 0xFFFFFFFFu;
-      if (m < m_end && sl0 + s < n_slices) {
+      if (m < m_end && xok[q]) {
         const int n = m / HoWo, rm = m - n * HoWo;
         const int oy = rm / p.Wo, ox = rm - oy * p.Wo;
         const int iy0 = oy * p.stride_h - p.pad_t, ix0 = ox * p.stride_w - p.pad_l;
-        const int iy = iy0 + sl_dy[s], ix = ix0 + sl_dx[s];
+        const int iy = iy0 + xdy[q], ix = ix0 + xdx[q];
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-          off = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + c4) * 4u + sl_delta[s];
+          off = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin) * 4u + xdelta[q];
       }
-      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-      st4(&Xs[r * WG_PB + s * 32 + c4], v);
+      rb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  };
+
+  if (m_begin < m_end) prefetch(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += WG_BM) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int idx = tid + 256 * q;
+      const int r = idx / (BCO / 4), c4 = (idx - r * (BCO / 4)) * 4;
+      st4(&dYs[r * PA + c4], ra[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int idx = tid + 256 * q;
+      const int r = idx / (BKI / 4), rem = idx - r * (BKI / 4);
+      st4(&Xs[r * PB + rem * 4], rb[q]);
     }
     __syncthreads();
+    if (mb + WG_BM < m_end) prefetch(mb + WG_BM);
 #pragma unroll
     for (int ks = 0; ks < WG_BM / 2; ++ks) {
       const int mrow = ks * 2 + (lane >> 5);
-      float a[2], b[3];
+      float a[CT], b[ST];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = dYs[mrow * WG_PA + (wm * 2 + i) * 32 + (lane & 31)];
+      for (int i = 0; i < CT; ++i) a[i] = dYs[mrow * PA + (wm * CT + i) * 32 + (lane & 31)];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) b[j] = Xs[mrow * WG_PB + (wn * 3 + j) * 32 + (lane & 31)];
+      for (int j = 0; j < ST; ++j) b[j] = Xs[mrow * PB + (wn * ST + j) * 32 + (lane & 31)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < ST; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
   // C/D map: col = lane & 31 (k within slice), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co within tile)
   float* slab = p.slabs + static_cast<long>(blockIdx.z) * p.Cout * p.K;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < CT; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int sl = sl0 + wn * 3 + j;
+    for (int j = 0; j < ST; ++j) {
+      const int sl = sl0 + wn * ST + j;
       if (sl >= n_slices) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + (wm * CT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co < p.Cout) slab[static_cast<long>(co) * p.K + sl * 32 + (lane & 31)] = acc[i][j][r];
       }
     }
 }
 
+// out[seg][i] = sum over the splits of one segment, in order (deterministic)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                        long n, int splits) {
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * 256) {
-    float s = slabs[i];
-    for (int k = 1; k < splits; ++k) s += slabs[static_cast<long>(k) * n + i];
-    out[i] = s;
+  const float* base = slabs + static_cast<long>(blockIdx.y) * splits * n;
+  float* o = out + static_cast<long>(blockIdx.y) * n;
+  const long n4 = n >> 2;   // n = Cout * K, K % 32 == 0
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<long>(gridDim.x) * 256) {
+    float4 s = ld4(base + i * 4);
+    for (int k = 1; k < splits; ++k) {
+      const float4 v = ld4(base + static_cast<long>(k) * n + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    st4(o + i * 4, s);
   }
 }
 
@@ -182,16 +213,85 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
 
 using namespace diffsal;
 
+namespace {
+
+struct WgradCfg { int bco, sl, mfma_per_kstep; };
+constexpr int kNumWgradCfgs = 5;
+constexpr WgradCfg kWgradCfgs[kNumWgradCfgs] = {{128, 6, 6}, {96, 8, 6}, {64, 12, 6}, {32, 12, 3}, {96, 4, 3}};
+
+struct WgradPlan { int cfg, splits, rows_per_split; };
+
+// Pick the tile shape and the M split from a small cost model (cycles):
+//  * a workgroup step (32 rows) is MFMA-bound at 16 k-steps x mfma_per_kstep x 64 cycles; two workgroups share a CU,
+//    512 run at once, so `rounds` of 512 each take 2 x steps x step_cycles;
+//  * every split writes and re-reads a Cout x K slab (~1250 B/cycle of HBM).
+// A workgroup count just above a multiple of 512 costs a whole extra round -- the reason this is not a fixed target.
+WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
+  WgradPlan pl{0, 1, 0};
+  double best = 1e300;
+  const long max_splits = (seg_rows + 4 * WG_BM - 1) / (4 * WG_BM);
+  int only = -1;
+  if (const char* e = getenv("DIFFSAL_WGRAD_CFG")) only = atoi(e) % kNumWgradCfgs;   // tuning aid
+  for (int c = 0; c < kNumWgradCfgs; ++c) {
+    if (only >= 0 && c != only) continue;
+    const WgradCfg cf = kWgradCfgs[c];
+    // the narrow-Cout tiles re-read the input once per 32/64 output channels (no memory term in the model below):
+    // only for layers that are that narrow
+    if (only < 0 && ((c == 3 && Cout > 48) || (c == 2 && Cout > 64))) continue;
+    const long tiles = ((Cout + cf.bco - 1) / cf.bco) * ((K / 32 + cf.sl - 1) / cf.sl) * segments;
+    const double step_cycles = 16.0 * cf.mfma_per_kstep * 64.0;
+    for (int r = 1; r <= 8; ++r) {
+      long sp = r * 512L / tiles;
+      sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
+      sp = sp > 256 ? 256 : sp;
+      const long wgs = tiles * sp;
+      const long rounds = (wgs + 511) / 512;
+      const long rps = ((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM;
+      const double steps = static_cast<double>(rps) / WG_BM + 4.0;
+      const double occ = wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0);
+      double t = rounds * occ * steps * step_cycles;
+      if (sp > 1) t += 2.0 * sp * segments * Cout * static_cast<double>(K) * 4.0 / 1250.0;
+      if (t < best) { best = t; pl.cfg = c; pl.splits = static_cast<int>(sp); pl.rows_per_split = static_cast<int>(rps); }
+    }
+  }
+  if (getenv("DIFFSAL_WGRAD_VERBOSE"))
+    fprintf(stderr, "wgrad plan: Cout=%d K=%ld seg_rows=%ld segs=%d -> cfg %d splits %d rows/split %d model %.0f cycles\n",
+            Cout, K, seg_rows, segments, pl.cfg, pl.splits, pl.rows_per_split, best);
+  return pl;
+}
+
+int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
+  const WgradPlan pl = wgrad_plan(a.Cout, a.K, a.seg_rows, segments);
+  a.splits = pl.splits;
+  a.rows_per_split = pl.rows_per_split;
+  const WgradCfg cf = kWgradCfgs[pl.cfg];
+  const dim3 grid((a.Cout + cf.bco - 1) / cf.bco, (a.K / 32 + cf.sl - 1) / cf.sl, segments * pl.splits);
+  const long n = static_cast<long>(a.Cout) * a.K;
+  if (pl.splits == 1) a.slabs = out;   // one split per segment: the tile goes straight to its destination
+  switch (pl.cfg) {
+    case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((wgrad_kernel<3, 1, 4, 2>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((wgrad_kernel<2, 1, 4, 3>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((wgrad_kernel<1, 1, 4, 3>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((wgrad_kernel<3, 1, 4, 1>), grid, dim3(256), 0, s, a); break;
+  }
+  int rc = check_launch("conv_wgrad");
+  if (rc || pl.splits == 1) return rc;
+  long g = (n / 4 + 255) / 256;
+  g = g > 1024 ? 1024 : g;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(static_cast<int>(g), segments), dim3(256), 0, s,
+                     static_cast<const float*>(a.slabs), out, n, pl.splits);
+  return check_launch("conv_wgrad(sum)");
+}
+
+}  // namespace
+
 extern "C" size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cin % 32) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const long K = static_cast<long>(d->KH) * d->KW * d->Cin;
-  const long tiles = ((d->Cout + WG_BCO - 1) / WG_BCO) * ((K / 32 + WG_SL - 1) / WG_SL);
-  long splits = (1024 + tiles - 1) / tiles;
-  const long max_splits = (M + 4 * WG_BM - 1) / (4 * WG_BM);
-  splits = splits < 1 ? 1 : (splits > max_splits ? max_splits : splits);
-  splits = splits > 256 ? 256 : splits;
-  return static_cast<size_t>(splits) * d->Cout * K * sizeof(float);
+  const WgradPlan pl = wgrad_plan(d->Cout, K, M, 1);
+  return static_cast<size_t>(pl.splits) * d->Cout * K * sizeof(float);
 }
 
 extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, const float* dy, float* dw_packed,
@@ -205,28 +305,44 @@ extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, c
   DS_REQUIRE(M > 0 && M < (1L << 31) && in_bytes < (1L << 32) - 16 && d->KH * d->KW <= 32, DIFFSAL_E_SHAPE,
              "conv_wgrad: problem too large");
   const size_t need = diffsal_conv_wgrad_ws_bytes(d);
-  DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(in), DIFFSAL_E_ARG,
+  DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(in) && aligned16(dw_packed), DIFFSAL_E_ARG,
              "conv_wgrad: needs %zu bytes of 16-byte aligned workspace", need);
-  const int splits = static_cast<int>(need / (static_cast<size_t>(d->Cout) * K * sizeof(float)));
   WgradArgs a;
   a.in = in; a.dy = dy; a.slabs = static_cast<float*>(ws);
   a.M = static_cast<int>(M); a.K = static_cast<int>(K); a.Cout = d->Cout;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w;
-  a.rows_per_split = static_cast<int>(((M + splits - 1) / splits + WG_BM - 1) / WG_BM * WG_BM);
+  a.seg_rows = static_cast<int>(M);
   a.in_bytes = static_cast<unsigned>(in_bytes);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((d->Cout + WG_BCO - 1) / WG_BCO, (static_cast<int>(K / 32) + WG_SL - 1) / WG_SL, splits);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, a);
-  int rc = check_launch("conv_wgrad");
-  if (rc) return rc;
-  const long n = static_cast<long>(d->Cout) * K;
-  long g = (n + 255) / 256;
-  g = g > 2048 ? 2048 : g;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(static_cast<int>(g)), dim3(256), 0, s, static_cast<const float*>(ws),
-                     dw_packed, n, splits);
-  return check_launch("conv_wgrad(sum)");
+  return wgrad_launch(a, 1, dw_packed, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t diffsal_wgrad_segmented_ws_bytes(int segments, int seg_rows, int K, int Cout) {
+  if (segments <= 0 || seg_rows <= 0 || K <= 0 || K % 32 || Cout <= 0) return 0;
+  const WgradPlan pl = wgrad_plan(Cout, K, seg_rows, segments);
+  return static_cast<size_t>(segments) * pl.splits * Cout * K * sizeof(float);
+}
+
+extern "C" int diffsal_wgrad_segmented(const float* x, const float* dy, float* out, int segments, int seg_rows, int K,
+                                       int Cout, void* ws, size_t ws_bytes, diffsal_stream_t stream) {
+  DS_REQUIRE(x && dy && out && ws, DIFFSAL_E_ARG, "wgrad_segmented: null argument");
+  DS_REQUIRE(segments > 0 && seg_rows > 0 && K > 0 && K % 32 == 0 && Cout > 0 && Cout % 4 == 0, DIFFSAL_E_SHAPE,
+             "wgrad_segmented: bad shape segments=%d seg_rows=%d K=%d Cout=%d", segments, seg_rows, K, Cout);
+  const long M = static_cast<long>(segments) * seg_rows;
+  const long in_bytes = M * K * 4;
+  DS_REQUIRE(M < (1L << 31) && in_bytes < (1L << 32) - 16, DIFFSAL_E_SHAPE, "wgrad_segmented: problem too large");
+  const size_t need = diffsal_wgrad_segmented_ws_bytes(segments, seg_rows, K, Cout);
+  DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(x) && aligned16(out), DIFFSAL_E_ARG,
+             "wgrad_segmented: needs %zu bytes of 16-byte aligned workspace", need);
+  WgradArgs a;
+  a.in = x; a.dy = dy; a.slabs = static_cast<float*>(ws);
+  a.M = static_cast<int>(M); a.K = K; a.Cout = Cout;
+  a.H = 1; a.W = static_cast<int>(M); a.Cin = K; a.Ho = 1; a.Wo = static_cast<int>(M);
+  a.KW = 1; a.taps = 1; a.stride_h = 1; a.stride_w = 1; a.pad_t = 0; a.pad_l = 0; a.dil_h = 1; a.dil_w = 1;
+  a.seg_rows = seg_rows;
+  a.in_bytes = static_cast<unsigned>(in_bytes);
+  return wgrad_launch(a, segments, out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int diffsal_colsum(const float* dy, float* out, int M, int C, int seg_rows, void* ws, size_t ws_bytes,

@@ -269,7 +269,13 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     nws = lib.diffsal_conv_wgrad_ws_bytes(C.byref(d))
     ws = torch.empty((nws // 4,), device=x.device, dtype=torch.float32)
     dw = torch.empty((Cout, kh * kw * Cin), device=x.device, dtype=torch.float32)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), nws, _stream()), "conv_wgrad")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin))
     return dw
 
 
@@ -386,18 +392,41 @@ def dwconv_bwd(x: Tensor, w: Tensor, du: Tensor, k: int, stride: int, pad: int, 
     return dx, dw
 
 
+def wgrad_segmented(x: Tensor, dy: Tensor, segments: int) -> Tensor:
+    """out[s] = dy_s^T @ x_s for the ``segments`` equal row blocks of x [M, K] and dy [M, Cout] -> [segments, Cout, K]."""
+    lib = _lib.load()
+    M, K = x.shape
+    Cout = dy.shape[1]
+    if M % segments or dy.shape[0] != M:
+        raise RuntimeError(f"wgrad_segmented: {M} rows do not split into {segments} segments")
+    nws = lib.diffsal_wgrad_segmented_ws_bytes(segments, M // segments, K, Cout)
+    ws = torch.empty((max(nws // 4, 4),), device=x.device, dtype=torch.float32)
+    out = torch.empty((segments, Cout, K), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_wgrad_segmented(_p(x), _p(dy), _p(out), segments, M // segments, K, Cout, _p(ws), nws, _stream()),
+               "wgrad_segmented")
+    return out
+
+
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, heads: int, scale: float):
-    """-> (dq, dk, dv)."""
+    """-> (dq, dk, dv).  Pass 1: per-query kernel (dq, P, dS); pass 2: dk = dS^T q, dv = P^T dout per image on the
+    matrix cores (segmented weight-gradient GEMM), keeping each head's own column block."""
     lib = _lib.load()
     N, Lq, Cc = q.shape
     Lk = k.shape[1]
-    blocks = lib.diffsal_attention_bwd_blocks(Lq, Cc, heads)
-    part = torch.empty((N, blocks, 2, Lk, Cc), device=q.device, dtype=torch.float32)
+    d = Cc // heads
+    ld = (heads * Lk + 3) // 4 * 4
+    alloc = torch.empty if ld == heads * Lk else torch.zeros
+    P = alloc((N * Lq, ld), device=q.device, dtype=torch.float32)
+    dS = alloc((N * Lq, ld), device=q.device, dtype=torch.float32)
     dq = torch.empty_like(q)
-    _lib.check(lib.diffsal_attention_bwd(_p(q), _p(k), _p(v), _p(dout), _p(dq), _p(part), N, Lq, Lk, Cc, heads, scale,
-                                         _stream()), "attention_bwd")
-    s = part.double().sum(dim=1).float()
-    return dq, s[:, 0].contiguous(), s[:, 1].contiguous()
+    _lib.check(lib.diffsal_attention_bwd(_p(q), _p(k), _p(v), _p(dout), _p(dq), _p(P), _p(dS), N, Lq, Lk, Cc, heads, ld,
+                                         scale, _stream()), "attention_bwd")
+    if Cc % 32:
+        raise RuntimeError(f"attention_bwd: C={Cc} must be a multiple of 32")
+    dk_full = wgrad_segmented(q.reshape(N * Lq, Cc), dS, N)       # [N, ld, C]: rows (head, t) x all channels
+    dv_full = wgrad_segmented(dout.reshape(N * Lq, Cc), P, N)
+    pick = lambda full: torch.cat([full[:, h * Lk:(h + 1) * Lk, h * d:(h + 1) * d] for h in range(heads)], dim=2)
+    return dq, pick(dk_full).contiguous(), pick(dv_full).contiguous()
 
 
 def resize_bilinear_bwd(dy: Tensor, h: int, w: int) -> Tensor:

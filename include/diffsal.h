@@ -95,6 +95,12 @@ int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, con
 size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wgrad(const diffsal_conv_desc* d /*host*/, const float* in, const float* dy, float* dw_packed,
                        void* ws, size_t ws_bytes, diffsal_stream_t stream);
+/* Batched form for token GEMMs: out[s][co][k] = sum over the seg_rows rows m of segment s of dy[m, co] * x[m, k]
+ * (x: [segments*seg_rows, K], dy: [segments*seg_rows, Cout]).  Used by the attention backward (one segment per
+ * image: dK = dS^T Q, dV = P^T dO; R/.../attention.py:97-108).  K % 32 == 0, Cout % 4 == 0. */
+size_t diffsal_wgrad_segmented_ws_bytes(int segments, int seg_rows, int K, int Cout);
+int diffsal_wgrad_segmented(const float* x, const float* dy, float* out, int segments, int seg_rows, int K, int Cout,
+                            void* ws, size_t ws_bytes, diffsal_stream_t stream);
 /* out[g, c] = sum of dy[m, c] over the rows of segment g (M / seg_rows segments): bias gradients (one segment)
  * and per-image vector gradients (one segment per image).  ws: >= (M/seg_rows) * 64 * C * 8 bytes (fp64 partials:
  * reductions across threads run in double so that heavily cancelling sums do not depend on the atomics order). */
@@ -141,11 +147,13 @@ int diffsal_dwconv_bwd_data(const float* du, const float* w, float* dx, int N, i
 int diffsal_dwconv_bwd_weight_chunks(int N, int H, int W, int k, int stride, int pad);
 int diffsal_dwconv_bwd_weight(const float* x, const float* du, double* part, int N, int H, int W, int C, int k,
                               int stride, int pad, diffsal_stream_t stream);
-/* Backward of diffsal_attention: dq [N,Lq,C]; dk, dv as per-workgroup partials part[N][blocks][2][Lk][C],
- * blocks = diffsal_attention_bwd_blocks(); the caller sums over blocks. */
+/* Backward of diffsal_attention, pass 1: dq [N,Lq,C], plus the softmax P and dS = P (dP - <P,dP>) scale as
+ * [N*Lq][ld] rows (column = head*Lk + t, ld >= heads*Lk, columns beyond heads*Lk untouched).  Pass 2 (dk, dv) is
+ * diffsal_wgrad_segmented on (dS, q) and (P, dout): no atomics, deterministic. */
 int diffsal_attention_bwd_blocks(int Lq, int C, int heads);
-int diffsal_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* part,
-                          int N, int Lq, int Lk, int C, int heads, float scale, diffsal_stream_t stream);
+int diffsal_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* p_out,
+                          float* ds_out, int N, int Lq, int Lk, int C, int heads, int ld, float scale,
+                          diffsal_stream_t stream);
 
 /* ---- K16 (training): remaining backward kernels ----------------------------------------------------
  * adjoint of diffsal_resize_bilinear (dy [N,H,W,C] -> dx [N,h,w,C]); backward of pack_frames for the visual

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Print the kernel timeline of one denoise step from a rocprofv3 --kernel-trace CSV.
 
-usage: tools/step_timeline.py <dir-or-csv> [step_index]
-Steps are delimited by the temb kernel (first launch of SalUNet.forward)."""
+usage: tools/step_timeline.py <dir-or-csv> [step_index] [delimiter-kernel-substring]
+Steps are delimited by the temb kernel (first launch of SalUNet.forward) unless another kernel name is given
+(training: "adam_kernel", the last launch of a step)."""
 import csv
 import glob
 import os
@@ -16,7 +17,11 @@ def main():
         src = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[0]
     rows = list(csv.DictReader(open(src)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "temb_dense0" in r["Kernel_Name"] or "temb_kernel" in r["Kernel_Name"]]
+    delim = sys.argv[3] if len(sys.argv) > 3 else None
+    if delim:
+        idx = [i + 1 for i, r in enumerate(rows) if delim in r["Kernel_Name"]]
+    else:
+        idx = [i for i, r in enumerate(rows) if "temb_dense0" in r["Kernel_Name"] or "temb_kernel" in r["Kernel_Name"]]
     a, b = idx[which], idx[which + 1]
     t0 = int(rows[a]["Start_Timestamp"])
     tot, groups = 0.0, {}
