@@ -69,6 +69,8 @@ SIGNATURES = {
     "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
+    "diffsal_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_col2im_disjoint": (c_i, [c_f, c_f] + [c_i] * 12 + [c_f]),
     "diffsal_reduce_blocks": (c_i, []),
     "diffsal_scale_by": (c_i, [c_f, c_f, c_f, C.c_long, c_f]),
     "diffsal_mse_loss": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_long, c_fl, c_f]),

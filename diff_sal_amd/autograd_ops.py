@@ -15,9 +15,15 @@ from .ops import ACT_NONE, ACT_RELU
 Tensor = torch.Tensor
 
 
-def dgrad_weight(w: Tensor) -> Tensor:
-    """Packed weight of the data-gradient convolution: dX = conv(dY, W^T flipped).  w: [Cout, Cin, KH, KW]."""
-    return ops.pack_conv_weight(w.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous())
+def dgrad_weight(w: Tensor, stride=(1, 1)) -> Tensor:
+    """Weight of the data-gradient computation of a conv with parameter w [Cout, Cin, KH, KW] (or Conv3d [.., KT,1,1]).
+
+    Overlapping taps (stride < kernel): packed weight of dX = conv(dY, W^T flipped).  Disjoint taps (stride >= kernel
+    on both axes): the [KH*KW*Cin, Cout] matrix of the GEMM dXcols = dY W, scattered by col2im (ConvFn.backward)."""
+    kh, kw = (w.shape[2], 1) if w.dim() == 5 else tuple(w.shape[2:])
+    if stride[0] >= kh and stride[1] >= kw and (kh, kw) != (1, 1):
+        return ops.pack_cols_weight(w)
+    return ops.pack_dgrad_weight(w)
 
 
 class ConvFn(torch.autograd.Function):
@@ -61,6 +67,12 @@ class ConvFn(torch.autograd.Function):
                 # flipped-kernel convolution over dY with padding dil*(k-1) - pad
                 pt, pl = dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1]
                 dx = ops.conv_igemm(g, w_dgrad, kh=kh, kw=kw, pad=(pt, pl), dil=dil, out_hw=(H, W))
+            elif stride[0] >= kh and stride[1] >= kw and dil == (1, 1):
+                # taps never overlap: one GEMM dXcols = dY W, then every input pixel copies its single source
+                if tuple(w_dgrad.shape) != (kh * kw * x.shape[-1], Cout):
+                    raise RuntimeError("ConvFn: disjoint-tap backward needs dgrad_weight(w, stride) (columns layout)")
+                cols = ops.conv_igemm(g.reshape(1, 1, N * Ho * Wo, Cout), w_dgrad)
+                dx = ops.col2im_disjoint(cols.reshape(N * Ho * Wo, -1), x.shape, (Ho, Wo), kh, kw, stride, pad)
             else:
                 # strided conv: scatter dY onto a zero grid at the stride (layout plumbing), then a stride-1 conv
                 Hd, Wd = (Ho - 1) * stride[0] + 1, (Wo - 1) * stride[1] + 1
@@ -83,7 +95,8 @@ def linear(x, w, bias=None, *, residual=None, act=ACT_NONE):
     M = 1
     for s in lead:
         M *= s
-    wd = w.detach().t().contiguous() if x.requires_grad else None
+    wd = ops.pack_dgrad_weight(w) if (x.requires_grad and w.shape[0] % 32 == 0) else (
+        w.detach().t().contiguous() if x.requires_grad else None)
     y = conv(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, w_dgrad=wd,
              residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
     return y.reshape(*lead, w.shape[0])

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffsal_hip.so")
-SOURCES = ["igemm.hip", "lin_stream.hip", "wgrad.hip", "backward.hip", "optim.hip", "norm.hip", "misc.hip"]
+SOURCES = ["igemm.hip", "lin_stream.hip", "wgrad.hip", "backward.hip", "optim.hip", "pack.hip", "norm.hip", "misc.hip"]
 
 
 def _hipcc():

@@ -627,13 +627,14 @@ __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------------
 // Audio fusion backward (transformer.py:133-146).  Forward: a = nearest-up(a_small), m = mean_t a*x,
-// s = softmax_x(m), out[b,c,t,y,x] = a*s (NCTHW).  One workgroup = (b, source row ys, 32-channel slab) and walks
-// the `up` output rows of that source row, so every contribution to da_small is workgroup-local (deterministic).
-//   ds = sum_t dout*a;  dm = s (ds - sum_x ds s);  dx = dm a / T;  da = dout s + dm x / T  (summed over the up x up block)
+// s = softmax_x(m), out[b,c,t,y,x] = a*s (NCTHW).  One workgroup = (b, output row y, 32-channel slab):
+//   ds = sum_t dout*a;  dm = s (ds - sum_x ds s);  dx = dm a / T;  da = dout s + dm x / T
+// da of the `up` output rows / columns sharing one audio cell: columns are summed in registers by the one thread
+// that owns the cell, rows go to part[(b,t,ys,xs)][dyr][c] and are added by diffsal_colsum (fixed order): no atomics.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void audio_fuse_bwd_kernel(const float* __restrict__ a_small, const float* __restrict__ x,
                                                              const float* __restrict__ dout, float* __restrict__ dx,
-                                                             float* __restrict__ da_small, int T, int H, int W, int C,
+                                                             float* __restrict__ part, int T, int H, int W, int C,
                                                              int h, int w, int up) {
   extern __shared__ float sh[];  // s[32][W+1] | dm[32][W+1] | da[T][w][32]
   const int WP = W + 1;
@@ -643,80 +644,92 @@ __global__ __launch_bounds__(256) void audio_fuse_bwd_kernel(const float* __rest
   const int cslabs = C / 32;
   int bid = blockIdx.x;
   const int cs = bid % cslabs; bid /= cslabs;
-  const int ys = bid % h;
-  const int b = bid / h;
+  const int y = bid % H;
+  const int b = bid / H;
+  const int ys = y / up, dyr = y - ys * up;
   const int cl = threadIdx.x & 31, xl = threadIdx.x >> 5;
   const int c = cs * 32 + cl;
   const float invT = 1.0f / static_cast<float>(T);
-  for (int i = threadIdx.x; i < T * w * 32; i += 256) sA[i] = 0.f;
-  __syncthreads();
-  for (int dyr = 0; dyr < up; ++dyr) {
-    const int y = ys * up + dyr;
-    // A: m[c][x] (lanes = channels)
-    for (int xx = xl; xx < W; xx += 8) {
-      const int xs = xx / up;
-      float acc = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c];
-        acc = fmaf(av, x[(((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c], acc);
-      }
-      sS[cl * WP + xx] = acc * invT;
+  // A: m[c][x] (lanes = channels)
+  for (int xx = xl; xx < W; xx += 8) {
+    const int xs = xx / up;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c];
+      acc = fmaf(av, x[(((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c], acc);
     }
-    __syncthreads();
-    // B: softmax over x per channel row (8 lanes per row)
-    {
-      const int row = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-      float mx = -3.0e38f;
-      for (int xx = l8; xx < W; xx += 8) mx = fmaxf(mx, sS[row * WP + xx]);
-      mx = group_max<8>(mx);
-      float sum = 0.f;
-      for (int xx = l8; xx < W; xx += 8) { const float e = expf(sS[row * WP + xx] - mx); sS[row * WP + xx] = e; sum += e; }
-      sum = group_sum<8>(sum);
-      const float inv = 1.0f / sum;
-      for (int xx = l8; xx < W; xx += 8) sS[row * WP + xx] *= inv;
-    }
-    __syncthreads();
-    // C: ds[c][x] = sum_t dout*a (lanes = x: dout rows are x-contiguous), and da += dout*s
-    for (int i = threadIdx.x; i < 32 * W; i += 256) {
-      const int xx = i % W, cc = i / W;
-      const int cg = cs * 32 + cc, xs = xx / up;
-      const float sv = sS[cc * WP + xx];
-      float acc = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const float g = dout[(((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx];
-        const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + cg];
-        acc = fmaf(g, av, acc);
-        atomicAdd(&sA[(t * w + xs) * 32 + cc], g * sv);
-      }
-      sD[cc * WP + xx] = acc;
-    }
-    __syncthreads();
-    // D: dm = s (ds - sum_x ds s)
-    {
-      const int row = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-      float dot = 0.f;
-      for (int xx = l8; xx < W; xx += 8) dot += sD[row * WP + xx] * sS[row * WP + xx];
-      dot = group_sum<8>(dot);
-      for (int xx = l8; xx < W; xx += 8) sD[row * WP + xx] = sS[row * WP + xx] * (sD[row * WP + xx] - dot);
-    }
-    __syncthreads();
-    // E: dx = dm a / T ; da += dm x / T   (lanes = channels)
-    for (int xx = xl; xx < W; xx += 8) {
-      const int xs = xx / up;
-      const float dm = sD[cl * WP + xx] * invT;
-      for (int t = 0; t < T; ++t) {
-        const long xo = (((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c;
-        const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c];
-        dx[xo] = dm * av;
-        atomicAdd(&sA[(t * w + xs) * 32 + cl], dm * x[xo]);
-      }
-    }
-    __syncthreads();
+    sS[cl * WP + xx] = acc * invT;
   }
+  __syncthreads();
+  // B: softmax over x per channel row (8 lanes per row)
+  {
+    const int row = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    float mx = -3.0e38f;
+    for (int xx = l8; xx < W; xx += 8) mx = fmaxf(mx, sS[row * WP + xx]);
+    mx = group_max<8>(mx);
+    float sum = 0.f;
+    for (int xx = l8; xx < W; xx += 8) { const float e = expf(sS[row * WP + xx] - mx); sS[row * WP + xx] = e; sum += e; }
+    sum = group_sum<8>(sum);
+    const float inv = 1.0f / sum;
+    for (int xx = l8; xx < W; xx += 8) sS[row * WP + xx] *= inv;
+  }
+  __syncthreads();
+  // C: thread = (channel, audio cell): ds[c][x] = sum_t dout*a for the cell's `up` columns, da = sum dout*s over them
+  for (int i = threadIdx.x; i < 32 * w; i += 256) {
+    const int xs = i % w, cc = i / w;         // lanes walk x: dout rows are x-contiguous
+    const int cg = cs * 32 + cc;
+    float dsu[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dsu[u] = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + cg];
+      const float* g = dout + (((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xs * up;
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < up) {
+          const float gv = g[u];
+          dsu[u] = fmaf(gv, av, dsu[u]);
+          acc = fmaf(gv, sS[cc * WP + xs * up + u], acc);
+        }
+      sA[(t * w + xs) * 32 + cc] = acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < up) sD[cc * WP + xs * up + u] = dsu[u];
+  }
+  __syncthreads();
+  // D: dm = s (ds - sum_x ds s)
+  {
+    const int row = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    float dot = 0.f;
+    for (int xx = l8; xx < W; xx += 8) dot += sD[row * WP + xx] * sS[row * WP + xx];
+    dot = group_sum<8>(dot);
+    for (int xx = l8; xx < W; xx += 8) sD[row * WP + xx] = sS[row * WP + xx] * (sD[row * WP + xx] - dot);
+  }
+  __syncthreads();
+  // E: thread = (channel, audio cell), lanes = channels: dx = dm a / T ; da += sum over the cell's columns of dm x / T
+  for (int i = threadIdx.x; i < 32 * w; i += 256) {
+    const int c2l = i & 31, xs = i >> 5;
+    const int c2 = cs * 32 + c2l;
+    for (int t = 0; t < T; ++t) {
+      const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c2];
+      float acc = 0.f;
+      for (int u = 0; u < up; ++u) {
+        const int xx = xs * up + u;
+        const float dm = sD[c2l * WP + xx] * invT;
+        const long xo = (((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c2;
+        dx[xo] = dm * av;
+        acc = fmaf(dm, x[xo], acc);
+      }
+      sA[(t * w + xs) * 32 + c2l] += acc;
+    }
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < T * w * 32; i += 256) {
     const int cc = i & 31, r = i >> 5;
     const int xs = r % w, t = r / w;
-    da_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + cs * 32 + cc] = sA[i];
+    part[((((static_cast<long>(b) * T + t) * h + ys) * w + xs) * up + dyr) * C + cs * 32 + cc] = sA[i];
   }
 }
 
@@ -750,9 +763,10 @@ extern "C" int diffsal_act_bwd(const float* dy, const float* ref, float* dx, siz
 
 extern "C" int diffsal_rowstats_chunks(int M, int seg_rows) {
   const int segs = M / seg_rows;
+  // ~1024 workgroups in flight (4 per CU) as long as a chunk keeps >= 64 rows
   int chunks = 1024 / (segs > 0 ? segs : 1);
-  chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-  while (chunks > 1 && seg_rows / chunks < 16) chunks >>= 1;
+  chunks = chunks < 1 ? 1 : (chunks > 1024 ? 1024 : chunks);
+  while (chunks > 1 && seg_rows / chunks < 64) chunks >>= 1;
   return chunks;
 }
 
@@ -975,17 +989,18 @@ extern "C" int diffsal_dense_small_bwd(const float* in, const float* w, const fl
   return check_launch("dense_small_bwd");
 }
 
-extern "C" int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* dout, float* dx, float* da_small,
+extern "C" int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* dout, float* dx, float* part,
                                       int B, int T, int H, int W, int C, int h, int w, diffsal_stream_t stream) {
-  DS_REQUIRE(a_small && x && dout && dx && da_small, DIFFSAL_E_ARG, "audio_fuse_bwd: null argument");
+  DS_REQUIRE(a_small && x && dout && dx && part, DIFFSAL_E_ARG, "audio_fuse_bwd: null argument");
   DS_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && h > 0 && w > 0, DIFFSAL_E_SHAPE,
              "audio_fuse_bwd: bad shape");
   int up = 1;
   if (h != H && w != W) up = H / h;
-  DS_REQUIRE(up >= 1 && h * up == H && w * up == W, DIFFSAL_E_SHAPE, "audio_fuse_bwd: incompatible audio map");
+  DS_REQUIRE(up >= 1 && up <= 8 && h * up == H && w * up == W, DIFFSAL_E_SHAPE,
+             "audio_fuse_bwd: incompatible audio map (integer up-factor <= 8 expected)");
   const size_t lds = (static_cast<size_t>(64) * (W + 1) + static_cast<size_t>(T) * w * 32) * sizeof(float);
   DS_REQUIRE(lds <= 64 * 1024, DIFFSAL_E_SHAPE, "audio_fuse_bwd: row too wide for LDS (W=%d)", W);
-  hipLaunchKernelGGL(audio_fuse_bwd_kernel, dim3(B * h * (C / 32)), dim3(256), lds, static_cast<hipStream_t>(stream),
-                     a_small, x, dout, dx, da_small, T, H, W, C, h, w, up);
+  hipLaunchKernelGGL(audio_fuse_bwd_kernel, dim3(B * H * (C / 32)), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     a_small, x, dout, dx, part, T, H, W, C, h, w, up);
   return check_launch("audio_fuse_bwd");
 }

@@ -198,15 +198,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(seg) * chunks + chunk) * C + i] = shd[i];
 }
 
-// out[g][c] (fp32) = sum over chunks of part[g][chunk][c] (fp64)
+// out[g][c] (fp32) = sum over chunks of part[g][chunk][c] (fp64).  Workgroup = (32 channels, segment); 8 thread groups
+// take every 8th chunk, then the 8 group sums are added in a fixed order.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out,
                                                            int segs, int chunks, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= segs * C) return;
-  const int g = i / C, c = i - g * C;
+  __shared__ double sh[8][33];
+  const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
   double s = 0.0;
-  for (int k = 0; k < chunks; ++k) s += part[(static_cast<long>(g) * chunks + k) * C + c];
-  out[i] = static_cast<float>(s);
+  if (c < C)
+    for (int k = kg; k < chunks; k += 8) s += part[(static_cast<long>(g) * chunks + k) * C + c];
+  sh[kg][cl] = s;
+  __syncthreads();
+  if (kg == 0 && c < C) {
+    double t = sh[0][cl];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += sh[j][cl];
+    out[static_cast<long>(g) * C + c] = static_cast<float>(t);
+  }
 }
 
 }  // namespace diffsal
@@ -351,9 +360,9 @@ extern "C" int diffsal_colsum(const float* dy, float* out, int M, int C, int seg
   DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 4096 && seg_rows > 0 && M % seg_rows == 0, DIFFSAL_E_SHAPE,
              "colsum: bad shape M=%d C=%d seg_rows=%d", M, C, seg_rows);
   const int segs = M / seg_rows;
-  int chunks = 2048 / segs;
-  chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-  while (chunks > 1 && seg_rows / chunks < 8) chunks >>= 1;
+  int chunks = 1024 / segs;
+  chunks = chunks < 1 ? 1 : (chunks > 512 ? 512 : chunks);
+  while (chunks > 1 && seg_rows / chunks < 32) chunks >>= 1;
   DS_REQUIRE(ws_bytes >= static_cast<size_t>(segs) * chunks * C * sizeof(double), DIFFSAL_E_ARG,
              "colsum: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -361,7 +370,7 @@ extern "C" int diffsal_colsum(const float* dy, float* out, int M, int C, int seg
                      C, seg_rows, chunks);
   int rc = check_launch("colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((segs * C + 255) / 256), dim3(256), 0, s,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32, segs), dim3(256), 0, s,
                      static_cast<const double*>(ws), out, segs, chunks, C);
   return check_launch("colsum(sum)");
 }

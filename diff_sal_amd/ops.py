@@ -87,24 +87,80 @@ def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, ep
     return out
 
 
+def _as_conv4(w: Tensor) -> Tensor:
+    """Conv3d weights [Cout, Cin, KT, 1, 1] and Linear weights [N, K] as [Cout, Cin, taps, 1] views."""
+    if w.dim() == 5:
+        return w[:, :, :, 0, 0].unsqueeze(-1)
+    if w.dim() == 2:
+        return w[:, :, None, None]
+    return w
+
+
+def _pack(w4: Tensor, mode: int) -> Tensor:
+    """csrc/pack.hip on a contiguous [Cout, Cin, kh, kw] (modes 0, 1) or packed [Cout, K] (mode 2, shape from w4)."""
+    lib = _lib.load()
+    co, ci, kh, kw = w4.shape
+    taps = kh * kw
+    src = w4.contiguous()
+    if mode == 1:
+        out = torch.empty((ci, taps * co), device=w4.device, dtype=torch.float32)
+    elif mode == 3:
+        out = torch.empty((taps * ci, co), device=w4.device, dtype=torch.float32)
+    else:
+        out = torch.empty((co, taps * ci), device=w4.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_pack_weight(_p(src), _p(out), co, ci, taps, mode, _stream()), "pack_weight")
+    return out
+
+
 def pack_conv_weight(w: Tensor) -> Tensor:
     """[Cout, Cin, KH, KW] (or Conv3d [Cout, Cin, KT, 1, 1]) -> [Cout, K] in the kernel's k order
     (ci // 32, tap, ci % 32); see include/diffsal.h."""
-    w = w.detach()
-    if w.dim() == 5:
-        w = w[:, :, :, 0, 0].unsqueeze(-1)  # [Cout, Cin, KT, 1]
-    co, ci, kh, kw = w.shape
-    return (w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3)
-            .reshape(co, kh * kw * ci).contiguous())
+    return _pack(_as_conv4(w.detach()), 0)
+
+
+def pack_dgrad_weight(w: Tensor) -> Tensor:
+    """Packed weight of the data-gradient convolution: [Cin, KH*KW*Cout], taps flipped (include/diffsal.h, mode 1)."""
+    return _pack(_as_conv4(w.detach()), 1)
+
+
+def pack_cols_weight(w: Tensor) -> Tensor:
+    """[KH*KW*Cin, Cout]: weight of the GEMM dXcols = dY W for non-overlapping convolutions (mode 3)."""
+    return _pack(_as_conv4(w.detach()), 3)
+
+
+def col2im_disjoint(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pad) -> Tensor:
+    """cols [N*Ho*Wo, kh*kw*C] -> dx [N,H,W,C] for a convolution with stride >= kernel (each input pixel has one source)."""
+    lib = _lib.load()
+    N, H, W, Cc = in_shape
+    dx = torch.empty((N, H, W, Cc), device=cols.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_col2im_disjoint(_p(cols), _p(dx), N, H, W, Cc, out_hw[0], out_hw[1], kh, kw, stride[0], stride[1],
+                                           pad[0], pad[1], _stream()), "col2im_disjoint")
+    return dx
+
+
+class _PackWeightFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        ctx.shape = tuple(w.shape)
+        return _pack(_as_conv4(w), 0)
+
+    @staticmethod
+    def backward(ctx, dwp):
+        lib = _lib.load()
+        shape = ctx.shape
+        co, ci = shape[0], shape[1]
+        taps = 1
+        for s_ in shape[2:]:
+            taps *= s_
+        dw = torch.empty(shape, device=dwp.device, dtype=torch.float32)
+        _lib.check(lib.diffsal_pack_weight(_p(dwp.contiguous()), _p(dw), co, ci, taps, 2, _stream()), "pack_weight")
+        return dw
 
 
 def pack_conv_weight_diff(w: Tensor) -> Tensor:
-    """pack_conv_weight that stays on the autograd tape (pure permutes/reshapes): dW flows back to ``w``."""
-    if w.dim() == 5:
-        w = w[:, :, :, 0, 0].unsqueeze(-1)
-    co, ci, kh, kw = w.shape
-    return (w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci // 32, 32).permute(0, 2, 1, 3)
-            .reshape(co, kh * kw * ci).contiguous())
+    """pack_conv_weight that stays on the autograd tape: dW (packed, from conv_wgrad) flows back to ``w`` in the
+    parameter layout."""
+    return _PackWeightFn.apply(w)
 
 
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
@@ -286,7 +342,7 @@ def colsum(dy: Tensor, seg_rows: Optional[int] = None) -> Tensor:
     M = dy.numel() // Cc
     seg = M if seg_rows is None else seg_rows
     out = torch.empty((M // seg, Cc), device=dy.device, dtype=torch.float32)
-    nws = (M // seg) * 64 * Cc * 8
+    nws = (M // seg) * 512 * Cc * 8
     ws = torch.empty((nws // 8,), device=dy.device, dtype=torch.float64)
     _lib.check(lib.diffsal_colsum(_p(dy), _p(out), M, Cc, seg, ws.data_ptr(), nws, _stream()), "colsum")
     return out
@@ -488,10 +544,13 @@ def audio_fuse_bwd(a_small: Tensor, x: Tensor, dout: Tensor, h: int, w: int):
     lib = _lib.load()
     B, T, H, W, Cc = x.shape
     dx = torch.empty_like(x)
-    da = torch.empty_like(a_small)
-    _lib.check(lib.diffsal_audio_fuse_bwd(_p(a_small), _p(x), _p(dout), _p(dx), _p(da), B, T, H, W, Cc, h, w, _stream()),
+    up = H // h if (h != H and w != W) else 1
+    # part[(b,t,ys,xs)][dyr][c]: the `up` output rows over one audio cell, summed below in a fixed order
+    part = torch.empty((B * T * h * w * up, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_audio_fuse_bwd(_p(a_small), _p(x), _p(dout), _p(dx), _p(part), B, T, H, W, Cc, h, w, _stream()),
                "audio_fuse_bwd")
-    return dx, da
+    da = part if up == 1 else colsum(part, up)
+    return dx, da.reshape(a_small.shape)
 
 
 # ---- K16 tail: loss, clip, optimizer on flat buffers (csrc/optim.hip) --------------------------------

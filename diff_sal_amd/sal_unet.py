@@ -468,7 +468,7 @@ class SalUNet(nn.Module):
 
         f = ag.conv_in(x, self.conv_in.weight.reshape(self.ch, 9), self.conv_in.bias, 0)
         f = ag.conv(f, pw(self.down1.conv.weight), kh=3, kw=3, stride=(4, 4), out_hw=((H - 2) // 4 + 1, (W - 2) // 4 + 1),
-                    bias=self.down1.conv.bias, w_dgrad=dgw(self.down1.conv.weight))
+                    bias=self.down1.conv.bias, w_dgrad=dgw(self.down1.conv.weight, (4, 4)))
         noise, off = [], 0
         for i, blk in enumerate(self.res_encoder):
             rb, dn = blk[0], blk[1]
@@ -561,7 +561,7 @@ class SalUNet(nn.Module):
                 raise RuntimeError(f"ReduceTemp: T={T}, kernel/stride {kt} must give exactly one frame")
             w3 = dec.redu_chan_up[i].proj[0].weight
             z = ag.conv(z.view(Bn, T, Hs * Ws, C), pw(w3), kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
-                        w_dgrad=dgw(w3[:, :, :, 0, 0].unsqueeze(-1)))
+                        w_dgrad=dgw(w3, (kt, 1)))
             zs.append(z.view(Bn, Hs, Ws, self.ori_embed_dim))
         acc = ag.resize_sum(zs, th, tw_)
         mt = dec.mt_proj

@@ -89,6 +89,19 @@ int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, con
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
                        const float* residual, float* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 
+/* ---- weight layout transforms (w: the reference's parameter layout [Cout][Cin][taps], taps = KH*KW or KT):
+ *   mode 0: dst[co][(ci/32, tap, ci%32)] = w[co][ci][tap]            -- the `w` argument of diffsal_conv_igemm
+ *   mode 1: dst[ci][(co/32, tap, co%32)] = w[co][ci][taps-1-tap]     -- `w` of the data-gradient conv (Cout % 32 == 0)
+ *   mode 2: dst[co][ci][tap] = src[co][(ci/32, tap, ci%32)]          -- diffsal_conv_wgrad output back to parameter layout
+ *   mode 3: dst[(tap, ci)][co] = w[co][ci][tap]                      -- GEMM weight of dXcols = dY W (Cout % 32 == 0)
+ * Cin % 32 == 0, taps <= 25.
+ * col2im_disjoint: data gradient of a convolution whose taps never overlap (stride >= kernel, e.g. the 3x3 stride-4
+ * Downsample, sal_unet.py:47-84, and ReduceTemp's k=s=5 Conv3d, common_block.py:125-142): dx[n,iy,ix,:] = the one
+ * cols[(n,oy,ox)][(ky,kx)][:] that maps there, else 0; cols [N*Ho*Wo, KH*KW*C] comes from one diffsal_conv_igemm GEMM. */
+int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH, int KW,
+                            int stride_h, int stride_w, int pad_t, int pad_l, diffsal_stream_t stream);
+int diffsal_pack_weight(const float* src, float* dst, int Cout, int Cin, int taps, int mode, diffsal_stream_t stream);
+
 /* ---- K16 (training): weight gradient of the layer above, in the SAME packed layout as `w`:
  * dw[co, k] = sum_m dy[m, co] * A[m, k].  Replaces the wgrad of autograd's conv / linear backward.
  * ws: >= diffsal_conv_wgrad_ws_bytes(d) bytes (partial slabs, summed in a fixed order).  Cout % 4 == 0. */
@@ -102,7 +115,7 @@ size_t diffsal_wgrad_segmented_ws_bytes(int segments, int seg_rows, int K, int C
 int diffsal_wgrad_segmented(const float* x, const float* dy, float* out, int segments, int seg_rows, int K, int Cout,
                             void* ws, size_t ws_bytes, diffsal_stream_t stream);
 /* out[g, c] = sum of dy[m, c] over the rows of segment g (M / seg_rows segments): bias gradients (one segment)
- * and per-image vector gradients (one segment per image).  ws: >= (M/seg_rows) * 64 * C * 8 bytes (fp64 partials:
+ * and per-image vector gradients (one segment per image).  ws: >= (M/seg_rows) * 512 * C * 8 bytes (fp64 partials:
  * reductions across threads run in double so that heavily cancelling sums do not depend on the atomics order). */
 int diffsal_colsum(const float* dy, float* out, int M, int C, int seg_rows, void* ws, size_t ws_bytes,
                    diffsal_stream_t stream);
@@ -170,8 +183,10 @@ int diffsal_conv_in_bwd(const float* x, const float* dy, double* part, int B, in
 int diffsal_dense_small_bwd(const float* in, const float* w, const float* dout, float* dw, float* db, float* din,
                             int B, int K, int N, int swish_in, diffsal_stream_t stream);
 
-/* backward of diffsal_audio_fuse: dout [B,C,T,H,W] -> dx [B,T,H,W,C] (frames layout) and da_small [B*T, h*w, C] */
-int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* dout, float* dx, float* da_small, int B,
+/* backward of diffsal_audio_fuse: dout [B,C,T,H,W] -> dx [B,T,H,W,C] (frames layout) and the audio-map gradient as
+ * per-output-row partials part[((b*T+t)*h + ys)*w + xs][dyr][c] (up = H/h rows per audio row, up <= 8): da_small is
+ * diffsal_colsum(part viewed [B*T*h*w*up, C], seg_rows = up); with up == 1 part IS da_small [B*T, h*w, C]. */
+int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* dout, float* dx, float* part, int B,
                            int T, int H, int W, int C, int h, int w, diffsal_stream_t stream);
 
 /* ---- K6: frame packing: visual features NCTHW[B,C,Tv,h,w] + noise NHWC[B,h,w,C] ->

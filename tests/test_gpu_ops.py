@@ -32,7 +32,7 @@ def nhwc(x):
 def pack_conv(w):
     from diff_sal_amd.ops import pack_conv_weight
 
-    return pack_conv_weight(w)
+    return pack_conv_weight(w.to(DEV)).cpu() if not w.is_cuda else pack_conv_weight(w)
 
 
 @pytest.fixture(scope="module")
@@ -259,3 +259,30 @@ def test_head_sigmoid_and_axpy(ops):
     a, c, e = rnd("a1", 1000), rnd("a2", 1000), rnd("a3", 1000)
     got = ops.axpbypcz(a.to(DEV), 0.5, c.to(DEV), -1.25, e.to(DEV), 2.0)
     assert rel_err(got, 0.5 * a - 1.25 * c + 2.0 * e) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(96, 64, 3, 3), (40, 32, 3, 3), (256, 96, 5, 1, 1), (192, 96), (32, 512, 1, 1)])
+def test_weight_pack_dgrad_pack_and_unpack_match_the_permute_definitions(shape):
+    """csrc/pack.hip modes 0/1/2 against the layout definitions written as torch permutes (include/diffsal.h)."""
+    from diff_sal_amd import ops
+
+    torch.manual_seed(3)
+    w = torch.randn(shape)
+    w4 = w[:, :, :, 0, 0].unsqueeze(-1) if w.dim() == 5 else (w[:, :, None, None] if w.dim() == 2 else w)
+    co, ci, kh, kw = w4.shape
+
+    def pack_ref(v):  # [Co, Ci, kh, kw] -> [Co, (ci/32, tap, ci%32)]
+        o, i = v.shape[:2]
+        return v.permute(0, 2, 3, 1).reshape(o, kh * kw, i // 32, 32).permute(0, 2, 1, 3).reshape(o, kh * kw * i)
+
+    wd = w.to("cuda")
+    assert torch.equal(ops.pack_conv_weight(wd).cpu(), pack_ref(w4))
+    if co % 32 == 0:
+        assert torch.equal(ops.pack_dgrad_weight(wd).cpu(), pack_ref(w4.permute(1, 0, 2, 3).flip(2, 3)))
+    # unpack is the autograd backward of the differentiable pack
+    p = wd.clone().requires_grad_(True)
+    g = torch.randn(co, kh * kw * ci)
+    ops.pack_conv_weight_diff(p).backward(g.to("cuda"))
+    ref = w4.clone().requires_grad_(True)
+    pack_ref(ref).backward(g)
+    assert torch.equal(p.grad.cpu().reshape(ref.grad.shape), ref.grad)

@@ -61,7 +61,7 @@ def test_conv_backward_matches_autograd(ag, case):
     bd, rvd = b.detach().to(DEV).requires_grad_(True), rv.detach().to(DEV).requires_grad_(True)
     kw = dict(stride=(s, s), pad=(0, 0) if asym else (p, p), dil=(d, d), out_hw=tuple(y.shape[-2:]))
     yd = agops.conv(xd, ops.pack_conv_weight_diff(wd), kh=k, kw=k, bias=bd, rowvec=rvd, act=act,
-                    w_dgrad=agops.dgrad_weight(wd), **kw)
+                    w_dgrad=agops.dgrad_weight(wd, (s, s)), **kw)
     assert rel(yd, nhwc(y)) < 2e-5
     yd.backward(nhwc(gy).to(DEV))
     assert rel(xd.grad, nhwc(x.grad)) < 2e-5
@@ -288,6 +288,27 @@ def test_audio_fuse_backward(ag, stage):
     od.backward(g.to(DEV))
     assert rel(xd.grad, x5.grad.permute(0, 2, 3, 4, 1)) < 5e-5
     assert rel(ad.grad, a_small.grad) < 5e-5
+
+
+def test_reduce_temp_backward_uses_disjoint_tap_path(ag):
+    """Conv3d k=(5,1,1) stride 5 over T=9 frames -> one frame (common_block.py:125-142, quirk Q10): frames 0-4 get one
+    tap each, frames 5-8 get zero gradient."""
+    agops, ops = ag
+    B, T, HW, C, Co = 2, 9, 40, 64, 96
+    x = rnd("rtx", B, C, T, HW, 1).requires_grad_(True)
+    w = rnd("rtw", Co, C, 5, 1, 1, scale=0.05).requires_grad_(True)
+    y = F.relu(F.conv3d(x, w, None, stride=(5, 1, 1)))
+    gy = rnd("rtg", *y.shape)
+    y.backward(gy)
+    xd = x.detach()[..., 0].permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)     # [B, T, HW, C]
+    wd = w.detach().to(DEV).requires_grad_(True)
+    yd = agops.conv(xd, ops.pack_conv_weight_diff(wd), kh=5, kw=1, stride=(5, 1), act=1, w_dgrad=agops.dgrad_weight(wd, (5, 1)))
+    assert tuple(agops.dgrad_weight(wd, (5, 1)).shape) == (5 * C, Co)
+    assert rel(yd, y[..., 0].permute(0, 2, 3, 1)) < 2e-5
+    yd.backward(gy[..., 0].permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert rel(xd.grad, x.grad[..., 0].permute(0, 2, 3, 1)) < 2e-5
+    assert float(xd.grad[:, 5:].abs().max()) == 0.0
+    assert rel(wd.grad, w.grad) < 2e-5
 
 
 # ---- loss / clip / optimizer kernels (csrc/optim.hip) ----
