@@ -53,7 +53,7 @@ SIGNATURES = {
     "diffsal_attention_bwd": (c_i, [c_f] * 7 + [c_i] * 6 + [c_fl, c_f]),
     "diffsal_wgrad_segmented_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "diffsal_wgrad_segmented": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
-    "diffsal_resize_bilinear_bwd": (c_i, [c_f, c_f] + [c_i] * 6 + [c_f]),
+    "diffsal_resize_bilinear_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "diffsal_unpack_frames": (c_i, [c_f, c_f] + [c_i] * 5 + [c_f]),
     "diffsal_head_bwd": (c_i, [c_f] * 6 + [c_i, c_i, c_i, c_f]),
     "diffsal_conv_in_bwd": (c_i, [c_f, c_f, c_f] + [c_i] * 5 + [c_f]),
@@ -72,6 +72,7 @@ SIGNATURES = {
     "diffsal_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_col2im_disjoint": (c_i, [c_f, c_f] + [c_i] * 12 + [c_f]),
     "diffsal_reduce_blocks": (c_i, []),
+    "diffsal_multi_copy": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.POINTER(C.c_long), c_i, c_f, c_f]),
     "diffsal_scale_by": (c_i, [c_f, c_f, c_f, C.c_long, c_f]),
     "diffsal_mse_loss": (c_i, [c_f, c_f, c_f, c_f, c_f, C.c_long, c_fl, c_f]),
     "diffsal_grad_norm": (c_i, [c_f, C.c_long, c_fl, c_f, c_f, c_f]),

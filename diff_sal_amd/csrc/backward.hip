@@ -502,6 +502,43 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   }
 }
 
+// One axis of the same adjoint on [outer][L][inner] -> [outer][l][inner]: rows then columns costs ~2(f+1) taps per
+// element and pass instead of (2f+3)^2 in the joint form above (f = up-factor), and the first pass shrinks the data by f.
+template <int VEC>
+__global__ __launch_bounds__(256) void resize_bwd_axis_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                              long outer, int L, int l, int inner, float scale) {
+  const int cv = inner / VEC;
+  const long total = outer * l * cv;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % cv) * VEC;
+    long r = i / cv;
+    const int il = static_cast<int>(r % l);
+    const long o = r / l;
+    const int lo = max(0, static_cast<int>(floorf((il - 0.5f) / scale - 0.5f)) - 1);
+    const int hi = min(L - 1, static_cast<int>(ceilf((il + 1.5f) / scale - 0.5f)) + 1);
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int Y = lo; Y <= hi; ++Y) {
+      int y0, y1; float ly;
+      bilin_coord(Y, scale, l, y0, y1, ly);
+      const float wy = (y0 == il ? 1.f - ly : 0.f) + (y1 == il ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const float* g = dy + (o * L + Y) * inner + c;
+      if constexpr (VEC == 4) {
+        const float4 v = ld4(g);
+        acc[0] = fmaf(wy, v.x, acc[0]); acc[1] = fmaf(wy, v.y, acc[1]);
+        acc[2] = fmaf(wy, v.z, acc[2]); acc[3] = fmaf(wy, v.w, acc[3]);
+      } else {
+        acc[0] = fmaf(wy, g[0], acc[0]);
+      }
+    }
+    float* out = dx + i * VEC;
+    if constexpr (VEC == 4) st4(out, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    else out[0] = acc[0];
+  }
+}
+
 // frames [B][Tin*hw][C] (first Q = Tv*hw rows) -> NCTHW [B][C][Q]: backward of pack_frames for the visual features
 __global__ __launch_bounds__(256) void unpack_frames_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
                                                             int Q, long in_batch_stride, int tiles_q) {
@@ -600,8 +637,8 @@ __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __res
                                                               const float* __restrict__ dout, float* __restrict__ dw,
                                                               float* __restrict__ db, float* __restrict__ din, int B,
                                                               int K, int N, int swish_in) {
-  const long nw = static_cast<long>(N) * K, nd = static_cast<long>(B) * K;
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < nw + N + nd; i += static_cast<long>(gridDim.x) * 256) {
+  const long nw = static_cast<long>(N) * K;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < nw + N; i += static_cast<long>(gridDim.x) * 256) {
     if (i < nw) {
       const int n = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<long>(n) * K);
       float s = 0.f;
@@ -610,18 +647,42 @@ __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __res
         s = fmaf(dout[b * N + n], swish_in ? swishf(v) : v, s);
       }
       dw[i] = s;
-    } else if (i < nw + N) {
+    } else {
       const int n = static_cast<int>(i - nw);
       float s = 0.f;
       for (int b = 0; b < B; ++b) s += dout[b * N + n];
       db[n] = s;
-    } else {
-      const long j = i - nw - N;
-      const int b = static_cast<int>(j / K), k = static_cast<int>(j - static_cast<long>(b) * K);
-      float s = 0.f;
-      for (int n = 0; n < N; ++n) s = fmaf(dout[b * N + n], w[static_cast<long>(n) * K + k], s);
-      din[j] = swish_in ? s * swish_grad(in[j]) : s;
     }
+  }
+}
+
+// din[b,k] = f'(in[b,k]) sum_n dout[b,n] W[n,k]: workgroup = (32 k, one b); 8 thread groups each take every 8th n
+// (W rows are k-contiguous: coalesced), combined in a fixed order.  (A thread per output would walk N rows serially.)
+__global__ __launch_bounds__(256) void dense_small_din_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ dout, float* __restrict__ din,
+                                                              int K, int N, int swish_in) {
+  __shared__ float sh[8][33];
+  const int kl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kl, b = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (k < K) {
+    int n = g;
+    for (; n + 24 < N; n += 32) {
+      s0 = fmaf(dout[b * N + n], w[static_cast<long>(n) * K + k], s0);
+      s1 = fmaf(dout[b * N + n + 8], w[static_cast<long>(n + 8) * K + k], s1);
+      s2 = fmaf(dout[b * N + n + 16], w[static_cast<long>(n + 16) * K + k], s2);
+      s3 = fmaf(dout[b * N + n + 24], w[static_cast<long>(n + 24) * K + k], s3);
+    }
+    for (; n < N; n += 8) s0 = fmaf(dout[b * N + n], w[static_cast<long>(n) * K + k], s0);
+  }
+  sh[g][kl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && k < K) {
+    float t = sh[0][kl];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += sh[j][kl];
+    const long o = static_cast<long>(b) * K + k;
+    din[o] = swish_in ? t * swish_grad(in[o]) : t;
   }
 }
 
@@ -936,12 +997,20 @@ extern "C" int diffsal_attention_bwd(const float* q, const float* k, const float
 }
 
 extern "C" int diffsal_resize_bilinear_bwd(const float* dy, float* dx, int N, int h, int w, int H, int W, int C,
-                                           diffsal_stream_t stream) {
+                                           void* ws, size_t ws_bytes, diffsal_stream_t stream) {
   DS_REQUIRE(dy && dx, DIFFSAL_E_ARG, "resize_bilinear_bwd: null argument");
   DS_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, DIFFSAL_E_SHAPE, "resize_bilinear_bwd: bad shape");
   const float sy = static_cast<float>(h) / static_cast<float>(H), sx = static_cast<float>(w) / static_cast<float>(W);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (C % 4 == 0 && aligned16(dy) && aligned16(dx))
+  const size_t tmp_bytes = static_cast<size_t>(N) * h * W * C * sizeof(float);
+  if (C % 4 == 0 && aligned16(dy) && aligned16(dx) && ws && aligned16(ws) && ws_bytes >= tmp_bytes && (H != h || W != w)) {
+    // separable: rows ([N][H][W*C] -> [N][h][W*C]) into ws, then columns ([N*h][W][C] -> [N*h][w][C])
+    float* tmp = static_cast<float*>(ws);
+    hipLaunchKernelGGL((resize_bwd_axis_kernel<4>), dim3(ew_grid_b(static_cast<long>(N) * h * W * (C / 4))), dim3(256), 0, s,
+                       dy, tmp, static_cast<long>(N), H, h, W * C, sy);
+    hipLaunchKernelGGL((resize_bwd_axis_kernel<4>), dim3(ew_grid_b(static_cast<long>(N) * h * w * (C / 4))), dim3(256), 0, s,
+                       tmp, dx, static_cast<long>(N) * h, W, w, C, sx);
+  } else if (C % 4 == 0 && aligned16(dy) && aligned16(dx))
     hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(ew_grid_b(static_cast<long>(N) * h * w * (C / 4))), dim3(256), 0, s,
                        dy, dx, N, h, w, H, W, C, sy, sx);
   else
@@ -983,9 +1052,11 @@ extern "C" int diffsal_dense_small_bwd(const float* in, const float* w, const fl
                                        float* din, int B, int K, int N, int swish_in, diffsal_stream_t stream) {
   DS_REQUIRE(in && w && dout && dw && db && din, DIFFSAL_E_ARG, "dense_small_bwd: null argument");
   DS_REQUIRE(B > 0 && K > 0 && N > 0, DIFFSAL_E_SHAPE, "dense_small_bwd: bad shape");
-  const long total = static_cast<long>(N) * K + N + static_cast<long>(B) * K;
+  const long total = static_cast<long>(N) * K + N;
   hipLaunchKernelGGL(dense_small_bwd_kernel, dim3(ew_grid_b(total)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
                      w, dout, dw, db, din, B, K, N, swish_in);
+  hipLaunchKernelGGL(dense_small_din_kernel, dim3((K + 31) / 32, B), dim3(256), 0, static_cast<hipStream_t>(stream), in, w,
+                     dout, din, K, N, swish_in);
   return check_launch("dense_small_bwd");
 }
 

@@ -80,6 +80,26 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__
   }
 }
 
+// Gather up to kMultiCopyMax separately allocated gradient tensors into their slots of the flat buffer in one launch
+// (the pointer table travels in the kernel arguments: no host-to-device copy, no synchronisation).
+constexpr int kMultiCopyMax = 48;
+struct MultiCopyArgs {
+  const float* src[kMultiCopyMax];
+  long dst_off[kMultiCopyMax];
+  long n[kMultiCopyMax];
+};
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a, float* __restrict__ dst) {
+  const int t = blockIdx.y;
+  const float* __restrict__ s = a.src[t];
+  float* __restrict__ d = dst + a.dst_off[t];
+  const long n = a.n[t], n4 = ((reinterpret_cast<uintptr_t>(s) & 15u) == 0) ? (n >> 2) : 0;   // dst slots are 256-B aligned
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<long>(gridDim.x) * 256)
+    st4(d + i * 4, ld4(s + i * 4));
+  for (long i = n4 * 4 + static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * 256)
+    d[i] = s[i];
+}
+
 struct AdamArgs {
   float gscale, omb1, beta2, omb2, eps, wd, step_size, bc2_sqrt, max_norm;  // omb = 1 - beta, rounded from double
 };
@@ -188,4 +208,29 @@ extern "C" int diffsal_adam_step(float* p, float* g, float* m, float* v, long n,
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, norm, n / 4, n, a,
                      store_clipped_grad);
   return check_launch("adam_step");
+}
+
+extern "C" int diffsal_multi_copy_max(void) { return kMultiCopyMax; }
+
+extern "C" int diffsal_multi_copy(const float* const* srcs /*host array*/, const long* dst_offsets /*host*/,
+                                  const long* sizes /*host*/, int count, float* dst, diffsal_stream_t stream) {
+  DS_REQUIRE(srcs && dst_offsets && sizes && dst, DIFFSAL_E_ARG, "multi_copy: null argument");
+  DS_REQUIRE(count >= 0, DIFFSAL_E_SHAPE, "multi_copy: negative count");
+  for (int base = 0; base < count; base += kMultiCopyMax) {
+    const int m = count - base < kMultiCopyMax ? count - base : kMultiCopyMax;
+    MultiCopyArgs a;
+    long biggest = 1;
+    for (int i = 0; i < m; ++i) {
+      DS_REQUIRE(srcs[base + i] && sizes[base + i] >= 0 && dst_offsets[base + i] >= 0 && dst_offsets[base + i] % 4 == 0,
+                 DIFFSAL_E_ARG, "multi_copy: bad entry %d", base + i);
+      a.src[i] = srcs[base + i]; a.dst_off[i] = dst_offsets[base + i]; a.n[i] = sizes[base + i];
+      if (a.n[i] > biggest) biggest = a.n[i];
+    }
+    for (int i = m; i < kMultiCopyMax; ++i) { a.src[i] = nullptr; a.dst_off[i] = 0; a.n[i] = 0; }
+    long gx = (biggest / 4 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(static_cast<int>(gx), m), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       dst);
+  }
+  return check_launch("multi_copy");
 }

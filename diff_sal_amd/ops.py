@@ -489,7 +489,9 @@ def resize_bilinear_bwd(dy: Tensor, h: int, w: int) -> Tensor:
     lib = _lib.load()
     N, H, W, Cc = dy.shape
     dx = torch.empty((N, h, w, Cc), device=dy.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_resize_bilinear_bwd(_p(dy), _p(dx), N, h, w, H, W, Cc, _stream()), "resize_bilinear_bwd")
+    ws = torch.empty((N * h * W * Cc,), device=dy.device, dtype=torch.float32) if Cc % 4 == 0 else None
+    _lib.check(lib.diffsal_resize_bilinear_bwd(_p(dy), _p(dx), N, h, w, H, W, Cc, _p(ws), ws.numel() * 4 if ws is not None else 0,
+                                               _stream()), "resize_bilinear_bwd")
     return dx
 
 
@@ -601,3 +603,16 @@ def scale_by(x: Tensor, s: Tensor) -> Tensor:
     out = torch.empty_like(x)
     _lib.check(lib.diffsal_scale_by(_p(x), _p(s.reshape(1)), _p(out), x.numel(), _stream()), "scale_by")
     return out
+
+
+def multi_copy(srcs: Sequence[Tensor], dst_offsets: Sequence[int], dst: Tensor) -> None:
+    """dst[off_i : off_i + srcs[i].numel()] = srcs[i] for all i, in a handful of launches (csrc/optim.hip)."""
+    lib = _lib.load()
+    n = len(srcs)
+    if n == 0:
+        return
+    keep = [t if t.is_contiguous() else t.contiguous() for t in srcs]
+    ptrs = (C.c_void_p * n)(*[_p(t) for t in keep])
+    offs = (C.c_long * n)(*[int(o) for o in dst_offsets])
+    sizes = (C.c_long * n)(*[t.numel() for t in keep])
+    _lib.check(lib.diffsal_multi_copy(ptrs, offs, sizes, n, _p(dst), _stream()), "multi_copy")

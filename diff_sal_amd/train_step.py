@@ -70,7 +70,7 @@ class FlatParams:
             view = self.flat_p[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+            p.grad = None
         # buckets: contiguous ranges of whole tensors, closed once they reach bucket_bytes
         self.buckets: List[range] = []       # element ranges of the flat buffer
         self.bucket_of: List[int] = []       # parameter index -> bucket
@@ -82,22 +82,48 @@ class FlatParams:
                 self.buckets.append(range(start, end))
                 start = end
         self.bucket_size = [0] * len(self.buckets)
-        for b in self.bucket_of:
+        self.bucket_members: List[List[int]] = [[] for _ in self.buckets]
+        for i, b in enumerate(self.bucket_of):
             self.bucket_size[b] += 1
+            self.bucket_members[b].append(i)
+
+    def grad_view(self, i: int) -> Tensor:
+        p, o = self.params[i], self.offsets[i]
+        return self.flat_g[o:o + p.numel()].view(p.shape)
 
     def zero_grad(self) -> None:
+        """Clear the flat gradient and detach the parameters from it: with ``p.grad is None`` autograd hands over each
+        freshly computed gradient tensor without an accumulation kernel; GradReducer gathers them bucket by bucket."""
         self.flat_g.zero_()
-        for p, o in zip(self.params, self.offsets):  # a caller may have set p.grad = None
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
-                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
+
+    def gather(self, indices: Sequence[int]) -> None:
+        """Copy the gradients autograd left on ``params[indices]`` into their flat slots (one multi-tensor kernel) and
+        re-point ``.grad`` at the flat views.  Parameters without a gradient keep a zero slot."""
+        todo = [i for i in indices if self.params[i].grad is not None
+                and self.params[i].grad.data_ptr() != self.flat_g.data_ptr() + 4 * self.offsets[i]]
+        if not todo:
+            return
+        if self.flat_g.is_cuda:
+            from . import ops
+
+            ops.multi_copy([self.params[i].grad for i in todo], [self.offsets[i] for i in todo], self.flat_g)
+        else:  # host tensors: only the gloo tests of the bucket logic come here
+            for i in todo:
+                self.grad_view(i).copy_(self.params[i].grad)
+        for i in todo:
+            self.params[i].grad = self.grad_view(i)
 
 
 class GradReducer:
-    """Bucketed asynchronous gradient SUM over the ranks of ``group`` (the mean's 1/world is applied by the consumer).
+    """Bucketed gradient gather + asynchronous SUM over the ranks of ``group`` (the mean's 1/world is applied by the
+    consumer).
 
-    ``arm()`` before backward; the per-parameter hooks launch a bucket's all-reduce when its last gradient has
-    been accumulated; ``finish()`` launches whatever is left (buckets holding parameters that received no
-    gradient this step) and waits for all of them."""
+    ``flat.zero_grad()`` then ``arm()`` before backward; when the last gradient of a bucket has been produced its
+    per-parameter hook gathers the bucket into the flat buffer (one kernel) and launches the bucket's all-reduce;
+    ``finish()`` handles whatever is left (buckets holding parameters that received no gradient this step) and
+    waits for all of them."""
 
     def __init__(self, flat: FlatParams, group=None):
         self.flat, self.group = flat, group
@@ -107,9 +133,8 @@ class GradReducer:
         self._work = []
         self._armed = False
         self.launch_order: List[int] = []
-        if self.world > 1:
-            for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _make_hook(self, i: int) -> Callable:
         def hook(_param):
@@ -127,18 +152,18 @@ class GradReducer:
         self._launched[b] = True
         r = self.flat.buckets[b]
         self.launch_order.append(b)
-        self._work.append(dist.all_reduce(self.flat.flat_g[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group,
-                                          async_op=True))
+        self.flat.gather(self.flat.bucket_members[b])
+        if self.world > 1:
+            self._work.append(dist.all_reduce(self.flat.flat_g[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
 
     def arm(self) -> None:
         self._pending = list(self.flat.bucket_size)
         self._launched = [False] * len(self.flat.buckets)
         self._work, self.launch_order = [], []
-        self._armed = self.world > 1
+        self._armed = True
 
     def finish(self) -> None:
-        if self.world <= 1:
-            return
         for b in range(len(self.flat.buckets)):
             self._launch(b)
         for w in self._work:

@@ -172,8 +172,10 @@ int diffsal_attention_bwd(const float* q, const float* k, const float* v, const 
  * adjoint of diffsal_resize_bilinear (dy [N,H,W,C] -> dx [N,h,w,C]); backward of pack_frames for the visual
  * features (frames [B,Tin,hw,C] -> NCTHW [B,C,Tv,hw]); head backward (dy = dpre w, part[blocks][C+1] holds
  * sum dpre*y and sum dpre); conv_in parameter gradients (part[10][chunks][C]: 9 taps + bias); dense_small backward. */
-int diffsal_resize_bilinear_bwd(const float* dy, float* dx, int N, int h, int w, int H, int W, int C,
-                                diffsal_stream_t stream);
+/* resize_bilinear_bwd: with ws >= N*h*W*C*4 bytes the adjoint runs as two one-axis passes (rows into ws, then
+ * columns); ws may be NULL (single joint pass, much slower for large up-factors). */
+int diffsal_resize_bilinear_bwd(const float* dy, float* dx, int N, int h, int w, int H, int W, int C, void* ws,
+                                size_t ws_bytes, diffsal_stream_t stream);
 int diffsal_unpack_frames(const float* frames, float* vis_grad, int B, int C, int Tv, int Tin, int hw,
                           diffsal_stream_t stream);
 int diffsal_head_bwd(const float* y, const float* w, const float* s_out, const float* ds, float* dy, double* part,
@@ -258,8 +260,13 @@ int diffsal_axpbypcz(const float* x, const float* y, const float* z, float a, fl
  *   gscale * min(1, max_norm / (norm[0] + 1e-6)) (norm may be NULL or max_norm <= 0: no clipping).  `step` counts
  *   from 1.  store_clipped_grad != 0 writes the scaled gradient back into g as clip_grad_norm_ does.
  * scale_by: out = x * s[0] with s a device scalar (the incoming d(loss) of the MSE backward).  n % 4 == 0.
+ * multi_copy: dst[dst_offsets[i] .. +sizes[i]) = srcs[i][0 .. sizes[i]) for i < count, a few launches for any count
+ *   (gathers the per-parameter gradients autograd produced into the flat gradient buffer; the three tables are HOST
+ *   arrays, the pointers in them device pointers; dst_offsets multiples of 4 elements).
  * Reductions are fp64 with a fixed order: a step is bit-reproducible.  No host synchronisation. */
 int diffsal_reduce_blocks(void);
+int diffsal_multi_copy(const float* const* srcs, const long* dst_offsets, const long* sizes, int count, float* dst,
+                       diffsal_stream_t stream);
 int diffsal_scale_by(const float* x, const float* s, float* out, long n, diffsal_stream_t stream);
 int diffsal_mse_loss(const float* pred, const float* target, float* dpred, float* loss, double* part, long n,
                      float loss_scale, diffsal_stream_t stream);
