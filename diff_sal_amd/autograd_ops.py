@@ -130,15 +130,7 @@ class GroupNormSwishFn(torch.autograd.Function):
         B, H, W, C = x.shape
         hw, cpg = H * W, C // groups
         st = ops.rowstats(x, hw, 0)                                  # [B, 2, C] float64
-        n = float(hw * cpg)
-        gs = st.reshape(B, 2, groups, cpg).sum(-1)                   # [B, 2, G]
-        mean = gs[:, 0] / n
-        var = (gs[:, 1] / n - mean * mean).clamp_min(0.0)
-        rstd = 1.0 / torch.sqrt(var + eps)
-        mu_c = mean.repeat_interleave(cpg, dim=1).float().contiguous()   # [B, C]
-        rs_c = rstd.repeat_interleave(cpg, dim=1).float().contiguous()
-        scale = (rs_c * gamma).contiguous()
-        shift = (beta - mu_c * scale).contiguous()
+        mu_c, rs_c, scale, shift, _, _ = ops.norm_finalize_fwd(st, gamma, beta, groups, float(hw * cpg), eps)
         ctx.groups = groups
         ctx.save_for_backward(x, gamma, beta, mu_c, rs_c)
         return ops.affine_act(x, scale, shift, hw, 4)
@@ -148,17 +140,9 @@ class GroupNormSwishFn(torch.autograd.Function):
         x, gamma, beta, mu_c, rs_c = ctx.saved_tensors
         B, H, W, C = x.shape
         hw, G = H * W, ctx.groups
-        cpg = C // G
         dy = dy.contiguous()
         t = ops.rowstats(x, hw, 2, dy=dy, mu=mu_c, rs=rs_c, gamma=gamma, beta=beta, stat_per_seg=True)  # [B,2,C]
-        dbeta, dgamma = t[:, 0].sum(0).float(), t[:, 1].sum(0).float()
-        gd = gamma.double()
-        n = float(hw * cpg)
-        A = (t[:, 0] * gd).reshape(B, G, cpg).sum(-1).repeat_interleave(cpg, dim=1) / n   # [B, C]
-        Bq = (t[:, 1] * gd).reshape(B, G, cpg).sum(-1).repeat_interleave(cpg, dim=1) / n
-        k1 = (rs_c * gamma).contiguous()
-        k2 = (rs_c.double() * A).float().contiguous()
-        k3 = (rs_c.double() * Bq).float().contiguous()
+        dgamma, dbeta, k1, k2, k3 = ops.norm_finalize_bwd(t, gamma, rs_c, G, float(hw * (C // G)))
         dx = ops.norm_bwd_apply(x, dy, None, mu_c, rs_c, gamma, beta, k1, k2, k3, hw, 2)
         return dx, dgamma, dbeta, None, None
 
@@ -169,51 +153,39 @@ def groupnorm_swish(x, gamma, beta, groups=32, eps=1e-6):
 
 class BatchNormReLUFn(torch.autograd.Function):
     """relu(BatchNorm2d(x)) in TRAIN mode on channels-last rows [M, C]: batch statistics over all rows (per rank,
-    unsynchronised -- exactly what the reference's DDP does); returns (y, batch_mean, biased_var)."""
+    unsynchronised -- exactly what the reference's DDP does).  ``running`` = (running_mean, running_var,
+    momentum) is updated in place by the statistics kernel, like nn.BatchNorm2d in train mode."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, running):
         C = x.shape[-1]
         M = x.numel() // C
-        st = ops.rowstats(x, M, 0)[0]                  # [2, C] float64
-        mean = st[0] / M
-        var = (st[1] / M - mean * mean).clamp_min(0.0)
-        rstd = 1.0 / torch.sqrt(var + eps)
-        mu = mean.float().reshape(1, C).contiguous()
-        rs = rstd.float().reshape(1, C).contiguous()
-        scale = (rs * gamma).contiguous()
-        shift = (beta - mu * scale).contiguous()
+        st = ops.rowstats(x, M, 0)                     # [1, 2, C] float64
+        bn = None if running is None else (running[0], running[1], running[2], M / max(M - 1, 1))
+        mu, rs, scale, shift, _, _ = ops.norm_finalize_fwd(st, gamma, beta, C, float(M), eps, bn=bn)
         y = ops.affine_act(x, scale, shift, M, ACT_RELU if relu else ACT_NONE)
         ctx.relu = relu
         ctx.save_for_backward(x, y if relu else x.new_empty(0), gamma, mu, rs)
-        ctx.mark_non_differentiable(mu, rs)
-        return y, mean.float(), var.float()
+        return y
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
+    def backward(ctx, dy):
         x, y, gamma, mu, rs = ctx.saved_tensors
         C = x.shape[-1]
         M = x.numel() // C
         dy = dy.contiguous()
         mode = 1 if ctx.relu else 3
-        t = ops.rowstats(x, M, mode, dy=dy, y=y if ctx.relu else None, mu=mu, rs=rs)[0]   # [2, C]
-        dbeta, dgamma = t[0].float(), t[1].float()
-        k1 = (gamma * rs).contiguous()                                  # [1, C]
-        k2 = (k1.double() * t[0] / M).float().contiguous()
-        k3 = (k1.double() * t[1] / M).float().contiguous()
+        t = ops.rowstats(x, M, mode, dy=dy, y=y if ctx.relu else None, mu=mu, rs=rs)   # [1, 2, C]
+        dgamma, dbeta, k1, k2, k3 = ops.norm_finalize_bwd(t, gamma, rs, C, float(M))
         dx = ops.norm_bwd_apply(x, dy, y if ctx.relu else None, mu, rs, None, None, k1, k2, k3, M, mode)
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None
 
 
 def batchnorm_relu_train(x, bn: "torch.nn.BatchNorm2d", relu=True):
     """Functional train-mode BatchNorm(+ReLU) that also updates the module's running statistics like nn.BatchNorm2d."""
-    y, mean, var = BatchNormReLUFn.apply(x, bn.weight, bn.bias, bn.eps, relu)
-    with torch.no_grad():
-        M = x.numel() // x.shape[-1]
-        mom = bn.momentum if bn.momentum is not None else 0.1
-        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-        bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
-        bn.num_batches_tracked += 1
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    y = BatchNormReLUFn.apply(x, bn.weight, bn.bias, bn.eps, relu, (bn.running_mean, bn.running_var, mom))
+    bn.num_batches_tracked += 1
     return y
 
 

@@ -108,6 +108,98 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < 2 * C; i += 256) o[i] = shd[i];
 }
 
+// out[seg][j] = sum over chunks of part[seg][chunk][j] (fp64 in, fp64 or fp32 out).  Workgroup = (32 columns, segment);
+// 8 thread groups take every 8th chunk, the 8 group sums are combined in a fixed order.
+template <typename OUT>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ part, OUT* __restrict__ out,
+                                                              int chunks, int Wd) {
+  __shared__ double sh[8][33];
+  const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl, g = blockIdx.y;
+  double s = 0.0;
+  if (j < Wd)
+    for (int k = kg; k < chunks; k += 8) s += part[(static_cast<long>(g) * chunks + k) * Wd + j];
+  sh[kg][cl] = s;
+  __syncthreads();
+  if (kg == 0 && j < Wd) {
+    double t = sh[0][cl];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += sh[q][cl];
+    out[static_cast<long>(g) * Wd + j] = static_cast<OUT>(t);
+  }
+}
+
+// GroupNorm / BatchNorm statistics -> per-(segment, channel) vectors, one workgroup for everything (tiny).
+//   sums[seg][2][C] = (sum x, sum x^2) per channel; groups of cpg = C/G channels share statistics over n = rows*cpg
+//   values (BatchNorm: G = C, one segment).  mu, rs, scale = rs*gamma, shift = beta - mu*scale.
+//   BatchNorm extras (bn_mean != NULL): batch mean / biased var out, running stats updated like nn.BatchNorm2d.
+__global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const double* __restrict__ sums,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ mu,
+                                                                float* __restrict__ rs, float* __restrict__ scale,
+                                                                float* __restrict__ shift, int segs, int C, int G, double n,
+                                                                double eps, float* __restrict__ bn_mean,
+                                                                float* __restrict__ bn_var, float* __restrict__ run_mean,
+                                                                float* __restrict__ run_var, float momentum, float unbias) {
+  const int cpg = C / G;
+  for (int i = threadIdx.x; i < segs * C; i += 256) {
+    const int sg = i / C, c = i - sg * C;
+    const int g0 = (c / cpg) * cpg;
+    double s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < cpg; ++q) {
+      s1 += sums[(static_cast<long>(sg) * 2 + 0) * C + g0 + q];
+      s2 += sums[(static_cast<long>(sg) * 2 + 1) * C + g0 + q];
+    }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float m = static_cast<float>(mean), r = static_cast<float>(1.0 / sqrt(var + eps));
+    const float sc = r * gamma[c];
+    mu[i] = m; rs[i] = r; scale[i] = sc; shift[i] = beta[c] - m * sc;
+    if (bn_mean != nullptr) {
+      const float vf = static_cast<float>(var);
+      bn_mean[i] = m; bn_var[i] = vf;
+      if (run_mean != nullptr) {
+        run_mean[c] = run_mean[c] * (1.f - momentum) + momentum * m;
+        run_var[c] = run_var[c] * (1.f - momentum) + momentum * (vf * unbias);
+      }
+    }
+  }
+}
+
+// Backward companion: t[seg][2][C] = (sum dz, sum dz*xhat) -> dbeta = sum_seg t0, dgamma = sum_seg t1,
+//   k1 = rs*gamma, k2 = rs * groupsum(t0*gamma)/n, k3 = rs * groupsum(t1*gamma)/n   (inputs of norm_bwd_apply)
+__global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const double* __restrict__ t, const float* __restrict__ gamma,
+                                                                const float* __restrict__ rs, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float* __restrict__ k1,
+                                                                float* __restrict__ k2, float* __restrict__ k3, int segs,
+                                                                int C, int G, double n) {
+  const int cpg = C / G;
+  for (int i = threadIdx.x; i < segs * C; i += 256) {
+    const int sg = i / C, c = i - sg * C;
+    const int g0 = (c / cpg) * cpg;
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < cpg; ++q) {
+      const double gq = static_cast<double>(gamma[g0 + q]);
+      a += t[(static_cast<long>(sg) * 2 + 0) * C + g0 + q] * gq;
+      b += t[(static_cast<long>(sg) * 2 + 1) * C + g0 + q] * gq;
+    }
+    const double r = static_cast<double>(rs[i]);
+    k1[i] = rs[i] * gamma[c];
+    k2[i] = static_cast<float>(r * (a / n));
+    k3[i] = static_cast<float>(r * (b / n));
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double d0 = 0.0, d1 = 0.0;
+    for (int sg = 0; sg < segs; ++sg) {
+      d0 += t[(static_cast<long>(sg) * 2 + 0) * C + c];
+      d1 += t[(static_cast<long>(sg) * 2 + 1) * C + c];
+    }
+    dbeta[c] = static_cast<float>(d0);
+    dgamma[c] = static_cast<float>(d1);
+  }
+}
+
 // y = act(x * s[seg, c] + t[seg, c])   (BatchNorm / GroupNorm forward once the statistics are folded into s, t)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sc,
                                                          const float* __restrict__ sh_, float* __restrict__ out, long M,
@@ -845,6 +937,44 @@ extern "C" int diffsal_rowstats(const float* x, const float* dy, const float* y,
                      static_cast<hipStream_t>(stream), x, dy, y, mu, rs, gamma, beta, part, M, C, seg_rows, chunks, mode,
                      stat_per_seg);
   return check_launch("rowstats");
+}
+
+extern "C" int diffsal_reduce_partials(const double* part, void* out, int segs, int chunks, int width, int out_is_f64,
+                                       diffsal_stream_t stream) {
+  DS_REQUIRE(part && out, DIFFSAL_E_ARG, "reduce_partials: null argument");
+  DS_REQUIRE(segs > 0 && chunks > 0 && width > 0, DIFFSAL_E_SHAPE, "reduce_partials: bad shape");
+  const dim3 grid((width + 31) / 32, segs);
+  if (out_is_f64)
+    hipLaunchKernelGGL((reduce_partials_kernel<double>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), part,
+                       static_cast<double*>(out), chunks, width);
+  else
+    hipLaunchKernelGGL((reduce_partials_kernel<float>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), part,
+                       static_cast<float*>(out), chunks, width);
+  return check_launch("reduce_partials");
+}
+
+extern "C" int diffsal_norm_finalize_fwd(const double* sums, const float* gamma, const float* beta, float* mu, float* rs,
+                                         float* scale, float* shift, int segs, int C, int groups, double n, double eps,
+                                         float* bn_mean, float* bn_var, float* running_mean, float* running_var,
+                                         float momentum, float unbias, diffsal_stream_t stream) {
+  DS_REQUIRE(sums && gamma && beta && mu && rs && scale && shift, DIFFSAL_E_ARG, "norm_finalize_fwd: null argument");
+  DS_REQUIRE(segs > 0 && C > 0 && groups > 0 && C % groups == 0 && n > 0, DIFFSAL_E_SHAPE, "norm_finalize_fwd: bad shape");
+  DS_REQUIRE((bn_mean == nullptr) == (bn_var == nullptr) && (running_mean == nullptr) == (running_var == nullptr),
+             DIFFSAL_E_ARG, "norm_finalize_fwd: BatchNorm outputs come in pairs");
+  DS_REQUIRE(bn_mean == nullptr || segs == 1, DIFFSAL_E_SHAPE, "norm_finalize_fwd: BatchNorm has one segment");
+  hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums, gamma, beta, mu,
+                     rs, scale, shift, segs, C, groups, n, eps, bn_mean, bn_var, running_mean, running_var, momentum, unbias);
+  return check_launch("norm_finalize_fwd");
+}
+
+extern "C" int diffsal_norm_finalize_bwd(const double* t, const float* gamma, const float* rs, float* dgamma, float* dbeta,
+                                         float* k1, float* k2, float* k3, int segs, int C, int groups, double n,
+                                         diffsal_stream_t stream) {
+  DS_REQUIRE(t && gamma && rs && dgamma && dbeta && k1 && k2 && k3, DIFFSAL_E_ARG, "norm_finalize_bwd: null argument");
+  DS_REQUIRE(segs > 0 && C > 0 && groups > 0 && C % groups == 0 && n > 0, DIFFSAL_E_SHAPE, "norm_finalize_bwd: bad shape");
+  hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), t, gamma, rs, dgamma,
+                     dbeta, k1, k2, k3, segs, C, groups, n);
+  return check_launch("norm_finalize_bwd");
 }
 
 extern "C" int diffsal_affine_act(const float* x, const float* scale, const float* shift, float* out, int M, int C,

@@ -370,7 +370,45 @@ def rowstats(x: Tensor, seg_rows: int, mode: int = 0, dy=None, y=None, mu=None, 
     part = torch.empty((M // seg_rows, chunks, 2, Cc), device=x.device, dtype=torch.float64)
     _lib.check(lib.diffsal_rowstats(_p(x), _p(dy), _p(y), _p(mu), _p(rs), _p(gamma), _p(beta), part.data_ptr(), M, Cc, seg_rows,
                                     mode, int(stat_per_seg), _stream()), "rowstats")
-    return part.sum(dim=1)
+    return reduce_partials(part, M // seg_rows, chunks, 2 * Cc, f64=True).view(M // seg_rows, 2, Cc)
+
+
+def reduce_partials(part: Tensor, segs: int, chunks: int, width: int, f64: bool = False) -> Tensor:
+    """Sum fp64 partials [segs, chunks, width] over the chunks (fixed order) -> [segs, width] (fp64 or fp32)."""
+    lib = _lib.load()
+    out = torch.empty((segs, width), device=part.device, dtype=torch.float64 if f64 else torch.float32)
+    _lib.check(lib.diffsal_reduce_partials(part.data_ptr(), out.data_ptr(), segs, chunks, width, int(f64), _stream()),
+               "reduce_partials")
+    return out
+
+
+def norm_finalize_fwd(sums: Tensor, gamma: Tensor, beta: Tensor, groups: int, n: float, eps: float, bn=None):
+    """sums [segs, 2, C] fp64 -> (mu, rs, scale, shift) [segs, C] (+ (mean, var) [C] when ``bn`` = (running_mean,
+    running_var, momentum, unbias) is given: BatchNorm, running statistics updated in place)."""
+    lib = _lib.load()
+    segs, _, Cc = sums.shape
+    mu, rs, scale, shift = (torch.empty((segs, Cc), device=sums.device, dtype=torch.float32) for _ in range(4))
+    if bn is not None:
+        mean, var = torch.empty((Cc,), device=sums.device), torch.empty((Cc,), device=sums.device)
+        rm, rv, mom, unb = bn
+        args = (_p(mean), _p(var), _p(rm), _p(rv), float(mom), float(unb))
+    else:
+        mean = var = None
+        args = (None, None, None, None, 0.0, 1.0)
+    _lib.check(lib.diffsal_norm_finalize_fwd(sums.data_ptr(), _p(gamma), _p(beta), _p(mu), _p(rs), _p(scale), _p(shift), segs,
+                                             Cc, groups, float(n), float(eps), *args, _stream()), "norm_finalize_fwd")
+    return mu, rs, scale, shift, mean, var
+
+
+def norm_finalize_bwd(t: Tensor, gamma: Tensor, rs: Tensor, groups: int, n: float):
+    """t [segs, 2, C] fp64 -> (dgamma [C], dbeta [C], k1, k2, k3 [segs, C])."""
+    lib = _lib.load()
+    segs, _, Cc = t.shape
+    dg, db = torch.empty((Cc,), device=t.device), torch.empty((Cc,), device=t.device)
+    k1, k2, k3 = (torch.empty((segs, Cc), device=t.device, dtype=torch.float32) for _ in range(3))
+    _lib.check(lib.diffsal_norm_finalize_bwd(t.data_ptr(), _p(gamma), _p(rs), _p(dg), _p(db), _p(k1), _p(k2), _p(k3), segs, Cc,
+                                             groups, float(n), _stream()), "norm_finalize_bwd")
+    return dg, db, k1, k2, k3
 
 
 def affine_act(x: Tensor, scale: Tensor, shift: Tensor, seg_rows: int, act: int) -> Tensor:
@@ -402,7 +440,7 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5):
     dx = torch.empty_like(x)
     _lib.check(lib.diffsal_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(dx), part.data_ptr(), M, Cc, eps, _stream()),
                "layernorm_bwd")
-    s = part.sum(dim=0).float()
+    s = reduce_partials(part, 1, blocks, 2 * Cc).view(2, Cc)
     return dx, s[0], s[1]
 
 
@@ -444,7 +482,7 @@ def dwconv_bwd(x: Tensor, w: Tensor, du: Tensor, k: int, stride: int, pad: int, 
         part = torch.empty((k * k, chunks, Cc), device=x.device, dtype=torch.float64)
         _lib.check(lib.diffsal_dwconv_bwd_weight(_p(x), _p(du), part.data_ptr(), N, H, W, Cc, k, stride, pad, _stream()),
                    "dwconv_bwd_weight")
-        dw = part.sum(dim=1).float()
+        dw = reduce_partials(part, k * k, chunks, Cc)
     return dx, dw
 
 
@@ -514,7 +552,7 @@ def head_bwd(y: Tensor, w: Tensor, s_out: Tensor, ds: Tensor):
     dy = torch.empty_like(y)
     _lib.check(lib.diffsal_head_bwd(_p(y), _p(w), _p(s_out), _p(ds), _p(dy), part.data_ptr(), blocks, M, Cc, _stream()),
                "head_bwd")
-    s = part.sum(dim=0).float()
+    s = reduce_partials(part, 1, blocks, Cc + 1).view(-1)
     return dy, s[:Cc].contiguous(), s[Cc:].contiguous()
 
 
@@ -526,7 +564,7 @@ def conv_in_bwd(x: Tensor, dy: Tensor):
     chunks = 128
     part = torch.empty((10, chunks, Cc), device=x.device, dtype=torch.float64)
     _lib.check(lib.diffsal_conv_in_bwd(_p(x), _p(dy), part.data_ptr(), B, H, W, Cc, chunks, _stream()), "conv_in_bwd")
-    s = part.sum(dim=1).float()
+    s = reduce_partials(part, 10, chunks, Cc)
     return s[:9].t().contiguous(), s[9].contiguous()
 
 

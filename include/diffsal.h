@@ -127,13 +127,31 @@ int diffsal_act_bwd(const float* dy, const float* ref, float* dx, size_t n, int 
 /* ---- K16 (training): normalisation layers ------------------------------------------------------
  * Per-channel dual sums over the rows of each segment -> part[segs][chunks][2][C] (fp64), chunks = diffsal_rowstats_chunks():
  *   mode 0 (x, x^2): BatchNorm (train) / GroupNorm statistics;  mode 1/2/3: (dz, dz*xhat) for BN+ReLU, GN+swish, plain.
- * The caller folds the partials into per-(segment, channel) vectors (tiny) and calls the element-wise kernels below.
+ * diffsal_reduce_partials + diffsal_norm_finalize_* fold the partials into per-(segment, channel) vectors for the
+ * element-wise kernels below.
  * Replace the forward / backward of nn.BatchNorm2d (train), nn.GroupNorm + swish (sal_unet.py:36-44,
  * common_block.py:33-36,196-216). */
 int diffsal_rowstats_chunks(int M, int seg_rows);
 int diffsal_rowstats(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
                      const float* gamma, const float* beta, double* part, int M, int C, int seg_rows, int mode,
                      int stat_per_seg, diffsal_stream_t stream);
+/* Sum fp64 per-workgroup partials part[segs][chunks][width] over the chunks, fixed order -> out[segs][width]
+ * (double if out_is_f64, else float).  Every reduction kernel of the training step leaves such partials. */
+int diffsal_reduce_partials(const double* part, void* out, int segs, int chunks, int width, int out_is_f64,
+                            diffsal_stream_t stream);
+/* GroupNorm / train-mode BatchNorm statistics -> the vectors the apply kernels consume.  sums[segs][2][C] = per-channel
+ * (sum x, sum x^2); `groups` channel groups share statistics over n values each (BatchNorm: groups = C, segs = 1,
+ * n = rows).  Writes mu, rs, scale = rs*gamma, shift = beta - mu*scale, each [segs][C].  BatchNorm extras, all optional:
+ * bn_mean / bn_var [C] (batch mean, biased variance) and the nn.BatchNorm2d running-statistics update
+ * run = (1-momentum) run + momentum * (mean | var * unbias)  (R/.../common_block.py:196-223 in train mode).
+ * norm_finalize_bwd: t[segs][2][C] = (sum dz, sum dz*xhat) -> dbeta, dgamma [C] and k1, k2, k3 [segs][C] for
+ * diffsal_norm_bwd_apply. */
+int diffsal_norm_finalize_fwd(const double* sums, const float* gamma, const float* beta, float* mu, float* rs,
+                              float* scale, float* shift, int segs, int C, int groups, double n, double eps,
+                              float* bn_mean, float* bn_var, float* running_mean, float* running_var, float momentum,
+                              float unbias, diffsal_stream_t stream);
+int diffsal_norm_finalize_bwd(const double* t, const float* gamma, const float* rs, float* dgamma, float* dbeta, float* k1,
+                              float* k2, float* k3, int segs, int C, int groups, double n, diffsal_stream_t stream);
 /* out = act(x * scale[seg, c] + shift[seg, c]); act: DIFFSAL_ACT_NONE / RELU, or 4 = swish */
 int diffsal_affine_act(const float* x, const float* scale, const float* shift, float* out, int M, int C, int seg_rows,
                        int act, diffsal_stream_t stream);
