@@ -28,27 +28,31 @@ struct WgradArgs {
   unsigned in_bytes;
 };
 
-constexpr int WG_BM = 32;     // pixels per reduction step
+constexpr int WG_BM = 64;     // granularity of the M split (a multiple of every kernel's rows-per-step)
 
 // Tile = (WCO*CT*32 output channels) x (WK*ST K-slices of 32); the 4 waves form a WCO x WK grid and each owns
 // CT x ST MFMA 32x32 accumulators.  Global loads of step i+1 are issued into registers before the MFMA loop of
 // step i, so HBM/L2 latency hides behind 16 * CT * ST MFMAs per wave.
-template <int CT, int WCO, int WK, int ST>
+template <int CT, int WCO, int WK, int ST, int BM = 32>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   static_assert(WCO * WK == 4, "four waves");
   constexpr int BCO = WCO * CT * 32, SL = WK * ST, BKI = SL * 32;
   constexpr int PA = BCO + 4, PB = BKI + 4;      // ds_read_b32 of 32 consecutive floats per half wave: conflict-free
-  constexpr int NA = BCO / 32, NB = BKI / 32;    // float4 loads per thread per step
-  __shared__ __attribute__((aligned(16))) float dYs[WG_BM * PA];
-  __shared__ __attribute__((aligned(16))) float Xs[WG_BM * PB];
+  constexpr int NA = BCO / 32 * (BM / 32), NB = BKI / 32 * (BM / 32);    // float4 loads per thread per step
+  __shared__ __attribute__((aligned(16))) float dYs[BM * PA];
+  __shared__ __attribute__((aligned(16))) float Xs[BM * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WK, wn = wave % WK;
   const int co0 = blockIdx.x * BCO;
   const int sl0 = blockIdx.y * SL;          // first K slice of this tile
   const int n_slices = p.K / 32;
   const int seg = blockIdx.z / p.splits, sp = blockIdx.z - seg * p.splits;
-  const int m_begin = seg * p.seg_rows + sp * p.rows_per_split;
-  const int m_end = min(min(p.M, (seg + 1) * p.seg_rows), m_begin + p.rows_per_split);
+  // the splits of a segment interleave at step granularity (split sp takes steps sp, sp + splits, ...): at any moment the
+  // resident workgroups stream through adjacent chunks of dY / X (halos shared in L2) instead of marching in lockstep at a
+  // fixed large stride.  (Measured neutral on MI355X; kept because it bounds the working set.)
+  const int m_begin = seg * p.seg_rows + sp * BM;
+  const int m_end = min(p.M, (seg + 1) * p.seg_rows);
+  const int m_stride = p.splits * BM;
   const int HoWo = p.Ho * p.Wo;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   };
 
   if (m_begin < m_end) prefetch(m_begin);
-  for (int mb = m_begin; mb < m_end; mb += WG_BM) {
+  for (int mb = m_begin; mb < m_end; mb += m_stride) {
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int idx = tid + 256 * q;
@@ -121,9 +125,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       st4(&Xs[r * PB + rem * 4], rb[q]);
     }
     __syncthreads();
-    if (mb + WG_BM < m_end) prefetch(mb + WG_BM);
+    if (mb + m_stride < m_end) prefetch(mb + m_stride);
 #pragma unroll
-    for (int ks = 0; ks < WG_BM / 2; ++ks) {
+    for (int ks = 0; ks < BM / 2; ++ks) {
       const int mrow = ks * 2 + (lane >> 5);
       float a[CT], b[ST];
 #pragma unroll
@@ -238,7 +242,7 @@ struct WgradPlan { int cfg, splits, rows_per_split; };
 WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
   WgradPlan pl{0, 1, 0};
   double best = 1e300;
-  const long max_splits = (seg_rows + 4 * WG_BM - 1) / (4 * WG_BM);
+  const long max_splits = (seg_rows + 127) / 128;
   int only = -1;
   if (const char* e = getenv("DIFFSAL_WGRAD_CFG")) only = atoi(e) % kNumWgradCfgs;   // tuning aid
   for (int c = 0; c < kNumWgradCfgs; ++c) {
@@ -256,12 +260,18 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
       const long wgs = tiles * sp;
       const long rounds = (wgs + 511) / 512;
       const long rps = ((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM;
-      const double steps = static_cast<double>(rps) / WG_BM + 4.0;
+      const double steps = static_cast<double>(rps) / 32.0 + 4.0;   // in 32-row steps
       const double occ = wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0);
       double t = rounds * occ * steps * step_cycles;
       if (sp > 1) t += 2.0 * sp * segments * Cout * static_cast<double>(K) * 4.0 / 1250.0;
       if (t < best) { best = t; pl.cfg = c; pl.splits = static_cast<int>(sp); pl.rows_per_split = static_cast<int>(rps); }
     }
+  }
+  if (const char* e = getenv("DIFFSAL_WGRAD_SPLITS")) {   // tuning aid
+    long sp = atol(e);
+    sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
+    pl.splits = static_cast<int>(sp);
+    pl.rows_per_split = static_cast<int>(((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM);
   }
   if (getenv("DIFFSAL_WGRAD_VERBOSE"))
     fprintf(stderr, "wgrad plan: Cout=%d K=%ld seg_rows=%ld segs=%d -> cfg %d splits %d rows/split %d model %.0f cycles\n",
