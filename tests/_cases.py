@@ -42,3 +42,25 @@ def check_taps(taps, g, rtol, names=None):
         worst[name] = err
         assert err < rtol, (name, err)
     return worst
+
+
+def train_fixture_inputs(golden_dir, name):
+    """Inputs of oracle/gen_golden.py::gen_train_step (closed form) + the fixture."""
+    av = name.endswith("_av")
+    cfg = CASES["tiny_av"][0]
+    g = np.load(f"{golden_dir}/{name}.npz")
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    tag = str(g["tag"])
+    noise, feats, audio = orc.synth_inputs(cfg, 2, av, tag=tag)
+    sal = torch.sigmoid(orc.synth_tensor(tag + ".sal", (2, 1, *cfg.img_size)))
+    dq = orc.synth_tensor(tag + ".dq", tuple(sal.shape))
+    return cfg, sd, sal, dq, noise, int(g["t0"]), feats, audio, g
+
+
+def sampled_err(got, g, key):
+    """max |got - fixture| over the fixture's strided samples of tensor ``key``, and the fixture tensor's max |.|."""
+    got = got.detach().float().cpu()
+    assert tuple(got.shape) == tuple(g[f"tap.{key}.shape"]), (key, got.shape)
+    stride = int(g[f"tap.{key}.stride"])
+    ref = torch.from_numpy(g[f"tap.{key}.sample"])
+    return (got.reshape(-1)[::stride] - ref).abs().max().item(), float(g[f"tap.{key}.stats"][2])

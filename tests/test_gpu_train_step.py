@@ -157,3 +157,54 @@ def test_training_steps_match_oracle_adam(av):
     with torch.no_grad():
         ref = orc.salunet_forward(full_sd, cfg, noise, torch.full((B,), t0), feats, audio)
     assert (out.cpu() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["train_tiny_av", "train_tiny_vis"])
+def test_training_step_matches_reference_fixture(golden_dir, name):
+    """One step of DiffusionTrainStep vs the REAL reference's step (tests/golden/train_*.npz, oracle/gen_golden.py::
+    gen_train_step: .train() mode, dropout off, MSE, clip 1.0, Adam 1e-4): loss, output, every parameter gradient,
+    clip norm, BatchNorm running statistics and the updated parameters.  The fixture inputs were chosen so that no ReLU
+    pre-activation sits within 1.5e-6 of zero (see the module docstring)."""
+    from diff_sal_amd.train_step import DiffusionTrainStep
+    from tests._cases import sampled_err, train_fixture_inputs
+
+    cfg, sd, sal, dq, noise, t0, feats, audio, g = train_fixture_inputs(golden_dir, name)
+    net = build(cfg, sd)
+    net.dropout_p = 0.0
+    ts = DiffusionTrainStep(net, lr=1e-4, grad_clip=1.0)
+    cond = {"feat_list": [f.to(DEV) for f in feats], "audio_feat": None if audio is None else audio.to(DEV)}
+    x0, x_t, t, _ = ts.prepare_data(sal.to(DEV), t0=t0, noise=noise.to(DEV), dequant_noise=dq.to(DEV))
+    net.train()
+    with torch.no_grad():
+        pred = net.forward_train(x_t, t, cond["feat_list"], cond["audio_feat"])   # output check; running stats advance once
+    e, _ = sampled_err(pred, g, "pred")
+    assert e < 1e-4
+    for k, b in net.named_buffers():            # running statistics after exactly one train-mode forward
+        if "running" in k:
+            e, m = sampled_err(b, g, "buf." + k)
+            assert e < 1e-5 * max(m, 1.0), (k, e, m)
+    net.load_state_dict(sd)                     # rewind the buffers; parameters are untouched
+    loss = ts.loss_and_backward(x0, x_t, t, cond)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    no_grad = set(g["no_grad"].tolist())
+    names = [k for k, _ in net.named_parameters()]
+    gmax = max(float(g[f"tap.grad.{k}.stats"][2]) for k in names if k not in no_grad)
+    worst = []
+    for k, p in net.named_parameters():
+        if k in no_grad:
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-6 * gmax, k
+            continue
+        e, m = sampled_err(p.grad, g, "grad." + k)
+        worst.append((e / (1e-4 * m + 2e-6 * gmax), k, e, m))
+    worst.sort()
+    print("worst gradient errors (fraction of tolerance 1e-4*max + 2e-6*gmax):", worst[-4:])
+    assert worst[-1][0] < 1.0, worst[-1]
+    ts.optimizer_step()
+    assert abs(ts.last_norm.item() - float(g["total_norm"])) < 1e-4 * float(g["total_norm"])
+    for k, p in net.named_parameters():
+        if k in no_grad or float(g[f"tap.grad.{k}.stats"][2]) < 1e-4 * gmax:
+            continue
+        e, _ = sampled_err(p, g, "after." + k)
+        # after clipping by ~3e3-6e3 most entries are ~1e-8 = Adam's eps, where the update lr*g/(|g|+eps) is linear in g:
+        # a 1e-3-of-max gradient difference becomes tenths of one step (the kernel itself is pinned to 1e-6 in test_gpu_train_ops)
+        assert e < 5e-5, (k, e)                 # half of one Adam step (lr = 1e-4)

@@ -70,3 +70,45 @@ def test_timestep_embedding_fractional():
     assert e.shape == (2, 96)
     assert torch.allclose(e[1, :48], torch.zeros(48)) and torch.allclose(e[1, 48:], torch.ones(48))
     assert abs(e[0, 0].item() - np.sin(998.996)) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["train_tiny_av", "train_tiny_vis"])
+def test_restatement_training_step_matches_reference(golden_dir, name):
+    """Loss, every parameter gradient, clip norm and the Adam-updated parameters of one REAL reference training step
+    (train-mode BatchNorm, dropout off) vs autograd through the restatement + the same torch optimizer calls."""
+    from diff_sal_amd.diffusion_utils import get_beta_schedule, to_torch
+    from tests._cases import sampled_err, train_fixture_inputs
+
+    cfg, sd, sal, dq, noise, t0, feats, audio, g = train_fixture_inputs(golden_dir, name)
+    a_hat = (1.0 - to_torch(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000))).cumprod(0)
+    x0 = sal + 0.01 * dq
+    x_t = a_hat[t0].sqrt() * x0 + (1 - a_hat[t0]).sqrt() * noise
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    leaf = {k: (torch.nn.Parameter(v.clone()) if k in names else v.clone()) for k, v in sd.items()}
+    opt = torch.optim.Adam([leaf[k] for k in names], lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    orc.BN_TRAIN = True
+    try:
+        pred = orc.salunet_forward(leaf, cfg, x_t, torch.full((2,), t0), feats, audio)
+    finally:
+        orc.BN_TRAIN = False
+    loss = (pred - x0).square().sum(dim=(1, 2, 3)).mean(dim=0)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    e, m = sampled_err(pred, g, "pred")
+    assert e < 2e-5
+    no_grad = set(g["no_grad"].tolist())
+    gmax = max(float(g[f"tap.grad.{k}.stats"][2]) for k in names if k not in no_grad)
+    for k in names:
+        if k in no_grad:
+            assert leaf[k].grad is None or float(leaf[k].grad.abs().max()) == 0.0, k
+            continue
+        e, m = sampled_err(leaf[k].grad, g, "grad." + k)
+        assert e < 2e-4 * m + 1e-5 * gmax, (k, e, m)
+    norm = torch.nn.utils.clip_grad_norm_([leaf[k] for k in names], 1.0)
+    assert abs(float(norm) - float(g["total_norm"])) < 1e-4 * float(g["total_norm"])
+    opt.step()
+    for k in names:
+        if k in no_grad or float(g[f"tap.grad.{k}.stats"][2]) < 1e-4 * gmax:
+            continue                   # gradient is rounding noise (zero by symmetry, e.g. a conv bias before BatchNorm)
+        e, m = sampled_err(leaf[k], g, "after." + k)
+        assert e < 2e-5, (k, e)        # one Adam step moves a parameter by at most lr = 1e-4
