@@ -29,9 +29,13 @@ def test_train_forward_and_all_parameter_gradients_match_oracle_autograd(av):
 
     # reference: autograd through the oracle with batch-statistics BN
     leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    # the conditioning features come from trainable encoders upstream (MViT, AudioAttnNet): they need gradients too
+    feats_r = [f.clone().requires_grad_(True) for f in feats]
+    audio_r = None if audio is None else audio.clone().requires_grad_(True)
+    x_r = x
     orc.BN_TRAIN = True
     try:
-        pred = orc.salunet_forward(leaf, cfg, x, t, feats, audio)
+        pred = orc.salunet_forward(leaf, cfg, x_r, t, feats_r, audio_r)
     finally:
         orc.BN_TRAIN = False
     loss = ((pred - x0) ** 2).sum(dim=(1, 2, 3)).mean()
@@ -40,7 +44,10 @@ def test_train_forward_and_all_parameter_gradients_match_oracle_autograd(av):
     net = build(cfg, sd)
     net.train()
     net.dropout_p = 0.0
-    out = net(x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None if audio is None else audio.to(DEV))
+    feats_d = [f.to(DEV).requires_grad_(True) for f in feats]
+    audio_d = None if audio is None else audio.to(DEV).requires_grad_(True)
+    x_d = x.to(DEV)
+    out = net(x_d, t.to(DEV), feats_d, audio_d)
     assert (out.detach().cpu() - pred.detach()).abs().max().item() < 1e-4
     l2 = ((out - x0.to(DEV)) ** 2).sum(dim=(1, 2, 3)).mean()
     l2.backward()
@@ -66,6 +73,18 @@ def test_train_forward_and_all_parameter_gradients_match_oracle_autograd(av):
     print("median fraction:", worst[len(worst) // 2][0])
     assert checked > 150
     assert worst[-1][0] < 1.0, worst[-1]
+    # input gradients (feat_list[3] is never read by the reference graph: quirk Q3, its gradient is None / zero)
+    # (x_t itself is data -- R/diffusion_trainer.py:106-117 -- and gets no gradient: conv_in's backward is parameters-only)
+    pairs = [(f"feat{i}", a, b) for i, (a, b) in enumerate(zip(feats_d, feats_r))]
+    if audio is not None:
+        pairs.append(("audio", audio_d, audio_r))
+    for nm, a, b in pairs:
+        if b.grad is None or float(b.grad.abs().max()) == 0.0:
+            assert a.grad is None or float(a.grad.abs().max()) <= 1e-6 * scale, nm
+            continue
+        assert a.grad is not None, nm
+        err = (a.grad.cpu() - b.grad).abs().max().item()
+        assert err < 5e-3 * b.grad.abs().max().item() + 5e-5 * scale, (nm, err, b.grad.abs().max().item())
 
 
 def _oracle_train_steps(cfg, sd, batches, av, n_steps, lr):
