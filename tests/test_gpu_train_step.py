@@ -227,3 +227,46 @@ def test_training_step_matches_reference_fixture(golden_dir, name):
         # after clipping by ~3e3-6e3 most entries are ~1e-8 = Adam's eps, where the update lr*g/(|g|+eps) is linear in g:
         # a 1e-3-of-max gradient difference becomes tenths of one step (the kernel itself is pinned to 1e-6 in test_gpu_train_ops)
         assert e < 5e-5, (k, e)                 # half of one Adam step (lr = 1e-4)
+
+
+def test_end_to_end_training_through_video_saliency_model_with_a_torch_encoder():
+    """The drop-in story for training: VideoSaliencyModel with an ordinary PyTorch visual encoder (stand-in for MViT,
+    which is outside the path) in front of the HIP denoiser.  DiffusionTrainStep flattens BOTH modules' parameters; the
+    encoder's gradients come through the denoiser's hand-written backward (feature gradients) and torch autograd."""
+    from diff_sal_amd import VideoSaliencyModel
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    H, W = cfg.img_size
+
+    class ToyEncoder(torch.nn.Module):       # clip [B,3,8,H,W] -> 4 feature maps, coarsest first (R/models/diff_model.py:96-104)
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.ModuleList([torch.nn.Conv3d(3, c, 1) for c in cfg.up_channel])
+
+        def forward(self, clip):
+            outs = []
+            for p, s in zip(self.proj, (32, 16, 8, 4)):
+                outs.append(p(torch.nn.functional.adaptive_avg_pool3d(clip, (8, H // s, W // s))))
+            return outs
+
+    torch.manual_seed(0)
+    model = VideoSaliencyModel(channel_list=None, visual_net=ToyEncoder(), decoder_net=build(cfg, sd)).to(DEV)
+    model.decoder_net.dropout_p = 0.0
+    ts = DiffusionTrainStep(model, lr=2e-4, grad_clip=1.0)
+    n_dec = sum(p.numel() for p in model.decoder_net.parameters())
+    n_enc = sum(p.numel() for p in model.visual_net.parameters())
+    assert ts.flat.live_numel == n_dec + n_enc
+    enc_before = [p.detach().clone() for p in model.visual_net.parameters()]
+    g = torch.Generator().manual_seed(5)
+    clip = torch.randn((2, 3, 8, H, W), generator=g).to(DEV)
+    sal = torch.rand((2, 1, H, W), generator=g).to(DEV)
+    noise = torch.randn((2, 1, H, W), generator=g).to(DEV)
+    losses = [ts.step(sal, {"img": clip}, t0=300, noise=noise, dequant_noise=torch.zeros_like(sal)).item() for _ in range(6)]
+    print("losses", losses)
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]                                     # same batch every step: the loss must go down
+    moved = [float((p.detach() - b).abs().max()) for p, b in zip(model.visual_net.parameters(), enc_before)]
+    assert min(moved[:6]) > 0.0                                       # the three feature maps the graph reads train the encoder
+    assert all(p.grad is None or p.grad.data_ptr() >= ts.flat.flat_g.data_ptr() for p in model.parameters())
