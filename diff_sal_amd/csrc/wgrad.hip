@@ -157,19 +157,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-// out[seg][i] = sum over the splits of one segment, in order (deterministic)
+// out[seg][i] = sum over the splits of one segment (deterministic: fixed association).  Workgroup = 16 float4 columns x
+// 16 split groups: group g adds splits g, g+16, ... in order, then the 16 group sums are added in order.  (One thread per
+// column walking all splits serially left 9 workgroups with 256-512 dependent steps each on the small token GEMMs.)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                        long n, int splits) {
+  __shared__ float4 sh[16][17];
   const float* base = slabs + static_cast<long>(blockIdx.y) * splits * n;
   float* o = out + static_cast<long>(blockIdx.y) * n;
   const long n4 = n >> 2;   // n = Cout * K, K % 32 == 0
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<long>(gridDim.x) * 256) {
-    float4 s = ld4(base + i * 4);
-    for (int k = 1; k < splits; ++k) {
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long i = static_cast<long>(blockIdx.x) * 16 + cl;
+  float4 s = make_float4(0, 0, 0, 0);
+  if (i < n4)
+    for (int k = g; k < splits; k += 16) {
       const float4 v = ld4(base + static_cast<long>(k) * n + i * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    st4(o + i * 4, s);
+  sh[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && i < n4) {
+    float4 t = sh[0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) { t.x += sh[q][cl].x; t.y += sh[q][cl].y; t.z += sh[q][cl].z; t.w += sh[q][cl].w; }
+    st4(o + i * 4, t);
   }
 }
 
@@ -256,7 +267,7 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
     for (int r = 1; r <= 8; ++r) {
       long sp = r * 512L / tiles;
       sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
-      sp = sp > 256 ? 256 : sp;
+      sp = sp > 512 ? 512 : sp;
       const long wgs = tiles * sp;
       const long rounds = (wgs + 511) / 512;
       const long rps = ((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM;
@@ -296,8 +307,7 @@ int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
   }
   int rc = check_launch("conv_wgrad");
   if (rc || pl.splits == 1) return rc;
-  long g = (n / 4 + 255) / 256;
-  g = g > 1024 ? 1024 : g;
+  const long g = (n / 4 + 15) / 16;
   hipLaunchKernelGGL(slab_sum_kernel, dim3(static_cast<int>(g), segments), dim3(256), 0, s,
                      static_cast<const float*>(a.slabs), out, n, pl.splits);
   return check_launch("conv_wgrad(sum)");
