@@ -108,23 +108,24 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < 2 * C; i += 256) o[i] = shd[i];
 }
 
-// out[seg][j] = sum over chunks of part[seg][chunk][j] (fp64 in, fp64 or fp32 out).  Workgroup = (32 columns, segment);
-// 8 thread groups take every 8th chunk, the 8 group sums are combined in a fixed order.
+// out[seg][j] = sum over chunks of part[seg][chunk][j] (fp64 in, fp64 or fp32 out).  Workgroup = (8 columns, segment);
+// 32 thread groups take every 32nd chunk, the 32 group sums are combined in a fixed order (short dependent chains and
+// enough workgroups even when there are only ~200 columns).
 template <typename OUT>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ part, OUT* __restrict__ out,
                                                               int chunks, int Wd) {
-  __shared__ double sh[8][33];
-  const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + cl, g = blockIdx.y;
+  __shared__ double sh[32][9];
+  const int cl = threadIdx.x & 7, kg = threadIdx.x >> 3;
+  const int j = blockIdx.x * 8 + cl, g = blockIdx.y;
   double s = 0.0;
   if (j < Wd)
-    for (int k = kg; k < chunks; k += 8) s += part[(static_cast<long>(g) * chunks + k) * Wd + j];
+    for (int k = kg; k < chunks; k += 32) s += part[(static_cast<long>(g) * chunks + k) * Wd + j];
   sh[kg][cl] = s;
   __syncthreads();
   if (kg == 0 && j < Wd) {
     double t = sh[0][cl];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) t += sh[q][cl];
+    for (int q = 1; q < 32; ++q) t += sh[q][cl];
     out[static_cast<long>(g) * Wd + j] = static_cast<OUT>(t);
   }
 }
@@ -943,7 +944,7 @@ extern "C" int diffsal_reduce_partials(const double* part, void* out, int segs, 
                                        diffsal_stream_t stream) {
   DS_REQUIRE(part && out, DIFFSAL_E_ARG, "reduce_partials: null argument");
   DS_REQUIRE(segs > 0 && chunks > 0 && width > 0, DIFFSAL_E_SHAPE, "reduce_partials: bad shape");
-  const dim3 grid((width + 31) / 32, segs);
+  const dim3 grid((width + 7) / 8, segs);
   if (out_is_f64)
     hipLaunchKernelGGL((reduce_partials_kernel<double>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), part,
                        static_cast<double*>(out), chunks, width);

@@ -213,22 +213,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(seg) * chunks + chunk) * C + i] = shd[i];
 }
 
-// out[g][c] (fp32) = sum over chunks of part[g][chunk][c] (fp64).  Workgroup = (32 channels, segment); 8 thread groups
-// take every 8th chunk, then the 8 group sums are added in a fixed order.
+// out[g][c] (fp32) = sum over chunks of part[g][chunk][c] (fp64).  Workgroup = (8 channels, segment); 32 thread groups
+// take every 32nd chunk, then the 32 group sums are added in a fixed order.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out,
                                                            int segs, int chunks, int C) {
-  __shared__ double sh[8][33];
-  const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl, g = blockIdx.y;
+  __shared__ double sh[32][9];
+  const int cl = threadIdx.x & 7, kg = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl, g = blockIdx.y;
   double s = 0.0;
   if (c < C)
-    for (int k = kg; k < chunks; k += 8) s += part[(static_cast<long>(g) * chunks + k) * C + c];
+    for (int k = kg; k < chunks; k += 32) s += part[(static_cast<long>(g) * chunks + k) * C + c];
   sh[kg][cl] = s;
   __syncthreads();
   if (kg == 0 && c < C) {
     double t = sh[0][cl];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) t += sh[j][cl];
+    for (int j = 1; j < 32; ++j) t += sh[j][cl];
     out[static_cast<long>(g) * C + c] = static_cast<float>(t);
   }
 }
@@ -390,7 +390,7 @@ extern "C" int diffsal_colsum(const float* dy, float* out, int M, int C, int seg
                      C, seg_rows, chunks);
   int rc = check_launch("colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32, segs), dim3(256), 0, s,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 7) / 8, segs), dim3(256), 0, s,
                      static_cast<const double*>(ws), out, segs, chunks, C);
   return check_launch("colsum(sum)");
 }
