@@ -928,7 +928,7 @@ extern "C" int diffsal_rowstats(const float* x, const float* dy, const float* y,
                                 const float* gamma, const float* beta, double* part, int M, int C, int seg_rows,
                                 int mode, int stat_per_seg, diffsal_stream_t stream) {
   DS_REQUIRE(x && part, DIFFSAL_E_ARG, "rowstats: null argument");
-  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 2048 && seg_rows > 0 && M % seg_rows == 0 && mode >= 0 && mode <= 3,
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && seg_rows > 0 && M % seg_rows == 0 && mode >= 0 && mode <= 3,
              DIFFSAL_E_SHAPE, "rowstats: bad shape M=%d C=%d seg_rows=%d mode=%d", M, C, seg_rows, mode);
   DS_REQUIRE(mode == 0 || (dy && mu && rs), DIFFSAL_E_ARG, "rowstats: backward modes need dy, mu, rs");
   DS_REQUIRE(mode != 1 || y, DIFFSAL_E_ARG, "rowstats: mode 1 needs y");
@@ -1066,8 +1066,8 @@ extern "C" int diffsal_dwconv_bwd_weight_chunks(int N, int H, int W, int k, int 
 extern "C" int diffsal_dwconv_bwd_weight(const float* x, const float* du, double* part, int N, int H, int W, int C, int k,
                                          int stride, int pad, diffsal_stream_t stream) {
   DS_REQUIRE(x && du && part, DIFFSAL_E_ARG, "dwconv_bwd_weight: null argument");
-  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && C <= 4096 && k > 0 && stride > 0 && pad >= 0, DIFFSAL_E_SHAPE,
-             "dwconv_bwd_weight: bad shape");
+  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && C <= 1024 && k > 0 && stride > 0 && pad >= 0, DIFFSAL_E_SHAPE,
+             "dwconv_bwd_weight: bad shape (C <= 1024: one thread per 4 channels of a row)");
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int chunks = diffsal_dwconv_bwd_weight_chunks(N, H, W, k, stride, pad);
   hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(chunks, k * k), dim3(256), C * sizeof(double),

@@ -192,23 +192,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   extern __shared__ double shd[];  // [C]
   const int seg = blockIdx.y, chunk = blockIdx.x;
   const int c4n = C >> 2;
-  const int rpp = 256 / c4n > 0 ? 256 / c4n : 1;
-  const int c4 = threadIdx.x % c4n, rs = threadIdx.x / c4n;
+  const int tpr = c4n < 256 ? c4n : 256;          // threads across a row; wider rows are walked in column blocks
+  const int rpp = 256 / tpr;
+  const int cc = threadIdx.x % tpr, rs = threadIdx.x / tpr;
   const long r0 = static_cast<long>(seg) * seg_rows;
   const long rb = r0 + static_cast<long>(seg_rows) * chunk / chunks;
   const long re = min(static_cast<long>(M), r0 + static_cast<long>(seg_rows) * (chunk + 1) / chunks);
-  float4 s = make_float4(0, 0, 0, 0);
-  if (rs < rpp)
-    for (long m = rb + rs; m < re; m += rpp) {
-      const float4 v = ld4(dy + m * C + c4 * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
   for (int i = threadIdx.x; i < C; i += 256) shd[i] = 0.0;
   __syncthreads();
-  if (rs < rpp) {
-    atomicAdd(&shd[c4 * 4 + 0], static_cast<double>(s.x)); atomicAdd(&shd[c4 * 4 + 1], static_cast<double>(s.y));
-    atomicAdd(&shd[c4 * 4 + 2], static_cast<double>(s.z)); atomicAdd(&shd[c4 * 4 + 3], static_cast<double>(s.w));
-  }
+  if (rs < rpp)
+    for (int c4 = cc; c4 < c4n; c4 += tpr) {
+      float4 s = make_float4(0, 0, 0, 0);
+      for (long m = rb + rs; m < re; m += rpp) {
+        const float4 v = ld4(dy + m * C + c4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      atomicAdd(&shd[c4 * 4 + 0], static_cast<double>(s.x)); atomicAdd(&shd[c4 * 4 + 1], static_cast<double>(s.y));
+      atomicAdd(&shd[c4 * 4 + 2], static_cast<double>(s.z)); atomicAdd(&shd[c4 * 4 + 3], static_cast<double>(s.w));
+    }
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += 256) part[(static_cast<long>(seg) * chunks + chunk) * C + i] = shd[i];
 }

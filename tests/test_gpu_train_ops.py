@@ -38,6 +38,10 @@ CASES = [
     (3, 12, 20, 64, 96, 3, 1, 2, 2, False, 1),     # dilated + ReLU
     (2, 15, 23, 96, 96, 3, 2, 0, 1, True, 0),      # Downsample (asym pad, stride 2)
     (1, 30, 46, 96, 96, 3, 4, 0, 1, True, 0),      # Downsample4x4
+    # benchmark-size layers (one clip): mt_proj, stage-3 UpEmbed conv (9 frames, dilation 2), the first Downsample
+    (1, 112, 192, 768, 96, 3, 1, 1, 1, False, 0),
+    (9, 56, 96, 192, 96, 3, 1, 2, 2, False, 0),
+    (1, 224, 384, 96, 96, 3, 4, 0, 1, True, 0),
     (2, 10, 12, 128, 64, 1, 1, 0, 1, False, 0),    # 1x1
 ]
 
@@ -70,14 +74,17 @@ def test_conv_backward_matches_autograd(ag, case):
     assert rel(rvd.grad, rv.grad) < 2e-5
 
 
-def test_linear_backward_with_residual(ag):
+@pytest.mark.parametrize("rows,K,N", [(50, 96, 192), (23000, 96, 96), (23000, 192, 96), (252, 768, 1536)])
+def test_linear_backward_with_residual(ag, rows, K, N):
+    """Token GEMMs incl. the shapes that take the streaming kernel in the data gradient (M >= 65536, K, N in {96,192})
+    and the 1536-wide stage-0 MLP."""
     agops, ops = ag
-    x = rnd("lx", 3, 50, 96).requires_grad_(True)
-    w = rnd("lw", 192, 96, scale=0.1).requires_grad_(True)
-    b = rnd("lb", 192, scale=0.1).requires_grad_(True)
-    r = rnd("lr", 3, 50, 192).requires_grad_(True)
+    x = rnd("lx", 3, rows, K).requires_grad_(True)
+    w = rnd("lw", N, K, scale=0.1).requires_grad_(True)
+    b = rnd("lb", N, scale=0.1).requires_grad_(True)
+    r = rnd("lr", 3, rows, N).requires_grad_(True)
     y = F.linear(x, w, b) + r
-    gy = rnd("lgy", 3, 50, 192)
+    gy = rnd("lgy", 3, rows, N)
     y.backward(gy)
     xd, wd, bd, rd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b, r))
     yd = agops.linear(xd, wd, bd, residual=rd)
@@ -185,10 +192,10 @@ def test_depthwise_conv_backward(ag, C, H, W, k, stride, pad):
     assert rel(wd.grad, w.grad.reshape(C, k * k).t()) < 2e-5
 
 
-@pytest.mark.parametrize("C,Lq,Lk,heads", [(96, 200, 18, 2), (768, 84, 18, 2), (32, 64, 2, 2)])
+@pytest.mark.parametrize("C,Lq,Lk,heads", [(96, 200, 18, 2), (768, 84, 18, 2), (32, 64, 2, 2), (96, 5376, 18, 2)])
 def test_attention_backward(ag, C, Lq, Lk, heads):
     agops, _ = ag
-    n = 3
+    n = 3   # the last case is one stage-3 frame of the benchmark (Lq = 56*96)
     q, k, v = (rnd(nm, n, L, C).requires_grad_(True) for nm, L in (("abq", Lq), ("abk", Lk), ("abv", Lk)))
     d = C // heads
     qh, kh, vh = (t.reshape(n, -1, heads, d).transpose(1, 2) for t in (q, k, v))
@@ -309,6 +316,19 @@ def test_reduce_temp_backward_uses_disjoint_tap_path(ag):
     assert rel(xd.grad, x.grad[..., 0].permute(0, 2, 3, 1)) < 2e-5
     assert float(xd.grad[:, 5:].abs().max()) == 0.0
     assert rel(wd.grad, w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("M,C,seg", [(756, 1536, 756), (4096, 96, 4096), (3000, 2048, 750), (64, 4, 8)])
+def test_colsum_wide_and_segmented(ag, M, C, seg):
+    """Bias / per-image column sums, including rows wider than 1024 channels (stage-0 MLP hidden = 1536 at full size:
+    a 256-thread row mapping once silently dropped channels >= 1024; only the full-size gradient test caught it)."""
+    _, ops = ag
+    torch.manual_seed(C)
+    dy = torch.randn(M, C)
+    got = ops.colsum(dy.to(DEV), seg).cpu()
+    ref = dy.double().reshape(M // seg, seg, C).sum(1)
+    assert tuple(got.shape) == (M // seg, C)
+    assert (got.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
 
 
 # ---- loss / clip / optimizer kernels (csrc/optim.hip) ----

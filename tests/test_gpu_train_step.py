@@ -270,3 +270,50 @@ def test_end_to_end_training_through_video_saliency_model_with_a_torch_encoder()
     moved = [float((p.detach() - b).abs().max()) for p, b in zip(model.visual_net.parameters(), enc_before)]
     assert min(moved[:6]) > 0.0                                       # the three feature maps the graph reads train the encoder
     assert all(p.grad is None or p.grad.data_ptr() >= ts.flat.flat_g.data_ptr() for p in model.parameters())
+
+
+def test_full_size_training_gradients_match_oracle_autograd():
+    """BASELINE-size (224x384, 768/384/192/96 channels) audio-visual clip, B=1: every parameter gradient of the HIP path vs
+    autograd through the CPU oracle.  This is the only test that runs the training kernels in the configurations the
+    benchmark uses (streaming token GEMMs in the data gradient, all weight-gradient tile shapes and split plans, the
+    segmented GEMMs of the attention backward at Lq=5376, the disjoint-tap data gradients, 9.3 M-element reductions).
+    With ~20 M ReLU pre-activations a dozen sign flips are certain (module docstring; each perturbs everything upstream
+    by ~1e-3), so this is a gross-error detector: median error over parameters < 5e-3 of each tensor's max, worst < 5e-2.
+    (It caught a column-sum kernel that dropped channels >= 1024: error 0.91 on the 1536-wide MLP bias.)  Kernel-level
+    accuracy at these shapes is pinned separately, kink-free, in test_gpu_train_ops.py (full-size cases)."""
+    torch.manual_seed(0)
+    cfg = orc.SalUNetConfig()
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    x, feats, audio = orc.synth_inputs(cfg, 1, True, tag="fulltrain")
+    x0 = torch.sigmoid(orc.synth_tensor("fulltrain.x0", (1, 1, *cfg.img_size)))
+    t = torch.tensor([637])
+    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    orc.BN_TRAIN = True
+    try:
+        pred = orc.salunet_forward(leaf, cfg, x, t, feats, audio)
+    finally:
+        orc.BN_TRAIN = False
+    loss = ((pred - x0) ** 2).sum(dim=(1, 2, 3)).mean()
+    loss.backward()
+
+    net = build(cfg, sd)
+    net.train()
+    net.dropout_p = 0.0
+    out = net(x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], audio.to(DEV))
+    assert (out.detach().cpu() - pred.detach()).abs().max().item() < 1e-4
+    l2 = ((out - x0.to(DEV)) ** 2).sum(dim=(1, 2, 3)).mean()
+    l2.backward()
+    assert abs(l2.item() - loss.item()) < 1e-4 * abs(loss.item())
+    scale = torch.stack([g.grad.abs().max() for g in leaf.values() if g.grad is not None]).median().item()
+    errs = []
+    for name, p in net.named_parameters():
+        ref = leaf[name].grad
+        if ref is None or ref.abs().max().item() < 1e-4 * scale:
+            continue
+        errs.append(((p.grad.cpu() - ref).abs().max().item() / ref.abs().max().item(), name))
+    errs.sort()
+    med, p90, worst = errs[len(errs) // 2][0], errs[int(0.9 * len(errs))][0], errs[-1]
+    print("full-size gradient errors relative to each tensor's max: median %.2e, p90 %.2e, worst %s (%d tensors)"
+          % (med, p90, worst, len(errs)))
+    assert len(errs) > 150
+    assert med < 5e-3 and p90 < 1e-2 and worst[0] < 5e-2, (med, p90, worst)
