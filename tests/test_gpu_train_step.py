@@ -277,8 +277,8 @@ def test_full_size_training_gradients_match_oracle_autograd():
     autograd through the CPU oracle.  This is the only test that runs the training kernels in the configurations the
     benchmark uses (streaming token GEMMs in the data gradient, all weight-gradient tile shapes and split plans, the
     segmented GEMMs of the attention backward at Lq=5376, the disjoint-tap data gradients, 9.3 M-element reductions).
-    With ~20 M ReLU pre-activations a dozen sign flips are certain (module docstring; each perturbs everything upstream
-    by ~1e-3), so this is a gross-error detector: median error over parameters < 5e-3 of each tensor's max, worst < 5e-2.
+    With 23.8 M ReLU pre-activations sign flips are certain (measured on this very input with tools/relu_flip_census.py
+    against an fp64 run: 13 flips, 251 pre-activations within 1e-5 of zero; each flip perturbs everything upstream by ~1e-3), so this is a gross-error detector: median error over parameters < 5e-3 of each tensor's max, worst < 5e-2.
     (It caught a column-sum kernel that dropped channels >= 1024: error 0.91 on the 1536-wide MLP bias.)  Kernel-level
     accuracy at these shapes is pinned separately, kink-free, in test_gpu_train_ops.py (full-size cases)."""
     torch.manual_seed(0)

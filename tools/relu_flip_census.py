@@ -6,12 +6,13 @@ from oracle import salunet_oracle as orc
 from tests._cases import CASES
 from tests.test_gpu_salunet import build
 from diff_sal_amd import autograd_ops as ag
-cfg = CASES["tiny_av"][0]
+cfg = orc.SalUNetConfig() if "full" in sys.argv else CASES["tiny_av"][0]
+B = 1 if "full" in sys.argv else 2
 sd = orc.synth_state_dict(orc.state_dict_template(cfg))
 tag, t0 = sys.argv[1], int(sys.argv[2])
 av = "av" in sys.argv
-x, feats, audio = orc.synth_inputs(cfg, 2, av, tag=tag)
-t = torch.tensor([t0, t0])
+x, feats, audio = orc.synth_inputs(cfg, B, av, tag=tag)
+t = torch.tensor([t0] * B)
 if "qs" in sys.argv:
     from diff_sal_amd.diffusion_utils import get_beta_schedule, to_torch
     a_hat = (1.0 - to_torch(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000))).cumprod(dim=0)
