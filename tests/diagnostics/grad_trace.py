@@ -2,7 +2,7 @@
 usage: grad_trace.py TAG T0 [av]"""
 import sys, os, torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import salunet_oracle as orc
 from tests._cases import CASES
 from tests.test_gpu_salunet import build

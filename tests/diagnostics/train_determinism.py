@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import salunet_oracle as orc
 from tests._cases import CASES
 from tests.test_gpu_salunet import build

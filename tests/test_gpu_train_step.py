@@ -5,8 +5,8 @@ Tolerances.  Every backward kernel is pinned to ~1e-6 against autograd of the sa
 whole-network gradient cannot be compared that tightly: the decoder has 11 ReLUs over ~1.5 M pre-activations, a few
 of which land within 1e-6 of zero on any input, and two correct fp32 evaluations (different summation order) put such
 an element on different sides of the kink.  One flipped element changes the local gradient by O(1e-2) of its layer's
-maximum and everything upstream by ~1e-3 (measured: tools/relu_flip_census.py counts the flips against an fp64 run,
-tools/grad_trace.py shows the error entering exactly at the flipped layer; with no flip the HIP gradients are
+maximum and everything upstream by ~1e-3 (measured: tests/diagnostics/relu_flip_census.py counts the flips against an fp64 run,
+tests/diagnostics/grad_trace.py shows the error entering exactly at the flipped layer; with no flip the HIP gradients are
 within 2e-6 of fp64).  Hence 5e-3 here."""
 import pytest
 import torch
@@ -277,7 +277,7 @@ def test_full_size_training_gradients_match_oracle_autograd():
     autograd through the CPU oracle.  This is the only test that runs the training kernels in the configurations the
     benchmark uses (streaming token GEMMs in the data gradient, all weight-gradient tile shapes and split plans, the
     segmented GEMMs of the attention backward at Lq=5376, the disjoint-tap data gradients, 9.3 M-element reductions).
-    With 23.8 M ReLU pre-activations sign flips are certain (measured on this very input with tools/relu_flip_census.py
+    With 23.8 M ReLU pre-activations sign flips are certain (measured on this very input with tests/diagnostics/relu_flip_census.py
     against an fp64 run: 13 flips, 251 pre-activations within 1e-5 of zero; each flip perturbs everything upstream by ~1e-3), so this is a gross-error detector: median error over parameters < 5e-3 of each tensor's max, worst < 5e-2.
     (It caught a column-sum kernel that dropped channels >= 1024: error 0.91 on the 1536-wide MLP bias.)  Kernel-level
     accuracy at these shapes is pinned separately, kink-free, in test_gpu_train_ops.py (full-size cases)."""

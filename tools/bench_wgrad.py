@@ -5,12 +5,11 @@ import os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from diff_sal_amd import ops
-from oracle import salunet_oracle as orc
 
 av = (sys.argv[1] if len(sys.argv) > 1 else "av") == "av"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device("cuda", 0)
-cfg = orc.SalUNetConfig()
+cfg = bench.Config()
 net, sd = bench.build_net(cfg, dev)
 H, W = cfg.img_size
 g = torch.Generator().manual_seed(0)
