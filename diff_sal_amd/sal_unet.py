@@ -448,6 +448,9 @@ class SalUNet(nn.Module):
             raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
         x = x.contiguous().float()
         B, _, H, W = x.shape
+        if B == 0:
+            raise RuntimeError("SalUNet.forward_train: empty batch (BatchNorm batch statistics are undefined); "
+                               "nn.BatchNorm2d raises for it too")
         ns, dec = self.num_stages, self.invpt_decoder
         if dropout_seed is None:
             SalUNet._dropout_calls += 1

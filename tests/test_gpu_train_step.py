@@ -317,3 +317,34 @@ def test_full_size_training_gradients_match_oracle_autograd():
           % (med, p90, worst, len(errs)))
     assert len(errs) > 150
     assert med < 5e-3 and p90 < 1e-2 and worst[0] < 5e-2, (med, p90, worst)
+
+
+@pytest.mark.parametrize("B,av", [(1, True), (3, False)])
+def test_train_step_odd_batches_and_dropout_determinism(B, av):
+    """Ragged cases of the training forward: batch 1 and 3 (BatchNorm statistics over 9 / 27 frames), active dropout with an
+    explicit seed is reproducible and differs from another seed; an empty batch raises like nn.BatchNorm2d does."""
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    x, feats, audio = orc.synth_inputs(cfg, B, av, tag=f"odd{B}")
+    t = torch.full((B,), 77)
+    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    orc.BN_TRAIN = True
+    try:
+        pred = orc.salunet_forward(leaf, cfg, x, t, feats, audio)
+    finally:
+        orc.BN_TRAIN = False
+    net = build(cfg, sd)
+    net.train()
+    args = (x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None if audio is None else audio.to(DEV))
+    net.dropout_p = 0.0
+    out = net(*args)
+    assert (out.detach().cpu() - pred.detach()).abs().max().item() < 1e-4
+    net.dropout_p = 0.1
+    a = net.forward_train(*args, dropout_seed=1234)
+    b = net.forward_train(*args, dropout_seed=1234)
+    c = net.forward_train(*args, dropout_seed=99)
+    assert torch.equal(a, b)
+    if av:   # visual-only output does not see the ResnetBlock path in a way dropout could change much; AV must differ
+        assert (a - c).abs().max().item() > 0
+    with pytest.raises(RuntimeError):
+        net.forward_train(args[0][:0], args[1][:0], [f[:0] for f in args[2]], None if args[3] is None else args[3][:0])
