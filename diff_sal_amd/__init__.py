@@ -2,9 +2,9 @@
 from .sal_unet import SalUNet  # noqa: F401
 from .diff_model import VideoSaliencyModel  # noqa: F401
 from .dpm_solver import DPM_Solver, NoiseScheduleVP, model_wrapper  # noqa: F401
-from .sampling import DiffusionSampler, generalized_steps  # noqa: F401
+from .sampling import DiffusionSampler, ddpm_steps, generalized_steps  # noqa: F401
 from .diffusion_utils import get_beta_schedule, to_torch  # noqa: F401
 from .train_step import DiffusionTrainStep, FlatParams, GradReducer  # noqa: F401
 
 __all__ = ["SalUNet", "VideoSaliencyModel", "DPM_Solver", "NoiseScheduleVP", "model_wrapper", "DiffusionSampler",
-           "generalized_steps", "get_beta_schedule", "to_torch", "DiffusionTrainStep", "FlatParams", "GradReducer"]
+           "generalized_steps", "ddpm_steps", "get_beta_schedule", "to_torch", "DiffusionTrainStep", "FlatParams", "GradReducer"]

@@ -49,6 +49,13 @@ class DiffusionSampler:
         self.sqrt_one_minus_alphas_hat = torch.sqrt(1.0 - alphas_hat)
         self.sqrt_recip_alphas_hat = torch.sqrt(1.0 / alphas_hat)
         self.sqrt_recipm1_alphas_hat = torch.sqrt(1.0 / alphas_hat - 1)
+        self.log_one_minus_alphas_hat = torch.log(1.0 - alphas_hat)
+        # DDPM posterior tables exactly as the trainer builds them (R/diffusion_trainer.py:66-75), including its
+        # coefficient quirk: coef1 uses sqrt(alphas_hat[t]) where the DDPM paper has sqrt(alphas_hat[t-1])
+        self.posterior_variance = betas * (1.0 - self.alphas_hat_prev) / (1.0 - alphas_hat)
+        self.posterior_log_variance_clipped = torch.log(torch.maximum(self.posterior_variance, torch.tensor(1e-20)))
+        self.posterior_mean_coef1 = betas * torch.sqrt(alphas_hat) / (1.0 - alphas_hat)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_hat_prev) * torch.sqrt(1.0 - betas) / (1.0 - alphas_hat)
         self.num_timesteps = betas.shape[0]
         self.device = device
         # Optional modes, both OFF by default and reported separately from the headline metric:
@@ -70,6 +77,44 @@ class DiffusionSampler:
     def predict_noise_from_start(self, x_t: Tensor, t: int, x0: Tensor) -> Tensor:
         r, rm1 = float(self.sqrt_recip_alphas_hat[t]), float(self.sqrt_recipm1_alphas_hat[t])
         return _lincomb(x_t, r / rm1, x0, -1.0 / rm1)
+
+    # ---- DDPM ancestral sampling (R/diffusion_trainer.py:482-527; the caller at :574-580 is broken upstream) ----
+    def predict_start_from_noise(self, x_t: Tensor, t: int, noise: Tensor) -> Tensor:
+        return _lincomb(x_t, float(self.sqrt_recip_alphas_hat[t]), noise, -float(self.sqrt_recipm1_alphas_hat[t]))
+
+    def q_posterior(self, x_start: Tensor, x_t: Tensor, t: int):
+        mean = _lincomb(x_start, float(self.posterior_mean_coef1[t]), x_t, float(self.posterior_mean_coef2[t]))
+        return mean, self.posterior_variance[t], self.posterior_log_variance_clipped[t]
+
+    @torch.no_grad()
+    def p_mean_variance(self, x: Tensor, t: int, img, clip_denoised: bool = True, audio_cond: Optional[Tensor] = None):
+        """``clip_denoised`` is accepted and, as in the reference (:505-506: ``x_recon.clamp(-1, 1)`` without assignment),
+        has no effect."""
+        net = self.model.decoder_net
+        t_tensor = torch.full((x.shape[0],), t, dtype=torch.int64, device=x.device)
+        out = net(x, t_tensor, img, audio_cond) if audio_cond is not None else net(x, t_tensor, img)
+        x_recon = out if self.training_target == "x0" else self.predict_start_from_noise(x, t, out)
+        return self.q_posterior(x_recon, x, t)
+
+    @torch.no_grad()
+    def p_sample(self, x: Tensor, t: int, img, clip_denoised: bool = True, audio_cond: Optional[Tensor] = None,
+                 noise: Optional[Tensor] = None) -> Tensor:
+        mean, _, log_var = self.p_mean_variance(x, t, img, clip_denoised=clip_denoised, audio_cond=audio_cond)
+        if t == 0:
+            return mean                                   # no noise at the last step (:517-519)
+        if noise is None:
+            noise = torch.randn_like(x)
+        return _lincomb(mean, 1.0, noise, float(torch.exp(0.5 * log_var)))
+
+    @torch.no_grad()
+    def sample_ddpm(self, x: Tensor, img=None, audio_cond: Optional[Tensor] = None, noises=None) -> Tensor:
+        """``timesteps`` ancestral steps on the grid ``range(0, T, T // timesteps)`` reversed (:574-578).  The conditioning
+        list is never mutated here, so the reference's per-step ``copy.deepcopy`` is not needed."""
+        skip = self.num_timesteps // self.timesteps
+        seq = list(range(0, self.num_timesteps, skip))
+        for i, t in enumerate(reversed(seq)):
+            x = self.p_sample(x, t, img, audio_cond=audio_cond, noise=None if noises is None else noises[i])
+        return x
 
     # ---- DDIM (the reference's live sampler) ----
     def _shortcut(self, x, img, audio_cond):
@@ -178,6 +223,8 @@ class DiffusionSampler:
             return self.sample_ddim(x, vis_list, audio_embed)
         if self.sample_type in ("dpmsolver", "dpmsolver++"):
             return self.sample_dpm_solver(x, vis_list, audio_embed)
+        if self.sample_type == "ddpm":
+            return self.sample_ddpm(x, vis_list, audio_embed)
         raise NotImplementedError(self.sample_type)
 
 
@@ -208,4 +255,28 @@ def generalized_steps(x, seq, model, b, img=None, **kwargs):
             c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
             c2 = ((1 - at_next) - c1 ** 2).sqrt()
             xs.append((at_next.sqrt() * x0_t + c1 * torch.randn_like(x) + c2 * et).to("cpu"))
+    return xs, x0_preds
+
+
+def ddpm_steps(x, seq, model, b, **kwargs):
+    """Legacy ancestral loop with the reference signature (R/util/denoising.py:35-69): ``model(x, t)`` predicts noise;
+    returns (xs, x0_preds).  Runs on whatever device ``x`` is on (the reference hard-codes 'cuda')."""
+    with torch.no_grad():
+        n = x.size(0)
+        seq = list(seq)
+        seq_next = [-1] + seq[:-1]
+        xs, x0_preds = [x], []
+        for i, j in zip(reversed(seq), reversed(seq_next)):
+            t = (torch.ones(n) * i).to(x.device)
+            next_t = (torch.ones(n) * j).to(x.device)
+            at = compute_alpha(b, t.long())
+            atm1 = compute_alpha(b, next_t.long())
+            beta_t = 1 - at / atm1
+            xt = xs[-1].to(x.device)
+            e = model(xt, t.float())
+            x0_from_e = torch.clamp((1.0 / at).sqrt() * xt - (1.0 / at - 1).sqrt() * e, -1, 1)
+            x0_preds.append(x0_from_e.to("cpu"))
+            mean = ((atm1.sqrt() * beta_t) * x0_from_e + ((1 - beta_t).sqrt() * (1 - atm1)) * xt) / (1.0 - at)
+            mask = (1 - (t == 0).float()).view(-1, 1, 1, 1)
+            xs.append((mean + mask * torch.exp(0.5 * beta_t.log()) * torch.randn_like(xt)).to("cpu"))
     return xs, x0_preds

@@ -252,6 +252,28 @@ def gen_trainer_ddim():
         sqrt_recip=tr.sqrt_recip_alphas_hat.numpy(), sqrt_recipm1=tr.sqrt_recipm1_alphas_hat.numpy())
     print("ddim: out range", out.min().item(), out.max().item())
 
+    # DDPM ancestral sampling through the reference trainer's own p_sample / p_mean_variance / q_posterior
+    # (R/diffusion_trainer.py:482-527).  The `ddpm` branch of sample_image is broken as shipped (it needs a
+    # spatiotemp_net nobody builds), its loop body is not: 10 steps with the loop of :574-580, conditioning = the visual
+    # features (that loop has no audio), the Gaussian draws replaced by closed-form tensors so they can be replayed.
+    x, feats, _ = orc.synth_inputs(cfg, 1, True, tag="ddpm")
+    seq = list(range(0, tr.num_timesteps, tr.num_timesteps // 10))
+    draws = [orc.synth_tensor(f"ddpm.z{i}", tuple(x.shape)) for i in range(len(seq))]
+    it = iter(draws)
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda v, *a, **k: next(it)
+    try:
+        xd = x
+        for t_ in reversed(seq):
+            xd = tr.p_sample(xd, t_, [f.clone() for f in feats])
+    finally:
+        torch.randn_like = real_randn_like
+    np.savez_compressed(
+        os.path.join(GOLD, "ddpm_tiny_av.npz"), output=xd.numpy(), posterior_variance=tr.posterior_variance.numpy(),
+        posterior_log_variance_clipped=tr.posterior_log_variance_clipped.numpy(),
+        posterior_mean_coef1=tr.posterior_mean_coef1.numpy(), posterior_mean_coef2=tr.posterior_mean_coef2.numpy())
+    print("ddpm: out range", xd.min().item(), xd.max().item())
+
     # the same net through the reference DPM-Solver (multistep-2, 50 NFE, x_start) with a
     # non-mutating model_fn (the trainer's own DPM branch is broken as shipped: D1-D4)
     from models.dpm_solver.sampler import DPM_Solver, NoiseScheduleVP, model_wrapper

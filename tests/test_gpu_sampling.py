@@ -88,3 +88,19 @@ def test_hip_graph_mode_and_f1_shortcut_agree_with_the_plain_loop():
     assert (short.sample_dpm_solver(xd, fd, None) - plain).abs().max().item() < 1e-5
     ddim = DiffusionSampler(top, timesteps=8, sample_type="ddim")
     assert (short.sample_ddim(xd, fd, None) - ddim.sample_ddim(xd, fd, None)).abs().max().item() < 1e-6
+
+
+def test_sample_ddpm_10_steps_matches_reference_trainer(golden_dir):
+    """DDPM ancestral sampling: the reference trainer's own p_sample loop (R/diffusion_trainer.py:482-527, 574-580), 10 steps,
+    visual conditioning, Gaussian draws replayed from closed-form tensors."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    x, feats, _ = orc.synth_inputs(cfg, 1, True, tag="ddpm")
+    g = np.load(f"{golden_dir}/ddpm_tiny_av.npz")
+    zs = [orc.synth_tensor(f"ddpm.z{i}", tuple(x.shape)).to(DEV) for i in range(10)]
+    s = DiffusionSampler(Top(build(cfg, sd)), timesteps=10, sample_type="ddpm")
+    out = s.sample_ddpm(x.to(DEV), [f.to(DEV) for f in feats], None, noises=zs)
+    ref = torch.from_numpy(g["output"])
+    assert (out.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()

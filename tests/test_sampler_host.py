@@ -135,3 +135,36 @@ def test_ddim_loop_host_logic_with_toy_net():
         eps = (torch.sqrt(1 / ah[time]) * ref - x0) / torch.sqrt(1 / ah[time] - 1)
         ref = torch.sqrt(ah[nxt]) * x0 + torch.sqrt(1 - ah[nxt]) * eps
     assert torch.allclose(out, ref, atol=1e-5)
+
+
+def test_ddpm_posterior_tables_match_trainer(golden_dir):
+    """posterior_* tables of R/diffusion_trainer.py:66-75 (including its sqrt(alphas_hat[t]) quirk in coef1)."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    g = np.load(f"{golden_dir}/ddpm_tiny_av.npz")
+    s = DiffusionSampler(model=type("M", (), {"decoder_net": None})())
+    for k in ("posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+        assert np.allclose(getattr(s, k).numpy(), g[k], rtol=1e-6, atol=1e-30), k
+
+
+def test_ddpm_loop_and_legacy_ddpm_steps_host_logic():
+    """sample_ddpm / p_sample on CPU tensors with a closed-form x0-predictor vs the recursion written out; the legacy
+    ddpm_steps signature (noise-predicting model(x, t)) runs and returns the two lists of the reference."""
+    from diff_sal_amd.sampling import DiffusionSampler, ddpm_steps
+
+    net = lambda x, t, img, a=None: torch.sigmoid(0.5 * x + 0.001 * t.float().view(-1, 1, 1, 1))  # noqa: E731
+    s = DiffusionSampler(model=type("M", (), {"decoder_net": staticmethod(net)})(), timesteps=10, sample_type="ddpm")
+    x = orc.synth_tensor("ddpm.toy", (2, 1, 4, 6))
+    seq = list(range(0, 1000, 100))
+    zs = [orc.synth_tensor(f"ddpm.toy.z{i}", (2, 1, 4, 6)) for i in range(len(seq))]
+    out = s.sample_ddpm(x.clone(), None, None, noises=zs)
+    ref = x.clone()
+    for i, t in enumerate(reversed(seq)):
+        x0 = net(ref, torch.full((2,), t), None)
+        mean = s.posterior_mean_coef1[t] * x0 + s.posterior_mean_coef2[t] * ref
+        ref = mean if t == 0 else mean + zs[i] * torch.exp(0.5 * s.posterior_log_variance_clipped[t])
+    assert torch.allclose(out, ref, atol=1e-6)
+    assert s.sample_image(x.clone()).shape == x.shape          # dispatcher routes sample_type="ddpm"
+    xs, x0s = ddpm_steps(x, seq, lambda xt, t: 0.1 * xt, s.betas)
+    assert len(xs) == len(seq) + 1 and len(x0s) == len(seq) and xs[-1].shape == x.shape
+    assert float(x0s[0].abs().max()) <= 1.0                      # the reference clamps x0 to [-1, 1]
