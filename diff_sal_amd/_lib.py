@@ -35,7 +35,8 @@ SIGNATURES = {
     "diffsal_conv_igemm_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
-    "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
+    "diffsal_conv_wgrad_splits": (c_i, [C.POINTER(ConvDesc)]),
+    "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_colsum": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "diffsal_act_bwd": (c_i, [c_f, c_f, c_f, c_sz, c_i, c_f]),
     "diffsal_rowstats_chunks": (c_i, [c_i, c_i]),

@@ -54,8 +54,14 @@ class ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         g = ops.relu_bwd(dy, y) if act == ACT_RELU else dy
         N, Ho, Wo, Cout = g.shape
-        dw = ops.conv_wgrad(x, g, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(g).reshape(Cout) if (has_b and ctx.needs_input_grad[2]) else None
+        want_b = has_b and ctx.needs_input_grad[2]
+        dw = db = None
+        if ctx.needs_input_grad[1] and want_b:      # the bias gradient rides along in the weight-gradient kernel
+            dw, db = ops.conv_wgrad(x, g, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, want_bias=True)
+        elif ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, g, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil)
+        elif want_b:
+            db = ops.colsum(g).reshape(Cout)
         drv = ops.colsum(g, Ho * Wo) if (has_rv and ctx.needs_input_grad[3]) else None
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         dx = None

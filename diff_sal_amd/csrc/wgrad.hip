@@ -21,6 +21,7 @@ struct WgradArgs {
   const float* in;   // layer input, NHWC
   const float* dy;   // [M][Cout]
   float* slabs;      // [segments * splits][Cout][K]
+  double* dbias;     // optional [segments * splits][Cout]: column sums of dY over the split's rows (bias gradient partials)
   int M, K, Cout;
   int H, W, Cin, Ho, Wo;
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
@@ -110,6 +111,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
   };
 
+  // bias gradient rides along: the first K-tile's workgroups add up the dY tile they stage anyway (fp64 per thread)
+  const bool do_bias = p.dbias != nullptr && blockIdx.y == 0 && tid < BCO;
+  double bias_acc = 0.0;
   if (m_begin < m_end) prefetch(m_begin);
   for (int mb = m_begin; mb < m_end; mb += m_stride) {
 #pragma unroll
@@ -126,6 +130,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
     __syncthreads();
     if (mb + m_stride < m_end) prefetch(mb + m_stride);
+    if (do_bias) {
+      float s4 = 0.f;
+#pragma unroll
+      for (int r = 0; r < BM; ++r) s4 += dYs[r * PA + tid];
+      bias_acc += static_cast<double>(s4);
+    }
 #pragma unroll
     for (int ks = 0; ks < BM / 2; ++ks) {
       const int mrow = ks * 2 + (lane >> 5);
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
     __syncthreads();
   }
+  if (do_bias && co0 + tid < p.Cout) p.dbias[static_cast<long>(blockIdx.z) * p.Cout + co0 + tid] = bias_acc;
   // C/D map: col = lane & 31 (k within slice), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co within tile)
   float* slab = p.slabs + static_cast<long>(blockIdx.z) * p.Cout * p.K;
 #pragma unroll
@@ -324,8 +335,15 @@ extern "C" size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d) {
   return static_cast<size_t>(pl.splits) * d->Cout * K * sizeof(float);
 }
 
+extern "C" int diffsal_conv_wgrad_splits(const diffsal_conv_desc* d) {
+  if (!d || d->Cin <= 0 || d->Cin % 32) return 0;
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  const long K = static_cast<long>(d->KH) * d->KW * d->Cin;
+  return wgrad_plan(d->Cout, K, M, 1).splits;
+}
+
 extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, const float* dy, float* dw_packed,
-                                  void* ws, size_t ws_bytes, diffsal_stream_t stream) {
+                                  double* dbias_part, void* ws, size_t ws_bytes, diffsal_stream_t stream) {
   DS_REQUIRE(d && in && dy && dw_packed && ws, DIFFSAL_E_ARG, "conv_wgrad: null argument");
   DS_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0 && d->Cout % 4 == 0, DIFFSAL_E_SHAPE,
              "conv_wgrad: Cin=%d must be a multiple of 32 and Cout=%d of 4", d->Cin, d->Cout);
@@ -338,7 +356,7 @@ extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, c
   DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(in) && aligned16(dw_packed), DIFFSAL_E_ARG,
              "conv_wgrad: needs %zu bytes of 16-byte aligned workspace", need);
   WgradArgs a;
-  a.in = in; a.dy = dy; a.slabs = static_cast<float*>(ws);
+  a.in = in; a.dy = dy; a.slabs = static_cast<float*>(ws); a.dbias = dbias_part;
   a.M = static_cast<int>(M); a.K = static_cast<int>(K); a.Cout = d->Cout;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
@@ -366,7 +384,7 @@ extern "C" int diffsal_wgrad_segmented(const float* x, const float* dy, float* o
   DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(x) && aligned16(out), DIFFSAL_E_ARG,
              "wgrad_segmented: needs %zu bytes of 16-byte aligned workspace", need);
   WgradArgs a;
-  a.in = x; a.dy = dy; a.slabs = static_cast<float*>(ws);
+  a.in = x; a.dy = dy; a.slabs = static_cast<float*>(ws); a.dbias = nullptr;
   a.M = static_cast<int>(M); a.K = K; a.Cout = Cout;
   a.H = 1; a.W = static_cast<int>(M); a.Cin = K; a.Ho = 1; a.Wo = static_cast<int>(M);
   a.KW = 1; a.taps = 1; a.stride_h = 1; a.stride_w = 1; a.pad_t = 0; a.pad_l = 0; a.dil_h = 1; a.dil_w = 1;

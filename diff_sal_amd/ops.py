@@ -316,8 +316,10 @@ def axpbypcz(x: Tensor, a: float, y: Optional[Tensor] = None, b: float = 0.0, z:
 # ------------------------------------------------------------------------------------------------
 # training-side kernels
 # ------------------------------------------------------------------------------------------------
-def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1)) -> Tensor:
-    """dW in the packed layout [Cout, kh*kw*Cin] for the conv  y = conv_igemm(x, w_packed, ...).  x NHWC, dy NHWC."""
+def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
+               want_bias: bool = False):
+    """dW in the packed layout [Cout, kh*kw*Cin] for the conv  y = conv_igemm(x, w_packed, ...).  x NHWC, dy NHWC.
+    want_bias: also return db [Cout] (column sums of dy, accumulated by the same kernel) -> (dW, db)."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     _, Ho, Wo, Cout = dy.shape
@@ -325,13 +327,20 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     nws = lib.diffsal_conv_wgrad_ws_bytes(C.byref(d))
     ws = torch.empty((nws // 4,), device=x.device, dtype=torch.float32)
     dw = torch.empty((Cout, kh * kw * Cin), device=x.device, dtype=torch.float32)
+    bpart = None
+    if want_bias:
+        splits = lib.diffsal_conv_wgrad_splits(C.byref(d))
+        bpart = torch.empty((splits, Cout), device=x.device, dtype=torch.float64)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), nws, _stream()), "conv_wgrad")
+    _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), bpart.data_ptr() if want_bias else None, _p(ws),
+                                      nws, _stream()), "conv_wgrad")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin))
+    if want_bias:
+        return dw, reduce_partials(bpart, 1, bpart.shape[0], Cout).view(Cout)
     return dw
 
 

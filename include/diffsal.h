@@ -104,10 +104,14 @@ int diffsal_pack_weight(const float* src, float* dst, int Cout, int Cin, int tap
 
 /* ---- K16 (training): weight gradient of the layer above, in the SAME packed layout as `w`:
  * dw[co, k] = sum_m dy[m, co] * A[m, k].  Replaces the wgrad of autograd's conv / linear backward.
- * ws: >= diffsal_conv_wgrad_ws_bytes(d) bytes (partial slabs, summed in a fixed order).  Cout % 4 == 0. */
+ * ws: >= diffsal_conv_wgrad_ws_bytes(d) bytes (partial slabs, summed in a fixed order).  Cout % 4 == 0.
+ * dbias_part (optional, may be NULL): [diffsal_conv_wgrad_splits(d)][Cout] doubles receiving the column sums of dy per
+ * M split -- the bias gradient rides along on the dY tiles the kernel stages anyway; finish with
+ * diffsal_reduce_partials(dbias_part, db, 1, splits, Cout, 0). */
 size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d /*host*/);
+int diffsal_conv_wgrad_splits(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wgrad(const diffsal_conv_desc* d /*host*/, const float* in, const float* dy, float* dw_packed,
-                       void* ws, size_t ws_bytes, diffsal_stream_t stream);
+                       double* dbias_part, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 /* Batched form for token GEMMs: out[s][co][k] = sum over the seg_rows rows m of segment s of dy[m, co] * x[m, k]
  * (x: [segments*seg_rows, K], dy: [segments*seg_rows, Cout]).  Used by the attention backward (one segment per
  * image: dK = dS^T Q, dV = P^T dO; R/.../attention.py:97-108).  K % 32 == 0, Cout % 4 == 0. */
