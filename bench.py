@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--sampler-mode", choices=["eager", "graph", "f1"], default="eager",
                     help="eager = headline; graph = whole trajectories replayed from a HIP graph; f1 = step-invariant "
                          "shortcut of visual-only mode (1 evaluation per trajectory) -- both reported separately")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32 = headline (exact fp32 MFMA); bf16x3 = split-precision bf16 MFMA in the implicit-GEMM kernel "
+                         "(opt-in mode, ~4e-6 relative error, reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32,
@@ -197,6 +200,7 @@ def main():
     from diff_sal_amd import ops
     from diff_sal_amd.sampling import DiffusionSampler
 
+    ops.set_gemm_precision(args.precision)
     cfg = Config()
     B, av = args.batch, args.mode == "av"
     net, sd = build_net(cfg, dev)
@@ -306,7 +310,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "fp32" else "f32 in/out, bf16x3 split-precision MFMA (NOT the headline configuration)",
         "data": "synthetic",
         "config": {
             "workload": ("BASELINE configs[1]: DHF1k visual-only" if not av else "BASELINE configs[2]: AVAD audio-visual")

@@ -70,6 +70,8 @@ SIGNATURES = {
     "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
+    "diffsal_set_gemm_precision": (c_i, [c_i]),
+    "diffsal_get_gemm_precision": (c_i, []),
     "diffsal_reduce_partials": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_norm_finalize_fwd": (c_i, [c_f] * 7 + [c_i, c_i, c_i, C.c_double, C.c_double] + [c_f] * 4 + [c_fl, c_fl, c_f]),
     "diffsal_norm_finalize_bwd": (c_i, [c_f] * 8 + [c_i, c_i, c_i, C.c_double, c_f]),

@@ -47,10 +47,18 @@ struct IgemmArgs {
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
 };
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int BK = 32;
 constexpr int PITCH = BK + 4;  // dwords; 36*r mod 64 hits 16 distinct 4-bank slots for 16 rows
 
-template <int WM, int WN, int TM, int TN>
+// PREC 0: exact fp32 on v_mfma_f32_32x32x2_f32 (the default, what the parity numbers are quoted on).
+// PREC 1: "bf16x3" -- every fp32 operand is split once, on its way into LDS, into hi = bf16(x) and lo = bf16(x - hi); the
+//   product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, fp32 accumulation).  Dropped
+//   term lo*lo ~ 2^-16 relative per product; measured ~4e-6 of the output maximum on a K = 1728 convolution GEMM
+//   (tools/spikes/bf16x3_gemm.hip).  Opt-in (diffsal_set_gemm_precision), reported separately from the headline.
+template <int WM, int WN, int TM, int TN, int PREC>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -151,11 +159,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     for (int j = 0; j < B_PASSES; ++j)
       rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
   };
+  // PREC 1 row layout (same 36-dword pitch): dwords 0..15 = the 32 hi halves (k order), 16..31 = the 32 lo halves
+  auto split_store = [&](float* rowp, const float4& v) {
+    const __bf16 h0 = static_cast<__bf16>(v.x), h1 = static_cast<__bf16>(v.y), h2 = static_cast<__bf16>(v.z),
+                 h3 = static_cast<__bf16>(v.w);
+    bf16x4 hi = {h0, h1, h2, h3};
+    bf16x4 lo = {static_cast<__bf16>(v.x - static_cast<float>(h0)), static_cast<__bf16>(v.y - static_cast<float>(h1)),
+                 static_cast<__bf16>(v.z - static_cast<float>(h2)), static_cast<__bf16>(v.w - static_cast<float>(h3))};
+    *reinterpret_cast<uint2*>(rowp + (lcol >> 1)) = __builtin_bit_cast(uint2, hi);
+    *reinterpret_cast<uint2*>(rowp + 16 + (lcol >> 1)) = __builtin_bit_cast(uint2, lo);
+  };
   auto store_tile = [&](float* stage) {
+    if constexpr (PREC == 0) {
 #pragma unroll
-    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH + lcol], ra[j]);
+      for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH + lcol], ra[j]);
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
+      for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_PASSES; ++j) split_store(&stage[(lrow + 32 * j) * PITCH], ra[j]);
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) split_store(&stage[(BM + lrow + 32 * j) * PITCH], rb[j]);
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -210,48 +235,94 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) rb[j] = tb[j];
   __syncthreads();
-  load_frags(smem, 0, 0);
-  for (int it = 0; it < nkt; ++it) {
-    float* cur = smem + (it & 1) * STAGE;
-    float* nxt = smem + ((it & 1) ^ 1) * STAGE;
-    // group 0: MFMAs on set 0; meanwhile fetch group 1, park slice it+1 in the other stage
-    load_frags(cur, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    do_mfmas(0);
-    store_tile(nxt);
-    // the registers are free again: slice it+2 starts its trip now and has a whole K slice of MFMAs to land
-    issue_loads(kt_begin + it + 2, it + 2 < nkt);
-    {  // spread the LDS writes over the first half of this group's MFMAs and the buffer loads over the second
-      constexpr int NM = 4 * TM * TN, NW = A_PASSES + B_PASSES, H1 = NM / 2, PER = (NW + H1 - 1) / H1;
-#pragma unroll
-      for (int i = 0; i < H1; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x200, PER, 0);  // then LDS writes
+  if constexpr (PREC == 0) {
+    load_frags(smem, 0, 0);
+    for (int it = 0; it < nkt; ++it) {
+      float* cur = smem + (it & 1) * STAGE;
+      float* nxt = smem + ((it & 1) ^ 1) * STAGE;
+      // group 0: MFMAs on set 0; meanwhile fetch group 1, park slice it+1 in the other stage
+      load_frags(cur, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfmas(0);
+      store_tile(nxt);
+      // the registers are free again: slice it+2 starts its trip now and has a whole K slice of MFMAs to land
+      issue_loads(kt_begin + it + 2, it + 2 < nkt);
+      {  // spread the LDS writes over the first half of this group's MFMAs and the buffer loads over the second
+        constexpr int NM = 4 * TM * TN, NW = A_PASSES + B_PASSES, H1 = NM / 2, PER = (NW + H1 - 1) / H1;
+  #pragma unroll
+        for (int i = 0; i < H1; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x200, PER, 0);  // then LDS writes
+        }
+  #pragma unroll
+        for (int i = H1; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);  // then buffer loads
+        }
       }
-#pragma unroll
-      for (int i = H1; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);  // then buffer loads
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      // group 1: meanwhile fetch group 2
+      load_frags(cur, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+      // group 2: meanwhile fetch group 3
+      load_frags(cur, 3, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfmas(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // every read of `cur` and every write of `nxt` has been issued: one barrier per K slice
+      __syncthreads();
+      // group 3: meanwhile fetch group 0 of the next slice
+      load_frags(nxt, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // group 1: meanwhile fetch group 2
-    load_frags(cur, 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    do_mfmas(1);
-    __builtin_amdgcn_sched_barrier(0);
-    // group 2: meanwhile fetch group 3
-    load_frags(cur, 3, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    do_mfmas(0);
-    __builtin_amdgcn_sched_barrier(0);
-    // every read of `cur` and every write of `nxt` has been issued: one barrier per K slice
-    __syncthreads();
-    // group 3: meanwhile fetch group 0 of the next slice
-    load_frags(nxt, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    do_mfmas(1);
-    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    // bf16x3: a K slice is two 16-wide MFMA steps; lane half h owns k = g*16 + h*8 .. +7 of step g (A and B agree, so
+    // the k order inside a step is free): one ds_read_b128 of hi halves and one of lo halves per 32-row tile and step.
+    bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    const int a_frag3 = (wm * TM * 32 + frow) * PITCH + (lane >> 5) * 4;
+    const int b_frag3 = (BM + wn * TN * 32 + frow) * PITCH + (lane >> 5) * 4;
+    auto load_frags3 = [&](const float* stage, int g, int set) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[set][i] = __builtin_bit_cast(bf16x8, ld4(stage + a_frag3 + i * 32 * PITCH + g * 8));
+        al[set][i] = __builtin_bit_cast(bf16x8, ld4(stage + a_frag3 + i * 32 * PITCH + 16 + g * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[set][j] = __builtin_bit_cast(bf16x8, ld4(stage + b_frag3 + j * 32 * PITCH + g * 8));
+        bl[set][j] = __builtin_bit_cast(bf16x8, ld4(stage + b_frag3 + j * 32 * PITCH + 16 + g * 8));
+      }
+    };
+    auto do_mfmas3 = [&](int set) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][i], bl[set][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][i], bh[set][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][i], bh[set][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    load_frags3(smem, 0, 0);
+    for (int it = 0; it < nkt; ++it) {
+      float* cur = smem + (it & 1) * STAGE;
+      float* nxt = smem + ((it & 1) ^ 1) * STAGE;
+      load_frags3(cur, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfmas3(0);
+      store_tile(nxt);
+      issue_loads(kt_begin + it + 2, it + 2 < nkt);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();          // all reads of `cur`, all writes of `nxt` issued
+      load_frags3(nxt, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      do_mfmas3(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -398,13 +469,18 @@ static Plan choose_plan(long M, int Cout, int K) {
   return best;
 }
 
+static int g_gemm_precision = 0;   // 0 = fp32 MFMA (default), 1 = bf16x3 split precision
+
 template <int WM, int WN, int TM, int TN>
 static int launch(IgemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  if (g_gemm_precision == 1)
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 1>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 0>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
   int rc = check_launch("diffsal_conv_igemm");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
@@ -435,6 +511,14 @@ static int validate(const diffsal_conv_desc* d) {
              "split the batch", in_bytes, w_bytes);
   return DIFFSAL_OK;
 }
+
+extern "C" int diffsal_set_gemm_precision(int mode) {
+  DS_REQUIRE(mode == 0 || mode == 1, DIFFSAL_E_ARG, "set_gemm_precision: mode %d (0 = fp32, 1 = bf16x3)", mode);
+  diffsal::g_gemm_precision = mode;
+  return DIFFSAL_OK;
+}
+
+extern "C" int diffsal_get_gemm_precision(void) { return diffsal::g_gemm_precision; }
 
 extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (validate(d) != DIFFSAL_OK) return 0;

@@ -22,6 +22,20 @@ Tensor = torch.Tensor
 PROFILE = None
 
 
+GEMM_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
+def set_gemm_precision(mode: str) -> None:
+    """Arithmetic of the implicit-GEMM kernel: "fp32" (default, exact) or "bf16x3" (split-precision bf16 MFMA with fp32
+    accumulation, ~4e-6 relative; opt-in, see include/diffsal.h)."""
+    _lib.check(_lib.load().diffsal_set_gemm_precision(GEMM_PRECISIONS[mode]), "set_gemm_precision")
+
+
+def get_gemm_precision() -> str:
+    m = _lib.load().diffsal_get_gemm_precision()
+    return [k for k, v in GEMM_PRECISIONS.items() if v == m][0]
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -82,6 +82,15 @@ typedef struct diffsal_conv_desc {
   int rowvec_ld;  /* leading dimension of rowvec (>= Cout) */
 } diffsal_conv_desc;
 
+/* Arithmetic of diffsal_conv_igemm's matrix-core loop (process-wide switch, not thread-safe against running launches):
+ *   0 (default): exact fp32, v_mfma_f32_32x32x2_f32;
+ *   1 "bf16x3": each fp32 operand is split into bf16 hi + lo on its way into LDS and the product is formed as
+ *     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error ~2^-16 relative per product,
+ *     ~4e-6 of the output maximum on the network's convolutions; well inside the 1e-3 parity bar, but not bit-equal
+ *     to fp32).  Opt-in; benchmark numbers for it are reported separately from the headline. */
+int diffsal_set_gemm_precision(int mode);
+int diffsal_get_gemm_precision(void);
+
 /* Bytes of scratch the call below needs for this shape (0 unless the planner picks split-K, which it does
  * when the M x Cout grid alone cannot fill the 256 CUs). */
 size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d /*host*/);

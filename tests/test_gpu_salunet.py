@@ -133,3 +133,27 @@ def test_image_based_false_uses_eight_frames():
         ref = orc.salunet_forward(sd, cfg0, x, torch.tensor([5, 50]), feats, None)
         out = net(x.to(DEV), torch.tensor([5, 50], device=DEV), [f.to(DEV) for f in feats], None)
     assert (out.cpu() - ref).abs().max().item() < RTOL * ref.abs().max().item()
+
+
+@pytest.fixture
+def bf16x3():
+    from diff_sal_amd import ops
+
+    ops.set_gemm_precision("bf16x3")
+    yield
+    ops.set_gemm_precision("fp32")
+
+
+@pytest.mark.parametrize("name", ["tiny_av", "small_vis", "full_av_b1"])
+def test_bf16x3_mode_stays_inside_the_parity_bar(golden_dir, name, bf16x3):
+    """Opt-in split-precision mode of the implicit-GEMM kernel (bf16 hi/lo operands, fp32 accumulation): the end-to-end
+    output against the reference's golden vectors.  Bar: 1e-3 relative (north_star); measured ~1e-5."""
+    cfg, sd, x, t, feats, audio, g = load_case(golden_dir, name)
+    net = build(cfg, sd)
+    with torch.no_grad():
+        out = net(x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None if audio is None else audio.to(DEV))
+    ref = torch.from_numpy(g["output"])
+    err = (out.cpu() - ref).abs().max().item()
+    print(name, "bf16x3 max abs err vs reference", err, "(output range", ref.min().item(), ref.max().item(), ")")
+    assert err < 1e-3 * ref.abs().max().item()
+    assert err > 0.0        # it really is a different arithmetic from the fp32 path
