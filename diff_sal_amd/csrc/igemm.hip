@@ -18,6 +18,8 @@
 //
 // Replaces the cuDNN/cuBLAS call sites behind torch.nn.Conv2d / Linear / Conv3d(k,1,1) in
 // R/models/saliency_decoder/{sal_unet,common_block,attention,transformer}.py (see diffsal.h).
+#include <type_traits>
+
 #include "common.h"
 
 namespace diffsal {
@@ -307,22 +309,62 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][i], bh[set][j], acc[i][j], 0, 0, 0);
         }
     };
+    // The MFMA phase of a K slice is ~5x shorter than in fp32, so global loads are issued THREE slices ahead (two
+    // register sets in flight) instead of two: at iteration `it` set it&1 holds slice it+1 (landed), the other set
+    // holds slice it+2 (in flight); after parking set it&1 in LDS it is re-used for slice it+3.
+    float4 qa[2][A_PASSES], qb[2][B_PASSES];
+    auto issue_loads3 = [&](int kt, bool live, int set) {
+      const int chunk = kt / p.taps;
+      const int tap = kt - chunk * p.taps;
+      const int ky = tap / p.KW;
+      const int kx = tap - ky * p.KW;
+      const unsigned delta = static_cast<unsigned>((ky * p.dil_h * p.W + kx * p.dil_w) * p.Cin + chunk * BK) * 4u;
+      const unsigned dead = live ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+      for (int j = 0; j < A_PASSES; ++j) {
+        const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;
+        qa[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[j] + delta) | oob | dead, 0, 0));
+      }
+      const unsigned kofs = static_cast<unsigned>(kt * BK) * 4u;
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j)
+        qb[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
+    };
+    auto store_tile3 = [&](float* stage, int set) {
+#pragma unroll
+      for (int j = 0; j < A_PASSES; ++j) split_store(&stage[(lrow + 32 * j) * PITCH], qa[set][j]);
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) split_store(&stage[(BM + lrow + 32 * j) * PITCH], qb[set][j]);
+    };
+    // (the generic prologue above already parked slice 0 in stage 0 and holds slice 1 in ra/rb)
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) qa[0][j] = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) qb[0][j] = rb[j];
+    issue_loads3(kt_begin + 2, nkt > 2, 1);
     load_frags3(smem, 0, 0);
-    for (int it = 0; it < nkt; ++it) {
-      float* cur = smem + (it & 1) * STAGE;
-      float* nxt = smem + ((it & 1) ^ 1) * STAGE;
+    auto slice = [&](int it, auto set_c) {       // set index must be a compile-time constant (register arrays)
+      constexpr int SET = decltype(set_c)::value;
+      float* cur = smem + SET * STAGE;            // slice parity == SET by construction
+      float* nxt = smem + (SET ^ 1) * STAGE;
       load_frags3(cur, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       do_mfmas3(0);
-      store_tile(nxt);
-      issue_loads(kt_begin + it + 2, it + 2 < nkt);
+      store_tile3(nxt, SET);
+      issue_loads3(kt_begin + it + 3, it + 3 < nkt, SET);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();          // all reads of `cur`, all writes of `nxt` issued
       load_frags3(nxt, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       do_mfmas3(1);
       __builtin_amdgcn_sched_barrier(0);
+    };
+    int it = 0;
+    for (; it + 1 < nkt; it += 2) {
+      slice(it, std::integral_constant<int, 0>{});
+      slice(it + 1, std::integral_constant<int, 1>{});
     }
+    if (it < nkt) slice(it, std::integral_constant<int, 0>{});
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)

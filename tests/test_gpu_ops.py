@@ -286,3 +286,31 @@ def test_weight_pack_dgrad_pack_and_unpack_match_the_permute_definitions(shape):
     ref = w4.clone().requires_grad_(True)
     pack_ref(ref).backward(g)
     assert torch.equal(p.grad.cpu().reshape(ref.grad.shape), ref.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 24, 96, 192, 3, 1, 1), (1, 28, 48, 384, 96, 3, 2, 2), (1, 1, 3000, 768, 768, 1, 0, 1)])
+def test_conv_igemm_bf16x3_mode_accuracy(shape):
+    """Opt-in split-precision mode of the GEMM kernel vs an fp64 convolution: error <= 2e-5 of the output maximum (each
+    fp32 operand = bf16 hi + bf16 lo, product = hi*hi + hi*lo + lo*hi with fp32 accumulation; lo*lo ~ 2^-16 is dropped),
+    and the result differs from the exact-fp32 mode (so the switch really selects another arithmetic)."""
+    from diff_sal_amd import ops
+
+    N, H, W, Cin, Cout, k, pad, dil = shape
+    torch.manual_seed(1)
+    x = torch.relu(torch.randn(N, Cin, H, W))
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=pad, dilation=dil).permute(0, 2, 3, 1)
+    xd, wp = nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV))
+    kw = dict(kh=k, kw=k, pad=(pad, pad), dil=(dil, dil))
+    y32 = ops.conv_igemm(xd, wp, **kw)
+    ops.set_gemm_precision("bf16x3")
+    try:
+        y3 = ops.conv_igemm(xd, wp, **kw)
+    finally:
+        ops.set_gemm_precision("fp32")
+    m = ref.abs().max().item()
+    e32 = (y32.cpu().double() - ref).abs().max().item() / m
+    e3 = (y3.cpu().double() - ref).abs().max().item() / m
+    print("fp32 err %.2e  bf16x3 err %.2e" % (e32, e3))
+    assert e32 < 2e-6 and e3 < 2e-5
+    assert not torch.equal(y3, y32)

@@ -104,3 +104,23 @@ def test_sample_ddpm_10_steps_matches_reference_trainer(golden_dir):
     out = s.sample_ddpm(x.to(DEV), [f.to(DEV) for f in feats], None, noises=zs)
     ref = torch.from_numpy(g["output"])
     assert (out.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+def test_sampling_trajectories_in_bf16x3_mode_stay_inside_the_parity_bar(golden_dir, tiny):
+    """The opt-in split-precision GEMM mode through whole trajectories: 10-step DDIM of the reference trainer and the 50-NFE
+    DPM-Solver of the reference sampler.  Bar 1e-3 relative (north_star); the error does not accumulate over the steps."""
+    from diff_sal_amd import ops
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    top, x, feats, audio = tiny
+    ops.set_gemm_precision("bf16x3")
+    try:
+        ddim = DiffusionSampler(top, timesteps=10, sample_type="ddim").sample_ddim(x, feats, audio)
+        dpm = DiffusionSampler(top, timesteps=50, sample_type="dpmsolver").sample_dpm_solver(x, feats, audio)
+    finally:
+        ops.set_gemm_precision("fp32")
+    for name, out in (("ddim_tiny_av", ddim), ("dpm50_tiny_av", dpm)):
+        ref = torch.from_numpy(np.load(f"{golden_dir}/{name}.npz")["output"])
+        err = (out.cpu() - ref).abs().max().item()
+        print(name, "bf16x3 max abs err", err)
+        assert err < 1e-3 * ref.abs().max().item()
