@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride_h", "stride_w", "pad_t", "pad_l",
-        "dil_h", "dil_w", "act", "rowvec_ld")]
+        "dil_h", "dil_w", "act", "rowvec_ld", "w_format")]
 
 
 SIGNATURES = {
@@ -76,6 +76,7 @@ SIGNATURES = {
     "diffsal_norm_finalize_fwd": (c_i, [c_f] * 7 + [c_i, c_i, c_i, C.c_double, C.c_double] + [c_f] * 4 + [c_fl, c_fl, c_f]),
     "diffsal_norm_finalize_bwd": (c_i, [c_f] * 8 + [c_i, c_i, c_i, C.c_double, c_f]),
     "diffsal_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_split_weight": (c_i, [c_f, c_f, C.c_long, c_f]),
     "diffsal_col2im_disjoint": (c_i, [c_f, c_f] + [c_i] * 12 + [c_f]),
     "diffsal_reduce_blocks": (c_i, []),
     "diffsal_multi_copy": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.POINTER(C.c_long), c_i, c_f, c_f]),

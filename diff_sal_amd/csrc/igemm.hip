@@ -43,6 +43,7 @@ struct IgemmArgs {
   int H, W, Cin, Ho, Wo, Cout;
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int act, rowvec_ld;
+  int w_split;               // bf16x3 mode: weights arrive pre-split (diffsal_split_weight), no conversion of the B operand
   int n_tiles_n, n_tiles;  // tiles along N, total tiles
   unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
   int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
@@ -180,8 +181,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     } else {
 #pragma unroll
       for (int j = 0; j < A_PASSES; ++j) split_store(&stage[(lrow + 32 * j) * PITCH], ra[j]);
+      if (p.w_split) {
 #pragma unroll
-      for (int j = 0; j < B_PASSES; ++j) split_store(&stage[(BM + lrow + 32 * j) * PITCH], rb[j]);
+        for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) split_store(&stage[(BM + lrow + 32 * j) * PITCH], rb[j]);
+      }
     }
   };
 
@@ -333,8 +339,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     auto store_tile3 = [&](float* stage, int set) {
 #pragma unroll
       for (int j = 0; j < A_PASSES; ++j) split_store(&stage[(lrow + 32 * j) * PITCH], qa[set][j]);
+      if (p.w_split) {   // pre-split rows already have the LDS row layout: 16 dwords hi | 16 dwords lo
 #pragma unroll
-      for (int j = 0; j < B_PASSES; ++j) split_store(&stage[(BM + lrow + 32 * j) * PITCH], qb[set][j]);
+        for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], qb[set][j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < B_PASSES; ++j) split_store(&stage[(BM + lrow + 32 * j) * PITCH], qb[set][j]);
+      }
     };
     // (the generic prologue above already parked slice 0 in stage 0 and holds slice 1 in ra/rb)
 #pragma unroll
@@ -589,11 +600,14 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
+  DS_REQUIRE(d->w_format == 0 || (d->w_format == 1 && diffsal::g_gemm_precision == 1), DIFFSAL_E_ARG,
+             "conv_igemm: w_format=%d needs the bf16x3 GEMM precision (diffsal_set_gemm_precision(1))", d->w_format);
+  a.w_split = d->w_format;
   a.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
   a.w_bytes = static_cast<unsigned>(static_cast<long>(d->Cout) * a.K * 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
-  if (d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
+  if (d->w_format == 0 && d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
       d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual))) {
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;

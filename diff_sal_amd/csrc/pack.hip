@@ -101,6 +101,25 @@ __global__ __launch_bounds__(256) void col2im_disjoint_kernel(const float* __res
   }
 }
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+// fp32 [..][32-k slices] -> per slice: 16 dwords of bf16 hi halves (k order) + 16 dwords of lo halves
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, long n4) {
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<long>(gridDim.x) * 256) {
+    const float4 v = ld4(src + i * 4);
+    const long slice = i >> 3;
+    const int pos = static_cast<int>(i & 7) * 4;          // first of 4 consecutive k inside the slice
+    const __bf16 h0 = static_cast<__bf16>(v.x), h1 = static_cast<__bf16>(v.y), h2 = static_cast<__bf16>(v.z),
+                 h3 = static_cast<__bf16>(v.w);
+    const bf16x4_t hi = {h0, h1, h2, h3};
+    const bf16x4_t lo = {static_cast<__bf16>(v.x - static_cast<float>(h0)), static_cast<__bf16>(v.y - static_cast<float>(h1)),
+                         static_cast<__bf16>(v.z - static_cast<float>(h2)), static_cast<__bf16>(v.w - static_cast<float>(h3))};
+    float* row = dst + slice * 32;
+    *reinterpret_cast<uint2*>(row + (pos >> 1)) = __builtin_bit_cast(uint2, hi);
+    *reinterpret_cast<uint2*>(row + 16 + (pos >> 1)) = __builtin_bit_cast(uint2, lo);
+  }
+}
+
 }  // namespace
 }  // namespace diffsal
 
@@ -140,4 +159,15 @@ extern "C" int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int 
   hipLaunchKernelGGL(col2im_disjoint_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), cols,
                      dx, N, H, W, C, Ho, Wo, KH, KW, stride_h, stride_w, pad_t, pad_l);
   return check_launch("col2im_disjoint");
+}
+
+extern "C" int diffsal_split_weight(const float* src, float* dst, long n, diffsal_stream_t stream) {
+  DS_REQUIRE(src && dst && src != dst, DIFFSAL_E_ARG, "split_weight: null or aliased argument");
+  DS_REQUIRE(n > 0 && n % 32 == 0 && aligned16(src) && aligned16(dst), DIFFSAL_E_SHAPE,
+             "split_weight: need n %% 32 == 0 and 16-byte aligned buffers");
+  long g = (n / 4 + 255) / 256;
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(split_weight_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst,
+                     n / 4);
+  return check_launch("split_weight");
 }

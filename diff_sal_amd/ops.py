@@ -132,6 +132,17 @@ def pack_conv_weight(w: Tensor) -> Tensor:
     return _pack(_as_conv4(w.detach()), 0)
 
 
+def split_weight(w_packed: Tensor) -> Tensor:
+    """bf16x3 mode only: pre-split a packed fp32 weight [Cout, K] into bf16 hi/lo halves per 32-k slice (same shape and
+    size; include/diffsal.h, w_format = 1).  The result is tagged so that conv_igemm announces the format to the kernel;
+    it is only valid while the GEMM precision is "bf16x3"."""
+    lib = _lib.load()
+    out = torch.empty_like(w_packed)
+    _lib.check(lib.diffsal_split_weight(_p(w_packed.contiguous()), _p(out), w_packed.numel(), _stream()), "split_weight")
+    out._diffsal_split = True
+    return out
+
+
 def pack_dgrad_weight(w: Tensor) -> Tensor:
     """Packed weight of the data-gradient convolution: [Cin, KH*KW*Cout], taps flipped (include/diffsal.h, mode 1)."""
     return _pack(_as_conv4(w.detach()), 1)
@@ -196,7 +207,7 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], act,
-                 rowvec.shape[-1] if rowvec is not None else 0)
+                 rowvec.shape[-1] if rowvec is not None else 0, 1 if getattr(w_packed, "_diffsal_split", False) else 0)
     if rowvec is not None:
         assert rowvec.stride(-1) == 1 and rowvec.dtype == torch.float32 and rowvec.is_cuda
         d.rowvec_ld = rowvec.stride(0)

@@ -211,7 +211,7 @@ class SalUNet(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _cache_key(self):
-        return (self._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (self._pack_epoch, ops.get_gemm_precision()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def parameters_updated(self) -> None:
         """Tell the module its parameters were rewritten behind autograd's version counters (the fused Adam kernel
@@ -220,8 +220,10 @@ class SalUNet(nn.Module):
 
     @staticmethod
     def _pack_conv(w: Tensor) -> Tensor:
-        """[Cout,Cin,KH,KW] -> [Cout, K] in the implicit-GEMM k order (channel chunk, tap, channel)."""
-        return ops.pack_conv_weight(w)
+        """[Cout,Cin,KH,KW] -> [Cout, K] in the implicit-GEMM k order (channel chunk, tap, channel); in the opt-in bf16x3
+        GEMM mode additionally pre-split into bf16 hi/lo halves so the kernel does not convert its B operand."""
+        wp = ops.pack_conv_weight(w)
+        return ops.split_weight(wp) if ops.get_gemm_precision() == "bf16x3" else wp
 
     @staticmethod
     def _bn_affine(bn: nn.BatchNorm2d):
@@ -268,7 +270,7 @@ class SalUNet(nn.Module):
             pk[f"s{i}.wk"] = a.conv_proj_k.conv.weight.detach().reshape(c, k * k).t().contiguous()
             pk[f"s{i}.wv"] = a.conv_proj_v.conv.weight.detach().reshape(c, k * k).t().contiguous()
             pk[f"s{i}.align.w"] = st.blocks[0].align_conv.weight.detach().reshape(c, 512).contiguous()
-            pk[f"s{i}.redu.w"] = ops.pack_conv_weight(dec.redu_chan_up[i].proj[0].weight)  # [Co, C, kt, 1, 1]
+            pk[f"s{i}.redu.w"] = self._pack_conv(dec.redu_chan_up[i].proj[0].weight)  # [Co, C, kt, 1, 1]
         pk["mt.w"] = self._pack_conv(dec.mt_proj[0].weight)
         pk["mt.scale"], pk["mt.shift"] = self._bn_affine(dec.mt_proj[1])
         pk["head.w"] = self.logits.linear_pred.weight.detach().reshape(-1).contiguous()

@@ -80,6 +80,9 @@ typedef struct diffsal_conv_desc {
   int KH, KW, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int act;        /* DIFFSAL_ACT_* */
   int rowvec_ld;  /* leading dimension of rowvec (>= Cout) */
+  int w_format;   /* 0: fp32 [Cout][K] (k order above).  1: the same rows pre-split for the bf16x3 mode by
+                   * diffsal_split_weight: per 32-k slice 16 dwords of bf16 hi halves then 16 dwords of lo halves (same
+                   * size); only valid while diffsal_get_gemm_precision() == 1 */
 } diffsal_conv_desc;
 
 /* Arithmetic of diffsal_conv_igemm's matrix-core loop (process-wide switch, not thread-safe against running launches):
@@ -110,6 +113,9 @@ int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, con
 int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH, int KW,
                             int stride_h, int stride_w, int pad_t, int pad_l, diffsal_stream_t stream);
 int diffsal_pack_weight(const float* src, float* dst, int Cout, int Cin, int taps, int mode, diffsal_stream_t stream);
+/* bf16x3 mode: split a packed fp32 weight [rows][K] (K % 32 == 0) into the w_format = 1 layout of diffsal_conv_desc
+ * (hi = bf16(x), lo = bf16(x - hi)); n = rows * K.  Saves the kernel the conversion of its B operand. */
+int diffsal_split_weight(const float* src, float* dst, long n, diffsal_stream_t stream);
 
 /* ---- K16 (training): weight gradient of the layer above, in the SAME packed layout as `w`:
  * dw[co, k] = sum_m dy[m, co] * A[m, k].  Replaces the wgrad of autograd's conv / linear backward.

@@ -306,8 +306,12 @@ def test_conv_igemm_bf16x3_mode_accuracy(shape):
     ops.set_gemm_precision("bf16x3")
     try:
         y3 = ops.conv_igemm(xd, wp, **kw)
+        y3s = ops.conv_igemm(xd, ops.split_weight(wp), **kw)     # weights pre-split on the host side of the launch
     finally:
         ops.set_gemm_precision("fp32")
+    assert torch.equal(y3s, y3)                                   # same arithmetic, the split just happens earlier
+    with pytest.raises(RuntimeError):                             # a pre-split weight is refused by the fp32 mode
+        ops.conv_igemm(xd, ops.split_weight(wp), **kw)
     m = ref.abs().max().item()
     e32 = (y32.cpu().double() - ref).abs().max().item() / m
     e3 = (y3.cpu().double() - ref).abs().max().item() / m
