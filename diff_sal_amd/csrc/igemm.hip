@@ -18,6 +18,7 @@
 //
 // Replaces the cuDNN/cuBLAS call sites behind torch.nn.Conv2d / Linear / Conv3d(k,1,1) in
 // R/models/saliency_decoder/{sal_unet,common_block,attention,transformer}.py (see diffsal.h).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -612,7 +613,11 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
-  const Plan pl = choose_plan(M, d->Cout, a.K);
+  Plan pl = choose_plan(M, d->Cout, a.K);
+  if (const char* e = getenv("DIFFSAL_IGEMM_CFG")) {   // tuning aid: force a tile shape (no split-K)
+    pl.cfg = atoi(e) % kNumCfgs;
+    pl.splits = 1;
+  }
   a.splits = pl.splits;
   a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;
   a.partial = nullptr;
