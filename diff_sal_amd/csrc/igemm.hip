@@ -51,6 +51,8 @@ struct IgemmArgs {
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
 };
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -164,14 +166,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
       rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
   };
   // PREC 1 row layout (same 36-dword pitch): dwords 0..15 = the 32 hi halves (k order), 16..31 = the 32 lo halves
+  // two elements at a time: cvt_pk, shift / mask back to fp32, packed subtract, cvt_pk = 2.5 VALU per element
+  auto split_pair = [](float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+  };
   auto split_store = [&](float* rowp, const float4& v) {
-    const __bf16 h0 = static_cast<__bf16>(v.x), h1 = static_cast<__bf16>(v.y), h2 = static_cast<__bf16>(v.z),
-                 h3 = static_cast<__bf16>(v.w);
-    bf16x4 hi = {h0, h1, h2, h3};
-    bf16x4 lo = {static_cast<__bf16>(v.x - static_cast<float>(h0)), static_cast<__bf16>(v.y - static_cast<float>(h1)),
-                 static_cast<__bf16>(v.z - static_cast<float>(h2)), static_cast<__bf16>(v.w - static_cast<float>(h3))};
-    *reinterpret_cast<uint2*>(rowp + (lcol >> 1)) = __builtin_bit_cast(uint2, hi);
-    *reinterpret_cast<uint2*>(rowp + 16 + (lcol >> 1)) = __builtin_bit_cast(uint2, lo);
+    uint2 hi, lo;
+    split_pair(v.x, v.y, hi.x, lo.x);
+    split_pair(v.z, v.w, hi.y, lo.y);
+    *reinterpret_cast<uint2*>(rowp + (lcol >> 1)) = hi;
+    *reinterpret_cast<uint2*>(rowp + 16 + (lcol >> 1)) = lo;
   };
   auto store_tile = [&](float* stage) {
     if constexpr (PREC == 0) {
