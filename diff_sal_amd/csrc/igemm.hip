@@ -504,8 +504,11 @@ struct Plan { int cfg, splits; };
 //   round = max(occ * t_mfma, t_mfma + t_fixed),  time = ceil(workgroups / (256 occ)) * round
 // (+ the slab round trip for split-K).  Short-K GEMMs therefore prefer more, smaller residents;
 // long-K convolutions prefer the widest tile that still fills the chip.
+static int g_gemm_precision = 0;   // 0 = fp32 MFMA (default), 1 = bf16x3 split precision
+
 static Plan choose_plan(long M, int Cout, int K) {
-  const double mac_per_s_cu = 157.3e12 / 2.0 / kCUs;
+  // the bf16x3 loop sustains ~2x the fp32 one on large tiles: split-K slabs and fixed latencies weigh twice as much
+  const double mac_per_s_cu = (g_gemm_precision == 1 ? 2.0 : 1.0) * 157.3e12 / 2.0 / kCUs;
   const double t_fixed = 10e-6;
   const int KT = K / BK;
   Plan best{5, 1};
@@ -530,8 +533,6 @@ static Plan choose_plan(long M, int Cout, int K) {
   }
   return best;
 }
-
-static int g_gemm_precision = 0;   // 0 = fp32 MFMA (default), 1 = bf16x3 split precision
 
 template <int WM, int WN, int TM, int TN>
 static int launch(IgemmArgs& a, hipStream_t s) {
