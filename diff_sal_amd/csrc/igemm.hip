@@ -68,7 +68,13 @@ template <int WM, int WN, int TM, int TN, int PREC>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
-  constexpr int A_PASSES = BM / 32;
+  // A-operand loader: fp32 -> a thread owns 4 consecutive k of a row (one 16-byte load), 32 rows per pass;
+  // bf16x3 -> 8 consecutive k (two loads), 64 rows per pass, so that its bf16 hi and lo halves are 16 bytes each and go
+  // to LDS as conflict-free ds_write_b128 (the 8-byte stores of a 4-k owner were 4-way bank conflicted).
+  constexpr int A_RPP = PREC == 1 ? 64 : 32;
+  constexpr int A_LPT = PREC == 1 ? 2 : 1;
+  constexpr int A_PASSES = BM / A_RPP;
+  constexpr int A_REGS = A_PASSES * A_LPT;
   constexpr int B_PASSES = BN / 32;
   constexpr int STAGE = (BM + BN) * PITCH;  // floats per LDS stage
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -107,6 +113,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   // on the data: ~4 VALU per load, so the loader hides completely under the MFMAs.
   const int lrow = tid >> 3;
   const int lcol = (tid & 7) * 4;
+  const int lrow_a = PREC == 1 ? tid >> 2 : lrow;
+  const int lcol_a = PREC == 1 ? (tid & 3) * 8 : lcol;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int j = 0; j < A_PASSES; ++j) {
-    int m = m0 + lrow + 32 * j;
+    int m = m0 + lrow_a + A_RPP * j;
     m = m < p.M ? m : p.M - 1;  // rows past M compute garbage that is never stored
     const int n = m / HoWo;
     const int rem = m - n * HoWo;
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     const int ox = rem - oy * p.Wo;
     const int iy0 = oy * p.stride_h - p.pad_t;
     const int ix0 = ox * p.stride_w - p.pad_l;
-    a_voff[j] = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + lcol) * 4u;
+    a_voff[j] = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + lcol_a) * 4u;
     unsigned bits = 0;
     for (int t = 0; t < p.taps; ++t) {
       const int ky = t / p.KW, kx = t - ky * p.KW;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     b_voff[j] = static_cast<unsigned>(n * p.K + lcol) * 4u;
   }
 
-  float4 ra[A_PASSES], rb[B_PASSES];
+  float4 ra[A_REGS], rb[B_PASSES];
   const int kt_begin = split * p.kt_per_split;
   const int kt_end = min(p.K / BK, kt_begin + p.kt_per_split);
   const int nkt = kt_end - kt_begin;
@@ -157,8 +165,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
       const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;  // 0 when the tap is inside, else all ones
-      const unsigned off = (a_voff[j] + delta) | oob | dead;
-      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+#pragma unroll
+      for (int l = 0; l < A_LPT; ++l) {
+        const unsigned off = (a_voff[j] + delta + 16u * l) | oob | dead;
+        ra[j * A_LPT + l] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+      }
     }
     const unsigned kofs = static_cast<unsigned>(kt * BK) * 4u;
 #pragma unroll
@@ -181,6 +192,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     *reinterpret_cast<uint2*>(rowp + (lcol >> 1)) = hi;
     *reinterpret_cast<uint2*>(rowp + 16 + (lcol >> 1)) = lo;
   };
+  auto split_store8 = [&](float* rowp, const float4& v0, const float4& v1) {   // 8 consecutive k: 16 B of hi, 16 B of lo
+    uint4 hi, lo;
+    split_pair(v0.x, v0.y, hi.x, lo.x);
+    split_pair(v0.z, v0.w, hi.y, lo.y);
+    split_pair(v1.x, v1.y, hi.z, lo.z);
+    split_pair(v1.z, v1.w, hi.w, lo.w);
+    *reinterpret_cast<uint4*>(rowp + (lcol_a >> 1)) = hi;
+    *reinterpret_cast<uint4*>(rowp + 16 + (lcol_a >> 1)) = lo;
+  };
   auto store_tile = [&](float* stage) {
     if constexpr (PREC == 0) {
 #pragma unroll
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
       for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < A_PASSES; ++j) split_store(&stage[(lrow + 32 * j) * PITCH], ra[j]);
+      for (int j = 0; j < A_PASSES; ++j) split_store8(&stage[(lrow_a + A_RPP * j) * PITCH], ra[j * A_LPT], ra[j * A_LPT + A_LPT - 1]);
       if (p.w_split) {
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
@@ -240,15 +260,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 
   // prologue: the loads of slices 0 and 1 are in flight together (slice 1 borrows a second register set)
   issue_loads(kt_begin + 1, nkt > 1);
-  float4 ta[A_PASSES], tb[B_PASSES];
+  float4 ta[A_REGS], tb[B_PASSES];
 #pragma unroll
-  for (int j = 0; j < A_PASSES; ++j) ta[j] = ra[j];
+  for (int j = 0; j < A_REGS; ++j) ta[j] = ra[j];
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) tb[j] = rb[j];
   issue_loads(kt_begin, true);
   store_tile(smem);
 #pragma unroll
-  for (int j = 0; j < A_PASSES; ++j) ra[j] = ta[j];
+  for (int j = 0; j < A_REGS; ++j) ra[j] = ta[j];
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) rb[j] = tb[j];
   __syncthreads();
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     // The MFMA phase of a K slice is ~5x shorter than in fp32, so global loads are issued THREE slices ahead (two
     // register sets in flight) instead of two: at iteration `it` set it&1 holds slice it+1 (landed), the other set
     // holds slice it+2 (in flight); after parking set it&1 in LDS it is re-used for slice it+3.
-    float4 qa[2][A_PASSES], qb[2][B_PASSES];
+    float4 qa[2][A_REGS], qb[2][B_PASSES];
     auto issue_loads3 = [&](int kt, bool live, int set) {
       const int chunk = kt / p.taps;
       const int tap = kt - chunk * p.taps;
@@ -338,7 +358,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
       for (int j = 0; j < A_PASSES; ++j) {
         const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;
-        qa[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[j] + delta) | oob | dead, 0, 0));
+#pragma unroll
+        for (int l = 0; l < A_LPT; ++l)
+          qa[set][j * A_LPT + l] = __builtin_bit_cast(
+              float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[j] + delta + 16u * l) | oob | dead, 0, 0));
       }
       const unsigned kofs = static_cast<unsigned>(kt * BK) * 4u;
 #pragma unroll
@@ -347,7 +370,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     };
     auto store_tile3 = [&](float* stage, int set) {
 #pragma unroll
-      for (int j = 0; j < A_PASSES; ++j) split_store(&stage[(lrow + 32 * j) * PITCH], qa[set][j]);
+      for (int j = 0; j < A_PASSES; ++j)
+        split_store8(&stage[(lrow_a + A_RPP * j) * PITCH], qa[set][j * A_LPT], qa[set][j * A_LPT + A_LPT - 1]);
       if (p.w_split) {   // pre-split rows already have the LDS row layout: 16 dwords hi | 16 dwords lo
 #pragma unroll
         for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], qb[set][j]);
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     };
     // (the generic prologue above already parked slice 0 in stage 0 and holds slice 1 in ra/rb)
 #pragma unroll
-    for (int j = 0; j < A_PASSES; ++j) qa[0][j] = ra[j];
+    for (int j = 0; j < A_REGS; ++j) qa[0][j] = ra[j];
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) qb[0][j] = rb[j];
     issue_loads3(kt_begin + 2, nkt > 2, 1);
