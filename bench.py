@@ -38,6 +38,61 @@ class _Stop(Exception):
     pass
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, the
+    reference's own launch shape: `torchrun --nproc_per_node`, R/scripts/train_av.sh:13, R/train_av_data.py:38-61) and
+    relay rank 0's JSON line.  The parent never initialises the GPU (no HIP call before or after the children start),
+    so nothing is ever exec'ed or forked from a process that holds a device."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def plumbing_only(args, rank, world):
+    """No GPU in this process (CPU-only host, e.g. the build container): exercise exactly the multi-rank plumbing of the
+    benchmark -- rendezvous, barrier, MAX-over-ranks timing, rank-0 JSON -- over gloo, and say so.  The hot path itself has
+    no CPU fallback, so `value` is null."""
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(backend="gloo", init_method="env://")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    el = time.perf_counter() - t0
+    ranks = 1
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        ranks = dist.get_world_size()
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "denoise-steps/sec (batch x NFE / wall time), 16x224x384 clip, 50-step DPM-Solver",
+                          "value": None, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "NONE: no GPU visible -- launcher / rendezvous plumbing only (gloo)"},
+                          "rccl_ranks": ranks, "backend": "gloo", "devices": ["cpu"] * world,
+                          "max_over_ranks_s": round(el, 4)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 class Config:
     """The decoder of R/cfgs/audio_visual.py:50-82 / R/cfgs/visual.py:33-70 (the only configuration the reference ships)."""
     img_size = (224, 384)
@@ -179,19 +234,25 @@ def main():
     ap.add_argument("--sampler-mode", choices=["eager", "graph", "f1"], default="eager",
                     help="eager = headline; graph = whole trajectories replayed from a HIP graph; f1 = step-invariant "
                          "shortcut of visual-only mode (1 evaluation per trajectory) -- both reported separately")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="fp32 = headline (exact fp32 MFMA); bf16x3 = split-precision bf16 MFMA in the implicit-GEMM kernel "
-                         "(opt-in mode, ~4e-6 relative error, reported separately)")
-    ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra bf16x3 pass reported beside the headline")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16", "fp16"], default="fp32",
+                    help="fp32 = headline (exact fp32 MFMA); bf16x3 = split-precision bf16 MFMA on fp32 tensors (~4e-6); "
+                         "bf16 / fp16 = 16-bit STORAGE of activations + packed weights, native 16-bit MFMA, fp32 accumulate "
+                         "(BASELINE configs[1] / configs[4]; own tolerance table, DESIGN.md 2b).  All but fp32 are opt-in "
+                         "modes reported separately from the headline")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra reduced-precision passes reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 is the fastest setting measured on the 256-core box)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        return plumbing_only(args, rank, world)
     if world > 1:
         import torch.distributed as dist
 
@@ -202,10 +263,16 @@ def main():
     from diff_sal_amd import ops
     from diff_sal_amd.sampling import DiffusionSampler
 
-    ops.set_gemm_precision(args.precision)
     cfg = Config()
     B, av = args.batch, args.mode == "av"
     net, sd = build_net(cfg, dev)
+    STORAGE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+    def set_precision(mode):
+        net.compute_dtype = STORAGE.get(mode, torch.float32)
+        net.gemm_precision = "bf16x3" if mode == "bf16x3" else "fp32"
+
+    set_precision(args.precision)
 
     # synthetic clips, resident in HBM before the timed region; rank-dependent seed (each rank owns its clips)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -286,32 +353,40 @@ def main():
     k_flops = sum(f for _, _, f in ev)
     n_launch = max(len(ev), 1)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "igemm_hbm_traffic.json")
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get("bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            traffic = None
+    common = {"launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),
+              "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3)}
     if args.precision == "fp32":
         roofline = {
             "kernel": "diffsal::igemm_kernel (fp32 MFMA implicit GEMM: 3x3 convs, token GEMMs, ReduceTemp)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),
-            "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3),
-        }
-    else:   # three bf16 MFMAs per fp32-accurate product: the instruction-level peak is the bf16 one
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, **common}
+    elif args.precision == "bf16x3":   # three bf16 MFMAs per fp32-accurate product: the instruction-level peak is the bf16 one
         roofline = {
             "kernel": "diffsal::igemm_kernel<..., bf16x3> (split-precision bf16 MFMA implicit GEMM, fp32 accumulate)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "executed_mfma_tflops": round(3 * achieved, 2), "executed_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
             "note": "achieved = algorithmic 2MNK FLOPs / time; the kernel issues 3 bf16 MFMAs per product (hi*hi+hi*lo+lo*hi)",
-            "launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),
-            "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3),
-        }
+            **common}
+    else:
+        roofline = {
+            "kernel": f"diffsal::igemm16_kernel<..., {args.precision}> (native 16-bit MFMA implicit GEMM on {args.precision} "
+                      "storage, fp32 accumulate)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, **common}
 
+    DT_LABEL = {"fp32": "f32", "bf16x3": "f32 in/out, bf16x3 split-precision MFMA (NOT the headline configuration)",
+                "bf16": "bf16 storage, f32 accumulate (NOT the headline configuration; BASELINE configs[1] as written)",
+                "fp16": "f16 storage, f32 accumulate (NOT the headline configuration; BASELINE configs[4] arithmetic)"}
+    devices = [torch.cuda.get_device_name(dev)]
+    ranks_seen = 1
+    if world > 1:
+        import torch.distributed as dist
+
+        ranks_seen = dist.get_world_size()
+        names = [None] * world
+        dist.all_gather_object(names, f"cuda:{local_rank} {torch.cuda.get_device_name(dev)}")
+        devices = names
     result = {
         "metric": "denoise-steps/sec (batch x NFE / wall time), 16x224x384 clip, 50-step DPM-Solver",
         "value": round(world * B * args.steps / elapsed, 3),
@@ -323,7 +398,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f32 in/out, bf16x3 split-precision MFMA (NOT the headline configuration)",
+        "dtype": DT_LABEL[args.precision],
         "data": "synthetic",
         "config": {
             "workload": ("BASELINE configs[1]: DHF1k visual-only" if not av else "BASELINE configs[2]: AVAD audio-visual")
@@ -333,32 +408,59 @@ def main():
             "sampler_mode": args.sampler_mode + ("" if not special else " (NOT the headline configuration)"),
             "gflop_per_clip_step": 151.61 if not av else 152.73,
         },
+        "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
         "roofline": roofline,
     }
 
     if world == 1 and args.precision == "fp32" and not special and not args.no_alt_precision:
-        # The same K steps once more in the opt-in bf16x3 mode of the implicit-GEMM kernel, reported next to the headline
-        # (not instead of it), with the output difference between the two arithmetics on one network evaluation.
+        # The same K steps once more in each opt-in reduced-precision mode, reported next to the headline (not instead of
+        # it), with the output difference from the fp32 arithmetic on one network evaluation.
         with torch.no_grad():
             t_probe = torch.full((B,), 500, device=dev)
             y32 = inner(x_T, t_probe, feats, audio)
-            ops.set_gemm_precision("bf16x3")
-            y3 = inner(x_T, t_probe, feats, audio)
-        run_steps(max(args.warmup, 1))
-        torch.cuda.synchronize()
-        a0 = time.perf_counter()
-        run_steps(args.steps)
-        torch.cuda.synchronize()
-        a_el = time.perf_counter() - a0
-        ops.set_gemm_precision("fp32")
-        result["alt_precision"] = {
-            "mode": "bf16x3 (fp32 operands split into bf16 hi+lo inside the GEMM kernel, 3 bf16 MFMAs per product, fp32 "
-                    "accumulation; opt-in: diffsal_set_gemm_precision(1))",
-            "value": round(B * args.steps / a_el, 3), "unit": "denoise-steps/s", "ms_per_step": round(a_el / args.steps * 1e3, 4),
-            "speedup_vs_headline": round(elapsed / a_el, 3),
-            "max_abs_output_diff_vs_fp32": float((y3 - y32).abs().max().item()),
-            "output_range": [float(y32.min().item()), float(y32.max().item())],
-        }
+        alts = []
+        for mode, desc in (
+                ("bf16x3", "fp32 tensors; operands split into bf16 hi+lo inside the GEMM kernel, 3 bf16 MFMAs per product, fp32 "
+                           "accumulation (diffsal_conv_desc.precision = 1)"),
+                ("bf16", "bf16 STORAGE of activations and packed weights, native bf16 MFMA, fp32 accumulation and statistics "
+                         "(SalUNet(compute_dtype=torch.bfloat16); BASELINE configs[1] as written)"),
+                ("fp16", "fp16 STORAGE of activations and packed weights, native fp16 MFMA, fp32 accumulation and statistics "
+                         "(SalUNet(compute_dtype=torch.float16); the arithmetic of BASELINE configs[4])")):
+            set_precision(mode)
+            with torch.no_grad():
+                y3 = inner(x_T, t_probe, feats, audio)
+            run_steps(max(args.warmup, 1))
+            torch.cuda.synchronize()
+            a0 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            a_el = time.perf_counter() - a0
+            # 16-bit modes finish a step faster than Python can enqueue it: also time whole trajectories replayed from
+            # a HIP graph (same kernels, same order; the sampler's optional mode)
+            graph = None
+            if mode in STORAGE and args.steps >= NFE_PER_TRAJECTORY:
+                net.forward = inner
+                gs = DiffusionSampler(Top(net), timesteps=NFE_PER_TRAJECTORY, sample_type="dpmsolver", skip_type="logSNR",
+                                      denoise=True, training_target="x0", hip_graph=True)
+                gs.sample_dpm_solver(x_T, feats, audio)
+                torch.cuda.synchronize()
+                ntraj = max(1, args.steps // NFE_PER_TRAJECTORY)
+                g0 = time.perf_counter()
+                for _ in range(ntraj):
+                    gs.sample_dpm_solver(x_T, feats, audio)
+                torch.cuda.synchronize()
+                g_el = time.perf_counter() - g0
+                graph = {"value": round(B * ntraj * NFE_PER_TRAJECTORY / g_el, 3), "unit": "denoise-steps/s",
+                         "ms_per_step": round(g_el / (ntraj * NFE_PER_TRAJECTORY) * 1e3, 4),
+                         "note": "whole 50-NFE trajectories replayed from one HIP graph"}
+                net.forward = counted
+            alts.append({"mode": mode, "what": desc, "value": round(B * args.steps / a_el, 3), "unit": "denoise-steps/s",
+                         "ms_per_step": round(a_el / args.steps * 1e3, 4), "speedup_vs_headline": round(elapsed / a_el, 3),
+                         "hip_graph": graph,
+                         "max_abs_output_diff_vs_fp32": float((y3 - y32).abs().max().item()),
+                         "output_range": [float(y32.min().item()), float(y32.max().item())]})
+        set_precision("fp32")
+        result["alt_precision"] = alts
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: a few B-clip oracle evaluations (the per-step network cost dominates a trajectory).
         # This leg is the ONLY place the CPU oracle is touched; it gets the same weights and inputs as the GPU path.

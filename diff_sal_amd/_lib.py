@@ -21,7 +21,12 @@ class ConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride_h", "stride_w", "pad_t", "pad_l",
-        "dil_h", "dil_w", "act", "rowvec_ld", "w_format")]
+        "dil_h", "dil_w", "act", "rowvec_ld", "w_format", "precision", "dtype")]
+
+
+# must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
+# so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
+ABI_VERSION = 2
 
 
 SIGNATURES = {
@@ -29,9 +34,9 @@ SIGNATURES = {
     "diffsal_last_error": (C.c_char_p, []),
     "diffsal_temb_mlp": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "diffsal_dense_small": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f]),
-    "diffsal_conv_in": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_conv_in": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_groupnorm_ws_bytes": (c_sz, [c_i, c_i]),
-    "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_f]),
+    "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_i, c_f]),
     "diffsal_conv_igemm_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
@@ -60,18 +65,17 @@ SIGNATURES = {
     "diffsal_conv_in_bwd": (c_i, [c_f, c_f, c_f] + [c_i] * 5 + [c_f]),
     "diffsal_dense_small_bwd": (c_i, [c_f] * 6 + [c_i] * 4 + [c_f]),
     "diffsal_audio_fuse_bwd": (c_i, [c_f] * 5 + [c_i] * 7 + [c_f]),
-    "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
-    "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
-    "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
-    "diffsal_audio_fuse": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
-    "diffsal_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),
-    "diffsal_dwconv3_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f]),
-    "diffsal_dwpool_ln_kv": (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
-    "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f]),
-    "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_audio_fuse": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, c_f]),
+    "diffsal_dwconv3_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
+    "diffsal_dwpool_ln_kv": (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
+    "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
+    "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "diffsal_cast": (c_i, [c_f, c_i, c_f, c_i, C.c_long, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
-    "diffsal_set_gemm_precision": (c_i, [c_i]),
-    "diffsal_get_gemm_precision": (c_i, []),
     "diffsal_reduce_partials": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_norm_finalize_fwd": (c_i, [c_f] * 7 + [c_i, c_i, c_i, C.c_double, C.c_double] + [c_f] * 4 + [c_fl, c_fl, c_f]),
     "diffsal_norm_finalize_bwd": (c_i, [c_f] * 8 + [c_i, c_i, c_i, C.c_double, c_f]),
@@ -87,6 +91,8 @@ SIGNATURES = {
 }
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+PREC_FP32, PREC_BF16X3 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 
 def library_path():
@@ -103,10 +109,12 @@ def load():
         try:
             _build.build_library()
         except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise RuntimeError(
-                    f"libdiffsal_hip.so is missing and could not be built ({e}); run `python -m diff_sal_amd.build`"
-                ) from e
+            # never bind the current signatures to a binary older than its sources: a changed argument list would be
+            # silent memory corruption on the GPU.  DIFFSAL_NO_REBUILD=1 opts out (the ABI version is still checked).
+            raise RuntimeError(
+                f"libdiffsal_hip.so is {'stale' if os.path.exists(path) else 'missing'} and could not be built ({e}); "
+                "run `python -m diff_sal_amd.build` (or set DIFFSAL_NO_REBUILD=1 to load the existing binary as is)"
+            ) from e
     # PyTorch bundles its own libamdhip64 (same soname as /opt/rocm's).  Import it first so that ONE HIP
     # runtime lives in the process and streams / device pointers are shared with torch.
     import torch  # noqa: F401
@@ -116,6 +124,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    got = lib.diffsal_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path} reports ABI version {got}, the Python binding expects {ABI_VERSION}: "
+                           "rebuild with `python -m diff_sal_amd.build --force`")
     _LIB = lib
     return lib
 

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffsal_hip.so")
-SOURCES = ["igemm.hip", "lin_stream.hip", "wgrad.hip", "backward.hip", "optim.hip", "pack.hip", "norm.hip", "misc.hip"]
+SOURCES = ["igemm.hip", "igemm16.hip", "lin_stream.hip", "wgrad.hip", "backward.hip", "optim.hip", "pack.hip", "norm.hip", "misc.hip"]
 
 
 def _hipcc():
@@ -24,21 +24,25 @@ def needs_build():
         os.path.join(CSRC, "common.h"),
         os.path.join(os.path.dirname(HERE), "include", "diffsal.h"),
     ]
-    return any(os.path.getmtime(d) > t for d in deps)
+    # an installed copy may ship the binary without its sources: nothing to compare against, nothing to rebuild
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into one shared object next to the package."""
     if not force and not needs_build():
         return LIB
-    objs = []
-    for s in SOURCES:
+    objs, procs = [], []
+    for s in SOURCES:  # one hipcc per translation unit, all at once (8 files, a few hundred MB each)
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(o)
+    failed = [cmd for cmd, pr in procs if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

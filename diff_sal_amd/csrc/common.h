@@ -66,6 +66,43 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// 16-bit storage (DIFFSAL_BF16 / DIFFSAL_F16): the same 4-channel accessors on 8-byte runs; arithmetic stays fp32,
+// one round-to-nearest-even on the way out.
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xFFFF0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  const f32x4_t f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<bf16x4_t*>(p) = __builtin_convertvector(f, bf16x4_t);
+}
+__device__ __forceinline__ float4 ld4(const f16_t* p) {
+  const f16x4_t h = *reinterpret_cast<const f16x4_t*>(p);
+  const f32x4_t f = __builtin_convertvector(h, f32x4_t);
+  return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ void st4(f16_t* p, float4 v) {
+  const f32x4_t f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<f16x4_t*>(p) = __builtin_convertvector(f, f16x4_t);
+}
+// 4-element accesses of T need 4 * sizeof(T) alignment
+template <typename T> inline bool aligned_vec4(const T* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
+
+// Run `CALL(T)` with T = the storage type named by a DIFFSAL_F32 / BF16 / F16 code.
+#define DS_DTYPE_DISPATCH(dtype, what, CALL)                                                      \
+  do {                                                                                            \
+    if ((dtype) == DIFFSAL_F32) { CALL(float); }                                                  \
+    else if ((dtype) == DIFFSAL_BF16) { CALL(diffsal::bf16_t); }                                  \
+    else if ((dtype) == DIFFSAL_F16) { CALL(diffsal::f16_t); }                                    \
+    else { diffsal::set_error("%s: dtype %d (DIFFSAL_F32, DIFFSAL_BF16 or DIFFSAL_F16)", what, (dtype)); return DIFFSAL_E_ARG; } \
+  } while (0)
+
 // Source coordinate of a bilinear resize with align_corners=False (PyTorch area_pixel_compute_source_index).
 __device__ __forceinline__ void bilin_coord(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
   float s = (static_cast<float>(dst) + 0.5f) * scale - 0.5f;

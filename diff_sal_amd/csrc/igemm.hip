@@ -25,6 +25,12 @@
 
 namespace diffsal {
 
+// igemm16.hip: the same operator on bf16 / fp16 storage (native 16-bit MFMA)
+size_t igemm16_ws_bytes(const diffsal_conv_desc* d);
+int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                   const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
+                   hipStream_t s);
+
 // lin_stream.hip: barrier-free streaming kernel for short-K, huge-M linear layers
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
                       int K, int N, int act, hipStream_t s);
@@ -528,11 +534,9 @@ struct Plan { int cfg, splits; };
 //   round = max(occ * t_mfma, t_mfma + t_fixed),  time = ceil(workgroups / (256 occ)) * round
 // (+ the slab round trip for split-K).  Short-K GEMMs therefore prefer more, smaller residents;
 // long-K convolutions prefer the widest tile that still fills the chip.
-static int g_gemm_precision = 0;   // 0 = fp32 MFMA (default), 1 = bf16x3 split precision
-
-static Plan choose_plan(long M, int Cout, int K) {
+static Plan choose_plan(long M, int Cout, int K, int precision) {
   // the bf16x3 loop sustains ~2x the fp32 one on large tiles: split-K slabs and fixed latencies weigh twice as much
-  const double mac_per_s_cu = (g_gemm_precision == 1 ? 2.0 : 1.0) * 157.3e12 / 2.0 / kCUs;
+  const double mac_per_s_cu = (precision == DIFFSAL_PREC_BF16X3 ? 2.0 : 1.0) * 157.3e12 / 2.0 / kCUs;
   const double t_fixed = 10e-6;
   const int KT = K / BK;
   Plan best{5, 1};
@@ -559,12 +563,12 @@ static Plan choose_plan(long M, int Cout, int K) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch(IgemmArgs& a, hipStream_t s) {
+static int launch(IgemmArgs& a, hipStream_t s, int precision) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  if (g_gemm_precision == 1)
+  if (precision == DIFFSAL_PREC_BF16X3)
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 1>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 0>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
@@ -591,38 +595,45 @@ static int validate(const diffsal_conv_desc* d) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   DS_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), DIFFSAL_E_SHAPE, "conv_igemm: problem too large");
   DS_REQUIRE(d->KH * d->KW <= 32, DIFFSAL_E_SHAPE, "conv_igemm: at most 32 taps (KH*KW=%d)", d->KH * d->KW);
-  const long in_bytes = static_cast<long>(d->N) * d->H * d->W * d->Cin * 4;
-  const long w_bytes = static_cast<long>(d->Cout) * d->KH * d->KW * d->Cin * 4;
+  DS_REQUIRE(d->precision == DIFFSAL_PREC_FP32 || d->precision == DIFFSAL_PREC_BF16X3, DIFFSAL_E_ARG,
+             "conv_igemm: precision %d (DIFFSAL_PREC_FP32 or DIFFSAL_PREC_BF16X3)", d->precision);
+  DS_REQUIRE(d->dtype == DIFFSAL_F32 || d->dtype == DIFFSAL_BF16 || d->dtype == DIFFSAL_F16, DIFFSAL_E_ARG,
+             "conv_igemm: dtype %d (DIFFSAL_F32, DIFFSAL_BF16 or DIFFSAL_F16)", d->dtype);
+  DS_REQUIRE(d->dtype == DIFFSAL_F32 || (d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0), DIFFSAL_E_ARG,
+             "conv_igemm: 16-bit storage uses the native MFMA (precision and w_format must be 0)");
+  const long esz = d->dtype == DIFFSAL_F32 ? 4 : 2;
+  const long in_bytes = static_cast<long>(d->N) * d->H * d->W * d->Cin * esz;
+  const long w_bytes = static_cast<long>(d->Cout) * d->KH * d->KW * d->Cin * esz;
   DS_REQUIRE(in_bytes < (1L << 32) - 16 && w_bytes < (1L << 32) - 16, DIFFSAL_E_SHAPE,
              "conv_igemm: input (%ld B) and weight (%ld B) must each stay below 4 GiB (32-bit buffer offsets); "
              "split the batch", in_bytes, w_bytes);
   return DIFFSAL_OK;
 }
 
-extern "C" int diffsal_set_gemm_precision(int mode) {
-  DS_REQUIRE(mode == 0 || mode == 1, DIFFSAL_E_ARG, "set_gemm_precision: mode %d (0 = fp32, 1 = bf16x3)", mode);
-  diffsal::g_gemm_precision = mode;
-  return DIFFSAL_OK;
-}
-
-extern "C" int diffsal_get_gemm_precision(void) { return diffsal::g_gemm_precision; }
-
 extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (validate(d) != DIFFSAL_OK) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
-  const Plan pl = choose_plan(M, d->Cout, d->KH * d->KW * d->Cin);
+  if (d->dtype != DIFFSAL_F32) return igemm16_ws_bytes(d);
+  const Plan pl = choose_plan(M, d->Cout, d->KH * d->KW * d->Cin, d->precision);
   return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
 }
 
-extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, const float* w,
+extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, const void* w_v,
                                   const float* bias, const float* scale, const float* shift,
-                                  const float* rowvec, const float* residual, float* out, void* ws,
+                                  const float* rowvec, const void* residual_v, void* out_v, void* ws,
                                   size_t ws_bytes, diffsal_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
-  DS_REQUIRE(in && w && out, DIFFSAL_E_ARG, "conv_igemm: null argument");
+  DS_REQUIRE(in_v && w_v && out_v, DIFFSAL_E_ARG, "conv_igemm: null argument");
   DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "conv_igemm: scale and shift go together");
-  DS_REQUIRE(aligned16(in) && aligned16(w), DIFFSAL_E_ALIGN, "conv_igemm: in/w must be 16-byte aligned");
+  DS_REQUIRE(aligned16(in_v) && aligned16(w_v), DIFFSAL_E_ALIGN, "conv_igemm: in/w must be 16-byte aligned");
+  if (d->dtype != DIFFSAL_F32)
+    return igemm16_launch(d, in_v, w_v, bias, scale, shift, rowvec, residual_v, out_v, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream));
+  const float* in = static_cast<const float*>(in_v);
+  const float* w = static_cast<const float*>(w_v);
+  const float* residual = static_cast<const float*>(residual_v);
+  float* out = static_cast<float*>(out_v);
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
 
   IgemmArgs a;
@@ -634,8 +645,8 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
-  DS_REQUIRE(d->w_format == 0 || (d->w_format == 1 && diffsal::g_gemm_precision == 1), DIFFSAL_E_ARG,
-             "conv_igemm: w_format=%d needs the bf16x3 GEMM precision (diffsal_set_gemm_precision(1))", d->w_format);
+  DS_REQUIRE(d->w_format == 0 || (d->w_format == 1 && d->precision == DIFFSAL_PREC_BF16X3), DIFFSAL_E_ARG,
+             "conv_igemm: w_format=%d needs precision = DIFFSAL_PREC_BF16X3 in the descriptor", d->w_format);
   a.w_split = d->w_format;
   a.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
   a.w_bytes = static_cast<unsigned>(static_cast<long>(d->Cout) * a.K * 4);
@@ -646,7 +657,7 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
-  Plan pl = choose_plan(M, d->Cout, a.K);
+  Plan pl = choose_plan(M, d->Cout, a.K, d->precision);
   if (const char* e = getenv("DIFFSAL_IGEMM_CFG")) {   // tuning aid: force a tile shape (no split-K)
     pl.cfg = atoi(e) % kNumCfgs;
     pl.splits = 1;
@@ -662,11 +673,11 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const float* in, c
     a.partial = static_cast<float*>(ws);
   }
   switch (pl.cfg) {
-    case 0: return launch<2, 2, 2, 3>(a, s);
-    case 1: return launch<2, 2, 2, 2>(a, s);
-    case 2: return launch<4, 1, 1, 3>(a, s);
-    case 3: return launch<2, 2, 1, 2>(a, s);
-    case 4: return launch<2, 2, 2, 1>(a, s);
-    default: return launch<2, 2, 1, 1>(a, s);
+    case 0: return launch<2, 2, 2, 3>(a, s, d->precision);
+    case 1: return launch<2, 2, 2, 2>(a, s, d->precision);
+    case 2: return launch<4, 1, 1, 3>(a, s, d->precision);
+    case 3: return launch<2, 2, 1, 2>(a, s, d->precision);
+    case 4: return launch<2, 2, 2, 1>(a, s, d->precision);
+    default: return launch<2, 2, 1, 1>(a, s, d->precision);
   }
 }

@@ -1,0 +1,453 @@
+// Implicit-GEMM convolution / linear layer on bf16 / fp16 STORAGE (BASELINE configs[1] "bf16", configs[4] "fp16"):
+// activations, weights, residual and output are 16-bit in HBM, products run on the native 16-bit matrix cores
+// (v_mfma_f32_32x32x16_{bf16,f16}) and accumulate in fp32; bias / BN affine / per-image vector stay fp32 and are
+// applied to the fp32 accumulator before the single rounding to the storage type.
+//
+// Same operator, same im2col k order (ci/32, tap, ci%32) and same packed weight layout [Cout][K] as igemm.hip (the fp32
+// kernel); what changes is the geometry of a K stage.  A 32-channel run of one pixel is 64 bytes here, so ONE LDS stage
+// row holds TWO consecutive 32-k sub-slices (128 bytes, the same bytes per row and the same 36-dword pitch as the fp32
+// kernel: conflict-free ds_read_b128).  The 8 loader lanes of a row split 4 + 4 over the two sub-slices, each half
+// with its own (tap, channel-chunk) displacement; the matrix-core loop then runs four 16-wide k-steps per stage, one
+// ds_read_b128 per 32-row fragment and step.  Half the HBM bytes and 1/8 of the matrix-pipe time of the fp32 kernel.
+//
+// Replaces the same reference call sites as diffsal_conv_igemm (see include/diffsal.h); selected by
+// diffsal_conv_desc.dtype.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace diffsal {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mma16;
+template <> struct Mma16<__bf16> {
+  typedef bf16x8 vec;
+  static __device__ __forceinline__ f32x16 run(vec a, vec b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<_Float16> {
+  typedef f16x8 vec;
+  static __device__ __forceinline__ f32x16 run(vec a, vec b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+struct Igemm16Args {
+  const T* in;
+  const T* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* rowvec;
+  const T* residual;
+  T* out;
+  int M, K;
+  int H, W, Cin, Ho, Wo, Cout;
+  int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
+  int act, rowvec_ld;
+  int n_tiles_n, n_tiles;
+  unsigned in_bytes, w_bytes;
+  int splits, st_per_split;  // split-K over 64-k stages
+  float* partial;            // [splits][M][Cout] fp32 partial sums when splits > 1
+};
+
+constexpr int SUBK = 32;            // elements per sub-slice (one 64-byte run of a pixel)
+constexpr int STK = 2 * SUBK;       // elements per LDS stage row
+constexpr int PITCH16 = 36;         // dwords per LDS row (32 data + 4 pad)
+
+template <int WM, int WN, int TM, int TN, typename T>
+__global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
+  typedef typename Mma16<T>::vec frag_t;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_PASSES = BM / 32;
+  constexpr int B_PASSES = BN / 32;
+  constexpr int STAGE = (BM + BN) * PITCH16;  // dwords per LDS stage
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  int tile;
+  const int split = blockIdx.y;
+  {  // XCD-aware order: each XCD owns a contiguous run of tiles (see igemm.hip)
+    const int nwg = p.n_tiles;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tile_m = tile / p.n_tiles_n;
+  const int tile_n = tile - tile_m * p.n_tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // loader: 8 lanes per row; lanes 0-3 fetch sub-slice 0 (4 x 16 B = 32 elements), lanes 4-7 sub-slice 1
+  const int lrow = tid >> 3;
+  const int l8 = tid & 7;
+  const int lsub = l8 >> 2;
+  const int lcol_dw = l8 * 4;  // dword column inside the LDS row
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(p.w), 0, static_cast<int>(p.w_bytes), 0x00020000);
+
+  unsigned a_voff[A_PASSES];
+  unsigned a_valid[A_PASSES];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) {
+    int m = m0 + lrow + 32 * j;
+    m = m < p.M ? m : p.M - 1;
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride_h - p.pad_t;
+    const int ix0 = ox * p.stride_w - p.pad_l;
+    a_voff[j] = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + (l8 & 3) * 8) * 2u;
+    unsigned bits = 0;
+    for (int t = 0; t < p.taps; ++t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      const int iy = iy0 + ky * p.dil_h, ix = ix0 + kx * p.dil_w;
+      bits |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) ? (1u << t) : 0u;
+    }
+    a_valid[j] = bits;
+  }
+  unsigned b_voff[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    int n = n0 + lrow + 32 * j;
+    n = n < p.Cout ? n : p.Cout - 1;
+    b_voff[j] = static_cast<unsigned>(n * p.K + l8 * 8) * 2u;
+  }
+
+  float4 ra[A_PASSES], rb[B_PASSES];
+  const int KT32 = p.K / SUBK;                 // sub-slices in K
+  const int n_stages = (KT32 + 1) / 2;
+  const int st_begin = split * p.st_per_split;
+  const int st_end = min(n_stages, st_begin + p.st_per_split);
+  const int nst = st_end - st_begin;
+
+  auto issue_loads = [&](int st, bool live) {
+    // the two sub-slices of this stage: wave-uniform scalars, then a per-lane pick
+    const int k0 = 2 * st, k1 = 2 * st + 1;
+    const int c0 = k0 / p.taps, t0 = k0 - c0 * p.taps;
+    const int c1 = k1 / p.taps, t1 = k1 - c1 * p.taps;
+    const int ky0 = t0 / p.KW, kx0 = t0 - ky0 * p.KW;
+    const int ky1 = t1 / p.KW, kx1 = t1 - ky1 * p.KW;
+    const unsigned d0 = static_cast<unsigned>((ky0 * p.dil_h * p.W + kx0 * p.dil_w) * p.Cin + c0 * SUBK) * 2u;
+    const unsigned d1 = static_cast<unsigned>((ky1 * p.dil_h * p.W + kx1 * p.dil_w) * p.Cin + c1 * SUBK) * 2u;
+    const unsigned dead0 = (live && k0 < KT32) ? 0u : 0xFFFFFFFFu;
+    const unsigned dead1 = (live && k1 < KT32) ? 0u : 0xFFFFFFFFu;
+    const unsigned delta = lsub ? d1 : d0;
+    const unsigned dead = lsub ? dead1 : dead0;
+    const int tap = lsub ? t1 : t0;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) {
+      const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;
+      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[j] + delta) | oob | dead, 0, 0));
+    }
+    const unsigned kofs = static_cast<unsigned>(st * STK) * 2u;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
+  };
+  auto store_tile = [&](float* stage) {
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH16 + lcol_dw], ra[j]);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH16 + lcol_dw], rb[j]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment of k-step kk (16 elements = 8 dwords of the row): lane half h supplies elements 8h .. 8h+7 of the step
+  const int frow = lane & 31;
+  const int fk = (lane >> 5) * 4;
+  const int a_frag = (wm * TM * 32 + frow) * PITCH16 + fk;
+  const int b_frag = (BM + wn * TN * 32 + frow) * PITCH16 + fk;
+  float4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](const float* stage, int kk, int set) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = ld4(stage + a_frag + i * 32 * PITCH16 + kk * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[set][j] = ld4(stage + b_frag + j * 32 * PITCH16 + kk * 8);
+  };
+  auto do_mfmas = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = Mma16<T>::run(__builtin_bit_cast(frag_t, fa[set][i]), __builtin_bit_cast(frag_t, fb[set][j]), acc[i][j]);
+  };
+
+  // prologue: stages 0 and 1 in flight together
+  issue_loads(st_begin + 1, nst > 1);
+  float4 ta[A_PASSES], tb[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) ta[j] = ra[j];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) tb[j] = rb[j];
+  issue_loads(st_begin, true);
+  store_tile(smem);
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) ra[j] = ta[j];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) rb[j] = tb[j];
+  __syncthreads();
+  load_frags(smem, 0, 0);
+  for (int it = 0; it < nst; ++it) {
+    float* cur = smem + (it & 1) * STAGE;
+    float* nxt = smem + ((it & 1) ^ 1) * STAGE;
+    load_frags(cur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    store_tile(nxt);
+    issue_loads(st_begin + it + 2, it + 2 < nst);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every read of `cur` and every write of `nxt` has been issued
+    load_frags(nxt, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+  if (p.splits > 1) {
+    float* part = p.partial + static_cast<long>(split) * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + col_l;
+      if (n >= p.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + (wm * TM + i) * 32 + row_h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) part[static_cast<long>(m) * p.Cout + n] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
+  const T* __restrict__ resid = p.residual;
+  const float* __restrict__ rowv = p.rowvec;
+  T* __restrict__ outp = p.out;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + col_l;
+    if (n >= p.Cout) continue;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + (wm * TM + i) * 32 + row_h;
+      float res[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = mb + (r & 3) + 8 * (r >> 2);
+        m = m < p.M ? m : p.M - 1;
+        res[r] = resid ? static_cast<float>(resid[static_cast<long>(m) * p.Cout + n]) : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        v += bi;
+        if (p.scale) v = v * sc + sh;
+        if (rowv) v += rowv[static_cast<long>(m / HoWo) * p.rowvec_ld + n];
+        if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
+        else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
+        v += res[r];
+        outp[static_cast<long>(m) * p.Cout + n] = static_cast<T>(v);
+      }
+    }
+  }
+}
+
+// Sum the fp32 split-K slabs in a fixed order, apply the epilogue, round once to the storage type.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk16_reduce_kernel(Igemm16Args<T> p) {
+  const int n4 = p.Cout >> 2;
+  const long total = static_cast<long>(p.M) * n4;
+  const long slab = static_cast<long>(p.M) * p.Cout;
+  const int HoWo = p.Ho * p.Wo;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int n = static_cast<int>(i % n4) * 4;
+    const long m = i / n4;
+    const long o = m * p.Cout + n;
+    float4 a = ld4(p.partial + o);
+    for (int s = 1; s < p.splits; ++s) {
+      const float4 b = ld4(p.partial + s * slab + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    float4 rs = make_float4(0, 0, 0, 0);
+    if (p.residual) rs = ld4(p.residual + o);
+    const float rr[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j];
+      if (p.bias) x += p.bias[n + j];
+      if (p.scale) x = x * p.scale[n + j] + p.shift[n + j];
+      if (p.rowvec) x += p.rowvec[(m / HoWo) * p.rowvec_ld + n + j];
+      if (p.act == DIFFSAL_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (p.act == DIFFSAL_ACT_GELU_ERF) x = gelu_erf(x);
+      else if (p.act == DIFFSAL_ACT_SIGMOID) x = sigmoidf_(x);
+      v[j] = x + rr[j];
+    }
+    st4(p.out + o, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
+struct TileCfg16 { int bm, bn, occ; float eff; };
+// order must match the dispatch switch below
+static const TileCfg16 kCfgs16[] = {{128, 192, 1, 0.80f}, {128, 128, 2, 0.75f}, {128, 96, 2, 0.65f}, {64, 128, 2, 0.60f},
+                                    {128, 64, 2, 0.60f},  {64, 64, 4, 0.50f},   {256, 96, 1, 0.80f},  {256, 128, 1, 0.85f}};
+constexpr int kNumCfgs16 = 8;
+constexpr int kCUs16 = 256;
+
+struct Plan16 { int cfg, splits; };
+
+// Same analytic model as igemm.hip's planner with the 16-bit matrix rate (2.5 PFLOP/s dense); `eff` folds in the
+// LDS-bandwidth limit of the narrower wave tiles (reads per MFMA), fixed latencies weigh 16x more than in fp32.
+static Plan16 choose_plan16(long M, int Cout, int K) {
+  const double mac_per_s_cu = 2.5e15 / 2.0 / kCUs16;
+  const double t_fixed = 6e-6;
+  const int NST = (K / SUBK + 1) / 2;
+  Plan16 best{5, 1};
+  double best_t = 1e30;
+  for (int c = 0; c < kNumCfgs16; ++c) {
+    const TileCfg16& t = kCfgs16[c];
+    if (t.bn > Cout && t.bn - Cout >= 32 && c != 5) continue;
+    const long tiles = ((M + t.bm - 1) / t.bm) * ((Cout + t.bn - 1) / t.bn);
+    for (int S = 1; S <= 16; S *= 2) {
+      if (S > 1 && (NST / S < 4 || Cout % 4 != 0)) break;
+      const long wgs = tiles * S;
+      const long slots = static_cast<long>(kCUs16) * t.occ;
+      const double rounds = static_cast<double>((wgs + slots - 1) / slots);
+      const int st_per = (NST + S - 1) / S;
+      const double t_mfma = static_cast<double>(t.bm) * t.bn * (st_per * STK) / (mac_per_s_cu * t.eff);
+      const double resident = static_cast<double>(wgs < slots ? (wgs + kCUs16 - 1) / kCUs16 : t.occ);
+      const double round = resident * t_mfma > t_mfma + t_fixed ? resident * t_mfma : t_mfma + t_fixed;
+      double tt = rounds * round;
+      if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6;
+      if (tt < best_t) { best_t = tt; best = Plan16{c, S}; }
+    }
+  }
+  return best;
+}
+
+template <int WM, int WN, int TM, int TN, typename T>
+static int launch16(Igemm16Args<T>& a, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  a.n_tiles_n = (a.Cout + BN - 1) / BN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  a.n_tiles = a.n_tiles_n * tiles_m;
+  hipLaunchKernelGGL((igemm16_kernel<WM, WN, TM, TN, T>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  int rc = check_launch("diffsal_conv_igemm(16-bit)");
+  if (rc || a.splits == 1) return rc;
+  const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
+  long g = (total4 + 255) / 256;
+  g = g > 2048 ? 2048 : g;
+  hipLaunchKernelGGL((splitk16_reduce_kernel<T>), dim3(static_cast<int>(g)), dim3(256), 0, s, a);
+  return check_launch("diffsal_conv_igemm(16-bit split-K reduce)");
+}
+
+static Plan16 plan_for(const diffsal_conv_desc* d) {
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  Plan16 pl = choose_plan16(M, d->Cout, d->KH * d->KW * d->Cin);
+  if (const char* e = getenv("DIFFSAL_IGEMM16_CFG")) {  // tuning aid: force a tile shape (no split-K)
+    pl.cfg = atoi(e) % kNumCfgs16;
+    pl.splits = 1;
+  }
+  return pl;
+}
+
+size_t igemm16_ws_bytes(const diffsal_conv_desc* d) {
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  const Plan16 pl = plan_for(d);
+  return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
+}
+
+template <typename T>
+static int run16(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
+                 hipStream_t s) {
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  Igemm16Args<T> a;
+  a.in = static_cast<const T*>(in); a.w = static_cast<const T*>(w); a.bias = bias; a.scale = scale; a.shift = shift;
+  a.rowvec = rowvec; a.residual = static_cast<const T*>(residual); a.out = static_cast<T*>(out);
+  a.M = static_cast<int>(M);
+  a.K = d->KH * d->KW * d->Cin;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
+  a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
+  a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
+  a.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 2);
+  a.w_bytes = static_cast<unsigned>(static_cast<long>(d->Cout) * a.K * 2);
+  const Plan16 pl = plan_for(d);
+  a.splits = pl.splits;
+  const int n_stages = (a.K / SUBK + 1) / 2;
+  a.st_per_split = (n_stages + pl.splits - 1) / pl.splits;
+  a.partial = nullptr;
+  if (pl.splits > 1) {
+    const size_t need = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
+    DS_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
+                   (!residual || (reinterpret_cast<uintptr_t>(residual) & 7u) == 0),
+               DIFFSAL_E_ARG,
+               "conv_igemm(16-bit): split-K needs %zu bytes of 16-byte aligned workspace (diffsal_conv_igemm_ws_bytes), got %zu",
+               need, ws_bytes);
+    a.partial = static_cast<float*>(ws);
+  }
+  switch (pl.cfg) {
+    case 0: return launch16<2, 2, 2, 3, T>(a, s);
+    case 1: return launch16<2, 2, 2, 2, T>(a, s);
+    case 2: return launch16<4, 1, 1, 3, T>(a, s);
+    case 3: return launch16<2, 2, 1, 2, T>(a, s);
+    case 4: return launch16<2, 2, 2, 1, T>(a, s);
+    case 6: return launch16<4, 1, 2, 3, T>(a, s);
+    case 7: return launch16<4, 1, 2, 4, T>(a, s);
+    default: return launch16<2, 2, 1, 1, T>(a, s);
+  }
+}
+
+int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                   const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
+                   hipStream_t s) {
+  if (d->dtype == DIFFSAL_BF16)
+    return run16<__bf16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s);
+  return run16<_Float16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s);
+}
+
+}  // namespace diffsal

@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
 // With skip_mod = s only rows/columns with index % s != s-1 are produced (the stride-s 3x3 consumer
 // never reads the others).
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                      const float* __restrict__ bias, T* __restrict__ out, int B,
                                                       int H, int W, int C, int skip_mod, int Hn, int Wn) {
   const int c4n = C >> 2;
   const int ppb = 256 / c4n;  // pixels per pass
@@ -113,8 +114,9 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 // K6: NCTHW -> frames-of-NHWC transpose through a 64x65 LDS tile, plus the noise map as last frame.
 // vis [B][C][Q], Q = Tv*hw  ->  out [B][Tout*hw][C] (first Q rows); noise [B][hw][C] -> rows Tv*hw...
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restrict__ vis, const float* __restrict__ noise,
-                                                          float* __restrict__ out, int C, int Q, int hw, int Tout,
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restrict__ vis, const T* __restrict__ noise,
+                                                          T* __restrict__ out, int C, int Q, int hw, int Tout,
                                                           int tiles_q, int tiles_c, int n_transpose_blocks) {
   __shared__ float tile[64][65];
   const int b = blockIdx.y;
@@ -131,13 +133,13 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restric
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {  // r: q within tile, tx: channel (contiguous writes)
       const int q = q0 + r, c = c0 + tx;
-      if (q < Q && c < C) out[out_b + static_cast<long>(q) * C + c] = tile[tx][r];
+      if (q < Q && c < C) out[out_b + static_cast<long>(q) * C + c] = static_cast<T>(tile[tx][r]);
     }
   } else if (noise) {
     const int nb = gridDim.x - n_transpose_blocks;
     const long n4 = static_cast<long>(hw) * C / 4;
-    const float* src = noise + static_cast<long>(b) * hw * C;
-    float* dst = out + out_b + static_cast<long>(Q) * C;
+    const T* src = noise + static_cast<long>(b) * hw * C;
+    T* dst = out + out_b + static_cast<long>(Q) * C;
     for (long i = static_cast<long>(blockIdx.x - n_transpose_blocks) * 256 + threadIdx.x; i < n4;
          i += static_cast<long>(nb) * 256)
       st4(dst + i * 4, ld4(src + i * 4));
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // bilinear resize (align_corners=False) on NHWC.  R/.../common_block.py:197; sal_unet.py:325-327,482-484
 // ------------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int h,
+template <int VEC, typename T>
+__global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int h,
                                                      int w, int H, int W, int C, float sy, float sx) {
   const int cv = C / VEC;
   const long total = static_cast<long>(N) * H * W * cv;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     bilin_coord(Y, sy, h, y0, y1, ly);
     bilin_coord(X, sx, w, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* b = in + static_cast<long>(n) * h * w * C + c;
+    const T* b = in + static_cast<long>(n) * h * w * C + c;
     const long o = ((static_cast<long>(n) * H + Y) * W + X) * C + c;
     if constexpr (VEC == 4) {
       const float4 v00 = ld4(b + (static_cast<long>(y0) * w + x0) * C), v01 = ld4(b + (static_cast<long>(y0) * w + x1) * C);
@@ -176,15 +178,15 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
       r.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
       st4(out + o, r);
     } else {
-      const float v00 = b[(static_cast<long>(y0) * w + x0) * C], v01 = b[(static_cast<long>(y0) * w + x1) * C];
-      const float v10 = b[(static_cast<long>(y1) * w + x0) * C], v11 = b[(static_cast<long>(y1) * w + x1) * C];
-      out[o] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      const float v00 = static_cast<float>(b[(static_cast<long>(y0) * w + x0) * C]), v01 = static_cast<float>(b[(static_cast<long>(y0) * w + x1) * C]);
+      const float v10 = static_cast<float>(b[(static_cast<long>(y1) * w + x0) * C]), v11 = static_cast<float>(b[(static_cast<long>(y1) * w + x1) * C]);
+      out[o] = static_cast<T>(hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
     }
   }
 }
 
 struct ResizeSumArgs {
-  const float* in[4];
+  const void* in[4];  // T* of the launch's storage type
   int h[4], w[4];
   float sy[4], sx[4];
   int n_in;
@@ -196,8 +198,8 @@ struct ResizeSumArgs {
 // 4 (factor 2) source rows/columns, so the NR x NR source window is loaded ONCE and reused for all 16 outputs:
 // 2 loads per output instead of 16 -- the naive form is bound by L1/L2 request rate, not by HBM.
 // All coordinates / weights are wave-uniform scalars.
-template <int NR>
-__device__ __forceinline__ void patch_accumulate(const float* __restrict__ in, int n, int h, int w, int C, int Y0,
+template <int NR, typename T>
+__device__ __forceinline__ void patch_accumulate(const T* __restrict__ in, int n, int h, int w, int C, int Y0,
                                                  int X0, float sy, float sx, int c, float4 (&acc)[4][4]) {
   float wy[4][NR], wx[4][NR];
   int ry0 = 0, rx0 = 0;
@@ -215,7 +217,7 @@ __device__ __forceinline__ void patch_accumulate(const float* __restrict__ in, i
     }
   }
   float4 win[NR][NR];
-  const float* base = in + static_cast<long>(n) * h * w * C + c;
+  const T* base = in + static_cast<long>(n) * h * w * C + c;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int yy = min(ry0 + i, h - 1);
@@ -254,7 +256,8 @@ __device__ __forceinline__ void patch_accumulate(const float* __restrict__ in, i
 // out = ((in0^ + in1^) + in2^) + in3^, x^ = bilinear resize of x to (H, W): one write of the big map.
 // Requires H, W multiples of 4 and every input an integer factor (2, 4, 8, ...) smaller; n_in = 1 is the
 // plain resize.  R/.../sal_unet.py:482-487, common_block.py:197.
-__global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float* __restrict__ out, int H, int W, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, T* __restrict__ out, int H, int W, int C,
                                                          int w_patches, long n_patches) {
   const int lane = threadIdx.x & 63;
   const long patch = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -274,9 +277,10 @@ __global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float*
     for (int s = 0; s < 4; ++s) {
       if (s < a.n_in) {
         const int f = H / a.h[s];  // wave-uniform
-        if (f >= 8) patch_accumulate<2>(a.in[s], n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
-        else if (f == 4) patch_accumulate<3>(a.in[s], n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
-        else patch_accumulate<4>(a.in[s], n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
+        const T* src = static_cast<const T*>(a.in[s]);
+        if (f >= 8) patch_accumulate<2, T>(src, n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
+        else if (f == 4) patch_accumulate<3, T>(src, n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
+        else patch_accumulate<4, T>(src, n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
       }
     }
 #pragma unroll
@@ -288,7 +292,8 @@ __global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, float*
 }
 
 // General fallback (any sizes): one wavefront per output pixel.
-__global__ __launch_bounds__(256) void resize_sum_generic_kernel(ResizeSumArgs a, float* __restrict__ out, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_sum_generic_kernel(ResizeSumArgs a, T* __restrict__ out, int H, int W,
                                                                  int C, int w_tiles) {
   int bid = blockIdx.x;
   const int xt = bid % w_tiles; bid /= w_tiles;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void resize_sum_generic_kernel(ResizeSumArgs a
         bilin_coord(Y, a.sy[s], h, y0, y1, ly);
         bilin_coord(X, a.sx[s], w, x0, x1, lx);
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* b = a.in[s] + static_cast<long>(n) * h * w * C + c;
+        const T* b = static_cast<const T*>(a.in[s]) + static_cast<long>(n) * h * w * C + c;
         const float4 v00 = ld4(b + (static_cast<long>(y0) * w + x0) * C), v01 = ld4(b + (static_cast<long>(y0) * w + x1) * C);
         const float4 v10 = ld4(b + (static_cast<long>(y1) * w + x0) * C), v11 = ld4(b + (static_cast<long>(y1) * w + x1) * C);
         acc.x += hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
@@ -330,8 +335,9 @@ __global__ __launch_bounds__(256) void resize_sum_generic_kernel(ResizeSumArgs a
 // reads of x), waves/iterations = x positions; the W-long rows are transposed through LDS so the
 // NCTHW stores are W-contiguous.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void audio_fuse_kernel(const float* __restrict__ a_small, const float* __restrict__ x,
-                                                         float* __restrict__ out, int T, int H, int W, int C, int h, int w,
+template <typename TT>
+__global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ a_small, const TT* __restrict__ x,
+                                                         TT* __restrict__ out, int T, int H, int W, int C, int h, int w,
                                                          int up) {
   extern __shared__ float sh[];  // s[32][W+1]
   const int WP = W + 1;
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const float* __restrict
     const int xs = xx / up;
     float s = 0.f;
     for (int t = 0; t < T; ++t) {
-      const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c];
-      const float xv = x[(((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c];
+      const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c]);
+      const float xv = static_cast<float>(x[(((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c]);
       s = fmaf(av, xv, s);
     }
     sh[cl * WP + xx] = s / static_cast<float>(T);
@@ -380,8 +386,8 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const float* __restrict
     const int t = (i / W) % T;
     const int cc = i / (W * T);
     const int cg = cs * 32 + cc;
-    const float av = a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xx / up) * C + cg];
-    out[(((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx] = av * sh[cc * WP + xx];
+    const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xx / up) * C + cg]);
+    out[(((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx] = static_cast<TT>(av * sh[cc * WP + xx]);
   }
 }
 
@@ -394,9 +400,9 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const float* __restrict
 // address (broadcast), different g read neighbouring 16-byte slots (conflict-free).
 // FLOPs are 0.4 % of a step: the kernel is bound by the q / o traffic.
 // ------------------------------------------------------------------------------------------------
-template <int LK, int G>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                        const float* __restrict__ v, float* __restrict__ o, int Lq,
+template <int LK, int G, typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ v, T* __restrict__ o, int Lq,
                                                         int Lk, int C, int heads, float scale) {
   extern __shared__ float sh[];  // K[Lk][C] | V[Lk][C]
   float* Ks = sh;
@@ -417,8 +423,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int lc = valid ? l : Lq - 1;  // out-of-range lanes stay alive for the shuffles
   const int d = C / heads, nf4 = d >> 2;
   const int cb = hd * d;
-  const float* qr = q + (static_cast<long>(n) * Lq + lc) * C + cb;
-  float* orow = o + (static_cast<long>(n) * Lq + lc) * C + cb;
+  const T* qr = q + (static_cast<long>(n) * Lq + lc) * C + cb;
+  T* orow = o + (static_cast<long>(n) * Lq + lc) * C + cb;
   float sc[LK];
 #pragma unroll
   for (int t = 0; t < LK; ++t) sc[t] = 0.f;
@@ -459,7 +465,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 }
 
 // K14 tail: per-pixel dot with w[C] + sigmoid; G lanes per pixel.
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, long NHW,
                                                    int C) {
   const int gl = threadIdx.x & 7, gr = threadIdx.x >> 3;  // 8 lanes per pixel, 32 pixels per block
@@ -485,6 +492,13 @@ __global__ __launch_bounds__(256) void axpbypcz_kernel(const float* __restrict__
   }
 }
 
+// storage-type conversion (weights once per parameter version; fp32 <-> bf16 / fp16), round to nearest even
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n) {
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * 256)
+    dst[i] = static_cast<D>(static_cast<float>(src[i]));
+}
+
 static int ew_grid(long total_threads) {
   long g = (total_threads + 255) / 256;
   return static_cast<int>(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -494,7 +508,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 1; }
+extern "C" int diffsal_version(void) { return 2; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
@@ -524,8 +538,8 @@ extern "C" int diffsal_dense_small(const float* in, int B, int K, int swish_in, 
   return check_launch("dense_small");
 }
 
-extern "C" int diffsal_conv_in(const float* x, const float* w, const float* bias, float* out, int B, int H, int W,
-                               int C, int skip_mod, diffsal_stream_t stream) {
+extern "C" int diffsal_conv_in(const float* x, const float* w, const float* bias, void* out, int B, int H, int W,
+                               int C, int skip_mod, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(x && w && bias && out, DIFFSAL_E_ARG, "conv_in: null argument");
   DS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "conv_in: bad shape");
   DS_REQUIRE(aligned16(out), DIFFSAL_E_ALIGN, "conv_in: misaligned output");
@@ -536,13 +550,16 @@ extern "C" int diffsal_conv_in(const float* x, const float* w, const float* bias
   const int ppb = 256 / (C / 4);
   long g = (static_cast<long>(B) * Hn * Wn + ppb - 1) / ppb;
   g = g > 8192 ? 8192 : g;
-  hipLaunchKernelGGL(conv_in_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w,
-                     bias, out, B, H, W, C, skip_mod, Hn, Wn);
+#define CALL(T)                                                                                                     \
+  hipLaunchKernelGGL((conv_in_kernel<T>), dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x, \
+                     w, bias, static_cast<T*>(out), B, H, W, C, skip_mod, Hn, Wn)
+  DS_DTYPE_DISPATCH(dtype, "conv_in", CALL);
+#undef CALL
   return check_launch("conv_in");
 }
 
-extern "C" int diffsal_pack_frames(const float* vis, const float* noise, float* out, int B, int C, int Tv, int Tout,
-                                   int hw, diffsal_stream_t stream) {
+extern "C" int diffsal_pack_frames(const float* vis, const void* noise, void* out, int B, int C, int Tv, int Tout,
+                                   int hw, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(vis && out, DIFFSAL_E_ARG, "pack_frames: null argument");
   DS_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && Tv > 0 && hw > 0 && Tout >= Tv + (noise ? 1 : 0), DIFFSAL_E_SHAPE,
              "pack_frames: bad shape C=%d Tv=%d Tout=%d hw=%d", C, Tv, Tout, hw);
@@ -551,17 +568,17 @@ extern "C" int diffsal_pack_frames(const float* vis, const float* noise, float* 
   const int tiles_q = (Q + 63) / 64, tiles_c = (C + 63) / 64;
   const int ntb = tiles_q * tiles_c;
   const int copy_blocks = noise ? ew_grid(static_cast<long>(hw) * C / 4) : 0;
-  hipLaunchKernelGGL(pack_frames_kernel, dim3(ntb + copy_blocks, B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     vis, noise, out, C, Q, hw, Tout, tiles_q, tiles_c, ntb);
+#define CALL(T)                                                                                                    \
+  hipLaunchKernelGGL((pack_frames_kernel<T>), dim3(ntb + copy_blocks, B), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                     vis, static_cast<const T*>(noise), static_cast<T*>(out), C, Q, hw, Tout, tiles_q, tiles_c, ntb)
+  DS_DTYPE_DISPATCH(dtype, "pack_frames", CALL);
+#undef CALL
   return check_launch("pack_frames");
 }
 
-extern "C" int diffsal_resize_bilinear(const float* in, float* out, int N, int h, int w, int H, int W, int C,
-                                       diffsal_stream_t stream) {
-  DS_REQUIRE(in && out, DIFFSAL_E_ARG, "resize_bilinear: null argument");
-  DS_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, DIFFSAL_E_SHAPE, "resize_bilinear: bad shape");
+template <typename T>
+static void resize_bilinear_t(const T* in, T* out, int N, int h, int w, int H, int W, int C, hipStream_t s) {
   const float sy = static_cast<float>(h) / static_cast<float>(H), sx = static_cast<float>(w) / static_cast<float>(W);
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const int f = H / h;
   // x2 is cheaper with one thread per output (4 loads, mostly L1 hits); the patch form pays from x4 up
   if (C % 4 == 0 && aligned16(in) && aligned16(out) && H % 4 == 0 && W % 4 == 0 && f >= 4 && (f & (f - 1)) == 0 &&
@@ -570,20 +587,30 @@ extern "C" int diffsal_resize_bilinear(const float* in, float* out, int N, int h
     a.n_in = 1;
     for (int i = 0; i < 4; ++i) { a.in[i] = in; a.h[i] = h; a.w[i] = w; a.sy[i] = sy; a.sx[i] = sx; }
     const long n_patches = static_cast<long>(N) * (H / 4) * (W / 4);
-    hipLaunchKernelGGL(resize_sum_kernel, dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a, out, H, W, C,
-                       W / 4, n_patches);
+    hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a, out, H, W,
+                       C, W / 4, n_patches);
   } else if (C % 4 == 0 && aligned16(in) && aligned16(out)) {
     const long total = static_cast<long>(N) * H * W * (C / 4);
-    hipLaunchKernelGGL((resize_kernel<4>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
+    hipLaunchKernelGGL((resize_kernel<4, T>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
   } else {
     const long total = static_cast<long>(N) * H * W * C;
-    hipLaunchKernelGGL((resize_kernel<1>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
+    hipLaunchKernelGGL((resize_kernel<1, T>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
   }
+}
+
+extern "C" int diffsal_resize_bilinear(const void* in, void* out, int N, int h, int w, int H, int W, int C, int dtype,
+                                       diffsal_stream_t stream) {
+  DS_REQUIRE(in && out, DIFFSAL_E_ARG, "resize_bilinear: null argument");
+  DS_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, DIFFSAL_E_SHAPE, "resize_bilinear: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(T) resize_bilinear_t<T>(static_cast<const T*>(in), static_cast<T*>(out), N, h, w, H, W, C, s)
+  DS_DTYPE_DISPATCH(dtype, "resize_bilinear", CALL);
+#undef CALL
   return check_launch("resize_bilinear");
 }
 
-extern "C" int diffsal_resize_sum(const float* const* ins, const int* hs, const int* ws, int n_in, float* out, int N,
-                                  int H, int W, int C, diffsal_stream_t stream) {
+extern "C" int diffsal_resize_sum(const void* const* ins, const int* hs, const int* ws, int n_in, void* out, int N,
+                                  int H, int W, int C, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(ins && hs && ws && out, DIFFSAL_E_ARG, "resize_sum: null argument");
   DS_REQUIRE(n_in >= 1 && n_in <= 4 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE,
              "resize_sum: bad shape n_in=%d C=%d", n_in, C);
@@ -606,20 +633,26 @@ extern "C" int diffsal_resize_sum(const float* const* ins, const int* hs, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (patchable) {
     const long n_patches = static_cast<long>(N) * (H / 4) * (W / 4);
-    hipLaunchKernelGGL(resize_sum_kernel, dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a, out, H, W, C,
-                       W / 4, n_patches);
+#define CALL(T)                                                                                                        \
+  hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a,          \
+                     static_cast<T*>(out), H, W, C, W / 4, n_patches)
+    DS_DTYPE_DISPATCH(dtype, "resize_sum", CALL);
+#undef CALL
   } else {
     const int w_tiles = (W + 3) / 4;
     const long blocks = static_cast<long>(N) * H * w_tiles;
     DS_REQUIRE(blocks < (1L << 31), DIFFSAL_E_SHAPE, "resize_sum: output too large");
-    hipLaunchKernelGGL(resize_sum_generic_kernel, dim3(static_cast<int>(blocks)), dim3(256), 0, s, a, out, H, W, C,
-                       w_tiles);
+#define CALL(T)                                                                                                        \
+  hipLaunchKernelGGL((resize_sum_generic_kernel<T>), dim3(static_cast<int>(blocks)), dim3(256), 0, s, a,               \
+                     static_cast<T*>(out), H, W, C, w_tiles)
+    DS_DTYPE_DISPATCH(dtype, "resize_sum", CALL);
+#undef CALL
   }
   return check_launch("resize_sum");
 }
 
-extern "C" int diffsal_audio_fuse(const float* a_small, const float* x, float* out, int B, int T, int H, int W, int C,
-                                  int h, int w, diffsal_stream_t stream) {
+extern "C" int diffsal_audio_fuse(const void* a_small, const void* x, void* out, int B, int T, int H, int W, int C,
+                                  int h, int w, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(a_small && x && out, DIFFSAL_E_ARG, "audio_fuse: null argument");
   DS_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && h > 0 && w > 0, DIFFSAL_E_SHAPE,
              "audio_fuse: bad shape C=%d", C);
@@ -632,39 +665,56 @@ extern "C" int diffsal_audio_fuse(const float* a_small, const float* x, float* o
     DS_REQUIRE(h == H && w == W, DIFFSAL_E_SHAPE, "audio_fuse: audio map %dx%d incompatible with %dx%d", h, w, H, W);
   }
   const size_t lds = static_cast<size_t>(32) * (W + 1) * sizeof(float);
-  hipLaunchKernelGGL(audio_fuse_kernel, dim3(B * H * (C / 32)), dim3(256), lds, static_cast<hipStream_t>(stream),
-                     a_small, x, out, T, H, W, C, h, w, up);
+#define CALL(TT)                                                                                                     \
+  hipLaunchKernelGGL((audio_fuse_kernel<TT>), dim3(B * H * (C / 32)), dim3(256), lds, static_cast<hipStream_t>(stream), \
+                     static_cast<const TT*>(a_small), static_cast<const TT*>(x), static_cast<TT*>(out), T, H, W, C, h, w, up)
+  DS_DTYPE_DISPATCH(dtype, "audio_fuse", CALL);
+#undef CALL
   return check_launch("audio_fuse");
 }
 
-template <int LK, int G>
-static void launch_attention(const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk, int C,
+template <int LK, int G, typename T>
+static void launch_attention(const T* q, const T* k, const T* v, T* o, int N, int Lq, int Lk, int C,
                              int heads, float scale, hipStream_t s) {
   const size_t lds = static_cast<size_t>(2) * Lk * C * sizeof(float);
   static bool raised = false;
   if (lds > 64 * 1024 && !raised) {  // opt in to > 64 KiB of dynamic LDS (host-side attribute, not a stream op)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<LK, G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<LK, G, T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = true;
   }
   const int qpb = (4 / heads) * (64 / G);  // queries per workgroup
-  hipLaunchKernelGGL((attention_kernel<LK, G>), dim3((Lq + qpb - 1) / qpb, N), dim3(256), lds, s, q, k, v, o, Lq, Lk,
-                     C, heads, scale);
+  hipLaunchKernelGGL((attention_kernel<LK, G, T>), dim3((Lq + qpb - 1) / qpb, N), dim3(256), lds, s, q, k, v, o, Lq,
+                     Lk, C, heads, scale);
 }
 
-template <int LK>
-static void launch_attention_g(int G, const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk,
+template <int LK, typename T>
+static void launch_attention_g(int G, const T* q, const T* k, const T* v, T* o, int N, int Lq, int Lk,
                                int C, int heads, float scale, hipStream_t s) {
   switch (G) {
-    case 16: launch_attention<LK, 16>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
-    case 8: launch_attention<LK, 8>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
-    case 4: launch_attention<LK, 4>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
-    default: launch_attention<LK, 1>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    case 16: launch_attention<LK, 16, T>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    case 8: launch_attention<LK, 8, T>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    case 4: launch_attention<LK, 4, T>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
+    default: launch_attention<LK, 1, T>(q, k, v, o, N, Lq, Lk, C, heads, scale, s); break;
   }
 }
 
-extern "C" int diffsal_attention(const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk,
-                                 int C, int heads, float scale, diffsal_stream_t stream) {
+template <typename T>
+static void attention_t(const T* q, const T* k, const T* v, T* o, int N, int Lq, int Lk, int C, int heads, float scale,
+                        hipStream_t s) {
+  // lanes per (query, head): about 3 float4 pieces of the head dim per lane, at most 16 lanes
+  const int nf4 = C / heads / 4;
+  int G = 1;
+  while (G < 16 && nf4 / (2 * G) >= 3) G *= 2;
+  if (G == 2) G = 4;
+  if (Lk <= 4) launch_attention_g<4, T>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+  else if (Lk <= 8) launch_attention_g<8, T>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+  else if (Lk <= 18) launch_attention_g<18, T>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+  else launch_attention_g<32, T>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+}
+
+extern "C" int diffsal_attention(const void* q, const void* k, const void* v, void* o, int N, int Lq, int Lk,
+                                 int C, int heads, float scale, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(q && k && v && o, DIFFSAL_E_ARG, "attention: null argument");
   DS_REQUIRE(N > 0 && Lq > 0 && Lk > 0 && Lk <= 32, DIFFSAL_E_SHAPE, "attention: bad shape Lq=%d Lk=%d", Lq, Lk);
   DS_REQUIRE(heads == 1 || heads == 2 || heads == 4, DIFFSAL_E_SHAPE, "attention: heads=%d (1, 2 or 4 are built)", heads);
@@ -675,27 +725,25 @@ extern "C" int diffsal_attention(const float* q, const float* k, const float* v,
   DS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), DIFFSAL_E_ALIGN,
              "attention: misaligned pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // lanes per (query, head): about 3 float4 pieces of the head dim per lane, at most 16 lanes
-  const int nf4 = C / heads / 4;
-  int G = 1;
-  while (G < 16 && nf4 / (2 * G) >= 3) G *= 2;
-  if (G == 2) G = 4;
-  if (Lk <= 4) launch_attention_g<4>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
-  else if (Lk <= 8) launch_attention_g<8>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
-  else if (Lk <= 18) launch_attention_g<18>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
-  else launch_attention_g<32>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
+#define CALL(T) \
+  attention_t<T>(static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v), static_cast<T*>(o), N, Lq, Lk, C, heads, scale, s)
+  DS_DTYPE_DISPATCH(dtype, "attention", CALL);
+#undef CALL
   return check_launch("attention");
 }
 
-extern "C" int diffsal_head_sigmoid(const float* x, const float* w, const float* bias, float* out, int NHW, int C,
-                                    diffsal_stream_t stream) {
+extern "C" int diffsal_head_sigmoid(const void* x, const float* w, const float* bias, float* out, int NHW, int C,
+                                    int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(x && w && bias && out, DIFFSAL_E_ARG, "head_sigmoid: null argument");
   DS_REQUIRE(NHW > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "head_sigmoid: bad shape");
   DS_REQUIRE(aligned16(x) && aligned16(w), DIFFSAL_E_ALIGN, "head_sigmoid: misaligned pointer");
   long g = (static_cast<long>(NHW) + 31) / 32;
   g = g > 4096 ? 4096 : g;
-  hipLaunchKernelGGL(head_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias,
-                     out, static_cast<long>(NHW), C);
+#define CALL(T)                                                                                               \
+  hipLaunchKernelGGL((head_kernel<T>), dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                     static_cast<const T*>(x), w, bias, out, static_cast<long>(NHW), C)
+  DS_DTYPE_DISPATCH(dtype, "head_sigmoid", CALL);
+#undef CALL
   return check_launch("head_sigmoid");
 }
 
@@ -706,4 +754,24 @@ extern "C" int diffsal_axpbypcz(const float* x, const float* y, const float* z, 
   hipLaunchKernelGGL(axpbypcz_kernel, dim3(ew_grid(static_cast<long>(n))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, y, z, a, b, c, out, n);
   return check_launch("axpbypcz");
+}
+
+extern "C" int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, diffsal_stream_t stream) {
+  DS_REQUIRE(src && dst, DIFFSAL_E_ARG, "cast: null argument");
+  if (n <= 0) return DIFFSAL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int g = ew_grid(n);
+#define CALL_D(D)                                                                                      \
+  do {                                                                                                 \
+    if (src_dtype == DIFFSAL_F32)                                                                      \
+      hipLaunchKernelGGL((cast_kernel<float, D>), dim3(g), dim3(256), 0, s, static_cast<const float*>(src), static_cast<D*>(dst), n); \
+    else if (src_dtype == DIFFSAL_BF16)                                                                \
+      hipLaunchKernelGGL((cast_kernel<bf16_t, D>), dim3(g), dim3(256), 0, s, static_cast<const bf16_t*>(src), static_cast<D*>(dst), n); \
+    else if (src_dtype == DIFFSAL_F16)                                                                 \
+      hipLaunchKernelGGL((cast_kernel<f16_t, D>), dim3(g), dim3(256), 0, s, static_cast<const f16_t*>(src), static_cast<D*>(dst), n); \
+    else { set_error("cast: src dtype %d", src_dtype); return DIFFSAL_E_ARG; }                         \
+  } while (0)
+  DS_DTYPE_DISPATCH(dst_dtype, "cast", CALL_D);
+#undef CALL_D
+  return check_launch("cast");
 }

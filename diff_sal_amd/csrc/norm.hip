@@ -15,7 +15,8 @@ namespace diffsal {
 // ------------------------------------------------------------------------------------------------
 constexpr int GN_CHUNKS = 32;
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ ws,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws,
                                                        int HW, int C, int groups) {
   extern __shared__ double sh[];  // [C][2]
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int p_end = static_cast<long>(HW) * (chunk + 1) / GN_CHUNKS;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (active) {
-    const float* base = x + (static_cast<long>(b) * HW) * C + my_c4 * 4;
+    const T* base = x + (static_cast<long>(b) * HW) * C + my_c4 * 4;
     for (int p = p_begin + my_p; p < p_end; p += pix_per_pass) {
       const float4 v = ld4(base + static_cast<long>(p) * C);
       s[0] += v.x; q[0] += v.x * v.x;
@@ -56,9 +57,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ ws,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const double* __restrict__ ws,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ out, int HW, int C, int groups, float eps) {
+                                                       T* __restrict__ out, int HW, int C, int groups, float eps) {
   extern __shared__ float shf[];  // [C] scale, [C] shift
   const int b = blockIdx.y;
   const int cpg = C / groups;
@@ -81,8 +83,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   __syncthreads();
   const int c4n = C >> 2;
   const long total4 = static_cast<long>(HW) * c4n;
-  const float* xb = x + static_cast<long>(b) * HW * C;
-  float* ob = out + static_cast<long>(b) * HW * C;
+  const T* xb = x + static_cast<long>(b) * HW * C;
+  T* ob = out + static_cast<long>(b) * HW * C;
   for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
     const int c = static_cast<int>(i % c4n) * 4;
     float4 v = ld4(xb + i * 4);
@@ -98,9 +100,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // Row helpers: a lane group of G lanes owns one token of C channels (C % 4 == 0), NV = ceil(C/4/G)
 // float4 per lane.  Two-pass (mean, then centred variance) in registers.
 // ------------------------------------------------------------------------------------------------
-template <int G, int NV>
+template <int G, int NV, typename T>
 __device__ __forceinline__ void ln_rows_finish(float4 (&v)[NV], int gl, int C, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float eps, float* __restrict__ orow) {
+                                               const float* __restrict__ beta, float eps, T* __restrict__ orow) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -136,30 +138,30 @@ __device__ __forceinline__ void ln_rows_finish(float4 (&v)[NV], int gl, int C, c
 }
 
 // LayerNorm over C.  R/.../transformer.py:110,121; sal_unet.py:447,473
-template <int G, int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ out,
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out,
                                                         int M, int C, float eps) {
   constexpr int ROWS = 256 / G;
   const int gl = threadIdx.x % G;
   const int gr = threadIdx.x / G;
   for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < M; row += static_cast<long>(gridDim.x) * ROWS) {
-    const float* xr = x + row * C;
+    const T* xr = x + row * C;
     float4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (gl + i * G) * 4;
       v[i] = c < C ? ld4(xr + c) : make_float4(0, 0, 0, 0);
     }
-    ln_rows_finish<G, NV>(v, gl, C, gamma, beta, eps, out + row * C);
+    ln_rows_finish<G, NV, T>(v, gl, C, gamma, beta, eps, out + row * C);
   }
 }
 
 // depthwise 3x3 (pad 1, stride 1) + LayerNorm.  R/.../attention.py:36-47,94 (quirk Q8: centre slice)
-template <int G, int NV>
-__global__ __launch_bounds__(256) void dwconv3_ln_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(256) void dwconv3_ln_kernel(const T* __restrict__ x, const float* __restrict__ w9,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ out, int N, int H, int W, int C, float eps) {
+                                                         T* __restrict__ out, int N, int H, int W, int C, float eps) {
   constexpr int ROWS = 256 / G;
   const int gl = threadIdx.x % G;
   const int gr = threadIdx.x / G;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(const float* __restrict
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = xw + kx - 1;
         if (ix < 0 || ix >= W) continue;
-        const float* xr = x + (row + static_cast<long>(ky - 1) * W + (kx - 1)) * C;
+        const T* xr = x + (row + static_cast<long>(ky - 1) * W + (kx - 1)) * C;
         const float* wr = w9 + (ky * 3 + kx) * C;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -193,18 +195,18 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(const float* __restrict
         }
       }
     }
-    ln_rows_finish<G, NV>(v, gl, C, gamma, beta, eps, out + row * C);
+    ln_rows_finish<G, NV, T>(v, gl, C, gamma, beta, eps, out + row * C);
   }
 }
 
 // depthwise k x k, stride k, no padding, + LayerNorm, for K and V at once: one workgroup per pooled token.
 // R/.../attention.py:49-76,88-95.  Threads = (256/G position lanes) x (G channel lanes).
-template <int G, int NV>
-__global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const float* __restrict__ xk, const float* __restrict__ xv,
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const T* __restrict__ xk, const T* __restrict__ xv,
                                                            const float* __restrict__ wk, const float* __restrict__ wv,
                                                            const float* __restrict__ gk, const float* __restrict__ bk,
                                                            const float* __restrict__ gv, const float* __restrict__ bv,
-                                                           float* __restrict__ ok, float* __restrict__ ov, int H, int W,
+                                                           T* __restrict__ ok, T* __restrict__ ov, int H, int W,
                                                            int C, int k, int gh, int gw, float eps) {
   constexpr int PL = 256 / G;
   extern __shared__ float shp[];  // [2][PL][C]
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const float* __restri
         }
       }
     }
-    if (pl == 0) ln_rows_finish<G, NV>(v, gl, C, gk, bk, eps, ok + static_cast<long>(tok) * C);
-    else ln_rows_finish<G, NV>(v, gl, C, gv, bv, eps, ov + static_cast<long>(tok) * C);
+    if (pl == 0) ln_rows_finish<G, NV, T>(v, gl, C, gk, bk, eps, ok + static_cast<long>(tok) * C);
+    else ln_rows_finish<G, NV, T>(v, gl, C, gv, bv, eps, ov + static_cast<long>(tok) * C);
   }
 }
 
@@ -284,8 +286,23 @@ extern "C" size_t diffsal_groupnorm_ws_bytes(int B, int groups) {
   return static_cast<size_t>(B) * GN_CHUNKS * groups * 2 * sizeof(double);
 }
 
-extern "C" int diffsal_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* out, int B,
-                                       int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+template <typename T>
+static int groupnorm_swish_t(const T* x, const float* gamma, const float* beta, T* out, int B, int HW, int C, int groups,
+                             float eps, void* ws, hipStream_t s) {
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(GN_CHUNKS, B), dim3(256), 2 * C * sizeof(double), s, x,
+                     static_cast<double*>(ws), HW, C, groups);
+  int rc = check_launch("groupnorm_swish(stats)");
+  if (rc) return rc;
+  const long total4 = static_cast<long>(HW) * (C / 4);
+  int gx = static_cast<int>((total4 + 255) / 256);
+  gx = gx > 512 ? 512 : gx;
+  hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x,
+                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps);
+  return check_launch("groupnorm_swish(apply)");
+}
+
+extern "C" int diffsal_groupnorm_swish(const void* x, const float* gamma, const float* beta, void* out, int B,
+                                       int HW, int C, int groups, float eps, void* ws, size_t ws_bytes, int dtype,
                                        diffsal_stream_t stream) {
   DS_REQUIRE(x && gamma && beta && out && ws, DIFFSAL_E_ARG, "groupnorm_swish: null argument");
   DS_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 1024, DIFFSAL_E_SHAPE,
@@ -293,16 +310,10 @@ extern "C" int diffsal_groupnorm_swish(const float* x, const float* gamma, const
   DS_REQUIRE(ws_bytes >= diffsal_groupnorm_ws_bytes(B, groups), DIFFSAL_E_ARG, "groupnorm_swish: workspace too small");
   DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(ws), DIFFSAL_E_ALIGN, "groupnorm_swish: misaligned pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(GN_CHUNKS, B), dim3(256), 2 * C * sizeof(double), s, x,
-                     static_cast<double*>(ws), HW, C, groups);
-  int rc = check_launch("groupnorm_swish(stats)");
-  if (rc) return rc;
-  const long total4 = static_cast<long>(HW) * (C / 4);
-  int gx = static_cast<int>((total4 + 255) / 256);
-  gx = gx > 512 ? 512 : gx;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x,
-                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps);
-  return check_launch("groupnorm_swish(apply)");
+#define CALL(T) return groupnorm_swish_t<T>(static_cast<const T*>(x), gamma, beta, static_cast<T*>(out), B, HW, C, groups, eps, ws, s)
+  DS_DTYPE_DISPATCH(dtype, "groupnorm_swish", CALL);
+#undef CALL
+  return DIFFSAL_OK;
 }
 
 static int row_grid(long rows, int rows_per_block) {
@@ -310,51 +321,80 @@ static int row_grid(long rows, int rows_per_block) {
   return static_cast<int>(g > 8192 ? 8192 : g);
 }
 
-extern "C" int diffsal_layernorm(const float* x, const float* gamma, const float* beta, float* out, int M, int C,
-                                 float eps, diffsal_stream_t stream) {
-  DS_REQUIRE(x && gamma && beta && out, DIFFSAL_E_ARG, "layernorm: null argument");
-  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm: bad shape M=%d C=%d", M, C);
-  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), DIFFSAL_E_ALIGN,
-             "layernorm: misaligned pointer");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+template <typename T>
+static int layernorm_t(const T* x, const float* gamma, const float* beta, T* out, int M, int C, float eps, hipStream_t s) {
 #define CALL(G, NV) \
-  hipLaunchKernelGGL((layernorm_kernel<G, NV>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, gamma, beta, out, M, C, eps)
+  hipLaunchKernelGGL((layernorm_kernel<G, NV, T>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, gamma, beta, out, M, C, eps)
   DS_ROW_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("layernorm");
 }
 
-extern "C" int diffsal_dwconv3_ln(const float* x, const float* w9, const float* gamma, const float* beta, float* out,
-                                  int N, int H, int W, int C, float eps, diffsal_stream_t stream) {
-  DS_REQUIRE(x && w9 && gamma && beta && out, DIFFSAL_E_ARG, "dwconv3_ln: null argument");
-  DS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "dwconv3_ln: bad shape");
-  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(w9) && aligned16(gamma) && aligned16(beta), DIFFSAL_E_ALIGN,
-             "dwconv3_ln: misaligned pointer");
+extern "C" int diffsal_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,
+                                 float eps, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(x && gamma && beta && out, DIFFSAL_E_ARG, "layernorm: null argument");
+  DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm: bad shape M=%d C=%d", M, C);
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), DIFFSAL_E_ALIGN,
+             "layernorm: misaligned pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALLT(T) return layernorm_t<T>(static_cast<const T*>(x), gamma, beta, static_cast<T*>(out), M, C, eps, s)
+  DS_DTYPE_DISPATCH(dtype, "layernorm", CALLT);
+#undef CALLT
+  return DIFFSAL_OK;
+}
+
+template <typename T>
+static int dwconv3_ln_t(const T* x, const float* w9, const float* gamma, const float* beta, T* out, int N, int H, int W,
+                        int C, float eps, hipStream_t s) {
   const long M = static_cast<long>(N) * H * W;
-#define CALL(G, NV)                                                                                              \
-  hipLaunchKernelGGL((dwconv3_ln_kernel<G, NV>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, w9, gamma, beta, \
+#define CALL(G, NV)                                                                                                 \
+  hipLaunchKernelGGL((dwconv3_ln_kernel<G, NV, T>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, w9, gamma, beta, \
                      out, N, H, W, C, eps)
   DS_ROW_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("dwconv3_ln");
 }
 
-extern "C" int diffsal_dwpool_ln_kv(const float* xk, const float* xv, const float* wk, const float* wv,
-                                    const float* gk, const float* bk, const float* gv, const float* bv, float* out_k,
-                                    float* out_v, int N, int H, int W, int C, int k, float eps,
+extern "C" int diffsal_dwconv3_ln(const void* x, const float* w9, const float* gamma, const float* beta, void* out,
+                                  int N, int H, int W, int C, float eps, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(x && w9 && gamma && beta && out, DIFFSAL_E_ARG, "dwconv3_ln: null argument");
+  DS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "dwconv3_ln: bad shape");
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(w9) && aligned16(gamma) && aligned16(beta), DIFFSAL_E_ALIGN,
+             "dwconv3_ln: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALLT(T) return dwconv3_ln_t<T>(static_cast<const T*>(x), w9, gamma, beta, static_cast<T*>(out), N, H, W, C, eps, s)
+  DS_DTYPE_DISPATCH(dtype, "dwconv3_ln", CALLT);
+#undef CALLT
+  return DIFFSAL_OK;
+}
+
+template <typename T>
+static int dwpool_ln_kv_t(const T* xk, const T* xv, const float* wk, const float* wv, const float* gk, const float* bk,
+                          const float* gv, const float* bv, T* out_k, T* out_v, int N, int H, int W, int C, int k,
+                          float eps, hipStream_t s) {
+  const int gh = (H - k) / k + 1, gw = (W - k) / k + 1;
+#define CALL(G, NV)                                                                                                \
+  hipLaunchKernelGGL((dwpool_ln_kv_kernel<G, NV, T>), dim3(N * gh * gw), dim3(256), 2 * (256 / G) * C * sizeof(float), s, \
+                     xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, H, W, C, k, gh, gw, eps)
+  DS_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("dwpool_ln_kv");
+}
+
+extern "C" int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float* wk, const float* wv,
+                                    const float* gk, const float* bk, const float* gv, const float* bv, void* out_k,
+                                    void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
                                     diffsal_stream_t stream) {
   DS_REQUIRE(xk && xv && wk && wv && gk && bk && gv && bv && out_k && out_v, DIFFSAL_E_ARG, "dwpool_ln_kv: null argument");
   DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && H >= k && W >= k, DIFFSAL_E_SHAPE,
              "dwpool_ln_kv: bad shape H=%d W=%d C=%d k=%d", H, W, C, k);
   DS_REQUIRE(aligned16(xk) && aligned16(xv) && aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v),
              DIFFSAL_E_ALIGN, "dwpool_ln_kv: misaligned pointer");
-  const int gh = (H - k) / k + 1, gw = (W - k) / k + 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(G, NV)                                                                                             \
-  hipLaunchKernelGGL((dwpool_ln_kv_kernel<G, NV>), dim3(N * gh * gw), dim3(256), 2 * (256 / G) * C * sizeof(float), s, \
-                     xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, H, W, C, k, gh, gw, eps)
-  DS_ROW_DISPATCH(C, CALL);
-#undef CALL
-  return check_launch("dwpool_ln_kv");
+#define CALLT(T)                                                                                                  \
+  return dwpool_ln_kv_t<T>(static_cast<const T*>(xk), static_cast<const T*>(xv), wk, wv, gk, bk, gv, bv,          \
+                           static_cast<T*>(out_k), static_cast<T*>(out_v), N, H, W, C, k, eps, s)
+  DS_DTYPE_DISPATCH(dtype, "dwpool_ln_kv", CALLT);
+#undef CALLT
+  return DIFFSAL_OK;
 }

@@ -60,10 +60,15 @@ def sample_sharded(sampler, x_T: torch.Tensor, feats: List[torch.Tensor], audio:
     for s in range(mine.start, mine.stop, batch):
         e = min(s + batch, mine.stop)
         a = None if audio is None else audio[s:e]
-        if sampler.sample_type == "ddim":
-            outs.append(sampler.sample_ddim(x_T[s:e], [f[s:e] for f in feats], a))
+        fs = [f[s:e] for f in feats]
+        if sampler.sample_type == "ddim":          # same dispatch as DiffusionSampler.sample_image
+            outs.append(sampler.sample_ddim(x_T[s:e], fs, a))
+        elif sampler.sample_type in ("dpmsolver", "dpmsolver++"):
+            outs.append(sampler.sample_dpm_solver(x_T[s:e], fs, a))
+        elif sampler.sample_type == "ddpm":
+            outs.append(sampler.sample_ddpm(x_T[s:e], fs, a))
         else:
-            outs.append(sampler.sample_dpm_solver(x_T[s:e], [f[s:e] for f in feats], a))
+            raise NotImplementedError(sampler.sample_type)
     local = torch.cat(outs) if outs else x_T[:0]
     if not gather or world == 1:
         return local

@@ -46,48 +46,59 @@ def interpolate_fn(x: Tensor, xp: Tensor, yp: Tensor) -> Tensor:
     return torch.stack(cols, dim=1)
 
 
-class NoiseScheduleVP:
-    """VP-SDE noise schedule: alpha_t, sigma_t, lambda_t = log(alpha_t/sigma_t) and its inverse.
+def _interp1(x: Tensor, xp: Tensor, yp: Tensor) -> Tensor:
+    """1-D piecewise-linear interpolation through increasing keypoints ``xp`` (linear extrapolation by the end segments)."""
+    s = (torch.searchsorted(xp, x.contiguous()) - 1).clamp(0, xp.numel() - 2)
+    return yp[s] + (x - xp[s]) * (yp[s + 1] - yp[s]) / (xp[s + 1] - xp[s])
 
-    ``schedule='discrete'`` (betas or alphas_cumprod of an N-step DDPM, t_i = (i+1)/N, piecewise-linear
-    log alpha) or ``'linear'`` (continuous VPSDE).  For cosine-like schedules log-SNR is clipped at
-    -5.1 near t = T, which shortens the table (``total_N`` = 996 for the 1000-step cosine schedule,
-    SURVEY F3).  sampler.py:6-167.  All tables live on the host.
-    """
+
+class NoiseScheduleVP:
+    """VP-SDE noise schedule: alpha_t, sigma_t, lambda_t = log(alpha_t / sigma_t) and the inverse of lambda
+    (reference surface: sampler.py:6-167; the maths is Lu et al., DPM-Solver section 3.1 / appendix D).
+
+    ``schedule='discrete'``: an N-step DDPM given by ``betas`` or ``alphas_cumprod``; log alpha is piecewise linear through
+    t_i = (i + 1) / N.  ``'linear'``: the continuous VPSDE with beta(t) = beta_0 + t (beta_1 - beta_0).
+    Schedules whose log-SNR falls below -5.1 near t = T (cosine) are truncated there -- ``total_N`` = 996 for the
+    1000-step cosine schedule -- because 1 - alpha^2 loses all precision beyond.
+
+    Everything is a HOST table: two 1-D fp32 arrays (time knots, log alpha at the knots) and their reversed copies for
+    the inverse map, built once; queries are a searchsorted + lerp on the host, so a sampling loop never waits on the
+    device for a coefficient."""
+
+    CLIP_LAMBDA = -5.1
 
     def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None, continuous_beta_0=0.1,
                  continuous_beta_1=20.0, dtype=torch.float32):
         if schedule not in ("discrete", "linear"):
             raise ValueError(f"Unsupported noise schedule {schedule}. The schedule needs to be 'discrete' or 'linear'")
-        self.schedule = schedule
-        self.T = 1.0
-        if schedule == "discrete":
-            if betas is not None:
-                log_alphas = 0.5 * torch.log(1 - betas.detach().cpu()).cumsum(dim=0)
-            else:
-                assert alphas_cumprod is not None
-                log_alphas = 0.5 * torch.log(alphas_cumprod.detach().cpu())
-            log_alphas = self.numerical_clip_alpha(log_alphas)
-            self.log_alpha_array = log_alphas.reshape(1, -1).to(dtype=dtype)
-            self.total_N = self.log_alpha_array.shape[1]
-            self.t_array = torch.linspace(0.0, 1.0, self.total_N + 1)[1:].reshape(1, -1).to(dtype=dtype)
-        else:
-            self.total_N = 1000
-            self.beta_0 = continuous_beta_0
-            self.beta_1 = continuous_beta_1
+        self.schedule, self.T = schedule, 1.0
+        if schedule == "linear":
+            self.total_N, self.beta_0, self.beta_1 = 1000, continuous_beta_0, continuous_beta_1
+            return
+        if betas is None and alphas_cumprod is None:
+            raise ValueError("the discrete schedule needs betas or alphas_cumprod")
+        la = (0.5 * torch.log(1 - betas.detach().cpu()).cumsum(dim=0) if betas is not None
+              else 0.5 * torch.log(alphas_cumprod.detach().cpu()))
+        la = self.numerical_clip_alpha(la)
+        self.total_N = int(la.numel())
+        self._la = la.to(dtype).contiguous()                                             # decreasing in t
+        self._t = torch.linspace(0.0, 1.0, self.total_N + 1)[1:].to(dtype).contiguous()  # knots (i + 1) / N
+        self._la_up, self._t_down = torch.flip(self._la, [0]).contiguous(), torch.flip(self._t, [0]).contiguous()
+        # [1, N] views under the reference's attribute names
+        self.log_alpha_array, self.t_array = self._la.reshape(1, -1), self._t.reshape(1, -1)
 
-    @staticmethod
-    def numerical_clip_alpha(log_alphas: Tensor, clipped_lambda: float = -5.1) -> Tensor:
-        log_sigmas = 0.5 * torch.log(1.0 - torch.exp(2.0 * log_alphas))
-        lambs = log_alphas - log_sigmas
-        idx = int(torch.searchsorted(torch.flip(lambs, [0]), torch.tensor(clipped_lambda, dtype=lambs.dtype)))
-        return log_alphas[:-idx] if idx > 0 else log_alphas
+    @classmethod
+    def numerical_clip_alpha(cls, log_alphas: Tensor, clipped_lambda: Optional[float] = None) -> Tensor:
+        """Drop the tail of the table on which lambda = log alpha - log sigma < ``clipped_lambda``."""
+        lim = cls.CLIP_LAMBDA if clipped_lambda is None else clipped_lambda
+        lam = log_alphas - 0.5 * torch.log(1.0 - torch.exp(2.0 * log_alphas))       # decreasing along the table
+        n_drop = int(torch.searchsorted(torch.flip(lam, [0]), torch.tensor(lim, dtype=lam.dtype)))
+        return log_alphas[: log_alphas.numel() - n_drop]
 
     def marginal_log_mean_coeff(self, t: Tensor) -> Tensor:
-        if self.schedule == "discrete":
-            dev = t.device
-            return interpolate_fn(t.reshape(-1, 1).cpu(), self.t_array, self.log_alpha_array).reshape(-1).to(dev)
-        return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        if self.schedule == "linear":
+            return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        return _interp1(t.detach().cpu().reshape(-1).to(self._t.dtype), self._t, self._la).to(t.device)
 
     def marginal_alpha(self, t: Tensor) -> Tensor:
         return torch.exp(self.marginal_log_mean_coeff(t))
@@ -100,15 +111,14 @@ class NoiseScheduleVP:
         return lm - 0.5 * torch.log(1.0 - torch.exp(2.0 * lm))
 
     def inverse_lambda(self, lamb: Tensor) -> Tensor:
+        """t with marginal_lambda(t) = lamb: lambda -> log alpha = -softplus(-2 lambda) / 2 in closed form, then the
+        table read backwards (discrete) or the quadratic in t solved in its cancellation-free form (linear)."""
         if self.schedule == "linear":
             tmp = 2.0 * (self.beta_1 - self.beta_0) * torch.logaddexp(-2.0 * lamb, torch.zeros((1,)).to(lamb))
-            delta = self.beta_0 ** 2 + tmp
-            return tmp / (torch.sqrt(delta) + self.beta_0) / (self.beta_1 - self.beta_0)
-        dev = lamb.device
-        lamb = lamb.cpu()
-        log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,), dtype=lamb.dtype), -2.0 * lamb)
-        t = interpolate_fn(log_alpha.reshape(-1, 1), torch.flip(self.log_alpha_array, [1]), torch.flip(self.t_array, [1]))
-        return t.reshape(-1).to(dev)
+            return tmp / (torch.sqrt(self.beta_0 ** 2 + tmp) + self.beta_0) / (self.beta_1 - self.beta_0)
+        lc = lamb.detach().cpu().reshape(-1)
+        log_alpha = -0.5 * torch.logaddexp(torch.zeros((1,), dtype=lc.dtype), -2.0 * lc)
+        return _interp1(log_alpha.to(self._la.dtype), self._la_up, self._t_down).to(lamb.device)
 
 
 def _lincomb(x: Tensor, a, y: Optional[Tensor] = None, b=0.0, z: Optional[Tensor] = None, c=0.0) -> Tensor:
@@ -274,142 +284,157 @@ class DPM_Solver:
         return self.data_prediction_fn(x, s, img)
 
     # ---- updates: scalar coefficients on the host, one fused launch each -----------------------
-    def _sched(self, t: Tensor):
+    def _sched(self, t):
+        """(lambda, log alpha, sigma) at time ``t`` as host fp32 scalars-in-tensors (same fp32 arithmetic as the schedule)."""
         ns = self.noise_schedule
-        t = t.detach().cpu().reshape(-1)[:1].float()
+        t = torch.as_tensor(t).detach().cpu().reshape(-1)[:1].float()
         log_alpha = ns.marginal_log_mean_coeff(t)
         sigma = torch.sqrt(1.0 - torch.exp(2.0 * log_alpha))
         lam = log_alpha - 0.5 * torch.log(1.0 - torch.exp(2.0 * log_alpha))
         return lam, log_alpha, sigma
 
+    def _coefficients(self, t_hist, t, order, solver_type="dpmsolver"):
+        """Host scalars (A, [c0, c1, c2][:order]) of the multistep update of order 1-3 from t_hist[-1] to t,
+
+            x_t = A x + c0 m0 + c1 m1 + c2 m2,      m0 = model at t_hist[-1], m1 at t_hist[-2], m2 at t_hist[-3],
+
+        i.e. the finite-difference forms of the published updates (Lu et al., DPM-Solver eq. 4.1 / DPM-Solver++ alg. 2;
+        reference: sampler.py:548-593 order 1, :797-853 order 2, :855-905 order 3) with the differences D1, D2 expanded
+        into direct weights of the stored model outputs -- one fused launch per update, and a table the whole trajectory
+        can precompute."""
+        if solver_type not in ("dpmsolver", "taylor"):
+            raise ValueError(f"'solver_type' must be either 'dpmsolver' or 'taylor', got {solver_type}")
+        pp = self.algorithm_type == "dpmsolver++"
+        lam0, la0, sig0 = self._sched(t_hist[-1])
+        lam_t, la_t, sig_t = self._sched(t)
+        h = lam_t - lam0
+        if pp:
+            phi1 = torch.expm1(-h)
+            A, scale = sig_t / sig0, torch.exp(la_t)
+        else:
+            phi1 = torch.expm1(h)
+            A, scale = torch.exp(la_t - la0), sig_t
+        P1 = scale * phi1
+        if order == 1:
+            return float(A), [float(-P1)]
+        lam1 = self._sched(t_hist[-2])[0]
+        r0 = (lam0 - lam1) / h
+        u = 1.0 / r0
+        if order == 2:
+            if solver_type == "dpmsolver":
+                Dc = 0.5 * P1
+            else:
+                Dc = -(scale * (phi1 / h + 1.0)) if pp else scale * (phi1 / h - 1.0)
+            return float(A), [float(-(P1 + Dc * u)), float(Dc * u)]
+        if order != 3:
+            raise ValueError(f"Solver order must be 1 or 2 or 3, got {order}")
+        lam2 = self._sched(t_hist[-3])[0]
+        r1 = (lam1 - lam2) / h
+        v, w, z = 1.0 / r1, r0 / (r0 + r1), 1.0 / (r0 + r1)
+        if pp:      # x_t = A x - a phi1 m0 + a phi2 D1 - a phi3 D2
+            phi2 = phi1 / h + 1.0
+            phi3 = phi2 / h - 0.5
+            P2, P3 = scale * phi2, scale * phi3
+        else:       # x_t = A x - s phi1 m0 - s phi2 D1 - s phi3 D2
+            phi2 = phi1 / h - 1.0
+            phi3 = phi2 / h - 0.5
+            P2, P3 = -(scale * phi2), scale * phi3
+        # D1 = (u + w u) m0 - (u + w (u + v)) m1 + w v m2 ;  D2 = z (u m0 - (u + v) m1 + v m2)
+        c0 = -P1 + P2 * (u + w * u) - P3 * z * u
+        c1 = -P2 * (u + w * (u + v)) + P3 * z * (u + v)
+        c2 = P2 * w * v - P3 * z * v
+        return float(A), [float(c0), float(c1), float(c2)]
+
+    @staticmethod
+    def _apply(x, A, coeffs, models):
+        """x <- A x + sum_i coeffs[i] * models[-1-i]; three terms per launch."""
+        m = [models[-1 - i] for i in range(len(coeffs))]
+        if len(coeffs) == 1:
+            return _lincomb(x, A, m[0], coeffs[0])
+        y = _lincomb(x, A, m[0], coeffs[0], m[1], coeffs[1])
+        return y if len(coeffs) == 2 else _lincomb(y, 1.0, m[2], coeffs[2])
+
     def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False, img=None):
         """DPM-Solver-1 (= DDIM) from time s to t (sampler.py:548-593)."""
-        lam_s, la_s, sig_s = self._sched(s)
-        lam_t, la_t, sig_t = self._sched(t)
-        h = lam_t - lam_s
         if model_s is None:
             model_s = self.model_fn(x, s, img)
-        if self.algorithm_type == "dpmsolver++":
-            x_t = _lincomb(x, sig_t / sig_s, model_s, -(torch.exp(la_t) * torch.expm1(-h)))
-        else:
-            x_t = _lincomb(x, torch.exp(la_t - la_s), model_s, -(sig_t * torch.expm1(h)))
+        A, c = self._coefficients([s], t, 1)
+        x_t = self._apply(x, A, c, [model_s])
         return (x_t, {"model_s": model_s}) if return_intermediate else x_t
 
     def multistep_dpm_solver_second_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpmsolver"):
         """Multistep DPM-Solver-2 from t_prev_list[-1] to t (sampler.py:797-853)."""
-        if solver_type not in ("dpmsolver", "taylor"):
-            raise ValueError(f"'solver_type' must be either 'dpmsolver' or 'taylor', got {solver_type}")
-        m1, m0 = model_prev_list[-2], model_prev_list[-1]
-        lam_p1, _, _ = self._sched(t_prev_list[-2])
-        lam_p0, la_p0, sig_p0 = self._sched(t_prev_list[-1])
-        lam_t, la_t, sig_t = self._sched(t)
-        h_0 = lam_p0 - lam_p1
-        h = lam_t - lam_p0
-        r0 = h_0 / h
-        # D1_0 = (1/r0) (m0 - m1);  x_t = A x - Bc m0 - Dc D1_0  =>  one 3-term combination
-        inv_r0 = 1.0 / r0
-        if self.algorithm_type == "dpmsolver++":
-            phi_1 = torch.expm1(-h)
-            A = sig_t / sig_p0
-            Bc = torch.exp(la_t) * phi_1
-            Dc = 0.5 * Bc if solver_type == "dpmsolver" else -(torch.exp(la_t) * (phi_1 / h + 1.0))
-        else:
-            phi_1 = torch.expm1(h)
-            A = torch.exp(la_t - la_p0)
-            Bc = sig_t * phi_1
-            Dc = 0.5 * Bc if solver_type == "dpmsolver" else sig_t * (phi_1 / h - 1.0)
-        return _lincomb(x, A, m0, -(Bc + Dc * inv_r0), m1, Dc * inv_r0)
+        A, c = self._coefficients(t_prev_list, t, 2, solver_type)
+        return self._apply(x, A, c, model_prev_list)
 
     def multistep_dpm_solver_third_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpmsolver"):
         """Multistep DPM-Solver-3 (sampler.py:855-905)."""
-        m2, m1, m0 = model_prev_list
-        lam_p2, _, _ = self._sched(t_prev_list[0])
-        lam_p1, _, _ = self._sched(t_prev_list[1])
-        lam_p0, la_p0, sig_p0 = self._sched(t_prev_list[2])
-        lam_t, la_t, sig_t = self._sched(t)
-        h_1, h_0, h = lam_p1 - lam_p2, lam_p0 - lam_p1, lam_t - lam_p0
-        r0, r1 = float(h_0 / h), float(h_1 / h)
-        D1_0 = (1.0 / r0) * (m0 - m1)
-        D1_1 = (1.0 / r1) * (m1 - m2)
-        D1 = D1_0 + (r0 / (r0 + r1)) * (D1_0 - D1_1)
-        D2 = (1.0 / (r0 + r1)) * (D1_0 - D1_1)
-        if self.algorithm_type == "dpmsolver++":
-            phi_1 = torch.expm1(-h)
-            phi_2 = phi_1 / h + 1.0
-            phi_3 = phi_2 / h - 0.5
-            a = torch.exp(la_t)
-            return (float(sig_t / sig_p0) * x - float(a * phi_1) * m0 + float(a * phi_2) * D1 - float(a * phi_3) * D2)
-        phi_1 = torch.expm1(h)
-        phi_2 = phi_1 / h - 1.0
-        phi_3 = phi_2 / h - 0.5
-        return (float(torch.exp(la_t - la_p0)) * x - float(sig_t * phi_1) * m0 - float(sig_t * phi_2) * D1
-                - float(sig_t * phi_3) * D2)
+        A, c = self._coefficients(t_prev_list, t, 3, solver_type)
+        return self._apply(x, A, c, model_prev_list)
 
     def multistep_dpm_solver_update(self, x, model_prev_list, t_prev_list, t, order, solver_type="dpmsolver"):
-        if order == 1:
-            return self.dpm_solver_first_update(x, t_prev_list[-1], t, model_s=model_prev_list[-1])
-        if order == 2:
-            return self.multistep_dpm_solver_second_update(x, model_prev_list, t_prev_list, t, solver_type)
-        if order == 3:
-            return self.multistep_dpm_solver_third_update(x, model_prev_list, t_prev_list, t, solver_type)
-        raise ValueError(f"Solver order must be 1 or 2 or 3, got {order}")
+        if order not in (1, 2, 3):
+            raise ValueError(f"Solver order must be 1 or 2 or 3, got {order}")
+        A, c = self._coefficients(t_prev_list, t, order, solver_type)
+        return self._apply(x, A, c, model_prev_list)
 
     # ---- driver -----------------------------------------------------------------------------------
-    def sample(self, x, img=None, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform",
-               method="multistep", lower_order_final=True, denoise_to_zero=False, solver_type="dpmsolver",
-               atol=0.0078, rtol=0.05, return_intermediate=False):
-        """Integrate the diffusion ODE from t_start (default T) to t_end (default 1/N) with ``steps``
-        model evaluations (+1 if ``denoise_to_zero``).  ``img`` is handed to the model unchanged at
-        every evaluation.  sampler.py:1048-1253."""
-        if method != "multistep":
-            raise NotImplementedError(
-                f"method={method!r}: only 'multistep' is built (the reference's singlestep/adaptive paths never "
-                "forward `img` to the model, SURVEY D5, and the shipped config selects multistep)")
+    def plan(self, steps, order=2, skip_type="time_uniform", t_start=None, t_end=None, lower_order_final=True,
+             solver_type="dpmsolver"):
+        """The whole trajectory as a host-side table, computed before anything is enqueued:
+
+            times [steps + 1]                   the grid t_0' = T ... t_steps' = t_end
+            table[s-1] = (A, [c0, c1, ...])     update from times[s-1] to times[s], s = 1..steps
+
+        Step s uses order min(s, order) while the history warms up, and (``lower_order_final`` with fewer than 10 steps)
+        min(order, steps + 1 - s) towards the end -- the rule of sampler.py:1190-1203.  A sampling loop is then
+        "evaluate, combine" with no schedule arithmetic in between; one table serves every clip and every HIP-graph
+        capture with the same (steps, order, skip_type, algorithm)."""
         ns = self.noise_schedule
         t_0 = 1.0 / ns.total_N if t_end is None else t_end
         t_T = ns.T if t_start is None else t_start
         assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0."
         assert steps >= order
-        intermediates: List[Tensor] = []
-        with torch.no_grad():
-            timesteps = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps)
-            assert timesteps.shape[0] - 1 == steps
-            step = 0
-            t = timesteps[step]
-            t_prev_list = [t]
-            model_prev_list = [self.model_fn(x, t, img)]
-            if self.correcting_xt_fn is not None:
-                x = self.correcting_xt_fn(x, t, step)
+        times = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps)
+        assert times.shape[0] - 1 == steps
+        table = []
+        for s in range(1, steps + 1):
+            p = min(s, order)
+            if s >= order and lower_order_final and steps < 10:
+                p = min(order, steps + 1 - s)
+            table.append(self._coefficients([times[i] for i in range(max(0, s - p), s)], times[s], p, solver_type))
+        return times, table, t_0
+
+    def sample(self, x, img=None, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform",
+               method="multistep", lower_order_final=True, denoise_to_zero=False, solver_type="dpmsolver",
+               atol=0.0078, rtol=0.05, return_intermediate=False):
+        """Integrate the diffusion ODE from t_start (default T) to t_end (default 1/N) with ``steps`` model evaluations
+        (+1 if ``denoise_to_zero``); ``img`` reaches the model unchanged at every evaluation.  Same arguments as the
+        reference's ``DPM_Solver.sample`` (sampler.py:1048); only ``method='multistep'`` is built."""
+        if method != "multistep":
+            raise NotImplementedError(
+                f"method={method!r}: only 'multistep' is built (the reference's singlestep/adaptive paths never "
+                "forward `img` to the model, SURVEY D5, and the shipped config selects multistep)")
+        times, table, t_0 = self.plan(steps, order, skip_type, t_start, t_end, lower_order_final, solver_type)
+        fix = self.correcting_xt_fn
+        trace: List[Tensor] = []
+
+        def landed(x, t, idx):
+            if fix is not None:
+                x = fix(x, t, idx)
             if return_intermediate:
-                intermediates.append(x)
-            for step in range(1, order):  # warm-up with lower orders
-                t = timesteps[step]
-                x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step, solver_type)
-                if self.correcting_xt_fn is not None:
-                    x = self.correcting_xt_fn(x, t, step)
-                if return_intermediate:
-                    intermediates.append(x)
-                t_prev_list.append(t)
-                model_prev_list.append(self.model_fn(x, t, img))
-            for step in range(order, steps + 1):
-                t = timesteps[step]
-                step_order = min(order, steps + 1 - step) if (lower_order_final and steps < 10) else order
-                x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step_order, solver_type)
-                if self.correcting_xt_fn is not None:
-                    x = self.correcting_xt_fn(x, t, step)
-                if return_intermediate:
-                    intermediates.append(x)
-                for i in range(order - 1):
-                    t_prev_list[i] = t_prev_list[i + 1]
-                    model_prev_list[i] = model_prev_list[i + 1]
-                t_prev_list[-1] = t
-                if step < steps:  # the last model value is never used
-                    model_prev_list[-1] = self.model_fn(x, t, img)
+                trace.append(x)
+            return x
+
+        with torch.no_grad():
+            ring: List[Tensor] = [self.model_fn(x, times[0], img)]      # last `order` model outputs, newest last
+            x = landed(x, times[0], 0)
+            for s, (A, coeffs) in enumerate(table, start=1):
+                x = landed(self._apply(x, A, coeffs, ring), times[s], s)
+                if s < steps:                                           # the value at the final time is never used
+                    ring.append(self.model_fn(x, times[s], img))
+                    del ring[:-order]
             if denoise_to_zero:
                 t = torch.ones((1,)) * t_0
-                x = self.denoise_to_zero_fn(x, t, img)
-                if self.correcting_xt_fn is not None:
-                    x = self.correcting_xt_fn(x, t, step + 1)
-                if return_intermediate:
-                    intermediates.append(x)
-        return (x, intermediates) if return_intermediate else x
+                x = landed(self.denoise_to_zero_fn(x, t, img), t, steps + 1)
+        return (x, trace) if return_intermediate else x

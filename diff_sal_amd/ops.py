@@ -1,13 +1,16 @@
 """Tensor-level wrappers over the C ABI of libdiffsal_hip.so.
 
 PyTorch is used for device memory and streams only: each function hands raw device pointers and
-the current HIP stream to a hand-written gfx950 kernel.  Activations are fp32 and channels-last
-(images [N,H,W,C], tokens [M,C]).  There is no CPU / PyTorch fallback: a missing library or a
-non-GPU tensor raises.
+the current HIP stream to a hand-written gfx950 kernel.  Activations are channels-last (images
+[N,H,W,C], tokens [M,C]); fp32 by default, bf16 / fp16 storage for the forward operators when the
+tensors passed in are 16-bit (BASELINE configs[1] / configs[4]; arithmetic and statistics stay fp32).
+There is no CPU / PyTorch fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -22,18 +25,43 @@ Tensor = torch.Tensor
 PROFILE = None
 
 
-GEMM_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+GEMM_PRECISIONS = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}
+
+# The arithmetic of the implicit-GEMM kernel is a PER-CALL field of diffsal_conv_desc (the library holds no mode).  On
+# the Python side the value put into each descriptor comes from a thread-local context: a process default
+# (set_gemm_precision, used by the tools and the bench) that `gemm_precision(...)` overrides for a block -- SalUNet
+# wraps its forward in it when its own ``gemm_precision`` attribute is set.
+_DEFAULT_PRECISION = ["fp32"]
+_tls = threading.local()
 
 
 def set_gemm_precision(mode: str) -> None:
-    """Arithmetic of the implicit-GEMM kernel: "fp32" (default, exact) or "bf16x3" (split-precision bf16 MFMA with fp32
+    """Default arithmetic of conv_igemm on fp32 tensors: "fp32" (exact) or "bf16x3" (split-precision bf16 MFMA with fp32
     accumulation, ~4e-6 relative; opt-in, see include/diffsal.h)."""
-    _lib.check(_lib.load().diffsal_set_gemm_precision(GEMM_PRECISIONS[mode]), "set_gemm_precision")
+    if mode not in GEMM_PRECISIONS:
+        raise ValueError(f"unknown GEMM precision {mode!r}; choose from {sorted(GEMM_PRECISIONS)}")
+    _DEFAULT_PRECISION[0] = mode
 
 
 def get_gemm_precision() -> str:
-    m = _lib.load().diffsal_get_gemm_precision()
-    return [k for k, v in GEMM_PRECISIONS.items() if v == m][0]
+    return getattr(_tls, "precision", None) or _DEFAULT_PRECISION[0]
+
+
+@contextlib.contextmanager
+def gemm_precision(mode: Optional[str]):
+    """``with ops.gemm_precision("bf16x3"):`` -- descriptors built inside carry that precision (None = no change)."""
+    if mode is not None and mode not in GEMM_PRECISIONS:
+        raise ValueError(f"unknown GEMM precision {mode!r}; choose from {sorted(GEMM_PRECISIONS)}")
+    prev = getattr(_tls, "precision", None)
+    if mode is not None:
+        _tls.precision = mode
+    try:
+        yield
+    finally:
+        _tls.precision = prev
+
+
+DTYPE_CODES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
 
 def _stream() -> int:
@@ -41,12 +69,41 @@ def _stream() -> int:
 
 
 def _p(t: Optional[Tensor]):
+    """Device pointer of a contiguous fp32 GPU tensor (parameters, statistics, every training-side tensor)."""
     if t is None:
         return None
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
         raise ValueError(f"diff_sal_amd ops need contiguous fp32 GPU tensors, got {t.dtype} {t.device} "
                          f"contiguous={t.is_contiguous()}")
     return t.data_ptr()
+
+
+def _dt(t: Tensor) -> int:
+    """DIFFSAL_F32 / BF16 / F16 code of an activation tensor."""
+    try:
+        return DTYPE_CODES[t.dtype]
+    except KeyError:
+        raise ValueError(f"diff_sal_amd ops: unsupported activation dtype {t.dtype}") from None
+
+
+def _pa(t: Optional[Tensor], code: int):
+    """Device pointer of an activation tensor that must be contiguous, on the GPU and of the call's storage type."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous() or DTYPE_CODES.get(t.dtype) != code:
+        raise ValueError(f"diff_sal_amd ops: expected a contiguous GPU tensor of storage code {code}, got {t.dtype} "
+                         f"{t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
+    """Storage-type conversion on the device (round to nearest even)."""
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    xc = x.contiguous()
+    _lib.check(_lib.load().diffsal_cast(_pa(xc, _dt(xc)), _dt(xc), out.data_ptr(), _dt(out), xc.numel(), _stream()), "cast")
+    return out
 
 
 def temb_mlp(t: Tensor, freq: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
@@ -78,14 +135,15 @@ def dense_small(x: Tensor, w: Tensor, bias: Optional[Tensor], swish_in: bool) ->
     return out
 
 
-def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0) -> Tensor:
-    """K2. x [B,1,H,W] -> NHWC [B,H,W,C]; with skip_mod=4 the pixels a stride-4 3x3 consumer never
-    reads are left unwritten."""
+def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0, out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """K2. x [B,1,H,W] (fp32) -> NHWC [B,H,W,C] of ``out_dtype``; with skip_mod=4 the pixels a stride-4 3x3 consumer
+    never reads are left unwritten."""
     lib = _lib.load()
     B, _, H, W = x.shape
     Cc = w9.shape[0]
-    out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), _p(out), B, H, W, Cc, skip_mod, _stream()), "conv_in")
+    out = torch.empty((B, H, W, Cc), device=x.device, dtype=out_dtype)
+    _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), out.data_ptr(), B, H, W, Cc, skip_mod, _dt(out), _stream()),
+               "conv_in")
     return out
 
 
@@ -96,8 +154,9 @@ def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, ep
     out = torch.empty_like(x)
     nbytes = lib.diffsal_groupnorm_ws_bytes(B, groups)
     ws = torch.empty((nbytes // 8,), device=x.device, dtype=torch.float64)
-    _lib.check(lib.diffsal_groupnorm_swish(_p(x), _p(gamma), _p(beta), _p(out), B, H * W, Cc, groups, eps,
-                                           ws.data_ptr(), nbytes, _stream()), "groupnorm_swish")
+    dt = _dt(x)
+    _lib.check(lib.diffsal_groupnorm_swish(_pa(x, dt), _p(gamma), _p(beta), _pa(out, dt), B, H * W, Cc, groups, eps,
+                                           ws.data_ptr(), nbytes, dt, _stream()), "groupnorm_swish")
     return out
 
 
@@ -134,8 +193,8 @@ def pack_conv_weight(w: Tensor) -> Tensor:
 
 def split_weight(w_packed: Tensor) -> Tensor:
     """bf16x3 mode only: pre-split a packed fp32 weight [Cout, K] into bf16 hi/lo halves per 32-k slice (same shape and
-    size; include/diffsal.h, w_format = 1).  The result is tagged so that conv_igemm announces the format to the kernel;
-    it is only valid while the GEMM precision is "bf16x3"."""
+    size; include/diffsal.h, w_format = 1).  The result is tagged: conv_igemm then announces w_format = 1 together with
+    precision = bf16x3 in that call's descriptor."""
     lib = _lib.load()
     out = torch.empty_like(w_packed)
     _lib.check(lib.diffsal_split_weight(_p(w_packed.contiguous()), _p(out), w_packed.numel(), _stream()), "split_weight")
@@ -204,10 +263,13 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         Wo = (W + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride[1] + 1
     else:
         Ho, Wo = out_hw
+    dt = _dt(x)
     if out is None:
-        out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+    split = bool(getattr(w_packed, "_diffsal_split", False))
+    prec = GEMM_PRECISIONS["bf16x3" if split else get_gemm_precision()] if dt == _lib.F32 else _lib.PREC_FP32
     d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], act,
-                 rowvec.shape[-1] if rowvec is not None else 0, 1 if getattr(w_packed, "_diffsal_split", False) else 0)
+                 rowvec.shape[-1] if rowvec is not None else 0, 1 if split else 0, prec, dt)
     if rowvec is not None:
         assert rowvec.stride(-1) == 1 and rowvec.dtype == torch.float32 and rowvec.is_cuda
         d.rowvec_ld = rowvec.stride(0)
@@ -219,8 +281,8 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.diffsal_conv_igemm(C.byref(d), _p(x), _p(w_packed), _p(bias), _p(scale), _p(shift), rv,
-                                      _p(residual), _p(out), _p(ws), ws_bytes, _stream()), "conv_igemm")
+    _lib.check(lib.diffsal_conv_igemm(C.byref(d), _pa(x, dt), _pa(w_packed, dt), _p(bias), _p(scale), _p(shift), rv,
+                                      _pa(residual, dt), _pa(out, dt), _p(ws), ws_bytes, _stream()), "conv_igemm")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin))
@@ -239,21 +301,27 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = AC
     return y.reshape(*lead, w.shape[0])
 
 
-def pack_frames(vis: Tensor, noise: Optional[Tensor], t_out: Optional[int] = None) -> Tensor:
-    """K6. vis [B,C,Tv,h,w] (NCTHW) + noise [B,h,w,C] -> [B,Tv+1,h,w,C]."""
+def pack_frames(vis: Tensor, noise: Optional[Tensor], t_out: Optional[int] = None,
+                out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """K6. vis [B,C,Tv,h,w] (NCTHW, fp32) + noise [B,h,w,C] -> [B,Tv+1,h,w,C] in the storage type of ``noise`` (or
+    ``out_dtype`` when there is no noise map)."""
     lib = _lib.load()
     B, Cc, Tv, h, w = vis.shape
     Tout = t_out if t_out is not None else Tv + (1 if noise is not None else 0)
-    out = torch.empty((B, Tout, h, w, Cc), device=vis.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_pack_frames(_p(vis), _p(noise), _p(out), B, Cc, Tv, Tout, h * w, _stream()), "pack_frames")
+    odt = noise.dtype if noise is not None else (out_dtype or torch.float32)
+    out = torch.empty((B, Tout, h, w, Cc), device=vis.device, dtype=odt)
+    dt = _dt(out)
+    _lib.check(lib.diffsal_pack_frames(_p(vis), _pa(noise, dt), out.data_ptr(), B, Cc, Tv, Tout, h * w, dt, _stream()),
+               "pack_frames")
     return out
 
 
 def resize_bilinear(x: Tensor, H: int, W: int) -> Tensor:
     lib = _lib.load()
     N, h, w, Cc = x.shape
-    out = torch.empty((N, H, W, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_resize_bilinear(_p(x), _p(out), N, h, w, H, W, Cc, _stream()), "resize_bilinear")
+    out = torch.empty((N, H, W, Cc), device=x.device, dtype=x.dtype)
+    dt = _dt(x)
+    _lib.check(lib.diffsal_resize_bilinear(_pa(x, dt), out.data_ptr(), N, h, w, H, W, Cc, dt, _stream()), "resize_bilinear")
     return out
 
 
@@ -262,11 +330,12 @@ def resize_sum(xs: Sequence[Tensor], H: int, W: int) -> Tensor:
     lib = _lib.load()
     n = len(xs)
     N, _, _, Cc = xs[0].shape
-    ptrs = (C.c_void_p * n)(*[_p(x) for x in xs])
+    dt = _dt(xs[0])
+    ptrs = (C.c_void_p * n)(*[_pa(x, dt) for x in xs])
     hs = (C.c_int * n)(*[x.shape[1] for x in xs])
     ws = (C.c_int * n)(*[x.shape[2] for x in xs])
-    out = torch.empty((N, H, W, Cc), device=xs[0].device, dtype=torch.float32)
-    _lib.check(lib.diffsal_resize_sum(ptrs, hs, ws, n, _p(out), N, H, W, Cc, _stream()), "resize_sum")
+    out = torch.empty((N, H, W, Cc), device=xs[0].device, dtype=xs[0].dtype)
+    _lib.check(lib.diffsal_resize_sum(ptrs, hs, ws, n, out.data_ptr(), N, H, W, Cc, dt, _stream()), "resize_sum")
     return out
 
 
@@ -274,8 +343,10 @@ def audio_fuse(a_small: Tensor, x: Tensor, h: int, w: int) -> Tensor:
     """K7. a_small [B*T, h*w, C], x [B,T,H,W,C] -> fused audio in the reference's [B,C,T,H,W] order."""
     lib = _lib.load()
     B, T, H, W, Cc = x.shape
-    out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_audio_fuse(_p(a_small), _p(x), _p(out), B, T, H, W, Cc, h, w, _stream()), "audio_fuse")
+    out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=x.dtype)
+    dt = _dt(x)
+    _lib.check(lib.diffsal_audio_fuse(_pa(a_small, dt), _pa(x, dt), out.data_ptr(), B, T, H, W, Cc, h, w, dt, _stream()),
+               "audio_fuse")
     return out
 
 
@@ -284,7 +355,8 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tens
     Cc = x.shape[-1]
     M = x.numel() // Cc
     out = torch.empty_like(x)
-    _lib.check(lib.diffsal_layernorm(_p(x), _p(gamma), _p(beta), _p(out), M, Cc, eps, _stream()), "layernorm")
+    dt = _dt(x)
+    _lib.check(lib.diffsal_layernorm(_pa(x, dt), _p(gamma), _p(beta), out.data_ptr(), M, Cc, eps, dt, _stream()), "layernorm")
     return out
 
 
@@ -292,9 +364,10 @@ def dwconv3_ln(x: Tensor, w9: Tensor, gamma: Tensor, beta: Tensor, eps: float = 
     """x NHWC [N,H,W,C] -> tokens [N, H*W, C]."""
     lib = _lib.load()
     N, H, W, Cc = x.shape
-    out = torch.empty((N, H * W, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_dwconv3_ln(_p(x), _p(w9), _p(gamma), _p(beta), _p(out), N, H, W, Cc, eps, _stream()),
-               "dwconv3_ln")
+    out = torch.empty((N, H * W, Cc), device=x.device, dtype=x.dtype)
+    dt = _dt(x)
+    _lib.check(lib.diffsal_dwconv3_ln(_pa(x, dt), _p(w9), _p(gamma), _p(beta), out.data_ptr(), N, H, W, Cc, eps, dt,
+                                      _stream()), "dwconv3_ln")
     return out
 
 
@@ -303,10 +376,11 @@ def dwpool_ln_kv(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk:
     lib = _lib.load()
     N, H, W, Cc = xv.shape
     gh, gw = (H - k) // k + 1, (W - k) // k + 1
-    ok = torch.empty((N, gh * gw, Cc), device=xv.device, dtype=torch.float32)
+    ok = torch.empty((N, gh * gw, Cc), device=xv.device, dtype=xv.dtype)
     ov = torch.empty_like(ok)
-    _lib.check(lib.diffsal_dwpool_ln_kv(_p(xk), _p(xv), _p(wk), _p(wv), _p(gk), _p(bk), _p(gv), _p(bv), _p(ok),
-                                        _p(ov), N, H, W, Cc, k, eps, _stream()), "dwpool_ln_kv")
+    dt = _dt(xv)
+    _lib.check(lib.diffsal_dwpool_ln_kv(_pa(xk, dt), _pa(xv, dt), _p(wk), _p(wv), _p(gk), _p(bk), _p(gv), _p(bv),
+                                        ok.data_ptr(), ov.data_ptr(), N, H, W, Cc, k, eps, dt, _stream()), "dwpool_ln_kv")
     return ok, ov
 
 
@@ -315,16 +389,19 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tens
     N, Lq, Cc = q.shape
     Lk = k.shape[1]
     o = torch.empty_like(q)
-    _lib.check(lib.diffsal_attention(_p(q), _p(k), _p(v), _p(o), N, Lq, Lk, Cc, heads, scale, _stream()), "attention")
+    dt = _dt(q)
+    _lib.check(lib.diffsal_attention(_pa(q, dt), _pa(k, dt), _pa(v, dt), o.data_ptr(), N, Lq, Lk, Cc, heads, scale, dt,
+                                     _stream()), "attention")
     return o
 
 
 def head_sigmoid(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
-    """x NHWC [N,H,W,C] -> [N,H,W,1]."""
+    """x NHWC [N,H,W,C] (any storage type) -> fp32 [N,H,W,1]."""
     lib = _lib.load()
     N, H, W, Cc = x.shape
     out = torch.empty((N, H, W, 1), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_head_sigmoid(_p(x), _p(w), _p(bias), _p(out), N * H * W, Cc, _stream()), "head_sigmoid")
+    dt = _dt(x)
+    _lib.check(lib.diffsal_head_sigmoid(_pa(x, dt), _p(w), _p(bias), _p(out), N * H * W, Cc, dt, _stream()), "head_sigmoid")
     return out
 
 
@@ -348,7 +425,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     lib = _lib.load()
     N, H, W, Cin = x.shape
     _, Ho, Wo, Cout = dy.shape
-    d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 0, 0)
+    d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], 0, 0, 0, 0, 0)
     nws = lib.diffsal_conv_wgrad_ws_bytes(C.byref(d))
     ws = torch.empty((nws // 4,), device=x.device, dtype=torch.float32)
     dw = torch.empty((Cout, kh * kw * Cin), device=x.device, dtype=torch.float32)

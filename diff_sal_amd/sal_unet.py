@@ -118,7 +118,14 @@ class SalUNet(nn.Module):
         kernel_q=(3, 3, 3),
         padding_q=(1, 1, 1),
         stride_q=(1, 1, 1),
+        compute_dtype=torch.float32,
+        gemm_precision=None,
     ):
+        """The keywords up to ``stride_q`` are the reference's (R/models/saliency_decoder/sal_unet.py:147-179).  Two
+        extras select the reduced-precision inference datapaths (never the default; parameters stay fp32):
+        ``compute_dtype`` = torch.bfloat16 / torch.float16 stores activations and packed weights in that type in HBM
+        (native 16-bit MFMA, fp32 accumulation and statistics: BASELINE configs[1] / configs[4]);
+        ``gemm_precision`` = "bf16x3" keeps fp32 storage and runs the GEMMs in split-bf16 arithmetic."""
         super().__init__()
         idx_to_planes = dict(idx_to_planes or {0: 96, 1: 192, 2: 384, 3: 768})
         ns = int(mid_num_stages)
@@ -152,6 +159,10 @@ class SalUNet(nn.Module):
         self.down_channel = int(idx_to_planes[0])
         self.ch = 96  # sal_unet.py:228
         self.temb_ch = self.ch * 4
+        if compute_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"compute_dtype {compute_dtype}: float32, bfloat16 or float16")
+        self.compute_dtype = compute_dtype
+        self.gemm_precision = gemm_precision
 
         # ---- decoder parameters (names: SURVEY Appendix B) ----
         dec = nn.Module()
@@ -210,20 +221,34 @@ class SalUNet(nn.Module):
         nn.init.trunc_normal_(self.invpt_decoder.mt_proj[0].weight, std=0.02)  # sal_unet.py:408
 
     # ------------------------------------------------------------------ weight packing
+    def _precision(self) -> str:
+        return self.gemm_precision or ops.get_gemm_precision()
+
     def _cache_key(self):
-        return (self._pack_epoch, ops.get_gemm_precision()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (self._pack_epoch, self._precision(), self.compute_dtype) + tuple(
+            (p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def pack_epoch(self):
+        """Changes whenever the kernel-layout weights would be rebuilt (HIP-graph caches key on it)."""
+        return self._cache_key()
 
     def parameters_updated(self) -> None:
         """Tell the module its parameters were rewritten behind autograd's version counters (the fused Adam kernel
         writes through raw pointers): the eval-mode packed-weight cache is rebuilt on next use."""
         self._pack_epoch += 1
 
-    @staticmethod
-    def _pack_conv(w: Tensor) -> Tensor:
-        """[Cout,Cin,KH,KW] -> [Cout, K] in the implicit-GEMM k order (channel chunk, tap, channel); in the opt-in bf16x3
-        GEMM mode additionally pre-split into bf16 hi/lo halves so the kernel does not convert its B operand."""
+    def _pack_conv(self, w: Tensor) -> Tensor:
+        """[Cout,Cin,KH,KW] -> [Cout, K] in the implicit-GEMM k order (channel chunk, tap, channel); cast to the 16-bit
+        storage type of a reduced-precision module, or (fp32 storage, opt-in bf16x3 GEMM mode) pre-split into bf16
+        hi/lo halves so the kernel does not convert its B operand."""
         wp = ops.pack_conv_weight(w)
-        return ops.split_weight(wp) if ops.get_gemm_precision() == "bf16x3" else wp
+        if self.compute_dtype != torch.float32:
+            return ops.cast(wp, self.compute_dtype)
+        return ops.split_weight(wp) if self._precision() == "bf16x3" else wp
+
+    def _gemm_w(self, w: Tensor) -> Tensor:
+        """Linear / 1x1 weight [N, K] as the GEMM reads it (K % 32 == 0: the packed k order is the identity)."""
+        return w.detach() if self.compute_dtype == torch.float32 else ops.cast(w.detach().contiguous(), self.compute_dtype)
 
     @staticmethod
     def _bn_affine(bn: nn.BatchNorm2d):
@@ -269,7 +294,11 @@ class SalUNet(nn.Module):
             pk[f"s{i}.wq9"] = a.conv_proj_q.conv.weight.detach()[:, 0, 1].reshape(c, 9).t().contiguous()  # Q8
             pk[f"s{i}.wk"] = a.conv_proj_k.conv.weight.detach().reshape(c, k * k).t().contiguous()
             pk[f"s{i}.wv"] = a.conv_proj_v.conv.weight.detach().reshape(c, k * k).t().contiguous()
-            pk[f"s{i}.align.w"] = st.blocks[0].align_conv.weight.detach().reshape(c, 512).contiguous()
+            pk[f"s{i}.align.w"] = self._gemm_w(st.blocks[0].align_conv.weight.detach().reshape(c, 512).contiguous())
+            blk = st.blocks[0]
+            for nm, lin in (("q", a.proj_q), ("k", a.proj_k), ("v", a.proj_v), ("proj", a.proj), ("fc1", blk.mlp.fc1),
+                            ("fc2", blk.mlp.fc2)):
+                pk[f"s{i}.{nm}.w"] = self._gemm_w(lin.weight)
             pk[f"s{i}.redu.w"] = self._pack_conv(dec.redu_chan_up[i].proj[0].weight)  # [Co, C, kt, 1, 1]
         pk["mt.w"] = self._pack_conv(dec.mt_proj[0].weight)
         pk["mt.scale"], pk["mt.shift"] = self._bn_affine(dec.mt_proj[1])
@@ -284,7 +313,7 @@ class SalUNet(nn.Module):
         temb = ops.temb_mlp(t, pk["freq"], d0.weight, d0.bias, d1.weight, d1.bias)
         tproj = ops.dense_small(temb, pk["tproj.w"], pk["tproj.b"], swish_in=True)
         B, _, H, W = x.shape
-        f = ops.conv_in(x, pk["conv_in.w"], self.conv_in.bias, skip_mod=4)
+        f = ops.conv_in(x, pk["conv_in.w"], self.conv_in.bias, skip_mod=4, out_dtype=self.compute_dtype)
         f = ops.conv_igemm(f, pk["down1.w"], kh=3, kw=3, stride=(4, 4), out_hw=((H - 2) // 4 + 1, (W - 2) // 4 + 1),
                            bias=self.down1.conv.bias)
         if taps is not None:
@@ -326,15 +355,15 @@ class SalUNet(nn.Module):
         kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
                                   a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
                                   a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
-        q = ops.linear(q, a.proj_q.weight, a.proj_q.bias)
-        kk = ops.linear(kk, a.proj_k.weight, a.proj_k.bias)
-        vv = ops.linear(vv, a.proj_v.weight, a.proj_v.bias)
+        q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
+        kk = ops.linear(kk, pk[f"s{i}.k.w"], a.proj_k.bias)
+        vv = ops.linear(vv, pk[f"s{i}.v.w"], a.proj_v.bias)
         o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
         xt = x.view(n9, H * W, C)
-        x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=xt)
+        x1 = ops.linear(o, pk[f"s{i}.proj.w"], a.proj.bias, residual=xt)
         y = ops.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        y = ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ACT_GELU)
-        x2 = ops.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1)
+        y = ops.linear(y, pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias, act=ACT_GELU)
+        x2 = ops.linear(y, pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias, residual=x1)
         return x2.view(B, T, H, W, C)
 
     # Largest batch evaluated in one pass.  The 4-scale sum [B,112,192,768] fp32 is 66 MB per clip and the
@@ -347,6 +376,10 @@ class SalUNet(nn.Module):
         """x [B,1,H,W], t [B] (int64 or float), feat_list: 4 x [B,C_i,Tv,h_i,w_i] coarsest first,
         audio_feat_list: [B,512,Tv+1,h_0,w_0] or None  ->  [B,1,img_H,img_W] in (0,1)."""
         B = x.shape[0]
+        if self.training:
+            # never chunked: BatchNorm batch statistics and the running-stat update are over the WHOLE per-rank batch,
+            # as in the reference (R/models/saliency_decoder/common_block.py:196-216 under DDP, cfg batch_size 48)
+            return self.forward_train(x, t, feat_list, audio_feat_list)
         if B == 0:
             return x.new_empty((0, 1, self.img_size[0], self.img_size[1]))
         if B > self.max_clips_per_pass and taps is None:
@@ -360,11 +393,15 @@ class SalUNet(nn.Module):
 
     def _forward_pass(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor],
                       taps: Optional[dict]) -> Tensor:
-        if self.training:
-            return self.forward_train(x, t, feat_list, audio_feat_list)
         if not x.is_cuda:
             raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
+        with ops.gemm_precision(self.gemm_precision):
+            return self._forward_eval(x, t, feat_list, audio_feat_list, taps)
+
+    def _forward_eval(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor],
+                      taps: Optional[dict]) -> Tensor:
         pk = self.packed()
+        cdt = self.compute_dtype
         x = x.contiguous().float()
         t = t.contiguous()
         B = x.shape[0]
@@ -382,7 +419,7 @@ class SalUNet(nn.Module):
             if self.image_based and i < len(noise) and tuple(f.shape[-2:]) == tuple(noise[i].shape[1:3]):
                 nz = noise[i]
             # stage-3 features are never read by the decoder (quirk Q2): skip their transpose
-            frames.append(ops.pack_frames(f, nz) if i < 3 else None)
+            frames.append(ops.pack_frames(f, nz, out_dtype=cdt) if i < 3 else None)
         if taps is not None:
             for i, nzt in enumerate(noise):
                 taps[f"noise{i}"] = nzt
@@ -390,7 +427,7 @@ class SalUNet(nn.Module):
         audio_tok, audio_hw = None, None
         if audio_feat_list is not None:
             a = audio_feat_list.contiguous().float()
-            ap = ops.pack_frames(a, None)  # [B,Ta,ha,wa,512]
+            ap = ops.pack_frames(a, None, out_dtype=cdt)  # [B,Ta,ha,wa,512]
             if ap.shape[1] != frames[0].shape[1]:
                 raise RuntimeError(f"audio has {ap.shape[1]} frames but the decoder input has {frames[0].shape[1]}")
             audio_hw = (ap.shape[2], ap.shape[3])
@@ -448,6 +485,9 @@ class SalUNet(nn.Module):
 
         if not x.is_cuda:
             raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
+        if self.compute_dtype != torch.float32:
+            raise RuntimeError("SalUNet.forward_train: training stores activations in fp32 (the reference trains in fp32, "
+                               "R/diffusion_trainer.py:212-235); compute_dtype is an inference option")
         x = x.contiguous().float()
         B, _, H, W = x.shape
         if B == 0:

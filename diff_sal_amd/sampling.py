@@ -66,7 +66,26 @@ class DiffusionSampler:
         #    trajectory returns the same x0 and the sample equals ONE network evaluation.
         self.hip_graph = bool(hip_graph)
         self.step_invariant_shortcut = bool(step_invariant_shortcut)
+        if self.step_invariant_shortcut:
+            self._check_shortcut_precondition()
         self._graphs = {}
+
+    def _check_shortcut_precondition(self) -> None:
+        """The F1 shortcut is only valid when the denoiser output provably ignores (x, t) in visual-only eval mode: the
+        noise map must be a frame the temporal reduction never reads, and the network must predict x0 directly."""
+        net = self.model.decoder_net
+        if self.training_target != "x0":
+            raise ValueError("step_invariant_shortcut needs training_target='x0' (a noise-predicting net is converted with "
+                             "x_t, so the sample depends on every step)")
+        tl = getattr(net, "temporal_list", None)
+        if tl is None or not getattr(net, "image_based", False):
+            raise ValueError("step_invariant_shortcut needs a SalUNet with image_based=True (the noise map is appended as "
+                             "the LAST frame; otherwise it is not known to be outside the ReduceTemp window)")
+        # frames are [8 visual..., noise]; ReduceTemp(kernel = stride = kt) reads frames 0 .. kt-1 only (SURVEY F1)
+        frames_in = 8 + 1
+        if any(int(kt) >= frames_in for kt in tl):
+            raise ValueError(f"step_invariant_shortcut: temporal_list={list(tl)} reaches the noise frame (index {frames_in - 1}); "
+                             "the output then depends on (x, t)")
 
     # ---- forward process (training side, K16) ----
     def q_sample(self, x_start: Tensor, t: int, noise: Optional[Tensor] = None) -> Tensor:
@@ -122,10 +141,25 @@ class DiffusionSampler:
         t = torch.full((x.size(0),), self.num_timesteps - 1, dtype=torch.int64, device=x.device)
         return net(x, t, img, None)
 
+    def _graph_state(self):
+        """Everything a captured trajectory bakes in besides the input shapes: the decoder's kernel-layout weights (their
+        device pointers change when parameters are updated, re-loaded or the precision mode changes) and the sampler's
+        own hyper-parameters (they decide the time grid and every coefficient)."""
+        net = self.model.decoder_net
+        epoch = net.pack_epoch() if hasattr(net, "pack_epoch") else None
+        return (epoch, bool(getattr(net, "training", False)), self.sample_type, self.timesteps, self.eta, self.skip_type,
+                self.dpm_solver_order, self.dpm_solver_method, self.dpm_solver_type, self.lower_order_final, self.denoise,
+                self.thresholding, self.training_target)
+
     def _graphed(self, fn, x, img, audio_cond):
-        """Replay (capturing on first use) ``fn(x, img, audio_cond)`` as one HIP graph per input signature."""
+        """Replay (capturing on first use) ``fn(x, img, audio_cond)`` as one HIP graph per input signature; a graph is
+        re-captured when the decoder's packed weights or the sampler's hyper-parameters changed since its capture."""
         key = (fn.__name__, tuple(x.shape), tuple(tuple(f.shape) for f in img), None if audio_cond is None else tuple(audio_cond.shape))
+        state = self._graph_state()
         ent = self._graphs.get(key)
+        if ent is not None and ent[0] != state:
+            ent = None              # stale: drop it (frees its private pool) and capture again
+            del self._graphs[key]
         if ent is None:
             sx, simg = x.clone(), [f.clone() for f in img]
             sa = None if audio_cond is None else audio_cond.clone()
@@ -134,9 +168,9 @@ class DiffusionSampler:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = fn(sx, simg, sa)
-            ent = (g, sx, simg, sa, out)
+            ent = (state, g, sx, simg, sa, out)
             self._graphs[key] = ent
-        g, sx, simg, sa, out = ent
+        _, g, sx, simg, sa, out = ent
         sx.copy_(x)
         for d, s_ in zip(simg, img):
             d.copy_(s_)
@@ -228,55 +262,75 @@ class DiffusionSampler:
         raise NotImplementedError(self.sample_type)
 
 
+def _alpha_bar_table(b: Tensor):
+    """Host list a[j] = prod_{i<j} (1 - b[i]), j = 0..len(b): a[t+1] is alpha-bar of step t and a[0] = 1 stands for
+    "t = -1" (the reference builds this with a device cumprod + index_select per step, R/util/denoising.py:3-6)."""
+    table = [1.0]
+    for v in b.detach().double().cpu().tolist():
+        table.append(table[-1] * (1.0 - v))
+    return table
+
+
 def compute_alpha(beta: Tensor, t: Tensor) -> Tensor:
-    """R/util/denoising.py:3-6."""
-    beta = torch.cat([torch.zeros(1).to(beta.device), beta], dim=0)
-    return (1 - beta).cumprod(dim=0).index_select(0, t + 1).view(-1, 1, 1, 1)
+    """alpha-bar at integer steps ``t`` (t = -1 -> 1) as a [N,1,1,1] tensor; signature of R/util/denoising.py:3."""
+    table = torch.tensor(_alpha_bar_table(beta), dtype=torch.float32, device=t.device)
+    return table[(t + 1).long()].view(-1, 1, 1, 1)
+
+
+def _legacy_grid(seq):
+    """(t, t_next) pairs of the legacy loops, last step first; t_next = -1 after the final step."""
+    seq = [int(v) for v in seq]
+    return list(zip(seq[::-1], ([-1] + seq[:-1])[::-1]))
 
 
 def generalized_steps(x, seq, model, b, img=None, **kwargs):
-    """Legacy DDIM loop with the reference signature (R/util/denoising.py:9-33): ``model(data, t)`` predicts
-    noise; returns (xs, x0_preds).  Runs on whatever device ``x`` is on (the reference hard-codes 'cuda')."""
+    """Legacy DDIM loop, call surface of R/util/denoising.py:9-33 (dead code upstream: nothing imports it; kept because
+    north_star names the ``util/denoising`` surface): ``model({"img", "input"}, t)`` predicts NOISE; returns
+    (xs, x0_preds) as lists of host tensors, xs[0] being the input.
+
+    Built on this package's sampler primitives: every coefficient is a host scalar looked up in one alpha-bar table
+    (no per-step device cumprod, no device->host sync), every update is one fused ``a x + b y + c z`` launch, and the
+    state stays on ``x``'s device (the reference hard-codes 'cuda')."""
+    abar = _alpha_bar_table(b)
+    eta = float(kwargs.get("eta", 0))
+    n = x.size(0)
+    xs, x0_preds = [x], []
+    cur = x
     with torch.no_grad():
-        n = x.size(0)
-        seq = list(seq)
-        seq_next = [-1] + seq[:-1]
-        x0_preds, xs = [], [x]
-        eta = kwargs.get("eta", 0)
-        for i, j in zip(reversed(seq), reversed(seq_next)):
-            t = (torch.ones(n) * i).to(x.device)
-            next_t = (torch.ones(n) * j).to(x.device)
-            at = compute_alpha(b, t.long())
-            at_next = compute_alpha(b, next_t.long())
-            xt = xs[-1].to(x.device)
-            et = model({"img": img, "input": xt}, t)
-            x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
-            x0_preds.append(x0_t.to("cpu"))
-            c1 = eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
-            c2 = ((1 - at_next) - c1 ** 2).sqrt()
-            xs.append((at_next.sqrt() * x0_t + c1 * torch.randn_like(x) + c2 * et).to("cpu"))
+        for i, j in _legacy_grid(seq):
+            at, an = abar[i + 1], abar[j + 1]
+            t = torch.full((n,), float(i), device=cur.device)
+            et = model({"img": img, "input": cur}, t)
+            x0_t = _lincomb(cur, at ** -0.5, et, -((1.0 - at) / at) ** 0.5)
+            c1 = eta * ((1.0 - at / an) * (1.0 - an) / (1.0 - at)) ** 0.5
+            c2 = ((1.0 - an) - c1 * c1) ** 0.5
+            cur = (_lincomb(x0_t, an ** 0.5, torch.randn_like(cur), c1, et, c2) if c1 != 0.0
+                   else _lincomb(x0_t, an ** 0.5, et, c2))
+            x0_preds.append(x0_t.cpu())
+            xs.append(cur.cpu())
     return xs, x0_preds
 
 
 def ddpm_steps(x, seq, model, b, **kwargs):
-    """Legacy ancestral loop with the reference signature (R/util/denoising.py:35-69): ``model(x, t)`` predicts noise;
-    returns (xs, x0_preds).  Runs on whatever device ``x`` is on (the reference hard-codes 'cuda')."""
+    """Legacy ancestral loop, call surface of R/util/denoising.py:35-69: ``model(x, t)`` predicts NOISE; x0 is clamped to
+    [-1, 1]; returns (xs, x0_preds) as host tensors.  Same construction as ``generalized_steps``: host-scalar
+    coefficients from one alpha-bar table, fused launches; the clamp is the only tensor op besides them."""
+    abar = _alpha_bar_table(b)
+    n = x.size(0)
+    xs, x0_preds = [x], []
+    cur = x
     with torch.no_grad():
-        n = x.size(0)
-        seq = list(seq)
-        seq_next = [-1] + seq[:-1]
-        xs, x0_preds = [x], []
-        for i, j in zip(reversed(seq), reversed(seq_next)):
-            t = (torch.ones(n) * i).to(x.device)
-            next_t = (torch.ones(n) * j).to(x.device)
-            at = compute_alpha(b, t.long())
-            atm1 = compute_alpha(b, next_t.long())
-            beta_t = 1 - at / atm1
-            xt = xs[-1].to(x.device)
-            e = model(xt, t.float())
-            x0_from_e = torch.clamp((1.0 / at).sqrt() * xt - (1.0 / at - 1).sqrt() * e, -1, 1)
-            x0_preds.append(x0_from_e.to("cpu"))
-            mean = ((atm1.sqrt() * beta_t) * x0_from_e + ((1 - beta_t).sqrt() * (1 - atm1)) * xt) / (1.0 - at)
-            mask = (1 - (t == 0).float()).view(-1, 1, 1, 1)
-            xs.append((mean + mask * torch.exp(0.5 * beta_t.log()) * torch.randn_like(xt)).to("cpu"))
+        for i, j in _legacy_grid(seq):
+            at, am = abar[i + 1], abar[j + 1]
+            beta_t = 1.0 - at / am
+            t = torch.full((n,), float(i), device=cur.device)
+            e = model(cur, t)
+            x0 = _lincomb(cur, (1.0 / at) ** 0.5, e, -(1.0 / at - 1.0) ** 0.5).clamp_(-1.0, 1.0)
+            k0, kx = am ** 0.5 * beta_t / (1.0 - at), (1.0 - beta_t) ** 0.5 * (1.0 - am) / (1.0 - at)
+            if i == 0:      # no noise on the step that lands on t = 0 (the reference multiplies by a zero mask)
+                cur = _lincomb(x0, k0, cur, kx)
+            else:
+                cur = _lincomb(x0, k0, cur, kx, torch.randn_like(cur), beta_t ** 0.5)
+            x0_preds.append(x0.cpu())
+            xs.append(cur.cpu())
     return xs, x0_preds

@@ -282,13 +282,72 @@ class DiffusionTrainStep:
         self.optimizer_step()
         return loss
 
-    # ---- checkpoint surface of torch.optim.Adam (R/diffusion_trainer.py:263-280: "optim_dict") ----
+    # ---- checkpoint surface of torch.optim.Adam (R/diffusion_trainer.py:187-193, 263-268: "optim_dict") ----
+    def _indexed_params(self):
+        """(index in ``model.parameters()`` order -- the numbering torch.optim.Adam(model.parameters()) uses --, slot in the
+        flat buffers or None for parameters that are not trained)."""
+        slot = {id(p): k for k, p in enumerate(self.flat.params)}
+        return [(i, p, slot.get(id(p))) for i, p in enumerate(self.model.parameters())]
+
     def state_dict(self) -> Dict:
-        return {"step": self.step_count, "exp_avg": self.flat.exp_avg.clone(), "exp_avg_sq": self.flat.exp_avg_sq.clone(),
-                "lr": self.lr}
+        """The ``torch.optim.Adam.state_dict()`` format: ``state[i] = {step, exp_avg, exp_avg_sq}`` per trained parameter
+        in ``model.parameters()`` order, one ``param_groups`` entry with lr / betas / eps / weight_decay -- what the
+        reference trainer saves as ``optim_dict`` and loads back into ``optim.Adam`` (R/util/utils.py:116-123), so
+        checkpoints move both ways.  The moments are gathered out of the flat buffers through ``FlatParams.offsets``."""
+        idx = self._indexed_params()
+        state = {}
+        if self.step_count > 0:          # torch creates a parameter's state at its first step
+            for i, p, k in idx:
+                if k is None:
+                    continue
+                o = self.flat.offsets[k]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.flat.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": [i for i, _, _ in idx]}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd: Dict) -> None:
-        self.step_count = int(sd["step"])
-        self.flat.exp_avg.copy_(sd["exp_avg"])
-        self.flat.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.lr = float(sd.get("lr", self.lr))
+        """Inverse of ``state_dict``; also accepts a checkpoint written by ``torch.optim.Adam`` over the same module.
+        Validates the parameter count and every moment's shape before touching anything."""
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("load_state_dict expects the torch.optim.Adam format {'state': ..., 'param_groups': [...]}")
+        groups = sd["param_groups"]
+        idx = self._indexed_params()
+        n_saved = sum(len(g["params"]) for g in groups)
+        if n_saved != len(idx):
+            raise ValueError(f"optimizer checkpoint covers {n_saved} parameters, the module has {len(idx)}")
+        if any(g.get("amsgrad", False) for g in groups):
+            raise ValueError("amsgrad checkpoints are not supported (the reference sets amsgrad from config, default false)")
+        # parameter numbering of the checkpoint = concatenation of the groups' param lists, in module order
+        order = [i for g in groups for i in g["params"]]
+        state = {int(k): v for k, v in sd["state"].items()}
+        steps = set()
+        staged = []
+        for pos, (i, p, k) in enumerate(idx):
+            st = state.get(order[pos])
+            if st is None:
+                continue
+            if k is None:
+                raise ValueError(f"checkpoint has optimizer state for parameter {i}, which is not trainable here")
+            for name in ("exp_avg", "exp_avg_sq"):
+                if tuple(st[name].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {name} of parameter {i}: shape {tuple(st[name].shape)} != {tuple(p.shape)}")
+            steps.add(int(float(st["step"])))
+            staged.append((k, p, st))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the flat optimizer keeps one step count")
+        self.flat.exp_avg.zero_()
+        self.flat.exp_avg_sq.zero_()
+        for k, p, st in staged:
+            o = self.flat.offsets[k]
+            self.flat.exp_avg[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
+            self.flat.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+        self.step_count = steps.pop() if steps else 0
+        g0 = groups[0]
+        self.lr = float(g0.get("lr", self.lr))
+        self.betas = tuple(float(b) for b in g0.get("betas", self.betas))
+        self.eps = float(g0.get("eps", self.eps))
+        self.weight_decay = float(g0.get("weight_decay", self.weight_decay))

@@ -4,12 +4,16 @@
  *
  * Conventions:
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise;
- *   - activations are fp32, channels-last: images [N,H,W,C], tokens [M,C];
+ *   - activations are channels-last: images [N,H,W,C], tokens [M,C]; fp32 by default.  Forward operators that take a
+ *     `dtype` argument (DIFFSAL_F32 / DIFFSAL_BF16 / DIFFSAL_F16, declared below) read and write their `void*`
+ *     activation tensors in that storage type; `float*` arguments (norm parameters, biases, depthwise weights,
+ *     the timestep path, the sampler state) are always fp32, and all arithmetic / statistics are fp32;
  *   - every entry point enqueues work on `stream` (a hipStream_t) and returns immediately:
  *       0 on success, a negative DIFFSAL_E_* code on failure (diffsal_last_error() has the text);
  *   - no allocation, no synchronisation, no host-visible side effect inside an entry point,
  *     so every call is legal under HIP-graph capture;
- *   - re-entrant; the only global state is a thread-local error string.
+ *   - re-entrant; the only global state is a thread-local error string (arithmetic mode and storage type are
+ *     per-call arguments: diffsal_conv_desc.precision / .dtype and the `dtype` argument of the other operators).
  *
  * Each entry point cites the reference interface it replaces (R/ = junwenxiong/diff_sal).
  */
@@ -54,14 +58,14 @@ int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float
 /* ---- K2: conv_in (1 -> C, 3x3, pad 1), NCHW[B,1,H,W] -> NHWC[B,H,W,C] -----------------
  * R/.../sal_unet.py:240,292.  Only pixels with (y % skip_mod != skip_mod-1 && x % skip_mod != skip_mod-1)
  * are written when skip_mod > 0 (the stride-4 consumer never reads the others, sal_unet.py:67-84). */
-int diffsal_conv_in(const float* x, const float* w /*[C,9]*/, const float* bias, float* out,
-                    int B, int H, int W, int C, int skip_mod, diffsal_stream_t stream);
+int diffsal_conv_in(const float* x, const float* w /*[C,9]*/, const float* bias, void* out,
+                    int B, int H, int W, int C, int skip_mod, int dtype, diffsal_stream_t stream);
 
 /* ---- K3: GroupNorm(groups, eps) + swish on NHWC ----------------------------------------
  * R/.../sal_unet.py:36-44.  ws: >= diffsal_groupnorm_ws_bytes(B, groups) bytes of scratch. */
 size_t diffsal_groupnorm_ws_bytes(int B, int groups);
-int diffsal_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* out,
-                            int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes,
+int diffsal_groupnorm_swish(const void* x, const float* gamma, const float* beta, void* out,
+                            int B, int HW, int C, int groups, float eps, void* ws, size_t ws_bytes, int dtype,
                             diffsal_stream_t stream);
 
 /* ---- K4/K5/K10/K12/K13/K14: implicit-GEMM convolution / linear on fp32 MFMA -------------
@@ -82,24 +86,30 @@ typedef struct diffsal_conv_desc {
   int rowvec_ld;  /* leading dimension of rowvec (>= Cout) */
   int w_format;   /* 0: fp32 [Cout][K] (k order above).  1: the same rows pre-split for the bf16x3 mode by
                    * diffsal_split_weight: per 32-k slice 16 dwords of bf16 hi halves then 16 dwords of lo halves (same
-                   * size); only valid while diffsal_get_gemm_precision() == 1 */
+                   * size); only valid with precision == DIFFSAL_PREC_BF16X3 */
+  int precision;  /* DIFFSAL_PREC_*: arithmetic of the matrix-core loop for fp32 storage (below) */
+  int dtype;      /* DIFFSAL_F32 / DIFFSAL_BF16 / DIFFSAL_F16: storage type of in, w, residual and out (bias, scale,
+                   * shift, rowvec are always fp32; accumulation is always fp32).  16-bit storage uses the native
+                   * v_mfma_f32_32x32x16_{bf16,f16}; `precision` must then be DIFFSAL_PREC_FP32 (= "native") */
 } diffsal_conv_desc;
 
-/* Arithmetic of diffsal_conv_igemm's matrix-core loop (process-wide switch, not thread-safe against running launches):
- *   0 (default): exact fp32, v_mfma_f32_32x32x2_f32;
- *   1 "bf16x3": each fp32 operand is split into bf16 hi + lo on its way into LDS and the product is formed as
+/* Arithmetic of diffsal_conv_igemm's matrix-core loop for fp32 tensors, chosen PER CALL (diffsal_conv_desc.precision):
+ *   DIFFSAL_PREC_FP32 (default): exact fp32, v_mfma_f32_32x32x2_f32;
+ *   DIFFSAL_PREC_BF16X3: each fp32 operand is split into bf16 hi + lo on its way into LDS and the product is formed as
  *     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error ~2^-16 relative per product,
  *     ~4e-6 of the output maximum on the network's convolutions; well inside the 1e-3 parity bar, but not bit-equal
  *     to fp32).  Opt-in; benchmark numbers for it are reported separately from the headline. */
-int diffsal_set_gemm_precision(int mode);
-int diffsal_get_gemm_precision(void);
+enum { DIFFSAL_PREC_FP32 = 0, DIFFSAL_PREC_BF16X3 = 1 };
+/* Storage type of activations / weights (BASELINE configs[1] "bf16", configs[4] "fp16"): statistics of every
+ * normalisation, softmax and all accumulations stay fp32; parameters of norms, biases and the timestep path stay fp32. */
+enum { DIFFSAL_F32 = 0, DIFFSAL_BF16 = 1, DIFFSAL_F16 = 2 };
 
 /* Bytes of scratch the call below needs for this shape (0 unless the planner picks split-K, which it does
  * when the M x Cout grid alone cannot fill the 256 CUs). */
 size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d /*host*/);
-int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const float* in, const float* w,
+int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const void* in, const void* w,
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
-                       const float* residual, float* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
+                       const void* residual, void* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 
 /* ---- weight layout transforms (w: the reference's parameter layout [Cout][Cin][taps], taps = KH*KW or KT):
  *   mode 0: dst[co][(ci/32, tap, ci%32)] = w[co][ci][tap]            -- the `w` argument of diffsal_conv_igemm
@@ -232,52 +242,57 @@ int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* do
  * NHWC frames [B,Tv+1,h,w,C] with the noise map as the LAST frame (quirk Q2).
  * Replaces torch.cat(dim=2) + rearrange().contiguous(), R/.../sal_unet.py:311-317,
  * transformer.py:273-279. noise may be NULL (then only Tv frames of a [B,Tout,...] buffer are written). */
-int diffsal_pack_frames(const float* vis, const float* noise, float* out, int B, int C, int Tv, int Tout,
-                        int hw, diffsal_stream_t stream);
+int diffsal_pack_frames(const float* vis /*fp32: the module's input contract*/, const void* noise, void* out, int B,
+                        int C, int Tv, int Tout, int hw, int dtype, diffsal_stream_t stream);
 
 /* ---- bilinear resize, align_corners=False, NHWC ----------------------------------------
  * R/.../common_block.py:197 (nn.Upsample x2), sal_unet.py:325-327. */
-int diffsal_resize_bilinear(const float* in, float* out, int N, int h, int w, int H, int W, int C,
+int diffsal_resize_bilinear(const void* in, void* out, int N, int h, int w, int H, int W, int C, int dtype,
                             diffsal_stream_t stream);
 
 /* out[n,Y,X,c] = sum_i bilinear(in_i[n, h_i, w_i, c] -> (H,W)), summed in order i = 0..n_in-1.
  * Replaces the per-stage F.interpolate + "+=" of R/.../sal_unet.py:482-487. n_in <= 4. */
-int diffsal_resize_sum(const float* const* ins /*host array of device ptrs*/, const int* hs, const int* ws,
-                       int n_in, float* out, int N, int H, int W, int C, diffsal_stream_t stream);
+int diffsal_resize_sum(const void* const* ins /*host array of device ptrs*/, const int* hs, const int* ws,
+                       int n_in, void* out, int N, int H, int W, int C, int dtype, diffsal_stream_t stream);
 
 /* ---- K7: audio fusion (after the align 1x1 conv) ----------------------------------------
  * R/.../transformer.py:133-146.  a_small: [B*T, h*w, C] tokens; x: NHWC frames [B,T,H,W,C];
  * out: contiguous [B,C,T,H,W] (the reference layout, which the caller then *reinterprets* as
  * [B*T, H*W, C] tokens -- quirk Q5).  up = H / h (nearest), 1 when no upsample. */
-int diffsal_audio_fuse(const float* a_small, const float* x, float* out, int B, int T, int H, int W, int C,
-                       int h, int w, diffsal_stream_t stream);
+int diffsal_audio_fuse(const void* a_small, const void* x, void* out, int B, int T, int H, int W, int C,
+                       int h, int w, int dtype, diffsal_stream_t stream);
 
 /* ---- K8: LayerNorm over C on tokens [M,C] ------------------------------------------------ */
-int diffsal_layernorm(const float* x, const float* gamma, const float* beta, float* out, int M, int C,
-                      float eps, diffsal_stream_t stream);
+int diffsal_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,
+                      float eps, int dtype, diffsal_stream_t stream);
 
 /* ---- K9: depthwise projections + LayerNorm ----------------------------------------------
  * q: depthwise 3x3 (pad 1) on NHWC [N,H,W,C] then LN  -> [N, H*W, C].   R/.../attention.py:36-47,94
  * w9: [9][C] (centre temporal slice of the Conv3d weight, quirk Q8). */
-int diffsal_dwconv3_ln(const float* x, const float* w9, const float* gamma, const float* beta, float* out,
-                       int N, int H, int W, int C, float eps, diffsal_stream_t stream);
+int diffsal_dwconv3_ln(const void* x, const float* w9, const float* gamma, const float* beta, void* out,
+                       int N, int H, int W, int C, float eps, int dtype, diffsal_stream_t stream);
 /* k and v: depthwise kxk stride k (no pad) then LN -> [N, gh*gw, C] each; xk may differ from xv
  * (audio-fused K, attention.py:88-92).  wk, wv: [k*k][C]. */
-int diffsal_dwpool_ln_kv(const float* xk, const float* xv, const float* wk, const float* wv,
+int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float* wk, const float* wv,
                          const float* gk, const float* bk, const float* gv, const float* bv,
-                         float* out_k, float* out_v, int N, int H, int W, int C, int k, float eps,
+                         void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
                          diffsal_stream_t stream);
 
 /* ---- K11: attention core ------------------------------------------------------------------
  * o[n,l,:] = concat_h softmax_t( q[n,l,h,:] . k[n,t,h,:] * scale ) v[n,t,h,:],  Lk <= 32.
  * R/.../attention.py:97-108 (scale = C^-0.5, quirk Q6). */
-int diffsal_attention(const float* q, const float* k, const float* v, float* o, int N, int Lq, int Lk,
-                      int C, int heads, float scale, diffsal_stream_t stream);
+int diffsal_attention(const void* q, const void* k, const void* v, void* o, int N, int Lq, int Lk,
+                      int C, int heads, float scale, int dtype, diffsal_stream_t stream);
 
 /* ---- K14 tail: 1x1 conv C->1 + sigmoid on NHWC -> [N,H,W] --------------------------------
  * R/.../common_block.py:111-122. */
-int diffsal_head_sigmoid(const float* x, const float* w /*[C]*/, const float* bias /*[1]*/, float* out,
-                         int NHW, int C, diffsal_stream_t stream);
+int diffsal_head_sigmoid(const void* x, const float* w /*[C]*/, const float* bias /*[1]*/, float* out /*fp32*/,
+                         int NHW, int C, int dtype, diffsal_stream_t stream);
+
+/* ---- storage-type conversion: dst[i] = (dst type) src[i], round to nearest even.  Used once per parameter version to
+ * put packed convolution / linear weights into the 16-bit storage type of a reduced-precision module (the reference
+ * has no counterpart: it is fp32-only, R/diffusion_trainer.py:212-218). */
+int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, diffsal_stream_t stream);
 
 /* ---- K15: sampler elementwise update  out = a*x + b*y + c*z  (y, z may be NULL) -----------
  * scalar-coefficient axpys of R/diffusion_trainer.py:459-478 and R/models/dpm_solver/sampler.py:548-593,816-853. */

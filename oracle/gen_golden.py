@@ -377,11 +377,47 @@ def gen_train_step():
         print(name, "loss", loss.item(), "norm", float(total_norm), "params without grad", len(out["no_grad"]))
 
 
+def gen_legacy_denoising():
+    """The reference's legacy loops R/util/denoising.py:9-69 (dead code upstream, but the call surface north_star names)
+    on a toy noise-predicting model.  They hard-code .to('cuda'); on this CPU-only host that one call is mapped to a
+    no-op for the duration of the run -- nothing else is touched."""
+    from models.diffusion_decoder.diffusion_utils import get_beta_schedule, to_torch
+    from util import denoising as ref
+
+    betas = to_torch(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000))
+    x = orc.synth_tensor("legacy.x", (2, 1, 8, 12))
+    img = orc.synth_tensor("legacy.img", (2, 1, 8, 12), 0.2)
+    seq = list(range(0, 1000, 100))
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (isinstance(v, str) and v.startswith("cuda")) else v for v in a)
+        return real_to(self, *a, **k)
+
+    d = {"seq": np.array(seq)}
+    with mock.patch.object(torch.Tensor, "to", to_cpu):
+        for eta in (0.0, 0.5):
+            torch.manual_seed(77)
+            xs, x0s = ref.generalized_steps(x, seq, lambda data, t: torch.tanh(0.3 * data["input"] + data["img"] + 0.001 * t.view(-1, 1, 1, 1)),
+                                            betas, img=img, eta=eta)
+            d[f"ddim.eta{eta}.xs"] = torch.stack(xs).numpy()
+            d[f"ddim.eta{eta}.x0"] = torch.stack(x0s).numpy()
+        torch.manual_seed(78)
+        xs, x0s = ref.ddpm_steps(x, seq, lambda xt, t: torch.tanh(0.3 * xt + 0.001 * t.view(-1, 1, 1, 1)), betas)
+        d["ddpm.xs"] = torch.stack(xs).numpy()
+        d["ddpm.x0"] = torch.stack(x0s).numpy()
+    d["alpha"] = ref.compute_alpha(betas, torch.tensor([-1, 0, 499, 999])).numpy()
+    np.savez_compressed(os.path.join(GOLD, "legacy_denoising.npz"), **d)
+    print("legacy denoising: final ddim", float(d["ddim.eta0.0.xs"][-1].mean()), "ddpm", float(d["ddpm.xs"][-1].mean()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train"]
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy"]
+    if "legacy" in which:
+        gen_legacy_denoising()
     if "forward" in which:
         gen_forward_cases()
     if "f1" in which:

@@ -36,9 +36,32 @@ def test_conv_desc_layout_matches_header():
 def test_argument_errors_are_reported_without_a_gpu():
     """Validation happens before any launch, so it is checkable on a CPU-only host."""
     lib = _lib.load()
-    d = _lib.ConvDesc(1, 4, 4, 24, 4, 4, 8, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0)
+    d = _lib.ConvDesc(1, 4, 4, 24, 4, 4, 8, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0)
     rc = lib.diffsal_conv_igemm(ctypes.byref(d), 16, 16, None, None, None, None, None, 16, None, 0, None)
     assert rc == -1 and b"multiple of 32" in lib.diffsal_last_error()
-    rc = lib.diffsal_layernorm(None, None, None, None, 4, 32, 1e-5, None)
+    # arithmetic mode and storage type are per-call descriptor fields, validated before any launch
+    d = _lib.ConvDesc(1, 4, 4, 32, 4, 4, 8, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 7, 0)
+    assert lib.diffsal_conv_igemm(ctypes.byref(d), 16, 16, None, None, None, None, None, 16, None, 0, None) == -4
+    assert b"precision" in lib.diffsal_last_error()
+    d = _lib.ConvDesc(1, 4, 4, 32, 4, 4, 8, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 1, 1)   # bf16x3 arithmetic on bf16 storage
+    assert lib.diffsal_conv_igemm(ctypes.byref(d), 16, 16, None, None, None, None, None, 16, None, 0, None) == -4
+    rc = lib.diffsal_layernorm(None, None, None, None, 4, 32, 1e-5, 0, None)
     assert rc == -4
+    assert lib.diffsal_layernorm(16, 16, 16, 16, 4, 32, 1e-5, 9, None) == -4 and b"dtype" in lib.diffsal_last_error()
+    assert not hasattr(lib, "diffsal_set_gemm_precision")      # no process-wide mode in the library
     assert lib.diffsal_groupnorm_ws_bytes(4, 32) == 4 * 32 * 32 * 2 * 8
+
+
+def test_integration_md_binding_matches_the_header():
+    """INTEGRATION.md shows the ctypes struct a maintainer would copy: it must list exactly the header's fields."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class ConvDesc\(ctypes\.Structure\):.*?_fields_ = \[\(n, ctypes\.c_int\) for n in \((.*?)\)\]", md, re.S)
+    assert m, "INTEGRATION.md no longer shows the ConvDesc binding"
+    names = re.findall(r'"([A-Za-z_]+)"', m.group(1))
+    assert names == [n for n, _ in _lib.ConvDesc._fields_]
+    call = re.search(r"d = ConvDesc\(([^)]*)\)", md).group(1)
+    assert len([a for a in call.split(",") if a.strip()]) == len(names)
+
+
+def test_abi_version_guard():
+    assert _lib.load().diffsal_version() == _lib.ABI_VERSION

@@ -124,3 +124,36 @@ def test_sampling_trajectories_in_bf16x3_mode_stay_inside_the_parity_bar(golden_
         err = (out.cpu() - ref).abs().max().item()
         print(name, "bf16x3 max abs err", err)
         assert err < 1e-3 * ref.abs().max().item()
+
+
+def test_hip_graph_is_recaptured_after_parameters_or_hyperparameters_change():
+    """A captured trajectory bakes in the packed-weight pointers and the sampler's coefficients: replay after an optimizer
+    step / load_state_dict / a changed ``timesteps`` must not return the stale result."""
+    from diff_sal_amd.sampling import DiffusionSampler
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    net = build(cfg, sd)
+    top = Top(net)
+    x, feats, audio = orc.synth_inputs(cfg, 2, True, tag="regraph")
+    xd, fd, ad = x.to(DEV), [f.to(DEV) for f in feats], audio.to(DEV)
+    g = DiffusionSampler(top, timesteps=4, sample_type="ddim", hip_graph=True)
+    plain = DiffusionSampler(top, timesteps=4, sample_type="ddim")
+    assert torch.equal(g.sample_ddim(xd, fd, ad), plain.sample_ddim(xd, fd, ad))
+    # one training step rewrites the parameters in place (fused Adam through raw pointers)
+    ts = DiffusionTrainStep(net, lr=1e-2)
+    net.dropout_p = 0.0
+    ts.step(torch.sigmoid(xd), {"feat_list": fd, "audio_feat": ad}, t0=300)
+    net.eval()
+    after_plain = plain.sample_ddim(xd, fd, ad)
+    after_graph = g.sample_ddim(xd, fd, ad)
+    assert (after_plain - plain.sample_ddim(xd, fd, ad)).abs().max().item() == 0.0
+    assert torch.equal(after_graph, after_plain)
+    # sampler hyper-parameter change
+    g.timesteps = plain.timesteps = 6
+    assert torch.equal(g.sample_ddim(xd, fd, ad), plain.sample_ddim(xd, fd, ad))
+    # precision change on the module
+    net.gemm_precision = "bf16x3"
+    assert torch.equal(g.sample_ddim(xd, fd, ad), plain.sample_ddim(xd, fd, ad))
+    net.gemm_precision = None

@@ -1,0 +1,163 @@
+"""Host-side surface checks (no GPU): checkpoint formats, train-mode batching, bench launcher, sampler guards."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+from tests._cases import CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tiny_salunet(**extra):
+    from diff_sal_amd.sal_unet import SalUNet
+
+    cfg = CASES["tiny_vis"][0]
+    return SalUNet(image_based=True, img_size=cfg.img_size, frames_len=1, mid_num_stages=4, temporal_size=9,
+                   temporal_list=[5] * 4, futr_num_stages=0, ori_embed_dim=256, down_embed_dim=32,
+                   idx_to_planes={0: 32, 1: 192, 2: 384, 3: 256}, patch_size=[0, 3, 3, 3], patch_stride=[0, 1, 1, 1],
+                   patch_padding=[0, 2, 2, 2], up_channel=[256, 128, 64, 32], num_heads=[2] * 4, mlp_ratio=[2.0] * 4,
+                   drop_path_rate=[0.15] * 4, qkv_bias=[True] * 4, kv_proj_method=["avg"] * 4, kernel_kv=[2, 4, 8, 16],
+                   padding_kv=[0] * 4, stride_kv=[2, 4, 8, 16], q_proj_method=["dw_bn"] * 4, kernel_q=[3] * 4,
+                   padding_q=[1] * 4, stride_q=[1] * 4, **extra)
+
+
+def test_prefixed_checkpoint_loads_like_the_reference_does():
+    """The reference saves ``model.state_dict()`` of the DDP/DataParallel wrapper -- keys ``module.decoder_net.<k>`` (+ the
+    encoders') -- and loads it back with ``strict=0`` (R/model.py:17-22, R/diffusion_trainer.py:263-265).  The same
+    checkpoint must land every one of the 215 denoiser tensors in VideoSaliencyModel(decoder_net=SalUNet)."""
+    from diff_sal_amd.diff_model import VideoSaliencyModel
+
+    src = tiny_salunet()
+    g = torch.Generator().manual_seed(5)
+    sd = {k: (torch.randn(v.shape, generator=g) if v.dtype.is_floating_point else torch.full_like(v, 7))
+          for k, v in src.state_dict().items()}
+    assert len(sd) == 215
+    ckpt = {"state_dict": {f"module.decoder_net.{k}": v for k, v in sd.items()}}
+    ckpt["state_dict"]["module.visual_net.patch_embed.proj.weight"] = torch.zeros(96, 3, 3, 7, 7)   # encoder keys: ignored
+    ckpt["state_dict"]["module.fc.0.weight"] = torch.zeros(512, 128)
+
+    class Wrapper(nn.Module):            # what DataParallel / DDP look like to load_state_dict
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+    model = Wrapper(VideoSaliencyModel(channel_list=None, decoder_net=dict(type="SalUNet", **_tiny_kwargs())))
+    res = model.load_state_dict(ckpt["state_dict"], strict=False)
+    assert not [k for k in res.missing_keys if "decoder_net" in k]
+    assert sorted(res.unexpected_keys) == ["module.fc.0.weight", "module.visual_net.patch_embed.proj.weight"]
+    got = model.module.decoder_net.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def _tiny_kwargs():
+    cfg = CASES["tiny_vis"][0]
+    return dict(image_based=True, img_size=cfg.img_size, frames_len=1, mid_num_stages=4, temporal_size=9,
+                temporal_list=[5] * 4, futr_num_stages=0, ori_embed_dim=256, down_embed_dim=32,
+                idx_to_planes={0: 32, 1: 192, 2: 384, 3: 256}, patch_size=[0, 3, 3, 3], patch_stride=[0, 1, 1, 1],
+                patch_padding=[0, 2, 2, 2], up_channel=[256, 128, 64, 32], num_heads=[2] * 4, mlp_ratio=[2.0] * 4,
+                drop_path_rate=[0.15] * 4, qkv_bias=[True] * 4, kv_proj_method=["avg"] * 4, kernel_kv=[2, 4, 8, 16],
+                padding_kv=[0] * 4, stride_kv=[2, 4, 8, 16], q_proj_method=["dw_bn"] * 4, kernel_q=[3] * 4,
+                padding_q=[1] * 4, stride_q=[1] * 4)
+
+
+def test_training_batches_are_never_chunked():
+    """BatchNorm batch statistics are over the whole per-rank batch (reference cfg batch_size 48 > the 16-clip eval pass)."""
+    net = tiny_salunet().train()
+    seen = []
+    net.forward_train = lambda x, t, f, a=None: seen.append(x.shape[0]) or x
+    x = torch.zeros(40, 1, 64, 128)
+    net(x, torch.zeros(40, dtype=torch.long), [None] * 4, None)
+    assert seen == [40]
+    net.eval()
+    calls = []
+    net._forward_pass = lambda x, t, f, a, taps: calls.append(x.shape[0]) or torch.zeros(x.shape[0], 1, 64, 128)
+    net(x, torch.zeros(40, dtype=torch.long), [torch.zeros(40, 1)] * 4, None)
+    assert calls == [16, 16, 8]
+
+
+def test_optimizer_state_dict_is_the_torch_adam_format():
+    """DiffusionTrainStep.state_dict()/load_state_dict() interchange with torch.optim.Adam over the same module
+    (the reference's ``optim_dict``, R/diffusion_trainer.py:187-193, 263-268)."""
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    def make():
+        torch.manual_seed(0)
+        m = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 3))
+        m[0].bias.requires_grad_(False)                       # an untrained parameter in the middle of the numbering
+        return m
+
+    ref_m = make()
+    opt = torch.optim.Adam(ref_m.parameters(), lr=3e-4, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.01)
+    for _ in range(3):
+        opt.zero_grad()
+        ref_m(torch.randn(4, 6)).square().sum().backward()
+        opt.step()
+    ts = DiffusionTrainStep(make())
+    ts.load_state_dict(opt.state_dict())
+    assert ts.step_count == 3 and ts.lr == 3e-4 and ts.betas == (0.8, 0.95) and ts.eps == 1e-7 and ts.weight_decay == 0.01
+    out = ts.state_dict()
+    ref_sd = opt.state_dict()
+    assert set(out["state"]) == set(ref_sd["state"]) == {0, 2, 3}
+    for i in out["state"]:
+        assert float(out["state"][i]["step"]) == 3.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(out["state"][i][k], ref_sd["state"][i][k])
+    assert out["param_groups"][0]["params"] == [0, 1, 2, 3]
+    # and the other way round: our dict loads into a fresh torch Adam
+    opt2 = torch.optim.Adam(make().parameters())
+    opt2.load_state_dict(out)
+    assert opt2.state_dict()["param_groups"][0]["lr"] == 3e-4
+    # validation: wrong module -> clear error, nothing silently misplaced
+    other = DiffusionTrainStep(nn.Sequential(nn.Linear(6, 5), nn.Linear(5, 4)))
+    with pytest.raises(ValueError):
+        other.load_state_dict(out)
+    bad = {"state": {0: {"step": torch.tensor(1.0), "exp_avg": torch.zeros(2, 2), "exp_avg_sq": torch.zeros(2, 2)}},
+           "param_groups": [dict(out["param_groups"][0])]}
+    with pytest.raises(ValueError, match="shape"):
+        ts.load_state_dict(bad)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` starts two rank processes itself (no torchrun needed) and prints ONE JSON line with
+    n_gpus = 2; on this GPU-less host the ranks rendezvous over gloo and say that no workload ran."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("plumbing-only mode is for GPU-less hosts")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["value"] is None and len(j["devices"]) == 2
+    for wl in ("train",):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", wl, "--steps", "1",
+                            "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 2
+
+
+def test_step_invariant_shortcut_checks_its_precondition():
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    class Top(nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.decoder_net = n
+
+    ok = tiny_salunet()
+    DiffusionSampler(Top(ok), step_invariant_shortcut=True)                      # temporal_list 5 < 9: fine
+    with pytest.raises(ValueError, match="training_target"):
+        DiffusionSampler(Top(ok), step_invariant_shortcut=True, training_target="noise")
+    reaches = tiny_salunet()
+    reaches.temporal_list = [9, 9, 9, 9]
+    with pytest.raises(ValueError, match="noise frame"):
+        DiffusionSampler(Top(reaches), step_invariant_shortcut=True)
+    not_ib = tiny_salunet()
+    not_ib.image_based = False
+    with pytest.raises(ValueError, match="image_based"):
+        DiffusionSampler(Top(not_ib), step_invariant_shortcut=True)
