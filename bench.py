@@ -38,6 +38,40 @@ class _Stop(Exception):
     pass
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# SURVEY 8(a) rows that are dense contractions (implicit-GEMM kernel); everything else is a streaming kernel
+GEMM_CLASSES = ("K2", "K4", "K5", "K7-align", "K10", "K12", "K13", "K14", "gemm", "wgrad")
+
+
+def class_table(events, mfma_peak_tflops):
+    """Per kernel class: launches, algorithmic FLOPs and once-through bytes (SURVEY 8d denominators) of ONE
+    step, HIP-event time of exactly those launches, and the achieved fraction of BOTH rooflines; `bound` names the
+    roofline the class sits closer to, `frac` its fraction there."""
+    agg = {}
+    for e0, e1, fl, cls, nb in events:
+        a = agg.setdefault(cls, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += fl
+        a[2] += nb
+        a[3] += e0.elapsed_time(e1)
+    rows = []
+    for cls in sorted(agg, key=lambda c: -agg[c][3]):
+        n, fl, nb, ms = agg[cls]
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        gbs = nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        f_m, f_h = tf / mfma_peak_tflops, gbs / HBM_PEAK_GBS
+        bound = "mfma" if (cls in GEMM_CLASSES and f_m >= f_h) else "hbm"
+        rows.append({"class": cls, "bound": bound, "launches": n, "gflop": round(fl / 1e9, 3), "mbytes": round(nb / 1e6, 2),
+                     "ms": round(ms, 4), "tflops": round(tf, 2), "gbs": round(gbs, 1), "frac_mfma": round(f_m, 4),
+                     "frac_hbm": round(f_h, 4), "frac": round(f_m if bound == "mfma" else f_h, 4)})
+    return rows
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, the
     reference's own launch shape: `torchrun --nproc_per_node`, R/scripts/train_av.sh:13, R/train_av_data.py:38-61) and
@@ -174,28 +208,41 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
 
     for _ in range(max(args.warmup, 1)):
         ts.step(sal, cond)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            ops.PROFILE = []
-        loss = ts.step(sal, cond)
-    ev, ops.PROFILE = ops.PROFILE, None
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    regions, ev = [], []
+    for rep_i in range(args.repeats):      # each region: exactly K steps between barrier + synchronize; MAX over ranks
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if rep_i == args.repeats - 1 and i == args.steps - 1:
+                ops.PROFILE = []
+            loss = ts.step(sal, cond)
+        if ops.PROFILE is not None:
+            ev, ops.PROFILE = ops.PROFILE, None
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        regions.append(el)
+    elapsed = median(regions)
+    gemm_ev = [e for e in ev if e[3] in GEMM_CLASSES]
+    k_ms = sum(e[0].elapsed_time(e[1]) for e in gemm_ev)
+    k_flops = sum(e[2] for e in gemm_ev)
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    ranks_seen, devices = 1, [torch.cuda.get_device_name(dev)]
     if world > 1:
         import torch.distributed as dist
 
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
-    k_flops = sum(f for _, _, f in ev)
-    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        ranks_seen = dist.get_world_size()
+        devices = [None] * world
+        dist.all_gather_object(devices, f"cuda:{dev.index} {torch.cuda.get_device_name(dev)}")
     result = {
         "metric": "training samples/sec (diffusion train step of the denoiser: fwd + MSE + bwd + all-reduce + clip + Adam)",
         "value": round(world * B * args.steps / elapsed, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -207,11 +254,13 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
                    "batch_per_gpu": B, "trainable_params": ts.flat.live_numel, "grad_buckets": len(ts.flat.buckets),
                    "exchange": "RCCL all-reduce of the flat fp32 gradient, bucketed, overlapped with backward",
                    "final_loss": float(loss.item())},
+        "repeats": args.repeats, "ms_per_step_all_regions": [round(r / args.steps * 1e3, 4) for r in regions],
+        "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
         "roofline": {"kernel": "diffsal::igemm_kernel + wgrad_kernel (fp32 MFMA: forward, data-gradient and "
                                "weight-gradient convolutions/GEMMs of one step)",
                      "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": len(ev),
-                     "step_ms_in_kernel": round(k_ms, 3)},
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": len(gemm_ev),
+                     "step_ms_in_kernel": round(k_ms, 3), "classes": class_table(ev, FP32_MFMA_PEAK_TFLOPS)},
     }
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -240,6 +289,8 @@ def main():
                          "(BASELINE configs[1] / configs[4]; own tolerance table, DESIGN.md 2b).  All but fp32 are opt-in "
                          "modes reported separately from the headline")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra reduced-precision passes reported beside the headline")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of exactly --steps steps each; the reported value is their median (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32,
@@ -330,36 +381,54 @@ def main():
 
             dist.barrier()
 
-    run_steps(max(args.warmup, 1))
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps, profile_last=True)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    def timed_region(profile_last):
+        """exactly K steps between barrier + synchronize on both sides; MAX over ranks"""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps, profile_last=profile_last)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
 
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    run_steps(max(args.warmup, 1))
+    regions = [timed_region(i == args.repeats - 1) for i in range(args.repeats)]
+    elapsed = median(regions)
 
     # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
-    ev = state.get("events") or []
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
-    k_flops = sum(f for _, _, f in ev)
+    all_ev = state.get("events") or []
+    ev = [e for e in all_ev if e[3] in GEMM_CLASSES]          # the implicit-GEMM family = the dominant kernel
+    k_ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+    k_flops = sum(e[2] for e in ev)
     n_launch = max(len(ev), 1)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    peak_for_mode = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+    traffic, traffic_src = None, None
+    tf = os.path.join(ROOT, "profiles", f"r02_igemm_hbm_traffic_{args.precision}.json")
+    if os.path.exists(tf):      # PMC pass of THIS build (tools/pmc_traffic.py; separate --pmc run as the guide prescribes)
+        try:
+            tj = json.load(open(tf))
+            traffic, traffic_src = tj.get("bytes_per_launch"), f"profiles/{os.path.basename(tf)} ({tj.get('build', 'build n/a')})"
+        except Exception:  # noqa: BLE001
+            traffic = None
     common = {"launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),
-              "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3)}
+              "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3), "traffic_source": traffic_src,
+              "step_ms_all_kernels": round(sum(e[0].elapsed_time(e[1]) for e in all_ev), 3),
+              "classes": class_table(all_ev, peak_for_mode)}
     if args.precision == "fp32":
         roofline = {
             "kernel": "diffsal::igemm_kernel (fp32 MFMA implicit GEMM: 3x3 convs, token GEMMs, ReduceTemp)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, **common}
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **common}
     elif args.precision == "bf16x3":   # three bf16 MFMAs per fp32-accurate product: the instruction-level peak is the bf16 one
         roofline = {
             "kernel": "diffsal::igemm_kernel<..., bf16x3> (split-precision bf16 MFMA implicit GEMM, fp32 accumulate)",
@@ -395,6 +464,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "repeats": args.repeats, "ms_per_step_all_regions": [round(r / args.steps * 1e3, 4) for r in regions],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

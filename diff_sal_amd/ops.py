@@ -20,9 +20,36 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc  # noqa: F
 
 Tensor = torch.Tensor
 
-# When set to a list (bench.py, one step inside its timed region), every implicit-GEMM launch is bracketed
-# by HIP events on the launching stream and (start, end, algorithmic_flops) is appended.
+# When set to a list (bench.py, one step inside its timed region), every operator launch is bracketed by HIP events on
+# the launching stream and (start, end, algorithmic_flops, class, algorithmic_bytes) is appended.  ``class`` is the
+# SURVEY 8(a) row the launch belongs to ("K12", ...); bytes = once-through traffic (inputs + outputs + weights in
+# their storage type), the denominators of SURVEY 8(d).
 PROFILE = None
+
+
+class _prof:
+    __slots__ = ("cls", "flops", "nbytes", "e0")
+
+    def __init__(self, cls, flops=0.0, nbytes=0.0):
+        self.cls, self.flops, self.nbytes, self.e0 = cls, float(flops), float(nbytes), None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.e0 is not None and et is None and PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.e0, e1, self.flops, self.cls, self.nbytes))
+        return False
+
+
+def _nb(*ts) -> float:
+    """bytes of the given tensors (None skipped)"""
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
 
 GEMM_PRECISIONS = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}
@@ -119,8 +146,9 @@ def temb_mlp(t: Tensor, freq: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Te
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("t must be a contiguous GPU tensor")
     out = torch.empty((2, B, 4 * ch), device=t.device, dtype=torch.float32)  # [0] = hidden scratch, [1] = temb
-    _lib.check(lib.diffsal_temb_mlp(t.data_ptr(), is_f32, B, ch, _p(freq), _p(w0), _p(b0), _p(w1), _p(b1),
-                                    _p(out[0]), _p(out[1]), _stream()), "temb_mlp")
+    with _prof("K1", 2.0 * B * (ch * 4 * ch + 16 * ch * ch), _nb(w0, w1)):
+        _lib.check(lib.diffsal_temb_mlp(t.data_ptr(), is_f32, B, ch, _p(freq), _p(w0), _p(b0), _p(w1), _p(b1),
+                                        _p(out[0]), _p(out[1]), _stream()), "temb_mlp")
     out = out[1]
     return out
 
@@ -130,8 +158,9 @@ def dense_small(x: Tensor, w: Tensor, bias: Optional[Tensor], swish_in: bool) ->
     B, K = x.shape
     N = w.shape[0]
     out = torch.empty((B, N), device=x.device, dtype=torch.float32)
-    _lib.check(lib.diffsal_dense_small(_p(x), B, K, int(swish_in), _p(w), _p(bias), N, _p(out), _stream()),
-               "dense_small")
+    with _prof("K1", 2.0 * B * K * N, _nb(w, x, out)):
+        _lib.check(lib.diffsal_dense_small(_p(x), B, K, int(swish_in), _p(w), _p(bias), N, _p(out), _stream()),
+                   "dense_small")
     return out
 
 
@@ -142,8 +171,10 @@ def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0, out_dtype: t
     B, _, H, W = x.shape
     Cc = w9.shape[0]
     out = torch.empty((B, H, W, Cc), device=x.device, dtype=out_dtype)
-    _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), out.data_ptr(), B, H, W, Cc, skip_mod, _dt(out), _stream()),
-               "conv_in")
+    frac = ((skip_mod - 1) / skip_mod) ** 2 if skip_mod > 0 else 1.0     # share of the pixels actually produced
+    with _prof("K2-conv_in", 18.0 * B * H * W * Cc * frac, _nb(x) + _nb(out) * frac):
+        _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), out.data_ptr(), B, H, W, Cc, skip_mod, _dt(out), _stream()),
+                   "conv_in")
     return out
 
 
@@ -155,8 +186,9 @@ def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, ep
     nbytes = lib.diffsal_groupnorm_ws_bytes(B, groups)
     ws = torch.empty((nbytes // 8,), device=x.device, dtype=torch.float64)
     dt = _dt(x)
-    _lib.check(lib.diffsal_groupnorm_swish(_pa(x, dt), _p(gamma), _p(beta), _pa(out, dt), B, H * W, Cc, groups, eps,
-                                           ws.data_ptr(), nbytes, dt, _stream()), "groupnorm_swish")
+    with _prof("K3", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_groupnorm_swish(_pa(x, dt), _p(gamma), _p(beta), _pa(out, dt), B, H * W, Cc, groups, eps,
+                                               ws.data_ptr(), nbytes, dt, _stream()), "groupnorm_swish")
     return out
 
 
@@ -250,7 +282,7 @@ def pack_conv_weight_diff(w: Tensor) -> Tensor:
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
                out_hw: Optional[Sequence[int]] = None, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+               act: int = ACT_NONE, out: Optional[Tensor] = None, tag: str = "gemm") -> Tensor:
     """Implicit-GEMM conv on NHWC x [N,H,W,Cin] with packed weight [Cout, kh*kw*Cin] -> [N,Ho,Wo,Cout].
 
     ``pad`` is (top, left); bottom/right padding is implied by ``out_hw`` (zero fill outside)."""
@@ -278,25 +310,20 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         rv = None
     ws_bytes = lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32) if ws_bytes else None
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(lib.diffsal_conv_igemm(C.byref(d), _pa(x, dt), _pa(w_packed, dt), _p(bias), _p(scale), _p(shift), rv,
-                                      _pa(residual, dt), _pa(out, dt), _p(ws), ws_bytes, _stream()), "conv_igemm")
-    if PROFILE is not None:
-        e1.record()
-        PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin))
+    with _prof(tag, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, w_packed, residual, out)):
+        _lib.check(lib.diffsal_conv_igemm(C.byref(d), _pa(x, dt), _pa(w_packed, dt), _p(bias), _p(scale), _p(shift), rv,
+                                          _pa(residual, dt), _pa(out, dt), _p(ws), ws_bytes, _stream()), "conv_igemm")
     return out
 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
-           residual: Optional[Tensor] = None) -> Tensor:
+           residual: Optional[Tensor] = None, tag: str = "K10") -> Tensor:
     """Token GEMM: x [..., K] @ w[N, K]^T (+bias, act, +residual) through the same MFMA kernel."""
     lead = x.shape[:-1]
     M = 1
     for s in lead:
         M *= s
-    y = conv_igemm(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act,
+    y = conv_igemm(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, tag=tag,
                    residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
     return y.reshape(*lead, w.shape[0])
 
@@ -311,17 +338,19 @@ def pack_frames(vis: Tensor, noise: Optional[Tensor], t_out: Optional[int] = Non
     odt = noise.dtype if noise is not None else (out_dtype or torch.float32)
     out = torch.empty((B, Tout, h, w, Cc), device=vis.device, dtype=odt)
     dt = _dt(out)
-    _lib.check(lib.diffsal_pack_frames(_p(vis), _pa(noise, dt), out.data_ptr(), B, Cc, Tv, Tout, h * w, dt, _stream()),
-               "pack_frames")
+    with _prof("K6", 0.0, _nb(vis, noise, out)):
+        _lib.check(lib.diffsal_pack_frames(_p(vis), _pa(noise, dt), out.data_ptr(), B, Cc, Tv, Tout, h * w, dt, _stream()),
+                   "pack_frames")
     return out
 
 
-def resize_bilinear(x: Tensor, H: int, W: int) -> Tensor:
+def resize_bilinear(x: Tensor, H: int, W: int, tag: str = "K12-up") -> Tensor:
     lib = _lib.load()
     N, h, w, Cc = x.shape
     out = torch.empty((N, H, W, Cc), device=x.device, dtype=x.dtype)
     dt = _dt(x)
-    _lib.check(lib.diffsal_resize_bilinear(_pa(x, dt), out.data_ptr(), N, h, w, H, W, Cc, dt, _stream()), "resize_bilinear")
+    with _prof(tag, 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_resize_bilinear(_pa(x, dt), out.data_ptr(), N, h, w, H, W, Cc, dt, _stream()), "resize_bilinear")
     return out
 
 
@@ -335,7 +364,8 @@ def resize_sum(xs: Sequence[Tensor], H: int, W: int) -> Tensor:
     hs = (C.c_int * n)(*[x.shape[1] for x in xs])
     ws = (C.c_int * n)(*[x.shape[2] for x in xs])
     out = torch.empty((N, H, W, Cc), device=xs[0].device, dtype=xs[0].dtype)
-    _lib.check(lib.diffsal_resize_sum(ptrs, hs, ws, n, out.data_ptr(), N, H, W, Cc, dt, _stream()), "resize_sum")
+    with _prof("K13-up", 0.0, _nb(*xs) + _nb(out)):
+        _lib.check(lib.diffsal_resize_sum(ptrs, hs, ws, n, out.data_ptr(), N, H, W, Cc, dt, _stream()), "resize_sum")
     return out
 
 
@@ -345,8 +375,9 @@ def audio_fuse(a_small: Tensor, x: Tensor, h: int, w: int) -> Tensor:
     B, T, H, W, Cc = x.shape
     out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=x.dtype)
     dt = _dt(x)
-    _lib.check(lib.diffsal_audio_fuse(_pa(a_small, dt), _pa(x, dt), out.data_ptr(), B, T, H, W, Cc, h, w, dt, _stream()),
-               "audio_fuse")
+    with _prof("K7", 0.0, _nb(a_small, x, out)):
+        _lib.check(lib.diffsal_audio_fuse(_pa(a_small, dt), _pa(x, dt), out.data_ptr(), B, T, H, W, Cc, h, w, dt, _stream()),
+                   "audio_fuse")
     return out
 
 
@@ -356,7 +387,8 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5) -> Tens
     M = x.numel() // Cc
     out = torch.empty_like(x)
     dt = _dt(x)
-    _lib.check(lib.diffsal_layernorm(_pa(x, dt), _p(gamma), _p(beta), out.data_ptr(), M, Cc, eps, dt, _stream()), "layernorm")
+    with _prof("K8", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_layernorm(_pa(x, dt), _p(gamma), _p(beta), out.data_ptr(), M, Cc, eps, dt, _stream()), "layernorm")
     return out
 
 
@@ -366,8 +398,9 @@ def dwconv3_ln(x: Tensor, w9: Tensor, gamma: Tensor, beta: Tensor, eps: float = 
     N, H, W, Cc = x.shape
     out = torch.empty((N, H * W, Cc), device=x.device, dtype=x.dtype)
     dt = _dt(x)
-    _lib.check(lib.diffsal_dwconv3_ln(_pa(x, dt), _p(w9), _p(gamma), _p(beta), out.data_ptr(), N, H, W, Cc, eps, dt,
-                                      _stream()), "dwconv3_ln")
+    with _prof("K9", 18.0 * N * H * W * Cc, _nb(x, out)):
+        _lib.check(lib.diffsal_dwconv3_ln(_pa(x, dt), _p(w9), _p(gamma), _p(beta), out.data_ptr(), N, H, W, Cc, eps, dt,
+                                          _stream()), "dwconv3_ln")
     return out
 
 
@@ -379,8 +412,9 @@ def dwpool_ln_kv(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk:
     ok = torch.empty((N, gh * gw, Cc), device=xv.device, dtype=xv.dtype)
     ov = torch.empty_like(ok)
     dt = _dt(xv)
-    _lib.check(lib.diffsal_dwpool_ln_kv(_pa(xk, dt), _pa(xv, dt), _p(wk), _p(wv), _p(gk), _p(bk), _p(gv), _p(bv),
-                                        ok.data_ptr(), ov.data_ptr(), N, H, W, Cc, k, eps, dt, _stream()), "dwpool_ln_kv")
+    with _prof("K9", 4.0 * N * H * W * Cc, _nb(xk, ok, ov) + (0.0 if xk.data_ptr() == xv.data_ptr() else _nb(xv))):
+        _lib.check(lib.diffsal_dwpool_ln_kv(_pa(xk, dt), _pa(xv, dt), _p(wk), _p(wv), _p(gk), _p(bk), _p(gv), _p(bv),
+                                            ok.data_ptr(), ov.data_ptr(), N, H, W, Cc, k, eps, dt, _stream()), "dwpool_ln_kv")
     return ok, ov
 
 
@@ -390,8 +424,9 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tens
     Lk = k.shape[1]
     o = torch.empty_like(q)
     dt = _dt(q)
-    _lib.check(lib.diffsal_attention(_pa(q, dt), _pa(k, dt), _pa(v, dt), o.data_ptr(), N, Lq, Lk, Cc, heads, scale, dt,
-                                     _stream()), "attention")
+    with _prof("K11", 4.0 * N * Lq * Lk * Cc, _nb(q, k, v, o)):
+        _lib.check(lib.diffsal_attention(_pa(q, dt), _pa(k, dt), _pa(v, dt), o.data_ptr(), N, Lq, Lk, Cc, heads, scale, dt,
+                                         _stream()), "attention")
     return o
 
 
@@ -401,7 +436,8 @@ def head_sigmoid(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
     N, H, W, Cc = x.shape
     out = torch.empty((N, H, W, 1), device=x.device, dtype=torch.float32)
     dt = _dt(x)
-    _lib.check(lib.diffsal_head_sigmoid(_pa(x, dt), _p(w), _p(bias), _p(out), N * H * W, Cc, dt, _stream()), "head_sigmoid")
+    with _prof("K14-head", 2.0 * N * H * W * Cc, _nb(x, out)):
+        _lib.check(lib.diffsal_head_sigmoid(_pa(x, dt), _p(w), _p(bias), _p(out), N * H * W, Cc, dt, _stream()), "head_sigmoid")
     return out
 
 
@@ -410,8 +446,9 @@ def axpbypcz(x: Tensor, a: float, y: Optional[Tensor] = None, b: float = 0.0, z:
     lib = _lib.load()
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.diffsal_axpbypcz(_p(x), _p(y), _p(z), float(a), float(b), float(c), _p(out), x.numel(), _stream()),
-               "axpbypcz")
+    with _prof("K15", 0.0, _nb(x, y, z, out)):
+        _lib.check(lib.diffsal_axpbypcz(_p(x), _p(y), _p(z), float(a), float(b), float(c), _p(out), x.numel(), _stream()),
+                   "axpbypcz")
     return out
 
 
@@ -433,14 +470,9 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     if want_bias:
         splits = lib.diffsal_conv_wgrad_splits(C.byref(d))
         bpart = torch.empty((splits, Cout), device=x.device, dtype=torch.float64)
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), bpart.data_ptr() if want_bias else None, _p(ws),
-                                      nws, _stream()), "conv_wgrad")
-    if PROFILE is not None:
-        e1.record()
-        PROFILE.append((e0, e1, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin))
+    with _prof("wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, dy, dw)):
+        _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), bpart.data_ptr() if want_bias else None, _p(ws),
+                                          nws, _stream()), "conv_wgrad")
     if want_bias:
         return dw, reduce_partials(bpart, 1, bpart.shape[0], Cout).view(Cout)
     return dw

@@ -315,7 +315,7 @@ class SalUNet(nn.Module):
         B, _, H, W = x.shape
         f = ops.conv_in(x, pk["conv_in.w"], self.conv_in.bias, skip_mod=4, out_dtype=self.compute_dtype)
         f = ops.conv_igemm(f, pk["down1.w"], kh=3, kw=3, stride=(4, 4), out_hw=((H - 2) // 4 + 1, (W - 2) // 4 + 1),
-                           bias=self.down1.conv.bias)
+                           bias=self.down1.conv.bias, tag="K2")
         if taps is not None:
             taps["temb"], taps["down1"] = temb, f
         outs, off = [], 0
@@ -324,18 +324,18 @@ class SalUNet(nn.Module):
             co = rb.conv1.out_channels
             h = ops.groupnorm_swish(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
             h = ops.conv_igemm(h, pk[f"res{i}.conv1.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv1.bias,
-                               rowvec=tproj[:, off:off + co])
+                               rowvec=tproj[:, off:off + co], tag="K4")
             off += co
             h = ops.groupnorm_swish(h, rb.norm2.weight, rb.norm2.bias, 32, rb.norm2.eps)
             sc = f
             if hasattr(rb, "nin_shortcut"):
-                sc = ops.conv_igemm(f, pk[f"res{i}.nin.w"], bias=rb.nin_shortcut.bias)
-            f = ops.conv_igemm(h, pk[f"res{i}.conv2.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc)
+                sc = ops.conv_igemm(f, pk[f"res{i}.nin.w"], bias=rb.nin_shortcut.bias, tag="K4")
+            f = ops.conv_igemm(h, pk[f"res{i}.conv2.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc, tag="K4")
             if taps is not None:
                 taps[f"res{i}"] = f
             hh, ww = f.shape[1:3]
             f = ops.conv_igemm(f, pk[f"res{i}.down.w"], kh=3, kw=3, stride=(2, 2),
-                               out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1), bias=dn.conv.bias)
+                               out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1), bias=dn.conv.bias, tag="K5")
             outs.append(f)
         return outs[::-1]
 
@@ -348,7 +348,7 @@ class SalUNet(nn.Module):
         xn = ops.layernorm(x, blk.norm.weight, blk.norm.bias, blk.norm.eps)
         k_src = xn
         if audio_tok is not None:
-            a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias)  # [B*T, ha*wa, C]
+            a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias, tag="K7-align")  # [B*T, ha*wa, C]
             k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
         q = ops.dwconv3_ln(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
                            a.conv_proj_q.bn.eps)
@@ -444,10 +444,10 @@ class SalUNet(nn.Module):
                 d = self.dilation[i]
                 u = ops.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
                 u = ops.conv_igemm(u, pk[f"s{i}.pe1.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
-                                   scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU)
+                                   scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
                 skip = frames[i] if i in (1, 2) else None  # transformer.py:265-270
                 u = ops.conv_igemm(u, pk[f"s{i}.pe2.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
-                                   scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU,
+                                   scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU, tag="K12",
                                    residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C))
                 xcur = u.view(Bn, T, 2 * h, 2 * w, C)
             xcur = self._block(i, xcur, pk, audio_tok, audio_hw)
@@ -459,16 +459,17 @@ class SalUNet(nn.Module):
             kt = self.temporal_list[i]
             if (T - kt) // kt + 1 != 1:
                 raise RuntimeError(f"ReduceTemp: T={T}, kernel/stride {kt} must give exactly one frame")
-            z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU)
+            z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
+                               tag="K13")
             zs.append(z.view(Bn, H, W, self.ori_embed_dim))
         acc = ops.resize_sum(zs, th, tw)
         if taps is not None:
             taps["multi_scale"] = acc
         mt = dec.mt_proj
         y = ops.conv_igemm(acc, pk["mt.w"], kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, scale=pk["mt.scale"],
-                           shift=pk["mt.shift"], act=ACT_RELU)
+                           shift=pk["mt.shift"], act=ACT_RELU, tag="K14")
         s = ops.head_sigmoid(y, pk["head.w"], self.logits.linear_pred.bias)
-        out = ops.resize_bilinear(s, self.img_size[0], self.img_size[1])
+        out = ops.resize_bilinear(s, self.img_size[0], self.img_size[1], tag="K14-head")
         return out.view(B, 1, self.img_size[0], self.img_size[1])
 
     # ------------------------------------------------------------------ training forward

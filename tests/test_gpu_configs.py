@@ -64,11 +64,14 @@ def test_config4_batch64_av_full_size(dname):
         assert o64.shape == (B, 1, 224, 384) and o64.dtype == torch.float32
         assert torch.isfinite(o64).all() and o64.min() > 0 and o64.max() < 1
         # chunked evaluation == per-clip evaluation (clips are independent in eval mode)
-        tol = 1e-5 if dname == "fp32" else 0.0   # 16-bit: identical tiles, identical roundings -> bitwise equal
+        # fp32: only the summation order differs between a 1-clip and a 16-clip pass (tile / split-K plans depend on M).
+        # 16-bit storage: the same order difference is rounded to the storage type at every layer, so the two
+        # evaluations agree to the datapath's own end-to-end tolerance (tests/test_gpu_lowp.py::LOWP_ATOL), not bitwise.
+        tol = {"fp32": 1e-5, "fp16": 4e-3, "bf16": 3e-2}[dname]
         for i in (0, 15, 16, 37, 63):
             oi = net(xd[i:i + 1], t[i:i + 1], [f[i:i + 1] for f in fd], ad[i:i + 1])
             d = (oi - o64[i:i + 1]).abs().max().item()
-            assert d <= max(tol, 1e-5), (dname, i, d)
+            assert d <= tol, (dname, i, d)
         # and different clips do give different maps
         assert (o64[0] - o64[1]).abs().max().item() > 1e-3
     # peak working set of a 16-clip pass: the 4-scale sum [16,112,192,768] (1.06 GB fp32) + its producers; the whole

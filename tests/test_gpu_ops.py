@@ -303,15 +303,21 @@ def test_conv_igemm_bf16x3_mode_accuracy(shape):
     xd, wp = nhwc(x).to(DEV), ops.pack_conv_weight(w.to(DEV))
     kw = dict(kh=k, kw=k, pad=(pad, pad), dil=(dil, dil))
     y32 = ops.conv_igemm(xd, wp, **kw)
-    ops.set_gemm_precision("bf16x3")
-    try:
+    with ops.gemm_precision("bf16x3"):                            # per-call descriptor field, scoped on the Python side
         y3 = ops.conv_igemm(xd, wp, **kw)
         y3s = ops.conv_igemm(xd, ops.split_weight(wp), **kw)     # weights pre-split on the host side of the launch
-    finally:
-        ops.set_gemm_precision("fp32")
+    assert ops.get_gemm_precision() == "fp32"
     assert torch.equal(y3s, y3)                                   # same arithmetic, the split just happens earlier
-    with pytest.raises(RuntimeError):                             # a pre-split weight is refused by the fp32 mode
-        ops.conv_igemm(xd, ops.split_weight(wp), **kw)
+    # a pre-split weight carries its arithmetic: outside the context it still runs (and only runs) as bf16x3 ...
+    assert torch.equal(ops.conv_igemm(xd, ops.split_weight(wp), **kw), y3)
+    # ... and the library refuses the inconsistent descriptor (w_format = 1 with precision = fp32) outright
+    import ctypes
+
+    from diff_sal_amd import _lib
+    d = _lib.ConvDesc(N, H, W, Cin, y32.shape[1], y32.shape[2], Cout, k, k, 1, 1, pad, pad, dil, dil, 0, 0, 1, 0, 0)
+    rc = _lib.load().diffsal_conv_igemm(ctypes.byref(d), xd.data_ptr(), wp.data_ptr(), None, None, None, None, None,
+                                        y32.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == -4 and b"w_format" in _lib.load().diffsal_last_error()
     m = ref.abs().max().item()
     e32 = (y32.cpu().double() - ref).abs().max().item() / m
     e3 = (y3.cpu().double() - ref).abs().max().item() / m
