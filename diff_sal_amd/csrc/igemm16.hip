@@ -332,8 +332,11 @@ __global__ __launch_bounds__(256) void splitk16_reduce_kernel(Igemm16Args<T> p) 
 
 struct TileCfg16 { int bm, bn, occ; float eff; };
 // order must match the dispatch switch below
-static const TileCfg16 kCfgs16[] = {{128, 192, 1, 0.80f}, {128, 128, 2, 0.75f}, {128, 96, 2, 0.65f}, {64, 128, 2, 0.60f},
-                                    {128, 64, 2, 0.60f},  {64, 64, 4, 0.50f},   {256, 96, 1, 0.80f},  {256, 128, 1, 0.85f}};
+// eff: measured on the network's shapes (tools/tune_igemm16.py, profiles/r02_tune_igemm16_bf16.log): with operands
+// delivered through L1 at ~27 B/clk/CU the two-resident 128x96 / 128x128 tiles win almost everywhere; the 256-row
+// tiles (one resident workgroup, two stages of prefetch) do not cover the load latency yet and lose 30-40 %.
+static const TileCfg16 kCfgs16[] = {{128, 192, 1, 0.62f}, {128, 128, 2, 0.70f}, {128, 96, 2, 0.75f}, {64, 128, 2, 0.55f},
+                                    {128, 64, 2, 0.55f},  {64, 64, 4, 0.55f},   {256, 96, 1, 0.50f},  {256, 128, 1, 0.50f}};
 constexpr int kNumCfgs16 = 8;
 constexpr int kCUs16 = 256;
 
@@ -342,7 +345,7 @@ struct Plan16 { int cfg, splits; };
 // Same analytic model as igemm.hip's planner with the 16-bit matrix rate (2.5 PFLOP/s dense); `eff` folds in the
 // LDS-bandwidth limit of the narrower wave tiles (reads per MFMA), fixed latencies weigh 16x more than in fp32.
 static Plan16 choose_plan16(long M, int Cout, int K) {
-  const double mac_per_s_cu = 2.5e15 / 2.0 / kCUs16;
+  const double mac_per_s_cu = 1.0e15 / 2.0 / kCUs16;   // what the loop sustains at eff = 1 (not the 2.5 PF/s pipe peak)
   const double t_fixed = 6e-6;
   const int NST = (K / SUBK + 1) / 2;
   Plan16 best{5, 1};

@@ -294,6 +294,16 @@ int diffsal_head_sigmoid(const void* x, const float* w /*[C]*/, const float* bia
  * has no counterpart: it is fp32-only, R/diffusion_trainer.py:212-218). */
 int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, diffsal_stream_t stream);
 
+/* ---- evaluation metrics on the device: CC, SIM, NSS, KL-div of predicted vs ground-truth saliency maps -----------
+ * R/models/sal_losses.py:14-37 (nss2), :63-97 (cc_s2), :100-131 (kldiv2), :134-176 (normalize_map2, similarity2), as
+ * called per validation batch by get_kl_cc_sim_loss_wo_weight (R/diffusion_trainer.py:741,797,868).
+ * pred, gt: [B][n] fp32 (n = T*H*W values per image).  per_image (optional): [B][4] = (cc, sim, nss, kl);
+ * mean_out: [4] batch means in the same order (what the reference functions return).  Two streaming passes, fp64
+ * accumulation in a fixed order; ws >= diffsal_saliency_metrics_ws_bytes(B) bytes. */
+size_t diffsal_saliency_metrics_ws_bytes(int B);
+int diffsal_saliency_metrics(const float* pred, const float* gt, int B, long n, void* ws, size_t ws_bytes,
+                             float* per_image, float* mean_out, diffsal_stream_t stream);
+
 /* ---- K15: sampler elementwise update  out = a*x + b*y + c*z  (y, z may be NULL) -----------
  * scalar-coefficient axpys of R/diffusion_trainer.py:459-478 and R/models/dpm_solver/sampler.py:548-593,816-853. */
 int diffsal_axpbypcz(const float* x, const float* y, const float* z, float a, float b, float c, float* out,
