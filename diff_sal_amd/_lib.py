@@ -76,6 +76,12 @@ SIGNATURES = {
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "diffsal_cast": (c_i, [c_f, c_i, c_f, c_i, C.c_long, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
+    "diffsal_attention_general": (c_i, [c_f] * 7 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f]),
+    "diffsal_im2col3d": (c_i, [c_f, c_f] + [c_i] * 15 + [c_f]),
+    "diffsal_pool3d_ln": (c_i, [c_f] * 5 + [c_i] * 9 + [C.c_long, C.c_long, c_fl, c_f]),
+    "diffsal_maxpool_tokens": (c_i, [c_f, c_f] + [c_i] * 11 + [c_f]),
+    "diffsal_relpos_project": (c_i, [c_f] * 5 + [c_i] * 8 + [c_f]),
+    "diffsal_tokens_to_channels_first": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_saliency_metrics_ws_bytes": (c_sz, [c_i]),
     "diffsal_saliency_metrics": (c_i, [c_f, c_f, c_i, C.c_long, c_f, c_sz, c_f, c_f, c_f]),
     "diffsal_reduce_partials": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -1,0 +1,302 @@
+// Kernels of the MViTv2-S video encoder (R/models/mvit.py) that are not plain GEMMs / LayerNorms (those reuse
+// diffsal_conv_igemm / diffsal_layernorm): patch-embedding im2col, the depthwise-Conv3d poolings of q / k / v fused with
+// their LayerNorm, the max-pool of the skip path, the relative-position projections that feed diffsal_attention_general,
+// and the token -> NCTHW output transpose.  Tokens are [B, 1 + T*H*W, C] with the class token in row 0 (mvit.py:1097-1099).
+#include "common.h"
+
+namespace diffsal {
+
+// ------------------------------------------------------------------------------------------------
+// PatchEmbed3D: Conv3d(3 -> 96, kernel (3,7,7), stride (2,4,4), padding (1,3,3)), mvit.py:983-989 / :157-163.
+// cols[m][k] with m = (b, to, ho, wo), k = (c, kt, ky, kx) -- the order of weight.reshape(Cout, Cin*KT*KH*KW) --
+// zero-padded to Kp columns (a multiple of 32); the projection itself is one GEMM.  x: [B, C, T, H, W].
+// One wavefront per output pixel, lanes over k: reads along kx are contiguous runs of the input row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ x, float* __restrict__ cols, int C, int T,
+                                                       int H, int W, int To, int Ho, int Wo, int KT, int KH, int KW, int st,
+                                                       int sh, int sw, int pt, int ph, int pw, int Kp, long M) {
+  const int lane = threadIdx.x & 63;
+  const long m = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int wo = static_cast<int>(m % Wo);
+  long r = m / Wo;
+  const int ho = static_cast<int>(r % Ho); r /= Ho;
+  const int to = static_cast<int>(r % To);
+  const int b = static_cast<int>(r / To);
+  const int K = C * KT * KH * KW;
+  const float* xb = x + static_cast<long>(b) * C * T * H * W;
+  for (int k = lane; k < Kp; k += 64) {
+    float v = 0.f;
+    if (k < K) {
+      const int kx = k % KW;
+      int q = k / KW;
+      const int ky = q % KH; q /= KH;
+      const int kt = q % KT;
+      const int c = q / KT;
+      const int it = to * st - pt + kt, iy = ho * sh - ph + ky, ix = wo * sw - pw + kx;
+      if (it >= 0 && it < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = xb[((static_cast<long>(c) * T + it) * H + iy) * W + ix];
+    }
+    cols[m * Kp + k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention_pool (mvit.py:446-494) for one of q / k / v: depthwise Conv3d 3x3x3 (pad 1, stride (st, sh, sw), no bias,
+// one filter per channel of the HEAD, shared by all heads) on the video tokens, class token passed through, then
+// LayerNorm over the head dimension D on every token (class token included).
+// in : element (b, n, head, d) at  in + b*in_sb + n*in_sn + head*D + d   (a slice of the fused qkv GEMM output)
+// out: [B, heads, 1 + To*Ho*Wo, D]
+// A group of G lanes owns one output token (float4 per lane); D <= 4*G.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void pool3d_ln_kernel(const float* __restrict__ in, const float* __restrict__ w27,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out, long in_sb, long in_sn, int heads, int D,
+                                                        int T, int H, int W, int To, int Ho, int Wo, int st, int sh, int sw,
+                                                        float eps, long rows) {
+  constexpr int ROWS = 256 / G;
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  const int Lo = To * Ho * Wo;
+  const int c = gl * 4;
+  const bool act = c < D;
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < rows; row += static_cast<long>(gridDim.x) * ROWS) {
+    const int n = static_cast<int>(row % (Lo + 1));
+    const long bh = row / (Lo + 1);
+    const int head = static_cast<int>(bh % heads);
+    const int b = static_cast<int>(bh / heads);
+    const float* base = in + b * in_sb + static_cast<long>(head) * D + c;
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (act) {
+      if (n == 0) {
+        acc = ld4(base);
+      } else {
+        const int l = n - 1;
+        const int wo = l % Wo, ho = (l / Wo) % Ho, to = l / (Wo * Ho);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+          const int it = to * st - 1 + kt;
+          if (it < 0 || it >= T) continue;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int iy = ho * sh - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const int ix = wo * sw - 1 + kx;
+              if (ix < 0 || ix >= W) continue;
+              const float4 a = ld4(base + (1 + (static_cast<long>(it) * H + iy) * W + ix) * in_sn);
+              const float4 ww = ld4(w27 + ((kt * 3 + ky) * 3 + kx) * D + c);
+              acc.x = fmaf(a.x, ww.x, acc.x); acc.y = fmaf(a.y, ww.y, acc.y);
+              acc.z = fmaf(a.z, ww.z, acc.z); acc.w = fmaf(a.w, ww.w, acc.w);
+            }
+          }
+        }
+      }
+    }
+    // LayerNorm over D (two-pass in registers, lane group butterfly)
+    float s = act ? (acc.x + acc.y) + (acc.z + acc.w) : 0.f;
+    s = group_sum<G>(s);
+    const float mean = s / static_cast<float>(D);
+    float qv = 0.f;
+    if (act) {
+      const float a0 = acc.x - mean, a1 = acc.y - mean, a2 = acc.z - mean, a3 = acc.w - mean;
+      qv = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    qv = group_sum<G>(qv);
+    const float rstd = 1.0f / sqrtf(qv / static_cast<float>(D) + eps);
+    if (act) {
+      const float4 g = ld4(gamma + c), be = ld4(beta + c);
+      float4 o;
+      o.x = (acc.x - mean) * rstd * g.x + be.x; o.y = (acc.y - mean) * rstd * g.y + be.y;
+      o.z = (acc.z - mean) * rstd * g.z + be.z; o.w = (acc.w - mean) * rstd * g.w + be.w;
+      st4(out + row * D + c, o);
+    }
+  }
+}
+
+// MaxPool3d of the skip path (mvit.py:765-777, 788-792): kernel (kt,kh,kw) = stride + 1 where stride > 1, padding k/2,
+// on tokens [B, 1 + T*H*W, C]; class token passed through.  One float4 of channels per thread.
+__global__ __launch_bounds__(256) void maxpool_tokens_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                             int T, int H, int W, int To, int Ho, int Wo, int kt, int kh,
+                                                             int kw, int st, int sh, int sw, long total4) {
+  const int c4n = C >> 2;
+  const int Lo = To * Ho * Wo, Li = T * H * W;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    const long tok = i / c4n;
+    const int n = static_cast<int>(tok % (Lo + 1));
+    const int b = static_cast<int>(tok / (Lo + 1));
+    const float* ib = in + static_cast<long>(b) * (Li + 1) * C + c;
+    float4 m;
+    if (n == 0) {
+      m = ld4(ib);
+    } else {
+      const int l = n - 1;
+      const int wo = l % Wo, ho = (l / Wo) % Ho, to = l / (Wo * Ho);
+      m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+      for (int a = 0; a < kt; ++a) {
+        const int it = to * st - kt / 2 + a;
+        if (it < 0 || it >= T) continue;
+        for (int e = 0; e < kh; ++e) {
+          const int iy = ho * sh - kh / 2 + e;
+          if (iy < 0 || iy >= H) continue;
+          for (int f = 0; f < kw; ++f) {
+            const int ix = wo * sw - kw / 2 + f;
+            if (ix < 0 || ix >= W) continue;
+            const float4 v = ld4(ib + (1 + (static_cast<long>(it) * H + iy) * W + ix) * C);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+          }
+        }
+      }
+    }
+    st4(out + tok * C + c, m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Relative-position projections of add_decomposed_rel_pos (mvit.py:363-410): for query (t, y, x) of head vector q,
+//   extra[0 .. kt)        = q . Rt[t][j]        Rt: [qt][kt][D]
+//   extra[8 .. 8 + kh)    = q . Rh[y][j]        Rh: [qh][kh][D]
+//   extra[24 .. 24 + kw)  = q . Rw[x][j]        Rw: [qw][kw][D]
+// (unused slots and the class-token row are zero).  q: [B*heads, 1 + qt*qh*qw, D] (the pooled, normalised, UNSCALED q).
+// One wavefront per query: lane e < 48 forms one dot product.
+// ------------------------------------------------------------------------------------------------
+constexpr int REL_E = 48, REL_T0 = 0, REL_H0 = 8, REL_W0 = 24;
+
+__global__ __launch_bounds__(256) void relpos_project_kernel(const float* __restrict__ q, const float* __restrict__ Rt,
+                                                             const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                             float* __restrict__ extra, int D, int qt, int qh, int qw, int kt,
+                                                             int kh, int kw, long rows) {
+  extern __shared__ float sq[];   // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = static_cast<long>(blockIdx.x) * 4 + wave;
+  const int L = qt * qh * qw;
+  const bool live = row < rows;
+  const long rc = live ? row : rows - 1;
+  const int n = static_cast<int>(rc % (L + 1));
+  for (int d = lane; d < D; d += 64) sq[wave * D + d] = q[rc * D + d];
+  __syncthreads();
+  if (!live || lane >= REL_E) return;
+  float r = 0.f;
+  if (n > 0) {
+    const int l = n - 1;
+    const int x = l % qw, y = (l / qw) % qh, t = l / (qw * qh);
+    const float* R = nullptr;
+    if (lane < REL_H0) { if (lane < kt) R = Rt + (static_cast<long>(t) * kt + lane) * D; }
+    else if (lane < REL_W0) { if (lane - REL_H0 < kh) R = Rh + (static_cast<long>(y) * kh + (lane - REL_H0)) * D; }
+    else { if (lane - REL_W0 < kw) R = Rw + (static_cast<long>(x) * kw + (lane - REL_W0)) * D; }
+    if (R) {
+      const float* qs = sq + wave * D;
+      for (int d = 0; d < D; d += 4) {
+        const float4 a = ld4(R + d);
+        r = fmaf(a.x, qs[d], fmaf(a.y, qs[d + 1], fmaf(a.z, qs[d + 2], fmaf(a.w, qs[d + 3], r))));
+      }
+    }
+  }
+  extra[row * REL_E + lane] = r;
+}
+
+// tokens [B, off + L, C] (rows off.. of each batch) -> [B, C, L]: the NCTHW feature maps MViT returns (mvit.py:1128-1134).
+__global__ __launch_bounds__(256) void tokens_to_channels_first_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                       int C, int L, int off, int tiles_l) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y;
+  const int tl = blockIdx.x % tiles_l, tc = blockIdx.x / tiles_l;
+  const int l0 = tl * 64, c0 = tc * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* src = in + (static_cast<long>(b) * (off + L) + off) * C;
+  for (int r = ty; r < 64; r += 4) {   // r: token within tile, tx: channel (contiguous reads)
+    const int l = l0 + r, c = c0 + tx;
+    tile[r][tx] = (l < L && c < C) ? src[static_cast<long>(l) * C + c] : 0.f;
+  }
+  __syncthreads();
+  float* dst = out + static_cast<long>(b) * C * L;
+  for (int r = ty; r < 64; r += 4) {   // r: channel within tile, tx: token (contiguous writes)
+    const int c = c0 + r, l = l0 + tx;
+    if (c < C && l < L) dst[static_cast<long>(c) * L + l] = tile[tx][r];
+  }
+}
+
+static int rows_grid(long rows, int per_block) {
+  long g = (rows + per_block - 1) / per_block;
+  return static_cast<int>(g > 65535 * 16 ? 65535 * 16 : g);
+}
+
+}  // namespace diffsal
+
+using namespace diffsal;
+
+extern "C" int diffsal_im2col3d(const float* x, float* cols, int B, int C, int T, int H, int W, int KT, int KH, int KW, int st,
+                                int sh, int sw, int pt, int ph, int pw, int Kp, diffsal_stream_t stream) {
+  DS_REQUIRE(x && cols, DIFFSAL_E_ARG, "im2col3d: null argument");
+  DS_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && KT > 0 && KH > 0 && KW > 0 && st > 0 && sh > 0 && sw > 0 &&
+                 Kp >= C * KT * KH * KW && Kp % 32 == 0,
+             DIFFSAL_E_SHAPE, "im2col3d: bad shape (Kp=%d must cover C*KT*KH*KW and be a multiple of 32)", Kp);
+  const int To = (T + 2 * pt - KT) / st + 1, Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+  DS_REQUIRE(To > 0 && Ho > 0 && Wo > 0, DIFFSAL_E_SHAPE, "im2col3d: empty output");
+  const long M = static_cast<long>(B) * To * Ho * Wo;
+  DS_REQUIRE((M + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "im2col3d: too many rows");
+  hipLaunchKernelGGL(im2col3d_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, cols, C, T, H, W, To, Ho, Wo, KT, KH, KW, st, sh, sw, pt, ph, pw, Kp, M);
+  return check_launch("im2col3d");
+}
+
+extern "C" int diffsal_pool3d_ln(const float* in, const float* w27, const float* gamma, const float* beta, float* out, int B,
+                                 int heads, int D, int T, int H, int W, int st, int sh, int sw, long in_stride_b,
+                                 long in_stride_n, float eps, diffsal_stream_t stream) {
+  DS_REQUIRE(in && w27 && gamma && beta && out, DIFFSAL_E_ARG, "pool3d_ln: null argument");
+  DS_REQUIRE(B > 0 && heads > 0 && D > 0 && D % 4 == 0 && D <= 256 && T > 0 && H > 0 && W > 0 && st > 0 && sh > 0 && sw > 0,
+             DIFFSAL_E_SHAPE, "pool3d_ln: bad shape D=%d", D);
+  DS_REQUIRE(aligned16(in) && aligned16(out) && aligned16(w27) && aligned16(gamma) && aligned16(beta) &&
+                 in_stride_b % 4 == 0 && in_stride_n % 4 == 0,
+             DIFFSAL_E_ALIGN, "pool3d_ln: misaligned pointer / stride");
+  const int To = (T - 1) / st + 1, Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;   // (X + 2 - 3) / s + 1
+  const long rows = static_cast<long>(B) * heads * (static_cast<long>(To) * Ho * Wo + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(G)                                                                                                          \
+  hipLaunchKernelGGL((pool3d_ln_kernel<G>), dim3(rows_grid(rows, 256 / G)), dim3(256), 0, s, in, w27, gamma, beta, out,    \
+                     in_stride_b, in_stride_n, heads, D, T, H, W, To, Ho, Wo, st, sh, sw, eps, rows)
+  if (D <= 32) { CALL(8); } else if (D <= 64) { CALL(16); } else if (D <= 128) { CALL(32); } else { CALL(64); }
+#undef CALL
+  return check_launch("pool3d_ln");
+}
+
+extern "C" int diffsal_maxpool_tokens(const float* in, float* out, int B, int C, int T, int H, int W, int kt, int kh, int kw,
+                                      int st, int sh, int sw, diffsal_stream_t stream) {
+  DS_REQUIRE(in && out, DIFFSAL_E_ARG, "maxpool_tokens: null argument");
+  DS_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
+             DIFFSAL_E_SHAPE, "maxpool_tokens: bad shape");
+  DS_REQUIRE(aligned16(in) && aligned16(out), DIFFSAL_E_ALIGN, "maxpool_tokens: misaligned pointer");
+  const int To = (T + 2 * (kt / 2) - kt) / st + 1, Ho = (H + 2 * (kh / 2) - kh) / sh + 1, Wo = (W + 2 * (kw / 2) - kw) / sw + 1;
+  const long total4 = static_cast<long>(B) * (static_cast<long>(To) * Ho * Wo + 1) * (C / 4);
+  long g = (total4 + 255) / 256;
+  g = g > 16384 ? 16384 : g;
+  hipLaunchKernelGGL(maxpool_tokens_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                     C, T, H, W, To, Ho, Wo, kt, kh, kw, st, sh, sw, total4);
+  return check_launch("maxpool_tokens");
+}
+
+extern "C" int diffsal_relpos_project(const float* q, const float* Rt, const float* Rh, const float* Rw, float* extra, int BH,
+                                      int D, int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream) {
+  DS_REQUIRE(q && Rt && Rh && Rw && extra, DIFFSAL_E_ARG, "relpos_project: null argument");
+  DS_REQUIRE(BH > 0 && D > 0 && D % 4 == 0 && D <= 1024 && qt > 0 && qh > 0 && qw > 0 && kt > 0 && kt <= REL_H0 - REL_T0 &&
+                 kh > 0 && kh <= REL_W0 - REL_H0 && kw > 0 && kw <= REL_E - REL_W0,
+             DIFFSAL_E_SHAPE, "relpos_project: key grid %dx%dx%d exceeds the (8, 16, 24) slots", kt, kh, kw);
+  DS_REQUIRE(aligned16(Rt) && aligned16(Rh) && aligned16(Rw), DIFFSAL_E_ALIGN, "relpos_project: misaligned table");
+  const long rows = static_cast<long>(BH) * (static_cast<long>(qt) * qh * qw + 1);
+  DS_REQUIRE((rows + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "relpos_project: too many rows");
+  hipLaunchKernelGGL(relpos_project_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 4 * D * sizeof(float),
+                     static_cast<hipStream_t>(stream), q, Rt, Rh, Rw, extra, D, qt, qh, qw, kt, kh, kw, rows);
+  return check_launch("relpos_project");
+}
+
+extern "C" int diffsal_tokens_to_channels_first(const float* in, float* out, int B, int C, int L, int off,
+                                                diffsal_stream_t stream) {
+  DS_REQUIRE(in && out, DIFFSAL_E_ARG, "tokens_to_channels_first: null argument");
+  DS_REQUIRE(B > 0 && C > 0 && L > 0 && off >= 0, DIFFSAL_E_SHAPE, "tokens_to_channels_first: bad shape");
+  const int tiles_l = (L + 63) / 64, tiles_c = (C + 63) / 64;
+  hipLaunchKernelGGL(tokens_to_channels_first_kernel, dim3(tiles_l * tiles_c, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, C, L, off, tiles_l);
+  return check_launch("tokens_to_channels_first");
+}

@@ -10,9 +10,10 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .mvit import MViT
 from .sal_unet import SalUNet
 
-OBJECT_REGISTRY = {"SalUNet": SalUNet}
+OBJECT_REGISTRY = {"SalUNet": SalUNet, "MViT": MViT}
 
 
 def register_module(cls):

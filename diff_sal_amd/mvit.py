@@ -1,0 +1,255 @@
+"""MViTv2 video encoder (once per clip), MI355X-native forward.
+
+Drop-in for the reference ``models/mvit.py::MViT`` as DiffSal configures it (R/cfgs/audio_visual.py:28-33:
+``arch="small", out_scales=[0,1,2,3]``): same constructor keywords for that configuration, same ``state_dict`` names and
+shapes (so the Kinetics checkpoint the reference loads keeps loading), same ``forward(x)`` contract -- a clip
+[B,3,16,H,W] (or [B*16,3,H,W]) in, four NCTHW feature maps [B,C,8,h,w] out, COARSEST FIRST (R/models/mvit.py:1090-1143).
+
+The nn layers below are parameter storage only.  The forward is a sequence of HIP kernels reached through the C ABI:
+  * every Linear (qkv, proj, MLP, dim-change skip, the patch projection after an im2col) is the implicit-GEMM kernel with
+    fused bias / GELU / residual epilogues;
+  * pooling attention = ``pool3d_ln`` (depthwise Conv3d + LayerNorm, reading q / k / v in place from the fused qkv
+    output) -> ``relpos_project`` -> ``attention_general`` (flash-style fp32-MFMA attention; the decomposed
+    relative-position bias rides in 48 extra contraction columns; residual pooling is its epilogue);
+  * tokens stay [B, 1 + T*H*W, C] throughout; the only layout change is the final transpose to NCTHW per output scale.
+
+Built: the configuration the reference uses -- class token on, relative positions on, residual pooling on,
+``dim_mul_in_attention=True``, no absolute position embedding.  Inference only for now: the visual
+encoder's backward is the next step, so under ``DiffusionTrainStep`` its parameters must be frozen.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .ops import ACT_GELU
+
+Tensor = torch.Tensor
+
+ARCH_ZOO = {  # R/models/mvit.py:888-917
+    "tiny": dict(embed_dims=96, num_layers=10, num_heads=1, downscale_indices=[1, 3, 8]),
+    "small": dict(embed_dims=96, num_layers=16, num_heads=1, downscale_indices=[1, 3, 14]),
+    "base": dict(embed_dims=96, num_layers=24, num_heads=1, downscale_indices=[2, 5, 21]),
+    "large": dict(embed_dims=144, num_layers=48, num_heads=2, downscale_indices=[2, 8, 44]),
+}
+
+
+class _Attn(nn.Module):
+    def __init__(self, in_dims, out_dims, heads, rel_hw, rel_t):
+        super().__init__()
+        hd = out_dims // heads
+        self.rel_pos_h = nn.Parameter(torch.zeros(rel_hw, hd))
+        self.rel_pos_w = nn.Parameter(torch.zeros(rel_hw, hd))
+        self.rel_pos_t = nn.Parameter(torch.zeros(rel_t, hd))
+        self.qkv = nn.Linear(in_dims, 3 * out_dims)
+        self.proj = nn.Linear(out_dims, out_dims)
+        for w in "qkv":
+            setattr(self, f"pool_{w}", nn.Conv3d(hd, hd, 3, padding=1, groups=hd, bias=False))
+            setattr(self, f"norm_{w}", nn.LayerNorm(hd))
+
+
+class _Block(nn.Module):
+    def __init__(self, in_dims, out_dims, heads, stride_q, stride_kv, rel_hw, rel_t):
+        super().__init__()
+        self.in_dims, self.out_dims, self.heads = in_dims, out_dims, heads
+        self.stride_q, self.stride_kv = tuple(stride_q), tuple(stride_kv)
+        self.norm1 = nn.LayerNorm(in_dims)
+        self.attn = _Attn(in_dims, out_dims, heads, rel_hw, rel_t)
+        self.norm2 = nn.LayerNorm(out_dims)
+        mlp = nn.Module()
+        mlp.fc1, mlp.fc2 = nn.Linear(out_dims, 4 * out_dims), nn.Linear(4 * out_dims, out_dims)
+        self.mlp = mlp
+        if in_dims != out_dims:
+            self.proj = nn.Linear(in_dims, out_dims)
+
+
+class MViT(nn.Module):
+    """Keyword names follow R/models/mvit.py:919-944; unsupported non-default values raise."""
+
+    def __init__(self, arch="base", spatial_size=224, temporal_size=16, in_channels=3, pretrained: Optional[str] = None,
+                 out_scales=-1, drop_path_rate=0.0, use_abs_pos_embed=False, interpolate_mode="trilinear",
+                 pool_kernel=(3, 3, 3), dim_mul=2, head_mul=2, adaptive_kv_stride=(1, 8, 8), rel_pos_embed=True,
+                 residual_pooling=True, dim_mul_in_attention=True, with_cls_token=True, output_cls_token=False,
+                 rel_pos_zero_init=False, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if (use_abs_pos_embed or tuple(pool_kernel) != (3, 3, 3) or dim_mul != 2 or head_mul != 2 or not rel_pos_embed
+                or not residual_pooling or not dim_mul_in_attention or not with_cls_token or output_cls_token
+                or mlp_ratio != 4.0 or not qkv_bias or norm_layer is not nn.LayerNorm or in_channels != 3):
+            raise NotImplementedError("MViT: only the configuration DiffSal uses is built (class token, relative positions, "
+                                      "residual pooling, dim_mul_in_attention, 3x3x3 pooling, mlp_ratio 4)")
+        a = dict(ARCH_ZOO[arch.lower()]) if isinstance(arch, str) else dict(arch)
+        self.embed_dims, self.num_layers = a["embed_dims"], a["num_layers"]
+        if self.embed_dims != 96:
+            raise NotImplementedError("MViT: the reference hard-codes a 96-channel patch embedding (mvit.py:983-989)")
+        down = list(a["downscale_indices"])
+        dim_mul_idx = list(a.get("dim_mul_indices", down))
+        self.num_scales = len(down) + 1
+        stage_of = {idx - 1: i for i, idx in enumerate(down)}
+        stage_of[self.num_layers - 1] = self.num_scales - 1
+        scales = [out_scales] if isinstance(out_scales, int) else list(out_scales)
+        self.out_scales = sorted(s + self.num_scales if s < 0 else s for s in scales)
+        pe = nn.Module()
+        pe.projection = nn.Conv3d(3, 96, (3, 7, 7), stride=(2, 4, 4), padding=(1, 3, 3))
+        self.patch_embed = pe
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, self.embed_dims))
+        self.blocks = nn.ModuleList()
+        self.stage_of_layer: Dict[int, int] = {}
+        heads, dims, stride_kv, size = a["num_heads"], self.embed_dims, tuple(adaptive_kv_stride), (8, 56, 56)
+        for i in range(self.num_layers):                       # R/models/mvit.py:1011-1053
+            if i in down or i in dim_mul_idx:
+                heads *= head_mul
+            if i in down:
+                stride_q = (1, 2, 2)
+                stride_kv = tuple(max(s // 2, 1) for s in stride_kv)
+            else:
+                stride_q = (1, 1, 1)
+            out_dims = dims * dim_mul if i in dim_mul_idx else dims
+            if out_dims // heads != 96:
+                raise NotImplementedError(f"MViT: head dimension {out_dims // heads} (the attention kernel is built for 96)")
+            rel_hw = 2 * max(size[1] // stride_q[1], size[1] // stride_kv[1]) - 1
+            self.blocks.append(_Block(dims, out_dims, heads, stride_q, stride_kv, rel_hw, 2 * size[0] - 1))
+            size = tuple(s // q for s, q in zip(size, stride_q))
+            dims = out_dims
+            if i in stage_of and stage_of[i] in self.out_scales:
+                self.stage_of_layer[i] = stage_of[i]
+                self.add_module(f"norm{stage_of[i]}", nn.LayerNorm(out_dims))
+        self._tables: Dict = {}
+        self._pack: Optional[Dict[str, Tensor]] = None
+        self._pack_key = None
+        self._init_weights(rel_pos_zero_init)
+        if pretrained:
+            self.init_weights(pretrained)
+
+    def _init_weights(self, rel_zero: bool):
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv3d)):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.zeros_(m.bias)
+        if not rel_zero:
+            for blk in self.blocks:
+                for p in (blk.attn.rel_pos_h, blk.attn.rel_pos_w, blk.attn.rel_pos_t):
+                    nn.init.trunc_normal_(p, std=0.02)
+
+    def init_weights(self, pretrained: str) -> None:
+        """Load a ``backbone.``-prefixed checkpoint; relative-position tables of another length are linearly resampled
+        (R/models/mvit.py:1057-1088)."""
+        ck = torch.load(pretrained, map_location="cpu")
+        ck = ck.get("state_dict", ck)
+        sd = {k[len("backbone."):]: v for k, v in ck.items() if k.startswith("backbone.")}
+        if not sd:
+            raise ValueError(f"backbone. is not in the pretrained model {pretrained}")
+        mine = self.state_dict()
+        for k in [k for k in sd if "attn.rel_pos" in k and k in mine]:
+            (l1, d1), (l2, d2) = sd[k].shape, mine[k].shape
+            if d1 == d2 and l1 != l2:
+                sd[k] = F.interpolate(sd[k].t().unsqueeze(0), size=l2, mode="linear").view(d2, l2).permute(1, 0)
+        self.load_state_dict(sd, strict=False)
+
+    # ------------------------------------------------------------------ weight / table packing
+    def _key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self) -> Dict[str, Tensor]:
+        key = self._key()
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        pk: Dict[str, Tensor] = {}
+        w = self.patch_embed.projection.weight.detach().reshape(96, -1)            # [96, 441], k = (c, kt, ky, kx)
+        pk["patch.w"] = F.pad(w, (0, 448 - w.shape[1])).contiguous()
+        for i, blk in enumerate(self.blocks):
+            a = blk.attn
+            for n in "qkv":
+                pk[f"b{i}.pool_{n}"] = getattr(a, f"pool_{n}").weight.detach().reshape(96, 27).t().contiguous()   # [27][D]
+        self._pack, self._pack_key, self._tables = pk, key, {}
+        return pk
+
+    @staticmethod
+    def _rel_table(rel: Tensor, q_size: int, k_size: int) -> Tensor:
+        """[q_size, k_size, D] gathered relative-position table (R/models/mvit.py:330-361); parameter preprocessing,
+        cached per (layer, grid) until a parameter changes."""
+        max_rel = int(2 * max(q_size, k_size) - 1)
+        r = rel.detach()
+        if r.shape[0] != max_rel:
+            r = F.interpolate(r.t().unsqueeze(0), size=max_rel, mode="linear").squeeze(0).t()
+        q_ratio, k_ratio = max(k_size / q_size, 1.0), max(q_size / k_size, 1.0)
+        idx = (torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio
+        return r[idx.long().to(r.device)].contiguous()
+
+    def _tables_for(self, i: int, q_size, k_size):
+        tk = (i, tuple(q_size), tuple(k_size))
+        t = self._tables.get(tk)
+        if t is None:
+            a = self.blocks[i].attn
+            Rt = self._rel_table(a.rel_pos_t, q_size[0], k_size[0])
+            Rh = self._rel_table(a.rel_pos_h, q_size[1], k_size[1])
+            Rw = self._rel_table(a.rel_pos_w, q_size[2], k_size[2])
+            # one-hot key columns matching ops.relpos_project's slots: [0,8) t, [8,24) h, [24,48) w; class-token row 0
+            kt, kh, kw = k_size
+            dev = Rt.device
+            l = torch.arange(kt * kh * kw, device=dev)
+            oh = torch.zeros((1 + kt * kh * kw, 48), device=dev)
+            oh[1 + l, l // (kh * kw)] = 1.0
+            oh[1 + l, 8 + (l // kw) % kh] = 1.0
+            oh[1 + l, 24 + l % kw] = 1.0
+            t = (Rt, Rh, Rw, oh.contiguous())
+            self._tables[tk] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def _block(self, i: int, x: Tensor, size, pk) -> Tensor:
+        """MultiScaleBlock.forward (R/models/mvit.py:779-802) on tokens [B, 1+T*H*W, C]."""
+        blk = self.blocks[i]
+        a = blk.attn
+        B, N, _ = x.shape
+        xn = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, tag="mvit-gemm").view(B, N, 3, blk.heads, 96)
+        q, q_size = ops.pool3d_ln(qkv[:, :, 0], pk[f"b{i}.pool_q"], a.norm_q.weight, a.norm_q.bias, size, blk.stride_q, a.norm_q.eps)
+        k, k_size = ops.pool3d_ln(qkv[:, :, 1], pk[f"b{i}.pool_k"], a.norm_k.weight, a.norm_k.bias, size, blk.stride_kv, a.norm_k.eps)
+        v, _ = ops.pool3d_ln(qkv[:, :, 2], pk[f"b{i}.pool_v"], a.norm_v.weight, a.norm_v.bias, size, blk.stride_kv, a.norm_v.eps)
+        Rt, Rh, Rw, onehot = self._tables_for(i, q_size, k_size)
+        extra = ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size)
+        o = ops.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual=q, skip_first=True)
+        skip = ops.linear(xn, blk.proj.weight, blk.proj.bias, tag="mvit-gemm") if hasattr(blk, "proj") else x
+        if max(blk.stride_q) > 1:
+            ks = tuple(s + 1 if s > 1 else s for s in blk.stride_q)
+            skip = ops.maxpool_tokens(skip, size, ks, blk.stride_q)
+        x = ops.linear(o, a.proj.weight, a.proj.bias, residual=skip, tag="mvit-gemm")
+        y = ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        h = ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ACT_GELU, tag="mvit-gemm")
+        return ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x, tag="mvit-gemm"), q_size
+
+    def forward(self, x: Tensor, taps: Optional[dict] = None) -> List[Tensor]:
+        if not x.is_cuda:
+            raise RuntimeError("diff_sal_amd.MViT runs on the GPU only (no CPU fallback); got a CPU tensor")
+        if self.training and any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
+            raise RuntimeError("diff_sal_amd.MViT: the HIP backward of the visual encoder is not built yet; freeze it "
+                               "(requires_grad_(False)) or call it under torch.no_grad()")
+        if x.dim() == 4:                                         # [B*16, 3, H, W]  (R/models/mvit.py:1091-1092)
+            x = x.view(-1, x.shape[-3], 16, x.shape[-2], x.shape[-1])
+        x = x.contiguous().float()
+        B = x.shape[0]
+        pk = self.packed()
+        cols, size = ops.im2col3d(x, (3, 7, 7), (2, 4, 4), (1, 3, 3), 448)
+        L = size[0] * size[1] * size[2]
+        tok = torch.empty((B, 1 + L, 96), device=x.device, dtype=torch.float32)
+        tok[:, 0] = self.cls_token.detach().view(1, 96)
+        for b in range(B):                                       # the patch projection writes rows 1.. of each clip
+            ops.conv_igemm(cols[b * L:(b + 1) * L].view(1, 1, L, 448), pk["patch.w"], bias=self.patch_embed.projection.bias,
+                           out=tok[b, 1:].view(1, 1, L, 96), tag="mvit-gemm")
+        if taps is not None:
+            taps["tokens0"] = tok
+        outs = []
+        for i in range(self.num_layers):
+            tok, size = self._block(i, tok, size, pk)
+            if taps is not None:
+                taps[f"block{i}"] = tok
+            if i in self.stage_of_layer:
+                nm = getattr(self, f"norm{self.stage_of_layer[i]}")
+                tok = ops.layernorm(tok, nm.weight, nm.bias, nm.eps)       # replaces x for the next block (mvit.py:1123-1126)
+                outs.append(ops.tokens_to_channels_first(tok, 1).view(B, tok.shape[2], *size))
+        return outs[::-1]

@@ -797,3 +797,105 @@ def multi_copy(srcs: Sequence[Tensor], dst_offsets: Sequence[int], dst: Tensor) 
     offs = (C.c_long * n)(*[int(o) for o in dst_offsets])
     sizes = (C.c_long * n)(*[t.numel() for t in keep])
     _lib.check(lib.diffsal_multi_copy(ptrs, offs, sizes, n, _p(dst), _stream()), "multi_copy")
+
+
+# ------------------------------------------------------------------------------------------------
+# once-per-clip encoders: general attention + MViTv2 pieces (csrc/attention.hip, csrc/mvit.hip)
+# ------------------------------------------------------------------------------------------------
+def _bhl_strides(t: Tensor):
+    """(batch, head, row) element strides of a [B,H,L,D] view whose last dimension is dense."""
+    if t.dim() != 4 or t.stride(3) != 1 or t.dtype != torch.float32 or not t.is_cuda:
+        raise ValueError("attention operands must be fp32 GPU views [B,H,L,D] with a dense last dimension")
+    return (C.c_long * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra: Optional[Tensor] = None,
+                      k_extra: Optional[Tensor] = None, residual: Optional[Tensor] = None, skip_first: bool = False) -> Tensor:
+    """softmax(scale q k^T + q_extra k_extra^T) v (+ residual) for [B,H,L,D] views -> [B, Lq, H*DV] (include/diffsal.h)."""
+    lib = _lib.load()
+    B, H, Lq, D = q.shape
+    Lk, DV = k.shape[2], v.shape[3]
+    E = 0 if q_extra is None else q_extra.shape[-1]
+    out = torch.empty((B, Lq, H * DV), device=q.device, dtype=torch.float32)
+    flops = 2.0 * B * H * Lq * Lk * (D + E + DV)
+    with _prof("attn", flops, _nb(q, k, v, out)):
+        _lib.check(lib.diffsal_attention_general(
+            q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
+            _p(out), B, H, Lq, Lk, D, E, DV, _bhl_strides(q), _bhl_strides(k), _bhl_strides(v),
+            None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _stream()), "attention_general")
+    return out
+
+
+def im2col3d(x: Tensor, kernel, stride, pad, Kp: int) -> Tensor:
+    """x [B,C,T,H,W] -> cols [B*To*Ho*Wo, Kp] (k = (c, kt, ky, kx), zero-padded)."""
+    lib = _lib.load()
+    B, Cc, T, H, W = x.shape
+    To, Ho, Wo = ((s + 2 * p - k) // st + 1 for s, p, k, st in zip((T, H, W), pad, kernel, stride))
+    cols = torch.empty((B * To * Ho * Wo, Kp), device=x.device, dtype=torch.float32)
+    with _prof("patch", 0.0, _nb(x, cols)):
+        _lib.check(lib.diffsal_im2col3d(_p(x), _p(cols), B, Cc, T, H, W, *kernel, *stride, *pad, Kp, _stream()), "im2col3d")
+    return cols, (To, Ho, Wo)
+
+
+def pool3d_ln(x: Tensor, w27: Tensor, gamma: Tensor, beta: Tensor, size, stride, eps: float = 1e-5) -> Tensor:
+    """x: [B, N, heads, D] view of the fused qkv output (N = 1 + T*H*W) -> [B, heads, 1 + To*Ho*Wo, D]."""
+    lib = _lib.load()
+    B, N, heads, D = x.shape
+    T, H, W = size
+    assert N == 1 + T * H * W and x.stride(3) == 1 and x.stride(2) == D
+    To, Ho, Wo = ((s - 1) // st + 1 for s, st in zip(size, stride))
+    out = torch.empty((B, heads, 1 + To * Ho * Wo, D), device=x.device, dtype=torch.float32)
+    with _prof("pool", 54.0 * out.numel(), _nb(out) * 2):
+        _lib.check(lib.diffsal_pool3d_ln(x.data_ptr(), _p(w27), _p(gamma), _p(beta), _p(out), B, heads, D, T, H, W, *stride,
+                                         x.stride(0), x.stride(1), eps, _stream()), "pool3d_ln")
+    return out, (To, Ho, Wo)
+
+
+def maxpool_tokens(x: Tensor, size, kernel, stride) -> Tensor:
+    lib = _lib.load()
+    B, N, Cc = x.shape
+    T, H, W = size
+    To, Ho, Wo = ((s + 2 * (k // 2) - k) // st + 1 for s, k, st in zip(size, kernel, stride))
+    out = torch.empty((B, 1 + To * Ho * Wo, Cc), device=x.device, dtype=torch.float32)
+    with _prof("pool", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_maxpool_tokens(_p(x), _p(out), B, Cc, T, H, W, *kernel, *stride, _stream()), "maxpool_tokens")
+    return out
+
+
+def relpos_project(q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Tensor, q_size, k_size) -> Tensor:
+    """q [B,heads,1+Lq,D] -> the 48 bias columns per query [B,heads,1+Lq,48]."""
+    lib = _lib.load()
+    B, heads, N, D = q.shape
+    extra = torch.empty((B, heads, N, 48), device=q.device, dtype=torch.float32)
+    with _prof("relpos", 2.0 * B * heads * N * D * sum(k_size), _nb(q, extra)):
+        _lib.check(lib.diffsal_relpos_project(_p(q), _p(Rt), _p(Rh), _p(Rw), _p(extra), B * heads, D, *q_size, *k_size, _stream()),
+                   "relpos_project")
+    return extra
+
+
+def tokens_to_channels_first(x: Tensor, off: int = 0) -> Tensor:
+    """x [B, off+L, C] -> [B, C, L]."""
+    lib = _lib.load()
+    B, N, Cc = x.shape
+    out = torch.empty((B, Cc, N - off), device=x.device, dtype=torch.float32)
+    with _prof("K6", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_tokens_to_channels_first(_p(x), _p(out), B, Cc, N - off, off, _stream()), "tokens_to_channels_first")
+    return out
+
+
+def saliency_metrics(pred: Tensor, gt: Tensor):
+    """-> (means [4], per_image [B,4]) in the order (cc, sim, nss, kl); R/models/sal_losses.py:14-176."""
+    lib = _lib.load()
+    if pred.shape != gt.shape:
+        raise RuntimeError(f"saliency_metrics: shapes differ: {tuple(pred.shape)} vs {tuple(gt.shape)}")
+    B = pred.shape[0]
+    n = pred.numel() // B
+    p, g = pred.contiguous().float(), gt.contiguous().float()
+    nws = lib.diffsal_saliency_metrics_ws_bytes(B)
+    ws = torch.empty((nws // 8,), device=pred.device, dtype=torch.float64)
+    per = torch.empty((B, 4), device=pred.device, dtype=torch.float32)
+    mean = torch.empty((4,), device=pred.device, dtype=torch.float32)
+    with _prof("metrics", 0.0, 2 * _nb(p, g)):
+        _lib.check(lib.diffsal_saliency_metrics(_p(p), _p(g), B, n, ws.data_ptr(), nws, _p(per), _p(mean), _stream()),
+                   "saliency_metrics")
+    return mean, per

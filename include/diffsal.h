@@ -294,6 +294,43 @@ int diffsal_head_sigmoid(const void* x, const float* w /*[C]*/, const float* bia
  * has no counterpart: it is fp32-only, R/diffusion_trainer.py:212-218). */
 int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, diffsal_stream_t stream);
 
+/* ==== once-per-clip encoders around the denoiser =======================================================
+ * ---- general softmax attention on the fp32 matrix cores (flash-style, one pass over the keys) -------------------------
+ * out[b, l, h*DV + :] = softmax_t( scale * q[b,h,l,:] . k[b,h,t,:]  +  q_extra[b,h,l,:] . k_extra[t,:] ) v[b,h,t,:]
+ *                       (+ residual[b,h,l,:], not on row 0 if skip_first)
+ * q / k / v / residual are addressed through (batch, head, row) element strides, so slices of a fused qkv GEMM output
+ * are read in place; q_extra [B,H,Lq,E] and k_extra [Lk,E] are contiguous and carry an additive attention bias as E
+ * extra contraction columns (MViT: E = 48, see diffsal_relpos_project; otherwise E = 0 and both are NULL).
+ * Built (D, E, DV): (96,48,96), (96,0,96), (64,0,64), (32,0,32).  Replaces
+ *   R/models/mvit.py:587-605 (MultiScaleAttention: attn = (q*scale) k^T, add_decomposed_rel_pos, softmax, attn v, + q),
+ *   R/models/audio_attention.py:50-58 (dots, softmax, out). */
+int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
+                              const float* residual, float* out, int B, int H, int Lq, int Lk, int D, int E, int DV,
+                              const long* q_strides /*host [3]*/, const long* k_strides, const long* v_strides,
+                              const long* r_strides, float scale, int skip_first, diffsal_stream_t stream);
+
+/* ---- MViTv2 pieces that are not GEMMs / LayerNorms (R/models/mvit.py) -------------------------------------------------
+ * im2col3d: columns of PatchEmbed3D's Conv3d (mvit.py:157-163, 983-989): x [B,C,T,H,W] -> cols [B*To*Ho*Wo][Kp],
+ *   k = (c, kt, ky, kx) as in weight.reshape(Cout, -1), zero-padded to Kp (multiple of 32); the projection is one GEMM.
+ * pool3d_ln: attention_pool (mvit.py:446-494): depthwise Conv3d 3x3x3 pad 1 stride (st,sh,sw) over the video tokens of
+ *   every head + LayerNorm(D); class token (row 0) skips the conv.  in element (b, n, head, d) at
+ *   in + b*in_stride_b + n*in_stride_n + head*D + d; w27 [27][D]; out [B, heads, 1 + To*Ho*Wo, D].
+ * maxpool_tokens: the skip path's MaxPool3d (mvit.py:765-777) on tokens [B, 1+T*H*W, C], padding k/2, class token kept.
+ * relpos_project: per query the E = 48 bias columns of add_decomposed_rel_pos (mvit.py:363-410):
+ *   [0,kt) q.Rt[t], [8,8+kh) q.Rh[y], [24,24+kw) q.Rw[x], rest 0, class-token row 0; Rt [qt][kt][D] etc. are the
+ *   gathered tables (resize_decomposed_rel_pos, :330-361); q [BH, 1+qt*qh*qw, D] unscaled.  kt <= 8, kh <= 16, kw <= 24.
+ * tokens_to_channels_first: [B, off+L, C] rows off.. -> [B, C, L] (the NCTHW maps MViT returns, :1128-1134). */
+int diffsal_im2col3d(const float* x, float* cols, int B, int C, int T, int H, int W, int KT, int KH, int KW, int st, int sh,
+                     int sw, int pt, int ph, int pw, int Kp, diffsal_stream_t stream);
+int diffsal_pool3d_ln(const float* in, const float* w27, const float* gamma, const float* beta, float* out, int B, int heads,
+                      int D, int T, int H, int W, int st, int sh, int sw, long in_stride_b, long in_stride_n, float eps,
+                      diffsal_stream_t stream);
+int diffsal_maxpool_tokens(const float* in, float* out, int B, int C, int T, int H, int W, int kt, int kh, int kw, int st,
+                           int sh, int sw, diffsal_stream_t stream);
+int diffsal_relpos_project(const float* q, const float* Rt, const float* Rh, const float* Rw, float* extra, int BH, int D,
+                           int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream);
+int diffsal_tokens_to_channels_first(const float* in, float* out, int B, int C, int L, int off, diffsal_stream_t stream);
+
 /* ---- evaluation metrics on the device: CC, SIM, NSS, KL-div of predicted vs ground-truth saliency maps -----------
  * R/models/sal_losses.py:14-37 (nss2), :63-97 (cc_s2), :100-131 (kldiv2), :134-176 (normalize_map2, similarity2), as
  * called per validation batch by get_kl_cc_sim_loss_wo_weight (R/diffusion_trainer.py:741,797,868).

@@ -377,6 +377,68 @@ def gen_train_step():
         print(name, "loss", loss.item(), "norm", float(total_norm), "params without grad", len(out["no_grad"]))
 
 
+MVIT_CASES = {
+    # name: (arch, input [B,3,16,H,W])
+    "tiny": (dict(embed_dims=96, num_layers=5, num_heads=1, downscale_indices=[1, 2, 4]), (2, 3, 16, 64, 96)),
+    "small_full": ("small", (1, 3, 16, 224, 384)),
+}
+
+
+def gen_mvit():
+    """The reference's MViTv2 video encoder (R/models/mvit.py:796-1152) on closed-form weights and clips: the four output
+    scales (coarsest first) plus per-block token taps, and a check that the restatement (oracle/mvit_oracle.py) agrees."""
+    for m in ("cv2", "torchvision", "torchvision.transforms"):
+        sys.modules.setdefault(m, mock.MagicMock())
+    from models.mvit import MViT
+    from oracle import mvit_oracle as mo
+
+    for name, (arch, shape) in MVIT_CASES.items():
+        net = MViT(arch=arch if isinstance(arch, str) else dict(arch), out_scales=[0, 1, 2, 3]).eval()
+        cfg = mo.MViTConfig(arch=arch)
+        tmpl = mo.state_dict_template(cfg)
+        ref_sd = net.state_dict()
+        assert set(ref_sd) == set(tmpl), set(ref_sd) ^ set(tmpl)
+        for k in ref_sd:
+            assert tuple(ref_sd[k].shape) == tuple(tmpl[k].shape), (k, ref_sd[k].shape, tmpl[k].shape)
+        sd = mo.synth_state_dict(tmpl)
+        net.load_state_dict(sd, strict=True)
+        x = orc.synth_tensor(f"mvit.{name}.x", shape)
+        taps = {}
+        hooks = [blk.register_forward_hook((lambda i: lambda _m, _i, o: taps.__setitem__(f"block{i}", o[0].detach().clone()))(i))
+                 for i, blk in enumerate(net.blocks)]
+        with torch.no_grad():
+            outs = net(x)
+        for h in hooks:
+            h.remove()
+        otaps = {}
+        with torch.no_grad():
+            mine = mo.mvit_forward(sd, cfg, x, taps=otaps)
+        for a, b in zip(outs, mine):
+            e = (a - b).abs().max().item() / a.abs().max().item()
+            assert a.shape == b.shape and e < 2e-5, (a.shape, b.shape, e)
+        for k in taps:
+            e = (otaps[k] - taps[k]).abs().max().item() / (taps[k].abs().max().item() + 1e-12)
+            assert e < 2e-5, (k, e)
+        print(f"[mvit_{name}] outputs", [tuple(o.shape) for o in outs], "restatement agrees")
+        d = dict(weights_checksum=np.array(checksum(sd)), inputs_checksum=np.array(float(x.double().abs().sum())),
+                 n_params=np.array(sum(v.numel() for v in sd.values())))
+        d.update(pack_taps({f"out{i}": o for i, o in enumerate(outs)}))
+        d.update(pack_taps(taps, samples=1024))
+        np.savez_compressed(os.path.join(GOLD, f"mvit_{name}.npz"), **d)
+
+
+def gen_metrics():
+    """CC / SIM / NSS / KL of the reference's own functions (R/models/sal_losses.py:14-176) on closed-form maps."""
+    from models import sal_losses as ref
+
+    gt = torch.relu(orc.synth_tensor("met.gt", (3, 1, 64, 128)) - 1.0) + 0.001 * torch.sigmoid(orc.synth_tensor("met.gt2", (3, 1, 64, 128)))
+    pred = torch.sigmoid(orc.synth_tensor("met.pred", (3, 1, 64, 128)) + 2.0 * gt - 1.0)     # correlated with gt
+    d = dict(pred=pred.numpy(), gt=gt.numpy(), cc=np.array(float(ref.cc_s2(pred, gt))), sim=np.array(float(ref.similarity2(pred, gt))),
+             nss=np.array(float(ref.nss2(pred, gt))), kl=np.array(float(ref.kldiv2(pred, gt))))
+    np.savez_compressed(os.path.join(GOLD, "sal_metrics.npz"), **d)
+    print("metrics:", {k: float(v) for k, v in d.items() if v.ndim == 0})
+
+
 def gen_legacy_denoising():
     """The reference's legacy loops R/util/denoising.py:9-69 (dead code upstream, but the call surface north_star names)
     on a toy noise-predicting model.  They hard-code .to('cuda'); on this CPU-only host that one call is mapped to a
@@ -415,9 +477,13 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy"]
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics"]
     if "legacy" in which:
         gen_legacy_denoising()
+    if "mvit" in which:
+        gen_mvit()
+    if "metrics" in which:
+        gen_metrics()
     if "forward" in which:
         gen_forward_cases()
     if "f1" in which:

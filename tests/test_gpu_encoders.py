@@ -1,0 +1,193 @@
+"""Once-per-clip encoders: the general attention kernel, the MViTv2 pieces and the whole video encoder
+against the CPU restatement / the reference's golden vectors; the on-device evaluation metrics."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mvit_oracle as mo
+from oracle import salunet_oracle as orc
+from tests._cases import check_taps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+RTOL = 1e-3
+
+
+def rel_err(got, ref):
+    ref = ref.float().cpu()
+    return (got.float().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+
+
+def rnd(name, *shape, scale=1.0):
+    return orc.synth_tensor(name, shape, scale)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diff_sal_amd import ops as o
+
+    return o
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 300, 75, 64), (1, 1, 129, 673, 96), (2, 4, 33, 32, 96), (1, 2, 1, 5, 32)])
+def test_attention_general_plain(ops, shape):
+    """softmax(scale q k^T) v for several (B, H, Lq, Lk, D): ragged query / key tile remainders included."""
+    B, H, Lq, Lk, D = shape
+    q, k, v = rnd("gq", B, H, Lq, D), rnd("gk", B, H, Lk, D), rnd("gv", B, H, Lk, D)
+    scale = D ** -0.5
+    ref = (torch.softmax((q * scale) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B, Lq, H * D)
+    got = ops.attention_general(q.to(DEV), k.to(DEV), v.to(DEV), scale=scale)
+    assert rel_err(got, ref) < 2e-5
+
+
+def test_attention_general_reads_a_fused_qkv_in_place(ops):
+    """q / k / v as strided views of one [B, N, 3, H, D] GEMM output (the AudioAttnNet call shape, heads 2 x 64)."""
+    B, N, H, D = 2, 756, 2, 64
+    qkv = rnd("fq", B, N, 3, H, D)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax((q * D ** -0.5) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B, N, H * D)
+    qd = qkv.to(DEV)
+    got = ops.attention_general(*(qd[:, :, i].permute(0, 2, 1, 3) for i in range(3)), scale=D ** -0.5)
+    assert rel_err(got, ref) < 2e-5
+
+
+def test_attention_general_with_relative_position_bias_and_residual(ops):
+    """The MViT call: decomposed rel-pos bias through the 48 extra columns, class token without bias, residual pooling."""
+    B, H, D = 2, 2, 96
+    q_size, k_size = (2, 6, 10), (2, 3, 5)
+    Lq, Lk = 1 + 2 * 6 * 10, 1 + 2 * 3 * 5
+    q, k, v = rnd("rq", B, H, Lq, D), rnd("rk", B, H, Lk, D), rnd("rv", B, H, Lk, D)
+    rel_t, rel_h, rel_w = rnd("rt", 2 * 2 - 1, D, scale=0.2), rnd("rh", 2 * 6 - 1, D, scale=0.2), rnd("rw", 2 * 10 - 1, D, scale=0.2)
+    Rt, Rh, Rw = (mo.resize_decomposed_rel_pos(r, a, b) for r, a, b in ((rel_t, 2, 2), (rel_h, 6, 3), (rel_w, 10, 5)))
+    attn = (q * D ** -0.5) @ k.transpose(-1, -2)
+    rq = q[:, :, 1:].reshape(B, H, *q_size, D)
+    rel = (torch.einsum("bythwc,tkc->bythwk", rq, Rt)[..., :, None, None] + torch.einsum("bythwc,hkc->bythwk", rq, Rh)[..., None, :, None]
+           + torch.einsum("bythwc,wkc->bythwk", rq, Rw)[..., None, None, :])
+    attn[:, :, 1:, 1:] += rel.reshape(B, H, Lq - 1, Lk - 1)
+    o = attn.softmax(-1) @ v
+    o[:, :, 1:] += q[:, :, 1:]
+    ref = o.transpose(1, 2).reshape(B, Lq, H * D)
+    qd = q.to(DEV)
+    extra = ops.relpos_project(qd, Rt.contiguous().to(DEV), Rh.contiguous().to(DEV), Rw.contiguous().to(DEV), q_size, k_size)
+    kt, kh, kw = k_size
+    oh = torch.zeros(Lk, 48)
+    l = torch.arange(Lk - 1)
+    oh[1 + l, l // (kh * kw)] = 1
+    oh[1 + l, 8 + (l // kw) % kh] = 1
+    oh[1 + l, 24 + l % kw] = 1
+    got = ops.attention_general(qd, k.to(DEV), v.to(DEV), scale=D ** -0.5, q_extra=extra, k_extra=oh.to(DEV), residual=qd,
+                                skip_first=True)
+    assert rel_err(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("stride", [(1, 1, 1), (1, 2, 2), (1, 8, 8)])
+def test_pool3d_ln_matches_attention_pool(ops, stride):
+    B, heads, D, size = 2, 2, 96, (4, 9, 17)
+    N = 1 + size[0] * size[1] * size[2]
+    qkv = rnd("pq", B, N, 3, heads, D)
+    w = rnd("pw", D, 1, 3, 3, 3, scale=0.2)
+    g, b = rnd("pg", D, scale=0.1) + 1, rnd("pb", D, scale=0.1)
+    ref, ref_size = mo.attention_pool(qkv[:, :, 1].permute(0, 2, 1, 3), w, stride, size, g, b)
+    got, out_size = ops.pool3d_ln(qkv.to(DEV)[:, :, 1], w.reshape(D, 27).t().contiguous().to(DEV), g.to(DEV), b.to(DEV), size, stride)
+    assert tuple(out_size) == tuple(ref_size) and rel_err(got, ref) < 2e-5
+
+
+def test_maxpool_tokens_im2col_and_transpose(ops):
+    B, C, size = 2, 192, (3, 8, 11)
+    x = rnd("mx", B, 1 + size[0] * size[1] * size[2], C)
+    t = x[:, 1:].reshape(B, *size, C).permute(0, 4, 1, 2, 3)
+    ref = torch.cat([x[:, :1], F.max_pool3d(t, (1, 3, 3), (1, 2, 2), (0, 1, 1)).reshape(B, C, -1).transpose(1, 2)], 1)
+    assert torch.equal(ops.maxpool_tokens(x.to(DEV), size, (1, 3, 3), (1, 2, 2)).cpu(), ref)
+    # patch embedding = im2col + GEMM
+    clip = rnd("clip", 1, 3, 6, 20, 28)
+    w, bias = rnd("pew", 96, 3, 3, 7, 7, scale=0.05), rnd("peb", 96, scale=0.1)
+    ref = F.conv3d(clip, w, bias, stride=(2, 4, 4), padding=(1, 3, 3))
+    cols, size_o = ops.im2col3d(clip.to(DEV), (3, 7, 7), (2, 4, 4), (1, 3, 3), 448)
+    assert tuple(size_o) == tuple(ref.shape[2:])
+    wp = F.pad(w.reshape(96, -1), (0, 7)).contiguous().to(DEV)
+    got = ops.linear(cols, wp, bias.to(DEV))
+    assert rel_err(got, ref.flatten(2).transpose(1, 2).reshape(-1, 96)) < 2e-5
+    # tokens -> channels first, skipping the class-token row
+    tk = rnd("tk", 2, 1 + 70, 96)
+    assert torch.equal(ops.tokens_to_channels_first(tk.to(DEV), 1).cpu(), tk[:, 1:].transpose(1, 2).contiguous())
+
+
+def build_mvit(arch):
+    from diff_sal_amd.mvit import MViT
+
+    cfg = mo.MViTConfig(arch=arch)
+    sd = mo.synth_state_dict(mo.state_dict_template(cfg))
+    net = MViT(arch=arch if isinstance(arch, str) else dict(arch), out_scales=[0, 1, 2, 3])
+    assert set(net.state_dict()) == set(sd) and all(tuple(v.shape) == tuple(sd[k].shape) for k, v in net.state_dict().items())
+    net.load_state_dict(sd, strict=True)
+    return net.to(DEV).eval().requires_grad_(False), cfg, sd
+
+
+MVIT_CASES = {"tiny": (dict(embed_dims=96, num_layers=5, num_heads=1, downscale_indices=[1, 2, 4]), (2, 3, 16, 64, 96)),
+              "small_full": ("small", (1, 3, 16, 224, 384))}
+
+
+@pytest.mark.parametrize("name", list(MVIT_CASES))
+def test_mvit_forward_matches_reference_golden(golden_dir, name):
+    """The whole video encoder against the reference's own outputs (oracle/gen_golden.py::gen_mvit): four scales,
+    coarsest first, plus per-block token taps.  1e-3 relative (north_star)."""
+    arch, shape = MVIT_CASES[name]
+    net, cfg, sd = build_mvit(arch)
+    g = np.load(f"{golden_dir}/mvit_{name}.npz")
+    x = orc.synth_tensor(f"mvit.{name}.x", shape)
+    taps = {}
+    with torch.no_grad():
+        outs = net(x.to(DEV), taps=taps)
+    torch.cuda.synchronize()
+    assert len(outs) == 4 and outs[0].shape[1] == 768 and outs[3].shape[1] == 96
+    named = {f"out{i}": o for i, o in enumerate(outs)}
+    named.update({k: v for k, v in taps.items() if k.startswith("block")})
+    worst = check_taps(named, g, RTOL)
+    print(name, "worst rel err", max(worst.values()), "over", len(worst), "tensors")
+    assert {"out0", "out3", "block0"} <= set(worst)
+
+
+def test_mvit_feeds_the_denoiser_through_video_saliency_model():
+    """VideoSaliencyModel(visual_net=MViT, decoder_net=SalUNet): clip in, saliency map out, all on the HIP path."""
+    from diff_sal_amd.diff_model import VideoSaliencyModel
+    from tests.test_gpu_salunet import build
+
+    cfg = orc.SalUNetConfig(img_size=(64, 96))
+    dec = build(cfg, orc.synth_state_dict(orc.state_dict_template(cfg)))
+    enc, mcfg, msd = build_mvit("small")
+    model = VideoSaliencyModel(channel_list=None, visual_net=enc, decoder_net=dec).eval()
+    clip = orc.synth_tensor("e2e.clip", (1, 3, 16, 64, 96))
+    xt = orc.synth_tensor("e2e.x", (1, 1, 64, 96))
+    with torch.no_grad():
+        out = model({"img": clip.to(DEV), "input": xt.to(DEV)}, torch.tensor([500], device=DEV))
+        feats = mo.mvit_forward(msd, mcfg, clip)
+        ref = orc.salunet_forward(dec.state_dict() if False else orc.synth_state_dict(orc.state_dict_template(cfg)), cfg, xt,
+                                  torch.tensor([500]), feats, None)
+    assert out.shape == (1, 1, 64, 96) and (out.cpu() - ref).abs().max().item() < RTOL * ref.abs().max().item()
+
+
+def test_saliency_metrics_match_the_reference_formulas(golden_dir):
+    """CC / SIM / NSS / KL of R/models/sal_losses.py on the device vs the reference's own values (fixture) and vs a direct
+    torch evaluation at the benchmark map size."""
+    from diff_sal_amd import sal_losses as sl
+
+    g = np.load(f"{golden_dir}/sal_metrics.npz")
+    pred, gt = torch.from_numpy(g["pred"]), torch.from_numpy(g["gt"])
+    m = sl.saliency_metrics(pred.to(DEV), gt.to(DEV))
+    for k in ("cc", "sim", "nss", "kl"):
+        ref = float(g[k])
+        assert abs(float(m[k]) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(m[k]), ref)
+    assert abs(float(sl.cc_s2(pred.to(DEV), gt.to(DEV))) - float(g["cc"])) < 1e-4
+    # full-size maps, B = 4: formulas restated in fp64
+    torch.manual_seed(0)
+    p, t = torch.rand(4, 1, 224, 384), (torch.rand(4, 1, 224, 384) > 0.97).float() + 0.01 * torch.rand(4, 1, 224, 384)
+    m = sl.saliency_metrics(p.to(DEV), t.to(DEV))
+    pd, td = p.double().flatten(1), t.double().flatten(1)
+    cc = (((pd - pd.mean(1, keepdim=True)) * (td - td.mean(1, keepdim=True))).sum(1)
+          / ((pd - pd.mean(1, keepdim=True)).square().sum(1) * (td - td.mean(1, keepdim=True)).square().sum(1)).sqrt()).mean()
+    nss = ((((pd - pd.mean(1, keepdim=True)) / (pd.std(1, keepdim=True) + 2.2204e-16)) * td).sum(1) / td.sum(1)).mean()
+    assert abs(float(m["cc"]) - float(cc)) < 1e-5 and abs(float(m["nss"]) - float(nss)) < 1e-5 * max(1.0, abs(float(nss)))
+    assert m["per_image"].shape == (4, 4)

@@ -112,3 +112,25 @@ def test_restatement_training_step_matches_reference(golden_dir, name):
             continue                   # gradient is rounding noise (zero by symmetry, e.g. a conv bias before BatchNorm)
         e, m = sampled_err(leaf[k], g, "after." + k)
         assert e < 2e-5, (k, e)        # one Adam step moves a parameter by at most lr = 1e-4
+
+
+@pytest.mark.parametrize("name,arch,shape", [("tiny", dict(embed_dims=96, num_layers=5, num_heads=1, downscale_indices=[1, 2, 4]), (2, 3, 16, 64, 96))])
+def test_mvit_oracle_reproduces_the_reference_fixture(golden_dir, name, arch, shape):
+    """oracle/mvit_oracle.py (restatement of R/models/mvit.py) against the outputs of the real reference encoder."""
+    import numpy as np
+
+    from oracle import mvit_oracle as mo
+    from oracle import salunet_oracle as orc
+    from tests._cases import check_taps
+
+    cfg = mo.MViTConfig(arch=arch)
+    sd = mo.synth_state_dict(mo.state_dict_template(cfg))
+    x = orc.synth_tensor(f"mvit.{name}.x", shape)
+    taps = {}
+    with torch.no_grad():
+        outs = mo.mvit_forward(sd, cfg, x, taps=taps)
+    g = np.load(f"{golden_dir}/mvit_{name}.npz")
+    named = {f"out{i}": o for i, o in enumerate(outs)}
+    named.update({k: v for k, v in taps.items() if k.startswith("block")})
+    worst = check_taps(named, g, 2e-5)
+    assert len(worst) == 4 + 5
