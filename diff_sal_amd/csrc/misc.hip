@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, T* __restrict__ out, int B,
-                                                      int H, int W, int C, int skip_mod, int Hn, int Wn) {
+                                                      int H, int W, int C, int skip_mod, int Hn, int Wn, int relu) {
   const int c4n = C >> 2;
   const int ppb = 256 / c4n;  // pixels per pass
   const int c4 = threadIdx.x % c4n, ps = threadIdx.x / c4n;
@@ -105,6 +105,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = fmaf(v, wr[j][ky * 3 + kx], o[j]);
       }
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
     }
     st4(out + ((static_cast<long>(b) * H + yh) * W + xw) * C + c, make_float4(o[0], o[1], o[2], o[3]));
   }
@@ -499,6 +503,27 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D*
     dst[i] = static_cast<D>(static_cast<float>(src[i]));
 }
 
+// MaxPool2d(k, stride s, no padding, floor) on NHWC.  R/models/vggish.py:76-84 (VGG feature stack).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C,
+                                                        int Ho, int Wo, int k, int s, long total4) {
+  const int c4n = C >> 2;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    long pix = i / c4n;
+    const int xo = static_cast<int>(pix % Wo); pix /= Wo;
+    const int yo = static_cast<int>(pix % Ho);
+    const long n = pix / Ho;
+    float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) {
+        const float4 v = ld4(in + ((n * H + yo * s + dy) * W + xo * s + dx) * C + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    st4(out + ((n * Ho + yo) * Wo + xo) * C + c, m);
+  }
+}
+
 static int ew_grid(long total_threads) {
   long g = (total_threads + 255) / 256;
   return static_cast<int>(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -508,7 +533,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 2; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 3; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
@@ -539,7 +564,8 @@ extern "C" int diffsal_dense_small(const float* in, int B, int K, int swish_in, 
 }
 
 extern "C" int diffsal_conv_in(const float* x, const float* w, const float* bias, void* out, int B, int H, int W,
-                               int C, int skip_mod, int dtype, diffsal_stream_t stream) {
+                               int C, int skip_mod, int act, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(act == DIFFSAL_ACT_NONE || act == DIFFSAL_ACT_RELU, DIFFSAL_E_ARG, "conv_in: act %d (none or ReLU)", act);
   DS_REQUIRE(x && w && bias && out, DIFFSAL_E_ARG, "conv_in: null argument");
   DS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "conv_in: bad shape");
   DS_REQUIRE(aligned16(out), DIFFSAL_E_ALIGN, "conv_in: misaligned output");
@@ -552,7 +578,7 @@ extern "C" int diffsal_conv_in(const float* x, const float* w, const float* bias
   g = g > 8192 ? 8192 : g;
 #define CALL(T)                                                                                                     \
   hipLaunchKernelGGL((conv_in_kernel<T>), dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), x, \
-                     w, bias, static_cast<T*>(out), B, H, W, C, skip_mod, Hn, Wn)
+                     w, bias, static_cast<T*>(out), B, H, W, C, skip_mod, Hn, Wn, act)
   DS_DTYPE_DISPATCH(dtype, "conv_in", CALL);
 #undef CALL
   return check_launch("conv_in");
@@ -774,4 +800,20 @@ extern "C" int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_d
   DS_DTYPE_DISPATCH(dst_dtype, "cast", CALL_D);
 #undef CALL_D
   return check_launch("cast");
+}
+
+extern "C" int diffsal_maxpool2d(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int dtype,
+                                 diffsal_stream_t stream) {
+  DS_REQUIRE(in && out, DIFFSAL_E_ARG, "maxpool2d: null argument");
+  DS_REQUIRE(N > 0 && H >= k && W >= k && C > 0 && C % 4 == 0 && k > 0 && stride > 0, DIFFSAL_E_SHAPE, "maxpool2d: bad shape");
+  DS_REQUIRE(aligned16(in) && aligned16(out), DIFFSAL_E_ALIGN, "maxpool2d: misaligned pointer");
+  const int Ho = (H - k) / stride + 1, Wo = (W - k) / stride + 1;
+  const long total4 = static_cast<long>(N) * Ho * Wo * (C / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(T)                                                                                                        \
+  hipLaunchKernelGGL((maxpool2d_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, s, static_cast<const T*>(in),          \
+                     static_cast<T*>(out), H, W, C, Ho, Wo, k, stride, total4)
+  DS_DTYPE_DISPATCH(dtype, "maxpool2d", CALL);
+#undef CALL
+  return check_launch("maxpool2d");
 }

@@ -2,18 +2,22 @@
 
 Same constructor keywords and ``forward(data, t)`` / ``forward_vggish(audio)`` behaviour; the sub-networks may be
 given as ready ``nn.Module`` instances or as mmcv-style dicts ``{"type": <class or registered name>, **kwargs}``.
-The denoiser (``decoder_net``) is the MI355X-native ``SalUNet``; the once-per-clip encoders (MViT, VGGish,
-AudioAttnNet) are outside this round's hot path and are accepted as arbitrary modules.
+The denoiser (``decoder_net``) is the MI355X-native ``SalUNet``; the once-per-clip encoders (``MViT``, ``VGGish``,
+``AudioAttnNet``) have HIP forwards too and are registered under the reference's type names, and any other
+``nn.Module`` is accepted in their place.
 """
 from __future__ import annotations
 
 import torch
 from torch import nn
 
+from . import ops
+from .audio_attention import AudioAttnNet
 from .mvit import MViT
 from .sal_unet import SalUNet
+from .vggish import VGGish
 
-OBJECT_REGISTRY = {"SalUNet": SalUNet, "MViT": MViT}
+OBJECT_REGISTRY = {"SalUNet": SalUNet, "MViT": MViT, "VGGish": VGGish, "AudioAttnNet": AudioAttnNet}
 
 
 def register_module(cls):
@@ -48,6 +52,16 @@ class VideoSaliencyModel(nn.Module):
         """audio [B,1,T,H,W] -> (feat, feat) with feat [B,512,T,h,w]   (diff_model.py:70-81)."""
         bs, T = audio.shape[0], audio.shape[2]
         a = audio.reshape(-1, audio.shape[1], audio.shape[3], audio.shape[4])
+        if isinstance(self.audio_net, VGGish) and isinstance(self.spatiotemp_net, AudioAttnNet) and a.is_cuda:
+            # both stages are ours: stay channels-last tokens [B, T*h*w, C] from the last VGG layer to the end of the
+            # transformer (the reference's NCHW -> NCTHW -> tokens -> NCTHW rearranges become one final transpose)
+            with torch.no_grad():
+                fm = self.audio_net.features_nhwc(a)                      # [(b t), h, w, C]
+            _, h, w, c = fm.shape
+            self.spatiotemp_net._check_frames(T)
+            tok = self.spatiotemp_net.forward_tokens(fm.view(bs, T * h * w, c))
+            f = ops.tokens_to_channels_first(tok, 0).view(bs, c, T, h, w)
+            return f, f
         with torch.no_grad():
             f = self.audio_net.forward_feat(a)
         f = f.reshape(bs, T, *f.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()

@@ -164,7 +164,8 @@ def dense_small(x: Tensor, w: Tensor, bias: Optional[Tensor], swish_in: bool) ->
     return out
 
 
-def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0, out_dtype: torch.dtype = torch.float32) -> Tensor:
+def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0, out_dtype: torch.dtype = torch.float32,
+            act: int = ACT_NONE) -> Tensor:
     """K2. x [B,1,H,W] (fp32) -> NHWC [B,H,W,C] of ``out_dtype``; with skip_mod=4 the pixels a stride-4 3x3 consumer
     never reads are left unwritten."""
     lib = _lib.load()
@@ -173,7 +174,7 @@ def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0, out_dtype: t
     out = torch.empty((B, H, W, Cc), device=x.device, dtype=out_dtype)
     frac = ((skip_mod - 1) / skip_mod) ** 2 if skip_mod > 0 else 1.0     # share of the pixels actually produced
     with _prof("K2-conv_in", 18.0 * B * H * W * Cc * frac, _nb(x) + _nb(out) * frac):
-        _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), out.data_ptr(), B, H, W, Cc, skip_mod, _dt(out), _stream()),
+        _lib.check(lib.diffsal_conv_in(_p(x), _p(w9), _p(bias), out.data_ptr(), B, H, W, Cc, skip_mod, act, _dt(out), _stream()),
                    "conv_in")
     return out
 
@@ -899,3 +900,14 @@ def saliency_metrics(pred: Tensor, gt: Tensor):
         _lib.check(lib.diffsal_saliency_metrics(_p(p), _p(g), B, n, ws.data_ptr(), nws, _p(per), _p(mean), _stream()),
                    "saliency_metrics")
     return mean, per
+
+
+def maxpool2d(x: Tensor, k: int = 2, stride: int = 2) -> Tensor:
+    """MaxPool2d(k, stride) on NHWC (no padding)."""
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, (H - k) // stride + 1, (W - k) // stride + 1, Cc), device=x.device, dtype=x.dtype)
+    dt = _dt(x)
+    with _prof("pool", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_maxpool2d(_pa(x, dt), out.data_ptr(), N, H, W, Cc, k, stride, dt, _stream()), "maxpool2d")
+    return out

@@ -59,7 +59,8 @@ int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float
  * R/.../sal_unet.py:240,292.  Only pixels with (y % skip_mod != skip_mod-1 && x % skip_mod != skip_mod-1)
  * are written when skip_mod > 0 (the stride-4 consumer never reads the others, sal_unet.py:67-84). */
 int diffsal_conv_in(const float* x, const float* w /*[C,9]*/, const float* bias, void* out,
-                    int B, int H, int W, int C, int skip_mod, int dtype, diffsal_stream_t stream);
+                    int B, int H, int W, int C, int skip_mod, int act /*DIFFSAL_ACT_NONE | RELU*/, int dtype,
+                    diffsal_stream_t stream);
 
 /* ---- K3: GroupNorm(groups, eps) + swish on NHWC ----------------------------------------
  * R/.../sal_unet.py:36-44.  ws: >= diffsal_groupnorm_ws_bytes(B, groups) bytes of scratch. */
@@ -330,6 +331,11 @@ int diffsal_maxpool_tokens(const float* in, float* out, int B, int C, int T, int
 int diffsal_relpos_project(const float* q, const float* Rt, const float* Rh, const float* Rw, float* extra, int BH, int D,
                            int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream);
 int diffsal_tokens_to_channels_first(const float* in, float* out, int B, int C, int L, int off, diffsal_stream_t stream);
+
+/* ---- VGGish feature stack (R/models/vggish.py:70-106): 3x3 convs are diffsal_conv_in (1 input channel, act = ReLU) and
+ * diffsal_conv_igemm (bias + ReLU epilogue); this is its MaxPool2d(k, stride) on NHWC (no padding, floor). */
+int diffsal_maxpool2d(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int dtype,
+                      diffsal_stream_t stream);
 
 /* ---- evaluation metrics on the device: CC, SIM, NSS, KL-div of predicted vs ground-truth saliency maps -----------
  * R/models/sal_losses.py:14-37 (nss2), :63-97 (cc_s2), :100-131 (kldiv2), :134-176 (normalize_map2, similarity2), as

@@ -427,6 +427,44 @@ def gen_mvit():
         np.savez_compressed(os.path.join(GOLD, f"mvit_{name}.npz"), **d)
 
 
+AUDIO_CASES = {"tiny": (2, 1, 9, 32, 64), "full": (1, 1, 9, 112, 192)}     # [B,1,T,H,W] log-mel clips (full = the shipped size)
+
+
+def gen_audio():
+    """The reference's audio branch: VGGish.forward_feat (R/models/vggish.py:93-95) followed by AudioAttnNet
+    (R/models/audio_attention.py:93-143), chained as VideoSaliencyModel.forward_vggish does (R/models/diff_model.py:70-81)."""
+    from models.audio_attention import AudioAttnNet
+    from models.vggish import VGGish
+    from oracle import audio_oracle as ao
+
+    vgg = VGGish(pretrained=False).eval()
+    net = AudioAttnNet(depth=1, heads=2, dim=512, mlp_dim=256, patch_dim=512, num_patches=16, height=7, width=12, pool="cls",
+                       dim_head=64, dropout=0.0, emb_dropout=0.0).eval()
+    for mod, tmpl in ((vgg, ao.vgg_template()), (net, ao.attn_template())):
+        ref_sd = mod.state_dict()
+        assert set(ref_sd) == set(tmpl), set(ref_sd) ^ set(tmpl)
+        assert all(tuple(ref_sd[k].shape) == tuple(tmpl[k].shape) for k in tmpl)
+    vsd, asd = ao.synth_state_dict(ao.vgg_template(), "vgg."), ao.synth_state_dict(ao.attn_template(), "aan.")
+    vgg.load_state_dict(vsd)
+    net.load_state_dict(asd)
+    for name, shape in AUDIO_CASES.items():
+        audio = orc.synth_tensor(f"audio.{name}", shape)
+        bs, T = shape[0], shape[2]
+        with torch.no_grad():
+            f = vgg.forward_feat(audio.view(-1, 1, shape[3], shape[4]))
+            f5 = f.reshape(bs, T, *f.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
+            out = net(f5.clone())
+            mine_f = ao.vgg_features(vsd, audio.view(-1, 1, shape[3], shape[4]))
+            mine = ao.audio_branch(vsd, asd, audio)
+        e1 = (mine_f - f).abs().max().item() / f.abs().max().item()
+        e2 = (mine - out).abs().max().item() / out.abs().max().item()
+        print(f"[audio_{name}] features {tuple(f.shape)} out {tuple(out.shape)} restatement err {e1:.2e} {e2:.2e}")
+        assert e1 < 2e-5 and e2 < 2e-5
+        d = dict(inputs_checksum=np.array(float(audio.double().abs().sum())))
+        d.update(pack_taps({"features": f, "out": out}))
+        np.savez_compressed(os.path.join(GOLD, f"audio_{name}.npz"), **d)
+
+
 def gen_metrics():
     """CC / SIM / NSS / KL of the reference's own functions (R/models/sal_losses.py:14-176) on closed-form maps."""
     from models import sal_losses as ref
@@ -477,13 +515,15 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics"]
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio"]
     if "legacy" in which:
         gen_legacy_denoising()
     if "mvit" in which:
         gen_mvit()
     if "metrics" in which:
         gen_metrics()
+    if "audio" in which:
+        gen_audio()
     if "forward" in which:
         gen_forward_cases()
     if "f1" in which:

@@ -191,3 +191,65 @@ def test_saliency_metrics_match_the_reference_formulas(golden_dir):
     nss = ((((pd - pd.mean(1, keepdim=True)) / (pd.std(1, keepdim=True) + 2.2204e-16)) * td).sum(1) / td.sum(1)).mean()
     assert abs(float(m["cc"]) - float(cc)) < 1e-5 and abs(float(m["nss"]) - float(nss)) < 1e-5 * max(1.0, abs(float(nss)))
     assert m["per_image"].shape == (4, 4)
+
+
+def build_audio():
+    from diff_sal_amd.audio_attention import AudioAttnNet
+    from diff_sal_amd.vggish import VGGish
+    from oracle import audio_oracle as ao
+
+    vsd, asd = ao.synth_state_dict(ao.vgg_template(), "vgg."), ao.synth_state_dict(ao.attn_template(), "aan.")
+    vgg = VGGish(pretrained=False)
+    net = AudioAttnNet(depth=1, heads=2, dim=512, mlp_dim=256, patch_dim=512, num_patches=16, height=7, width=12, pool="cls",
+                       dim_head=64, dropout=0.0, emb_dropout=0.0)
+    assert set(vgg.state_dict()) == set(vsd) and set(net.state_dict()) == set(asd)
+    vgg.load_state_dict(vsd)
+    net.load_state_dict(asd)
+    return vgg.to(DEV).eval(), net.to(DEV).eval(), vsd, asd
+
+
+@pytest.mark.parametrize("name,shape", [("tiny", (2, 1, 9, 32, 64)), ("full", (1, 1, 9, 112, 192))])
+def test_audio_branch_matches_reference_golden(golden_dir, name, shape):
+    """VGGish.forward_feat and AudioAttnNet (module contracts, NCHW / NCTHW) and the fused channels-last path of
+    VideoSaliencyModel.forward_vggish, against the reference's own outputs (oracle/gen_golden.py::gen_audio)."""
+    from diff_sal_amd.diff_model import VideoSaliencyModel
+
+    vgg, net, _, _ = build_audio()
+    g = np.load(f"{golden_dir}/audio_{name}.npz")
+    audio = orc.synth_tensor(f"audio.{name}", shape).to(DEV)
+    bs, T = shape[0], shape[2]
+    with torch.no_grad():
+        f = vgg.forward_feat(audio.view(-1, 1, shape[3], shape[4]))
+        out = net(f.reshape(bs, T, *f.shape[1:]).permute(0, 2, 1, 3, 4).contiguous())
+        model = VideoSaliencyModel(channel_list=None, audio_net=vgg, spatiotemp_net=net)
+        fused, fused2 = model.forward_vggish(audio)
+    worst = check_taps({"features": f, "out": out}, g, RTOL)
+    print(name, worst)
+    assert fused is fused2 and fused.shape == out.shape and (fused - out).abs().max().item() < 1e-5 * out.abs().max().item()
+    with pytest.raises(RuntimeError, match="non-singleton dimension 2"):
+        net(torch.zeros(1, 512, 5, 2, 4, device=DEV))                 # the reference fails the same way for T != 9
+
+
+def test_audio_visual_model_end_to_end_on_the_hip_path():
+    """configs[2] plumbing: VideoSaliencyModel(MViT + VGGish + AudioAttnNet + SalUNet).forward(data, t) == the chain of
+    the three CPU restatements on the same clip / audio / noisy map."""
+    from diff_sal_amd.diff_model import VideoSaliencyModel
+    from oracle import audio_oracle as ao
+    from tests.test_gpu_salunet import build
+
+    cfg = orc.SalUNetConfig()                                          # full widths; 224 x 384 so that audio (7 x 12) lines up
+    dsd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    dec = build(cfg, dsd)
+    enc, mcfg, msd = build_mvit("small")
+    vgg, net, vsd, asd = build_audio()
+    model = VideoSaliencyModel(channel_list=None, visual_net=enc, audio_net=vgg, spatiotemp_net=net, decoder_net=dec).eval()
+    clip = orc.synth_tensor("av.clip", (1, 3, 16, 224, 384))
+    audio = orc.synth_tensor("av.audio", (1, 1, 9, 112, 192))
+    xt = orc.synth_tensor("av.x", (1, 1, 224, 384))
+    t = torch.tensor([321])
+    with torch.no_grad():
+        out = model({"img": clip.to(DEV), "input": xt.to(DEV), "audio": audio.to(DEV)}, t.to(DEV))
+        ref = orc.salunet_forward(dsd, cfg, xt, t, mo.mvit_forward(msd, mcfg, clip), ao.audio_branch(vsd, asd, audio))
+    err = (out.cpu() - ref).abs().max().item()
+    print("AV end-to-end max abs err", err)
+    assert err < RTOL * ref.abs().max().item()
