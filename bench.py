@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of exactly --steps steps each; the reported value is their median (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the end-to-end (encoders + 50 steps) leg")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 is the fastest setting measured on the 256-core box)")
@@ -531,6 +532,46 @@ def main():
                          "output_range": [float(y32.min().item()), float(y32.max().item())]})
         set_precision("fp32")
         result["alt_precision"] = alts
+    if world == 1 and args.precision == "fp32" and not special and not args.no_encoders:
+        # "also report end-to-end clips/s including encoders separately".  The once-per-clip encoders (MViTv2-S
+        # video encoder; VGGish + AudioAttnNet in AV mode) on the HIP path, random-init weights of the reference
+        # architectures, timed on a synthetic clip batch; end-to-end = encoders once + 50 denoising steps per clip batch.
+        from diff_sal_amd.audio_attention import AudioAttnNet
+        from diff_sal_amd.mvit import MViT
+        from diff_sal_amd.vggish import VGGish
+
+        torch.manual_seed(7)
+        enc = MViT(arch="small", out_scales=[0, 1, 2, 3]).to(dev).eval().requires_grad_(False)
+        clip = torch.randn((B, 3, 16, H, W), device=dev)
+        mods = [("mvit_s", lambda: enc(clip))]
+        if av:
+            vgg = VGGish(pretrained=False).to(dev).eval().requires_grad_(False)
+            aan = AudioAttnNet(depth=1, heads=2, dim=512, mlp_dim=256, patch_dim=512, num_patches=16, height=7, width=12,
+                               pool="cls", dim_head=64).to(dev).eval().requires_grad_(False)
+            wav = torch.randn((B, 1, 9, 112, 192), device=dev)
+            top = Top(net)
+            from diff_sal_amd.diff_model import VideoSaliencyModel
+
+            vm = VideoSaliencyModel(channel_list=None, audio_net=vgg, spatiotemp_net=aan)
+            mods.append(("vggish+audio_attn", lambda: vm.forward_vggish(wav)))
+        enc_ms = {}
+        with torch.no_grad():
+            for nm, fn in mods:
+                fn()
+                torch.cuda.synchronize()
+                ts_ = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    ts_.append(time.perf_counter() - t0)
+                enc_ms[nm] = round(median(ts_) * 1e3, 3)
+        denoise_ms = elapsed / args.steps * 1e3 * NFE_PER_TRAJECTORY
+        total_ms = denoise_ms + sum(enc_ms.values())
+        result["end_to_end"] = {
+            "what": "encoders once per clip batch + 50 denoising steps, all on the HIP path (not the headline metric)",
+            "encoder_ms_per_batch": enc_ms, "denoise_ms_per_batch": round(denoise_ms, 3),
+            "clips_per_s": round(B / (total_ms * 1e-3), 3), "encoder_share": round(sum(enc_ms.values()) / total_ms, 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: a few B-clip oracle evaluations (the per-step network cost dominates a trajectory).
         # This leg is the ONLY place the CPU oracle is touched; it gets the same weights and inputs as the GPU path.

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 SIGNATURES = {
@@ -83,6 +83,7 @@ SIGNATURES = {
     "diffsal_maxpool_tokens": (c_i, [c_f, c_f] + [c_i] * 11 + [c_f]),
     "diffsal_relpos_project": (c_i, [c_f] * 5 + [c_i] * 8 + [c_f]),
     "diffsal_tokens_to_channels_first": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_resize_update": (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl] * 5 + [c_f]),
     "diffsal_saliency_metrics_ws_bytes": (c_sz, [c_i]),
     "diffsal_saliency_metrics": (c_i, [c_f, c_f, c_i, C.c_long, c_f, c_sz, c_f, c_f, c_f]),
     "diffsal_reduce_partials": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T
     } else {
       const float v00 = static_cast<float>(b[(static_cast<long>(y0) * w + x0) * C]), v01 = static_cast<float>(b[(static_cast<long>(y0) * w + x1) * C]);
       const float v10 = static_cast<float>(b[(static_cast<long>(y1) * w + x0) * C]), v11 = static_cast<float>(b[(static_cast<long>(y1) * w + x1) * C]);
-      out[o] = static_cast<T>(hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+      out[o] = static_cast<T>(hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));   // == bilerp1 for C = 1
     }
   }
 }
@@ -485,14 +485,56 @@ __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, cons
   }
 }
 
+// a x + b y + c z with ONE rounding sequence shared by the stand-alone sampler update and the fused step epilogue below,
+// so that the two paths agree bit for bit.
+__device__ __forceinline__ float lincomb3(float a, float x, float b, float y, bool has_y, float c, float z, bool has_z) {
+  float r = a * x;
+  if (has_y) r = fmaf(b, y, r);
+  if (has_z) r = fmaf(c, z, r);
+  return r;
+}
+
 __global__ __launch_bounds__(256) void axpbypcz_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ z, float a, float b, float c,
                                                        float* __restrict__ out, size_t n) {
-  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256) {
-    float r = a * x[i];
-    if (y) r += b * y[i];
-    if (z) r += c * z[i];
-    out[i] = r;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256)
+    out[i] = lincomb3(a, x[i], b, y ? y[i] : 0.f, y != nullptr, c, z ? z[i] : 0.f, z != nullptr);
+}
+
+// One bilinear sample of a single-channel map (align_corners = False), the arithmetic of resize_kernel<1>.
+__device__ __forceinline__ float bilerp1(const float* __restrict__ img, int h, int w, int Y, int X, float sy, float sx) {
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilin_coord(Y, sy, h, y0, y1, ly);
+  bilin_coord(X, sx, w, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float v00 = img[static_cast<long>(y0) * w + x0], v01 = img[static_cast<long>(y0) * w + x1];
+  const float v10 = img[static_cast<long>(y1) * w + x0], v11 = img[static_cast<long>(y1) * w + x1];
+  return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused tail of a denoising step: the final x2 bilinear resize of the sigmoid map (sal_unet.py:325-327),
+// the x0 -> model-output conversion of the solver's wrapper (sampler.py:286-292: noise = (x - alpha x0) / sigma) and the
+// multistep update x_next = A x + c0 m + c1 m_prev (sampler.py:548-593, 797-853) in ONE pass over the 1.4 MB state:
+//   x0 = resize(s);  m = ex * x + e0 * x0;  x_next = A * x + c0 * m + c1 * m_prev
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_update_kernel(const float* __restrict__ s_low, const float* __restrict__ x,
+                                                            const float* __restrict__ m_prev, float* __restrict__ x0_out,
+                                                            float* __restrict__ m_out, float* __restrict__ x_next, int h,
+                                                            int w, int H, int W, float sy, float sx, float ex, float e0,
+                                                            float A, float c0, float c1, long total) {
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int X = static_cast<int>(i % W);
+    const long r = i / W;
+    const int Y = static_cast<int>(r % H);
+    const long n = r / H;
+    const float x0 = bilerp1(s_low + n * h * w, h, w, Y, X, sy, sx);
+    const float xv = x[i];
+    const float m = ex == 0.f ? e0 * x0 : lincomb3(ex, xv, e0, x0, true, 0.f, 0.f, false);
+    if (x0_out) x0_out[i] = x0;
+    m_out[i] = m;
+    if (x_next) x_next[i] = lincomb3(A, xv, c0, m, true, c1, m_prev ? m_prev[i] : 0.f, m_prev != nullptr);
   }
 }
 
@@ -533,7 +575,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 3; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 4; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
@@ -816,4 +858,16 @@ extern "C" int diffsal_maxpool2d(const void* in, void* out, int N, int H, int W,
   DS_DTYPE_DISPATCH(dtype, "maxpool2d", CALL);
 #undef CALL
   return check_launch("maxpool2d");
+}
+
+extern "C" int diffsal_resize_update(const float* s_low, const float* x, const float* m_prev, float* x0_out, float* m_out,
+                                     float* x_next, int N, int h, int w, int H, int W, float ex, float e0, float A, float c0,
+                                     float c1, diffsal_stream_t stream) {
+  DS_REQUIRE(s_low && x && m_out, DIFFSAL_E_ARG, "resize_update: null argument");
+  DS_REQUIRE(N > 0 && h > 0 && w > 0 && H > 0 && W > 0, DIFFSAL_E_SHAPE, "resize_update: bad shape");
+  const long total = static_cast<long>(N) * H * W;
+  hipLaunchKernelGGL(resize_update_kernel, dim3(ew_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), s_low, x,
+                     m_prev, x0_out, m_out, x_next, h, w, H, W, static_cast<float>(h) / static_cast<float>(H),
+                     static_cast<float>(w) / static_cast<float>(W), ex, e0, A, c0, c1, total);
+  return check_launch("resize_update");
 }

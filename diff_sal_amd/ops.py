@@ -911,3 +911,19 @@ def maxpool2d(x: Tensor, k: int = 2, stride: int = 2) -> Tensor:
     with _prof("pool", 0.0, _nb(x, out)):
         _lib.check(lib.diffsal_maxpool2d(_pa(x, dt), out.data_ptr(), N, H, W, Cc, k, stride, dt, _stream()), "maxpool2d")
     return out
+
+
+def resize_update(s_low: Tensor, x: Tensor, m_prev: Optional[Tensor], ex: float, e0: float, A: float, c0: float, c1: float,
+                  want_x0: bool = False, want_next: bool = True):
+    """Fused end of a denoising step (include/diffsal.h): s_low [N,h,w,1] sigmoid map, x [N,1,H,W] sampler state ->
+    (m, x_next, x0) with x0 = resize(s_low), m = ex x + e0 x0, x_next = A x + c0 m + c1 m_prev."""
+    lib = _lib.load()
+    N, h, w = s_low.shape[0], s_low.shape[1], s_low.shape[2]
+    H, W = x.shape[-2], x.shape[-1]
+    m = torch.empty_like(x)
+    xn = torch.empty_like(x) if want_next else None
+    x0 = torch.empty_like(x) if want_x0 else None
+    with _prof("K15", 0.0, _nb(s_low, x, m_prev, m, xn, x0)):
+        _lib.check(lib.diffsal_resize_update(_p(s_low), _p(x), _p(m_prev), _p(x0), _p(m), _p(xn), N, h, w, H, W, float(ex), float(e0),
+                                             float(A), float(c0), float(c1), _stream()), "resize_update")
+    return m, xn, x0

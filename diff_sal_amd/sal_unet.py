@@ -398,8 +398,30 @@ class SalUNet(nn.Module):
         with ops.gemm_precision(self.gemm_precision):
             return self._forward_eval(x, t, feat_list, audio_feat_list, taps)
 
+    def forward_fused_update(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor], *,
+                             ex: float, e0: float, A: float, c0: float, c1: float = 0.0, m_prev: Optional[Tensor] = None):
+        """One evaluation whose last kernel also does the solver's work: returns (m, x_next) with
+        x0 = the network output, m = ex x + e0 x0 (the wrapper's x_start -> noise conversion), x_next = A x + c0 m + c1 m_prev
+        (the multistep update).  Eval mode only; bit-equal to forward() followed by the stand-alone sampler kernels."""
+        if self.training:
+            raise RuntimeError("forward_fused_update is an inference path")
+        if not x.is_cuda:
+            raise RuntimeError("diff_sal_amd.SalUNet runs on the GPU only (no CPU fallback); got a CPU tensor")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        ms, xs = [], []
+        with ops.gemm_precision(self.gemm_precision):
+            for s in range(0, B, self.max_clips_per_pass):
+                e = min(B, s + self.max_clips_per_pass)
+                low = self._forward_eval(x[s:e], t[s:e], [f[s:e] for f in feat_list],
+                                         None if audio_feat_list is None else audio_feat_list[s:e], None, lowres=True)
+                m, xn, _ = ops.resize_update(low, x[s:e], None if m_prev is None else m_prev[s:e].contiguous(), ex, e0, A, c0, c1)
+                ms.append(m)
+                xs.append(xn)
+        return (ms[0], xs[0]) if len(ms) == 1 else (torch.cat(ms), torch.cat(xs))
+
     def _forward_eval(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor],
-                      taps: Optional[dict]) -> Tensor:
+                      taps: Optional[dict], lowres: bool = False) -> Tensor:
         pk = self.packed()
         cdt = self.compute_dtype
         x = x.contiguous().float()
@@ -469,6 +491,8 @@ class SalUNet(nn.Module):
         y = ops.conv_igemm(acc, pk["mt.w"], kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, scale=pk["mt.scale"],
                            shift=pk["mt.shift"], act=ACT_RELU, tag="K14")
         s = ops.head_sigmoid(y, pk["head.w"], self.logits.linear_pred.bias)
+        if lowres:                       # the caller fuses the final resize with the solver update
+            return s
         out = ops.resize_bilinear(s, self.img_size[0], self.img_size[1], tag="K14-head")
         return out.view(B, 1, self.img_size[0], self.img_size[1])
 

@@ -28,7 +28,7 @@ class DiffusionSampler:
                  num_diffusion_timesteps=1000, training_target="x0", sample_type="ddim", timesteps=1, eta=0.0,
                  skip_type="logSNR", dpm_solver_order=2, dpm_solver_method="multistep", dpm_solver_type="dpmsolver",
                  lower_order_final=False, denoise=True, thresholding=False, device=None, hip_graph=False,
-                 step_invariant_shortcut=False):
+                 step_invariant_shortcut=False, fused_update=True):
         """``model`` exposes ``decoder_net`` and optionally ``visual_net`` / ``audio_net`` / ``forward_vggish``
         (a ``VideoSaliencyModel``; a DDP/DataParallel wrapper is unwrapped through ``.module``).
         Keyword names = the YAML fields the trainer reads (R/cfgs/diffusion.yml:24-28, 37, 63-78)."""
@@ -66,6 +66,9 @@ class DiffusionSampler:
         #    trajectory returns the same x0 and the sample equals ONE network evaluation.
         self.hip_graph = bool(hip_graph)
         self.step_invariant_shortcut = bool(step_invariant_shortcut)
+        #  fused_update (ON by default: same arithmetic, bit-equal results): the DPM-Solver branch folds each step's final
+        #    resize + x0->noise conversion + multistep update into the denoiser's last kernel (SalUNet.forward_fused_update).
+        self.fused_update = bool(fused_update)
         if self.step_invariant_shortcut:
             self._check_shortcut_precondition()
         self._graphs = {}
@@ -149,7 +152,7 @@ class DiffusionSampler:
         epoch = net.pack_epoch() if hasattr(net, "pack_epoch") else None
         return (epoch, bool(getattr(net, "training", False)), self.sample_type, self.timesteps, self.eta, self.skip_type,
                 self.dpm_solver_order, self.dpm_solver_method, self.dpm_solver_type, self.lower_order_final, self.denoise,
-                self.thresholding, self.training_target)
+                self.thresholding, self.training_target, self.fused_update)
 
     def _graphed(self, fn, x, img, audio_cond):
         """Replay (capturing on first use) ``fn(x, img, audio_cond)`` as one HIP graph per input signature; a graph is
@@ -224,7 +227,47 @@ class DiffusionSampler:
             return self._graphed(self._sample_dpm_solver, x, img, audio_cond)
         return self._sample_dpm_solver(x, img, audio_cond)
 
+    def _fusable(self, x) -> bool:
+        """The fused step tail (SalUNet.forward_fused_update) applies when the denoiser is ours in eval mode, predicts x0,
+        and the solver is the multistep noise-prediction DPM-Solver of order <= 2 without thresholding -- the shipped
+        configuration (R/cfgs/diffusion.yml:63-78 with sample_type dpmsolver)."""
+        net = self.model.decoder_net
+        return (self.fused_update and hasattr(net, "forward_fused_update") and not net.training and x.is_cuda
+                and self.training_target == "x0" and self.sample_type == "dpmsolver" and self.dpm_solver_method == "multistep"
+                and self.dpm_solver_order <= 2 and not self.thresholding and self.dpm_solver_type in ("dpmsolver", "taylor"))
+
+    def _sample_dpm_solver_fused(self, x, img, audio_cond):
+        """Same trajectory as DPM_Solver.sample (dpm_solver.py), driven from its precomputed coefficient table, with every
+        step's tail -- final resize, x0 -> noise conversion, multistep update -- folded into the network's last kernel:
+        a denoising step is then "one SalUNet evaluation", nothing else (two elementwise launches fewer per step)."""
+        net = self.model.decoder_net
+        ns = NoiseScheduleVP(schedule="discrete", betas=self.betas)
+        solver = DPM_Solver(lambda *a, **k: None, ns, algorithm_type=self.sample_type)
+        steps = self.timesteps - 1 if self.denoise else self.timesteps
+        times, table, t_0 = solver.plan(steps, self.dpm_solver_order, self.skip_type, None, None, self.lower_order_final,
+                                        self.dpm_solver_type)
+        n = x.shape[0]
+        m_prev = None
+        for s in range(steps):
+            tc = times[s].reshape(1)
+            alpha, sigma = float(ns.marginal_alpha(tc)), float(ns.marginal_std(tc))
+            t_in = torch.full((n,), (float(times[s]) - 1.0 / ns.total_N) * 1000.0, dtype=torch.float32, device=x.device)
+            A, coeffs = table[s]
+            m, x = net.forward_fused_update(x, t_in, img, audio_cond, ex=1.0 / sigma, e0=-alpha / sigma, A=A, c0=coeffs[0],
+                                            c1=coeffs[1] if len(coeffs) > 1 else 0.0,
+                                            m_prev=m_prev if len(coeffs) > 1 else None)
+            m_prev = m
+        if self.denoise:                                  # denoise_to_zero_fn: data prediction at t_0 (sampler.py:542)
+            tc = torch.ones((1,)) * t_0
+            alpha, sigma = float(ns.marginal_alpha(tc)), float(ns.marginal_std(tc))
+            t_in = torch.full((n,), (t_0 - 1.0 / ns.total_N) * 1000.0, dtype=torch.float32, device=x.device)
+            noise = _lincomb(x, 1.0 / sigma, net(x, t_in, img, audio_cond), -alpha / sigma)
+            x = _lincomb(x, 1.0 / alpha, noise, -sigma / alpha)
+        return x
+
     def _sample_dpm_solver(self, x, img, audio_cond):
+        if self._fusable(x):
+            return self._sample_dpm_solver_fused(x, img, audio_cond)
         net = self.model.decoder_net
 
         def model_fn(x, t, vis_feat, **kw):

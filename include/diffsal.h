@@ -352,6 +352,17 @@ int diffsal_saliency_metrics(const float* pred, const float* gt, int B, long n, 
 int diffsal_axpbypcz(const float* x, const float* y, const float* z, float a, float b, float c, float* out,
                      size_t n, diffsal_stream_t stream);
 
+/* ---- K14 tail + K15 fused: the end of a denoising step in one pass over the sampler state.
+ *   x0 = bilinear(s_low [N,h,w] -> [N,H,W])          final resize of the sigmoid map, R/.../sal_unet.py:325-327
+ *   m  = ex * x + e0 * x0                            wrapper's model-output conversion (x_start -> noise:
+ *                                                    ex = 1/sigma_t, e0 = -alpha_t/sigma_t, R/models/dpm_solver/sampler.py:286-292;
+ *                                                    ex = 0, e0 = 1 keeps x0)
+ *   x_next = A * x + c0 * m + c1 * m_prev            multistep update, sampler.py:548-593, 797-853 (m_prev NULL: order 1)
+ * x0_out and x_next may be NULL.  Same per-element arithmetic as diffsal_resize_bilinear + diffsal_axpbypcz (bit-equal). */
+int diffsal_resize_update(const float* s_low, const float* x, const float* m_prev, float* x0_out, float* m_out, float* x_next,
+                          int N, int h, int w, int H, int W, float ex, float e0, float A, float c0, float c1,
+                          diffsal_stream_t stream);
+
 /* ---- K16 tail: loss, gradient clipping and the optimizer, on flat fp32 buffers -------------
  * diffsal_reduce_blocks(): number of doubles the `part` scratch of the two reductions below must hold.
  *

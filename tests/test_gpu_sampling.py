@@ -157,3 +157,33 @@ def test_hip_graph_is_recaptured_after_parameters_or_hyperparameters_change():
     net.gemm_precision = "bf16x3"
     assert torch.equal(g.sample_ddim(xd, fd, ad), plain.sample_ddim(xd, fd, ad))
     net.gemm_precision = None
+
+
+def test_fused_step_tail_is_bit_equal_to_the_plain_solver_loop(golden_dir, tiny):
+    """final resize + x0->noise conversion + multistep update folded into the denoiser's last kernel.
+    Same arithmetic per element as the stand-alone kernels: identical trajectories, and both match the reference's."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    top, x, feats, audio = tiny
+    kw = dict(timesteps=50, sample_type="dpmsolver", skip_type="logSNR", denoise=True)
+    fused = DiffusionSampler(top, fused_update=True, **kw)
+    plain = DiffusionSampler(top, fused_update=False, **kw)
+    assert fused._fusable(x) and not plain._fusable(x)
+    a, b = fused.sample_dpm_solver(x, feats, audio), plain.sample_dpm_solver(x, feats, audio)
+    assert torch.equal(a, b)
+    ref = torch.from_numpy(np.load(f"{golden_dir}/dpm50_tiny_av.npz")["output"])
+    assert (a.cpu() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+    # few steps + lower_order_final + time_uniform grid + batch > 1, visual-only
+    x2 = torch.cat([x, 0.5 * x])
+    f2 = [torch.cat([f, f.flip(2)]) for f in feats]
+    kw2 = dict(timesteps=7, sample_type="dpmsolver", skip_type="time_uniform", denoise=False, lower_order_final=True)
+    assert torch.equal(DiffusionSampler(top, fused_update=True, **kw2).sample_dpm_solver(x2, f2, None),
+                       DiffusionSampler(top, fused_update=False, **kw2).sample_dpm_solver(x2, f2, None))
+    # the ops it replaces, directly
+    from diff_sal_amd import ops
+    s_low = torch.rand(2, 32, 64, 1, device=DEV)
+    xs, mp = torch.randn(2, 1, 64, 128, device=DEV), torch.randn(2, 1, 64, 128, device=DEV)
+    m, xn, x0 = ops.resize_update(s_low, xs, mp, 1.7, -0.6, 0.9, -0.3, 0.2, want_x0=True)
+    x0_ref = ops.resize_bilinear(s_low, 64, 128).view(2, 1, 64, 128)
+    m_ref = ops.axpbypcz(xs, 1.7, x0_ref, -0.6)
+    assert torch.equal(x0, x0_ref) and torch.equal(m, m_ref) and torch.equal(xn, ops.axpbypcz(xs, 0.9, m_ref, -0.3, mp, 0.2))
