@@ -356,11 +356,27 @@ def main():
         return inner(x, t, f, a)
 
     net.forward = counted
+    inner_fused = net.forward_fused_update
+
+    def counted_fused(x, t, f, a=None, **kw):
+        """the sampler's fused step (network evaluation + solver update in one call) counts as one step, like `counted`"""
+        if state["budget"] <= 0:
+            raise _Stop
+        state["budget"] -= 1
+        if state["budget"] == 0 and state["profile_last"]:
+            ops.PROFILE = []
+            try:
+                return inner_fused(x, t, f, a, **kw)
+            finally:
+                state["events"], ops.PROFILE = ops.PROFILE, None
+        return inner_fused(x, t, f, a, **kw)
+
+    net.forward_fused_update = counted_fused
 
     special = args.sampler_mode != "eager"
     if special:
         assert args.steps % NFE_PER_TRAJECTORY == 0, "graph / f1 modes time whole 50-NFE trajectories"
-        net.forward = inner
+        net.forward, net.forward_fused_update = inner, inner_fused
         sampler.hip_graph = args.sampler_mode == "graph"
         sampler.step_invariant_shortcut = args.sampler_mode == "f1"
 
@@ -510,7 +526,7 @@ def main():
             # a HIP graph (same kernels, same order; the sampler's optional mode)
             graph = None
             if mode in STORAGE and args.steps >= NFE_PER_TRAJECTORY:
-                net.forward = inner
+                net.forward, net.forward_fused_update = inner, inner_fused
                 gs = DiffusionSampler(Top(net), timesteps=NFE_PER_TRAJECTORY, sample_type="dpmsolver", skip_type="logSNR",
                                       denoise=True, training_target="x0", hip_graph=True)
                 gs.sample_dpm_solver(x_T, feats, audio)
@@ -524,7 +540,7 @@ def main():
                 graph = {"value": round(B * ntraj * NFE_PER_TRAJECTORY / g_el, 3), "unit": "denoise-steps/s",
                          "ms_per_step": round(g_el / (ntraj * NFE_PER_TRAJECTORY) * 1e3, 4),
                          "note": "whole 50-NFE trajectories replayed from one HIP graph"}
-                net.forward = counted
+                net.forward, net.forward_fused_update = counted, counted_fused
             alts.append({"mode": mode, "what": desc, "value": round(B * args.steps / a_el, 3), "unit": "denoise-steps/s",
                          "ms_per_step": round(a_el / args.steps * 1e3, 4), "speedup_vs_headline": round(elapsed / a_el, 3),
                          "hip_graph": graph,

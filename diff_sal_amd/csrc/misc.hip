@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // bilinear resize (align_corners=False) on NHWC.  R/.../common_block.py:197; sal_unet.py:325-327,482-484
 // ------------------------------------------------------------------------------------------------
+// One bilinear blend with a fixed operation order (explicit FMAs): shared by the stand-alone single-channel resize and
+// the fused step tail so that the two produce identical bits.
+__device__ __forceinline__ float bilerp_w(float v00, float v01, float v10, float v11, float hx, float lx, float hy, float ly) {
+  const float top = fmaf(lx, v01, hx * v00);
+  const float bot = fmaf(lx, v11, hx * v10);
+  return fmaf(ly, bot, hy * top);
+}
+
 template <int VEC, typename T>
 __global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int h,
                                                      int w, int H, int W, int C, float sy, float sx) {
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T
     } else {
       const float v00 = static_cast<float>(b[(static_cast<long>(y0) * w + x0) * C]), v01 = static_cast<float>(b[(static_cast<long>(y0) * w + x1) * C]);
       const float v10 = static_cast<float>(b[(static_cast<long>(y1) * w + x0) * C]), v11 = static_cast<float>(b[(static_cast<long>(y1) * w + x1) * C]);
-      out[o] = static_cast<T>(hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));   // == bilerp1 for C = 1
+      out[o] = static_cast<T>(bilerp_w(v00, v01, v10, v11, hx, lx, hy, ly));   // == bilerp1 for C = 1
     }
   }
 }
@@ -510,7 +518,7 @@ __device__ __forceinline__ float bilerp1(const float* __restrict__ img, int h, i
   const float hy = 1.f - ly, hx = 1.f - lx;
   const float v00 = img[static_cast<long>(y0) * w + x0], v01 = img[static_cast<long>(y0) * w + x1];
   const float v10 = img[static_cast<long>(y1) * w + x0], v11 = img[static_cast<long>(y1) * w + x1];
-  return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  return bilerp_w(v00, v01, v10, v11, hx, lx, hy, ly);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -251,7 +251,8 @@ class DiffusionSampler:
         for s in range(steps):
             tc = times[s].reshape(1)
             alpha, sigma = float(ns.marginal_alpha(tc)), float(ns.marginal_std(tc))
-            t_in = torch.full((n,), (float(times[s]) - 1.0 / ns.total_N) * 1000.0, dtype=torch.float32, device=x.device)
+            # network time exactly as model_wrapper computes it: fp32 tensor arithmetic on the host, then a device fill
+            t_in = torch.full((n,), float((tc - 1.0 / ns.total_N) * 1000.0), dtype=torch.float32, device=x.device)
             A, coeffs = table[s]
             m, x = net.forward_fused_update(x, t_in, img, audio_cond, ex=1.0 / sigma, e0=-alpha / sigma, A=A, c0=coeffs[0],
                                             c1=coeffs[1] if len(coeffs) > 1 else 0.0,
@@ -260,7 +261,7 @@ class DiffusionSampler:
         if self.denoise:                                  # denoise_to_zero_fn: data prediction at t_0 (sampler.py:542)
             tc = torch.ones((1,)) * t_0
             alpha, sigma = float(ns.marginal_alpha(tc)), float(ns.marginal_std(tc))
-            t_in = torch.full((n,), (t_0 - 1.0 / ns.total_N) * 1000.0, dtype=torch.float32, device=x.device)
+            t_in = torch.full((n,), float((tc - 1.0 / ns.total_N) * 1000.0), dtype=torch.float32, device=x.device)
             noise = _lincomb(x, 1.0 / sigma, net(x, t_in, img, audio_cond), -alpha / sigma)
             x = _lincomb(x, 1.0 / alpha, noise, -sigma / alpha)
         return x
