@@ -291,6 +291,8 @@ def main():
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra reduced-precision passes reported beside the headline")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of exactly --steps steps each; the reported value is their median (SURVEY 8d)")
+    ap.add_argument("--dump-launches", default=None,
+                    help="write every operator launch of the profiled step (class, GFLOP, MB, us, TF/s, GB/s) to this JSON file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoders", action="store_true", help="skip the end-to-end (encoders + 50 steps) leg")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -428,6 +430,13 @@ def main():
     k_flops = sum(e[2] for e in ev)
     n_launch = max(len(ev), 1)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    if args.dump_launches and rank == 0:
+        rows = []
+        for e0, e1, fl, cls, nb in all_ev:
+            us = e0.elapsed_time(e1) * 1e3
+            rows.append({"class": cls, "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3), "us": round(us, 2),
+                         "tflops": round(fl / us / 1e6, 2) if us > 0 else 0.0, "gbs": round(nb / us / 1e3, 1) if us > 0 else 0.0})
+        json.dump({"precision": args.precision, "mode": args.mode, "batch": B, "launches": rows}, open(args.dump_launches, "w"), indent=0)
     peak_for_mode = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
     traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", f"r02_igemm_hbm_traffic_{args.precision}.json")

@@ -45,8 +45,28 @@ class Transformer(nn.Module):
         self.layers = nn.ModuleList([nn.ModuleList([_Attention(dim, heads, dim_head, dropout), _FeedForward(dim, mlp_dim, dropout)])
                                      for _ in range(depth)])
 
+    def forward_train(self, x: Tensor) -> Tensor:
+        """Same graph on the autograd tape, HIP forward and backward per operator (the reference trains this module:
+        spatiotemp_net has requires_grad parameters, R/models/diff_model.py:76-78)."""
+        from . import autograd_ops as ag
+        from . import encoder_autograd as eg
+
+        B, N, dim = x.shape
+        for attn, ff in self.layers:
+            xn = ag.layernorm(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
+            qkv = ag.linear(xn, attn.to_qkv.weight, None).view(B, N, 3, attn.heads, attn.dim_head)
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous() for i in range(3))   # head-major copies (layout plumbing)
+            o = eg.attention_general(q, k, v, scale=attn.scale)
+            x = ag.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=x) if attn.project_out else ag.add(o, x)
+            y = ag.layernorm(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
+            h = ag.gelu(ag.linear(y, ff.net[1].weight, ff.net[1].bias))
+            x = ag.linear(h, ff.net[4].weight, ff.net[4].bias, residual=x)
+        return ag.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+
     def forward(self, x: Tensor) -> Tensor:
         """x [B, N, dim] -> [B, N, dim]  (R/models/audio_attention.py:63-90)."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_train(x)
         B, N, dim = x.shape
         for attn, ff in self.layers:
             xn = ops.layernorm(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
@@ -88,6 +108,10 @@ class AudioAttnNet(nn.Module):
             raise RuntimeError("diff_sal_amd.AudioAttnNet runs on the GPU only (no CPU fallback); got a CPU tensor")
         b, c, t, h, w = audio.shape
         self._check_frames(t)
+        if torch.is_grad_enabled() and (audio.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import encoder_autograd as eg
+
+            return eg.tokens_to_channels_first(self.forward_tokens(eg.pack_tokens(audio.float())), 0).view(b, c, t, h, w)
         tok = ops.pack_frames(audio.contiguous().float(), None).view(b, t * h * w, c)      # b c t h w -> b (t h w) c
         out = self.forward_tokens(tok)
         return ops.tokens_to_channels_first(out, 0).view(b, c, t, h, w)

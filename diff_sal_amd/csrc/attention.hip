@@ -33,6 +33,7 @@ struct AttnArgs {
   const float* v;
   const float* residual; // same indexing as q, or null
   float* out;            // [B, Lq, H*DV]
+  float* lse;            // [B,H,Lq] log-sum-exp of every row (training: the backward recomputes P from it), or null
   long q_sb, q_sh, q_sl;  // element strides of q (batch, head, row)
   long k_sb, k_sh, k_sl;
   long v_sb, v_sh, v_sl;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
   // ---- finish: out[q][d] = O^T[d][q] / l (+ residual); this lane holds d = 32 t + 4 hf + (r & 3) + 8 (r >> 2)
   const float l_tot = l_run + __shfl_xor(l_run, 32, kWave);
   const float inv = 1.0f / l_tot;
+  if (p.lse && qi < p.Lq && hf == 0) p.lse[static_cast<long>(bh) * p.Lq + qi] = m_run + logf(l_tot);
   if (qi < p.Lq) {
     float* orow = p.out + (static_cast<long>(b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV;
     const bool add_res = p.residual && !(p.skip_first && qi == 0);
@@ -210,12 +212,389 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
   }
 }
 
+// =================================================================================================================
+// Backward of the attention above (training of the encoders).  Flash-style: P is recomputed from the
+// saved row log-sum-exp; delta[q] = sum_d dO[q,d] * O_attn[q,d] (O_attn = out - residual) comes from a small pre-pass.
+//   dS = P * (dP - delta),  dP = dO V^T
+//   dq = scale * dS K (+ dO on residual rows),  dq_extra = dS k_extra,  dK = scale-folded dS^T Q',  dV = P^T dO
+// Two kernels, both in the transposed one-lane-one-row formulation of the forward:
+//   attention_bwd_q_kernel : a wavefront owns 32 queries, loops over key tiles   -> dq, dq_extra
+//   attention_bwd_kv_kernel: a wavefront owns 32 keys,    loops over query tiles -> dk, dv
+// No atomics; every output element is produced by exactly one lane (deterministic).
+// =================================================================================================================
+struct AttnBwdArgs {
+  const float* q; const float* q_extra; const float* k; const float* k_extra; const float* v;
+  const float* dout;     // [B, Lq, H*DV]
+  const float* out;      // forward output (same layout as dout)
+  const float* residual; // forward residual or null
+  const float* lse;      // [B,H,Lq]
+  float* delta;          // [B,H,Lq] scratch
+  float* dq;             // [B,H,Lq,D] contiguous
+  float* dq_extra;       // [B,H,Lq,E] contiguous or null
+  float* dk;             // [B,H,Lk,D] contiguous
+  float* dv;             // [B,H,Lk,DV] contiguous
+  long q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, r_sb, r_sh, r_sl;
+  int H, Lq, Lk;
+  float scale;
+  int skip_first;
+};
+
+// delta[b,h,l] = sum_d dout[b,l,h*DV+d] * (out[b,l,h*DV+d] - residual[b,h,l,d]); G lanes per row.
+template <int DV>
+__global__ __launch_bounds__(256) void attention_bwd_delta_kernel(AttnBwdArgs p, long rows) {
+  constexpr int G = 8;
+  const int gl = threadIdx.x % G;
+  const long row = static_cast<long>(blockIdx.x) * (256 / G) + threadIdx.x / G;
+  const bool live = row < rows;
+  const long rc = live ? row : rows - 1;
+  const int l = static_cast<int>(rc % p.Lq);
+  const long bh = rc / p.Lq;
+  const int h = static_cast<int>(bh % p.H), b = static_cast<int>(bh / p.H);
+  const long o = (static_cast<long>(b) * p.Lq + l) * (static_cast<long>(p.H) * DV) + h * DV;
+  const bool has_res = p.residual && !(p.skip_first && l == 0);
+  const float* rr = p.residual ? p.residual + b * p.r_sb + h * p.r_sh + static_cast<long>(l) * p.r_sl : nullptr;
+  float s = 0.f;
+  for (int d = gl * 4; d < DV; d += G * 4) {
+    const float4 g = ld4(p.dout + o + d);
+    float4 y = ld4(p.out + o + d);
+    if (has_res) { const float4 r4 = ld4(rr + d); y.x -= r4.x; y.y -= r4.y; y.z -= r4.z; y.w -= r4.w; }
+    s += (g.x * y.x + g.y * y.y) + (g.z * y.z + g.w * y.w);
+  }
+  s = group_sum<G>(s);
+  if (live && gl == 0) p.delta[rc] = s;
+}
+
+template <int D, int E, int DV>
+__global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
+  constexpr int DQ = D + E;
+  constexpr int HQ = DQ / 2, HV = DV / 2;
+  constexpr int NQT = (DQ + 31) / 32;            // output tiles of dQ'^T (rows = contraction index of QK^T)
+  constexpr int KP = NQT * 32 + 4;               // K' rows padded with zeros up to a whole tile
+  constexpr int VP = DV + 4;
+  __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * VP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int ql = lane & 31, hf = lane >> 5;
+  const int qi = blockIdx.x * 128 + wave * 32 + ql;
+  const int qc = qi < p.Lq ? qi : p.Lq - 1;
+
+  float qf[HQ], gf[HV];   // this lane's halves of [q*scale | q_extra] and of dO
+  {
+    const float* qr = p.q + b * p.q_sb + h * p.q_sh + static_cast<long>(qc) * p.q_sl;
+    const float* qe = E ? p.q_extra + (static_cast<long>(bh) * p.Lq + qc) * E : nullptr;
+#pragma unroll
+    for (int j4 = 0; j4 < HQ / 4; ++j4) {
+      const int e0 = hf * HQ + j4 * 4;
+      float4 t;
+      if (e0 < D) { t = ld4(qr + e0); t.x *= p.scale; t.y *= p.scale; t.z *= p.scale; t.w *= p.scale; }
+      else t = ld4(qe + (e0 - D));
+      qf[j4 * 4 + 0] = t.x; qf[j4 * 4 + 1] = t.y; qf[j4 * 4 + 2] = t.z; qf[j4 * 4 + 3] = t.w;
+    }
+    const float* gr = p.dout + (static_cast<long>(b) * p.Lq + qc) * (static_cast<long>(p.H) * DV) + h * DV + hf * HV;
+#pragma unroll
+    for (int j4 = 0; j4 < HV / 4; ++j4) {
+      const float4 t = ld4(gr + j4 * 4);
+      gf[j4 * 4 + 0] = t.x; gf[j4 * 4 + 1] = t.y; gf[j4 * 4 + 2] = t.z; gf[j4 * 4 + 3] = t.w;
+    }
+  }
+  const float lse = p.lse[static_cast<long>(bh) * p.Lq + qc];
+  const float delta = p.delta[static_cast<long>(bh) * p.Lq + qc];
+
+  f32x16 acc[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* kb = p.k + b * p.k_sb + h * p.k_sh;
+  const float* vb = p.v + b * p.v_sb + h * p.v_sh;
+  const int n_tiles = (p.Lk + 31) / 32;
+  constexpr int KC4 = NQT * 8;                                   // float4 pieces per padded K' row
+  constexpr int KF4 = 32 * KC4, VF4 = 32 * DV / 4;
+  constexpr int KPT = (KF4 + 255) / 256, VPT = (VF4 + 255) / 256;
+  float4 kreg[KPT], vreg[VPT];
+  auto fetch = [&](int tile) {
+    const int key0 = tile * 32;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
+      const int key = key0 + row;
+      float4 t = make_float4(0, 0, 0, 0);
+      if (idx < KF4 && key < p.Lk && c4 < DQ) t = c4 < D ? ld4(kb + static_cast<long>(key) * p.k_sl + c4)
+                                                        : ld4(p.k_extra + static_cast<long>(key) * E + (c4 - D));
+      kreg[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
+      const int key = key0 + row;
+      float4 t = make_float4(0, 0, 0, 0);
+      if (idx < VF4 && key < p.Lk) t = ld4(vb + static_cast<long>(key) * p.v_sl + c4);
+      vreg[i] = t;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
+      if (idx < KF4) st4(&Ks[row * KP + c4], kreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
+      if (idx < VF4) st4(&Vs[row * VP + c4], vreg[i]);
+    }
+  };
+  fetch(0);
+  park();
+  __syncthreads();
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    const float* krow = &Ks[ql * KP + hf * HQ];
+#pragma unroll
+    for (int j4 = 0; j4 < HQ / 4; ++j4) {
+      const float4 a = ld4(krow + j4 * 4);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[j4 * 4 + 0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[j4 * 4 + 1], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[j4 * 4 + 2], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[j4 * 4 + 3], s, 0, 0, 0);
+    }
+    const float* vrow = &Vs[ql * VP + hf * HV];                 // dP^T = V dO^T
+#pragma unroll
+    for (int j4 = 0; j4 < HV / 4; ++j4) {
+      const float4 a = ld4(vrow + j4 * 4);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, gf[j4 * 4 + 0], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, gf[j4 * 4 + 1], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, gf[j4 * 4 + 2], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, gf[j4 * 4 + 3], dp, 0, 0, 0);
+    }
+    const int key_base = tile * 32 + hf * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key_base + (r & 3) + 8 * (r >> 2);
+      const float pr = key < p.Lk ? expf(s[r] - lse) : 0.f;
+      s[r] = pr * (dp[r] - delta);                                // dS^T
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                // dQ'^T += K'^T dS^T
+      const int krow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+      for (int t = 0; t < NQT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow_i * KP + t * 32 + ql], s[r], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+    if (tile + 1 < n_tiles) {
+      park();
+      __syncthreads();
+    }
+  }
+  if (qi >= p.Lq) return;
+  // this lane holds contraction rows c = 32 t + 4 hf + (r & 3) + 8 (r >> 2) of its query
+  float* dqr = p.dq + (static_cast<long>(bh) * p.Lq + qi) * D;
+  float* der = E ? p.dq_extra + (static_cast<long>(bh) * p.Lq + qi) * E : nullptr;
+  const bool add_res = p.residual && !(p.skip_first && qi == 0);
+  const float* gres = p.dout + (static_cast<long>(b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV;
+#pragma unroll
+  for (int t = 0; t < NQT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * t + 4 * hf + 8 * g;
+      float4 v4 = make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+      if (c < D) {
+        v4.x *= p.scale; v4.y *= p.scale; v4.z *= p.scale; v4.w *= p.scale;
+        if (add_res) { const float4 r4 = ld4(gres + c); v4.x += r4.x; v4.y += r4.y; v4.z += r4.z; v4.w += r4.w; }
+        st4(dqr + c, v4);
+      } else if (c < DQ) {
+        st4(der + (c - D), v4);
+      }
+    }
+}
+
+template <int D, int E, int DV>
+__global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
+  constexpr int DQ = D + E;
+  constexpr int HQ = DQ / 2, HV = DV / 2;
+  constexpr int NKT = D / 32, NVT = DV / 32;
+  constexpr int QP = DQ + 4, GP = DV + 4;
+  static_assert(D % 32 == 0, "dK tiles");
+  __shared__ __attribute__((aligned(16))) float Qs[32 * QP];    // [q*scale | q_extra] of the current query tile
+  __shared__ __attribute__((aligned(16))) float Gs[32 * GP];    // dO of the current query tile
+  __shared__ float Ls[32], Ds[32];                               // lse, delta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int kl = lane & 31, hf = lane >> 5;
+  const int ki = blockIdx.x * 128 + wave * 32 + kl;
+  const int kc = ki < p.Lk ? ki : p.Lk - 1;
+
+  float kf[HQ], vf[HV];   // this lane's halves of [k | k_extra] and v for its key
+  {
+    const float* kr = p.k + b * p.k_sb + h * p.k_sh + static_cast<long>(kc) * p.k_sl;
+    const float* ke = E ? p.k_extra + static_cast<long>(kc) * E : nullptr;
+#pragma unroll
+    for (int j4 = 0; j4 < HQ / 4; ++j4) {
+      const int e0 = hf * HQ + j4 * 4;
+      const float4 t = e0 < D ? ld4(kr + e0) : ld4(ke + (e0 - D));
+      kf[j4 * 4 + 0] = t.x; kf[j4 * 4 + 1] = t.y; kf[j4 * 4 + 2] = t.z; kf[j4 * 4 + 3] = t.w;
+    }
+    const float* vr = p.v + b * p.v_sb + h * p.v_sh + static_cast<long>(kc) * p.v_sl + hf * HV;
+#pragma unroll
+    for (int j4 = 0; j4 < HV / 4; ++j4) {
+      const float4 t = ld4(vr + j4 * 4);
+      vf[j4 * 4 + 0] = t.x; vf[j4 * 4 + 1] = t.y; vf[j4 * 4 + 2] = t.z; vf[j4 * 4 + 3] = t.w;
+    }
+  }
+  f32x16 ak[NKT], av[NVT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ak[t][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NVT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) av[t][r] = 0.f;
+
+  const float* qb = p.q + b * p.q_sb + h * p.q_sh;
+  const int n_tiles = (p.Lq + 31) / 32;
+  constexpr int QF4 = 32 * DQ / 4, GF4 = 32 * DV / 4;
+  constexpr int QPT = (QF4 + 255) / 256, GPT = (GF4 + 255) / 256;
+  float4 qreg[QPT], greg[GPT];
+  float lreg = 0.f, dreg = 0.f;
+  auto fetch = [&](int tile) {
+    const int q0 = tile * 32;
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
+      const int qq = q0 + row;
+      float4 t = make_float4(0, 0, 0, 0);
+      if (idx < QF4 && qq < p.Lq) {
+        if (c4 < D) { t = ld4(qb + static_cast<long>(qq) * p.q_sl + c4); t.x *= p.scale; t.y *= p.scale; t.z *= p.scale; t.w *= p.scale; }
+        else t = ld4(p.q_extra + (static_cast<long>(bh) * p.Lq + qq) * E + (c4 - D));
+      }
+      qreg[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
+      const int qq = q0 + row;
+      float4 t = make_float4(0, 0, 0, 0);
+      if (idx < GF4 && qq < p.Lq) t = ld4(p.dout + (static_cast<long>(b) * p.Lq + qq) * (static_cast<long>(p.H) * DV) + h * DV + c4);
+      greg[i] = t;
+    }
+    if (tid < 32) {
+      const int qq = q0 + tid;
+      lreg = qq < p.Lq ? p.lse[static_cast<long>(bh) * p.Lq + qq] : 3.0e38f;   // exp(s - huge) = 0 for rows past the end
+      dreg = qq < p.Lq ? p.delta[static_cast<long>(bh) * p.Lq + qq] : 0.f;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
+      if (idx < QF4) st4(&Qs[row * QP + c4], qreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
+      if (idx < GF4) st4(&Gs[row * GP + c4], greg[i]);
+    }
+    if (tid < 32) { Ls[tid] = lreg; Ds[tid] = dreg; }
+  };
+  fetch(0);
+  park();
+  __syncthreads();
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+    // S = Q' K'^T (rows = queries, column = this lane's key):  A = Q'[query = lane & 31][hf*HQ + j], B = kf[j]
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    const float* qrow = &Qs[kl * QP + hf * HQ];
+#pragma unroll
+    for (int j4 = 0; j4 < HQ / 4; ++j4) {
+      const float4 a = ld4(qrow + j4 * 4);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kf[j4 * 4 + 0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kf[j4 * 4 + 1], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kf[j4 * 4 + 2], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kf[j4 * 4 + 3], s, 0, 0, 0);
+    }
+    const float* grow = &Gs[kl * GP + hf * HV];                  // dP = dO V^T
+#pragma unroll
+    for (int j4 = 0; j4 < HV / 4; ++j4) {
+      const float4 a = ld4(grow + j4 * 4);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, vf[j4 * 4 + 0], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, vf[j4 * 4 + 1], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, vf[j4 * 4 + 2], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, vf[j4 * 4 + 3], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
+      const float pr = expf(s[r] - Ls[qrow_i]);
+      s[r] = pr;                                                 // P
+      dp[r] = pr * (dp[r] - Ds[qrow_i]);                         // dS
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+      for (int t = 0; t < NVT; ++t)                              // dV^T += dO^T P
+        av[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[qrow_i * GP + t * 32 + kl], s[r], av[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)                              // dK^T += (scale q)^T dS
+        ak[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qrow_i * QP + t * 32 + kl], dp[r], ak[t], 0, 0, 0);
+    }
+    __syncthreads();
+    if (tile + 1 < n_tiles) {
+      park();
+      __syncthreads();
+    }
+  }
+  if (ki >= p.Lk) return;
+  float* dkr = p.dk + (static_cast<long>(bh) * p.Lk + ki) * D;
+  float* dvr = p.dv + (static_cast<long>(bh) * p.Lk + ki) * DV;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      st4(dkr + 32 * t + 4 * hf + 8 * g, make_float4(ak[t][4 * g + 0], ak[t][4 * g + 1], ak[t][4 * g + 2], ak[t][4 * g + 3]));
+#pragma unroll
+  for (int t = 0; t < NVT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      st4(dvr + 32 * t + 4 * hf + 8 * g, make_float4(av[t][4 * g + 0], av[t][4 * g + 1], av[t][4 * g + 2], av[t][4 * g + 3]));
+}
+
+template <int D, int E, int DV>
+static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
+  const long rows = static_cast<long>(B) * a.H * a.Lq;
+  hipLaunchKernelGGL((attention_bwd_delta_kernel<DV>), dim3(static_cast<unsigned>((rows + 31) / 32)), dim3(256), 0, s, a, rows);
+  int rc = check_launch("attention_general_bwd(delta)");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attention_bwd_q_kernel<D, E, DV>), dim3((a.Lq + 127) / 128, B * a.H), dim3(256), 0, s, a);
+  rc = check_launch("attention_general_bwd(dq)");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV>), dim3((a.Lk + 127) / 128, B * a.H), dim3(256), 0, s, a);
+  return check_launch("attention_general_bwd(dk, dv)");
+}
+
 }  // namespace diffsal
 
 using namespace diffsal;
 
 extern "C" int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra,
-                                         const float* v, const float* residual, float* out, int B, int H, int Lq, int Lk,
+                                         const float* v, const float* residual, float* out, float* lse, int B, int H, int Lq, int Lk,
                                          int D, int E, int DV, const long* q_strides, const long* k_strides,
                                          const long* v_strides, const long* r_strides, float scale, int skip_first,
                                          diffsal_stream_t stream) {
@@ -232,7 +611,7 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
     DS_REQUIRE(q_strides[i] % 4 == 0 && k_strides[i] % 4 == 0 && v_strides[i] % 4 == 0 && (!residual || r_strides[i] % 4 == 0),
                DIFFSAL_E_ALIGN, "attention_general: strides must be multiples of 4 elements");
   AttnArgs a;
-  a.q = q; a.q_extra = q_extra; a.k = k; a.k_extra = k_extra; a.v = v; a.residual = residual; a.out = out;
+  a.q = q; a.q_extra = q_extra; a.k = k; a.k_extra = k_extra; a.v = v; a.residual = residual; a.out = out; a.lse = lse;
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
@@ -249,4 +628,34 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
     return DIFFSAL_E_SHAPE;
   }
   return check_launch("attention_general");
+}
+
+extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra,
+                                             const float* v, const float* residual, const float* out, const float* lse,
+                                             const float* dout, float* delta_ws, float* dq, float* dq_extra, float* dk,
+                                             float* dv, int B, int H, int Lq, int Lk, int D, int E, int DV,
+                                             const long* q_strides, const long* k_strides, const long* v_strides,
+                                             const long* r_strides, float scale, int skip_first, diffsal_stream_t stream) {
+  DS_REQUIRE(q && k && v && out && lse && dout && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides,
+             DIFFSAL_E_ARG, "attention_general_bwd: null argument");
+  DS_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && static_cast<long>(B) * H < 65536, DIFFSAL_E_SHAPE,
+             "attention_general_bwd: bad shape");
+  DS_REQUIRE((E == 0) == (q_extra == nullptr) && (E == 0) == (k_extra == nullptr) && (E == 0) == (dq_extra == nullptr),
+             DIFFSAL_E_ARG, "attention_general_bwd: q_extra / k_extra / dq_extra must be given exactly when E > 0");
+  DS_REQUIRE(!residual || r_strides, DIFFSAL_E_ARG, "attention_general_bwd: residual needs its strides");
+  AttnBwdArgs a;
+  a.q = q; a.q_extra = q_extra; a.k = k; a.k_extra = k_extra; a.v = v; a.dout = dout; a.out = out; a.residual = residual;
+  a.lse = lse; a.delta = delta_ws; a.dq = dq; a.dq_extra = dq_extra; a.dk = dk; a.dv = dv;
+  a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
+  a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
+  a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
+  a.r_sb = residual ? r_strides[0] : 0; a.r_sh = residual ? r_strides[1] : 0; a.r_sl = residual ? r_strides[2] : 0;
+  a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.skip_first = skip_first;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (D == 96 && E == 48 && DV == 96) return launch_attention_bwd<96, 48, 96>(a, B, s);
+  if (D == 96 && E == 0 && DV == 96) return launch_attention_bwd<96, 0, 96>(a, B, s);
+  if (D == 64 && E == 0 && DV == 64) return launch_attention_bwd<64, 0, 64>(a, B, s);
+  if (D == 32 && E == 0 && DV == 32) return launch_attention_bwd<32, 0, 32>(a, B, s);
+  set_error("attention_general_bwd: (D, E, DV) = (%d, %d, %d) is not built", D, E, DV);
+  return DIFFSAL_E_SHAPE;
 }

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void pool3d_ln_kernel(const float* __restrict_
         }
       }
     }
+    if (gamma == nullptr) {          // training path: convolution only, LayerNorm is its own differentiable operator
+      if (act) st4(out + row * D + c, acc);
+      continue;
+    }
     // LayerNorm over D (two-pass in registers, lane group butterfly)
     float s = act ? (acc.x + acc.y) + (acc.z + acc.w) : 0.f;
     s = group_sum<G>(s);
@@ -218,6 +222,258 @@ __global__ __launch_bounds__(256) void tokens_to_channels_first_kernel(const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the depthwise pooling convolution above (conv-only form).  Gather form, no atomics:
+//   data  : d_in[b, n, head, :] = sum over the taps whose output position exists of dy[out] * w[tap]   (class token: copy)
+//   weight: per-workgroup partial sums part[chunk][27][D] (double), reduced in a fixed order by diffsal_reduce_partials.
+// d_in is written through the same (batch, token) strides as the forward's input view, i.e. straight into the q / k / v
+// slice of the fused-qkv gradient buffer.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void pool3d_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w27,
+                                                              float* __restrict__ din, long in_sb, long in_sn, int heads,
+                                                              int D, int T, int H, int W, int To, int Ho, int Wo, int st,
+                                                              int sh, int sw, long rows) {
+  constexpr int ROWS = 256 / G;
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  const int Li = T * H * W, Lo = To * Ho * Wo;
+  const int c = gl * 4;
+  if (c >= D) return;
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < rows; row += static_cast<long>(gridDim.x) * ROWS) {
+    const int n = static_cast<int>(row % (Li + 1));
+    const long bh = row / (Li + 1);
+    const int head = static_cast<int>(bh % heads);
+    const int b = static_cast<int>(bh / heads);
+    const float* dyb = dy + bh * (Lo + 1) * D + c;
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (n == 0) {
+      acc = ld4(dyb);
+    } else {
+      const int l = n - 1;
+      const int ix = l % W, iy = (l / W) % H, it = l / (W * H);
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const int nt = it + 1 - kt;
+        if (nt < 0 || nt % st != 0 || nt / st >= To) continue;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int ny = iy + 1 - ky;
+          if (ny < 0 || ny % sh != 0 || ny / sh >= Ho) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int nx = ix + 1 - kx;
+            if (nx < 0 || nx % sw != 0 || nx / sw >= Wo) continue;
+            const float4 g = ld4(dyb + (1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw) * D);
+            const float4 ww = ld4(w27 + ((kt * 3 + ky) * 3 + kx) * D + c);
+            acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
+            acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+          }
+        }
+      }
+    }
+    st4(din + b * in_sb + static_cast<long>(n) * in_sn + static_cast<long>(head) * D + c, acc);
+  }
+}
+
+constexpr int POOL_WCHUNKS = 256;
+
+// one workgroup per chunk of output tokens; thread = (tap group, channel quad); LDS tree over the token lanes
+__global__ __launch_bounds__(256) void pool3d_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ dy,
+                                                                double* __restrict__ part, long in_sb, long in_sn, int heads,
+                                                                int D, int T, int H, int W, int To, int Ho, int Wo, int st,
+                                                                int sh, int sw, long rows /* B*heads*Lo video tokens */) {
+  extern __shared__ double shw[];   // [27][D]
+  const int c4n = D >> 2;
+  const int tl = threadIdx.x / c4n, c = (threadIdx.x % c4n) * 4;   // token lane, channel quad
+  const int TL = 256 / c4n;
+  const bool live = tl < TL;
+  const int Lo = To * Ho * Wo;
+  const long lo = rows * blockIdx.x / POOL_WCHUNKS, hi = rows * (blockIdx.x + 1) / POOL_WCHUNKS;
+  float4 acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = make_float4(0, 0, 0, 0);
+  if (live) {
+    for (long r = lo + tl; r < hi; r += TL) {
+      const int l = static_cast<int>(r % Lo);
+      const long bh = r / Lo;
+      const int head = static_cast<int>(bh % heads), b = static_cast<int>(bh / heads);
+      const int wo = l % Wo, ho = (l / Wo) % Ho, to = l / (Wo * Ho);
+      const float4 g = ld4(dy + (bh * (Lo + 1) + 1 + l) * D + c);
+      const float* base = in + b * in_sb + static_cast<long>(head) * D + c;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const int it = to * st - 1 + kt;
+        if (it < 0 || it >= T) continue;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = ho * sh - 1 + ky;
+          if (iy < 0 || iy >= H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = wo * sw - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const float4 a = ld4(base + (1 + (static_cast<long>(it) * H + iy) * W + ix) * in_sn);
+            float4& o = acc[(kt * 3 + ky) * 3 + kx];
+            o.x = fmaf(a.x, g.x, o.x); o.y = fmaf(a.y, g.y, o.y); o.z = fmaf(a.z, g.z, o.z); o.w = fmaf(a.w, g.w, o.w);
+          }
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < 27 * D; i += 256) shw[i] = 0.0;
+  __syncthreads();
+  for (int turn = 0; turn < TL; ++turn) {          // fixed order over the token lanes: deterministic
+    if (live && tl == turn) {
+#pragma unroll
+      for (int i = 0; i < 27; ++i) {
+        shw[i * D + c + 0] += acc[i].x; shw[i * D + c + 1] += acc[i].y;
+        shw[i * D + c + 2] += acc[i].z; shw[i * D + c + 3] += acc[i].w;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 27 * D; i += 256) part[static_cast<long>(blockIdx.x) * 27 * D + i] = shw[i];
+}
+
+// MaxPool of the skip path with the arg-max recorded (training): idx[b, n, c] = input token index (1-based video token,
+// 0 for the class token); ties keep the first window position in (t, y, x) order, as torch.nn.MaxPool3d does.
+__global__ __launch_bounds__(256) void maxpool_tokens_idx_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 int* __restrict__ idx, int C, int T, int H, int W, int To,
+                                                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw,
+                                                                 long total) {
+  const int Lo = To * Ho * Wo, Li = T * H * W;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % C);
+    const long tok = i / C;
+    const int n = static_cast<int>(tok % (Lo + 1));
+    const int b = static_cast<int>(tok / (Lo + 1));
+    const float* ib = in + static_cast<long>(b) * (Li + 1) * C + c;
+    float m;
+    int am = 0;
+    if (n == 0) {
+      m = ib[0];
+    } else {
+      const int l = n - 1;
+      const int wo = l % Wo, ho = (l / Wo) % Ho, to = l / (Wo * Ho);
+      m = -3.0e38f;
+      for (int a = 0; a < kt; ++a) {
+        const int it = to * st - kt / 2 + a;
+        if (it < 0 || it >= T) continue;
+        for (int e = 0; e < kh; ++e) {
+          const int iy = ho * sh - kh / 2 + e;
+          if (iy < 0 || iy >= H) continue;
+          for (int f = 0; f < kw; ++f) {
+            const int ix = wo * sw - kw / 2 + f;
+            if (ix < 0 || ix >= W) continue;
+            const int tokin = 1 + (it * H + iy) * W + ix;
+            const float v = ib[static_cast<long>(tokin) * C];
+            if (v > m) { m = v; am = tokin; }
+          }
+        }
+      }
+    }
+    out[i] = m;
+    idx[i] = am;
+  }
+}
+
+// d_in[b, tok, c] = sum of dy over the (at most kt*kh*kw / stride) outputs whose recorded arg-max is this token
+__global__ __launch_bounds__(256) void maxpool_tokens_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                                 float* __restrict__ din, int C, int T, int H, int W, int To,
+                                                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw,
+                                                                 long total) {
+  const int Lo = To * Ho * Wo, Li = T * H * W;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % C);
+    const long tok = i / C;
+    const int n = static_cast<int>(tok % (Li + 1));
+    const int b = static_cast<int>(tok / (Li + 1));
+    const long ob = static_cast<long>(b) * (Lo + 1) * C + c;
+    float g = 0.f;
+    if (n == 0) {
+      g = dy[ob];
+    } else {
+      const int l = n - 1;
+      const int ix = l % W, iy = (l / W) % H, it = l / (W * H);
+      for (int a = 0; a < kt; ++a) {          // outputs whose window position a covers this input: to*st - kt/2 + a == it
+        const int nt = it + kt / 2 - a;
+        if (nt < 0 || nt % st != 0 || nt / st >= To) continue;
+        for (int e = 0; e < kh; ++e) {
+          const int ny = iy + kh / 2 - e;
+          if (ny < 0 || ny % sh != 0 || ny / sh >= Ho) continue;
+          for (int f = 0; f < kw; ++f) {
+            const int nx = ix + kw / 2 - f;
+            if (nx < 0 || nx % sw != 0 || nx / sw >= Wo) continue;
+            const long o = ob + (1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw) * C;
+            if (idx[o] == n) g += dy[o];
+          }
+        }
+      }
+    }
+    din[i] = g;
+  }
+}
+
+// Backward of relpos_project, query side: dq[row][d] (+)= sum_e dE[row][e] * R_e[d]  (class-token rows: nothing).
+// One wavefront per query, lane = channel (D <= 128: two channels per lane at most).
+__global__ __launch_bounds__(256) void relpos_bwd_q_kernel(const float* __restrict__ dE, const float* __restrict__ Rt,
+                                                           const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                           float* __restrict__ dq, int D, int qt, int qh, int qw, int kt, int kh,
+                                                           int kw, int accumulate, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int L = qt * qh * qw;
+  const int n = static_cast<int>(row % (L + 1));
+  for (int d = lane; d < D; d += 64) {
+    float r = 0.f;
+    if (n > 0) {
+      const int l = n - 1;
+      const int x = l % qw, y = (l / qw) % qh, t = l / (qw * qh);
+      const float* e = dE + row * REL_E;
+      for (int j = 0; j < kt; ++j) r = fmaf(e[REL_T0 + j], Rt[(static_cast<long>(t) * kt + j) * D + d], r);
+      for (int j = 0; j < kh; ++j) r = fmaf(e[REL_H0 + j], Rh[(static_cast<long>(y) * kh + j) * D + d], r);
+      for (int j = 0; j < kw; ++j) r = fmaf(e[REL_W0 + j], Rw[(static_cast<long>(x) * kw + j) * D + d], r);
+    }
+    if (accumulate) dq[row * D + d] += r; else dq[row * D + d] = r;
+  }
+}
+
+// Backward of relpos_project, table side: for axis a in {t, y, x}: dR[i][j][d] = sum over the queries whose coordinate on
+// that axis is i of dE[query][slot0 + j] * q[query][d].  One workgroup per (axis, i); thread = (j, channel quad),
+// sequential fp32 sum over the queries in index order (deterministic).
+__global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __restrict__ dE, const float* __restrict__ q,
+                                                                float* __restrict__ dRt, float* __restrict__ dRh,
+                                                                float* __restrict__ dRw, int BH, int D, int qt, int qh, int qw,
+                                                                int kt, int kh, int kw) {
+  int i = blockIdx.x, axis = 0;
+  if (i >= qt) { i -= qt; axis = 1; }
+  if (axis == 1 && i >= qh) { i -= qh; axis = 2; }
+  const int kk = axis == 0 ? kt : (axis == 1 ? kh : kw);
+  const int slot0 = axis == 0 ? REL_T0 : (axis == 1 ? REL_H0 : REL_W0);
+  float* dR = axis == 0 ? dRt : (axis == 1 ? dRh : dRw);
+  const int c4n = D >> 2;
+  const int L = qt * qh * qw;
+  const int n_a = axis == 0 ? qh * qw : (axis == 1 ? qt * qw : qt * qh);       // queries per image with this coordinate
+  for (int item = threadIdx.x; item < kk * c4n; item += 256) {
+    const int j = item / c4n, c = (item % c4n) * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int bh = 0; bh < BH; ++bh) {
+      for (int m = 0; m < n_a; ++m) {
+        int t, y, x;
+        if (axis == 0) { t = i; y = m / qw; x = m % qw; }
+        else if (axis == 1) { y = i; t = m / qw; x = m % qw; }
+        else { x = i; t = m / qh; y = m % qh; }
+        const long row = static_cast<long>(bh) * (L + 1) + 1 + (static_cast<long>(t) * qh + y) * qw + x;
+        const float e = dE[row * REL_E + slot0 + j];
+        const float4 qv = ld4(q + row * D + c);
+        acc.x = fmaf(e, qv.x, acc.x); acc.y = fmaf(e, qv.y, acc.y); acc.z = fmaf(e, qv.z, acc.z); acc.w = fmaf(e, qv.w, acc.w);
+      }
+    }
+    st4(dR + (static_cast<long>(i) * kk + j) * D + c, acc);
+  }
+}
+
 static int rows_grid(long rows, int per_block) {
   long g = (rows + per_block - 1) / per_block;
   return static_cast<int>(g > 65535 * 16 ? 65535 * 16 : g);
@@ -245,10 +501,10 @@ extern "C" int diffsal_im2col3d(const float* x, float* cols, int B, int C, int T
 extern "C" int diffsal_pool3d_ln(const float* in, const float* w27, const float* gamma, const float* beta, float* out, int B,
                                  int heads, int D, int T, int H, int W, int st, int sh, int sw, long in_stride_b,
                                  long in_stride_n, float eps, diffsal_stream_t stream) {
-  DS_REQUIRE(in && w27 && gamma && beta && out, DIFFSAL_E_ARG, "pool3d_ln: null argument");
+  DS_REQUIRE(in && w27 && out && (gamma == nullptr) == (beta == nullptr), DIFFSAL_E_ARG, "pool3d_ln: null argument");
   DS_REQUIRE(B > 0 && heads > 0 && D > 0 && D % 4 == 0 && D <= 256 && T > 0 && H > 0 && W > 0 && st > 0 && sh > 0 && sw > 0,
              DIFFSAL_E_SHAPE, "pool3d_ln: bad shape D=%d", D);
-  DS_REQUIRE(aligned16(in) && aligned16(out) && aligned16(w27) && aligned16(gamma) && aligned16(beta) &&
+  DS_REQUIRE(aligned16(in) && aligned16(out) && aligned16(w27) && (!gamma || (aligned16(gamma) && aligned16(beta))) &&
                  in_stride_b % 4 == 0 && in_stride_n % 4 == 0,
              DIFFSAL_E_ALIGN, "pool3d_ln: misaligned pointer / stride");
   const int To = (T - 1) / st + 1, Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;   // (X + 2 - 3) / s + 1
@@ -299,4 +555,86 @@ extern "C" int diffsal_tokens_to_channels_first(const float* in, float* out, int
   hipLaunchKernelGGL(tokens_to_channels_first_kernel, dim3(tiles_l * tiles_c, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, out, C, L, off, tiles_l);
   return check_launch("tokens_to_channels_first");
+}
+
+extern "C" int diffsal_pool3d_bwd_data(const float* dy, const float* w27, float* din, int B, int heads, int D, int T, int H,
+                                       int W, int st, int sh, int sw, long in_stride_b, long in_stride_n,
+                                       diffsal_stream_t stream) {
+  DS_REQUIRE(dy && w27 && din, DIFFSAL_E_ARG, "pool3d_bwd_data: null argument");
+  DS_REQUIRE(B > 0 && heads > 0 && D > 0 && D % 4 == 0 && D <= 256 && T > 0 && H > 0 && W > 0 && st > 0 && sh > 0 && sw > 0,
+             DIFFSAL_E_SHAPE, "pool3d_bwd_data: bad shape");
+  DS_REQUIRE(aligned16(dy) && aligned16(w27) && aligned16(din) && in_stride_b % 4 == 0 && in_stride_n % 4 == 0, DIFFSAL_E_ALIGN,
+             "pool3d_bwd_data: misaligned pointer / stride");
+  const int To = (T - 1) / st + 1, Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
+  const long rows = static_cast<long>(B) * heads * (static_cast<long>(T) * H * W + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(G)                                                                                                        \
+  hipLaunchKernelGGL((pool3d_bwd_data_kernel<G>), dim3(rows_grid(rows, 256 / G)), dim3(256), 0, s, dy, w27, din,         \
+                     in_stride_b, in_stride_n, heads, D, T, H, W, To, Ho, Wo, st, sh, sw, rows)
+  if (D <= 32) { CALL(8); } else if (D <= 64) { CALL(16); } else if (D <= 128) { CALL(32); } else { CALL(64); }
+#undef CALL
+  return check_launch("pool3d_bwd_data");
+}
+
+extern "C" int diffsal_pool3d_bwd_weight_chunks(void) { return POOL_WCHUNKS; }
+
+extern "C" int diffsal_pool3d_bwd_weight(const float* in, const float* dy, double* part, int B, int heads, int D, int T, int H,
+                                         int W, int st, int sh, int sw, long in_stride_b, long in_stride_n,
+                                         diffsal_stream_t stream) {
+  DS_REQUIRE(in && dy && part, DIFFSAL_E_ARG, "pool3d_bwd_weight: null argument");
+  DS_REQUIRE(B > 0 && heads > 0 && D > 0 && D % 4 == 0 && D <= 256 && T > 0 && H > 0 && W > 0, DIFFSAL_E_SHAPE,
+             "pool3d_bwd_weight: bad shape");
+  DS_REQUIRE(27 * D * sizeof(double) <= 64 * 1024, DIFFSAL_E_SHAPE, "pool3d_bwd_weight: D=%d too wide", D);
+  const int To = (T - 1) / st + 1, Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
+  const long rows = static_cast<long>(B) * heads * To * Ho * Wo;
+  hipLaunchKernelGGL(pool3d_bwd_weight_kernel, dim3(POOL_WCHUNKS), dim3(256), 27 * D * sizeof(double),
+                     static_cast<hipStream_t>(stream), in, dy, part, in_stride_b, in_stride_n, heads, D, T, H, W, To, Ho, Wo,
+                     st, sh, sw, rows);
+  return check_launch("pool3d_bwd_weight");
+}
+
+extern "C" int diffsal_maxpool_tokens_idx(const float* in, float* out, int* idx, int B, int C, int T, int H, int W, int kt,
+                                          int kh, int kw, int st, int sh, int sw, diffsal_stream_t stream) {
+  DS_REQUIRE(in && out && idx, DIFFSAL_E_ARG, "maxpool_tokens_idx: null argument");
+  DS_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
+             DIFFSAL_E_SHAPE, "maxpool_tokens_idx: bad shape");
+  const int To = (T + 2 * (kt / 2) - kt) / st + 1, Ho = (H + 2 * (kh / 2) - kh) / sh + 1, Wo = (W + 2 * (kw / 2) - kw) / sw + 1;
+  const long total = static_cast<long>(B) * (static_cast<long>(To) * Ho * Wo + 1) * C;
+  long g = (total + 255) / 256;
+  g = g > 32768 ? 32768 : g;
+  hipLaunchKernelGGL(maxpool_tokens_idx_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     out, idx, C, T, H, W, To, Ho, Wo, kt, kh, kw, st, sh, sw, total);
+  return check_launch("maxpool_tokens_idx");
+}
+
+extern "C" int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float* din, int B, int C, int T, int H, int W, int kt,
+                                          int kh, int kw, int st, int sh, int sw, diffsal_stream_t stream) {
+  DS_REQUIRE(dy && idx && din, DIFFSAL_E_ARG, "maxpool_tokens_bwd: null argument");
+  DS_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
+             DIFFSAL_E_SHAPE, "maxpool_tokens_bwd: bad shape");
+  const int To = (T + 2 * (kt / 2) - kt) / st + 1, Ho = (H + 2 * (kh / 2) - kh) / sh + 1, Wo = (W + 2 * (kw / 2) - kw) / sw + 1;
+  const long total = static_cast<long>(B) * (static_cast<long>(T) * H * W + 1) * C;
+  long g = (total + 255) / 256;
+  g = g > 32768 ? 32768 : g;
+  hipLaunchKernelGGL(maxpool_tokens_bwd_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
+                     idx, din, C, T, H, W, To, Ho, Wo, kt, kh, kw, st, sh, sw, total);
+  return check_launch("maxpool_tokens_bwd");
+}
+
+extern "C" int diffsal_relpos_project_bwd(const float* dextra, const float* q, const float* Rt, const float* Rh, const float* Rw,
+                                          float* dq, int accumulate, float* dRt, float* dRh, float* dRw, int BH, int D, int qt,
+                                          int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream) {
+  DS_REQUIRE(dextra && q && Rt && Rh && Rw && dq && dRt && dRh && dRw, DIFFSAL_E_ARG, "relpos_project_bwd: null argument");
+  DS_REQUIRE(BH > 0 && D > 0 && D % 4 == 0 && D <= 1024 && qt > 0 && qh > 0 && qw > 0 && kt > 0 && kt <= REL_H0 - REL_T0 &&
+                 kh > 0 && kh <= REL_W0 - REL_H0 && kw > 0 && kw <= REL_E - REL_W0,
+             DIFFSAL_E_SHAPE, "relpos_project_bwd: bad shape");
+  const long rows = static_cast<long>(BH) * (static_cast<long>(qt) * qh * qw + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(relpos_bwd_q_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, dextra, Rt, Rh, Rw, dq,
+                     D, qt, qh, qw, kt, kh, kw, accumulate, rows);
+  int rc = check_launch("relpos_project_bwd(q)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(relpos_bwd_tables_kernel, dim3(qt + qh + qw), dim3(256), 0, s, dextra, q, dRt, dRh, dRw, BH, D, qt, qh, qw,
+                     kt, kh, kw);
+  return check_launch("relpos_project_bwd(tables)");
 }

@@ -60,7 +60,12 @@ class VideoSaliencyModel(nn.Module):
             _, h, w, c = fm.shape
             self.spatiotemp_net._check_frames(T)
             tok = self.spatiotemp_net.forward_tokens(fm.view(bs, T * h * w, c))
-            f = ops.tokens_to_channels_first(tok, 0).view(bs, c, T, h, w)
+            if tok.requires_grad:                                         # training: keep the transpose on the tape
+                from . import encoder_autograd as eg
+
+                f = eg.tokens_to_channels_first(tok, 0).view(bs, c, T, h, w)
+            else:
+                f = ops.tokens_to_channels_first(tok, 0).view(bs, c, T, h, w)
             return f, f
         with torch.no_grad():
             f = self.audio_net.forward_feat(a)

@@ -14,8 +14,14 @@ The nn layers below are parameter storage only.  The forward is a sequence of HI
   * tokens stay [B, 1 + T*H*W, C] throughout; the only layout change is the final transpose to NCTHW per output scale.
 
 Built: the configuration the reference uses -- class token on, relative positions on, residual pooling on,
-``dim_mul_in_attention=True``, no absolute position embedding.  Inference only for now: the visual
-encoder's backward is the next step, so under ``DiffusionTrainStep`` its parameters must be frozen.
+``dim_mul_in_attention=True``, no absolute position embedding.
+
+Training (the reference trains the visual encoder inside the diffusion step, R/diffusion_trainer.py:212-235): when
+gradients are enabled and a parameter requires them, ``forward`` runs the same graph on the autograd tape with every
+operator an ``autograd.Function`` whose forward AND backward are HIP kernels (``autograd_ops.py``,
+``encoder_autograd.py``: flash-attention backward with the rel-pos columns, depthwise-pool / max-pool / rel-pos-projection
+backward; GEMM data and weight gradients through the implicit-GEMM and wgrad kernels).  DropPath is 0 in the shipped
+configuration (``drop_path_rate`` default) and is not built.
 """
 from __future__ import annotations
 
@@ -223,12 +229,76 @@ class MViT(nn.Module):
         h = ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ACT_GELU, tag="mvit-gemm")
         return ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x, tag="mvit-gemm"), q_size
 
+    # ------------------------------------------------------------------ training forward (autograd tape, HIP fwd + bwd)
+    def _block_train(self, i: int, x: Tensor, size) -> Tensor:
+        from . import autograd_ops as ag
+        from . import encoder_autograd as eg
+
+        blk = self.blocks[i]
+        a = blk.attn
+        B, N, _ = x.shape
+        xn = ag.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        qkv = ag.linear(xn, a.qkv.weight, a.qkv.bias).view(B, N, 3, blk.heads, 96)
+        w27 = [getattr(a, f"pool_{n}").weight.reshape(96, 27).t().contiguous() for n in "qkv"]
+        pq, pk_, pv = eg.qkv_pool(qkv, w27[0], w27[1], w27[2], size, blk.stride_q, blk.stride_kv)
+        q_size = tuple((s - 1) // st + 1 for s, st in zip(size, blk.stride_q))
+        k_size = tuple((s - 1) // st + 1 for s, st in zip(size, blk.stride_kv))
+        q = ag.layernorm(pq, a.norm_q.weight, a.norm_q.bias, a.norm_q.eps)
+        k = ag.layernorm(pk_, a.norm_k.weight, a.norm_k.bias, a.norm_k.eps)
+        v = ag.layernorm(pv, a.norm_v.weight, a.norm_v.bias, a.norm_v.eps)
+        # relative-position tables: parameter preprocessing (linear resample + gather) stays on the tape so that the
+        # table gradients of relpos_project flow back to rel_pos_t / rel_pos_h / rel_pos_w
+        Rt = self._rel_table_diff(a.rel_pos_t, q_size[0], k_size[0])
+        Rh = self._rel_table_diff(a.rel_pos_h, q_size[1], k_size[1])
+        Rw = self._rel_table_diff(a.rel_pos_w, q_size[2], k_size[2])
+        onehot = self._tables_for(i, q_size, k_size)[3]
+        extra = eg.relpos_project(q, Rt, Rh, Rw, q_size, k_size)
+        o = eg.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual_q=True, skip_first=True)
+        skip = ag.linear(xn, blk.proj.weight, blk.proj.bias) if hasattr(blk, "proj") else x
+        if max(blk.stride_q) > 1:
+            skip = eg.maxpool_tokens(skip, size, tuple(s + 1 if s > 1 else s for s in blk.stride_q), blk.stride_q)
+        x = ag.linear(o, a.proj.weight, a.proj.bias, residual=skip)
+        y = ag.layernorm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        h = ag.gelu(ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+        return ag.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x), q_size
+
+    @staticmethod
+    def _rel_table_diff(rel: Tensor, q_size: int, k_size: int) -> Tensor:
+        max_rel = int(2 * max(q_size, k_size) - 1)
+        r = rel
+        if r.shape[0] != max_rel:
+            r = F.interpolate(r.t().unsqueeze(0), size=max_rel, mode="linear").squeeze(0).t()
+        q_ratio, k_ratio = max(k_size / q_size, 1.0), max(q_size / k_size, 1.0)
+        idx = (torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio
+        return r[idx.long().to(r.device)].contiguous()
+
+    def forward_train(self, x: Tensor) -> List[Tensor]:
+        from . import autograd_ops as ag
+        from . import encoder_autograd as eg
+
+        B = x.shape[0]
+        self.packed()
+        cols, size = ops.im2col3d(x, (3, 7, 7), (2, 4, 4), (1, 3, 3), 448)           # the clip needs no gradient
+        L = size[0] * size[1] * size[2]
+        w = F.pad(self.patch_embed.projection.weight.reshape(96, -1), (0, 7))
+        patches = ag.linear(cols.view(B, L, 448), w, self.patch_embed.projection.bias)
+        tok = torch.cat([self.cls_token.expand(B, -1, -1), patches], dim=1)
+        outs = []
+        for i in range(self.num_layers):
+            tok, size = self._block_train(i, tok, size)
+            if i in self.stage_of_layer:
+                nm = getattr(self, f"norm{self.stage_of_layer[i]}")
+                tok = ag.layernorm(tok, nm.weight, nm.bias, nm.eps)
+                outs.append(eg.tokens_to_channels_first(tok, 1).view(B, tok.shape[2], *size))
+        return outs[::-1]
+
     def forward(self, x: Tensor, taps: Optional[dict] = None) -> List[Tensor]:
         if not x.is_cuda:
             raise RuntimeError("diff_sal_amd.MViT runs on the GPU only (no CPU fallback); got a CPU tensor")
-        if self.training and any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
-            raise RuntimeError("diff_sal_amd.MViT: the HIP backward of the visual encoder is not built yet; freeze it "
-                               "(requires_grad_(False)) or call it under torch.no_grad()")
+        if x.dim() == 4:                                         # [B*16, 3, H, W]  (R/models/mvit.py:1091-1092)
+            x = x.view(-1, x.shape[-3], 16, x.shape[-2], x.shape[-1])
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self.forward_train(x.contiguous().float())
         if x.dim() == 4:                                         # [B*16, 3, H, W]  (R/models/mvit.py:1091-1092)
             x = x.view(-1, x.shape[-3], 16, x.shape[-2], x.shape[-1])
         x = x.contiguous().float()

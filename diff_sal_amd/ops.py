@@ -811,20 +811,45 @@ def _bhl_strides(t: Tensor):
 
 
 def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra: Optional[Tensor] = None,
-                      k_extra: Optional[Tensor] = None, residual: Optional[Tensor] = None, skip_first: bool = False) -> Tensor:
-    """softmax(scale q k^T + q_extra k_extra^T) v (+ residual) for [B,H,L,D] views -> [B, Lq, H*DV] (include/diffsal.h)."""
+                      k_extra: Optional[Tensor] = None, residual: Optional[Tensor] = None, skip_first: bool = False,
+                      want_lse: bool = False):
+    """softmax(scale q k^T + q_extra k_extra^T) v (+ residual) for [B,H,L,D] views -> [B, Lq, H*DV] (include/diffsal.h);
+    with want_lse also the row log-sum-exp [B,H,Lq] the backward needs."""
     lib = _lib.load()
     B, H, Lq, D = q.shape
     Lk, DV = k.shape[2], v.shape[3]
     E = 0 if q_extra is None else q_extra.shape[-1]
     out = torch.empty((B, Lq, H * DV), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, H, Lq), device=q.device, dtype=torch.float32) if want_lse else None
     flops = 2.0 * B * H * Lq * Lk * (D + E + DV)
     with _prof("attn", flops, _nb(q, k, v, out)):
         _lib.check(lib.diffsal_attention_general(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
-            _p(out), B, H, Lq, Lk, D, E, DV, _bhl_strides(q), _bhl_strides(k), _bhl_strides(v),
+            _p(out), _p(lse), B, H, Lq, Lk, D, E, DV, _bhl_strides(q), _bhl_strides(k), _bhl_strides(v),
             None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _stream()), "attention_general")
-    return out
+    return (out, lse) if want_lse else out
+
+
+def attention_general_bwd(q, k, v, out, lse, dout, *, scale: float, q_extra=None, k_extra=None, residual=None,
+                          skip_first: bool = False):
+    """-> (dq [B,H,Lq,D], dq_extra [B,H,Lq,E] or None, dk [B,H,Lk,D], dv [B,H,Lk,DV]); dq includes the residual path."""
+    lib = _lib.load()
+    B, H, Lq, D = q.shape
+    Lk, DV = k.shape[2], v.shape[3]
+    E = 0 if q_extra is None else q_extra.shape[-1]
+    dev = q.device
+    dq = torch.empty((B, H, Lq, D), device=dev)
+    dqe = torch.empty((B, H, Lq, E), device=dev) if E else None
+    dk, dv = torch.empty((B, H, Lk, D), device=dev), torch.empty((B, H, Lk, DV), device=dev)
+    delta = torch.empty((B, H, Lq), device=dev)
+    flops = 2.0 * B * H * Lq * Lk * (2 * (D + E) + 2 * DV + D + E + DV)
+    with _prof("attn-bwd", flops, _nb(q, k, v, out, dout, dq, dk, dv)):
+        _lib.check(lib.diffsal_attention_general_bwd(
+            q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
+            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk, D, E, DV,
+            _bhl_strides(q), _bhl_strides(k), _bhl_strides(v), None if residual is None else _bhl_strides(residual),
+            float(scale), int(skip_first), _stream()), "attention_general_bwd")
+    return dq, dqe, dk, dv
 
 
 def im2col3d(x: Tensor, kernel, stride, pad, Kp: int) -> Tensor:
@@ -927,3 +952,72 @@ def resize_update(s_low: Tensor, x: Tensor, m_prev: Optional[Tensor], ex: float,
         _lib.check(lib.diffsal_resize_update(_p(s_low), _p(x), _p(m_prev), _p(x0), _p(m), _p(xn), N, h, w, H, W, float(ex), float(e0),
                                              float(A), float(c0), float(c1), _stream()), "resize_update")
     return m, xn, x0
+
+
+# ---- training of the encoders: forward variants that keep what the backward needs, and the backward kernels ----
+def pool3d(x: Tensor, w27: Tensor, size, stride) -> Tensor:
+    """attention_pool's depthwise Conv3d alone (no LayerNorm): x [B,N,heads,D] view -> [B,heads,1+Lo,D]."""
+    lib = _lib.load()
+    B, N, heads, D = x.shape
+    T, H, W = size
+    assert N == 1 + T * H * W and x.stride(3) == 1 and x.stride(2) == D
+    To, Ho, Wo = ((s - 1) // st + 1 for s, st in zip(size, stride))
+    out = torch.empty((B, heads, 1 + To * Ho * Wo, D), device=x.device, dtype=torch.float32)
+    with _prof("pool", 54.0 * out.numel(), _nb(out) * 2):
+        _lib.check(lib.diffsal_pool3d_ln(x.data_ptr(), _p(w27), None, None, _p(out), B, heads, D, T, H, W, *stride, x.stride(0),
+                                         x.stride(1), 0.0, _stream()), "pool3d")
+    return out, (To, Ho, Wo)
+
+
+def pool3d_bwd(x: Tensor, w27: Tensor, dy: Tensor, dx_view: Tensor, size, stride):
+    """dx (written into ``dx_view``, a view with x's strides) and dw27 [27][D] of ``pool3d``."""
+    lib = _lib.load()
+    B, N, heads, D = x.shape
+    T, H, W = size
+    assert dx_view.stride() == x.stride() and dx_view.shape == x.shape
+    dy = dy.contiguous()
+    with _prof("pool-bwd", 54.0 * dy.numel(), _nb(dy) * 2 + dx_view.numel() * 4):
+        _lib.check(lib.diffsal_pool3d_bwd_data(_p(dy), _p(w27), dx_view.data_ptr(), B, heads, D, T, H, W, *stride, x.stride(0),
+                                               x.stride(1), _stream()), "pool3d_bwd_data")
+        chunks = lib.diffsal_pool3d_bwd_weight_chunks()
+        part = torch.empty((chunks, 27 * D), device=x.device, dtype=torch.float64)
+        _lib.check(lib.diffsal_pool3d_bwd_weight(x.data_ptr(), _p(dy), part.data_ptr(), B, heads, D, T, H, W, *stride, x.stride(0),
+                                                 x.stride(1), _stream()), "pool3d_bwd_weight")
+    return reduce_partials(part.view(1, chunks, 27 * D), 1, chunks, 27 * D).view(27, D)
+
+
+def maxpool_tokens_idx(x: Tensor, size, kernel, stride):
+    lib = _lib.load()
+    B, N, Cc = x.shape
+    T, H, W = size
+    To, Ho, Wo = ((s + 2 * (k // 2) - k) // st + 1 for s, k, st in zip(size, kernel, stride))
+    out = torch.empty((B, 1 + To * Ho * Wo, Cc), device=x.device, dtype=torch.float32)
+    idx = torch.empty((B, 1 + To * Ho * Wo, Cc), device=x.device, dtype=torch.int32)
+    with _prof("pool", 0.0, _nb(x, out, idx)):
+        _lib.check(lib.diffsal_maxpool_tokens_idx(_p(x), _p(out), idx.data_ptr(), B, Cc, T, H, W, *kernel, *stride, _stream()),
+                   "maxpool_tokens_idx")
+    return out, idx
+
+
+def maxpool_tokens_bwd(dy: Tensor, idx: Tensor, size, kernel, stride) -> Tensor:
+    lib = _lib.load()
+    B, _, Cc = dy.shape
+    T, H, W = size
+    din = torch.empty((B, 1 + T * H * W, Cc), device=dy.device, dtype=torch.float32)
+    with _prof("pool-bwd", 0.0, _nb(dy, din, idx)):
+        _lib.check(lib.diffsal_maxpool_tokens_bwd(_p(dy.contiguous()), idx.data_ptr(), _p(din), B, Cc, T, H, W, *kernel, *stride,
+                                                  _stream()), "maxpool_tokens_bwd")
+    return din
+
+
+def relpos_project_bwd(dextra: Tensor, q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Tensor, q_size, k_size, dq_accum: Optional[Tensor] = None):
+    """-> (dq [B,heads,N,D] (added into dq_accum when given), dRt, dRh, dRw)."""
+    lib = _lib.load()
+    B, heads, N, D = q.shape
+    dq = dq_accum if dq_accum is not None else torch.empty_like(q)
+    dRt, dRh, dRw = torch.empty_like(Rt), torch.empty_like(Rh), torch.empty_like(Rw)
+    with _prof("relpos-bwd", 4.0 * B * heads * N * D * sum(k_size), _nb(q, dextra, dq)):
+        _lib.check(lib.diffsal_relpos_project_bwd(_p(dextra.contiguous()), _p(q), _p(Rt), _p(Rh), _p(Rw), _p(dq),
+                                                  int(dq_accum is not None), _p(dRt), _p(dRh), _p(dRw), B * heads, D, *q_size,
+                                                  *k_size, _stream()), "relpos_project_bwd")
+    return dq, dRt, dRh, dRw

@@ -41,6 +41,10 @@ class VGGish(nn.Module):
                                         nn.Linear(4096, 128), nn.ReLU(True))
         self._pack = None
         self._pack_key = None
+        # The reference runs this module under torch.no_grad() (R/models/diff_model.py:73-74): its 72 M parameters never
+        # receive a gradient, yet DDP buckets and all-reduces them.  Freeze them so that optimizers / gradient exchanges
+        # built on `requires_grad` skip them (state_dict is unaffected).
+        self.requires_grad_(False)
         if pretrained:
             if not os.path.exists(self.PRETRAINED):
                 raise FileNotFoundError(f"VGGish(pretrained=True) loads {self.PRETRAINED} as the reference does; not found")

@@ -1,0 +1,226 @@
+"""Training of the encoders on the HIP path: every new backward kernel against PyTorch autograd of the same fp32
+operator, the whole MViT / AudioAttnNet gradients against autograd through the CPU restatements, and one
+DiffusionTrainStep through VideoSaliencyModel(MViT + VGGish + AudioAttnNet + SalUNet)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import audio_oracle as ao
+from oracle import mvit_oracle as mo
+from oracle import salunet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(name, *shape, scale=1.0):
+    return orc.synth_tensor(name, shape, scale)
+
+
+def close(got, ref, tol, what=""):
+    ref = ref.detach().float().cpu()
+    e = (got.detach().float().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+    assert e < tol, (what, e)
+    return e
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 150, 70, 64, 0), (1, 2, 1 + 2 * 6 * 10, 1 + 2 * 3 * 5, 96, 48), (1, 1, 40, 129, 96, 0)])
+def test_attention_general_backward(shape):
+    """dq (incl. the residual path), dq_extra, dk, dv of the flash-attention backward vs autograd of the dense formula."""
+    from diff_sal_amd import encoder_autograd as eg
+
+    B, H, Lq, Lk, D, E = shape
+    q, k, v = (rnd(n, B, H, L, D).requires_grad_(True) for n, L in (("bq", Lq), ("bk", Lk), ("bv", Lk)))
+    qe = (rnd("bqe", B, H, Lq, E, scale=0.3).requires_grad_(True) if E else None)
+    ke = None
+    if E:
+        ke = torch.zeros(Lk, E)
+        ke[torch.arange(1, Lk), torch.randint(0, E, (Lk - 1,), generator=torch.Generator().manual_seed(1))] = 1.0
+    G = rnd("bg", B, Lq, H * D)
+    s = (q * D ** -0.5) @ k.transpose(-1, -2)
+    if E:
+        s = s + qe @ ke.t()
+    o = s.softmax(-1) @ v
+    if E:
+        o = torch.cat([o[:, :, :1], o[:, :, 1:] + q[:, :, 1:]], 2)
+    (o.transpose(1, 2).reshape(B, Lq, H * D) * G).sum().backward()
+    qd, kd, vd = (t.detach().to(DEV).requires_grad_(True) for t in (q, k, v))
+    qed = qe.detach().to(DEV).requires_grad_(True) if E else None
+    out = eg.attention_general(qd, kd, vd, scale=D ** -0.5, q_extra=qed, k_extra=None if ke is None else ke.to(DEV),
+                               residual_q=bool(E), skip_first=bool(E))
+    (out * G.to(DEV)).sum().backward()
+    close(out, o.transpose(1, 2).reshape(B, Lq, H * D), 2e-5, "out")
+    for n, a, b in (("dq", qd, q), ("dk", kd, k), ("dv", vd, v)) + ((("dqe", qed, qe),) if E else ()):
+        close(a.grad, b.grad, 5e-5, n)
+
+
+def test_pool_maxpool_relpos_backward():
+    from diff_sal_amd import encoder_autograd as eg
+
+    # depthwise pooling of q / k / v on a fused qkv tensor
+    B, heads, D, size = 2, 2, 96, (3, 7, 9)
+    N = 1 + size[0] * size[1] * size[2]
+    qkv = rnd("tq", B, N, 3, heads, D).requires_grad_(True)
+    ws = [rnd(f"tw{i}", D, 1, 3, 3, 3, scale=0.2).requires_grad_(True) for i in range(3)]
+    strides = ((1, 2, 2), (1, 4, 4), (1, 4, 4))
+    refs = []
+    for i in range(3):
+        x = qkv[:, :, i].permute(0, 2, 1, 3)
+        t = x[:, :, 1:].reshape(B * heads, *size, D).permute(0, 4, 1, 2, 3)
+        t = F.conv3d(t, ws[i], None, stride=strides[i], padding=1, groups=D)
+        refs.append(torch.cat([x[:, :, :1], t.reshape(B, heads, D, -1).transpose(2, 3)], 2))
+    Gs = [rnd(f"tg{i}", *r.shape) for i, r in enumerate(refs)]
+    sum((r * g).sum() for r, g in zip(refs, Gs)).backward()
+    qd = qkv.detach().to(DEV).requires_grad_(True)
+    wd = [w.detach().reshape(D, 27).t().contiguous().to(DEV).requires_grad_(True) for w in ws]
+    outs = eg.qkv_pool(qd, wd[0], wd[1], wd[2], size, strides[0], strides[1])
+    sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
+    for o, r in zip(outs, refs):
+        close(o, r, 2e-5, "pool fwd")
+    close(qd.grad, qkv.grad, 5e-5, "dqkv")
+    for i in range(3):
+        close(wd[i].grad, ws[i].grad.reshape(D, 27).t(), 5e-5, f"dw{i}")
+    # max-pool of the skip path
+    C, size = 64, (2, 6, 9)
+    x = rnd("mp", 2, 1 + size[0] * size[1] * size[2], C).requires_grad_(True)
+    t = x[:, 1:].reshape(2, *size, C).permute(0, 4, 1, 2, 3)
+    ref = torch.cat([x[:, :1], F.max_pool3d(t, (1, 3, 3), (1, 2, 2), (0, 1, 1)).reshape(2, C, -1).transpose(1, 2)], 1)
+    g = rnd("mpg", *ref.shape)
+    (ref * g).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = eg.maxpool_tokens(xd, size, (1, 3, 3), (1, 2, 2))
+    (got * g.to(DEV)).sum().backward()
+    assert torch.equal(got.detach().cpu(), ref.detach()) and torch.equal(xd.grad.cpu(), x.grad)
+    # relative-position projections
+    B, heads, D, q_size, k_size = 2, 2, 96, (2, 5, 7), (2, 3, 4)
+    L = q_size[0] * q_size[1] * q_size[2]
+    q = rnd("rq", B, heads, 1 + L, D).requires_grad_(True)
+    Rs = [rnd(f"rr{i}", a, b, D, scale=0.2).requires_grad_(True) for i, (a, b) in enumerate(zip(q_size, k_size))]
+    rq = q[:, :, 1:].reshape(B, heads, *q_size, D)
+    ex = torch.zeros(B, heads, 1 + L, 48)
+    ex[:, :, 1:, 0:k_size[0]] = torch.einsum("bythwc,tkc->bythwk", rq, Rs[0]).reshape(B, heads, L, -1)
+    ex[:, :, 1:, 8:8 + k_size[1]] = torch.einsum("bythwc,hkc->bythwk", rq, Rs[1]).reshape(B, heads, L, -1)
+    ex[:, :, 1:, 24:24 + k_size[2]] = torch.einsum("bythwc,wkc->bythwk", rq, Rs[2]).reshape(B, heads, L, -1)
+    g = rnd("rg", *ex.shape)
+    (ex * g).sum().backward()
+    qd = q.detach().to(DEV).requires_grad_(True)
+    Rd = [r.detach().to(DEV).requires_grad_(True) for r in Rs]
+    got = eg.relpos_project(qd, Rd[0], Rd[1], Rd[2], q_size, k_size)
+    (got * g.to(DEV)).sum().backward()
+    close(got, ex, 2e-5, "relpos fwd")
+    close(qd.grad, q.grad, 5e-5, "relpos dq")
+    for i in range(3):
+        close(Rd[i].grad, Rs[i].grad, 5e-5, f"dR{i}")
+
+
+def test_mvit_all_parameter_gradients_match_oracle_autograd():
+    """Whole video encoder: d(sum_i <out_i, G_i>) / d(every parameter) on the HIP path vs autograd through the CPU
+    restatement of R/models/mvit.py (smooth graph: GELU / softmax / LayerNorm; the only kinks are max-pool ties)."""
+    from tests.test_gpu_encoders import build_mvit
+
+    arch = dict(embed_dims=96, num_layers=5, num_heads=1, downscale_indices=[1, 2, 4])
+    net, cfg, sd = build_mvit(arch)
+    net.requires_grad_(True)
+    clip = rnd("mvit.train.x", 2, 3, 16, 64, 96)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    outs_ref = mo.mvit_forward(leaf, cfg, clip)
+    Gs = [rnd(f"mvit.train.g{i}", *o.shape) for i, o in enumerate(outs_ref)]
+    sum((o * g).sum() for o, g in zip(outs_ref, Gs)).backward()
+    outs = net(clip.to(DEV))
+    assert all(o.requires_grad for o in outs)
+    sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
+    for o, r in zip(outs, outs_ref):
+        close(o, r, 1e-4, "mvit out")
+    scale = torch.stack([v.grad.abs().max() for v in leaf.values()]).median().item()
+    worst = {}
+    for name, p in net.named_parameters():
+        ref = leaf[name].grad
+        assert p.grad is not None, name
+        e = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3 * scale)
+        worst[name] = e
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    print("mvit grads: worst", max(worst.values()), "median", float(np.median(list(worst.values()))))
+    assert not bad, bad
+
+
+def test_audio_attn_gradients_match_oracle_autograd():
+    from tests.test_gpu_encoders import build_audio
+
+    _, net, _, asd = build_audio()
+    f = rnd("aan.train.f", 2, 512, 9, 2, 4)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in asd.items()}
+    fr = f.clone().requires_grad_(True)
+    ref = ao.audio_attn_forward(leaf, fr)
+    g = rnd("aan.train.g", *ref.shape)
+    (ref * g).sum().backward()
+    fd = f.to(DEV).requires_grad_(True)
+    out = net(fd)
+    (out * g.to(DEV)).sum().backward()
+    close(out, ref, 1e-4, "aan out")
+    close(fd.grad, fr.grad, 1e-3, "aan dinput")
+    for name, p in net.named_parameters():
+        if leaf[name].grad is None:          # to_patch_embedding / pos_embedding: dead in the reference too (Q13)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        close(p.grad, leaf[name].grad, 1e-3, name)
+
+
+def test_training_step_through_the_full_audio_visual_model():
+    """configs[3] as the reference runs it (R/diffusion_trainer.py:212-235): MViT + (frozen) VGGish + AudioAttnNet + SalUNet
+    in one DiffusionTrainStep.  The first step's loss and gradient norm against autograd through the chained CPU
+    restatements; then the loss must fall on a repeated batch."""
+    from diff_sal_amd.diff_model import VideoSaliencyModel
+    from diff_sal_amd.train_step import DiffusionTrainStep
+    from tests.test_gpu_encoders import build_audio, build_mvit
+    from tests.test_gpu_salunet import build
+
+    cfg = orc.SalUNetConfig(img_size=(64, 128))
+    dsd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    dec = build(cfg, dsd)
+    dec.dropout_p = 0.0
+    enc, mcfg, msd = build_mvit("small")
+    enc.requires_grad_(True)
+    vgg, aan, vsd, asd = build_audio()
+    model = VideoSaliencyModel(channel_list=None, visual_net=enc, audio_net=vgg, spatiotemp_net=aan, decoder_net=dec)
+    B = 2
+    clip, audio = rnd("avt.clip", B, 3, 16, 64, 128), rnd("avt.audio", B, 1, 9, 32, 64)
+    sal = torch.sigmoid(rnd("avt.sal", B, 1, 64, 128))
+    noise = rnd("avt.noise", B, 1, 64, 128)
+    t0 = 400
+    ts = DiffusionTrainStep(model, lr=1e-4, grad_clip=1.0, store_clipped_grad=False)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert ts.flat.live_numel == n_train and not any(p.requires_grad for p in vgg.parameters())
+    # reference: chained restatements, train-mode BatchNorm in the denoiser
+    leaf_d = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in dsd.items()}
+    leaf_m = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    leaf_a = {k: v.clone().requires_grad_(True) for k, v in asd.items()}
+    a_hat = (1.0 - ts_betas()).cumprod(0)
+    x_t = a_hat[t0].sqrt() * sal + (1 - a_hat[t0]).sqrt() * noise
+    orc.BN_TRAIN = True
+    try:
+        with torch.no_grad():
+            vf = ao.vgg_features(vsd, audio.reshape(-1, 1, 32, 64))
+        vf = vf.reshape(B, 9, *vf.shape[1:]).permute(0, 2, 1, 3, 4)
+        pred = orc.salunet_forward(leaf_d, cfg, x_t, torch.full((B,), t0), mo.mvit_forward(leaf_m, mcfg, clip),
+                                   ao.audio_attn_forward(leaf_a, vf))
+    finally:
+        orc.BN_TRAIN = False
+    loss_ref = ((pred - sal) ** 2).sum(dim=(1, 2, 3)).mean()
+    loss_ref.backward()
+    gn_ref = torch.sqrt(sum(v.grad.double().pow(2).sum() for d in (leaf_d, leaf_m, leaf_a) for v in d.values() if v.grad is not None))
+    data = {"img": clip.to(DEV), "audio": audio.to(DEV)}
+    kw = dict(t0=t0, noise=noise.to(DEV), dequant_noise=torch.zeros_like(sal).to(DEV))
+    l0 = ts.step(sal.to(DEV), data, **kw)
+    print("loss", float(l0), "ref", float(loss_ref), "grad norm", float(ts.last_norm), "ref", float(gn_ref))
+    assert abs(float(l0) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    assert abs(float(ts.last_norm) - float(gn_ref)) < 2e-3 * float(gn_ref)
+    losses = [float(l0)] + [float(ts.step(sal.to(DEV), data, **kw)) for _ in range(4)]
+    print("losses", losses)
+    assert losses[-1] < losses[0]
+
+
+def ts_betas():
+    from diff_sal_amd.diffusion_utils import get_beta_schedule, to_torch
+
+    return to_torch(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000))
