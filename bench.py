@@ -196,8 +196,30 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
     H, W = cfg.img_size
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     sal = torch.rand((B, 1, H, W), generator=g).to(dev)
-    cond = {"feat_list": feats, "audio_feat": audio}
-    ts = DiffusionTrainStep(net)                      # reference hyper-parameters: Adam 1e-4, clip 1.0, dropout 0.1
+    full = args.train_scope == "full"
+    if full:
+        # the step as the reference runs it (R/diffusion_trainer.py:212-235): the encoders are INSIDE the step --
+        # MViTv2-S forward + backward, VGGish forward (frozen, no_grad) and AudioAttnNet forward + backward in AV mode
+        from diff_sal_amd.audio_attention import AudioAttnNet
+        from diff_sal_amd.diff_model import VideoSaliencyModel
+        from diff_sal_amd.mvit import MViT
+        from diff_sal_amd.vggish import VGGish
+
+        torch.manual_seed(11)                         # same random-init encoder weights on every rank
+        enc = MViT(arch="small", out_scales=[0, 1, 2, 3])
+        kw = dict(visual_net=enc, decoder_net=net)
+        if av:
+            kw.update(audio_net=VGGish(pretrained=False),
+                      spatiotemp_net=AudioAttnNet(depth=1, heads=2, dim=512, mlp_dim=256, patch_dim=512, num_patches=16, height=7,
+                                                  width=12, pool="cls", dim_head=64))
+        model = VideoSaliencyModel(channel_list=None, **kw).to(dev)
+        cond = {"img": torch.randn((B, 3, 16, H, W), generator=g).to(dev)}
+        if av:
+            cond["audio"] = torch.randn((B, 1, 9, H // 2, W // 2), generator=g).to(dev)
+        ts = DiffusionTrainStep(model)
+    else:
+        cond = {"feat_list": feats, "audio_feat": audio}
+        ts = DiffusionTrainStep(net)                  # reference hyper-parameters: Adam 1e-4, clip 1.0, dropout 0.1
     ts._rng = np.random.RandomState(99)               # same timestep sequence on every rank / run
 
     def barrier():
@@ -249,8 +271,11 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: " + ("audio-visual" if av else "visual-only")
-                   + f" training step, per-GPU batch {B} (global {world * B}), 224x384, SalUNet parameters only "
-                     "(conditioning features are inputs; MViT/VGGish are outside the path, SURVEY 8f)",
+                   + f" training step, per-GPU batch {B} (global {world * B}), 224x384, "
+                   + ("VideoSaliencyModel end to end: MViTv2-S (fwd+bwd)" + (" + VGGish (frozen) + AudioAttnNet (fwd+bwd)" if av else "")
+                      + " + SalUNet (fwd+bwd), as R/diffusion_trainer.py:212-235 runs it" if full else
+                      "SalUNet parameters only (conditioning features are inputs; --train-scope decoder)"),
+                   "train_scope": args.train_scope,
                    "batch_per_gpu": B, "trainable_params": ts.flat.live_numel, "grad_buckets": len(ts.flat.buckets),
                    "exchange": "RCCL all-reduce of the flat fp32 gradient, bucketed, overlapped with backward",
                    "final_loss": float(loss.item())},
@@ -280,6 +305,9 @@ def main():
     ap.add_argument("--workload", choices=["sample", "train"], default="sample",
                     help="sample = the headline metric; train = BASELINE configs[3] (one step = prepare_data + forward + "
                          "MSE + backward + gradient all-reduce + clip + Adam on a per-GPU batch), reported as samples/s")
+    ap.add_argument("--train-scope", choices=["full", "decoder"], default="full",
+                    help="--workload train: full = MViT + (VGGish, AudioAttnNet) + SalUNet inside the step, as the reference; "
+                         "decoder = the denoiser alone on given features (round-1 measurement)")
     ap.add_argument("--sampler-mode", choices=["eager", "graph", "f1"], default="eager",
                     help="eager = headline; graph = whole trajectories replayed from a HIP graph; f1 = step-invariant "
                          "shortcut of visual-only mode (1 evaluation per trajectory) -- both reported separately")

@@ -91,7 +91,8 @@ def test_pool_maxpool_relpos_backward():
     xd = x.detach().to(DEV).requires_grad_(True)
     got = eg.maxpool_tokens(xd, size, (1, 3, 3), (1, 2, 2))
     (got * g.to(DEV)).sum().backward()
-    assert torch.equal(got.detach().cpu(), ref.detach()) and torch.equal(xd.grad.cpu(), x.grad)
+    assert torch.equal(got.detach().cpu(), ref.detach())
+    close(xd.grad, x.grad, 1e-6, "maxpool dx")       # an input that wins several windows sums their gradients in another order
     # relative-position projections
     B, heads, D, q_size, k_size = 2, 2, 96, (2, 5, 7), (2, 3, 4)
     L = q_size[0] * q_size[1] * q_size[2]
@@ -182,7 +183,7 @@ def test_training_step_through_the_full_audio_visual_model():
     enc, mcfg, msd = build_mvit("small")
     enc.requires_grad_(True)
     vgg, aan, vsd, asd = build_audio()
-    model = VideoSaliencyModel(channel_list=None, visual_net=enc, audio_net=vgg, spatiotemp_net=aan, decoder_net=dec)
+    model = VideoSaliencyModel(channel_list=None, visual_net=enc, audio_net=vgg, spatiotemp_net=aan, decoder_net=dec).to(DEV)
     B = 2
     clip, audio = rnd("avt.clip", B, 3, 16, 64, 128), rnd("avt.audio", B, 1, 9, 32, 64)
     sal = torch.sigmoid(rnd("avt.sal", B, 1, 64, 128))
