@@ -233,6 +233,8 @@ struct AttnBwdArgs {
   float* dq_extra;       // [B,H,Lq,E] contiguous or null
   float* dk;             // [B,H,Lk,D] contiguous
   float* dv;             // [B,H,Lk,DV] contiguous
+  float* kv_part;        // [q_splits][B*H*Lk*(D+DV)] partial dk | dv when q_splits > 1 (summed by attention_bwd_kv_sum_kernel)
+  int q_splits;          // the kv kernel's query range is cut into this many pieces (few keys, many queries: MViT's early layers)
   long q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, r_sb, r_sh, r_sl;
   int H, Lq, Lk;
   float scale;
@@ -462,7 +464,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
     for (int r = 0; r < 16; ++r) av[t][r] = 0.f;
 
   const float* qb = p.q + b * p.q_sb + h * p.q_sh;
-  const int n_tiles = (p.Lq + 31) / 32;
+  const int all_tiles = (p.Lq + 31) / 32;
+  const int tile_lo = static_cast<int>(static_cast<long>(all_tiles) * blockIdx.z / p.q_splits);
+  const int tile_hi = static_cast<int>(static_cast<long>(all_tiles) * (blockIdx.z + 1) / p.q_splits);
   constexpr int QF4 = 32 * DQ / 4, GF4 = 32 * DV / 4;
   constexpr int QPT = (QF4 + 255) / 256, GPT = (GF4 + 255) / 256;
   float4 qreg[QPT], greg[GPT];
@@ -511,11 +515,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
     }
     if (tid < 32) { Ls[tid] = lreg; Ds[tid] = dreg; }
   };
-  fetch(0);
+  fetch(tile_lo);
   park();
   __syncthreads();
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    if (tile + 1 < n_tiles) fetch(tile + 1);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    if (tile + 1 < tile_hi) fetch(tile + 1);
     // S = Q' K'^T (rows = queries, column = this lane's key):  A = Q'[query = lane & 31][hf*HQ + j], B = kf[j]
     f32x16 s, dp;
 #pragma unroll
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
         ak[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qrow_i * QP + t * 32 + kl], dp[r], ak[t], 0, 0, 0);
     }
     __syncthreads();
-    if (tile + 1 < n_tiles) {
+    if (tile + 1 < tile_hi) {
       park();
       __syncthreads();
     }
@@ -564,6 +568,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
   if (ki >= p.Lk) return;
   float* dkr = p.dk + (static_cast<long>(bh) * p.Lk + ki) * D;
   float* dvr = p.dv + (static_cast<long>(bh) * p.Lk + ki) * DV;
+  if (p.q_splits > 1) {     // partial sums of this query range: [split][dk (all rows) | dv (all rows)]
+    const long n_k = static_cast<long>(gridDim.y) * p.Lk;
+    float* base = p.kv_part + static_cast<long>(blockIdx.z) * n_k * (D + DV);
+    dkr = base + (static_cast<long>(bh) * p.Lk + ki) * D;
+    dvr = base + n_k * D + (static_cast<long>(bh) * p.Lk + ki) * DV;
+  }
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
@@ -576,6 +586,20 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
       st4(dvr + 32 * t + 4 * hf + 8 * g, make_float4(av[t][4 * g + 0], av[t][4 * g + 1], av[t][4 * g + 2], av[t][4 * g + 3]));
 }
 
+// dk | dv = sum over the query splits, in split order (deterministic)
+__global__ __launch_bounds__(256) void attention_bwd_kv_sum_kernel(const float* __restrict__ part, float* __restrict__ dk,
+                                                                   float* __restrict__ dv, long n_dk, long n_dv, int splits) {
+  const long n = n_dk + n_dv;
+  for (long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n; i += static_cast<long>(gridDim.x) * 1024) {
+    float4 a = ld4(part + i);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = ld4(part + s * n + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    st4(i < n_dk ? dk + i : dv + (i - n_dk), a);
+  }
+}
+
 template <int D, int E, int DV>
 static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
   const long rows = static_cast<long>(B) * a.H * a.Lq;
@@ -585,8 +609,15 @@ static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
   hipLaunchKernelGGL((attention_bwd_q_kernel<D, E, DV>), dim3((a.Lq + 127) / 128, B * a.H), dim3(256), 0, s, a);
   rc = check_launch("attention_general_bwd(dq)");
   if (rc) return rc;
-  hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV>), dim3((a.Lk + 127) / 128, B * a.H), dim3(256), 0, s, a);
-  return check_launch("attention_general_bwd(dk, dv)");
+  hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV>), dim3((a.Lk + 127) / 128, B * a.H, a.q_splits), dim3(256), 0, s, a);
+  rc = check_launch("attention_general_bwd(dk, dv)");
+  if (rc || a.q_splits == 1) return rc;
+  const long n_dk = static_cast<long>(B) * a.H * a.Lk * D, n_dv = static_cast<long>(B) * a.H * a.Lk * DV;
+  long g = ((n_dk + n_dv) / 4 + 255) / 256;
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(attention_bwd_kv_sum_kernel, dim3(static_cast<int>(g)), dim3(256), 0, s, a.kv_part, a.dk, a.dv, n_dk, n_dv,
+                     a.q_splits);
+  return check_launch("attention_general_bwd(sum)");
 }
 
 }  // namespace diffsal
@@ -630,10 +661,21 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
   return check_launch("attention_general");
 }
 
+// Query splits of the dk / dv kernel: enough workgroups to fill the chip when there are few keys (Lk = 673 at B*H = 4 is
+// 24 workgroups), at most one split per 8 query tiles.
+extern "C" int diffsal_attention_general_bwd_splits(int B, int H, int Lq, int Lk) {
+  const long wgs = static_cast<long>((Lk + 127) / 128) * B * H;
+  long s = (768 + wgs - 1) / wgs;
+  const long max_s = ((Lq + 31) / 32 + 7) / 8;
+  s = s > max_s ? max_s : s;
+  s = s > 64 ? 64 : s;
+  return static_cast<int>(s < 1 ? 1 : s);
+}
+
 extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra,
                                              const float* v, const float* residual, const float* out, const float* lse,
-                                             const float* dout, float* delta_ws, float* dq, float* dq_extra, float* dk,
-                                             float* dv, int B, int H, int Lq, int Lk, int D, int E, int DV,
+                                             const float* dout, float* delta_ws, float* kv_part_ws, float* dq, float* dq_extra,
+                                             float* dk, float* dv, int B, int H, int Lq, int Lk, int D, int E, int DV,
                                              const long* q_strides, const long* k_strides, const long* v_strides,
                                              const long* r_strides, float scale, int skip_first, diffsal_stream_t stream) {
   DS_REQUIRE(q && k && v && out && lse && dout && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides,
@@ -651,6 +693,11 @@ extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extr
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
   a.r_sb = residual ? r_strides[0] : 0; a.r_sh = residual ? r_strides[1] : 0; a.r_sl = residual ? r_strides[2] : 0;
   a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.skip_first = skip_first;
+  a.q_splits = diffsal_attention_general_bwd_splits(B, H, Lq, Lk);
+  a.kv_part = kv_part_ws;
+  DS_REQUIRE(a.q_splits == 1 || (kv_part_ws && aligned16(kv_part_ws)), DIFFSAL_E_ARG,
+             "attention_general_bwd: %d query splits need kv_part_ws of splits * B*H*Lk*(D+DV) floats", a.q_splits);
+  DS_REQUIRE((static_cast<long>(B) * H * Lk * D) % 4 == 0, DIFFSAL_E_SHAPE, "attention_general_bwd: dk size");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (D == 96 && E == 48 && DV == 96) return launch_attention_bwd<96, 48, 96>(a, B, s);
   if (D == 96 && E == 0 && DV == 96) return launch_attention_bwd<96, 0, 96>(a, B, s);

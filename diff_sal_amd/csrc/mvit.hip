@@ -440,37 +440,44 @@ __global__ __launch_bounds__(256) void relpos_bwd_q_kernel(const float* __restri
 }
 
 // Backward of relpos_project, table side: for axis a in {t, y, x}: dR[i][j][d] = sum over the queries whose coordinate on
-// that axis is i of dE[query][slot0 + j] * q[query][d].  One workgroup per (axis, i); thread = (j, channel quad),
-// sequential fp32 sum over the queries in index order (deterministic).
+// that axis is i of dE[query][slot0 + j] * q[query][d].  One workgroup per (axis coordinate i, chunk of the queries);
+// thread = (j, channel quad); per-chunk partial sums part[chunk][table offset] (double) are combined in a fixed order by
+// diffsal_reduce_partials: deterministic, no atomics.  Table offsets: Rt at 0, Rh after qt*kt*D, Rw after that.
+constexpr int REL_CHUNKS = 32;
+
 __global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __restrict__ dE, const float* __restrict__ q,
-                                                                float* __restrict__ dRt, float* __restrict__ dRh,
-                                                                float* __restrict__ dRw, int BH, int D, int qt, int qh, int qw,
-                                                                int kt, int kh, int kw) {
+                                                                double* __restrict__ part, int BH, int D, int qt, int qh,
+                                                                int qw, int kt, int kh, int kw) {
   int i = blockIdx.x, axis = 0;
   if (i >= qt) { i -= qt; axis = 1; }
   if (axis == 1 && i >= qh) { i -= qh; axis = 2; }
+  const int chunk = blockIdx.y;
   const int kk = axis == 0 ? kt : (axis == 1 ? kh : kw);
   const int slot0 = axis == 0 ? REL_T0 : (axis == 1 ? REL_H0 : REL_W0);
-  float* dR = axis == 0 ? dRt : (axis == 1 ? dRh : dRw);
+  const long width = (static_cast<long>(qt) * kt + static_cast<long>(qh) * kh + static_cast<long>(qw) * kw) * D;
+  const long tab0 = axis == 0 ? 0 : (axis == 1 ? static_cast<long>(qt) * kt * D
+                                               : (static_cast<long>(qt) * kt + static_cast<long>(qh) * kh) * D);
   const int c4n = D >> 2;
   const int L = qt * qh * qw;
   const int n_a = axis == 0 ? qh * qw : (axis == 1 ? qt * qw : qt * qh);       // queries per image with this coordinate
+  const long n_all = static_cast<long>(BH) * n_a;
+  const long lo = n_all * chunk / REL_CHUNKS, hi = n_all * (chunk + 1) / REL_CHUNKS;
   for (int item = threadIdx.x; item < kk * c4n; item += 256) {
     const int j = item / c4n, c = (item % c4n) * 4;
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int bh = 0; bh < BH; ++bh) {
-      for (int m = 0; m < n_a; ++m) {
-        int t, y, x;
-        if (axis == 0) { t = i; y = m / qw; x = m % qw; }
-        else if (axis == 1) { y = i; t = m / qw; x = m % qw; }
-        else { x = i; t = m / qh; y = m % qh; }
-        const long row = static_cast<long>(bh) * (L + 1) + 1 + (static_cast<long>(t) * qh + y) * qw + x;
-        const float e = dE[row * REL_E + slot0 + j];
-        const float4 qv = ld4(q + row * D + c);
-        acc.x = fmaf(e, qv.x, acc.x); acc.y = fmaf(e, qv.y, acc.y); acc.z = fmaf(e, qv.z, acc.z); acc.w = fmaf(e, qv.w, acc.w);
-      }
+    for (long u = lo; u < hi; ++u) {
+      const int bh = static_cast<int>(u / n_a), m = static_cast<int>(u - static_cast<long>(bh) * n_a);
+      int t, y, x;
+      if (axis == 0) { t = i; y = m / qw; x = m % qw; }
+      else if (axis == 1) { y = i; t = m / qw; x = m % qw; }
+      else { x = i; t = m / qh; y = m % qh; }
+      const long row = static_cast<long>(bh) * (L + 1) + 1 + (static_cast<long>(t) * qh + y) * qw + x;
+      const float e = dE[row * REL_E + slot0 + j];
+      const float4 qv = ld4(q + row * D + c);
+      acc.x = fmaf(e, qv.x, acc.x); acc.y = fmaf(e, qv.y, acc.y); acc.z = fmaf(e, qv.z, acc.z); acc.w = fmaf(e, qv.w, acc.w);
     }
-    st4(dR + (static_cast<long>(i) * kk + j) * D + c, acc);
+    double* o = part + chunk * width + tab0 + (static_cast<long>(i) * kk + j) * D + c;
+    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
   }
 }
 
@@ -621,10 +628,12 @@ extern "C" int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float
   return check_launch("maxpool_tokens_bwd");
 }
 
+extern "C" int diffsal_relpos_project_bwd_chunks(void) { return REL_CHUNKS; }
+
 extern "C" int diffsal_relpos_project_bwd(const float* dextra, const float* q, const float* Rt, const float* Rh, const float* Rw,
-                                          float* dq, int accumulate, float* dRt, float* dRh, float* dRw, int BH, int D, int qt,
-                                          int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream) {
-  DS_REQUIRE(dextra && q && Rt && Rh && Rw && dq && dRt && dRh && dRw, DIFFSAL_E_ARG, "relpos_project_bwd: null argument");
+                                          float* dq, int accumulate, double* part, int BH, int D, int qt, int qh, int qw, int kt,
+                                          int kh, int kw, diffsal_stream_t stream) {
+  DS_REQUIRE(dextra && q && Rt && Rh && Rw && dq && part, DIFFSAL_E_ARG, "relpos_project_bwd: null argument");
   DS_REQUIRE(BH > 0 && D > 0 && D % 4 == 0 && D <= 1024 && qt > 0 && qh > 0 && qw > 0 && kt > 0 && kt <= REL_H0 - REL_T0 &&
                  kh > 0 && kh <= REL_W0 - REL_H0 && kw > 0 && kw <= REL_E - REL_W0,
              DIFFSAL_E_SHAPE, "relpos_project_bwd: bad shape");
@@ -634,7 +643,7 @@ extern "C" int diffsal_relpos_project_bwd(const float* dextra, const float* q, c
                      D, qt, qh, qw, kt, kh, kw, accumulate, rows);
   int rc = check_launch("relpos_project_bwd(q)");
   if (rc) return rc;
-  hipLaunchKernelGGL(relpos_bwd_tables_kernel, dim3(qt + qh + qw), dim3(256), 0, s, dextra, q, dRt, dRh, dRw, BH, D, qt, qh, qw,
-                     kt, kh, kw);
+  hipLaunchKernelGGL(relpos_bwd_tables_kernel, dim3(qt + qh + qw, REL_CHUNKS), dim3(256), 0, s, dextra, q, part, BH, D, qt, qh,
+                     qw, kt, kh, kw);
   return check_launch("relpos_project_bwd(tables)");
 }

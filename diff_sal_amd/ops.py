@@ -842,11 +842,13 @@ def attention_general_bwd(q, k, v, out, lse, dout, *, scale: float, q_extra=None
     dqe = torch.empty((B, H, Lq, E), device=dev) if E else None
     dk, dv = torch.empty((B, H, Lk, D), device=dev), torch.empty((B, H, Lk, DV), device=dev)
     delta = torch.empty((B, H, Lq), device=dev)
+    splits = lib.diffsal_attention_general_bwd_splits(B, H, Lq, Lk)
+    kv_part = torch.empty((splits, B * H * Lk * (D + DV)), device=dev) if splits > 1 else None
     flops = 2.0 * B * H * Lq * Lk * (2 * (D + E) + 2 * DV + D + E + DV)
     with _prof("attn-bwd", flops, _nb(q, k, v, out, dout, dq, dk, dv)):
         _lib.check(lib.diffsal_attention_general_bwd(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
-            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk, D, E, DV,
+            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk, D, E, DV,
             _bhl_strides(q), _bhl_strides(k), _bhl_strides(v), None if residual is None else _bhl_strides(residual),
             float(scale), int(skip_first), _stream()), "attention_general_bwd")
     return dq, dqe, dk, dv
@@ -1015,9 +1017,13 @@ def relpos_project_bwd(dextra: Tensor, q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Te
     lib = _lib.load()
     B, heads, N, D = q.shape
     dq = dq_accum if dq_accum is not None else torch.empty_like(q)
-    dRt, dRh, dRw = torch.empty_like(Rt), torch.empty_like(Rh), torch.empty_like(Rw)
+    chunks = lib.diffsal_relpos_project_bwd_chunks()
+    width = Rt.numel() + Rh.numel() + Rw.numel()
+    part = torch.empty((chunks, width), device=q.device, dtype=torch.float64)
     with _prof("relpos-bwd", 4.0 * B * heads * N * D * sum(k_size), _nb(q, dextra, dq)):
         _lib.check(lib.diffsal_relpos_project_bwd(_p(dextra.contiguous()), _p(q), _p(Rt), _p(Rh), _p(Rw), _p(dq),
-                                                  int(dq_accum is not None), _p(dRt), _p(dRh), _p(dRw), B * heads, D, *q_size,
-                                                  *k_size, _stream()), "relpos_project_bwd")
-    return dq, dRt, dRh, dRw
+                                                  int(dq_accum is not None), part.data_ptr(), B * heads, D, *q_size, *k_size,
+                                                  _stream()), "relpos_project_bwd")
+        flat = reduce_partials(part.view(1, chunks, width), 1, chunks, width).view(-1)
+    a, b = Rt.numel(), Rt.numel() + Rh.numel()
+    return dq, flat[:a].view(Rt.shape), flat[a:b].view(Rh.shape), flat[b:].view(Rw.shape)

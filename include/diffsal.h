@@ -313,9 +313,10 @@ int diffsal_attention_general(const float* q, const float* q_extra, const float*
 /* Backward (training of the encoders): P is recomputed from `lse`; delta_ws [B,H,Lq] is scratch.  Outputs are contiguous
  * head-major tensors: dq [B,H,Lq,D] (includes the residual path's dO when `residual` was given), dq_extra [B,H,Lq,E]
  * (NULL iff E == 0), dk [B,H,Lk,D], dv [B,H,Lk,DV]; k_extra is a constant table and gets no gradient.  No atomics. */
+int diffsal_attention_general_bwd_splits(int B, int H, int Lq, int Lk); /* S; kv_part_ws needs S*B*H*Lk*(D+DV) floats if S > 1 */
 int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
                                   const float* residual, const float* out, const float* lse, const float* dout,
-                                  float* delta_ws, float* dq, float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
+                                  float* delta_ws, float* kv_part_ws, float* dq, float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
                                   int Lk, int D, int E, int DV, const long* q_strides, const long* k_strides,
                                   const long* v_strides, const long* r_strides, float scale, int skip_first,
                                   diffsal_stream_t stream);
@@ -346,8 +347,9 @@ int diffsal_tokens_to_channels_first(const float* in, float* out, int B, int C, 
  * pool3d_bwd_data writes d_in through the forward input's strides (straight into the q / k / v slice of the qkv gradient);
  * pool3d_bwd_weight leaves part[chunks][27][D] doubles (chunks = diffsal_pool3d_bwd_weight_chunks()) for
  * diffsal_reduce_partials.  maxpool_tokens_idx also records the arg-max token (first maximum in (t,y,x) order, as
- * torch.nn.MaxPool3d); maxpool_tokens_bwd routes dy back through it.  relpos_project_bwd: dq (+)= dextra . R and the three
- * table gradients dRt / dRh / dRw (same shapes as Rt / Rh / Rw). */
+ * torch.nn.MaxPool3d); maxpool_tokens_bwd routes dy back through it.  relpos_project_bwd: dq (+)= dextra . R and per-chunk
+ * partials of the three table gradients (chunks = diffsal_relpos_project_bwd_chunks(); finish with
+ * diffsal_reduce_partials(part, out, 1, chunks, width, 0) -> dRt | dRh | dRw back to back). */
 int diffsal_pool3d_bwd_data(const float* dy, const float* w27, float* din, int B, int heads, int D, int T, int H, int W, int st,
                             int sh, int sw, long in_stride_b, long in_stride_n, diffsal_stream_t stream);
 int diffsal_pool3d_bwd_weight_chunks(void);
@@ -357,9 +359,10 @@ int diffsal_maxpool_tokens_idx(const float* in, float* out, int* idx, int B, int
                                int st, int sh, int sw, diffsal_stream_t stream);
 int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float* din, int B, int C, int T, int H, int W, int kt, int kh,
                                int kw, int st, int sh, int sw, diffsal_stream_t stream);
+int diffsal_relpos_project_bwd_chunks(void);
 int diffsal_relpos_project_bwd(const float* dextra, const float* q, const float* Rt, const float* Rh, const float* Rw, float* dq,
-                               int accumulate, float* dRt, float* dRh, float* dRw, int BH, int D, int qt, int qh, int qw, int kt,
-                               int kh, int kw, diffsal_stream_t stream);
+                               int accumulate, double* part /*[chunks][(qt*kt + qh*kh + qw*kw) * D]: dRt | dRh | dRw partials*/,
+                               int BH, int D, int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream);
 
 /* ---- VGGish feature stack (R/models/vggish.py:70-106): 3x3 convs are diffsal_conv_in (1 input channel, act = ReLU) and
  * diffsal_conv_igemm (bias + ReLU epilogue); this is its MaxPool2d(k, stride) on NHWC (no padding, floor). */
