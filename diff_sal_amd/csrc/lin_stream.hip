@@ -170,4 +170,200 @@ int try_linear_stream(const float* x, const float* w, const float* bias, const f
   return rc == DIFFSAL_OK ? 1 : rc;
 }
 
+// =================================================================================================================
+// Fused MLP half of the finest decoder stage's TransformerBlock (+ the norm that feeds ReduceTemp):
+//     x2 = x1 + fc2( gelu( fc1( LayerNorm_2(x1) ) ) )            R/models/saliency_decoder/transformer.py:153-157,
+//     z  = LayerNorm_mts(x2)   (optional, frames < t_keep only)   common_block.py:125-147, sal_unet.py:447,473
+// for C = 96, hidden = 192 (the only stage whose two weight matrices fit in LDS: 147 KB).  Replaces four launches
+// (LayerNorm, fc1 + GELU, fc2 + residual, LayerNorm) and removes three round trips of the 74 MB token tensor and one of
+// the 149 MB hidden tensor per step (B = 4): the hidden activations never leave registers.
+//
+// One wavefront owns 32 tokens at a time and works TRANSPOSED (hidden^T = W1 xn^T, out^T = W2 hidden^T) so that the
+// C/D layout of one product (column = lane & 31 = token, 16 rows per lane) is directly the B operand of the next one
+// (v_mfma_f32_32x32x2_f32 takes its two k values from the two lane halves; the k order of a contraction is free as long
+// as A and B agree, so half h pairs "its" rows {4h + (r & 3) + 8 (r >> 2)} with the same columns of the weight).  Both
+// weights stay in LDS for the lifetime of the workgroup; steady state has no barriers.  Exact fp32.
+// =================================================================================================================
+struct MlpBlockArgs {
+  const float* x1;
+  const float* g2; const float* be2;      // norm2
+  const float* w1; const float* b1;       // fc1 [192][96]
+  const float* w2; const float* b2;       // fc2 [96][192]
+  const float* gz; const float* bez;      // norm_mts (z output), may be null with z
+  float* x2;
+  float* z;
+  int M;
+  float eps2, epsz;
+  int hw, T, t_keep;                      // z is written for tokens whose frame (m / hw) % T < t_keep
+};
+
+__global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
+  constexpr int C = 96, HID = 192;
+  constexpr int P1 = C + 4, P2 = HID + 4;           // LDS pitches (floats): conflict-free ds_read_b128 per 16-lane group
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* W1s = sm;                                   // [HID][P1]
+  float* W2s = W1s + HID * P1;                       // [C][P2]
+  float* vec = W2s + C * P2;                         // g2 | be2 | b2 | gz | bez (C each), b1 (HID)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < HID * (C / 4); i += 256) {
+    const int n = i / (C / 4), c4 = (i - n * (C / 4)) * 4;
+    st4(W1s + n * P1 + c4, ld4(p.w1 + n * C + c4));
+  }
+  for (int i = tid; i < C * (HID / 4); i += 256) {
+    const int c = i / (HID / 4), n4 = (i - c * (HID / 4)) * 4;
+    st4(W2s + c * P2 + n4, ld4(p.w2 + c * HID + n4));
+  }
+  for (int i = tid; i < C; i += 256) {
+    vec[i] = p.g2[i]; vec[C + i] = p.be2[i]; vec[2 * C + i] = p.b2[i];
+    vec[3 * C + i] = p.z ? p.gz[i] : 0.f; vec[4 * C + i] = p.z ? p.bez[i] : 0.f;
+  }
+  for (int i = tid; i < HID; i += 256) vec[5 * C + i] = p.b1[i];
+  __syncthreads();
+
+  const int ml = lane & 31, hf = lane >> 5;
+  const int n_tiles = (p.M + 31) / 32;
+  const int n_waves = gridDim.x * 4;
+  const float* w1frag = W1s + ml * P1 + 4 * hf;      // + 32 t * P1 + 8 i : W1[n = 32t + ml][c = 8i + 4hf ..]
+  const float* w2frag = W2s + ml * P2 + 4 * hf;      // + 32 u * P2 + 32 t + 8 g : W2[c = 32u + ml][n = 32t + 8g + 4hf ..]
+
+  float4 xa[12], xnext[12];
+  auto load_tile = [&](int tile, float4 (&dst)[12]) {
+    int m = tile * 32 + ml;
+    m = m < p.M ? m : p.M - 1;
+    const float* src = p.x1 + static_cast<long>(m) * C + 4 * hf;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dst[i] = ld4(src + 8 * i);          // channels 8i + 4hf .. + 3
+  };
+  auto ln_rows = [&](const float4 (&v)[12], float& mean, float& rstd, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    s += __shfl_xor(s, 32, kWave);
+    mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    q += __shfl_xor(q, 32, kWave);
+    rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+  };
+
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < n_tiles) load_tile(tile, xa);
+  for (; tile < n_tiles; tile += n_waves) {
+    if (tile + n_waves < n_tiles) load_tile(tile + n_waves, xnext);  // lands during this tile's 576 MFMAs
+    // ---- LayerNorm_2 in registers
+    float mean, rstd;
+    ln_rows(xa, mean, rstd, p.eps2);
+    // ---- hidden^T = W1 xn^T + b1, GELU:  6 tiles of 32 hidden units, column = this lane's token
+    f32x16 hid[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t][r] = vec[5 * C + 32 * t + 4 * hf + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      // the normalised piece is formed right before use (4 values live instead of 48)
+      const float4 g = ld4(vec + 8 * i + 4 * hf), b = ld4(vec + C + 8 * i + 4 * hf);
+      const float n0 = (xa[i].x - mean) * rstd * g.x + b.x, n1 = (xa[i].y - mean) * rstd * g.y + b.y;
+      const float n2 = (xa[i].z - mean) * rstd * g.z + b.z, n3 = (xa[i].w - mean) * rstd * g.w + b.w;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const float4 a = ld4(w1frag + 32 * t * P1 + 8 * i);
+        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, n0, hid[t], 0, 0, 0);
+        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, n1, hid[t], 0, 0, 0);
+        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, n2, hid[t], 0, 0, 0);
+        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, n3, hid[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one piece's weight fragments in flight at a time (register budget)
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t][r] = gelu_erf(hid[t][r]);
+    // ---- out^T = W2 hidden^T: 3 tiles of 32 channels; k pairs = (half 0's row, half 1's row) of each hidden register
+    f32x16 o[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const float4 a = ld4(w2frag + 32 * u * P2 + 32 * t + 8 * g);
+          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, hid[t][4 * g + 0], o[u], 0, 0, 0);
+          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, hid[t][4 * g + 1], o[u], 0, 0, 0);
+          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, hid[t][4 * g + 2], o[u], 0, 0, 0);
+          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hid[t][4 * g + 3], o[u], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- x2 = out + b2 + x1: this lane holds channels c = 32u + 8g + 4hf .. + 3 of its token = piece i = 4u + g of xa
+    const int m = tile * 32 + ml;
+    float4 (&y)[12] = xa;                       // x2 overwrites x1 in place (x1 is not needed afterwards)
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = 4 * u + g;
+        const float4 b = ld4(vec + 2 * C + 8 * i + 4 * hf);
+        y[i].x = o[u][4 * g + 0] + b.x + xa[i].x; y[i].y = o[u][4 * g + 1] + b.y + xa[i].y;
+        y[i].z = o[u][4 * g + 2] + b.z + xa[i].z; y[i].w = o[u][4 * g + 3] + b.w + xa[i].w;
+      }
+    if (m < p.M) {
+      float* dst = p.x2 + static_cast<long>(m) * C + 4 * hf;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) st4(dst + 8 * i, y[i]);
+    }
+    if (p.z) {
+      float mz, rz;
+      ln_rows(y, mz, rz, p.epsz);
+      const bool keep = m < p.M && ((m / p.hw) % p.T) < p.t_keep;
+      if (keep) {
+        float* dz = p.z + static_cast<long>(m) * C + 4 * hf;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const float4 g = ld4(vec + 3 * C + 8 * i + 4 * hf), b = ld4(vec + 4 * C + 8 * i + 4 * hf);
+          st4(dz + 8 * i, make_float4((y[i].x - mz) * rz * g.x + b.x, (y[i].y - mz) * rz * g.y + b.y,
+                                      (y[i].z - mz) * rz * g.z + b.z, (y[i].w - mz) * rz * g.w + b.w));
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xa[i] = xnext[i];
+  }
+}
+
 }  // namespace diffsal
+
+extern "C" int diffsal_mlp_block(const float* x1, const float* g2, const float* be2, float eps2, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, float* x2, float* z, const float* gz,
+                                 const float* bez, float epsz, long M, int C, int hidden, int hw, int T, int t_keep,
+                                 diffsal_stream_t stream) {
+  using namespace diffsal;
+  DS_REQUIRE(x1 && g2 && be2 && w1 && b1 && w2 && b2 && x2, DIFFSAL_E_ARG, "mlp_block: null argument");
+  DS_REQUIRE(C == 96 && hidden == 192, DIFFSAL_E_SHAPE, "mlp_block: built for C = 96, hidden = 192 (got %d, %d)", C, hidden);
+  DS_REQUIRE(M > 0 && M < (1L << 31) / 96, DIFFSAL_E_SHAPE, "mlp_block: M = %ld", M);
+  DS_REQUIRE(!z || (gz && bez && hw > 0 && T > 0 && t_keep > 0), DIFFSAL_E_ARG, "mlp_block: z needs its norm and the frame geometry");
+  DS_REQUIRE(aligned16(x1) && aligned16(x2) && aligned16(w1) && aligned16(w2) && (!z || aligned16(z)), DIFFSAL_E_ALIGN,
+             "mlp_block: misaligned pointer");
+  DS_REQUIRE(x1 != x2, DIFFSAL_E_ARG, "mlp_block: in-place operation is not supported (tiles are prefetched)");
+  MlpBlockArgs a{x1, g2, be2, w1, b1, w2, b2, gz, bez, x2, z, static_cast<int>(M), eps2, epsz, hw > 0 ? hw : 1, T > 0 ? T : 1, t_keep};
+  const size_t lds = (static_cast<size_t>(192) * 100 + 96 * 196 + 5 * 96 + 192) * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  const int n_tiles = static_cast<int>((M + 31) / 32);
+  int grid = 256;
+  if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
+  hipLaunchKernelGGL(mlp_block_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  return check_launch("mlp_block");
+}

@@ -1027,3 +1027,22 @@ def relpos_project_bwd(dextra: Tensor, q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Te
         flat = reduce_partials(part.view(1, chunks, width), 1, chunks, width).view(-1)
     a, b = Rt.numel(), Rt.numel() + Rh.numel()
     return dq, flat[:a].view(Rt.shape), flat[a:b].view(Rh.shape), flat[b:].view(Rw.shape)
+
+
+def mlp_block(x1: Tensor, norm2, fc1, fc2, norm_z=None, frames=None):
+    """Fused norm2 -> fc1 -> GELU -> fc2 -> +x1 (-> norm_z) of the C = 96 TransformerBlock (include/diffsal.h).
+    x1 [..., 96] fp32; norm2 / norm_z: (gamma, beta, eps); fc1 / fc2: (weight, bias); frames = (hw, T, t_keep) limits the
+    rows of z that are written.  -> (x2, z or None)."""
+    lib = _lib.load()
+    Cc = x1.shape[-1]
+    M = x1.numel() // Cc
+    x2 = torch.empty_like(x1)
+    z = torch.empty_like(x1) if norm_z is not None else None
+    hw, T, tk = frames if frames is not None else (M, 1, 1)
+    gz, bz, ez = norm_z if norm_z is not None else (None, None, 0.0)
+    hid = fc1[0].shape[0]
+    with _prof("K10", 4.0 * M * Cc * hid, _nb(x1, x2, z)):
+        _lib.check(lib.diffsal_mlp_block(_p(x1), _p(norm2[0]), _p(norm2[1]), float(norm2[2]), _p(fc1[0]), _p(fc1[1]), _p(fc2[0]),
+                                         _p(fc2[1]), _p(x2), _p(z), _p(gz), _p(bz), float(ez), M, Cc, hid, hw, T, tk, _stream()),
+                   "mlp_block")
+    return x2, z

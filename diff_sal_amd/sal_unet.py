@@ -339,8 +339,9 @@ class SalUNet(nn.Module):
             outs.append(f)
         return outs[::-1]
 
-    def _block(self, i: int, x: Tensor, pk, audio_tok: Optional[Tensor], audio_hw) -> Tensor:
-        """TransformerBlock on frames x [B,T,H,W,C] (transformer.py:124-159, attention.py:86-113)."""
+    def _block(self, i: int, x: Tensor, pk, audio_tok: Optional[Tensor], audio_hw, norm_z=None):
+        """TransformerBlock on frames x [B,T,H,W,C] (transformer.py:124-159, attention.py:86-113) -> (x_out, z) where
+        z = norm_z(x_out) on the frames ReduceTemp reads if the fused C = 96 MLP kernel produced it, else None."""
         B, T, H, W, C = x.shape
         blk = self.invpt_decoder.mid_stages[i].blocks[0]
         a = blk.attn
@@ -361,10 +362,17 @@ class SalUNet(nn.Module):
         o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
         xt = x.view(n9, H * W, C)
         x1 = ops.linear(o, pk[f"s{i}.proj.w"], a.proj.bias, residual=xt)
+        if C == 96 and blk.mlp.fc1.out_features == 192 and x1.dtype == torch.float32 and self._precision() == "fp32":
+            # finest stage: norm2 -> fc1 -> GELU -> fc2 -> +x1 -> norm_mts in ONE launch (both MLP weights live in LDS)
+            x2, z = ops.mlp_block(x1, (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias),
+                                  (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias),
+                                  None if norm_z is None else (norm_z.weight, norm_z.bias, norm_z.eps),
+                                  (H * W, T, self.temporal_list[i]))
+            return x2.view(B, T, H, W, C), (None if z is None else z.view(B, T, H, W, C))
         y = ops.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
         y = ops.linear(y, pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias, act=ACT_GELU)
         x2 = ops.linear(y, pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias, residual=x1)
-        return x2.view(B, T, H, W, C)
+        return x2.view(B, T, H, W, C), None
 
     # Largest batch evaluated in one pass.  The 4-scale sum [B,112,192,768] fp32 is 66 MB per clip and the
     # implicit-GEMM loader addresses each operand with 32-bit byte offsets (< 4 GiB): larger batches
@@ -472,15 +480,16 @@ class SalUNet(nn.Module):
                                    scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU, tag="K12",
                                    residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C))
                 xcur = u.view(Bn, T, 2 * h, 2 * w, C)
-            xcur = self._block(i, xcur, pk, audio_tok, audio_hw)
+            kt = self.temporal_list[i]
+            if (xcur.shape[1] - kt) // kt + 1 != 1:
+                raise RuntimeError(f"ReduceTemp: T={xcur.shape[1]}, kernel/stride {kt} must give exactly one frame")
+            nm = dec.norm_mts[i]
+            xcur, z = self._block(i, xcur, pk, audio_tok, audio_hw, norm_z=nm)
             if taps is not None:
                 taps[f"stage{i}"] = xcur
             Bn, T, H, W, _ = xcur.shape
-            nm = dec.norm_mts[i]
-            z = ops.layernorm(xcur, nm.weight, nm.bias, nm.eps)
-            kt = self.temporal_list[i]
-            if (T - kt) // kt + 1 != 1:
-                raise RuntimeError(f"ReduceTemp: T={T}, kernel/stride {kt} must give exactly one frame")
+            if z is None:
+                z = ops.layernorm(xcur, nm.weight, nm.bias, nm.eps)
             z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
                                tag="K13")
             zs.append(z.view(Bn, H, W, self.ori_embed_dim))

@@ -279,6 +279,17 @@ int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float* wk, const 
                          void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
                          diffsal_stream_t stream);
 
+/* ---- K8 + K10 fused for the finest stage (C = 96, hidden = 192: both MLP weights fit in LDS):
+ *   x2 = x1 + fc2(gelu_erf(fc1(LayerNorm(x1; g2, be2, eps2)) + b1)) + b2 ... i.e. transformer.py:153-157's
+ *        `x = x + mlp(norm2(x))` with Mlp of common_block.py:125-147;
+ *   z  = LayerNorm(x2; gz, bez, epsz) (sal_unet.py:447,473 norm_mts), written only for tokens of frames < t_keep
+ *        (token m belongs to frame (m / hw) % T; ReduceTemp reads frames 0..4 only) -- z may be NULL.
+ * x1, x2, z: [M, C] fp32 tokens; w1 [hidden][C], w2 [C][hidden] as stored by nn.Linear.  One launch instead of four; the
+ * hidden activations never leave registers.  x2 must not alias x1. */
+int diffsal_mlp_block(const float* x1, const float* g2, const float* be2, float eps2, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float* x2, float* z, const float* gz, const float* bez, float epsz,
+                      long M, int C, int hidden, int hw, int T, int t_keep, diffsal_stream_t stream);
+
 /* ---- K11: attention core ------------------------------------------------------------------
  * o[n,l,:] = concat_h softmax_t( q[n,l,h,:] . k[n,t,h,:] * scale ) v[n,t,h,:],  Lk <= 32.
  * R/.../attention.py:97-108 (scale = C^-0.5, quirk Q6). */

@@ -324,3 +324,28 @@ def test_conv_igemm_bf16x3_mode_accuracy(shape):
     print("fp32 err %.2e  bf16x3 err %.2e" % (e32, e3))
     assert e32 < 2e-6 and e3 < 2e-5
     assert not torch.equal(y3, y32)
+
+
+@pytest.mark.parametrize("M,with_z", [(193536 // 8, True), (4001, False), (64, True)])
+def test_mlp_block_fused_kernel(ops, M, with_z):
+    """norm2 -> fc1 -> GELU -> fc2 -> +x1 (-> norm_mts on the kept frames) of the C = 96 TransformerBlock in one launch
+    (transformer.py:153-157, common_block.py:125-147, sal_unet.py:447) vs the same chain in fp32 torch."""
+    C, HID = 96, 192
+    x1 = rnd("mbx", M, C) * 1.3 + 0.1
+    g2, b2n = rnd("mbg", C, scale=0.1) + 1, rnd("mbb", C, scale=0.1)
+    w1, bb1 = rnd("mbw1", HID, C, scale=0.12), rnd("mbb1", HID, scale=0.1)
+    w2, bb2 = rnd("mbw2", C, HID, scale=0.08), rnd("mbb2", C, scale=0.1)
+    gz, bz = rnd("mbgz", C, scale=0.1) + 1, rnd("mbbz", C, scale=0.1)
+    ref_x2 = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (C,), g2, b2n, 1e-5), w1, bb1)), w2, bb2)
+    ref_z = F.layer_norm(ref_x2, (C,), gz, bz, 1e-5)
+    hw, T, keep = 7, 9, 5
+    d = lambda t: t.to(DEV)
+    x2, z = ops.mlp_block(d(x1), (d(g2), d(b2n), 1e-5), (d(w1), d(bb1)), (d(w2), d(bb2)),
+                          (d(gz), d(bz), 1e-5) if with_z else None, (hw, T, keep))
+    assert rel_err(x2, ref_x2) < 2e-5
+    if with_z:
+        rows = torch.arange(M)
+        kept = ((rows // hw) % T) < keep
+        assert rel_err(z.cpu()[kept], ref_z[kept]) < 2e-5
+    else:
+        assert z is None
