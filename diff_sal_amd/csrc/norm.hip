@@ -30,12 +30,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (active) {
     const T* base = x + (static_cast<long>(b) * HW) * C + my_c4 * 4;
-    for (int p = p_begin + my_p; p < p_end; p += pix_per_pass) {
-      const float4 v = ld4(base + static_cast<long>(p) * C);
-      s[0] += v.x; q[0] += v.x * v.x;
-      s[1] += v.y; q[1] += v.y * v.y;
-      s[2] += v.z; q[2] += v.z * v.z;
-      s[3] += v.w; q[3] += v.w * v.w;
+    constexpr int U = 8;   // independent loads in flight (the serial form was one memory round trip per pixel pass)
+    for (int p0 = p_begin + my_p; p0 < p_end; p0 += pix_per_pass * U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + u * pix_per_pass;
+        v[u] = p < p_end ? ld4(base + static_cast<long>(p) * C) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[0] += v[u].x; q[0] += v[u].x * v[u].x;
+        s[1] += v[u].y; q[1] += v[u].y * v[u].y;
+        s[2] += v[u].z; q[2] += v[u].z * v[u].z;
+        s[3] += v[u].w; q[3] += v[u].w * v[u].w;
+      }
     }
   }
   for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.0;
@@ -199,6 +208,64 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(const T* __restrict__ x
   }
 }
 
+// Strip form of the kernel above for C <= 4 G (one float4 per lane): a lane group walks SEG output pixels along a row
+// with a sliding 3x3 window in registers -- 3 new 16-byte loads per output instead of 9, and the nine weight vectors are
+// loaded once per thread instead of once per output (18 -> ~4 vector loads per output: the kernel was bound by L1
+// request rate, not by HBM).
+template <int G, int SEG, typename T>
+__global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restrict__ x, const float* __restrict__ w9,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ out, int N, int H, int W, int C, float eps) {
+  constexpr int GROUPS = 256 / G;
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  const int c = gl * 4;
+  const bool act = c < C;
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = act ? ld4(w9 + t * C + c) : make_float4(0, 0, 0, 0);
+  const int strips_w = (W + SEG - 1) / SEG;
+  const long n_strips = static_cast<long>(N) * H * strips_w;
+  const float4 zero = make_float4(0, 0, 0, 0);
+  for (long sidx = static_cast<long>(blockIdx.x) * GROUPS + gr; sidx < n_strips; sidx += static_cast<long>(gridDim.x) * GROUPS) {
+    const int xs = static_cast<int>(sidx % strips_w) * SEG;
+    const long ny = sidx / strips_w;
+    const int y = static_cast<int>(ny % H);
+    const T* rowp[3];
+    bool rv[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      rv[ky] = act && iy >= 0 && iy < H;
+      rowp[ky] = x + ((ny + (ky - 1)) * W) * C + c;     // row iy of the same image (only dereferenced when valid)
+    }
+    float4 c0[3], c1[3], c2[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      c0[ky] = (rv[ky] && xs - 1 >= 0) ? ld4(rowp[ky] + static_cast<long>(xs - 1) * C) : zero;
+      c1[ky] = rv[ky] ? ld4(rowp[ky] + static_cast<long>(xs) * C) : zero;
+    }
+    const int xe = min(xs + SEG, W);
+    for (int xx = xs; xx < xe; ++xx) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) c2[ky] = (rv[ky] && xx + 1 < W) ? ld4(rowp[ky] + static_cast<long>(xx + 1) * C) : zero;
+      float4 v[1];
+      v[0] = zero;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float4 a0 = c0[ky], a1 = c1[ky], a2 = c2[ky];
+        const float4 w0 = w[ky * 3 + 0], w1 = w[ky * 3 + 1], w2 = w[ky * 3 + 2];
+        v[0].x = fmaf(a2.x, w2.x, fmaf(a1.x, w1.x, fmaf(a0.x, w0.x, v[0].x)));
+        v[0].y = fmaf(a2.y, w2.y, fmaf(a1.y, w1.y, fmaf(a0.y, w0.y, v[0].y)));
+        v[0].z = fmaf(a2.z, w2.z, fmaf(a1.z, w1.z, fmaf(a0.z, w0.z, v[0].z)));
+        v[0].w = fmaf(a2.w, w2.w, fmaf(a1.w, w1.w, fmaf(a0.w, w0.w, v[0].w)));
+      }
+      ln_rows_finish<G, 1, T>(v, gl, C, gamma, beta, eps, out + (ny * W + xx) * C);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
+    }
+  }
+}
+
 // depthwise k x k, stride k, no padding, + LayerNorm, for K and V at once: one workgroup per pooled token.
 // R/.../attention.py:49-76,88-95.  Threads = (256/G position lanes) x (G channel lanes).
 template <int G, int NV, typename T>
@@ -347,6 +414,15 @@ template <typename T>
 static int dwconv3_ln_t(const T* x, const float* w9, const float* gamma, const float* beta, T* out, int N, int H, int W,
                         int C, float eps, hipStream_t s) {
   const long M = static_cast<long>(N) * H * W;
+  if (C <= 256 && W >= 16) {   // one float4 per lane: sliding-window strips along the row
+    constexpr int SEG = 8;
+    const long n_strips = static_cast<long>(N) * H * ((W + SEG - 1) / SEG);
+#define CALLS(G) \
+  hipLaunchKernelGGL((dwconv3_ln_strip_kernel<G, SEG, T>), dim3(row_grid(n_strips, 256 / G)), dim3(256), 0, s, x, w9, gamma, beta, out, N, H, W, C, eps)
+    if (C <= 32) { CALLS(8); } else if (C <= 64) { CALLS(16); } else if (C <= 128) { CALLS(32); } else { CALLS(64); }
+#undef CALLS
+    return check_launch("dwconv3_ln(strip)");
+  }
 #define CALL(G, NV)                                                                                                 \
   hipLaunchKernelGGL((dwconv3_ln_kernel<G, NV, T>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, w9, gamma, beta, \
                      out, N, H, W, C, eps)

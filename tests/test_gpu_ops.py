@@ -174,7 +174,7 @@ def test_layernorm(ops, C):
     assert rel_err(got, F.layer_norm(x, (C,), g, b, 1e-5)) < 2e-5
 
 
-@pytest.mark.parametrize("C,H,W,k", [(96, 16, 32, 16), (192, 8, 12, 4), (768, 7, 12, 2), (32, 16, 32, 16)])
+@pytest.mark.parametrize("C,H,W,k", [(96, 16, 32, 16), (192, 8, 12, 4), (768, 7, 12, 2), (32, 16, 32, 16), (128, 10, 27, 2), (192, 28, 48, 8)])
 def test_depthwise_projections(ops, C, H, W, k):
     n = 3
     xn, xa = rnd("dq%d" % C, n, C, H, W), rnd("da%d" % C, n, C, H, W)
