@@ -13,6 +13,7 @@
 // Replaces the same reference call sites as diffsal_conv_igemm (see include/diffsal.h); selected by
 // diffsal_conv_desc.dtype.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -131,14 +132,17 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
     b_voff[j] = static_cast<unsigned>(n * p.K + l8 * 8) * 2u;
   }
 
-  float4 ra[A_PASSES], rb[B_PASSES];
+  // Global loads run THREE stages ahead of the matrix cores (two register sets in flight + the stage being parked):
+  // a stage's MFMA phase is ~8x shorter than in the fp32 kernel, so two stages ahead no longer covers an L2 round trip.
+  float4 ra[2][A_PASSES], rb[2][B_PASSES];
   const int KT32 = p.K / SUBK;                 // sub-slices in K
   const int n_stages = (KT32 + 1) / 2;
   const int st_begin = split * p.st_per_split;
   const int st_end = min(n_stages, st_begin + p.st_per_split);
   const int nst = st_end - st_begin;
 
-  auto issue_loads = [&](int st, bool live) {
+  auto issue_loads = [&](int st, bool live, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     // the two sub-slices of this stage: wave-uniform scalars, then a per-lane pick
     const int k0 = 2 * st, k1 = 2 * st + 1;
     const int c0 = k0 / p.taps, t0 = k0 - c0 * p.taps;
@@ -155,18 +159,19 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
       const unsigned oob = ((a_valid[j] >> tap) & 1u) - 1u;
-      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[j] + delta) | oob | dead, 0, 0));
+      ra[SET][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (a_voff[j] + delta) | oob | dead, 0, 0));
     }
     const unsigned kofs = static_cast<unsigned>(st * STK) * 2u;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j)
-      rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
+      rb[SET][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[j] + kofs) | dead, 0, 0));
   };
-  auto store_tile = [&](float* stage) {
+  auto store_tile = [&](float* stage, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
 #pragma unroll
-    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH16 + lcol_dw], ra[j]);
+    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH16 + lcol_dw], ra[SET][j]);
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH16 + lcol_dw], rb[j]);
+    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH16 + lcol_dw], rb[SET][j]);
   };
 
   f32x16 acc[TM][TN];
@@ -197,29 +202,25 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
         acc[i][j] = Mma16<T>::run(__builtin_bit_cast(frag_t, fa[set][i]), __builtin_bit_cast(frag_t, fb[set][j]), acc[i][j]);
   };
 
-  // prologue: stages 0 and 1 in flight together
-  issue_loads(st_begin + 1, nst > 1);
-  float4 ta[A_PASSES], tb[B_PASSES];
-#pragma unroll
-  for (int j = 0; j < A_PASSES; ++j) ta[j] = ra[j];
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) tb[j] = rb[j];
-  issue_loads(st_begin, true);
-  store_tile(smem);
-#pragma unroll
-  for (int j = 0; j < A_PASSES; ++j) ra[j] = ta[j];
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) rb[j] = tb[j];
+  // prologue: stages 0, 1, 2 in flight together; stage 0 is parked, 1 and 2 stay in the two register sets
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  issue_loads(st_begin, true, S0{});
+  issue_loads(st_begin + 1, nst > 1, S1{});
+  store_tile(smem, S0{});                 // waits for stage 0 only (vmcnt is in issue order)
+  issue_loads(st_begin + 2, nst > 2, S0{});
   __syncthreads();
   load_frags(smem, 0, 0);
-  for (int it = 0; it < nst; ++it) {
+  // iteration `it` computes stage it from LDS, parks stage it+1 (register set (it+1) & 1) and re-uses that set for
+  // stage it+3; the set index must be a compile-time constant (register arrays), hence the two-way unrolled loop
+  auto step = [&](int it, auto park_c) {
     float* cur = smem + (it & 1) * STAGE;
     float* nxt = smem + ((it & 1) ^ 1) * STAGE;
     load_frags(cur, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     do_mfmas(0);
-    store_tile(nxt);
-    issue_loads(st_begin + it + 2, it + 2 < nst);
+    store_tile(nxt, park_c);
+    issue_loads(st_begin + it + 3, it + 3 < nst, park_c);
     __builtin_amdgcn_sched_barrier(0);
     load_frags(cur, 2, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -234,6 +235,14 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
     __builtin_amdgcn_sched_barrier(0);
     do_mfmas(1);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int it = 0;
+    for (; it + 1 < nst; it += 2) {
+      step(it, S1{});       // stage it+1 sits in set 1 (odd stages), then set 1 fetches stage it+3
+      step(it + 1, S0{});   // stage it+2 sits in set 0
+    }
+    if (it < nst) step(it, S1{});
   }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
