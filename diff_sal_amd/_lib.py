@@ -74,6 +74,7 @@ SIGNATURES = {
     "diffsal_dwconv3_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_dwpool_ln_kv": (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_mlp_block": (c_i, [c_f, c_f, c_f, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, C.c_long, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_block16": (c_i, [c_f] * 6 + [c_fl] + [c_f] * 8 + [c_fl, C.c_long] + [c_i] * 6 + [c_f]),
     "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "diffsal_cast": (c_i, [c_f, c_i, c_f, c_i, C.c_long, c_f]),

@@ -1046,3 +1046,23 @@ def mlp_block(x1: Tensor, norm2, fc1, fc2, norm_z=None, frames=None):
                                          _p(fc2[1]), _p(x2), _p(z), _p(gz), _p(bz), float(ez), M, Cc, hid, hw, T, tk, _stream()),
                    "mlp_block")
     return x2, z
+
+
+def block16(o: Tensor, x: Tensor, proj, norm2, fc1, fc2, norm_z=None, frames=None):
+    """16-bit storage: x1 = x + proj(o); x2 = x1 + fc2(gelu(fc1(norm2(x1)))); z = norm_z(x2) on the kept frames -- one
+    launch (include/diffsal.h).  proj / fc1 / fc2: (weight in the storage type, fp32 bias); norms: (gamma, beta, eps)."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    dt = _dt(x)
+    x2 = torch.empty_like(x)
+    z = torch.empty_like(x) if norm_z is not None else None
+    hw, T, tk = frames if frames is not None else (M, 1, 1)
+    gz, bz, ez = norm_z if norm_z is not None else (None, None, 0.0)
+    hid = fc1[0].shape[0]
+    with _prof("K10", 2.0 * M * Cc * (Cc + 2 * hid), _nb(o, x, x2, z)):
+        _lib.check(lib.diffsal_block16(_pa(o, dt), _pa(x, dt), _pa(proj[0], dt), _p(proj[1]), _p(norm2[0]), _p(norm2[1]), float(norm2[2]),
+                                       _pa(fc1[0], dt), _p(fc1[1]), _pa(fc2[0], dt), _p(fc2[1]), x2.data_ptr(),
+                                       None if z is None else z.data_ptr(), _p(gz), _p(bz), float(ez), M, Cc, hid, hw, T, tk, dt,
+                                       _stream()), "block16")
+    return x2, z

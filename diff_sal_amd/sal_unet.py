@@ -361,6 +361,13 @@ class SalUNet(nn.Module):
         vv = ops.linear(vv, pk[f"s{i}.v.w"], a.proj_v.bias)
         o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
         xt = x.view(n9, H * W, C)
+        if C == 96 and blk.mlp.fc1.out_features == 192 and x.dtype != torch.float32:
+            # finest stage on 16-bit storage: proj + residual + norm2 + MLP + residual + norm_mts in ONE launch
+            x2, z = ops.block16(o, xt, (pk[f"s{i}.proj.w"], a.proj.bias), (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
+                                (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias), (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias),
+                                None if norm_z is None else (norm_z.weight, norm_z.bias, norm_z.eps),
+                                (H * W, T, self.temporal_list[i]))
+            return x2.view(B, T, H, W, C), (None if z is None else z.view(B, T, H, W, C))
         x1 = ops.linear(o, pk[f"s{i}.proj.w"], a.proj.bias, residual=xt)
         if C == 96 and blk.mlp.fc1.out_features == 192 and x1.dtype == torch.float32 and self._precision() == "fp32":
             # finest stage: norm2 -> fc1 -> GELU -> fc2 -> +x1 -> norm_mts in ONE launch (both MLP weights live in LDS)

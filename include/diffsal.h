@@ -290,6 +290,14 @@ int diffsal_mlp_block(const float* x1, const float* g2, const float* be2, float 
                       const float* w2, const float* b2, float* x2, float* z, const float* gz, const float* bez, float epsz,
                       long M, int C, int hidden, int hw, int T, int t_keep, diffsal_stream_t stream);
 
+/* The same stage on bf16 / fp16 storage: all three weight matrices fit in LDS, so proj + residual is fused in as well:
+ *   x1 = x + o wp^T + bp;  x2 = x1 + fc2(gelu(fc1(LayerNorm(x1))));  z = LayerNorm(x2) on frames < t_keep
+ * (attention.py:110, transformer.py:151-157, sal_unet.py:447).  o, x, wp, w1, w2, x2, z: 16-bit (dtype); vectors fp32. */
+int diffsal_block16(const void* o, const void* x, const void* wp, const float* bp, const float* g2, const float* be2, float eps2,
+                    const void* w1, const float* b1, const void* w2, const float* b2, void* x2, void* z, const float* gz,
+                    const float* bez, float epsz, long M, int C, int hidden, int hw, int T, int t_keep, int dtype,
+                    diffsal_stream_t stream);
+
 /* ---- K11: attention core ------------------------------------------------------------------
  * o[n,l,:] = concat_h softmax_t( q[n,l,h,:] . k[n,t,h,:] * scale ) v[n,t,h,:],  Lk <= 32.
  * R/.../attention.py:97-108 (scale = C^-0.5, quirk Q6). */

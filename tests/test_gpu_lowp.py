@@ -280,3 +280,34 @@ def test_lowp_training_is_refused():
     x, feats, _ = orc.synth_inputs(cfg, 1, False)
     with pytest.raises(RuntimeError, match="inference option"):
         net(x.to(DEV), torch.tensor([1], device=DEV), [f.to(DEV) for f in feats])
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("M,with_z", [(24001, True), (77, False)])
+def test_block16_fused_kernel(ops, dname, M, with_z):
+    """proj + residual + norm2 + fc1 + GELU + fc2 + residual (+ norm_mts) of the C = 96 stage in one launch on 16-bit storage,
+    vs the same chain in fp32 torch on the same rounded inputs / weights (the hidden activations are rounded once to the
+    storage type inside the kernel, as the unfused path does when it stores them)."""
+    dt = DTYPES[dname]
+    C, HID = 96, 192
+    o, x = q(rnd("b16o", M, C), dt), q(rnd("b16x", M, C) * 1.2, dt)
+    wp, bp = q(rnd("b16wp", C, C, scale=0.1), dt), rnd("b16bp", C, scale=0.1)
+    g2, be2 = rnd("b16g", C, scale=0.1) + 1, rnd("b16b", C, scale=0.1)
+    w1, b1 = q(rnd("b16w1", HID, C, scale=0.12), dt), rnd("b16b1", HID, scale=0.1)
+    w2, b2 = q(rnd("b16w2", C, HID, scale=0.08), dt), rnd("b16b2", C, scale=0.1)
+    gz, bz = rnd("b16gz", C, scale=0.1) + 1, rnd("b16bz", C, scale=0.1)
+    x1 = x + F.linear(o, wp, bp)
+    ref_x2 = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (C,), g2, be2, 1e-5), w1, b1)), w2, b2)
+    ref_z = F.layer_norm(ref_x2, (C,), gz, bz, 1e-5)
+    d = lambda t: t.to(DEV)
+    dq_ = lambda t: t.to(DEV).to(dt)
+    hw, T, keep = 7, 9, 5
+    x2, z = ops.block16(dq_(o), dq_(x), (dq_(wp), d(bp)), (d(g2), d(be2), 1e-5), (dq_(w1), d(b1)), (dq_(w2), d(b2)),
+                        (d(gz), d(bz), 1e-5) if with_z else None, (hw, T, keep))
+    assert x2.dtype == dt
+    # three chained GEMMs with 16-bit operands: the normalised activations and the hidden layer are rounded to the storage
+    # type before they are multiplied (2-3 roundings along the path instead of 1)
+    assert rel_err(x2, ref_x2) < 3 * OP_RTOL[dname]
+    if with_z:
+        kept = ((torch.arange(M) // hw) % T) < keep
+        assert rel_err(z.float().cpu()[kept], ref_z[kept]) < 3 * OP_RTOL[dname]
