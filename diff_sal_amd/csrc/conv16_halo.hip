@@ -1,0 +1,317 @@
+// 3x3 stride-1 "same" convolution (dilation 1 or 2) on bf16 / fp16 storage with an LDS halo patch.
+//
+// The generic 16-bit implicit-GEMM kernel (igemm16.hip) fetches the A operand once per tap: nine 64-byte runs per pixel
+// and 32-channel chunk travel L2 -> L1 -> registers -> LDS, and that delivery path (~27 B/clk/CU), not the matrix pipe,
+// sets its speed (36 % of the 16-bit MFMA peak at best for a 128 x 96 tile).  Here a workgroup owns a TH x TW block of
+// output pixels and stages, per 32-channel chunk, the (TH + 2d) x (TW + 2d) input patch ONCE; all nine taps read their
+// A fragments from it with a constant LDS displacement (tap offset), so the A bytes per MFMA drop ~6x and a 512-pixel
+// block amortises the nine weight slices (9 x Cout_tile x 64 B per chunk) over twice as many pixels as before.
+//
+//   tile A: 16 x 32 pixels, 8 wavefronts (each 2 image rows of 32 pixels), patch up to 20 x 36 pixels
+//   tile B: 16 x 16 pixels, 4 wavefronts (each 4 image rows of 16 pixels), patch up to 20 x 20 pixels
+//   N tile: 96 or 128 output channels (TN = 3 / 4 MFMA column tiles)
+//
+// One LDS stage (patch + nine weight slices, 80-byte pixel pitch: conflict-free ds_read_b128 for 16 consecutive pixels);
+// the next chunk's loads are issued into registers before the 108 / 144 MFMAs of the current chunk and parked behind a
+// barrier afterwards.  Same packed weight layout [Cout][Cin/32][9][32], same fused epilogue (bias, BN affine, per-image
+// vector, activation, residual) and the same fp32 accumulation as the other implicit-GEMM kernels.  Selected by
+// diffsal_conv_igemm for 16-bit storage when the shape qualifies (UpEmbed, ResnetBlock and mt_proj convolutions:
+// R/models/saliency_decoder/common_block.py:196-216, sal_unet.py:104-112,407).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace diffsal {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct HaloMma;
+template <> struct HaloMma<__bf16> {
+  typedef hbf16x8 vec;
+  static __device__ __forceinline__ f32x16 run(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct HaloMma<_Float16> {
+  typedef hf16x8 vec;
+  static __device__ __forceinline__ f32x16 run(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T>
+struct HaloArgs {
+  const T* in;
+  const T* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* rowvec;
+  const T* residual;
+  T* out;
+  int N, H, W, Cin, Cout, K;   // K = 9 * Cin
+  int dil, act, rowvec_ld;
+  int tiles_x, tiles_y, tiles_n;
+};
+
+constexpr int HP = 40;   // elements per staged pixel / weight row: 32 data + 8 pad (80 bytes)
+
+template <int TW, int NW, int TN, typename T>
+__global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
+  typedef typename HaloMma<T>::vec vec;
+  constexpr int TH = 16;
+  constexpr int NT = NW * 64;
+  constexpr int RPM = 32 / TW;                     // image rows per 32-pixel MFMA tile
+  constexpr int TM = (TH * TW) / (NW * 32);        // MFMA row tiles per wavefront
+  static_assert(TM == 2, "each wavefront owns 64 pixels");
+  constexpr int PHM = TH + 4, PWM = TW + 4;        // patch extent for dilation 2
+  constexpr int BN = TN * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T* Ps = reinterpret_cast<T*>(smraw);             // [PH][PW][HP]
+  T* Bs = Ps + PHM * PWM * HP;                     // [9][BN][HP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // block -> (image, tile_y, tile_x, n tile); consecutive blocks share the patch's neighbourhood and the same weights
+  int b = blockIdx.x;
+  const int tn = b % p.tiles_n; b /= p.tiles_n;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int img = b / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int d = p.dil;
+  const int PH = TH + 2 * d, PW = TW + 2 * d;
+  const int n_chunks = p.Cin >> 5;
+
+  // ---- loader bookkeeping: 16-byte pieces; patch piece = (pixel, quarter), weight piece = (co, tap, quarter).
+  // Branch-free: buffer loads return zero for out-of-range offsets, so padding / tails carry offset 0x80000000.
+  constexpr int A_MAX = (PHM * PWM * 4 + NT - 1) / NT;
+  constexpr int B_PER = (9 * BN * 4 + NT - 1) / NT;
+  constexpr unsigned DEAD = 0x80000000u;
+  const T* in_img = p.in + static_cast<long>(img) * p.H * p.W * p.Cin;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(in_img), 0, p.H * p.W * p.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(p.w), 0, p.Cout * p.K * 2, 0x00020000);
+  unsigned a_voff[A_MAX], b_voff[B_PER];
+  const int a_pieces = PH * PW * 4;
+#pragma unroll
+  for (int i = 0; i < A_MAX; ++i) {
+    const int idx = tid + i * NT;
+    const int q = idx & 3, pix = idx >> 2;
+    const int pr = pix / PW, pc = pix - pr * PW;
+    const int gy = y0 - d + pr, gx = x0 - d + pc;
+    const bool ok = idx < a_pieces && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_voff[i] = ok ? static_cast<unsigned>(((gy * p.W + gx) * p.Cin + q * 8) * 2) : DEAD;
+  }
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int idx = tid + i * NT;
+    const int co = idx / 36, r = idx - co * 36;            // 36 pieces = 9 taps x 4 quarters, contiguous in memory
+    const bool ok = idx < 9 * BN * 4 && n0 + co < p.Cout;
+    b_voff[i] = ok ? static_cast<unsigned>(((n0 + co) * p.K + r * 8) * 2) : DEAD;
+  }
+  uint4 ra[A_MAX], rb[B_PER];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i)
+      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i] + chunk * 64, 0, 0));
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i] + chunk * 576, 0, 0));
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_MAX; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < PHM * PWM * 4) *reinterpret_cast<uint4*>(Ps + (idx >> 2) * HP + (idx & 3) * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < 9 * BN * 4) {
+        const int co = idx / 36, r = idx - co * 36;
+        const int tap = r >> 2, q = r & 3;
+        *reinterpret_cast<uint4*>(Bs + (tap * BN + co) * HP + q * 8) = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment addressing: lane -> pixel (py, px) of its MFMA row tile; k half = lane >> 5
+  const int lp = lane & 31, kh = lane >> 5;
+  int a_base[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int py = (wave * TM + i) * RPM + lp / TW, px = lp % TW;
+    a_base[i] = (py * PW + px) * HP + kh * 8;
+  }
+  const int b_base = lp * HP + kh * 8;
+
+  fetch(0);
+  park();
+  __syncthreads();
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    if (chunk + 1 < n_chunks) fetch(chunk + 1);       // lands during this chunk's 18 x TM x TN MFMAs
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int toff = (ky * d * PW + kx * d) * HP;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        vec fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const vec*>(Ps + a_base[i] + toff + kk * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const vec*>(Bs + (tap * BN + j * 32) * HP + b_base + kk * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = HaloMma<T>::run(fb[j], fa[i], acc[i][j]);   // D^T: rows = channels, cols = pixels
+      }
+    }
+    __syncthreads();                                  // every wavefront is done with this chunk's LDS image
+    if (chunk + 1 < n_chunks) {
+      park();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  The weights went in as the MFMA "A" operand, so a lane holds, for pixel lane & 31 of its row tile,
+  // output channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5): four consecutive channels per register quad.  The raw fp32 sums
+  // are staged through the (now idle) LDS in two passes of half the block and leave as coalesced 8-byte stores with the
+  // per-channel affine, per-image vector, activation and residual applied on the way (one rounding, like igemm16.hip).
+  constexpr int CP = BN + 4;                       // fp32 staging pitch: 16-byte stores of 8 consecutive lanes hit 8 x 4 distinct banks
+  constexpr int PASS_PIX = NW * 32;                // pixels per pass (half of the block)
+  constexpr int C4 = BN / 4;
+  float* Cs = reinterpret_cast<float*>(smraw);
+  const T* __restrict__ resid = p.residual;
+  const float* __restrict__ rowv = p.rowvec;
+  T* __restrict__ outp = p.out;
+  const int hq = (lane >> 5) * 4;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (wave / (NW / 2) == ps) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int pp = ((wave % (NW / 2)) * TM + i) * 32 + lp;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(Cs + pp * CP + j * 32 + g * 8 + hq) =
+                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < PASS_PIX * C4 / NT; ++k) {
+      const int idx = tid + k * NT;
+      const int pp = idx / C4, c4 = idx - pp * C4;
+      const int mt = ps * (NW / 2) * TM + (pp >> 5), pl = pp & 31;
+      const int gy = y0 + mt * RPM + pl / TW, gx = x0 + pl % TW;
+      const int n = n0 + c4 * 4;
+      if (gy >= p.H || gx >= p.W || n >= p.Cout) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(Cs + pp * CP + c4 * 4);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      if (p.scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+      }
+      if (rowv) {
+        const float4 t = *reinterpret_cast<const float4*>(rowv + static_cast<long>(img) * p.rowvec_ld + n);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+      if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+      }
+      const long o = ((static_cast<long>(img) * p.H + gy) * p.W + gx) * p.Cout + n;
+      if (resid) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(resid + o);
+        T rt[4];
+        __builtin_memcpy(rt, &rr, 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += static_cast<float>(rt[e]);
+      }
+      T ot[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ot[e] = static_cast<T>(v[e]);
+      uint2 ov;
+      __builtin_memcpy(&ov, ot, 8);
+      *reinterpret_cast<uint2*>(outp + o) = ov;
+    }
+    if (ps == 0) __syncthreads();
+  }
+}
+
+template <int TW, int NW, int TN, typename T>
+static int launch_halo(HaloArgs<T>& a, hipStream_t s) {
+  constexpr int TH = 16;
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = (a.H + TH - 1) / TH;
+  a.tiles_n = (a.Cout + TN * 32 - 1) / (TN * 32);
+  const size_t lds = (static_cast<size_t>(TH + 4) * (TW + 4) + 9 * TN * 32) * HP * sizeof(T);
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_halo_kernel<TW, NW, TN, T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  const long blocks = static_cast<long>(a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
+  hipLaunchKernelGGL((conv16_halo_kernel<TW, NW, TN, T>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, s, a);
+  return check_launch("diffsal_conv_igemm(16-bit halo)");
+}
+
+template <typename T>
+static int run_halo(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                    const float* shift, const float* rowvec, const void* residual, void* out, hipStream_t s) {
+  HaloArgs<T> a;
+  a.in = static_cast<const T*>(in); a.w = static_cast<const T*>(w); a.bias = bias; a.scale = scale; a.shift = shift;
+  a.rowvec = rowvec; a.residual = static_cast<const T*>(residual); a.out = static_cast<T*>(out);
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.K = 9 * d->Cin; a.dil = d->dil_h; a.act = d->act;
+  a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
+  const bool n128 = (d->Cout % 96 != 0) && (d->Cout % 128 == 0);   // 96-wide N tiles unless only 128 divides Cout
+  const bool wide = (d->W % 32 == 0) || d->W >= 64;       // 16 x 32 pixel tiles when the width fills them
+  if (wide) return n128 ? launch_halo<32, 8, 4, T>(a, s) : launch_halo<32, 8, 3, T>(a, s);
+  return n128 ? launch_halo<16, 4, 4, T>(a, s) : launch_halo<16, 4, 3, T>(a, s);
+}
+
+// 1 if the halo kernel handles this descriptor (16-bit storage assumed), else 0
+int conv16_halo_applies(const diffsal_conv_desc* d) {
+  bool force = false;
+  if (const char* e = getenv("DIFFSAL_NO_HALO")) { if (e[0] == '1') return 0; }
+  if (const char* e = getenv("DIFFSAL_FORCE_HALO")) force = (e[0] == '1');
+  return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
+         (d->dil_h == 1 || d->dil_h == 2) && d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H && d->Wo == d->W &&
+         d->Cin % 32 == 0 && d->Cout % 4 == 0 && d->H >= 8 && d->W >= 16 && d->Cout >= 64 &&
+         (force || static_cast<long>(d->N) * d->H * d->W >= 80000);   // below that the generic tiles fill the chip better
+}
+
+// the coalesced epilogue moves 8-byte output / residual pieces and 16-byte parameter pieces
+int conv16_halo_pointers_ok(const diffsal_conv_desc* d, const float* bias, const float* scale, const float* shift,
+                            const float* rowvec, const void* residual, const void* out) {
+  auto al = [](const void* q, uintptr_t m) { return (reinterpret_cast<uintptr_t>(q) & m) == 0; };
+  const int ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
+  return al(out, 7) && al(residual, 7) && al(bias, 15) && al(scale, 15) && al(shift, 15) && al(rowvec, 15) && (!rowvec || ld % 4 == 0);
+}
+
+int conv16_halo_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                       const float* shift, const float* rowvec, const void* residual, void* out, hipStream_t s) {
+  if (d->dtype == DIFFSAL_BF16) return run_halo<__bf16>(d, in, w, bias, scale, shift, rowvec, residual, out, s);
+  return run_halo<_Float16>(d, in, w, bias, scale, shift, rowvec, residual, out, s);
+}
+
+}  // namespace diffsal

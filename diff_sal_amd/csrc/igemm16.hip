@@ -54,6 +54,7 @@ struct Igemm16Args {
   int n_tiles_n, n_tiles;
   unsigned in_bytes, w_bytes;
   int splits, st_per_split;  // split-K over 64-k stages
+  int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is aligned for 8 / 16-byte pieces
   float* partial;            // [splits][M][Cout] fp32 partial sums when splits > 1
 };
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = Mma16<T>::run(__builtin_bit_cast(frag_t, fa[set][i]), __builtin_bit_cast(frag_t, fb[set][j]), acc[i][j]);
+        acc[i][j] = Mma16<T>::run(__builtin_bit_cast(frag_t, fb[set][j]), __builtin_bit_cast(frag_t, fa[set][i]), acc[i][j]);  // D^T
   };
 
   // prologue: stages 0, 1, 2 in flight together; stage 0 is parked, 1 and 2 stay in the two register sets
@@ -245,62 +246,100 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
     if (it < nst) step(it, S1{});
   }
 
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // ---- epilogue.  The weight fragment is the MFMA "A" operand, so D is the transposed tile: a lane holds, for output
+  // row (pixel) lane & 31 of its 32-row block, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- register quads of four
+  // consecutive channels.  Two-byte stores straight from that layout (what round 2 started with) cost more than the
+  // whole K loop on the M ~ 2e5 layers, so the fp32 sums are staged through the idle LDS stages, NPASS row groups at a
+  // time, and leave as coalesced 8-byte (16-bit output) / 16-byte (split-K slab) pieces with the epilogue applied once.
   const int col_l = lane & 31;
-  const int row_h = (lane >> 5) * 4;
-  if (p.splits > 1) {
-    float* part = p.partial + static_cast<long>(split) * p.M * p.Cout;
+  const int hq = (lane >> 5) * 4;
+  const T* __restrict__ resid = p.residual;
+  const float* __restrict__ rowv = p.rowvec;
+  T* __restrict__ outp = p.out;
+  float* part = p.splits > 1 ? p.partial + static_cast<long>(split) * p.M * p.Cout : nullptr;
+  if (!p.vec_epilogue) {   // Cout % 4 != 0 or pointers not 8 / 16-byte aligned: scalar stores from the register layout
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + col_l;
-      if (n >= p.Cout) continue;
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + col_l;
+      if (m >= p.M) continue;
+      const int img = rowv ? m / HoWo : 0;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + (wm * TM + i) * 32 + row_h;
+      for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < p.M) part[static_cast<long>(m) * p.Cout + n] = acc[i][j][r];
+          const int n = n0 + (wn * TN + j) * 32 + (r & 3) + 8 * (r >> 2) + hq;
+          if (n >= p.Cout) continue;
+          const long o = static_cast<long>(m) * p.Cout + n;
+          float v = acc[i][j][r];
+          if (part) { part[o] = v; continue; }
+          if (p.bias) v += p.bias[n];
+          if (p.scale) v = v * p.scale[n] + (p.shift ? p.shift[n] : 0.f);
+          if (rowv) v += rowv[static_cast<long>(img) * p.rowvec_ld + n];
+          if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
+          else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
+          if (resid) v += static_cast<float>(resid[o]);
+          outp[o] = static_cast<T>(v);
         }
       }
     }
     return;
   }
-  const T* __restrict__ resid = p.residual;
-  const float* __restrict__ rowv = p.rowvec;
-  T* __restrict__ outp = p.out;
+  constexpr int CP = BN + 4;                                  // fp32 staging pitch (dwords): conflict-free 16-byte stores
+  constexpr int NPASS = (BM * CP <= 2 * STAGE) ? 1 : ((BM / 2) * CP <= 2 * STAGE ? 2 : 4);
+  static_assert(WM % NPASS == 0 && (BM / NPASS) * CP <= 2 * STAGE, "staging passes must split the wave rows");
+  constexpr int RP = BM / NPASS;                              // rows per pass
+  constexpr int C4 = BN / 4;
+  __syncthreads();                                            // the last stage's fragment reads are done
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + col_l;
-    if (n >= p.Cout) continue;
-    const float bi = p.bias ? p.bias[n] : 0.f;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float sh = p.shift ? p.shift[n] : 0.f;
+  for (int ps = 0; ps < NPASS; ++ps) {
+    if (wm / (WM / NPASS) == ps) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32 + row_h;
-      float res[16];
+      for (int i = 0; i < TM; ++i) {
+        const int row = ((wm % (WM / NPASS)) * TM + i) * 32 + col_l;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = mb + (r & 3) + 8 * (r >> 2);
-        m = m < p.M ? m : p.M - 1;
-        res[r] = resid ? static_cast<float>(resid[static_cast<long>(m) * p.Cout + n]) : 0.f;
-      }
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m >= p.M) continue;
-        float v = acc[i][j][r];
-        v += bi;
-        if (p.scale) v = v * sc + sh;
-        if (rowv) v += rowv[static_cast<long>(m / HoWo) * p.rowvec_ld + n];
-        if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
-        else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
-        v += res[r];
-        outp[static_cast<long>(m) * p.Cout + n] = static_cast<T>(v);
+          for (int g = 0; g < 4; ++g)
+            st4(smem + row * CP + (wn * TN + j) * 32 + g * 8 + hq,
+                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
       }
     }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < RP * C4 / 256; ++k) {
+      const int idx = tid + k * 256;
+      const int row = idx / C4, c4 = idx - row * C4;
+      const int m = m0 + ps * RP + row, n = n0 + c4 * 4;
+      if (m >= p.M || n >= p.Cout) continue;
+      const float4 a4 = ld4(smem + row * CP + c4 * 4);
+      const long o = static_cast<long>(m) * p.Cout + n;
+      if (part) { st4(part + o, a4); continue; }
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (p.bias) { const float4 t = ld4(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      if (p.scale) {
+        const float4 sc = ld4(p.scale + n);
+        const float4 sh = p.shift ? ld4(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+      }
+      if (rowv) {
+        const float4 t = ld4(rowv + static_cast<long>(m / HoWo) * p.rowvec_ld + n);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+      if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+      }
+      if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    if (ps + 1 < NPASS) __syncthreads();
   }
 }
 
@@ -396,6 +435,13 @@ static int launch16(Igemm16Args<T>& a, hipStream_t s) {
   return check_launch("diffsal_conv_igemm(16-bit split-K reduce)");
 }
 
+// conv16_halo.hip: LDS-halo kernel for 3x3 stride-1 "same" convolutions
+int conv16_halo_applies(const diffsal_conv_desc* d);
+int conv16_halo_pointers_ok(const diffsal_conv_desc* d, const float* bias, const float* scale, const float* shift,
+                            const float* rowvec, const void* residual, const void* out);
+int conv16_halo_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                       const float* shift, const float* rowvec, const void* residual, void* out, hipStream_t s);
+
 static Plan16 plan_for(const diffsal_conv_desc* d) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   Plan16 pl = choose_plan16(M, d->Cout, d->KH * d->KW * d->Cin);
@@ -403,10 +449,12 @@ static Plan16 plan_for(const diffsal_conv_desc* d) {
     pl.cfg = atoi(e) % kNumCfgs16;
     pl.splits = 1;
   }
+  if (conv16_halo_applies(d)) pl.splits = 1;   // halo-eligible shapes report no workspace; keep the pointer-alignment fallback valid
   return pl;
 }
 
 size_t igemm16_ws_bytes(const diffsal_conv_desc* d) {
+  if (conv16_halo_applies(d)) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const Plan16 pl = plan_for(d);
   return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
@@ -442,6 +490,11 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
                need, ws_bytes);
     a.partial = static_cast<float*>(ws);
   }
+  {
+    auto al = [](const void* q, uintptr_t m) { return (reinterpret_cast<uintptr_t>(q) & m) == 0; };
+    a.vec_epilogue = d->Cout % 4 == 0 && al(out, 7) && al(residual, 7) && al(bias, 15) && al(scale, 15) && al(shift, 15) &&
+                     al(rowvec, 15) && (!rowvec || a.rowvec_ld % 4 == 0) && al(a.partial, 15);
+  }
   switch (pl.cfg) {
     case 0: return launch16<2, 2, 2, 3, T>(a, s);
     case 1: return launch16<2, 2, 2, 2, T>(a, s);
@@ -457,6 +510,8 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
 int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                    const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
                    hipStream_t s) {
+  if (conv16_halo_applies(d) && conv16_halo_pointers_ok(d, bias, scale, shift, rowvec, residual, out))
+    return conv16_halo_launch(d, in, w, bias, scale, shift, rowvec, residual, out, s);
   if (d->dtype == DIFFSAL_BF16)
     return run16<__bf16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s);
   return run16<_Float16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s);
