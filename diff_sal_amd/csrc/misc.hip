@@ -210,97 +210,100 @@ struct ResizeSumArgs {
 // 4 (factor 2) source rows/columns, so the NR x NR source window is loaded ONCE and reused for all 16 outputs:
 // 2 loads per output instead of 16 -- the naive form is bound by L1/L2 request rate, not by HBM.
 // All coordinates / weights are wave-uniform scalars.
-template <int NR, typename T>
-__device__ __forceinline__ void patch_accumulate(const T* __restrict__ in, int n, int h, int w, int C, int Y0,
+__device__ __forceinline__ float uniform_f(float v) {   // wave-uniform value -> SGPR
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// nr = source rows / columns a 4-aligned run of 4 outputs touches: 2 (factor >= 8), 3 (factor 4) or 4 (factor 2);
+// wave-uniform, so ONE code path serves every scale (three specialised copies tripled the live accumulators).
+template <typename T>
+__device__ __forceinline__ void patch_accumulate(const T* __restrict__ in, int nr, int n, int h, int w, int C, int Y0,
                                                  int X0, float sy, float sx, int c, float4 (&acc)[4][4]) {
-  float wy[4][NR], wx[4][NR];
-  int ry0 = 0, rx0 = 0;
+  // horizontal weights of the 4 output columns over the source columns, and (y0, y1, ly) of the 4 output rows: all
+  // wave-uniform, kept in SGPRs; the vertical weights of a source row are rebuilt from (y0, y1, ly) when it is used
+  float wx[4][4], lyd[4];
+  int y0d[4], y1d[4];
+  int rx0 = 0;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     int y0, y1, x0, x1;
     float ly, lx;
     bilin_coord(Y0 + d, sy, h, y0, y1, ly);
     bilin_coord(X0 + d, sx, w, x0, x1, lx);
-    if (d == 0) { ry0 = y0; rx0 = x0; }
+    if (d == 0) rx0 = __builtin_amdgcn_readfirstlane(x0);
+    y0d[d] = __builtin_amdgcn_readfirstlane(y0);
+    y1d[d] = __builtin_amdgcn_readfirstlane(y1);
+    lyd[d] = uniform_f(ly);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      wy[d][i] = (ry0 + i == y0 ? 1.f - ly : 0.f) + (ry0 + i == y1 ? ly : 0.f);
-      wx[d][i] = (rx0 + i == x0 ? 1.f - lx : 0.f) + (rx0 + i == x1 ? lx : 0.f);
-    }
+    for (int k = 0; k < 4; ++k) wx[d][k] = uniform_f((rx0 + k == x0 ? 1.f - lx : 0.f) + (rx0 + k == x1 ? lx : 0.f));
   }
-  float4 win[NR][NR];
+  const int ry0 = y0d[0];
+  // one source row at a time: nr loads -> 4 horizontally blended values -> spread over the 4 output rows.  Keeps the
+  // live set at the 16 accumulators + one row (the whole-window form needed 500 VGPRs: one wave per SIMD).
   const T* base = in + static_cast<long>(n) * h * w * C + c;
+#pragma unroll 1
+  for (int i = 0; i < nr; ++i) {
+    const T* rp = base + static_cast<long>(min(ry0 + i, h - 1)) * w * C;
+    float4 row[4];
+    row[0] = ld4(rp + static_cast<long>(min(rx0, w - 1)) * C);
+    row[1] = ld4(rp + static_cast<long>(min(rx0 + 1, w - 1)) * C);
+    row[2] = nr > 2 ? ld4(rp + static_cast<long>(min(rx0 + 2, w - 1)) * C) : make_float4(0, 0, 0, 0);
+    row[3] = nr > 3 ? ld4(rp + static_cast<long>(min(rx0 + 3, w - 1)) * C) : make_float4(0, 0, 0, 0);
+    float wy[4];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int yy = min(ry0 + i, h - 1);
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int xx = min(rx0 + k, w - 1);
-      win[i][k] = ld4(base + (static_cast<long>(yy) * w + xx) * C);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    float4 tmp[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      float4 t = make_float4(0, 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        t.x = fmaf(wy[d][i], win[i][k].x, t.x); t.y = fmaf(wy[d][i], win[i][k].y, t.y);
-        t.z = fmaf(wy[d][i], win[i][k].z, t.z); t.w = fmaf(wy[d][i], win[i][k].w, t.w);
-      }
-      tmp[k] = t;
-    }
+    for (int d = 0; d < 4; ++d) wy[d] = (ry0 + i == y0d[d] ? 1.f - lyd[d] : 0.f) + (ry0 + i == y1d[d] ? lyd[d] : 0.f);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float4 r = make_float4(0, 0, 0, 0);
+      float4 t = make_float4(0, 0, 0, 0);
 #pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        r.x = fmaf(wx[e][k], tmp[k].x, r.x); r.y = fmaf(wx[e][k], tmp[k].y, r.y);
-        r.z = fmaf(wx[e][k], tmp[k].z, r.z); r.w = fmaf(wx[e][k], tmp[k].w, r.w);
+      for (int k = 0; k < 4; ++k) {
+        t.x = fmaf(wx[e][k], row[k].x, t.x); t.y = fmaf(wx[e][k], row[k].y, t.y);
+        t.z = fmaf(wx[e][k], row[k].z, t.z); t.w = fmaf(wx[e][k], row[k].w, t.w);
       }
-      acc[d][e].x += r.x; acc[d][e].y += r.y; acc[d][e].z += r.z; acc[d][e].w += r.w;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        acc[d][e].x = fmaf(wy[d], t.x, acc[d][e].x); acc[d][e].y = fmaf(wy[d], t.y, acc[d][e].y);
+        acc[d][e].z = fmaf(wy[d], t.z, acc[d][e].z); acc[d][e].w = fmaf(wy[d], t.w, acc[d][e].w);
+      }
     }
   }
 }
 
-// out = ((in0^ + in1^) + in2^) + in3^, x^ = bilinear resize of x to (H, W): one write of the big map.
+// out = in0^ + in1^ + in2^ + in3^, x^ = bilinear resize of x to (H, W): one write of the big map.
 // Requires H, W multiples of 4 and every input an integer factor (2, 4, 8, ...) smaller; n_in = 1 is the
-// plain resize.  R/.../sal_unet.py:482-487, common_block.py:197.
+// plain resize.  One wavefront per (4x4 output patch, 256-channel slab).  R/.../sal_unet.py:482-487, common_block.py:197.
 template <typename T>
 __global__ __launch_bounds__(256) void resize_sum_kernel(ResizeSumArgs a, T* __restrict__ out, int H, int W, int C,
                                                          int w_patches, long n_patches) {
   const int lane = threadIdx.x & 63;
-  const long patch = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (patch >= n_patches) return;
+  const int c_slabs = (C + 255) >> 8;
+  const long item = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (item >= n_patches * c_slabs) return;
+  const long patch = item / c_slabs;
+  const int c = static_cast<int>(item - patch * c_slabs) * 256 + lane * 4;
   const int px = static_cast<int>(patch % w_patches);
   const long t = patch / w_patches;
   const int py = static_cast<int>(t % (H >> 2));
   const int n = static_cast<int>(t / (H >> 2));
   const int Y0 = __builtin_amdgcn_readfirstlane(py * 4), X0 = __builtin_amdgcn_readfirstlane(px * 4);
-  for (int c = lane * 4; c < C; c += 256) {
-    float4 acc[4][4];
+  if (c >= C) return;
+  float4 acc[4][4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[d][e] = make_float4(0, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < a.n_in) {
-        const int f = H / a.h[s];  // wave-uniform
-        const T* src = static_cast<const T*>(a.in[s]);
-        if (f >= 8) patch_accumulate<2, T>(src, n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
-        else if (f == 4) patch_accumulate<3, T>(src, n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
-        else patch_accumulate<4, T>(src, n, a.h[s], a.w[s], C, Y0, X0, a.sy[s], a.sx[s], c, acc);
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        st4(out + ((static_cast<long>(n) * H + Y0 + d) * W + X0 + e) * C + c, acc[d][e]);
+    for (int e = 0; e < 4; ++e) acc[d][e] = make_float4(0, 0, 0, 0);
+#pragma unroll 1
+  for (int s = 0; s < a.n_in; ++s) {
+    const int hs = a.h[s], ws = a.w[s];
+    const int f = H / hs;  // wave-uniform
+    const T* src = static_cast<const T*>(a.in[s]);
+    patch_accumulate<T>(src, f >= 8 ? 2 : (f == 4 ? 3 : 4), n, hs, ws, C, Y0, X0, a.sy[s], a.sx[s], c, acc);
   }
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      st4(out + ((static_cast<long>(n) * H + Y0 + d) * W + X0 + e) * C + c, acc[d][e]);
 }
 
 // General fallback (any sizes): one wavefront per output pixel.
@@ -676,13 +679,14 @@ static void resize_bilinear_t(const T* in, T* out, int N, int h, int w, int H, i
   const float sy = static_cast<float>(h) / static_cast<float>(H), sx = static_cast<float>(w) / static_cast<float>(W);
   const int f = H / h;
   // x2 is cheaper with one thread per output (4 loads, mostly L1 hits); the patch form pays from x4 up
-  if (C % 4 == 0 && aligned16(in) && aligned16(out) && H % 4 == 0 && W % 4 == 0 && f >= 4 && (f & (f - 1)) == 0 &&
+  if (C % 4 == 0 && aligned16(in) && aligned16(out) && H % 4 == 0 && W % 4 == 0 && f >= 2 && (f & (f - 1)) == 0 &&
       h * f == H && w * f == W) {
     ResizeSumArgs a;
     a.n_in = 1;
     for (int i = 0; i < 4; ++i) { a.in[i] = in; a.h[i] = h; a.w[i] = w; a.sy[i] = sy; a.sx[i] = sx; }
     const long n_patches = static_cast<long>(N) * (H / 4) * (W / 4);
-    hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a, out, H, W,
+    const long waves = n_patches * ((C + 255) / 256);
+    hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(static_cast<int>((waves + 3) / 4)), dim3(256), 0, s, a, out, H, W,
                        C, W / 4, n_patches);
   } else if (C % 4 == 0 && aligned16(in) && aligned16(out)) {
     const long total = static_cast<long>(N) * H * W * (C / 4);
@@ -728,8 +732,9 @@ extern "C" int diffsal_resize_sum(const void* const* ins, const int* hs, const i
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (patchable) {
     const long n_patches = static_cast<long>(N) * (H / 4) * (W / 4);
+    const long waves = n_patches * ((C + 255) / 256);
 #define CALL(T)                                                                                                        \
-  hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(static_cast<int>((n_patches + 3) / 4)), dim3(256), 0, s, a,          \
+  hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(static_cast<int>((waves + 3) / 4)), dim3(256), 0, s, a,              \
                      static_cast<T*>(out), H, W, C, W / 4, n_patches)
     DS_DTYPE_DISPATCH(dtype, "resize_sum", CALL);
 #undef CALL
