@@ -48,7 +48,7 @@ def class_table(events, mfma_peak_tflops):
     step, HIP-event time of exactly those launches, and the achieved fraction of BOTH rooflines; `bound` names the
     roofline the class sits closer to, `frac` its fraction there."""
     agg = {}
-    for e0, e1, fl, cls, nb in events:
+    for e0, e1, fl, cls, nb, *_ in events:
         a = agg.setdefault(cls, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += fl
@@ -460,9 +460,9 @@ def main():
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     if args.dump_launches and rank == 0:
         rows = []
-        for e0, e1, fl, cls, nb in all_ev:
+        for e0, e1, fl, cls, nb, *note in all_ev:
             us = e0.elapsed_time(e1) * 1e3
-            rows.append({"class": cls, "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3), "us": round(us, 2),
+            rows.append({"class": cls, "op": note[0] if note else "", "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3), "us": round(us, 2),
                          "tflops": round(fl / us / 1e6, 2) if us > 0 else 0.0, "gbs": round(nb / us / 1e3, 1) if us > 0 else 0.0})
         json.dump({"precision": args.precision, "mode": args.mode, "batch": B, "launches": rows}, open(args.dump_launches, "w"), indent=0)
     peak_for_mode = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS

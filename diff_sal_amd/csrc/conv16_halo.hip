@@ -50,10 +50,16 @@ struct HaloArgs {
   int N, H, W, Cin, Cout, K;   // K = 9 * Cin
   int dil, act, rowvec_ld;
   int tiles_x, tiles_y, tiles_n;
+  unsigned long long* stamps;   // development aid: per-workgroup phase time stamps (DIFFSAL_HALO_STAMPS), normally null
 };
 
 constexpr int HP = 40;   // elements per staged pixel / weight row: 32 data + 8 pad (80 bytes)
 
+// Pipeline.  A "step" is one kernel row ky of one 32-channel chunk: 3 taps x 2 k-steps x TM x TN MFMAs per wavefront.
+// LDS holds the input patch of TWO chunks (double buffer) and a two-slot ring of weight rows (3 taps x BN x 32
+// channels each).  At step g a thread first parks what it fetched during step g-1 -- the weight row of step g+1 and one
+// third of the NEXT chunk's patch -- into the buffers nobody reads during step g, then issues the fetches step g+1 will
+// park, then runs the step's MFMAs; one barrier per step.  No phase without matrix work, 20 staging VGPRs.
 template <int TW, int NW, int TN, typename T>
 __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
   typedef typename HaloMma<T>::vec vec;
@@ -62,13 +68,13 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
   constexpr int RPM = 32 / TW;                     // image rows per 32-pixel MFMA tile
   constexpr int TM = (TH * TW) / (NW * 32);        // MFMA row tiles per wavefront
   static_assert(TM == 2, "each wavefront owns 64 pixels");
-  constexpr int PHM = TH + 4, PWM = TW + 4;        // patch extent for dilation 2
   constexpr int BN = TN * 32;
+  constexpr int B_ELEMS = 3 * BN * HP;             // one ring slot: [3 taps][BN][HP]
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  T* Ps = reinterpret_cast<T*>(smraw);             // [PH][PW][HP]
-  T* Bs = Ps + PHM * PWM * HP;                     // [9][BN][HP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto stamp = [&](int k) { if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + k] = wall_clock64(); };
+  stamp(0);
   // block -> (image, tile_y, tile_x, n tile); consecutive blocks share the patch's neighbourhood and the same weights
   int b = blockIdx.x;
   const int tn = b % p.tiles_n; b /= p.tiles_n;
@@ -78,22 +84,28 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
   const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
   const int d = p.dil;
   const int PH = TH + 2 * d, PW = TW + 2 * d;
+  const int a_elems = PH * PW * HP;
+  T* As = reinterpret_cast<T*>(smraw);             // [2][PH][PW][HP]
+  T* Bs = As + 2 * a_elems;                        // [2][3][BN][HP]
   const int n_chunks = p.Cin >> 5;
+  const int G = 3 * n_chunks;
 
-  // ---- loader bookkeeping: 16-byte pieces; patch piece = (pixel, quarter), weight piece = (co, tap, quarter).
+  // ---- loader bookkeeping: 16-byte pieces; patch piece = (pixel, quarter), weight piece = (co, kx, quarter).
   // Branch-free: buffer loads return zero for out-of-range offsets, so padding / tails carry offset 0x80000000.
-  constexpr int A_MAX = (PHM * PWM * 4 + NT - 1) / NT;
-  constexpr int B_PER = (9 * BN * 4 + NT - 1) / NT;
+  constexpr int A_MAX = ((TH + 4) * (TW + 4) * 4 + NT - 1) / NT;
+  constexpr int A_STEP = (A_MAX + 2) / 3;          // patch pieces a thread moves per step
+  constexpr int B_PER = (3 * BN * 4 + NT - 1) / NT;
   constexpr unsigned DEAD = 0x80000000u;
   const T* in_img = p.in + static_cast<long>(img) * p.H * p.W * p.Cin;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(in_img), 0, p.H * p.W * p.Cin * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(p.w), 0, p.Cout * p.K * 2, 0x00020000);
-  unsigned a_voff[A_MAX], b_voff[B_PER];
+  unsigned a_voff[3 * A_STEP], b_voff[B_PER];
+  int b_dst[B_PER];
   const int a_pieces = PH * PW * 4;
 #pragma unroll
-  for (int i = 0; i < A_MAX; ++i) {
+  for (int i = 0; i < 3 * A_STEP; ++i) {
     const int idx = tid + i * NT;
     const int q = idx & 3, pix = idx >> 2;
     const int pr = pix / PW, pc = pix - pr * PW;
@@ -104,43 +116,43 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
     const int idx = tid + i * NT;
-    const int co = idx / 36, r = idx - co * 36;            // 36 pieces = 9 taps x 4 quarters, contiguous in memory
-    const bool ok = idx < 9 * BN * 4 && n0 + co < p.Cout;
+    const int co = idx / 12, r = idx - co * 12;            // 12 pieces = 3 taps x 4 quarters: 192 contiguous bytes
+    const bool ok = idx < 3 * BN * 4 && n0 + co < p.Cout;
     b_voff[i] = ok ? static_cast<unsigned>(((n0 + co) * p.K + r * 8) * 2) : DEAD;
+    b_dst[i] = idx < 3 * BN * 4 ? ((r >> 2) * BN + co) * HP + (r & 3) * 8 : -1;
   }
-  uint4 ra[A_MAX], rb[B_PER];
-  auto fetch = [&](int chunk) {
+  uint4 ra[A_STEP], rb[B_PER];
+  // fetches that step gs will park: weight row of step gs+1; third (gs % 3) of the patch of chunk gs/3 + 1
+  auto issue = [&](int gs) {
+    const int c1 = gs / 3 + 1, part = gs - (c1 - 1) * 3;
+    const unsigned a_dead = c1 < n_chunks ? 0u : DEAD;
+    const unsigned b_dead = gs + 1 < G ? 0u : DEAD;
 #pragma unroll
-    for (int i = 0; i < A_MAX; ++i)
-      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i] + chunk * 64, 0, 0));
+    for (int i = 0; i < A_STEP; ++i) {
+      const unsigned vo = part == 0 ? a_voff[i] : (part == 1 ? a_voff[A_STEP + i] : a_voff[2 * A_STEP + i]);
+      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (vo + c1 * 64) | a_dead, 0, 0));
+    }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i] + chunk * 576, 0, 0));
+      rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (b_voff[i] + (gs + 1) * 192) | b_dead, 0, 0));
   };
-  auto park = [&]() {
+  auto park = [&](int gs) {
+    const int c1 = gs / 3 + 1, part = gs - (c1 - 1) * 3;
+    if (c1 < n_chunks) {
+      T* dst = As + (c1 & 1) * a_elems;
 #pragma unroll
-    for (int i = 0; i < A_MAX; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < PHM * PWM * 4) *reinterpret_cast<uint4*>(Ps + (idx >> 2) * HP + (idx & 3) * 8) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < 9 * BN * 4) {
-        const int co = idx / 36, r = idx - co * 36;
-        const int tap = r >> 2, q = r & 3;
-        *reinterpret_cast<uint4*>(Bs + (tap * BN + co) * HP + q * 8) = rb[i];
+      for (int i = 0; i < A_STEP; ++i) {
+        const int idx = tid + (part * A_STEP + i) * NT;
+        if (idx < a_pieces) *reinterpret_cast<uint4*>(dst + (idx >> 2) * HP + (idx & 3) * 8) = ra[i];
       }
     }
+    if (gs + 1 < G) {
+      T* dst = Bs + ((gs + 1) & 1) * B_ELEMS;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i)
+        if (b_dst[i] >= 0) *reinterpret_cast<uint4*>(dst + b_dst[i]) = rb[i];
+    }
   };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- fragment addressing: lane -> pixel (py, px) of its MFMA row tile; k half = lane >> 5
   const int lp = lane & 31, kh = lane >> 5;
@@ -151,48 +163,89 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
     a_base[i] = (py * PW + px) * HP + kh * 8;
   }
   const int b_base = lp * HP + kh * 8;
+  stamp(1);
 
-  fetch(0);
-  park();
-  __syncthreads();
-  for (int chunk = 0; chunk < n_chunks; ++chunk) {
-    if (chunk + 1 < n_chunks) fetch(chunk + 1);       // lands during this chunk's 18 x TM x TN MFMAs
+  {  // prologue: chunk 0's whole patch and weight row 0 land together, then the first regular fetch is put in flight
+    uint4 pa[3 * A_STEP];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int toff = (ky * d * PW + kx * d) * HP;
+    for (int i = 0; i < 3 * A_STEP; ++i)
+      pa[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_voff[i], 0, 0));
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        vec fa[TM], fb[TN];
+    for (int i = 0; i < B_PER; ++i)
+      rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[i], 0, 0));
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const vec*>(Ps + a_base[i] + toff + kk * 16);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const vec*>(Bs + (tap * BN + j * 32) * HP + b_base + kk * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = HaloMma<T>::run(fb[j], fa[i], acc[i][j]);   // D^T: rows = channels, cols = pixels
-      }
+    for (int i = 0; i < 3 * A_STEP; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < a_pieces) *reinterpret_cast<uint4*>(As + (idx >> 2) * HP + (idx & 3) * 8) = pa[i];
     }
-    __syncthreads();                                  // every wavefront is done with this chunk's LDS image
-    if (chunk + 1 < n_chunks) {
-      park();
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      if (b_dst[i] >= 0) *reinterpret_cast<uint4*>(Bs + b_dst[i]) = rb[i];
+    issue(0);
+    __syncthreads();
+  }
+  stamp(2);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const T* Ab = As + (chunk & 1) * a_elems;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int g = chunk * 3 + ky;
+      park(g);                                           // what step g-1 fetched; nobody reads those buffers now
+      issue(g + 1);                                      // lands during this step's MFMAs
+      const T* Bb = Bs + (g & 1) * B_ELEMS;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int toff = (ky * d * PW + kx * d) * HP;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          vec fa[TM], fb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const vec*>(Ab + a_base[i] + toff + kk * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const vec*>(Bb + (kx * BN + j * 32) * HP + b_base + kk * 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = HaloMma<T>::run(fb[j], fa[i], acc[i][j]);   // D^T: rows = channels, cols = pixels
+        }
+      }
       __syncthreads();
     }
   }
+  stamp(3);
 
   // ---- epilogue.  The weights went in as the MFMA "A" operand, so a lane holds, for pixel lane & 31 of its row tile,
   // output channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5): four consecutive channels per register quad.  The raw fp32 sums
   // are staged through the (now idle) LDS in two passes of half the block and leave as coalesced 8-byte stores with the
   // per-channel affine, per-image vector, activation and residual applied on the way (one rounding, like igemm16.hip).
+  // A thread keeps ONE channel quad for all its pieces, so the per-channel parameters are read once.
   constexpr int CP = BN + 4;                       // fp32 staging pitch: 16-byte stores of 8 consecutive lanes hit 8 x 4 distinct banks
   constexpr int PASS_PIX = NW * 32;                // pixels per pass (half of the block)
   constexpr int C4 = BN / 4;
+  constexpr int RG = NT / C4;                      // pixels moved per iteration
   float* Cs = reinterpret_cast<float*>(smraw);
   const T* __restrict__ resid = p.residual;
-  const float* __restrict__ rowv = p.rowvec;
   T* __restrict__ outp = p.out;
   const int hq = (lane >> 5) * 4;
+  const int c4 = tid % C4, rg = tid / C4;
+  const int n = n0 + c4 * 4;
+  const bool mover = rg < RG && n < p.Cout;
+  float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_scale = make_float4(1.f, 1.f, 1.f, 1.f), e_shift = e_bias, e_row = e_bias;
+  if (mover) {
+    if (p.bias) e_bias = *reinterpret_cast<const float4*>(p.bias + n);
+    if (p.scale) e_scale = *reinterpret_cast<const float4*>(p.scale + n);
+    if (p.scale && p.shift) e_shift = *reinterpret_cast<const float4*>(p.shift + n);
+    if (p.rowvec) e_row = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n);
+  }
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     if (wave / (NW / 2) == ps) {
@@ -208,52 +261,36 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
       }
     }
     __syncthreads();
+    if (mover) {
 #pragma unroll 4
-    for (int k = 0; k < PASS_PIX * C4 / NT; ++k) {
-      const int idx = tid + k * NT;
-      const int pp = idx / C4, c4 = idx - pp * C4;
-      const int mt = ps * (NW / 2) * TM + (pp >> 5), pl = pp & 31;
-      const int gy = y0 + mt * RPM + pl / TW, gx = x0 + pl % TW;
-      const int n = n0 + c4 * 4;
-      if (gy >= p.H || gx >= p.W || n >= p.Cout) continue;
-      const float4 a4 = *reinterpret_cast<const float4*>(Cs + pp * CP + c4 * 4);
-      float v[4] = {a4.x, a4.y, a4.z, a4.w};
-      if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-      if (p.scale) {
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-        const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+      for (int pp = rg; pp < PASS_PIX; pp += RG) {
+        const int mt = ps * (NW / 2) * TM + (pp >> 5), pl = pp & 31;
+        const int gy = y0 + mt * RPM + pl / TW, gx = x0 + pl % TW;
+        if (gy >= p.H || gx >= p.W) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(Cs + pp * CP + c4 * 4);
+        float v[4] = {a4.x + e_bias.x, a4.y + e_bias.y, a4.z + e_bias.z, a4.w + e_bias.w};
+        if (p.scale) {
+          v[0] = v[0] * e_scale.x + e_shift.x; v[1] = v[1] * e_scale.y + e_shift.y;
+          v[2] = v[2] * e_scale.z + e_shift.z; v[3] = v[3] * e_scale.w + e_shift.w;
+        }
+        v[0] += e_row.x; v[1] += e_row.y; v[2] += e_row.z; v[3] += e_row.w;
+        if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+        }
+        const long o = ((static_cast<long>(img) * p.H + gy) * p.W + gx) * p.Cout + n;
+        if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+        st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
       }
-      if (rowv) {
-        const float4 t = *reinterpret_cast<const float4*>(rowv + static_cast<long>(img) * p.rowvec_ld + n);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-      }
-      if (p.act == DIFFSAL_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-      } else if (p.act == DIFFSAL_ACT_SIGMOID) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
-      }
-      const long o = ((static_cast<long>(img) * p.H + gy) * p.W + gx) * p.Cout + n;
-      if (resid) {
-        const uint2 rr = *reinterpret_cast<const uint2*>(resid + o);
-        T rt[4];
-        __builtin_memcpy(rt, &rr, 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += static_cast<float>(rt[e]);
-      }
-      T ot[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ot[e] = static_cast<T>(v[e]);
-      uint2 ov;
-      __builtin_memcpy(&ov, ot, 8);
-      *reinterpret_cast<uint2*>(outp + o) = ov;
     }
     if (ps == 0) __syncthreads();
+    stamp(4 + ps);
   }
 }
 
@@ -263,7 +300,7 @@ static int launch_halo(HaloArgs<T>& a, hipStream_t s) {
   a.tiles_x = (a.W + TW - 1) / TW;
   a.tiles_y = (a.H + TH - 1) / TH;
   a.tiles_n = (a.Cout + TN * 32 - 1) / (TN * 32);
-  const size_t lds = (static_cast<size_t>(TH + 4) * (TW + 4) + 9 * TN * 32) * HP * sizeof(T);
+  const size_t lds = (2 * static_cast<size_t>(TH + 2 * a.dil) * (TW + 2 * a.dil) + 2 * 3 * TN * 32) * HP * sizeof(T);
   static bool raised = false;
   if (!raised) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_halo_kernel<TW, NW, TN, T>),
@@ -275,6 +312,12 @@ static int launch_halo(HaloArgs<T>& a, hipStream_t s) {
   return check_launch("diffsal_conv_igemm(16-bit halo)");
 }
 
+// tile choice shared by the eligibility test and the launcher
+static void halo_tiles(const diffsal_conv_desc* d, bool* wide, bool* n128) {
+  *n128 = (d->Cout % 96 != 0) && (d->Cout % 128 == 0);   // 96-wide N tiles unless only 128 divides Cout
+  *wide = (d->W % 32 == 0) || d->W >= 64;                // 16 x 32 pixel tiles when the width fills them
+}
+
 template <typename T>
 static int run_halo(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                     const float* shift, const float* rowvec, const void* residual, void* out, hipStream_t s) {
@@ -283,8 +326,10 @@ static int run_halo(const diffsal_conv_desc* d, const void* in, const void* w, c
   a.rowvec = rowvec; a.residual = static_cast<const T*>(residual); a.out = static_cast<T*>(out);
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.K = 9 * d->Cin; a.dil = d->dil_h; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
-  const bool n128 = (d->Cout % 96 != 0) && (d->Cout % 128 == 0);   // 96-wide N tiles unless only 128 divides Cout
-  const bool wide = (d->W % 32 == 0) || d->W >= 64;       // 16 x 32 pixel tiles when the width fills them
+  a.stamps = nullptr;
+  if (const char* e = getenv("DIFFSAL_HALO_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
+  bool wide, n128;
+  halo_tiles(d, &wide, &n128);
   if (wide) return n128 ? launch_halo<32, 8, 4, T>(a, s) : launch_halo<32, 8, 3, T>(a, s);
   return n128 ? launch_halo<16, 4, 4, T>(a, s) : launch_halo<16, 4, 3, T>(a, s);
 }
@@ -294,10 +339,15 @@ int conv16_halo_applies(const diffsal_conv_desc* d) {
   bool force = false;
   if (const char* e = getenv("DIFFSAL_NO_HALO")) { if (e[0] == '1') return 0; }
   if (const char* e = getenv("DIFFSAL_FORCE_HALO")) force = (e[0] == '1');
-  return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
-         (d->dil_h == 1 || d->dil_h == 2) && d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H && d->Wo == d->W &&
-         d->Cin % 32 == 0 && d->Cout % 4 == 0 && d->H >= 8 && d->W >= 16 && d->Cout >= 64 &&
-         (force || static_cast<long>(d->N) * d->H * d->W >= 80000);   // below that the generic tiles fill the chip better
+  const bool shape_ok = d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
+                        (d->dil_h == 1 || d->dil_h == 2) && d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H &&
+                        d->Wo == d->W && d->Cin % 32 == 0 && d->Cout % 4 == 0 && d->H >= 8 && d->W >= 16 && d->Cout >= 64;
+  if (!shape_ok) return 0;
+  bool wide, n128;
+  halo_tiles(d, &wide, &n128);
+  const size_t lds = (2 * static_cast<size_t>(16 + 2 * d->dil_h) * ((wide ? 32 : 16) + 2 * d->dil_h) + 6 * (n128 ? 128 : 96)) * HP * 2;
+  if (lds > 160 * 1024) return 0;
+  return force || static_cast<long>(d->N) * d->H * d->W >= 80000;   // below that the generic tiles fill the chip better
 }
 
 // the coalesced epilogue moves 8-byte output / residual pieces and 16-byte parameter pieces

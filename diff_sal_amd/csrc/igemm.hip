@@ -55,6 +55,7 @@ struct IgemmArgs {
   unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
   int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
+  int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is 16-byte aligned
 };
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const float bv = s == 0 ? fb[set][j].x : s == 1 ? fb[set][j].y : s == 2 ? fb[set][j].z : fb[set][j].w;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
         }
       }
     }
@@ -345,9 +346,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {   // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][i], bl[set][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][i], bh[set][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][i], bh[set][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[set][j], ah[set][i], acc[i][j], 0, 0, 0);   // D^T, as above
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[set][j], al[set][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[set][j], ah[set][i], acc[i][j], 0, 0, 0);
         }
     };
     // The MFMA phase of a K slice is ~5x shorter than in fp32, so global loads are issued THREE slices ahead (two
@@ -417,73 +418,100 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
     if (it < nkt) slice(it, std::integral_constant<int, 0>{});
   }
 
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // ---- epilogue.  The weight fragment is the MFMA "A" operand, so D is the transposed tile: a lane holds, for output
+  // row lane & 31 of its 32-row block, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- register quads of four
+  // consecutive channels.  The sums are staged through the idle LDS stages, NPASS row groups at a time, and leave as
+  // fully coalesced 16-byte pieces (a 96-channel row is 384 contiguous bytes) with the epilogue applied on the way;
+  // scalar stores from the register layout (2 x 128 bytes per wave instruction) cost the short-K GEMMs a third of their time.
   const int col_l = lane & 31;
-  const int row_h = (lane >> 5) * 4;
-  if (p.splits > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
-    float* part = p.partial + static_cast<long>(split) * p.M * p.Cout;
+  const int hq = (lane >> 5) * 4;
+  const float* __restrict__ resid = p.residual;
+  const float* __restrict__ rowv = p.rowvec;
+  float* __restrict__ outp = p.out;
+  float* part = p.splits > 1 ? p.partial + static_cast<long>(split) * p.M * p.Cout : nullptr;
+  if (!p.vec_epilogue) {   // Cout % 4 != 0 or a pointer not 16-byte aligned: scalar stores from the register layout
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + col_l;
-      if (n >= p.Cout) continue;
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + col_l;
+      if (m >= p.M) continue;
+      const int img = rowv ? m / HoWo : 0;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + (wm * TM + i) * 32 + row_h;
+      for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < p.M) part[static_cast<long>(m) * p.Cout + n] = acc[i][j][r];
+          const int n = n0 + (wn * TN + j) * 32 + (r & 3) + 8 * (r >> 2) + hq;
+          if (n >= p.Cout) continue;
+          const long o = static_cast<long>(m) * p.Cout + n;
+          float v = acc[i][j][r];
+          if (part) { part[o] = v; continue; }
+          if (p.bias) v += p.bias[n];
+          if (p.scale) v = v * p.scale[n] + (p.shift ? p.shift[n] : 0.f);
+          if (rowv) v += rowv[static_cast<long>(img) * p.rowvec_ld + n];
+          if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
+          else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
+          if (resid) v += resid[o];
+          outp[o] = v;
         }
       }
     }
     return;
   }
-  // Fetch every residual value of this thread's outputs BEFORE the arithmetic and the stores: they are
-  // independent loads that fly together (out must not alias residual / rowvec).
-  float res[TM][TN][16];
-  const float* __restrict__ resid = p.residual;
-  const float* __restrict__ rowv = p.rowvec;
-  float* __restrict__ outp = p.out;
+  constexpr int CP = BN + 4;                                  // staging pitch (dwords): conflict-free 16-byte stores
+  constexpr int NPASS = (BM * CP <= 2 * STAGE) ? 1 : ((BM / 2) * CP <= 2 * STAGE ? 2 : 4);
+  static_assert(WM % NPASS == 0 && (BM / NPASS) * CP <= 2 * STAGE, "staging passes must split the wave rows");
+  constexpr int RP = BM / NPASS;                              // rows per pass
+  constexpr int C4 = BN / 4;
+  __syncthreads();                                            // the last stage's fragment reads are done
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + col_l;
-    const int nc = n < p.Cout ? n : p.Cout - 1;
+  for (int ps = 0; ps < NPASS; ++ps) {
+    if (wm / (WM / NPASS) == ps) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32 + row_h;
+      for (int i = 0; i < TM; ++i) {
+        const int row = ((wm % (WM / NPASS)) * TM + i) * 32 + col_l;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = mb + (r & 3) + 8 * (r >> 2);
-        m = m < p.M ? m : p.M - 1;
-        res[i][j][r] = resid ? resid[static_cast<long>(m) * p.Cout + nc] : 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            st4(smem + row * CP + (wn * TN + j) * 32 + g * 8 + hq,
+                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
       }
     }
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + col_l;
-    if (n >= p.Cout) continue;
-    const float bi = p.bias ? p.bias[n] : 0.f;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float sh = p.shift ? p.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32 + row_h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m >= p.M) continue;
-        float v = acc[i][j][r];
-        v += bi;
-        if (p.scale) v = v * sc + sh;
-        if (rowv) v += rowv[static_cast<long>(m / HoWo) * p.rowvec_ld + n];
-        if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
-        else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
-        v += res[i][j][r];
-        outp[static_cast<long>(m) * p.Cout + n] = v;
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < RP * C4 / 256; ++k) {
+      const int idx = tid + k * 256;
+      const int row = idx / C4, c4 = idx - row * C4;
+      const int m = m0 + ps * RP + row, n = n0 + c4 * 4;
+      if (m >= p.M || n >= p.Cout) continue;
+      const float4 a4 = ld4(smem + row * CP + c4 * 4);
+      const long o = static_cast<long>(m) * p.Cout + n;
+      if (part) { st4(part + o, a4); continue; }
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (p.bias) { const float4 t = ld4(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      if (p.scale) {
+        const float4 sc = ld4(p.scale + n);
+        const float4 sh = p.shift ? ld4(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
       }
+      if (rowv) {
+        const float4 t = ld4(rowv + static_cast<long>(m / HoWo) * p.rowvec_ld + n);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+      if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+      }
+      if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
     }
+    if (ps + 1 < NPASS) __syncthreads();
   }
 }
 
@@ -672,6 +700,8 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
                need, ws_bytes);
     a.partial = static_cast<float*>(ws);
   }
+  a.vec_epilogue = d->Cout % 4 == 0 && aligned16(out) && (!residual || aligned16(residual)) && (!bias || aligned16(bias)) &&
+                   (!scale || (aligned16(scale) && aligned16(shift))) && (!rowvec || (aligned16(rowvec) && a.rowvec_ld % 4 == 0));
   switch (pl.cfg) {
     case 0: return launch<2, 2, 2, 3>(a, s, d->precision);
     case 1: return launch<2, 2, 2, 2>(a, s, d->precision);

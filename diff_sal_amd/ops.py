@@ -28,10 +28,10 @@ PROFILE = None
 
 
 class _prof:
-    __slots__ = ("cls", "flops", "nbytes", "e0")
+    __slots__ = ("cls", "flops", "nbytes", "e0", "note")
 
-    def __init__(self, cls, flops=0.0, nbytes=0.0):
-        self.cls, self.flops, self.nbytes, self.e0 = cls, float(flops), float(nbytes), None
+    def __init__(self, cls, flops=0.0, nbytes=0.0, note=""):
+        self.cls, self.flops, self.nbytes, self.e0, self.note = cls, float(flops), float(nbytes), None, note
 
     def __enter__(self):
         if PROFILE is not None:
@@ -43,7 +43,7 @@ class _prof:
         if self.e0 is not None and et is None and PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.append((self.e0, e1, self.flops, self.cls, self.nbytes))
+            PROFILE.append((self.e0, e1, self.flops, self.cls, self.nbytes, self.note))
         return False
 
 
@@ -311,7 +311,8 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         rv = None
     ws_bytes = lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32) if ws_bytes else None
-    with _prof(tag, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, w_packed, residual, out)):
+    with _prof(tag, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, w_packed, residual, out),
+               f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw}" if PROFILE is not None else ""):
         _lib.check(lib.diffsal_conv_igemm(C.byref(d), _pa(x, dt), _pa(w_packed, dt), _p(bias), _p(scale), _p(shift), rv,
                                           _pa(residual, dt), _pa(out, dt), _p(ws), ws_bytes, _stream()), "conv_igemm")
     return out
