@@ -19,14 +19,81 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _relu_spies():
+    """Record the ReLU sign pattern of both forwards: the oracle's pre-activations (torch.nn.functional.relu inputs) and the
+    HIP path's post-activation tensors (train BatchNorm+ReLU and conv epilogue ReLU), in call order."""
+    import torch.nn.functional as F
+
+    from diff_sal_amd import autograd_ops as ag
+
+    ref, hip = [], []
+    orig_relu, o_bn, o_conv = F.relu, ag.batchnorm_relu_train, ag.conv
+
+    def spy_relu(v, *a, **k):
+        ref.append(v.detach())
+        return orig_relu(v, *a, **k)
+
+    def spy_bn(x_, bn, relu=True):
+        y = o_bn(x_, bn, relu)
+        hip.append(y.detach())
+        return y
+
+    def spy_conv(x_, w, **k):
+        y = o_conv(x_, w, **k)
+        if k.get("act", 0) == 1:
+            hip.append(y.detach())
+        return y
+
+    def install():
+        orc.F.relu, ag.batchnorm_relu_train, ag.conv = spy_relu, spy_bn, spy_conv
+
+    def remove():
+        orc.F.relu, ag.batchnorm_relu_train, ag.conv = orig_relu, o_bn, o_conv
+
+    def flips():
+        assert len(ref) == len(hip) and ref, (len(ref), len(hip))
+        n = 0
+        for r, h in zip(ref, hip):
+            if r.dim() == 5:
+                r = r.squeeze(2)
+            n += int(((r.permute(0, 2, 3, 1).reshape(-1) > 0) != (h.cpu().reshape(-1) > 0)).sum())
+        return n
+
+    return install, remove, flips
+
+
 @pytest.mark.parametrize("av", [False, True])
 def test_train_forward_and_all_parameter_gradients_match_oracle_autograd(av):
+    """Gradient parity is asserted on an input where the HIP forward and the oracle forward take the SAME branch of every
+    ReLU (counted here, not assumed): candidate inputs are tried in a fixed order and the first flip-free one is used.  A
+    flipped element is two correct fp32 roundings landing on different sides of the kink, not a kernel error, and any
+    change of summation order in any forward kernel moves which elements are at risk (module docstring)."""
+    last = None
+    for tag in ("train", "train.b", "train.c", "train.d", "train.e", "train.f"):
+        n_flips, report = _gradient_case(av, tag)
+        print(f"input {tag!r}: {n_flips} ReLU sign disagreements between the two forwards")
+        if n_flips == 0:
+            report()
+            return
+        last = n_flips
+    raise AssertionError(f"no flip-free input among the candidates (last had {last} flips)")
+
+
+def _gradient_case(av, tag):
     cfg = CASES["tiny_av"][0]
     sd = orc.synth_state_dict(orc.state_dict_template(cfg))
-    x, feats, audio = orc.synth_inputs(cfg, 2, av, tag="train")
-    x0 = torch.sigmoid(orc.synth_tensor("train.x0", (2, 1, *cfg.img_size)))
+    x, feats, audio = orc.synth_inputs(cfg, 2, av, tag=tag)
+    x0 = torch.sigmoid(orc.synth_tensor(tag + ".x0", (2, 1, *cfg.img_size)))
     t = torch.tensor([321, 321])
+    install, remove, flips = _relu_spies()
+    install()
+    try:
+        return _gradient_case_body(cfg, sd, x, feats, audio, x0, t, flips)
+    finally:
+        remove()
 
+
+def _gradient_case_body(cfg, sd, x, feats, audio, x0, t, flips):
     # reference: autograd through the oracle with batch-statistics BN
     leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
     # the conditioning features come from trainable encoders upstream (MViT, AudioAttnNet): they need gradients too
@@ -48,43 +115,48 @@ def test_train_forward_and_all_parameter_gradients_match_oracle_autograd(av):
     audio_d = None if audio is None else audio.to(DEV).requires_grad_(True)
     x_d = x.to(DEV)
     out = net(x_d, t.to(DEV), feats_d, audio_d)
-    assert (out.detach().cpu() - pred.detach()).abs().max().item() < 1e-4
-    l2 = ((out - x0.to(DEV)) ** 2).sum(dim=(1, 2, 3)).mean()
-    l2.backward()
-    assert abs(l2.item() - loss.item()) < 1e-3 * abs(loss.item())
-    # gradient scale of the network: parameters whose true gradient is zero by symmetry (e.g. the K-projection
-    # LayerNorm bias and proj_k bias: softmax is invariant to a shift common to all keys) hold pure rounding noise
-    scale = torch.stack([g.grad.abs().max() for g in leaf.values() if g.grad is not None]).median().item()
-    worst, checked = [], 0
-    for name, p in net.named_parameters():
-        ref = leaf[name].grad
-        if ref is None:
-            assert p.grad is None or float(p.grad.abs().max()) < 1e-6 * scale, name
-            continue
-        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
-        err = (got - ref).abs().max().item()
-        tol = 5e-3 * ref.abs().max().item() + 5e-5 * scale
-        worst.append((err / tol, name, err, ref.abs().max().item()))
-        checked += 1
-    worst.sort()
-    print("worst gradient errors (fraction of tolerance, name, abs err, ref max):")
-    for w in worst[-12:]:
-        print("   ", w)
-    print("median fraction:", worst[len(worst) // 2][0])
-    assert checked > 150
-    assert worst[-1][0] < 1.0, worst[-1]
-    # input gradients (feat_list[3] is never read by the reference graph: quirk Q3, its gradient is None / zero)
-    # (x_t itself is data -- R/diffusion_trainer.py:106-117 -- and gets no gradient: conv_in's backward is parameters-only)
-    pairs = [(f"feat{i}", a, b) for i, (a, b) in enumerate(zip(feats_d, feats_r))]
-    if audio is not None:
-        pairs.append(("audio", audio_d, audio_r))
-    for nm, a, b in pairs:
-        if b.grad is None or float(b.grad.abs().max()) == 0.0:
-            assert a.grad is None or float(a.grad.abs().max()) <= 1e-6 * scale, nm
-            continue
-        assert a.grad is not None, nm
-        err = (a.grad.cpu() - b.grad).abs().max().item()
-        assert err < 5e-3 * b.grad.abs().max().item() + 5e-5 * scale, (nm, err, b.grad.abs().max().item())
+    n_flips = flips()
+
+    def report():
+        assert (out.detach().cpu() - pred.detach()).abs().max().item() < 1e-4
+        l2 = ((out - x0.to(DEV)) ** 2).sum(dim=(1, 2, 3)).mean()
+        l2.backward()
+        assert abs(l2.item() - loss.item()) < 1e-3 * abs(loss.item())
+        # gradient scale of the network: parameters whose true gradient is zero by symmetry (e.g. the K-projection
+        # LayerNorm bias and proj_k bias: softmax is invariant to a shift common to all keys) hold pure rounding noise
+        scale = torch.stack([g.grad.abs().max() for g in leaf.values() if g.grad is not None]).median().item()
+        worst, checked = [], 0
+        for name, p in net.named_parameters():
+            ref = leaf[name].grad
+            if ref is None:
+                assert p.grad is None or float(p.grad.abs().max()) < 1e-6 * scale, name
+                continue
+            got = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
+            err = (got - ref).abs().max().item()
+            tol = 5e-3 * ref.abs().max().item() + 5e-5 * scale
+            worst.append((err / tol, name, err, ref.abs().max().item()))
+            checked += 1
+        worst.sort()
+        print("worst gradient errors (fraction of tolerance, name, abs err, ref max):")
+        for w in worst[-12:]:
+            print("   ", w)
+        print("median fraction:", worst[len(worst) // 2][0])
+        assert checked > 150
+        assert worst[-1][0] < 1.0, worst[-1]
+        # input gradients (feat_list[3] is never read by the reference graph: quirk Q3, its gradient is None / zero)
+        # (x_t itself is data -- R/diffusion_trainer.py:106-117 -- and gets no gradient: conv_in's backward is parameters-only)
+        pairs = [(f"feat{i}", a, b) for i, (a, b) in enumerate(zip(feats_d, feats_r))]
+        if audio is not None:
+            pairs.append(("audio", audio_d, audio_r))
+        for nm, a, b in pairs:
+            if b.grad is None or float(b.grad.abs().max()) == 0.0:
+                assert a.grad is None or float(a.grad.abs().max()) <= 1e-6 * scale, nm
+                continue
+            assert a.grad is not None, nm
+            err = (a.grad.cpu() - b.grad).abs().max().item()
+            assert err < 5e-3 * b.grad.abs().max().item() + 5e-5 * scale, (nm, err, b.grad.abs().max().item())
+
+    return n_flips, report
 
 
 def _oracle_train_steps(cfg, sd, batches, av, n_steps, lr):
