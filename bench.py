@@ -471,7 +471,9 @@ def main():
     if os.path.exists(tf):      # PMC pass of THIS build (tools/pmc_traffic.py; separate --pmc run as the guide prescribes)
         try:
             tj = json.load(open(tf))
-            traffic, traffic_src = tj.get("bytes_per_launch"), f"profiles/{os.path.basename(tf)} ({tj.get('build', 'build n/a')})"
+            # HBM bytes of the whole GEMM family per step / its operator launches per step: per launch, like `achieved`
+            traffic = tj["bytes_per_step"] / n_launch if "bytes_per_step" in tj else tj.get("bytes_per_launch")
+            traffic_src = f"profiles/{os.path.basename(tf)} ({tj.get('build', 'build n/a')})"
         except Exception:  # noqa: BLE001
             traffic = None
     common = {"launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),

@@ -13,3 +13,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$PREC -- python
 find $OUT -name "*kernel_stats.csv" | head; find $OUT -name "*counter_collection.csv" | head
 # keep only the summaries (the traces are large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
+# HBM traffic summary of the GEMM family (bench.py reads profiles/r02_igemm_hbm_traffic_<precision>.json)
+python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $OUT/pmc_fetch_$PREC $OUT/pmc_write_$PREC $OUT/r02_igemm_hbm_traffic_$PREC.json $PREC "${BUILD_ID:-build n/a}"
+cp $(find $OUT/stats_$PREC -name "*kernel_stats.csv" | head -1) $OUT/r02_${PREC}_kernel_stats.csv
