@@ -25,6 +25,15 @@ namespace diffsal {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Unconditional 16-byte load from an address the caller has clamped into valid memory, zeroed when `ok` is false: a
+// conditional load inside an unrolled staging loop compiles to a branch plus a full vmcnt drain per piece, which left the
+// K/V (Q/dO) prefetch latency-bound.
+__device__ __forceinline__ float4 ld4_or_zero(const float* ptr, bool ok) {
+  float4 t = ld4(ptr);
+  if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+  return t;
+}
+
 struct AttnArgs {
   const float* q;        // [B,H,Lq,D] via strides
   const float* q_extra;  // [B,H,Lq,E] contiguous, or null when E == 0
@@ -44,7 +53,7 @@ struct AttnArgs {
 };
 
 template <int D, int E, int DV>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
   constexpr int DQ = D + E;             // contraction length of QK^T
   static_assert(DQ % 8 == 0 && DV % 32 == 0 && D % 4 == 0 && E % 4 == 0, "shape");
   constexpr int HQ = DQ / 2;            // per lane half
@@ -100,19 +109,18 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
       const int idx = tid + i * 256;
       const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
       const int key = key0 + row;
-      float4 t = make_float4(0, 0, 0, 0);
-      if (idx < KF4 && key < p.Lk) t = c4 < D ? ld4(kb + static_cast<long>(key) * p.k_sl + c4)
-                                             : ld4(p.k_extra + static_cast<long>(key) * E + (c4 - D));
-      kreg[i] = t;
+      const long kc = key < p.Lk ? key : p.Lk - 1;
+      const float* src = kb + kc * p.k_sl + (c4 < D ? c4 : 0);
+      if constexpr (E > 0) src = c4 < D ? src : p.k_extra + kc * E + (c4 - D);
+      kreg[i] = ld4_or_zero(src, idx < KF4 && key < p.Lk);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
       const int key = key0 + row;
-      float4 t = make_float4(0, 0, 0, 0);
-      if (idx < VF4 && key < p.Lk) t = ld4(vb + static_cast<long>(key) * p.v_sl + c4);
-      vreg[i] = t;
+      const long kc = key < p.Lk ? key : p.Lk - 1;
+      vreg[i] = ld4_or_zero(vb + kc * p.v_sl + c4, idx < VF4 && key < p.Lk);
     }
   };
   auto park = [&]() {
@@ -323,19 +331,18 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
       const int key = key0 + row;
-      float4 t = make_float4(0, 0, 0, 0);
-      if (idx < KF4 && key < p.Lk && c4 < DQ) t = c4 < D ? ld4(kb + static_cast<long>(key) * p.k_sl + c4)
-                                                        : ld4(p.k_extra + static_cast<long>(key) * E + (c4 - D));
-      kreg[i] = t;
+      const long kc = key < p.Lk ? key : p.Lk - 1;
+      const float* src = kb + kc * p.k_sl + (c4 < D ? c4 : 0);
+      if constexpr (E > 0) src = (c4 < D || c4 >= DQ) ? src : p.k_extra + kc * E + (c4 - D);
+      kreg[i] = ld4_or_zero(src, idx < KF4 && key < p.Lk && c4 < DQ);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
       const int key = key0 + row;
-      float4 t = make_float4(0, 0, 0, 0);
-      if (idx < VF4 && key < p.Lk) t = ld4(vb + static_cast<long>(key) * p.v_sl + c4);
-      vreg[i] = t;
+      const long kc = key < p.Lk ? key : p.Lk - 1;
+      vreg[i] = ld4_or_zero(vb + kc * p.v_sl + c4, idx < VF4 && key < p.Lk);
     }
   };
   auto park = [&]() {
@@ -478,11 +485,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
       const int idx = tid + i * 256;
       const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
       const int qq = q0 + row;
-      float4 t = make_float4(0, 0, 0, 0);
-      if (idx < QF4 && qq < p.Lq) {
-        if (c4 < D) { t = ld4(qb + static_cast<long>(qq) * p.q_sl + c4); t.x *= p.scale; t.y *= p.scale; t.z *= p.scale; t.w *= p.scale; }
-        else t = ld4(p.q_extra + (static_cast<long>(bh) * p.Lq + qq) * E + (c4 - D));
-      }
+      const long qcl = qq < p.Lq ? qq : p.Lq - 1;
+      const float* src = qb + qcl * p.q_sl + (c4 < D ? c4 : 0);
+      if constexpr (E > 0) src = c4 < D ? src : p.q_extra + (static_cast<long>(bh) * p.Lq + qcl) * E + (c4 - D);
+      float4 t = ld4_or_zero(src, idx < QF4 && qq < p.Lq);
+      const float sc = c4 < D ? p.scale : 1.0f;
+      t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
       qreg[i] = t;
     }
 #pragma unroll
@@ -490,9 +498,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
       const int qq = q0 + row;
-      float4 t = make_float4(0, 0, 0, 0);
-      if (idx < GF4 && qq < p.Lq) t = ld4(p.dout + (static_cast<long>(b) * p.Lq + qq) * (static_cast<long>(p.H) * DV) + h * DV + c4);
-      greg[i] = t;
+      const long qcl = qq < p.Lq ? qq : p.Lq - 1;
+      greg[i] = ld4_or_zero(p.dout + (static_cast<long>(b) * p.Lq + qcl) * (static_cast<long>(p.H) * DV) + h * DV + c4, idx < GF4 && qq < p.Lq);
     }
     if (tid < 32) {
       const int qq = q0 + tid;

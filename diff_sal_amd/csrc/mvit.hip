@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256) void pool3d_bwd_data_kernel(const float* __res
                                                               int D, int T, int H, int W, int To, int Ho, int Wo, int st,
                                                               int sh, int sw, long rows) {
   constexpr int ROWS = 256 / G;
+  extern __shared__ __attribute__((aligned(16))) float w_s[];   // [27][D]: read per tap from LDS (in registers they cost 108 VGPRs)
+  for (int i = threadIdx.x; i < 27 * D; i += 256) w_s[i] = w27[i];
+  __syncthreads();
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   const int Li = T * H * W, Lo = To * Ho * Wo;
   const int c = gl * 4;
@@ -251,20 +254,24 @@ __global__ __launch_bounds__(256) void pool3d_bwd_data_kernel(const float* __res
     } else {
       const int l = n - 1;
       const int ix = l % W, iy = (l / W) % H, it = l / (W * H);
-#pragma unroll
+      // branch-free: an absent tap reads the class-token row with weight 0 (27 independent loads in flight instead of
+      // a branch and a drain per tap); one kernel plane (9 taps, 18 loads) at a time keeps 3-4 waves per SIMD resident
+#pragma unroll 1
       for (int kt = 0; kt < 3; ++kt) {
         const int nt = it + 1 - kt;
-        if (nt < 0 || nt % st != 0 || nt / st >= To) continue;
+        const bool vt = nt >= 0 && nt % st == 0 && nt / st < To;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int ny = iy + 1 - ky;
-          if (ny < 0 || ny % sh != 0 || ny / sh >= Ho) continue;
+          const bool vy = vt && ny >= 0 && ny % sh == 0 && ny / sh < Ho;
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int nx = ix + 1 - kx;
-            if (nx < 0 || nx % sw != 0 || nx / sw >= Wo) continue;
-            const float4 g = ld4(dyb + (1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw) * D);
-            const float4 ww = ld4(w27 + ((kt * 3 + ky) * 3 + kx) * D + c);
+            const bool v = vy && nx >= 0 && nx % sw == 0 && nx / sw < Wo;
+            const long o = v ? 1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw : 0;
+            const float4 g = ld4(dyb + o * D);
+            float4 ww = ld4(w_s + ((kt * 3 + ky) * 3 + kx) * D + c);
+            if (!v) ww = make_float4(0.f, 0.f, 0.f, 0.f);
             acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
             acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
           }
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void pool3d_bwd_data_kernel(const float* __res
   }
 }
 
-constexpr int POOL_WCHUNKS = 256;
+constexpr int POOL_WCHUNKS = 1024;   // 4 workgroups per CU: the gather is latency-bound
 
 // one workgroup per chunk of output tokens; thread = (tap group, channel quad); LDS tree over the token lanes
 __global__ __launch_bounds__(256) void pool3d_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ dy,
@@ -284,14 +291,15 @@ __global__ __launch_bounds__(256) void pool3d_bwd_weight_kernel(const float* __r
                                                                 int sh, int sw, long rows /* B*heads*Lo video tokens */) {
   extern __shared__ double shw[];   // [27][D]
   const int c4n = D >> 2;
-  const int tl = threadIdx.x / c4n, c = (threadIdx.x % c4n) * 4;   // token lane, channel quad
-  const int TL = 256 / c4n;
+  const int grp = threadIdx.x / c4n, c = (threadIdx.x % c4n) * 4;   // (token lane, kernel plane kt), channel quad
+  const int TL = 256 / (3 * c4n);                                  // token lanes; each owns three threads per quad (kt = 0..2)
+  const int tl = grp / 3, kt = grp - tl * 3;
   const bool live = tl < TL;
   const int Lo = To * Ho * Wo;
   const long lo = rows * blockIdx.x / POOL_WCHUNKS, hi = rows * (blockIdx.x + 1) / POOL_WCHUNKS;
-  float4 acc[27];
+  float4 acc[9];
 #pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = make_float4(0, 0, 0, 0);
+  for (int i = 0; i < 9; ++i) acc[i] = make_float4(0, 0, 0, 0);
   if (live) {
     for (long r = lo + tl; r < hi; r += TL) {
       const int l = static_cast<int>(r % Lo);
@@ -300,22 +308,23 @@ __global__ __launch_bounds__(256) void pool3d_bwd_weight_kernel(const float* __r
       const int wo = l % Wo, ho = (l / Wo) % Ho, to = l / (Wo * Ho);
       const float4 g = ld4(dy + (bh * (Lo + 1) + 1 + l) * D + c);
       const float* base = in + b * in_sb + static_cast<long>(head) * D + c;
+      // branch-free: a tap outside the volume reads the class-token row and contributes g * 0
+      const int it = to * st - 1 + kt;
+      const bool vt = it >= 0 && it < T;
 #pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const int it = to * st - 1 + kt;
-        if (it < 0 || it >= T) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = ho * sh - 1 + ky;
+        const bool vy = vt && iy >= 0 && iy < H;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = ho * sh - 1 + ky;
-          if (iy < 0 || iy >= H) continue;
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = wo * sw - 1 + kx;
-            if (ix < 0 || ix >= W) continue;
-            const float4 a = ld4(base + (1 + (static_cast<long>(it) * H + iy) * W + ix) * in_sn);
-            float4& o = acc[(kt * 3 + ky) * 3 + kx];
-            o.x = fmaf(a.x, g.x, o.x); o.y = fmaf(a.y, g.y, o.y); o.z = fmaf(a.z, g.z, o.z); o.w = fmaf(a.w, g.w, o.w);
-          }
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = wo * sw - 1 + kx;
+          const bool v = vy && ix >= 0 && ix < W;
+          const long o = v ? 1 + (static_cast<long>(it) * H + iy) * W + ix : 0;
+          float4 a = ld4(base + o * in_sn);
+          if (!v) a = make_float4(0.f, 0.f, 0.f, 0.f);
+          float4& acc_t = acc[ky * 3 + kx];
+          acc_t.x = fmaf(a.x, g.x, acc_t.x); acc_t.y = fmaf(a.y, g.y, acc_t.y);
+          acc_t.z = fmaf(a.z, g.z, acc_t.z); acc_t.w = fmaf(a.w, g.w, acc_t.w);
         }
       }
     }
@@ -325,9 +334,9 @@ __global__ __launch_bounds__(256) void pool3d_bwd_weight_kernel(const float* __r
   for (int turn = 0; turn < TL; ++turn) {          // fixed order over the token lanes: deterministic
     if (live && tl == turn) {
 #pragma unroll
-      for (int i = 0; i < 27; ++i) {
-        shw[i * D + c + 0] += acc[i].x; shw[i * D + c + 1] += acc[i].y;
-        shw[i * D + c + 2] += acc[i].z; shw[i * D + c + 3] += acc[i].w;
+      for (int i = 0; i < 9; ++i) {
+        double* d = shw + (kt * 9 + i) * D + c;
+        d[0] += acc[i].x; d[1] += acc[i].y; d[2] += acc[i].z; d[3] += acc[i].w;
       }
     }
     __syncthreads();
@@ -465,7 +474,8 @@ __global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __r
   for (int item = threadIdx.x; item < kk * c4n; item += 256) {
     const int j = item / c4n, c = (item % c4n) * 4;
     float4 acc = make_float4(0, 0, 0, 0);
-    for (long u = lo; u < hi; ++u) {
+#pragma unroll 8
+    for (long u = lo; u < hi; ++u) {   // unrolled: eight rows' loads in flight, the additions keep their order
       const int bh = static_cast<int>(u / n_a), m = static_cast<int>(u - static_cast<long>(bh) * n_a);
       int t, y, x;
       if (axis == 0) { t = i; y = m / qw; x = m % qw; }
@@ -576,7 +586,7 @@ extern "C" int diffsal_pool3d_bwd_data(const float* dy, const float* w27, float*
   const long rows = static_cast<long>(B) * heads * (static_cast<long>(T) * H * W + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(G)                                                                                                        \
-  hipLaunchKernelGGL((pool3d_bwd_data_kernel<G>), dim3(rows_grid(rows, 256 / G)), dim3(256), 0, s, dy, w27, din,         \
+  hipLaunchKernelGGL((pool3d_bwd_data_kernel<G>), dim3(rows_grid(rows, 256 / G)), dim3(256), 27 * D * sizeof(float), s, dy, w27, din,         \
                      in_stride_b, in_stride_n, heads, D, T, H, W, To, Ho, Wo, st, sh, sw, rows)
   if (D <= 32) { CALL(8); } else if (D <= 64) { CALL(16); } else if (D <= 128) { CALL(32); } else { CALL(64); }
 #undef CALL
