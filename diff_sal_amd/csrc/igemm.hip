@@ -565,7 +565,6 @@ struct Plan { int cfg, splits; };
 static Plan choose_plan(long M, int Cout, int K, int precision) {
   // the bf16x3 loop sustains ~2x the fp32 one on large tiles: split-K slabs and fixed latencies weigh twice as much
   const double mac_per_s_cu = (precision == DIFFSAL_PREC_BF16X3 ? 2.0 : 1.0) * 157.3e12 / 2.0 / kCUs;
-  const double t_fixed = 10e-6;
   const int KT = K / BK;
   Plan best{5, 1};
   double best_t = 1e30;
@@ -573,16 +572,23 @@ static Plan choose_plan(long M, int Cout, int K, int precision) {
     const TileCfg& t = kCfgs[c];
     if (t.bn > Cout && t.bn - Cout >= 32 && c != 5) continue;  // mostly-empty N tile
     const long tiles = ((M + t.bm - 1) / t.bm) * ((Cout + t.bn - 1) / t.bn);
+    // pipe-idle time per workgroup: first-load latency (~4 us) + the store tail, which scales with the tile (stamps: 1.5-3.3 us
+    // prologue, 4.7 us epilogue for 128x96)
+    const double t_fixed = 4e-6 + 6e-6 * (t.bm * t.bn) / (128.0 * 96.0);
     for (int S = 1; S <= 16; S *= 2) {
       if (S > 1 && (KT / S < 6 || Cout % 4 != 0)) break;
       const long wgs = tiles * S;
       const long slots = static_cast<long>(kCUs) * t.occ;
-      const double rounds = static_cast<double>((wgs + slots - 1) / slots);
       const int kt_per = (KT + S - 1) / S;
       const double t_mfma = static_cast<double>(t.bm) * t.bn * (kt_per * BK) / (mac_per_s_cu * t.eff);
-      const double resident = static_cast<double>(wgs < slots ? (wgs + kCUs - 1) / kCUs : t.occ);
-      const double round = resident * t_mfma > t_mfma + t_fixed ? resident * t_mfma : t_mfma + t_fixed;
-      double tt = rounds * round;
+      // full rounds at full residency, then the remainder at ITS residency: the last workgroups of a launch have the CU
+      // (almost) to themselves and finish sooner than a full round (in-kernel stamps)
+      auto round_time = [&](double resident) {
+        return resident * t_mfma > t_mfma + t_fixed ? resident * t_mfma : t_mfma + t_fixed;
+      };
+      const long full = wgs / slots, rest = wgs - full * slots;
+      double tt = full * round_time(t.occ);
+      if (rest > 0) tt += round_time(static_cast<double>((rest + kCUs - 1) / kCUs));
       if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6;
       if (tt < best_t) { best_t = tt; best = Plan{c, S}; }
     }

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""fp32 implicit-GEMM tile sweep on the thin-K token GEMMs of the denoiser (K10 / K13 / K4-1x1 shapes, B=4): the planner's
+choice and each forced tile shape (DIFFSAL_IGEMM_CFG, no split-K).  GPU only."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_sal_amd import ops  # noqa: E402
+from tools.tune_igemm16 import timed  # noqa: E402
+
+CFG = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64"]
+SHAPES = [(193536, 96, 96), (193536, 96, 192), (193536, 192, 96), (48384, 192, 192), (48384, 192, 384), (48384, 384, 192),
+          (12096, 384, 384), (12096, 384, 768), (12096, 768, 384), (3024, 768, 768), (3024, 768, 1536), (3024, 1536, 768),
+          (648, 768, 768), (648, 384, 384), (48384, 3456, 192), (12096, 6912, 384), (5376, 1728, 384), (1344, 3456, 768), (21504, 96, 192), (5376, 192, 384), (1344, 384, 768)]
+
+
+def main():
+    for M, K, N in SHAPES:
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * 0.05
+        b = torch.randn(N, device="cuda")
+        os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        us = timed(lambda: ops.linear(x, w, b))
+        fl = 2.0 * M * K * N
+        line = f"M={M:6d} K={K:4d} N={N:4d} planner {us:7.1f} us {fl / us / 1e6:6.1f} TF/s |"
+        for c, cn in enumerate(CFG):
+            if (c == 0 and N < 161) or (c in (1, 3) and N < 97):
+                continue
+            os.environ["DIFFSAL_IGEMM_CFG"] = str(c)
+            u = timed(lambda: ops.linear(x, w, b))
+            line += f" {cn} {u:6.1f}"
+        os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
