@@ -103,6 +103,7 @@ SIGNATURES = {
     "diffsal_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_split_weight": (c_i, [c_f, c_f, C.c_long, c_f]),
     "diffsal_col2im_disjoint": (c_i, [c_f, c_f] + [c_i] * 12 + [c_f]),
+    "diffsal_col2im_gather": (c_i, [c_f, c_f] + [c_i] * 12 + [c_f]),
     "diffsal_reduce_blocks": (c_i, []),
     "diffsal_multi_copy": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.POINTER(C.c_long), c_i, c_f, c_f]),
     "diffsal_scale_by": (c_i, [c_f, c_f, c_f, C.c_long, c_f]),

@@ -18,10 +18,10 @@ Tensor = torch.Tensor
 def dgrad_weight(w: Tensor, stride=(1, 1)) -> Tensor:
     """Weight of the data-gradient computation of a conv with parameter w [Cout, Cin, KH, KW] (or Conv3d [.., KT,1,1]).
 
-    Overlapping taps (stride < kernel): packed weight of dX = conv(dY, W^T flipped).  Disjoint taps (stride >= kernel
-    on both axes): the [KH*KW*Cin, Cout] matrix of the GEMM dXcols = dY W, scattered by col2im (ConvFn.backward)."""
+    Stride 1: packed weight of dX = conv(dY, W^T flipped).  Strided convolutions (taps disjoint or overlapping): the
+    [KH*KW*Cin, Cout] matrix of the GEMM dXcols = dY W, whose columns col2im maps back onto the input (ConvFn.backward)."""
     kh, kw = (w.shape[2], 1) if w.dim() == 5 else tuple(w.shape[2:])
-    if stride[0] >= kh and stride[1] >= kw and (kh, kw) != (1, 1):
+    if tuple(stride) != (1, 1) and (kh, kw) != (1, 1):
         return ops.pack_cols_weight(w)
     return ops.pack_dgrad_weight(w)
 
@@ -79,13 +79,15 @@ class ConvFn(torch.autograd.Function):
                     raise RuntimeError("ConvFn: disjoint-tap backward needs dgrad_weight(w, stride) (columns layout)")
                 cols = ops.conv_igemm(g.reshape(1, 1, N * Ho * Wo, Cout), w_dgrad)
                 dx = ops.col2im_disjoint(cols.reshape(N * Ho * Wo, -1), x.shape, (Ho, Wo), kh, kw, stride, pad)
+            elif dil == (1, 1):
+                # strided conv with overlapping taps (3x3 stride-2 Downsample): the same GEMM, then every input pixel sums
+                # the column entries that map onto it -- exactly the forward's MACs, no zero-inserted dY
+                if tuple(w_dgrad.shape) != (kh * kw * x.shape[-1], Cout):
+                    raise RuntimeError("ConvFn: strided backward needs dgrad_weight(w, stride) (columns layout)")
+                cols = ops.conv_igemm(g.reshape(1, 1, N * Ho * Wo, Cout), w_dgrad)
+                dx = ops.col2im_gather(cols.reshape(N * Ho * Wo, -1), x.shape, (Ho, Wo), kh, kw, stride, pad)
             else:
-                # strided conv: scatter dY onto a zero grid at the stride (layout plumbing), then a stride-1 conv
-                Hd, Wd = (Ho - 1) * stride[0] + 1, (Wo - 1) * stride[1] + 1
-                gd = g.new_zeros((N, Hd, Wd, Cout))
-                gd[:, ::stride[0], ::stride[1]] = g
-                pt, pl = dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1]
-                dx = ops.conv_igemm(gd, w_dgrad, kh=kh, kw=kw, pad=(pt, pl), dil=dil, out_hw=(H, W))
+                raise NotImplementedError("ConvFn: data gradient of a strided AND dilated convolution")
         return dx, dw, db, drv, dres, None, None
 
 

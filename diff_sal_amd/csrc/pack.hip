@@ -101,6 +101,37 @@ __global__ __launch_bounds__(256) void col2im_disjoint_kernel(const float* __res
   }
 }
 
+// Overlapping taps (stride < kernel, e.g. the 3x3 stride-2 Downsample): every input pixel sums the (at most
+// ceil(KH/sh) * ceil(KW/sw)) column entries that map onto it, in (ky, kx) order -- deterministic, no atomics, and the GEMM that
+// produced `cols` did exactly the forward's MACs (a zero-inserted stride-1 convolution does stride_h * stride_w times more).
+__global__ __launch_bounds__(256) void col2im_gather_kernel(const float* __restrict__ cols, float* __restrict__ dx, int N,
+                                                            int H, int W, int C, int Ho, int Wo, int KH, int KW, int sh,
+                                                            int sw, int pt, int pl) {
+  const int c4n = C >> 2;
+  const long total = static_cast<long>(N) * H * W * c4n;
+  const long row_len = static_cast<long>(KH) * KW * C;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c4 = static_cast<int>(i % c4n);
+    long r = i / c4n;
+    const int ix = static_cast<int>(r % W); r /= W;
+    const int iy = static_cast<int>(r % H);
+    const int n = static_cast<int>(r / H);
+    float4 v = make_float4(0, 0, 0, 0);
+    for (int ky = 0; ky < KH; ++ky) {
+      const int ay = iy + pt - ky;
+      if (ay < 0 || ay % sh != 0 || ay / sh >= Ho) continue;
+      for (int kx = 0; kx < KW; ++kx) {
+        const int ax = ix + pl - kx;
+        if (ax < 0 || ax % sw != 0 || ax / sw >= Wo) continue;
+        const float4 t = ld4(cols + ((static_cast<long>(n) * Ho + ay / sh) * Wo + ax / sw) * row_len +
+                             static_cast<long>(ky * KW + kx) * C + c4 * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+    }
+    st4(dx + i * 4, v);
+  }
+}
+
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 // fp32 [..][32-k slices] -> per slice: 16 dwords of bf16 hi halves (k order) + 16 dwords of lo halves
@@ -159,6 +190,21 @@ extern "C" int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int 
   hipLaunchKernelGGL(col2im_disjoint_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), cols,
                      dx, N, H, W, C, Ho, Wo, KH, KW, stride_h, stride_w, pad_t, pad_l);
   return check_launch("col2im_disjoint");
+}
+
+extern "C" int diffsal_col2im_gather(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH, int KW,
+                                     int stride_h, int stride_w, int pad_t, int pad_l, diffsal_stream_t stream) {
+  DS_REQUIRE(cols && dx, DIFFSAL_E_ARG, "col2im_gather: null argument");
+  DS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride_h > 0 &&
+                 stride_w > 0 && pad_t >= 0 && pad_l >= 0,
+             DIFFSAL_E_SHAPE, "col2im_gather: bad shape");
+  DS_REQUIRE(aligned16(cols) && aligned16(dx), DIFFSAL_E_ARG, "col2im_gather: buffers must be 16-byte aligned");
+  const long total = static_cast<long>(N) * H * W * (C / 4);
+  long g = (total + 255) / 256;
+  g = g > 8192 ? 8192 : g;
+  hipLaunchKernelGGL(col2im_gather_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), cols, dx,
+                     N, H, W, C, Ho, Wo, KH, KW, stride_h, stride_w, pad_t, pad_l);
+  return check_launch("col2im_gather");
 }
 
 extern "C" int diffsal_split_weight(const float* src, float* dst, long n, diffsal_stream_t stream) {

@@ -255,6 +255,17 @@ def col2im_disjoint(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pa
     return dx
 
 
+def col2im_gather(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pad) -> Tensor:
+    """cols [N*Ho*Wo, kh*kw*C] -> dx [N,H,W,C] for a strided convolution whose taps overlap (1 < stride < kernel): every
+    input pixel sums the column entries that map onto it (fixed order, no atomics)."""
+    lib = _lib.load()
+    N, H, W, Cc = in_shape
+    dx = torch.empty((N, H, W, Cc), device=cols.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_col2im_gather(_p(cols), _p(dx), N, H, W, Cc, out_hw[0], out_hw[1], kh, kw, stride[0], stride[1],
+                                         pad[0], pad[1], _stream()), "col2im_gather")
+    return dx
+
+
 class _PackWeightFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w):

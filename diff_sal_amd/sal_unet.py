@@ -572,7 +572,7 @@ class SalUNet(nn.Module):
                         w_dgrad=dgw(rb.conv2.weight))
             hh, ww = f.shape[1:3]
             f = ag.conv(f, pw(dn.conv.weight), kh=3, kw=3, stride=(2, 2), out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1),
-                        bias=dn.conv.bias, w_dgrad=dgw(dn.conv.weight))
+                        bias=dn.conv.bias, w_dgrad=dgw(dn.conv.weight, (2, 2)))
             noise.append(f)
         noise = noise[::-1]
 

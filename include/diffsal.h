@@ -123,6 +123,11 @@ int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const void* in, cons
  * cols[(n,oy,ox)][(ky,kx)][:] that maps there, else 0; cols [N*Ho*Wo, KH*KW*C] comes from one diffsal_conv_igemm GEMM. */
 int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH, int KW,
                             int stride_h, int stride_w, int pad_t, int pad_l, diffsal_stream_t stream);
+/* col2im_gather: the same for OVERLAPPING taps (1 < stride < kernel: the 3x3 stride-2 Downsample of the ResBlock encoder,
+ * sal_unet.py:47-84): every input pixel sums, in (ky, kx) order, the column entries that map onto it.  With the mode-3
+ * GEMM in front this is the strided data gradient at exactly the forward's MAC count. */
+int diffsal_col2im_gather(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH, int KW,
+                          int stride_h, int stride_w, int pad_t, int pad_l, diffsal_stream_t stream);
 int diffsal_pack_weight(const float* src, float* dst, int Cout, int Cin, int taps, int mode, diffsal_stream_t stream);
 /* bf16x3 mode: split a packed fp32 weight [rows][K] (K % 32 == 0) into the w_format = 1 layout of diffsal_conv_desc
  * (hi = bf16(x), lo = bf16(x - hi)); n = rows * K.  Saves the kernel the conversion of its B operand. */
