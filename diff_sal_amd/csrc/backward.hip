@@ -1080,12 +1080,7 @@ static void launch_attention_bwd(const float* q, const float* k, const float* v,
                                  float* p_out, float* ds_out, int N, int Lq, int Lk, int C, int heads, int ld, float scale,
                                  int blocks, hipStream_t s) {
   const size_t lds = static_cast<size_t>(2) * Lk * (C / heads) * sizeof(float);
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<LK, G>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
+  if (lds > 64 * 1024) DS_RAISE_DYNAMIC_LDS((attention_bwd_kernel<LK, G>), 160 * 1024);
   hipLaunchKernelGGL((attention_bwd_kernel<LK, G>), dim3(blocks, N, heads), dim3(256), lds, s, q, k, v, dout, dq, p_out,
                      ds_out, Lq, Lk, C, heads, ld, scale);
 }

@@ -250,11 +250,7 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
 template <typename T>
 static int launch_block16(const Block16Args<T>& a, hipStream_t s) {
   const size_t lds = (static_cast<size_t>(96) * 104 + 192 * 104 + 96 * 200) * sizeof(T) + (6 * 96 + 192) * sizeof(float);
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
+  DS_RAISE_DYNAMIC_LDS((block16_kernel<T>), 160 * 1024);
   const int n_tiles = (a.M + 31) / 32;
   int grid = 256;
   if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;

@@ -94,6 +94,20 @@ __device__ __forceinline__ void st4(f16_t* p, float4 v) {
 // 4-element accesses of T need 4 * sizeof(T) alignment
 template <typename T> inline bool aligned_vec4(const T* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS once PER DEVICE (the attribute is per device; a process that drives
+// several GPUs must not rely on a per-process flag).  A benign race at worst sets the attribute twice.
+#define DS_RAISE_DYNAMIC_LDS(fn, bytes)                                                                       \
+  do {                                                                                                        \
+    static unsigned long long ds_raised_mask_ = 0;                                                            \
+    int ds_dev_ = 0;                                                                                          \
+    (void)hipGetDevice(&ds_dev_);                                                                             \
+    const unsigned long long ds_bit_ = 1ull << (ds_dev_ & 63);                                                \
+    if (!(ds_raised_mask_ & ds_bit_)) {                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+      ds_raised_mask_ |= ds_bit_;                                                                             \
+    }                                                                                                         \
+  } while (0)
+
 // Run `CALL(T)` with T = the storage type named by a DIFFSAL_F32 / BF16 / F16 code.
 #define DS_DTYPE_DISPATCH(dtype, what, CALL)                                                      \
   do {                                                                                            \

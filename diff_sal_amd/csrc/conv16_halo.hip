@@ -301,12 +301,7 @@ static int launch_halo(HaloArgs<T>& a, hipStream_t s) {
   a.tiles_y = (a.H + TH - 1) / TH;
   a.tiles_n = (a.Cout + TN * 32 - 1) / (TN * 32);
   const size_t lds = (2 * static_cast<size_t>(TH + 2 * a.dil) * (TW + 2 * a.dil) + 2 * 3 * TN * 32) * HP * sizeof(T);
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv16_halo_kernel<TW, NW, TN, T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
+  DS_RAISE_DYNAMIC_LDS((conv16_halo_kernel<TW, NW, TN, T>), 160 * 1024);
   const long blocks = static_cast<long>(a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
   hipLaunchKernelGGL((conv16_halo_kernel<TW, NW, TN, T>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, s, a);
   return check_launch("diffsal_conv_igemm(16-bit halo)");

@@ -143,12 +143,7 @@ template <int KH, int TN, bool HAS_RES>
 static int launch_stream(const LinStreamArgs& a, hipStream_t s) {
   constexpr int K = KHALF * KH, N = 32 * TN;
   const size_t lds = static_cast<size_t>(N) * (K + 4) * sizeof(float);
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stream_kernel<KH, TN, HAS_RES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
+  if (lds > 64 * 1024) DS_RAISE_DYNAMIC_LDS((lin_stream_kernel<KH, TN, HAS_RES>), 160 * 1024);
   const int per_cu = (TN <= 3 && lds <= 80 * 1024) ? 2 : 1;  // TN = 6 needs > 256 registers: one wave per SIMD
   const int n_tiles = (a.M + 31) / 32;
   int grid = 256 * per_cu;
@@ -356,11 +351,7 @@ extern "C" int diffsal_mlp_block(const float* x1, const float* g2, const float* 
   DS_REQUIRE(x1 != x2, DIFFSAL_E_ARG, "mlp_block: in-place operation is not supported (tiles are prefetched)");
   MlpBlockArgs a{x1, g2, be2, w1, b1, w2, b2, gz, bez, x2, z, static_cast<int>(M), eps2, epsz, hw > 0 ? hw : 1, T > 0 ? T : 1, t_keep};
   const size_t lds = (static_cast<size_t>(192) * 100 + 96 * 196 + 5 * 96 + 192) * sizeof(float);
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
+  DS_RAISE_DYNAMIC_LDS((mlp_block_kernel), 160 * 1024);
   const int n_tiles = static_cast<int>((M + 31) / 32);
   int grid = 256;
   if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;

@@ -777,12 +777,7 @@ template <int LK, int G, typename T>
 static void launch_attention(const T* q, const T* k, const T* v, T* o, int N, int Lq, int Lk, int C,
                              int heads, float scale, hipStream_t s) {
   const size_t lds = static_cast<size_t>(2) * Lk * (C / heads) * sizeof(float);
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {  // opt in to > 64 KiB of dynamic LDS (host-side attribute, not a stream op)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<LK, G, T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
+  if (lds > 64 * 1024) DS_RAISE_DYNAMIC_LDS((attention_kernel<LK, G, T>), 160 * 1024);
   const int qpb = 4 * (64 / G);  // queries per workgroup (all four wavefronts serve the same head)
   hipLaunchKernelGGL((attention_kernel<LK, G, T>), dim3((Lq + qpb - 1) / qpb, N * heads), dim3(256), lds, s, q, k, v, o,
                      Lq, Lk, C, heads, scale);

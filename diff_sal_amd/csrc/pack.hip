@@ -165,12 +165,7 @@ extern "C" int diffsal_pack_weight(const float* src, float* dst, int Cout, int C
              "pack_weight: the data-gradient layouts need Cout %% 32 == 0, got %d", Cout);
   DS_REQUIRE(aligned16(src) && aligned16(dst), DIFFSAL_E_ARG, "pack_weight: buffers must be 16-byte aligned");
   const size_t lds = static_cast<size_t>(32) * (32 * taps + 1) * sizeof(float);
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              128 * 1024);
-    raised = true;
-  }
+  if (lds > 64 * 1024) DS_RAISE_DYNAMIC_LDS((pack_tile_kernel), 128 * 1024);
   hipLaunchKernelGGL(pack_tile_kernel, dim3(Cin / 32, (Cout + 31) / 32), dim3(256), lds, static_cast<hipStream_t>(stream),
                      src, dst, Cout, Cin, taps, mode);
   return check_launch("pack_weight");
