@@ -224,56 +224,34 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
   stamp(3);
 
   // ---- epilogue.  The weights went in as the MFMA "A" operand, so a lane holds, for pixel lane & 31 of its row tile,
-  // output channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5): four consecutive channels per register quad.  The raw fp32 sums
-  // are staged through the (now idle) LDS in two passes of half the block and leave as coalesced 8-byte stores with the
-  // per-channel affine, per-image vector, activation and residual applied on the way (one rounding, like igemm16.hip).
-  // A thread keeps ONE channel quad for all its pieces, so the per-channel parameters are read once.
-  constexpr int CP = BN + 4;                       // fp32 staging pitch: 16-byte stores of 8 consecutive lanes hit 8 x 4 distinct banks
-  constexpr int PASS_PIX = NW * 32;                // pixels per pass (half of the block)
-  constexpr int C4 = BN / 4;
-  constexpr int RG = NT / C4;                      // pixels moved per iteration
-  float* Cs = reinterpret_cast<float*>(smraw);
+  // output channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5): four consecutive channels per register quad, stored as one
+  // 8-byte piece with the per-channel affine, per-image vector, activation and residual applied on the way (one rounding,
+  // like igemm16.hip; no LDS staging, no barrier).
   const T* __restrict__ resid = p.residual;
   T* __restrict__ outp = p.out;
   const int hq = (lane >> 5) * 4;
-  const int c4 = tid % C4, rg = tid / C4;
-  const int n = n0 + c4 * 4;
-  const bool mover = rg < RG && n < p.Cout;
-  float4 e_bias = make_float4(0.f, 0.f, 0.f, 0.f), e_scale = make_float4(1.f, 1.f, 1.f, 1.f), e_shift = e_bias, e_row = e_bias;
-  if (mover) {
-    if (p.bias) e_bias = *reinterpret_cast<const float4*>(p.bias + n);
-    if (p.scale) e_scale = *reinterpret_cast<const float4*>(p.scale + n);
-    if (p.scale && p.shift) e_shift = *reinterpret_cast<const float4*>(p.shift + n);
-    if (p.rowvec) e_row = *reinterpret_cast<const float4*>(p.rowvec + static_cast<long>(img) * p.rowvec_ld + n);
-  }
+  const float* rv_row = p.rowvec ? p.rowvec + static_cast<long>(img) * p.rowvec_ld : nullptr;
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    if (wave / (NW / 2) == ps) {
+  for (int i = 0; i < TM; ++i) {
+    const int mt = wave * TM + i;
+    const int gy = y0 + mt * RPM + lp / TW, gx = x0 + lp % TW;
+    if (gy >= p.H || gx >= p.W) continue;
+    const long obase = ((static_cast<long>(img) * p.H + gy) * p.W + gx) * p.Cout;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int pp = ((wave % (NW / 2)) * TM + i) * 32 + lp;
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(Cs + pp * CP + j * 32 + g * 8 + hq) =
-                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-      }
-    }
-    __syncthreads();
-    if (mover) {
-#pragma unroll 4
-      for (int pp = rg; pp < PASS_PIX; pp += RG) {
-        const int mt = ps * (NW / 2) * TM + (pp >> 5), pl = pp & 31;
-        const int gy = y0 + mt * RPM + pl / TW, gx = x0 + pl % TW;
-        if (gy >= p.H || gx >= p.W) continue;
-        const float4 a4 = *reinterpret_cast<const float4*>(Cs + pp * CP + c4 * 4);
-        float v[4] = {a4.x + e_bias.x, a4.y + e_bias.y, a4.z + e_bias.z, a4.w + e_bias.w};
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + j * 32 + g * 8 + hq;
+        if (n >= p.Cout) continue;
+        const long o = obase + n;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (p.bias) { const float4 t = ld4(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         if (p.scale) {
-          v[0] = v[0] * e_scale.x + e_shift.x; v[1] = v[1] * e_scale.y + e_shift.y;
-          v[2] = v[2] * e_scale.z + e_shift.z; v[3] = v[3] * e_scale.w + e_shift.w;
+          const float4 sc = ld4(p.scale + n);
+          const float4 sh = p.shift ? ld4(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
         }
-        v[0] += e_row.x; v[1] += e_row.y; v[2] += e_row.z; v[3] += e_row.w;
+        if (rv_row) { const float4 t = ld4(rv_row + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         if (p.act == DIFFSAL_ACT_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -284,14 +262,13 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
         }
-        const long o = ((static_cast<long>(img) * p.H + gy) * p.W + gx) * p.Cout + n;
         if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
       }
     }
-    if (ps == 0) __syncthreads();
-    stamp(4 + ps);
   }
+  stamp(4);
+  stamp(5);
 }
 
 template <int TW, int NW, int TN, typename T>

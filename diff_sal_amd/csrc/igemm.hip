@@ -50,6 +50,7 @@ struct IgemmArgs {
   int H, W, Cin, Ho, Wo, Cout;
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int act, rowvec_ld;
+  int linear;                // 1: 1x1 / stride 1 / no padding (a plain [M, Cin] x [Cin, Cout] product)
   int w_split;               // bf16x3 mode: weights arrive pre-split (diffsal_split_weight), no conversion of the B operand
   int n_tiles_n, n_tiles;  // tiles along N, total tiles
   unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
@@ -134,6 +135,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   for (int j = 0; j < A_PASSES; ++j) {
     int m = m0 + lrow_a + A_RPP * j;
     m = m < p.M ? m : p.M - 1;  // rows past M compute garbage that is never stored
+    if (p.linear) {   // 1x1, stride 1, no padding: row m of a [M, Cin] matrix -- skips three integer divisions per row
+      a_voff[j] = static_cast<unsigned>(m * p.Cin + lcol_a) * 4u;
+      a_valid[j] = 1u;
+      continue;
+    }
     const int n = m / HoWo;
     const int rem = m - n * HoWo;
     const int oy = rem / p.Wo;
@@ -421,7 +427,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   // ---- epilogue.  The weight fragment is the MFMA "A" operand, so D is the transposed tile: a lane holds, for output
   // row lane & 31 of its 32-row block, channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- register quads of four
   // consecutive channels.  The sums are staged through the idle LDS stages, NPASS row groups at a time, and leave as
-  // fully coalesced 16-byte pieces (a 96-channel row is 384 contiguous bytes) with the epilogue applied on the way;
+  // fully coalesced 16-byte pieces (a 96-channel row is 384 contiguous bytes) with the epilogue applied on the way
+  // (16-byte stores straight from the quads measured 2 % slower end to end here, 5-15 % FASTER in the 16-bit kernel);
   // scalar stores from the register layout (2 x 128 bytes per wave instruction) cost the short-K GEMMs a third of their time.
   const int col_l = lane & 31;
   const int hq = (lane >> 5) * 4;
@@ -679,6 +686,7 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
+  a.linear = d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W;
   DS_REQUIRE(d->w_format == 0 || (d->w_format == 1 && d->precision == DIFFSAL_PREC_BF16X3), DIFFSAL_E_ARG,
              "conv_igemm: w_format=%d needs precision = DIFFSAL_PREC_BF16X3 in the descriptor", d->w_format);
   a.w_split = d->w_format;
