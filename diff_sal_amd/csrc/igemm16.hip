@@ -56,6 +56,7 @@ struct Igemm16Args {
   unsigned in_bytes, w_bytes;
   int splits, st_per_split;  // split-K over 64-k stages
   int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is aligned for 8 / 16-byte pieces
+  int persist_wgs;           // > 0: workgroups of the persistent linear kernel (256 CUs x residents of the tile shape)
   float* partial;            // [splits][M][Cout] fp32 partial sums when splits > 1
 };
 
@@ -331,6 +332,219 @@ __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
   }
 }
 
+// =================================================================================================================
+// Persistent form for plain [M, K] x [K, N] products (1x1 convolutions / Linear layers, no split-K).  The short-K token
+// GEMMs of the transformer stages spend ~0.7 us of an ~8 us workgroup lifetime in MFMAs: the rest is index arithmetic, the
+// first-load latency and the store tail, once per 128-row tile (in-kernel stamps).  Here a workgroup
+// walks a strided list of tiles and the three-stage-ahead prefetch simply runs on into the next tile -- a tile's origin is
+// two byte offsets, so there is no per-tile setup to speak of -- while the register-direct epilogue needs neither LDS nor a
+// barrier.  Rows past M and columns past Cout read zeros through the buffer descriptors' range check.
+// =================================================================================================================
+template <int WM, int WN, int TM, int TN, typename T>
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm16_linear_kernel(Igemm16Args<T> p) {
+  typedef typename Mma16<T>::vec frag_t;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_PASSES = BM / 32;
+  constexpr int B_PASSES = BN / 32;
+  constexpr int STAGE = (BM + BN) * PITCH16;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = tid >> 3, l8 = tid & 7, lsub = l8 >> 2, lcol_dw = l8 * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.w), 0, static_cast<int>(p.w_bytes), 0x00020000);
+  unsigned a_rel[A_PASSES], b_rel[B_PASSES];   // byte offsets of this thread's 16-byte piece relative to the tile origin
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) a_rel[j] = static_cast<unsigned>((lrow + 32 * j) * p.K + l8 * 8) * 2u;
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) b_rel[j] = static_cast<unsigned>((lrow + 32 * j) * p.K + l8 * 8) * 2u;
+
+  const int KT32 = p.K / SUBK;
+  const int nst = (KT32 + 1) / 2;
+  const int n_tiles = p.n_tiles;
+  const int my_tiles = (n_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+  const int total = my_tiles * nst;                 // global stage count of this workgroup
+  // issue side: the next stage to fetch, as (tile, stage) with the tile's two origins
+  int iss_w = blockIdx.x, iss_st = 0;
+  unsigned iss_a = 0, iss_b = 0;
+  auto origins = [&](int w, unsigned& oa, unsigned& ob) __attribute__((always_inline)) {
+    const int tmi = w / p.n_tiles_n, tni = w - tmi * p.n_tiles_n;
+    oa = static_cast<unsigned>(tmi) * static_cast<unsigned>(BM * p.K * 2);
+    ob = static_cast<unsigned>(tni) * static_cast<unsigned>(BN * p.K * 2);
+  };
+  origins(iss_w, iss_a, iss_b);
+  float4 ra[2][A_PASSES], rb[2][B_PASSES];
+  auto issue_next = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    const bool live = iss_w < n_tiles;
+    const int ks = 2 * iss_st + lsub;
+    const unsigned dead = (live && ks < KT32) ? 0u : 0xFFFFFFFFu;
+    const unsigned kofs = static_cast<unsigned>(iss_st * STK) * 2u;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j)
+      ra[SET][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (iss_a + a_rel[j] + kofs) | dead, 0, 0));
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[SET][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (iss_b + b_rel[j] + kofs) | dead, 0, 0));
+    if (++iss_st == nst) {
+      iss_st = 0;
+      iss_w += gridDim.x;
+      if (iss_w < n_tiles) origins(iss_w, iss_a, iss_b);
+    }
+  };
+  auto store_tile = [&](float* stage, auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH16 + lcol_dw], ra[SET][j]);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH16 + lcol_dw], rb[SET][j]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const int a_frag = (wm * TM * 32 + frow) * PITCH16 + fk;
+  const int b_frag = (BM + wn * TN * 32 + frow) * PITCH16 + fk;
+  float4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](const float* stage, int kk, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = ld4(stage + a_frag + i * 32 * PITCH16 + kk * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[set][j] = ld4(stage + b_frag + j * 32 * PITCH16 + kk * 8);
+  };
+  auto do_mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = Mma16<T>::run(__builtin_bit_cast(frag_t, fb[set][j]), __builtin_bit_cast(frag_t, fa[set][i]), acc[i][j]);  // D^T
+  };
+
+  // compute side: which tile the stages being multiplied belong to
+  int cmp_w = blockIdx.x, cmp_st = 0;
+  const int col_l = lane & 31, hq = (lane >> 5) * 4;
+  const T* __restrict__ resid = p.residual;
+  T* __restrict__ outp = p.out;
+  // the residual quads of the tile being multiplied are fetched at its first k-step and wait in registers: in the epilogue
+  // they would be a dependent round trip with the matrix pipe idle
+  uint2 rres[TM][TN][4];
+  auto fetch_residual = [&]() __attribute__((always_inline)) {
+    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    const int m0 = tmi * BM, n0 = tni * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + col_l;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + (wn * TN + j) * 32 + g * 8 + hq;
+          const bool ok = m < p.M && n < p.Cout;
+          const long o = ok ? static_cast<long>(m) * p.Cout + n : 0;
+          rres[i][j][g] = *reinterpret_cast<const uint2*>(resid + o);
+        }
+    }
+  };
+  auto finish_tile = [&]() __attribute__((always_inline)) {
+    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    const int m0 = tmi * BM, n0 = tni * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + col_l;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + (wn * TN + j) * 32 + g * 8 + hq;
+          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          acc[i][j][4 * g] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+          if (m >= p.M || n >= p.Cout) continue;
+          const long o = static_cast<long>(m) * p.Cout + n;
+          if (p.bias) { const float4 t = ld4(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (p.scale) {
+            const float4 sc = ld4(p.scale + n);
+            const float4 sh = p.shift ? ld4(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+          }
+          if (p.rowvec) {
+            const float4 t = ld4(p.rowvec + static_cast<long>(m / (p.Ho * p.Wo)) * p.rowvec_ld + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+          }
+          if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+          }
+          if (resid) {
+            T rt[4];
+            __builtin_memcpy(rt, &rres[i][j][g], 8);
+            v[0] += static_cast<float>(rt[0]); v[1] += static_cast<float>(rt[1]); v[2] += static_cast<float>(rt[2]); v[3] += static_cast<float>(rt[3]);
+          }
+          st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
+        }
+      }
+    }
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  issue_next(S0{});                       // global stage 0
+  issue_next(S1{});                       // 1
+  store_tile(smem, S0{});
+  issue_next(S0{});                       // 2
+  __syncthreads();
+  load_frags(smem, 0, 0);
+  // global step g multiplies stage g from LDS, parks stage g+1 (register set (g+1) & 1) and re-uses that set for g+3
+  auto step = [&](int g, auto park_c) __attribute__((always_inline)) {
+    float* cur = smem + (g & 1) * STAGE;
+    float* nxt = smem + ((g & 1) ^ 1) * STAGE;
+    if (resid && cmp_st == 0) fetch_residual();
+    load_frags(cur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    store_tile(nxt, park_c);
+    issue_next(park_c);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    load_frags(nxt, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++cmp_st == nst) {                // that was the tile's last k-step: store it, start the next one from zero
+      finish_tile();
+      cmp_st = 0;
+      cmp_w += gridDim.x;
+    }
+  };
+  int g = 0;
+  for (; g + 1 < total; g += 2) {
+    step(g, S1{});
+    step(g + 1, S0{});
+  }
+  if (g < total) step(g, S1{});
+}
+
 // Sum the fp32 split-K slabs in a fixed order, apply the epilogue, round once to the storage type.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk16_reduce_kernel(Igemm16Args<T> p) {
@@ -413,6 +627,11 @@ static int launch16(Igemm16Args<T>& a, hipStream_t s) {
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
+  if (a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0) {   // plain product: persistent workgroups
+    const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
+    hipLaunchKernelGGL((igemm16_linear_kernel<WM, WN, TM, TN, T>), dim3(grid), dim3(256), 0, s, a);
+    return check_launch("diffsal_conv_igemm(16-bit linear)");
+  }
   hipLaunchKernelGGL((igemm16_kernel<WM, WN, TM, TN, T>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
   int rc = check_launch("diffsal_conv_igemm(16-bit)");
   if (rc || a.splits == 1) return rc;
@@ -484,6 +703,8 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
     a.vec_epilogue = d->Cout % 4 == 0 && al(out, 7) && al(residual, 7) && al(bias, 15) && al(scale, 15) && al(shift, 15) &&
                      al(rowvec, 15) && (!rowvec || a.rowvec_ld % 4 == 0) && al(a.partial, 15);
   }
+  a.persist_wgs = kCUs16 * kCfgs16[pl.cfg].occ;
+  if (const char* e = getenv("DIFFSAL_NO_PERSIST")) { if (e[0] == '1') a.persist_wgs = 0; }
   switch (pl.cfg) {
     case 0: return launch16<2, 2, 2, 3, T>(a, s);
     case 1: return launch16<2, 2, 2, 2, T>(a, s);
