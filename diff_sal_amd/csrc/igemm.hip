@@ -51,6 +51,7 @@ struct IgemmArgs {
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int act, rowvec_ld;
   int linear;                // 1: 1x1 / stride 1 / no padding (a plain [M, Cin] x [Cin, Cout] product)
+  int persist_wgs;           // > 0: workgroups of the persistent linear kernel (256 CUs x residents of the tile shape)
   int w_split;               // bf16x3 mode: weights arrive pre-split (diffsal_split_weight), no conversion of the B operand
   int n_tiles_n, n_tiles;  // tiles along N, total tiles
   unsigned in_bytes, w_bytes;  // sizes for the buffer descriptors (< 4 GiB each)
@@ -522,6 +523,206 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
   }
 }
 
+// =================================================================================================================
+// Persistent form for plain [M, K] x [K, N] products in exact fp32 (1x1 convolutions / Linear layers, no split-K): a
+// workgroup walks a strided list of tiles and the two-slices-ahead prefetch runs on into the next tile, whose origin is
+// just two byte offsets; the epilogue stores the register quads directly (no LDS, no barrier).  Per-tile index
+// arithmetic, first-load latency and store tail (1.8 + 1.5 + 4.7 us per 128 x 96 tile by the in-kernel stamps, against
+// ~9 us of MFMAs at K = 192) leave the critical path.  Same arithmetic and summation order as igemm_kernel<.., 0>.
+// =================================================================================================================
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kernel(IgemmArgs p) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_PASSES = BM / 32;
+  constexpr int B_PASSES = BN / 32;
+  constexpr int STAGE = (BM + BN) * PITCH;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, static_cast<int>(p.w_bytes), 0x00020000);
+  unsigned a_rel[A_PASSES], b_rel[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) a_rel[j] = static_cast<unsigned>((lrow + 32 * j) * p.K + lcol) * 4u;
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) b_rel[j] = static_cast<unsigned>((lrow + 32 * j) * p.K + lcol) * 4u;
+
+  const int nkt = p.K / BK;
+  const int n_tiles = p.n_tiles;
+  const int my_tiles = (n_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+  const int total = my_tiles * nkt;
+  int iss_w = blockIdx.x, iss_kt = 0;
+  unsigned iss_a = 0, iss_b = 0;
+  auto origins = [&](int w, unsigned& oa, unsigned& ob) __attribute__((always_inline)) {
+    const int tmi = w / p.n_tiles_n, tni = w - tmi * p.n_tiles_n;
+    oa = static_cast<unsigned>(tmi) * static_cast<unsigned>(BM * p.K * 4);
+    ob = static_cast<unsigned>(tni) * static_cast<unsigned>(BN * p.K * 4);
+  };
+  origins(iss_w, iss_a, iss_b);
+  float4 ra[A_PASSES], rb[B_PASSES];
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    const unsigned dead = iss_w < n_tiles ? 0u : 0xFFFFFFFFu;
+    const unsigned kofs = static_cast<unsigned>(iss_kt * BK) * 4u;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j)
+      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (iss_a + a_rel[j] + kofs) | dead, 0, 0));
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (iss_b + b_rel[j] + kofs) | dead, 0, 0));
+    if (++iss_kt == nkt) {
+      iss_kt = 0;
+      iss_w += gridDim.x;
+      if (iss_w < n_tiles) origins(iss_w, iss_a, iss_b);
+    }
+  };
+  auto store_tile = [&](float* stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) st4(&stage[(lrow + 32 * j) * PITCH + lcol], ra[j]);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) st4(&stage[(BM + lrow + 32 * j) * PITCH + lcol], rb[j]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const int a_frag = (wm * TM * 32 + frow) * PITCH + fk;
+  const int b_frag = (BM + wn * TN * 32 + frow) * PITCH + fk;
+  float4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](const float* stage, int kk, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[set][i] = ld4(stage + a_frag + i * 32 * PITCH + kk * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[set][j] = ld4(stage + b_frag + j * 32 * PITCH + kk * 8);
+  };
+  auto do_mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float av = s4 == 0 ? fa[set][i].x : s4 == 1 ? fa[set][i].y : s4 == 2 ? fa[set][i].z : fa[set][i].w;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float bv = s4 == 0 ? fb[set][j].x : s4 == 1 ? fb[set][j].y : s4 == 2 ? fb[set][j].z : fb[set][j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
+        }
+      }
+    }
+  };
+
+  int cmp_w = blockIdx.x, cmp_kt = 0;
+  const int col_l = lane & 31, hq = (lane >> 5) * 4;
+  const float* __restrict__ resid = p.residual;
+  float* __restrict__ outp = p.out;
+  auto finish_tile = [&]() __attribute__((always_inline)) {
+    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    const int m0 = tmi * BM, n0 = tni * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + col_l;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + (wn * TN + j) * 32 + g * 8 + hq;
+          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          acc[i][j][4 * g] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+          if (m >= p.M || n >= p.Cout) continue;
+          const long o = static_cast<long>(m) * p.Cout + n;
+          if (p.bias) { const float4 t = ld4(p.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (p.scale) {
+            const float4 sc = ld4(p.scale + n);
+            const float4 sh = p.shift ? ld4(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+          }
+          if (p.rowvec) {
+            const float4 t = ld4(p.rowvec + static_cast<long>(m / (p.Ho * p.Wo)) * p.rowvec_ld + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+          }
+          if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+          }
+          if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
+        }
+      }
+    }
+  };
+
+  // prologue: slices 0 and 1 in flight together (slice 1 borrows a second register set)
+  issue_next();
+  float4 ta[A_PASSES], tb[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) ta[j] = ra[j];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) tb[j] = rb[j];
+  issue_next();
+  {  // park slice 0 (in ta/tb); ra/rb keep slice 1
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) st4(&smem[(lrow + 32 * j) * PITCH + lcol], ta[j]);
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) st4(&smem[(BM + lrow + 32 * j) * PITCH + lcol], tb[j]);
+  }
+  __syncthreads();
+  load_frags(smem, 0, 0);
+  for (int g = 0; g < total; ++g) {
+    float* cur = smem + (g & 1) * STAGE;
+    float* nxt = smem + ((g & 1) ^ 1) * STAGE;
+    load_frags(cur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    store_tile(nxt);        // slice g+1
+    issue_next();           // slice g+2 starts its trip
+    {  // spread the LDS writes over the first half of this group's MFMAs and the buffer loads over the second
+      constexpr int NM = 4 * TM * TN, NW = A_PASSES + B_PASSES, H1 = NM / 2, PER = (NW + H1 - 1) / H1;
+#pragma unroll
+      for (int i = 0; i < H1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, PER, 0);
+      }
+#pragma unroll
+      for (int i = H1; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    load_frags(nxt, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++cmp_kt == nkt) {   // the tile's last K slice: store it, start the next tile from zero
+      finish_tile();
+      cmp_kt = 0;
+      cmp_w += gridDim.x;
+    }
+  }
+}
+
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue; float4 over Cout.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs p) {
   const int n4 = p.Cout >> 2;
@@ -609,6 +810,11 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
+  if (precision != DIFFSAL_PREC_BF16X3 && a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0) {
+    const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
+    hipLaunchKernelGGL((igemm_linear_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, s, a);
+    return check_launch("diffsal_conv_igemm(linear)");
+  }
   if (precision == DIFFSAL_PREC_BF16X3)
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 1>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
   else
@@ -716,6 +922,8 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
   }
   a.vec_epilogue = d->Cout % 4 == 0 && aligned16(out) && (!residual || aligned16(residual)) && (!bias || aligned16(bias)) &&
                    (!scale || (aligned16(scale) && aligned16(shift))) && (!rowvec || (aligned16(rowvec) && a.rowvec_ld % 4 == 0));
+  a.persist_wgs = kCUs * kCfgs[pl.cfg].occ;
+  if (const char* e = getenv("DIFFSAL_NO_PERSIST")) { if (e[0] == '1') a.persist_wgs = 0; }
   switch (pl.cfg) {
     case 0: return launch<2, 2, 2, 3>(a, s, d->precision);
     case 1: return launch<2, 2, 2, 2>(a, s, d->precision);

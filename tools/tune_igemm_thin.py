@@ -22,9 +22,15 @@ def main():
         w = torch.randn(N, K, device="cuda") * 0.05
         b = torch.randn(N, device="cuda")
         os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        os.environ["DIFFSAL_NO_PERSIST"] = "1"
+        y0 = ops.linear(x, w, b)
+        us0 = timed(lambda: ops.linear(x, w, b))
+        os.environ["DIFFSAL_NO_PERSIST"] = "0"
+        y1 = ops.linear(x, w, b)
         us = timed(lambda: ops.linear(x, w, b))
         fl = 2.0 * M * K * N
-        line = f"M={M:6d} K={K:4d} N={N:4d} planner {us:7.1f} us {fl / us / 1e6:6.1f} TF/s |"
+        line = (f"M={M:6d} K={K:4d} N={N:4d} one-tile {us0:7.1f} us | persistent {us:7.1f} us {fl / us / 1e6:6.1f} TF/s "
+                f"diff {(y0 - y1).abs().max().item():.1e} |")
         for c, cn in enumerate(CFG):
             if (c == 0 and N < 161) or (c in (1, 3) and N < 97):
                 continue
