@@ -482,7 +482,8 @@ def main():
               "classes": class_table(all_ev, peak_for_mode)}
     if args.precision == "fp32":
         roofline = {
-            "kernel": "diffsal::igemm_kernel (fp32 MFMA implicit GEMM: 3x3 convs, token GEMMs, ReduceTemp)",
+            "kernel": "diffsal::igemm_kernel / igemm_linear_kernel / lin_stream_kernel / mlp_block_kernel (fp32 MFMA GEMM family: "
+                      "3x3 convs, token GEMMs, ReduceTemp, fused MLP)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **common}
     elif args.precision == "bf16x3":   # three bf16 MFMAs per fp32-accurate product: the instruction-level peak is the bf16 one
@@ -495,10 +496,10 @@ def main():
             **common}
     else:
         roofline = {
-            "kernel": f"diffsal::igemm16_kernel<..., {args.precision}> (native 16-bit MFMA implicit GEMM on {args.precision} "
-                      "storage, fp32 accumulate)",
+            "kernel": f"diffsal::igemm16_kernel / igemm16_linear_kernel / conv16_halo_kernel / block16_kernel <{args.precision}> "
+                      f"(native 16-bit MFMA GEMM family on {args.precision} storage, fp32 accumulate)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, **common}
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **common}
 
     DT_LABEL = {"fp32": "f32", "bf16x3": "f32 in/out, bf16x3 split-precision MFMA (NOT the headline configuration)",
                 "bf16": "bf16 storage, f32 accumulate (NOT the headline configuration; BASELINE configs[1] as written)",
