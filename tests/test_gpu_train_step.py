@@ -344,9 +344,10 @@ def test_end_to_end_training_through_video_saliency_model_with_a_torch_encoder()
     assert all(p.grad is None or p.grad.data_ptr() >= ts.flat.flat_g.data_ptr() for p in model.parameters())
 
 
-def test_full_size_training_gradients_match_oracle_autograd():
-    """BASELINE-size (224x384, 768/384/192/96 channels) audio-visual clip, B=1: every parameter gradient of the HIP path vs
-    autograd through the CPU oracle.  This is the only test that runs the training kernels in the configurations the
+@pytest.mark.parametrize("B", [1, 4])
+def test_full_size_training_gradients_match_oracle_autograd(B):
+    """BASELINE-size (224x384, 768/384/192/96 channels) audio-visual clips, B=1 and B=4 (the per-GPU batch of BASELINE
+    configs[3]): every parameter gradient of the HIP path vs autograd through the CPU oracle.  This is the only test that runs the training kernels in the configurations the
     benchmark uses (streaming token GEMMs in the data gradient, all weight-gradient tile shapes and split plans, the
     segmented GEMMs of the attention backward at Lq=5376, the disjoint-tap data gradients, 9.3 M-element reductions).
     With 23.8 M ReLU pre-activations sign flips are certain (measured on this very input with tests/diagnostics/relu_flip_census.py
@@ -356,9 +357,10 @@ def test_full_size_training_gradients_match_oracle_autograd():
     torch.manual_seed(0)
     cfg = orc.SalUNetConfig()
     sd = orc.synth_state_dict(orc.state_dict_template(cfg))
-    x, feats, audio = orc.synth_inputs(cfg, 1, True, tag="fulltrain")
-    x0 = torch.sigmoid(orc.synth_tensor("fulltrain.x0", (1, 1, *cfg.img_size)))
-    t = torch.tensor([637])
+    tag = "fulltrain" if B == 1 else f"fulltrain{B}"
+    x, feats, audio = orc.synth_inputs(cfg, B, True, tag=tag)
+    x0 = torch.sigmoid(orc.synth_tensor(tag + ".x0", (B, 1, *cfg.img_size)))
+    t = torch.tensor([637] * B)
     leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
     orc.BN_TRAIN = True
     try:
