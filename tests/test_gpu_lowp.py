@@ -311,3 +311,58 @@ def test_block16_fused_kernel(ops, dname, M, with_z):
     if with_z:
         kept = ((torch.arange(M) // hw) % T) < keep
         assert rel_err(z.float().cpu()[kept], ref_z[kept]) < 3 * OP_RTOL[dname]
+
+
+HALO_CASES = [
+    # N, H, W, Cin, Cout, dil   (forced: the planner only picks the halo kernel from 80 000 pixels up)
+    (3, 13, 19, 64, 80, 2),      # narrow tile, ragged rows / columns / channels (80 = 2.5 MFMA column tiles)
+    (2, 16, 32, 96, 96, 1),      # exactly one wide tile per image
+    (1, 40, 70, 32, 128, 1),     # wide tile with a column remainder, one channel chunk, 128-wide N tile
+    (2, 33, 48, 160, 192, 2),    # two N tiles, five chunks, row remainder of one
+]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_halo_conv_kernel_matches_generic_kernel_and_torch(ops, case, dname, monkeypatch):
+    """conv16_halo_kernel (LDS patch, weight-row ring) on shapes with every kind of remainder: bit-identical to igemm16_kernel
+    (same k order, same fp32 accumulation) and within the datapath tolerance of torch, with the full epilogue."""
+    dt = DTYPES[dname]
+    N, H, W, Cin, Cout, d = case
+    x = q(rnd("hx%d" % Cin, N, Cin, H, W), dt)
+    w = q(rnd("hw%d" % Cout, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin)), dt)
+    b = rnd("hb", Cout, scale=0.1)
+    res = q(rnd("hr", N, Cout, H, W), dt)
+    ref = F.relu(F.conv2d(x, w, b, padding=d, dilation=d)) + res
+    wp = ops.cast(ops.pack_conv_weight(w.to(DEV)), dt)
+    args = dict(kh=3, kw=3, pad=(d, d), dil=(d, d), bias=b.to(DEV), act=ops.ACT_RELU, residual=nhwc(res).to(DEV).to(dt))
+    xin = nhwc(x).to(DEV).to(dt)
+    monkeypatch.setenv("DIFFSAL_NO_HALO", "1")
+    generic = ops.conv_igemm(xin, wp, **args)
+    monkeypatch.setenv("DIFFSAL_NO_HALO", "0")
+    monkeypatch.setenv("DIFFSAL_FORCE_HALO", "1")
+    halo = ops.conv_igemm(xin, wp, **args)
+    assert torch.equal(halo, generic)
+    assert rel_err(halo, nhwc(ref)) < OP_RTOL[dname]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7])
+def test_persistent_linear_kernel_16bit(ops, dname, cfg, monkeypatch):
+    """igemm16_linear_kernel (tiles walked by persistent workgroups, prefetch across tile boundaries) == the one-tile kernel,
+    bit for bit, for every tile shape, on row / column remainders, K = 32 (one stage), 96 (half-empty stage) and 160."""
+    dt = DTYPES[dname]
+    if cfg is not None:
+        monkeypatch.setenv("DIFFSAL_IGEMM16_CFG", str(cfg))
+    for M, K, N in ((1000, 160, 72), (130, 96, 100), (4100, 32, 224), (777, 384, 96)):
+        x = q(rnd("px%d" % K, M, K), dt).to(DEV).to(dt)
+        w = q(rnd("pw%d" % N, N, K, scale=1.0 / math.sqrt(K)), dt).to(DEV).to(dt)
+        b = rnd("pb", N, scale=0.1).to(DEV)
+        r = q(rnd("pr", M, N), dt).to(DEV).to(dt)
+        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+        one = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
+        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
+        per = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
+        assert torch.equal(one, per), (M, K, N)
+        ref = F.gelu(x.float() @ w.float().t() + b) + r.float()
+        assert rel_err(per, ref) < OP_RTOL[dname]

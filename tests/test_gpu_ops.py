@@ -98,6 +98,22 @@ def test_linear_matches_torch(ops, M, K, N, act):
     assert rel_err(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
+def test_persistent_linear_kernel_fp32(ops, cfg, monkeypatch):
+    """igemm_linear_kernel (persistent workgroups, prefetch across tile boundaries, register-direct stores) == the one-tile
+    kernel bit for bit, for every tile shape, with row / column remainders, K = 32 (a single slice), 96 and 160."""
+    if cfg is not None:
+        monkeypatch.setenv("DIFFSAL_IGEMM_CFG", str(cfg))
+    for M, K, N in ((1000, 160, 72), (130, 96, 100), (4100, 32, 224), (777, 384, 96)):
+        x, w, b, r = rnd("px%d" % K, M, K).to(DEV), rnd("pw%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("pb", N, scale=0.1).to(DEV), rnd("pr", M, N).to(DEV)
+        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+        one = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
+        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
+        per = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
+        assert torch.equal(one, per), (M, K, N)
+        assert rel_err(per, F.gelu(F.linear(x, w, b)) + r) < 2e-5
+
+
 @pytest.mark.parametrize("K,N,act,res", [(96, 96, 0, True), (96, 96, 0, False), (96, 192, 2, False), (192, 96, 0, True),
                                          (96, 192, 1, True)])
 def test_streaming_short_k_linear(ops, K, N, act, res):
