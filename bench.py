@@ -254,6 +254,14 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
             el = float(tt.item())
         regions.append(el)
     elapsed = median(regions)
+    if args.dump_launches and rank == 0:     # per-launch table of the profiled step (shape -> TF/s, GB/s)
+        rows = []
+        for e0, e1, fl, cls, nb, *note in ev:
+            us = e0.elapsed_time(e1) * 1e3
+            rows.append({"class": cls, "op": note[0] if note else "", "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3),
+                         "us": round(us, 2), "tflops": round(fl / us / 1e6, 2) if us > 0 else 0.0,
+                         "gbs": round(nb / us / 1e3, 1) if us > 0 else 0.0})
+        json.dump({"workload": "train", "mode": args.mode, "batch": B, "launches": rows}, open(args.dump_launches, "w"), indent=0)
     gemm_ev = [e for e in ev if e[3] in GEMM_CLASSES]
     k_ms = sum(e[0].elapsed_time(e[1]) for e in gemm_ev)
     k_flops = sum(e[2] for e in gemm_ev)

@@ -483,7 +483,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     if want_bias:
         splits = lib.diffsal_conv_wgrad_splits(C.byref(d))
         bpart = torch.empty((splits, Cout), device=x.device, dtype=torch.float64)
-    with _prof("wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, dy, dw)):
+    with _prof("wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, dy, dw),
+               f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw}" if PROFILE is not None else ""):
         _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), bpart.data_ptr() if want_bias else None, _p(ws),
                                           nws, _stream()), "conv_wgrad")
     if want_bias:
