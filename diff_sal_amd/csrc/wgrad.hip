@@ -27,6 +27,7 @@ struct WgradArgs {
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
   int seg_rows, splits, rows_per_split;   // blockIdx.z = segment * splits + split
   unsigned in_bytes;
+  unsigned dy_bytes;   // M * Cout * 4 (< 4 GiB): dY goes through a buffer descriptor too, so that its tail loads need no branch
 };
 
 constexpr int WG_BM = 64;     // granularity of the M split (a multiple of every kernel's rows-per-step)
@@ -57,6 +58,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   const int HoWo = p.Ho * p.Wo;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, static_cast<int>(p.in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, static_cast<int>(p.dy_bytes), 0x00020000);
 
   f32x16 acc[CT][ST];
 #pragma unroll
@@ -92,8 +95,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       const int idx = tid + 256 * q;
       const int r = idx / (BCO / 4), c4 = (idx - r * (BCO / 4)) * 4;
       const int m = mb + r, co = co0 + c4;
-      ra[q] = make_float4(0, 0, 0, 0);
-      if (m < m_end && co < p.Cout) ra[q] = ld4(p.dy + static_cast<long>(m) * p.Cout + co);  // Cout % 4 == 0
+      // branch-free (a conditional load costs a branch and a full vmcnt drain per piece): rows past the split's end and
+      // columns past Cout read zeros through the descriptor's range check.  Cout % 4 == 0.
+      const unsigned off = (m < m_end && co < p.Cout) ? static_cast<unsigned>(m * p.Cout + co) * 4u : 0xFFFFFFFFu;
+      ra[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, off, 0, 0));
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
@@ -350,8 +355,8 @@ extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, c
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const long K = static_cast<long>(d->KH) * d->KW * d->Cin;
   const long in_bytes = static_cast<long>(d->N) * d->H * d->W * d->Cin * 4;
-  DS_REQUIRE(M > 0 && M < (1L << 31) && in_bytes < (1L << 32) - 16 && d->KH * d->KW <= 32, DIFFSAL_E_SHAPE,
-             "conv_wgrad: problem too large");
+  DS_REQUIRE(M > 0 && M < (1L << 31) && in_bytes < (1L << 32) - 16 && M * d->Cout * 4 < (1L << 32) - 16 && d->KH * d->KW <= 32,
+             DIFFSAL_E_SHAPE, "conv_wgrad: problem too large");
   const size_t need = diffsal_conv_wgrad_ws_bytes(d);
   DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(in) && aligned16(dw_packed), DIFFSAL_E_ARG,
              "conv_wgrad: needs %zu bytes of 16-byte aligned workspace", need);
@@ -363,6 +368,7 @@ extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, c
   a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil_h = d->dil_h; a.dil_w = d->dil_w;
   a.seg_rows = static_cast<int>(M);
   a.in_bytes = static_cast<unsigned>(in_bytes);
+  a.dy_bytes = static_cast<unsigned>(M * d->Cout * 4);
   return wgrad_launch(a, 1, dw_packed, static_cast<hipStream_t>(stream));
 }
 
@@ -379,7 +385,8 @@ extern "C" int diffsal_wgrad_segmented(const float* x, const float* dy, float* o
              "wgrad_segmented: bad shape segments=%d seg_rows=%d K=%d Cout=%d", segments, seg_rows, K, Cout);
   const long M = static_cast<long>(segments) * seg_rows;
   const long in_bytes = M * K * 4;
-  DS_REQUIRE(M < (1L << 31) && in_bytes < (1L << 32) - 16, DIFFSAL_E_SHAPE, "wgrad_segmented: problem too large");
+  DS_REQUIRE(M < (1L << 31) && in_bytes < (1L << 32) - 16 && M * Cout * 4 < (1L << 32) - 16, DIFFSAL_E_SHAPE,
+             "wgrad_segmented: problem too large");
   const size_t need = diffsal_wgrad_segmented_ws_bytes(segments, seg_rows, K, Cout);
   DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(x) && aligned16(out), DIFFSAL_E_ARG,
              "wgrad_segmented: needs %zu bytes of 16-byte aligned workspace", need);
@@ -390,6 +397,7 @@ extern "C" int diffsal_wgrad_segmented(const float* x, const float* dy, float* o
   a.KW = 1; a.taps = 1; a.stride_h = 1; a.stride_w = 1; a.pad_t = 0; a.pad_l = 0; a.dil_h = 1; a.dil_w = 1;
   a.seg_rows = seg_rows;
   a.in_bytes = static_cast<unsigned>(in_bytes);
+  a.dy_bytes = static_cast<unsigned>(M * Cout * 4);
   return wgrad_launch(a, segments, out, static_cast<hipStream_t>(stream));
 }
 
