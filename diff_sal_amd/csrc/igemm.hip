@@ -622,6 +622,25 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
   const int col_l = lane & 31, hq = (lane >> 5) * 4;
   const float* __restrict__ resid = p.residual;
   float* __restrict__ outp = p.out;
+  // the residual quads of the tile being multiplied are fetched at its first K slice and wait in registers: in the epilogue
+  // they would be a dependent round trip with the matrix pipe idle
+  float4 rres[TM][TN][4];
+  auto fetch_residual = [&]() __attribute__((always_inline)) {
+    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    const int m0 = tmi * BM, n0 = tni * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + col_l;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + (wn * TN + j) * 32 + g * 8 + hq;
+          const bool ok = m < p.M && n < p.Cout;
+          rres[i][j][g] = ld4(resid + (ok ? static_cast<long>(m) * p.Cout + n : 0));
+        }
+    }
+  };
   auto finish_tile = [&]() __attribute__((always_inline)) {
     const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
     const int m0 = tmi * BM, n0 = tni * BN;
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
           }
-          if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (resid) { const float4 t = rres[i][j][g]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
           st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
         }
       }
@@ -683,6 +702,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
   for (int g = 0; g < total; ++g) {
     float* cur = smem + (g & 1) * STAGE;
     float* nxt = smem + ((g & 1) ^ 1) * STAGE;
+    if (resid && cmp_kt == 0) fetch_residual();
     load_frags(cur, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     do_mfmas(0);
