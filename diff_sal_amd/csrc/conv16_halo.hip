@@ -76,7 +76,14 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
   auto stamp = [&](int k) { if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + k] = wall_clock64(); };
   stamp(0);
   // block -> (image, tile_y, tile_x, n tile); consecutive blocks share the patch's neighbourhood and the same weights
-  int b = blockIdx.x;
+  int b;
+  {  // XCD-aware order (see igemm.hip): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
+     // tiles -- neighbouring patches share their halo rows and the N tiles of a patch share all of it, in ONE L2
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
   const int tn = b % p.tiles_n; b /= p.tiles_n;
   const int tx = b % p.tiles_x; b /= p.tiles_x;
   const int ty = b % p.tiles_y;
