@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 SIGNATURES = {
@@ -38,6 +38,11 @@ SIGNATURES = {
     "diffsal_maxpool2d": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_groupnorm_ws_bytes": (c_sz, [c_i, c_i]),
     "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_i, c_f]),
+    "diffsal_groupnorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_f, c_sz, c_i, c_f]),
+    "diffsal_softmax_rows": (c_i, [c_f, c_f, C.c_long, c_i, c_fl, c_f]),
+    "diffsal_upsample_nearest2": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_avgpool2": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_sigmoid_gate": (c_i, [c_f, c_f, c_f, C.c_long, c_f]),
     "diffsal_conv_igemm_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),

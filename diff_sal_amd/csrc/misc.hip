@@ -605,7 +605,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 6; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 7; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
@@ -695,6 +695,106 @@ static void resize_bilinear_t(const T* in, T* out, int N, int h, int w, int H, i
     const long total = static_cast<long>(N) * H * W * C;
     hipLaunchKernelGGL((resize_kernel<1, T>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pieces of the legacy DDPM-style UNet (R/models/diffusion_decoder/diffusion.py), fp32, NHWC:
+//   softmax_rows      out[r, :] = softmax(scale * x[r, :])               AttnBlock :166-168 (full HW x HW attention)
+//   upsample_nearest2 out[n, 2y+dy, 2x+dx, :] = in[n, y, x, :]           Upsample :46-47
+//   avgpool2          out[n, y, x, :] = mean of the 2x2 window           Downsample without conv :69
+//   sigmoid_gate      out = sigmoid(y) * x                               feat_interact :318
+// ------------------------------------------------------------------------------------------------
+namespace diffsal {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                           int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);   // one wavefront per row
+  if (row >= rows) return;
+  const float* xr = x + row * cols;
+  float* orow = out + row * cols;
+  float mx = -3.0e38f;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xr[c] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += expf(xr[c] * scale - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < cols; c += 64) orow[c] = expf(xr[c] * scale - mx) * inv;
+}
+
+__global__ __launch_bounds__(256) void upsample_nearest2_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
+                                                                int W, int C, long total4) {
+  const int c4n = C >> 2;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c4 = static_cast<int>(i % c4n);
+    long r = i / c4n;
+    const int X = static_cast<int>(r % (2 * W)); r /= 2 * W;
+    const int Y = static_cast<int>(r % (2 * H));
+    const long n = r / (2 * H);
+    st4(out + i * 4, ld4(in + ((n * H + (Y >> 1)) * W + (X >> 1)) * C + c4 * 4));
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                       int C, long total4) {
+  const int c4n = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c4 = static_cast<int>(i % c4n);
+    long r = i / c4n;
+    const int X = static_cast<int>(r % Wo); r /= Wo;
+    const int Y = static_cast<int>(r % Ho);
+    const long n = r / Ho;
+    const float* b = in + ((n * H + 2 * Y) * W + 2 * X) * C + c4 * 4;
+    const float4 a = ld4(b), bb = ld4(b + C), c = ld4(b + static_cast<long>(W) * C), d = ld4(b + static_cast<long>(W) * C + C);
+    // torch.avg_pool2d sums the window in (row, column) order and multiplies by 1 / 4
+    st4(out + i * 4, make_float4(((a.x + bb.x) + c.x + d.x) * 0.25f, ((a.y + bb.y) + c.y + d.y) * 0.25f,
+                                 ((a.z + bb.z) + c.z + d.z) * 0.25f, ((a.w + bb.w) + c.w + d.w) * 0.25f));
+  }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_gate_kernel(const float* __restrict__ y, const float* __restrict__ x,
+                                                           float* __restrict__ out, long n4) {
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<long>(gridDim.x) * 256) {
+    const float4 a = ld4(y + i * 4), b = ld4(x + i * 4);
+    st4(out + i * 4, make_float4(sigmoidf_(a.x) * b.x, sigmoidf_(a.y) * b.y, sigmoidf_(a.z) * b.z, sigmoidf_(a.w) * b.w));
+  }
+}
+
+}  // namespace diffsal
+using namespace diffsal;
+
+extern "C" int diffsal_softmax_rows(const float* x, float* out, long rows, int cols, float scale, diffsal_stream_t stream) {
+  DS_REQUIRE(x && out && rows > 0 && cols > 0, DIFFSAL_E_ARG, "softmax_rows: bad argument");
+  DS_REQUIRE((rows + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "softmax_rows: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, out, rows, cols, scale);
+  return check_launch("softmax_rows");
+}
+
+extern "C" int diffsal_upsample_nearest2(const float* in, float* out, int N, int H, int W, int C, diffsal_stream_t stream) {
+  DS_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "upsample_nearest2: bad shape");
+  DS_REQUIRE(aligned16(in) && aligned16(out), DIFFSAL_E_ALIGN, "upsample_nearest2: misaligned pointer");
+  const long total4 = static_cast<long>(N) * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_nearest2_kernel, dim3(ew_grid(total4)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, H, W, C,
+                     total4);
+  return check_launch("upsample_nearest2");
+}
+
+extern "C" int diffsal_avgpool2(const float* in, float* out, int N, int H, int W, int C, diffsal_stream_t stream) {
+  DS_REQUIRE(in && out && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "avgpool2: bad shape");
+  DS_REQUIRE(aligned16(in) && aligned16(out), DIFFSAL_E_ALIGN, "avgpool2: misaligned pointer");
+  const long total4 = static_cast<long>(N) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(ew_grid(total4)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, H, W, C, total4);
+  return check_launch("avgpool2");
+}
+
+extern "C" int diffsal_sigmoid_gate(const float* y, const float* x, float* out, long n, diffsal_stream_t stream) {
+  DS_REQUIRE(y && x && out && n > 0 && n % 4 == 0, DIFFSAL_E_SHAPE, "sigmoid_gate: bad argument (n %% 4 == 0)");
+  DS_REQUIRE(aligned16(y) && aligned16(x) && aligned16(out), DIFFSAL_E_ALIGN, "sigmoid_gate: misaligned pointer");
+  hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), y, x, out, n / 4);
+  return check_launch("sigmoid_gate");
 }
 
 extern "C" int diffsal_resize_bilinear(const void* in, void* out, int N, int h, int w, int H, int W, int C, int dtype,

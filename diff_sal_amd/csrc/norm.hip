@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const double* __restrict__ ws,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       T* __restrict__ out, int HW, int C, int groups, float eps) {
+                                                       T* __restrict__ out, int HW, int C, int groups, float eps, int swish) {
   extern __shared__ float shf[];  // [C] scale, [C] shift
   const int b = blockIdx.y;
   const int cpg = C / groups;
@@ -97,10 +97,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
     const int c = static_cast<int>(i % c4n) * 4;
     float4 v = ld4(xb + i * 4);
-    v.x = swishf(v.x * shf[c + 0] + shf[C + c + 0]);
-    v.y = swishf(v.y * shf[c + 1] + shf[C + c + 1]);
-    v.z = swishf(v.z * shf[c + 2] + shf[C + c + 2]);
-    v.w = swishf(v.w * shf[c + 3] + shf[C + c + 3]);
+    v.x = v.x * shf[c + 0] + shf[C + c + 0];
+    v.y = v.y * shf[c + 1] + shf[C + c + 1];
+    v.z = v.z * shf[c + 2] + shf[C + c + 2];
+    v.w = v.w * shf[c + 3] + shf[C + c + 3];
+    if (swish) { v.x = swishf(v.x); v.y = swishf(v.y); v.z = swishf(v.z); v.w = swishf(v.w); }
     st4(ob + i * 4, v);
   }
 }
@@ -355,7 +356,7 @@ extern "C" size_t diffsal_groupnorm_ws_bytes(int B, int groups) {
 
 template <typename T>
 static int groupnorm_swish_t(const T* x, const float* gamma, const float* beta, T* out, int B, int HW, int C, int groups,
-                             float eps, void* ws, hipStream_t s) {
+                             float eps, void* ws, hipStream_t s, int swish = 1) {
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(GN_CHUNKS, B), dim3(256), 2 * C * sizeof(double), s, x,
                      static_cast<double*>(ws), HW, C, groups);
   int rc = check_launch("groupnorm_swish(stats)");
@@ -364,7 +365,7 @@ static int groupnorm_swish_t(const T* x, const float* gamma, const float* beta, 
   int gx = static_cast<int>((total4 + 255) / 256);
   gx = gx > 512 ? 512 : gx;
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x,
-                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps);
+                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps, swish);
   return check_launch("groupnorm_swish(apply)");
 }
 
@@ -379,6 +380,22 @@ extern "C" int diffsal_groupnorm_swish(const void* x, const float* gamma, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(T) return groupnorm_swish_t<T>(static_cast<const T*>(x), gamma, beta, static_cast<T*>(out), B, HW, C, groups, eps, ws, s)
   DS_DTYPE_DISPATCH(dtype, "groupnorm_swish", CALL);
+#undef CALL
+  return DIFFSAL_OK;
+}
+
+// GroupNorm with the activation optional: act = 0 plain affine GroupNorm (AttnBlock.norm of the legacy UNet,
+// R/models/diffusion_decoder/diffusion.py:145,173), act = 1 the K3 form above.
+extern "C" int diffsal_groupnorm(const void* x, const float* gamma, const float* beta, void* out, int B, int HW, int C,
+                                 int groups, float eps, int act, void* ws, size_t ws_bytes, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(x && gamma && beta && out && ws, DIFFSAL_E_ARG, "groupnorm: null argument");
+  DS_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 1024 && (act == 0 || act == 1),
+             DIFFSAL_E_SHAPE, "groupnorm: bad shape B=%d HW=%d C=%d groups=%d act=%d", B, HW, C, groups, act);
+  DS_REQUIRE(ws_bytes >= diffsal_groupnorm_ws_bytes(B, groups), DIFFSAL_E_ARG, "groupnorm: workspace too small");
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(ws), DIFFSAL_E_ALIGN, "groupnorm: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(T) return groupnorm_swish_t<T>(static_cast<const T*>(x), gamma, beta, static_cast<T*>(out), B, HW, C, groups, eps, ws, s, act)
+  DS_DTYPE_DISPATCH(dtype, "groupnorm", CALL);
 #undef CALL
   return DIFFSAL_OK;
 }

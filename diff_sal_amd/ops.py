@@ -1079,3 +1079,55 @@ def block16(o: Tensor, x: Tensor, proj, norm2, fc1, fc2, norm_z=None, frames=Non
                                        None if z is None else z.data_ptr(), _p(gz), _p(bz), float(ez), M, Cc, hid, hw, T, tk, dt,
                                        _stream()), "block16")
     return x2, z
+
+
+# ---- pieces of the legacy DDPM-style UNet (diffusion_unet.py; R/models/diffusion_decoder/diffusion.py) ----------------
+def groupnorm(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1e-6, swish: bool = False) -> Tensor:
+    """GroupNorm on NHWC [B,H,W,C] with the swish optional (AttnBlock.norm has none)."""
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    nbytes = lib.diffsal_groupnorm_ws_bytes(B, groups)
+    ws = torch.empty((nbytes // 8,), device=x.device, dtype=torch.float64)
+    dt = _dt(x)
+    with _prof("K3", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_groupnorm(_pa(x, dt), _p(gamma), _p(beta), _pa(out, dt), B, H * W, Cc, groups, eps, int(swish),
+                                         ws.data_ptr(), nbytes, dt, _stream()), "groupnorm")
+    return out
+
+
+def softmax_rows(x: Tensor, scale: float = 1.0) -> Tensor:
+    """softmax(scale * x) over the last axis of a contiguous fp32 tensor."""
+    lib = _lib.load()
+    cols = x.shape[-1]
+    out = torch.empty_like(x)
+    with _prof("softmax", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_softmax_rows(_p(x), _p(out), x.numel() // cols, cols, float(scale), _stream()), "softmax_rows")
+    return out
+
+
+def upsample_nearest2(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, 2 * H, 2 * W, Cc), device=x.device, dtype=torch.float32)
+    with _prof("K12-up", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_upsample_nearest2(_p(x), _p(out), N, H, W, Cc, _stream()), "upsample_nearest2")
+    return out
+
+
+def avgpool2(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
+    with _prof("pool", 0.0, _nb(x, out)):
+        _lib.check(lib.diffsal_avgpool2(_p(x), _p(out), N, H, W, Cc, _stream()), "avgpool2")
+    return out
+
+
+def sigmoid_gate(y: Tensor, x: Tensor) -> Tensor:
+    """sigmoid(y) * x, same shape, fp32 contiguous."""
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    with _prof("K15", 0.0, _nb(y, x, out)):
+        _lib.check(lib.diffsal_sigmoid_gate(_p(y), _p(x), _p(out), x.numel(), _stream()), "sigmoid_gate")
+    return out

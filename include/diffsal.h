@@ -388,6 +388,20 @@ int diffsal_relpos_project_bwd(const float* dextra, const float* q, const float*
                                int accumulate, double* part /*[chunks][(qt*kt + qh*kh + qw*kw) * D]: dRt | dRh | dRw partials*/,
                                int BH, int D, int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream);
 
+/* ---- legacy DDPM-style UNet of R/models/diffusion_decoder/diffusion.py (DiffusionModel :197-357; not instantiated by
+ * any configuration of the reference, kept for completeness of the models/diffusion_decoder surface), fp32 NHWC.  Its
+ * ResnetBlocks / Downsample / conv_out reuse diffsal_conv_igemm and K3; what it adds:
+ *   groupnorm         GroupNorm with the activation optional (act 0: AttnBlock.norm :145,173; act 1 == groupnorm_swish)
+ *   softmax_rows      out[r,:] = softmax(scale * x[r,:]) over the HW keys of the full self-attention (:166-168); the two
+ *                     products around it are diffsal_conv_igemm calls with k / v^T of one image as the weight operand
+ *   upsample_nearest2 Upsample :46-47;  avgpool2: Downsample without conv :69;  sigmoid_gate: feat_interact :318 */
+int diffsal_groupnorm(const void* x, const float* gamma, const float* beta, void* out, int B, int HW, int C, int groups,
+                      float eps, int act, void* ws, size_t ws_bytes, int dtype, diffsal_stream_t stream);
+int diffsal_softmax_rows(const float* x, float* out, long rows, int cols, float scale, diffsal_stream_t stream);
+int diffsal_upsample_nearest2(const float* in, float* out, int N, int H, int W, int C, diffsal_stream_t stream);
+int diffsal_avgpool2(const float* in, float* out, int N, int H, int W, int C, diffsal_stream_t stream);
+int diffsal_sigmoid_gate(const float* y, const float* x, float* out, long n, diffsal_stream_t stream);
+
 /* ---- VGGish feature stack (R/models/vggish.py:70-106): 3x3 convs are diffsal_conv_in (1 input channel, act = ReLU) and
  * diffsal_conv_igemm (bias + ReLU epilogue); this is its MaxPool2d(k, stride) on NHWC (no padding, floor). */
 int diffsal_maxpool2d(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int dtype,

@@ -511,13 +511,52 @@ def gen_legacy_denoising():
     print("legacy denoising: final ddim", float(d["ddim.eta0.0.xs"][-1].mean()), "ddpm", float(d["ddpm.xs"][-1].mean()))
 
 
+LEGACY_UNET_CASES = {
+    # name: (config kwargs, batch, H, W)
+    "tiny": (dict(), 2, 16, 32),
+    "pool": (dict(ch=32, ch_mult=(1, 4, 16), num_res_blocks=2, attn_resolutions=(16, 4), in_channels=3, out_ch=2,
+                  resamp_with_conv=False, model_type="bayesian"), 1, 16, 16),
+}
+
+
+def gen_legacy_unet():
+    """The legacy DDPM-style UNet, R/models/diffusion_decoder/diffusion.py:197-357 (DiffusionModel), run as shipped."""
+    from models.diffusion_decoder.diffusion import DiffusionModel
+    from oracle import legacy_unet_oracle as lo
+
+    for name, (kw, B, H, W) in LEGACY_UNET_CASES.items():
+        cfg = lo.LegacyUNetConfig(**kw)
+        net = DiffusionModel(lo.namespace(cfg)).eval()
+        tmpl = lo.state_dict_template(cfg)
+        ref_sd = net.state_dict()
+        assert set(ref_sd) == set(tmpl), [k for k in ref_sd if k not in tmpl] + [k for k in tmpl if k not in ref_sd]
+        assert all(tuple(ref_sd[k].shape) == tuple(tmpl[k].shape) for k in tmpl)
+        sd = lo.synth_state_dict(tmpl, f"legacy.{name}.")
+        net.load_state_dict(sd)
+        x = orc.synth_tensor(f"legacy.{name}.x", (B, cfg.in_channels, H, W))
+        t = torch.tensor([17, 803][:B])
+        nlev = len(cfg.ch_mult) - 1
+        feat = orc.synth_tensor(f"legacy.{name}.feat", (B, cfg.feat_dim, H >> nlev, W >> nlev))
+        with torch.no_grad():
+            out = net(x, t, [feat])
+            mine = lo.forward(sd, cfg, x, t, [feat])
+        err = (mine - out).abs().max().item() / out.abs().max().item()
+        print(f"[legacy_unet_{name}] {len(tmpl)} tensors, out {tuple(out.shape)} max {out.abs().max().item():.3f} restatement err {err:.2e}")
+        assert err < 2e-5
+        np.savez_compressed(os.path.join(GOLD, f"legacy_unet_{name}.npz"), out=out.numpy(),
+                            inputs_checksum=np.array(float(x.double().abs().sum() + feat.double().abs().sum())),
+                            state_checksum=np.array(checksum(sd)))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio"]
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio", "legacy_unet"]
     if "legacy" in which:
         gen_legacy_denoising()
+    if "legacy_unet" in which:
+        gen_legacy_unet()
     if "mvit" in which:
         gen_mvit()
     if "metrics" in which:
