@@ -52,10 +52,19 @@ def _resample_params(c: int, with_conv: bool, stride: int) -> nn.Module:
     return m
 
 
+class _FeatInteraction(nn.Module):
+    """Parameter holder of the reference's FeatInteraction (diffusion.py:359-369)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.feat_trans = Transformer(dim=dim, depth=1, heads=4, dim_head=64, mlp_dim=256)
+
+
 class DiffusionModel(nn.Module):
-    def __init__(self, config):
+    def __init__(self, config, _multiscale: bool = False):
         super().__init__()
         self.config = config
+        self.multiscale = _multiscale
         mc = config.model
         ch, out_ch, ch_mult = mc.ch, mc.out_ch, tuple(mc.ch_mult)
         if float(mc.dropout) != 0.0:
@@ -82,7 +91,7 @@ class DiffusionModel(nn.Module):
             for _ in range(self.num_res_blocks):
                 block.append(_res_params(block_in, block_out, self.temb_ch))
                 block_in = block_out
-                if curr in attn_res:
+                if curr in attn_res and not _multiscale:
                     attn.append(_attn_params(block_in))
             d = nn.Module()
             d.block, d.attn = block, attn
@@ -103,8 +112,10 @@ class DiffusionModel(nn.Module):
                     skip_in = ch * in_mult[i]
                 block.append(_res_params(block_in + skip_in, block_out, self.temb_ch))
                 block_in = block_out
-                if curr in attn_res:
+                if curr in attn_res and not _multiscale:
                     attn.append(_attn_params(block_in))
+                if curr in attn_res and _multiscale and j == 0:
+                    attn.append(_FeatInteraction(block_in))
             u = nn.Module()
             u.block, u.attn = block, attn
             if i != 0:
@@ -113,7 +124,8 @@ class DiffusionModel(nn.Module):
             self.up.insert(0, u)
         self.norm_out = nn.GroupNorm(32, block_in, eps=1e-6, affine=True)
         self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
-        self.feat_trans = Transformer(dim=512, depth=1, heads=4, dim_head=64, mlp_dim=256)
+        if not _multiscale:
+            self.feat_trans = Transformer(dim=512, depth=1, heads=4, dim_head=64, mlp_dim=256)
         self._packed = None
 
     # ---- packed GEMM weights (rebuilt when a parameter changes) -------------------------------------------------------------
@@ -187,10 +199,12 @@ class DiffusionModel(nn.Module):
             x = ops.conv_igemm(x, pk[name + ".conv"], kh=3, kw=3, pad=(1, 1), bias=m.conv.bias, tag="K4")
         return x
 
-    def feat_interact(self, x: Tensor, y: Tensor) -> Tensor:
-        """x NHWC [B,h,w,512], y NCHW [B,512,h,w] (diffusion.py:311-319) -> NHWC."""
+    def feat_interact(self, x: Tensor, y: Tensor, trans: Optional[nn.Module] = None) -> Tensor:
+        """x NHWC [B,h,w,C], y NCHW [B,C,h,w] (diffusion.py:311-319, FeatInteraction :364-369) -> NHWC."""
         b, c, h, w = y.shape
-        yt = self.feat_trans(y.permute(0, 2, 3, 1).reshape(b, h * w, c).contiguous())
+        if tuple(x.shape) != (b, h, w, c):
+            raise RuntimeError(f"feat_interact: feature {tuple(y.shape)} does not match the UNet tensor {tuple(x.shape)} (NHWC)")
+        yt = (trans or self.feat_trans)(y.permute(0, 2, 3, 1).reshape(b, h * w, c).contiguous())
         return ops.sigmoid_gate(yt.reshape(b, h, w, c), x)
 
     # ---- forward --------------------------------------------------------------------------------------------------------
@@ -214,6 +228,8 @@ class DiffusionModel(nn.Module):
             temb = ops.dense_small(ops.dense_small(emb.contiguous(), d0.weight, d0.bias, False), d1.weight, d1.bias, True)
 
             B, Cin, H, W = x.shape
+            if self.multiscale and (H != self.resolution or W != self.width):     # the reference asserts this (:494-495)
+                raise AssertionError(f"DiffusionModel_w_MultiScale: input {H}x{W} != configured {self.resolution}x{self.width}")
             xin = x.new_zeros((B, H, W, 32 * ((Cin + 31) // 32)))
             xin[..., :Cin] = x.permute(0, 2, 3, 1)
             hs: List[Tensor] = [ops.conv_igemm(xin, pk["conv_in"], kh=3, kw=3, pad=(1, 1), bias=self.conv_in.bias, tag="K2")]
@@ -228,15 +244,30 @@ class DiffusionModel(nn.Module):
             h = self._res("mid.block_1", self.mid.block_1, hs[-1], temb, pk)
             h = self._attn("mid.attn_1", self.mid.attn_1, h, pk)
             h = self._res("mid.block_2", self.mid.block_2, h, temb, pk)
-            h = self.feat_interact(h, vis_feat[0])
+            next_feat = 0          # the reference pops vis_feat (mutating the caller's list, its own TODO); an index does the same
+            if not self.multiscale:
+                h = self.feat_interact(h, vis_feat[0])
             for i in reversed(range(self.num_resolutions)):
                 u = self.up[i]
                 for j, blk in enumerate(u.block):
                     h = self._res(f"up.{i}.block.{j}", blk, torch.cat([h, hs.pop()], dim=-1), temb, pk)
-                    if len(u.attn) > 0:
+                    if self.multiscale:
+                        if j == 0 and len(u.attn) > 0:
+                            h = self.feat_interact(h, vis_feat[next_feat], u.attn[0].feat_trans)
+                            next_feat += 1
+                    elif len(u.attn) > 0:
                         h = self._attn(f"up.{i}.attn.{j}", u.attn[j], h, pk)
                 if i != 0:
                     h = self._upsample(f"up.{i}.upsample", u.upsample, h, pk)
             h = ops.groupnorm_swish(h, self.norm_out.weight, self.norm_out.bias, 32, self.norm_out.eps)
             out = ops.conv_igemm(h, pk["conv_out"], kh=3, kw=3, pad=(1, 1), bias=self.conv_out.bias, tag="K14")
             return out.permute(0, 3, 1, 2).contiguous()
+
+
+class DiffusionModel_w_MultiScale(DiffusionModel):
+    """R/models/diffusion_decoder/diffusion.py:380-548: no attention in the encoder; in the decoder the first block of every
+    level whose resolution is in ``attn_resolutions`` is followed by a FeatInteraction with the next entry of ``vis_feat``
+    (coarsest first).  The caller's list is not mutated."""
+
+    def __init__(self, config):
+        super().__init__(config, _multiscale=True)

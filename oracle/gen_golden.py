@@ -516,17 +516,31 @@ LEGACY_UNET_CASES = {
     "tiny": (dict(), 2, 16, 32),
     "pool": (dict(ch=32, ch_mult=(1, 4, 16), num_res_blocks=2, attn_resolutions=(16, 4), in_channels=3, out_ch=2,
                   resamp_with_conv=False, model_type="bayesian"), 1, 16, 16),
+    "multiscale": (dict(ch=32, ch_mult=(1, 2, 4), attn_resolutions=(8, 4), multiscale=True), 2, 16, 32),
 }
+
+
+def legacy_unet_feats(cfg, name, B, H, W):
+    """vis_feat of a legacy-UNet case: one [B,512,h,w] map at the coarsest level, or (multi-scale variant) one map per decoder
+    level whose resolution is in attn_resolutions, coarsest first, with that level's channel count."""
+    nlev = len(cfg.ch_mult) - 1
+    if not cfg.multiscale:
+        return [orc.synth_tensor(f"legacy.{name}.feat", (B, cfg.feat_dim, H >> nlev, W >> nlev))]
+    feats = []
+    for i in reversed(range(nlev + 1)):
+        if (cfg.image_size >> i) in cfg.attn_resolutions:
+            feats.append(orc.synth_tensor(f"legacy.{name}.feat{i}", (B, cfg.ch * cfg.ch_mult[i], H >> i, W >> i)))
+    return feats
 
 
 def gen_legacy_unet():
     """The legacy DDPM-style UNet, R/models/diffusion_decoder/diffusion.py:197-357 (DiffusionModel), run as shipped."""
-    from models.diffusion_decoder.diffusion import DiffusionModel
+    from models.diffusion_decoder.diffusion import DiffusionModel, DiffusionModel_w_MultiScale
     from oracle import legacy_unet_oracle as lo
 
     for name, (kw, B, H, W) in LEGACY_UNET_CASES.items():
         cfg = lo.LegacyUNetConfig(**kw)
-        net = DiffusionModel(lo.namespace(cfg)).eval()
+        net = (DiffusionModel_w_MultiScale if cfg.multiscale else DiffusionModel)(lo.namespace(cfg)).eval()
         tmpl = lo.state_dict_template(cfg)
         ref_sd = net.state_dict()
         assert set(ref_sd) == set(tmpl), [k for k in ref_sd if k not in tmpl] + [k for k in tmpl if k not in ref_sd]
@@ -535,16 +549,15 @@ def gen_legacy_unet():
         net.load_state_dict(sd)
         x = orc.synth_tensor(f"legacy.{name}.x", (B, cfg.in_channels, H, W))
         t = torch.tensor([17, 803][:B])
-        nlev = len(cfg.ch_mult) - 1
-        feat = orc.synth_tensor(f"legacy.{name}.feat", (B, cfg.feat_dim, H >> nlev, W >> nlev))
+        feats = legacy_unet_feats(cfg, name, B, H, W)
         with torch.no_grad():
-            out = net(x, t, [feat])
-            mine = lo.forward(sd, cfg, x, t, [feat])
+            out = net(x, t, list(feats))      # the multi-scale variant pops its argument
+            mine = lo.forward(sd, cfg, x, t, feats)
         err = (mine - out).abs().max().item() / out.abs().max().item()
         print(f"[legacy_unet_{name}] {len(tmpl)} tensors, out {tuple(out.shape)} max {out.abs().max().item():.3f} restatement err {err:.2e}")
         assert err < 2e-5
         np.savez_compressed(os.path.join(GOLD, f"legacy_unet_{name}.npz"), out=out.numpy(),
-                            inputs_checksum=np.array(float(x.double().abs().sum() + feat.double().abs().sum())),
+                            inputs_checksum=np.array(float(x.double().abs().sum() + sum(f.double().abs().sum() for f in feats))),
                             state_checksum=np.array(checksum(sd)))
 
 
