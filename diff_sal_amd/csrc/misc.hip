@@ -605,7 +605,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 7; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 8; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
@@ -695,6 +695,68 @@ static void resize_bilinear_t(const T* in, T* out, int N, int h, int w, int H, i
     const long total = static_cast<long>(N) * H * W * C;
     hipLaunchKernelGGL((resize_kernel<1, T>), dim3(ew_grid(total)), dim3(256), 0, s, in, out, N, h, w, H, W, C, sy, sx);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 fused: conv_in (1 -> C, 3x3, pad 1) followed, with nothing in between, by Downsample4x4's 3x3 stride-4 convolution
+// (R/.../sal_unet.py:240,292 and :67-84) is ONE linear map of the single-channel input: a 5x5 stride-4 convolution whose
+// weights  W_eff[co][dy][dx] = sum_ci sum_{ky2+ky1=dy, kx2+kx1=dx} W2[co,ci,ky2,kx2] W1[ci,ky1,kx1]  and bias
+// b_eff = b2 + sum W2 b1  the host composes once per parameter update (in fp64).  Exact for H, W multiples of 4: the
+// stride-4 windows then never reach Downsample4x4's zero row / column, every conv_in output they read is a genuine one, and
+// conv_in's own padding is the zero ring of x on the top / left.  Replaces a 132 MB intermediate (fp32) and a 3.6 GFLOP GEMM
+// by 25 multiply-adds per output value.  One thread per (output pixel, channel quad); the 25 inputs of a pixel are
+// broadcast loads, the weights live in LDS.
+// ------------------------------------------------------------------------------------------------
+namespace diffsal {
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_s4_kernel(const float* __restrict__ x, const float* __restrict__ w25,
+                                                         const float* __restrict__ bias, T* __restrict__ out, int H, int W,
+                                                         int C, long total4) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];   // [25][C] then bias [C]
+  for (int i = threadIdx.x; i < 25 * C; i += 256) wsm[i] = w25[i];
+  for (int i = threadIdx.x; i < C; i += 256) wsm[25 * C + i] = bias[i];
+  __syncthreads();
+  const int c4n = C >> 2, Ho = H >> 2, Wo = W >> 2;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    long r = i / c4n;
+    const int ox = static_cast<int>(r % Wo); r /= Wo;
+    const int oy = static_cast<int>(r % Ho);
+    const long n = r / Ho;
+    const float* xb = x + n * H * W;
+    float4 acc = ld4(wsm + 25 * C + c);
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+      const int iy = 4 * oy - 1 + dy;
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const int ix = 4 * ox - 1 + dx;
+        const bool ok = iy >= 0 && ix >= 0;                       // bottom / right never leave the image (H, W % 4 == 0)
+        float v = xb[static_cast<long>(ok ? iy : 0) * W + (ok ? ix : 0)];   // unconditional load from a clamped address
+        v = ok ? v : 0.f;
+        const float4 ww = ld4(wsm + (dy * 5 + dx) * C + c);
+        acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
+      }
+    }
+    st4(out + i * 4, acc);
+  }
+}
+}  // namespace diffsal
+using namespace diffsal;
+
+extern "C" int diffsal_conv_in_s4(const float* x, const float* w25, const float* bias, void* out, int B, int H, int W, int C,
+                                  int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(x && w25 && bias && out, DIFFSAL_E_ARG, "conv_in_s4: null argument");
+  DS_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && C > 0 && C % 4 == 0 && 26 * C * 4 <= 64 * 1024, DIFFSAL_E_SHAPE,
+             "conv_in_s4: bad shape B=%d H=%d W=%d C=%d (H, W multiples of 4)", B, H, W, C);
+  DS_REQUIRE(aligned16(out) && aligned16(w25) && aligned16(bias), DIFFSAL_E_ALIGN, "conv_in_s4: misaligned pointer");
+  const long total4 = static_cast<long>(B) * (H / 4) * (W / 4) * (C / 4);
+#define CALL(T)                                                                                                        \
+  hipLaunchKernelGGL((conv_in_s4_kernel<T>), dim3(ew_grid(total4)), dim3(256), 26 * C * sizeof(float),                   \
+                     static_cast<hipStream_t>(stream), x, w25, bias, static_cast<T*>(out), H, W, C, total4)
+  DS_DTYPE_DISPATCH(dtype, "conv_in_s4", CALL);
+#undef CALL
+  return check_launch("conv_in_s4");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -179,6 +179,33 @@ def conv_in(x: Tensor, w9: Tensor, bias: Tensor, skip_mod: int = 0, out_dtype: t
     return out
 
 
+def conv_in_s4(x: Tensor, w25: Tensor, bias: Tensor, out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """K2 fused: conv_in + the stride-4 Downsample as one 5x5 stride-4 convolution.  x [B,1,H,W] fp32 (H, W % 4 == 0),
+    w25 [25, C] / bias [C] from ``compose_conv_in_s4`` -> NHWC [B,H/4,W/4,C] of ``out_dtype``."""
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    Cc = w25.shape[1]
+    out = torch.empty((B, H // 4, W // 4, Cc), device=x.device, dtype=out_dtype)
+    with _prof("K2", 50.0 * B * (H // 4) * (W // 4) * Cc, _nb(x, out)):
+        _lib.check(lib.diffsal_conv_in_s4(_p(x), _p(w25), _p(bias), out.data_ptr(), B, H, W, Cc, _dt(out), _stream()), "conv_in_s4")
+    return out
+
+
+def compose_conv_in_s4(w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor):
+    """Host-side composition (fp64) of conv_in [C1,1,3,3] + bias and the following 3x3 stride-4 conv [C,C1,3,3] + bias into the
+    5x5 weights [25, C] (tap-major) and bias [C] of diffsal_conv_in_s4.  A parameter-layout transform, like weight packing."""
+    w1d, w2d = w1.detach().double().cpu()[:, 0], w2.detach().double().cpu()
+    C = w2d.shape[0]
+    weff = torch.zeros((C, 5, 5), dtype=torch.float64)
+    for ky2 in range(3):
+        for kx2 in range(3):
+            # contribution of tap (ky2, kx2) of the second conv: [C, C1] x [C1, 3, 3] placed at offset (ky2, kx2)
+            weff[:, ky2:ky2 + 3, kx2:kx2 + 3] += torch.einsum("oc,cyx->oyx", w2d[:, :, ky2, kx2], w1d)
+    beff = b2.detach().double().cpu() + torch.einsum("ocyx,c->o", w2d, b1.detach().double().cpu())
+    dev = w1.device
+    return weff.reshape(C, 25).t().contiguous().float().to(dev), beff.float().to(dev)
+
+
 def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
     """K3 on NHWC [B,H,W,C]."""
     lib = _lib.load()

@@ -55,6 +55,13 @@ int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* fr
 int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float* w, const float* bias,
                         int N, float* out, diffsal_stream_t stream);
 
+/* ---- K2 fused: conv_in followed directly by Downsample4x4's 3x3 stride-4 convolution (sal_unet.py:240,292 + :67-84) as ONE
+ * 5x5 stride-4 convolution of the single-channel input; w25 [25][C] (tap-major) and bias [C] are the composed weights
+ * W_eff[co][dy][dx] = sum_ci sum_{ky2+ky1=dy, kx2+kx1=dx} W2[co,ci,ky2,kx2] W1[ci,ky1,kx1], b_eff = b2 + sum W2 b1 (host side).
+ * Exact for H, W multiples of 4.  x NCHW [B,1,H,W] fp32 -> out NHWC [B,H/4,W/4,C] in `dtype`. */
+int diffsal_conv_in_s4(const float* x, const float* w25, const float* bias, void* out, int B, int H, int W, int C, int dtype,
+                       diffsal_stream_t stream);
+
 /* ---- K2: conv_in (1 -> C, 3x3, pad 1), NCHW[B,1,H,W] -> NHWC[B,H,W,C] -----------------
  * R/.../sal_unet.py:240,292.  Only pixels with (y % skip_mod != skip_mod-1 && x % skip_mod != skip_mod-1)
  * are written when skip_mod > 0 (the stride-4 consumer never reads the others, sal_unet.py:67-84). */

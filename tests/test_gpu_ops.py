@@ -365,3 +365,21 @@ def test_mlp_block_fused_kernel(ops, M, with_z):
         assert rel_err(z.cpu()[kept], ref_z[kept]) < 2e-5
     else:
         assert z is None
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 64), (1, 224, 384), (3, 8, 12)])
+def test_conv_in_s4_equals_conv_in_then_stride4_downsample(ops, B, H, W):
+    """The composed 5x5 stride-4 convolution == Conv2d(1, 96, 3, pad 1) followed by pad (0,1,0,1) + Conv2d(96, 96, 3, stride 4)
+    (sal_unet.py:240,292 + :67-84) for H, W multiples of 4, and == the two-kernel HIP path."""
+    C = 96
+    x = rnd("s4x", B, 1, H, W)
+    w1, b1 = rnd("s4w1", C, 1, 3, 3, scale=0.3), rnd("s4b1", C, scale=0.1)
+    w2, b2 = rnd("s4w2", C, C, 3, 3, scale=(9 * C) ** -0.5), rnd("s4b2", C, scale=0.1)
+    ref = F.conv2d(F.pad(F.conv2d(x, w1, b1, padding=1), (0, 1, 0, 1)), w2, b2, stride=4)
+    w25, beff = ops.compose_conv_in_s4(w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV))
+    got = ops.conv_in_s4(x.to(DEV), w25, beff)
+    assert got.shape == nhwc(ref).shape
+    assert rel_err(got, nhwc(ref)) < 2e-6
+    f = ops.conv_in(x.to(DEV), w1.reshape(C, 9).contiguous().to(DEV), b1.to(DEV), skip_mod=4)
+    two = ops.conv_igemm(f, ops.pack_conv_weight(w2.to(DEV)), kh=3, kw=3, stride=(4, 4), out_hw=tuple(ref.shape[-2:]), bias=b2.to(DEV))
+    assert rel_err(got, two) < 5e-6
