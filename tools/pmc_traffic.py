@@ -13,7 +13,7 @@ import sys
 
 
 def per_kernel(d, counter, match):
-    f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)   # newest run
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter and any(m in r["Kernel_Name"] for m in match):
@@ -27,12 +27,12 @@ def main():
     prec = sys.argv[4] if len(sys.argv) > 4 else "fp32"
     build = sys.argv[5] if len(sys.argv) > 5 else "build n/a"
     # the GEMM family of the precision: tiled implicit GEMM (+ split-K reduce), streaming linears, fused MLP / block kernels
-    match = (["igemm_kernel", "splitk_reduce_kernel", "lin_stream_kernel", "mlp_block_kernel"] if prec == "fp32" else
-             ["igemm16_kernel", "splitk16_reduce_kernel", "conv16_halo_kernel", "block16_kernel"])
+    match = (["igemm_kernel", "igemm_linear_kernel", "splitk_reduce_kernel", "lin_stream_kernel", "mlp_block_kernel"] if prec == "fp32" else
+             ["igemm16_kernel", "igemm16_linear_kernel", "splitk16_reduce_kernel", "conv16_halo_kernel", "block16_kernel"])
     fk, nf = per_kernel(fetch_dir, "FETCH_SIZE", match)
     wk, nw = per_kernel(write_dir, "WRITE_SIZE", match)
     assert nf == nw and nf > 0, (nf, nw)
-    _, steps = per_kernel(fetch_dir, "FETCH_SIZE", ["conv_in_kernel"])      # one conv_in launch per denoising step
+    _, steps = per_kernel(fetch_dir, "FETCH_SIZE", ["conv_in"])      # one conv_in (or fused conv_in_s4) launch per denoising step
     assert steps > 0
     read_b, write_b = 2.0 * fk * 1024.0, wk * 1024.0
     res = {
