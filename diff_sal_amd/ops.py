@@ -409,6 +409,36 @@ def resize_sum(xs: Sequence[Tensor], H: int, W: int) -> Tensor:
     return out
 
 
+def tapsum(ys: Sequence[Tensor], H: int, W: int, Cout: int, dil: int = 1, bias: Optional[Tensor] = None,
+           scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, act: int = ACT_NONE, tag: str = "K12-tap") -> Tensor:
+    """conv3x3(dil)(sum_i bilinear(z_i -> (H, W))) from the tap products ys[i] = z_i x Wcat^T  [N, h_i, w_i, 9*Cout]
+    (``tap_weight``): out NHWC [N,H,W,Cout] = act(scale * (bias + gathered sum) + shift).  See csrc/tapsum.hip."""
+    lib = _lib.load()
+    n = len(ys)
+    N = ys[0].shape[0]
+    dt = _dt(ys[0])
+    for y in ys:
+        if y.shape[-1] != 9 * Cout or not y.is_contiguous() or y.dtype != ys[0].dtype:
+            raise RuntimeError(f"tapsum: every source must be a contiguous [N,h,w,{9 * Cout}] tensor of one dtype, got {tuple(y.shape)}")
+    ptrs = (C.c_void_p * n)(*[_pa(y, dt) for y in ys])
+    hs = (C.c_int * n)(*[y.shape[1] for y in ys])
+    ws = (C.c_int * n)(*[y.shape[2] for y in ys])
+    out = torch.empty((N, H, W, Cout), device=ys[0].device, dtype=ys[0].dtype)
+    with _prof(tag, 2.0 * 36.0 * n * out.numel(), _nb(*ys) + _nb(out)):
+        _lib.check(lib.diffsal_tapsum(ptrs, hs, ws, n, out.data_ptr(), N, H, W, Cout, dil, _p(bias), _p(scale), _p(shift), act, dt,
+                                      _stream()), "tapsum")
+    return out
+
+
+def tap_weight(w: Tensor) -> Tensor:
+    """Conv2d weight [Cout, Cin, 3, 3] -> the [9*Cout, Cin] matrix of the nine 1x1 channel mixings (row = tap * Cout + co),
+    already in the GEMM's packed k order (a 1x1 weight is its own packed form).  Parameter-layout transform."""
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise RuntimeError("tap_weight: 3x3 kernels only")
+    return pack_conv_weight(w.detach().permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1).contiguous())
+
+
 def audio_fuse(a_small: Tensor, x: Tensor, h: int, w: int) -> Tensor:
     """K7. a_small [B*T, h*w, C], x [B,T,H,W,C] -> fused audio in the reference's [B,C,T,H,W] order."""
     lib = _lib.load()

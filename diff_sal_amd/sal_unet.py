@@ -246,6 +246,17 @@ class SalUNet(nn.Module):
             return ops.cast(wp, self.compute_dtype)
         return ops.split_weight(wp) if self._precision() == "bf16x3" else wp
 
+    def _tap_weight(self, w: Tensor) -> Tensor:
+        """Conv2d 3x3 weight -> the [9*Cout, Cin] matrix of its nine 1x1 tap mixings (row = tap * Cout + co), in the storage /
+        split format of this module's GEMM weights (see ops.tapsum)."""
+        co, ci = w.shape[:2]
+        return self._pack_conv(w.detach().permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1).contiguous())
+
+    def _use_tap_conv(self, taps) -> bool:
+        # fp32 storage only: there the 3x3 convolutions are bound by the matrix rate, so 3-4x fewer FLOPs is 3x less time.  On
+        # 16-bit storage the LDS-halo / generic kernels already run them in about the time the gather itself needs.
+        return self.tap_conv and taps is None and self.compute_dtype == torch.float32
+
     def _gemm_w(self, w: Tensor) -> Tensor:
         """Linear / 1x1 weight [N, K] as the GEMM reads it (K % 32 == 0: the packed k order is the identity)."""
         return w.detach() if self.compute_dtype == torch.float32 else ops.cast(w.detach().contiguous(), self.compute_dtype)
@@ -287,6 +298,7 @@ class SalUNet(nn.Module):
             if st.patch_embed is not None:
                 pe = st.patch_embed[0].proj
                 pk[f"s{i}.pe1.w"] = self._pack_conv(pe[1].weight)
+                pk[f"s{i}.pe1.tapw"] = self._tap_weight(pe[1].weight)
                 pk[f"s{i}.pe1.scale"], pk[f"s{i}.pe1.shift"] = self._bn_affine(pe[2])
                 pk[f"s{i}.pe2.w"] = self._pack_conv(pe[4].weight)
                 pk[f"s{i}.pe2.scale"], pk[f"s{i}.pe2.shift"] = self._bn_affine(pe[5])
@@ -303,6 +315,7 @@ class SalUNet(nn.Module):
                 pk[f"s{i}.{nm}.w"] = self._gemm_w(lin.weight)
             pk[f"s{i}.redu.w"] = self._pack_conv(dec.redu_chan_up[i].proj[0].weight)  # [Co, C, kt, 1, 1]
         pk["mt.w"] = self._pack_conv(dec.mt_proj[0].weight)
+        pk["mt.tapw"] = self._tap_weight(dec.mt_proj[0].weight)
         pk["mt.scale"], pk["mt.shift"] = self._bn_affine(dec.mt_proj[1])
         pk["head.w"] = self.logits.linear_pred.weight.detach().reshape(-1).contiguous()
         self._pack_cache, self._pack_key = pk, key
@@ -392,6 +405,10 @@ class SalUNet(nn.Module):
     # implicit-GEMM loader addresses each operand with 32-bit byte offsets (< 4 GiB): larger batches
     # (BASELINE config 5 uses 64 clips per GPU) are evaluated in chunks; clips are independent in eval mode.
     max_clips_per_pass = 16
+    # eval path: a 3x3 convolution that directly follows a bilinear up-sampling (UpEmbed conv1, mt_proj on the 4-scale sum) runs
+    # as nine 1x1 tap mixings at the SOURCE resolution (one GEMM, 4x / 3x fewer FLOPs) + a gather of the interpolated taps
+    # (ops.tapsum, csrc/tapsum.hip).  Exact up to summation order; off when intermediate taps are requested.
+    tap_conv = True
 
     def forward(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor] = None,
                 taps: Optional[dict] = None) -> Tensor:
@@ -486,9 +503,14 @@ class SalUNet(nn.Module):
             if self.dilation[i] != 0:
                 Bn, T, h, w, Cp = xcur.shape
                 d = self.dilation[i]
-                u = ops.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
-                u = ops.conv_igemm(u, pk[f"s{i}.pe1.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
-                                   scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
+                if self._use_tap_conv(taps) and d in (1, 2) and h >= 2 and w >= 2:
+                    y9 = ops.linear(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.tapw"], None, tag="K12")
+                    u = ops.tapsum([y9], 2 * h, 2 * w, C, dil=d, scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"],
+                                   act=ACT_RELU, tag="K12-tap")
+                else:
+                    u = ops.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
+                    u = ops.conv_igemm(u, pk[f"s{i}.pe1.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
+                                       scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
                 skip = frames[i] if i in (1, 2) else None  # transformer.py:265-270
                 u = ops.conv_igemm(u, pk[f"s{i}.pe2.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
                                    scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU, tag="K12",
@@ -507,12 +529,19 @@ class SalUNet(nn.Module):
             z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
                                tag="K13")
             zs.append(z.view(Bn, H, W, self.ori_embed_dim))
-        acc = ops.resize_sum(zs, th, tw)
-        if taps is not None:
-            taps["multi_scale"] = acc
         mt = dec.mt_proj
-        y = ops.conv_igemm(acc, pk["mt.w"], kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, scale=pk["mt.scale"],
-                           shift=pk["mt.shift"], act=ACT_RELU, tag="K14")
+        if self._use_tap_conv(taps) and all(
+                th % z_.shape[1] == 0 and (th // z_.shape[1]) & (th // z_.shape[1] - 1) == 0 and z_.shape[1] >= 2 and
+                tw == z_.shape[2] * (th // z_.shape[1]) for z_ in zs):
+            ys = [ops.linear(z_, pk["mt.tapw"], None, tag="K14") for z_ in zs]
+            y = ops.tapsum(ys, th, tw, mt[0].out_channels, dil=1, bias=mt[0].bias, scale=pk["mt.scale"], shift=pk["mt.shift"],
+                           act=ACT_RELU, tag="K14-tap")
+        else:
+            acc = ops.resize_sum(zs, th, tw)
+            if taps is not None:
+                taps["multi_scale"] = acc
+            y = ops.conv_igemm(acc, pk["mt.w"], kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, scale=pk["mt.scale"],
+                               shift=pk["mt.shift"], act=ACT_RELU, tag="K14")
         s = ops.head_sigmoid(y, pk["head.w"], self.logits.linear_pred.bias)
         if lowres:                       # the caller fuses the final resize with the solver update
             return s

@@ -55,6 +55,20 @@ int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* fr
 int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float* w, const float* bias,
                         int N, float* out, diffsal_stream_t stream);
 
+/* ---- K12 / K14 restructured: a 3x3 convolution (dilation dil) of a bilinearly up-sampled map, or of a SUM of up-sampled
+ * maps, without forming the up-sampled map (csrc/tapsum.hip):
+ *   conv3x3( sum_i up_i(z_i) )[p] = sum_i sum_tap up_i( W_tap z_i )[p + dil * delta_tap]       (1x1 mixing commutes with bilerp)
+ * The nine channel mixings of every source run as ONE diffsal_conv_igemm at the SOURCE resolution,
+ * Y_i [N, h_i, w_i, 9*C] = z_i x Wcat^T with Wcat[tap*C + co][ci] = W[co][ci][ky][kx]; this entry gathers
+ *   out[n,Y,X,c] = act(scale[c] * (bias[c] + sum_i sum_tap [p' inside] bilerp_i(Y_i[..., tap*C + c]; p')) + shift[c])
+ * with p' = (Y,X) + dil*(ky-1,kx-1) (taps outside the image are the convolution's zero padding).  Sources: 1..4, each a
+ * power-of-two factor (>= 1) smaller than H x W; act NONE or RELU.  UpEmbed's first convolution
+ * (bilinear x2 + 3x3 dilation 2, common_block.py:196-216): 4x fewer FLOPs; mt_proj on the 4-scale sum (sal_unet.py:480-489,
+ * :407): 3x fewer.  Exact up to summation order. */
+int diffsal_tapsum(const void* const* srcs, const int* hs, const int* ws, int n_src, void* out, int N, int H, int W, int C,
+                   int dil, const float* bias, const float* scale, const float* shift, int act, int dtype,
+                   diffsal_stream_t stream);
+
 /* ---- K2 fused: conv_in followed directly by Downsample4x4's 3x3 stride-4 convolution (sal_unet.py:240,292 + :67-84) as ONE
  * 5x5 stride-4 convolution of the single-channel input; w25 [25][C] (tap-major) and bias [C] are the composed weights
  * W_eff[co][dy][dx] = sum_ci sum_{ky2+ky1=dy, kx2+kx1=dx} W2[co,ci,ky2,kx2] W1[ci,ky1,kx1], b_eff = b2 + sum W2 b1 (host side).

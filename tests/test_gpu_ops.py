@@ -383,3 +383,27 @@ def test_conv_in_s4_equals_conv_in_then_stride4_downsample(ops, B, H, W):
     f = ops.conv_in(x.to(DEV), w1.reshape(C, 9).contiguous().to(DEV), b1.to(DEV), skip_mod=4)
     two = ops.conv_igemm(f, ops.pack_conv_weight(w2.to(DEV)), kh=3, kw=3, stride=(4, 4), out_hw=tuple(ref.shape[-2:]), bias=b2.to(DEV))
     assert rel_err(got, two) < 5e-6
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, Cout, (H, W), factors, dil
+    (3, 64, 96, (16, 24), (2,), 2),          # UpEmbed conv1: bilinear x2 then 3x3 dilation 2; odd batch (half-empty wave)
+    (2, 96, 160, (8, 12), (2,), 2),          # two 128-channel slabs
+    (2, 64, 96, (32, 48), (2, 4, 8, 16), 1),  # mt_proj: 3x3 on the 4-scale sum
+    (1, 32, 32, (16, 16), (1, 4), 1),        # a source already at the target resolution
+    (3, 64, 96, (14, 24), (2,), 2),          # stage-1 UpEmbed: 7x12 -> 14x24, H not a multiple of 4 (ragged patch row)
+    (2, 32, 64, (6, 10), (2,), 1),           # both extents ragged
+])
+def test_tapsum_equals_conv_of_upsampled_sum(ops, case):
+    """conv3x3(sum_i bilinear(z_i)) == tapsum of the per-source GEMMs with the nine 1x1 tap mixings (csrc/tapsum.hip)."""
+    N, Cin, Cout, (H, W), factors, dil = case
+    zs = [rnd("tz%d" % f, N, Cin, H // f, W // f) for f in factors]
+    w = rnd("tw", Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    b, sc, sh = rnd("tb", Cout, scale=0.1), 1.0 + rnd("tsc", Cout, scale=0.1), rnd("tsh", Cout, scale=0.1)
+    up = sum(F.interpolate(z, size=(H, W), mode="bilinear", align_corners=False) if z.shape[-2:] != (H, W) else z for z in zs)
+    ref = F.relu((F.conv2d(up, w, b, padding=dil, dilation=dil)) * sc[None, :, None, None] + sh[None, :, None, None])
+    wcat = ops.tap_weight(w.to(DEV))
+    ys = [ops.linear(nhwc(z).to(DEV), wcat, None) for z in zs]
+    got = ops.tapsum(ys, H, W, Cout, dil=dil, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), act=ops.ACT_RELU)
+    assert got.shape == nhwc(ref).shape
+    assert rel_err(got, nhwc(ref)) < 1e-5
