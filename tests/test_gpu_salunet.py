@@ -48,6 +48,17 @@ def test_hip_forward_matches_reference_golden(golden_dir, name):
     ref_taps = {k: net.tap_to_reference_layout(k, v) for k, v in taps.items()}
     worst = check_taps(ref_taps, g, RTOL)
     assert {"temb", "down1", "res0", "noise0", "stage0", "stage3", "multi_scale"} <= set(worst)
+    # without taps the eval path takes the restructured form of UpEmbed conv1 / mt_proj (nine 1x1 tap mixings at the source
+    # resolution + gather, csrc/tapsum.hip) and the composed conv_in: same reference output, same bar
+    assert net.tap_conv
+    with torch.no_grad():
+        out2 = net(x.to(DEV), t.to(DEV), feats_d, None if audio is None else audio.to(DEV))
+        net.tap_conv = False
+        out3 = net(x.to(DEV), t.to(DEV), feats_d, None if audio is None else audio.to(DEV))
+    err2, err3 = (out2.cpu() - ref).abs().max().item(), (out3.cpu() - ref).abs().max().item()
+    print(name, "max abs err, restructured path", err2, "direct path without taps", err3)
+    assert err2 < RTOL * ref.abs().max().item() and err3 < RTOL * ref.abs().max().item()
+    assert (out2 - out3).abs().max().item() < 2e-5
 
 
 def test_hip_forward_matches_oracle_on_fresh_inputs(golden_dir):
