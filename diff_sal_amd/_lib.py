@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 SIGNATURES = {
@@ -38,6 +38,8 @@ SIGNATURES = {
     "diffsal_maxpool2d": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_conv_in_s4": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_tapsum": (c_i, [c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "diffsal_tapsum_bwd_ws_bytes": (C.c_long, [c_i, c_i, c_i, c_i]),
+    "diffsal_tapsum_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_groupnorm_ws_bytes": (c_sz, [c_i, c_i]),
     "diffsal_groupnorm_swish": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_i, c_f]),
     "diffsal_groupnorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_f, c_sz, c_i, c_f]),

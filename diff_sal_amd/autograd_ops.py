@@ -317,6 +317,46 @@ def resize_sum(xs, H, W):
     return ResizeSumFn.apply(H, W, *xs)
 
 
+class TapSumFn(torch.autograd.Function):
+    """conv3x3(dil)(sum_i bilinear(z_i)) from the tap products y_all = cat_i(z_i) x Wcat^T (rows: source after source, each
+    [N*h_i*w_i, 9*Cout]) -- ops.tapsum; the adjoint writes every source's block of d(y_all) with ops.tapsum_bwd."""
+
+    @staticmethod
+    def forward(ctx, y_all, bias, meta):
+        shapes, N, H, W, Cout, dil = meta
+        views, off = [], 0
+        for h, w in shapes:
+            views.append(y_all[off:off + N * h * w].view(N, h, w, 9 * Cout))
+            off += N * h * w
+        if off != y_all.shape[0]:
+            raise RuntimeError("TapSumFn: the rows of y_all do not add up to the sources' pixels")
+        ctx.meta = meta
+        ctx.rows = y_all.shape[0]
+        return ops.tapsum(views, H, W, Cout, dil=dil, bias=bias, tag="tapsum")
+
+    @staticmethod
+    def backward(ctx, du):
+        shapes, N, H, W, Cout, dil = ctx.meta
+        du = du.contiguous()
+        d_all = torch.empty((ctx.rows, 9 * Cout), device=du.device, dtype=torch.float32)
+        off = 0
+        for h, w in shapes:
+            ops.tapsum_bwd(du, h, w, dil, out=d_all[off:off + N * h * w].view(N, h, w, 9 * Cout))
+            off += N * h * w
+        db = ops.colsum(du.view(-1, Cout)).reshape(Cout) if ctx.needs_input_grad[1] else None
+        return d_all, db, None
+
+
+def tapsum(y_all, shapes, N, H, W, Cout, dil=1, bias=None):
+    return TapSumFn.apply(y_all, bias, (tuple(shapes), N, H, W, Cout, dil))
+
+
+def tap_weight(w):
+    """Conv2d weight [Cout, Cin, 3, 3] -> [9*Cout, Cin] (row = tap * Cout + co), differentiable (torch permutation)."""
+    co, ci = w.shape[:2]
+    return w.permute(2, 3, 0, 1).reshape(9 * co, ci)
+
+
 class PackFramesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vis, noise):

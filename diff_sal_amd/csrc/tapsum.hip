@@ -147,6 +147,44 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adjoint of tapsum with respect to one source's tap products (training): dY[n, iy, ix, tap, :] =
+//   sum_{Y, X} wy(Y -> iy) wx(X -> ix) dU[n, Y - dil (ky-1), X - dil (kx-1), :]   (terms outside the image drop out),
+// gather form, deterministic.  Separable like the plain resize adjoint (backward.hip): a row pass makes the three
+// ky-shifted row reductions R[ky] [N][h][W*C], a column pass the nine (ky, kx) outputs.  blockIdx.y = ky (rows) / tap (columns).
+// ------------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(256) void tapsum_bwd_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long outer,
+                                                              int L, int l, int inner, float scale, int dil, long slab) {
+  const int j = blockIdx.y;
+  const int shift = dil * ((PASS == 0 ? j : j % 3) - 1);
+  const float* src = in + (PASS == 0 ? 0L : static_cast<long>(j / 3) * slab);
+  float* dst = out + (PASS == 0 ? static_cast<long>(j) * slab : static_cast<long>(j) * inner);
+  const long out_pitch = PASS == 0 ? inner : 9L * inner;
+  const int cv = inner / 4;
+  const long total = outer * l * cv;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % cv) * 4;
+    long r = i / cv;
+    const int il = static_cast<int>(r % l);
+    const long o = r / l;
+    const int lo = max(0, static_cast<int>(floorf((il - 0.5f) / scale - 0.5f)) - 1);
+    const int hi = min(L - 1, static_cast<int>(ceilf((il + 1.5f) / scale - 0.5f)) + 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int Y = lo; Y <= hi; ++Y) {
+      int y0, y1; float ly;
+      bilin_coord(Y, scale, l, y0, y1, ly);
+      const float wy = (y0 == il ? 1.f - ly : 0.f) + (y1 == il ? ly : 0.f);
+      const int Ys = Y - shift;
+      if (wy == 0.f || Ys < 0 || Ys >= L) continue;
+      const float4 v = ld4(src + (o * L + Ys) * inner + c);
+      acc.x = fmaf(wy, v.x, acc.x); acc.y = fmaf(wy, v.y, acc.y);
+      acc.z = fmaf(wy, v.z, acc.z); acc.w = fmaf(wy, v.w, acc.w);
+    }
+    st4(dst + (o * l + il) * out_pitch + c, acc);
+  }
+}
+
 }  // namespace diffsal
 
 using namespace diffsal;
@@ -187,4 +225,27 @@ extern "C" int diffsal_tapsum(const void* const* srcs, const int* hs, const int*
   DS_DTYPE_DISPATCH(dtype, "tapsum", CALL);
 #undef CALL
   return check_launch("tapsum");
+}
+
+extern "C" long diffsal_tapsum_bwd_ws_bytes(int N, int W, int C, int h) {
+  return 3L * N * h * W * C * static_cast<long>(sizeof(float));
+}
+
+extern "C" int diffsal_tapsum_bwd(const float* du, float* dy, float* ws, int N, int H, int W, int C, int h, int w, int dil,
+                                  diffsal_stream_t stream) {
+  DS_REQUIRE(du && dy && ws, DIFFSAL_E_ARG, "tapsum_bwd: null argument");
+  DS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && h >= 2 && w >= 2 && h <= H && w <= W && (dil == 1 || dil == 2),
+             DIFFSAL_E_SHAPE, "tapsum_bwd: bad shape N=%d H=%d W=%d C=%d h=%d w=%d dil=%d", N, H, W, C, h, w, dil);
+  DS_REQUIRE(aligned16(du) && aligned16(dy) && aligned16(ws), DIFFSAL_E_ALIGN, "tapsum_bwd: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long slab = static_cast<long>(N) * h * W * C;
+  const long rows = static_cast<long>(N) * h * (static_cast<long>(W) * C / 4);
+  const long cols = static_cast<long>(N) * h * w * (C / 4);
+  const unsigned gr = static_cast<unsigned>(std::min<long>((rows + 255) / 256, 1L << 20));
+  const unsigned gc = static_cast<unsigned>(std::min<long>((cols + 255) / 256, 1L << 20));
+  hipLaunchKernelGGL((tapsum_bwd_axis_kernel<0>), dim3(gr, 3), dim3(256), 0, s, du, ws, static_cast<long>(N), H, h, W * C,
+                     static_cast<float>(h) / static_cast<float>(H), dil, slab);
+  hipLaunchKernelGGL((tapsum_bwd_axis_kernel<1>), dim3(gc, 9), dim3(256), 0, s, ws, dy, static_cast<long>(N) * h, W, w, C,
+                     static_cast<float>(w) / static_cast<float>(W), dil, slab);
+  return check_launch("tapsum_bwd");
 }

@@ -430,6 +430,24 @@ def tapsum(ys: Sequence[Tensor], H: int, W: int, Cout: int, dil: int = 1, bias: 
     return out
 
 
+def tapsum_bwd(du: Tensor, h: int, w: int, dil: int, out: Optional[Tensor] = None) -> Tensor:
+    """Adjoint of ``tapsum`` (no affine / activation) for one source: du [N,H,W,C] fp32 -> dy [N,h,w,9*C].  ``out`` lets the
+    caller place the result inside a larger buffer (the sources of one GEMM share a row-concatenated matrix)."""
+    lib = _lib.load()
+    N, H, W, Cc = du.shape
+    if du.dtype != torch.float32 or not du.is_contiguous():
+        raise RuntimeError("tapsum_bwd: fp32 contiguous NHWC gradient expected")
+    if out is None:
+        out = torch.empty((N, h, w, 9 * Cc), device=du.device, dtype=torch.float32)
+    elif tuple(out.shape) != (N, h, w, 9 * Cc) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise RuntimeError(f"tapsum_bwd: out must be a contiguous fp32 [{N},{h},{w},{9 * Cc}] tensor")
+    ws = torch.empty((int(lib.diffsal_tapsum_bwd_ws_bytes(N, W, Cc, h)) // 4,), device=du.device, dtype=torch.float32)
+    with _prof("tapsum_bwd", 0.0, _nb(du) + 2 * _nb(ws) + _nb(out)):
+        _lib.check(lib.diffsal_tapsum_bwd(du.data_ptr(), out.data_ptr(), ws.data_ptr(), N, H, W, Cc, h, w, dil, _stream()),
+                   "tapsum_bwd")
+    return out
+
+
 def tap_weight(w: Tensor) -> Tensor:
     """Conv2d weight [Cout, Cin, 3, 3] -> the [9*Cout, Cin] matrix of the nine 1x1 channel mixings (row = tap * Cout + co),
     already in the GEMM's packed k order (a 1x1 weight is its own packed form).  Parameter-layout transform."""

@@ -638,8 +638,12 @@ class SalUNet(nn.Module):
                 Bn, T, h, w, Cp = xcur.shape
                 d = self.dilation[i]
                 pe = st.patch_embed[0].proj
-                u = ag.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
-                u = ag.conv(u, pw(pe[1].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[1].weight))
+                if self.tap_conv:   # nine 1x1 mixings at the low resolution + gather (csrc/tapsum.hip), adjoint likewise
+                    y9 = ag.linear(xcur.view(Bn * T * h * w, Cp), ag.tap_weight(pe[1].weight))
+                    u = ag.tapsum(y9, [(h, w)], Bn * T, 2 * h, 2 * w, C, dil=d)
+                else:
+                    u = ag.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
+                    u = ag.conv(u, pw(pe[1].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[1].weight))
                 u = ag.batchnorm_relu_train(u, pe[2])
                 u = ag.conv(u, pw(pe[4].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[4].weight))
                 u = ag.batchnorm_relu_train(u, pe[5])
@@ -685,9 +689,14 @@ class SalUNet(nn.Module):
             z = ag.conv(z.view(Bn, T, Hs * Ws, C), pw(w3), kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
                         w_dgrad=dgw(w3, (kt, 1)))
             zs.append(z.view(Bn, Hs, Ws, self.ori_embed_dim))
-        acc = ag.resize_sum(zs, th, tw_)
         mt = dec.mt_proj
-        y = ag.conv(acc, pw(mt[0].weight), kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, w_dgrad=dgw(mt[0].weight))
+        if self.tap_conv:
+            z_all = torch.cat([z.reshape(-1, self.ori_embed_dim) for z in zs], 0)
+            y9 = ag.linear(z_all, ag.tap_weight(mt[0].weight))
+            y = ag.tapsum(y9, [z.shape[1:3] for z in zs], B, th, tw_, mt[0].weight.shape[0], dil=1, bias=mt[0].bias)
+        else:
+            acc = ag.resize_sum(zs, th, tw_)
+            y = ag.conv(acc, pw(mt[0].weight), kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, w_dgrad=dgw(mt[0].weight))
         y = ag.batchnorm_relu_train(y, mt[1])
         s_ = ag.head_sigmoid(y, self.logits.linear_pred.weight.reshape(-1), self.logits.linear_pred.bias)
         out = ag.resize_bilinear(s_, self.img_size[0], self.img_size[1])

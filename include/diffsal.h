@@ -68,6 +68,13 @@ int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float
 int diffsal_tapsum(const void* const* srcs, const int* hs, const int* ws, int n_src, void* out, int N, int H, int W, int C,
                    int dil, const float* bias, const float* scale, const float* shift, int act, int dtype,
                    diffsal_stream_t stream);
+/* Training: the adjoint of diffsal_tapsum (act NONE, no affine) with respect to ONE source's tap products,
+ *   dy [N,h,w,9*C] (fp32) from du [N,H,W,C]; ws: diffsal_tapsum_bwd_ws_bytes(N, W, C, h) bytes of scratch (the three row passes).
+ * Gather form, deterministic; replaces the full-resolution dgrad + wgrad of the convolution behind nn.Upsample in training
+ * (common_block.py:196-216, sal_unet.py:480-489). */
+long diffsal_tapsum_bwd_ws_bytes(int N, int W, int C, int h);
+int diffsal_tapsum_bwd(const float* du, float* dy, float* ws, int N, int H, int W, int C, int h, int w, int dil,
+                       diffsal_stream_t stream);
 
 /* ---- K2 fused: conv_in followed directly by Downsample4x4's 3x3 stride-4 convolution (sal_unet.py:240,292 + :67-84) as ONE
  * 5x5 stride-4 convolution of the single-channel input; w25 [25][C] (tap-major) and bias [C] are the composed weights

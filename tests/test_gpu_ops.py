@@ -385,7 +385,7 @@ def test_conv_in_s4_equals_conv_in_then_stride4_downsample(ops, B, H, W):
     assert rel_err(got, two) < 5e-6
 
 
-@pytest.mark.parametrize("case", [
+TAPSUM_CASES = [
     # N, Cin, Cout, (H, W), factors, dil
     (3, 64, 96, (16, 24), (2,), 2),          # UpEmbed conv1: bilinear x2 then 3x3 dilation 2; odd batch (half-empty wave)
     (2, 96, 160, (8, 12), (2,), 2),          # two 128-channel slabs
@@ -393,7 +393,10 @@ def test_conv_in_s4_equals_conv_in_then_stride4_downsample(ops, B, H, W):
     (1, 32, 32, (16, 16), (1, 4), 1),        # a source already at the target resolution
     (3, 64, 96, (14, 24), (2,), 2),          # stage-1 UpEmbed: 7x12 -> 14x24, H not a multiple of 4 (ragged patch row)
     (2, 32, 64, (6, 10), (2,), 1),           # both extents ragged
-])
+]
+
+
+@pytest.mark.parametrize("case", TAPSUM_CASES, ids=[str(c) for c in TAPSUM_CASES])
 def test_tapsum_equals_conv_of_upsampled_sum(ops, case):
     """conv3x3(sum_i bilinear(z_i)) == tapsum of the per-source GEMMs with the nine 1x1 tap mixings (csrc/tapsum.hip)."""
     N, Cin, Cout, (H, W), factors, dil = case
@@ -407,3 +410,27 @@ def test_tapsum_equals_conv_of_upsampled_sum(ops, case):
     got = ops.tapsum(ys, H, W, Cout, dil=dil, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), act=ops.ACT_RELU)
     assert got.shape == nhwc(ref).shape
     assert rel_err(got, nhwc(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("case", TAPSUM_CASES, ids=[str(c) for c in TAPSUM_CASES])
+def test_tapsum_autograd_matches_conv_of_upsampled_sum(ops, case):
+    """Training path: d/dz_i, d/dW, d/dbias of conv3x3(sum_i bilinear(z_i)) through GEMM + tapsum and their adjoints
+    (autograd_ops.TapSumFn, diffsal_tapsum_bwd) == torch autograd of the direct expression."""
+    from diff_sal_amd import autograd_ops as ag
+    N, Cin, Cout, (H, W), factors, dil = case
+    zs = [rnd("gz%d" % f, N, Cin, H // f, W // f).requires_grad_() for f in factors]
+    w = rnd("gw", Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).requires_grad_()
+    b = rnd("gb", Cout, scale=0.1).requires_grad_()
+    g = rnd("gg", N, Cout, H, W)
+    up = sum(F.interpolate(z, size=(H, W), mode="bilinear", align_corners=False) if z.shape[-2:] != (H, W) else z for z in zs)
+    F.conv2d(up, w, b, padding=dil, dilation=dil).backward(g)
+    zd = [nhwc(z.detach()).to(DEV).requires_grad_() for z in zs]
+    wd, bd = w.detach().to(DEV).requires_grad_(), b.detach().to(DEV).requires_grad_()
+    z_all = torch.cat([z.reshape(-1, Cin) for z in zd], 0)
+    y9 = ag.linear(z_all, ag.tap_weight(wd))
+    out = ag.tapsum(y9, [z.shape[1:3] for z in zd], N, H, W, Cout, dil=dil, bias=bd)
+    out.backward(nhwc(g).to(DEV))
+    for z, zr in zip(zd, zs):
+        assert rel_err(z.grad, nhwc(zr.grad)) < 1e-5
+    assert rel_err(wd.grad, w.grad) < 1e-5
+    assert rel_err(bd.grad, b.grad) < 1e-5
