@@ -638,7 +638,7 @@ class SalUNet(nn.Module):
                 Bn, T, h, w, Cp = xcur.shape
                 d = self.dilation[i]
                 pe = st.patch_embed[0].proj
-                if self.tap_conv:   # nine 1x1 mixings at the low resolution + gather (csrc/tapsum.hip), adjoint likewise
+                if self.tap_conv and d in (1, 2) and h >= 2 and w >= 2:   # nine 1x1 mixings at the low resolution + gather (csrc/tapsum.hip), adjoint likewise
                     y9 = ag.linear(xcur.view(Bn * T * h * w, Cp), ag.tap_weight(pe[1].weight))
                     u = ag.tapsum(y9, [(h, w)], Bn * T, 2 * h, 2 * w, C, dil=d)
                 else:
@@ -690,7 +690,8 @@ class SalUNet(nn.Module):
                         w_dgrad=dgw(w3, (kt, 1)))
             zs.append(z.view(Bn, Hs, Ws, self.ori_embed_dim))
         mt = dec.mt_proj
-        if self.tap_conv:
+        if self.tap_conv and all(th % z_.shape[1] == 0 and (th // z_.shape[1]) & (th // z_.shape[1] - 1) == 0 and
+                                 z_.shape[1] >= 2 and z_.shape[2] >= 2 and tw_ == z_.shape[2] * (th // z_.shape[1]) for z_ in zs):
             z_all = torch.cat([z.reshape(-1, self.ori_embed_dim) for z in zs], 0)
             y9 = ag.linear(z_all, ag.tap_weight(mt[0].weight))
             y = ag.tapsum(y9, [z.shape[1:3] for z in zs], B, th, tw_, mt[0].weight.shape[0], dil=1, bias=mt[0].bias)
