@@ -498,6 +498,18 @@ class SalUNet(nn.Module):
         h0, w0 = xcur.shape[2:4]
         th, tw = h0 * 2 ** (ns - 1) * 2, w0 * 2 ** (ns - 1) * 2
         zs = []
+        # tap path of mt_proj: the ReduceTemp outputs of all stages land in ONE row-concatenated matrix, so that the nine tap
+        # mixings of the four scales are a single GEMM
+        z_all, z_off, sizes = None, 0, []
+        hh, ww = h0, w0
+        for i in range(ns):
+            if self.dilation[i] != 0:
+                hh, ww = 2 * hh, 2 * ww
+            sizes.append((hh, ww))
+        if self._use_tap_conv(taps) and all(th % a_ == 0 and (th // a_) & (th // a_ - 1) == 0 and a_ >= 2 and b_ >= 2 and
+                                            tw == b_ * (th // a_) for a_, b_ in sizes):
+            z_all = torch.empty((frames[0].shape[0] * sum(a_ * b_ for a_, b_ in sizes), self.ori_embed_dim),
+                                device=frames[0].device, dtype=cdt)
         for i in range(ns):
             C = self.up_channels[i]
             if self.dilation[i] != 0:
@@ -526,14 +538,23 @@ class SalUNet(nn.Module):
             Bn, T, H, W, _ = xcur.shape
             if z is None:
                 z = ops.layernorm(xcur, nm.weight, nm.bias, nm.eps)
+            z_out = None
+            if z_all is not None:
+                if (H, W) != sizes[i]:
+                    raise RuntimeError(f"stage {i}: {H}x{W} tokens, expected {sizes[i]}")
+                z_out = z_all[z_off:z_off + Bn * H * W].view(Bn, 1, H * W, self.ori_embed_dim)
+                z_off += Bn * H * W
             z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
-                               tag="K13")
+                               out=z_out, tag="K13")
             zs.append(z.view(Bn, H, W, self.ori_embed_dim))
         mt = dec.mt_proj
-        if self._use_tap_conv(taps) and all(
-                th % z_.shape[1] == 0 and (th // z_.shape[1]) & (th // z_.shape[1] - 1) == 0 and z_.shape[1] >= 2 and
-                tw == z_.shape[2] * (th // z_.shape[1]) for z_ in zs):
-            ys = [ops.linear(z_, pk["mt.tapw"], None, tag="K14") for z_ in zs]
+        if z_all is not None:
+            y9 = ops.linear(z_all, pk["mt.tapw"], None, tag="K14")
+            ys, off = [], 0
+            for z_ in zs:
+                m_ = z_.shape[0] * z_.shape[1] * z_.shape[2]
+                ys.append(y9[off:off + m_].view(z_.shape[0], z_.shape[1], z_.shape[2], y9.shape[-1]))
+                off += m_
             y = ops.tapsum(ys, th, tw, mt[0].out_channels, dil=1, bias=mt[0].bias, scale=pk["mt.scale"], shift=pk["mt.shift"],
                            act=ACT_RELU, tag="K14-tap")
         else:
