@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--workload", choices=["sample", "train"], default="sample",
                     help="sample = the headline metric; train = BASELINE configs[3] (one step = prepare_data + forward + "
                          "MSE + backward + gradient all-reduce + clip + Adam on a per-GPU batch), reported as samples/s")
+    ap.add_argument("--tap16", default=None, help="16-bit storage: comma list of s1,s2,s3,mt uses of the tap form (tuning aid)")
     ap.add_argument("--train-scope", choices=["full", "decoder"], default="full",
                     help="--workload train: full = MViT + (VGGish, AudioAttnNet) + SalUNet inside the step, as the reference; "
                          "decoder = the denoiser alone on given features (round-1 measurement)")
@@ -363,6 +364,8 @@ def main():
         net.gemm_precision = "bf16x3" if mode == "bf16x3" else "fp32"
 
     set_precision(args.precision)
+    if args.tap16 is not None:
+        net.tap_conv16 = tuple(x for x in args.tap16.split(",") if x)
 
     # synthetic clips, resident in HBM before the timed region; rank-dependent seed (each rank owns its clips)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)

@@ -246,6 +246,24 @@ def test_lowp_forward_vs_reference_golden(golden_dir, name, dname):
 
 
 @pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("name", ["small_vis", "full_av_b1"])
+def test_lowp_forward_with_tap_convolutions(golden_dir, name, dname):
+    """Opt-in on 16-bit storage (SalUNet.tap_conv16): UpEmbed's first convolution / mt_proj as tap GEMM + tapsum gather; same bar."""
+    cfg, sd, x, t, feats, audio, g = load_case(golden_dir, name)
+    net = build(cfg, sd, DTYPES[dname])
+    net.tap_conv16 = ("s1", "s2", "s3", "mt")
+    with torch.no_grad():
+        out = net(x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None if audio is None else audio.to(DEV))
+        net.tap_conv16 = ()
+        base = net(x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None if audio is None else audio.to(DEV))
+    ref = torch.from_numpy(g["output"])
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"LOWP {dname} {name} tap form: max abs {err:.3e} (direct form {(base.cpu() - ref).abs().max().item():.3e})")
+    assert err < LOWP_ATOL[dname]
+    assert not torch.equal(out, base)        # the switch did change the executed path
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
 def test_lowp_sampling_trajectories(golden_dir, dname):
     """10-step DDIM of the reference trainer and the 50-NFE DPM-Solver of the reference sampler with a 16-bit denoiser:
     the sampler state x stays fp32, only the network evaluation is reduced precision."""
