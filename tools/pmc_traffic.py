@@ -27,7 +27,7 @@ def main():
     prec = sys.argv[4] if len(sys.argv) > 4 else "fp32"
     build = sys.argv[5] if len(sys.argv) > 5 else "build n/a"
     # the GEMM family of the precision: tiled implicit GEMM (+ split-K reduce), streaming linears, fused MLP / block kernels
-    match = (["igemm_kernel", "igemm_linear_kernel", "splitk_reduce_kernel", "lin_stream_kernel", "mlp_block_kernel"] if prec == "fp32" else
+    match = (["igemm_kernel", "igemm_linear_kernel", "splitk_reduce_kernel", "lin_stream_kernel", "mlp_block_kernel", "tapsum_kernel"] if prec == "fp32" else
              ["igemm16_kernel", "igemm16_linear_kernel", "splitk16_reduce_kernel", "conv16_halo_kernel", "block16_kernel"])
     fk, nf = per_kernel(fetch_dir, "FETCH_SIZE", match)
     wk, nw = per_kernel(write_dir, "WRITE_SIZE", match)
