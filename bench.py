@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--workload", choices=["sample", "train"], default="sample",
                     help="sample = the headline metric; train = BASELINE configs[3] (one step = prepare_data + forward + "
                          "MSE + backward + gradient all-reduce + clip + Adam on a per-GPU batch), reported as samples/s")
+    ap.add_argument("--no-reference-graph", action="store_true",
+                    help="skip the extra profiled step on the reference's own graph (profiling passes: keeps the trace to the shipped step)")
     ap.add_argument("--tap16", default=None, help="16-bit storage: comma list of s1,s2,s3,mt uses of the tap form (tuning aid)")
     ap.add_argument("--train-scope", choices=["full", "decoder"], default="full",
                     help="--workload train: full = MViT + (VGGish, AudioAttnNet) + SalUNet inside the step, as the reference; "
@@ -492,7 +494,7 @@ def main():
               "step_ms_all_kernels": round(sum(e[0].elapsed_time(e[1]) for e in all_ev), 3),
               "classes": class_table(all_ev, peak_for_mode)}
     ref_graph = None
-    if args.precision == "fp32" and getattr(net, "tap_conv", False) and not special:
+    if args.precision == "fp32" and getattr(net, "tap_conv", False) and not special and not args.no_reference_graph:
         # the same step on the reference's own graph (3x3 convolutions AFTER the bilinear up-samplings, sal_unet.py:480-489,
         # common_block.py:196-216): its GEMM FLOPs are SURVEY 8(d)'s algorithmic figure; the shipped path executes fewer
         net.tap_conv = False

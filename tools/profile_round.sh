@@ -6,7 +6,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; PREC=$2; shift 2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-alt-precision --no-encoders --precision $PREC --steps 50 --warmup 5 --repeats 1 $*"
+ARGS="--no-cpu-baseline --no-alt-precision --no-encoders --no-reference-graph --precision $PREC --steps 50 --warmup 5 --repeats 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$PREC -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/stats_$PREC.json 2> $OUT/stats_$PREC.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$PREC -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_fetch_$PREC.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$PREC -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_write_$PREC.err
