@@ -58,6 +58,7 @@ struct IgemmArgs {
   int splits, kt_per_split;  // split-K: workgroup (tile, s) covers K slices [s*kt_per_split, ...)
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
   int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is 16-byte aligned
+  int xcd_order;             // persistent linear kernel: tiles walked so that one XCD owns whole M-tile rows (see the kernel)
 };
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -552,13 +553,32 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
   for (int j = 0; j < B_PASSES; ++j) b_rel[j] = static_cast<unsigned>((lrow + 32 * j) * p.K + lcol) * 4u;
 
   const int nkt = p.K / BK;
-  const int n_tiles = p.n_tiles;
-  const int my_tiles = (n_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+  // Tile walk: virtual index v = blockIdx.x + i * gridDim.x.  Plain order: v = tile, N fastest.  XCD order (large launches,
+  // gridDim.x % 8 == 0): workgroup b runs on XCD b % 8, and XCD x owns the M tiles x, x + 8, ... with all their N tiles, so the
+  // N tiles that share an A row block meet in ONE L2 instead of eight.  v_end: first virtual index past this worker's tiles.
+  int n_tiles = p.n_tiles;
+  if (p.xcd_order) {
+    const int x = blockIdx.x & 7, ntm = p.n_tiles / p.n_tiles_n;
+    n_tiles = 8 * p.n_tiles_n * (ntm > x ? (ntm - x + 7) >> 3 : 0);
+  }
+  auto tile_mn = [&](int v, int& tmi, int& tni) __attribute__((always_inline)) {
+    if (p.xcd_order) {
+      const int q = v >> 3, ml = q / p.n_tiles_n;
+      tni = q - ml * p.n_tiles_n;
+      tmi = ml * 8 + (v & 7);
+    } else {
+      tmi = v / p.n_tiles_n;
+      tni = v - tmi * p.n_tiles_n;
+    }
+  };
+  const int my_tiles = n_tiles > static_cast<int>(blockIdx.x)
+                           ? (n_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : 0;
   const int total = my_tiles * nkt;
   int iss_w = blockIdx.x, iss_kt = 0;
   unsigned iss_a = 0, iss_b = 0;
   auto origins = [&](int w, unsigned& oa, unsigned& ob) __attribute__((always_inline)) {
-    const int tmi = w / p.n_tiles_n, tni = w - tmi * p.n_tiles_n;
+    int tmi, tni;
+    tile_mn(w, tmi, tni);
     oa = static_cast<unsigned>(tmi) * static_cast<unsigned>(BM * p.K * 4);
     ob = static_cast<unsigned>(tni) * static_cast<unsigned>(BN * p.K * 4);
   };
@@ -626,7 +646,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
   // they would be a dependent round trip with the matrix pipe idle
   float4 rres[TM][TN][4];
   auto fetch_residual = [&]() __attribute__((always_inline)) {
-    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    int tmi, tni;
+    tile_mn(cmp_w, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -642,7 +663,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
     }
   };
   auto finish_tile = [&]() __attribute__((always_inline)) {
-    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    int tmi, tni;
+    tile_mn(cmp_w, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -832,6 +854,9 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
   a.n_tiles = a.n_tiles_n * tiles_m;
   if (precision != DIFFSAL_PREC_BF16X3 && a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0) {
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
+    const char* e_xcd = getenv("DIFFSAL_NO_XCD_ORDER");
+    const bool no_xcd = e_xcd && e_xcd[0] == '1';
+    a.xcd_order = (!no_xcd && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm_linear_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, s, a);
     return check_launch("diffsal_conv_igemm(linear)");
   }
@@ -904,6 +929,7 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
 
   IgemmArgs a;
+  a.xcd_order = 0;
   a.in = in; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec;
   a.residual = residual; a.out = out;
   a.M = static_cast<int>(M);

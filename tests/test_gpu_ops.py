@@ -114,6 +114,26 @@ def test_persistent_linear_kernel_fp32(ops, cfg, monkeypatch):
         assert rel_err(per, F.gelu(F.linear(x, w, b)) + r) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
+def test_persistent_linear_kernel_xcd_tile_order(ops, cfg, monkeypatch):
+    """Large launches of igemm_linear_kernel walk the tiles XCD by XCD (one XCD owns whole M-tile rows): every tile still
+    computed exactly once -- bit-equal with the plain order and with the one-tile kernel; M-tile counts that are not multiples
+    of 8, ragged rows and columns."""
+    if cfg is not None:
+        monkeypatch.setenv("DIFFSAL_IGEMM_CFG", str(cfg))
+    for M, K, N in ((48421, 96, 864), (33000, 32, 200), (70001, 64, 136)):
+        x, w, b, r = rnd("qx%d" % K, M, K).to(DEV), rnd("qw%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("qb", N, scale=0.1).to(DEV), rnd("qr%d" % N, M, N).to(DEV)
+        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+        one = ops.linear(x, w, b, residual=r, act=ops.ACT_RELU)
+        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
+        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "1")
+        plain = ops.linear(x, w, b, residual=r, act=ops.ACT_RELU)
+        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "0")
+        xcd = ops.linear(x, w, b, residual=r, act=ops.ACT_RELU)
+        assert torch.equal(one, plain) and torch.equal(one, xcd), (M, K, N)
+        assert rel_err(xcd, F.relu(F.linear(x, w, b)) + r) < 2e-5
+
+
 @pytest.mark.parametrize("K,N,act,res", [(96, 96, 0, True), (96, 96, 0, False), (96, 192, 2, False), (192, 96, 0, True),
                                          (96, 192, 1, True)])
 def test_streaming_short_k_linear(ops, K, N, act, res):
