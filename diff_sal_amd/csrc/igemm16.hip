@@ -53,6 +53,7 @@ struct Igemm16Args {
   int act, rowvec_ld;
   int linear;                // 1: 1x1 / stride 1 / no padding (a plain [M, Cin] x [Cin, Cout] product)
   int n_tiles_n, n_tiles;
+  int xcd_order;   // persistent linear kernel: XCD-aware tile walk
   unsigned in_bytes, w_bytes;
   int splits, st_per_split;  // split-K over 64-k stages
   int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is aligned for 8 / 16-byte pieces
@@ -364,14 +365,31 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm16_linear_ke
 
   const int KT32 = p.K / SUBK;
   const int nst = (KT32 + 1) / 2;
-  const int n_tiles = p.n_tiles;
-  const int my_tiles = (n_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+  // tile walk: plain (v = tile, N fastest) or XCD order (one XCD owns whole M-tile rows) -- see igemm_linear_kernel in igemm.hip
+  int n_tiles = p.n_tiles;
+  if (p.xcd_order) {
+    const int x = blockIdx.x & 7, ntm = p.n_tiles / p.n_tiles_n;
+    n_tiles = 8 * p.n_tiles_n * (ntm > x ? (ntm - x + 7) >> 3 : 0);
+  }
+  auto tile_mn = [&](int v, int& tmi, int& tni) __attribute__((always_inline)) {
+    if (p.xcd_order) {
+      const int q = v >> 3, ml = q / p.n_tiles_n;
+      tni = q - ml * p.n_tiles_n;
+      tmi = ml * 8 + (v & 7);
+    } else {
+      tmi = v / p.n_tiles_n;
+      tni = v - tmi * p.n_tiles_n;
+    }
+  };
+  const int my_tiles = n_tiles > static_cast<int>(blockIdx.x)
+                           ? (n_tiles - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x) : 0;
   const int total = my_tiles * nst;                 // global stage count of this workgroup
   // issue side: the next stage to fetch, as (tile, stage) with the tile's two origins
   int iss_w = blockIdx.x, iss_st = 0;
   unsigned iss_a = 0, iss_b = 0;
   auto origins = [&](int w, unsigned& oa, unsigned& ob) __attribute__((always_inline)) {
-    const int tmi = w / p.n_tiles_n, tni = w - tmi * p.n_tiles_n;
+    int tmi, tni;
+    tile_mn(w, tmi, tni);
     oa = static_cast<unsigned>(tmi) * static_cast<unsigned>(BM * p.K * 2);
     ob = static_cast<unsigned>(tni) * static_cast<unsigned>(BN * p.K * 2);
   };
@@ -437,7 +455,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm16_linear_ke
   // they would be a dependent round trip with the matrix pipe idle
   uint2 rres[TM][TN][4];
   auto fetch_residual = [&]() __attribute__((always_inline)) {
-    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    int tmi, tni;
+    tile_mn(cmp_w, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -454,7 +473,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm16_linear_ke
     }
   };
   auto finish_tile = [&]() __attribute__((always_inline)) {
-    const int tmi = cmp_w / p.n_tiles_n, tni = cmp_w - tmi * p.n_tiles_n;
+    int tmi, tni;
+    tile_mn(cmp_w, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -629,6 +649,8 @@ static int launch16(Igemm16Args<T>& a, hipStream_t s) {
   a.n_tiles = a.n_tiles_n * tiles_m;
   if (a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0) {   // plain product: persistent workgroups
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
+    const char* e_xcd = getenv("DIFFSAL_NO_XCD_ORDER");
+    a.xcd_order = (!(e_xcd && e_xcd[0] == '1') && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm16_linear_kernel<WM, WN, TM, TN, T>), dim3(grid), dim3(256), 0, s, a);
     return check_launch("diffsal_conv_igemm(16-bit linear)");
   }
@@ -673,6 +695,7 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
                  hipStream_t s) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   Igemm16Args<T> a;
+  a.xcd_order = 0;
   a.in = static_cast<const T*>(in); a.w = static_cast<const T*>(w); a.bias = bias; a.scale = scale; a.shift = shift;
   a.rowvec = rowvec; a.residual = static_cast<const T*>(residual); a.out = static_cast<T*>(out);
   a.M = static_cast<int>(M);

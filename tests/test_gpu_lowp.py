@@ -372,15 +372,20 @@ def test_persistent_linear_kernel_16bit(ops, dname, cfg, monkeypatch):
     dt = DTYPES[dname]
     if cfg is not None:
         monkeypatch.setenv("DIFFSAL_IGEMM16_CFG", str(cfg))
-    for M, K, N in ((1000, 160, 72), (130, 96, 100), (4100, 32, 224), (777, 384, 96)):
+    # the last two shapes are large launches: there the tiles are walked XCD by XCD (DIFFSAL_NO_XCD_ORDER=1: plain order)
+    for M, K, N in ((1000, 160, 72), (130, 96, 100), (4100, 32, 224), (777, 384, 96), (48421, 96, 864), (70001, 64, 136)):
         x = q(rnd("px%d" % K, M, K), dt).to(DEV).to(dt)
         w = q(rnd("pw%d" % N, N, K, scale=1.0 / math.sqrt(K)), dt).to(DEV).to(dt)
         b = rnd("pb", N, scale=0.1).to(DEV)
-        r = q(rnd("pr", M, N), dt).to(DEV).to(dt)
+        r = q(rnd("pr%d" % M, M, N), dt).to(DEV).to(dt)
         monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
         one = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
         monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
         per = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
         assert torch.equal(one, per), (M, K, N)
+        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "1")
+        plain = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
+        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "0")
+        assert torch.equal(plain, per), (M, K, N)
         ref = F.gelu(x.float() @ w.float().t() + b) + r.float()
         assert rel_err(per, ref) < OP_RTOL[dname]
