@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256) void tokens_to_channels_first_kernel(const flo
 // d_in is written through the same (batch, token) strides as the forward's input view, i.e. straight into the q / k / v
 // slice of the fused-qkv gradient buffer.
 // ------------------------------------------------------------------------------------------------
-template <int G>
+// NCS: spatial taps that can reach an input pixel per axis -- 3 (stride 1), 2 (stride 2), 1 (stride >= 3): the candidates are
+// k = (i + 1) % s + j s, j < NCS, so a stride-8 key / value pooling does 3 loads per input token instead of 27 (24 of them
+// dummies).  NCS = 0: every one of the 27 taps is tried (unequal spatial strides).  Valid taps are visited in the same order
+// in both forms, so the results are bit-identical.
+template <int G, int NCS>
 __global__ __launch_bounds__(256) void pool3d_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w27,
                                                               float* __restrict__ din, long in_sb, long in_sn, int heads,
                                                               int D, int T, int H, int W, int To, int Ho, int Wo, int st,
@@ -260,20 +264,42 @@ __global__ __launch_bounds__(256) void pool3d_bwd_data_kernel(const float* __res
       for (int kt = 0; kt < 3; ++kt) {
         const int nt = it + 1 - kt;
         const bool vt = nt >= 0 && nt % st == 0 && nt / st < To;
+        if constexpr (NCS == 0) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int ny = iy + 1 - ky;
-          const bool vy = vt && ny >= 0 && ny % sh == 0 && ny / sh < Ho;
+          for (int ky = 0; ky < 3; ++ky) {
+            const int ny = iy + 1 - ky;
+            const bool vy = vt && ny >= 0 && ny % sh == 0 && ny / sh < Ho;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int nx = ix + 1 - kx;
-            const bool v = vy && nx >= 0 && nx % sw == 0 && nx / sw < Wo;
-            const long o = v ? 1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw : 0;
-            const float4 g = ld4(dyb + o * D);
-            float4 ww = ld4(w_s + ((kt * 3 + ky) * 3 + kx) * D + c);
-            if (!v) ww = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
-            acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+            for (int kx = 0; kx < 3; ++kx) {
+              const int nx = ix + 1 - kx;
+              const bool v = vy && nx >= 0 && nx % sw == 0 && nx / sw < Wo;
+              const long o = v ? 1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw : 0;
+              const float4 g = ld4(dyb + o * D);
+              float4 ww = ld4(w_s + ((kt * 3 + ky) * 3 + kx) * D + c);
+              if (!v) ww = make_float4(0.f, 0.f, 0.f, 0.f);
+              acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
+              acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+            }
+          }
+        } else {
+          const int k0y = (iy + 1) % sh, k0x = (ix + 1) % sw;
+#pragma unroll
+          for (int jy = 0; jy < NCS; ++jy) {
+            const int ky = k0y + jy * sh, dy_ = iy + 1 - ky;
+            const int ny = dy_ / sh;
+            const bool vy = vt && ky <= 2 && dy_ >= 0 && ny < Ho;
+#pragma unroll
+            for (int jx = 0; jx < NCS; ++jx) {
+              const int kx = k0x + jx * sw, dx_ = ix + 1 - kx;
+              const int nx = dx_ / sw;
+              const bool v = vy && kx <= 2 && dx_ >= 0 && nx < Wo;
+              const long o = v ? 1 + (static_cast<long>(nt / st) * Ho + ny) * Wo + nx : 0;
+              const float4 g = ld4(dyb + o * D);
+              float4 ww = ld4(w_s + (v ? ((kt * 3 + ky) * 3 + kx) * D : 0) + c);
+              if (!v) ww = make_float4(0.f, 0.f, 0.f, 0.f);
+              acc.x = fmaf(g.x, ww.x, acc.x); acc.y = fmaf(g.y, ww.y, acc.y);
+              acc.z = fmaf(g.z, ww.z, acc.z); acc.w = fmaf(g.w, ww.w, acc.w);
+            }
           }
         }
       }
@@ -585,11 +611,19 @@ extern "C" int diffsal_pool3d_bwd_data(const float* dy, const float* w27, float*
   const int To = (T - 1) / st + 1, Ho = (H - 1) / sh + 1, Wo = (W - 1) / sw + 1;
   const long rows = static_cast<long>(B) * heads * (static_cast<long>(T) * H * W + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL2(G, NCS)                                                                                                  \
+  hipLaunchKernelGGL((pool3d_bwd_data_kernel<G, NCS>), dim3(rows_grid(rows, 256 / G)), dim3(256), 27 * D * sizeof(float), s, dy, \
+                     w27, din, in_stride_b, in_stride_n, heads, D, T, H, W, To, Ho, Wo, st, sh, sw, rows)
 #define CALL(G)                                                                                                        \
-  hipLaunchKernelGGL((pool3d_bwd_data_kernel<G>), dim3(rows_grid(rows, 256 / G)), dim3(256), 27 * D * sizeof(float), s, dy, w27, din,         \
-                     in_stride_b, in_stride_n, heads, D, T, H, W, To, Ho, Wo, st, sh, sw, rows)
+  do {                                                                                                                 \
+    if (sh != sw) CALL2(G, 0);                                                                                         \
+    else if (sh == 1) CALL2(G, 3);                                                                                     \
+    else if (sh == 2) CALL2(G, 2);                                                                                     \
+    else CALL2(G, 1);                                                                                                  \
+  } while (0)
   if (D <= 32) { CALL(8); } else if (D <= 64) { CALL(16); } else if (D <= 128) { CALL(32); } else { CALL(64); }
 #undef CALL
+#undef CALL2
   return check_launch("pool3d_bwd_data");
 }
 

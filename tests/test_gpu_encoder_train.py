@@ -63,24 +63,28 @@ def test_pool_maxpool_relpos_backward():
     N = 1 + size[0] * size[1] * size[2]
     qkv = rnd("tq", B, N, 3, heads, D).requires_grad_(True)
     ws = [rnd(f"tw{i}", D, 1, 3, 3, 3, scale=0.2).requires_grad_(True) for i in range(3)]
-    strides = ((1, 2, 2), (1, 4, 4), (1, 4, 4))
-    refs = []
-    for i in range(3):
-        x = qkv[:, :, i].permute(0, 2, 1, 3)
-        t = x[:, :, 1:].reshape(B * heads, *size, D).permute(0, 4, 1, 2, 3)
-        t = F.conv3d(t, ws[i], None, stride=strides[i], padding=1, groups=D)
-        refs.append(torch.cat([x[:, :, :1], t.reshape(B, heads, D, -1).transpose(2, 3)], 2))
-    Gs = [rnd(f"tg{i}", *r.shape) for i, r in enumerate(refs)]
-    sum((r * g).sum() for r, g in zip(refs, Gs)).backward()
-    qd = qkv.detach().to(DEV).requires_grad_(True)
-    wd = [w.detach().reshape(D, 27).t().contiguous().to(DEV).requires_grad_(True) for w in ws]
-    outs = eg.qkv_pool(qd, wd[0], wd[1], wd[2], size, strides[0], strides[1])
-    sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
-    for o, r in zip(outs, refs):
-        close(o, r, 2e-5, "pool fwd")
-    close(qd.grad, qkv.grad, 5e-5, "dqkv")
-    for i in range(3):
-        close(wd[i].grad, ws[i].grad.reshape(D, 27).t(), 5e-5, f"dw{i}")
+    # stride classes of the data-gradient kernel: 1 (three taps reach an input pixel per axis), 2 (two), >= 3 (one), unequal (all 27 tried)
+    for strides in (((1, 2, 2), (1, 4, 4), (1, 4, 4)), ((1, 1, 1), (1, 8, 8), (1, 8, 8)), ((1, 1, 1), (1, 2, 4), (1, 2, 4))):
+        qkv.grad = None
+        for w in ws:
+            w.grad = None
+        refs = []
+        for i in range(3):
+            x = qkv[:, :, i].permute(0, 2, 1, 3)
+            t = x[:, :, 1:].reshape(B * heads, *size, D).permute(0, 4, 1, 2, 3)
+            t = F.conv3d(t, ws[i], None, stride=strides[i], padding=1, groups=D)
+            refs.append(torch.cat([x[:, :, :1], t.reshape(B, heads, D, -1).transpose(2, 3)], 2))
+        Gs = [rnd(f"tg{i}", *r.shape) for i, r in enumerate(refs)]
+        sum((r * g).sum() for r, g in zip(refs, Gs)).backward()
+        qd = qkv.detach().to(DEV).requires_grad_(True)
+        wd = [w.detach().reshape(D, 27).t().contiguous().to(DEV).requires_grad_(True) for w in ws]
+        outs = eg.qkv_pool(qd, wd[0], wd[1], wd[2], size, strides[0], strides[1])
+        sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
+        for o, r in zip(outs, refs):
+            close(o, r, 2e-5, "pool fwd")
+        close(qd.grad, qkv.grad, 5e-5, "dqkv")
+        for i in range(3):
+            close(wd[i].grad, ws[i].grad.reshape(D, 27).t(), 5e-5, f"dw{i}")
     # max-pool of the skip path
     C, size = 64, (2, 6, 9)
     x = rnd("mp", 2, 1 + size[0] * size[1] * size[2], C).requires_grad_(True)
