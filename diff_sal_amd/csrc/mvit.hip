@@ -497,23 +497,45 @@ __global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __r
   const int n_a = axis == 0 ? qh * qw : (axis == 1 ? qt * qw : qt * qh);       // queries per image with this coordinate
   const long n_all = static_cast<long>(BH) * n_a;
   const long lo = n_all * chunk / REL_CHUNKS, hi = n_all * (chunk + 1) / REL_CHUNKS;
-  for (int item = threadIdx.x; item < kk * c4n; item += 256) {
-    const int j = item / c4n, c = (item % c4n) * 4;
-    float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll 8
-    for (long u = lo; u < hi; ++u) {   // unrolled: eight rows' loads in flight, the additions keep their order
-      const int bh = static_cast<int>(u / n_a), m = static_cast<int>(u - static_cast<long>(bh) * n_a);
-      int t, y, x;
-      if (axis == 0) { t = i; y = m / qw; x = m % qw; }
-      else if (axis == 1) { y = i; t = m / qw; x = m % qw; }
-      else { x = i; t = m / qh; y = m % qh; }
+  // a thread owns a channel quad and FOUR table columns j: the query quad is loaded once for the four products (the gather is
+  // bound by L1 / L2 reads of q, which the one-column form re-read kk times per axis); the additions keep their order
+  const int kk4 = (kk + 3) >> 2;
+  for (int item = threadIdx.x; item < kk4 * c4n; item += 256) {
+    const int j0 = (item / c4n) * 4, c = (item % c4n) * 4;
+    float4 acc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[jj] = make_float4(0, 0, 0, 0);
+    // the query walk is the same for every thread: (image, two free coordinates) advance as wave-uniform counters, no
+    // divisions in the loop.  a = slow free coordinate, b2 = fast one (axis 0: (y, x); axis 1: (t, x); axis 2: (t, y))
+    const int nb = axis == 2 ? qh : qw;
+    int bh = static_cast<int>(lo / n_a);
+    int m0 = static_cast<int>(lo - static_cast<long>(bh) * n_a);
+    int a = m0 / nb, b2 = m0 - a * nb;
+#pragma unroll 4
+    for (long u = lo; u < hi; ++u) {
+      const int t = axis == 0 ? i : a;
+      const int y = axis == 0 ? a : (axis == 1 ? i : b2);
+      const int x = axis == 2 ? i : b2;
       const long row = static_cast<long>(bh) * (L + 1) + 1 + (static_cast<long>(t) * qh + y) * qw + x;
-      const float e = dE[row * REL_E + slot0 + j];
+      if (++b2 == nb) {
+        b2 = 0;
+        if (++a * nb == n_a) { a = 0; ++bh; }
+      }
       const float4 qv = ld4(q + row * D + c);
-      acc.x = fmaf(e, qv.x, acc.x); acc.y = fmaf(e, qv.y, acc.y); acc.z = fmaf(e, qv.z, acc.z); acc.w = fmaf(e, qv.w, acc.w);
+      const float* er = dE + row * REL_E + slot0 + j0;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float e = er[j0 + jj < kk ? jj : 0];
+        acc[jj].x = fmaf(e, qv.x, acc[jj].x); acc[jj].y = fmaf(e, qv.y, acc[jj].y);
+        acc[jj].z = fmaf(e, qv.z, acc[jj].z); acc[jj].w = fmaf(e, qv.w, acc[jj].w);
+      }
     }
-    double* o = part + chunk * width + tab0 + (static_cast<long>(i) * kk + j) * D + c;
-    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      if (j0 + jj >= kk) continue;
+      double* o = part + chunk * width + tab0 + (static_cast<long>(i) * kk + j0 + jj) * D + c;
+      o[0] = acc[jj].x; o[1] = acc[jj].y; o[2] = acc[jj].z; o[3] = acc[jj].w;
+    }
   }
 }
 
