@@ -232,3 +232,34 @@ def test_third_order_coefficients_equal_the_finite_difference_form():
             p1 = _m.expm1(h); p2 = p1 / h - 1.0; p3 = p2 / h - 0.5
             want = _m.exp(float(lat - la0)) * x - float(st) * p1 * m0 - float(st) * p2 * D1 - float(st) * p3 * D2
         assert (got - want).abs().max().item() < 2e-5 * want.abs().max().item()
+
+
+def test_fused_plan_is_the_solver_plan_and_is_cached_per_hyper_parameters():
+    """DiffusionSampler._fused_plan: the per-step host scalars of the fused DPM-Solver trajectory come from DPM_Solver.plan and
+    model_wrapper's time / x0 -> noise arithmetic; one table per hyper-parameter set, rebuilt when any of them changes."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    class Top:
+        decoder_net = None
+
+    smp = DiffusionSampler(Top(), timesteps=50, sample_type="dpmsolver", skip_type="logSNR", denoise=True, training_target="x0")
+    rows, last = smp._fused_plan(49)
+    assert smp._fused_plan(49) is smp._plan_cache[next(iter(smp._plan_cache))]          # second call: the cached object
+    ns = NoiseScheduleVP(schedule="discrete", betas=smp.betas)
+    times, table, t_0 = DPM_Solver(lambda *a, **k: None, ns, algorithm_type="dpmsolver").plan(49, 2, "logSNR", None, None, False,
+                                                                                          "dpmsolver")
+    assert len(rows) == 49
+    for s, (t_net, ex, e0, A, c0, c1, two) in enumerate(rows):
+        tc = times[s].reshape(1)
+        alpha, sigma = float(ns.marginal_alpha(tc)), float(ns.marginal_std(tc))
+        assert t_net == float((tc - 1.0 / ns.total_N) * 1000.0)
+        assert ex == 1.0 / sigma and e0 == -alpha / sigma
+        assert A == table[s][0] and c0 == table[s][1][0] and two == (len(table[s][1]) > 1)
+        assert c1 == (table[s][1][1] if two else 0.0)
+    assert rows[0][6] is False and all(r[6] for r in rows[1:])                         # first step is first order
+    assert last[0] == float((torch.ones(1) * t_0 - 1.0 / ns.total_N) * 1000.0)
+    smp.timesteps = 20                                                                   # a changed hyper-parameter: new table
+    rows20, _ = smp._fused_plan(19)
+    assert len(rows20) == 19 and len(smp._plan_cache) == 2
+    smp.skip_type = "time_uniform"
+    assert smp._fused_plan(19)[0] != rows20 and len(smp._plan_cache) == 3
