@@ -29,7 +29,8 @@ namespace diffsal {
 size_t igemm16_ws_bytes(const diffsal_conv_desc* d);
 int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                    const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
-                   hipStream_t s);
+                   hipStream_t s, const void* in2 = nullptr, const void* w2 = nullptr, const float* bias2 = nullptr,
+                   void* out2 = nullptr);
 
 // lin_stream.hip: barrier-free streaming kernel for short-K, huge-M linear layers
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
@@ -59,7 +60,19 @@ struct IgemmArgs {
   float* partial;            // [splits][M][Cout] raw partial sums when splits > 1
   int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is 16-byte aligned
   int xcd_order;             // persistent linear kernel: tiles walked so that one XCD owns whole M-tile rows (see the kernel)
+  // pair launch (diffsal_linear_pair): a second problem of the SAME shape rides in the same grid (blockIdx.z = 1)
+  int pair;
+  const float* in2;
+  const float* w2;
+  const float* bias2;
+  float* out2;
+  float* partial2;
 };
+
+// blockIdx.z = 1 of a pair launch works on the second pointer set (uniform selects on the kernel arguments)
+__device__ __forceinline__ void select_pair(IgemmArgs& p, int which) {
+  if (p.pair && which) { p.in = p.in2; p.w = p.w2; p.bias = p.bias2; p.out = p.out2; p.partial = p.partial2; }
+}
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -76,6 +89,7 @@ constexpr int PITCH = BK + 4;  // dwords; 36*r mod 64 hits 16 distinct 4-bank sl
 //   (tools/spikes/bf16x3_gemm.hip).  Opt-in (diffsal_set_gemm_precision), reported separately from the headline.
 template <int WM, int WN, int TM, int TN, int PREC>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
+  select_pair(p, blockIdx.z);
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   // A-operand loader: fp32 -> a thread owns 4 consecutive k of a row (one 16-byte load), 32 rows per pass;
@@ -767,6 +781,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
 
 // Sum the split-K slabs in a fixed order (deterministic) and apply the epilogue; float4 over Cout.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs p) {
+  select_pair(p, blockIdx.y);
   const int n4 = p.Cout >> 2;
   const long total = static_cast<long>(p.M) * n4;
   const long slab = static_cast<long>(p.M) * p.Cout;
@@ -852,7 +867,8 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  if (precision != DIFFSAL_PREC_BF16X3 && a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0) {
+  const unsigned nz = a.pair ? 2u : 1u;
+  if (precision != DIFFSAL_PREC_BF16X3 && a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0 && !a.pair) {
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
     const char* e_xcd = getenv("DIFFSAL_NO_XCD_ORDER");
     const bool no_xcd = e_xcd && e_xcd[0] == '1';
@@ -861,15 +877,15 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
     return check_launch("diffsal_conv_igemm(linear)");
   }
   if (precision == DIFFSAL_PREC_BF16X3)
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 1>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 1>), dim3(a.n_tiles, a.splits, nz), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 0>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 0>), dim3(a.n_tiles, a.splits, nz), dim3(256), 0, s, a);
   int rc = check_launch("diffsal_conv_igemm");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
   long g = (total4 + 255) / 256;
   g = g > 2048 ? 2048 : g;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<int>(g)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<int>(g), nz), dim3(256), 0, s, a);
   return check_launch("diffsal_conv_igemm(split-K reduce)");
 }
 
@@ -910,10 +926,17 @@ extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
 }
 
-extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, const void* w_v,
-                                  const float* bias, const float* scale, const float* shift,
-                                  const float* rowvec, const void* residual_v, void* out_v, void* ws,
-                                  size_t ws_bytes, diffsal_stream_t stream) {
+// second problem of a pair launch (same descriptor): diffsal_linear_pair
+struct PairExtra {
+  const void* in2;
+  const void* w2;
+  const float* bias2;
+  void* out2;
+};
+
+static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const void* w_v, const float* bias, const float* scale,
+                           const float* shift, const float* rowvec, const void* residual_v, void* out_v, void* ws,
+                           size_t ws_bytes, diffsal_stream_t stream, const PairExtra* px) {
   int rc = validate(d);
   if (rc) return rc;
   DS_REQUIRE(in_v && w_v && out_v, DIFFSAL_E_ARG, "conv_igemm: null argument");
@@ -921,7 +944,8 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
   DS_REQUIRE(aligned16(in_v) && aligned16(w_v), DIFFSAL_E_ALIGN, "conv_igemm: in/w must be 16-byte aligned");
   if (d->dtype != DIFFSAL_F32)
     return igemm16_launch(d, in_v, w_v, bias, scale, shift, rowvec, residual_v, out_v, ws, ws_bytes,
-                          static_cast<hipStream_t>(stream));
+                          static_cast<hipStream_t>(stream), px ? px->in2 : nullptr, px ? px->w2 : nullptr,
+                          px ? px->bias2 : nullptr, px ? px->out2 : nullptr);
   const float* in = static_cast<const float*>(in_v);
   const float* w = static_cast<const float*>(w_v);
   const float* residual = static_cast<const float*>(residual_v);
@@ -930,6 +954,12 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
 
   IgemmArgs a;
   a.xcd_order = 0;
+  a.pair = px ? 1 : 0;
+  a.in2 = px ? static_cast<const float*>(px->in2) : nullptr;
+  a.w2 = px ? static_cast<const float*>(px->w2) : nullptr;
+  a.bias2 = px ? px->bias2 : nullptr;
+  a.out2 = px ? static_cast<float*>(px->out2) : nullptr;
+  a.partial2 = nullptr;
   a.in = in; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec;
   a.residual = residual; a.out = out;
   a.M = static_cast<int>(M);
@@ -947,7 +977,7 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   if (d->w_format == 0 && d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
-      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual))) {
+      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) && !px) {
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
@@ -960,14 +990,17 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
   a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;
   a.partial = nullptr;
   if (pl.splits > 1) {
-    const size_t need = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
+    const size_t one = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
+    const size_t need = px ? 2 * one : one;
     DS_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && aligned16(out), DIFFSAL_E_ARG,
                "conv_igemm: split-K needs %zu bytes of 16-byte aligned workspace (diffsal_conv_igemm_ws_bytes), got %zu",
                need, ws_bytes);
     a.partial = static_cast<float*>(ws);
+    a.partial2 = px ? a.partial + one / sizeof(float) : nullptr;
   }
   a.vec_epilogue = d->Cout % 4 == 0 && aligned16(out) && (!residual || aligned16(residual)) && (!bias || aligned16(bias)) &&
                    (!scale || (aligned16(scale) && aligned16(shift))) && (!rowvec || (aligned16(rowvec) && a.rowvec_ld % 4 == 0));
+  if (px) a.vec_epilogue = a.vec_epilogue && aligned16(px->out2) && (!px->bias2 || aligned16(px->bias2));
   a.persist_wgs = kCUs * kCfgs[pl.cfg].occ;
   if (const char* e = getenv("DIFFSAL_NO_PERSIST")) { if (e[0] == '1') a.persist_wgs = 0; }
   switch (pl.cfg) {
@@ -978,4 +1011,24 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
     case 4: return launch<2, 2, 2, 1>(a, s, d->precision);
     default: return launch<2, 2, 1, 1>(a, s, d->precision);
   }
+}
+
+extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, const void* w_v,
+                                  const float* bias, const float* scale, const float* shift,
+                                  const float* rowvec, const void* residual_v, void* out_v, void* ws,
+                                  size_t ws_bytes, diffsal_stream_t stream) {
+  return conv_igemm_impl(d, in_v, w_v, bias, scale, shift, rowvec, residual_v, out_v, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int diffsal_linear_pair(const diffsal_conv_desc* d, const void* in0, const void* in1, const void* w0, const void* w1,
+                                   const float* bias0, const float* bias1, void* out0, void* out1, void* ws, size_t ws_bytes,
+                                   diffsal_stream_t stream) {
+  DS_REQUIRE(d && in0 && in1 && w0 && w1 && out0 && out1, DIFFSAL_E_ARG, "linear_pair: null argument");
+  DS_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
+                 d->Ho == d->H && d->Wo == d->W && d->act == DIFFSAL_ACT_NONE && d->w_format == 0 && d->precision == DIFFSAL_PREC_FP32,
+             DIFFSAL_E_SHAPE, "linear_pair: two plain [M,K] x [K,N] products of one shape (1x1, no activation, exact arithmetic)");
+  DS_REQUIRE((bias0 == nullptr) == (bias1 == nullptr), DIFFSAL_E_ARG, "linear_pair: both products carry a bias or neither does");
+  DS_REQUIRE(aligned16(in1) && aligned16(w1), DIFFSAL_E_ALIGN, "linear_pair: in/w must be 16-byte aligned");
+  const PairExtra px{in1, w1, bias1, out1};
+  return conv_igemm_impl(d, in0, w0, bias0, nullptr, nullptr, nullptr, nullptr, out0, ws, ws_bytes, stream, &px);
 }

@@ -59,7 +59,19 @@ struct Igemm16Args {
   int vec_epilogue;          // 1: Cout % 4 == 0 and every epilogue pointer is aligned for 8 / 16-byte pieces
   int persist_wgs;           // > 0: workgroups of the persistent linear kernel (256 CUs x residents of the tile shape)
   float* partial;            // [splits][M][Cout] fp32 partial sums when splits > 1
+  // pair launch (diffsal_linear_pair): a second problem of the same shape in the same grid (blockIdx.z = 1)
+  int pair;
+  const T* in2;
+  const T* w2;
+  const float* bias2;
+  T* out2;
+  float* partial2;
 };
+
+template <typename T>
+__device__ __forceinline__ void select_pair16(Igemm16Args<T>& p, int which) {
+  if (p.pair && which) { p.in = p.in2; p.w = p.w2; p.bias = p.bias2; p.out = p.out2; p.partial = p.partial2; }
+}
 
 constexpr int SUBK = 32;            // elements per sub-slice (one 64-byte run of a pixel)
 constexpr int STK = 2 * SUBK;       // elements per LDS stage row
@@ -67,6 +79,7 @@ constexpr int PITCH16 = 36;         // dwords per LDS row (32 data + 4 pad)
 
 template <int WM, int WN, int TM, int TN, typename T>
 __global__ __launch_bounds__(256) void igemm16_kernel(Igemm16Args<T> p) {
+  select_pair16(p, blockIdx.z);
   typedef typename Mma16<T>::vec frag_t;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -568,6 +581,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm16_linear_ke
 // Sum the fp32 split-K slabs in a fixed order, apply the epilogue, round once to the storage type.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk16_reduce_kernel(Igemm16Args<T> p) {
+  select_pair16(p, blockIdx.y);
   const int n4 = p.Cout >> 2;
   const long total = static_cast<long>(p.M) * n4;
   const long slab = static_cast<long>(p.M) * p.Cout;
@@ -647,20 +661,21 @@ static int launch16(Igemm16Args<T>& a, hipStream_t s) {
   a.n_tiles_n = (a.Cout + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   a.n_tiles = a.n_tiles_n * tiles_m;
-  if (a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0) {   // plain product: persistent workgroups
+  const unsigned nz = a.pair ? 2u : 1u;
+  if (a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0 && !a.pair) {   // plain product: persistent workgroups
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
     const char* e_xcd = getenv("DIFFSAL_NO_XCD_ORDER");
     a.xcd_order = (!(e_xcd && e_xcd[0] == '1') && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm16_linear_kernel<WM, WN, TM, TN, T>), dim3(grid), dim3(256), 0, s, a);
     return check_launch("diffsal_conv_igemm(16-bit linear)");
   }
-  hipLaunchKernelGGL((igemm16_kernel<WM, WN, TM, TN, T>), dim3(a.n_tiles, a.splits), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((igemm16_kernel<WM, WN, TM, TN, T>), dim3(a.n_tiles, a.splits, nz), dim3(256), 0, s, a);
   int rc = check_launch("diffsal_conv_igemm(16-bit)");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
   long g = (total4 + 255) / 256;
   g = g > 2048 ? 2048 : g;
-  hipLaunchKernelGGL((splitk16_reduce_kernel<T>), dim3(static_cast<int>(g)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((splitk16_reduce_kernel<T>), dim3(static_cast<int>(g), nz), dim3(256), 0, s, a);
   return check_launch("diffsal_conv_igemm(16-bit split-K reduce)");
 }
 
@@ -692,10 +707,13 @@ size_t igemm16_ws_bytes(const diffsal_conv_desc* d) {
 template <typename T>
 static int run16(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                  const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
-                 hipStream_t s) {
+                 hipStream_t s, const void* in2, const void* w2, const float* bias2, void* out2) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   Igemm16Args<T> a;
   a.xcd_order = 0;
+  a.pair = in2 ? 1 : 0;
+  a.in2 = static_cast<const T*>(in2); a.w2 = static_cast<const T*>(w2); a.bias2 = bias2; a.out2 = static_cast<T*>(out2);
+  a.partial2 = nullptr;
   a.in = static_cast<const T*>(in); a.w = static_cast<const T*>(w); a.bias = bias; a.scale = scale; a.shift = shift;
   a.rowvec = rowvec; a.residual = static_cast<const T*>(residual); a.out = static_cast<T*>(out);
   a.M = static_cast<int>(M);
@@ -713,18 +731,20 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
   a.st_per_split = (n_stages + pl.splits - 1) / pl.splits;
   a.partial = nullptr;
   if (pl.splits > 1) {
-    const size_t need = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
+    const size_t one = static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float);
+    const size_t need = in2 ? 2 * one : one;
     DS_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
                    (!residual || (reinterpret_cast<uintptr_t>(residual) & 7u) == 0),
                DIFFSAL_E_ARG,
                "conv_igemm(16-bit): split-K needs %zu bytes of 16-byte aligned workspace (diffsal_conv_igemm_ws_bytes), got %zu",
                need, ws_bytes);
     a.partial = static_cast<float*>(ws);
+    a.partial2 = in2 ? a.partial + one / sizeof(float) : nullptr;
   }
   {
     auto al = [](const void* q, uintptr_t m) { return (reinterpret_cast<uintptr_t>(q) & m) == 0; };
     a.vec_epilogue = d->Cout % 4 == 0 && al(out, 7) && al(residual, 7) && al(bias, 15) && al(scale, 15) && al(shift, 15) &&
-                     al(rowvec, 15) && (!rowvec || a.rowvec_ld % 4 == 0) && al(a.partial, 15);
+                     al(rowvec, 15) && (!rowvec || a.rowvec_ld % 4 == 0) && al(a.partial, 15) && al(out2, 7) && al(bias2, 15);
   }
   a.persist_wgs = kCUs16 * kCfgs16[pl.cfg].occ;
   if (const char* e = getenv("DIFFSAL_NO_PERSIST")) { if (e[0] == '1') a.persist_wgs = 0; }
@@ -742,12 +762,12 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
 
 int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                    const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
-                   hipStream_t s) {
-  if (conv16_halo_applies(d) && conv16_halo_pointers_ok(d, bias, scale, shift, rowvec, residual, out))
+                   hipStream_t s, const void* in2, const void* w2, const float* bias2, void* out2) {
+  if (!in2 && conv16_halo_applies(d) && conv16_halo_pointers_ok(d, bias, scale, shift, rowvec, residual, out))
     return conv16_halo_launch(d, in, w, bias, scale, shift, rowvec, residual, out, s);
   if (d->dtype == DIFFSAL_BF16)
-    return run16<__bf16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s);
-  return run16<_Float16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s);
+    return run16<__bf16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s, in2, w2, bias2, out2);
+  return run16<_Float16>(d, in, w, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, s, in2, w2, bias2, out2);
 }
 
 }  // namespace diffsal

@@ -11,7 +11,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -366,6 +366,31 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = AC
     y = conv_igemm(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, tag=tag,
                    residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
     return y.reshape(*lead, w.shape[0])
+
+
+def linear_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Optional[Tensor], b1: Optional[Tensor],
+                tag: str = "K10") -> Tuple[Tensor, Tensor]:
+    """Two token GEMMs of one shape in one launch: (x0 @ w0^T + b0, x1 @ w1^T + b1); x_i [..., K], w_i [N, K] (exact
+    arithmetic or 16-bit storage; not the pre-split bf16x3 weight format)."""
+    lib = _lib.load()
+    if x0.shape != x1.shape or w0.shape != w1.shape or x0.dtype != x1.dtype or (b0 is None) != (b1 is None):
+        raise RuntimeError("linear_pair: the two products must have one shape and storage type")
+    lead, K = x0.shape[:-1], x0.shape[-1]
+    M = 1
+    for s_ in lead:
+        M *= s_
+    N = w0.shape[0]
+    dt = _dt(x0)
+    d = ConvDesc(1, 1, M, K, 1, M, N, 1, 1, 1, 1, 0, 0, 1, 1, ACT_NONE, 0, 0, _lib.PREC_FP32, dt)
+    y0 = torch.empty((*lead, N), device=x0.device, dtype=x0.dtype)
+    y1 = torch.empty_like(y0)
+    ws_bytes = 2 * lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
+    ws = torch.empty((ws_bytes // 4,), device=x0.device, dtype=torch.float32) if ws_bytes else None
+    x0c, x1c = x0.contiguous(), x1.contiguous()
+    with _prof(tag, 4.0 * M * K * N, _nb(x0c, x1c, w0, w1, y0, y1), f"2 x (M={M} K={K} N={N}) 1x1 pair"):
+        _lib.check(lib.diffsal_linear_pair(C.byref(d), _pa(x0c, dt), _pa(x1c, dt), _pa(w0, dt), _pa(w1, dt), _p(b0), _p(b1),
+                                           y0.data_ptr(), y1.data_ptr(), _p(ws), ws_bytes, _stream()), "linear_pair")
+    return y0, y1
 
 
 def pack_frames(vis: Tensor, noise: Optional[Tensor], t_out: Optional[int] = None,

@@ -379,8 +379,12 @@ class SalUNet(nn.Module):
                                   a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
                                   a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
         q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
-        kk = ops.linear(kk, pk[f"s{i}.k.w"], a.proj_k.bias)
-        vv = ops.linear(vv, pk[f"s{i}.v.w"], a.proj_v.bias)
+        if self.pair_kv and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and (
+                self.compute_dtype != torch.float32 or ops.get_gemm_precision() == "fp32"):
+            kk, vv = ops.linear_pair(kk, vv, pk[f"s{i}.k.w"], pk[f"s{i}.v.w"], a.proj_k.bias, a.proj_v.bias)   # one launch
+        else:
+            kk = ops.linear(kk, pk[f"s{i}.k.w"], a.proj_k.bias)
+            vv = ops.linear(vv, pk[f"s{i}.v.w"], a.proj_v.bias)
         o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
         xt = x.view(n9, H * W, C)
         if C == 96 and blk.mlp.fc1.out_features == 192 and x.dtype != torch.float32:
@@ -411,6 +415,7 @@ class SalUNet(nn.Module):
     # as nine 1x1 tap mixings at the SOURCE resolution (one GEMM, 4x / 3x fewer FLOPs) + a gather of the interpolated taps
     # (ops.tapsum, csrc/tapsum.hip).  Exact up to summation order; off when intermediate taps are requested.
     tap_conv = True
+    pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
     # step (1720 -> 1779 steps/s; "s3" and "mt" lose), but the nine tap products are rounded to 16 bits before they are summed
     # and the worst bf16 fixture error moves from 2.2e-2 to 2.9e-2 against a 3e-2 bar.

@@ -139,6 +139,14 @@ size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const void* in, const void* w,
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
                        const void* residual, void* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
+/* Two plain products of ONE shape in one launch (grid z = 2): out_i [M,N] = in_i [M,K] x w_i [N,K]^T + bias_i.  The key and value
+ * projections of a transformer block (attention.py:78-83: proj_k / proj_v on the 648 pooled tokens of a stage) are 8-26 us
+ * launches at their latency floor; paired they are four launches per step instead of eight.  d: a 1x1 descriptor (KH = KW = 1,
+ * act NONE, exact arithmetic, any storage type); ws: 2 x diffsal_conv_igemm_ws_bytes(d) bytes. */
+int diffsal_linear_pair(const diffsal_conv_desc* d, const void* in0, const void* in1, const void* w0, const void* w1,
+                        const float* bias0, const float* bias1, void* out0, void* out1, void* ws, size_t ws_bytes,
+                        diffsal_stream_t stream);
+
 
 /* ---- weight layout transforms (w: the reference's parameter layout [Cout][Cin][taps], taps = KH*KW or KT):
  *   mode 0: dst[co][(ci/32, tap, ci%32)] = w[co][ci][tap]            -- the `w` argument of diffsal_conv_igemm

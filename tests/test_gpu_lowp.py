@@ -389,3 +389,19 @@ def test_persistent_linear_kernel_16bit(ops, dname, cfg, monkeypatch):
         assert torch.equal(plain, per), (M, K, N)
         ref = F.gelu(x.float() @ w.float().t() + b) + r.float()
         assert rel_err(per, ref) < OP_RTOL[dname]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("M,K,N", [(648, 768, 768), (648, 96, 96), (650, 384, 384), (70, 64, 36)])
+def test_linear_pair_16bit_equals_two_launches(ops, dname, M, K, N, monkeypatch):
+    """diffsal_linear_pair on 16-bit storage == the two single launches bit for bit."""
+    dt = DTYPES[dname]
+    monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+    x0 = q(rnd("q0x%d" % K, M, K), dt).to(DEV).to(dt)
+    x1 = q(rnd("q1x%d" % K, M, K), dt).to(DEV).to(dt)
+    w0 = q(rnd("q0w%d" % N, N, K, scale=1.0 / math.sqrt(K)), dt).to(DEV).to(dt)
+    w1 = q(rnd("q1w%d" % N, N, K, scale=1.0 / math.sqrt(K)), dt).to(DEV).to(dt)
+    b0, b1 = rnd("q0b", N, scale=0.1).to(DEV), rnd("q1b", N, scale=0.1).to(DEV)
+    y0, y1 = ops.linear_pair(x0, x1, w0, w1, b0, b1)
+    assert torch.equal(y0, ops.linear(x0, w0, b0)) and torch.equal(y1, ops.linear(x1, w1, b1))
+    assert rel_err(y1, x1.float() @ w1.float().t() + b1) < OP_RTOL[dname]

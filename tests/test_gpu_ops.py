@@ -98,6 +98,20 @@ def test_linear_matches_torch(ops, M, K, N, act):
     assert rel_err(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(648, 768, 768), (648, 96, 96), (650, 384, 384), (3024, 192, 200), (70, 64, 36)])
+def test_linear_pair_equals_two_launches(ops, M, K, N, monkeypatch):
+    """diffsal_linear_pair (key and value projections in one grid, z = 2) == the two single launches bit for bit (same tile
+    plan, same split-K order), with and without bias, ragged M / N."""
+    monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")     # the single launches on the same one-tile kernel the pair uses
+    x0, x1 = rnd("p0x%d" % K, 2, M // 2, K).to(DEV), rnd("p1x%d" % K, 2, M // 2, K).to(DEV)
+    w0, w1 = rnd("p0w%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("p1w%d" % N, N, K, scale=K ** -0.5).to(DEV)
+    b0, b1 = rnd("p0b", N, scale=0.1).to(DEV), rnd("p1b", N, scale=0.1).to(DEV)
+    for bias in ((b0, b1), (None, None)):
+        y0, y1 = ops.linear_pair(x0, x1, w0, w1, bias[0], bias[1])
+        assert torch.equal(y0, ops.linear(x0, w0, bias[0])) and torch.equal(y1, ops.linear(x1, w1, bias[1]))
+        assert rel_err(y1, F.linear(x1, w1, bias[1])) < 2e-5
+
+
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
 def test_persistent_linear_kernel_fp32(ops, cfg, monkeypatch):
     """igemm_linear_kernel (persistent workgroups, prefetch across tile boundaries, register-direct stores) == the one-tile
