@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 SIGNATURES = {
@@ -77,6 +77,7 @@ SIGNATURES = {
     "diffsal_dense_small_bwd": (c_i, [c_f] * 6 + [c_i] * 4 + [c_f]),
     "diffsal_audio_fuse_bwd": (c_i, [c_f] * 5 + [c_i] * 7 + [c_f]),
     "diffsal_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_pack_frames_multi": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_audio_fuse": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),

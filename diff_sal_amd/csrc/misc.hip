@@ -119,14 +119,12 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 // vis [B][C][Q], Q = Tv*hw  ->  out [B][Tout*hw][C] (first Q rows); noise [B][hw][C] -> rows Tv*hw...
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restrict__ vis, const T* __restrict__ noise,
-                                                          T* __restrict__ out, int C, int Q, int hw, int Tout,
-                                                          int tiles_q, int tiles_c, int n_transpose_blocks) {
-  __shared__ float tile[64][65];
-  const int b = blockIdx.y;
+__device__ __forceinline__ void pack_frames_body(const float* __restrict__ vis, const T* __restrict__ noise, T* __restrict__ out,
+                                                 int C, int Q, int hw, int Tout, int tiles_q, int n_transpose_blocks, int bx,
+                                                 int n_blocks, int b, float (*tile)[65]) {
   const long out_b = static_cast<long>(b) * Tout * hw * C;
-  if (static_cast<int>(blockIdx.x) < n_transpose_blocks) {
-    const int tq = blockIdx.x % tiles_q, tcx = blockIdx.x / tiles_q;
+  if (bx < n_transpose_blocks) {
+    const int tq = bx % tiles_q, tcx = bx / tiles_q;
     const int q0 = tq * 64, c0 = tcx * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float* src = vis + static_cast<long>(b) * C * Q;
@@ -140,14 +138,41 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restric
       if (q < Q && c < C) out[out_b + static_cast<long>(q) * C + c] = static_cast<T>(tile[tx][r]);
     }
   } else if (noise) {
-    const int nb = gridDim.x - n_transpose_blocks;
+    const int nb = n_blocks - n_transpose_blocks;
     const long n4 = static_cast<long>(hw) * C / 4;
     const T* src = noise + static_cast<long>(b) * hw * C;
     T* dst = out + out_b + static_cast<long>(Q) * C;
-    for (long i = static_cast<long>(blockIdx.x - n_transpose_blocks) * 256 + threadIdx.x; i < n4;
-         i += static_cast<long>(nb) * 256)
+    for (long i = static_cast<long>(bx - n_transpose_blocks) * 256 + threadIdx.x; i < n4; i += static_cast<long>(nb) * 256)
       st4(dst + i * 4, ld4(src + i * 4));
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restrict__ vis, const T* __restrict__ noise,
+                                                          T* __restrict__ out, int C, int Q, int hw, int Tout,
+                                                          int tiles_q, int tiles_c, int n_transpose_blocks) {
+  __shared__ float tile[64][65];
+  (void)tiles_c;
+  pack_frames_body<T>(vis, noise, out, C, Q, hw, Tout, tiles_q, n_transpose_blocks, blockIdx.x, gridDim.x, blockIdx.y, tile);
+}
+
+// The frame tensors of all decoder stages in ONE launch (the three per-stage launches are 16-21 us each, mostly launch
+// latency): blockIdx.x runs through the problems' block ranges.
+struct PackMulti {
+  const float* vis[4];
+  const void* noise[4];
+  void* out[4];
+  int C[4], Q[4], hw[4], Tout[4], tiles_q[4], ntb[4], blocks[4];
+  int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frames_multi_kernel(PackMulti m) {
+  __shared__ float tile[64][65];
+  int bx = blockIdx.x, j = 0;
+  while (j + 1 < m.n && bx >= m.blocks[j]) { bx -= m.blocks[j]; ++j; }
+  pack_frames_body<T>(m.vis[j], static_cast<const T*>(m.noise[j]), static_cast<T*>(m.out[j]), m.C[j], m.Q[j], m.hw[j], m.Tout[j],
+                      m.tiles_q[j], m.ntb[j], bx, m.blocks[j], blockIdx.y, tile);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -605,7 +630,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 11; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 12; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
@@ -672,6 +697,36 @@ extern "C" int diffsal_pack_frames(const float* vis, const void* noise, void* ou
   DS_DTYPE_DISPATCH(dtype, "pack_frames", CALL);
 #undef CALL
   return check_launch("pack_frames");
+}
+
+extern "C" int diffsal_pack_frames_multi(const float* const* vis, const void* const* noise, void* const* out, int n, int B,
+                                         const int* C, const int* Tv, const int* Tout, const int* hw, int dtype,
+                                         diffsal_stream_t stream) {
+  DS_REQUIRE(vis && noise && out && C && Tv && Tout && hw, DIFFSAL_E_ARG, "pack_frames_multi: null argument");
+  DS_REQUIRE(n >= 1 && n <= 4 && B > 0, DIFFSAL_E_SHAPE, "pack_frames_multi: 1..4 problems, got %d", n);
+  PackMulti m;
+  m.n = n;
+  long total = 0;
+  for (int j = 0; j < 4; ++j) {
+    const int jj = j < n ? j : 0;
+    DS_REQUIRE(vis[jj] && out[jj], DIFFSAL_E_ARG, "pack_frames_multi: null tensor %d", jj);
+    DS_REQUIRE(C[jj] > 0 && C[jj] % 4 == 0 && Tv[jj] > 0 && hw[jj] > 0 && Tout[jj] >= Tv[jj] + (noise[jj] ? 1 : 0), DIFFSAL_E_SHAPE,
+               "pack_frames_multi: bad shape C=%d Tv=%d Tout=%d hw=%d", C[jj], Tv[jj], Tout[jj], hw[jj]);
+    DS_REQUIRE(aligned16(out[jj]) && (!noise[jj] || aligned16(noise[jj])), DIFFSAL_E_ALIGN, "pack_frames_multi: misaligned pointer");
+    m.vis[j] = vis[jj]; m.noise[j] = noise[jj]; m.out[j] = out[jj];
+    m.C[j] = C[jj]; m.Q[j] = Tv[jj] * hw[jj]; m.hw[j] = hw[jj]; m.Tout[j] = Tout[jj];
+    m.tiles_q[j] = (m.Q[j] + 63) / 64;
+    m.ntb[j] = m.tiles_q[j] * ((C[jj] + 63) / 64);
+    m.blocks[j] = m.ntb[j] + (noise[jj] ? ew_grid(static_cast<long>(hw[jj]) * C[jj] / 4) : 0);
+    if (j < n) total += m.blocks[j];
+  }
+  DS_REQUIRE(total < (1L << 31), DIFFSAL_E_SHAPE, "pack_frames_multi: too many blocks");
+#define CALL(T)                                                                                                        \
+  hipLaunchKernelGGL((pack_frames_multi_kernel<T>), dim3(static_cast<unsigned>(total), B), dim3(256), 0,              \
+                     static_cast<hipStream_t>(stream), m)
+  DS_DTYPE_DISPATCH(dtype, "pack_frames_multi", CALL);
+#undef CALL
+  return check_launch("pack_frames_multi");
 }
 
 template <typename T>

@@ -409,6 +409,29 @@ def pack_frames(vis: Tensor, noise: Optional[Tensor], t_out: Optional[int] = Non
     return out
 
 
+def pack_frames_multi(vis: Sequence[Tensor], noise: Sequence[Optional[Tensor]], out_dtype: torch.dtype) -> list:
+    """K6 for several stages in one launch: vis[j] [B,C_j,Tv,h_j,w_j] (fp32) + noise[j] [B,h_j,w_j,C_j] or None ->
+    [B,Tv+1 (or Tv),h_j,w_j,C_j] each, all in ``out_dtype`` (the noise maps must already have that type)."""
+    lib = _lib.load()
+    n = len(vis)
+    B = vis[0].shape[0]
+    outs, Cs, Tvs, Touts, hws = [], [], [], [], []
+    for v, nz in zip(vis, noise):
+        b, Cc, Tv, h, w = v.shape
+        if b != B or v.dtype != torch.float32 or not v.is_contiguous() or (nz is not None and (nz.dtype != out_dtype or not nz.is_contiguous())):
+            raise RuntimeError("pack_frames_multi: one batch size, contiguous fp32 features, noise maps in the output type")
+        Tout = Tv + (1 if nz is not None else 0)
+        outs.append(torch.empty((B, Tout, h, w, Cc), device=v.device, dtype=out_dtype))
+        Cs.append(Cc); Tvs.append(Tv); Touts.append(Tout); hws.append(h * w)
+    dt = _dt(outs[0])
+    arr = lambda xs: (C.c_void_p * n)(*[None if x is None else x.data_ptr() for x in xs])
+    ints = lambda xs: (C.c_int * n)(*xs)
+    with _prof("K6", 0.0, sum(_nb(v, nz, o) for v, nz, o in zip(vis, noise, outs))):
+        _lib.check(lib.diffsal_pack_frames_multi(arr(vis), arr(noise), arr(outs), n, B, ints(Cs), ints(Tvs), ints(Touts), ints(hws),
+                                                 dt, _stream()), "pack_frames_multi")
+    return outs
+
+
 def resize_bilinear(x: Tensor, H: int, W: int, tag: str = "K12-up") -> Tensor:
     lib = _lib.load()
     N, h, w, Cc = x.shape

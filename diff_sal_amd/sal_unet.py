@@ -481,17 +481,23 @@ class SalUNet(nn.Module):
         dec = self.invpt_decoder
 
         noise = self._noise_encoder(x, t, pk, taps)
-        frames: List[Optional[Tensor]] = []
-        for i in range(ns):
+        frames: List[Optional[Tensor]] = [None] * ns
+        todo = []
+        for i in range(min(ns, 3)):       # stage-3 features are never read by the decoder (quirk Q2): skip their transpose
             f = feat_list[i].contiguous().float() if i < len(feat_list) else None
             if f is None:
-                frames.append(None)
                 continue
             nz = None
             if self.image_based and i < len(noise) and tuple(f.shape[-2:]) == tuple(noise[i].shape[1:3]):
                 nz = noise[i]
-            # stage-3 features are never read by the decoder (quirk Q2): skip their transpose
-            frames.append(ops.pack_frames(f, nz, out_dtype=cdt) if i < 3 else None)
+            todo.append((i, f, nz))
+        if len(todo) > 1 and all(nz is None or nz.dtype == cdt for _, _, nz in todo):
+            outs = ops.pack_frames_multi([f for _, f, _ in todo], [nz for _, _, nz in todo], cdt)    # all stages, one launch
+            for (i, _, _), o in zip(todo, outs):
+                frames[i] = o
+        else:
+            for i, f, nz in todo:
+                frames[i] = ops.pack_frames(f, nz, out_dtype=cdt)
         if taps is not None:
             for i, nzt in enumerate(noise):
                 taps[f"noise{i}"] = nzt

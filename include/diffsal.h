@@ -286,6 +286,11 @@ int diffsal_audio_fuse_bwd(const float* a_small, const float* x, const float* do
  * transformer.py:273-279. noise may be NULL (then only Tv frames of a [B,Tout,...] buffer are written). */
 int diffsal_pack_frames(const float* vis /*fp32: the module's input contract*/, const void* noise, void* out, int B,
                         int C, int Tv, int Tout, int hw, int dtype, diffsal_stream_t stream);
+/* The same for up to four (vis, noise, out) triples of one batch size and storage type in ONE launch: the frame tensors of all
+ * decoder stages (sal_unet.py:414-441 builds them stage by stage). */
+int diffsal_pack_frames_multi(const float* const* vis, const void* const* noise, void* const* out, int n, int B, const int* C,
+                              const int* Tv, const int* Tout, const int* hw, int dtype, diffsal_stream_t stream);
+
 
 /* ---- bilinear resize, align_corners=False, NHWC ----------------------------------------
  * R/.../common_block.py:197 (nn.Upsample x2), sal_unet.py:325-327. */

@@ -284,6 +284,18 @@ def test_pack_frames(ops):
     assert torch.equal(got2, vis.permute(0, 2, 3, 4, 1).contiguous())
 
 
+def test_pack_frames_multi_equals_per_stage_launches(ops):
+    """The frame tensors of several stages in one launch == one pack_frames per stage (pure data movement: exact)."""
+    B, Tv = 2, 8
+    shapes = ((768, 7, 12), (384, 14, 24), (100, 5, 9))          # the last: channels not a multiple of 64, ragged token tiles
+    vis = [rnd("pmv%d" % c, B, c, Tv, h, w).to(DEV) for c, h, w in shapes]
+    nzs = [rnd("pmn%d" % c, B, h, w, c).to(DEV) for c, h, w in shapes]
+    for noise in (nzs, [nzs[0], None, nzs[2]], [None, None, None]):
+        outs = ops.pack_frames_multi(vis, noise, torch.float32)
+        for v, nz, o in zip(vis, noise, outs):
+            assert torch.equal(o, ops.pack_frames(v, nz))
+
+
 @pytest.mark.parametrize("hw,HW,C", [((7, 12), (14, 24), 96), ((7, 12), (112, 192), 32), ((112, 192), (224, 384), 1), ((5, 9), (10, 18), 6)])
 def test_resize_bilinear(ops, hw, HW, C):
     x = rnd("rs", 2, C, *hw)
