@@ -169,14 +169,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 // depthwise 3x3 (pad 1, stride 1) + LayerNorm.  R/.../attention.py:36-47,94 (quirk Q8: centre slice)
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(256) void dwconv3_ln_kernel(const T* __restrict__ x, const float* __restrict__ w9,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         T* __restrict__ out, int N, int H, int W, int C, float eps) {
+__device__ __forceinline__ void dwconv3_ln_body(const T* __restrict__ x, const float* __restrict__ w9,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                T* __restrict__ out, int N, int H, int W, int C, float eps, int bx, int nb) {
   constexpr int ROWS = 256 / G;
   const int gl = threadIdx.x % G;
   const int gr = threadIdx.x / G;
   const long M = static_cast<long>(N) * H * W;
-  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < M; row += static_cast<long>(gridDim.x) * ROWS) {
+  for (long row = static_cast<long>(bx) * ROWS + gr; row < M; row += static_cast<long>(nb) * ROWS) {
     const int xw = static_cast<int>(row % W);
     const int yh = static_cast<int>((row / W) % H);
     float4 v[NV];
@@ -209,14 +209,21 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(const T* __restrict__ x
   }
 }
 
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(256) void dwconv3_ln_kernel(const T* __restrict__ x, const float* __restrict__ w9,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ out, int N, int H, int W, int C, float eps) {
+  dwconv3_ln_body<G, NV, T>(x, w9, gamma, beta, out, N, H, W, C, eps, blockIdx.x, gridDim.x);
+}
+
 // Strip form of the kernel above for C <= 4 G (one float4 per lane): a lane group walks SEG output pixels along a row
 // with a sliding 3x3 window in registers -- 3 new 16-byte loads per output instead of 9, and the nine weight vectors are
 // loaded once per thread instead of once per output (18 -> ~4 vector loads per output: the kernel was bound by L1
 // request rate, not by HBM).
 template <int G, int SEG, typename T>
-__global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restrict__ x, const float* __restrict__ w9,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               T* __restrict__ out, int N, int H, int W, int C, float eps) {
+__device__ __forceinline__ void dwconv3_ln_strip_body(const T* __restrict__ x, const float* __restrict__ w9,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      T* __restrict__ out, int N, int H, int W, int C, float eps, int bx, int nb) {
   constexpr int GROUPS = 256 / G;
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   const int c = gl * 4;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restri
   const int strips_w = (W + SEG - 1) / SEG;
   const long n_strips = static_cast<long>(N) * H * strips_w;
   const float4 zero = make_float4(0, 0, 0, 0);
-  for (long sidx = static_cast<long>(blockIdx.x) * GROUPS + gr; sidx < n_strips; sidx += static_cast<long>(gridDim.x) * GROUPS) {
+  for (long sidx = static_cast<long>(bx) * GROUPS + gr; sidx < n_strips; sidx += static_cast<long>(nb) * GROUPS) {
     const int xs = static_cast<int>(sidx % strips_w) * SEG;
     const long ny = sidx / strips_w;
     const int y = static_cast<int>(ny % H);
@@ -267,20 +274,27 @@ __global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restri
   }
 }
 
+template <int G, int SEG, typename T>
+__global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restrict__ x, const float* __restrict__ w9,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ out, int N, int H, int W, int C, float eps) {
+  dwconv3_ln_strip_body<G, SEG, T>(x, w9, gamma, beta, out, N, H, W, C, eps, blockIdx.x, gridDim.x);
+}
+
 // depthwise k x k, stride k, no padding, + LayerNorm, for K and V at once: one workgroup per pooled token.
 // R/.../attention.py:49-76,88-95.  Threads = (256/G position lanes) x (G channel lanes).
 template <int G, int NV, typename T>
-__global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const T* __restrict__ xk, const T* __restrict__ xv,
-                                                           const float* __restrict__ wk, const float* __restrict__ wv,
-                                                           const float* __restrict__ gk, const float* __restrict__ bk,
-                                                           const float* __restrict__ gv, const float* __restrict__ bv,
-                                                           T* __restrict__ ok, T* __restrict__ ov, int H, int W,
-                                                           int C, int k, int gh, int gw, float eps) {
+__device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, const T* __restrict__ xv,
+                                                  const float* __restrict__ wk, const float* __restrict__ wv,
+                                                  const float* __restrict__ gk, const float* __restrict__ bk,
+                                                  const float* __restrict__ gv, const float* __restrict__ bv,
+                                                  T* __restrict__ ok, T* __restrict__ ov, int H, int W,
+                                                  int C, int k, int gh, int gw, float eps, int tok) {
   constexpr int PL = 256 / G;
   extern __shared__ float shp[];  // [2][PL][C]
   const int gl = threadIdx.x % G;
   const int pl = threadIdx.x / G;
-  const int tok = blockIdx.x;  // n * gh*gw + gy*gw + gx
+  // tok = n * gh*gw + gy*gw + gx
   const int n = tok / (gh * gw);
   const int g = tok - n * gh * gw;
   const int gy = g / gw, gx = g - gy * gw;
@@ -329,6 +343,41 @@ __global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const T* __restrict__
     }
     if (pl == 0) ln_rows_finish<G, NV, T>(v, gl, C, gk, bk, eps, ok + static_cast<long>(tok) * C);
     else ln_rows_finish<G, NV, T>(v, gl, C, gv, bv, eps, ov + static_cast<long>(tok) * C);
+  }
+}
+
+template <int G, int NV, typename T>
+__global__ __launch_bounds__(256) void dwpool_ln_kv_kernel(const T* __restrict__ xk, const T* __restrict__ xv,
+                                                           const float* __restrict__ wk, const float* __restrict__ wv,
+                                                           const float* __restrict__ gk, const float* __restrict__ bk,
+                                                           const float* __restrict__ gv, const float* __restrict__ bv,
+                                                           T* __restrict__ ok, T* __restrict__ ov, int H, int W,
+                                                           int C, int k, int gh, int gw, float eps) {
+  dwpool_ln_kv_body<G, NV, T>(xk, xv, wk, wv, gk, bk, gv, bv, ok, ov, H, W, C, k, gh, gw, eps, blockIdx.x);
+}
+
+// The query branch (depthwise 3x3 + LayerNorm on every token) and the pooled key / value branch of a transformer block read
+// the same normalised frames and do not depend on each other: one grid, the first nq workgroups run the query body, the
+// rest one pooled token each.  (Two launches of 10-60 us, mostly latency at the coarse stages, become one.)
+struct QkvPrepArgs {
+  const void* xq; const float* w9; const float* gq; const float* bq; void* oq;
+  const void* xk; const void* xv; const float* wk; const float* wv;
+  const float* gk; const float* bk; const float* gv; const float* bv; void* ok; void* ov;
+  int N, H, W, C, k, gh, gw, nq;
+  float eps;
+};
+
+template <bool STRIP, int G, int NV, typename T>
+__global__ __launch_bounds__(256) void qkv_prep_kernel(QkvPrepArgs a) {
+  const int b = blockIdx.x;
+  if (b < a.nq) {
+    if constexpr (STRIP)
+      dwconv3_ln_strip_body<G, 8, T>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W, a.C, a.eps, b, a.nq);
+    else
+      dwconv3_ln_body<G, NV, T>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W, a.C, a.eps, b, a.nq);
+  } else {
+    dwpool_ln_kv_body<G, NV, T>(static_cast<const T*>(a.xk), static_cast<const T*>(a.xv), a.wk, a.wv, a.gk, a.bk, a.gv, a.bv,
+                                static_cast<T*>(a.ok), static_cast<T*>(a.ov), a.H, a.W, a.C, a.k, a.gh, a.gw, a.eps, b - a.nq);
   }
 }
 
@@ -488,6 +537,45 @@ extern "C" int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float*
   return dwpool_ln_kv_t<T>(static_cast<const T*>(xk), static_cast<const T*>(xv), wk, wv, gk, bk, gv, bv,          \
                            static_cast<T*>(out_k), static_cast<T*>(out_v), N, H, W, C, k, eps, s)
   DS_DTYPE_DISPATCH(dtype, "dwpool_ln_kv", CALLT);
+#undef CALLT
+  return DIFFSAL_OK;
+}
+
+template <typename T>
+static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
+  const int nkv = a.N * a.gh * a.gw;
+  const bool strip = a.C <= 256 && a.W >= 16;
+  const size_t lds_of = 2 * a.C * sizeof(float);     // x (256 / G) position lanes
+#define CALL(G, NV)                                                                                                  \
+  do {                                                                                                               \
+    if (strip && NV == 1) {                                                                                          \
+      a.nq = row_grid(static_cast<long>(a.N) * a.H * ((a.W + 7) / 8), 256 / G);                                        \
+      hipLaunchKernelGGL((qkv_prep_kernel<true, G, 1, T>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);    \
+    } else {                                                                                                         \
+      a.nq = row_grid(static_cast<long>(a.N) * a.H * a.W, 256 / G);                                                   \
+      hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);  \
+    }                                                                                                                \
+  } while (0)
+  DS_ROW_DISPATCH(a.C, CALL);
+#undef CALL
+  return check_launch("qkv_prep");
+}
+
+extern "C" int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq, const float* bq, void* out_q, const void* xk,
+                                const void* xv, const float* wk, const float* wv, const float* gk, const float* bk,
+                                const float* gv, const float* bv, void* out_k, void* out_v, int N, int H, int W, int C, int k,
+                                float eps, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(xq && w9 && gq && bq && out_q && xk && xv && wk && wv && gk && bk && gv && bv && out_k && out_v, DIFFSAL_E_ARG,
+             "qkv_prep: null argument");
+  DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && H >= k && W >= k, DIFFSAL_E_SHAPE,
+             "qkv_prep: bad shape H=%d W=%d C=%d k=%d", H, W, C, k);
+  DS_REQUIRE(aligned16(xq) && aligned16(out_q) && aligned16(w9) && aligned16(gq) && aligned16(bq) && aligned16(xk) && aligned16(xv) &&
+                 aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v),
+             DIFFSAL_E_ALIGN, "qkv_prep: misaligned pointer");
+  QkvPrepArgs a{xq, w9, gq, bq, out_q, xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, N, H, W, C, k, (H - k) / k + 1, (W - k) / k + 1, 0, eps};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALLT(T) return qkv_prep_t<T>(a, s)
+  DS_DTYPE_DISPATCH(dtype, "qkv_prep", CALLT);
 #undef CALLT
   return DIFFSAL_OK;
 }

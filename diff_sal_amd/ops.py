@@ -540,6 +540,26 @@ def dwconv3_ln(x: Tensor, w9: Tensor, gamma: Tensor, beta: Tensor, eps: float = 
     return out
 
 
+def qkv_prep(xq: Tensor, w9: Tensor, gq: Tensor, bq: Tensor, xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor,
+             bk: Tensor, gv: Tensor, bv: Tensor, k: int, eps: float = 1e-5):
+    """``dwconv3_ln(xq, ...)`` and ``dwpool_ln_kv(xk, xv, ...)`` of one transformer block in one launch -> (q, k, v) tokens."""
+    lib = _lib.load()
+    N, H, W, Cc = xq.shape
+    if xk.shape != xq.shape or xv.shape != xq.shape or xk.dtype != xq.dtype or xv.dtype != xq.dtype:
+        raise RuntimeError("qkv_prep: the three inputs must share shape and storage type")
+    gh, gw = (H - k) // k + 1, (W - k) // k + 1
+    oq = torch.empty((N, H * W, Cc), device=xq.device, dtype=xq.dtype)
+    ok = torch.empty((N, gh * gw, Cc), device=xq.device, dtype=xq.dtype)
+    ov = torch.empty_like(ok)
+    dt = _dt(xq)
+    same = xk.data_ptr() == xv.data_ptr() == xq.data_ptr()
+    with _prof("K9", 22.0 * N * H * W * Cc, _nb(xq, oq, ok, ov) + (0.0 if same else _nb(xk))):
+        _lib.check(lib.diffsal_qkv_prep(_pa(xq, dt), _p(w9), _p(gq), _p(bq), oq.data_ptr(), _pa(xk, dt), _pa(xv, dt), _p(wk),
+                                        _p(wv), _p(gk), _p(bk), _p(gv), _p(bv), ok.data_ptr(), ov.data_ptr(), N, H, W, Cc, k,
+                                        eps, dt, _stream()), "qkv_prep")
+    return oq, ok, ov
+
+
 def dwpool_ln_kv(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tensor, gv: Tensor, bv: Tensor,
                  k: int, eps: float = 1e-5):
     lib = _lib.load()

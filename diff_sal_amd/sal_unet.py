@@ -373,11 +373,17 @@ class SalUNet(nn.Module):
         if audio_tok is not None:
             a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias, tag="K7-align")  # [B*T, ha*wa, C]
             k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
-        q = ops.dwconv3_ln(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
-                           a.conv_proj_q.bn.eps)
-        kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
-                                  a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
-                                  a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
+        if self.merge_qkv_prep and a.conv_proj_q.bn.eps == a.conv_proj_k.bn.eps and k_src.dtype == xn.dtype:
+            q, kk, vv = ops.qkv_prep(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
+                                     k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+                                     a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
+                                     a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
+        else:
+            q = ops.dwconv3_ln(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
+                               a.conv_proj_q.bn.eps)
+            kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+                                      a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
+                                      a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
         q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
         if self.pair_kv and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and (
                 self.compute_dtype != torch.float32 or ops.get_gemm_precision() == "fp32"):
@@ -415,6 +421,7 @@ class SalUNet(nn.Module):
     # as nine 1x1 tap mixings at the SOURCE resolution (one GEMM, 4x / 3x fewer FLOPs) + a gather of the interpolated taps
     # (ops.tapsum, csrc/tapsum.hip).  Exact up to summation order; off when intermediate taps are requested.
     tap_conv = True
+    merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
     # step (1720 -> 1779 steps/s; "s3" and "mt" lose), but the nine tap products are rounded to 16 bits before they are summed

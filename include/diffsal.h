@@ -324,6 +324,13 @@ int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float* wk, const 
                          const float* gk, const float* bk, const float* gv, const float* bv,
                          void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
                          diffsal_stream_t stream);
+/* diffsal_dwconv3_ln (query branch) and diffsal_dwpool_ln_kv (key / value branch) of one transformer block in ONE launch: both
+ * read the block's normalised frames and neither depends on the other (attention.py:86-95).  Same results as the two entries. */
+int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq, const float* bq, void* out_q, const void* xk,
+                     const void* xv, const float* wk, const float* wv, const float* gk, const float* bk, const float* gv,
+                     const float* bv, void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
+                     diffsal_stream_t stream);
+
 
 /* ---- K8 + K10 fused for the finest stage (C = 96, hidden = 192: both MLP weights fit in LDS):
  *   x2 = x1 + fc2(gelu_erf(fc1(LayerNorm(x1; g2, be2, eps2)) + b1)) + b2 ... i.e. transformer.py:153-157's

@@ -244,6 +244,11 @@ def test_depthwise_projections(ops, C, H, W, k):
     kk, vv = ops.dwpool_ln_kv(dv(nhwc(xa)), dv(nhwc(xn)), dv(wk.reshape(C, k * k).t().contiguous()),
                               dv(wv.reshape(C, k * k).t().contiguous()), dv(g[1]), dv(b[1]), dv(g[2]), dv(b[2]), k)
     assert rel_err(q, q_ref) < 2e-5 and rel_err(kk, k_ref) < 2e-5 and rel_err(vv, v_ref) < 2e-5
+    # the merged launch (query branch + pooled key / value branch in one grid) == the two entries, bit for bit
+    q2, k2, v2 = ops.qkv_prep(dv(nhwc(xn)), dv(w3[:, 0, 1].reshape(C, 9).t().contiguous()), dv(g[0]), dv(b[0]), dv(nhwc(xa)),
+                              dv(nhwc(xn)), dv(wk.reshape(C, k * k).t().contiguous()), dv(wv.reshape(C, k * k).t().contiguous()),
+                              dv(g[1]), dv(b[1]), dv(g[2]), dv(b[2]), k)
+    assert torch.equal(q2, q) and torch.equal(k2, kk) and torch.equal(v2, vv)
 
 
 @pytest.mark.parametrize("C,Lq,Lk,heads", [(96, 200, 18, 2), (768, 84, 18, 2), (32, 64, 2, 2), (192, 333, 18, 2)])
