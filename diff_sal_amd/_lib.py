@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 SIGNATURES = {
@@ -84,7 +84,7 @@ SIGNATURES = {
     "diffsal_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_dwconv3_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_dwpool_ln_kv": (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
-    "diffsal_qkv_prep": (c_i, [c_f] * 15 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
+    "diffsal_qkv_prep": (c_i, [c_f] * 15 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_fl, c_i, c_i, c_f]),
     "diffsal_mlp_block": (c_i, [c_f, c_f, c_f, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_fl, C.c_long, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_block16": (c_i, [c_f] * 6 + [c_fl] + [c_f] * 8 + [c_fl, C.c_long] + [c_i] * 6 + [c_f]),
     "diffsal_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),

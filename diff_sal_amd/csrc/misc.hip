@@ -630,7 +630,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 13; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 14; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,

@@ -147,6 +147,44 @@ __device__ __forceinline__ void ln_rows_finish(float4 (&v)[NV], int gl, int C, c
   }
 }
 
+// The same LayerNorm applied in place to a token held in registers (the block's `norm` folded into the kernels that read
+// its output): identical arithmetic to ln_rows_finish, and the value is rounded through the storage type T exactly as the
+// stand-alone LayerNorm's store + reload would, so the fused and the two-kernel forms agree bit for bit.
+template <int G, int NV, typename T>
+__device__ __forceinline__ void ln_rows_inplace(float4 (&v)[NV], int gl, int C, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  s = group_sum<G>(s);
+  const float mean = s / static_cast<float>(C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  q = group_sum<G>(q);
+  const float rstd = 1.0f / sqrtf(q / static_cast<float>(C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (gl + i * G) * 4;
+    if (c < C) {
+      const float4 g = ld4(gamma + c), b = ld4(beta + c);
+      v[i].x = static_cast<float>(static_cast<T>((v[i].x - mean) * rstd * g.x + b.x));
+      v[i].y = static_cast<float>(static_cast<T>((v[i].y - mean) * rstd * g.y + b.y));
+      v[i].z = static_cast<float>(static_cast<T>((v[i].z - mean) * rstd * g.z + b.z));
+      v[i].w = static_cast<float>(static_cast<T>((v[i].w - mean) * rstd * g.w + b.w));
+    }
+  }
+}
+
 // LayerNorm over C.  R/.../transformer.py:110,121; sal_unet.py:447,473
 template <int G, int NV, typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -168,10 +206,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }
 
 // depthwise 3x3 (pad 1, stride 1) + LayerNorm.  R/.../attention.py:36-47,94 (quirk Q8: centre slice)
-template <int G, int NV, typename T>
+// PRELN: the input is the block's un-normalised frames and every loaded token goes through the block's LayerNorm (pg, pb,
+// peps) first -- see ln_rows_inplace.  Validity and trip counts are uniform within a lane group, so the group reductions
+// inside always see a whole group.
+template <int G, int NV, typename T, bool PRELN = false>
 __device__ __forceinline__ void dwconv3_ln_body(const T* __restrict__ x, const float* __restrict__ w9,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                T* __restrict__ out, int N, int H, int W, int C, float eps, int bx, int nb) {
+                                                T* __restrict__ out, int N, int H, int W, int C, float eps, int bx, int nb,
+                                                const float* __restrict__ pg = nullptr, const float* __restrict__ pb = nullptr,
+                                                float peps = 0.f) {
   constexpr int ROWS = 256 / G;
   const int gl = threadIdx.x % G;
   const int gr = threadIdx.x / G;
@@ -192,15 +235,36 @@ __device__ __forceinline__ void dwconv3_ln_body(const T* __restrict__ x, const f
         if (ix < 0 || ix >= W) continue;
         const T* xr = x + (row + static_cast<long>(ky - 1) * W + (kx - 1)) * C;
         const float* wr = w9 + (ky * 3 + kx) * C;
+        if constexpr (PRELN) {
+          float4 a[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const int c = (gl + i * G) * 4;
-          if (c < C) {
-            const float4 a = ld4(xr + c), ww = ld4(wr + c);
-            v[i].x = fmaf(a.x, ww.x, v[i].x);
-            v[i].y = fmaf(a.y, ww.y, v[i].y);
-            v[i].z = fmaf(a.z, ww.z, v[i].z);
-            v[i].w = fmaf(a.w, ww.w, v[i].w);
+          for (int i = 0; i < NV; ++i) {
+            const int c = (gl + i * G) * 4;
+            a[i] = c < C ? ld4(xr + c) : make_float4(0, 0, 0, 0);
+          }
+          ln_rows_inplace<G, NV, T>(a, gl, C, pg, pb, peps);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const int c = (gl + i * G) * 4;
+            if (c < C) {
+              const float4 ww = ld4(wr + c);
+              v[i].x = fmaf(a[i].x, ww.x, v[i].x);
+              v[i].y = fmaf(a[i].y, ww.y, v[i].y);
+              v[i].z = fmaf(a[i].z, ww.z, v[i].z);
+              v[i].w = fmaf(a[i].w, ww.w, v[i].w);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const int c = (gl + i * G) * 4;
+            if (c < C) {
+              const float4 a = ld4(xr + c), ww = ld4(wr + c);
+              v[i].x = fmaf(a.x, ww.x, v[i].x);
+              v[i].y = fmaf(a.y, ww.y, v[i].y);
+              v[i].z = fmaf(a.z, ww.z, v[i].z);
+              v[i].w = fmaf(a.w, ww.w, v[i].w);
+            }
           }
         }
       }
@@ -220,10 +284,22 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(const T* __restrict__ x
 // with a sliding 3x3 window in registers -- 3 new 16-byte loads per output instead of 9, and the nine weight vectors are
 // loaded once per thread instead of once per output (18 -> ~4 vector loads per output: the kernel was bound by L1
 // request rate, not by HBM).
-template <int G, int SEG, typename T>
+template <int G, int SEG, typename T, bool PRELN = false>
 __device__ __forceinline__ void dwconv3_ln_strip_body(const T* __restrict__ x, const float* __restrict__ w9,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      T* __restrict__ out, int N, int H, int W, int C, float eps, int bx, int nb) {
+                                                      T* __restrict__ out, int N, int H, int W, int C, float eps, int bx, int nb,
+                                                      const float* __restrict__ pg = nullptr,
+                                                      const float* __restrict__ pb = nullptr, float peps = 0.f) {
+  // PRELN: a loaded token is normalised (the block's LayerNorm) before it enters the window; a padding position stays zero
+  auto fetch = [&](const T* p, bool valid) __attribute__((always_inline)) -> float4 {
+    float4 t[1];
+    t[0] = valid ? ld4(p) : make_float4(0, 0, 0, 0);
+    if constexpr (PRELN) {
+      ln_rows_inplace<G, 1, T>(t, threadIdx.x % G, C, pg, pb, peps);
+      if (!valid) t[0] = make_float4(0, 0, 0, 0);
+    }
+    return t[0];
+  };
   constexpr int GROUPS = 256 / G;
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   const int c = gl * 4;
@@ -249,13 +325,13 @@ __device__ __forceinline__ void dwconv3_ln_strip_body(const T* __restrict__ x, c
     float4 c0[3], c1[3], c2[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      c0[ky] = (rv[ky] && xs - 1 >= 0) ? ld4(rowp[ky] + static_cast<long>(xs - 1) * C) : zero;
-      c1[ky] = rv[ky] ? ld4(rowp[ky] + static_cast<long>(xs) * C) : zero;
+      c0[ky] = fetch(rowp[ky] + static_cast<long>(xs - 1) * C, rv[ky] && xs - 1 >= 0);
+      c1[ky] = fetch(rowp[ky] + static_cast<long>(xs) * C, rv[ky]);
     }
     const int xe = min(xs + SEG, W);
     for (int xx = xs; xx < xe; ++xx) {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) c2[ky] = (rv[ky] && xx + 1 < W) ? ld4(rowp[ky] + static_cast<long>(xx + 1) * C) : zero;
+      for (int ky = 0; ky < 3; ++ky) c2[ky] = fetch(rowp[ky] + static_cast<long>(xx + 1) * C, rv[ky] && xx + 1 < W);
       float4 v[1];
       v[0] = zero;
 #pragma unroll
@@ -283,13 +359,15 @@ __global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restri
 
 // depthwise k x k, stride k, no padding, + LayerNorm, for K and V at once: one workgroup per pooled token.
 // R/.../attention.py:49-76,88-95.  Threads = (256/G position lanes) x (G channel lanes).
-template <int G, int NV, typename T>
+template <int G, int NV, typename T, bool PRELN = false>
 __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, const T* __restrict__ xv,
                                                   const float* __restrict__ wk, const float* __restrict__ wv,
                                                   const float* __restrict__ gk, const float* __restrict__ bk,
                                                   const float* __restrict__ gv, const float* __restrict__ bv,
                                                   T* __restrict__ ok, T* __restrict__ ov, int H, int W,
-                                                  int C, int k, int gh, int gw, float eps, int tok) {
+                                                  int C, int k, int gh, int gw, float eps, int tok,
+                                                  const float* __restrict__ pg = nullptr, const float* __restrict__ pb = nullptr,
+                                                  float peps = 0.f, bool ln_k = false, bool ln_v = false) {
   constexpr int PL = 256 / G;
   extern __shared__ float shp[];  // [2][PL][C]
   const int gl = threadIdx.x % G;
@@ -305,16 +383,40 @@ __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, cons
   for (int pos = pl; pos < k * k; pos += PL) {
     const int dy = pos / k, dx = pos - dy * k;
     const long off = (img + static_cast<long>(gy * k + dy) * W + (gx * k + dx)) * C;
+    if constexpr (PRELN) {
+      // the position loop has the same trip count for every lane of a position group, so the reductions see whole groups
+      float4 a[NV], b[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (gl + i * G) * 4;
-      if (c < C) {
-        const float4 a = ld4(xk + off + c), w1 = ld4(wk + static_cast<long>(pos) * C + c);
-        ak[i].x = fmaf(a.x, w1.x, ak[i].x); ak[i].y = fmaf(a.y, w1.y, ak[i].y);
-        ak[i].z = fmaf(a.z, w1.z, ak[i].z); ak[i].w = fmaf(a.w, w1.w, ak[i].w);
-        const float4 b = ld4(xv + off + c), w2 = ld4(wv + static_cast<long>(pos) * C + c);
-        av[i].x = fmaf(b.x, w2.x, av[i].x); av[i].y = fmaf(b.y, w2.y, av[i].y);
-        av[i].z = fmaf(b.z, w2.z, av[i].z); av[i].w = fmaf(b.w, w2.w, av[i].w);
+      for (int i = 0; i < NV; ++i) {
+        const int c = (gl + i * G) * 4;
+        a[i] = c < C ? ld4(xk + off + c) : make_float4(0, 0, 0, 0);
+        b[i] = c < C ? ld4(xv + off + c) : make_float4(0, 0, 0, 0);
+      }
+      if (ln_k) ln_rows_inplace<G, NV, T>(a, gl, C, pg, pb, peps);
+      if (ln_v) ln_rows_inplace<G, NV, T>(b, gl, C, pg, pb, peps);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (gl + i * G) * 4;
+        if (c < C) {
+          const float4 w1 = ld4(wk + static_cast<long>(pos) * C + c), w2 = ld4(wv + static_cast<long>(pos) * C + c);
+          ak[i].x = fmaf(a[i].x, w1.x, ak[i].x); ak[i].y = fmaf(a[i].y, w1.y, ak[i].y);
+          ak[i].z = fmaf(a[i].z, w1.z, ak[i].z); ak[i].w = fmaf(a[i].w, w1.w, ak[i].w);
+          av[i].x = fmaf(b[i].x, w2.x, av[i].x); av[i].y = fmaf(b[i].y, w2.y, av[i].y);
+          av[i].z = fmaf(b[i].z, w2.z, av[i].z); av[i].w = fmaf(b[i].w, w2.w, av[i].w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (gl + i * G) * 4;
+        if (c < C) {
+          const float4 a = ld4(xk + off + c), w1 = ld4(wk + static_cast<long>(pos) * C + c);
+          ak[i].x = fmaf(a.x, w1.x, ak[i].x); ak[i].y = fmaf(a.y, w1.y, ak[i].y);
+          ak[i].z = fmaf(a.z, w1.z, ak[i].z); ak[i].w = fmaf(a.w, w1.w, ak[i].w);
+          const float4 b = ld4(xv + off + c), w2 = ld4(wv + static_cast<long>(pos) * C + c);
+          av[i].x = fmaf(b.x, w2.x, av[i].x); av[i].y = fmaf(b.y, w2.y, av[i].y);
+          av[i].z = fmaf(b.z, w2.z, av[i].z); av[i].w = fmaf(b.w, w2.w, av[i].w);
+        }
       }
     }
   }
@@ -365,19 +467,25 @@ struct QkvPrepArgs {
   const float* gk; const float* bk; const float* gv; const float* bv; void* ok; void* ov;
   int N, H, W, C, k, gh, gw, nq;
   float eps;
+  // PRELN: the block's LayerNorm (transformer.py:110: x = self.norm(x)) applied to the tokens as they are loaded -- the
+  // query input and the value input always, the key input when it is the same normalised tensor (visual-only)
+  const float* pg; const float* pb; float peps; int ln_k;
 };
 
-template <bool STRIP, int G, int NV, typename T>
+template <bool STRIP, int G, int NV, typename T, bool PRELN>
 __global__ __launch_bounds__(256) void qkv_prep_kernel(QkvPrepArgs a) {
   const int b = blockIdx.x;
   if (b < a.nq) {
     if constexpr (STRIP)
-      dwconv3_ln_strip_body<G, 8, T>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W, a.C, a.eps, b, a.nq);
+      dwconv3_ln_strip_body<G, 8, T, PRELN>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W,
+                                            a.C, a.eps, b, a.nq, a.pg, a.pb, a.peps);
     else
-      dwconv3_ln_body<G, NV, T>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W, a.C, a.eps, b, a.nq);
+      dwconv3_ln_body<G, NV, T, PRELN>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W, a.C,
+                                       a.eps, b, a.nq, a.pg, a.pb, a.peps);
   } else {
-    dwpool_ln_kv_body<G, NV, T>(static_cast<const T*>(a.xk), static_cast<const T*>(a.xv), a.wk, a.wv, a.gk, a.bk, a.gv, a.bv,
-                                static_cast<T*>(a.ok), static_cast<T*>(a.ov), a.H, a.W, a.C, a.k, a.gh, a.gw, a.eps, b - a.nq);
+    dwpool_ln_kv_body<G, NV, T, PRELN>(static_cast<const T*>(a.xk), static_cast<const T*>(a.xv), a.wk, a.wv, a.gk, a.bk, a.gv,
+                                       a.bv, static_cast<T*>(a.ok), static_cast<T*>(a.ov), a.H, a.W, a.C, a.k, a.gh, a.gw, a.eps,
+                                       b - a.nq, a.pg, a.pb, a.peps, a.ln_k != 0, true);
   }
 }
 
@@ -550,10 +658,12 @@ static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
   do {                                                                                                               \
     if (strip && NV == 1) {                                                                                          \
       a.nq = row_grid(static_cast<long>(a.N) * a.H * ((a.W + 7) / 8), 256 / G);                                        \
-      hipLaunchKernelGGL((qkv_prep_kernel<true, G, 1, T>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);    \
+      if (a.pg) hipLaunchKernelGGL((qkv_prep_kernel<true, G, 1, T, true>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a); \
+      else hipLaunchKernelGGL((qkv_prep_kernel<true, G, 1, T, false>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);     \
     } else {                                                                                                         \
       a.nq = row_grid(static_cast<long>(a.N) * a.H * a.W, 256 / G);                                                   \
-      hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);  \
+      if (a.pg) hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T, true>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a); \
+      else hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T, false>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);     \
     }                                                                                                                \
   } while (0)
   DS_ROW_DISPATCH(a.C, CALL);
@@ -564,7 +674,10 @@ static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
 extern "C" int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq, const float* bq, void* out_q, const void* xk,
                                 const void* xv, const float* wk, const float* wv, const float* gk, const float* bk,
                                 const float* gv, const float* bv, void* out_k, void* out_v, int N, int H, int W, int C, int k,
-                                float eps, int dtype, diffsal_stream_t stream) {
+                                float eps, const float* pre_gamma, const float* pre_beta, float pre_eps, int pre_ln_k, int dtype,
+                                diffsal_stream_t stream) {
+  DS_REQUIRE((pre_gamma == nullptr) == (pre_beta == nullptr) && (!pre_gamma || (aligned16(pre_gamma) && aligned16(pre_beta))),
+             DIFFSAL_E_ARG, "qkv_prep: pre-LayerNorm gamma and beta go together (16-byte aligned)");
   DS_REQUIRE(xq && w9 && gq && bq && out_q && xk && xv && wk && wv && gk && bk && gv && bv && out_k && out_v, DIFFSAL_E_ARG,
              "qkv_prep: null argument");
   DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && H >= k && W >= k, DIFFSAL_E_SHAPE,
@@ -572,7 +685,8 @@ extern "C" int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq
   DS_REQUIRE(aligned16(xq) && aligned16(out_q) && aligned16(w9) && aligned16(gq) && aligned16(bq) && aligned16(xk) && aligned16(xv) &&
                  aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v),
              DIFFSAL_E_ALIGN, "qkv_prep: misaligned pointer");
-  QkvPrepArgs a{xq, w9, gq, bq, out_q, xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, N, H, W, C, k, (H - k) / k + 1, (W - k) / k + 1, 0, eps};
+  QkvPrepArgs a{xq, w9, gq, bq, out_q, xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, N, H, W, C, k, (H - k) / k + 1, (W - k) / k + 1, 0, eps,
+                pre_gamma, pre_beta, pre_eps, pre_ln_k};
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALLT(T) return qkv_prep_t<T>(a, s)
   DS_DTYPE_DISPATCH(dtype, "qkv_prep", CALLT);

@@ -541,8 +541,10 @@ def dwconv3_ln(x: Tensor, w9: Tensor, gamma: Tensor, beta: Tensor, eps: float = 
 
 
 def qkv_prep(xq: Tensor, w9: Tensor, gq: Tensor, bq: Tensor, xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor,
-             bk: Tensor, gv: Tensor, bv: Tensor, k: int, eps: float = 1e-5):
-    """``dwconv3_ln(xq, ...)`` and ``dwpool_ln_kv(xk, xv, ...)`` of one transformer block in one launch -> (q, k, v) tokens."""
+             bk: Tensor, gv: Tensor, bv: Tensor, k: int, eps: float = 1e-5, pre_ln=None):
+    """``dwconv3_ln(xq, ...)`` and ``dwpool_ln_kv(xk, xv, ...)`` of one transformer block in one launch -> (q, k, v) tokens.
+    ``pre_ln = (gamma, beta, eps, ln_k)``: xq / xv (and xk when ``ln_k``) are un-normalised and pass through that LayerNorm
+    as they are loaded (the block's ``norm``), bit-equal with a separate ``layernorm`` launch."""
     lib = _lib.load()
     N, H, W, Cc = xq.shape
     if xk.shape != xq.shape or xv.shape != xq.shape or xk.dtype != xq.dtype or xv.dtype != xq.dtype:
@@ -554,9 +556,10 @@ def qkv_prep(xq: Tensor, w9: Tensor, gq: Tensor, bq: Tensor, xk: Tensor, xv: Ten
     dt = _dt(xq)
     same = xk.data_ptr() == xv.data_ptr() == xq.data_ptr()
     with _prof("K9", 22.0 * N * H * W * Cc, _nb(xq, oq, ok, ov) + (0.0 if same else _nb(xk))):
+        pg, pb, pe, plk = (pre_ln[0], pre_ln[1], float(pre_ln[2]), int(bool(pre_ln[3]))) if pre_ln is not None else (None, None, 0.0, 0)
         _lib.check(lib.diffsal_qkv_prep(_pa(xq, dt), _p(w9), _p(gq), _p(bq), oq.data_ptr(), _pa(xk, dt), _pa(xv, dt), _p(wk),
                                         _p(wv), _p(gk), _p(bk), _p(gv), _p(bv), ok.data_ptr(), ov.data_ptr(), N, H, W, Cc, k,
-                                        eps, dt, _stream()), "qkv_prep")
+                                        eps, _p(pg), _p(pb), pe, plk, dt, _stream()), "qkv_prep")
     return oq, ok, ov
 
 

@@ -368,22 +368,33 @@ class SalUNet(nn.Module):
         blk = self.invpt_decoder.mid_stages[i].blocks[0]
         a = blk.attn
         n9 = B * T
-        xn = ops.layernorm(x, blk.norm.weight, blk.norm.bias, blk.norm.eps)
-        k_src = xn
+        k_src = None                       # None: the key branch reads the same normalised frames as q and v
         if audio_tok is not None:
             a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias, tag="K7-align")  # [B*T, ha*wa, C]
             k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
-        if self.merge_qkv_prep and a.conv_proj_q.bn.eps == a.conv_proj_k.bn.eps and k_src.dtype == xn.dtype:
-            q, kk, vv = ops.qkv_prep(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
-                                     k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+        if self.merge_qkv_prep and self.fold_norm1 and a.conv_proj_q.bn.eps == a.conv_proj_k.bn.eps:
+            # the block's `norm` is applied to the tokens as qkv_prep loads them: x_n = norm(x) is never written
+            xv_ = x.view(n9, H, W, C)
+            q, kk, vv = ops.qkv_prep(xv_, pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
+                                     xv_ if k_src is None else k_src.view(n9, H, W, C), xv_, pk[f"s{i}.wk"], pk[f"s{i}.wv"],
                                      a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
-                                     a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
+                                     a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps,
+                                     pre_ln=(blk.norm.weight, blk.norm.bias, blk.norm.eps, k_src is None))
         else:
-            q = ops.dwconv3_ln(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
-                               a.conv_proj_q.bn.eps)
-            kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
-                                      a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
-                                      a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
+            xn = ops.layernorm(x, blk.norm.weight, blk.norm.bias, blk.norm.eps)
+            if k_src is None:
+                k_src = xn
+            if self.merge_qkv_prep and a.conv_proj_q.bn.eps == a.conv_proj_k.bn.eps and k_src.dtype == xn.dtype:
+                q, kk, vv = ops.qkv_prep(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
+                                         k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+                                         a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
+                                         a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
+            else:
+                q = ops.dwconv3_ln(xn.view(n9, H, W, C), pk[f"s{i}.wq9"], a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias,
+                                   a.conv_proj_q.bn.eps)
+                kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+                                          a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
+                                          a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
         q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
         if self.pair_kv and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and (
                 self.compute_dtype != torch.float32 or ops.get_gemm_precision() == "fp32"):
@@ -421,6 +432,9 @@ class SalUNet(nn.Module):
     # as nine 1x1 tap mixings at the SOURCE resolution (one GEMM, 4x / 3x fewer FLOPs) + a gather of the interpolated taps
     # (ops.tapsum, csrc/tapsum.hip).  Exact up to summation order; off when intermediate taps are requested.
     tap_conv = True
+    # the block's first LayerNorm applied inside qkv_prep (no normalised tensor in HBM).  Bit-equal, but measured slower: the
+    # per-token reductions sit on the load path of latency-bound kernels (K9 0.163 -> 0.36 ms for 0.07 ms less K8): off.
+    fold_norm1 = False
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16

@@ -325,10 +325,15 @@ int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float* wk, const 
                          void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
                          diffsal_stream_t stream);
 /* diffsal_dwconv3_ln (query branch) and diffsal_dwpool_ln_kv (key / value branch) of one transformer block in ONE launch: both
- * read the block's normalised frames and neither depends on the other (attention.py:86-95).  Same results as the two entries. */
+ * read the block's normalised frames and neither depends on the other (attention.py:86-95).  Same results as the two entries.
+ * pre_gamma / pre_beta (or NULL): the block's own LayerNorm (transformer.py:110, x = self.norm(x)) is applied to every token as
+ * it is loaded -- xq and xv are then the UN-normalised frames, xk too when pre_ln_k != 0 (visual-only: the key input is the same
+ * normalised tensor; with audio it is the fused audio map, pre_ln_k = 0) -- so the normalised tensor is never written.  Bit-equal
+ * with diffsal_layernorm followed by the plain form (the normalised value is rounded through the storage type). */
 int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq, const float* bq, void* out_q, const void* xk,
                      const void* xv, const float* wk, const float* wv, const float* gk, const float* bk, const float* gv,
-                     const float* bv, void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps, int dtype,
+                     const float* bv, void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps,
+                     const float* pre_gamma, const float* pre_beta, float pre_eps, int pre_ln_k, int dtype,
                      diffsal_stream_t stream);
 
 

@@ -405,3 +405,24 @@ def test_linear_pair_16bit_equals_two_launches(ops, dname, M, K, N, monkeypatch)
     y0, y1 = ops.linear_pair(x0, x1, w0, w1, b0, b1)
     assert torch.equal(y0, ops.linear(x0, w0, b0)) and torch.equal(y1, ops.linear(x1, w1, b1))
     assert rel_err(y1, x1.float() @ w1.float().t() + b1) < OP_RTOL[dname]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("C,H,W,k", [(96, 16, 32, 16), (768, 7, 12, 2), (192, 28, 48, 8)])
+def test_qkv_prep_folded_layernorm_16bit(ops, dname, C, H, W, k):
+    """diffsal_qkv_prep with the block's LayerNorm folded into its loads == layernorm launch + plain qkv_prep, bit for bit, on
+    16-bit storage (the folded form rounds the normalised value through the storage type like the store + reload does)."""
+    dt = DTYPES[dname]
+    n = 3
+    raw = q(rnd("fx%d" % C, n, H, W, C), dt).to(DEV).to(dt)
+    xa = q(rnd("fa%d" % C, n, H, W, C), dt).to(DEV).to(dt)
+    w9 = rnd("fw9", 9, C, scale=0.3).to(DEV)
+    wk, wv = rnd("fwk", k * k, C, scale=1.0 / k).to(DEV), rnd("fwv", k * k, C, scale=1.0 / k).to(DEV)
+    g = [(rnd("fg%d" % i, C, scale=0.2) + 1.0).to(DEV) for i in range(4)]
+    b = [rnd("fb%d" % i, C, scale=0.2).to(DEV) for i in range(4)]
+    normed = ops.layernorm(raw, g[3], b[3], 1e-5)
+    for ln_k in (True, False):
+        ref = ops.qkv_prep(normed, w9, g[0], b[0], normed if ln_k else xa, normed, wk, wv, g[1], b[1], g[2], b[2], k)
+        got = ops.qkv_prep(raw, w9, g[0], b[0], raw if ln_k else xa, raw, wk, wv, g[1], b[1], g[2], b[2], k,
+                           pre_ln=(g[3], b[3], 1e-5, ln_k))
+        assert all(torch.equal(r_, g_) for r_, g_ in zip(ref, got)), (C, ln_k)

@@ -249,6 +249,18 @@ def test_depthwise_projections(ops, C, H, W, k):
                               dv(nhwc(xn)), dv(wk.reshape(C, k * k).t().contiguous()), dv(wv.reshape(C, k * k).t().contiguous()),
                               dv(g[1]), dv(b[1]), dv(g[2]), dv(b[2]), k)
     assert torch.equal(q2, q) and torch.equal(k2, kk) and torch.equal(v2, vv)
+    # the block's first LayerNorm folded into the loads == layernorm launch + plain form (key input normalised or not)
+    pg, pb = dv(rnd("dpg", C, scale=0.2) + 1.0), dv(rnd("dpb", C, scale=0.2))
+    raw = dv(nhwc(xn))
+    normed = ops.layernorm(raw, pg, pb, 1e-5)
+    args = (dv(w3[:, 0, 1].reshape(C, 9).t().contiguous()), dv(g[0]), dv(b[0]))
+    kvw = (dv(wk.reshape(C, k * k).t().contiguous()), dv(wv.reshape(C, k * k).t().contiguous()), dv(g[1]), dv(b[1]), dv(g[2]), dv(b[2]), k)
+    for ln_k in (True, False):
+        xk_plain = normed if ln_k else dv(nhwc(xa))
+        xk_fold = raw if ln_k else dv(nhwc(xa))
+        ref3 = ops.qkv_prep(normed, *args, xk_plain, normed, *kvw)
+        got3 = ops.qkv_prep(raw, *args, xk_fold, raw, *kvw, pre_ln=(pg, pb, 1e-5, ln_k))
+        assert all(torch.equal(r_, g_) for r_, g_ in zip(ref3, got3)), (C, H, W, k, ln_k)
 
 
 @pytest.mark.parametrize("C,Lq,Lk,heads", [(96, 200, 18, 2), (768, 84, 18, 2), (32, 64, 2, 2), (192, 333, 18, 2)])
