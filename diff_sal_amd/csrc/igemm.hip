@@ -827,7 +827,12 @@ struct Plan { int cfg, splits; };
 //   round = max(occ * t_mfma, t_mfma + t_fixed),  time = ceil(workgroups / (256 occ)) * round
 // (+ the slab round trip for split-K).  Short-K GEMMs therefore prefer more, smaller residents;
 // long-K convolutions prefer the widest tile that still fills the chip.
-static Plan choose_plan(long M, int Cout, int K, int precision) {
+static bool is_linear(const diffsal_conv_desc* d) {
+  return d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H &&
+         d->Wo == d->W;
+}
+
+static Plan choose_plan(long M, int Cout, int K, int precision, bool linear = false) {
   // the bf16x3 loop sustains ~2x the fp32 one on large tiles: split-K slabs and fixed latencies weigh twice as much
   const double mac_per_s_cu = (precision == DIFFSAL_PREC_BF16X3 ? 2.0 : 1.0) * 157.3e12 / 2.0 / kCUs;
   const int KT = K / BK;
@@ -845,7 +850,11 @@ static Plan choose_plan(long M, int Cout, int K, int precision) {
       const long wgs = tiles * S;
       const long slots = static_cast<long>(kCUs) * t.occ;
       const int kt_per = (KT + S - 1) / S;
-      const double t_mfma = static_cast<double>(t.bm) * t.bn * (kt_per * BK) / (mac_per_s_cu * t.eff);
+      // plain products (1x1, the persistent kernel): measured per-CU rates of the large tiles with two residents are ~0.85 of
+      // what the table says relative to four residents of 64x64 (tools/tune_igemm_thin.py: K <= 768 token and tap GEMMs are
+      // 5-17 % faster on 64x64; K14's M = 28560, K = 768, N = 864 stays on 128x96 by 3 %)
+      const double eff = (linear && S == 1 && precision != DIFFSAL_PREC_BF16X3 && c != 5) ? t.eff * 0.86 : t.eff;
+      const double t_mfma = static_cast<double>(t.bm) * t.bn * (kt_per * BK) / (mac_per_s_cu * eff);
       // full rounds at full residency, then the remainder at ITS residency: the last workgroups of a launch have the CU
       // (almost) to themselves and finish sooner than a full round (in-kernel stamps)
       auto round_time = [&](double resident) {
@@ -922,7 +931,7 @@ extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (validate(d) != DIFFSAL_OK) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   if (d->dtype != DIFFSAL_F32) return igemm16_ws_bytes(d);
-  const Plan pl = choose_plan(M, d->Cout, d->KH * d->KW * d->Cin, d->precision);
+  const Plan pl = choose_plan(M, d->Cout, d->KH * d->KW * d->Cin, d->precision, is_linear(d));
   return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
 }
 
@@ -981,7 +990,7 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
-  Plan pl = choose_plan(M, d->Cout, a.K, d->precision);
+  Plan pl = choose_plan(M, d->Cout, a.K, d->precision, a.linear != 0);
   if (const char* e = getenv("DIFFSAL_IGEMM_CFG")) {   // tuning aid: force a tile shape (no split-K)
     pl.cfg = atoi(e) % kNumCfgs;
     pl.splits = 1;

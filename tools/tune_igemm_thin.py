@@ -11,13 +11,14 @@ from diff_sal_amd import ops  # noqa: E402
 from tools.tune_igemm16 import timed  # noqa: E402
 
 CFG = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64"]
+TAP_SHAPES = [(48384, 192, 864), (12096, 384, 1728), (3024, 768, 3456), (28560, 768, 864)]   # tap GEMMs (K12 conv1, K14)
 SHAPES = [(193536, 96, 96), (193536, 96, 192), (193536, 192, 96), (48384, 192, 192), (48384, 192, 384), (48384, 384, 192),
           (12096, 384, 384), (12096, 384, 768), (12096, 768, 384), (3024, 768, 768), (3024, 768, 1536), (3024, 1536, 768),
           (648, 768, 768), (648, 384, 384), (48384, 3456, 192), (12096, 6912, 384), (5376, 1728, 384), (1344, 3456, 768), (21504, 96, 192), (5376, 192, 384), (1344, 384, 768)]
 
 
 def main():
-    for M, K, N in SHAPES:
+    for M, K, N in (TAP_SHAPES if "--tap" in sys.argv else SHAPES):
         x = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
         b = torch.randn(N, device="cuda")
