@@ -995,6 +995,10 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
     pl.cfg = atoi(e) % kNumCfgs;
     pl.splits = 1;
   }
+  if (const char* e = getenv("DIFFSAL_PLAN_DEBUG")) {   // tuning aid: which tile shape / split the planner chose
+    if (e[0] == '1') fprintf(stderr, "[diffsal plan] M=%ld K=%d N=%d linear=%d -> %dx%d splits=%d\n", M, a.K, d->Cout, a.linear,
+                             kCfgs[pl.cfg].bm, kCfgs[pl.cfg].bn, pl.splits);
+  }
   a.splits = pl.splits;
   a.kt_per_split = (a.K / BK + pl.splits - 1) / pl.splits;
   a.partial = nullptr;

@@ -1,11 +1,15 @@
-import os, sys, torch
-sys.path.insert(0, os.getcwd())
-from diff_sal_amd import ops
-from tools.tune_igemm16 import timed
-for M, K, N in [(48384, 192, 864), (12096, 384, 1728)]:
-    x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05
-    for env in [{}, {"DIFFSAL_IGEMM_CFG": "5"}, {"DIFFSAL_IGEMM_CFG": "2"}, {"DIFFSAL_NO_XCD_ORDER": "1"}, {"DIFFSAL_IGEMM_CFG": "5", "DIFFSAL_NO_XCD_ORDER": "1"}]:
-        for k in ("DIFFSAL_IGEMM_CFG", "DIFFSAL_NO_XCD_ORDER"): os.environ.pop(k, None)
-        os.environ.update(env)
-        ops.linear(x, w, None)
-        print(M, K, N, env, round(timed(lambda: ops.linear(x, w, None)), 1))
+#!/usr/bin/env python3
+"""Print the fp32 planner's tile shape / split-K for every GEMM-family launch of one denoising step (DIFFSAL_PLAN_DEBUG=1)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+env = dict(os.environ, DIFFSAL_PLAN_DEBUG="1")
+out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline",
+                      "--no-encoders", "--no-alt-precision", "--no-reference-graph"], env=env, capture_output=True, text=True)
+seen = []
+for line in out.stderr.splitlines():
+    if line.startswith("[diffsal plan]") and line not in seen:
+        seen.append(line)
+print("\n".join(seen))
