@@ -18,11 +18,16 @@ SHAPES = [(193536, 96, 96), (193536, 96, 192), (193536, 192, 96), (48384, 192, 1
 
 
 def main():
+    lowp = "--bf16" in sys.argv          # 16-bit storage: the igemm16 kernels and their own tile table
+    var = "DIFFSAL_IGEMM16_CFG" if lowp else "DIFFSAL_IGEMM_CFG"
+    names = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64", "256x96", "256x128"] if lowp else CFG
     for M, K, N in (TAP_SHAPES if "--tap" in sys.argv else SHAPES):
         x = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
+        if lowp:
+            x, w = x.bfloat16(), w.bfloat16()
         b = torch.randn(N, device="cuda")
-        os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        os.environ.pop(var, None)
         os.environ["DIFFSAL_NO_PERSIST"] = "1"
         y0 = ops.linear(x, w, b)
         us0 = timed(lambda: ops.linear(x, w, b))
@@ -31,14 +36,14 @@ def main():
         us = timed(lambda: ops.linear(x, w, b))
         fl = 2.0 * M * K * N
         line = (f"M={M:6d} K={K:4d} N={N:4d} one-tile {us0:7.1f} us | persistent {us:7.1f} us {fl / us / 1e6:6.1f} TF/s "
-                f"diff {(y0 - y1).abs().max().item():.1e} |")
-        for c, cn in enumerate(CFG):
-            if (c == 0 and N < 161) or (c in (1, 3) and N < 97):
+                f"diff {(y0.float() - y1.float()).abs().max().item():.1e} |")
+        for c, cn in enumerate(names):
+            if (c == 0 and N < 161) or (c in (1, 3, 7) and N < 97):
                 continue
-            os.environ["DIFFSAL_IGEMM_CFG"] = str(c)
+            os.environ[var] = str(c)
             u = timed(lambda: ops.linear(x, w, b))
             line += f" {cn} {u:6.1f}"
-        os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        os.environ.pop(var, None)
         print(line, flush=True)
 
 
