@@ -386,20 +386,24 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ 
   const int cs = bid % cslabs; bid /= cslabs;
   const int y = bid % H;
   const int b = bid / H;
-  const int cl = threadIdx.x & 31;
-  const int xl = threadIdx.x >> 5;  // 0..7
-  const int c = cs * 32 + cl;
   const int ys = y / up;
-  // pass 1: m[c][x]
-  for (int xx = xl; xx < W; xx += 8) {
-    const int xs = xx / up;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) {
-      const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c]);
-      const float xv = static_cast<float>(x[(((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c]);
-      s = fmaf(av, xv, s);
+  // pass 1: m[c][x] = mean_t a * x.  A lane owns four channels of one x position (16-byte loads: 8 lanes cover the slab's
+  // 128 contiguous bytes of a pixel, 32 positions per sweep); per (c, x) the products are added in frame order.
+  {
+    const int cq = (threadIdx.x & 7) * 4, xl = threadIdx.x >> 3;   // channel quad within the slab, x lane 0..31
+    const int c = cs * 32 + cq;
+    for (int xx = xl; xx < W; xx += 32) {
+      const int xs = xx / up;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < T; ++t) {
+        const float4 av = ld4(a_small + ((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c);
+        const float4 xv = ld4(x + (((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c);
+        s.x = fmaf(av.x, xv.x, s.x); s.y = fmaf(av.y, xv.y, s.y); s.z = fmaf(av.z, xv.z, s.z); s.w = fmaf(av.w, xv.w, s.w);
+      }
+      const float ft = static_cast<float>(T);
+      sh[(cq + 0) * WP + xx] = s.x / ft; sh[(cq + 1) * WP + xx] = s.y / ft;
+      sh[(cq + 2) * WP + xx] = s.z / ft; sh[(cq + 3) * WP + xx] = s.w / ft;
     }
-    sh[cl * WP + xx] = s / static_cast<float>(T);
   }
   __syncthreads();
   // pass 2: softmax over x for each of the 32 channel rows: 8 lanes per row
@@ -420,11 +424,17 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ 
   }
   __syncthreads();
   // pass 3: out[b, c, t, y, :] = a * s, x fastest across lanes
+  // flat over (channel, frame, x) with x fastest across lanes; the index split uses reciprocal multiplies (i < 2^23, exact
+  // after the integer fix-up) instead of three integer divisions per 4-byte store
   const int total = 32 * T * W;
+  const float inv_w = 1.0f / static_cast<float>(W), inv_t = 1.0f / static_cast<float>(T);
   for (int i = threadIdx.x; i < total; i += 256) {
-    const int xx = i % W;
-    const int t = (i / W) % T;
-    const int cc = i / (W * T);
+    int iw = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_w);
+    int xx = i - iw * W;
+    if (xx < 0) { --iw; xx += W; } else if (xx >= W) { ++iw; xx -= W; }
+    int cc = static_cast<int>((static_cast<float>(iw) + 0.5f) * inv_t);
+    int t = iw - cc * T;
+    if (t < 0) { --cc; t += T; } else if (t >= T) { ++cc; t -= T; }
     const int cg = cs * 32 + cc;
     const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xx / up) * C + cg]);
     out[(((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx] = static_cast<TT>(av * sh[cc * WP + xx]);
@@ -973,6 +983,7 @@ extern "C" int diffsal_audio_fuse(const void* a_small, const void* x, void* out,
   DS_REQUIRE(a_small && x && out, DIFFSAL_E_ARG, "audio_fuse: null argument");
   DS_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && h > 0 && w > 0, DIFFSAL_E_SHAPE,
              "audio_fuse: bad shape C=%d", C);
+  DS_REQUIRE(aligned16(a_small) && aligned16(x), DIFFSAL_E_ALIGN, "audio_fuse: misaligned pointer");
   int up = 1;
   if (h != H && w != W) {  // quirk Q3: upsample only when BOTH differ; factor H // h
     up = H / h;
