@@ -94,8 +94,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const long total4 = static_cast<long>(HW) * c4n;
   const T* xb = x + static_cast<long>(b) * HW * C;
   T* ob = out + static_cast<long>(b) * HW * C;
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
-    const int c = static_cast<int>(i % c4n) * 4;
+  // channel quad of element i = i mod c4n, carried along instead of a 64-bit modulo per element
+  const long i0 = static_cast<long>(blockIdx.x) * 256 + threadIdx.x, step = static_cast<long>(gridDim.x) * 256;
+  int cq = static_cast<int>(i0 % c4n);
+  const int cstep = static_cast<int>(step % c4n);
+  for (long i = i0; i < total4; i += step) {
+    const int c = cq * 4;
+    cq += cstep;
+    if (cq >= c4n) cq -= c4n;
     float4 v = ld4(xb + i * 4);
     v.x = v.x * shf[c + 0] + shf[C + c + 0];
     v.y = v.y * shf[c + 1] + shf[C + c + 1];
