@@ -80,8 +80,8 @@ def spawn_ranks(n: int) -> int:
     import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
+    with socket.socket() as sk:      # a free port; the children bind it a moment later (a lost race fails the rendezvous loudly,
+        sk.bind(("127.0.0.1", 0))     # and the watchdog below then ends every rank instead of hanging)
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
@@ -89,11 +89,75 @@ def spawn_ranks(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # rank 0's stdout is drained by a thread so that polling the children never blocks on a full pipe
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("DIFFSAL_BENCH_TIMEOUT_S", "3600"))
+    failed = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            # a rank died (or the job overran): its peers would wait for it in init_process_group / a collective forever
+            failed = abs(bad[0]) if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            sys.stderr.write(f"bench.py: rank failure or timeout (exit codes {codes}); all ranks stopped\n")
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    return failed
+
+
+def plumbing_train_leg(world):
+    """CPU-only host: the gradient-exchange half of the `train` object on host tensors over gloo -- the same FlatParams /
+    GradReducer code the GPU step uses (bucket hooks, asynchronous all_reduce, wait), a MIN / MAX checksum comparison of the
+    replicas -- with every timing field null (there is no CPU training step to time)."""
+    import torch.distributed as dist
+
+    from diff_sal_amd.train_step import FlatParams, GradReducer
+
+    torch.manual_seed(5)
+    m = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Tanh(), torch.nn.Linear(96, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+    flat = FlatParams(m, bucket_bytes=4 << 10)
+    red = GradReducer(flat, None, exchange_single_rank=True)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    x = torch.randn(16, 64, generator=torch.Generator().manual_seed(100 + rank))
+    for _ in range(2):
+        flat.zero_grad()
+        red.arm()
+        m(x).square().mean().backward()
+        red.finish()
+        flat.flat_p.add_(flat.flat_g, alpha=-0.1 / max(world, 1))
+    chk = torch.stack([flat.flat_p.double().sum(), flat.flat_p.double().abs().sum()])
+    lo, hi = chk.clone(), chk.clone()
+    if dist.is_initialized():
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return {"what": "NONE: no GPU visible -- gradient-exchange plumbing only (toy module, gloo)", "value": None, "unit": "samples/s",
+            "n_gpus": world, "ms_per_step": None, "grad_buckets": len(flat.buckets),
+            "exchange": {"backend": dist.get_backend() if dist.is_initialized() else "none", "world": world,
+                         "collective_executed": bool(dist.is_initialized() and red.exchange),
+                         "bytes_per_step_per_rank": int(flat.numel * 4),
+                         "buckets_mb": [round(len(r) * 4 / 2 ** 20, 4) for r in flat.buckets],
+                         "launch_order": list(red.launch_order), "replicas_identical": bool(torch.equal(lo, hi)),
+                         "allreduce_ms_per_bucket": None, "ms_per_step_without_exchange": None, "exposed_ms": None,
+                         "overlap_frac": None}}
 
 
 def plumbing_only(args, rank, world):
@@ -115,8 +179,12 @@ def plumbing_only(args, rank, world):
         el = float(tt.item())
         ranks = dist.get_world_size()
         dist.barrier()
+    train = None
+    if args.workload == "sample" and not args.no_train_leg:
+        train = plumbing_train_leg(world)
     if rank == 0:
         print(json.dumps({"metric": "denoise-steps/sec (batch x NFE / wall time), 16x224x384 clip, 50-step DPM-Solver",
+                          "train": train,
                           "value": None, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -185,18 +253,16 @@ class Top(torch.nn.Module):
         self.decoder_net, self.audio_net, self.visual_net = net, None, None
 
 
-def bench_train(args, net, cfg, feats, audio, dev, rank, world):
-    """BASELINE configs[3]: the diffusion training step of the denoiser on a per-GPU batch (weak scaling)."""
+def build_train_step(cfg, net, feats, audio, dev, rank, *, batch, av, full, exchange_single_rank=False):
+    """The model, inputs and DiffusionTrainStep of BASELINE configs[3] on this rank's synthetic clips."""
     import numpy as np
 
-    from diff_sal_amd import ops
     from diff_sal_amd.train_step import DiffusionTrainStep
 
-    B, av = args.batch, args.mode == "av"
+    B = batch
     H, W = cfg.img_size
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     sal = torch.rand((B, 1, H, W), generator=g).to(dev)
-    full = args.train_scope == "full"
     if full:
         # the step as the reference runs it (R/diffusion_trainer.py:212-235): the encoders are INSIDE the step --
         # MViTv2-S forward + backward, VGGish forward (frozen, no_grad) and AudioAttnNet forward + backward in AV mode
@@ -216,42 +282,165 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
         cond = {"img": torch.randn((B, 3, 16, H, W), generator=g).to(dev)}
         if av:
             cond["audio"] = torch.randn((B, 1, 9, H // 2, W // 2), generator=g).to(dev)
-        ts = DiffusionTrainStep(model)
+        ts = DiffusionTrainStep(model, exchange_single_rank=exchange_single_rank)
     else:
         cond = {"feat_list": feats, "audio_feat": audio}
-        ts = DiffusionTrainStep(net)                  # reference hyper-parameters: Adam 1e-4, clip 1.0, dropout 0.1
+        ts = DiffusionTrainStep(net, exchange_single_rank=exchange_single_rank)   # reference hyper-parameters: Adam 1e-4, clip 1.0, dropout 0.1
     ts._rng = np.random.RandomState(99)               # same timestep sequence on every rank / run
+    return ts, sal, cond
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
 
+def _dist_on():
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
+def timed_train_region(ts, sal, cond, steps, dev, profile_last=False):
+    """exactly `steps` training steps between barrier + synchronize on both sides; MAX over ranks.  Returns (seconds, last loss,
+    events of the last step if profile_last)."""
+    import torch.distributed as dist
+
+    from diff_sal_amd import ops
+
+    ev = []
+    torch.cuda.synchronize()
+    if _dist_on():
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(steps):
+        if profile_last and i == steps - 1:
+            ops.PROFILE = []
+        loss = ts.step(sal, cond)
+    if ops.PROFILE is not None:
+        ev, ops.PROFILE = ops.PROFILE, None
+    torch.cuda.synchronize()
+    if _dist_on():
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if _dist_on():
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el, loss, ev
+
+
+def exchange_report(ts, sal, cond, steps, dev, world, ms_with):
+    """What the ONE collective of the training step costs and how much of it the backward hides (north_star: a single RCCL grad
+    all-reduce over xGMI): payload, blocking time of each bucket's all-reduce measured alone, the step re-timed with the
+    exchange switched off, and from the two the exposed time and the overlap fraction.  Also whether the replicas stayed
+    bit-identical (MIN / MAX all-reduce of a parameter checksum) -- taken BEFORE the exchange is switched off."""
+    import torch.distributed as dist
+
+    flat, red = ts.flat, ts.reducer
+    rep = {"backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if _dist_on() else "none",
+           "world": world, "collective_executed": bool(_dist_on() and red.exchange),
+           "bytes_per_step_per_rank": int(flat.numel * 4), "buckets_mb": [round(len(r) * 4 / 2 ** 20, 2) for r in flat.buckets]}
+    chk = torch.stack([flat.flat_p.double().sum(), flat.flat_p.double().abs().sum()])
+    lo, hi = chk.clone(), chk.clone()
+    if _dist_on():
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    rep["replicas_identical"] = bool(torch.equal(lo, hi))
+    rep["param_checksum"] = [float(chk[0].item()), float(chk[1].item())]
+    if not (_dist_on() and red.exchange):
+        rep.update(allreduce_ms_per_bucket=None, ms_per_step_without_exchange=None, exposed_ms=None, overlap_frac=None)
+        return rep
+    scratch = torch.zeros_like(flat.flat_g)
+    per = []
+    for r in flat.buckets:          # blocking all-reduce of each bucket, alone on the GPU: median of 5
+        v = scratch[r.start:r.stop]
+        ts_ = []
+        for _ in range(6):
+            torch.cuda.synchronize()
             dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ts.group)
+            torch.cuda.synchronize()
+            ts_.append((time.perf_counter() - t0) * 1e3)
+        per.append(round(median(ts_[1:]), 4))
+    rep["allreduce_ms_per_bucket"] = per
+    total = sum(per)
+    gbytes = flat.numel * 4 / 1e9
+    rep["allreduce_ms_total"] = round(total, 4)
+    # ring all-reduce moves 2 (w-1)/w of the payload over each rank's links
+    rep["allreduce_bus_gbs"] = round(gbytes * 2 * (world - 1) / max(world, 1) / (total * 1e-3), 2) if total > 0 and world > 1 else None
+    red.exchange = False            # same step, no collective (the replicas drift apart from here on: last measurement)
+    try:
+        ts.broadcast_buffers, keep_bb = False, ts.broadcast_buffers
+        ts.step(sal, cond)
+        el, _, _ = timed_train_region(ts, sal, cond, steps, dev)
+    finally:
+        red.exchange, ts.broadcast_buffers = True, keep_bb
+    ms_without = el / steps * 1e3
+    exposed = max(0.0, ms_with - ms_without)
+    rep["ms_per_step_without_exchange"] = round(ms_without, 4)
+    rep["exposed_ms"] = round(exposed, 4)
+    rep["overlap_frac"] = round(max(0.0, min(1.0, 1.0 - exposed / total)), 4) if total > 0 else None
+    return rep
 
+
+def train_leg(cfg, dev, rank, world, *, steps=10, warmup=3, batch=4):
+    """The `train` object of the default bench line (every N): BASELINE configs[3] -- full-model audio-visual training step,
+    per-GPU batch 4, weak scaling -- so that one `bench.py --gpus N` run also answers north_star's multi-GPU training
+    question.  At N = 1 a single-rank RCCL group is created so that the collective code path (bucket hooks -> asynchronous
+    all_reduce -> buffer broadcast) executes on hardware too."""
+    import torch.distributed as dist
+
+    own_group = False
+    note = None
+    if not _dist_on():
+        try:
+            import socket
+            from datetime import timedelta
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    timeout=timedelta(minutes=5))
+            own_group = True
+        except Exception as e:  # noqa: BLE001
+            note = f"single-rank RCCL group could not be created ({type(e).__name__}: {e}); step timed without a collective"
+    try:
+        net, _ = build_net(cfg, dev)
+        H, W = cfg.img_size
+        ts, sal, cond = build_train_step(cfg, net, None, None, dev, rank, batch=batch, av=True, full=True,
+                                         exchange_single_rank=True)
+        for _ in range(max(warmup, 1)):
+            ts.step(sal, cond)
+        el, loss, _ = timed_train_region(ts, sal, cond, steps, dev)
+        ms = el / steps * 1e3
+        out = {"what": "BASELINE configs[3]: audio-visual training step of the WHOLE model (MViTv2-S fwd+bwd, frozen VGGish, "
+                       "AudioAttnNet fwd+bwd, SalUNet fwd+bwd; MSE, one bucketed gradient all-reduce, clip 1.0, Adam), "
+                       f"per-GPU batch {batch} (global {world * batch}), 224x384, fp32, synthetic data; not the headline metric",
+               "value": round(world * batch * steps / el, 3), "unit": "samples/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": round(ms, 4), "scaling": "weak", "batch_per_gpu": batch,
+               "trainable_params": ts.flat.live_numel, "grad_buckets": len(ts.flat.buckets), "final_loss": float(loss.item())}
+        out["exchange"] = exchange_report(ts, sal, cond, steps, dev, world, ms)
+        if note:
+            out["note"] = note
+        return out
+    finally:
+        if own_group and _dist_on():
+            dist.destroy_process_group()
+
+
+def bench_train(args, net, cfg, feats, audio, dev, rank, world):
+    """BASELINE configs[3]: the diffusion training step of the denoiser on a per-GPU batch (weak scaling)."""
+    B, av = args.batch, args.mode == "av"
+    full = args.train_scope == "full"
+    ts, sal, cond = build_train_step(cfg, net, feats, audio, dev, rank, batch=B, av=av, full=full)
     for _ in range(max(args.warmup, 1)):
         ts.step(sal, cond)
     regions, ev = [], []
     for rep_i in range(args.repeats):      # each region: exactly K steps between barrier + synchronize; MAX over ranks
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            if rep_i == args.repeats - 1 and i == args.steps - 1:
-                ops.PROFILE = []
-            loss = ts.step(sal, cond)
-        if ops.PROFILE is not None:
-            ev, ops.PROFILE = ops.PROFILE, None
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+        el, loss, e = timed_train_region(ts, sal, cond, args.steps, dev, profile_last=rep_i == args.repeats - 1)
+        ev = e or ev
         regions.append(el)
     elapsed = median(regions)
     if args.dump_launches and rank == 0:     # per-launch table of the profiled step (shape -> TF/s, GB/s)
@@ -287,6 +476,7 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
                    "batch_per_gpu": B, "trainable_params": ts.flat.live_numel, "grad_buckets": len(ts.flat.buckets),
                    "exchange": "RCCL all-reduce of the flat fp32 gradient, bucketed, overlapped with backward",
                    "final_loss": float(loss.item())},
+        "exchange": exchange_report(ts, sal, cond, args.steps, dev, world, elapsed / args.steps * 1e3),
         "repeats": args.repeats, "ms_per_step_all_regions": [round(r / args.steps * 1e3, 4) for r in regions],
         "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
         "roofline": {"kernel": "diffsal::igemm_kernel + wgrad_kernel (fp32 MFMA: forward, data-gradient and "
@@ -333,6 +523,10 @@ def main():
     ap.add_argument("--dump-launches", default=None,
                     help="write every operator launch of the profiled step (class, GFLOP, MB, us, TF/s, GB/s) to this JSON file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the `train` object (BASELINE configs[3]: ~10 full-model AV training steps per rank, with the "
+                         "gradient exchange report) that the default line carries at every N")
+    ap.add_argument("--train-leg-steps", type=int, default=10)
     ap.add_argument("--no-encoders", action="store_true", help="skip the end-to-end (encoders + 50 steps) leg")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32,
@@ -681,6 +875,14 @@ def main():
             "what": "encoders once per clip batch + 50 denoising steps, all on the HIP path (not the headline metric)",
             "encoder_ms_per_batch": enc_ms, "denoise_ms_per_batch": round(denoise_ms, 3),
             "clips_per_s": round(B / (total_ms * 1e-3), 3), "encoder_share": round(sum(enc_ms.values()) / total_ms, 4)}
+    if args.precision == "fp32" and not special and not args.no_train_leg:
+        # every rank takes part (the gradient all-reduce is the one collective of the repo); the sampling network and its
+        # inputs are released first
+        net.forward, net.forward_fused_update = inner, inner_fused
+        try:
+            result["train"] = train_leg(cfg, dev, rank, world, steps=args.train_leg_steps, warmup=3, batch=4)
+        except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of the extra leg)
+            result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: a few B-clip oracle evaluations (the per-step network cost dominates a trajectory).
         # This leg is the ONLY place the CPU oracle is touched; it gets the same weights and inputs as the GPU path.

@@ -26,12 +26,14 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 SIGNATURES = {
     "diffsal_version": (c_i, []),
     "diffsal_last_error": (C.c_char_p, []),
+    "diffsal_set_tuning": (c_i, [C.c_char_p, c_i]),
+    "diffsal_get_tuning": (c_i, [C.c_char_p]),
     "diffsal_temb_mlp": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "diffsal_dense_small": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f]),
     "diffsal_conv_in": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
@@ -170,3 +172,12 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().diffsal_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libdiffsal_hip {what} failed (code {rc}): {msg}")
+
+
+def set_tuning(name: str, value) -> None:
+    """Set a test / tuning switch of the library (include/diffsal.h: diffsal_set_tuning); None or a negative value unsets it."""
+    check(load().diffsal_set_tuning(name.encode(), -1 if value is None else int(value)), "set_tuning")
+
+
+def get_tuning(name: str) -> int:
+    return load().diffsal_get_tuning(name.encode())

@@ -28,19 +28,45 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _jobs():
+    """Concurrent hipcc processes: DIFFSAL_BUILD_JOBS, else half the host's cores (each compile needs a few hundred MB)."""
+    env = os.environ.get("DIFFSAL_BUILD_JOBS")
+    if env and env.isdigit() and int(env) > 0:
+        return int(env)
+    return max(1, min(len(SOURCES), (os.cpu_count() or 2) // 2))
+
+
+def _stale(src, obj, common_deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in [src] + common_deps)
+
+
 def build_library(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared object next to the package."""
+    """Compile the HIP sources for gfx950 into one shared object next to the package.  Only translation units whose object
+    is older than the source or a shared header are recompiled; at most _jobs() hipcc processes run at a time.  Extra compiler
+    flags (e.g. -DDIFFSAL_DEV_STAMPS for tools/probe_halo_stamps.py) come from DIFFSAL_EXTRA_HIPCC_FLAGS."""
     if not force and not needs_build():
         return LIB
-    objs, procs = [], []
-    for s in SOURCES:  # one hipcc per translation unit, all at once (8 files, a few hundred MB each)
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
+    common = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "diffsal.h")]
+    extra = os.environ.get("DIFFSAL_EXTRA_HIPCC_FLAGS", "").split()
+    objs, todo = [], []
+    for s in SOURCES:
+        src, o = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-    failed = [cmd for cmd, pr in procs if pr.wait() != 0]
+        if force or extra or _stale(src, o, common):
+            todo.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", src, "-o", o])
+    running, failed, jobs = [], [], _jobs()
+    while todo or running:
+        while todo and len(running) < jobs:
+            cmd = todo.pop(0)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, pr = running.pop(0)
+        if pr.wait() != 0:
+            failed.append(cmd)
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

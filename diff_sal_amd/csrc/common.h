@@ -33,6 +33,15 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Test / tuning switches ("Environment switches").  The environment is read ONCE, when the library is loaded; afterwards
+// a switch changes only through diffsal_set_tuning() -- no getenv on a launch path, and no way for an inherited variable to
+// reach a kernel argument.  tune(key) < 0 means "unset".
+enum TuneKey {
+  TUNE_NO_PERSIST = 0, TUNE_NO_XCD_ORDER, TUNE_NO_HALO, TUNE_FORCE_HALO, TUNE_IGEMM_CFG, TUNE_IGEMM16_CFG, TUNE_PLAN_DEBUG,
+  TUNE_WGRAD_CFG, TUNE_WGRAD_SPLITS, TUNE_WGRAD_VERBOSE, TUNE_NO_FUSED_BLOCK, TUNE_COUNT
+};
+int tune(int key);
+
 // Butterfly all-reduce over `width` (power of two <= 64) consecutive lanes.
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {

@@ -50,8 +50,15 @@ struct HaloArgs {
   int N, H, W, Cin, Cout, K;   // K = 9 * Cin
   int dil, act, rowvec_ld;
   int tiles_x, tiles_y, tiles_n;
-  unsigned long long* stamps;   // development aid: per-workgroup phase time stamps (DIFFSAL_HALO_STAMPS), normally null
+#ifdef DIFFSAL_DEV_STAMPS
+  unsigned long long* stamps;   // development build only: per-workgroup phase time stamps (diffsal_set_halo_stamps)
+#endif
 };
+
+#ifdef DIFFSAL_DEV_STAMPS
+static unsigned long long* g_halo_stamps = nullptr;
+static size_t g_halo_stamp_bytes = 0;
+#endif
 
 constexpr int HP = 40;   // elements per staged pixel / weight row: 32 data + 8 pad (80 bytes)
 
@@ -73,7 +80,11 @@ __global__ __launch_bounds__(NW * 64) void conv16_halo_kernel(HaloArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DIFFSAL_DEV_STAMPS
   auto stamp = [&](int k) { if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + k] = wall_clock64(); };
+#else
+  auto stamp = [](int) {};
+#endif
   stamp(0);
   // block -> (image, tile_y, tile_x, n tile); consecutive blocks share the patch's neighbourhood and the same weights
   int b;
@@ -305,8 +316,16 @@ static int run_halo(const diffsal_conv_desc* d, const void* in, const void* w, c
   a.rowvec = rowvec; a.residual = static_cast<const T*>(residual); a.out = static_cast<T*>(out);
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.K = 9 * d->Cin; a.dil = d->dil_h; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
-  a.stamps = nullptr;
-  if (const char* e = getenv("DIFFSAL_HALO_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
+#ifdef DIFFSAL_DEV_STAMPS
+  a.stamps = g_halo_stamps;
+  if (a.stamps) {   // 8 stamps per workgroup: refuse a buffer the launch would overrun
+    bool wide_, n128_;
+    halo_tiles(d, &wide_, &n128_);
+    const long tw_ = wide_ ? 32 : 16, tn_ = (n128_ ? 4 : 3) * 32;
+    const long blocks = static_cast<long>(d->N) * ((d->H + 15) / 16) * ((d->W + tw_ - 1) / tw_) * ((d->Cout + tn_ - 1) / tn_);
+    if (static_cast<size_t>(blocks) * 8 * sizeof(unsigned long long) > g_halo_stamp_bytes) a.stamps = nullptr;
+  }
+#endif
   bool wide, n128;
   halo_tiles(d, &wide, &n128);
   if (wide) return n128 ? launch_halo<32, 8, 4, T>(a, s) : launch_halo<32, 8, 3, T>(a, s);
@@ -316,8 +335,8 @@ static int run_halo(const diffsal_conv_desc* d, const void* in, const void* w, c
 // 1 if the halo kernel handles this descriptor (16-bit storage assumed), else 0
 int conv16_halo_applies(const diffsal_conv_desc* d) {
   bool force = false;
-  if (const char* e = getenv("DIFFSAL_NO_HALO")) { if (e[0] == '1') return 0; }
-  if (const char* e = getenv("DIFFSAL_FORCE_HALO")) force = (e[0] == '1');
+  if (tune(TUNE_NO_HALO) == 1) return 0;
+  force = tune(TUNE_FORCE_HALO) == 1;
   const bool shape_ok = d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
                         (d->dil_h == 1 || d->dil_h == 2) && d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H &&
                         d->Wo == d->W && d->Cin % 32 == 0 && d->Cout % 4 == 0 && d->H >= 8 && d->W >= 16 && d->Cout >= 64;
@@ -344,3 +363,13 @@ int conv16_halo_launch(const diffsal_conv_desc* d, const void* in, const void* w
 }
 
 }  // namespace diffsal
+
+#ifdef DIFFSAL_DEV_STAMPS
+// Development builds only (hipcc -DDIFFSAL_DEV_STAMPS; tools/probe_halo_stamps.py): a caller-owned device buffer receives 8 time
+// stamps per workgroup of every following halo launch that fits in `bytes`; (nullptr, 0) turns it off.  Not in the shipped ABI.
+extern "C" int diffsal_set_halo_stamps(void* device_buffer, size_t bytes) {
+  diffsal::g_halo_stamps = static_cast<unsigned long long*>(device_buffer);
+  diffsal::g_halo_stamp_bytes = device_buffer ? bytes : 0;
+  return DIFFSAL_OK;
+}
+#endif

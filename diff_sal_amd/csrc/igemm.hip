@@ -879,8 +879,7 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
   const unsigned nz = a.pair ? 2u : 1u;
   if (precision != DIFFSAL_PREC_BF16X3 && a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0 && !a.pair) {
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
-    const char* e_xcd = getenv("DIFFSAL_NO_XCD_ORDER");
-    const bool no_xcd = e_xcd && e_xcd[0] == '1';
+    const bool no_xcd = tune(TUNE_NO_XCD_ORDER) == 1;
     a.xcd_order = (!no_xcd && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm_linear_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, s, a);
     return check_launch("diffsal_conv_igemm(linear)");
@@ -991,12 +990,12 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
   Plan pl = choose_plan(M, d->Cout, a.K, d->precision, a.linear != 0);
-  if (const char* e = getenv("DIFFSAL_IGEMM_CFG")) {   // tuning aid: force a tile shape (no split-K)
-    pl.cfg = atoi(e) % kNumCfgs;
+  if (tune(TUNE_IGEMM_CFG) >= 0) {   // tuning aid: force a tile shape (no split-K)
+    pl.cfg = tune(TUNE_IGEMM_CFG) % kNumCfgs;
     pl.splits = 1;
   }
-  if (const char* e = getenv("DIFFSAL_PLAN_DEBUG")) {   // tuning aid: which tile shape / split the planner chose
-    if (e[0] == '1') fprintf(stderr, "[diffsal plan] M=%ld K=%d N=%d linear=%d -> %dx%d splits=%d\n", M, a.K, d->Cout, a.linear,
+  if (tune(TUNE_PLAN_DEBUG) == 1) {   // tuning aid: which tile shape / split the planner chose
+    fprintf(stderr, "[diffsal plan] M=%ld K=%d N=%d linear=%d -> %dx%d splits=%d\n", M, a.K, d->Cout, a.linear,
                              kCfgs[pl.cfg].bm, kCfgs[pl.cfg].bn, pl.splits);
   }
   a.splits = pl.splits;
@@ -1015,7 +1014,7 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
                    (!scale || (aligned16(scale) && aligned16(shift))) && (!rowvec || (aligned16(rowvec) && a.rowvec_ld % 4 == 0));
   if (px) a.vec_epilogue = a.vec_epilogue && aligned16(px->out2) && (!px->bias2 || aligned16(px->bias2));
   a.persist_wgs = kCUs * kCfgs[pl.cfg].occ;
-  if (const char* e = getenv("DIFFSAL_NO_PERSIST")) { if (e[0] == '1') a.persist_wgs = 0; }
+  if (tune(TUNE_NO_PERSIST) == 1) a.persist_wgs = 0;
   switch (pl.cfg) {
     case 0: return launch<2, 2, 2, 3>(a, s, d->precision);
     case 1: return launch<2, 2, 2, 2>(a, s, d->precision);

@@ -689,8 +689,8 @@ int conv16_halo_launch(const diffsal_conv_desc* d, const void* in, const void* w
 static Plan16 plan_for(const diffsal_conv_desc* d) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   Plan16 pl = choose_plan16(M, d->Cout, d->KH * d->KW * d->Cin);
-  if (const char* e = getenv("DIFFSAL_IGEMM16_CFG")) {  // tuning aid: force a tile shape (no split-K)
-    pl.cfg = atoi(e) % kNumCfgs16;
+  if (tune(TUNE_IGEMM16_CFG) >= 0) {  // tuning aid: force a tile shape (no split-K)
+    pl.cfg = tune(TUNE_IGEMM16_CFG) % kNumCfgs16;
     pl.splits = 1;
   }
   if (conv16_halo_applies(d)) pl.splits = 1;   // halo-eligible shapes report no workspace; keep the pointer-alignment fallback valid
@@ -747,7 +747,7 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
                      al(rowvec, 15) && (!rowvec || a.rowvec_ld % 4 == 0) && al(a.partial, 15) && al(out2, 7) && al(bias2, 15);
   }
   a.persist_wgs = kCUs16 * kCfgs16[pl.cfg].occ;
-  if (const char* e = getenv("DIFFSAL_NO_PERSIST")) { if (e[0] == '1') a.persist_wgs = 0; }
+  if (tune(TUNE_NO_PERSIST) == 1) a.persist_wgs = 0;
   switch (pl.cfg) {
     case 0: return launch16<2, 2, 2, 3, T>(a, s);
     case 1: return launch16<2, 2, 2, 2, T>(a, s);

@@ -149,7 +149,8 @@ extern "C" size_t diffsal_saliency_metrics_ws_bytes(int B) {
 extern "C" int diffsal_saliency_metrics(const float* pred, const float* gt, int B, long n, void* ws, size_t ws_bytes,
                                         float* per_image, float* mean_out, diffsal_stream_t stream) {
   DS_REQUIRE(pred && gt && ws && mean_out, DIFFSAL_E_ARG, "saliency_metrics: null argument");
-  DS_REQUIRE(B > 0 && B <= 4096 && n > 1, DIFFSAL_E_SHAPE, "saliency_metrics: bad shape B=%d n=%ld", B, n);
+  // the final kernel keeps 4 doubles per image in LDS (64 KiB without opting in to more): 2048 images per call
+  DS_REQUIRE(B > 0 && B <= 2048 && n > 1, DIFFSAL_E_SHAPE, "saliency_metrics: bad shape B=%d (1..2048) n=%ld", B, n);
   DS_REQUIRE(ws_bytes >= diffsal_saliency_metrics_ws_bytes(B) && aligned16(ws), DIFFSAL_E_ARG,
              "saliency_metrics: workspace too small or misaligned");
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -2,6 +2,9 @@
 // bilinear resizes, audio fusion, the pooled-KV attention core, the sigmoid head and the sampler axpy.
 #include "common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace diffsal {
 
 static thread_local char g_err[512] = "";
@@ -11,6 +14,20 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static const char* const kTuneNames[TUNE_COUNT] = {
+    "DIFFSAL_NO_PERSIST", "DIFFSAL_NO_XCD_ORDER", "DIFFSAL_NO_HALO", "DIFFSAL_FORCE_HALO", "DIFFSAL_IGEMM_CFG",
+    "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
+    "DIFFSAL_NO_FUSED_BLOCK"};
+static int g_tune[TUNE_COUNT];
+static const bool g_tune_init = [] {
+  for (int k = 0; k < TUNE_COUNT; ++k) {
+    const char* e = getenv(kTuneNames[k]);
+    g_tune[k] = (e && e[0]) ? atoi(e) : -1;
+  }
+  return true;
+}();
+int tune(int key) { return (key >= 0 && key < TUNE_COUNT) ? __atomic_load_n(&g_tune[key], __ATOMIC_RELAXED) : -1; }
 
 // ------------------------------------------------------------------------------------------------
 // K1: sinusoidal embedding + dense0 + swish (this kernel), then dense1 through dense_small_kernel.
@@ -640,8 +657,25 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 14; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 15; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
+
+extern "C" int diffsal_set_tuning(const char* name, int value) {
+  DS_REQUIRE(name, DIFFSAL_E_ARG, "set_tuning: null name");
+  for (int k = 0; k < TUNE_COUNT; ++k)
+    if (strcmp(name, kTuneNames[k]) == 0) {
+      __atomic_store_n(&g_tune[k], value, __ATOMIC_RELAXED);
+      return DIFFSAL_OK;
+    }
+  set_error("set_tuning: unknown switch '%s'", name);
+  return DIFFSAL_E_ARG;
+}
+extern "C" int diffsal_get_tuning(const char* name) {
+  if (name)
+    for (int k = 0; k < TUNE_COUNT; ++k)
+      if (strcmp(name, kTuneNames[k]) == 0) return tune(k);
+  return -1;
+}
 
 extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, const float* freq, const float* w0,
                                 const float* b0, const float* w1, const float* b1, float* hidden_ws, float* temb_out,

@@ -272,7 +272,7 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
   double best = 1e300;
   const long max_splits = (seg_rows + 127) / 128;
   int only = -1;
-  if (const char* e = getenv("DIFFSAL_WGRAD_CFG")) only = atoi(e) % kNumWgradCfgs;   // tuning aid
+  if (tune(TUNE_WGRAD_CFG) >= 0) only = tune(TUNE_WGRAD_CFG) % kNumWgradCfgs;   // tuning aid
   for (int c = 0; c < kNumWgradCfgs; ++c) {
     if (only >= 0 && c != only) continue;
     const WgradCfg cf = kWgradCfgs[c];
@@ -295,13 +295,13 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
       if (t < best) { best = t; pl.cfg = c; pl.splits = static_cast<int>(sp); pl.rows_per_split = static_cast<int>(rps); }
     }
   }
-  if (const char* e = getenv("DIFFSAL_WGRAD_SPLITS")) {   // tuning aid
-    long sp = atol(e);
+  if (tune(TUNE_WGRAD_SPLITS) > 0) {   // tuning aid
+    long sp = tune(TUNE_WGRAD_SPLITS);
     sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
     pl.splits = static_cast<int>(sp);
     pl.rows_per_split = static_cast<int>(((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM);
   }
-  if (getenv("DIFFSAL_WGRAD_VERBOSE"))
+  if (tune(TUNE_WGRAD_VERBOSE) == 1)
     fprintf(stderr, "wgrad plan: Cout=%d K=%ld seg_rows=%ld segs=%d -> cfg %d splits %d rows/split %d model %.0f cycles\n",
             Cout, K, seg_rows, segments, pl.cfg, pl.splits, pl.rows_per_split, best);
   return pl;

@@ -39,9 +39,11 @@ class EMAHelper(object):
         for name, param in _unwrap(module).named_parameters():
             if param.requires_grad:
                 param.data.copy_(self.shadow[name].data)
-        m = _unwrap(module)
-        if hasattr(m, "parameters_updated"):       # packed GEMM weights of this package's modules follow the parameters
-            m.parameters_updated()
+        # `param.data.copy_` does not move the version counters the packed-weight caches key on: tell EVERY module of the tree
+        # (a VideoSaliencyModel nests the denoiser and the encoders) that its parameters changed
+        for m in _unwrap(module).modules():
+            if hasattr(m, "parameters_updated"):
+                m.parameters_updated()
 
     def ema_copy(self, module):
         inner = _unwrap(module)

@@ -126,6 +126,7 @@ class MViT(nn.Module):
         self._tables: Dict = {}
         self._pack: Optional[Dict[str, Tensor]] = None
         self._pack_key = None
+        self._pack_epoch = 0
         self._init_weights(rel_pos_zero_init)
         if pretrained:
             self.init_weights(pretrained)
@@ -158,7 +159,14 @@ class MViT(nn.Module):
 
     # ------------------------------------------------------------------ weight / table packing
     def _key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def parameters_updated(self) -> None:
+        """Parameters were rewritten behind autograd's version counters (the fused Adam kernel writes the flat buffer through
+        raw pointers; ``param.data.copy_`` does not bump ``_version`` either): the packed patch / pooling weights and the
+        gathered relative-position tables are rebuilt on next use."""
+        self._pack_epoch += 1
+        self._pack, self._pack_key, self._tables = None, None, {}
 
     def packed(self) -> Dict[str, Tensor]:
         key = self._key()

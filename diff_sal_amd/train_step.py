@@ -125,9 +125,13 @@ class GradReducer:
     ``finish()`` handles whatever is left (buckets holding parameters that received no gradient this step) and
     waits for all of them."""
 
-    def __init__(self, flat: FlatParams, group=None):
+    def __init__(self, flat: FlatParams, group=None, exchange_single_rank: bool = False):
         self.flat, self.group = flat, group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        have_group = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if have_group else 1
+        # whether the collective is issued: always with more than one rank; with ONE rank only on request (the call path --
+        # hook, bucket gather, asynchronous all_reduce, wait -- then runs unchanged, RCCL reducing over a single rank)
+        self.exchange = self.world > 1 or (have_group and bool(exchange_single_rank))
         self._pending: List[int] = []
         self._launched: List[bool] = []
         self._work = []
@@ -153,7 +157,7 @@ class GradReducer:
         r = self.flat.buckets[b]
         self.launch_order.append(b)
         self.flat.gather(self.flat.bucket_members[b])
-        if self.world > 1:
+        if self.exchange:
             self._work.append(dist.all_reduce(self.flat.flat_g[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
 
@@ -183,7 +187,7 @@ class DiffusionTrainStep:
                  beta_schedule: str = "cosine", beta_start: float = 1e-4, beta_end: float = 0.02,
                  num_diffusion_timesteps: int = 1000, gaussian_dequantization: bool = True,
                  bucket_mb: float = 32.0, process_group=None, broadcast_buffers: bool = True,
-                 store_clipped_grad: bool = False):
+                 store_clipped_grad: bool = False, exchange_single_rank: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(beta1), float(beta2)), float(eps), float(weight_decay)
         self.grad_clip, self.mse_weight = float(grad_clip), float(mse_weight)
@@ -197,9 +201,9 @@ class DiffusionTrainStep:
         self.num_timesteps = int(betas.shape[0])
         self.flat = FlatParams(model, int(bucket_mb * (1 << 20)))
         self.group = process_group
-        self.reducer = GradReducer(self.flat, process_group)
+        self.reducer = GradReducer(self.flat, process_group, exchange_single_rank)
         self.world = self.reducer.world
-        self.broadcast_buffers = bool(broadcast_buffers) and self.world > 1
+        self.broadcast_buffers = bool(broadcast_buffers) and self.reducer.exchange
         self.step_count = 0
         self.last_norm: Optional[Tensor] = None
         self._rng = np.random  # the reference draws t0 from numpy's global generator (diffusion_trainer.py:111)

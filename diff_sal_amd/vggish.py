@@ -41,6 +41,7 @@ class VGGish(nn.Module):
                                         nn.Linear(4096, 128), nn.ReLU(True))
         self._pack = None
         self._pack_key = None
+        self._pack_epoch = 0
         # The reference runs this module under torch.no_grad() (R/models/diff_model.py:73-74): its 72 M parameters never
         # receive a gradient, yet DDP buckets and all-reduces them.  Freeze them so that optimizers / gradient exchanges
         # built on `requires_grad` skip them (state_dict is unaffected).
@@ -50,8 +51,12 @@ class VGGish(nn.Module):
                 raise FileNotFoundError(f"VGGish(pretrained=True) loads {self.PRETRAINED} as the reference does; not found")
             self.load_state_dict(torch.load(self.PRETRAINED, map_location="cpu"))
 
+    def parameters_updated(self) -> None:
+        """Parameters were rewritten without a version bump (``param.data.copy_``, raw-pointer writes): repack on next use."""
+        self._pack_epoch += 1
+
     def _packed(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.features.parameters())
+        key = (self._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in self.features.parameters())
         if self._pack is None or key != self._pack_key:
             pk = {}
             for i, m in enumerate(self.features):

@@ -42,6 +42,14 @@ enum { DIFFSAL_ACT_NONE = 0, DIFFSAL_ACT_RELU = 1, DIFFSAL_ACT_GELU_ERF = 2, DIF
 int diffsal_version(void);
 const char* diffsal_last_error(void);
 
+/* Test / tuning switches (kernel-variant selection for bit-equality tests and tile sweeps; none changes results beyond
+ * summation order).  The DIFFSAL_* environment variables of the same names are read ONCE when the library is loaded; afterwards
+ * only this call changes a switch (value < 0 = unset).  Names: DIFFSAL_NO_PERSIST, DIFFSAL_NO_XCD_ORDER, DIFFSAL_NO_HALO,
+ * DIFFSAL_FORCE_HALO, DIFFSAL_IGEMM_CFG, DIFFSAL_IGEMM16_CFG, DIFFSAL_PLAN_DEBUG, DIFFSAL_WGRAD_CFG, DIFFSAL_WGRAD_SPLITS,
+ * DIFFSAL_WGRAD_VERBOSE, DIFFSAL_NO_FUSED_BLOCK.  Not part of the reference's surface (it has no such knobs). */
+int diffsal_set_tuning(const char* name, int value);
+int diffsal_get_tuning(const char* name);   /* current value, -1 if unset or unknown */
+
 /* ---- K1: timestep embedding + MLP ------------------------------------------------------
  * R/models/saliency_decoder/sal_unet.py:15-33 (get_timestep_embedding) and :304-307.
  * t: [B] int64 (t_is_f32 == 0) or float (t_is_f32 == 1); freq: [ch/2] table exp(-j*ln(1e4)/(ch/2-1)).

@@ -293,6 +293,66 @@ def gen_trainer_ddim():
     print("dpm50: out range", xe.min().item(), xe.max().item())
 
 
+def gen_full_size():
+    """Full-resolution pins asked for by the round-2 review: (1) configs[1]'s real shape -- visual-only, B = 4, 224x384 -- with
+    every intermediate tap (the final output is blind to the noise path there, F1, so the taps carry the check);
+    (2) a 50-NFE DPM-Solver trajectory (multistep-2, logSNR, denoise-to-zero, x_start) through the REAL reference network
+    at 224x384 in audio-visual mode: strided samples of the solver state at network evaluations 0 / 1 / 10 / 25 / 49 and
+    the final x (R/models/dpm_solver/sampler.py:1174-1215, R/diffusion_trainer.py:582-636 with D1-D4 fixed)."""
+    cfg = orc.SalUNetConfig()
+    net, sd = build_reference(cfg)
+    B = 4
+    t = torch.tensor([998.996, 612.25, 140.5, 0.46], dtype=torch.float32)
+    x, feats, _ = orc.synth_inputs(cfg, B, False, tag="full_vis_b4")
+    out, taps = run_reference(net, x, t, feats, None)
+    otaps = {}
+    with torch.no_grad():
+        mine = orc.salunet_forward(sd, cfg, x, t, feats, None, taps=otaps)
+    err = (mine - out).abs().max().item()
+    print(f"[full_vis_b4] ref-vs-restatement max|d| = {err:.3e}")
+    assert err < 2e-5, err
+    for k in taps:
+        e = (otaps[k] - taps[k]).abs().max().item() / (taps[k].abs().max().item() + 1e-12)
+        assert e < 2e-5, (k, e)
+    d = dict(output=out[:, :, ::2, ::2].numpy().copy(), output_stride=np.array(2), t=t.numpy(), batch=np.array(B),
+             audio=np.array(0), weights_checksum=np.array(checksum(sd)),
+             inputs_checksum=np.array(float(x.double().abs().sum() + sum(f.double().abs().sum() for f in feats))))
+    d.update(pack_taps(taps, samples=8192))
+    np.savez_compressed(os.path.join(GOLD, "salunet_full_vis_b4.npz"), **d)
+
+    from models.diffusion_decoder.diffusion_utils import get_beta_schedule
+    from models.dpm_solver.sampler import DPM_Solver, NoiseScheduleVP, model_wrapper
+
+    betas = torch.from_numpy(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)).float()
+    nsched = NoiseScheduleVP("discrete", betas=betas)
+    x, feats, audio = orc.synth_inputs(cfg, 1, True, tag="dpm50_full")
+    keep = (0, 1, 10, 25, 49)
+    seen, calls = {}, [0]
+
+    def model_fn(xx, tt, vis, **kw):
+        if calls[0] in keep:
+            seen[calls[0]] = (xx.detach().clone(), tt.detach().clone())
+        calls[0] += 1
+        return net(xx, tt, [v.clone() for v in vis], audio)
+
+    fn = model_wrapper(model_fn, nsched, model_type="x_start", model_kwargs={}, guidance_type="uncond")
+    solver = DPM_Solver(fn, nsched, algorithm_type="dpmsolver")
+    with torch.no_grad():
+        xe = solver.sample(x, feats, steps=49, order=2, skip_type="logSNR", method="multistep",
+                           lower_order_final=False, denoise_to_zero=True, solver_type="dpmsolver")
+    assert calls[0] == 50, calls
+    d = dict(output=xe.numpy(), nfe=np.array(calls[0]), weights_checksum=np.array(checksum(sd)),
+             inputs_checksum=np.array(float(x.double().abs().sum() + sum(f.double().abs().sum() for f in feats)
+                                            + audio.double().abs().sum())))
+    for k, (xx, tt) in seen.items():
+        flat = xx.reshape(-1)
+        d[f"x{k}.sample"] = flat[::21].numpy().copy()
+        d[f"x{k}.stats"] = np.array([flat.double().mean().item(), flat.double().std().item(), flat.abs().max().item()])
+        d[f"x{k}.t_input"] = tt.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "dpm50_full_av_b1.npz"), **d)
+    print("dpm50 full: out range", xe.min().item(), xe.max().item(), "t inputs", [float(seen[k][1][0]) for k in keep])
+
+
 def gen_train_step():
     """One training step of the REAL reference denoiser in .train() mode (batch-statistics BatchNorm, running-stat
     update), dropout probability set to 0 (masks cannot be reproduced), x0-prediction MSE
@@ -565,7 +625,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio", "legacy_unet"]
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio", "legacy_unet", "full"]
     if "legacy" in which:
         gen_legacy_denoising()
     if "legacy_unet" in which:
@@ -586,3 +646,5 @@ if __name__ == "__main__":
         gen_trainer_ddim()
     if "train" in which:
         gen_train_step()
+    if "full" in which:
+        gen_full_size()

@@ -17,3 +17,30 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+class _Tuning:
+    """Test / tuning switches of the HIP library (diffsal_set_tuning); everything set through the fixture is unset afterwards."""
+
+    def __init__(self):
+        self._touched = set()
+
+    def set(self, name, value):
+        from diff_sal_amd import _lib
+
+        self._touched.add(name)
+        _lib.set_tuning(name, value)
+
+    def reset(self):
+        from diff_sal_amd import _lib
+
+        for n in self._touched:
+            _lib.set_tuning(n, None)
+        self._touched.clear()
+
+
+@pytest.fixture
+def tuning():
+    t = _Tuning()
+    yield t
+    t.reset()

@@ -229,3 +229,68 @@ def ts_betas():
     from diff_sal_amd.diffusion_utils import get_beta_schedule, to_torch
 
     return to_torch(get_beta_schedule("cosine", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000))
+
+
+def test_eval_after_training_uses_the_trained_encoder_weights():
+    """The fused Adam kernel writes parameters through the flat buffer (no autograd version bump): the eval-mode caches of
+    EVERY module (MViT's packed patch / pooling weights and gathered relative-position tables, not only the denoiser's GEMM
+    weights) must be rebuilt.  After training steps the no_grad forward is compared with the chained CPU restatements
+    evaluated on the UPDATED state_dict; EMAHelper.ema() on the top-level module must reach the nested modules too."""
+    from diff_sal_amd.diff_model import VideoSaliencyModel
+    from diff_sal_amd.ema import EMAHelper
+    from diff_sal_amd.train_step import DiffusionTrainStep
+    from tests.test_gpu_encoders import build_mvit
+    from tests.test_gpu_salunet import build
+
+    cfg = orc.SalUNetConfig(img_size=(64, 128))
+    dec = build(cfg, orc.synth_state_dict(orc.state_dict_template(cfg)))
+    dec.dropout_p = 0.0
+    enc, mcfg, _ = build_mvit("small")
+    enc.requires_grad_(True)
+    model = VideoSaliencyModel(channel_list=None, visual_net=enc, decoder_net=dec).to(DEV)
+    B = 2
+    clip = rnd("evt.clip", B, 3, 16, 64, 128)
+    sal = torch.sigmoid(rnd("evt.sal", B, 1, 64, 128))
+    x_in, t = rnd("evt.x", B, 1, 64, 128), torch.tensor([300, 700])
+
+    def hip_eval():
+        model.eval()
+        with torch.no_grad():
+            feats = model.visual_net(clip.to(DEV))
+            return [f.float().cpu() for f in feats], model.decoder_net(x_in.to(DEV), t.to(DEV), feats).float().cpu()
+
+    def oracle_eval():
+        msd = {k: v.detach().float().cpu() for k, v in model.visual_net.state_dict().items()}
+        dsd = {k: v.detach().cpu() for k, v in model.decoder_net.state_dict().items()}
+        with torch.no_grad():
+            feats = mo.mvit_forward(msd, mcfg, clip)
+            return feats, orc.salunet_forward(dsd, cfg, x_in, t, feats, None)
+
+    hip_eval()                                   # populate every eval cache with the INITIAL weights
+    ts = DiffusionTrainStep(model, lr=2e-3, grad_clip=1.0)      # large steps: stale weights would be far outside the tolerance
+    model.train()
+    for _ in range(3):
+        ts.step(sal.to(DEV), {"img": clip.to(DEV)}, t0=400, noise=rnd("evt.n", B, 1, 64, 128).to(DEV),
+                dequant_noise=torch.zeros_like(sal).to(DEV))
+    f_hip, o_hip = hip_eval()
+    f_ref, o_ref = oracle_eval()
+    for i, (a, b) in enumerate(zip(f_hip, f_ref)):
+        close(a, b, 1e-4, f"feature {i} after training")
+    assert (o_hip - o_ref).abs().max().item() < 1e-4
+
+    # EMA on the top-level module: shadow = the weights before three more steps; ema() must make the eval path use them again
+    ema = EMAHelper(mu=0.0)
+    ema.register(model)
+    ema.update(model)                             # mu = 0: shadow = current parameters
+    f_keep, o_keep = hip_eval()
+    model.train()
+    for _ in range(2):
+        ts.step(sal.to(DEV), {"img": clip.to(DEV)}, t0=200, noise=rnd("evt.n2", B, 1, 64, 128).to(DEV),
+                dequant_noise=torch.zeros_like(sal).to(DEV))
+    f_moved, _ = hip_eval()
+    assert max((a - b).abs().max().item() for a, b in zip(f_moved, f_keep)) > 1e-4      # the two steps did move the encoder
+    ema.ema(model)
+    f_back, o_back = hip_eval()
+    for a, b in zip(f_back, f_keep):
+        assert torch.equal(a, b)
+    assert torch.equal(o_back, o_keep)

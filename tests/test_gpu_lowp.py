@@ -94,9 +94,9 @@ def test_conv_igemm_16bit_storage(ops, case, dname):
 
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
-def test_conv_igemm_16bit_every_tile_shape(ops, dname, cfg, monkeypatch):
+def test_conv_igemm_16bit_every_tile_shape(ops, dname, cfg, tuning):
     """Each of the eight tile configurations of the 16-bit kernel on a shape with row / column / K remainders."""
-    monkeypatch.setenv("DIFFSAL_IGEMM16_CFG", str(cfg))
+    tuning.set("DIFFSAL_IGEMM16_CFG", cfg)
     dt = DTYPES[dname]
     N, H, W, Cin, Cout = 2, 19, 27, 96, 224
     x = q(rnd("tx", N, Cin, H, W), dt)
@@ -342,7 +342,7 @@ HALO_CASES = [
 
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_halo_conv_kernel_matches_generic_kernel_and_torch(ops, case, dname, monkeypatch):
+def test_halo_conv_kernel_matches_generic_kernel_and_torch(ops, case, dname, tuning):
     """conv16_halo_kernel (LDS patch, weight-row ring) on shapes with every kind of remainder: bit-identical to igemm16_kernel
     (same k order, same fp32 accumulation) and within the datapath tolerance of torch, with the full epilogue."""
     dt = DTYPES[dname]
@@ -355,10 +355,10 @@ def test_halo_conv_kernel_matches_generic_kernel_and_torch(ops, case, dname, mon
     wp = ops.cast(ops.pack_conv_weight(w.to(DEV)), dt)
     args = dict(kh=3, kw=3, pad=(d, d), dil=(d, d), bias=b.to(DEV), act=ops.ACT_RELU, residual=nhwc(res).to(DEV).to(dt))
     xin = nhwc(x).to(DEV).to(dt)
-    monkeypatch.setenv("DIFFSAL_NO_HALO", "1")
+    tuning.set("DIFFSAL_NO_HALO", 1)
     generic = ops.conv_igemm(xin, wp, **args)
-    monkeypatch.setenv("DIFFSAL_NO_HALO", "0")
-    monkeypatch.setenv("DIFFSAL_FORCE_HALO", "1")
+    tuning.set("DIFFSAL_NO_HALO", 0)
+    tuning.set("DIFFSAL_FORCE_HALO", 1)
     halo = ops.conv_igemm(xin, wp, **args)
     assert torch.equal(halo, generic)
     assert rel_err(halo, nhwc(ref)) < OP_RTOL[dname]
@@ -366,26 +366,26 @@ def test_halo_conv_kernel_matches_generic_kernel_and_torch(ops, case, dname, mon
 
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5, 6, 7])
-def test_persistent_linear_kernel_16bit(ops, dname, cfg, monkeypatch):
+def test_persistent_linear_kernel_16bit(ops, dname, cfg, tuning):
     """igemm16_linear_kernel (tiles walked by persistent workgroups, prefetch across tile boundaries) == the one-tile kernel,
     bit for bit, for every tile shape, on row / column remainders, K = 32 (one stage), 96 (half-empty stage) and 160."""
     dt = DTYPES[dname]
     if cfg is not None:
-        monkeypatch.setenv("DIFFSAL_IGEMM16_CFG", str(cfg))
+        tuning.set("DIFFSAL_IGEMM16_CFG", cfg)
     # the last two shapes are large launches: there the tiles are walked XCD by XCD (DIFFSAL_NO_XCD_ORDER=1: plain order)
     for M, K, N in ((1000, 160, 72), (130, 96, 100), (4100, 32, 224), (777, 384, 96), (48421, 96, 864), (70001, 64, 136)):
         x = q(rnd("px%d" % K, M, K), dt).to(DEV).to(dt)
         w = q(rnd("pw%d" % N, N, K, scale=1.0 / math.sqrt(K)), dt).to(DEV).to(dt)
         b = rnd("pb", N, scale=0.1).to(DEV)
         r = q(rnd("pr%d" % M, M, N), dt).to(DEV).to(dt)
-        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+        tuning.set("DIFFSAL_NO_PERSIST", 1)
         one = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
-        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
+        tuning.set("DIFFSAL_NO_PERSIST", 0)
         per = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
         assert torch.equal(one, per), (M, K, N)
-        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "1")
+        tuning.set("DIFFSAL_NO_XCD_ORDER", 1)
         plain = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
-        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "0")
+        tuning.set("DIFFSAL_NO_XCD_ORDER", 0)
         assert torch.equal(plain, per), (M, K, N)
         ref = F.gelu(x.float() @ w.float().t() + b) + r.float()
         assert rel_err(per, ref) < OP_RTOL[dname]
@@ -393,10 +393,10 @@ def test_persistent_linear_kernel_16bit(ops, dname, cfg, monkeypatch):
 
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("M,K,N", [(648, 768, 768), (648, 96, 96), (650, 384, 384), (70, 64, 36)])
-def test_linear_pair_16bit_equals_two_launches(ops, dname, M, K, N, monkeypatch):
+def test_linear_pair_16bit_equals_two_launches(ops, dname, M, K, N, tuning):
     """diffsal_linear_pair on 16-bit storage == the two single launches bit for bit."""
     dt = DTYPES[dname]
-    monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+    tuning.set("DIFFSAL_NO_PERSIST", 1)
     x0 = q(rnd("q0x%d" % K, M, K), dt).to(DEV).to(dt)
     x1 = q(rnd("q1x%d" % K, M, K), dt).to(DEV).to(dt)
     w0 = q(rnd("q0w%d" % N, N, K, scale=1.0 / math.sqrt(K)), dt).to(DEV).to(dt)

@@ -99,10 +99,10 @@ def test_linear_matches_torch(ops, M, K, N, act):
 
 
 @pytest.mark.parametrize("M,K,N", [(648, 768, 768), (648, 96, 96), (650, 384, 384), (3024, 192, 200), (70, 64, 36)])
-def test_linear_pair_equals_two_launches(ops, M, K, N, monkeypatch):
+def test_linear_pair_equals_two_launches(ops, M, K, N, tuning):
     """diffsal_linear_pair (key and value projections in one grid, z = 2) == the two single launches bit for bit (same tile
     plan, same split-K order), with and without bias, ragged M / N."""
-    monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")     # the single launches on the same one-tile kernel the pair uses
+    tuning.set("DIFFSAL_NO_PERSIST", 1)     # the single launches on the same one-tile kernel the pair uses
     x0, x1 = rnd("p0x%d" % K, 2, M // 2, K).to(DEV), rnd("p1x%d" % K, 2, M // 2, K).to(DEV)
     w0, w1 = rnd("p0w%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("p1w%d" % N, N, K, scale=K ** -0.5).to(DEV)
     b0, b1 = rnd("p0b", N, scale=0.1).to(DEV), rnd("p1b", N, scale=0.1).to(DEV)
@@ -113,36 +113,36 @@ def test_linear_pair_equals_two_launches(ops, M, K, N, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
-def test_persistent_linear_kernel_fp32(ops, cfg, monkeypatch):
+def test_persistent_linear_kernel_fp32(ops, cfg, tuning):
     """igemm_linear_kernel (persistent workgroups, prefetch across tile boundaries, register-direct stores) == the one-tile
     kernel bit for bit, for every tile shape, with row / column remainders, K = 32 (a single slice), 96 and 160."""
     if cfg is not None:
-        monkeypatch.setenv("DIFFSAL_IGEMM_CFG", str(cfg))
+        tuning.set("DIFFSAL_IGEMM_CFG", cfg)
     for M, K, N in ((1000, 160, 72), (130, 96, 100), (4100, 32, 224), (777, 384, 96)):
         x, w, b, r = rnd("px%d" % K, M, K).to(DEV), rnd("pw%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("pb", N, scale=0.1).to(DEV), rnd("pr", M, N).to(DEV)
-        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+        tuning.set("DIFFSAL_NO_PERSIST", 1)
         one = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
-        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
+        tuning.set("DIFFSAL_NO_PERSIST", 0)
         per = ops.linear(x, w, b, residual=r, act=ops.ACT_GELU)
         assert torch.equal(one, per), (M, K, N)
         assert rel_err(per, F.gelu(F.linear(x, w, b)) + r) < 2e-5
 
 
 @pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
-def test_persistent_linear_kernel_xcd_tile_order(ops, cfg, monkeypatch):
+def test_persistent_linear_kernel_xcd_tile_order(ops, cfg, tuning):
     """Large launches of igemm_linear_kernel walk the tiles XCD by XCD (one XCD owns whole M-tile rows): every tile still
     computed exactly once -- bit-equal with the plain order and with the one-tile kernel; M-tile counts that are not multiples
     of 8, ragged rows and columns."""
     if cfg is not None:
-        monkeypatch.setenv("DIFFSAL_IGEMM_CFG", str(cfg))
+        tuning.set("DIFFSAL_IGEMM_CFG", cfg)
     for M, K, N in ((48421, 96, 864), (33000, 32, 200), (70001, 64, 136)):
         x, w, b, r = rnd("qx%d" % K, M, K).to(DEV), rnd("qw%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("qb", N, scale=0.1).to(DEV), rnd("qr%d" % N, M, N).to(DEV)
-        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "1")
+        tuning.set("DIFFSAL_NO_PERSIST", 1)
         one = ops.linear(x, w, b, residual=r, act=ops.ACT_RELU)
-        monkeypatch.setenv("DIFFSAL_NO_PERSIST", "0")
-        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "1")
+        tuning.set("DIFFSAL_NO_PERSIST", 0)
+        tuning.set("DIFFSAL_NO_XCD_ORDER", 1)
         plain = ops.linear(x, w, b, residual=r, act=ops.ACT_RELU)
-        monkeypatch.setenv("DIFFSAL_NO_XCD_ORDER", "0")
+        tuning.set("DIFFSAL_NO_XCD_ORDER", 0)
         xcd = ops.linear(x, w, b, residual=r, act=ops.ACT_RELU)
         assert torch.equal(one, plain) and torch.equal(one, xcd), (M, K, N)
         assert rel_err(xcd, F.relu(F.linear(x, w, b)) + r) < 2e-5

@@ -135,6 +135,14 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["value"] is None and len(j["devices"]) == 2
+    # the default line carries a `train` object at every N (BASELINE configs[3]); here its gradient-exchange plumbing ran over gloo
+    tr = j["train"]
+    ex = tr["exchange"]
+    assert tr["n_gpus"] == 2 and ex["world"] == 2 and ex["collective_executed"] and ex["replicas_identical"] is True
+    assert ex["bytes_per_step_per_rank"] > 0 and len(ex["buckets_mb"]) == tr["grad_buckets"] >= 2
+    assert sorted(ex["launch_order"]) == list(range(tr["grad_buckets"]))
+    for k in ("allreduce_ms_per_bucket", "ms_per_step_without_exchange", "exposed_ms", "overlap_frac"):
+        assert k in ex
     for wl in ("train",):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", wl, "--steps", "1",
                             "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)

@@ -39,6 +39,21 @@ def test_restatement_full_resolution(golden_dir, name):
     check_taps(taps, g, 2e-5)
 
 
+def test_restatement_full_resolution_batch4_taps(golden_dir):
+    """configs[1]'s real shape (visual-only, B = 4, 224x384): the restatement against the real reference's output and taps."""
+    cfg = orc.SalUNetConfig()
+    g = np.load(f"{golden_dir}/salunet_full_vis_b4.npz")
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    assert abs(_checksum(sd) - float(g["weights_checksum"])) < 1e-6 * float(g["weights_checksum"])
+    x, feats, _ = orc.synth_inputs(cfg, 4, False, tag="full_vis_b4")
+    taps = {}
+    with torch.no_grad():
+        out = orc.salunet_forward(sd, cfg, x, torch.from_numpy(g["t"]), feats, None, taps=taps)
+    st = int(g["output_stride"])
+    assert (out[:, :, ::st, ::st] - torch.from_numpy(g["output"])).abs().max().item() < 2e-5
+    assert len(check_taps(taps, g, 2e-5)) >= 12
+
+
 def test_inputs_not_mutated(golden_dir):
     cfg, sd, x, t, feats, audio, g = load_case(golden_dir, "tiny_av")
     before = [f.clone() for f in feats]

@@ -8,7 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diff_sal_amd import ops  # noqa: E402
+from diff_sal_amd import _lib, ops  # noqa: E402
 from tools.tune_igemm16 import timed  # noqa: E402
 
 SHAPES = [  # name, N, H, W, Cin, Cout, dil
@@ -30,16 +30,16 @@ def main():
         bias = torch.randn(Cout, device="cuda")
         res = torch.randn(N, H, W, Cout, device="cuda").to(dt)
         kw = dict(kh=3, kw=3, stride=(1, 1), pad=(dil, dil), dil=(dil, dil), out_hw=(H, W), bias=bias, residual=res)
-        os.environ["DIFFSAL_NO_HALO"] = "1"
+        _lib.set_tuning("DIFFSAL_NO_HALO", 1)
         ref = ops.conv_igemm(x, w, **kw)
         t_old = timed(lambda: ops.conv_igemm(x, w, **kw))
-        os.environ["DIFFSAL_NO_HALO"] = "0"
-        os.environ["DIFFSAL_FORCE_HALO"] = "1"
+        _lib.set_tuning("DIFFSAL_NO_HALO", 0)
+        _lib.set_tuning("DIFFSAL_FORCE_HALO", 1)
         out = ops.conv_igemm(x, w, **kw)
         t_new = timed(lambda: ops.conv_igemm(x, w, **kw))
         kp = {k: v for k, v in kw.items() if k not in ("bias", "residual")}
         t_new_plain = timed(lambda: ops.conv_igemm(x, w, **kp))
-        os.environ["DIFFSAL_NO_HALO"] = "1"
+        _lib.set_tuning("DIFFSAL_NO_HALO", 1)
         t_old_plain = timed(lambda: ops.conv_igemm(x, w, **kp))
         err = (out.float() - ref.float()).abs().max().item()
         flops = 2.0 * N * H * W * Cout * 9 * Cin

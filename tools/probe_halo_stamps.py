@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Development aid: per-workgroup phase stamps of the halo kernel (wall_clock64, 100 MHz) for one shape."""
+"""Development aid: per-workgroup phase stamps of the halo kernel (wall_clock64, 100 MHz) for one shape.  Needs a development
+build of the library: DIFFSAL_EXTRA_HIPCC_FLAGS=-DDIFFSAL_DEV_STAMPS python -m diff_sal_amd.build --force (the shipped build has
+neither the stamp stores nor the diffsal_set_halo_stamps entry)."""
+import ctypes
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diff_sal_amd import ops  # noqa: E402
+from diff_sal_amd import _lib, ops  # noqa: E402
 
 N, H, W, Cin, Cout, dil = 36, 56, 96, 192, 96, 1
 if len(sys.argv) > 1:
@@ -14,14 +17,18 @@ if len(sys.argv) > 1:
 x = torch.relu(torch.randn(N, H, W, Cin, device="cuda")).bfloat16()
 w = (torch.randn(Cout, 9 * Cin, device="cuda") * 0.05).bfloat16()
 kw = dict(kh=3, kw=3, stride=(1, 1), pad=(dil, dil), dil=(dil, dil), out_hw=(H, W))
-os.environ["DIFFSAL_FORCE_HALO"] = "1"
+_lib.set_tuning("DIFFSAL_FORCE_HALO", 1)
 for _ in range(3):
     ops.conv_igemm(x, w, **kw)
 buf = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
-os.environ["DIFFSAL_HALO_STAMPS"] = "%x" % buf.data_ptr()
+lib = _lib.load()
+if not hasattr(lib, "diffsal_set_halo_stamps"):
+    sys.exit("this libdiffsal_hip.so was built without -DDIFFSAL_DEV_STAMPS")
+lib.diffsal_set_halo_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+lib.diffsal_set_halo_stamps(buf.data_ptr(), buf.numel() * 8)
 ops.conv_igemm(x, w, **kw)
 torch.cuda.synchronize()
-os.environ.pop("DIFFSAL_HALO_STAMPS")
+lib.diffsal_set_halo_stamps(None, 0)
 s = buf.view(-1, 8).cpu()
 s = s[s[:, 0] > 0].double()
 t0 = s[:, 0].min()

@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diff_sal_amd import ops  # noqa: E402
+from diff_sal_amd import _lib, ops  # noqa: E402
 from tools.tune_igemm16 import timed  # noqa: E402
 
 dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
@@ -17,11 +17,11 @@ for M, K, N in [(193536, 96, 96), (193536, 96, 192), (193536, 192, 96), (48384, 
     w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
     b = torch.randn(N, device="cuda")
     r = torch.randn(M, N, device="cuda").to(dt)
-    os.environ["DIFFSAL_NO_PERSIST"] = "1"
+    _lib.set_tuning("DIFFSAL_NO_PERSIST", 1)
     y0 = ops.linear(x, w, b, residual=r, act=ops.ACT_NONE)
     t0 = timed(lambda: ops.linear(x, w, b, residual=r))
     t0p = timed(lambda: ops.linear(x, w, b))
-    os.environ["DIFFSAL_NO_PERSIST"] = "0"
+    _lib.set_tuning("DIFFSAL_NO_PERSIST", 0)
     y1 = ops.linear(x, w, b, residual=r)
     t1 = timed(lambda: ops.linear(x, w, b, residual=r))
     t1p = timed(lambda: ops.linear(x, w, b))

@@ -8,7 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diff_sal_amd import ops  # noqa: E402
+from diff_sal_amd import _lib, ops  # noqa: E402
 from tools.bench_igemm import SHAPES  # noqa: E402
 
 CFG_NAMES = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64", "256x96", "256x128"]
@@ -50,16 +50,16 @@ def main():
             kw = dict(kh=k, kw=k, stride=(st, st), pad=(pad, pad), dil=(dil, dil), out_hw=(Ho, Wo))
             flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
         nbytes = (x.numel() + w.numel() + N * Ho * Wo * Cout) * 2
-        os.environ.pop("DIFFSAL_IGEMM16_CFG", None)
+        _lib.set_tuning("DIFFSAL_IGEMM16_CFG", None)
         us = timed(lambda: ops.conv_igemm(x, w, **kw))
         line = f"{name} M={N * Ho * Wo:7d} planner {us:8.1f} us {flops / us / 1e6:7.1f} TF/s {nbytes / us / 1e3:6.0f} GB/s |"
         for c, cn in enumerate(CFG_NAMES):
             if (c in (0,) and Cout < 192 - 31) or (c in (1, 3, 7) and Cout < 97):
                 continue
-            os.environ["DIFFSAL_IGEMM16_CFG"] = str(c)
+            _lib.set_tuning("DIFFSAL_IGEMM16_CFG", c)
             u = timed(lambda: ops.conv_igemm(x, w, **kw))
             line += f" {cn} {u:7.1f}"
-        os.environ.pop("DIFFSAL_IGEMM16_CFG", None)
+        _lib.set_tuning("DIFFSAL_IGEMM16_CFG", None)
         print(line, flush=True)
 
 

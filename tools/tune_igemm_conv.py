@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diff_sal_amd import ops  # noqa: E402
+from diff_sal_amd import _lib, ops  # noqa: E402
 from tools.tune_igemm16 import timed  # noqa: E402
 
 CFG = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64"]
@@ -25,7 +25,7 @@ def main():
         pad = (dil, dil) if st == 1 else (0, 0)
         oh = (H, W) if st == 1 else ((H - 2) // 2 + 1, (W - 2) // 2 + 1)
         f = lambda: ops.conv_igemm(x, w, kh=kh, kw=kw, stride=(st, st), pad=pad, dil=(dil, dil), out_hw=oh)  # noqa: E731
-        os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        _lib.set_tuning("DIFFSAL_IGEMM_CFG", None)
         f()
         us = timed(f)
         M, K = n * oh[0] * oh[1], kh * kw * ci
@@ -33,9 +33,9 @@ def main():
         for c, cn in enumerate(CFG):
             if (c == 0 and co < 161) or (c in (1, 3) and co < 97):
                 continue
-            os.environ["DIFFSAL_IGEMM_CFG"] = str(c)
+            _lib.set_tuning("DIFFSAL_IGEMM_CFG", c)
             line += f" {cn} {timed(f):6.1f}"
-        os.environ.pop("DIFFSAL_IGEMM_CFG", None)
+        _lib.set_tuning("DIFFSAL_IGEMM_CFG", None)
         print(line, flush=True)
 
 

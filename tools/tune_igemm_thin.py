@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diff_sal_amd import ops  # noqa: E402
+from diff_sal_amd import _lib, ops  # noqa: E402
 from tools.tune_igemm16 import timed  # noqa: E402
 
 CFG = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64"]
@@ -27,11 +27,11 @@ def main():
         if lowp:
             x, w = x.bfloat16(), w.bfloat16()
         b = torch.randn(N, device="cuda")
-        os.environ.pop(var, None)
-        os.environ["DIFFSAL_NO_PERSIST"] = "1"
+        _lib.set_tuning(var, None)
+        _lib.set_tuning("DIFFSAL_NO_PERSIST", 1)
         y0 = ops.linear(x, w, b)
         us0 = timed(lambda: ops.linear(x, w, b))
-        os.environ["DIFFSAL_NO_PERSIST"] = "0"
+        _lib.set_tuning("DIFFSAL_NO_PERSIST", 0)
         y1 = ops.linear(x, w, b)
         us = timed(lambda: ops.linear(x, w, b))
         fl = 2.0 * M * K * N
@@ -40,10 +40,10 @@ def main():
         for c, cn in enumerate(names):
             if (c == 0 and N < 161) or (c in (1, 3, 7) and N < 97):
                 continue
-            os.environ[var] = str(c)
+            _lib.set_tuning(var, c)
             u = timed(lambda: ops.linear(x, w, b))
             line += f" {cn} {u:6.1f}"
-        os.environ.pop(var, None)
+        _lib.set_tuning(var, None)
         print(line, flush=True)
 
 
