@@ -880,7 +880,7 @@ def main():
         # inputs are released first
         net.forward, net.forward_fused_update = inner, inner_fused
         try:
-            result["train"] = train_leg(cfg, dev, rank, world, steps=args.train_leg_steps, warmup=3, batch=4)
+            result["train"] = train_leg(cfg, dev, rank, world, steps=args.train_leg_steps, warmup=5, batch=4)
         except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of the extra leg)
             result["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -293,4 +293,10 @@ def test_eval_after_training_uses_the_trained_encoder_weights():
     f_back, o_back = hip_eval()
     for a, b in zip(f_back, f_keep):
         assert torch.equal(a, b)
-    assert torch.equal(o_back, o_keep)
+    # the denoiser's BatchNorm running statistics are buffers (EMA covers parameters only), so its output is not o_keep; what
+    # must hold is that no module still evaluates with a stale packed copy: an explicit invalidation changes nothing
+    for m in model.modules():
+        if hasattr(m, "parameters_updated"):
+            m.parameters_updated()
+    f_again, o_again = hip_eval()
+    assert torch.equal(o_back, o_again) and all(torch.equal(a, b) for a, b in zip(f_back, f_again))
