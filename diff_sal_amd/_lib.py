@@ -26,12 +26,14 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 SIGNATURES = {
     "diffsal_version": (c_i, []),
     "diffsal_last_error": (C.c_char_p, []),
+    "diffsal_block_front": (c_i, [c_f, c_f, c_f, c_f, c_f, c_fl, c_f, c_f, c_f, c_fl, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i,
+                                  c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_set_tuning": (c_i, [C.c_char_p, c_i]),
     "diffsal_get_tuning": (c_i, [C.c_char_p]),
     "diffsal_temb_mlp": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

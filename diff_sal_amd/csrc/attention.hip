@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
       s[r] = key < p.Lk ? s[r] : -3.0e38f;
       mx = fmaxf(mx, s[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+    mx = fmaxf(mx, lane_xor32(mx));
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __expf(m_run - m_new);
     m_run = m_new;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
   }
 
   // ---- finish: out[q][d] = O^T[d][q] / l (+ residual); this lane holds d = 32 t + 4 hf + (r & 3) + 8 (r >> 2)
-  const float l_tot = l_run + __shfl_xor(l_run, 32, kWave);
+  const float l_tot = l_run + lane_xor32(l_run);
   const float inv = 1.0f / l_tot;
   if (p.lse && qi < p.Lq && hf == 0) p.lse[static_cast<long>(bh) * p.Lq + qi] = m_run + logf(l_tot);
   if (qi < p.Lq) {

@@ -126,14 +126,14 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += v[u][r];
-    s += __shfl_xor(s, 32, kWave);
+    s += lane_xor32(s);
     mean = s * (1.0f / C);
     float q = 0.f;
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float d = v[u][r] - mean; q = fmaf(d, d, q); }
-    q += __shfl_xor(q, 32, kWave);
+    q += lane_xor32(q);
     rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
   };
   // channel of accumulator register r of row tile u for this lane

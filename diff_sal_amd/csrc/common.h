@@ -42,18 +42,43 @@ enum TuneKey {
 };
 int tune(int key);
 
-// Butterfly all-reduce over `width` (power of two <= 64) consecutive lanes.
-template <int WIDTH>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+// Butterfly all-reduce over `width` (power of two <= 64) consecutive lanes, entirely on the VALU: quad permutes for the
+// strides 1 and 2, row_half_mirror / row_mirror for 4 and 8 (every quad / 8-lane group already holds its own total, so the
+// mirrored partner carries the same value the xor partner would), v_permlane16_swap / v_permlane32_swap for 16 and 32.
+// `__shfl_xor` compiles to ds_bpermute_b32 -- an LDS round trip of ~100 cycles per step on the critical path of every
+// LayerNorm-style reduction.  Bit-identical to the xor butterfly (each step adds the same two operands).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_xor16(float v) {   // value of lane ^ 16
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // odd rows of r[0] <-> even rows of r[1]
+  return __builtin_bit_cast(float, (__lane_id() & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {   // value of lane ^ 32
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // lanes 32-63 of r[0] <-> lanes 0-31 of r[1]
+  return __builtin_bit_cast(float, (__lane_id() & 32) ? r[0] : r[1]);
+}
+template <int WIDTH, typename OP>
+__device__ __forceinline__ float group_reduce(float v, OP op) {
+  static_assert(WIDTH >= 1 && WIDTH <= 64 && (WIDTH & (WIDTH - 1)) == 0, "power of two <= 64");
+  if constexpr (WIDTH >= 2) v = op(v, dpp_move<0xB1>(v));     // quad_perm [1,0,3,2]
+  if constexpr (WIDTH >= 4) v = op(v, dpp_move<0x4E>(v));     // quad_perm [2,3,0,1]
+  if constexpr (WIDTH >= 8) v = op(v, dpp_move<0x141>(v));    // row_half_mirror
+  if constexpr (WIDTH >= 16) v = op(v, dpp_move<0x140>(v));   // row_mirror
+  if constexpr (WIDTH >= 32) v = op(v, lane_xor16(v));
+  if constexpr (WIDTH >= 64) v = op(v, lane_xor32(v));
   return v;
 }
 template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+  return group_reduce<WIDTH>(v, [](float a, float b) { return a + b; });
+}
+template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-  return v;
+  return group_reduce<WIDTH>(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 __device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
@@ -74,6 +99,30 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// N groups of MFMAs whose A fragment is one 16-byte LDS read: the read of group i + 1 is issued BEFORE the MFMAs of group i
+// (pinned with sched_barrier: left alone, hipcc reads a fragment, waits for it, then issues its four dependent MFMAs, and a
+// quarter of the matrix time is LDS latency).  addr(i) -> const float*, body(i, fragment).
+template <int N, typename AddrF, typename BodyF>
+__device__ __forceinline__ void mfma_groups_f32(AddrF addr, BodyF body) {
+  float4 a = ld4(addr(0));
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float4 an = a;
+    if (i + 1 < N) an = ld4(addr(i + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    body(i, a);
+    __builtin_amdgcn_sched_barrier(0);
+    a = an;
+  }
+}
+#define DS_MFMA4(ACC, A, B0, B1, B2, B3)                                         \
+  do {                                                                           \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B0), ACC, 0, 0, 0);       \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B1), ACC, 0, 0, 0);       \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B2), ACC, 0, 0, 0);       \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B3), ACC, 0, 0, 0);       \
+  } while (0)
 
 // 16-bit storage (DIFFSAL_BF16 / DIFFSAL_F16): the same 4-channel accessors on 8-byte runs; arithmetic stays fp32,
 // one round-to-nearest-even on the way out.

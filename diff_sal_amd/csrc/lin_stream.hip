@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 12; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    s += __shfl_xor(s, 32, kWave);
+    s += lane_xor32(s);
     mean = s * (1.0f / C);
     float q = 0.f;
 #pragma unroll
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
       const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
     }
-    q += __shfl_xor(q, 32, kWave);
+    q += lane_xor32(q);
     rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
   };
 
@@ -258,21 +258,20 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
     for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) hid[t][r] = vec[5 * C + 32 * t + 4 * hf + (r & 3) + 8 * (r >> 2)];
+    {
+      // the normalised pieces (B operands); weight fragments are read one group ahead of their MFMAs (mfma_groups_f32)
+      float4 xnp[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      // the normalised piece is formed right before use (4 values live instead of 48)
-      const float4 g = ld4(vec + 8 * i + 4 * hf), b = ld4(vec + C + 8 * i + 4 * hf);
-      const float n0 = (xa[i].x - mean) * rstd * g.x + b.x, n1 = (xa[i].y - mean) * rstd * g.y + b.y;
-      const float n2 = (xa[i].z - mean) * rstd * g.z + b.z, n3 = (xa[i].w - mean) * rstd * g.w + b.w;
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const float4 a = ld4(w1frag + 32 * t * P1 + 8 * i);
-        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, n0, hid[t], 0, 0, 0);
-        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, n1, hid[t], 0, 0, 0);
-        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, n2, hid[t], 0, 0, 0);
-        hid[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, n3, hid[t], 0, 0, 0);
+      for (int i = 0; i < 12; ++i) {
+        const float4 g = ld4(vec + 8 * i + 4 * hf), b = ld4(vec + C + 8 * i + 4 * hf);
+        xnp[i] = make_float4((xa[i].x - mean) * rstd * g.x + b.x, (xa[i].y - mean) * rstd * g.y + b.y,
+                             (xa[i].z - mean) * rstd * g.z + b.z, (xa[i].w - mean) * rstd * g.w + b.w);
       }
-      __builtin_amdgcn_sched_barrier(0);      // one piece's weight fragments in flight at a time (register budget)
+      mfma_groups_f32<72>([&](int k) { return w1frag + 32 * (k % 6) * P1 + 8 * (k / 6); },          // k = 6 i + t
+                          [&](int k, float4 a) {
+                            const int i = k / 6, t = k % 6;
+                            DS_MFMA4(hid[t], a, xnp[i].x, xnp[i].y, xnp[i].z, xnp[i].w);
+                          });
     }
 #pragma unroll
     for (int t = 0; t < 6; ++t)
@@ -284,21 +283,11 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const float4 a = ld4(w2frag + 32 * u * P2 + 32 * t + 8 * g);
-          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, hid[t][4 * g + 0], o[u], 0, 0, 0);
-          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, hid[t][4 * g + 1], o[u], 0, 0, 0);
-          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, hid[t][4 * g + 2], o[u], 0, 0, 0);
-          o[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hid[t][4 * g + 3], o[u], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    mfma_groups_f32<72>([&](int k) { return w2frag + 32 * (k % 3) * P2 + 8 * (k / 3); },              // k = 3 (4 t + g) + u
+                        [&](int k, float4 a) {
+                          const int u = k % 3, tg = k / 3, t = tg >> 2, g = tg & 3;
+                          DS_MFMA4(o[u], a, hid[t][4 * g + 0], hid[t][4 * g + 1], hid[t][4 * g + 2], hid[t][4 * g + 3]);
+                        });
     // ---- x2 = out + b2 + x1: this lane holds channels c = 32u + 8g + 4hf .. + 3 of its token = piece i = 4u + g of xa
     const int m = tile * 32 + ml;
     float4 (&y)[12] = xa;                       // x2 overwrites x1 in place (x1 is not needed afterwards)

@@ -663,11 +663,11 @@ static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
 #define CALL(G, NV)                                                                                                  \
   do {                                                                                                               \
     if (strip && NV == 1) {                                                                                          \
-      a.nq = row_grid(static_cast<long>(a.N) * a.H * ((a.W + 7) / 8), 256 / G);                                        \
+      a.nq = a.oq ? row_grid(static_cast<long>(a.N) * a.H * ((a.W + 7) / 8), 256 / G) : 0;                             \
       if (a.pg) hipLaunchKernelGGL((qkv_prep_kernel<true, G, 1, T, true>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a); \
       else hipLaunchKernelGGL((qkv_prep_kernel<true, G, 1, T, false>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);     \
     } else {                                                                                                         \
-      a.nq = row_grid(static_cast<long>(a.N) * a.H * a.W, 256 / G);                                                   \
+      a.nq = a.oq ? row_grid(static_cast<long>(a.N) * a.H * a.W, 256 / G) : 0;                                        \
       if (a.pg) hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T, true>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a); \
       else hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T, false>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);     \
     }                                                                                                                \
@@ -684,11 +684,12 @@ extern "C" int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq
                                 diffsal_stream_t stream) {
   DS_REQUIRE((pre_gamma == nullptr) == (pre_beta == nullptr) && (!pre_gamma || (aligned16(pre_gamma) && aligned16(pre_beta))),
              DIFFSAL_E_ARG, "qkv_prep: pre-LayerNorm gamma and beta go together (16-byte aligned)");
-  DS_REQUIRE(xq && w9 && gq && bq && out_q && xk && xv && wk && wv && gk && bk && gv && bv && out_k && out_v, DIFFSAL_E_ARG,
+  // out_q == nullptr: pooled key / value branch only (the query branch lives in diffsal_block_front)
+  DS_REQUIRE((!out_q || (xq && w9 && gq && bq)) && xk && xv && wk && wv && gk && bk && gv && bv && out_k && out_v, DIFFSAL_E_ARG,
              "qkv_prep: null argument");
   DS_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && k > 0 && H >= k && W >= k, DIFFSAL_E_SHAPE,
              "qkv_prep: bad shape H=%d W=%d C=%d k=%d", H, W, C, k);
-  DS_REQUIRE(aligned16(xq) && aligned16(out_q) && aligned16(w9) && aligned16(gq) && aligned16(bq) && aligned16(xk) && aligned16(xv) &&
+  DS_REQUIRE((!out_q || (aligned16(xq) && aligned16(out_q) && aligned16(w9) && aligned16(gq) && aligned16(bq))) && aligned16(xk) && aligned16(xv) &&
                  aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v),
              DIFFSAL_E_ALIGN, "qkv_prep: misaligned pointer");
   QkvPrepArgs a{xq, w9, gq, bq, out_q, xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, N, H, W, C, k, (H - k) / k + 1, (W - k) / k + 1, 0, eps,

@@ -563,6 +563,55 @@ def qkv_prep(xq: Tensor, w9: Tensor, gq: Tensor, bq: Tensor, xk: Tensor, xv: Ten
     return oq, ok, ov
 
 
+def kv_prep(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tensor, gv: Tensor, bv: Tensor, k: int,
+            eps: float = 1e-5, pre_ln=None):
+    """The pooled key / value branch of ``qkv_prep`` alone (the query branch lives in ``block_front``): depthwise k x k
+    stride-k pooling + LayerNorm of xk / xv [N,H,W,C] -> (k, v) [N, gh*gw, C].  ``pre_ln = (gamma, beta, eps, ln_k)`` applies
+    the block's first LayerNorm to xv (and to xk when ``ln_k``) as the tokens are loaded."""
+    lib = _lib.load()
+    N, H, W, Cc = xv.shape
+    if xk.shape != xv.shape or xk.dtype != xv.dtype:
+        raise RuntimeError("kv_prep: the two inputs must share shape and storage type")
+    gh, gw = (H - k) // k + 1, (W - k) // k + 1
+    ok = torch.empty((N, gh * gw, Cc), device=xv.device, dtype=xv.dtype)
+    ov = torch.empty_like(ok)
+    dt = _dt(xv)
+    with _prof("K9", 4.0 * N * H * W * Cc, _nb(xv, ok, ov) + (0.0 if xk.data_ptr() == xv.data_ptr() else _nb(xk))):
+        pg, pb, pe, plk = (pre_ln[0], pre_ln[1], float(pre_ln[2]), int(bool(pre_ln[3]))) if pre_ln is not None else (None, None, 0.0, 0)
+        _lib.check(lib.diffsal_qkv_prep(None, None, None, None, None, _pa(xk, dt), _pa(xv, dt), _p(wk), _p(wv), _p(gk), _p(bk),
+                                        _p(gv), _p(bv), ok.data_ptr(), ov.data_ptr(), N, H, W, Cc, k, eps, _p(pg), _p(pb), pe,
+                                        plk, dt, _stream()), "qkv_prep(kv only)")
+    return ok, ov
+
+
+def block_front_supported(C: int, heads: int, Lk: int) -> bool:
+    return C == 96 and heads == 2 and 0 < Lk <= 32
+
+
+def block_front(x: Tensor, k: Tensor, v: Tensor, norm1, w9: Tensor, norm_q, lin_q, lin_p, heads: int, scale: float) -> Tensor:
+    """Fused first half of a TransformerBlock (csrc/tblock.hip): LayerNorm -> depthwise 3x3 -> LayerNorm -> proj_q -> attention
+    over the projected keys / values k, v [N, Lk, C] (-> + proj + residual on fp32 storage).  x [N,H,W,C]; norm1 / norm_q =
+    (gamma, beta, eps); lin_q = (weight [C,C] in the storage type, bias); lin_p likewise (fp32 storage) or None.
+    Returns x1 = x + proj(o) on fp32 storage, the attention output o on 16-bit storage."""
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    Lk = k.shape[1]
+    dt = _dt(x)
+    out = torch.empty_like(x)
+    with_p = x.dtype == torch.float32
+    if with_p and lin_p is None:
+        raise RuntimeError("block_front: fp32 storage needs the output projection")
+    M = N * H * W
+    fl = 2.0 * M * Cc * Cc * (2 if with_p else 1) + 4.0 * M * Lk * Cc + 22.0 * M * Cc
+    with _prof("K10f", fl, _nb(x, out, k, v, lin_q[0]) + (_nb(lin_p[0]) if with_p else 0.0), f"block_front M={M} C={Cc}"):
+        _lib.check(lib.diffsal_block_front(_pa(x, dt), _pa(k, dt), _pa(v, dt), _p(norm1[0]), _p(norm1[1]), float(norm1[2]),
+                                           _p(w9), _p(norm_q[0]), _p(norm_q[1]), float(norm_q[2]), _pa(lin_q[0], dt),
+                                           _p(lin_q[1]), _pa(lin_p[0], dt) if with_p else None,
+                                           _p(lin_p[1]) if with_p else None, out.data_ptr(), N, H, W, Cc, Lk, heads,
+                                           float(scale), dt, _stream()), "block_front")
+    return out
+
+
 def dwpool_ln_kv(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tensor, gv: Tensor, bv: Tensor,
                  k: int, eps: float = 1e-5):
     lib = _lib.load()

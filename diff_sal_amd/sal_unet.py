@@ -372,6 +372,34 @@ class SalUNet(nn.Module):
         if audio_tok is not None:
             a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias, tag="K7-align")  # [B*T, ha*wa, C]
             k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
+        xt = x.view(n9, H * W, C)
+        gh, gw = (H - self.kernel_kv[i]) // self.kernel_kv[i] + 1, (W - self.kernel_kv[i]) // self.kernel_kv[i] + 1
+        if (self.fused_front and ops.block_front_supported(C, self.heads[i], gh * gw) and blk.mlp.fc1.out_features == 2 * C
+                and (x.dtype != torch.float32 or self._precision() == "fp32")
+                and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False)):
+            # finest stage: [pooled k / v with the folded first LayerNorm] [k, v projections] [LayerNorm -> depthwise q ->
+            # LayerNorm -> proj_q -> attention (-> proj + residual)] [LayerNorm -> MLP -> residual (-> norm_mts)]: 4 launches,
+            # x_n, q_in, q and (fp32) o never reach HBM
+            xv_ = x.view(n9, H, W, C)
+            kk, vv = ops.kv_prep(xv_ if k_src is None else k_src.view(n9, H, W, C), xv_, pk[f"s{i}.wk"], pk[f"s{i}.wv"],
+                                 a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight, a.conv_proj_v.bn.bias,
+                                 self.kernel_kv[i], a.conv_proj_k.bn.eps,
+                                 pre_ln=(blk.norm.weight, blk.norm.bias, blk.norm.eps, k_src is None))
+            kk, vv = ops.linear_pair(kk, vv, pk[f"s{i}.k.w"], pk[f"s{i}.v.w"], a.proj_k.bias, a.proj_v.bias)
+            f32 = x.dtype == torch.float32
+            y = ops.block_front(xv_, kk, vv, (blk.norm.weight, blk.norm.bias, blk.norm.eps), pk[f"s{i}.wq9"],
+                                (a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias, a.conv_proj_q.bn.eps),
+                                (pk[f"s{i}.q.w"], a.proj_q.bias), (pk[f"s{i}.proj.w"], a.proj.bias) if f32 else None,
+                                self.heads[i], float(C) ** -0.5).view(n9, H * W, C)
+            nz = None if norm_z is None else (norm_z.weight, norm_z.bias, norm_z.eps)
+            if f32:
+                x2, z = ops.mlp_block(y, (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias),
+                                      (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias), nz, (H * W, T, self.temporal_list[i]))
+            else:
+                x2, z = ops.block16(y, xt, (pk[f"s{i}.proj.w"], a.proj.bias), (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
+                                    (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias), (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias), nz,
+                                    (H * W, T, self.temporal_list[i]))
+            return x2.view(B, T, H, W, C), (None if z is None else z.view(B, T, H, W, C))
         if self.merge_qkv_prep and self.fold_norm1 and a.conv_proj_q.bn.eps == a.conv_proj_k.bn.eps:
             # the block's `norm` is applied to the tokens as qkv_prep loads them: x_n = norm(x) is never written
             xv_ = x.view(n9, H, W, C)
@@ -403,7 +431,6 @@ class SalUNet(nn.Module):
             kk = ops.linear(kk, pk[f"s{i}.k.w"], a.proj_k.bias)
             vv = ops.linear(vv, pk[f"s{i}.v.w"], a.proj_v.bias)
         o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
-        xt = x.view(n9, H * W, C)
         if C == 96 and blk.mlp.fc1.out_features == 192 and x.dtype != torch.float32:
             # finest stage on 16-bit storage: proj + residual + norm2 + MLP + residual + norm_mts in ONE launch
             x2, z = ops.block16(o, xt, (pk[f"s{i}.proj.w"], a.proj.bias), (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
@@ -435,6 +462,8 @@ class SalUNet(nn.Module):
     # the block's first LayerNorm applied inside qkv_prep (no normalised tensor in HBM).  Bit-equal, but measured slower: the
     # per-token reductions sit on the load path of latency-bound kernels (K9 0.163 -> 0.36 ms for 0.07 ms less K8): off.
     fold_norm1 = False
+    # finest stage (C = 96): the block's first half is ONE launch (csrc/tblock.hip).  Off: the per-operator launches below
+    fused_front = True
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16

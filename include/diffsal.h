@@ -375,6 +375,20 @@ int diffsal_attention(const void* q, const void* k, const void* v, void* o, int 
 int diffsal_head_sigmoid(const void* x, const float* w /*[C]*/, const float* bias /*[1]*/, float* out /*fp32*/,
                          int NHW, int C, int dtype, diffsal_stream_t stream);
 
+/* ---- fused first half of a TransformerBlock (C = 96, 2 heads; csrc/tblock.hip) --------------------------------------------
+ * R/models/saliency_decoder/transformer.py:150-152, attention.py:36-47,87-110:
+ *   xn = LayerNorm(x; g1, b1, eps1);  q = Linear_q( LayerNorm(dwconv3x3(xn; w9); gq, bq, epsq) );
+ *   o  = softmax(q k^T * scale) v per head, with the block's PROJECTED keys / values k, v [N, Lk <= 32, C];
+ *   fp32 storage:   out = x + Linear_p(o)      (x1; the rest of the block is diffsal_mlp_block)
+ *   16-bit storage: out = o                    (the rest of the block is diffsal_block16)
+ * x, out [N, H, W, C] channels-last in the storage type `dtype`; wq, wp [C, C] in the storage type, row = output feature; w9
+ * [9, C] fp32, tap = 3 ky + kx (the centre temporal slice of the Conv3d weight, zero padding 1).  One persistent launch per
+ * call instead of LayerNorm, depthwise-q + LayerNorm, the proj_q GEMM, the attention core and the proj GEMM. */
+int diffsal_block_front(const void* x, const void* k, const void* v, const float* g1, const float* b1, float eps1,
+                        const float* w9, const float* gq, const float* bq, float epsq, const void* wq, const float* bias_q,
+                        const void* wp, const float* bias_p, void* out, int N, int H, int W, int C, int Lk, int heads,
+                        float scale, int dtype, diffsal_stream_t stream);
+
 /* ---- storage-type conversion: dst[i] = (dst type) src[i], round to nearest even.  Used once per parameter version to
  * put packed convolution / linear weights into the 16-bit storage type of a reduced-precision module (the reference
  * has no counterpart: it is fp32-only, R/diffusion_trainer.py:212-218). */
