@@ -42,6 +42,7 @@ SIGNATURES = {
     "diffsal_maxpool2d": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_conv_in_s4": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_tapsum": (c_i, [c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "diffsal_tapsum_head": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f]),
     "diffsal_tapsum_bwd_ws_bytes": (C.c_long, [c_i, c_i, c_i, c_i]),
     "diffsal_tapsum_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_groupnorm_ws_bytes": (c_sz, [c_i, c_i]),

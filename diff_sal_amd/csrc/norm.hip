@@ -386,20 +386,37 @@ __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, cons
 #pragma unroll
   for (int i = 0; i < NV; ++i) { ak[i] = make_float4(0, 0, 0, 0); av[i] = make_float4(0, 0, 0, 0); }
   const long img = static_cast<long>(n) * H * W;
-  for (int pos = pl; pos < k * k; pos += PL) {
-    const int dy = pos / k, dx = pos - dy * k;
-    const long off = (img + static_cast<long>(gy * k + dy) * W + (gx * k + dx)) * C;
-    if constexpr (PRELN) {
-      // the position loop has the same trip count for every lane of a position group, so the reductions see whole groups
-      float4 a[NV], b[NV];
+  if constexpr (PRELN) {
+    // The position loop has the same trip count for every lane of a position group, so the reductions see whole groups.
+    // The loads of position pos + PL are issued before position pos is normalised and accumulated (one iteration is a
+    // load -> reduce -> reduce -> FMA chain; without the look-ahead its global latency is paid k*k / PL times in a row), and
+    // when key and value read the same tensor through the same LayerNorm it is loaded and normalised once.
+    const bool same = (xk == xv) && (ln_k == ln_v);
+    auto pos_off = [&](int pos) {
+      const int dy = pos / k, dx = pos - dy * k;
+      return (img + static_cast<long>(gy * k + dy) * W + (gx * k + dx)) * C;
+    };
+    auto fetch = [&](int pos, float4 (&a)[NV], float4 (&b)[NV]) {
+      const long off = pos_off(pos);
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (gl + i * G) * 4;
         a[i] = c < C ? ld4(xk + off + c) : make_float4(0, 0, 0, 0);
-        b[i] = c < C ? ld4(xv + off + c) : make_float4(0, 0, 0, 0);
+        if (!same) b[i] = c < C ? ld4(xv + off + c) : make_float4(0, 0, 0, 0);
       }
+    };
+    float4 a[NV], b[NV], an[NV], bn[NV];
+    if (pl < k * k) fetch(pl, a, b);
+    for (int pos = pl; pos < k * k; pos += PL) {
+      const bool more = pos + PL < k * k;
+      if (more) fetch(pos + PL, an, bn);
       if (ln_k) ln_rows_inplace<G, NV, T>(a, gl, C, pg, pb, peps);
-      if (ln_v) ln_rows_inplace<G, NV, T>(b, gl, C, pg, pb, peps);
+      if (same) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) b[i] = a[i];
+      } else if (ln_v) {
+        ln_rows_inplace<G, NV, T>(b, gl, C, pg, pb, peps);
+      }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (gl + i * G) * 4;
@@ -411,7 +428,16 @@ __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, cons
           av[i].z = fmaf(b[i].z, w2.z, av[i].z); av[i].w = fmaf(b[i].w, w2.w, av[i].w);
         }
       }
-    } else {
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+      }
+    }
+  }
+  if constexpr (!PRELN) {
+    for (int pos = pl; pos < k * k; pos += PL) {
+      const int dy = pos / k, dx = pos - dy * k;
+      const long off = (img + static_cast<long>(gy * k + dy) * W + (gx * k + dx)) * C;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (gl + i * G) * 4;
@@ -672,6 +698,23 @@ static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
       else hipLaunchKernelGGL((qkv_prep_kernel<false, G, NV, T, false>), dim3(a.nq + nkv), dim3(256), (256 / G) * lds_of, s, a);     \
     }                                                                                                                \
   } while (0)
+  if (!a.oq && a.pg) {
+    // pooled branch alone (the query branch lives in block_front): one iteration of a workgroup is a load -> LayerNorm ->
+    // accumulate chain, so what matters is bytes in flight.  Three pieces per lane (C / 12 lanes per position) put 4x more
+    // positions into one iteration than the one-piece mapping of the row kernels.
+    const int c4 = a.C / 4;
+#define CALLKV(G)                                                                                                   \
+  do {                                                                                                              \
+    a.nq = 0;                                                                                                       \
+    hipLaunchKernelGGL((qkv_prep_kernel<false, G, 3, T, true>), dim3(nkv), dim3(256), (256 / G) * lds_of, s, a);     \
+    return check_launch("qkv_prep(kv)");                                                                            \
+  } while (0)
+    if (c4 == 24) CALLKV(8);
+    if (c4 == 48) CALLKV(16);
+    if (c4 == 96) CALLKV(32);
+    if (c4 == 192) CALLKV(64);
+#undef CALLKV
+  }
   DS_ROW_DISPATCH(a.C, CALL);
 #undef CALL
   return check_launch("qkv_prep");

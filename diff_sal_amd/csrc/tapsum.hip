@@ -31,6 +31,10 @@ struct TapSumArgs {
   const float* shift;
   int act;
   int N, H, W, C, dil;
+  // head form (C <= 128): instead of storing the [N,H,W,C] map, head_out[n,Y,X] = sigmoid(head_b + sum_c head_w[c] out[n,Y,X,c])
+  const float* head_w;
+  const float* head_b;
+  float* head_out;
 };
 
 __device__ __forceinline__ float uni_f(float v) {
@@ -96,7 +100,7 @@ __device__ __forceinline__ void tap_accumulate(const T* __restrict__ img, int nr
   }
 }
 
-template <typename T>
+template <typename T, bool HEAD = false>
 __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict__ out, int w_patches, int slabs, long n_items) {
   const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
   const long item = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -129,11 +133,13 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict
       tap_accumulate<T>(img, f <= 2 ? 4 : 3, hs, ws, P, Ys, Xs, a.H, a.W, a.sy[s], a.sx[s], acc);
     }
   }
-  if (!live) return;
+  if (!HEAD && !live) return;
   float4 bi = make_float4(0, 0, 0, 0), sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-  if (a.bias) bi = ld4(a.bias + c);
-  if (a.scale) sc = ld4(a.scale + c);
-  if (a.shift) sh = ld4(a.shift + c);
+  if (a.bias) bi = ld4(a.bias + cc);
+  if (a.scale) sc = ld4(a.scale + cc);
+  if (a.shift) sh = ld4(a.shift + cc);
+  float4 hw = make_float4(0, 0, 0, 0);
+  if constexpr (HEAD) { if (c < a.C) hw = ld4(a.head_w + c); }     // lanes beyond C contribute nothing to the pixel's dot product
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -142,8 +148,17 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict
       v.x = (v.x + bi.x) * sc.x + sh.x; v.y = (v.y + bi.y) * sc.y + sh.y;
       v.z = (v.z + bi.z) * sc.z + sh.z; v.w = (v.w + bi.w) * sc.w + sh.w;
       if (a.act == DIFFSAL_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (Y0 + d < a.H && X0 + e < a.W)       // ragged last patch row / column when H or W is not a multiple of 4
-        st4(out + ((static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e) * a.C + c, v);
+      if constexpr (HEAD) {
+        // MLPHead (R/models/saliency_decoder/common_block.py:111-122): 1x1 convolution to one channel + sigmoid, over the 32
+        // lanes of this image's half-wave; the C-channel map itself is never stored
+        float t = fmaf(v.x, hw.x, fmaf(v.y, hw.y, fmaf(v.z, hw.z, v.w * hw.w)));
+        t = group_sum<32>(t);
+        if (l32 == 0 && n < a.N && Y0 + d < a.H && X0 + e < a.W)
+          a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t + a.head_b[0]);
+      } else {
+        if (Y0 + d < a.H && X0 + e < a.W)       // ragged last patch row / column when H or W is not a multiple of 4
+          st4(out + ((static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e) * a.C + c, v);
+      }
     }
 }
 
@@ -189,10 +204,12 @@ __global__ __launch_bounds__(256) void tapsum_bwd_axis_kernel(const float* __res
 
 using namespace diffsal;
 
-extern "C" int diffsal_tapsum(const void* const* srcs, const int* hs, const int* ws, int n_src, void* out, int N, int H, int W,
-                              int C, int dil, const float* bias, const float* scale, const float* shift, int act, int dtype,
-                              diffsal_stream_t stream) {
-  DS_REQUIRE(srcs && hs && ws && out, DIFFSAL_E_ARG, "tapsum: null argument");
+static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, int n_src, void* out, int N, int H, int W, int C,
+                       int dil, const float* bias, const float* scale, const float* shift, int act, int dtype,
+                       const float* head_w, const float* head_b, float* head_out, diffsal_stream_t stream) {
+  DS_REQUIRE(srcs && hs && ws && (out || head_out), DIFFSAL_E_ARG, "tapsum: null argument");
+  DS_REQUIRE(!head_out || (head_w && head_b && C <= 128 && aligned16(head_w)), DIFFSAL_E_ARG,
+             "tapsum: the head form needs its weight (16-byte aligned), its bias and C <= 128");
   DS_REQUIRE(n_src >= 1 && n_src <= 4 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 &&
                  (dil == 1 || dil == 2) && (act == DIFFSAL_ACT_NONE || act == DIFFSAL_ACT_RELU),
              DIFFSAL_E_SHAPE, "tapsum: bad shape n_src=%d N=%d H=%d W=%d C=%d dil=%d act=%d", n_src, N, H, W, C, dil, act);
@@ -214,17 +231,39 @@ extern "C" int diffsal_tapsum(const void* const* srcs, const int* hs, const int*
   }
   a.bias = bias; a.scale = scale; a.shift = shift; a.act = act;
   a.N = N; a.H = H; a.W = W; a.C = C; a.dil = dil;
-  DS_REQUIRE(aligned16(out) && (!bias || aligned16(bias)) && (!scale || (aligned16(scale) && aligned16(shift))), DIFFSAL_E_ALIGN,
+  a.head_w = head_w; a.head_b = head_b; a.head_out = head_out;
+  DS_REQUIRE((!out || aligned16(out)) && (!bias || aligned16(bias)) && (!scale || (aligned16(scale) && aligned16(shift))), DIFFSAL_E_ALIGN,
              "tapsum: misaligned pointer");
   const int slabs = (C + 127) / 128;
   const long n_items = static_cast<long>((N + 1) / 2) * ((H + 3) / 4) * ((W + 3) / 4) * slabs;
   DS_REQUIRE((n_items + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "tapsum: output too large");
 #define CALL(T)                                                                                                          \
-  hipLaunchKernelGGL((tapsum_kernel<T>), dim3(static_cast<unsigned>((n_items + 3) / 4)), dim3(256), 0,                     \
-                     static_cast<hipStream_t>(stream), a, static_cast<T*>(out), (W + 3) / 4, slabs, n_items)
+  do {                                                                                                                   \
+    if (head_out)                                                                                                        \
+      hipLaunchKernelGGL((tapsum_kernel<T, true>), dim3(static_cast<unsigned>((n_items + 3) / 4)), dim3(256), 0,          \
+                         static_cast<hipStream_t>(stream), a, static_cast<T*>(nullptr), (W + 3) / 4, slabs, n_items);    \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((tapsum_kernel<T, false>), dim3(static_cast<unsigned>((n_items + 3) / 4)), dim3(256), 0,         \
+                         static_cast<hipStream_t>(stream), a, static_cast<T*>(out), (W + 3) / 4, slabs, n_items);        \
+  } while (0)
   DS_DTYPE_DISPATCH(dtype, "tapsum", CALL);
 #undef CALL
   return check_launch("tapsum");
+}
+
+extern "C" int diffsal_tapsum(const void* const* srcs, const int* hs, const int* ws, int n_src, void* out, int N, int H, int W,
+                              int C, int dil, const float* bias, const float* scale, const float* shift, int act, int dtype,
+                              diffsal_stream_t stream) {
+  DS_REQUIRE(out, DIFFSAL_E_ARG, "tapsum: null output");
+  return tapsum_impl(srcs, hs, ws, n_src, out, N, H, W, C, dil, bias, scale, shift, act, dtype, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int diffsal_tapsum_head(const void* const* srcs, const int* hs, const int* ws, int n_src, int N, int H, int W, int C,
+                                   int dil, const float* bias, const float* scale, const float* shift, int act,
+                                   const float* head_w, const float* head_b, float* head_out, int dtype,
+                                   diffsal_stream_t stream) {
+  DS_REQUIRE(head_out, DIFFSAL_E_ARG, "tapsum_head: null output");
+  return tapsum_impl(srcs, hs, ws, n_src, nullptr, N, H, W, C, dil, bias, scale, shift, act, dtype, head_w, head_b, head_out, stream);
 }
 
 extern "C" long diffsal_tapsum_bwd_ws_bytes(int N, int W, int C, int h) {

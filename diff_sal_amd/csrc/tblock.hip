@@ -110,12 +110,15 @@ template <typename T, int C> struct FrontLds {
 };
 
 template <typename T, int C>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_kernel(FrontArgs<T> p) {
+__global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void block_front_kernel(FrontArgs<T> p) {
   typedef FrontLds<T, C> L;
   constexpr bool F32 = L::F32;
   // fp32 storage runs one workgroup per CU (LDS) with 512 registers per lane: the next tile's halo pieces are fetched a tile
   // ahead.  16-bit storage fits two workgroups per CU, which cover each other's load phases; no look-ahead (256 registers)
   constexpr bool AHEAD = F32;
+  // C = 192 on 16-bit storage: Wq + the halo tile fill the LDS (one workgroup per CU) and the registers do not hold a second
+  // tile's pieces through phase D: all of a tile's pieces are requested at once when its phase A starts
+  constexpr bool BULK = !F32 && C > 96;
   typedef typename Mma16<T>::vec vec;
   typedef typename RawPiece<T>::type raw_t;
   auto raw_to_f4 = [](raw_t r) { return raw_to_f4_impl(r, static_cast<const T*>(nullptr)); };
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
   // phase A's global loads, issued one tile ahead: pass ps covers halo tokens ps * TPP + a_slot; returns the "inside the frame" bits
   constexpr int TPP = 256 / G;                                       // tokens per pass
   constexpr int NPASS = (FT_TOK + TPP - 1) / TPP;
-  raw_t pre[AHEAD ? NPASS : 2][3];
+  raw_t pre[(AHEAD || BULK) ? NPASS : 2][3];
   unsigned inside_mask = 0;
   auto fetch_pass = [&](int tile_, int ps, raw_t (&dst)[3]) -> bool {
     const int tx_ = tile_ % p.tiles_x, t2_ = tile_ / p.tiles_x;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
   };
   auto fetch_tile = [&](int tile_) -> unsigned {
     unsigned mask = 0;
-    if constexpr (AHEAD) {
+    if constexpr (AHEAD || BULK) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) mask |= (fetch_pass(tile_, ps, pre[ps]) ? 1u : 0u) << ps;
     }
@@ -211,20 +214,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
     const int ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
     const int y0 = ty * FT_TH, x0 = tx * FT_TW;
-    if constexpr (!AHEAD) inside_mask = fetch_pass(tile, 0, pre[0]) ? 1u : 0u;
+    if constexpr (BULK) inside_mask = fetch_tile(tile);
+    else if constexpr (!AHEAD) inside_mask = fetch_pass(tile, 0, pre[0]) ? 1u : 0u;
 
     // ---------------- phase A: halo tile (fetched while the previous tile was in phase D) -> LayerNorm_1 -> LDS; zeros outside
     // the frame are the convolution's padding
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int tok = ps * TPP + a_slot;
-      if constexpr (!AHEAD) {                                          // two passes in flight
+      if constexpr (!AHEAD && !BULK) {                                 // two passes in flight
         if (ps + 1 < NPASS) inside_mask |= (fetch_pass(tile, ps + 1, pre[(ps + 1) & 1]) ? 1u : 0u) << (ps + 1);
       }
       const bool inside = (inside_mask >> ps) & 1u;
       float4 vv[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[AHEAD ? ps : (ps & 1)][i]);
+      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[(AHEAD || BULK) ? ps : (ps & 1)][i]);
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += (vv[i].x + vv[i].y) + (vv[i].z + vv[i].w);
@@ -253,12 +257,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
     __syncthreads();
     stamp(1);
     // this frame's K / V pieces: in flight during phase B, parked in LDS in phase C
-    raw_t kraw[3], vraw[3];
+    constexpr int NKP = 32 * NP / 256;                                // K (and V) pieces per thread: 32 key rows of NP pieces
+    raw_t kraw[NKP], vraw[NKP];
     auto fetch_kv = [&]() {
       const T* ksrc = p.k + static_cast<long>(n) * p.Lk * C;
       const T* vsrc = p.v + static_cast<long>(n) * p.Lk * C;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NKP; ++i) {
         const int pc = tid + 256 * i;                                 // piece: key j = pc / NP, channels 4 (pc % NP) ..
         const int j = pc / NP;
         const int off = (j < p.Lk ? j : 0) * C + 4 * (pc - j * NP);
@@ -275,10 +280,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
     {
       // software-pipelined by hand: the LDS reads of half a tap (NG / 2 activation pieces + NG / 2 weight pieces) are issued
       // before the FMAs of the previous half -- left to itself the compiler waits for every pair of reads
-      constexpr int HG = NG / 2;
+      constexpr int HG = 6, SPT = NG / HG, NSTEP = 9 * SPT;          // six channel groups per step, SPT steps per tap
       float4 xa[2][HG], wa[2][HG];
       auto issue = [&](int step, float4 (&xd)[HG], float4 (&wd)[HG]) {
-        const int tap = step >> 1, g0 = (step & 1) * HG;
+        const int tap = step / SPT, g0 = (step % SPT) * HG;
         const int off = (tap / 3 - 1) * FT_HW + (tap % 3 - 1);
         const T* xs = xns + (centre + off) * PX + 4 * hf + 8 * g0;
         const float* ws = vecs + tap * C + 4 * hf + 8 * g0;
@@ -287,10 +292,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
       };
       issue(0, xa[0], wa[0]);
 #pragma unroll
-      for (int step = 0; step < 18; ++step) {
-        if (step + 1 < 18) issue(step + 1, xa[(step + 1) & 1], wa[(step + 1) & 1]);
+      for (int step = 0; step < NSTEP; ++step) {
+        if (step + 1 < NSTEP) issue(step + 1, xa[(step + 1) & 1], wa[(step + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        const int g0 = (step & 1) * HG;
+        const int g0 = (step % SPT) * HG;
 #pragma unroll
         for (int g = 0; g < HG; ++g) {
           const float4 a = xa[step & 1][g], w = wa[step & 1][g];
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 1 : 2)) void block_front_ker
 
     // ---------------- phase C: K (rows = keys) and V^T (rows = channels) of this frame replace it; pads are zero
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NKP; ++i) {
       const int pc = tid + 256 * i;
       const int j = pc / NP, c4 = 4 * (pc - j * NP);
       const bool okj = j < p.Lk;
@@ -576,7 +581,8 @@ extern "C" int diffsal_block_front(const void* x, const void* k, const void* v, 
                                    const float* bias_q, const void* wp, const float* bias_p, void* out, int N, int H, int W,
                                    int C, int Lk, int heads, float scale, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(x && k && v && g1 && b1 && w9 && gq && bq && wq && bias_q && out, DIFFSAL_E_ARG, "block_front: null argument");
-  DS_REQUIRE(C == 96 && heads == 2, DIFFSAL_E_SHAPE, "block_front: built for C = 96, 2 heads (got %d, %d)", C, heads);
+  DS_REQUIRE((C == 96 || (C == 192 && dtype != DIFFSAL_F32)) && heads == 2, DIFFSAL_E_SHAPE,
+             "block_front: built for C = 96 (and C = 192 on 16-bit storage), 2 heads (got C = %d, %d heads, dtype %d)", C, heads, dtype);
   DS_REQUIRE(N > 0 && H > 0 && W > 0 && Lk > 0 && Lk <= 32, DIFFSAL_E_SHAPE, "block_front: N=%d H=%d W=%d Lk=%d (Lk <= 32)", N, H, W, Lk);
   DS_REQUIRE(static_cast<long>(N) * H * W * C < (1L << 31), DIFFSAL_E_SHAPE, "block_front: tensor too large for one launch");
   DS_REQUIRE(dtype == DIFFSAL_F32 || dtype == DIFFSAL_BF16 || dtype == DIFFSAL_F16, DIFFSAL_E_ARG, "block_front: dtype %d", dtype);
@@ -585,15 +591,19 @@ extern "C" int diffsal_block_front(const void* x, const void* k, const void* v, 
   DS_REQUIRE(out != x, DIFFSAL_E_ARG, "block_front: in-place operation is not supported (neighbouring tiles read the halo)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_y = (H + FT_TH - 1) / FT_TH, tiles_x = (W + FT_TW - 1) / FT_TW;
-#define DS_FRONT(T)                                                                                                         \
+#define DS_FRONT(T, CC)                                                                                                       \
   {                                                                                                                         \
     FrontArgs<T> a{static_cast<const T*>(x), static_cast<const T*>(k), static_cast<const T*>(v), g1, b1, w9, gq, bq,        \
                    static_cast<const T*>(wq), bias_q, static_cast<const T*>(wp), bias_p, static_cast<T*>(out), N, H, W, Lk, \
                    eps1, epsq, scale, tiles_y, tiles_x};                                                                    \
-    return launch_front<T, 96>(a, s);                                                                                       \
+    return launch_front<T, CC>(a, s);                                                                                       \
   }
-  if (dtype == DIFFSAL_F32) DS_FRONT(float)
-  if (dtype == DIFFSAL_BF16) DS_FRONT(bf16_t)
-  DS_FRONT(f16_t)
+  if (dtype == DIFFSAL_F32) DS_FRONT(float, 96)
+  if (C == 96) {
+    if (dtype == DIFFSAL_BF16) DS_FRONT(bf16_t, 96)
+    DS_FRONT(f16_t, 96)
+  }
+  if (dtype == DIFFSAL_BF16) DS_FRONT(bf16_t, 192)
+  DS_FRONT(f16_t, 192)
 #undef DS_FRONT
 }

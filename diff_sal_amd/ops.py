@@ -146,9 +146,12 @@ def temb_mlp(t: Tensor, freq: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Te
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("t must be a contiguous GPU tensor")
     out = torch.empty((2, B, 4 * ch), device=t.device, dtype=torch.float32)  # [0] = hidden scratch, [1] = temb
+    rows = max(1, (64 * 1024) // (16 * ch))       # the kernels keep a [rows, 4 ch] operand in 64 KiB of LDS: larger batches in slices
     with _prof("K1", 2.0 * B * (ch * 4 * ch + 16 * ch * ch), _nb(w0, w1)):
-        _lib.check(lib.diffsal_temb_mlp(t.data_ptr(), is_f32, B, ch, _p(freq), _p(w0), _p(b0), _p(w1), _p(b1),
-                                        _p(out[0]), _p(out[1]), _stream()), "temb_mlp")
+        for s in range(0, B, rows):
+            n = min(rows, B - s)
+            _lib.check(lib.diffsal_temb_mlp(t[s:s + n].data_ptr(), is_f32, n, ch, _p(freq), _p(w0), _p(b0), _p(w1), _p(b1),
+                                            _p(out[0, s:s + n]), _p(out[1, s:s + n]), _stream()), "temb_mlp")
     out = out[1]
     return out
 
@@ -158,9 +161,12 @@ def dense_small(x: Tensor, w: Tensor, bias: Optional[Tensor], swish_in: bool) ->
     B, K = x.shape
     N = w.shape[0]
     out = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    rows = max(1, (64 * 1024) // (4 * K))         # [rows, K] operand in 64 KiB of LDS: larger batches in slices
     with _prof("K1", 2.0 * B * K * N, _nb(w, x, out)):
-        _lib.check(lib.diffsal_dense_small(_p(x), B, K, int(swish_in), _p(w), _p(bias), N, _p(out), _stream()),
-                   "dense_small")
+        for s in range(0, B, rows):
+            n = min(rows, B - s)
+            _lib.check(lib.diffsal_dense_small(_p(x[s:s + n]), n, K, int(swish_in), _p(w), _p(bias), N, _p(out[s:s + n]), _stream()),
+                       "dense_small")
     return out
 
 
@@ -458,9 +464,12 @@ def resize_sum(xs: Sequence[Tensor], H: int, W: int) -> Tensor:
 
 
 def tapsum(ys: Sequence[Tensor], H: int, W: int, Cout: int, dil: int = 1, bias: Optional[Tensor] = None,
-           scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, act: int = ACT_NONE, tag: str = "K12-tap") -> Tensor:
+           scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, act: int = ACT_NONE, tag: str = "K12-tap",
+           head: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
     """conv3x3(dil)(sum_i bilinear(z_i -> (H, W))) from the tap products ys[i] = z_i x Wcat^T  [N, h_i, w_i, 9*Cout]
-    (``tap_weight``): out NHWC [N,H,W,Cout] = act(scale * (bias + gathered sum) + shift).  See csrc/tapsum.hip."""
+    (``tap_weight``): out NHWC [N,H,W,Cout] = act(scale * (bias + gathered sum) + shift).  See csrc/tapsum.hip.
+    ``head = (w [Cout], b [1])``: MLPHead folded into the epilogue -> fp32 [N,H,W,1] = sigmoid(b + out . w); the Cout-channel
+    map is never stored."""
     lib = _lib.load()
     n = len(ys)
     N = ys[0].shape[0]
@@ -471,6 +480,12 @@ def tapsum(ys: Sequence[Tensor], H: int, W: int, Cout: int, dil: int = 1, bias: 
     ptrs = (C.c_void_p * n)(*[_pa(y, dt) for y in ys])
     hs = (C.c_int * n)(*[y.shape[1] for y in ys])
     ws = (C.c_int * n)(*[y.shape[2] for y in ys])
+    if head is not None:
+        out = torch.empty((N, H, W, 1), device=ys[0].device, dtype=torch.float32)
+        with _prof(tag, 2.0 * 36.0 * n * N * H * W * Cout + 2.0 * N * H * W * Cout, _nb(*ys) + _nb(out)):
+            _lib.check(lib.diffsal_tapsum_head(ptrs, hs, ws, n, N, H, W, Cout, dil, _p(bias), _p(scale), _p(shift), act,
+                                               _p(head[0]), _p(head[1]), out.data_ptr(), dt, _stream()), "tapsum_head")
+        return out
     out = torch.empty((N, H, W, Cout), device=ys[0].device, dtype=ys[0].dtype)
     with _prof(tag, 2.0 * 36.0 * n * out.numel(), _nb(*ys) + _nb(out)):
         _lib.check(lib.diffsal_tapsum(ptrs, hs, ws, n, out.data_ptr(), N, H, W, Cout, dil, _p(bias), _p(scale), _p(shift), act, dt,
@@ -584,8 +599,9 @@ def kv_prep(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tens
     return ok, ov
 
 
-def block_front_supported(C: int, heads: int, Lk: int) -> bool:
-    return C == 96 and heads == 2 and 0 < Lk <= 32
+def block_front_supported(C: int, heads: int, Lk: int, dtype: torch.dtype = torch.float32) -> bool:
+    """csrc/tblock.hip: C = 96 on every storage type, C = 192 on 16-bit storage (there Wq alone fits the LDS next to the tile)."""
+    return heads == 2 and 0 < Lk <= 32 and (C == 96 or (C == 192 and dtype != torch.float32))
 
 
 def block_front(x: Tensor, k: Tensor, v: Tensor, norm1, w9: Tensor, norm_q, lin_q, lin_p, heads: int, scale: float) -> Tensor:

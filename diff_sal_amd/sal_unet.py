@@ -374,12 +374,12 @@ class SalUNet(nn.Module):
             k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
         xt = x.view(n9, H * W, C)
         gh, gw = (H - self.kernel_kv[i]) // self.kernel_kv[i] + 1, (W - self.kernel_kv[i]) // self.kernel_kv[i] + 1
-        if (self.fused_front and ops.block_front_supported(C, self.heads[i], gh * gw) and blk.mlp.fc1.out_features == 2 * C
+        if (self.fused_front and ops.block_front_supported(C, self.heads[i], gh * gw, x.dtype)
                 and (x.dtype != torch.float32 or self._precision() == "fp32")
                 and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False)):
-            # finest stage: [pooled k / v with the folded first LayerNorm] [k, v projections] [LayerNorm -> depthwise q ->
-            # LayerNorm -> proj_q -> attention (-> proj + residual)] [LayerNorm -> MLP -> residual (-> norm_mts)]: 4 launches,
-            # x_n, q_in, q and (fp32) o never reach HBM
+            # [pooled k / v with the folded first LayerNorm] [k, v projections] [LayerNorm -> depthwise q -> LayerNorm -> proj_q ->
+            # attention (-> proj + residual on fp32)]: x_n, q_in, q and (fp32) o never reach HBM.  C = 96 continues with the
+            # fused second half (mlp_block / block16: 4 launches for the whole block), C = 192 with the per-operator launches
             xv_ = x.view(n9, H, W, C)
             kk, vv = ops.kv_prep(xv_ if k_src is None else k_src.view(n9, H, W, C), xv_, pk[f"s{i}.wk"], pk[f"s{i}.wv"],
                                  a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight, a.conv_proj_v.bn.bias,
@@ -392,14 +392,20 @@ class SalUNet(nn.Module):
                                 (pk[f"s{i}.q.w"], a.proj_q.bias), (pk[f"s{i}.proj.w"], a.proj.bias) if f32 else None,
                                 self.heads[i], float(C) ** -0.5).view(n9, H * W, C)
             nz = None if norm_z is None else (norm_z.weight, norm_z.bias, norm_z.eps)
-            if f32:
-                x2, z = ops.mlp_block(y, (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias),
-                                      (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias), nz, (H * W, T, self.temporal_list[i]))
-            else:
-                x2, z = ops.block16(y, xt, (pk[f"s{i}.proj.w"], a.proj.bias), (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
-                                    (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias), (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias), nz,
-                                    (H * W, T, self.temporal_list[i]))
-            return x2.view(B, T, H, W, C), (None if z is None else z.view(B, T, H, W, C))
+            if C == 96 and blk.mlp.fc1.out_features == 192:
+                if f32:
+                    x2, z = ops.mlp_block(y, (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias),
+                                          (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias), nz, (H * W, T, self.temporal_list[i]))
+                else:
+                    x2, z = ops.block16(y, xt, (pk[f"s{i}.proj.w"], a.proj.bias), (blk.norm2.weight, blk.norm2.bias, blk.norm2.eps),
+                                        (pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias), (pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias), nz,
+                                        (H * W, T, self.temporal_list[i]))
+                return x2.view(B, T, H, W, C), (None if z is None else z.view(B, T, H, W, C))
+            x1 = y if f32 else ops.linear(y, pk[f"s{i}.proj.w"], a.proj.bias, residual=xt)
+            y2 = ops.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            y2 = ops.linear(y2, pk[f"s{i}.fc1.w"], blk.mlp.fc1.bias, act=ACT_GELU)
+            x2 = ops.linear(y2, pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias, residual=x1)
+            return x2.view(B, T, H, W, C), None
         if self.merge_qkv_prep and self.fold_norm1 and a.conv_proj_q.bn.eps == a.conv_proj_k.bn.eps:
             # the block's `norm` is applied to the tokens as qkv_prep loads them: x_n = norm(x) is never written
             xv_ = x.view(n9, H, W, C)
@@ -451,10 +457,33 @@ class SalUNet(nn.Module):
         x2 = ops.linear(y, pk[f"s{i}.fc2.w"], blk.mlp.fc2.bias, residual=x1)
         return x2.view(B, T, H, W, C), None
 
-    # Largest batch evaluated in one pass.  The 4-scale sum [B,112,192,768] fp32 is 66 MB per clip and the
-    # implicit-GEMM loader addresses each operand with 32-bit byte offsets (< 4 GiB): larger batches
-    # (BASELINE config 5 uses 64 clips per GPU) are evaluated in chunks; clips are independent in eval mode.
-    max_clips_per_pass = 16
+    # Largest batch evaluated in one pass.  The implicit-GEMM loader addresses each operand with 32-bit BYTE offsets (< 4 GiB) and
+    # the row kernels count elements in 32-bit ints, so a pass is sized such that the largest tensor it touches stays inside
+    # both (``clips_per_pass``); larger batches are evaluated in passes (clips are independent in eval mode).  At the reference
+    # configuration that is 64+ clips per pass on every datapath that uses the tap form (BASELINE configs[4]: 64 clips per GPU in
+    # one pass), 32 on the direct fp32 form whose 4-scale sum [B,112,192,768] is 66 MB per clip.  ``max_clips_per_pass`` caps it.
+    max_clips_per_pass = 64
+
+    def clips_per_pass(self, tap_form: bool) -> int:
+        es = 4 if self.compute_dtype == torch.float32 else 2
+        H, W = self.img_size
+        ns, T = self.num_stages, 9
+        per_clip = [H * W * self.ch]                                   # conv_in output of the two-kernel K2 path
+        h, w = H // 32, W // 32
+        tok = 0
+        for i in range(ns):
+            if self.dilation[i] != 0:
+                if tap_form:
+                    per_clip.append(T * h * w * 9 * self.up_channels[i])   # tap products of UpEmbed conv1 at the source resolution
+                h, w = 2 * h, 2 * w
+            per_clip.append(T * h * w * self.up_channels[i] * 2)           # tokens and the MLP hidden layer
+            tok += h * w
+        per_clip.append(tok * 9 * self.down_channel if tap_form else 4 * h * w * self.ori_embed_dim)   # mt_proj taps / 4-scale sum
+        worst = max(per_clip)
+        by_bytes = ((1 << 32) - (1 << 24)) // (worst * es)
+        by_count = ((1 << 31) - (1 << 24)) // worst
+        return max(1, min(self.max_clips_per_pass, by_bytes, by_count))
+
     # eval path: a 3x3 convolution that directly follows a bilinear up-sampling (UpEmbed conv1, mt_proj on the 4-scale sum) runs
     # as nine 1x1 tap mixings at the SOURCE resolution (one GEMM, 4x / 3x fewer FLOPs) + a gather of the interpolated taps
     # (ops.tapsum, csrc/tapsum.hip).  Exact up to summation order; off when intermediate taps are requested.
@@ -464,6 +493,7 @@ class SalUNet(nn.Module):
     fold_norm1 = False
     # finest stage (C = 96): the block's first half is ONE launch (csrc/tblock.hip).  Off: the per-operator launches below
     fused_front = True
+    fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
@@ -482,10 +512,11 @@ class SalUNet(nn.Module):
             return self.forward_train(x, t, feat_list, audio_feat_list)
         if B == 0:
             return x.new_empty((0, 1, self.img_size[0], self.img_size[1]))
-        if B > self.max_clips_per_pass and taps is None:
+        cpp = self.clips_per_pass(self._use_tap_conv(taps, "mt"))
+        if B > cpp and taps is None:
             outs = []
-            for s in range(0, B, self.max_clips_per_pass):
-                e = min(B, s + self.max_clips_per_pass)
+            for s in range(0, B, cpp):
+                e = min(B, s + cpp)
                 outs.append(self._forward_pass(x[s:e], t[s:e], [f[s:e] for f in feat_list],
                                                None if audio_feat_list is None else audio_feat_list[s:e], None))
             return torch.cat(outs, dim=0)
@@ -510,9 +541,10 @@ class SalUNet(nn.Module):
         x = x.contiguous().float()
         B = x.shape[0]
         ms, xs = [], []
+        cpp = self.clips_per_pass(self._use_tap_conv(None, "mt"))
         with ops.gemm_precision(self.gemm_precision):
-            for s in range(0, B, self.max_clips_per_pass):
-                e = min(B, s + self.max_clips_per_pass)
+            for s in range(0, B, cpp):
+                e = min(B, s + cpp)
                 low = self._forward_eval(x[s:e], t[s:e], [f[s:e] for f in feat_list],
                                          None if audio_feat_list is None else audio_feat_list[s:e], None, lowres=True)
                 m, xn, _ = ops.resize_update(low, x[s:e], None if m_prev is None else m_prev[s:e].contiguous(), ex, e0, A, c0, c1)
@@ -622,6 +654,14 @@ class SalUNet(nn.Module):
                 m_ = z_.shape[0] * z_.shape[1] * z_.shape[2]
                 ys.append(y9[off:off + m_].view(z_.shape[0], z_.shape[1], z_.shape[2], y9.shape[-1]))
                 off += m_
+            if self.fold_head and mt[0].out_channels <= 128 and mt[0].out_channels % 4 == 0:
+                # MLPHead (1x1 to one channel + sigmoid) in the gather's epilogue: the [B,112,192,96] map never reaches HBM
+                s = ops.tapsum(ys, th, tw, mt[0].out_channels, dil=1, bias=mt[0].bias, scale=pk["mt.scale"], shift=pk["mt.shift"],
+                               act=ACT_RELU, tag="K14-tap", head=(pk["head.w"], self.logits.linear_pred.bias))
+                if lowres:
+                    return s
+                out = ops.resize_bilinear(s, self.img_size[0], self.img_size[1], tag="K14-head")
+                return out.view(B, 1, self.img_size[0], self.img_size[1])
             y = ops.tapsum(ys, th, tw, mt[0].out_channels, dil=1, bias=mt[0].bias, scale=pk["mt.scale"], shift=pk["mt.shift"],
                            act=ACT_RELU, tag="K14-tap")
         else:

@@ -76,6 +76,12 @@ int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float
 int diffsal_tapsum(const void* const* srcs, const int* hs, const int* ws, int n_src, void* out, int N, int H, int W, int C,
                    int dil, const float* bias, const float* scale, const float* shift, int act, int dtype,
                    diffsal_stream_t stream);
+/* The same gather with MLPHead folded into its epilogue (common_block.py:111-122: 1x1 convolution C -> 1 + sigmoid; C <= 128):
+ *   head_out[n, Y, X] = sigmoid( head_b[0] + sum_c head_w[c] * out[n, Y, X, c] ),   fp32 [N, H, W]
+ * the C-channel map `out` is never stored (mt_proj -> BN -> ReLU -> logits of sal_unet.py:489 + :320 in one launch). */
+int diffsal_tapsum_head(const void* const* srcs, const int* hs, const int* ws, int n_src, int N, int H, int W, int C, int dil,
+                        const float* bias, const float* scale, const float* shift, int act, const float* head_w,
+                        const float* head_b, float* head_out, int dtype, diffsal_stream_t stream);
 /* Training: the adjoint of diffsal_tapsum (act NONE, no affine) with respect to ONE source's tap products,
  *   dy [N,h,w,9*C] (fp32) from du [N,H,W,C]; ws: diffsal_tapsum_bwd_ws_bytes(N, W, C, h) bytes of scratch (the three row passes).
  * Gather form, deterministic; replaces the full-resolution dgrad + wgrad of the convolution behind nn.Upsample in training

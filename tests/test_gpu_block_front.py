@@ -51,10 +51,13 @@ def params(C, tag):
 
 
 @pytest.mark.parametrize("dname", list(DT))
-@pytest.mark.parametrize("shape", [(3, 16, 32, 18), (2, 8, 16, 2), (2, 13, 21, 18), (36, 56, 96, 18), (1, 5, 7, 32)])
+@pytest.mark.parametrize("shape", [(3, 16, 32, 18), (2, 8, 16, 2), (2, 13, 21, 18), (36, 56, 96, 18), (1, 5, 7, 32),
+                                   (3, 16, 24, 18, 192), (36, 28, 48, 18, 192), (1, 9, 11, 7, 192)])
 def test_block_front_matches_torch(ops, shape, dname):
-    N, H, W, Lk = shape
-    C, heads, dt = 96, 2, DT[dname]
+    N, H, W, Lk = shape[:4]
+    C, heads, dt = (shape[4] if len(shape) > 4 else 96), 2, DT[dname]
+    if C == 192 and dt == torch.float32:
+        pytest.skip("C = 192 is built for 16-bit storage only (two fp32 192 x 192 weights do not fit the LDS)")
     p = params(C, f"bf{H}")
     x = rnd(f"bfx{H}", N, H, W, C) * 1.5 + 0.2
     k, v = rnd(f"bfk{H}", N, Lk, C, scale=1.2), rnd(f"bfv{H}", N, Lk, C)
@@ -92,9 +95,11 @@ def test_block_front_equals_unfused_hip_kernels(ops):
 
 
 @pytest.mark.parametrize("dname", list(DT))
-def test_kv_prep_equals_the_pooled_branch_of_qkv_prep(ops, dname):
-    """out_q = NULL runs only the pooled key / value workgroups (with the folded first LayerNorm): bit-equal with the full launch."""
-    N, H, W, C, kk = 3, 16, 32, 96, 4
+@pytest.mark.parametrize("C,kk", [(96, 4), (192, 8), (64, 4)])
+def test_kv_prep_equals_the_pooled_branch_of_qkv_prep(ops, dname, C, kk):
+    """out_q = NULL runs only the pooled key / value workgroups (with the folded first LayerNorm).  Same arithmetic as the full
+    launch; for C = 96 / 192 / 384 / 768 a wider lane mapping (three pieces per lane), so equal up to summation order."""
+    N, H, W = 3, 16, 32
     dt = DT[dname]
     x = (rnd("kvx", N, H, W, C) * 1.5 + 0.2).to(DEV).to(dt)
     d = lambda name, *s, **kw: rnd(name, *s, **kw).to(DEV)
@@ -103,4 +108,6 @@ def test_kv_prep_equals_the_pooled_branch_of_qkv_prep(ops, dname):
     pre = (g[6], g[7], 1e-5, True)
     q, k1, v1 = ops.qkv_prep(x, w9, g[0], g[1], x, x, wk, wv, g[2], g[3], g[4], g[5], kk, 1e-5, pre_ln=pre)
     k2, v2 = ops.kv_prep(x, x, wk, wv, g[2], g[3], g[4], g[5], kk, 1e-5, pre_ln=pre)
-    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    tol = 2e-6 if dt == torch.float32 else (8e-3 if dt == torch.bfloat16 else 1e-3)     # 16-bit: one rounding step of the output
+    for a, b in ((k1, k2), (v1, v2)):
+        assert (a.float() - b.float()).abs().max().item() <= tol * b.float().abs().max().item()

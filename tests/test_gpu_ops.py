@@ -475,6 +475,28 @@ def test_tapsum_equals_conv_of_upsampled_sum(ops, case):
     assert rel_err(got, nhwc(ref)) < 1e-5
 
 
+@pytest.mark.parametrize("N,Cout,H,W", [(4, 96, 16, 32), (3, 32, 20, 24), (1, 128, 8, 16)])
+def test_tapsum_with_folded_head(ops, N, Cout, H, W):
+    """MLPHead (1x1 to one channel + sigmoid, common_block.py:111-122) in the gather's epilogue == tapsum then head_sigmoid,
+    for even / odd batches (the second image of a lane pair may be missing) and channel counts below the 128-lane slab."""
+    Cin, factors = 64, (2, 4)
+    zs = [rnd("hz%d" % f, N, Cin, H // f, W // f) for f in factors]
+    w = rnd("hw", Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    b, sc, sh = rnd("hb", Cout, scale=0.1), 1.0 + rnd("hsc", Cout, scale=0.1), rnd("hsh", Cout, scale=0.1)
+    hw_, hb_ = rnd("hhw", Cout, scale=0.3).to(DEV), rnd("hhb", 1, scale=0.1).to(DEV)
+    wcat = ops.tap_weight(w.to(DEV))
+    ys = [ops.linear(nhwc(z).to(DEV), wcat, None) for z in zs]
+    kw = dict(dil=1, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), act=ops.ACT_RELU)
+    two = ops.head_sigmoid(ops.tapsum(ys, H, W, Cout, **kw), hw_, hb_)
+    one = ops.tapsum(ys, H, W, Cout, head=(hw_, hb_), **kw)
+    assert one.shape == two.shape == (N, H, W, 1) and one.dtype == torch.float32
+    assert (one - two).abs().max().item() < 2e-6
+    up = sum(F.interpolate(z, size=(H, W), mode="bilinear", align_corners=False) for z in zs)
+    ref = F.relu(F.conv2d(up, w, b, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    ref = torch.sigmoid((ref * hw_.cpu()[None, :, None, None]).sum(1) + hb_.cpu())
+    assert (one.cpu()[..., 0] - ref).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("case", TAPSUM_CASES, ids=[str(c) for c in TAPSUM_CASES])
 def test_tapsum_autograd_matches_conv_of_upsampled_sum(ops, case):
     """Training path: d/dz_i, d/dW, d/dbias of conv3x3(sum_i bilinear(z_i)) through GEMM + tapsum and their adjoints

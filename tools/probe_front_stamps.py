@@ -14,8 +14,8 @@ lib = _lib.load()
 if not hasattr(lib, "diffsal_set_front_stamps"):
     sys.exit("this libdiffsal_hip.so was built without -DDIFFSAL_DEV_STAMPS")
 lib.diffsal_set_front_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-N, H, W, C, Lk, heads = 36, 56, 96, 96, 18, 2
-for dt in (torch.float32, torch.bfloat16):
+Lk, heads = 18, 2
+for dt, (N, H, W, C) in ((torch.float32, (36, 56, 96, 96)), (torch.bfloat16, (36, 56, 96, 96)), (torch.bfloat16, (36, 28, 48, 192))):
     r = lambda *s, sc=1.0: torch.randn(*s, device="cuda") * sc
     x, k, v = r(N, H, W, C).to(dt), r(N, Lk, C).to(dt), r(N, Lk, C).to(dt)
     g1, b1, gq, bq, w9 = r(C, sc=0.1) + 1, r(C, sc=0.1), r(C, sc=0.1) + 1, r(C, sc=0.1), r(9, C, sc=0.4)
@@ -32,7 +32,7 @@ for dt in (torch.float32, torch.bfloat16):
     s = buf.view(-1, 8, 8).cpu().double()
     s = s[s[:, 0, 0] > 0]
     t0 = s[:, 0, 0].min()
-    print(dt, "workgroups", s.shape[0], "span us", (s[:, :, 5].max() - t0).item() / 100)
+    print(dt, f"C={C} {H}x{W}", "workgroups", s.shape[0], "span us", (s[:, :, 5].max() - t0).item() / 100)
     names = ["A: halo + LN1 -> LDS", "B: dwconv + LNq", "C: K/V -> LDS", "D: q-proj, attention", "E: proj + store"]
     for it in range(min(6, s.shape[1])):
         live = s[:, it, 5] > 0
