@@ -40,7 +40,8 @@ class _Stop(Exception):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # SURVEY 8(a) rows that are dense contractions (implicit-GEMM kernel); everything else is a streaming kernel
-GEMM_CLASSES = ("K2", "K4", "K5", "K7-align", "K10", "K12", "K13", "K14", "gemm", "wgrad")
+# "K10f" = block_front (K8 + K9 + K10 + K11 of a stage in one MFMA launch)
+GEMM_CLASSES = ("K2", "K4", "K5", "K7-align", "K10", "K10f", "K12", "K13", "K14", "gemm", "wgrad")
 
 
 def class_table(events, mfma_peak_tflops):
@@ -673,16 +674,30 @@ def main():
                          "tflops": round(fl / us / 1e6, 2) if us > 0 else 0.0, "gbs": round(nb / us / 1e3, 1) if us > 0 else 0.0})
         json.dump({"precision": args.precision, "mode": args.mode, "batch": B, "launches": rows}, open(args.dump_launches, "w"), indent=0)
     peak_for_mode = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+    # roofline.traffic: HBM bytes of the GEMM family per launch from the PMC passes of THIS code (tools/profile_round.sh; separate
+    # --pmc runs as the guide prescribes).  A profile taken on other sources is refused: traffic = null, and the line says why.
     traffic, traffic_src = None, None
-    tf = os.path.join(ROOT, "profiles", f"r02_igemm_hbm_traffic_{args.precision}.json")
-    if os.path.exists(tf):      # PMC pass of THIS build (tools/pmc_traffic.py; separate --pmc run as the guide prescribes)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from build_id import source_id
+        bid = source_id()
+    except Exception:  # noqa: BLE001
+        bid = None
+    suf = args.precision + ("_av" if av else "")
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_hbm_traffic_{suf}.json")) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if cands:
+        tf = os.path.join(ROOT, "profiles", cands[-1])
         try:
             tj = json.load(open(tf))
-            # HBM bytes of the whole GEMM family per step / its operator launches per step: per launch, like `achieved`
-            traffic = tj["bytes_per_step"] / n_launch if "bytes_per_step" in tj else tj.get("bytes_per_launch")
-            traffic_src = f"profiles/{os.path.basename(tf)} ({tj.get('build', 'build n/a')})"
-        except Exception:  # noqa: BLE001
-            traffic = None
+            if bid is not None and tj.get("build") == bid:
+                # HBM bytes of the whole GEMM family per step / its operator launches per step: per launch, like `achieved`
+                traffic = tj["bytes_per_step"] / n_launch
+                traffic_src = f"profiles/{cands[-1]} (build {bid})"
+            else:
+                traffic_src = f"profiles/{cands[-1]} is from build {tj.get('build')}, this is {bid}: refused"
+        except Exception as e:  # noqa: BLE001
+            traffic_src = f"profiles/{cands[-1]} unreadable ({e})"
     common = {"launches_per_step": n_launch, "avg_launch_us": round(k_ms * 1e3 / n_launch, 2),
               "flops_per_launch": k_flops / n_launch, "step_ms_in_kernel": round(k_ms, 3), "traffic_source": traffic_src,
               "step_ms_all_kernels": round(sum(e[0].elapsed_time(e[1]) for e in all_ev), 3),
@@ -716,8 +731,8 @@ def main():
         n_alg = n_launch + sum(1 for e in all_ev if e[3] in ("K12-tap", "K14-tap"))
         alg_ms = ref_graph["ms_gemm_plus_tap_gathers"]
         roofline = {
-            "kernel": "diffsal::igemm_kernel / igemm_linear_kernel / lin_stream_kernel / mlp_block_kernel (fp32 MFMA GEMM family: "
-                      "3x3 convs, token GEMMs, ReduceTemp, fused MLP) + tapsum_kernel (gathers of the restructured convolutions)",
+            "kernel": "diffsal::igemm_kernel / igemm_linear_kernel / lin_stream_kernel / mlp_block_kernel / block_front_kernel (fp32 MFMA GEMM family: "
+                      "3x3 convs, token GEMMs, ReduceTemp, fused transformer-block halves) + tapsum_kernel (gathers of the restructured convolutions)",
             "bound": "mfma", "achieved": ref_graph["tflops_equivalent"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ref_graph["frac_equivalent"], "traffic": None if traffic is None else traffic * n_launch / n_alg,
             "executed_mfma_tflops": round(achieved, 2), "executed_frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -743,7 +758,7 @@ def main():
             **common}
     else:
         roofline = {
-            "kernel": f"diffsal::igemm16_kernel / igemm16_linear_kernel / conv16_halo_kernel / block16_kernel <{args.precision}> "
+            "kernel": f"diffsal::igemm16_kernel / igemm16_linear_kernel / conv16_halo_kernel / block16_kernel / block_front_kernel <{args.precision}> "
                       f"(native 16-bit MFMA GEMM family on {args.precision} storage, fp32 accumulate)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **common}
@@ -783,6 +798,7 @@ def main():
             "gflop_per_clip_step": 151.61 if not av else 152.73,
         },
         "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
+        "build": bid,
         "roofline": roofline,
     }
 

@@ -115,10 +115,9 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   constexpr bool F32 = L::F32;
   // fp32 storage runs one workgroup per CU (LDS) with 512 registers per lane: the next tile's halo pieces are fetched a tile
   // ahead.  16-bit storage fits two workgroups per CU, which cover each other's load phases; no look-ahead (256 registers)
-  constexpr bool AHEAD = F32;
-  // C = 192 on 16-bit storage: Wq + the halo tile fill the LDS (one workgroup per CU) and the registers do not hold a second
-  // tile's pieces through phase D: all of a tile's pieces are requested at once when its phase A starts
-  constexpr bool BULK = !F32 && C > 96;
+  // C = 192 on 16-bit storage: Wq + the halo tile fill the LDS: one workgroup per CU as well, same look-ahead
+  constexpr bool AHEAD = F32 || C > 96;
+  constexpr bool BULK = false;               // (kept: all of a tile's pieces requested at once when its phase A starts)
   typedef typename Mma16<T>::vec vec;
   typedef typename RawPiece<T>::type raw_t;
   auto raw_to_f4 = [](raw_t r) { return raw_to_f4_impl(r, static_cast<const T*>(nullptr)); };
@@ -326,6 +325,17 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
         qin[g].z = (qin[g].z - mean) * rstd * gm.z + bt.z; qin[g].w = (qin[g].w - mean) * rstd * gm.w + bt.w;
       }
     }
+    // 16-bit storage: q_in leaves the fp32 registers here (it is rounded to the storage type exactly once, as the unfused path
+    // does when it stores it): half the registers through phases C and D
+    vec qb[F32 ? 1 : C / 16];
+    if constexpr (!F32) {
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {                               // k-step s = 2 u + j consumes channel groups 2 s, 2 s + 1
+        f32x8 t8 = {qin[2 * s].x, qin[2 * s].y, qin[2 * s].z, qin[2 * s].w,
+                    qin[2 * s + 1].x, qin[2 * s + 1].y, qin[2 * s + 1].z, qin[2 * s + 1].w};
+        qb[s] = __builtin_convertvector(t8, vec);
+      }
+    }
     __syncthreads();                                                  // every wave is done with the halo tile
     stamp(2);
 
@@ -369,22 +379,43 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
     } else {
       // k-step s = 2 u + j consumes channel groups 2 s, 2 s + 1; the NU weight fragments of step s + 1 are read before the
       // MFMAs of step s
-      vec af[2][NU];
+      if constexpr (C <= 96) {
+        vec af[2][NU];
 #pragma unroll
-      for (int t = 0; t < NU; ++t) af[0][t] = *reinterpret_cast<const vec*>(wqf + 32 * t * PW);
+        for (int t = 0; t < NU; ++t) af[0][t] = *reinterpret_cast<const vec*>(wqf + 32 * t * PW);
 #pragma unroll
-      for (int s = 0; s < C / 16; ++s) {
-        if (s + 1 < C / 16) {
+        for (int s = 0; s < C / 16; ++s) {
+          if (s + 1 < C / 16) {
 #pragma unroll
-          for (int t = 0; t < NU; ++t) af[(s + 1) & 1][t] = *reinterpret_cast<const vec*>(wqf + 32 * t * PW + 16 * (s + 1));
+            for (int t = 0; t < NU; ++t) af[(s + 1) & 1][t] = *reinterpret_cast<const vec*>(wqf + 32 * t * PW + 16 * (s + 1));
+          }
+          const vec b = qb[s];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NU; ++t) qt[t] = Mma16<T>::mma(af[s & 1][t], b, qt[t]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        f32x8 t8 = {qin[2 * s].x, qin[2 * s].y, qin[2 * s].z, qin[2 * s].w,
-                    qin[2 * s + 1].x, qin[2 * s + 1].y, qin[2 * s + 1].z, qin[2 * s + 1].w};
-        const vec b = __builtin_convertvector(t8, vec);
-        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // six row tiles: the fragments of a k-step are read half a step ahead (three at a time) -- the register file also
+        // holds the next tile's halo pieces here
+        constexpr int HT = NU / 2;
+        vec af[2][HT];
 #pragma unroll
-        for (int t = 0; t < NU; ++t) qt[t] = Mma16<T>::mma(af[s & 1][t], b, qt[t]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < HT; ++t) af[0][t] = *reinterpret_cast<const vec*>(wqf + 32 * t * PW);
+#pragma unroll
+        for (int i = 0; i < 2 * (C / 16); ++i) {                       // i = 2 s + half
+          const int s = i >> 1, h0 = (i & 1) * HT;
+          if (i + 1 < 2 * (C / 16)) {
+            const int s1 = (i + 1) >> 1, h1 = ((i + 1) & 1) * HT;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) af[(i + 1) & 1][t] = *reinterpret_cast<const vec*>(wqf + 32 * (h1 + t) * PW + 16 * s1);
+          }
+          const vec b = qb[s];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) qt[h0 + t] = Mma16<T>::mma(af[i & 1][t], b, qt[h0 + t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 

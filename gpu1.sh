@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3h
-DIFFSAL_EXTRA_HIPCC_FLAGS=-DDIFFSAL_DEV_STAMPS DIFFSAL_BUILD_JOBS=16 python -m diff_sal_amd.build --force > gpurun_out/r3h/build.log 2>&1
-python tools/probe_front_stamps.py > gpurun_out/r3h/stamps.log 2>&1
-cat gpurun_out/r3h/stamps.log
+timeout 600 python -m pytest tests/test_gpu_block_front.py -x -q > gpurun_out/r3h/t.log 2>&1
+timeout 300 python tools/bench_block_front.py > gpurun_out/r3h/bf_ahead.log 2>&1
+tail -n 2 gpurun_out/r3h/t.log; cat gpurun_out/r3h/bf_ahead.log

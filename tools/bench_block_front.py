@@ -23,10 +23,9 @@ def timed(fn, n=20):
 
 
 def main():
-    N, H, W, C, Lk, heads = 36, 56, 96, 96, 18, 2
-    if len(sys.argv) > 1:
-        N, H, W = map(int, sys.argv[1:4])
-    for dt in (torch.float32, torch.bfloat16, torch.float16):
+    Lk, heads = 18, 2
+    for dt, (N, H, W, C) in ((torch.float32, (36, 56, 96, 96)), (torch.bfloat16, (36, 56, 96, 96)), (torch.float16, (36, 56, 96, 96)),
+                             (torch.bfloat16, (36, 28, 48, 192)), (torch.float16, (36, 28, 48, 192))):
         g = torch.Generator(device="cuda").manual_seed(0)
         r = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc
         x = r(N, H, W, C).to(dt)
@@ -50,7 +49,9 @@ def main():
         M = N * H * W
         tf, tu = timed(fused), timed(unfused)
         nb = 2 * M * C * x.element_size()
-        print(f"{str(dt):15s} M={M}: fused {tf:7.1f} us ({nb / tf / 1e3:6.0f} GB/s once-through)   unfused {tu:7.1f} us")
+        print(f"{str(dt):15s} C={C} M={M}: fused {tf:7.1f} us ({nb / tf / 1e3:6.0f} GB/s once-through)   unfused {tu:7.1f} us")
+        if C != 96:
+            continue
         # the block's second half on the same tokens
         w1, b1_, w2, b2_ = r(2 * C, C, sc=0.1).to(dt), r(2 * C, sc=0.1), r(C, 2 * C, sc=0.08).to(dt), r(C, sc=0.1)
         xt = x.view(N, H * W, C)

@@ -1,18 +1,24 @@
 #!/bin/bash
-# Round profile of the default benchmark on the GPU box: rocprofv3 kernel-trace stats (CSV) and the two PMC passes for HBM
-# traffic (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes).  Writes under gpurun_out/$1.
-# usage: tools/profile_round.sh <outdir-name> <precision> [extra bench args]
+# Round profile of the default benchmark on the GPU box, every artefact stamped with the source id (tools/build_id.py) of the
+# code it was taken on: rocprofv3 kernel-trace stats (CSV), the per-launch table, and the two PMC passes for HBM traffic
+# (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes).  Writes under gpurun_out/<out>/ with the
+# names profiles/ uses (<round>_...), so collecting is a copy.
+# usage: tools/profile_round.sh <outdir-name> <round-tag e.g. r03> <precision> <mode vis|av> [pmc]
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; PREC=$2; shift 2
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; TAG=$2; PREC=$3; MODE=$4; PMC=${5:-}
 mkdir -p $OUT
+BID=$(python3 $GRAFT_REPO_ROOT/tools/build_id.py)
+SUF=${PREC}$([ "$MODE" = av ] && echo _av)
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-alt-precision --no-encoders --no-reference-graph --precision $PREC --steps 50 --warmup 5 --repeats 1 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$PREC -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/stats_$PREC.json 2> $OUT/stats_$PREC.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$PREC -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_fetch_$PREC.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$PREC -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_write_$PREC.err
-find $OUT -name "*kernel_stats.csv" | head; find $OUT -name "*counter_collection.csv" | head
-# keep only the summaries (the traces are large)
+ARGS="--no-cpu-baseline --no-alt-precision --no-encoders --no-reference-graph --no-train-leg --precision $PREC --mode $MODE --warmup 5 --repeats 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 50 --dump-launches $OUT/${TAG}_launches_$SUF.json > $OUT/${TAG}_bench_profiled_$SUF.json 2> $OUT/stats_$SUF.err
+cp $(find $OUT/stats_$SUF -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${SUF}_kernel_stats.csv
+sed -i "1s/^/# build $BID: rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS --steps 50\n/" $OUT/${TAG}_${SUF}_kernel_stats.csv
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
-# HBM traffic summary of the GEMM family (bench.py reads profiles/r02_igemm_hbm_traffic_<precision>.json)
-python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $OUT/pmc_fetch_$PREC $OUT/pmc_write_$PREC $OUT/r02_igemm_hbm_traffic_$PREC.json $PREC "${BUILD_ID:-build n/a}"
-cp $(find $OUT/stats_$PREC -name "*kernel_stats.csv" | head -1) $OUT/r02_${PREC}_kernel_stats.csv
+if [ -n "$PMC" ]; then
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_fetch_$SUF.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_write_$SUF.err
+  python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $OUT/pmc_fetch_$SUF $OUT/pmc_write_$SUF $OUT/${TAG}_hbm_traffic_$SUF.json $PREC "$BID" $OUT/${TAG}_launches_$SUF.json > $OUT/pmc_traffic_$SUF.log 2>&1
+  find $OUT -name "*counter_collection.csv" -size +5M -delete
+fi
+echo "profile_round $SUF done (build $BID)"
