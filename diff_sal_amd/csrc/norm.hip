@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void dwconv3_ln_strip_kernel(const T* __restri
 
 // depthwise k x k, stride k, no padding, + LayerNorm, for K and V at once: one workgroup per pooled token.
 // R/.../attention.py:49-76,88-95.  Threads = (256/G position lanes) x (G channel lanes).
-template <int G, int NV, typename T, bool PRELN = false>
+template <int G, int NV, typename T, bool PRELN = false, bool PROJ = false>
 __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, const T* __restrict__ xv,
                                                   const float* __restrict__ wk, const float* __restrict__ wv,
                                                   const float* __restrict__ gk, const float* __restrict__ bk,
@@ -373,9 +373,11 @@ __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, cons
                                                   T* __restrict__ ok, T* __restrict__ ov, int H, int W,
                                                   int C, int k, int gh, int gw, float eps, int tok,
                                                   const float* __restrict__ pg = nullptr, const float* __restrict__ pb = nullptr,
-                                                  float peps = 0.f, bool ln_k = false, bool ln_v = false) {
+                                                  float peps = 0.f, bool ln_k = false, bool ln_v = false,
+                                                  const T* __restrict__ pwk = nullptr, const float* __restrict__ pbk = nullptr,
+                                                  const T* __restrict__ pwv = nullptr, const float* __restrict__ pbv = nullptr) {
   constexpr int PL = 256 / G;
-  extern __shared__ float shp[];  // [2][PL][C]
+  extern __shared__ float shp[];  // [2][PL][C] (+ [2][C] of T behind it when the projections are folded in)
   const int gl = threadIdx.x % G;
   const int pl = threadIdx.x / G;
   // tok = n * gh*gw + gy*gw + gx
@@ -475,8 +477,39 @@ __device__ __forceinline__ void dwpool_ln_kv_body(const T* __restrict__ xk, cons
         }
       }
     }
-    if (pl == 0) ln_rows_finish<G, NV, T>(v, gl, C, gk, bk, eps, ok + static_cast<long>(tok) * C);
-    else ln_rows_finish<G, NV, T>(v, gl, C, gv, bv, eps, ov + static_cast<long>(tok) * C);
+    if constexpr (PROJ) {
+      // proj_k / proj_v (attention.py:79-80,98-99) folded in: the normalised token is parked in LDS, rounded to the storage
+      // type as the stand-alone launch would have stored it
+      T* park = reinterpret_cast<T*>(shp + 2 * PL * C);
+      if (pl == 0) ln_rows_finish<G, NV, T>(v, gl, C, gk, bk, eps, park);
+      else ln_rows_finish<G, NV, T>(v, gl, C, gv, bv, eps, park + C);
+    } else {
+      if (pl == 0) ln_rows_finish<G, NV, T>(v, gl, C, gk, bk, eps, ok + static_cast<long>(tok) * C);
+      else ln_rows_finish<G, NV, T>(v, gl, C, gv, bv, eps, ov + static_cast<long>(tok) * C);
+    }
+  }
+  if constexpr (PROJ) {
+    __syncthreads();
+    const T* park = reinterpret_cast<const T*>(shp + 2 * PL * C);
+    // one output feature of K or V per group of G lanes (G = C / 12: the lanes of a group read consecutive 16-byte pieces of
+    // one weight row -- coalesced, three independent loads per lane -- and combine on the VALU); 256 / G features per pass
+    constexpr int FPP = 256 / G;
+    const int fg = threadIdx.x / G, fl = threadIdx.x % G;
+    for (int f0 = 0; f0 < 2 * C; f0 += FPP) {
+      const int idx = min(f0 + fg, 2 * C - 1);                    // (2 C is a multiple of FPP for C = 96, 192)
+      const int which = idx >= C, nn = idx - which * C;
+      const T* wrow = (which ? pwv : pwk) + static_cast<long>(nn) * C;
+      const T* xin = park + which * C;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (fl + i * G) * 4;
+        const float4 w4 = ld4(wrow + c), x4 = ld4(xin + c);
+        acc = fmaf(w4.x, x4.x, fmaf(w4.y, x4.y, fmaf(w4.z, x4.z, fmaf(w4.w, x4.w, acc))));
+      }
+      acc = group_sum<G>(acc);
+      if (fl == 0 && f0 + fg < 2 * C) (which ? ov : ok)[static_cast<long>(tok) * C + nn] = static_cast<T>(acc + (which ? pbv : pbk)[nn]);
+    }
   }
 }
 
@@ -502,9 +535,11 @@ struct QkvPrepArgs {
   // PRELN: the block's LayerNorm (transformer.py:110: x = self.norm(x)) applied to the tokens as they are loaded -- the
   // query input and the value input always, the key input when it is the same normalised tensor (visual-only)
   const float* pg; const float* pb; float peps; int ln_k;
+  // pooled branch alone, small C: proj_k / proj_v folded in ([C][C] weights in the storage type, fp32 biases); null = off
+  const void* pwk; const float* pbk; const void* pwv; const float* pbv;
 };
 
-template <bool STRIP, int G, int NV, typename T, bool PRELN>
+template <bool STRIP, int G, int NV, typename T, bool PRELN, bool PROJ = false>
 __global__ __launch_bounds__(256) void qkv_prep_kernel(QkvPrepArgs a) {
   const int b = blockIdx.x;
   if (b < a.nq) {
@@ -515,9 +550,10 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(QkvPrepArgs a) {
       dwconv3_ln_body<G, NV, T, PRELN>(static_cast<const T*>(a.xq), a.w9, a.gq, a.bq, static_cast<T*>(a.oq), a.N, a.H, a.W, a.C,
                                        a.eps, b, a.nq, a.pg, a.pb, a.peps);
   } else {
-    dwpool_ln_kv_body<G, NV, T, PRELN>(static_cast<const T*>(a.xk), static_cast<const T*>(a.xv), a.wk, a.wv, a.gk, a.bk, a.gv,
-                                       a.bv, static_cast<T*>(a.ok), static_cast<T*>(a.ov), a.H, a.W, a.C, a.k, a.gh, a.gw, a.eps,
-                                       b - a.nq, a.pg, a.pb, a.peps, a.ln_k != 0, true);
+    dwpool_ln_kv_body<G, NV, T, PRELN, PROJ>(static_cast<const T*>(a.xk), static_cast<const T*>(a.xv), a.wk, a.wv, a.gk, a.bk, a.gv,
+                                             a.bv, static_cast<T*>(a.ok), static_cast<T*>(a.ov), a.H, a.W, a.C, a.k, a.gh, a.gw, a.eps,
+                                             b - a.nq, a.pg, a.pb, a.peps, a.ln_k != 0, true, static_cast<const T*>(a.pwk), a.pbk,
+                                             static_cast<const T*>(a.pwv), a.pbv);
   }
 }
 
@@ -706,7 +742,11 @@ static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
 #define CALLKV(G)                                                                                                   \
   do {                                                                                                              \
     a.nq = 0;                                                                                                       \
-    hipLaunchKernelGGL((qkv_prep_kernel<false, G, 3, T, true>), dim3(nkv), dim3(256), (256 / G) * lds_of, s, a);     \
+    if (a.pwk)                                                                                                      \
+      hipLaunchKernelGGL((qkv_prep_kernel<false, G, 3, T, true, true>), dim3(nkv), dim3(256),                       \
+                         (256 / G) * lds_of + 2 * a.C * sizeof(T), s, a);                                           \
+    else                                                                                                            \
+      hipLaunchKernelGGL((qkv_prep_kernel<false, G, 3, T, true, false>), dim3(nkv), dim3(256), (256 / G) * lds_of, s, a); \
     return check_launch("qkv_prep(kv)");                                                                            \
   } while (0)
     if (c4 == 24) CALLKV(8);
@@ -736,10 +776,31 @@ extern "C" int diffsal_qkv_prep(const void* xq, const float* w9, const float* gq
                  aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v),
              DIFFSAL_E_ALIGN, "qkv_prep: misaligned pointer");
   QkvPrepArgs a{xq, w9, gq, bq, out_q, xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, N, H, W, C, k, (H - k) / k + 1, (W - k) / k + 1, 0, eps,
-                pre_gamma, pre_beta, pre_eps, pre_ln_k};
+                pre_gamma, pre_beta, pre_eps, pre_ln_k, nullptr, nullptr, nullptr, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALLT(T) return qkv_prep_t<T>(a, s)
   DS_DTYPE_DISPATCH(dtype, "qkv_prep", CALLT);
+#undef CALLT
+  return DIFFSAL_OK;
+}
+
+extern "C" int diffsal_kv_prep_proj(const void* xk, const void* xv, const float* wk, const float* wv, const float* gk,
+                                    const float* bk, const float* gv, const float* bv, const void* proj_wk, const float* proj_bk,
+                                    const void* proj_wv, const float* proj_bv, void* out_k, void* out_v, int N, int H, int W, int C,
+                                    int k, float eps, const float* pre_gamma, const float* pre_beta, float pre_eps, int pre_ln_k,
+                                    int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(xk && xv && wk && wv && gk && bk && gv && bv && proj_wk && proj_bk && proj_wv && proj_bv && out_k && out_v && pre_gamma &&
+                 pre_beta, DIFFSAL_E_ARG, "kv_prep_proj: null argument");
+  DS_REQUIRE(N > 0 && (C == 96 || C == 192) && k > 0 && H >= k && W >= k, DIFFSAL_E_SHAPE,
+             "kv_prep_proj: built for C = 96 / 192 (every workgroup reads both [C, C] weights); got H=%d W=%d C=%d k=%d", H, W, C, k);
+  DS_REQUIRE(aligned16(xk) && aligned16(xv) && aligned16(wk) && aligned16(wv) && aligned16(out_k) && aligned16(out_v) &&
+                 aligned16(proj_wk) && aligned16(proj_wv) && aligned16(pre_gamma) && aligned16(pre_beta),
+             DIFFSAL_E_ALIGN, "kv_prep_proj: misaligned pointer");
+  QkvPrepArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, xk, xv, wk, wv, gk, bk, gv, bv, out_k, out_v, N, H, W, C, k, (H - k) / k + 1,
+                (W - k) / k + 1, 0, eps, pre_gamma, pre_beta, pre_eps, pre_ln_k, proj_wk, proj_bk, proj_wv, proj_bv};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALLT(T) return qkv_prep_t<T>(a, s)
+  DS_DTYPE_DISPATCH(dtype, "kv_prep_proj", CALLT);
 #undef CALLT
   return DIFFSAL_OK;
 }

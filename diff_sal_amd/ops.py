@@ -599,6 +599,25 @@ def kv_prep(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tens
     return ok, ov
 
 
+def kv_prep_proj(xk: Tensor, xv: Tensor, wk: Tensor, wv: Tensor, gk: Tensor, bk: Tensor, gv: Tensor, bv: Tensor, k: int, eps: float,
+                 pre_ln, lin_k, lin_v):
+    """``kv_prep`` with proj_k / proj_v folded in (C = 96 / 192): the whole pooled key / value branch of a block in one launch.
+    lin_k / lin_v = (weight [C, C] in the storage type, bias)."""
+    lib = _lib.load()
+    N, H, W, Cc = xv.shape
+    gh, gw = (H - k) // k + 1, (W - k) // k + 1
+    ok = torch.empty((N, gh * gw, Cc), device=xv.device, dtype=xv.dtype)
+    ov = torch.empty_like(ok)
+    dt = _dt(xv)
+    with _prof("K9", 4.0 * N * H * W * Cc + 4.0 * N * gh * gw * Cc * Cc,
+               _nb(xv, ok, ov, lin_k[0], lin_v[0]) + (0.0 if xk.data_ptr() == xv.data_ptr() else _nb(xk))):
+        _lib.check(lib.diffsal_kv_prep_proj(_pa(xk, dt), _pa(xv, dt), _p(wk), _p(wv), _p(gk), _p(bk), _p(gv), _p(bv),
+                                            _pa(lin_k[0], dt), _p(lin_k[1]), _pa(lin_v[0], dt), _p(lin_v[1]), ok.data_ptr(),
+                                            ov.data_ptr(), N, H, W, Cc, k, eps, _p(pre_ln[0]), _p(pre_ln[1]), float(pre_ln[2]),
+                                            int(bool(pre_ln[3])), dt, _stream()), "kv_prep_proj")
+    return ok, ov
+
+
 def block_front_supported(C: int, heads: int, Lk: int, dtype: torch.dtype = torch.float32) -> bool:
     """csrc/tblock.hip: C = 96 on every storage type, C = 192 on 16-bit storage (there Wq alone fits the LDS next to the tile)."""
     return heads == 2 and 0 < Lk <= 32 and (C == 96 or (C == 192 and dtype != torch.float32))

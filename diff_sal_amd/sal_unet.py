@@ -377,15 +377,19 @@ class SalUNet(nn.Module):
         if (self.fused_front and ops.block_front_supported(C, self.heads[i], gh * gw, x.dtype)
                 and (x.dtype != torch.float32 or self._precision() == "fp32")
                 and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False)):
-            # [pooled k / v with the folded first LayerNorm] [k, v projections] [LayerNorm -> depthwise q -> LayerNorm -> proj_q ->
+            # [pooled k / v with the folded first LayerNorm] [their projections, one paired launch] [LayerNorm -> depthwise q -> LayerNorm -> proj_q ->
             # attention (-> proj + residual on fp32)]: x_n, q_in, q and (fp32) o never reach HBM.  C = 96 continues with the
-            # fused second half (mlp_block / block16: 4 launches for the whole block), C = 192 with the per-operator launches
+            # fused second half (mlp_block / block16: 4 launches for the whole block, 3 with fold_kv_proj), C = 192 with the per-operator launches
             xv_ = x.view(n9, H, W, C)
-            kk, vv = ops.kv_prep(xv_ if k_src is None else k_src.view(n9, H, W, C), xv_, pk[f"s{i}.wk"], pk[f"s{i}.wv"],
-                                 a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight, a.conv_proj_v.bn.bias,
-                                 self.kernel_kv[i], a.conv_proj_k.bn.eps,
-                                 pre_ln=(blk.norm.weight, blk.norm.bias, blk.norm.eps, k_src is None))
-            kk, vv = ops.linear_pair(kk, vv, pk[f"s{i}.k.w"], pk[f"s{i}.v.w"], a.proj_k.bias, a.proj_v.bias)
+            xk_ = xv_ if k_src is None else k_src.view(n9, H, W, C)
+            kvn = (a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight, a.conv_proj_v.bn.bias)
+            pre = (blk.norm.weight, blk.norm.bias, blk.norm.eps, k_src is None)
+            if self.fold_kv_proj and C == 96:
+                kk, vv = ops.kv_prep_proj(xk_, xv_, pk[f"s{i}.wk"], pk[f"s{i}.wv"], *kvn, self.kernel_kv[i], a.conv_proj_k.bn.eps, pre,
+                                          (pk[f"s{i}.k.w"], a.proj_k.bias), (pk[f"s{i}.v.w"], a.proj_v.bias))
+            else:
+                kk, vv = ops.kv_prep(xk_, xv_, pk[f"s{i}.wk"], pk[f"s{i}.wv"], *kvn, self.kernel_kv[i], a.conv_proj_k.bn.eps, pre_ln=pre)
+                kk, vv = ops.linear_pair(kk, vv, pk[f"s{i}.k.w"], pk[f"s{i}.v.w"], a.proj_k.bias, a.proj_v.bias)
             f32 = x.dtype == torch.float32
             y = ops.block_front(xv_, kk, vv, (blk.norm.weight, blk.norm.bias, blk.norm.eps), pk[f"s{i}.wq9"],
                                 (a.conv_proj_q.bn.weight, a.conv_proj_q.bn.bias, a.conv_proj_q.bn.eps),
@@ -493,6 +497,10 @@ class SalUNet(nn.Module):
     fold_norm1 = False
     # finest stage (C = 96): the block's first half is ONE launch (csrc/tblock.hip).  Off: the per-operator launches below
     fused_front = True
+    # proj_k / proj_v inside the pooled launch (the whole C = 96 block is then 3 launches).  Measured: 45 us against 31 + 10 us for
+    # the pooled launch + the paired projection GEMM at stage 3 (every one of the 648 workgroups re-reads both weight matrices
+    # from L2), 43 against 30 us at C = 192: off.
+    fold_kv_proj = False
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)

@@ -381,6 +381,16 @@ int diffsal_attention(const void* q, const void* k, const void* v, void* o, int 
 int diffsal_head_sigmoid(const void* x, const float* w /*[C]*/, const float* bias /*[1]*/, float* out /*fp32*/,
                          int NHW, int C, int dtype, diffsal_stream_t stream);
 
+/* The pooled key / value branch of a TransformerBlock in ONE launch, projections included (C = 96 / 192; attention.py:49-76,
+ * 79-80, 88-99): per pooled token  k = Linear_k(LN_k(pool_k(LN_1?(xk)))),  v = Linear_v(LN_v(pool_v(LN_1(xv)))),  pool = depthwise
+ * k x k stride-k convolution (weights wk / wv [k*k, C] fp32), LN_1 = the block's first LayerNorm applied as the tokens are loaded
+ * (to xv always, to xk when pre_ln_k), proj_w* [C, C] in the storage type.  out_k, out_v [N, gh*gw, C]. */
+int diffsal_kv_prep_proj(const void* xk, const void* xv, const float* wk, const float* wv, const float* gk, const float* bk,
+                         const float* gv, const float* bv, const void* proj_wk, const float* proj_bk, const void* proj_wv,
+                         const float* proj_bv, void* out_k, void* out_v, int N, int H, int W, int C, int k, float eps,
+                         const float* pre_gamma, const float* pre_beta, float pre_eps, int pre_ln_k, int dtype,
+                         diffsal_stream_t stream);
+
 /* ---- fused first half of a TransformerBlock (C = 96, 2 heads; csrc/tblock.hip) --------------------------------------------
  * R/models/saliency_decoder/transformer.py:150-152, attention.py:36-47,87-110:
  *   xn = LayerNorm(x; g1, b1, eps1);  q = Linear_q( LayerNorm(dwconv3x3(xn; w9); gq, bq, epsq) );

@@ -111,3 +111,26 @@ def test_kv_prep_equals_the_pooled_branch_of_qkv_prep(ops, dname, C, kk):
     tol = 2e-6 if dt == torch.float32 else (8e-3 if dt == torch.bfloat16 else 1e-3)     # 16-bit: one rounding step of the output
     for a, b in ((k1, k2), (v1, v2)):
         assert (a.float() - b.float()).abs().max().item() <= tol * b.float().abs().max().item()
+
+
+@pytest.mark.parametrize("dname", list(DT))
+@pytest.mark.parametrize("C,kk,av", [(96, 4, False), (192, 8, True)])
+def test_kv_prep_proj_equals_kv_prep_then_linear_pair(ops, dname, C, kk, av):
+    """proj_k / proj_v folded into the pooled launch == kv_prep followed by linear_pair (same rounding points, summation order aside);
+    visual-only (key from the same normalised tensor) and audio-visual (key from another, un-normalised tensor)."""
+    N, H, W = 3, 16, 32
+    dt = DT[dname]
+    d = lambda name, *s, **kw: rnd(name, *s, **kw).to(DEV)
+    x = (d("kpx", N, H, W, C) * 1.5 + 0.2).to(dt)
+    xk = (d("kpa", N, H, W, C) * 0.7).to(dt) if av else x
+    wk, wv = d("kpwk", kk * kk, C, scale=0.3), d("kpwv", kk * kk, C, scale=0.3)
+    g = [d(f"kpg{i}", C, scale=0.1) + (1 if i % 2 == 0 else 0) for i in range(6)]
+    pre = (g[4], g[5], 1e-5, not av)
+    lk, lv = (d("kplk", C, C, scale=C ** -0.5).to(dt), d("kpbk", C, scale=0.1)), (d("kplv", C, C, scale=C ** -0.5).to(dt), d("kpbv", C, scale=0.1))
+    k0, v0 = ops.kv_prep(xk, x, wk, wv, g[0], g[1], g[2], g[3], kk, 1e-5, pre_ln=pre)
+    k1, v1 = ops.linear_pair(k0, v0, lk[0], lv[0], lk[1], lv[1])
+    k2, v2 = ops.kv_prep_proj(xk, x, wk, wv, g[0], g[1], g[2], g[3], kk, 1e-5, pre, lk, lv)
+    tol = 2e-6 if dt == torch.float32 else (8e-3 if dt == torch.bfloat16 else 1e-3)
+    for a, b in ((k1, k2), (v1, v2)):
+        assert a.shape == b.shape
+        assert (a.float() - b.float()).abs().max().item() <= tol * a.float().abs().max().item()
