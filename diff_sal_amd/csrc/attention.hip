@@ -25,14 +25,13 @@ namespace diffsal {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Unconditional 16-byte load from an address the caller has clamped into valid memory, zeroed when `ok` is false: a
-// conditional load inside an unrolled staging loop compiles to a branch plus a full vmcnt drain per piece, which left the
-// K/V (Q/dO) prefetch latency-bound.
-__device__ __forceinline__ float4 ld4_or_zero(const float* ptr, bool ok) {
-  float4 t = ld4(ptr);
-  if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-  return t;
-}
+// Staging discipline of the three kernels below.  The next tile's pieces are fetched with UNCONDITIONAL 16-byte loads from
+// addresses clamped into valid memory and kept raw in registers; whether a piece is real (inside the tile, key / query inside
+// the sequence) is decided when it is parked in LDS, after the tile's MFMAs.  Any use of a loaded value next to its load
+// (a select, a scale) made hipcc wait for every load before issuing the next one -- twelve dependent L2 round trips per tile
+// in front of the matrix work, with one wave per SIMD nothing to hide them.  LDS fragments are read one group ahead of the
+// MFMAs that consume them (mfma_groups_f32 / mfma_groups_scalar_f32, common.h) for the same reason.
+__device__ __forceinline__ float4 keep_or_zero(float4 t, bool ok) { return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f); }
 
 struct AttnArgs {
   const float* q;        // [B,H,Lq,D] via strides
@@ -75,17 +74,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
   {
     const float* qr = p.q + b * p.q_sb + h * p.q_sh + static_cast<long>(qc) * p.q_sl;
     const float* qe = E ? p.q_extra + (static_cast<long>(bh) * p.Lq + qc) * E : nullptr;
+    // all pieces are requested before any is touched (a scale or a branch next to a load serialises the loads)
+    float4 raw[HQ / 4];
 #pragma unroll
     for (int j4 = 0; j4 < HQ / 4; ++j4) {
       const int e0 = hf * HQ + j4 * 4;   // D, HQ multiples of 4: a float4 piece never straddles q / q_extra
-      float4 t;
-      if (e0 < D) {
-        t = ld4(qr + e0);
-        t.x *= p.scale; t.y *= p.scale; t.z *= p.scale; t.w *= p.scale;
-      } else {
-        t = ld4(qe + (e0 - D));
-      }
-      qf[j4 * 4 + 0] = t.x; qf[j4 * 4 + 1] = t.y; qf[j4 * 4 + 2] = t.z; qf[j4 * 4 + 3] = t.w;
+      const float* src = qr + (e0 < D ? e0 : 0);
+      if constexpr (E > 0) src = e0 < D ? src : qe + (e0 - D);
+      raw[j4] = ld4(src);
+    }
+#pragma unroll
+    for (int j4 = 0; j4 < HQ / 4; ++j4) {
+      const float sc = hf * HQ + j4 * 4 < D ? p.scale : 1.0f;
+      qf[j4 * 4 + 0] = raw[j4].x * sc; qf[j4 * 4 + 1] = raw[j4].y * sc; qf[j4 * 4 + 2] = raw[j4].z * sc; qf[j4 * 4 + 3] = raw[j4].w * sc;
     }
   }
 
@@ -108,38 +109,39 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
     for (int i = 0; i < KPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
-      const int key = key0 + row;
+      const int key = key0 + (row < 32 ? row : 31);              // pieces past the tile read a valid row (never parked)
       const long kc = key < p.Lk ? key : p.Lk - 1;
       const float* src = kb + kc * p.k_sl + (c4 < D ? c4 : 0);
       if constexpr (E > 0) src = c4 < D ? src : p.k_extra + kc * E + (c4 - D);
-      kreg[i] = ld4_or_zero(src, idx < KF4 && key < p.Lk);
+      kreg[i] = ld4(src);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
-      const int key = key0 + row;
+      const int key = key0 + (row < 32 ? row : 31);
       const long kc = key < p.Lk ? key : p.Lk - 1;
-      vreg[i] = ld4_or_zero(vb + kc * p.v_sl + c4, idx < VF4 && key < p.Lk);
+      vreg[i] = ld4(vb + kc * p.v_sl + c4);
     }
   };
-  auto park = [&]() {
+  auto park = [&](int tile) {
+    const int key0 = tile * 32;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
-      if (idx < KF4) st4(&Ks[row * KP + c4], kreg[i]);
+      if (idx < KF4) st4(&Ks[row * KP + c4], keep_or_zero(kreg[i], key0 + row < p.Lk));
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
-      if (idx < VF4) st4(&Vs[row * VP + c4], vreg[i]);
+      if (idx < VF4) st4(&Vs[row * VP + c4], keep_or_zero(vreg[i], key0 + row < p.Lk));
     }
   };
 
   fetch(0);
-  park();
+  park(0);
   __syncthreads();
   for (int tile = 0; tile < n_tiles; ++tile) {
     if (tile + 1 < n_tiles) fetch(tile + 1);   // lands while this tile is computed
@@ -148,14 +150,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     const float* krow = &Ks[ql * KP + hf * HQ];
-#pragma unroll
-    for (int j4 = 0; j4 < HQ / 4; ++j4) {
-      const float4 a = ld4(krow + j4 * 4);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[j4 * 4 + 0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[j4 * 4 + 1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[j4 * 4 + 2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[j4 * 4 + 3], s, 0, 0, 0);
-    }
+    mfma_groups_f32<HQ / 4>([&](int j4) { return krow + j4 * 4; },
+                            [&](int j4, float4 a) { DS_MFMA4(s, a, qf[j4 * 4 + 0], qf[j4 * 4 + 1], qf[j4 * 4 + 2], qf[j4 * 4 + 3]); });
     // ---- online softmax for this lane's query over its 16 keys (+ the partner half's 16)
     const int key_base = tile * 32 + hf * 4;
     float mx = -3.0e38f;
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = key_base + (r & 3) + 8 * (r >> 2);
-      const float e = key < p.Lk ? expf(s[r] - m_new) : 0.f;
+      const float e = key < p.Lk ? __expf(s[r] - m_new) : 0.f;   // v_exp_f32 form: ~1e-6 relative, a quarter of the VALU work of expf
       s[r] = e;
       ps += e;
     }
@@ -182,17 +178,16 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-    // ---- O^T += V^T P^T : A = V[key row of (r, hf)][32 t + (lane & 31)] (LDS), B = p[r]
+    // ---- O^T += V^T P^T : A = V[key row of (r, hf)][32 t + (lane & 31)] (LDS, one scalar per MFMA, eight read ahead), B = p[r]
+    mfma_groups_scalar_f32<2 * NT, 8>(                         // group = (t, half of the 16 key rows): two resident waves share 512 registers
+        [&](int g, int j) { const int r = 8 * (g & 1) + j; return &Vs[(hf * 4 + (r & 3) + 8 * (r >> 2)) * VP + (g >> 1) * 32 + ql]; },
+        [&](int g, const float (&a)[8]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int krow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[krow_i * VP + t * 32 + ql], s[r], o[t], 0, 0, 0);
-    }
+          for (int j = 0; j < 8; ++j) o[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], s[8 * (g & 1) + j], o[g >> 1], 0, 0, 0);
+        });
     __syncthreads();                 // every wave is done with this tile
     if (tile + 1 < n_tiles) {
-      park();
+      park(tile + 1);
       __syncthreads();
     }
   }
@@ -293,13 +288,19 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
   {
     const float* qr = p.q + b * p.q_sb + h * p.q_sh + static_cast<long>(qc) * p.q_sl;
     const float* qe = E ? p.q_extra + (static_cast<long>(bh) * p.Lq + qc) * E : nullptr;
+    // all pieces are requested before any is touched (a scale or a branch next to a load serialises the loads)
+    float4 raw[HQ / 4];
 #pragma unroll
     for (int j4 = 0; j4 < HQ / 4; ++j4) {
       const int e0 = hf * HQ + j4 * 4;
-      float4 t;
-      if (e0 < D) { t = ld4(qr + e0); t.x *= p.scale; t.y *= p.scale; t.z *= p.scale; t.w *= p.scale; }
-      else t = ld4(qe + (e0 - D));
-      qf[j4 * 4 + 0] = t.x; qf[j4 * 4 + 1] = t.y; qf[j4 * 4 + 2] = t.z; qf[j4 * 4 + 3] = t.w;
+      const float* src = qr + (e0 < D ? e0 : 0);
+      if constexpr (E > 0) src = e0 < D ? src : qe + (e0 - D);
+      raw[j4] = ld4(src);
+    }
+#pragma unroll
+    for (int j4 = 0; j4 < HQ / 4; ++j4) {
+      const float sc = hf * HQ + j4 * 4 < D ? p.scale : 1.0f;
+      qf[j4 * 4 + 0] = raw[j4].x * sc; qf[j4 * 4 + 1] = raw[j4].y * sc; qf[j4 * 4 + 2] = raw[j4].z * sc; qf[j4 * 4 + 3] = raw[j4].w * sc;
     }
     const float* gr = p.dout + (static_cast<long>(b) * p.Lq + qc) * (static_cast<long>(p.H) * DV) + h * DV + hf * HV;
 #pragma unroll
@@ -330,37 +331,38 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
     for (int i = 0; i < KPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
-      const int key = key0 + row;
+      const int key = key0 + (row < 32 ? row : 31);
       const long kc = key < p.Lk ? key : p.Lk - 1;
       const float* src = kb + kc * p.k_sl + (c4 < D ? c4 : 0);
       if constexpr (E > 0) src = (c4 < D || c4 >= DQ) ? src : p.k_extra + kc * E + (c4 - D);
-      kreg[i] = ld4_or_zero(src, idx < KF4 && key < p.Lk && c4 < DQ);
+      kreg[i] = ld4(src);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
-      const int key = key0 + row;
+      const int key = key0 + (row < 32 ? row : 31);
       const long kc = key < p.Lk ? key : p.Lk - 1;
-      vreg[i] = ld4_or_zero(vb + kc * p.v_sl + c4, idx < VF4 && key < p.Lk);
+      vreg[i] = ld4(vb + kc * p.v_sl + c4);
     }
   };
-  auto park = [&]() {
+  auto park = [&](int tile) {
+    const int key0 = tile * 32;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
-      if (idx < KF4) st4(&Ks[row * KP + c4], kreg[i]);
+      if (idx < KF4) st4(&Ks[row * KP + c4], keep_or_zero(kreg[i], key0 + row < p.Lk && c4 < DQ));   // zero padding columns up to a tile
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
-      if (idx < VF4) st4(&Vs[row * VP + c4], vreg[i]);
+      if (idx < VF4) st4(&Vs[row * VP + c4], keep_or_zero(vreg[i], key0 + row < p.Lk));
     }
   };
   fetch(0);
-  park();
+  park(0);
   __syncthreads();
   for (int tile = 0; tile < n_tiles; ++tile) {
     if (tile + 1 < n_tiles) fetch(tile + 1);
@@ -368,40 +370,28 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     const float* krow = &Ks[ql * KP + hf * HQ];
-#pragma unroll
-    for (int j4 = 0; j4 < HQ / 4; ++j4) {
-      const float4 a = ld4(krow + j4 * 4);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[j4 * 4 + 0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[j4 * 4 + 1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[j4 * 4 + 2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[j4 * 4 + 3], s, 0, 0, 0);
-    }
+    mfma_groups_f32<HQ / 4>([&](int j4) { return krow + j4 * 4; },
+                            [&](int j4, float4 a) { DS_MFMA4(s, a, qf[j4 * 4 + 0], qf[j4 * 4 + 1], qf[j4 * 4 + 2], qf[j4 * 4 + 3]); });
     const float* vrow = &Vs[ql * VP + hf * HV];                 // dP^T = V dO^T
-#pragma unroll
-    for (int j4 = 0; j4 < HV / 4; ++j4) {
-      const float4 a = ld4(vrow + j4 * 4);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, gf[j4 * 4 + 0], dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, gf[j4 * 4 + 1], dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, gf[j4 * 4 + 2], dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, gf[j4 * 4 + 3], dp, 0, 0, 0);
-    }
+    mfma_groups_f32<HV / 4>([&](int j4) { return vrow + j4 * 4; },
+                            [&](int j4, float4 a) { DS_MFMA4(dp, a, gf[j4 * 4 + 0], gf[j4 * 4 + 1], gf[j4 * 4 + 2], gf[j4 * 4 + 3]); });
     const int key_base = tile * 32 + hf * 4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = key_base + (r & 3) + 8 * (r >> 2);
-      const float pr = key < p.Lk ? expf(s[r] - lse) : 0.f;
+      const float pr = key < p.Lk ? __expf(s[r] - lse) : 0.f;
       s[r] = pr * (dp[r] - delta);                                // dS^T
     }
+    // dQ'^T += K'^T dS^T : A = K'[key row of (r, hf)][32 t + (lane & 31)], one scalar per MFMA, sixteen read ahead
+    mfma_groups_scalar_f32<NQT, 16>(
+        [&](int t, int r) { return &Ks[(hf * 4 + (r & 3) + 8 * (r >> 2)) * KP + t * 32 + ql]; },
+        [&](int t, const float (&a)[16]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {                                // dQ'^T += K'^T dS^T
-      const int krow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-      for (int t = 0; t < NQT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow_i * KP + t * 32 + ql], s[r], acc[t], 0, 0, 0);
-    }
+          for (int r = 0; r < 16; ++r) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], s[r], acc[t], 0, 0, 0);
+        });
     __syncthreads();
     if (tile + 1 < n_tiles) {
-      park();
+      park(tile + 1);
       __syncthreads();
     }
   }
@@ -450,7 +440,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int j4 = 0; j4 < HQ / 4; ++j4) {
       const int e0 = hf * HQ + j4 * 4;
-      const float4 t = e0 < D ? ld4(kr + e0) : ld4(ke + (e0 - D));
+      const float* src = kr + (e0 < D ? e0 : 0);
+      if constexpr (E > 0) src = e0 < D ? src : ke + (e0 - D);
+      const float4 t = ld4(src);
       kf[j4 * 4 + 0] = t.x; kf[j4 * 4 + 1] = t.y; kf[j4 * 4 + 2] = t.z; kf[j4 * 4 + 3] = t.w;
     }
     const float* vr = p.v + b * p.v_sb + h * p.v_sh + static_cast<long>(kc) * p.v_sl + hf * HV;
@@ -484,46 +476,52 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
     for (int i = 0; i < QPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
-      const int qq = q0 + row;
+      const int qq = q0 + (row < 32 ? row : 31);
       const long qcl = qq < p.Lq ? qq : p.Lq - 1;
       const float* src = qb + qcl * p.q_sl + (c4 < D ? c4 : 0);
       if constexpr (E > 0) src = c4 < D ? src : p.q_extra + (static_cast<long>(bh) * p.Lq + qcl) * E + (c4 - D);
-      float4 t = ld4_or_zero(src, idx < QF4 && qq < p.Lq);
-      const float sc = c4 < D ? p.scale : 1.0f;
-      t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
-      qreg[i] = t;
+      qreg[i] = ld4(src);                                        // scaled and masked when it is parked
     }
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
-      const int qq = q0 + row;
+      const int qq = q0 + (row < 32 ? row : 31);
       const long qcl = qq < p.Lq ? qq : p.Lq - 1;
-      greg[i] = ld4_or_zero(p.dout + (static_cast<long>(b) * p.Lq + qcl) * (static_cast<long>(p.H) * DV) + h * DV + c4, idx < GF4 && qq < p.Lq);
+      greg[i] = ld4(p.dout + (static_cast<long>(b) * p.Lq + qcl) * (static_cast<long>(p.H) * DV) + h * DV + c4);
     }
     if (tid < 32) {
       const int qq = q0 + tid;
-      lreg = qq < p.Lq ? p.lse[static_cast<long>(bh) * p.Lq + qq] : 3.0e38f;   // exp(s - huge) = 0 for rows past the end
-      dreg = qq < p.Lq ? p.delta[static_cast<long>(bh) * p.Lq + qq] : 0.f;
+      const long qcl = qq < p.Lq ? qq : p.Lq - 1;
+      lreg = p.lse[static_cast<long>(bh) * p.Lq + qcl];
+      dreg = p.delta[static_cast<long>(bh) * p.Lq + qcl];
     }
   };
-  auto park = [&]() {
+  auto park = [&](int tile) {
+    const int q0 = tile * 32;
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DQ / 4), c4 = (idx - row * (DQ / 4)) * 4;
-      if (idx < QF4) st4(&Qs[row * QP + c4], qreg[i]);
+      float4 t = keep_or_zero(qreg[i], q0 + row < p.Lq);
+      const float sc = c4 < D ? p.scale : 1.0f;
+      t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
+      if (idx < QF4) st4(&Qs[row * QP + c4], t);
     }
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
-      if (idx < GF4) st4(&Gs[row * GP + c4], greg[i]);
+      if (idx < GF4) st4(&Gs[row * GP + c4], keep_or_zero(greg[i], q0 + row < p.Lq));
     }
-    if (tid < 32) { Ls[tid] = lreg; Ds[tid] = dreg; }
+    if (tid < 32) {
+      const bool in = q0 + tid < p.Lq;
+      Ls[tid] = in ? lreg : 3.0e38f;                             // exp(s - huge) = 0 for rows past the end
+      Ds[tid] = in ? dreg : 0.f;
+    }
   };
   fetch(tile_lo);
-  park();
+  park(tile_lo);
   __syncthreads();
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     if (tile + 1 < tile_hi) fetch(tile + 1);
@@ -532,43 +530,38 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     const float* qrow = &Qs[kl * QP + hf * HQ];
-#pragma unroll
-    for (int j4 = 0; j4 < HQ / 4; ++j4) {
-      const float4 a = ld4(qrow + j4 * 4);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kf[j4 * 4 + 0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kf[j4 * 4 + 1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kf[j4 * 4 + 2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kf[j4 * 4 + 3], s, 0, 0, 0);
-    }
+    mfma_groups_f32<HQ / 4>([&](int j4) { return qrow + j4 * 4; },
+                            [&](int j4, float4 a) { DS_MFMA4(s, a, kf[j4 * 4 + 0], kf[j4 * 4 + 1], kf[j4 * 4 + 2], kf[j4 * 4 + 3]); });
     const float* grow = &Gs[kl * GP + hf * HV];                  // dP = dO V^T
-#pragma unroll
-    for (int j4 = 0; j4 < HV / 4; ++j4) {
-      const float4 a = ld4(grow + j4 * 4);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, vf[j4 * 4 + 0], dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, vf[j4 * 4 + 1], dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, vf[j4 * 4 + 2], dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, vf[j4 * 4 + 3], dp, 0, 0, 0);
-    }
+    mfma_groups_f32<HV / 4>([&](int j4) { return grow + j4 * 4; },
+                            [&](int j4, float4 a) { DS_MFMA4(dp, a, vf[j4 * 4 + 0], vf[j4 * 4 + 1], vf[j4 * 4 + 2], vf[j4 * 4 + 3]); });
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qrow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
-      const float pr = expf(s[r] - Ls[qrow_i]);
+      const float pr = __expf(s[r] - Ls[qrow_i]);
       s[r] = pr;                                                 // P
       dp[r] = pr * (dp[r] - Ds[qrow_i]);                         // dS
     }
+    // dV^T += dO^T P and dK^T += (scale q)^T dS : A = dO / Q'[query row of (r, hf)][32 t + (lane & 31)], scalars read ahead
+    mfma_groups_scalar_f32<2 * (NVT + NKT), 8>(                // group = (output tile, half of the 16 query rows)
+        [&](int gg, int j) {
+          const int g = gg >> 1, r = 8 * (gg & 1) + j;
+          const int qrow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
+          return g < NVT ? &Gs[qrow_i * GP + g * 32 + kl] : &Qs[qrow_i * QP + (g - NVT) * 32 + kl];
+        },
+        [&](int gg, const float (&a)[8]) {
+          const int g = gg >> 1, r0 = 8 * (gg & 1);
+          if (g < NVT) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qrow_i = hf * 4 + (r & 3) + 8 * (r >> 2);
+            for (int j = 0; j < 8; ++j) av[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], s[r0 + j], av[g], 0, 0, 0);
+          } else {
 #pragma unroll
-      for (int t = 0; t < NVT; ++t)                              // dV^T += dO^T P
-        av[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[qrow_i * GP + t * 32 + kl], s[r], av[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NKT; ++t)                              // dK^T += (scale q)^T dS
-        ak[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qrow_i * QP + t * 32 + kl], dp[r], ak[t], 0, 0, 0);
-    }
+            for (int j = 0; j < 8; ++j) ak[g - NVT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], dp[r0 + j], ak[g - NVT], 0, 0, 0);
+          }
+        });
     __syncthreads();
     if (tile + 1 < tile_hi) {
-      park();
+      park(tile + 1);
       __syncthreads();
     }
   }

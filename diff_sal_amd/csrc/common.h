@@ -116,6 +116,25 @@ __device__ __forceinline__ void mfma_groups_f32(AddrF addr, BodyF body) {
     a = an;
   }
 }
+// The same for products whose A operand is ONE scalar LDS read per MFMA (the LDS tile is stored [contraction row][feature], the
+// operand wants a feature column): group i = the PER scalars of PER MFMAs, read before the MFMAs of group i - 1.
+// addr(i, j) -> const float* of scalar j of group i; body(i, fragment array).
+template <int N, int PER, typename AddrF, typename BodyF>
+__device__ __forceinline__ void mfma_groups_scalar_f32(AddrF addr, BodyF body) {
+  float a[2][PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) a[0][j] = *addr(0, j);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i + 1 < N) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) a[(i + 1) & 1][j] = *addr(i + 1, j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    body(i, a[i & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 #define DS_MFMA4(ACC, A, B0, B1, B2, B3)                                         \
   do {                                                                           \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B0), ACC, 0, 0, 0);       \
