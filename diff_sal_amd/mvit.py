@@ -124,6 +124,7 @@ class MViT(nn.Module):
                 self.stage_of_layer[i] = stage_of[i]
                 self.add_module(f"norm{stage_of[i]}", nn.LayerNorm(out_dims))
         self._tables: Dict = {}
+        self._const_tables: Dict = {}      # parameter-independent: one-hot key columns, relative-position gather indices
         self._pack: Optional[Dict[str, Tensor]] = None
         self._pack_key = None
         self._pack_epoch = 0
@@ -194,6 +195,22 @@ class MViT(nn.Module):
         idx = (torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio
         return r[idx.long().to(r.device)].contiguous()
 
+    def _onehot_for(self, k_size, dev) -> Tensor:
+        """One-hot key columns matching ops.relpos_project's slots: [0,8) t, [8,24) h, [24,48) w; class-token row 0.  Depends on
+        the key grid only (not on any parameter): built once per grid and device, kept across optimizer steps."""
+        ck = ("onehot", tuple(k_size), str(dev))
+        oh = self._const_tables.get(ck)
+        if oh is None:
+            kt, kh, kw = k_size
+            l = torch.arange(kt * kh * kw, device=dev)
+            oh = torch.zeros((1 + kt * kh * kw, 48), device=dev)
+            oh[1 + l, l // (kh * kw)] = 1.0
+            oh[1 + l, 8 + (l // kw) % kh] = 1.0
+            oh[1 + l, 24 + l % kw] = 1.0
+            oh = oh.contiguous()
+            self._const_tables[ck] = oh
+        return oh
+
     def _tables_for(self, i: int, q_size, k_size):
         tk = (i, tuple(q_size), tuple(k_size))
         t = self._tables.get(tk)
@@ -202,15 +219,7 @@ class MViT(nn.Module):
             Rt = self._rel_table(a.rel_pos_t, q_size[0], k_size[0])
             Rh = self._rel_table(a.rel_pos_h, q_size[1], k_size[1])
             Rw = self._rel_table(a.rel_pos_w, q_size[2], k_size[2])
-            # one-hot key columns matching ops.relpos_project's slots: [0,8) t, [8,24) h, [24,48) w; class-token row 0
-            kt, kh, kw = k_size
-            dev = Rt.device
-            l = torch.arange(kt * kh * kw, device=dev)
-            oh = torch.zeros((1 + kt * kh * kw, 48), device=dev)
-            oh[1 + l, l // (kh * kw)] = 1.0
-            oh[1 + l, 8 + (l // kw) % kh] = 1.0
-            oh[1 + l, 24 + l % kw] = 1.0
-            t = (Rt, Rh, Rw, oh.contiguous())
+            t = (Rt, Rh, Rw, self._onehot_for(k_size, Rt.device))
             self._tables[tk] = t
         return t
 
@@ -259,7 +268,7 @@ class MViT(nn.Module):
         Rt = self._rel_table_diff(a.rel_pos_t, q_size[0], k_size[0])
         Rh = self._rel_table_diff(a.rel_pos_h, q_size[1], k_size[1])
         Rw = self._rel_table_diff(a.rel_pos_w, q_size[2], k_size[2])
-        onehot = self._tables_for(i, q_size, k_size)[3]
+        onehot = self._onehot_for(k_size, x.device)
         extra = eg.relpos_project(q, Rt, Rh, Rw, q_size, k_size)
         o = eg.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual_q=True, skip_first=True)
         skip = ag.linear(xn, blk.proj.weight, blk.proj.bias) if hasattr(blk, "proj") else x
@@ -270,22 +279,25 @@ class MViT(nn.Module):
         h = ag.gelu(ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
         return ag.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x), q_size
 
-    @staticmethod
-    def _rel_table_diff(rel: Tensor, q_size: int, k_size: int) -> Tensor:
+    def _rel_table_diff(self, rel: Tensor, q_size: int, k_size: int) -> Tensor:
         max_rel = int(2 * max(q_size, k_size) - 1)
         r = rel
         if r.shape[0] != max_rel:
             r = F.interpolate(r.t().unsqueeze(0), size=max_rel, mode="linear").squeeze(0).t()
-        q_ratio, k_ratio = max(k_size / q_size, 1.0), max(q_size / k_size, 1.0)
-        idx = (torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio
-        return r[idx.long().to(r.device)].contiguous()
+        ck = ("relidx", q_size, k_size, str(rel.device))
+        idx = self._const_tables.get(ck)                 # gather indices: grid geometry only, resident on the device
+        if idx is None:
+            q_ratio, k_ratio = max(k_size / q_size, 1.0), max(q_size / k_size, 1.0)
+            idx = (torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio
+            idx = idx.long().to(rel.device)
+            self._const_tables[ck] = idx
+        return r[idx].contiguous()
 
     def forward_train(self, x: Tensor) -> List[Tensor]:
         from . import autograd_ops as ag
         from . import encoder_autograd as eg
 
         B = x.shape[0]
-        self.packed()
         cols, size = ops.im2col3d(x, (3, 7, 7), (2, 4, 4), (1, 3, 3), 448)           # the clip needs no gradient
         L = size[0] * size[1] * size[2]
         w = F.pad(self.patch_embed.projection.weight.reshape(96, -1), (0, 7))
