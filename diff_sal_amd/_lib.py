@@ -114,6 +114,7 @@ SIGNATURES = {
     "diffsal_relpos_project_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] + [c_i] * 8 + [c_f]),
     "diffsal_resize_update": (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl] * 5 + [c_f]),
     "diffsal_saliency_metrics_ws_bytes": (c_sz, [c_i]),
+    "diffsal_saliency_metrics_bwd": (c_i, [c_f, c_f, c_i, C.c_long, c_f, c_sz, c_f, c_f, c_f]),
     "diffsal_saliency_metrics": (c_i, [c_f, c_f, c_i, C.c_long, c_f, c_sz, c_f, c_f, c_f]),
     "diffsal_reduce_partials": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_norm_finalize_fwd": (c_i, [c_f] * 7 + [c_i, c_i, c_i, C.c_double, C.c_double] + [c_f] * 4 + [c_fl, c_fl, c_f]),

@@ -1154,8 +1154,21 @@ def tokens_to_channels_first(x: Tensor, off: int = 0) -> Tensor:
     return out
 
 
-def saliency_metrics(pred: Tensor, gt: Tensor):
-    """-> (means [4], per_image [B,4]) in the order (cc, sim, nss, kl); R/models/sal_losses.py:14-176."""
+def saliency_metrics_bwd(pred: Tensor, gt: Tensor, ws: Tensor, weights4: Tensor) -> Tensor:
+    """d(sum_k weights4[k] * term_k) / d pred for the four batch-mean terms (cc, sim, nss, kl) from the forward's workspace."""
+    lib = _lib.load()
+    B = pred.shape[0]
+    n = pred.numel() // B
+    dp = torch.empty_like(pred)
+    with _prof("metrics", 0.0, 3 * _nb(pred)):
+        _lib.check(lib.diffsal_saliency_metrics_bwd(_p(pred), _p(gt), B, n, ws.data_ptr(), ws.numel() * 8, _p(weights4), _p(dp),
+                                                    _stream()), "saliency_metrics_bwd")
+    return dp
+
+
+def saliency_metrics(pred: Tensor, gt: Tensor, keep_ws: bool = False):
+    """-> (means [4], per_image [B,4]) in the order (cc, sim, nss, kl); R/models/sal_losses.py:14-176.  keep_ws: also return
+    the contiguous fp32 inputs and the workspace (what saliency_metrics_bwd needs)."""
     lib = _lib.load()
     if pred.shape != gt.shape:
         raise RuntimeError(f"saliency_metrics: shapes differ: {tuple(pred.shape)} vs {tuple(gt.shape)}")
@@ -1169,6 +1182,8 @@ def saliency_metrics(pred: Tensor, gt: Tensor):
     with _prof("metrics", 0.0, 2 * _nb(p, g)):
         _lib.check(lib.diffsal_saliency_metrics(_p(p), _p(g), B, n, ws.data_ptr(), nws, _p(per), _p(mean), _stream()),
                    "saliency_metrics")
+    if keep_ws:
+        return mean, per, (p, g, ws)
     return mean, per
 
 

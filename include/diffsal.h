@@ -505,6 +505,11 @@ int diffsal_maxpool2d(const void* in, void* out, int N, int H, int W, int C, int
  * mean_out: [4] batch means in the same order (what the reference functions return).  Two streaming passes, fp64
  * accumulation in a fixed order; ws >= diffsal_saliency_metrics_ws_bytes(B) bytes. */
 size_t diffsal_saliency_metrics_ws_bytes(int B);
+/* Training: gradient of  w_cc CC + w_sim SIM + w_nss NSS + w_kl KL  (the four batch means above) with respect to pred, from the
+ * workspace the forward call left behind; weights4 = four floats on the device (upstream gradients x the configuration's loss
+ * weights).  The differentiable terms of get_kl_cc_sim_loss / get_lossv2 (R/models/sal_losses.py:179-259). */
+int diffsal_saliency_metrics_bwd(const float* pred, const float* gt, int B, long n, const void* ws, size_t ws_bytes,
+                                 const float* weights4, float* dpred, diffsal_stream_t stream);
 int diffsal_saliency_metrics(const float* pred, const float* gt, int B, long n, void* ws, size_t ws_bytes,
                              float* per_image, float* mean_out, diffsal_stream_t stream);
 

@@ -537,6 +537,31 @@ def gen_metrics():
     print("metrics:", {k: float(v) for k, v in d.items() if v.ndim == 0})
 
 
+def gen_loss_grads():
+    """The reference's training loss with its saliency terms switched ON (get_lossv2 -> get_kl_cc_sim_loss,
+    R/models/sal_losses.py:179-259): loss values and the gradient with respect to the prediction by the reference's own
+    autograd.  Two configurations: KL + CC + SIM + NSS, and MSE + CC + NSS.  Inputs = the closed-form maps of gen_metrics."""
+    from models import sal_losses as ref
+
+    gt = torch.relu(orc.synth_tensor("met.gt", (3, 1, 64, 128)) - 1.0) + 0.001 * torch.sigmoid(orc.synth_tensor("met.gt2", (3, 1, 64, 128)))
+    base = torch.sigmoid(orc.synth_tensor("met.pred", (3, 1, 64, 128)) + 2.0 * gt - 1.0)
+    d = {}
+    for name, lc in (("all", dict(loss_kl=True, loss_ce=False, loss_mse=False, loss_cc=True, loss_sim=True, loss_nss=True,
+                                  kl_weight=1.3, cc_weight=-0.7, sim_weight=-0.4, nss_weight=-0.05, mse_weight=1.0, ce_weight=1.0)),
+                     ("mse", dict(loss_kl=False, loss_ce=False, loss_mse=True, loss_cc=True, loss_sim=False, loss_nss=True,
+                                  kl_weight=1.0, cc_weight=-2.0, sim_weight=1.0, nss_weight=-0.1, mse_weight=0.01, ce_weight=1.0))):
+        cfg = types.SimpleNamespace(loss=types.SimpleNamespace(**lc))
+        pred = base.clone().requires_grad_(True)
+        out = ref.get_lossv2(cfg, pred, gt)
+        out["total"].backward()
+        for k in ("total", "main", "cc", "sim", "nss"):
+            d[f"{name}.{k}"] = np.array(float(out[k]))
+        d[f"{name}.grad"] = pred.grad.numpy().copy()
+        d[f"{name}.cfg"] = np.array([lc[k] for k in ("kl_weight", "cc_weight", "sim_weight", "nss_weight", "mse_weight")])
+        print(f"loss grads [{name}]:", {k: float(out[k]) for k in out}, "|grad| max", float(pred.grad.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "sal_loss_grads.npz"), **d)
+
+
 def gen_legacy_denoising():
     """The reference's legacy loops R/util/denoising.py:9-69 (dead code upstream, but the call surface north_star names)
     on a toy noise-predicting model.  They hard-code .to('cuda'); on this CPU-only host that one call is mapped to a
@@ -625,7 +650,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio", "legacy_unet", "full"]
+    which = sys.argv[1:] or ["forward", "f1", "sampler", "trainer", "train", "legacy", "mvit", "metrics", "audio", "legacy_unet", "full", "lossgrad"]
     if "legacy" in which:
         gen_legacy_denoising()
     if "legacy_unet" in which:
@@ -634,6 +659,8 @@ if __name__ == "__main__":
         gen_mvit()
     if "metrics" in which:
         gen_metrics()
+    if "lossgrad" in which:
+        gen_loss_grads()
     if "audio" in which:
         gen_audio()
     if "forward" in which:

@@ -253,3 +253,31 @@ def test_audio_visual_model_end_to_end_on_the_hip_path():
     err = (out.cpu() - ref).abs().max().item()
     print("AV end-to-end max abs err", err)
     assert err < RTOL * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["all", "mse"])
+def test_training_loss_terms_and_gradients_match_reference(golden_dir, name):
+    """get_lossv2 with the saliency terms switched ON (R/models/sal_losses.py:179-259): loss values and d total / d pred on the
+    device against the reference's own autograd (fixture of oracle/gen_golden.py::gen_loss_grads).  'all' = KL + CC + SIM + NSS,
+    'mse' = weighted MSE + CC + NSS."""
+    import types
+
+    from diff_sal_amd import sal_losses as sl
+
+    g = np.load(f"{golden_dir}/sal_loss_grads.npz")
+    m = np.load(f"{golden_dir}/sal_metrics.npz")
+    kl_w, cc_w, sim_w, nss_w, mse_w = (float(v) for v in g[f"{name}.cfg"])
+    lc = dict(loss_kl=name == "all", loss_ce=False, loss_mse=name == "mse", loss_cc=True, loss_sim=name == "all", loss_nss=True,
+              kl_weight=kl_w, cc_weight=cc_w, sim_weight=sim_w, nss_weight=nss_w, mse_weight=mse_w, ce_weight=1.0)
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(**lc))
+    pred = torch.from_numpy(m["pred"]).to(DEV).requires_grad_(True)
+    gt = torch.from_numpy(m["gt"]).to(DEV)
+    out = sl.get_lossv2(cfg, pred, gt)
+    out["total"].backward()
+    for k in ("total", "main", "cc", "sim", "nss"):
+        ref = float(g[f"{name}.{k}"])
+        assert abs(float(out[k]) - ref) <= 2e-5 * max(1.0, abs(ref)), (k, float(out[k]), ref)
+    gref = torch.from_numpy(g[f"{name}.grad"])
+    err = (pred.grad.cpu() - gref).abs().max().item() / gref.abs().max().item()
+    print(f"loss gradient [{name}]: rel err {err:.2e}")
+    assert err < 1e-4

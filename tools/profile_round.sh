@@ -13,12 +13,16 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --no-alt-precision --no-encoders --no-reference-graph --no-train-leg --precision $PREC --mode $MODE --warmup 5 --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 50 --dump-launches $OUT/${TAG}_launches_$SUF.json > $OUT/${TAG}_bench_profiled_$SUF.json 2> $OUT/stats_$SUF.err
 cp $(find $OUT/stats_$SUF -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${SUF}_kernel_stats.csv
-sed -i "1s/^/# build $BID: rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS --steps 50\n/" $OUT/${TAG}_${SUF}_kernel_stats.csv
-find $OUT -name "*kernel_trace.csv" -size +20M -delete
+echo "{\"file\": \"$(basename $OUT/${TAG}_${SUF}_kernel_stats.csv)\", \"build\": \"$BID\", \"command\": \"rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS --steps 50\"}" >> $OUT/${TAG}_manifest.jsonl
 if [ -n "$PMC" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_fetch_$SUF.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_write_$SUF.err
   python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $OUT/pmc_fetch_$SUF $OUT/pmc_write_$SUF $OUT/${TAG}_hbm_traffic_$SUF.json $PREC "$BID" $OUT/${TAG}_launches_$SUF.json > $OUT/pmc_traffic_$SUF.log 2>&1
+  # matrix-pipe busy fraction per kernel (its own pass; joined with the durations of the kernel-trace pass above)
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_busy_$SUF -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 10 > /dev/null 2> $OUT/pmc_busy_$SUF.err
+  { echo "<!-- build $BID: rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python3 bench.py $ARGS --steps 10, durations from the kernel-trace pass -->";
+    python3 $GRAFT_REPO_ROOT/tools/pmc_mfma_busy.py $OUT/pmc_busy_$SUF $OUT/stats_$SUF 8; } > $OUT/${TAG}_pmc_mfma_busy_$SUF.md 2> $OUT/pmc_busy_tool_$SUF.err
   find $OUT -name "*counter_collection.csv" -size +5M -delete
 fi
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
 echo "profile_round $SUF done (build $BID)"
