@@ -66,7 +66,8 @@ def _tiny_kwargs():
 
 
 def test_training_batches_are_never_chunked():
-    """BatchNorm batch statistics are over the whole per-rank batch (reference cfg batch_size 48 > the 16-clip eval pass)."""
+    """BatchNorm batch statistics are over the whole per-rank batch (reference cfg batch_size 48); eval batches beyond the pass size
+    (``clips_per_pass``: what keeps every operand inside 32-bit offsets, capped by ``max_clips_per_pass``) are evaluated in passes."""
     net = tiny_salunet().train()
     seen = []
     net.forward_train = lambda x, t, f, a=None: seen.append(x.shape[0]) or x
@@ -76,6 +77,10 @@ def test_training_batches_are_never_chunked():
     net.eval()
     calls = []
     net._forward_pass = lambda x, t, f, a, taps: calls.append(x.shape[0]) or torch.zeros(x.shape[0], 1, 64, 128)
+    net(x, torch.zeros(40, dtype=torch.long), [torch.zeros(40, 1)] * 4, None)
+    assert calls == [40]                       # small maps: 40 clips fit one pass
+    net.max_clips_per_pass = 16
+    calls.clear()
     net(x, torch.zeros(40, dtype=torch.long), [torch.zeros(40, 1)] * 4, None)
     assert calls == [16, 16, 8]
 
