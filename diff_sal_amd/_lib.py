@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 SIGNATURES = {
@@ -103,15 +103,21 @@ SIGNATURES = {
     "diffsal_im2col3d": (c_i, [c_f, c_f] + [c_i] * 15 + [c_f]),
     "diffsal_pool3d_ln": (c_i, [c_f] * 5 + [c_i] * 9 + [C.c_long, C.c_long, c_fl, c_f]),
     "diffsal_maxpool_tokens": (c_i, [c_f, c_f] + [c_i] * 11 + [c_f]),
-    "diffsal_relpos_project": (c_i, [c_f] * 5 + [c_i] * 8 + [c_f]),
+    "diffsal_relpos_project": (c_i, [c_f] * 5 + [c_i] * 9 + [c_f]),
     "diffsal_tokens_to_channels_first": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_pool3d_bwd_data": (c_i, [c_f] * 3 + [c_i] * 9 + [C.c_long, C.c_long, c_f]),
     "diffsal_pool3d_bwd_weight_chunks": (c_i, []),
     "diffsal_pool3d_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 9 + [C.c_long, C.c_long, c_f]),
     "diffsal_maxpool_tokens_idx": (c_i, [c_f] * 3 + [c_i] * 11 + [c_f]),
     "diffsal_maxpool_tokens_bwd": (c_i, [c_f] * 3 + [c_i] * 11 + [c_f]),
+    "diffsal_qkv_pool": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 3),
+    "diffsal_qkv_pool_bwd_data": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 3),
+    "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
+    "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),
+    "diffsal_qkv_pool_bwd_weight_chunks": (c_i, []),
+    "diffsal_qkv_pool_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 3),
     "diffsal_relpos_project_bwd_chunks": (c_i, []),
-    "diffsal_relpos_project_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] + [c_i] * 8 + [c_f]),
+    "diffsal_relpos_project_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] + [c_i] * 9 + [c_f]),
     "diffsal_resize_update": (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl] * 5 + [c_f]),
     "diffsal_saliency_metrics_ws_bytes": (c_sz, [c_i]),
     "diffsal_saliency_metrics_bwd": (c_i, [c_f, c_f, c_i, C.c_long, c_f, c_sz, c_f, c_f, c_f]),

@@ -651,11 +651,12 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
   const dim3 grid((Lq + 127) / 128, B * H);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (D == 96 && E == 48 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 48, 96>), grid, dim3(256), 0, s, a);
+  else if (D == 96 && E == 32 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 32, 96>), grid, dim3(256), 0, s, a);
   else if (D == 96 && E == 0 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 0, 96>), grid, dim3(256), 0, s, a);
   else if (D == 64 && E == 0 && DV == 64) hipLaunchKernelGGL((attention_fwd_kernel<64, 0, 64>), grid, dim3(256), 0, s, a);
   else if (D == 32 && E == 0 && DV == 32) hipLaunchKernelGGL((attention_fwd_kernel<32, 0, 32>), grid, dim3(256), 0, s, a);
   else {
-    set_error("attention_general: (D, E, DV) = (%d, %d, %d) is not built: (96,48,96), (96,0,96), (64,0,64), (32,0,32)", D, E, DV);
+    set_error("attention_general: (D, E, DV) = (%d, %d, %d) is not built: (96,48,96), (96,32,96), (96,0,96), (64,0,64), (32,0,32)", D, E, DV);
     return DIFFSAL_E_SHAPE;
   }
   return check_launch("attention_general");
@@ -700,6 +701,7 @@ extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extr
   DS_REQUIRE((static_cast<long>(B) * H * Lk * D) % 4 == 0, DIFFSAL_E_SHAPE, "attention_general_bwd: dk size");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (D == 96 && E == 48 && DV == 96) return launch_attention_bwd<96, 48, 96>(a, B, s);
+  if (D == 96 && E == 32 && DV == 96) return launch_attention_bwd<96, 32, 96>(a, B, s);
   if (D == 96 && E == 0 && DV == 96) return launch_attention_bwd<96, 0, 96>(a, B, s);
   if (D == 64 && E == 0 && DV == 64) return launch_attention_bwd<64, 0, 64>(a, B, s);
   if (D == 32 && E == 0 && DV == 32) return launch_attention_bwd<32, 0, 32>(a, B, s);

@@ -182,13 +182,17 @@ __global__ __launch_bounds__(256) void maxpool_tokens_kernel(const float* __rest
 // (unused slots and the class-token row are zero).  q: [B*heads, 1 + qt*qh*qw, D] (the pooled, normalised, UNSCALED q).
 // One wavefront per query: lane e < 48 forms one dot product.
 // ------------------------------------------------------------------------------------------------
-constexpr int REL_E = 48, REL_T0 = 0, REL_H0 = 8, REL_W0 = 24;
+// Column layouts: E = 48: t [0, 8), h [8, 24), w [24, 48);  E = 32 (key grids up to 8 x 8 x 16 -- every MViTv2-S stage at
+// 224 x 384): t [0, 8), h [8, 16), w [16, 32): a ninth less contraction length in the attention kernels' QK^T.
+constexpr int REL_T0 = 0, REL_H0 = 8;
+__host__ __device__ constexpr int rel_w0(int E) { return E == 32 ? 16 : 24; }
 
 __global__ __launch_bounds__(256) void relpos_project_kernel(const float* __restrict__ q, const float* __restrict__ Rt,
                                                              const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                              float* __restrict__ extra, int D, int qt, int qh, int qw, int kt,
-                                                             int kh, int kw, long rows) {
+                                                             int kh, int kw, long rows, int REL_E) {
   extern __shared__ float sq[];   // [4][D]
+  const int REL_W0 = rel_w0(REL_E);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = static_cast<long>(blockIdx.x) * 4 + wave;
   const int L = qt * qh * qw;
@@ -475,7 +479,8 @@ __global__ __launch_bounds__(256) void maxpool_tokens_bwd_kernel(const float* __
 __global__ __launch_bounds__(256) void relpos_bwd_q_kernel(const float* __restrict__ dE, const float* __restrict__ Rt,
                                                            const float* __restrict__ Rh, const float* __restrict__ Rw,
                                                            float* __restrict__ dq, int D, int qt, int qh, int qw, int kt, int kh,
-                                                           int kw, int accumulate, long rows) {
+                                                           int kw, int accumulate, long rows, int REL_E) {
+  const int REL_W0 = rel_w0(REL_E);
   const int lane = threadIdx.x & 63;
   const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -503,7 +508,8 @@ constexpr int REL_CHUNKS = 32;
 
 __global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __restrict__ dE, const float* __restrict__ q,
                                                                 double* __restrict__ part, int BH, int D, int qt, int qh,
-                                                                int qw, int kt, int kh, int kw) {
+                                                                int qw, int kt, int kh, int kw, int REL_E) {
+  const int REL_W0 = rel_w0(REL_E);
   int i = blockIdx.x, axis = 0;
   if (i >= qt) { i -= qt; axis = 1; }
   if (axis == 1 && i >= qh) { i -= qh; axis = 2; }
@@ -559,6 +565,12 @@ __global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __r
     }
   }
 }
+
+// mvit_pool.hip: head dimension 96 (8 lanes per query, 12 channels per lane)
+int relpos_project96(const float* q, const float* Rt, const float* Rh, const float* Rw, float* extra, long rows, int qt, int qh,
+                     int qw, int kt, int kh, int kw, int E, hipStream_t s);
+int relpos_bwd_q96(const float* dE, const float* Rt, const float* Rh, const float* Rw, float* dq, long rows, int qt, int qh,
+                   int qw, int kt, int kh, int kw, int accumulate, int E, hipStream_t s);
 
 static int rows_grid(long rows, int per_block) {
   long g = (rows + per_block - 1) / per_block;
@@ -621,16 +633,20 @@ extern "C" int diffsal_maxpool_tokens(const float* in, float* out, int B, int C,
 }
 
 extern "C" int diffsal_relpos_project(const float* q, const float* Rt, const float* Rh, const float* Rw, float* extra, int BH,
-                                      int D, int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream) {
+                                      int D, int qt, int qh, int qw, int kt, int kh, int kw, int E, diffsal_stream_t stream) {
   DS_REQUIRE(q && Rt && Rh && Rw && extra, DIFFSAL_E_ARG, "relpos_project: null argument");
+  DS_REQUIRE(E == 48 || E == 32, DIFFSAL_E_SHAPE, "relpos_project: E=%d (column layouts: 48 or 32)", E);
+  const int REL_E = E, REL_W0 = rel_w0(E);
   DS_REQUIRE(BH > 0 && D > 0 && D % 4 == 0 && D <= 1024 && qt > 0 && qh > 0 && qw > 0 && kt > 0 && kt <= REL_H0 - REL_T0 &&
                  kh > 0 && kh <= REL_W0 - REL_H0 && kw > 0 && kw <= REL_E - REL_W0,
-             DIFFSAL_E_SHAPE, "relpos_project: key grid %dx%dx%d exceeds the (8, 16, 24) slots", kt, kh, kw);
+             DIFFSAL_E_SHAPE, "relpos_project: key grid %dx%dx%d exceeds the slots of the E=%d layout", kt, kh, kw, E);
   DS_REQUIRE(aligned16(Rt) && aligned16(Rh) && aligned16(Rw), DIFFSAL_E_ALIGN, "relpos_project: misaligned table");
   const long rows = static_cast<long>(BH) * (static_cast<long>(qt) * qh * qw + 1);
   DS_REQUIRE((rows + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "relpos_project: too many rows");
+  if (D == 96 && rows < (1L << 31) && aligned16(q) && aligned16(extra))
+    return relpos_project96(q, Rt, Rh, Rw, extra, rows, qt, qh, qw, kt, kh, kw, E, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(relpos_project_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 4 * D * sizeof(float),
-                     static_cast<hipStream_t>(stream), q, Rt, Rh, Rw, extra, D, qt, qh, qw, kt, kh, kw, rows);
+                     static_cast<hipStream_t>(stream), q, Rt, Rh, Rw, extra, D, qt, qh, qw, kt, kh, kw, rows, E);
   return check_launch("relpos_project");
 }
 
@@ -721,18 +737,25 @@ extern "C" int diffsal_relpos_project_bwd_chunks(void) { return REL_CHUNKS; }
 
 extern "C" int diffsal_relpos_project_bwd(const float* dextra, const float* q, const float* Rt, const float* Rh, const float* Rw,
                                           float* dq, int accumulate, double* part, int BH, int D, int qt, int qh, int qw, int kt,
-                                          int kh, int kw, diffsal_stream_t stream) {
+                                          int kh, int kw, int E, diffsal_stream_t stream) {
   DS_REQUIRE(dextra && q && Rt && Rh && Rw && dq && part, DIFFSAL_E_ARG, "relpos_project_bwd: null argument");
+  DS_REQUIRE(E == 48 || E == 32, DIFFSAL_E_SHAPE, "relpos_project_bwd: E=%d (column layouts: 48 or 32)", E);
+  const int REL_E = E, REL_W0 = rel_w0(E);
   DS_REQUIRE(BH > 0 && D > 0 && D % 4 == 0 && D <= 1024 && qt > 0 && qh > 0 && qw > 0 && kt > 0 && kt <= REL_H0 - REL_T0 &&
                  kh > 0 && kh <= REL_W0 - REL_H0 && kw > 0 && kw <= REL_E - REL_W0,
              DIFFSAL_E_SHAPE, "relpos_project_bwd: bad shape");
   const long rows = static_cast<long>(BH) * (static_cast<long>(qt) * qh * qw + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(relpos_bwd_q_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, dextra, Rt, Rh, Rw, dq,
-                     D, qt, qh, qw, kt, kh, kw, accumulate, rows);
-  int rc = check_launch("relpos_project_bwd(q)");
+  int rc;
+  if (D == 96 && rows < (1L << 31) && aligned16(dextra) && aligned16(dq) && aligned16(Rt) && aligned16(Rh) && aligned16(Rw)) {
+    rc = relpos_bwd_q96(dextra, Rt, Rh, Rw, dq, rows, qt, qh, qw, kt, kh, kw, accumulate, E, s);
+  } else {
+    hipLaunchKernelGGL(relpos_bwd_q_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, dextra, Rt, Rh, Rw, dq,
+                       D, qt, qh, qw, kt, kh, kw, accumulate, rows, E);
+    rc = check_launch("relpos_project_bwd(q)");
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(relpos_bwd_tables_kernel, dim3(qt + qh + qw, REL_CHUNKS), dim3(256), 0, s, dextra, q, part, BH, D, qt, qh,
-                     qw, kt, kh, kw);
+                     qw, kt, kh, kw, E);
   return check_launch("relpos_project_bwd(tables)");
 }

@@ -75,7 +75,6 @@ __device__ __forceinline__ int iperm32f(int c) {   // inverse: column c of the b
   return 16 * j + 8 * h + e;
 }
 
-template <typename T> __device__ __forceinline__ float to_f(T v) { return static_cast<float>(v); }
 template <typename T> __device__ __forceinline__ T from_f(float v) { return static_cast<T>(v); }
 
 // a 4-element piece as it travels through registers: 16 bytes of fp32, 8 bytes of 16-bit storage
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   // ahead.  16-bit storage fits two workgroups per CU, which cover each other's load phases; no look-ahead (256 registers)
   // C = 192 on 16-bit storage: Wq + the halo tile fill the LDS: one workgroup per CU as well, same look-ahead
   constexpr bool AHEAD = F32 || C > 96;
-  constexpr bool BULK = false;               // (kept: all of a tile's pieces requested at once when its phase A starts)
   typedef typename Mma16<T>::vec vec;
   typedef typename RawPiece<T>::type raw_t;
   auto raw_to_f4 = [](raw_t r) { return raw_to_f4_impl(r, static_cast<const T*>(nullptr)); };
@@ -175,7 +173,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   // phase A's global loads, issued one tile ahead: pass ps covers halo tokens ps * TPP + a_slot; returns the "inside the frame" bits
   constexpr int TPP = 256 / G;                                       // tokens per pass
   constexpr int NPASS = (FT_TOK + TPP - 1) / TPP;
-  raw_t pre[(AHEAD || BULK) ? NPASS : 2][3];
+  raw_t pre[AHEAD ? NPASS : 2][3];
   unsigned inside_mask = 0;
   auto fetch_pass = [&](int tile_, int ps, raw_t (&dst)[3]) -> bool {
     const int tx_ = tile_ % p.tiles_x, t2_ = tile_ / p.tiles_x;
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   };
   auto fetch_tile = [&](int tile_) -> unsigned {
     unsigned mask = 0;
-    if constexpr (AHEAD || BULK) {
+    if constexpr (AHEAD) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) mask |= (fetch_pass(tile_, ps, pre[ps]) ? 1u : 0u) << ps;
     }
@@ -213,21 +211,20 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
     const int ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
     const int y0 = ty * FT_TH, x0 = tx * FT_TW;
-    if constexpr (BULK) inside_mask = fetch_tile(tile);
-    else if constexpr (!AHEAD) inside_mask = fetch_pass(tile, 0, pre[0]) ? 1u : 0u;
+    if constexpr (!AHEAD) inside_mask = fetch_pass(tile, 0, pre[0]) ? 1u : 0u;
 
     // ---------------- phase A: halo tile (fetched while the previous tile was in phase D) -> LayerNorm_1 -> LDS; zeros outside
     // the frame are the convolution's padding
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int tok = ps * TPP + a_slot;
-      if constexpr (!AHEAD && !BULK) {                                 // two passes in flight
+      if constexpr (!AHEAD) {                                          // two passes in flight
         if (ps + 1 < NPASS) inside_mask |= (fetch_pass(tile, ps + 1, pre[(ps + 1) & 1]) ? 1u : 0u) << (ps + 1);
       }
       const bool inside = (inside_mask >> ps) & 1u;
       float4 vv[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[(AHEAD || BULK) ? ps : (ps & 1)][i]);
+      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[AHEAD ? ps : (ps & 1)][i]);
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += (vv[i].x + vv[i].y) + (vv[i].z + vv[i].w);

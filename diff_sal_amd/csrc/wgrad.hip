@@ -267,7 +267,11 @@ struct WgradPlan { int cfg, splits, rows_per_split; };
 //    512 run at once, so `rounds` of 512 each take 2 x steps x step_cycles;
 //  * every split writes and re-reads a Cout x K slab (~1250 B/cycle of HBM).
 // A workgroup count just above a multiple of 512 costs a whole extra round -- the reason this is not a fixed target.
-WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
+//  * plain products (one tap: token GEMMs): every K tile re-reads dY and every Cout tile re-reads X through L2 -- at ~1200
+//    bytes per cycle chip-wide that, not the matrix pipe, bounds the narrow 96 x 128 tile on the wide layers of the video
+//    encoder (tools/tune_wgrad_mvit.py: Cout or K >= 1536 are 7-20 % faster on 128 x 192).  Convolutions keep the pure MFMA
+//    model: their taps re-use the input tile in L2 and were tuned on it (tools/tune_wgrad.py).
+WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments, bool one_tap = false) {
   WgradPlan pl{0, 1, 0};
   double best = 1e300;
   const long max_splits = (seg_rows + 127) / 128;
@@ -292,6 +296,11 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
       const double occ = wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0);
       double t = rounds * occ * steps * step_cycles;
       if (sp > 1) t += 2.0 * sp * segments * Cout * static_cast<double>(K) * 4.0 / 1250.0;
+      if (one_tap) {
+        const double tiles_k = static_cast<double>((K / 32 + cf.sl - 1) / cf.sl), tiles_co = static_cast<double>((Cout + cf.bco - 1) / cf.bco);
+        const double t_mem = 4.0 * seg_rows * segments * (Cout * tiles_k + K * tiles_co) / 1200.0;
+        t = 0.5 * (t > t_mem ? t : t_mem) + 0.5 * (t + t_mem);
+      }
       if (t < best) { best = t; pl.cfg = c; pl.splits = static_cast<int>(sp); pl.rows_per_split = static_cast<int>(rps); }
     }
   }
@@ -308,7 +317,7 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments) {
 }
 
 int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
-  const WgradPlan pl = wgrad_plan(a.Cout, a.K, a.seg_rows, segments);
+  const WgradPlan pl = wgrad_plan(a.Cout, a.K, a.seg_rows, segments, a.taps == 1);
   a.splits = pl.splits;
   a.rows_per_split = pl.rows_per_split;
   const WgradCfg cf = kWgradCfgs[pl.cfg];
@@ -336,7 +345,7 @@ extern "C" size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cin % 32) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const long K = static_cast<long>(d->KH) * d->KW * d->Cin;
-  const WgradPlan pl = wgrad_plan(d->Cout, K, M, 1);
+  const WgradPlan pl = wgrad_plan(d->Cout, K, M, 1, d->KH * d->KW == 1);
   return static_cast<size_t>(pl.splits) * d->Cout * K * sizeof(float);
 }
 
@@ -344,7 +353,7 @@ extern "C" int diffsal_conv_wgrad_splits(const diffsal_conv_desc* d) {
   if (!d || d->Cin <= 0 || d->Cin % 32) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const long K = static_cast<long>(d->KH) * d->KW * d->Cin;
-  return wgrad_plan(d->Cout, K, M, 1).splits;
+  return wgrad_plan(d->Cout, K, M, 1, d->KH * d->KW == 1).splits;
 }
 
 extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, const float* dy, float* dw_packed,
@@ -374,7 +383,7 @@ extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, c
 
 extern "C" size_t diffsal_wgrad_segmented_ws_bytes(int segments, int seg_rows, int K, int Cout) {
   if (segments <= 0 || seg_rows <= 0 || K <= 0 || K % 32 || Cout <= 0) return 0;
-  const WgradPlan pl = wgrad_plan(Cout, K, seg_rows, segments);
+  const WgradPlan pl = wgrad_plan(Cout, K, seg_rows, segments, true);
   return static_cast<size_t>(segments) * pl.splits * Cout * K * sizeof(float);
 }
 

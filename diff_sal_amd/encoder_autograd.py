@@ -44,18 +44,22 @@ class QKVPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, wq, wk, wv, size, stride_q, stride_kv):
-        outs, sizes = [], []
-        for i, (w, st) in enumerate(((wq, stride_q), (wk, stride_kv), (wv, stride_kv))):
-            o, s = ops.pool3d(qkv[:, :, i], w, size, st)
-            outs.append(o)
-            sizes.append(s)
         ctx.size, ctx.strides = size, (stride_q, stride_kv, stride_kv)
         ctx.save_for_backward(qkv, wq, wk, wv)
-        return outs[0], outs[1], outs[2]
+        if qkv.shape[-1] == 96 and qkv.is_contiguous():          # one launch for the three tensors
+            return ops.qkv_pool(qkv, (wq, wk, wv), size, stride_q, stride_kv)[:3]
+        return tuple(ops.pool3d(qkv[:, :, i], w, size, st)[0] for i, (w, st) in enumerate(zip((wq, wk, wv), ctx.strides)))
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
         qkv, wq, wk, wv = ctx.saved_tensors
+        sq, skv = ctx.strides[0], ctx.strides[1]
+        fused = (qkv.shape[-1] == 96 and qkv.is_contiguous() and sq[0] == 1 and skv[0] == 1 and sq[1] == sq[2]
+                 and skv[1] == skv[2])
+        if fused:
+            dqkv = ops.qkv_pool_bwd_data((dq, dk, dv), (wq, wk, wv), qkv.shape, ctx.size, sq, skv)
+            dws = ops.qkv_pool_bwd_weight(qkv, (dq, dk, dv), ctx.size, sq, skv)
+            return dqkv, dws[0], dws[1], dws[2], None, None, None
         dqkv = torch.empty_like(qkv)
         dws = []
         for i, (w, g, st) in enumerate(zip((wq, wk, wv), (dq, dk, dv), ctx.strides)):
@@ -69,20 +73,43 @@ def qkv_pool(qkv, wq, wk, wv, size, stride_q, stride_kv):
 
 class RelposProjectFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, Rt, Rh, Rw, q_size, k_size):
+    def forward(ctx, q, Rt, Rh, Rw, q_size, k_size, E):
         ctx.sizes = (q_size, k_size)
         ctx.save_for_backward(q, Rt, Rh, Rw)
-        return ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size)
+        return ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size, E)
 
     @staticmethod
     def backward(ctx, dextra):
         q, Rt, Rh, Rw = ctx.saved_tensors
         dq, dRt, dRh, dRw = ops.relpos_project_bwd(dextra, q, Rt, Rh, Rw, *ctx.sizes)
-        return dq, dRt, dRh, dRw, None, None
+        return dq, dRt, dRh, dRw, None, None, None
 
 
-def relpos_project(q, Rt, Rh, Rw, q_size, k_size):
-    return RelposProjectFn.apply(q, Rt, Rh, Rw, tuple(q_size), tuple(k_size))
+def relpos_project(q, Rt, Rh, Rw, q_size, k_size, E=48):
+    return RelposProjectFn.apply(q, Rt, Rh, Rw, tuple(q_size), tuple(k_size), int(E))
+
+
+class RelTablesFn(torch.autograd.Function):
+    """resize_decomposed_rel_pos of the three axes of one block (linear resample + index gather) as one sparse row map per
+    table: one launch forward, one backward (the torch form is ~14 small kernels per table and step, with a sort-based
+    index_put backward)."""
+
+    @staticmethod
+    def forward(ctx, rel_t, rel_h, rel_w, plans):
+        ctx.plans = plans
+        return tuple(ops.rel_tables((rel_t, rel_h, rel_w), plans))
+
+    @staticmethod
+    def backward(ctx, dt, dh, dw):
+        zeros = [None if g is not None else torch.zeros((pl["q"], pl["k"], 96), device=pl["idx2"].device)
+                 for g, pl in zip((dt, dh, dw), ctx.plans)]
+        gs = [g if g is not None else z for g, z in zip((dt, dh, dw), zeros)]
+        d = ops.rel_tables_bwd(gs, ctx.plans)
+        return d[0], d[1], d[2], None
+
+
+def rel_tables(rel_t, rel_h, rel_w, plans):
+    return RelTablesFn.apply(rel_t, rel_h, rel_w, plans)
 
 
 class MaxPoolTokensFn(torch.autograd.Function):

@@ -196,18 +196,13 @@ class MViT(nn.Module):
         return r[idx.long().to(r.device)].contiguous()
 
     def _onehot_for(self, k_size, dev) -> Tensor:
-        """One-hot key columns matching ops.relpos_project's slots: [0,8) t, [8,24) h, [24,48) w; class-token row 0.  Depends on
-        the key grid only (not on any parameter): built once per grid and device, kept across optimizer steps."""
+        """One-hot key columns matching ops.relpos_project's layout for this key grid (ops.relpos_columns: 32 columns when the
+        grid fits, else 48); class-token row 0.  Depends on the key grid only (not on any parameter): built once per grid and
+        device, kept across optimizer steps."""
         ck = ("onehot", tuple(k_size), str(dev))
         oh = self._const_tables.get(ck)
         if oh is None:
-            kt, kh, kw = k_size
-            l = torch.arange(kt * kh * kw, device=dev)
-            oh = torch.zeros((1 + kt * kh * kw, 48), device=dev)
-            oh[1 + l, l // (kh * kw)] = 1.0
-            oh[1 + l, 8 + (l // kw) % kh] = 1.0
-            oh[1 + l, 24 + l % kw] = 1.0
-            oh = oh.contiguous()
+            oh = ops.relpos_onehot(k_size, ops.relpos_columns(k_size), dev)
             self._const_tables[ck] = oh
         return oh
 
@@ -231,11 +226,11 @@ class MViT(nn.Module):
         B, N, _ = x.shape
         xn = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, tag="mvit-gemm").view(B, N, 3, blk.heads, 96)
-        q, q_size = ops.pool3d_ln(qkv[:, :, 0], pk[f"b{i}.pool_q"], a.norm_q.weight, a.norm_q.bias, size, blk.stride_q, a.norm_q.eps)
-        k, k_size = ops.pool3d_ln(qkv[:, :, 1], pk[f"b{i}.pool_k"], a.norm_k.weight, a.norm_k.bias, size, blk.stride_kv, a.norm_k.eps)
-        v, _ = ops.pool3d_ln(qkv[:, :, 2], pk[f"b{i}.pool_v"], a.norm_v.weight, a.norm_v.bias, size, blk.stride_kv, a.norm_v.eps)
+        q, k, v, q_size, k_size = ops.qkv_pool(
+            qkv, (pk[f"b{i}.pool_q"], pk[f"b{i}.pool_k"], pk[f"b{i}.pool_v"]), size, blk.stride_q, blk.stride_kv,
+            norms=tuple((n.weight, n.bias, n.eps) for n in (a.norm_q, a.norm_k, a.norm_v)))
         Rt, Rh, Rw, onehot = self._tables_for(i, q_size, k_size)
-        extra = ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size)
+        extra = ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size, ops.relpos_columns(k_size))
         o = ops.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual=q, skip_first=True)
         skip = ops.linear(xn, blk.proj.weight, blk.proj.bias, tag="mvit-gemm") if hasattr(blk, "proj") else x
         if max(blk.stride_q) > 1:
@@ -265,11 +260,11 @@ class MViT(nn.Module):
         v = ag.layernorm(pv, a.norm_v.weight, a.norm_v.bias, a.norm_v.eps)
         # relative-position tables: parameter preprocessing (linear resample + gather) stays on the tape so that the
         # table gradients of relpos_project flow back to rel_pos_t / rel_pos_h / rel_pos_w
-        Rt = self._rel_table_diff(a.rel_pos_t, q_size[0], k_size[0])
-        Rh = self._rel_table_diff(a.rel_pos_h, q_size[1], k_size[1])
-        Rw = self._rel_table_diff(a.rel_pos_w, q_size[2], k_size[2])
+        plans = tuple(self._rel_plan(r.shape[0], qs, ks, x.device)
+                      for r, qs, ks in zip((a.rel_pos_t, a.rel_pos_h, a.rel_pos_w), q_size, k_size))
+        Rt, Rh, Rw = eg.rel_tables(a.rel_pos_t, a.rel_pos_h, a.rel_pos_w, plans)
         onehot = self._onehot_for(k_size, x.device)
-        extra = eg.relpos_project(q, Rt, Rh, Rw, q_size, k_size)
+        extra = eg.relpos_project(q, Rt, Rh, Rw, q_size, k_size, ops.relpos_columns(k_size))
         o = eg.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual_q=True, skip_first=True)
         skip = ag.linear(xn, blk.proj.weight, blk.proj.bias) if hasattr(blk, "proj") else x
         if max(blk.stride_q) > 1:
@@ -279,19 +274,45 @@ class MViT(nn.Module):
         h = ag.gelu(ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
         return ag.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x), q_size
 
-    def _rel_table_diff(self, rel: Tensor, q_size: int, k_size: int) -> Tensor:
+    def _rel_plan(self, rel_len: int, q_size: int, k_size: int, dev) -> dict:
+        """resize_decomposed_rel_pos (R/models/mvit.py:330-361) of one axis as a sparse row map, built once per (table length,
+        grid) on the host: gathered[m] = w2[m,0] * rel[idx2[m,0]] + w2[m,1] * rel[idx2[m,1]] (the two taps of F.interpolate's
+        linear resample at the gathered row; weights (1, 0) when the table already has 2*max(q,k)-1 rows), and its transpose in
+        CSR form for the backward.  Geometry only -- no parameter enters."""
+        ck = ("relplan", rel_len, q_size, k_size, str(dev))
+        pl = self._const_tables.get(ck)
+        if pl is not None:
+            return pl
         max_rel = int(2 * max(q_size, k_size) - 1)
-        r = rel
-        if r.shape[0] != max_rel:
-            r = F.interpolate(r.t().unsqueeze(0), size=max_rel, mode="linear").squeeze(0).t()
-        ck = ("relidx", q_size, k_size, str(rel.device))
-        idx = self._const_tables.get(ck)                 # gather indices: grid geometry only, resident on the device
-        if idx is None:
-            q_ratio, k_ratio = max(k_size / q_size, 1.0), max(q_size / k_size, 1.0)
-            idx = (torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio
-            idx = idx.long().to(rel.device)
-            self._const_tables[ck] = idx
-        return r[idx].contiguous()
+        q_ratio, k_ratio = max(k_size / q_size, 1.0), max(q_size / k_size, 1.0)
+        o = ((torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio) + (k_size - 1) * k_ratio).long().reshape(-1)
+        if rel_len == max_rel:
+            i0, i1 = o, o
+            w0, w1 = torch.ones(o.numel()), torch.zeros(o.numel())
+        else:       # upsample_linear1d, align_corners=False: src = len/out * (dst + 0.5) - 0.5, clamped at 0 (float32 as in ATen)
+            src = (torch.tensor(rel_len, dtype=torch.float32) / max_rel) * (o.float() + 0.5) - 0.5
+            src = src.clamp_min(0.0)
+            i0 = src.long()
+            i1 = torch.where(i0 < rel_len - 1, i0 + 1, i0)
+            w1 = src - i0.float()
+            w0 = 1.0 - w1
+        M = o.numel()
+        idx2 = torch.stack([i0, i1], 1).int()
+        w2 = torch.stack([w0, w1], 1).float()
+        # transpose: entries (row = table row, col = m, weight), rows ascending, columns ascending inside a row
+        rows = torch.cat([i0, i1])
+        cols = torch.cat([torch.arange(M), torch.arange(M)])
+        wts = torch.cat([w0, w1]).float()
+        keep = wts != 0
+        rows, cols, wts = rows[keep], cols[keep], wts[keep]
+        order = torch.argsort(rows * (2 * M) + cols, stable=True)
+        rows, cols, wts = rows[order], cols[order], wts[order]
+        ptr = torch.zeros(rel_len + 1, dtype=torch.long)
+        ptr[1:] = torch.cumsum(torch.bincount(rows, minlength=rel_len), 0)
+        pl = dict(q=q_size, k=k_size, len=rel_len, idx2=idx2.contiguous().to(dev), w2=w2.contiguous().to(dev),
+                  csr_ptr=ptr.int().to(dev), csr_col=cols.int().contiguous().to(dev), csr_w=wts.contiguous().to(dev))
+        self._const_tables[ck] = pl
+        return pl
 
     def forward_train(self, x: Tensor) -> List[Tensor]:
         from . import autograd_ops as ag

@@ -1122,6 +1122,101 @@ def pool3d_ln(x: Tensor, w27: Tensor, gamma: Tensor, beta: Tensor, size, stride,
     return out, (To, Ho, Wo)
 
 
+def _cont(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr3(ts):
+    return (C.c_void_p * 3)(*[_p(t) for t in ts])
+
+
+def qkv_pool(qkv: Tensor, w27, size, stride_q, stride_kv, norms=None):
+    """The three attention_pool convolutions of a block in one launch (head dimension 96).  qkv: [B, N, 3, heads, 96]
+    contiguous; w27 = (wq, wk, wv) each [27, 96]; norms = ((gamma, beta, eps) x 3) adds the LayerNorms, None = convolutions
+    only.  -> (q, k, v) each [B, heads, 1 + Lo, 96], q_size, k_size."""
+    lib = _lib.load()
+    B, N, three, heads, D = qkv.shape
+    T, H, W = size
+    assert three == 3 and N == 1 + T * H * W and qkv.is_contiguous() and qkv.dtype == torch.float32
+    q_size = tuple((s - 1) // st + 1 for s, st in zip(size, stride_q))
+    k_size = tuple((s - 1) // st + 1 for s, st in zip(size, stride_kv))
+    Lq, Lk = q_size[0] * q_size[1] * q_size[2], k_size[0] * k_size[1] * k_size[2]
+    outs = [torch.empty((B, heads, 1 + L, D), device=qkv.device, dtype=torch.float32) for L in (Lq, Lk, Lk)]
+    w27 = [_cont(w) for w in w27]
+    if norms is not None:
+        gam, bet = [_cont(n[0]) for n in norms], [_cont(n[1]) for n in norms]
+        eps = (C.c_float * 3)(*[float(n[2]) for n in norms])
+        g3, b3 = _ptr3(gam), _ptr3(bet)
+    else:
+        g3 = b3 = eps = None
+    sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
+    nbytes = sum(o.numel() for o in outs) * 8
+    with _prof("pool", 54.0 * sum(o.numel() for o in outs), nbytes):
+        _lib.check(lib.diffsal_qkv_pool(_p(qkv), _ptr3(w27), g3, b3, eps, _ptr3(outs), B, heads, D, T, H, W, sq, skv, _stream()),
+                   "qkv_pool")
+    return outs[0], outs[1], outs[2], q_size, k_size
+
+
+def qkv_pool_bwd_data(dys, w27, qkv_shape, size, stride_q, stride_kv) -> Tensor:
+    """dqkv [B, N, 3, heads, 96] of ``qkv_pool`` (convolution form) from the three output gradients."""
+    lib = _lib.load()
+    B, N, _, heads, D = qkv_shape
+    T, H, W = size
+    dys = [_cont(d) for d in dys]
+    w27 = [_cont(w) for w in w27]
+    dqkv = torch.empty(tuple(qkv_shape), device=dys[0].device, dtype=torch.float32)
+    sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
+    with _prof("pool-bwd", 54.0 * sum(d.numel() for d in dys), sum(d.numel() for d in dys) * 4 + dqkv.numel() * 4):
+        _lib.check(lib.diffsal_qkv_pool_bwd_data(_ptr3(dys), _ptr3(w27), _p(dqkv), B, heads, D, T, H, W, sq, skv, _stream()),
+                   "qkv_pool_bwd_data")
+    return dqkv
+
+
+def qkv_pool_bwd_weight(qkv: Tensor, dys, size, stride_q, stride_kv) -> Tensor:
+    """The three filter gradients [3, 27, 96] of ``qkv_pool`` in one launch + one reduction."""
+    lib = _lib.load()
+    B, N, _, heads, D = qkv.shape
+    T, H, W = size
+    dys = [_cont(d) for d in dys]
+    chunks = lib.diffsal_qkv_pool_bwd_weight_chunks()
+    part = torch.empty((3, chunks, 27 * D), device=qkv.device, dtype=torch.float64)
+    sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
+    with _prof("pool-bwd", 54.0 * sum(d.numel() for d in dys), sum(d.numel() for d in dys) * 8):
+        _lib.check(lib.diffsal_qkv_pool_bwd_weight(_p(qkv), _ptr3(dys), part.data_ptr(), B, heads, D, T, H, W, sq, skv, _stream()),
+                   "qkv_pool_bwd_weight")
+    return reduce_partials(part, 3, chunks, 27 * D).view(3, 27, D)
+
+
+def _iptr3(ts):
+    return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+
+
+def rel_tables(rels, plans):
+    """(Rt, Rh, Rw) gathered relative-position tables [q, k, D] of one block from the learnt tables and their host-built sparse
+    row maps (``MViT._rel_plan``): one launch."""
+    lib = _lib.load()
+    D = rels[0].shape[1]
+    rels = [_cont(r) for r in rels]
+    outs = [torch.empty((pl["q"], pl["k"], D), device=rels[0].device, dtype=torch.float32) for pl in plans]
+    M = (C.c_int * 3)(*[pl["q"] * pl["k"] for pl in plans])
+    _lib.check(lib.diffsal_rel_tables(_ptr3(rels), _iptr3([pl["idx2"] for pl in plans]), _ptr3([pl["w2"] for pl in plans]),
+                                      _ptr3(outs), M, D, _stream()), "rel_tables")
+    return outs
+
+
+def rel_tables_bwd(douts, plans):
+    """Gradients of the three learnt tables [len, D] from the gradients of the gathered ones: one launch."""
+    lib = _lib.load()
+    D = douts[0].shape[-1]
+    douts = [_cont(d) for d in douts]
+    outs = [torch.empty((pl["len"], D), device=douts[0].device, dtype=torch.float32) for pl in plans]
+    R = (C.c_int * 3)(*[pl["len"] for pl in plans])
+    _lib.check(lib.diffsal_rel_tables_bwd(_ptr3(douts), _iptr3([pl["csr_ptr"] for pl in plans]),
+                                          _iptr3([pl["csr_col"] for pl in plans]), _ptr3([pl["csr_w"] for pl in plans]),
+                                          _ptr3(outs), R, D, _stream()), "rel_tables_bwd")
+    return outs
+
+
 def maxpool_tokens(x: Tensor, size, kernel, stride) -> Tensor:
     lib = _lib.load()
     B, N, Cc = x.shape
@@ -1133,14 +1228,33 @@ def maxpool_tokens(x: Tensor, size, kernel, stride) -> Tensor:
     return out
 
 
-def relpos_project(q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Tensor, q_size, k_size) -> Tensor:
-    """q [B,heads,1+Lq,D] -> the 48 bias columns per query [B,heads,1+Lq,48]."""
+def relpos_columns(k_size) -> int:
+    """Column layout of the relative-position bias for a key grid: 32 (t [0,8), h [8,16), w [16,32)) when it fits, else 48
+    (t [0,8), h [8,24), w [24,48)); include/diffsal.h."""
+    kt, kh, kw = k_size
+    return 32 if (kt <= 8 and kh <= 8 and kw <= 16) else 48
+
+
+def relpos_onehot(k_size, E: int, device) -> Tensor:
+    """[1 + kt*kh*kw, E] one-hot key rows matching ``relpos_project``'s columns; class-token row 0 stays zero."""
+    kt, kh, kw = k_size
+    w0 = 16 if E == 32 else 24
+    l = torch.arange(kt * kh * kw, device=device)
+    oh = torch.zeros((1 + kt * kh * kw, E), device=device)
+    oh[1 + l, l // (kh * kw)] = 1.0
+    oh[1 + l, 8 + (l // kw) % kh] = 1.0
+    oh[1 + l, w0 + l % kw] = 1.0
+    return oh
+
+
+def relpos_project(q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Tensor, q_size, k_size, E: int = 48) -> Tensor:
+    """q [B,heads,1+Lq,D] -> the E (48 or 32, see ``relpos_columns``) bias columns per query [B,heads,1+Lq,E]."""
     lib = _lib.load()
     B, heads, N, D = q.shape
-    extra = torch.empty((B, heads, N, 48), device=q.device, dtype=torch.float32)
+    extra = torch.empty((B, heads, N, E), device=q.device, dtype=torch.float32)
     with _prof("relpos", 2.0 * B * heads * N * D * sum(k_size), _nb(q, extra)):
-        _lib.check(lib.diffsal_relpos_project(_p(q), _p(Rt), _p(Rh), _p(Rw), _p(extra), B * heads, D, *q_size, *k_size, _stream()),
-                   "relpos_project")
+        _lib.check(lib.diffsal_relpos_project(_p(q), _p(Rt), _p(Rh), _p(Rw), _p(extra), B * heads, D, *q_size, *k_size, E,
+                                              _stream()), "relpos_project")
     return extra
 
 
@@ -1229,6 +1343,20 @@ def pool3d(x: Tensor, w27: Tensor, size, stride) -> Tensor:
     return out, (To, Ho, Wo)
 
 
+def pool3d_bwd_weight(x: Tensor, dy: Tensor, size, stride) -> Tensor:
+    """dw27 [27][D] of ``pool3d`` (per-workgroup double partial sums, reduced in a fixed order)."""
+    lib = _lib.load()
+    B, N, heads, D = x.shape
+    T, H, W = size
+    dy = dy.contiguous()
+    chunks = lib.diffsal_pool3d_bwd_weight_chunks()
+    part = torch.empty((chunks, 27 * D), device=x.device, dtype=torch.float64)
+    with _prof("pool-bwd", 54.0 * dy.numel(), _nb(dy) * 2):
+        _lib.check(lib.diffsal_pool3d_bwd_weight(x.data_ptr(), _p(dy), part.data_ptr(), B, heads, D, T, H, W, *stride, x.stride(0),
+                                                 x.stride(1), _stream()), "pool3d_bwd_weight")
+    return reduce_partials(part.view(1, chunks, 27 * D), 1, chunks, 27 * D).view(27, D)
+
+
 def pool3d_bwd(x: Tensor, w27: Tensor, dy: Tensor, dx_view: Tensor, size, stride):
     """dx (written into ``dx_view``, a view with x's strides) and dw27 [27][D] of ``pool3d``."""
     lib = _lib.load()
@@ -1236,14 +1364,10 @@ def pool3d_bwd(x: Tensor, w27: Tensor, dy: Tensor, dx_view: Tensor, size, stride
     T, H, W = size
     assert dx_view.stride() == x.stride() and dx_view.shape == x.shape
     dy = dy.contiguous()
-    with _prof("pool-bwd", 54.0 * dy.numel(), _nb(dy) * 2 + dx_view.numel() * 4):
+    with _prof("pool-bwd", 54.0 * dy.numel(), _nb(dy) + dx_view.numel() * 4):
         _lib.check(lib.diffsal_pool3d_bwd_data(_p(dy), _p(w27), dx_view.data_ptr(), B, heads, D, T, H, W, *stride, x.stride(0),
                                                x.stride(1), _stream()), "pool3d_bwd_data")
-        chunks = lib.diffsal_pool3d_bwd_weight_chunks()
-        part = torch.empty((chunks, 27 * D), device=x.device, dtype=torch.float64)
-        _lib.check(lib.diffsal_pool3d_bwd_weight(x.data_ptr(), _p(dy), part.data_ptr(), B, heads, D, T, H, W, *stride, x.stride(0),
-                                                 x.stride(1), _stream()), "pool3d_bwd_weight")
-    return reduce_partials(part.view(1, chunks, 27 * D), 1, chunks, 27 * D).view(27, D)
+    return pool3d_bwd_weight(x, dy, size, stride)
 
 
 def maxpool_tokens_idx(x: Tensor, size, kernel, stride):
@@ -1281,7 +1405,7 @@ def relpos_project_bwd(dextra: Tensor, q: Tensor, Rt: Tensor, Rh: Tensor, Rw: Te
     with _prof("relpos-bwd", 4.0 * B * heads * N * D * sum(k_size), _nb(q, dextra, dq)):
         _lib.check(lib.diffsal_relpos_project_bwd(_p(dextra.contiguous()), _p(q), _p(Rt), _p(Rh), _p(Rw), _p(dq),
                                                   int(dq_accum is not None), part.data_ptr(), B * heads, D, *q_size, *k_size,
-                                                  _stream()), "relpos_project_bwd")
+                                                  dextra.shape[-1], _stream()), "relpos_project_bwd")
         flat = reduce_partials(part.view(1, chunks, width), 1, chunks, width).view(-1)
     a, b = Rt.numel(), Rt.numel() + Rh.numel()
     return dq, flat[:a].view(Rt.shape), flat[a:b].view(Rh.shape), flat[b:].view(Rw.shape)

@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3s
-python tools/bench_mvit.py > gpurun_out/r3s/mvit.log 2>&1
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3s/stats -- python3 $GRAFT_REPO_ROOT/tools/bench_mvit.py > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/r3s/stats.err
-cd $GRAFT_REPO_ROOT
-cp $(find gpurun_out/r3s/stats -name "*kernel_stats.csv" | head -1) gpurun_out/r3s/mvit_kernel_stats.csv
-rm -rf gpurun_out/r3s/stats
-cat gpurun_out/r3s/mvit.log
+O=gpurun_out/r3t; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_encoders.py tests/test_gpu_encoder_train.py tests/test_abi.py -x -q > $O/t_enc.log 2>&1
+echo "rc=$?" >> $O/t_enc.log
+python tools/bench_mvit.py > $O/mvit.log 2>&1
+python tools/tune_wgrad_mvit.py > $O/sweep_wgrad.log 2>&1
+python bench.py --workload train --mode av --steps 10 --warmup 3 --repeats 2 > $O/train.json 2> $O/train.err
+tail -n 4 $O/t_enc.log; cat $O/mvit.log; cat $O/sweep_wgrad.log;  head -c 330 $O/train.json

@@ -416,7 +416,7 @@ int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long 
  *                       (+ residual[b,h,l,:], not on row 0 if skip_first)
  * q / k / v / residual are addressed through (batch, head, row) element strides, so slices of a fused qkv GEMM output
  * are read in place; q_extra [B,H,Lq,E] and k_extra [Lk,E] are contiguous and carry an additive attention bias as E
- * extra contraction columns (MViT: E = 48, see diffsal_relpos_project; otherwise E = 0 and both are NULL).
+ * extra contraction columns (MViT: E = 48 or 32, see diffsal_relpos_project; otherwise E = 0 and both are NULL).
  * Built (D, E, DV): (96,48,96), (96,0,96), (64,0,64), (32,0,32).  Replaces
  *   R/models/mvit.py:587-605 (MultiScaleAttention: attn = (q*scale) k^T, add_decomposed_rel_pos, softmax, attn v, + q),
  *   R/models/audio_attention.py:50-58 (dots, softmax, out). */
@@ -443,9 +443,11 @@ int diffsal_attention_general_bwd(const float* q, const float* q_extra, const fl
  *   every head + LayerNorm(D); class token (row 0) skips the conv.  in element (b, n, head, d) at
  *   in + b*in_stride_b + n*in_stride_n + head*D + d; w27 [27][D]; out [B, heads, 1 + To*Ho*Wo, D].
  * maxpool_tokens: the skip path's MaxPool3d (mvit.py:765-777) on tokens [B, 1+T*H*W, C], padding k/2, class token kept.
- * relpos_project: per query the E = 48 bias columns of add_decomposed_rel_pos (mvit.py:363-410):
- *   [0,kt) q.Rt[t], [8,8+kh) q.Rh[y], [24,24+kw) q.Rw[x], rest 0, class-token row 0; Rt [qt][kt][D] etc. are the
- *   gathered tables (resize_decomposed_rel_pos, :330-361); q [BH, 1+qt*qh*qw, D] unscaled.  kt <= 8, kh <= 16, kw <= 24.
+ * relpos_project: per query the E bias columns of add_decomposed_rel_pos (mvit.py:363-410), E = 48 or 32:
+ *   E = 48: [0,kt) q.Rt[t], [8,8+kh) q.Rh[y], [24,24+kw) q.Rw[x]   (kt <= 8, kh <= 16, kw <= 24)
+ *   E = 32: [0,kt) q.Rt[t], [8,8+kh) q.Rh[y], [16,16+kw) q.Rw[x]   (kt <= 8, kh <= 8, kw <= 16: every MViTv2-S stage at 224x384)
+ *   rest 0, class-token row 0; Rt [qt][kt][D] etc. are the gathered tables (resize_decomposed_rel_pos, :330-361);
+ *   q [BH, 1+qt*qh*qw, D] unscaled.  The key side of diffsal_attention_general carries one-hot rows in the same layout.
  * tokens_to_channels_first: [B, off+L, C] rows off.. -> [B, C, L] (the NCTHW maps MViT returns, :1128-1134). */
 int diffsal_im2col3d(const float* x, float* cols, int B, int C, int T, int H, int W, int KT, int KH, int KW, int st, int sh,
                      int sw, int pt, int ph, int pw, int Kp, diffsal_stream_t stream);
@@ -455,7 +457,7 @@ int diffsal_pool3d_ln(const float* in, const float* w27, const float* gamma, con
 int diffsal_maxpool_tokens(const float* in, float* out, int B, int C, int T, int H, int W, int kt, int kh, int kw, int st,
                            int sh, int sw, diffsal_stream_t stream);
 int diffsal_relpos_project(const float* q, const float* Rt, const float* Rh, const float* Rw, float* extra, int BH, int D,
-                           int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream);
+                           int qt, int qh, int qw, int kt, int kh, int kw, int E, diffsal_stream_t stream);
 int diffsal_tokens_to_channels_first(const float* in, float* out, int B, int C, int L, int off, diffsal_stream_t stream);
 /* Training of the video encoder: backward of the pieces above (all gather form, no atomics, fixed summation order).
  * pool3d_ln with gamma = beta = NULL is the convolution alone (its LayerNorm then runs as diffsal_layernorm).
@@ -474,10 +476,35 @@ int diffsal_maxpool_tokens_idx(const float* in, float* out, int* idx, int B, int
                                int st, int sh, int sw, diffsal_stream_t stream);
 int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float* din, int B, int C, int T, int H, int W, int kt, int kh,
                                int kw, int st, int sh, int sw, diffsal_stream_t stream);
+/* qkv_pool: the three attention_pool convolutions of one block in ONE launch, head dimension D = 96 (mvit.py:446-494, called
+ * three times per block at :556-590): qkv is the fused projection [B][1+T*H*W][3][heads][96]; w27 / gamma / beta / eps / out
+ * are arrays of three (q, k, v); gamma = beta = eps = NULL: convolutions only.  out[x]: [B*heads][1 + To*Ho*Wo][96] with the
+ * strides of q (stride_q[3]) or of k and v (stride_kv[3]).  Bit-identical to three diffsal_pool3d_ln calls in the convolution;
+ * the LayerNorm sums run over 8 lanes x 12 channels instead of 32 x 4.
+ * qkv_pool_bwd_data: every element of dqkv [B][N][3][heads][96] from the three output gradients (temporal stride 1, equal
+ * spatial strides); bit-identical to three diffsal_pool3d_bwd_data calls. */
+int diffsal_qkv_pool(const float* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
+                     const float* eps, float* const* out, int B, int heads, int D, int T, int H, int W, const int* stride_q,
+                     const int* stride_kv, diffsal_stream_t stream);
+int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* const* w27, float* dqkv, int B, int heads, int D, int T,
+                              int H, int W, const int* stride_q, const int* stride_kv, diffsal_stream_t stream);
+/* qkv_pool_bwd_weight: the three filter gradients in one launch: part[3][chunks][27*96] doubles (chunks =
+ * diffsal_qkv_pool_bwd_weight_chunks()), finished by diffsal_reduce_partials(part, out, 3, chunks, 27*96, 0). */
+int diffsal_qkv_pool_bwd_weight_chunks(void);
+int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const* dy, double* part, int B, int heads, int D, int T, int H,
+                                int W, const int* stride_q, const int* stride_kv, diffsal_stream_t stream);
+/* rel_tables: the three gathered relative-position tables of a block (resize_decomposed_rel_pos, mvit.py:330-361) as sparse
+ * row maps built once per grid on the host: out_t[m] = w2_t[m][0] * rel_t[idx2_t[m][0]] + w2_t[m][1] * rel_t[idx2_t[m][1]],
+ * m < M[t]; arrays of three (t, h, w).  rel_tables_bwd applies the transposed maps in CSR form (row starts [R[t] + 1],
+ * columns = m, weights): drel_t[r] = sum of w * dout_t[m] in CSR order. */
+int diffsal_rel_tables(const float* const* rel, const int* const* idx2, const float* const* w2, float* const* out, const int* M,
+                       int D, diffsal_stream_t stream);
+int diffsal_rel_tables_bwd(const float* const* dout, const int* const* csr_ptr, const int* const* csr_col,
+                           const float* const* csr_w, float* const* drel, const int* R, int D, diffsal_stream_t stream);
 int diffsal_relpos_project_bwd_chunks(void);
 int diffsal_relpos_project_bwd(const float* dextra, const float* q, const float* Rt, const float* Rh, const float* Rw, float* dq,
                                int accumulate, double* part /*[chunks][(qt*kt + qh*kh + qw*kw) * D]: dRt | dRh | dRw partials*/,
-                               int BH, int D, int qt, int qh, int qw, int kt, int kh, int kw, diffsal_stream_t stream);
+                               int BH, int D, int qt, int qh, int qw, int kt, int kh, int kw, int E, diffsal_stream_t stream);
 
 /* ---- legacy DDPM-style UNet of R/models/diffusion_decoder/diffusion.py (DiffusionModel :197-357; not instantiated by
  * any configuration of the reference, kept for completeness of the models/diffusion_decoder surface), fp32 NHWC.  Its

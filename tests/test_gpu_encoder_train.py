@@ -25,7 +25,8 @@ def close(got, ref, tol, what=""):
     return e
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 150, 70, 64, 0), (1, 2, 1 + 2 * 6 * 10, 1 + 2 * 3 * 5, 96, 48), (1, 1, 40, 129, 96, 0)])
+@pytest.mark.parametrize("shape", [(2, 2, 150, 70, 64, 0), (1, 2, 1 + 2 * 6 * 10, 1 + 2 * 3 * 5, 96, 48), (1, 2, 1 + 2 * 6 * 10, 1 + 2 * 3 * 5, 96, 32),
+                                   (1, 1, 40, 129, 96, 0)])
 def test_attention_general_backward(shape):
     """dq (incl. the residual path), dq_extra, dk, dv of the flash-attention backward vs autograd of the dense formula."""
     from diff_sal_amd import encoder_autograd as eg
@@ -103,20 +104,24 @@ def test_pool_maxpool_relpos_backward():
     q = rnd("rq", B, heads, 1 + L, D).requires_grad_(True)
     Rs = [rnd(f"rr{i}", a, b, D, scale=0.2).requires_grad_(True) for i, (a, b) in enumerate(zip(q_size, k_size))]
     rq = q[:, :, 1:].reshape(B, heads, *q_size, D)
-    ex = torch.zeros(B, heads, 1 + L, 48)
-    ex[:, :, 1:, 0:k_size[0]] = torch.einsum("bythwc,tkc->bythwk", rq, Rs[0]).reshape(B, heads, L, -1)
-    ex[:, :, 1:, 8:8 + k_size[1]] = torch.einsum("bythwc,hkc->bythwk", rq, Rs[1]).reshape(B, heads, L, -1)
-    ex[:, :, 1:, 24:24 + k_size[2]] = torch.einsum("bythwc,wkc->bythwk", rq, Rs[2]).reshape(B, heads, L, -1)
-    g = rnd("rg", *ex.shape)
-    (ex * g).sum().backward()
-    qd = q.detach().to(DEV).requires_grad_(True)
-    Rd = [r.detach().to(DEV).requires_grad_(True) for r in Rs]
-    got = eg.relpos_project(qd, Rd[0], Rd[1], Rd[2], q_size, k_size)
-    (got * g.to(DEV)).sum().backward()
-    close(got, ex, 2e-5, "relpos fwd")
-    close(qd.grad, q.grad, 5e-5, "relpos dq")
-    for i in range(3):
-        close(Rd[i].grad, Rs[i].grad, 5e-5, f"dR{i}")
+    for E, w0 in ((48, 24), (32, 16)):          # both column layouts of the bias
+        q.grad = None
+        for r in Rs:
+            r.grad = None
+        ex = torch.zeros(B, heads, 1 + L, E)
+        ex[:, :, 1:, 0:k_size[0]] = torch.einsum("bythwc,tkc->bythwk", rq, Rs[0]).reshape(B, heads, L, -1)
+        ex[:, :, 1:, 8:8 + k_size[1]] = torch.einsum("bythwc,hkc->bythwk", rq, Rs[1]).reshape(B, heads, L, -1)
+        ex[:, :, 1:, w0:w0 + k_size[2]] = torch.einsum("bythwc,wkc->bythwk", rq, Rs[2]).reshape(B, heads, L, -1)
+        g = rnd(f"rg{E}", *ex.shape)
+        (ex * g).sum().backward()
+        qd = q.detach().to(DEV).requires_grad_(True)
+        Rd = [r.detach().to(DEV).requires_grad_(True) for r in Rs]
+        got = eg.relpos_project(qd, Rd[0], Rd[1], Rd[2], q_size, k_size, E)
+        (got * g.to(DEV)).sum().backward()
+        close(got, ex, 2e-5, "relpos fwd")
+        close(qd.grad, q.grad, 5e-5, "relpos dq")
+        for i in range(3):
+            close(Rd[i].grad, Rs[i].grad, 5e-5, f"dR{i}")
 
 
 def test_mvit_all_parameter_gradients_match_oracle_autograd():

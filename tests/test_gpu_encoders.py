@@ -54,8 +54,10 @@ def test_attention_general_reads_a_fused_qkv_in_place(ops):
     assert rel_err(got, ref) < 2e-5
 
 
-def test_attention_general_with_relative_position_bias_and_residual(ops):
-    """The MViT call: decomposed rel-pos bias through the 48 extra columns, class token without bias, residual pooling."""
+@pytest.mark.parametrize("E", [48, 32])
+def test_attention_general_with_relative_position_bias_and_residual(ops, E):
+    """The MViT call: decomposed rel-pos bias through the extra contraction columns (48- and 32-column layouts), class token
+    without bias, residual pooling."""
     B, H, D = 2, 2, 96
     q_size, k_size = (2, 6, 10), (2, 3, 5)
     Lq, Lk = 1 + 2 * 6 * 10, 1 + 2 * 3 * 5
@@ -71,13 +73,15 @@ def test_attention_general_with_relative_position_bias_and_residual(ops):
     o[:, :, 1:] += q[:, :, 1:]
     ref = o.transpose(1, 2).reshape(B, Lq, H * D)
     qd = q.to(DEV)
-    extra = ops.relpos_project(qd, Rt.contiguous().to(DEV), Rh.contiguous().to(DEV), Rw.contiguous().to(DEV), q_size, k_size)
+    extra = ops.relpos_project(qd, Rt.contiguous().to(DEV), Rh.contiguous().to(DEV), Rw.contiguous().to(DEV), q_size, k_size, E)
     kt, kh, kw = k_size
-    oh = torch.zeros(Lk, 48)
+    assert ops.relpos_columns(k_size) == 32 and ops.relpos_columns((8, 9, 12)) == 48
+    oh = torch.zeros(Lk, E)
     l = torch.arange(Lk - 1)
     oh[1 + l, l // (kh * kw)] = 1
     oh[1 + l, 8 + (l // kw) % kh] = 1
-    oh[1 + l, 24 + l % kw] = 1
+    oh[1 + l, (24 if E == 48 else 16) + l % kw] = 1
+    assert torch.equal(oh, ops.relpos_onehot(k_size, E, "cpu"))
     got = ops.attention_general(qd, k.to(DEV), v.to(DEV), scale=D ** -0.5, q_extra=extra, k_extra=oh.to(DEV), residual=qd,
                                 skip_first=True)
     assert rel_err(got, ref) < 2e-5
@@ -93,6 +97,35 @@ def test_pool3d_ln_matches_attention_pool(ops, stride):
     ref, ref_size = mo.attention_pool(qkv[:, :, 1].permute(0, 2, 1, 3), w, stride, size, g, b)
     got, out_size = ops.pool3d_ln(qkv.to(DEV)[:, :, 1], w.reshape(D, 27).t().contiguous().to(DEV), g.to(DEV), b.to(DEV), size, stride)
     assert tuple(out_size) == tuple(ref_size) and rel_err(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("strides", [((1, 1, 1), (1, 2, 2)), ((1, 2, 2), (1, 4, 4)), ((1, 1, 1), (1, 8, 8)), ((1, 1, 1), (1, 1, 1))])
+def test_qkv_pool_one_launch_equals_three_pool3d_calls(ops, strides):
+    """The fused q / k / v pooling (8 lanes x 12 channels per token) against the per-tensor kernel: the convolution is the same
+    fmaf chain (bit-equal), the LayerNorm sums in another lane order (tolerance); the data gradient is bit-equal as well."""
+    B, heads, D, size = 2, 4, 96, (3, 10, 13)
+    N = 1 + size[0] * size[1] * size[2]
+    qkv = rnd("fq", B, N, 3, heads, D).to(DEV)
+    ws = [rnd(f"fw{i}", 27, D, scale=0.2).to(DEV) for i in range(3)]
+    norms = [(rnd(f"fg{i}", D, scale=0.1).to(DEV) + 1, rnd(f"fb{i}", D, scale=0.1).to(DEV), 1e-5) for i in range(3)]
+    sts = (strides[0], strides[1], strides[1])
+    conv = ops.qkv_pool(qkv, ws, size, strides[0], strides[1])
+    full = ops.qkv_pool(qkv, ws, size, strides[0], strides[1], norms=norms)
+    for i in range(3):
+        ref_c, sz = ops.pool3d(qkv[:, :, i], ws[i], size, sts[i])
+        ref_f, _ = ops.pool3d_ln(qkv[:, :, i], ws[i], norms[i][0], norms[i][1], size, sts[i], norms[i][2])
+        assert tuple(sz) == tuple(conv[3] if i == 0 else conv[4])
+        assert torch.equal(conv[i], ref_c), f"tensor {i}: convolution differs"
+        assert rel_err(full[i].cpu(), ref_f.cpu()) < 2e-6
+    dys = [rnd(f"fd{i}", *conv[i].shape).to(DEV) for i in range(3)]
+    got = ops.qkv_pool_bwd_data(dys, ws, qkv.shape, size, strides[0], strides[1])
+    ref = torch.empty_like(qkv)
+    for i in range(3):
+        ops.pool3d_bwd(qkv[:, :, i], ws[i], dys[i], ref[:, :, i], size, sts[i])
+    assert torch.equal(got, ref)
+    dws = ops.qkv_pool_bwd_weight(qkv, dys, size, strides[0], strides[1])      # other chunking than the per-tensor kernel
+    for i in range(3):
+        assert rel_err(dws[i].cpu(), ops.pool3d_bwd_weight(qkv[:, :, i], dys[i], size, sts[i]).cpu()) < 2e-6
 
 
 def test_maxpool_tokens_im2col_and_transpose(ops):

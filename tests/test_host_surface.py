@@ -174,3 +174,35 @@ def test_step_invariant_shortcut_checks_its_precondition():
     not_ib.image_based = False
     with pytest.raises(ValueError, match="image_based"):
         DiffusionSampler(Top(not_ib), step_invariant_shortcut=True)
+
+
+def test_rel_table_plan_reproduces_interpolate_and_gather_and_its_transpose():
+    """MViT._rel_plan (the sparse row map the training path hands to diffsal_rel_tables) against the torch form it replaces
+    (F.interpolate(mode='linear') + index gather, R/models/mvit.py:330-361), forward and transposed (CSR) -- on the host."""
+    from diff_sal_amd.mvit import MViT
+
+    enc = MViT(arch="tiny", out_scales=[3])
+    g = torch.Generator().manual_seed(5)
+    for rel_len, q, k in ((15, 8, 8), (111, 56, 7), (111, 96, 12), (27, 14, 7), (27, 24, 12), (13, 7, 7), (13, 12, 12), (55, 28, 7)):
+        rel = torch.randn(rel_len, 96, generator=g, requires_grad=True)
+        ref = MViT._rel_table(rel, q, k)                               # detached torch reference
+        pl = enc._rel_plan(rel_len, q, k, "cpu")
+        i2, w2 = pl["idx2"].long(), pl["w2"]
+        got = (w2[:, :1] * rel.detach()[i2[:, 0]] + w2[:, 1:] * rel.detach()[i2[:, 1]]).view(q, k, 96)
+        assert torch.allclose(got, ref, rtol=0, atol=2e-5), (rel_len, q, k, (got - ref).abs().max())   # lambda in float32: a few ulp from ATen
+        # transposed map against autograd of the torch form
+        max_rel = 2 * max(q, k) - 1
+        r = rel
+        if rel_len != max_rel:
+            r = torch.nn.functional.interpolate(r.t().unsqueeze(0), size=max_rel, mode="linear").squeeze(0).t()
+        q_ratio, k_ratio = max(k / q, 1.0), max(q / k, 1.0)
+        idx = ((torch.arange(q)[:, None] * q_ratio - torch.arange(k)[None, :] * k_ratio) + (k - 1) * k_ratio).long()
+        dout = torch.randn(q, k, 96, generator=g)
+        (r[idx] * dout).sum().backward()
+        ptr, col, cw = pl["csr_ptr"].long(), pl["csr_col"].long(), pl["csr_w"]
+        d = torch.zeros(rel_len, 96)
+        flat = dout.view(-1, 96)
+        for row in range(rel_len):
+            for e in range(int(ptr[row]), int(ptr[row + 1])):
+                d[row] += cw[e] * flat[col[e]]
+        assert torch.allclose(d, rel.grad, rtol=1e-4, atol=1e-4), (rel_len, q, k, (d - rel.grad).abs().max())

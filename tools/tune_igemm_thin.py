@@ -15,13 +15,18 @@ TAP_SHAPES = [(48384, 192, 864), (12096, 384, 1728), (3024, 768, 3456), (28560, 
 SHAPES = [(193536, 96, 96), (193536, 96, 192), (193536, 192, 96), (48384, 192, 192), (48384, 192, 384), (48384, 384, 192),
           (12096, 384, 384), (12096, 384, 768), (12096, 768, 384), (3024, 768, 768), (3024, 768, 1536), (3024, 1536, 768),
           (648, 768, 768), (648, 384, 384), (48384, 3456, 192), (12096, 6912, 384), (5376, 1728, 384), (1344, 3456, 768), (21504, 96, 192), (5376, 192, 384), (1344, 384, 768)]
+# MViTv2-S token GEMMs at 4 clips of 16x224x384 (forward and data-gradient orientations): --mvit
+MVIT_SHAPES = [(10756, 384, 1152), (10756, 384, 384), (10756, 384, 1536), (10756, 1536, 384), (10756, 1152, 384),
+               (43012, 192, 576), (43012, 192, 192), (43012, 192, 768), (43012, 768, 192), (43012, 576, 192), (43012, 192, 1152),
+               (172036, 96, 288), (172036, 96, 96), (172036, 96, 384), (172036, 384, 96), (172036, 96, 576), (172036, 288, 96),
+               (2692, 768, 2304), (2692, 768, 768), (2692, 768, 3072), (2692, 3072, 768), (2692, 2304, 768)]
 
 
 def main():
     lowp = "--bf16" in sys.argv          # 16-bit storage: the igemm16 kernels and their own tile table
     var = "DIFFSAL_IGEMM16_CFG" if lowp else "DIFFSAL_IGEMM_CFG"
     names = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64", "256x96", "256x128"] if lowp else CFG
-    for M, K, N in (TAP_SHAPES if "--tap" in sys.argv else SHAPES):
+    for M, K, N in (TAP_SHAPES if "--tap" in sys.argv else MVIT_SHAPES if "--mvit" in sys.argv else SHAPES):
         x = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
         if lowp:
