@@ -39,7 +39,9 @@ template <int CT, int WCO, int WK, int ST, int BM = 32>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   static_assert(WCO * WK == 4, "four waves");
   constexpr int BCO = WCO * CT * 32, SL = WK * ST, BKI = SL * 32;
-  constexpr int PA = BCO + 4, PB = BKI + 4;      // ds_read_b32 of 32 consecutive floats per half wave: conflict-free
+  // row pitch = 32 (mod 64) floats: the two half waves of a ds_read_b32 (rows m and m + 1, 32 consecutive floats each) use
+  // disjoint halves of the 64 banks; the float4 stores stay row-linear.  (+4 padding: 1-2 % slower, tools/tune_wgrad_mvit.py)
+  constexpr int PA = BCO + (96 - BCO % 64) % 64, PB = BKI + (96 - BKI % 64) % 64;
   constexpr int NA = BCO / 32 * (BM / 32), NB = BKI / 32 * (BM / 32);    // float4 loads per thread per step
   __shared__ __attribute__((aligned(16))) float dYs[BM * PA];
   __shared__ __attribute__((aligned(16))) float Xs[BM * PB];

@@ -257,6 +257,20 @@ def pack_conv_weight(w: Tensor) -> Tensor:
     return _pack(_as_conv4(w.detach()), 0)
 
 
+def pack_wino_weight(w: Tensor) -> Tensor:
+    """[Cout, Cin, 3, 3] -> the Winograd F(2x2, 3x3) weight U = G w G^T in the blocked layout diffsal_conv_wino reads:
+    [Cin/8][ceil(Cout/64)][16][64][8] fp32 (output channels past Cout zero); include/diffsal.h."""
+    w = w.detach().float()
+    Cout, Cin = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 3) and Cin % 8 == 0
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], device=w.device)
+    U = torch.einsum("ia,ocab,jb->ijoc", G, w, G).reshape(16, Cout, Cin)
+    cb = (Cout + 63) // 64
+    if cb * 64 != Cout:
+        U = torch.cat([U, U.new_zeros(16, cb * 64 - Cout, Cin)], 1)
+    return U.view(16, cb, 64, Cin // 8, 8).permute(3, 1, 0, 2, 4).contiguous()
+
+
 def split_weight(w_packed: Tensor) -> Tensor:
     """bf16x3 mode only: pre-split a packed fp32 weight [Cout, K] into bf16 hi/lo halves per 32-k slice (same shape and
     size; include/diffsal.h, w_format = 1).  The result is tagged: conv_igemm then announces w_format = 1 together with
@@ -327,10 +341,12 @@ def pack_conv_weight_diff(w: Tensor) -> Tensor:
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
                out_hw: Optional[Sequence[int]] = None, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               act: int = ACT_NONE, out: Optional[Tensor] = None, tag: str = "gemm") -> Tensor:
+               act: int = ACT_NONE, out: Optional[Tensor] = None, tag: str = "gemm", wino: Optional[Tensor] = None) -> Tensor:
     """Implicit-GEMM conv on NHWC x [N,H,W,Cin] with packed weight [Cout, kh*kw*Cin] -> [N,Ho,Wo,Cout].
 
-    ``pad`` is (top, left); bottom/right padding is implied by ``out_hw`` (zero fill outside)."""
+    ``pad`` is (top, left); bottom/right padding is implied by ``out_hw`` (zero fill outside).  ``wino``: the same weight in
+    Winograd form (``pack_wino_weight``); used instead of the direct kernel when the library's planner expects a gain
+    (``diffsal_conv_wino_supported``: fp32 3x3 stride-1, padding = dilation in {1, 2}, Cin and Cout >= 192)."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
@@ -353,6 +369,17 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         rv = rowvec.data_ptr()
     else:
         rv = None
+    if wino is not None and lib.diffsal_conv_wino_supported(C.byref(d)):
+        ws_bytes = lib.diffsal_conv_wino_ws_bytes(C.byref(d))
+        ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
+        dd = dil[0]
+        n_tiles = N * dd * dd * (((H + dd - 1) // dd + 1) // 2) * (((W + dd - 1) // dd + 1) // 2)
+        # FLOPs actually issued: 16 products per 2x2 tile, input and output channel (the direct form has 36)
+        with _prof(tag, 2.0 * n_tiles * 16 * Cin * Cout, _nb(x, wino, residual, out) + 2 * 16 * n_tiles * Cin * 4,
+                   f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw} winograd F(2x2,3x3)" if PROFILE is not None else ""):
+            _lib.check(lib.diffsal_conv_wino(C.byref(d), _p(x), _p(wino), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out),
+                                             _p(ws), ws_bytes, _stream()), "conv_wino")
+        return out
     ws_bytes = lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32) if ws_bytes else None
     with _prof(tag, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, w_packed, residual, out),

@@ -225,7 +225,7 @@ class SalUNet(nn.Module):
         return self.gemm_precision or ops.get_gemm_precision()
 
     def _cache_key(self):
-        return (self._pack_epoch, self._precision(), self.compute_dtype) + tuple(
+        return (self._pack_epoch, self._precision(), self.compute_dtype, self.winograd) + tuple(
             (p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def pack_epoch(self):
@@ -245,6 +245,13 @@ class SalUNet(nn.Module):
         if self.compute_dtype != torch.float32:
             return ops.cast(wp, self.compute_dtype)
         return ops.split_weight(wp) if self._precision() == "bf16x3" else wp
+
+    def _pack_wino(self, w: Tensor):
+        """Winograd F(2x2, 3x3) form of a 3x3 weight for the exact-fp32 path (ops.pack_wino_weight), else None: the library's
+        planner then decides per shape whether diffsal_conv_wino or the direct kernel runs (ops.conv_igemm(wino=...))."""
+        if self.compute_dtype != torch.float32 or self._precision() != "fp32" or not self.winograd:
+            return None
+        return ops.pack_wino_weight(w)
 
     def _tap_weight(self, w: Tensor) -> Tensor:
         """Conv2d 3x3 weight -> the [9*Cout, Cin] matrix of its nine 1x1 tap mixings (row = tap * Cout + co), in the storage /
@@ -288,6 +295,8 @@ class SalUNet(nn.Module):
             rb, dn = blk[0], blk[1]
             pk[f"res{i}.conv1.w"] = self._pack_conv(rb.conv1.weight)
             pk[f"res{i}.conv2.w"] = self._pack_conv(rb.conv2.weight)
+            pk[f"res{i}.conv1.wino"] = self._pack_wino(rb.conv1.weight)
+            pk[f"res{i}.conv2.wino"] = self._pack_wino(rb.conv2.weight)
             if hasattr(rb, "nin_shortcut"):
                 pk[f"res{i}.nin.w"] = self._pack_conv(rb.nin_shortcut.weight)
             pk[f"res{i}.down.w"] = self._pack_conv(dn.conv.weight)
@@ -303,6 +312,7 @@ class SalUNet(nn.Module):
                 pk[f"s{i}.pe1.tapw"] = self._tap_weight(pe[1].weight)
                 pk[f"s{i}.pe1.scale"], pk[f"s{i}.pe1.shift"] = self._bn_affine(pe[2])
                 pk[f"s{i}.pe2.w"] = self._pack_conv(pe[4].weight)
+                pk[f"s{i}.pe2.wino"] = self._pack_wino(pe[4].weight)
                 pk[f"s{i}.pe2.scale"], pk[f"s{i}.pe2.shift"] = self._bn_affine(pe[5])
             a = st.blocks[0].attn
             c = self.up_channels[i]
@@ -346,13 +356,14 @@ class SalUNet(nn.Module):
             co = rb.conv1.out_channels
             h = ops.groupnorm_swish(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
             h = ops.conv_igemm(h, pk[f"res{i}.conv1.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv1.bias,
-                               rowvec=tproj[:, off:off + co], tag="K4")
+                               rowvec=tproj[:, off:off + co], tag="K4", wino=pk[f"res{i}.conv1.wino"])
             off += co
             h = ops.groupnorm_swish(h, rb.norm2.weight, rb.norm2.bias, 32, rb.norm2.eps)
             sc = f
             if hasattr(rb, "nin_shortcut"):
                 sc = ops.conv_igemm(f, pk[f"res{i}.nin.w"], bias=rb.nin_shortcut.bias, tag="K4")
-            f = ops.conv_igemm(h, pk[f"res{i}.conv2.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc, tag="K4")
+            f = ops.conv_igemm(h, pk[f"res{i}.conv2.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc, tag="K4",
+                               wino=pk[f"res{i}.conv2.wino"])
             if taps is not None:
                 taps[f"res{i}"] = f
             hh, ww = f.shape[1:3]
@@ -501,6 +512,9 @@ class SalUNet(nn.Module):
     # the pooled launch + the paired projection GEMM at stage 3 (every one of the 648 workgroups re-reads both weight matrices
     # from L2), 43 against 30 us at C = 192: off.
     fold_kv_proj = False
+    # fp32 3x3 stride-1 convolutions (ResnetBlock conv1 / conv2, UpEmbed's second convolution) as Winograd F(2x2, 3x3) where the
+    # library's planner expects a gain (csrc/wino.hip; ~1e-6 relative transform rounding).  Off: always the direct kernel
+    winograd = True
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
@@ -633,7 +647,8 @@ class SalUNet(nn.Module):
                 skip = frames[i] if i in (1, 2) else None  # transformer.py:265-270
                 u = ops.conv_igemm(u, pk[f"s{i}.pe2.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
                                    scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU, tag="K12",
-                                   residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C))
+                                   residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C),
+                                   wino=pk[f"s{i}.pe2.wino"])
                 xcur = u.view(Bn, T, 2 * h, 2 * w, C)
             kt = self.temporal_list[i]
             if (xcur.shape[1] - kt) // kt + 1 != 1:

@@ -153,6 +153,20 @@ size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const void* in, const void* w,
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
                        const void* residual, void* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
+
+/* Winograd F(2x2, 3x3) form of the same operator for fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2},
+ * Cin % 32 == 0, Cout % 4 == 0 (ResnetBlock.conv1 / conv2, R/models/saliency_decoder/sal_unet.py:104-142; UpEmbed's second
+ * convolution, common_block.py:196-216): 2.25x fewer multiplications; the result differs from the direct convolution by
+ * transform rounding (~1e-6 relative).  `U` is the transformed weight G g G^T in blocked layout
+ * [Cin/8][ceil(Cout/64)][16][64][8] (rows past Cout zero): the host mirror builds it with ops.pack_wino_weight.
+ * diffsal_conv_wino_supported: 1 when the descriptor qualifies AND the planner expects a gain over diffsal_conv_igemm
+ * (Cin, Cout >= 192; DIFFSAL_NO_WINOGRAD=1: never, DIFFSAL_FORCE_WINOGRAD=1: whenever the shape qualifies).
+ * Epilogue and argument meaning as diffsal_conv_igemm; ws: diffsal_conv_wino_ws_bytes(d) bytes (transformed input + split slabs). */
+int diffsal_conv_wino_supported(const diffsal_conv_desc* d /*host*/);
+size_t diffsal_conv_wino_ws_bytes(const diffsal_conv_desc* d /*host*/);
+int diffsal_conv_wino(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
+                      const float* scale, const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                      size_t ws_bytes, diffsal_stream_t stream);
 /* Two plain products of ONE shape in one launch (grid z = 2): out_i [M,N] = in_i [M,K] x w_i [N,K]^T + bias_i.  The key and value
  * projections of a transformer block (attention.py:78-83: proj_k / proj_v on the 648 pooled tokens of a stage) are 8-26 us
  * launches at their latency floor; paired they are four launches per step instead of eight.  d: a 1x1 descriptor (KH = KW = 1,
