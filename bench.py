@@ -854,7 +854,7 @@ def main():
                          "output_range": [float(y32.min().item()), float(y32.max().item())]})
         set_precision("fp32")
         result["alt_precision"] = alts
-    if world == 1 and args.precision == "fp32" and not special and not args.no_encoders:
+    if world == 1 and args.precision in ("fp32", "bf16", "fp16") and not special and not args.no_encoders:
         # "also report end-to-end clips/s including encoders separately".  The once-per-clip encoders (MViTv2-S
         # video encoder; VGGish + AudioAttnNet in AV mode) on the HIP path, random-init weights of the reference
         # architectures, timed on a synthetic clip batch; end-to-end = encoders once + 50 denoising steps per clip batch.
@@ -863,7 +863,9 @@ def main():
         from diff_sal_amd.vggish import VGGish
 
         torch.manual_seed(7)
-        enc = MViT(arch="small", out_scales=[0, 1, 2, 3]).to(dev).eval().requires_grad_(False)
+        # 16-bit storage runs: the video encoder keeps its token stream and GEMM weights in the same storage type (MViT(compute_dtype))
+        enc = MViT(arch="small", out_scales=[0, 1, 2, 3], compute_dtype=STORAGE.get(args.precision, torch.float32))
+        enc = enc.to(dev).eval().requires_grad_(False)
         clip = torch.randn((B, 3, 16, H, W), device=dev)
         mods = [("mvit_s", lambda: enc(clip))]
         if av:

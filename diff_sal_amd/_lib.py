@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 SIGNATURES = {
@@ -110,7 +110,7 @@ SIGNATURES = {
     "diffsal_pool3d_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 9 + [C.c_long, C.c_long, c_f]),
     "diffsal_maxpool_tokens_idx": (c_i, [c_f] * 3 + [c_i] * 11 + [c_f]),
     "diffsal_maxpool_tokens_bwd": (c_i, [c_f] * 3 + [c_i] * 11 + [c_f]),
-    "diffsal_qkv_pool": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 3),
+    "diffsal_qkv_pool": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 2 + [c_i, c_f]),
     "diffsal_qkv_pool_bwd_data": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 3),
     "diffsal_conv_wino_supported": (c_i, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wino_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),

@@ -44,7 +44,7 @@ __device__ __forceinline__ float dot4(float4 a, float4 b, float s) {
 }  // namespace
 
 struct QkvPoolArgs {
-  const float* qkv;        // forward: the fused projection [B][N][3][heads][96]; backward: unused
+  const void* qkv;         // forward / filter gradient: the fused projection [B][N][3][heads][96] (forward: fp32 or 16-bit storage)
   const float* w27[3];     // [27][96] per tensor (tap-major)
   const float* gamma[3];   // forward, LN form
   const float* beta[3];
@@ -63,7 +63,8 @@ struct QkvPoolArgs {
 // forward: out_x[bh][n] = LN_x( depthwise Conv3d 3x3x3, pad 1, stride (st, sh, sw) of the x slice of qkv ), class token passed
 // through the convolution.  LN = false: convolution only (training: the LayerNorm is its own differentiable operator).
 // ------------------------------------------------------------------------------------------------------------------------
-template <bool LN>
+// TS: storage type of qkv (the 16-bit encoder path keeps its token GEMMs in bf16 / fp16); taps, LayerNorm and outputs are fp32.
+template <bool LN, typename TS>
 __global__ __launch_bounds__(256) void qkv_pool_kernel(QkvPoolArgs p) {
   __shared__ float4 w_s[28 * PQ];
   int blk = xcd_contiguous(blockIdx.x, gridDim.x), which = 0;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void qkv_pool_kernel(QkvPoolArgs p) {
     const int n = rc - bh * (Lo + 1);
     const int b = div_fast_(bh, heads, inv_heads);
     const int head = bh - b * heads;
-    const float* base = p.qkv + b * clip_stride + (which * heads + head) * PD + gl * 4;
+    const TS* base = static_cast<const TS*>(p.qkv) + b * clip_stride + (which * heads + head) * PD + gl * 4;
     float4 acc[3];
     if (n == 0) {
 #pragma unroll
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void qkv_pool_kernel(QkvPoolArgs p) {
             const int ix = x0 + kx;
             const bool v = vy && ix >= 0 && ix < W;
             const int tok = v ? 1 + (it * H + iy) * W + ix : 0;
-            const float* src = base + tok * tok_stride;
+            const TS* src = base + tok * tok_stride;
 #pragma unroll
             for (int i = 0; i < 3; ++i) a[ky * 3 + kx][i] = ld4(src + 32 * i);
             sel[ky * 3 + kx] = v ? (kt * 9 + ky * 3 + kx) * PQ : 27 * PQ;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_weight_kernel(QkvPoolArgs p,
       const int to = div_fast_(lw, Ho, inv_ho);
       const int ho = lw - to * Ho;
       const float4 gy = ld4(dy + (static_cast<long>(bh) * (Lo + 1) + 1 + l) * PD + c);
-      const float* base = p.qkv + b * clip_stride + (which * heads + head) * PD + c;
+      const float* base = static_cast<const float*>(p.qkv) + b * clip_stride + (which * heads + head) * PD + c;
       const int it = to * st - 1 + kt;
       const bool vt = it >= 0 && it < T;
       float4 a[9];
@@ -507,9 +508,9 @@ static int fill_geometry(QkvPoolArgs& a, int B, int heads, int T, int H, int W, 
   return DIFFSAL_OK;
 }
 
-extern "C" int diffsal_qkv_pool(const float* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
+extern "C" int diffsal_qkv_pool(const void* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
                                 const float* eps, float* const* out, int B, int heads, int D, int T, int H, int W,
-                                const int* stride_q, const int* stride_kv, diffsal_stream_t stream) {
+                                const int* stride_q, const int* stride_kv, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(qkv && w27 && out && stride_q && stride_kv && w27[0] && w27[1] && w27[2] && out[0] && out[1] && out[2],
              DIFFSAL_E_ARG, "qkv_pool: null argument");
   DS_REQUIRE(D == PD, DIFFSAL_E_SHAPE, "qkv_pool: head dimension %d (built for 96; use diffsal_pool3d_ln per tensor)", D);
@@ -521,6 +522,7 @@ extern "C" int diffsal_qkv_pool(const float* qkv, const float* const* w27, const
   if (rc) return rc;
   a.qkv = qkv;
   DS_REQUIRE(aligned16(qkv), DIFFSAL_E_ALIGN, "qkv_pool: misaligned qkv");
+  DS_REQUIRE(dtype == DIFFSAL_F32 || dtype == DIFFSAL_BF16 || dtype == DIFFSAL_F16, DIFFSAL_E_ARG, "qkv_pool: dtype %d", dtype);
   for (int x = 0; x < 3; ++x) {
     a.w27[x] = w27[x]; a.out[x] = out[x];
     DS_REQUIRE(aligned16(w27[x]) && aligned16(out[x]), DIFFSAL_E_ALIGN, "qkv_pool: misaligned pointer");
@@ -541,8 +543,13 @@ extern "C" int diffsal_qkv_pool(const float* qkv, const float* const* w27, const
   for (int g = 0; g < 2; ++g) a.blocks[g] = (a.rows[g] + PROWS * a.iters - 1) / (PROWS * a.iters);
   const unsigned grid = static_cast<unsigned>(a.blocks[0] + 2 * a.blocks[1]);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (ln) hipLaunchKernelGGL(qkv_pool_kernel<true>, dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(qkv_pool_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+#define CALL(TT)                                                                              \
+  do {                                                                                        \
+    if (ln) hipLaunchKernelGGL((qkv_pool_kernel<true, TT>), dim3(grid), dim3(256), 0, s, a);  \
+    else hipLaunchKernelGGL((qkv_pool_kernel<false, TT>), dim3(grid), dim3(256), 0, s, a);    \
+  } while (0)
+  DS_DTYPE_DISPATCH(dtype, "qkv_pool", CALL);
+#undef CALL
   return check_launch("qkv_pool");
 }
 

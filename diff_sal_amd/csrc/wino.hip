@@ -12,14 +12,15 @@
 //
 // Three steps:
 //  1. wino_input_kernel   V[chunk][tile block][xi][64 tiles][8 ci] = B^T x B   (8 input channels per chunk; 4x the input bytes,
-//                         written once, read once per block of 64 output channels -- from L2 / MALL for these sizes)
+//                         written once, read once per block of 64 output channels -- from the Infinity Cache for the layers that
+//                         use this path)
 //  2. wino_gemm_kernel    a workgroup owns 64 tiles x 64 output channels and ALL 16 xi: 4 waves as 2 x 2, each 32 tiles x 32
-//                         channels x 16 xi = 16 MFMA accumulators (256 registers); both operands arrive as contiguous 32 KB
-//                         blocks per chunk (U is the host-transformed weight in the same blocked layout), two LDS stages, one
-//                         barrier per chunk of 64 MFMAs per wave; the output transform A^T M A runs on the accumulators
-//                         (all 16 xi of a (tile, channel) sit in one lane) and feeds the usual epilogue.
-//  3. wino_reduce_kernel  only when the cin range is split over workgroups (few tiles x channels): sums the untransformed...
-//                         -- the TRANSFORMED partial outputs (the transform is linear) and applies the epilogue.
+//                         channels x 16 xi = 16 MFMA accumulators (256 registers, one wave per SIMD); both operands arrive as
+//                         contiguous 32 KB blocks per chunk by LDS-DMA (U is the host-transformed weight in the same blocked
+//                         layout) into two LDS stages, one barrier per chunk of 64 MFMAs per wave; the output transform A^T M A
+//                         runs on the accumulators (all 16 xi of a (tile, channel) sit in one lane) and feeds the usual epilogue.
+//  3. wino_reduce_kernel  only when the input channels are split over workgroups (few tiles x channel blocks): sums the partial
+//                         outputs -- already transformed, the transform is linear -- in a fixed order and applies the epilogue.
 #include "common.h"
 
 namespace diffsal {

@@ -80,8 +80,15 @@ class MViT(nn.Module):
                  out_scales=-1, drop_path_rate=0.0, use_abs_pos_embed=False, interpolate_mode="trilinear",
                  pool_kernel=(3, 3, 3), dim_mul=2, head_mul=2, adaptive_kv_stride=(1, 8, 8), rel_pos_embed=True,
                  residual_pooling=True, dim_mul_in_attention=True, with_cls_token=True, output_cls_token=False,
-                 rel_pos_zero_init=False, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm):
+                 rel_pos_zero_init=False, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm,
+                 compute_dtype: torch.dtype = torch.float32):
+        """``compute_dtype`` (inference only; not a reference argument): torch.bfloat16 / torch.float16 keep the token stream and
+        the weights of the token GEMMs in that storage type (native 16-bit MFMA, fp32 accumulation); the patch embedding, the
+        pooling convolutions, every LayerNorm statistic, the relative-position projections and the attention core stay fp32."""
         super().__init__()
+        if compute_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"MViT: compute_dtype {compute_dtype}")
+        self.compute_dtype = compute_dtype
         if (use_abs_pos_embed or tuple(pool_kernel) != (3, 3, 3) or dim_mul != 2 or head_mul != 2 or not rel_pos_embed
                 or not residual_pooling or not dim_mul_in_attention or not with_cls_token or output_cls_token
                 or mlp_ratio != 4.0 or not qkv_bias or norm_layer is not nn.LayerNorm or in_channels != 3):
@@ -160,7 +167,7 @@ class MViT(nn.Module):
 
     # ------------------------------------------------------------------ weight / table packing
     def _key(self):
-        return (self._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self._pack_epoch, self.compute_dtype) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def parameters_updated(self) -> None:
         """Parameters were rewritten behind autograd's version counters (the fused Adam kernel writes the flat buffer through
@@ -180,6 +187,11 @@ class MViT(nn.Module):
             a = blk.attn
             for n in "qkv":
                 pk[f"b{i}.pool_{n}"] = getattr(a, f"pool_{n}").weight.detach().reshape(96, 27).t().contiguous()   # [27][D]
+            if self.compute_dtype != torch.float32:            # 16-bit storage of the token GEMM weights
+                for n, lin in (("qkv", a.qkv), ("aproj", a.proj), ("fc1", blk.mlp.fc1), ("fc2", blk.mlp.fc2)):
+                    pk[f"b{i}.{n}.w"] = ops.cast(lin.weight.detach(), self.compute_dtype)
+                if hasattr(blk, "proj"):
+                    pk[f"b{i}.skip.w"] = ops.cast(blk.proj.weight.detach(), self.compute_dtype)
         self._pack, self._pack_key, self._tables = pk, key, {}
         return pk
 
@@ -220,26 +232,30 @@ class MViT(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _block(self, i: int, x: Tensor, size, pk) -> Tensor:
-        """MultiScaleBlock.forward (R/models/mvit.py:779-802) on tokens [B, 1+T*H*W, C]."""
+        """MultiScaleBlock.forward (R/models/mvit.py:779-802) on tokens [B, 1+T*H*W, C] (fp32, or the 16-bit storage type of
+        ``compute_dtype``: then the GEMMs read 16-bit weights and tokens, the pooled q / k / v, the relative-position columns
+        and the attention core are fp32, and the attention output is rounded once on its way into the projection)."""
         blk = self.blocks[i]
         a = blk.attn
         B, N, _ = x.shape
+        lp = x.dtype != torch.float32
+        w = (lambda n, lin: pk[f"b{i}.{n}.w"]) if lp else (lambda n, lin: lin.weight)
         xn = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, tag="mvit-gemm").view(B, N, 3, blk.heads, 96)
+        qkv = ops.linear(xn, w("qkv", a.qkv), a.qkv.bias, tag="mvit-gemm").view(B, N, 3, blk.heads, 96)
         q, k, v, q_size, k_size = ops.qkv_pool(
             qkv, (pk[f"b{i}.pool_q"], pk[f"b{i}.pool_k"], pk[f"b{i}.pool_v"]), size, blk.stride_q, blk.stride_kv,
             norms=tuple((n.weight, n.bias, n.eps) for n in (a.norm_q, a.norm_k, a.norm_v)))
         Rt, Rh, Rw, onehot = self._tables_for(i, q_size, k_size)
         extra = ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size, ops.relpos_columns(k_size))
         o = ops.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual=q, skip_first=True)
-        skip = ops.linear(xn, blk.proj.weight, blk.proj.bias, tag="mvit-gemm") if hasattr(blk, "proj") else x
+        skip = ops.linear(xn, w("skip", blk.proj), blk.proj.bias, tag="mvit-gemm") if hasattr(blk, "proj") else x
         if max(blk.stride_q) > 1:
             ks = tuple(s + 1 if s > 1 else s for s in blk.stride_q)
-            skip = ops.maxpool_tokens(skip, size, ks, blk.stride_q)
-        x = ops.linear(o, a.proj.weight, a.proj.bias, residual=skip, tag="mvit-gemm")
+            skip = ops.cast(ops.maxpool_tokens(ops.cast(skip, torch.float32), size, ks, blk.stride_q), x.dtype)
+        x = ops.linear(ops.cast(o, x.dtype), w("aproj", a.proj), a.proj.bias, residual=skip, tag="mvit-gemm")
         y = ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        h = ops.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ACT_GELU, tag="mvit-gemm")
-        return ops.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x, tag="mvit-gemm"), q_size
+        h = ops.linear(y, w("fc1", blk.mlp.fc1), blk.mlp.fc1.bias, act=ACT_GELU, tag="mvit-gemm")
+        return ops.linear(h, w("fc2", blk.mlp.fc2), blk.mlp.fc2.bias, residual=x, tag="mvit-gemm"), q_size
 
     # ------------------------------------------------------------------ training forward (autograd tape, HIP fwd + bwd)
     def _block_train(self, i: int, x: Tensor, size) -> Tensor:
@@ -354,6 +370,7 @@ class MViT(nn.Module):
                            out=tok[b, 1:].view(1, 1, L, 96), tag="mvit-gemm")
         if taps is not None:
             taps["tokens0"] = tok
+        tok = ops.cast(tok, self.compute_dtype)                  # the patch embedding itself is an fp32 GEMM (K = 441)
         outs = []
         for i in range(self.num_layers):
             tok, size = self._block(i, tok, size, pk)
@@ -362,5 +379,5 @@ class MViT(nn.Module):
             if i in self.stage_of_layer:
                 nm = getattr(self, f"norm{self.stage_of_layer[i]}")
                 tok = ops.layernorm(tok, nm.weight, nm.bias, nm.eps)       # replaces x for the next block (mvit.py:1123-1126)
-                outs.append(ops.tokens_to_channels_first(tok, 1).view(B, tok.shape[2], *size))
+                outs.append(ops.tokens_to_channels_first(ops.cast(tok, torch.float32), 1).view(B, tok.shape[2], *size))
         return outs[::-1]

@@ -1159,12 +1159,12 @@ def _ptr3(ts):
 
 def qkv_pool(qkv: Tensor, w27, size, stride_q, stride_kv, norms=None):
     """The three attention_pool convolutions of a block in one launch (head dimension 96).  qkv: [B, N, 3, heads, 96]
-    contiguous; w27 = (wq, wk, wv) each [27, 96]; norms = ((gamma, beta, eps) x 3) adds the LayerNorms, None = convolutions
+    contiguous, fp32 or 16-bit storage (outputs are fp32 either way); w27 = (wq, wk, wv) each [27, 96]; norms = ((gamma, beta, eps) x 3) adds the LayerNorms, None = convolutions
     only.  -> (q, k, v) each [B, heads, 1 + Lo, 96], q_size, k_size."""
     lib = _lib.load()
     B, N, three, heads, D = qkv.shape
     T, H, W = size
-    assert three == 3 and N == 1 + T * H * W and qkv.is_contiguous() and qkv.dtype == torch.float32
+    assert three == 3 and N == 1 + T * H * W and qkv.is_contiguous()
     q_size = tuple((s - 1) // st + 1 for s, st in zip(size, stride_q))
     k_size = tuple((s - 1) // st + 1 for s, st in zip(size, stride_kv))
     Lq, Lk = q_size[0] * q_size[1] * q_size[2], k_size[0] * k_size[1] * k_size[2]
@@ -1179,8 +1179,8 @@ def qkv_pool(qkv: Tensor, w27, size, stride_q, stride_kv, norms=None):
     sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
     nbytes = sum(o.numel() for o in outs) * 8
     with _prof("pool", 54.0 * sum(o.numel() for o in outs), nbytes):
-        _lib.check(lib.diffsal_qkv_pool(_p(qkv), _ptr3(w27), g3, b3, eps, _ptr3(outs), B, heads, D, T, H, W, sq, skv, _stream()),
-                   "qkv_pool")
+        _lib.check(lib.diffsal_qkv_pool(qkv.data_ptr(), _ptr3(w27), g3, b3, eps, _ptr3(outs), B, heads, D, T, H, W, sq, skv,
+                                        _dt(qkv), _stream()), "qkv_pool")
     return outs[0], outs[1], outs[2], q_size, k_size
 
 

@@ -497,9 +497,9 @@ int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float* din, int 
  * the LayerNorm sums run over 8 lanes x 12 channels instead of 32 x 4.
  * qkv_pool_bwd_data: every element of dqkv [B][N][3][heads][96] from the three output gradients (temporal stride 1, equal
  * spatial strides); bit-identical to three diffsal_pool3d_bwd_data calls. */
-int diffsal_qkv_pool(const float* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
+int diffsal_qkv_pool(const void* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
                      const float* eps, float* const* out, int B, int heads, int D, int T, int H, int W, const int* stride_q,
-                     const int* stride_kv, diffsal_stream_t stream);
+                     const int* stride_kv, int dtype /* storage type of qkv; outputs are fp32 */, diffsal_stream_t stream);
 int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* const* w27, float* dqkv, int B, int heads, int D, int T,
                               int H, int W, const int* stride_q, const int* stride_kv, diffsal_stream_t stream);
 /* qkv_pool_bwd_weight: the three filter gradients in one launch: part[3][chunks][27*96] doubles (chunks =

@@ -183,6 +183,33 @@ def test_mvit_forward_matches_reference_golden(golden_dir, name):
     assert {"out0", "out3", "block0"} <= set(worst)
 
 
+# 16-bit storage of the encoder's token stream and GEMM weights (MViT(compute_dtype=...)): relative error of the four feature maps
+# against the reference's fp32 outputs, in units of each map's maximum.  bf16 keeps 8 mantissa bits through 16 residual blocks.
+MVIT_LOWP_TOL = {torch.bfloat16: 2.5e-2, torch.float16: 4e-3}      # measured 1.0e-2 / 1.5e-3 on the full-size fixture
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_mvit_16bit_storage_path_against_reference_golden(golden_dir, dtype):
+    from diff_sal_amd.mvit import MViT
+
+    arch, shape = MVIT_CASES["small_full"]
+    net, cfg, sd = build_mvit(arch)
+    lp = MViT(arch=arch, out_scales=[0, 1, 2, 3], compute_dtype=dtype)
+    lp.load_state_dict(sd, strict=True)
+    lp = lp.to(DEV).eval().requires_grad_(False)
+    g = np.load(f"{golden_dir}/mvit_small_full.npz")
+    x = orc.synth_tensor("mvit.small_full.x", shape).to(DEV)
+    with torch.no_grad():
+        outs = lp(x)
+    assert all(o.dtype == torch.float32 for o in outs)
+    worst = check_taps({f"out{i}": o for i, o in enumerate(outs)}, g, MVIT_LOWP_TOL[dtype])   # strided samples of the reference's maps
+    print(dtype, "feature-map errors", worst)
+    assert set(worst) == {"out0", "out1", "out2", "out3"}
+    with torch.no_grad():                                                                   # and every element against the fp32 HIP path
+        ref = net(x)
+    assert max(rel_err(o, r) for o, r in zip(outs, ref)) < MVIT_LOWP_TOL[dtype]
+
+
 def test_mvit_feeds_the_denoiser_through_video_saliency_model():
     """VideoSaliencyModel(visual_net=MViT, decoder_net=SalUNet): clip in, saliency map out, all on the HIP path."""
     from diff_sal_amd.diff_model import VideoSaliencyModel
