@@ -484,7 +484,10 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
                                "weight-gradient convolutions/GEMMs of one step)",
                      "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": len(gemm_ev),
-                     "step_ms_in_kernel": round(k_ms, 3), "classes": class_table(ev, FP32_MFMA_PEAK_TFLOPS)},
+                     "step_ms_in_kernel": round(k_ms, 3), "classes": class_table(ev, FP32_MFMA_PEAK_TFLOPS),
+                     # how much of the step the class table brackets (HIP events of every library operator of one step; the rest
+                     # is torch-native elementwise / copy / fill kernels of the autograd tape and launch gaps)
+                     "classified_ms": round(sum(e[0].elapsed_time(e[1]) for e in ev), 3), "operators_bracketed": len(ev)},
     }
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -123,6 +123,10 @@ struct WinoArgs {
   const float* residual;
   int act, rowvec_ld;
   int splits, chunks_per_split;
+  // tail mode (splits == 1, more than one round of workgroups): blocks [0, n_full) are whole; each later block is cut into
+  // tail_split pieces of tail_chunks chunks that write partial outputs to `tail_slabs` (wino_tail_reduce_kernel finishes them)
+  int n_full, tail_split, tail_chunks;
+  float* tail_slabs;
   WinoGeom g;
 };
 
@@ -148,14 +152,18 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoArgs p) {
   const int wt = wave >> 1, wc = wave & 1;
   // workgroups are dealt round-robin over the 8 XCDs: walk the (tile block, channel block) list so that one XCD owns a
   // contiguous run of it -- the channel blocks of a tile block then read their shared V block from ONE L2
-  int vb;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  int vb, tail_piece = -1;
+  if (static_cast<int>(blockIdx.x) < p.n_full) {
+    const int nwg = p.n_full, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     vb = xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+  } else {                                   // a piece of a tail block: dispatched after every whole block
+    const int t = static_cast<int>(blockIdx.x) - p.n_full;
+    vb = p.n_full + t / p.tail_split;
+    tail_piece = t - (vb - p.n_full) * p.tail_split;
   }
   const int tb = vb / g.cout_blocks, cb = vb - tb * g.cout_blocks;
-  const int c_begin = blockIdx.y * p.chunks_per_split;
-  const int c_end = min(g.chunks, c_begin + p.chunks_per_split);
+  const int c_begin = tail_piece >= 0 ? tail_piece * p.tail_chunks : blockIdx.y * p.chunks_per_split;
+  const int c_end = min(g.chunks, c_begin + (tail_piece >= 0 ? p.tail_chunks : p.chunks_per_split));
 
   f32x16 acc[16];
 #pragma unroll
@@ -243,7 +251,8 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoArgs p) {
   int n, y0, x0;
   wino_tile_coords(g, t, n, y0, x0);
   const long HW = static_cast<long>(g.H) * g.W;
-  float* outp = p.out + (p.splits > 1 ? static_cast<long>(blockIdx.y) * g.N * HW * g.Cout : 0);
+  float* outp = tail_piece >= 0 ? p.tail_slabs + static_cast<long>(tail_piece) * g.N * HW * g.Cout
+                                : p.out + (p.splits > 1 ? static_cast<long>(blockIdx.y) * g.N * HW * g.Cout : 0);
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
     const int co = cb * 64 + wc * 32 + 8 * r4 + 4 * hf;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoArgs p) {
       }
     }
     float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bi, rw = bi;
-    const bool epi = p.splits == 1;
+    const bool epi = p.splits == 1 && tail_piece < 0;
     if (epi) {
       if (p.bias) bi = ld4(p.bias + co);
       if (p.scale) { sc = ld4(p.scale + co); sh = ld4(p.shift + co); }
@@ -332,9 +341,44 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(WinoArgs p, const floa
   }
 }
 
+// tail mode: sums the pieces of the tail blocks (tiles >= tile0, every channel) in a fixed order and applies the epilogue
+__global__ __launch_bounds__(256) void wino_tail_reduce_kernel(WinoArgs p, float* __restrict__ out, int tile0) {
+  const WinoGeom& g = p.g;
+  const int n4 = g.Cout >> 2;
+  const long HW = static_cast<long>(g.H) * g.W, slab = static_cast<long>(g.N) * HW * g.Cout;
+  const long total = static_cast<long>(g.n_tiles - tile0) * 4 * n4;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int co = static_cast<int>(i % n4) * 4;
+    const long r = i / n4;
+    const int px = static_cast<int>(r & 3), t = tile0 + static_cast<int>(r >> 2);
+    int n, y0, x0;
+    wino_tile_coords(g, t, n, y0, x0);
+    const int oy = y0 + g.d * (px >> 1), ox = x0 + g.d * (px & 1);
+    if (oy >= g.H || ox >= g.W) continue;
+    const long o = (static_cast<long>(n) * HW + static_cast<long>(oy) * g.W + ox) * g.Cout + co;
+    float4 a = ld4(p.tail_slabs + o);
+    for (int s = 1; s < p.tail_split; ++s) {
+      const float4 b = ld4(p.tail_slabs + s * slab + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xv = v[e];
+      if (p.bias) xv += p.bias[co + e];
+      if (p.scale) xv = xv * p.scale[co + e] + p.shift[co + e];
+      if (p.rowvec) xv += p.rowvec[static_cast<long>(n) * p.rowvec_ld + co + e];
+      xv = wino_act(xv, p.act);
+      if (p.residual) xv += p.residual[o + e];
+      v[e] = xv;
+    }
+    st4(out + o, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
 namespace {
 
-struct WinoPlan { WinoGeom g; int splits, chunks_per_split; size_t v_bytes, slab_bytes; };
+struct WinoPlan { WinoGeom g; int splits, chunks_per_split, n_full, tail_split, tail_chunks; size_t v_bytes, slab_bytes; };
 
 bool wino_shape_ok(const diffsal_conv_desc* d) {
   return d && d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
@@ -365,8 +409,27 @@ WinoPlan wino_plan(const diffsal_conv_desc* d) {
   pl.chunks_per_split = ((g.chunks + s - 1) / s + 1) & ~1;       // even (the kernel walks two chunks per iteration); chunks is even
   pl.splits = (g.chunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
   s = pl.splits;
+  // More than one round (one workgroup per CU): the last, partly filled round costs as much as a full one.  Cut ITS blocks
+  // (whole tile blocks, so the finishing pass owns complete rows of tiles) into pieces that fill the chip once more:
+  // 324 blocks = 256 whole + 68 x 3 pieces of 16 chunks instead of a second round of 48 chunks on a quarter of the CUs.
+  pl.n_full = wgs;
+  pl.tail_split = 1;
+  pl.tail_chunks = g.chunks;
+  if (s == 1 && wgs > 256) {
+    int n_full = (wgs / 256) * 256;
+    n_full -= n_full % g.cout_blocks;
+    const int rest = wgs - n_full;
+    int ts = rest > 0 ? 256 / rest : 1;
+    while (ts > 1 && (((g.chunks + ts - 1) / ts + 1) & ~1) < 12) --ts;
+    if (rest > 0 && ts >= 2) {
+      pl.n_full = n_full;
+      pl.tail_chunks = ((g.chunks + ts - 1) / ts + 1) & ~1;
+      pl.tail_split = (g.chunks + pl.tail_chunks - 1) / pl.tail_chunks;
+    }
+  }
   pl.v_bytes = static_cast<size_t>(g.chunks) * g.tile_blocks * 16 * 64 * 8 * sizeof(float);
-  pl.slab_bytes = s > 1 ? static_cast<size_t>(s) * g.N * g.H * g.W * g.Cout * sizeof(float) : 0;
+  const int slabs = s > 1 ? s : (pl.tail_split > 1 ? pl.tail_split : 0);
+  pl.slab_bytes = static_cast<size_t>(slabs) * g.N * g.H * g.W * g.Cout * sizeof(float);
   return pl;
 }
 
@@ -381,14 +444,15 @@ extern "C" int diffsal_conv_wino_supported(const diffsal_conv_desc* d) {
   if (!wino_shape_ok(d) || tune(TUNE_NO_WINOGRAD) == 1) return 0;
   if (tune(TUNE_FORCE_WINOGRAD) == 1) return 1;
   // Measured (tools/bench_wino.py stand-alone, bench.py in the step, B = 4): the products run at ~2.3 us per 8-channel
-  // chunk and round of <= 256 workgroups (one per CU, one wave per SIMD), 1.3-1.6x faster than the direct kernel on the six
-  // ResnetBlock convolutions (0.66 -> 0.52 ms per step).  The price is the transformed input, 4x the input bytes, written and
-  // read back: up to ~70 MB it lives in the 256 MB Infinity Cache between the two kernels; UpEmbed's second convolutions
-  // (36 frames: 75 / 150 / 300 MB) gain 1.12x / 1.20x / 0.90x stand-alone and nothing inside a step, and stay direct.  Fewer
-  // than 128 workgroups (single clips) leave half the chip idle at one workgroup per CU: direct.
+  // chunk and round of <= 256 workgroups (one per CU, one wave per SIMD).  Stand-alone against the direct kernel: the six
+  // ResnetBlock convolutions 1.36-1.65x, UpEmbed's second convolutions of stages 1 / 2 (36 frames, dilation 2) 1.45x / 1.33x
+  // once their last, partly filled round is cut into pieces (tail mode), stage 3 (Cout = 96: a quarter of the 64-channel blocks
+  // is padding, 300 MB of transformed input) 0.91x.  In the step: class K4 0.66 -> 0.51 ms, K12 1.26 -> 1.14 ms.  The
+  // transformed input is 4x the input bytes, written and read back: 160 MB bounds what still pays.  Fewer than 128 workgroups
+  // (single clips at full resolution) leave half the chip idle at one workgroup per CU: direct.
   const WinoPlan pl = wino_plan(d);
   const int wgs = pl.g.tile_blocks * pl.g.cout_blocks * pl.splits;
-  return (pl.v_bytes <= 70u * 1000u * 1000u && wgs >= 128 && d->Cout >= 128) ? 1 : 0;
+  return (pl.v_bytes <= 160u * 1000u * 1000u && wgs >= 128 && d->Cout >= 128) ? 1 : 0;
 }
 
 extern "C" size_t diffsal_conv_wino_ws_bytes(const diffsal_conv_desc* d) {
@@ -426,9 +490,21 @@ extern "C" int diffsal_conv_wino(const diffsal_conv_desc* d, const float* x, con
   a.V = V; a.U = U; a.out = pl.splits > 1 ? slabs : out;
   a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec; a.residual = residual;
   a.act = d->act; a.rowvec_ld = d->rowvec_ld; a.splits = pl.splits; a.chunks_per_split = pl.chunks_per_split; a.g = pl.g;
-  hipLaunchKernelGGL(wino_gemm_kernel, dim3(pl.g.tile_blocks * pl.g.cout_blocks, pl.splits), dim3(256), 0, s, a);   // 128 KB of static LDS
+  a.n_full = pl.n_full; a.tail_split = pl.tail_split; a.tail_chunks = pl.tail_chunks; a.tail_slabs = slabs;
+  const int n_blocks = pl.g.tile_blocks * pl.g.cout_blocks;
+  const int grid_x = pl.n_full + (n_blocks - pl.n_full) * pl.tail_split;
+  hipLaunchKernelGGL(wino_gemm_kernel, dim3(grid_x, pl.splits), dim3(256), 0, s, a);   // 128 KB of static LDS
   rc = check_launch("conv_wino(products)");
-  if (rc || pl.splits == 1) return rc;
+  if (rc) return rc;
+  if (pl.tail_split > 1) {
+    const int tile0 = (pl.n_full / pl.g.cout_blocks) * 64;
+    const long items = static_cast<long>(pl.g.n_tiles - tile0) * 4 * (d->Cout / 4);
+    long gt = (items + 255) / 256;
+    gt = gt > 2048 ? 2048 : gt;
+    hipLaunchKernelGGL(wino_tail_reduce_kernel, dim3(static_cast<unsigned>(gt)), dim3(256), 0, s, a, out, tile0);
+    return check_launch("conv_wino(tail sum)");
+  }
+  if (pl.splits == 1) return rc;
   const long total4 = static_cast<long>(d->N) * d->H * d->W * (d->Cout / 4);
   long gr = (total4 + 255) / 256;
   gr = gr > 2048 ? 2048 : gr;

@@ -27,24 +27,48 @@ Tensor = torch.Tensor
 PROFILE = None
 
 
+_PROF_DEPTH = [0]      # brackets nest (an operator's finishing reduction inside its own bracket): only the outermost one records
+
+
 class _prof:
-    __slots__ = ("cls", "flops", "nbytes", "e0", "note")
+    __slots__ = ("cls", "flops", "nbytes", "e0", "note", "counted")
 
     def __init__(self, cls, flops=0.0, nbytes=0.0, note=""):
-        self.cls, self.flops, self.nbytes, self.e0, self.note = cls, float(flops), float(nbytes), None, note
+        self.cls, self.flops, self.nbytes, self.e0, self.note, self.counted = cls, float(flops), float(nbytes), None, note, False
 
     def __enter__(self):
         if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            self.counted = True
+            if _PROF_DEPTH[0] == 0:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            _PROF_DEPTH[0] += 1
         return self
 
     def __exit__(self, et, ev, tb):
+        if self.counted:
+            _PROF_DEPTH[0] -= 1
         if self.e0 is not None and et is None and PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             PROFILE.append((self.e0, e1, self.flops, self.cls, self.nbytes, self.note))
         return False
+
+
+def _classed(cls: str):
+    """Bracket an operator without FLOP / byte accounting under a class name of bench.py's table (training-side kernels: the
+    class table then covers the whole step instead of its forward operators and GEMMs only)."""
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            if PROFILE is None:
+                return fn(*a, **k)
+            with _prof(cls):
+                return fn(*a, **k)
+        return wrapper
+    return deco
 
 
 def _nb(*ts) -> float:
@@ -123,6 +147,7 @@ def _pa(t: Optional[Tensor], code: int):
     return t.data_ptr()
 
 
+@_classed("pack")
 def cast(x: Tensor, dtype: torch.dtype) -> Tensor:
     """Storage-type conversion on the device (round to nearest even)."""
     if x.dtype == dtype:
@@ -235,6 +260,7 @@ def _as_conv4(w: Tensor) -> Tensor:
     return w
 
 
+@_classed("pack")
 def _pack(w4: Tensor, mode: int) -> Tensor:
     """csrc/pack.hip on a contiguous [Cout, Cin, kh, kw] (modes 0, 1) or packed [Cout, K] (mode 2, shape from w4)."""
     lib = _lib.load()
@@ -271,6 +297,7 @@ def pack_wino_weight(w: Tensor) -> Tensor:
     return U.view(16, cb, 64, Cin // 8, 8).permute(3, 1, 0, 2, 4).contiguous()
 
 
+@_classed("pack")
 def split_weight(w_packed: Tensor) -> Tensor:
     """bf16x3 mode only: pre-split a packed fp32 weight [Cout, K] into bf16 hi/lo halves per 32-k slice (same shape and
     size; include/diffsal.h, w_format = 1).  The result is tagged: conv_igemm then announces w_format = 1 together with
@@ -292,6 +319,7 @@ def pack_cols_weight(w: Tensor) -> Tensor:
     return _pack(_as_conv4(w.detach()), 3)
 
 
+@_classed("col2im")
 def col2im_disjoint(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pad) -> Tensor:
     """cols [N*Ho*Wo, kh*kw*C] -> dx [N,H,W,C] for a convolution with stride >= kernel (each input pixel has one source)."""
     lib = _lib.load()
@@ -302,6 +330,7 @@ def col2im_disjoint(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pa
     return dx
 
 
+@_classed("col2im")
 def col2im_gather(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pad) -> Tensor:
     """cols [N*Ho*Wo, kh*kw*C] -> dx [N,H,W,C] for a strided convolution whose taps overlap (1 < stride < kernel): every
     input pixel sums the column entries that map onto it (fixed order, no atomics)."""
@@ -749,6 +778,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     return dw
 
 
+@_classed("reduce")
 def colsum(dy: Tensor, seg_rows: Optional[int] = None) -> Tensor:
     """Column sums of dy [M, C] per segment of seg_rows rows -> [M // seg_rows, C] (one segment: [1, C])."""
     lib = _lib.load()
@@ -762,6 +792,7 @@ def colsum(dy: Tensor, seg_rows: Optional[int] = None) -> Tensor:
     return out
 
 
+@_classed("act-bwd")
 def act_bwd(dy: Tensor, ref: Tensor, mode: int) -> Tensor:
     """dy * act'(.): mode 1 ReLU (ref = y), 2 GELU (ref = pre-activation), 3 sigmoid (ref = y)."""
     lib = _lib.load()
@@ -774,6 +805,7 @@ def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
     return act_bwd(dy, y, 1)
 
 
+@_classed("norm-train")
 def rowstats(x: Tensor, seg_rows: int, mode: int = 0, dy=None, y=None, mu=None, rs=None, gamma=None, beta=None,
              stat_per_seg: bool = False) -> Tensor:
     """Per-channel dual sums over the rows of each segment -> [segs, 2, C] (float64, chunk partials already summed)."""
@@ -787,6 +819,7 @@ def rowstats(x: Tensor, seg_rows: int, mode: int = 0, dy=None, y=None, mu=None, 
     return reduce_partials(part, M // seg_rows, chunks, 2 * Cc, f64=True).view(M // seg_rows, 2, Cc)
 
 
+@_classed("reduce")
 def reduce_partials(part: Tensor, segs: int, chunks: int, width: int, f64: bool = False) -> Tensor:
     """Sum fp64 partials [segs, chunks, width] over the chunks (fixed order) -> [segs, width] (fp64 or fp32)."""
     lib = _lib.load()
@@ -796,6 +829,7 @@ def reduce_partials(part: Tensor, segs: int, chunks: int, width: int, f64: bool 
     return out
 
 
+@_classed("norm-train")
 def norm_finalize_fwd(sums: Tensor, gamma: Tensor, beta: Tensor, groups: int, n: float, eps: float, bn=None):
     """sums [segs, 2, C] fp64 -> (mu, rs, scale, shift) [segs, C] (+ (mean, var) [C] when ``bn`` = (running_mean,
     running_var, momentum, unbias) is given: BatchNorm, running statistics updated in place)."""
@@ -814,6 +848,7 @@ def norm_finalize_fwd(sums: Tensor, gamma: Tensor, beta: Tensor, groups: int, n:
     return mu, rs, scale, shift, mean, var
 
 
+@_classed("norm-train")
 def norm_finalize_bwd(t: Tensor, gamma: Tensor, rs: Tensor, groups: int, n: float):
     """t [segs, 2, C] fp64 -> (dgamma [C], dbeta [C], k1, k2, k3 [segs, C])."""
     lib = _lib.load()
@@ -825,6 +860,7 @@ def norm_finalize_bwd(t: Tensor, gamma: Tensor, rs: Tensor, groups: int, n: floa
     return dg, db, k1, k2, k3
 
 
+@_classed("norm-train")
 def affine_act(x: Tensor, scale: Tensor, shift: Tensor, seg_rows: int, act: int) -> Tensor:
     lib = _lib.load()
     Cc = x.shape[-1]
@@ -834,6 +870,7 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, seg_rows: int, act: int)
     return out
 
 
+@_classed("norm-train")
 def norm_bwd_apply(x, dy, y, mu, rs, gamma, beta, k1, k2, k3, seg_rows: int, mode: int) -> Tensor:
     lib = _lib.load()
     Cc = x.shape[-1]
@@ -844,6 +881,7 @@ def norm_bwd_apply(x, dy, y, mu, rs, gamma, beta, k1, k2, k3, seg_rows: int, mod
     return dx
 
 
+@_classed("K8-bwd")
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5):
     """-> (dx, dgamma, dbeta)."""
     lib = _lib.load()
@@ -858,6 +896,7 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5):
     return dx, s[0], s[1]
 
 
+@_classed("dropout")
 def dropout(x: Tensor, p: float, seed: int) -> Tensor:
     lib = _lib.load()
     out = torch.empty_like(x)
@@ -873,6 +912,7 @@ def gelu(x: Tensor) -> Tensor:
     return affine_act(x, one, zero, x.numel() // Cc, ACT_GELU)
 
 
+@_classed("K9-train")
 def dwconv(x: Tensor, w: Tensor, k: int, stride: int, pad: int) -> Tensor:
     """Depthwise k x k conv on NHWC x with w [k*k, C]."""
     lib = _lib.load()
@@ -883,6 +923,7 @@ def dwconv(x: Tensor, w: Tensor, k: int, stride: int, pad: int) -> Tensor:
     return out
 
 
+@_classed("K9-train")
 def dwconv_bwd(x: Tensor, w: Tensor, du: Tensor, k: int, stride: int, pad: int, need_dx=True, need_dw=True):
     lib = _lib.load()
     N, H, W, Cc = x.shape
@@ -900,6 +941,7 @@ def dwconv_bwd(x: Tensor, w: Tensor, du: Tensor, k: int, stride: int, pad: int, 
     return dx, dw
 
 
+@_classed("wgrad")
 def wgrad_segmented(x: Tensor, dy: Tensor, segments: int) -> Tensor:
     """out[s] = dy_s^T @ x_s for the ``segments`` equal row blocks of x [M, K] and dy [M, Cout] -> [segments, Cout, K]."""
     lib = _lib.load()
@@ -915,6 +957,7 @@ def wgrad_segmented(x: Tensor, dy: Tensor, segments: int) -> Tensor:
     return out
 
 
+@_classed("K11-bwd")
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, heads: int, scale: float):
     """-> (dq, dk, dv).  Pass 1: per-query kernel (dq, P, dS); pass 2: dk = dS^T q, dv = P^T dout per image on the
     matrix cores (segmented weight-gradient GEMM), keeping each head's own column block."""
@@ -937,6 +980,7 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, dout: Tensor, heads: int, sca
     return dq, pick(dk_full).contiguous(), pick(dv_full).contiguous()
 
 
+@_classed("resize-bwd")
 def resize_bilinear_bwd(dy: Tensor, h: int, w: int) -> Tensor:
     lib = _lib.load()
     N, H, W, Cc = dy.shape
@@ -947,6 +991,7 @@ def resize_bilinear_bwd(dy: Tensor, h: int, w: int) -> Tensor:
     return dx
 
 
+@_classed("K6-bwd")
 def unpack_frames(frames_grad: Tensor, Tv: int) -> Tensor:
     """[B,Tin,h,w,C] -> gradient of the NCTHW visual features [B,C,Tv,h,w]."""
     lib = _lib.load()
@@ -956,6 +1001,7 @@ def unpack_frames(frames_grad: Tensor, Tv: int) -> Tensor:
     return out
 
 
+@_classed("head-bwd")
 def head_bwd(y: Tensor, w: Tensor, s_out: Tensor, ds: Tensor):
     """-> (dy, dw [C], db [1])."""
     lib = _lib.load()
@@ -970,6 +1016,7 @@ def head_bwd(y: Tensor, w: Tensor, s_out: Tensor, ds: Tensor):
     return dy, s[:Cc].contiguous(), s[Cc:].contiguous()
 
 
+@_classed("K2-bwd")
 def conv_in_bwd(x: Tensor, dy: Tensor):
     """-> (dw [C, 9], db [C]) of conv_in."""
     lib = _lib.load()
@@ -982,6 +1029,7 @@ def conv_in_bwd(x: Tensor, dy: Tensor):
     return s[:9].t().contiguous(), s[9].contiguous()
 
 
+@_classed("K1-bwd")
 def dense_small_bwd(x: Tensor, w: Tensor, dout: Tensor, swish_in: bool):
     """-> (dx, dw, db)."""
     lib = _lib.load()
@@ -993,6 +1041,7 @@ def dense_small_bwd(x: Tensor, w: Tensor, dout: Tensor, swish_in: bool):
     return dx, dw, db
 
 
+@_classed("K7-bwd")
 def audio_fuse_bwd(a_small: Tensor, x: Tensor, dout: Tensor, h: int, w: int):
     """-> (dx [B,T,H,W,C], da_small [B*T, h*w, C])."""
     lib = _lib.load()
@@ -1012,6 +1061,7 @@ def _reduce_scratch(dev) -> Tensor:
     return torch.empty((_lib.load().diffsal_reduce_blocks(),), device=dev, dtype=torch.float64)
 
 
+@_classed("optim")
 def mse_loss(pred: Tensor, target: Tensor, loss_scale: float, want_grad: bool = True):
     """-> (loss [1], dpred or None): loss = loss_scale * sum (pred-target)^2 (R/models/sal_losses.py:189-192)."""
     lib = _lib.load()
@@ -1025,6 +1075,7 @@ def mse_loss(pred: Tensor, target: Tensor, loss_scale: float, want_grad: bool = 
     return loss, dpred
 
 
+@_classed("optim")
 def grad_norm(flat_grad: Tensor, gscale: float = 1.0) -> Tensor:
     """-> [1] tensor gscale * ||flat_grad||_2 (stays on the device)."""
     lib = _lib.load()
@@ -1035,6 +1086,7 @@ def grad_norm(flat_grad: Tensor, gscale: float = 1.0) -> Tensor:
     return norm
 
 
+@_classed("optim")
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
               weight_decay: float = 0.0, gscale: float = 1.0, norm: Optional[Tensor] = None, max_norm: float = 0.0,
               store_clipped_grad: bool = False) -> None:
@@ -1049,6 +1101,7 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, *, step: int, lr: floa
                                      float(max_norm), int(store_clipped_grad), _stream()), "adam_step")
 
 
+@_classed("optim")
 def scale_by(x: Tensor, s: Tensor) -> Tensor:
     """x * s[0] with s a one-element device tensor."""
     lib = _lib.load()
@@ -1057,6 +1110,7 @@ def scale_by(x: Tensor, s: Tensor) -> Tensor:
     return out
 
 
+@_classed("optim")
 def multi_copy(srcs: Sequence[Tensor], dst_offsets: Sequence[int], dst: Tensor) -> None:
     """dst[off_i : off_i + srcs[i].numel()] = srcs[i] for all i, in a handful of launches (csrc/optim.hip)."""
     lib = _lib.load()
@@ -1218,6 +1272,7 @@ def _iptr3(ts):
     return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
 
 
+@_classed("relpos")
 def rel_tables(rels, plans):
     """(Rt, Rh, Rw) gathered relative-position tables [q, k, D] of one block from the learnt tables and their host-built sparse
     row maps (``MViT._rel_plan``): one launch."""
@@ -1231,6 +1286,7 @@ def rel_tables(rels, plans):
     return outs
 
 
+@_classed("relpos-bwd")
 def rel_tables_bwd(douts, plans):
     """Gradients of the three learnt tables [len, D] from the gradients of the gathered ones: one launch."""
     lib = _lib.load()

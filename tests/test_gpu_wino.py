@@ -30,6 +30,7 @@ CASES = [
     (3, 5, 6, 32, 100, 1, "none"),
     (1, 6, 8, 768, 192, 1, "bias_rowvec"),            # few tiles, deep: the input channels are split over workgroups
     (4, 28, 48, 192, 384, 1, "bias_res"),             # ResnetBlock of stage 1 at its real size
+    (36, 14, 24, 384, 384, 2, "bn_relu_res"),         # UpEmbed-2 of stage 1: 324 blocks = 252 whole + 72 cut into 3 pieces (tail mode)
 ]
 
 
