@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoArgs p) {
   // Operand staging: LDS-DMA (global_load_lds_dwordx4: global -> LDS, no registers -- the 256 accumulators leave none for a
   // second in-flight chunk).  An instruction fills 64 consecutive float4 slots; the bank swizzle (wino_slot) is applied on the
   // SOURCE address: the lane that fills slot s loads float4 wino_slot(s) of the block, and the fragment reads apply the same
-  // involution.  The pieces of chunk c + 1 are issued between the MFMAs of chunk c (two per pair of positions) into the other
-  // stage; the __syncthreads() at the end of the chunk retires them (vmcnt(0)) before anyone reads that stage.
+  // involution.  The pieces of chunk c + 1 are issued between the MFMAs of the first half of chunk c (four per pair of positions)
+  // into the other stage; the __syncthreads() at the end of the chunk retires them (vmcnt(0)) before anyone reads that stage.
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
   const unsigned src_off = 16u * static_cast<unsigned>(tid ^ ((lane >> 4) & 1));   // bytes; the only per-lane address part
@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoArgs p) {
         a1n = ld4(us + 4 * (frag_a + (xi + 3) * 128));
         b1n = ld4(vs + 4 * (frag_b + (xi + 3) * 128));
       }
-      piece(vn, un, nxt, xi >> 1);
+      if (xi < 8) {                       // all sixteen pieces in the first half of the chunk: they have landed by its barrier
+        piece(vn, un, nxt, xi);
+        piece(vn, un, nxt, xi + 1);
+      }
       acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[xi], 0, 0, 0);   // rows = output channels, cols = tiles
       acc[xi + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[xi + 1], 0, 0, 0);
       acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[xi], 0, 0, 0);
@@ -230,11 +233,15 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoArgs p) {
       acc[xi + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[xi + 1], 0, 0, 0);
       // issue order inside the pair: the four fragment reads, then MFMAs with the two DMA pieces slipped between them
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if (xi < 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       a0 = a0n; b0 = b0n; a1 = a1n; b1 = b1n;
     }
