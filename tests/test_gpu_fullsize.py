@@ -102,3 +102,19 @@ def test_dpm_solver_50_nfe_full_size_trajectory(golden_dir, dname):
         bar = (RTOL if dname == "fp32" else LOWP_ATOL[dname]) * max(1.0, float(g[f"x{k}.stats"][2]))
         print(f"  state at evaluation {k}: max abs err {e:.3e} (|x| max {float(g[f'x{k}.stats'][2]):.2f})")
         assert e < bar
+
+
+def test_winograd_layers_are_active_at_batch4_and_agree_with_the_direct_kernels(golden_dir):
+    """configs[1]'s real shape: the eight layers the library's planner moves to Winograd F(2x2, 3x3) (six ResnetBlock convolutions,
+    UpEmbed-2 of stages 1 and 2) change the output by transform rounding only -- and they do run (the outputs are not bit-equal)."""
+    cfg, sd, x, t, feats, g = _b4(golden_dir)
+    net = build(cfg, sd)
+    args = (x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None)
+    with torch.no_grad():
+        on = net(*args)
+        net.winograd = False
+        off = net(*args)
+        net.winograd = True
+    d = (on - off).abs().max().item()
+    print(f"winograd on vs off at B=4: max abs diff {d:.2e}")
+    assert 0.0 < d < 2e-5
