@@ -744,7 +744,8 @@ def main():
             "note": "achieved = algorithmic FLOPs of the reference graph / time of the launches implementing them; the shipped "
                     "step executes fewer FLOPs (conv3x3(upsample(x)) runs as low-resolution tap GEMMs + a gather, exact; the ResnetBlock and two "
                     "UpEmbed 3x3 convolutions run as Winograd F(2x2,3x3), 16 instead of 36 products per tile), "
-                    "executed_* is the matrix-pipe rate on the FLOPs actually issued",
+                    "executed_* is the matrix-pipe rate on the FLOPs actually issued -- the number to read as kernel quality; `frac` prices the "
+                    "reference graph's FLOPs and can therefore pass 1.0 (48 % of its products are never issued)",
             "reference_graph": ref_graph, **common,
             "launches_per_step": n_alg, "avg_launch_us": round(alg_ms * 1e3 / n_alg, 2),
             "flops_per_launch": ref_graph["gemm_gflop_per_step"] * 1e9 / n_alg, "step_ms_in_kernel": alg_ms}
