@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 SIGNATURES = {
@@ -58,7 +58,7 @@ SIGNATURES = {
     "diffsal_linear_pair": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wgrad_splits": (c_i, [C.POINTER(ConvDesc)]),
-    "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_colsum": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "diffsal_act_bwd": (c_i, [c_f, c_f, c_f, c_sz, c_i, c_f]),
     "diffsal_rowstats_chunks": (c_i, [c_i, c_i]),
@@ -110,15 +110,15 @@ SIGNATURES = {
     "diffsal_pool3d_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 9 + [C.c_long, C.c_long, c_f]),
     "diffsal_maxpool_tokens_idx": (c_i, [c_f] * 3 + [c_i] * 11 + [c_f]),
     "diffsal_maxpool_tokens_bwd": (c_i, [c_f] * 3 + [c_i] * 11 + [c_f]),
-    "diffsal_qkv_pool": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 2 + [c_i, c_f]),
-    "diffsal_qkv_pool_bwd_data": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 3),
+    "diffsal_qkv_pool": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 2 + [c_i, c_i, c_f]),
+    "diffsal_qkv_pool_bwd_data": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 2 + [c_i, c_f]),
     "diffsal_conv_wino_supported": (c_i, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wino_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wino": (c_i, [C.POINTER(ConvDesc)] + [c_f] * 9 + [c_sz, c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
     "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),
     "diffsal_qkv_pool_bwd_weight_chunks": (c_i, []),
-    "diffsal_qkv_pool_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 3),
+    "diffsal_qkv_pool_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 2 + [c_i, c_f]),
     "diffsal_relpos_project_bwd_chunks": (c_i, []),
     "diffsal_relpos_project_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] + [c_i] * 9 + [c_f]),
     "diffsal_resize_update": (c_i, [c_f] * 6 + [c_i] * 5 + [c_fl] * 5 + [c_f]),

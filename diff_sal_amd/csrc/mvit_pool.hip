@@ -57,7 +57,21 @@ struct QkvPoolArgs {
   int rows[2];             // forward: B*heads*(1 + Lo); backward: B*N*heads for both
   int blocks[2];           // workgroups per tensor
   int iters;               // 32-token passes per workgroup
+  int w_channel_major;     // 1: filters (and their gradients) in the parameter's own [96][27] layout instead of tap-major [27][96]
 };
+
+// the 27 x 96 filter of one tensor -> LDS as [tap][channel quad] (+ a 28th all-zero row), from either memory layout
+__device__ __forceinline__ void stage_filter(float4* w_s, const float* __restrict__ w, int channel_major) {
+  for (int i = threadIdx.x; i < 27 * PQ; i += 256) {
+    if (channel_major) {
+      const int tap = i / PQ, c = (i - tap * PQ) * 4;
+      w_s[i] = make_float4(w[c * 27 + tap], w[(c + 1) * 27 + tap], w[(c + 2) * 27 + tap], w[(c + 3) * 27 + tap]);
+    } else {
+      w_s[i] = ld4(w + 4 * i);
+    }
+  }
+  if (threadIdx.x < PQ) w_s[27 * PQ + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // forward: out_x[bh][n] = LN_x( depthwise Conv3d 3x3x3, pad 1, stride (st, sh, sw) of the x slice of qkv ), class token passed
@@ -73,8 +87,7 @@ __global__ __launch_bounds__(256) void qkv_pool_kernel(QkvPoolArgs p) {
     if (blk >= p.blocks[1]) { blk -= p.blocks[1]; which = 2; }
   }
   const int g = which ? 1 : 0;
-  for (int i = threadIdx.x; i < 27 * PQ; i += 256) w_s[i] = ld4(p.w27[which] + 4 * i);
-  if (threadIdx.x < PQ) w_s[27 * PQ + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  stage_filter(w_s, p.w27[which], p.w_channel_major);
   __syncthreads();
   const int gl = threadIdx.x & 7, gr = threadIdx.x >> 3;
   const int T = p.T, H = p.H, W = p.W, To = p.To[g], Ho = p.Ho[g], Wo = p.Wo[g], st = p.st[g], sh = p.sh[g], sw = p.sw[g];
@@ -207,8 +220,7 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_data_kernel(QkvPoolArgs p) {
     if (blk >= p.blocks[1]) { blk -= p.blocks[1]; which = 2; }
   }
   const int g = which ? 1 : 0;
-  for (int i = threadIdx.x; i < 27 * PQ; i += 256) w_s[i] = ld4(p.w27[which] + 4 * i);
-  if (threadIdx.x < PQ) w_s[27 * PQ + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  stage_filter(w_s, p.w27[which], p.w_channel_major);
   __syncthreads();
   const int gl = threadIdx.x & 7, gr = threadIdx.x >> 3;
   const int H = p.H, W = p.W, To = p.To[g], Ho = p.Ho[g], Wo = p.Wo[g], s_sp = p.sh[g];
@@ -329,7 +341,10 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_weight_kernel(QkvPoolArgs p,
     __syncthreads();
   }
   double* o = part + (static_cast<long>(which) * QKV_WCHUNKS + blockIdx.x) * 27 * PD;
-  for (int i = threadIdx.x; i < 27 * PD; i += 256) o[i] = shw[i];
+  for (int i = threadIdx.x; i < 27 * PD; i += 256) {
+    const int tap = i / PD, ch = i - tap * PD;
+    o[p.w_channel_major ? ch * 27 + tap : i] = shw[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -510,7 +525,8 @@ static int fill_geometry(QkvPoolArgs& a, int B, int heads, int T, int H, int W, 
 
 extern "C" int diffsal_qkv_pool(const void* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
                                 const float* eps, float* const* out, int B, int heads, int D, int T, int H, int W,
-                                const int* stride_q, const int* stride_kv, int dtype, diffsal_stream_t stream) {
+                                const int* stride_q, const int* stride_kv, int dtype, int w_channel_major,
+                                diffsal_stream_t stream) {
   DS_REQUIRE(qkv && w27 && out && stride_q && stride_kv && w27[0] && w27[1] && w27[2] && out[0] && out[1] && out[2],
              DIFFSAL_E_ARG, "qkv_pool: null argument");
   DS_REQUIRE(D == PD, DIFFSAL_E_SHAPE, "qkv_pool: head dimension %d (built for 96; use diffsal_pool3d_ln per tensor)", D);
@@ -521,6 +537,7 @@ extern "C" int diffsal_qkv_pool(const void* qkv, const float* const* w27, const 
   int rc = fill_geometry(a, B, heads, T, H, W, stride_q, stride_kv, "qkv_pool");
   if (rc) return rc;
   a.qkv = qkv;
+  a.w_channel_major = w_channel_major ? 1 : 0;
   DS_REQUIRE(aligned16(qkv), DIFFSAL_E_ALIGN, "qkv_pool: misaligned qkv");
   DS_REQUIRE(dtype == DIFFSAL_F32 || dtype == DIFFSAL_BF16 || dtype == DIFFSAL_F16, DIFFSAL_E_ARG, "qkv_pool: dtype %d", dtype);
   for (int x = 0; x < 3; ++x) {
@@ -554,7 +571,7 @@ extern "C" int diffsal_qkv_pool(const void* qkv, const float* const* w27, const 
 }
 
 extern "C" int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* const* w27, float* dqkv, int B, int heads, int D,
-                                         int T, int H, int W, const int* stride_q, const int* stride_kv,
+                                         int T, int H, int W, const int* stride_q, const int* stride_kv, int w_channel_major,
                                          diffsal_stream_t stream) {
   DS_REQUIRE(dy && w27 && dqkv && stride_q && stride_kv && dy[0] && dy[1] && dy[2] && w27[0] && w27[1] && w27[2], DIFFSAL_E_ARG,
              "qkv_pool_bwd_data: null argument");
@@ -565,6 +582,7 @@ extern "C" int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* co
   int rc = fill_geometry(a, B, heads, T, H, W, stride_q, stride_kv, "qkv_pool_bwd_data");
   if (rc) return rc;
   a.dqkv = dqkv;
+  a.w_channel_major = w_channel_major ? 1 : 0;
   DS_REQUIRE(aligned16(dqkv), DIFFSAL_E_ALIGN, "qkv_pool_bwd_data: misaligned dqkv");
   for (int x = 0; x < 3; ++x) {
     a.w27[x] = w27[x]; a.dy[x] = dy[x];
@@ -583,7 +601,8 @@ extern "C" int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* co
 extern "C" int diffsal_qkv_pool_bwd_weight_chunks(void) { return QKV_WCHUNKS; }
 
 extern "C" int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const* dy, double* part, int B, int heads, int D, int T,
-                                           int H, int W, const int* stride_q, const int* stride_kv, diffsal_stream_t stream) {
+                                           int H, int W, const int* stride_q, const int* stride_kv, int w_channel_major,
+                                           diffsal_stream_t stream) {
   DS_REQUIRE(qkv && dy && part && stride_q && stride_kv && dy[0] && dy[1] && dy[2], DIFFSAL_E_ARG,
              "qkv_pool_bwd_weight: null argument");
   DS_REQUIRE(D == PD, DIFFSAL_E_SHAPE, "qkv_pool_bwd_weight: head dimension %d (built for 96)", D);
@@ -591,6 +610,7 @@ extern "C" int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const*
   int rc = fill_geometry(a, B, heads, T, H, W, stride_q, stride_kv, "qkv_pool_bwd_weight");
   if (rc) return rc;
   a.qkv = qkv;
+  a.w_channel_major = w_channel_major ? 1 : 0;
   DS_REQUIRE(aligned16(qkv), DIFFSAL_E_ALIGN, "qkv_pool_bwd_weight: misaligned qkv");
   for (int x = 0; x < 3; ++x) {
     a.dy[x] = dy[x];

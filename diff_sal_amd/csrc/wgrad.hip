@@ -22,6 +22,7 @@ struct WgradArgs {
   const float* dy;   // [M][Cout]
   float* slabs;      // [segments * splits][Cout][K]
   double* dbias;     // optional [segments * splits][Cout]: column sums of dY over the split's rows (bias gradient partials)
+  float* dbias_out;  // optional [Cout]: the finished bias gradient (written here when there is one split, else by slab_sum_kernel)
   int M, K, Cout;
   int H, W, Cin, Ho, Wo;
   int KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
     __syncthreads();
   }
-  if (do_bias && co0 + tid < p.Cout) p.dbias[static_cast<long>(blockIdx.z) * p.Cout + co0 + tid] = bias_acc;
+  if (do_bias && co0 + tid < p.Cout) {
+    p.dbias[static_cast<long>(blockIdx.z) * p.Cout + co0 + tid] = bias_acc;
+    if (p.dbias_out && gridDim.z == 1) p.dbias_out[co0 + tid] = static_cast<float>(bias_acc);
+  }
   // C/D map: col = lane & 31 (k within slice), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (co within tile)
   float* slab = p.slabs + static_cast<long>(blockIdx.z) * p.Cout * p.K;
 #pragma unroll
@@ -178,8 +182,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 // out[seg][i] = sum over the splits of one segment (deterministic: fixed association).  Workgroup = 16 float4 columns x
 // 16 split groups: group g adds splits g, g+16, ... in order, then the 16 group sums are added in order.  (One thread per
 // column walking all splits serially left 9 workgroups with 256-512 dependent steps each on the small token GEMMs.)
+// Blocks past g_main (bias_out != NULL) finish the bias gradient that rode along: bias_out[c] = sum over the splits of the fp64
+// partial column sums, in split order -- no separate reduction launch per layer.
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                       long n, int splits) {
+                                                       long n, int splits, int g_main, const double* __restrict__ bias_part,
+                                                       float* __restrict__ bias_out, int Cout) {
+  if (static_cast<int>(blockIdx.x) >= g_main) {
+    const int c = (static_cast<int>(blockIdx.x) - g_main) * 256 + threadIdx.x;
+    if (blockIdx.y == 0 && c < Cout) {
+      double t = 0.0;
+      for (int z = 0; z < splits; ++z) t += bias_part[static_cast<long>(z) * Cout + c];
+      bias_out[c] = static_cast<float>(t);
+    }
+    return;
+  }
   __shared__ float4 sh[16][17];
   const float* base = slabs + static_cast<long>(blockIdx.y) * splits * n;
   float* o = out + static_cast<long>(blockIdx.y) * n;
@@ -336,8 +352,10 @@ int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
   int rc = check_launch("conv_wgrad");
   if (rc || pl.splits == 1) return rc;
   const long g = (n / 4 + 15) / 16;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(static_cast<int>(g), segments), dim3(256), 0, s,
-                     static_cast<const float*>(a.slabs), out, n, pl.splits);
+  const bool bias = a.dbias && a.dbias_out && segments == 1;
+  const int extra = bias ? (a.Cout + 255) / 256 : 0;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(static_cast<int>(g) + extra, segments), dim3(256), 0, s,
+                     static_cast<const float*>(a.slabs), out, n, pl.splits, static_cast<int>(g), a.dbias, a.dbias_out, a.Cout);
   return check_launch("conv_wgrad(sum)");
 }
 
@@ -359,8 +377,9 @@ extern "C" int diffsal_conv_wgrad_splits(const diffsal_conv_desc* d) {
 }
 
 extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, const float* dy, float* dw_packed,
-                                  double* dbias_part, void* ws, size_t ws_bytes, diffsal_stream_t stream) {
+                                  double* dbias_part, float* dbias_out, void* ws, size_t ws_bytes, diffsal_stream_t stream) {
   DS_REQUIRE(d && in && dy && dw_packed && ws, DIFFSAL_E_ARG, "conv_wgrad: null argument");
+  DS_REQUIRE(!dbias_out || dbias_part, DIFFSAL_E_ARG, "conv_wgrad: dbias_out needs dbias_part (the per-split partial sums)");
   DS_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0 && d->Cout % 4 == 0, DIFFSAL_E_SHAPE,
              "conv_wgrad: Cin=%d must be a multiple of 32 and Cout=%d of 4", d->Cin, d->Cout);
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
@@ -372,7 +391,7 @@ extern "C" int diffsal_conv_wgrad(const diffsal_conv_desc* d, const float* in, c
   DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(in) && aligned16(dw_packed), DIFFSAL_E_ARG,
              "conv_wgrad: needs %zu bytes of 16-byte aligned workspace", need);
   WgradArgs a;
-  a.in = in; a.dy = dy; a.slabs = static_cast<float*>(ws); a.dbias = dbias_part;
+  a.in = in; a.dy = dy; a.slabs = static_cast<float*>(ws); a.dbias = dbias_part; a.dbias_out = dbias_out;
   a.M = static_cast<int>(M); a.K = static_cast<int>(K); a.Cout = d->Cout;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KW = d->KW; a.taps = d->KH * d->KW; a.stride_h = d->stride_h; a.stride_w = d->stride_w;
@@ -402,7 +421,7 @@ extern "C" int diffsal_wgrad_segmented(const float* x, const float* dy, float* o
   DS_REQUIRE(ws_bytes >= need && aligned16(ws) && aligned16(dy) && aligned16(x) && aligned16(out), DIFFSAL_E_ARG,
              "wgrad_segmented: needs %zu bytes of 16-byte aligned workspace", need);
   WgradArgs a;
-  a.in = x; a.dy = dy; a.slabs = static_cast<float*>(ws); a.dbias = nullptr;
+  a.in = x; a.dy = dy; a.slabs = static_cast<float*>(ws); a.dbias = nullptr; a.dbias_out = nullptr;
   a.M = static_cast<int>(M); a.K = K; a.Cout = Cout;
   a.H = 1; a.W = static_cast<int>(M); a.Cin = K; a.Ho = 1; a.Wo = static_cast<int>(M);
   a.KW = 1; a.taps = 1; a.stride_h = 1; a.stride_w = 1; a.pad_t = 0; a.pad_l = 0; a.dil_h = 1; a.dil_w = 1;

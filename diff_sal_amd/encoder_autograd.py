@@ -46,9 +46,11 @@ class QKVPoolFn(torch.autograd.Function):
     def forward(ctx, qkv, wq, wk, wv, size, stride_q, stride_kv):
         ctx.size, ctx.strides = size, (stride_q, stride_kv, stride_kv)
         ctx.save_for_backward(qkv, wq, wk, wv)
-        if qkv.shape[-1] == 96 and qkv.is_contiguous():          # one launch for the three tensors
+        if qkv.shape[-1] == 96 and qkv.is_contiguous():          # one launch for the three tensors (filters in either layout)
             return ops.qkv_pool(qkv, (wq, wk, wv), size, stride_q, stride_kv)[:3]
-        return tuple(ops.pool3d(qkv[:, :, i], w, size, st)[0] for i, (w, st) in enumerate(zip((wq, wk, wv), ctx.strides)))
+        cm = tuple(wq.shape) == (qkv.shape[-1], 27) and qkv.shape[-1] != 27
+        return tuple(ops.pool3d(qkv[:, :, i], w.t().contiguous() if cm else w, size, st)[0]
+                     for i, (w, st) in enumerate(zip((wq, wk, wv), ctx.strides)))
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
@@ -58,12 +60,14 @@ class QKVPoolFn(torch.autograd.Function):
                  and skv[1] == skv[2])
         if fused:
             dqkv = ops.qkv_pool_bwd_data((dq, dk, dv), (wq, wk, wv), qkv.shape, ctx.size, sq, skv)
-            dws = ops.qkv_pool_bwd_weight(qkv, (dq, dk, dv), ctx.size, sq, skv)
+            dws = ops.qkv_pool_bwd_weight(qkv, (dq, dk, dv), ctx.size, sq, skv, channel_major=tuple(wq.shape) == (96, 27))
             return dqkv, dws[0], dws[1], dws[2], None, None, None
         dqkv = torch.empty_like(qkv)
         dws = []
+        cm = tuple(wq.shape) == (qkv.shape[-1], 27) and qkv.shape[-1] != 27       # parameter layout: the per-tensor kernels are tap-major
         for i, (w, g, st) in enumerate(zip((wq, wk, wv), (dq, dk, dv), ctx.strides)):
-            dws.append(ops.pool3d_bwd(qkv[:, :, i], w, g, dqkv[:, :, i], ctx.size, st))
+            dw = ops.pool3d_bwd(qkv[:, :, i], w.t().contiguous() if cm else w, g, dqkv[:, :, i], ctx.size, st)
+            dws.append(dw.t().contiguous() if cm else dw)
         return dqkv, dws[0], dws[1], dws[2], None, None, None
 
 

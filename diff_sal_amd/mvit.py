@@ -267,7 +267,7 @@ class MViT(nn.Module):
         B, N, _ = x.shape
         xn = ag.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         qkv = ag.linear(xn, a.qkv.weight, a.qkv.bias).view(B, N, 3, blk.heads, 96)
-        w27 = [getattr(a, f"pool_{n}").weight.reshape(96, 27).t().contiguous() for n in "qkv"]
+        w27 = [getattr(a, f"pool_{n}").weight.reshape(96, 27) for n in "qkv"]      # the parameter's own layout: views, no copies
         pq, pk_, pv = eg.qkv_pool(qkv, w27[0], w27[1], w27[2], size, blk.stride_q, blk.stride_kv)
         q_size = tuple((s - 1) // st + 1 for s, st in zip(size, blk.stride_q))
         k_size = tuple((s - 1) // st + 1 for s, st in zip(size, blk.stride_kv))

@@ -765,16 +765,17 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1)
     nws = lib.diffsal_conv_wgrad_ws_bytes(C.byref(d))
     ws = torch.empty((nws // 4,), device=x.device, dtype=torch.float32)
     dw = torch.empty((Cout, kh * kw * Cin), device=x.device, dtype=torch.float32)
-    bpart = None
-    if want_bias:
+    bpart = db = None
+    if want_bias:                # per-split fp64 column sums of dy; the library finishes them into db (no separate reduction launch)
         splits = lib.diffsal_conv_wgrad_splits(C.byref(d))
         bpart = torch.empty((splits, Cout), device=x.device, dtype=torch.float64)
+        db = torch.empty((Cout,), device=x.device, dtype=torch.float32)
     with _prof("wgrad", 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, dy, dw),
                f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw}" if PROFILE is not None else ""):
-        _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), bpart.data_ptr() if want_bias else None, _p(ws),
-                                          nws, _stream()), "conv_wgrad")
+        _lib.check(lib.diffsal_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), bpart.data_ptr() if want_bias else None,
+                                          _p(db), _p(ws), nws, _stream()), "conv_wgrad")
     if want_bias:
-        return dw, reduce_partials(bpart, 1, bpart.shape[0], Cout).view(Cout)
+        return dw, db
     return dw
 
 
@@ -904,12 +905,18 @@ def dropout(x: Tensor, p: float, seed: int) -> Tensor:
     return out
 
 
+_GELU_CONST: dict = {}
+
+
 def gelu(x: Tensor) -> Tensor:
     """Stand-alone erf-GELU (training path keeps the pre-activation for the backward)."""
     Cc = x.shape[-1]
-    one = torch.ones((1, Cc), device=x.device, dtype=torch.float32)
-    zero = torch.zeros((1, Cc), device=x.device, dtype=torch.float32)
-    return affine_act(x, one, zero, x.numel() // Cc, ACT_GELU)
+    key = (Cc, x.device)
+    cst = _GELU_CONST.get(key)
+    if cst is None:                                   # identity affine of the shared kernel: built once per width and device
+        cst = _GELU_CONST[key] = (torch.ones((1, Cc), device=x.device, dtype=torch.float32),
+                                  torch.zeros((1, Cc), device=x.device, dtype=torch.float32))
+    return affine_act(x, cst[0], cst[1], x.numel() // Cc, ACT_GELU)
 
 
 @_classed("K9-train")
@@ -1211,6 +1218,17 @@ def _ptr3(ts):
     return (C.c_void_p * 3)(*[_p(t) for t in ts])
 
 
+def _filter_layout(ws) -> int:
+    """0: tap-major [27, 96] filters (the packed eval weights), 1: the parameter's own [96, 27] (= Conv3d weight.reshape(96, 27):
+    the training path hands the parameters over without a transposed copy and gets their gradients back in that layout)."""
+    shapes = {tuple(w.shape) for w in ws}
+    if shapes == {(27, 96)}:
+        return 0
+    if shapes == {(96, 27)}:
+        return 1
+    raise ValueError(f"pooling filters must all be [27, 96] or all [96, 27], got {sorted(shapes)}")
+
+
 def qkv_pool(qkv: Tensor, w27, size, stride_q, stride_kv, norms=None):
     """The three attention_pool convolutions of a block in one launch (head dimension 96).  qkv: [B, N, 3, heads, 96]
     contiguous, fp32 or 16-bit storage (outputs are fp32 either way); w27 = (wq, wk, wv) each [27, 96]; norms = ((gamma, beta, eps) x 3) adds the LayerNorms, None = convolutions
@@ -1224,6 +1242,7 @@ def qkv_pool(qkv: Tensor, w27, size, stride_q, stride_kv, norms=None):
     Lq, Lk = q_size[0] * q_size[1] * q_size[2], k_size[0] * k_size[1] * k_size[2]
     outs = [torch.empty((B, heads, 1 + L, D), device=qkv.device, dtype=torch.float32) for L in (Lq, Lk, Lk)]
     w27 = [_cont(w) for w in w27]
+    cm = _filter_layout(w27)
     if norms is not None:
         gam, bet = [_cont(n[0]) for n in norms], [_cont(n[1]) for n in norms]
         eps = (C.c_float * 3)(*[float(n[2]) for n in norms])
@@ -1234,7 +1253,7 @@ def qkv_pool(qkv: Tensor, w27, size, stride_q, stride_kv, norms=None):
     nbytes = sum(o.numel() for o in outs) * 8
     with _prof("pool", 54.0 * sum(o.numel() for o in outs), nbytes):
         _lib.check(lib.diffsal_qkv_pool(qkv.data_ptr(), _ptr3(w27), g3, b3, eps, _ptr3(outs), B, heads, D, T, H, W, sq, skv,
-                                        _dt(qkv), _stream()), "qkv_pool")
+                                        _dt(qkv), cm, _stream()), "qkv_pool")
     return outs[0], outs[1], outs[2], q_size, k_size
 
 
@@ -1245,16 +1264,18 @@ def qkv_pool_bwd_data(dys, w27, qkv_shape, size, stride_q, stride_kv) -> Tensor:
     T, H, W = size
     dys = [_cont(d) for d in dys]
     w27 = [_cont(w) for w in w27]
+    cm = _filter_layout(w27)
     dqkv = torch.empty(tuple(qkv_shape), device=dys[0].device, dtype=torch.float32)
     sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
     with _prof("pool-bwd", 54.0 * sum(d.numel() for d in dys), sum(d.numel() for d in dys) * 4 + dqkv.numel() * 4):
-        _lib.check(lib.diffsal_qkv_pool_bwd_data(_ptr3(dys), _ptr3(w27), _p(dqkv), B, heads, D, T, H, W, sq, skv, _stream()),
+        _lib.check(lib.diffsal_qkv_pool_bwd_data(_ptr3(dys), _ptr3(w27), _p(dqkv), B, heads, D, T, H, W, sq, skv, cm, _stream()),
                    "qkv_pool_bwd_data")
     return dqkv
 
 
-def qkv_pool_bwd_weight(qkv: Tensor, dys, size, stride_q, stride_kv) -> Tensor:
-    """The three filter gradients [3, 27, 96] of ``qkv_pool`` in one launch + one reduction."""
+def qkv_pool_bwd_weight(qkv: Tensor, dys, size, stride_q, stride_kv, channel_major: bool = False) -> Tensor:
+    """The three filter gradients of ``qkv_pool`` in one launch + one reduction: [3, 27, 96], or [3, 96, 27] (the parameter's
+    layout) with ``channel_major``."""
     lib = _lib.load()
     B, N, _, heads, D = qkv.shape
     T, H, W = size
@@ -1263,9 +1284,10 @@ def qkv_pool_bwd_weight(qkv: Tensor, dys, size, stride_q, stride_kv) -> Tensor:
     part = torch.empty((3, chunks, 27 * D), device=qkv.device, dtype=torch.float64)
     sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
     with _prof("pool-bwd", 54.0 * sum(d.numel() for d in dys), sum(d.numel() for d in dys) * 8):
-        _lib.check(lib.diffsal_qkv_pool_bwd_weight(_p(qkv), _ptr3(dys), part.data_ptr(), B, heads, D, T, H, W, sq, skv, _stream()),
-                   "qkv_pool_bwd_weight")
-    return reduce_partials(part, 3, chunks, 27 * D).view(3, 27, D)
+        _lib.check(lib.diffsal_qkv_pool_bwd_weight(_p(qkv), _ptr3(dys), part.data_ptr(), B, heads, D, T, H, W, sq, skv,
+                                                   int(channel_major), _stream()), "qkv_pool_bwd_weight")
+    out = reduce_partials(part, 3, chunks, 27 * D)
+    return out.view(3, D, 27) if channel_major else out.view(3, 27, D)
 
 
 def _iptr3(ts):

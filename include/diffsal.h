@@ -201,12 +201,13 @@ int diffsal_split_weight(const float* src, float* dst, long n, diffsal_stream_t 
  * dw[co, k] = sum_m dy[m, co] * A[m, k].  Replaces the wgrad of autograd's conv / linear backward.
  * ws: >= diffsal_conv_wgrad_ws_bytes(d) bytes (partial slabs, summed in a fixed order).  Cout % 4 == 0.
  * dbias_part (optional, may be NULL): [diffsal_conv_wgrad_splits(d)][Cout] doubles receiving the column sums of dy per
- * M split -- the bias gradient rides along on the dY tiles the kernel stages anyway; finish with
- * diffsal_reduce_partials(dbias_part, db, 1, splits, Cout, 0). */
+ * M split -- the bias gradient rides along on the dY tiles the kernel stages anyway.  dbias_out (optional, needs dbias_part):
+ * [Cout] floats, the finished bias gradient (split sums added in split order by the launch that sums the weight slabs, or
+ * written directly when there is one split); without it finish with diffsal_reduce_partials(dbias_part, db, 1, splits, Cout, 0). */
 size_t diffsal_conv_wgrad_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wgrad_splits(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wgrad(const diffsal_conv_desc* d /*host*/, const float* in, const float* dy, float* dw_packed,
-                       double* dbias_part, void* ws, size_t ws_bytes, diffsal_stream_t stream);
+                       double* dbias_part, float* dbias_out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 /* Batched form for token GEMMs: out[s][co][k] = sum over the seg_rows rows m of segment s of dy[m, co] * x[m, k]
  * (x: [segments*seg_rows, K], dy: [segments*seg_rows, Cout]).  Used by the attention backward (one segment per
  * image: dK = dS^T Q, dV = P^T dO; R/.../attention.py:97-108).  K % 32 == 0, Cout % 4 == 0. */
@@ -499,14 +500,18 @@ int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float* din, int 
  * spatial strides); bit-identical to three diffsal_pool3d_bwd_data calls. */
 int diffsal_qkv_pool(const void* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
                      const float* eps, float* const* out, int B, int heads, int D, int T, int H, int W, const int* stride_q,
-                     const int* stride_kv, int dtype /* storage type of qkv; outputs are fp32 */, diffsal_stream_t stream);
+                     const int* stride_kv, int dtype /* storage type of qkv; outputs are fp32 */,
+                     int w_channel_major /* 1: filters in the parameter's [96][27] layout, 0: tap-major [27][96] */,
+                     diffsal_stream_t stream);
 int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* const* w27, float* dqkv, int B, int heads, int D, int T,
-                              int H, int W, const int* stride_q, const int* stride_kv, diffsal_stream_t stream);
+                              int H, int W, const int* stride_q, const int* stride_kv, int w_channel_major,
+                              diffsal_stream_t stream);
 /* qkv_pool_bwd_weight: the three filter gradients in one launch: part[3][chunks][27*96] doubles (chunks =
  * diffsal_qkv_pool_bwd_weight_chunks()), finished by diffsal_reduce_partials(part, out, 3, chunks, 27*96, 0). */
 int diffsal_qkv_pool_bwd_weight_chunks(void);
 int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const* dy, double* part, int B, int heads, int D, int T, int H,
-                                int W, const int* stride_q, const int* stride_kv, diffsal_stream_t stream);
+                                int W, const int* stride_q, const int* stride_kv, int w_channel_major /* layout of each [27*96] row */,
+                                diffsal_stream_t stream);
 /* rel_tables: the three gathered relative-position tables of a block (resize_decomposed_rel_pos, mvit.py:330-361) as sparse
  * row maps built once per grid on the host: out_t[m] = w2_t[m][0] * rel_t[idx2_t[m][0]] + w2_t[m][1] * rel_t[idx2_t[m][1]],
  * m < M[t]; arrays of three (t, h, w).  rel_tables_bwd applies the transposed maps in CSR form (row starts [R[t] + 1],

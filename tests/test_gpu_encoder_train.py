@@ -77,15 +77,18 @@ def test_pool_maxpool_relpos_backward():
             refs.append(torch.cat([x[:, :, :1], t.reshape(B, heads, D, -1).transpose(2, 3)], 2))
         Gs = [rnd(f"tg{i}", *r.shape) for i, r in enumerate(refs)]
         sum((r * g).sum() for r, g in zip(refs, Gs)).backward()
-        qd = qkv.detach().to(DEV).requires_grad_(True)
-        wd = [w.detach().reshape(D, 27).t().contiguous().to(DEV).requires_grad_(True) for w in ws]
-        outs = eg.qkv_pool(qd, wd[0], wd[1], wd[2], size, strides[0], strides[1])
-        sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
-        for o, r in zip(outs, refs):
-            close(o, r, 2e-5, "pool fwd")
-        close(qd.grad, qkv.grad, 5e-5, "dqkv")
-        for i in range(3):
-            close(wd[i].grad, ws[i].grad.reshape(D, 27).t(), 5e-5, f"dw{i}")
+        for param_layout in (False, True):     # filters tap-major [27, D] (packed) or in the parameter's own [D, 27] layout
+            qd = qkv.detach().to(DEV).requires_grad_(True)
+            wd = [(w.detach().reshape(D, 27) if param_layout else w.detach().reshape(D, 27).t().contiguous()).to(DEV).requires_grad_(True)
+                  for w in ws]
+            outs = eg.qkv_pool(qd, wd[0], wd[1], wd[2], size, strides[0], strides[1])
+            sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
+            for o, r in zip(outs, refs):
+                close(o, r, 2e-5, "pool fwd")
+            close(qd.grad, qkv.grad, 5e-5, "dqkv")
+            for i in range(3):
+                ref_dw = ws[i].grad.reshape(D, 27)
+                close(wd[i].grad, ref_dw if param_layout else ref_dw.t(), 5e-5, f"dw{i}")
     # max-pool of the skip path
     C, size = 64, (2, 6, 9)
     x = rnd("mp", 2, 1 + size[0] * size[1] * size[2], C).requires_grad_(True)
