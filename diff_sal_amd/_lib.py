@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 SIGNATURES = {
@@ -58,6 +58,7 @@ SIGNATURES = {
     "diffsal_linear_pair": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wgrad_splits": (c_i, [C.POINTER(ConvDesc)]),
+    "diffsal_pack_weight_many": (c_i, [c_f, c_i, c_i, c_i, c_f]),
     "diffsal_conv_wgrad": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_colsum": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_sz, c_f]),
     "diffsal_act_bwd": (c_i, [c_f, c_f, c_f, c_sz, c_i, c_f]),

@@ -16,11 +16,10 @@
 namespace diffsal {
 namespace {
 
-__global__ __launch_bounds__(256) void pack_tile_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout,
-                                                        int Cin, int taps, int mode) {
-  extern __shared__ float tile[];            // [32][32 * taps + 1]
+__device__ __forceinline__ void pack_tile_body(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int taps,
+                                               int mode, int bx, int by, float* tile /* [32][32 * taps + 1] */) {
   const int row_len = 32 * taps, pitch = row_len + 1;
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int ci0 = bx * 32, co0 = by * 32;
   const int K = Cin * taps;
   const int f4_per_row = row_len >> 2;       // row_len % 4 == 0
   // ---- load: rows are indexed by co for every mode (source row = 32*taps contiguous floats)
@@ -29,7 +28,7 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const float* __restrict_
     const int co = co0 + r;
     float4 v = make_float4(0, 0, 0, 0);
     if (co < Cout) {
-      const long base = mode == 2 ? static_cast<long>(co) * K + static_cast<long>(blockIdx.x) * row_len
+      const long base = mode == 2 ? static_cast<long>(co) * K + static_cast<long>(bx) * row_len
                                   : (static_cast<long>(co) * Cin + ci0) * taps;
       v = ld4(src + base + j);
     }
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const float* __restrict_
       const int tap = j >> 5, c = j & 31;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = tile[r * pitch + (c + e) * taps + tap];
-      base = static_cast<long>(co0 + r) * K + static_cast<long>(blockIdx.x) * row_len;
+      base = static_cast<long>(co0 + r) * K + static_cast<long>(bx) * row_len;
     } else if (mode == 2) {   // row = co; element j = ci_l * taps + tap  <-  tile[r][tap * 32 + ci_l]
       if (co0 + r >= Cout) continue;
 #pragma unroll
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const float* __restrict_
       const int tp = j >> 5, c = j & 31;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = tile[(c + e) * pitch + r * taps + (taps - 1 - tp)];
-      base = static_cast<long>(ci0 + r) * (static_cast<long>(Cout) * taps) + static_cast<long>(blockIdx.y) * row_len;
+      base = static_cast<long>(ci0 + r) * (static_cast<long>(Cout) * taps) + static_cast<long>(by) * row_len;
     }
     st4(dst + base + j, make_float4(o[0], o[1], o[2], o[3]));
   }
@@ -76,6 +75,28 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const float* __restrict_
       st4(dst + (static_cast<long>(tap) * Cin + ci0 + cl) * Cout + co0 + j, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_tile_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout,
+                                                        int Cin, int taps, int mode) {
+  extern __shared__ float tile[];
+  pack_tile_body(src, dst, Cout, Cin, taps, mode, blockIdx.x, blockIdx.y, tile);
+}
+
+// Every weight repack of a training step in ONE launch (the optimizer rewrites all parameters between steps, so each layer's
+// forward, data-gradient and column layouts are rebuilt per step: ~165 launches of 6 us).  jobs: device table sorted by tile0;
+// a workgroup finds its job by bisection.
+__global__ __launch_bounds__(256) void pack_many_kernel(const diffsal_pack_job* __restrict__ jobs, int n_jobs) {
+  extern __shared__ float tile[];
+  const int t = blockIdx.x;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const diffsal_pack_job j = jobs[lo];
+  const int lt = t - j.tile0, tx = j.Cin / 32;
+  pack_tile_body(static_cast<const float*>(j.src), static_cast<float*>(j.dst), j.Cout, j.Cin, j.taps, j.mode, lt % tx, lt / tx, tile);
 }
 
 // dx[n, iy, ix, :] = cols[(n, oy, ox)][(ky, kx)][:] where (iy, ix) = (oy*s - pad + ky, ox*s - pad + kx) with ky < KH,
@@ -169,6 +190,17 @@ extern "C" int diffsal_pack_weight(const float* src, float* dst, int Cout, int C
   hipLaunchKernelGGL(pack_tile_kernel, dim3(Cin / 32, (Cout + 31) / 32), dim3(256), lds, static_cast<hipStream_t>(stream),
                      src, dst, Cout, Cin, taps, mode);
   return check_launch("pack_weight");
+}
+
+extern "C" int diffsal_pack_weight_many(const diffsal_pack_job* jobs_dev, int n_jobs, int total_tiles, int max_taps,
+                                        diffsal_stream_t stream) {
+  DS_REQUIRE(jobs_dev, DIFFSAL_E_ARG, "pack_weight_many: null job table");
+  DS_REQUIRE(n_jobs > 0 && total_tiles > 0 && max_taps > 0 && max_taps <= 25, DIFFSAL_E_SHAPE,
+             "pack_weight_many: n_jobs=%d total_tiles=%d max_taps=%d", n_jobs, total_tiles, max_taps);
+  const size_t lds = static_cast<size_t>(32) * (32 * max_taps + 1) * sizeof(float);
+  if (lds > 64 * 1024) DS_RAISE_DYNAMIC_LDS((pack_many_kernel), 128 * 1024);
+  hipLaunchKernelGGL(pack_many_kernel, dim3(total_tiles), dim3(256), lds, static_cast<hipStream_t>(stream), jobs_dev, n_jobs);
+  return check_launch("pack_weight_many");
 }
 
 extern "C" int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH,

@@ -183,16 +183,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 // 16 split groups: group g adds splits g, g+16, ... in order, then the 16 group sums are added in order.  (One thread per
 // column walking all splits serially left 9 workgroups with 256-512 dependent steps each on the small token GEMMs.)
 // Blocks past g_main (bias_out != NULL) finish the bias gradient that rode along: bias_out[c] = sum over the splits of the fp64
-// partial column sums, in split order -- no separate reduction launch per layer.
+// partial column sums (16 split groups, then the group sums in order) -- no separate reduction launch per layer.
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                        long n, int splits, int g_main, const double* __restrict__ bias_part,
                                                        float* __restrict__ bias_out, int Cout) {
-  if (static_cast<int>(blockIdx.x) >= g_main) {
-    const int c = (static_cast<int>(blockIdx.x) - g_main) * 256 + threadIdx.x;
-    if (blockIdx.y == 0 && c < Cout) {
-      double t = 0.0;
-      for (int z = 0; z < splits; ++z) t += bias_part[static_cast<long>(z) * Cout + c];
-      bias_out[c] = static_cast<float>(t);
+  if (static_cast<int>(blockIdx.x) >= g_main) {       // 16 columns x 16 split groups, the same fixed association as the slabs
+    __shared__ double shb[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = (static_cast<int>(blockIdx.x) - g_main) * 16 + cl;
+    double t = 0.0;
+    if (blockIdx.y == 0 && c < Cout)
+      for (int z = g; z < splits; z += 16) t += bias_part[static_cast<long>(z) * Cout + c];
+    shb[g][cl] = t;
+    __syncthreads();
+    if (g == 0 && blockIdx.y == 0 && c < Cout) {
+      double u = shb[0][cl];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) u += shb[q][cl];
+      bias_out[c] = static_cast<float>(u);
     }
     return;
   }
@@ -353,7 +361,7 @@ int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
   if (rc || pl.splits == 1) return rc;
   const long g = (n / 4 + 15) / 16;
   const bool bias = a.dbias && a.dbias_out && segments == 1;
-  const int extra = bias ? (a.Cout + 255) / 256 : 0;
+  const int extra = bias ? (a.Cout + 15) / 16 : 0;
   hipLaunchKernelGGL(slab_sum_kernel, dim3(static_cast<int>(g) + extra, segments), dim3(256), 0, s,
                      static_cast<const float*>(a.slabs), out, n, pl.splits, static_cast<int>(g), a.dbias, a.dbias_out, a.Cout);
   return check_launch("conv_wgrad(sum)");

@@ -277,6 +277,96 @@ def _pack(w4: Tensor, mode: int) -> Tensor:
     return out
 
 
+class _PackBatch:
+    """Weight repacks of a training step in one launch.  Inside ``with batched_packs():`` (DiffusionTrainStep wraps forward +
+    backward in it) a repack of an ``nn.Parameter`` is looked up by (storage address, shape, layout mode): a known entry returns
+    its persistent output buffer, which the ONE ``diffsal_pack_weight_many`` launch at the top of the context has just rebuilt
+    from the parameter's current values; an unknown one is packed directly and joins the table for the next step.  Only
+    Parameters are cached (their storage lives as long as the module; temporaries could reuse an address), entries whose
+    Parameter is gone or moved are dropped, and outside the context every call packs directly -- nothing stale can be read."""
+
+    def __init__(self):
+        self.entries = {}       # key -> [weakref(param), out, co, ci, taps, mode]
+        self.table = None       # device job table (uint8) of the current entry set
+        self.dirty = True
+        self.active = False
+        self.fresh = set()
+        self.tiles = 0
+        self.max_taps = 1
+
+    def refresh(self):
+        import weakref  # noqa: F401
+
+        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != k[0]]
+        for k in dead:
+            del self.entries[k]
+            self.dirty = True
+        self.fresh = set()
+        if not self.entries:
+            return
+        if self.dirty or self.table is None:
+            import numpy as np
+
+            dt = np.dtype([("src", "u8"), ("dst", "u8"), ("Cout", "i4"), ("Cin", "i4"), ("taps", "i4"), ("mode", "i4"),
+                           ("tile0", "i4"), ("reserved", "i4")])
+            jobs = np.zeros(len(self.entries), dtype=dt)
+            t0, mt, dev = 0, 1, None
+            for i, (k, e) in enumerate(self.entries.items()):
+                _, out, co, ci, taps, mode = e
+                jobs[i] = (k[0], out.data_ptr(), co, ci, taps, mode, t0, 0)
+                t0 += (ci // 32) * ((co + 31) // 32)
+                mt = max(mt, taps)
+                dev = out.device
+            self.table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+            self.tiles, self.max_taps, self.dirty = t0, mt, False
+        with _prof("pack"):
+            _lib.check(_lib.load().diffsal_pack_weight_many(self.table.data_ptr(), len(self.entries), self.tiles, self.max_taps,
+                                                            _stream()), "pack_weight_many")
+        self.fresh = set(self.entries)
+
+    def get(self, w, w4: Tensor, mode: int):
+        """Packed form of Parameter ``w`` (``w4`` = its contiguous [Cout, Cin, kh, kw] view) in layout ``mode``, or None when the
+        cache does not apply (the caller packs directly)."""
+        import weakref
+
+        if not self.active or not isinstance(w, torch.nn.Parameter) or not w4.is_contiguous() or w4.data_ptr() != w.data_ptr():
+            return None
+        co, ci, kh, kw = w4.shape
+        if ci % 32 or ((mode == 1 or mode == 3) and co % 32) or kh * kw > 25:
+            return None
+        key = (w.data_ptr(), (co, ci, kh, kw), mode)
+        e = self.entries.get(key)
+        if e is not None and key in self.fresh:
+            return e[1]
+        out = _pack(w4, mode)                              # first sight (or registered after this step's refresh): direct
+        if e is None:
+            self.entries[key] = [weakref.ref(w), out, co, ci, kh * kw, mode]
+            self.dirty = True
+        else:
+            e[1] = out
+            self.dirty = True
+        return out
+
+
+_PACKS = _PackBatch()
+
+
+@contextlib.contextmanager
+def batched_packs():
+    """One launch for the weight repacks of the parameters seen in earlier uses of this context (see ``_PackBatch``)."""
+    pb = _PACKS
+    if pb.active:
+        yield
+        return
+    pb.active = True
+    try:
+        pb.refresh()
+        yield
+    finally:
+        pb.active = False
+        pb.fresh = set()
+
+
 def pack_conv_weight(w: Tensor) -> Tensor:
     """[Cout, Cin, KH, KW] (or Conv3d [Cout, Cin, KT, 1, 1]) -> [Cout, K] in the kernel's k order
     (ci // 32, tap, ci % 32); see include/diffsal.h."""
@@ -311,12 +401,16 @@ def split_weight(w_packed: Tensor) -> Tensor:
 
 def pack_dgrad_weight(w: Tensor) -> Tensor:
     """Packed weight of the data-gradient convolution: [Cin, KH*KW*Cout], taps flipped (include/diffsal.h, mode 1)."""
-    return _pack(_as_conv4(w.detach()), 1)
+    w4 = _as_conv4(w.detach())
+    hit = _PACKS.get(w, w4, 1)
+    return hit if hit is not None else _pack(w4, 1)
 
 
 def pack_cols_weight(w: Tensor) -> Tensor:
     """[KH*KW*Cin, Cout]: weight of the GEMM dXcols = dY W for non-overlapping convolutions (mode 3)."""
-    return _pack(_as_conv4(w.detach()), 3)
+    w4 = _as_conv4(w.detach())
+    hit = _PACKS.get(w, w4, 3)
+    return hit if hit is not None else _pack(w4, 3)
 
 
 @_classed("col2im")
@@ -344,9 +438,9 @@ def col2im_gather(cols: Tensor, in_shape, out_hw, kh: int, kw: int, stride, pad)
 
 class _PackWeightFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w):
+    def forward(ctx, w, ready):
         ctx.shape = tuple(w.shape)
-        return _pack(_as_conv4(w), 0)
+        return ready.detach() if ready is not None else _pack(_as_conv4(w), 0)     # (a fresh tensor object over the batch's buffer)
 
     @staticmethod
     def backward(ctx, dwp):
@@ -358,13 +452,13 @@ class _PackWeightFn(torch.autograd.Function):
             taps *= s_
         dw = torch.empty(shape, device=dwp.device, dtype=torch.float32)
         _lib.check(lib.diffsal_pack_weight(_p(dwp.contiguous()), _p(dw), co, ci, taps, 2, _stream()), "pack_weight")
-        return dw
+        return dw, None
 
 
 def pack_conv_weight_diff(w: Tensor) -> Tensor:
     """pack_conv_weight that stays on the autograd tape: dW (packed, from conv_wgrad) flows back to ``w`` in the
     parameter layout."""
-    return _PackWeightFn.apply(w)
+    return _PackWeightFn.apply(w, _PACKS.get(w, _as_conv4(w.detach()), 0))
 
 
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),

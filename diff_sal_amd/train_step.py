@@ -255,9 +255,12 @@ class DiffusionTrainStep:
             self._sync_buffers()
         self.flat.zero_grad()
         self.reducer.arm()
-        pred = self._forward(x_t, t, cond)
-        loss = ag.mse_loss(pred, x0, self.mse_weight / x0.shape[0])
-        loss.backward()
+        from . import ops
+
+        with ops.batched_packs():        # every parameter's kernel layouts (forward, data-gradient) rebuilt by one launch
+            pred = self._forward(x_t, t, cond)
+            loss = ag.mse_loss(pred, x0, self.mse_weight / x0.shape[0])
+            loss.backward()
         self.reducer.finish()
         return loss.detach()
 

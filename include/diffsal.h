@@ -193,6 +193,17 @@ int diffsal_col2im_disjoint(const float* cols, float* dx, int N, int H, int W, i
 int diffsal_col2im_gather(const float* cols, float* dx, int N, int H, int W, int C, int Ho, int Wo, int KH, int KW,
                           int stride_h, int stride_w, int pad_t, int pad_l, diffsal_stream_t stream);
 int diffsal_pack_weight(const float* src, float* dst, int Cout, int Cin, int taps, int mode, diffsal_stream_t stream);
+/* Many repacks in one launch (training: every layer's layouts are rebuilt after each optimizer step).  jobs_dev: DEVICE array of
+ * n_jobs entries sorted by tile0, tile0 = running sum of (Cin / 32) * ceil(Cout / 32); total_tiles = that sum over all jobs;
+ * max_taps = largest taps of the batch.  Each job obeys diffsal_pack_weight's shape rules. */
+typedef struct diffsal_pack_job {
+  const void* src;
+  void* dst;
+  int Cout, Cin, taps, mode;
+  int tile0, reserved;
+} diffsal_pack_job;
+int diffsal_pack_weight_many(const diffsal_pack_job* jobs_dev /*device*/, int n_jobs, int total_tiles, int max_taps,
+                             diffsal_stream_t stream);
 /* bf16x3 mode: split a packed fp32 weight [rows][K] (K % 32 == 0) into the w_format = 1 layout of diffsal_conv_desc
  * (hi = bf16(x), lo = bf16(x - hi)); n = rows * K.  Saves the kernel the conversion of its B operand. */
 int diffsal_split_weight(const float* src, float* dst, long n, diffsal_stream_t stream);
