@@ -49,6 +49,12 @@ struct AttnArgs {
   int H, Lq, Lk;
   float scale;
   int skip_first;
+  // tail mode (as in the dq kernel of the backward): blocks [0, qb_full) of the (query tile, batch*head) list run whole; each
+  // later block is cut into qb_split pieces over the key tiles, which leave their normalised partial output and its
+  // log-sum-exp in the slabs; attention_fwd_tail_kernel merges them (softmax of the pieces' log-sum-exps)
+  int qb_x, qb_full, qb_split, qb_bh;
+  float* o_slabs;        // [qb_split][B][Lq][H*DV]
+  float* l_slabs;        // [qb_split][B*H][Lq]
 };
 
 template <int D, int E, int DV>
@@ -63,8 +69,14 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) float Vs[32 * VP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int blk = blockIdx.x, piece = -1;
+  if (blk >= p.qb_full) {
+    const int t = blk - p.qb_full;
+    blk = p.qb_full + t / p.qb_split;
+    piece = t - (blk - p.qb_full) * p.qb_split;
+  }
+  const int bh = blk / p.qb_x, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (blk - bh * p.qb_x) * 128 + wave * 32;
   const int ql = lane & 31, hf = lane >> 5;
   const int qi = q0 + ql;
   const int qc = qi < p.Lq ? qi : p.Lq - 1;   // clamped: lanes past the end compute garbage that is never stored
@@ -99,7 +111,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
 
   const float* kb = p.k + b * p.k_sb + h * p.k_sh;
   const float* vb = p.v + b * p.v_sb + h * p.v_sh;
-  const int n_tiles = (p.Lk + 31) / 32;
+  const int all_tiles = (p.Lk + 31) / 32;
+  const int per_piece = (all_tiles + p.qb_split - 1) / p.qb_split;
+  const int t_begin = piece < 0 ? 0 : piece * per_piece;
+  const int n_tiles = piece < 0 ? all_tiles : min(all_tiles, t_begin + per_piece);      // one past the last key tile of this block / piece
   constexpr int KF4 = 32 * DQ / 4, VF4 = 32 * DV / 4;          // float4 pieces per tile
   constexpr int KPT = (KF4 + 255) / 256, VPT = (VF4 + 255) / 256;
   float4 kreg[KPT], vreg[VPT];
@@ -140,10 +155,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
     }
   };
 
-  fetch(0);
-  park(0);
+  fetch(t_begin);
+  park(t_begin);
   __syncthreads();
-  for (int tile = 0; tile < n_tiles; ++tile) {
+  for (int tile = t_begin; tile < n_tiles; ++tile) {
     if (tile + 1 < n_tiles) fetch(tile + 1);   // lands while this tile is computed
     // ---- S^T = K Q^T : A = K[key = lane & 31][hf*HQ + j] (LDS), B = qf[j]
     f32x16 s;
@@ -195,6 +210,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
   // ---- finish: out[q][d] = O^T[d][q] / l (+ residual); this lane holds d = 32 t + 4 hf + (r & 3) + 8 (r >> 2)
   const float l_tot = l_run + lane_xor32(l_run);
   const float inv = 1.0f / l_tot;
+  if (piece >= 0) {                  // tail mode: this piece's normalised output and log-sum-exp, merged by attention_fwd_tail_kernel
+    if (qi < p.Lq) {
+      if (hf == 0) p.l_slabs[(static_cast<long>(piece) * p.qb_bh + bh) * p.Lq + qi] = m_run + logf(l_tot);
+      float* orow = p.o_slabs + ((static_cast<long>(piece) * (p.qb_bh / p.H) + b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          st4(orow + 32 * t + 4 * hf + 8 * g,
+              make_float4(o[t][4 * g + 0] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv));
+    }
+    return;
+  }
   if (p.lse && qi < p.Lq && hf == 0) p.lse[static_cast<long>(bh) * p.Lq + qi] = m_run + logf(l_tot);
   if (qi < p.Lq) {
     float* orow = p.out + (static_cast<long>(b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV;
@@ -212,6 +240,44 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
         }
         st4(orow + d, v4);
       }
+  }
+}
+
+// tail mode of the forward: rows of the blocks >= qb_full: out = sum_i w_i O_i (+ residual), w = softmax over the pieces'
+// log-sum-exps; lse = log sum_i exp(lse_i).  One thread per (row, 4 channels).
+template <int DV>
+__global__ __launch_bounds__(256) void attention_fwd_tail_kernel(AttnArgs p, int n_tail_blocks) {
+  constexpr int C4 = DV / 4;
+  const long items = static_cast<long>(n_tail_blocks) * 128 * C4;
+  const long l_slab = static_cast<long>(p.qb_bh) * p.Lq;
+  const long o_slab = l_slab * DV;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < items; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % C4) * 4;
+    const long r = i / C4;
+    const int blk = p.qb_full + static_cast<int>(r >> 7);
+    const int bh = blk / p.qb_x, b = bh / p.H, h = bh - b * p.H;
+    const int qi = (blk - bh * p.qb_x) * 128 + static_cast<int>(r & 127);
+    if (qi >= p.Lq) continue;
+    const long lrow = static_cast<long>(bh) * p.Lq + qi;
+    const long orow = (static_cast<long>(b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV + c;
+    float m = -3.0e38f;
+    for (int s = 0; s < p.qb_split; ++s) m = fmaxf(m, p.l_slabs[s * l_slab + lrow]);
+    float den = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.qb_split; ++s) {
+      const float w = __expf(p.l_slabs[s * l_slab + lrow] - m);
+      const float4 u = ld4(p.o_slabs + s * o_slab + orow);
+      den += w;
+      acc.x += w * u.x; acc.y += w * u.y; acc.z += w * u.z; acc.w += w * u.w;
+    }
+    const float inv = 1.0f / den;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    if (p.residual && !(p.skip_first && qi == 0)) {
+      const float4 r4 = ld4(p.residual + b * p.r_sb + h * p.r_sh + static_cast<long>(qi) * p.r_sl + c);
+      acc.x += r4.x; acc.y += r4.y; acc.z += r4.z; acc.w += r4.w;
+    }
+    st4(p.out + orow, acc);
+    if (p.lse && c == 0) p.lse[lrow] = m + logf(den);
   }
 }
 
@@ -238,6 +304,11 @@ struct AttnBwdArgs {
   float* dv;             // [B,H,Lk,DV] contiguous
   float* kv_part;        // [q_splits][B*H*Lk*(D+DV)] partial dk | dv when q_splits > 1 (summed by attention_bwd_kv_sum_kernel)
   int q_splits;          // the kv kernel's query range is cut into this many pieces (few keys, many queries: MViT's early layers)
+  // dq kernel, tail mode: blocks [0, qb_full) of the (query tile, batch*head) list run whole; each later block is cut into
+  // qb_split pieces over the key tiles, which write their partial dq | dq_extra rows to q_slabs (attention_bwd_q_tail_kernel
+  // adds them up): the last, partly filled round of workgroups (one per CU) fills the chip instead of a third of it.
+  int qb_x, qb_full, qb_split, qb_bh;
+  float* q_slabs;        // [qb_split][B*H*Lq][D + E]
   long q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, r_sb, r_sh, r_sl;
   int H, Lq, Lk;
   float scale;
@@ -269,6 +340,40 @@ __global__ __launch_bounds__(256) void attention_bwd_delta_kernel(AttnBwdArgs p,
   if (live && gl == 0) p.delta[rc] = s;
 }
 
+// batch * heads of a launch (stored with the dq tail plan)
+__device__ __forceinline__ int gridDimBH(const AttnBwdArgs& p) { return p.qb_bh; }
+
+// tail mode of the dq kernel: rows of the blocks >= qb_full: dq | dq_extra = sum of the pieces' partial rows (+ the residual path)
+template <int D, int E, int DV>
+__global__ __launch_bounds__(256) void attention_bwd_q_tail_kernel(AttnBwdArgs p, int n_tail_blocks) {
+  constexpr int DQ = D + E, C4 = DQ / 4;
+  const long items = static_cast<long>(n_tail_blocks) * 128 * C4;
+  const long slab = static_cast<long>(p.qb_bh) * p.Lq * DQ;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < items; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % C4) * 4;
+    const long r = i / C4;
+    const int blk = p.qb_full + static_cast<int>(r >> 7);
+    const int bh = blk / p.qb_x, b = bh / p.H, h = bh - b * p.H;
+    const int qi = (blk - bh * p.qb_x) * 128 + static_cast<int>(r & 127);
+    if (qi >= p.Lq) continue;
+    const long row = static_cast<long>(bh) * p.Lq + qi;
+    float4 v = ld4(p.q_slabs + row * DQ + c);
+    for (int s = 1; s < p.qb_split; ++s) {
+      const float4 u = ld4(p.q_slabs + s * slab + row * DQ + c);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (c < D) {
+      if (p.residual && !(p.skip_first && qi == 0)) {
+        const float4 r4 = ld4(p.dout + (static_cast<long>(b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV + c);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      }
+      st4(p.dq + row * D + c, v);
+    } else {
+      st4(p.dq_extra + row * E + (c - D), v);
+    }
+  }
+}
+
 template <int D, int E, int DV>
 __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
   constexpr int DQ = D + E;
@@ -279,9 +384,15 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
   __shared__ __attribute__((aligned(16))) float Vs[32 * VP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  int blk = blockIdx.x, piece = -1;
+  if (blk >= p.qb_full) {
+    const int t = blk - p.qb_full;
+    blk = p.qb_full + t / p.qb_split;
+    piece = t - (blk - p.qb_full) * p.qb_split;
+  }
+  const int bh = blk / p.qb_x, b = bh / p.H, h = bh - b * p.H;
   const int ql = lane & 31, hf = lane >> 5;
-  const int qi = blockIdx.x * 128 + wave * 32 + ql;
+  const int qi = (blk - bh * p.qb_x) * 128 + wave * 32 + ql;
   const int qc = qi < p.Lq ? qi : p.Lq - 1;
 
   float qf[HQ], gf[HV];   // this lane's halves of [q*scale | q_extra] and of dO
@@ -320,7 +431,10 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
 
   const float* kb = p.k + b * p.k_sb + h * p.k_sh;
   const float* vb = p.v + b * p.v_sb + h * p.v_sh;
-  const int n_tiles = (p.Lk + 31) / 32;
+  const int all_tiles = (p.Lk + 31) / 32;
+  const int per_piece = (all_tiles + p.qb_split - 1) / p.qb_split;
+  const int t_begin = piece < 0 ? 0 : piece * per_piece;
+  const int n_tiles = piece < 0 ? all_tiles : min(all_tiles, t_begin + per_piece);      // one past the last key tile of this block / piece
   constexpr int KC4 = NQT * 8;                                   // float4 pieces per padded K' row
   constexpr int KF4 = 32 * KC4, VF4 = 32 * DV / 4;
   constexpr int KPT = (KF4 + 255) / 256, VPT = (VF4 + 255) / 256;
@@ -361,10 +475,10 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
       if (idx < VF4) st4(&Vs[row * VP + c4], keep_or_zero(vreg[i], key0 + row < p.Lk));
     }
   };
-  fetch(0);
-  park(0);
+  fetch(t_begin);
+  park(t_begin);
   __syncthreads();
-  for (int tile = 0; tile < n_tiles; ++tile) {
+  for (int tile = t_begin; tile < n_tiles; ++tile) {
     if (tile + 1 < n_tiles) fetch(tile + 1);
     f32x16 s, dp;
 #pragma unroll
@@ -396,6 +510,19 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
     }
   }
   if (qi >= p.Lq) return;
+  if (piece >= 0) {       // partial sums of a tail piece: scaled, no residual (the tail kernel adds it once)
+    float* sl = p.q_slabs + ((static_cast<long>(piece) * gridDimBH(p) + bh) * p.Lq + qi) * DQ;
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 32 * t + 4 * hf + 8 * g;
+        if (c >= DQ) continue;
+        const float sc = c < D ? p.scale : 1.0f;
+        st4(sl + c, make_float4(acc[t][4 * g + 0] * sc, acc[t][4 * g + 1] * sc, acc[t][4 * g + 2] * sc, acc[t][4 * g + 3] * sc));
+      }
+    return;
+  }
   // this lane holds contraction rows c = 32 t + 4 hf + (r & 3) + 8 (r >> 2) of its query
   float* dqr = p.dq + (static_cast<long>(bh) * p.Lq + qi) * D;
   float* der = E ? p.dq_extra + (static_cast<long>(bh) * p.Lq + qi) * E : nullptr;
@@ -606,9 +733,22 @@ static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
   hipLaunchKernelGGL((attention_bwd_delta_kernel<DV>), dim3(static_cast<unsigned>((rows + 31) / 32)), dim3(256), 0, s, a, rows);
   int rc = check_launch("attention_general_bwd(delta)");
   if (rc) return rc;
-  hipLaunchKernelGGL((attention_bwd_q_kernel<D, E, DV>), dim3((a.Lq + 127) / 128, B * a.H), dim3(256), 0, s, a);
-  rc = check_launch("attention_general_bwd(dq)");
-  if (rc) return rc;
+  {
+    const int total = a.qb_x * a.qb_bh;
+    const int grid = a.qb_full + (total - a.qb_full) * a.qb_split;
+    hipLaunchKernelGGL((attention_bwd_q_kernel<D, E, DV>), dim3(grid), dim3(256), 0, s, a);
+    rc = check_launch("attention_general_bwd(dq)");
+    if (rc) return rc;
+    if (a.qb_split > 1) {
+      const int n_tail = total - a.qb_full;
+      const long items = static_cast<long>(n_tail) * 128 * ((D + E) / 4);
+      long g = (items + 255) / 256;
+      g = g > 2048 ? 2048 : g;
+      hipLaunchKernelGGL((attention_bwd_q_tail_kernel<D, E, DV>), dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a, n_tail);
+      rc = check_launch("attention_general_bwd(dq tail)");
+      if (rc) return rc;
+    }
+  }
   hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV>), dim3((a.Lk + 127) / 128, B * a.H, a.q_splits), dim3(256), 0, s, a);
   rc = check_launch("attention_general_bwd(dk, dv)");
   if (rc || a.q_splits == 1) return rc;
@@ -624,11 +764,34 @@ static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
 
 using namespace diffsal;
 
+// Tail mode plan of the forward and the dq kernel: pieces per tail block (1 = off) and the first tail block.  On: more than one round of workgroups
+// (one per CU) whose last round fills at most half of the chip, and enough key tiles to cut.
+static void attention_tail_plan(int BH, int Lq, int Lk, int* qb_x, int* qb_full, int* qb_split) {
+  const int gx = (Lq + 127) / 128, total = gx * BH, n_tiles = (Lk + 31) / 32;
+  *qb_x = gx; *qb_full = total; *qb_split = 1;
+  if (total <= 256) return;
+  const int full = (total / 256) * 256, rest = total - full;
+  if (rest == 0 || rest > 128) return;
+  int sp = 256 / rest;
+  while (sp > 1 && n_tiles / sp < 4) --sp;
+  if (sp < 2) return;
+  *qb_full = full; *qb_split = sp;
+}
+
+
+// floats of scratch for the forward's tail mode (0: not used for this shape): the pieces' outputs and log-sum-exps
+extern "C" size_t diffsal_attention_general_tail_floats(int B, int H, int Lq, int Lk, int DV) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  int gx, full, sp;
+  attention_tail_plan(B * H, Lq, Lk, &gx, &full, &sp);
+  return sp > 1 ? static_cast<size_t>(sp) * B * H * Lq * (DV + 1) : 0;
+}
+
 extern "C" int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra,
                                          const float* v, const float* residual, float* out, float* lse, int B, int H, int Lq, int Lk,
                                          int D, int E, int DV, const long* q_strides, const long* k_strides,
                                          const long* v_strides, const long* r_strides, float scale, int skip_first,
-                                         diffsal_stream_t stream) {
+                                         float* tail_ws, diffsal_stream_t stream) {
   DS_REQUIRE(q && k && v && out && q_strides && k_strides && v_strides, DIFFSAL_E_ARG, "attention_general: null argument");
   DS_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && static_cast<long>(B) * H < 65536, DIFFSAL_E_SHAPE,
              "attention_general: bad shape B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
@@ -648,7 +811,13 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
   a.r_sb = residual ? r_strides[0] : 0; a.r_sh = residual ? r_strides[1] : 0; a.r_sl = residual ? r_strides[2] : 0;
   a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.skip_first = skip_first;
-  const dim3 grid((Lq + 127) / 128, B * H);
+  a.qb_bh = B * H;
+  attention_tail_plan(B * H, Lq, Lk, &a.qb_x, &a.qb_full, &a.qb_split);
+  if (!tail_ws || !aligned16(tail_ws)) { a.qb_full = a.qb_x * a.qb_bh; a.qb_split = 1; }     // no scratch: every block whole
+  a.o_slabs = tail_ws;
+  a.l_slabs = tail_ws ? tail_ws + static_cast<long>(a.qb_split) * B * H * Lq * DV : nullptr;
+  const int total = a.qb_x * a.qb_bh, n_tail = total - a.qb_full;
+  const dim3 grid(static_cast<unsigned>(a.qb_full + n_tail * a.qb_split));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (D == 96 && E == 48 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 48, 96>), grid, dim3(256), 0, s, a);
   else if (D == 96 && E == 32 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 32, 96>), grid, dim3(256), 0, s, a);
@@ -659,7 +828,14 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
     set_error("attention_general: (D, E, DV) = (%d, %d, %d) is not built: (96,48,96), (96,32,96), (96,0,96), (64,0,64), (32,0,32)", D, E, DV);
     return DIFFSAL_E_SHAPE;
   }
-  return check_launch("attention_general");
+  int rc = check_launch("attention_general");
+  if (rc || n_tail == 0) return rc;
+  long g = (static_cast<long>(n_tail) * 128 * (DV / 4) + 255) / 256;
+  g = g > 2048 ? 2048 : g;
+  if (DV == 96) hipLaunchKernelGGL(attention_fwd_tail_kernel<96>, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a, n_tail);
+  else if (DV == 64) hipLaunchKernelGGL(attention_fwd_tail_kernel<64>, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a, n_tail);
+  else hipLaunchKernelGGL(attention_fwd_tail_kernel<32>, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a, n_tail);
+  return check_launch("attention_general(tail)");
 }
 
 // Query splits of the dk / dv kernel: enough workgroups to fill the chip when there are few keys (Lk = 673 at B*H = 4 is
@@ -673,9 +849,18 @@ extern "C" int diffsal_attention_general_bwd_splits(int B, int H, int Lq, int Lk
   return static_cast<int>(s < 1 ? 1 : s);
 }
 
+// floats of scratch for the dq kernel's tail mode (0: not used for this shape)
+extern "C" size_t diffsal_attention_general_bwd_qtail_floats(int B, int H, int Lq, int Lk, int D, int E) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  int gx, full, sp;
+  attention_tail_plan(B * H, Lq, Lk, &gx, &full, &sp);
+  return sp > 1 ? static_cast<size_t>(sp) * B * H * Lq * (D + E) : 0;
+}
+
 extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra,
                                              const float* v, const float* residual, const float* out, const float* lse,
-                                             const float* dout, float* delta_ws, float* kv_part_ws, float* dq, float* dq_extra,
+                                             const float* dout, float* delta_ws, float* kv_part_ws, float* q_tail_ws, float* dq,
+                                             float* dq_extra,
                                              float* dk, float* dv, int B, int H, int Lq, int Lk, int D, int E, int DV,
                                              const long* q_strides, const long* k_strides, const long* v_strides,
                                              const long* r_strides, float scale, int skip_first, diffsal_stream_t stream) {
@@ -696,6 +881,10 @@ extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extr
   a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.skip_first = skip_first;
   a.q_splits = diffsal_attention_general_bwd_splits(B, H, Lq, Lk);
   a.kv_part = kv_part_ws;
+  a.qb_bh = B * H;
+  attention_tail_plan(B * H, Lq, Lk, &a.qb_x, &a.qb_full, &a.qb_split);
+  if (!q_tail_ws || !aligned16(q_tail_ws)) { a.qb_full = a.qb_x * a.qb_bh; a.qb_split = 1; }     // no scratch: every block whole
+  a.q_slabs = q_tail_ws;
   DS_REQUIRE(a.q_splits == 1 || (kv_part_ws && aligned16(kv_part_ws)), DIFFSAL_E_ARG,
              "attention_general_bwd: %d query splits need kv_part_ws of splits * B*H*Lk*(D+DV) floats", a.q_splits);
   DS_REQUIRE((static_cast<long>(B) * H * Lk * D) % 4 == 0, DIFFSAL_E_SHAPE, "attention_general_bwd: dk size");

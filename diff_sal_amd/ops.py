@@ -1246,12 +1246,15 @@ def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra:
     E = 0 if q_extra is None else q_extra.shape[-1]
     out = torch.empty((B, Lq, H * DV), device=q.device, dtype=torch.float32)
     lse = torch.empty((B, H, Lq), device=q.device, dtype=torch.float32) if want_lse else None
+    nt = lib.diffsal_attention_general_tail_floats(B, H, Lq, Lk, DV)      # pieces of the last, partly filled round of workgroups
+    tail = torch.empty((nt,), device=q.device, dtype=torch.float32) if nt else None
     flops = 2.0 * B * H * Lq * Lk * (D + E + DV)
     with _prof("attn", flops, _nb(q, k, v, out)):
         _lib.check(lib.diffsal_attention_general(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
             _p(out), _p(lse), B, H, Lq, Lk, D, E, DV, _bhl_strides(q), _bhl_strides(k), _bhl_strides(v),
-            None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _stream()), "attention_general")
+            None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _p(tail), _stream()),
+            "attention_general")
     return (out, lse) if want_lse else out
 
 
@@ -1269,11 +1272,14 @@ def attention_general_bwd(q, k, v, out, lse, dout, *, scale: float, q_extra=None
     delta = torch.empty((B, H, Lq), device=dev)
     splits = lib.diffsal_attention_general_bwd_splits(B, H, Lq, Lk)
     kv_part = torch.empty((splits, B * H * Lk * (D + DV)), device=dev) if splits > 1 else None
+    nq = lib.diffsal_attention_general_bwd_qtail_floats(B, H, Lq, Lk, D, E)      # dq kernel: pieces of its last partial round
+    q_tail = torch.empty((nq,), device=dev) if nq else None
     flops = 2.0 * B * H * Lq * Lk * (2 * (D + E) + 2 * DV + D + E + DV)
     with _prof("attn-bwd", flops, _nb(q, k, v, out, dout, dq, dk, dv)):
         _lib.check(lib.diffsal_attention_general_bwd(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
-            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk, D, E, DV,
+            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(q_tail), _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk,
+            D, E, DV,
             _bhl_strides(q), _bhl_strides(k), _bhl_strides(v), None if residual is None else _bhl_strides(residual),
             float(scale), int(skip_first), _stream()), "attention_general_bwd")
     return dq, dqe, dk, dv

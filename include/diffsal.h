@@ -443,21 +443,29 @@ int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long 
  * q / k / v / residual are addressed through (batch, head, row) element strides, so slices of a fused qkv GEMM output
  * are read in place; q_extra [B,H,Lq,E] and k_extra [Lk,E] are contiguous and carry an additive attention bias as E
  * extra contraction columns (MViT: E = 48 or 32, see diffsal_relpos_project; otherwise E = 0 and both are NULL).
- * Built (D, E, DV): (96,48,96), (96,0,96), (64,0,64), (32,0,32).  Replaces
+ * Built (D, E, DV): (96,48,96), (96,32,96), (96,0,96), (64,0,64), (32,0,32).  Replaces
  *   R/models/mvit.py:587-605 (MultiScaleAttention: attn = (q*scale) k^T, add_decomposed_rel_pos, softmax, attn v, + q),
  *   R/models/audio_attention.py:50-58 (dots, softmax, out). */
 int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
                               const float* residual, float* out, float* lse /*[B,H,Lq] row log-sum-exp, or NULL*/, int B,
                               int H, int Lq, int Lk, int D, int E, int DV, const long* q_strides /*host [3]*/,
                               const long* k_strides, const long* v_strides, const long* r_strides, float scale,
-                              int skip_first, diffsal_stream_t stream);
+                              int skip_first, float* tail_ws, diffsal_stream_t stream);
+/* tail_ws (optional): diffsal_attention_general_tail_floats(...) floats.  With it the blocks of the last, partly filled
+ * round of workgroups are cut into pieces over the keys and a finishing launch merges the pieces' outputs by their
+ * log-sum-exps; without it (NULL, or the function returned 0) every block runs whole. */
+size_t diffsal_attention_general_tail_floats(int B, int H, int Lq, int Lk, int DV);
 /* Backward (training of the encoders): P is recomputed from `lse`; delta_ws [B,H,Lq] is scratch.  Outputs are contiguous
  * head-major tensors: dq [B,H,Lq,D] (includes the residual path's dO when `residual` was given), dq_extra [B,H,Lq,E]
  * (NULL iff E == 0), dk [B,H,Lk,D], dv [B,H,Lk,DV]; k_extra is a constant table and gets no gradient.  No atomics. */
 int diffsal_attention_general_bwd_splits(int B, int H, int Lq, int Lk); /* S; kv_part_ws needs S*B*H*Lk*(D+DV) floats if S > 1 */
+/* q_tail_ws (optional): diffsal_attention_general_bwd_qtail_floats(...) floats.  With it the dq kernel cuts the blocks of its
+ * last, partly filled round of workgroups into pieces over the keys and a finishing launch adds their partial rows (fixed
+ * order); without it (NULL, or the function returned 0) every block runs whole. */
+size_t diffsal_attention_general_bwd_qtail_floats(int B, int H, int Lq, int Lk, int D, int E);
 int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
                                   const float* residual, const float* out, const float* lse, const float* dout,
-                                  float* delta_ws, float* kv_part_ws, float* dq, float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
+                                  float* delta_ws, float* kv_part_ws, float* q_tail_ws, float* dq, float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
                                   int Lk, int D, int E, int DV, const long* q_strides, const long* k_strides,
                                   const long* v_strides, const long* r_strides, float scale, int skip_first,
                                   diffsal_stream_t stream);

@@ -26,7 +26,8 @@ def close(got, ref, tol, what=""):
 
 
 @pytest.mark.parametrize("shape", [(2, 2, 150, 70, 64, 0), (1, 2, 1 + 2 * 6 * 10, 1 + 2 * 3 * 5, 96, 48), (1, 2, 1 + 2 * 6 * 10, 1 + 2 * 3 * 5, 96, 32),
-                                   (1, 1, 40, 129, 96, 0)])
+                                   (1, 1, 40, 129, 96, 0),
+                                   (1, 16, 2689, 673, 96, 32)])      # MViT stage 3 at 4 clips: 352 dq blocks = 256 whole + 96 cut in two (tail mode)
 def test_attention_general_backward(shape):
     """dq (incl. the residual path), dq_extra, dk, dv of the flash-attention backward vs autograd of the dense formula."""
     from diff_sal_amd import encoder_autograd as eg

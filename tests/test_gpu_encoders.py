@@ -32,6 +32,22 @@ def ops():
     return o
 
 
+def test_attention_general_tail_mode(ops):
+    """352 workgroups (MViT stage 3 at batch 4): the 96 blocks past the first round run as two key-range pieces each and a
+    finishing launch merges them by their log-sum-exps; output (with the residual) and the row log-sum-exp must not change."""
+    B, H, Lq, Lk, D = 1, 16, 2689, 673, 96
+    from diff_sal_amd import _lib
+    assert _lib.load().diffsal_attention_general_tail_floats(B, H, Lq, Lk, D) == 2 * B * H * Lq * (D + 1)
+    q, k, v = rnd("tq", B, H, Lq, D), rnd("tk", B, H, Lk, D), rnd("tv", B, H, Lk, D)
+    s = (q * D ** -0.5) @ k.transpose(-1, -2)
+    o = torch.softmax(s, -1) @ v
+    o[:, :, 1:] += q[:, :, 1:]
+    qd = q.to(DEV)
+    got, lse = ops.attention_general(qd, k.to(DEV), v.to(DEV), scale=D ** -0.5, residual=qd, skip_first=True, want_lse=True)
+    assert rel_err(got, o.transpose(1, 2).reshape(B, Lq, H * D)) < 2e-5
+    assert (lse.cpu() - torch.logsumexp(s, -1)).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 300, 75, 64), (1, 1, 129, 673, 96), (2, 4, 33, 32, 96), (1, 2, 1, 5, 32)])
 def test_attention_general_plain(ops, shape):
     """softmax(scale q k^T) v for several (B, H, Lq, Lk, D): ragged query / key tile remainders included."""
