@@ -764,12 +764,23 @@ static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
 
 using namespace diffsal;
 
-// Tail mode plan of the forward and the dq kernel: pieces per tail block (1 = off) and the first tail block.  On: more than one round of workgroups
-// (one per CU) whose last round fills at most half of the chip, and enough key tiles to cut.
+// Tail mode plan of the forward and the dq kernel: pieces per tail block (1 = off) and the first tail block.  On when the
+// last round of workgroups (one per CU) fills at most half of the chip and there are enough key tiles to cut; a launch
+// of less than one round is cut whole (every block a tail block) when that shortens the longest CU's share by >= 15 %.
 static void attention_tail_plan(int BH, int Lq, int Lk, int* qb_x, int* qb_full, int* qb_split) {
   const int gx = (Lq + 127) / 128, total = gx * BH, n_tiles = (Lk + 31) / 32;
   *qb_x = gx; *qb_full = total; *qb_split = 1;
-  if (total <= 256) return;
+  if (total < 256) {
+    int best = 1;
+    float best_t = 1.0f;
+    for (int sp = 2; sp <= 4; ++sp) {
+      if (n_tiles / sp < 4) break;
+      const float t = static_cast<float>((total * sp + 255) / 256) / sp;
+      if (t < best_t - 1e-6f) { best_t = t; best = sp; }
+    }
+    if (best > 1 && best_t <= 0.85f) { *qb_full = 0; *qb_split = best; }
+    return;
+  }
   const int full = (total / 256) * 256, rest = total - full;
   if (rest == 0 || rest > 128) return;
   int sp = 256 / rest;
@@ -777,7 +788,6 @@ static void attention_tail_plan(int BH, int Lq, int Lk, int* qb_x, int* qb_full,
   if (sp < 2) return;
   *qb_full = full; *qb_split = sp;
 }
-
 
 // floats of scratch for the forward's tail mode (0: not used for this shape): the pieces' outputs and log-sum-exps
 extern "C" size_t diffsal_attention_general_tail_floats(int B, int H, int Lq, int Lk, int DV) {
