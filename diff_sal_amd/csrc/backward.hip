@@ -108,24 +108,37 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < 2 * C; i += 256) o[i] = shd[i];
 }
 
-// out[seg][j] = sum over chunks of part[seg][chunk][j] (fp64 in, fp64 or fp32 out).  Workgroup = (8 columns, segment);
-// 32 thread groups take every 32nd chunk, the 32 group sums are combined in a fixed order (short dependent chains and
-// enough workgroups even when there are only ~200 columns).
+// out[seg][j] = sum over chunks of part[seg][chunk][j] (fp64 in, fp64 or fp32 out).  Workgroup = (8 columns, segment),
+// 1024 threads: 128 thread groups take every 128th chunk (8 loads in flight per thread at 1024 chunks: the kernel is
+// pure load latency), then 32 threads per column add 4 group sums each and one adds those 32 -- fixed order, short chains,
+// and enough lanes even when there are only ~200 columns.
+constexpr int RP_GROUPS = 128;
 template <typename OUT>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ part, OUT* __restrict__ out,
-                                                              int chunks, int Wd) {
-  __shared__ double sh[32][9];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ part, OUT* __restrict__ out,
+                                                               int chunks, int Wd) {
+  __shared__ double sh[RP_GROUPS][9];
+  __shared__ double sh2[32][9];
   const int cl = threadIdx.x & 7, kg = threadIdx.x >> 3;
   const int j = blockIdx.x * 8 + cl, g = blockIdx.y;
   double s = 0.0;
-  if (j < Wd)
-    for (int k = kg; k < chunks; k += 32) s += part[(static_cast<long>(g) * chunks + k) * Wd + j];
+  if (j < Wd) {
+    const double* col = part + static_cast<long>(g) * chunks * Wd + j;
+    int k = kg;
+    for (; k + 3 * RP_GROUPS < chunks; k += 4 * RP_GROUPS) {      // four independent loads per trip
+      const double a = col[static_cast<long>(k) * Wd], b = col[static_cast<long>(k + RP_GROUPS) * Wd];
+      const double c = col[static_cast<long>(k + 2 * RP_GROUPS) * Wd], d = col[static_cast<long>(k + 3 * RP_GROUPS) * Wd];
+      s += (a + b) + (c + d);
+    }
+    for (; k < chunks; k += RP_GROUPS) s += col[static_cast<long>(k) * Wd];
+  }
   sh[kg][cl] = s;
   __syncthreads();
+  if (kg < 32) sh2[kg][cl] = (sh[4 * kg][cl] + sh[4 * kg + 1][cl]) + (sh[4 * kg + 2][cl] + sh[4 * kg + 3][cl]);
+  __syncthreads();
   if (kg == 0 && j < Wd) {
-    double t = sh[0][cl];
+    double t = sh2[0][cl];
 #pragma unroll
-    for (int q = 1; q < 32; ++q) t += sh[q][cl];
+    for (int q = 1; q < 32; ++q) t += sh2[q][cl];
     out[static_cast<long>(g) * Wd + j] = static_cast<OUT>(t);
   }
 }
@@ -946,10 +959,10 @@ extern "C" int diffsal_reduce_partials(const double* part, void* out, int segs, 
   DS_REQUIRE(segs > 0 && chunks > 0 && width > 0, DIFFSAL_E_SHAPE, "reduce_partials: bad shape");
   const dim3 grid((width + 7) / 8, segs);
   if (out_is_f64)
-    hipLaunchKernelGGL((reduce_partials_kernel<double>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), part,
+    hipLaunchKernelGGL((reduce_partials_kernel<double>), grid, dim3(1024), 0, static_cast<hipStream_t>(stream), part,
                        static_cast<double*>(out), chunks, width);
   else
-    hipLaunchKernelGGL((reduce_partials_kernel<float>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), part,
+    hipLaunchKernelGGL((reduce_partials_kernel<float>), grid, dim3(1024), 0, static_cast<hipStream_t>(stream), part,
                        static_cast<float*>(out), chunks, width);
   return check_launch("reduce_partials");
 }

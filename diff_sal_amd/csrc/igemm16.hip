@@ -664,8 +664,7 @@ static int launch16(Igemm16Args<T>& a, hipStream_t s) {
   const unsigned nz = a.pair ? 2u : 1u;
   if (a.linear && a.splits == 1 && a.vec_epilogue && a.persist_wgs > 0 && !a.pair) {   // plain product: persistent workgroups
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
-    const char* e_xcd = getenv("DIFFSAL_NO_XCD_ORDER");
-    a.xcd_order = (!(e_xcd && e_xcd[0] == '1') && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
+    a.xcd_order = (tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm16_linear_kernel<WM, WN, TM, TN, T>), dim3(grid), dim3(256), 0, s, a);
     return check_launch("diffsal_conv_igemm(16-bit linear)");
   }
