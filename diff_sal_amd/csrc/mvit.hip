@@ -437,24 +437,26 @@ __global__ __launch_bounds__(256) void maxpool_tokens_idx_kernel(const float* __
   }
 }
 
-// d_in[b, tok, c] = sum of dy over the (at most kt*kh*kw / stride) outputs whose recorded arg-max is this token
+// d_in[b, tok, c] = sum of dy over the (at most kt*kh*kw / stride) outputs whose recorded arg-max is this token.
+// Thread = (token, channel quad): the token's coordinates and its candidate windows are worked out once per 16 bytes.
 __global__ __launch_bounds__(256) void maxpool_tokens_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
                                                                  float* __restrict__ din, int C, int T, int H, int W, int To,
                                                                  int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw,
-                                                                 long total) {
+                                                                 long total4) {
   const int Lo = To * Ho * Wo, Li = T * H * W;
-  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
-    const int c = static_cast<int>(i % C);
-    const long tok = i / C;
+  const int c4n = C >> 2;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<long>(gridDim.x) * 256) {
+    const int c = static_cast<int>(i % c4n) * 4;
+    const long tok = i / c4n;
     const int n = static_cast<int>(tok % (Li + 1));
     const int b = static_cast<int>(tok / (Li + 1));
     const long ob = static_cast<long>(b) * (Lo + 1) * C + c;
-    float g = 0.f;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n == 0) {
-      g = dy[ob];
+      g = ld4(dy + ob);
     } else {
       const int l = n - 1;
-      const int ix = l % W, iy = (l / W) % H, it = l / (W * H);
+      const int ix = l % W, r = l / W, iy = r % H, it = r / H;
       for (int a = 0; a < kt; ++a) {          // outputs whose window position a covers this input: to*st - kt/2 + a == it
         const int nt = it + kt / 2 - a;
         if (nt < 0 || nt % st != 0 || nt / st >= To) continue;
@@ -465,12 +467,15 @@ __global__ __launch_bounds__(256) void maxpool_tokens_bwd_kernel(const float* __
             const int nx = ix + kw / 2 - f;
             if (nx < 0 || nx % sw != 0 || nx / sw >= Wo) continue;
             const long o = ob + (1 + (static_cast<long>(nt / st) * Ho + ny / sh) * Wo + nx / sw) * C;
-            if (idx[o] == n) g += dy[o];
+            const int4 am = *reinterpret_cast<const int4*>(idx + o);
+            const float4 d4 = ld4(dy + o);
+            g.x += am.x == n ? d4.x : 0.f; g.y += am.y == n ? d4.y : 0.f;
+            g.z += am.z == n ? d4.z : 0.f; g.w += am.w == n ? d4.w : 0.f;
           }
         }
       }
     }
-    din[i] = g;
+    st4(din + tok * C + c, g);
   }
 }
 
@@ -525,43 +530,68 @@ __global__ __launch_bounds__(256) void relpos_bwd_tables_kernel(const float* __r
   const long n_all = static_cast<long>(BH) * n_a;
   const long lo = n_all * chunk / REL_CHUNKS, hi = n_all * (chunk + 1) / REL_CHUNKS;
   // a thread owns a channel quad and FOUR table columns j: the query quad is loaded once for the four products (the gather is
-  // bound by L1 / L2 reads of q, which the one-column form re-read kk times per axis); the additions keep their order
+  // bound by L1 / L2 reads of q, which the one-column form re-read kk times per axis).  There are only kk4 * D/4 such items
+  // (48-144 at D = 96), so the 256 threads form G = 256 / items groups that each walk 1/G of the chunk's queries -- the walk
+  // is load latency -- and the groups' sums are added in group order through LDS (fixed order: deterministic).
+  __shared__ float4 sh[256][4];
   const int kk4 = (kk + 3) >> 2;
-  for (int item = threadIdx.x; item < kk4 * c4n; item += 256) {
-    const int j0 = (item / c4n) * 4, c = (item % c4n) * 4;
+  const int n_items = kk4 * c4n;
+  const int per_pass = n_items < 256 ? n_items : 256;
+  const int G = 256 / per_pass;
+  const int sub = threadIdx.x / per_pass, it_local = threadIdx.x - sub * per_pass;
+  const int nb = axis == 2 ? qh : qw;
+  for (int item0 = 0; item0 < n_items; item0 += per_pass) {
+    const int item = item0 + it_local;
+    const bool live = sub < G && item < n_items;
+    const int j0 = live ? (item / c4n) * 4 : 0, c = live ? (item % c4n) * 4 : 0;
     float4 acc[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc[jj] = make_float4(0, 0, 0, 0);
-    // the query walk is the same for every thread: (image, two free coordinates) advance as wave-uniform counters, no
-    // divisions in the loop.  a = slow free coordinate, b2 = fast one (axis 0: (y, x); axis 1: (t, x); axis 2: (t, y))
-    const int nb = axis == 2 ? qh : qw;
-    int bh = static_cast<int>(lo / n_a);
-    int m0 = static_cast<int>(lo - static_cast<long>(bh) * n_a);
-    int a = m0 / nb, b2 = m0 - a * nb;
+    if (live) {
+      // the query walk: (image, two free coordinates) advance as counters, no divisions in the loop.  a = slow free
+      // coordinate, b2 = fast one (axis 0: (y, x); axis 1: (t, x); axis 2: (t, y))
+      const long lo_s = lo + (hi - lo) * sub / G, hi_s = lo + (hi - lo) * (sub + 1) / G;
+      int bh = static_cast<int>(lo_s / n_a);
+      int m0 = static_cast<int>(lo_s - static_cast<long>(bh) * n_a);
+      int a = m0 / nb, b2 = m0 - a * nb;
 #pragma unroll 4
-    for (long u = lo; u < hi; ++u) {
-      const int t = axis == 0 ? i : a;
-      const int y = axis == 0 ? a : (axis == 1 ? i : b2);
-      const int x = axis == 2 ? i : b2;
-      const long row = static_cast<long>(bh) * (L + 1) + 1 + (static_cast<long>(t) * qh + y) * qw + x;
-      if (++b2 == nb) {
-        b2 = 0;
-        if (++a * nb == n_a) { a = 0; ++bh; }
-      }
-      const float4 qv = ld4(q + row * D + c);
-      const float* er = dE + row * REL_E + slot0 + j0;
+      for (long u = lo_s; u < hi_s; ++u) {
+        const int t = axis == 0 ? i : a;
+        const int y = axis == 0 ? a : (axis == 1 ? i : b2);
+        const int x = axis == 2 ? i : b2;
+        const long row = static_cast<long>(bh) * (L + 1) + 1 + (static_cast<long>(t) * qh + y) * qw + x;
+        if (++b2 == nb) {
+          b2 = 0;
+          if (++a * nb == n_a) { a = 0; ++bh; }
+        }
+        const float4 qv = ld4(q + row * D + c);
+        const float* er = dE + row * REL_E + slot0 + j0;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float e = er[j0 + jj < kk ? jj : 0];
-        acc[jj].x = fmaf(e, qv.x, acc[jj].x); acc[jj].y = fmaf(e, qv.y, acc[jj].y);
-        acc[jj].z = fmaf(e, qv.z, acc[jj].z); acc[jj].w = fmaf(e, qv.w, acc[jj].w);
+        for (int jj = 0; jj < 4; ++jj) {
+          const float e = er[j0 + jj < kk ? jj : 0];
+          acc[jj].x = fmaf(e, qv.x, acc[jj].x); acc[jj].y = fmaf(e, qv.y, acc[jj].y);
+          acc[jj].z = fmaf(e, qv.z, acc[jj].z); acc[jj].w = fmaf(e, qv.w, acc[jj].w);
+        }
       }
     }
+    if (G > 1) {
+      __syncthreads();               // the previous pass's readers are done
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      if (j0 + jj >= kk) continue;
-      double* o = part + chunk * width + tab0 + (static_cast<long>(i) * kk + j0 + jj) * D + c;
-      o[0] = acc[jj].x; o[1] = acc[jj].y; o[2] = acc[jj].z; o[3] = acc[jj].w;
+      for (int jj = 0; jj < 4; ++jj) sh[threadIdx.x][jj] = acc[jj];
+      __syncthreads();
+    }
+    if (live && sub == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        if (j0 + jj >= kk) continue;
+        double v[4] = {acc[jj].x, acc[jj].y, acc[jj].z, acc[jj].w};
+        for (int g2 = 1; g2 < G; ++g2) {
+          const float4 o4 = sh[g2 * per_pass + it_local][jj];
+          v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
+        }
+        double* o = part + chunk * width + tab0 + (static_cast<long>(i) * kk + j0 + jj) * D + c;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+      }
     }
   }
 }
@@ -722,14 +752,15 @@ extern "C" int diffsal_maxpool_tokens_idx(const float* in, float* out, int* idx,
 extern "C" int diffsal_maxpool_tokens_bwd(const float* dy, const int* idx, float* din, int B, int C, int T, int H, int W, int kt,
                                           int kh, int kw, int st, int sh, int sw, diffsal_stream_t stream) {
   DS_REQUIRE(dy && idx && din, DIFFSAL_E_ARG, "maxpool_tokens_bwd: null argument");
-  DS_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
-             DIFFSAL_E_SHAPE, "maxpool_tokens_bwd: bad shape");
+  DS_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
+             DIFFSAL_E_SHAPE, "maxpool_tokens_bwd: bad shape (C must be a multiple of 4)");
+  DS_REQUIRE(aligned16(dy) && aligned16(idx) && aligned16(din), DIFFSAL_E_ALIGN, "maxpool_tokens_bwd: misaligned pointer");
   const int To = (T + 2 * (kt / 2) - kt) / st + 1, Ho = (H + 2 * (kh / 2) - kh) / sh + 1, Wo = (W + 2 * (kw / 2) - kw) / sw + 1;
-  const long total = static_cast<long>(B) * (static_cast<long>(T) * H * W + 1) * C;
-  long g = (total + 255) / 256;
+  const long total4 = static_cast<long>(B) * (static_cast<long>(T) * H * W + 1) * (C / 4);
+  long g = (total4 + 255) / 256;
   g = g > 32768 ? 32768 : g;
   hipLaunchKernelGGL(maxpool_tokens_bwd_kernel, dim3(static_cast<int>(g)), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
-                     idx, din, C, T, H, W, To, Ho, Wo, kt, kh, kw, st, sh, sw, total);
+                     idx, din, C, T, H, W, To, Ho, Wo, kt, kh, kw, st, sh, sw, total4);
   return check_launch("maxpool_tokens_bwd");
 }
 
