@@ -144,6 +144,7 @@ SIGNATURES = {
 }
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_GELU_GRAD = 5      # training only: product * gelu'(residual) (include/diffsal.h)
 PREC_FP32, PREC_BF16X3 = 0, 1
 F32, BF16, F16 = 0, 1, 2
 

@@ -59,8 +59,8 @@ class Transformer(nn.Module):
             o = eg.attention_general(q, k, v, scale=attn.scale)
             x = ag.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=x) if attn.project_out else ag.add(o, x)
             y = ag.layernorm(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
-            h = ag.gelu(ag.linear(y, ff.net[1].weight, ff.net[1].bias))
-            x = ag.linear(h, ff.net[4].weight, ff.net[4].bias, residual=x)
+            h = ag.linear(y, ff.net[1].weight, ff.net[1].bias)            # pre-activation: the next node applies the GELU
+            x = ag.linear(h, ff.net[4].weight, ff.net[4].bias, residual=x, in_gelu=True)
         return ag.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
 
     def forward(self, x: Tensor) -> Tensor:

@@ -34,22 +34,28 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_packed, bias, rowvec, residual, w_dgrad, meta):
-        kh, kw, stride, pad, dil, out_hw, act = meta
+        kh, kw, stride, pad, dil, out_hw, act = meta[:7]
+        in_gelu = len(meta) > 7 and meta[7]      # x is the pre-activation of an erf-GELU in front of this layer (Mlp.fc2)
         if act not in (ACT_NONE, ACT_RELU):
             raise NotImplementedError("training path: only none / ReLU are fused into the conv epilogue")
         if act == ACT_RELU and residual is not None:
             raise NotImplementedError("training path: ReLU + residual in one epilogue is not differentiable from y")
-        y = ops.conv_igemm(x, w_packed, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, out_hw=out_hw, bias=bias,
+        if in_gelu and ((kh, kw) != (1, 1) or stride != (1, 1)):
+            raise NotImplementedError("training path: the GELU in front of a layer is folded into 1x1 stride-1 products only")
+        xin = ops.gelu(x) if in_gelu else x
+        y = ops.conv_igemm(xin, w_packed, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, out_hw=out_hw, bias=bias,
                            rowvec=rowvec, residual=residual, act=act)
         ctx.meta = meta
         ctx.has = (bias is not None, rowvec is not None, residual is not None)
-        ctx.save_for_backward(x, w_dgrad if w_dgrad is not None else x.new_empty(0), y if act == ACT_RELU else x.new_empty(0))
+        ctx.save_for_backward(xin, w_dgrad if w_dgrad is not None else x.new_empty(0), y if act == ACT_RELU else x.new_empty(0),
+                              x if in_gelu else x.new_empty(0))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        kh, kw, stride, pad, dil, out_hw, act = ctx.meta
-        x, w_dgrad, y = ctx.saved_tensors
+        kh, kw, stride, pad, dil, out_hw, act = ctx.meta[:7]
+        in_gelu = len(ctx.meta) > 7 and ctx.meta[7]
+        x, w_dgrad, y, pre = ctx.saved_tensors
         has_b, has_rv, has_res = ctx.has
         dy = dy.contiguous()
         g = ops.relu_bwd(dy, y) if act == ACT_RELU else dy
@@ -72,7 +78,11 @@ class ConvFn(torch.autograd.Function):
             if stride == (1, 1):
                 # flipped-kernel convolution over dY with padding dil*(k-1) - pad
                 pt, pl = dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1]
-                dx = ops.conv_igemm(g, w_dgrad, kh=kh, kw=kw, pad=(pt, pl), dil=dil, out_hw=(H, W))
+                if in_gelu:       # d(pre) = (dY W) * gelu'(pre): the multiplication rides in the product's epilogue
+                    dx = ops.conv_igemm(g, w_dgrad, kh=kh, kw=kw, pad=(pt, pl), dil=dil, out_hw=(H, W), residual=pre,
+                                        act=ops.ACT_GELU_GRAD)
+                else:
+                    dx = ops.conv_igemm(g, w_dgrad, kh=kh, kw=kw, pad=(pt, pl), dil=dil, out_hw=(H, W))
             elif stride[0] >= kh and stride[1] >= kw and dil == (1, 1):
                 # taps never overlap: one GEMM dXcols = dY W, then every input pixel copies its single source
                 if tuple(w_dgrad.shape) != (kh * kw * x.shape[-1], Cout):
@@ -92,20 +102,22 @@ class ConvFn(torch.autograd.Function):
 
 
 def conv(x, w_packed, *, kh=1, kw=1, stride=(1, 1), pad=(0, 0), dil=(1, 1), out_hw=None, bias=None, rowvec=None,
-         residual=None, act=ACT_NONE, w_dgrad=None):
+         residual=None, act=ACT_NONE, w_dgrad=None, in_gelu=False):
     return ConvFn.apply(x, w_packed, bias, rowvec, residual, w_dgrad,
-                        (kh, kw, tuple(stride), tuple(pad), tuple(dil), out_hw, act))
+                        (kh, kw, tuple(stride), tuple(pad), tuple(dil), out_hw, act, bool(in_gelu)))
 
 
-def linear(x, w, bias=None, *, residual=None, act=ACT_NONE):
-    """Token GEMM with autograd; w: [N, K] (its own packed form); dX uses w^T."""
+def linear(x, w, bias=None, *, residual=None, act=ACT_NONE, in_gelu=False):
+    """Token GEMM with autograd; w: [N, K] (its own packed form); dX uses w^T.  in_gelu: y = gelu(x) w^T + ... with x the
+    pre-activation (Mlp: fc2(gelu(fc1 x))); its backward multiplies by gelu'(x) in the data-gradient product's epilogue
+    instead of a separate pass over the hidden tensor."""
     lead = x.shape[:-1]
     M = 1
     for s in lead:
         M *= s
     wd = ops.pack_dgrad_weight(w) if (x.requires_grad and w.shape[0] % 32 == 0) else (
         w.detach().t().contiguous() if x.requires_grad else None)
-    y = conv(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, w_dgrad=wd,
+    y = conv(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, w_dgrad=wd, in_gelu=in_gelu,
              residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
     return y.reshape(*lead, w.shape[0])
 

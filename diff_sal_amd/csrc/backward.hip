@@ -20,10 +20,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     for (int c = 0; c < 4; ++c) {
       float d;
       if (mode == 1) d = rv[c] > 0.f ? 1.f : 0.f;
-      else if (mode == 2) {
-        const float x = rv[c];
-        d = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-      } else d = rv[c] * (1.0f - rv[c]);
+      else if (mode == 2) d = gelu_erf_grad(rv[c]);
+      else d = rv[c] * (1.0f - rv[c]);
       gv[c] *= d;
     }
     st4(dx + i * 4, make_float4(gv[0], gv[1], gv[2], gv[3]));

@@ -96,6 +96,19 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// d/dx of erf-GELU: Phi(x) + x * phi(x), with erf_as's polynomial; its exp(-x^2 / 2) is the one phi needs (one v_exp, one v_rcp
+// and ten FMAs per element -- cheap enough for a GEMM epilogue).  act_bwd_kernel (mode 2) uses the same function.
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float erf_x = copysignf(1.0f - p * t * e, x);
+  return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.0f + erf_x));
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -473,7 +473,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
           if (p.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
           else if (p.act == DIFFSAL_ACT_GELU_ERF) v = gelu_erf(v);
           else if (p.act == DIFFSAL_ACT_SIGMOID) v = sigmoidf_(v);
-          if (resid) v += resid[o];
+          if (p.act == DIFFSAL_ACT_GELU_GRAD) v *= gelu_erf_grad(resid[o]);
+          else if (resid) v += resid[o];
           outp[o] = v;
         }
       }
@@ -531,7 +532,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
       }
-      if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      if (p.act == DIFFSAL_ACT_GELU_GRAD) {
+        const float4 t = ld4(resid + o);
+        v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
+      } else if (resid) { const float4 t = ld4(resid + o); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
       st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
     }
     if (ps + 1 < NPASS) __syncthreads();
@@ -712,7 +716,10 @@ __global__ __launch_bounds__(256, (TM * TN <= 4 ? 2 : 1)) void igemm_linear_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
           }
-          if (resid) { const float4 t = rres[i][j][g]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (p.act == DIFFSAL_ACT_GELU_GRAD) {
+            const float4 t = rres[i][j][g];
+            v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
+          } else if (resid) { const float4 t = rres[i][j][g]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
           st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
         }
       }
@@ -805,7 +812,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs p) {
       if (p.act == DIFFSAL_ACT_RELU) x = fmaxf(x, 0.f);
       else if (p.act == DIFFSAL_ACT_GELU_ERF) x = gelu_erf(x);
       else if (p.act == DIFFSAL_ACT_SIGMOID) x = sigmoidf_(x);
-      if (p.residual) x += p.residual[o + j];
+      if (p.act == DIFFSAL_ACT_GELU_GRAD) x *= gelu_erf_grad(p.residual[o + j]);
+      else if (p.residual) x += p.residual[o + j];
       v[j] = x;
     }
     st4(p.out + o, make_float4(v[0], v[1], v[2], v[3]));
@@ -950,6 +958,9 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
   DS_REQUIRE(in_v && w_v && out_v, DIFFSAL_E_ARG, "conv_igemm: null argument");
   DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "conv_igemm: scale and shift go together");
   DS_REQUIRE(aligned16(in_v) && aligned16(w_v), DIFFSAL_E_ALIGN, "conv_igemm: in/w must be 16-byte aligned");
+  DS_REQUIRE((d->act >= DIFFSAL_ACT_NONE && d->act <= DIFFSAL_ACT_SIGMOID) ||
+                 (d->act == DIFFSAL_ACT_GELU_GRAD && d->dtype == DIFFSAL_F32 && residual_v && !px),
+             DIFFSAL_E_ARG, "conv_igemm: act=%d (DIFFSAL_ACT_GELU_GRAD: fp32 only, the pre-activation goes in `residual`)", d->act);
   if (d->dtype != DIFFSAL_F32)
     return igemm16_launch(d, in_v, w_v, bias, scale, shift, rowvec, residual_v, out_v, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), px ? px->in2 : nullptr, px ? px->w2 : nullptr,
@@ -985,7 +996,8 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   if (d->w_format == 0 && d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 &&
-      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) && !px) {
+      d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) && !px &&
+      d->act != DIFFSAL_ACT_GELU_GRAD) {
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }

@@ -287,8 +287,8 @@ class MViT(nn.Module):
             skip = eg.maxpool_tokens(skip, size, tuple(s + 1 if s > 1 else s for s in blk.stride_q), blk.stride_q)
         x = ag.linear(o, a.proj.weight, a.proj.bias, residual=skip)
         y = ag.layernorm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        h = ag.gelu(ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-        return ag.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x), q_size
+        h = ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias)       # pre-activation; the GELU belongs to fc2's node (its backward
+        return ag.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x, in_gelu=True), q_size    # rides in the dgrad epilogue)
 
     def _rel_plan(self, rel_len: int, q_size: int, k_size: int, dev) -> dict:
         """resize_decomposed_rel_pos (R/models/mvit.py:330-361) of one axis as a sparse row map, built once per (table length,

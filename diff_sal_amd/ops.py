@@ -16,7 +16,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc  # noqa: F401
+from ._lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc  # noqa: F401
 
 Tensor = torch.Tensor
 

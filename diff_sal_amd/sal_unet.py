@@ -827,8 +827,8 @@ class SalUNet(nn.Module):
             o = ag.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)
             x1 = ag.linear(o, a.proj.weight, a.proj.bias, residual=xcur.view(n9, Hs * Ws, C))
             y = ag.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            y = ag.gelu(ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-            x2 = ag.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1)
+            y = ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias)        # pre-activation: fc2's node applies the GELU
+            x2 = ag.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1, in_gelu=True)
             xcur = x2.view(Bn, T, Hs, Ws, C)
             # ---- norm + ReduceTemp
             nm = dec.norm_mts[i]

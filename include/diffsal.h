@@ -37,7 +37,10 @@ enum {
   DIFFSAL_E_ARG = -4      /* null pointer / bad enum */
 };
 
-enum { DIFFSAL_ACT_NONE = 0, DIFFSAL_ACT_RELU = 1, DIFFSAL_ACT_GELU_ERF = 2, DIFFSAL_ACT_SIGMOID = 3 };
+enum { DIFFSAL_ACT_NONE = 0, DIFFSAL_ACT_RELU = 1, DIFFSAL_ACT_GELU_ERF = 2, DIFFSAL_ACT_SIGMOID = 3,
+       /* training only, fp32 diffsal_conv_igemm only: out = (product + bias ...) * gelu'(residual[m, co]) -- `residual` carries the
+        * pre-activation of the erf-GELU in front of the layer whose data gradient this product is, and is NOT added */
+       DIFFSAL_ACT_GELU_GRAD = 5 };
 
 int diffsal_version(void);
 const char* diffsal_last_error(void);

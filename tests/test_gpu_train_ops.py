@@ -93,6 +93,26 @@ def test_linear_backward_with_residual(ag, rows, K, N):
         assert rel(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("rows,K,N", [(672, 384, 96), (3361, 1536, 384), (21507, 192, 96), (29, 64, 32)])
+def test_linear_with_the_gelu_in_front_folded_in(ag, rows, K, N):
+    """Mlp's fc2(gelu(h)) as one node: the backward multiplies by gelu'(h) in the data-gradient product's epilogue
+    (DIFFSAL_ACT_GELU_GRAD: persistent, tiled, split-K and scalar epilogues by shape); bit-equal to the two-node form."""
+    agops, ops = ag
+    h = rnd("gh", 3, rows, K).requires_grad_(True)
+    w = rnd("gw", N, K, scale=0.1).requires_grad_(True)
+    b = rnd("gb", N, scale=0.1).requires_grad_(True)
+    r = rnd("gr", 3, rows, N).requires_grad_(True)
+    gy = rnd("ggy", 3, rows, N)
+    (F.linear(F.gelu(h), w, b) + r).backward(gy)
+    hd, wd, bd, rd = (t.detach().to(DEV).requires_grad_(True) for t in (h, w, b, r))
+    agops.linear(hd, wd, bd, residual=rd, in_gelu=True).backward(gy.to(DEV))
+    for got, ref in ((hd.grad, h.grad), (wd.grad, w.grad), (bd.grad, b.grad), (rd.grad, r.grad)):
+        assert rel(got, ref) < 2e-5
+    h2, w2, b2, r2 = (t.detach().to(DEV).requires_grad_(True) for t in (h, w, b, r))
+    agops.linear(agops.gelu(h2), w2, b2, residual=r2).backward(gy.to(DEV))
+    assert torch.equal(h2.grad, hd.grad) and torch.equal(w2.grad, wd.grad)
+
+
 @pytest.mark.parametrize("C", [96, 192, 768, 32])
 def test_layernorm_backward(ag, C):
     agops, _ = ag
