@@ -317,6 +317,7 @@ def timed_train_region(ts, sal, cond, steps, dev, profile_last=False):
         loss = ts.step(sal, cond)
     if ops.PROFILE is not None:
         ev, ops.PROFILE = ops.PROFILE, None
+    timed_train_region.host_issue_s = time.perf_counter() - t0      # the host has queued every launch of the region by now
     torch.cuda.synchronize()
     if _dist_on():
         dist.barrier()
@@ -438,11 +439,12 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
     ts, sal, cond = build_train_step(cfg, net, feats, audio, dev, rank, batch=B, av=av, full=full)
     for _ in range(max(args.warmup, 1)):
         ts.step(sal, cond)
-    regions, ev = [], []
+    regions, ev, host_issue = [], [], []
     for rep_i in range(args.repeats):      # each region: exactly K steps between barrier + synchronize; MAX over ranks
         el, loss, e = timed_train_region(ts, sal, cond, args.steps, dev, profile_last=rep_i == args.repeats - 1)
         ev = e or ev
         regions.append(el)
+        host_issue.append(timed_train_region.host_issue_s)
     elapsed = median(regions)
     if args.dump_launches and rank == 0:     # per-launch table of the profiled step (shape -> TF/s, GB/s)
         rows = []
@@ -479,6 +481,9 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
                    "final_loss": float(loss.item())},
         "exchange": exchange_report(ts, sal, cond, args.steps, dev, world, elapsed / args.steps * 1e3),
         "repeats": args.repeats, "ms_per_step_all_regions": [round(r / args.steps * 1e3, 4) for r in regions],
+        # host time to QUEUE a step's launches (Python + autograd tape + ~1 800 launches): when it reaches ms_per_step the step is
+        # issue-bound and kernel-side savings no longer show (the first, unprofiled regions are the ones to read)
+        "host_issue_ms_per_step": [round(h / args.steps * 1e3, 4) for h in host_issue],
         "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
         "roofline": {"kernel": "diffsal::igemm_kernel + wgrad_kernel (fp32 MFMA: forward, data-gradient and "
                                "weight-gradient convolutions/GEMMs of one step)",

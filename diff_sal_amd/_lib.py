@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 SIGNATURES = {
@@ -67,7 +67,7 @@ SIGNATURES = {
     "diffsal_affine_act": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_norm_bwd_apply": (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_f]),
     "diffsal_layernorm_bwd_blocks": (c_i, [c_i, c_i]),
-    "diffsal_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),
+    "diffsal_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),
     "diffsal_dropout": (c_i, [c_f, c_f, c_sz, c_fl, C.c_uint64, c_f]),
     "diffsal_dwconv": (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f]),
     "diffsal_dwconv_bwd_data": (c_i, [c_f, c_f, c_f] + [c_i] * 7 + [c_f]),

@@ -53,12 +53,12 @@ class Transformer(nn.Module):
 
         B, N, dim = x.shape
         for attn, ff in self.layers:
-            xn = ag.layernorm(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
+            x, xn = ag.layernorm_fork(x, attn.norm.weight, attn.norm.bias, attn.norm.eps)
             qkv = ag.linear(xn, attn.to_qkv.weight, None).view(B, N, 3, attn.heads, attn.dim_head)
             q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous() for i in range(3))   # head-major copies (layout plumbing)
             o = eg.attention_general(q, k, v, scale=attn.scale)
             x = ag.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=x) if attn.project_out else ag.add(o, x)
-            y = ag.layernorm(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
+            x, y = ag.layernorm_fork(x, ff.net[0].weight, ff.net[0].bias, ff.net[0].eps)
             h = ag.linear(y, ff.net[1].weight, ff.net[1].bias)            # pre-activation: the next node applies the GELU
             x = ag.linear(h, ff.net[4].weight, ff.net[4].bias, residual=x, in_gelu=True)
         return ag.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)

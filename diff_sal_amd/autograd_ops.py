@@ -14,6 +14,14 @@ from .ops import ACT_NONE, ACT_RELU
 
 Tensor = torch.Tensor
 
+# Test / measurement switch (read once at import): DIFFSAL_NO_TAPE_FUSION=1 keeps every operator its own tape node -- LayerNorm
+# and the residual's gradient accumulation, GELU and fc2, rel-pos projection and attention -- i.e. the graph before the
+# fused nodes below; same results up to summation order.
+import os as _os
+
+_NO_FUSION = int(_os.environ.get("DIFFSAL_NO_TAPE_FUSION", "0") or 0)     # bit mask: 1 LayerNorm fork, 2 GELU into fc2, 4 rel-pos attention
+FUSE_LN_FORK, FUSE_GELU, FUSE_RELPOS = not (_NO_FUSION & 1), not (_NO_FUSION & 2), not (_NO_FUSION & 4)
+
 
 def dgrad_weight(w: Tensor, stride=(1, 1)) -> Tensor:
     """Weight of the data-gradient computation of a conv with parameter w [Cout, Cin, KH, KW] (or Conv3d [.., KT,1,1]).
@@ -111,6 +119,8 @@ def linear(x, w, bias=None, *, residual=None, act=ACT_NONE, in_gelu=False):
     """Token GEMM with autograd; w: [N, K] (its own packed form); dX uses w^T.  in_gelu: y = gelu(x) w^T + ... with x the
     pre-activation (Mlp: fc2(gelu(fc1 x))); its backward multiplies by gelu'(x) in the data-gradient product's epilogue
     instead of a separate pass over the hidden tensor."""
+    if in_gelu and not FUSE_GELU:
+        x, in_gelu = gelu(x), False
     lead = x.shape[:-1]
     M = 1
     for s in lead:
@@ -140,6 +150,34 @@ class LayerNormFn(torch.autograd.Function):
 
 def layernorm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class LayerNormForkFn(torch.autograd.Function):
+    """(x, LayerNorm(x)) for a pre-norm residual block: x goes on over the residual connection, the normalised copy into the
+    branch.  One node for both uses of x, so its backward is ONE kernel, dx = LN'(d_branch) + d_residual, where the tape
+    would run LayerNorm's backward and then an accumulation pass over the token tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma)
+        return x.view_as(x), ops.layernorm(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        add = None if dres is None else dres.contiguous()
+        dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps, add=add)
+        return dx, dg, db, None
+
+
+def layernorm_fork(x, gamma, beta, eps=1e-5):
+    """-> (x for the residual path, LayerNorm(x)); use the returned x, not the argument, downstream."""
+    if not FUSE_LN_FORK:
+        return x, LayerNormFn.apply(x, gamma, beta, eps)
+    return LayerNormForkFn.apply(x, gamma, beta, eps)
 
 
 class GroupNormSwishFn(torch.autograd.Function):

@@ -275,8 +275,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 // LayerNorm backward over C (rows in registers, statistics recomputed): dx, and per-block partial dgamma / dbeta.
 template <int G, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            double* __restrict__ part, int M, int C, float eps) {
+                                                            const float* __restrict__ gamma, const float* __restrict__ add,
+                                                            float* __restrict__ dx, double* __restrict__ part, int M, int C,
+                                                            float eps) {
   constexpr int ROWS = 256 / G;
   extern __shared__ double shd[];  // [2][C]
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.y = rstd * (gv[i].y * gm.y - a1 - (xv[i].y - mean) * rstd * a2);
         o.z = rstd * (gv[i].z * gm.z - a1 - (xv[i].z - mean) * rstd * a2);
         o.w = rstd * (gv[i].w * gm.w - a1 - (xv[i].w - mean) * rstd * a2);
+        if (add) {     // the gradient that reaches x on its other path (the residual connection around the normalised branch)
+          const float4 e = ld4(add + row * C + c);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
         st4(dx + row * C + c, o);
       }
     }
@@ -1020,15 +1025,16 @@ extern "C" int diffsal_layernorm_bwd_blocks(int M, int C) {
   return static_cast<int>(g > 1024 ? 1024 : g);
 }
 
-extern "C" int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, double* part,
-                                     int M, int C, float eps, diffsal_stream_t stream) {
+extern "C" int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* add, float* dx,
+                                     double* part, int M, int C, float eps, diffsal_stream_t stream) {
   DS_REQUIRE(x && dy && gamma && dx && part, DIFFSAL_E_ARG, "layernorm_bwd: null argument");
+  DS_REQUIRE(!add || aligned16(add), DIFFSAL_E_ALIGN, "layernorm_bwd: misaligned pointer");
   DS_REQUIRE(M > 0 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm_bwd: bad shape M=%d C=%d", M, C);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int blocks = diffsal_layernorm_bwd_blocks(M, C);
 #define CALL(G, NV)                                                                                                  \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<G, NV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), s, x, dy, gamma, dx, \
-                     part, M, C, eps)
+  hipLaunchKernelGGL((layernorm_bwd_kernel<G, NV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), s, x, dy, gamma, add, \
+                     dx, part, M, C, eps)
   DS_ROW_DISPATCH_B(C, CALL);
 #undef CALL
   return check_launch("layernorm_bwd");

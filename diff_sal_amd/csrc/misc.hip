@@ -657,7 +657,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 23; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 24; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_set_tuning(const char* name, int value) {

@@ -93,6 +93,39 @@ def relpos_project(q, Rt, Rh, Rw, q_size, k_size, E=48):
     return RelposProjectFn.apply(q, Rt, Rh, Rw, tuple(q_size), tuple(k_size), int(E))
 
 
+class RelposAttentionFn(torch.autograd.Function):
+    """MViT's pooling attention with its decomposed relative-position bias as one node: relpos_project + attention_general
+    forward; backward = attention backward, then the projection's query gradient ACCUMULATES into the attention's dq
+    (`accumulate` of diffsal_relpos_project_bwd) -- q feeds both, and as two nodes the tape adds the two [B,H,Lq,96]
+    gradients in a pass of its own."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, Rt, Rh, Rw, onehot, scale, q_size, k_size, E):
+        extra = ops.relpos_project(q, Rt, Rh, Rw, q_size, k_size, E)
+        out, lse = ops.attention_general(q, k, v, scale=scale, q_extra=extra, k_extra=onehot, residual=q, skip_first=True,
+                                         want_lse=True)
+        ctx.scale, ctx.sizes = scale, (q_size, k_size)
+        ctx.save_for_backward(q, k, v, extra, onehot, out, lse, Rt, Rh, Rw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, extra, onehot, out, lse, Rt, Rh, Rw = ctx.saved_tensors
+        dq, dqe, dk, dv = ops.attention_general_bwd(q, k, v, out, lse, dout.contiguous(), scale=ctx.scale, q_extra=extra,
+                                                    k_extra=onehot, residual=q, skip_first=True)
+        dq, dRt, dRh, dRw = ops.relpos_project_bwd(dqe, q, Rt, Rh, Rw, *ctx.sizes, dq_accum=dq)
+        return dq, dk, dv, dRt, dRh, dRw, None, None, None, None, None
+
+
+def relpos_attention(q, k, v, Rt, Rh, Rw, onehot, *, scale, q_size, k_size, E):
+    """softmax(scale q k^T + rel-pos bias) v + q (class-token row without bias / residual): mvit.py:363-410, 587-605."""
+    from .autograd_ops import FUSE_RELPOS
+    if not FUSE_RELPOS:
+        extra = relpos_project(q, Rt, Rh, Rw, q_size, k_size, E)
+        return attention_general(q, k, v, scale=scale, q_extra=extra, k_extra=onehot, residual_q=True, skip_first=True)
+    return RelposAttentionFn.apply(q, k, v, Rt, Rh, Rw, onehot, float(scale), tuple(q_size), tuple(k_size), int(E))
+
+
 class RelTablesFn(torch.autograd.Function):
     """resize_decomposed_rel_pos of the three axes of one block (linear resample + index gather) as one sparse row map per
     table: one launch forward, one backward (the torch form is ~14 small kernels per table and step, with a sort-based

@@ -265,7 +265,10 @@ class MViT(nn.Module):
         blk = self.blocks[i]
         a = blk.attn
         B, N, _ = x.shape
-        xn = ag.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        if hasattr(blk, "proj"):      # the skip path starts from the normalised tokens: x has one consumer
+            xn = ag.layernorm(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        else:                         # x feeds norm1 and the skip path: one node, one backward kernel for both (layernorm_fork)
+            x, xn = ag.layernorm_fork(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
         qkv = ag.linear(xn, a.qkv.weight, a.qkv.bias).view(B, N, 3, blk.heads, 96)
         w27 = [getattr(a, f"pool_{n}").weight.reshape(96, 27) for n in "qkv"]      # the parameter's own layout: views, no copies
         pq, pk_, pv = eg.qkv_pool(qkv, w27[0], w27[1], w27[2], size, blk.stride_q, blk.stride_kv)
@@ -280,13 +283,13 @@ class MViT(nn.Module):
                       for r, qs, ks in zip((a.rel_pos_t, a.rel_pos_h, a.rel_pos_w), q_size, k_size))
         Rt, Rh, Rw = eg.rel_tables(a.rel_pos_t, a.rel_pos_h, a.rel_pos_w, plans)
         onehot = self._onehot_for(k_size, x.device)
-        extra = eg.relpos_project(q, Rt, Rh, Rw, q_size, k_size, ops.relpos_columns(k_size))
-        o = eg.attention_general(q, k, v, scale=96 ** -0.5, q_extra=extra, k_extra=onehot, residual_q=True, skip_first=True)
+        o = eg.relpos_attention(q, k, v, Rt, Rh, Rw, onehot, scale=96 ** -0.5, q_size=q_size, k_size=k_size,
+                                E=ops.relpos_columns(k_size))
         skip = ag.linear(xn, blk.proj.weight, blk.proj.bias) if hasattr(blk, "proj") else x
         if max(blk.stride_q) > 1:
             skip = eg.maxpool_tokens(skip, size, tuple(s + 1 if s > 1 else s for s in blk.stride_q), blk.stride_q)
         x = ag.linear(o, a.proj.weight, a.proj.bias, residual=skip)
-        y = ag.layernorm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        x, y = ag.layernorm_fork(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
         h = ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias)       # pre-activation; the GELU belongs to fc2's node (its backward
         return ag.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x, in_gelu=True), q_size    # rides in the dgrad epilogue)
 

@@ -977,15 +977,15 @@ def norm_bwd_apply(x, dy, y, mu, rs, gamma, beta, k1, k2, k3, seg_rows: int, mod
 
 
 @_classed("K8-bwd")
-def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5):
-    """-> (dx, dgamma, dbeta)."""
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5, add: Optional[Tensor] = None):
+    """-> (dx (+ add), dgamma, dbeta)."""
     lib = _lib.load()
     Cc = x.shape[-1]
     M = x.numel() // Cc
     blocks = lib.diffsal_layernorm_bwd_blocks(M, Cc)
     part = torch.empty((blocks, 2, Cc), device=x.device, dtype=torch.float64)
     dx = torch.empty_like(x)
-    _lib.check(lib.diffsal_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(dx), part.data_ptr(), M, Cc, eps, _stream()),
+    _lib.check(lib.diffsal_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(add), _p(dx), part.data_ptr(), M, Cc, eps, _stream()),
                "layernorm_bwd")
     s = reduce_partials(part, 1, blocks, 2 * Cc).view(2, Cc)
     return dx, s[0], s[1]

@@ -806,7 +806,7 @@ class SalUNet(nn.Module):
             n9 = Bn * T
             blk = st.blocks[0]
             a = blk.attn
-            xn = ag.layernorm(xcur, blk.norm.weight, blk.norm.bias, blk.norm.eps)
+            xcur, xn = ag.layernorm_fork(xcur, blk.norm.weight, blk.norm.bias, blk.norm.eps)
             k_src = xn.view(n9, Hs, Ws, C)
             if audio_tok is not None:
                 a_small = ag.linear(audio_tok, blk.align_conv.weight.reshape(C, 512), blk.align_conv.bias)
@@ -826,7 +826,7 @@ class SalUNet(nn.Module):
             vv = ag.linear(vv, a.proj_v.weight, a.proj_v.bias)
             o = ag.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)
             x1 = ag.linear(o, a.proj.weight, a.proj.bias, residual=xcur.view(n9, Hs * Ws, C))
-            y = ag.layernorm(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            x1, y = ag.layernorm_fork(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             y = ag.linear(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias)        # pre-activation: fc2's node applies the GELU
             x2 = ag.linear(y, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x1, in_gelu=True)
             xcur = x2.view(Bn, T, Hs, Ws, C)

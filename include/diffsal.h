@@ -273,9 +273,11 @@ int diffsal_affine_act(const float* x, const float* scale, const float* shift, f
 int diffsal_norm_bwd_apply(const float* x, const float* dy, const float* y, const float* mu, const float* rs,
                            const float* gamma, const float* beta, const float* k1, const float* k2, const float* k3,
                            float* dx, int M, int C, int seg_rows, int mode, diffsal_stream_t stream);
-/* LayerNorm backward: dx and per-block partial (dgamma, dbeta) -> part[blocks][2][C], blocks = diffsal_layernorm_bwd_blocks() */
+/* LayerNorm backward: dx (+ add[M, C] when given: the gradient arriving at x over the residual connection around the normalised
+ * branch, so the tape needs no separate accumulation pass) and per-block partial (dgamma, dbeta) -> part[blocks][2][C],
+ * blocks = diffsal_layernorm_bwd_blocks() */
 int diffsal_layernorm_bwd_blocks(int M, int C);
-int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, double* part, int M, int C,
+int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* add, float* dx, double* part, int M, int C,
                           float eps, diffsal_stream_t stream);
 /* out = x * keep / (1-p), keep from a counter-based hash of (seed, index); same call = its own backward.
  * Replaces nn.Dropout(0.1) of ResnetBlock in train mode (sal_unet.py:109,133). */

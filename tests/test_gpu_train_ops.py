@@ -113,6 +113,27 @@ def test_linear_with_the_gelu_in_front_folded_in(ag, rows, K, N):
     assert torch.equal(h2.grad, hd.grad) and torch.equal(w2.grad, wd.grad)
 
 
+@pytest.mark.parametrize("C", [96, 384, 32])
+def test_layernorm_fork_adds_the_residual_gradient_in_its_backward_kernel(ag, C):
+    """Pre-norm residual block: x -> (x, LN(x)) as one node; dx = LN'(d_branch) + d_residual from one launch."""
+    agops, _ = ag
+    x = (rnd("lfx%d" % C, 3, 61, C) * 1.7 + 0.2).requires_grad_(True)
+    g = (rnd("lfg", C, scale=0.2) + 1.0).requires_grad_(True)
+    b = rnd("lfb", C, scale=0.2).requires_grad_(True)
+    w = rnd("lfw", C, C, scale=0.1)
+    gy = rnd("lfgy", 3, 61, C)
+    (x * 1.5 + F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w)).backward(gy)
+    xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, g, b))
+    xr, y = agops.layernorm_fork(xd, gd, bd, 1e-5)
+    (xr * 1.5 + F.linear(y, w.to(DEV))).backward(gy.to(DEV))
+    assert rel(xd.grad, x.grad) < 2e-5 and rel(gd.grad, g.grad) < 2e-5 and rel(bd.grad, b.grad) < 2e-5
+    x2 = x.detach().to(DEV).requires_grad_(True)           # only the branch is used: no residual gradient
+    agops.layernorm_fork(x2, gd.detach(), bd.detach(), 1e-5)[1].backward(gy.to(DEV))
+    x3 = x.detach().clone().requires_grad_(True)
+    F.layer_norm(x3, (C,), g.detach(), b.detach(), 1e-5).backward(gy)
+    assert rel(x2.grad, x3.grad) < 2e-5
+
+
 @pytest.mark.parametrize("C", [96, 192, 768, 32])
 def test_layernorm_backward(ag, C):
     agops, _ = ag
