@@ -115,7 +115,14 @@ def gemm_precision(mode: Optional[str]):
 DTYPE_CODES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device (the raw getter: ~10x cheaper than building a
+    torch.cuda.Stream object per launch, and a training step makes ~1 000 launches from Python)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -515,6 +515,7 @@ class SalUNet(nn.Module):
     # fp32 3x3 stride-1 convolutions (ResnetBlock conv1 / conv2, UpEmbed's second convolution) as Winograd F(2x2, 3x3) where the
     # library's planner expects a gain (csrc/wino.hip; ~1e-6 relative transform rounding).  Off: always the direct kernel
     winograd = True
+    _freq_tables: dict = {}       # (device, half) -> timestep-embedding frequencies on the device (constant)
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
@@ -730,7 +731,14 @@ class SalUNet(nn.Module):
 
         # K1: embedding table lookup (no parameters) + three small dense layers
         half = self.ch // 2
-        freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(x.device)
+        # the frequency table is a constant: built on the host once per device (a host-to-device copy of pageable memory in
+        # the step blocks the host until the GPU has drained everything queued before it -- the video encoder's forward --
+        # and the rest of the step is then issued into an empty queue)
+        fk = (str(x.device), half)
+        freq = SalUNet._freq_tables.get(fk)
+        if freq is None:
+            freq = SalUNet._freq_tables[fk] = torch.exp(
+                torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(x.device)
         arg = t.to(torch.float32)[:, None] * freq[None, :]
         emb = torch.cat([arg.sin(), arg.cos()], dim=1).contiguous()
         d0, d1 = self.temb.dense[0], self.temb.dense[1]
