@@ -13,13 +13,15 @@ namespace diffsal {
 // pass 1: per (image, pixel-chunk) partial sums per group  -> ws[B][chunks][groups][2] (double)
 // pass 2: finalise mean/rstd per (image, group), normalise, affine, swish.
 // ------------------------------------------------------------------------------------------------
-constexpr int GN_CHUNKS = 32;
+constexpr int GN_CHUNKS_MAX = 128;   // workspace is sized for this many pixel chunks per image
+static int gn_chunks() { const int t = tune(TUNE_GN_CHUNKS); return t > 0 && t <= GN_CHUNKS_MAX ? t : 32; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws,
                                                        int HW, int C, int groups) {
   extern __shared__ double sh[];  // [C][2]
   const int b = blockIdx.y, chunk = blockIdx.x;
+  const int GN_CHUNKS = gridDim.x;
   const int c4n = C >> 2;                     // float4 per pixel
   const int pix_per_pass = 256 / c4n > 0 ? 256 / c4n : 1;
   const int my_c4 = threadIdx.x % c4n;
@@ -69,25 +71,44 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const double* __restrict__ ws,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       T* __restrict__ out, int HW, int C, int groups, float eps, int swish) {
-  extern __shared__ float shf[];  // [C] scale, [C] shift
+                                                       T* __restrict__ out, int HW, int C, int groups, float eps, int swish,
+                                                       int GN_CHUNKS) {
+  extern __shared__ float shf[];  // [C] scale, [C] shift, [groups] mean, [groups] rstd
+  float* g_mean = shf + 2 * C;
+  float* g_rstd = g_mean + groups;
   const int b = blockIdx.y;
   const int cpg = C / groups;
+  // statistics of the image's groups, ONCE per group (not per channel: at C = 768 and 32 chunks that was 192 dependent
+  // 8-byte loads per thread, 20 us of every workgroup's life -- more than the normalisation itself): 8 lanes per group take
+  // every 8th chunk, their sums are combined in a fixed order, lane 0 finishes mean / rstd in fp64
+  for (int g0 = 0; g0 < groups; g0 += 32) {
+    const int g = g0 + (threadIdx.x >> 3), kl = threadIdx.x & 7;
+    double s = 0, q = 0;
+    if (g < groups)
+      for (int k = kl; k < GN_CHUNKS; k += 8) {
+        const double* o = ws + ((static_cast<long>(b) * GN_CHUNKS + k) * groups + g) * 2;
+        s += o[0]; q += o[1];
+      }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      s += __shfl_xor(s, off, 8);
+      q += __shfl_xor(q, off, 8);
+    }
+    if (kl == 0 && g < groups) {
+      const double n = static_cast<double>(HW) * cpg;
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      var = var < 0 ? 0 : var;
+      g_mean[g] = static_cast<float>(mean);
+      g_rstd[g] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    }
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
-    double s = 0, q = 0;
-    for (int k = 0; k < GN_CHUNKS; ++k) {
-      const double* o = ws + ((static_cast<long>(b) * GN_CHUNKS + k) * groups + g) * 2;
-      s += o[0]; q += o[1];
-    }
-    const double n = static_cast<double>(HW) * cpg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    var = var < 0 ? 0 : var;
-    const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
-    const float sc = rstd * gamma[c];
+    const float sc = g_rstd[g] * gamma[c];
     shf[c] = sc;
-    shf[C + c] = beta[c] - static_cast<float>(mean) * sc;
+    shf[C + c] = beta[c] - g_mean[g] * sc;
   }
   __syncthreads();
   const int c4n = C >> 2;
@@ -576,21 +597,26 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(QkvPrepArgs a) {
 using namespace diffsal;
 
 extern "C" size_t diffsal_groupnorm_ws_bytes(int B, int groups) {
-  return static_cast<size_t>(B) * GN_CHUNKS * groups * 2 * sizeof(double);
+  return static_cast<size_t>(B) * GN_CHUNKS_MAX * groups * 2 * sizeof(double);
 }
 
 template <typename T>
 static int groupnorm_swish_t(const T* x, const float* gamma, const float* beta, T* out, int B, int HW, int C, int groups,
                              float eps, void* ws, hipStream_t s, int swish = 1) {
-  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(GN_CHUNKS, B), dim3(256), 2 * C * sizeof(double), s, x,
+  const int chunks = gn_chunks();
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(chunks, B), dim3(256), 2 * C * sizeof(double), s, x,
                      static_cast<double*>(ws), HW, C, groups);
   int rc = check_launch("groupnorm_swish(stats)");
   if (rc) return rc;
   const long total4 = static_cast<long>(HW) * (C / 4);
   int gx = static_cast<int>((total4 + 255) / 256);
-  gx = gx > 512 ? 512 : gx;
-  hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(gx, B), dim3(256), 2 * C * sizeof(float), s, x,
-                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps, swish);
+  // ~512 workgroups in all (each repeats the per-image prologue: more of them cost more than they hide; tools/bench_gn.py)
+  int cap = 512 / B;
+  cap = cap < 32 ? 32 : cap;
+  if (tune(TUNE_GN_APPLY_WGS) > 0) cap = tune(TUNE_GN_APPLY_WGS);
+  gx = gx > cap ? cap : gx;
+  hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(gx, B), dim3(256), (2 * C + 2 * groups) * sizeof(float), s, x,
+                     static_cast<const double*>(ws), gamma, beta, out, HW, C, groups, eps, swish, chunks);
   return check_launch("groupnorm_swish(apply)");
 }
 
