@@ -422,3 +422,35 @@ def test_train_step_odd_batches_and_dropout_determinism(B, av):
         assert (a - c).abs().max().item() > 0
     with pytest.raises(RuntimeError):
         net.forward_train(args[0][:0], args[1][:0], [f[:0] for f in args[2]], None if args[3] is None else args[3][:0])
+
+
+def test_fused_tape_nodes_leave_every_gradient_where_the_separate_nodes_put_it(monkeypatch):
+    """LayerNorm + residual accumulation, GELU + fc2 and (in the encoder) rel-pos projection + attention are single tape nodes
+    (autograd_ops.layernorm_fork / linear(in_gelu) / encoder_autograd.relpos_attention); with the switches off the same step
+    runs on the separate nodes.  Same forward bit for bit, gradients equal up to the order of one addition per element."""
+    from diff_sal_amd import autograd_ops as ag
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    x, feats, audio = orc.synth_inputs(cfg, 2, True, tag="fuse")
+    t = torch.full((2,), 311)
+    args = (x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], audio.to(DEV))
+    gy = orc.synth_tensor("fuse_gy", tuple(x.shape), 1.0).to(DEV)
+
+    def run(fused):
+        for name in ("FUSE_LN_FORK", "FUSE_GELU", "FUSE_RELPOS"):
+            monkeypatch.setattr(ag, name, fused)
+        net = build(cfg, sd)
+        net.train()
+        net.dropout_p = 0.0
+        out = net(*args)
+        out.backward(gy)
+        return out.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    out_f, g_f = run(True)
+    out_s, g_s = run(False)
+    assert torch.equal(out_f, out_s)
+    assert g_f.keys() == g_s.keys() and len(g_f) > 100
+    for k in g_f:
+        den = g_s[k].abs().max().item() + 1e-12
+        assert (g_f[k] - g_s[k]).abs().max().item() / den < 2e-5, k
