@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 SIGNATURES = {
@@ -87,7 +87,7 @@ SIGNATURES = {
     "diffsal_pack_frames_multi": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f]),
     "diffsal_resize_bilinear": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_resize_sum": (c_i, [C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
-    "diffsal_audio_fuse": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "diffsal_audio_fuse": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_dwconv3_ln": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),
     "diffsal_dwpool_ln_kv": (c_i, [c_f] * 10 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f]),

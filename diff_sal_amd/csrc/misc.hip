@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void resize_sum_generic_kernel(ResizeSumArgs a
 template <typename TT>
 __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ a_small, const TT* __restrict__ x,
                                                          TT* __restrict__ out, int T, int H, int W, int C, int h, int w,
-                                                         int up) {
+                                                         int up, int a_ld) {
   extern __shared__ float sh[];  // s[32][W+1]
   const int WP = W + 1;
   const int cslabs = C / 32;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ 
       const int xs = xx / up;
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int t = 0; t < T; ++t) {
-        const float4 av = ld4(a_small + ((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * C + c);
+        const float4 av = ld4(a_small + ((static_cast<long>(b) * T + t) * h * w + ys * w + xs) * a_ld + c);
         const float4 xv = ld4(x + (((static_cast<long>(b) * T + t) * H + y) * W + xx) * C + c);
         s.x = fmaf(av.x, xv.x, s.x); s.y = fmaf(av.y, xv.y, s.y); s.z = fmaf(av.z, xv.z, s.z); s.w = fmaf(av.w, xv.w, s.w);
       }
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ 
     int t = iw - cc * T;
     if (t < 0) { --cc; t += T; } else if (t >= T) { ++cc; t -= T; }
     const int cg = cs * 32 + cc;
-    const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xx / up) * C + cg]);
+    const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xx / up) * a_ld + cg]);
     out[(((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx] = static_cast<TT>(av * sh[cc * WP + xx]);
   }
 }
@@ -657,7 +657,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 24; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 25; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 
 extern "C" int diffsal_set_tuning(const char* name, int value) {
@@ -1012,11 +1012,11 @@ extern "C" int diffsal_resize_sum(const void* const* ins, const int* hs, const i
   return check_launch("resize_sum");
 }
 
-extern "C" int diffsal_audio_fuse(const void* a_small, const void* x, void* out, int B, int T, int H, int W, int C,
+extern "C" int diffsal_audio_fuse(const void* a_small, int a_ld, const void* x, void* out, int B, int T, int H, int W, int C,
                                   int h, int w, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(a_small && x && out, DIFFSAL_E_ARG, "audio_fuse: null argument");
-  DS_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && h > 0 && w > 0, DIFFSAL_E_SHAPE,
-             "audio_fuse: bad shape C=%d", C);
+  DS_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && h > 0 && w > 0 && a_ld >= C && a_ld % 8 == 0, DIFFSAL_E_SHAPE,
+             "audio_fuse: bad shape C=%d a_ld=%d", C, a_ld);
   DS_REQUIRE(aligned16(a_small) && aligned16(x), DIFFSAL_E_ALIGN, "audio_fuse: misaligned pointer");
   int up = 1;
   if (h != H && w != W) {  // quirk Q3: upsample only when BOTH differ; factor H // h
@@ -1029,7 +1029,7 @@ extern "C" int diffsal_audio_fuse(const void* a_small, const void* x, void* out,
   const size_t lds = static_cast<size_t>(32) * (W + 1) * sizeof(float);
 #define CALL(TT)                                                                                                     \
   hipLaunchKernelGGL((audio_fuse_kernel<TT>), dim3(B * H * (C / 32)), dim3(256), lds, static_cast<hipStream_t>(stream), \
-                     static_cast<const TT*>(a_small), static_cast<const TT*>(x), static_cast<TT*>(out), T, H, W, C, h, w, up)
+                     static_cast<const TT*>(a_small), static_cast<const TT*>(x), static_cast<TT*>(out), T, H, W, C, h, w, up, a_ld)
   DS_DTYPE_DISPATCH(dtype, "audio_fuse", CALL);
 #undef CALL
   return check_launch("audio_fuse");

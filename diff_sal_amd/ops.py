@@ -678,13 +678,19 @@ def tap_weight(w: Tensor) -> Tensor:
 
 
 def audio_fuse(a_small: Tensor, x: Tensor, h: int, w: int) -> Tensor:
-    """K7. a_small [B*T, h*w, C], x [B,T,H,W,C] -> fused audio in the reference's [B,C,T,H,W] order."""
+    """K7. a_small [B*T, h*w, C] (contiguous, or a channel slice of a wider row: the stages' align products side by side),
+    x [B,T,H,W,C] -> fused audio in the reference's [B,C,T,H,W] order."""
     lib = _lib.load()
     B, T, H, W, Cc = x.shape
     out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=x.dtype)
     dt = _dt(x)
-    with _prof("K7", 0.0, _nb(a_small, x, out)):
-        _lib.check(lib.diffsal_audio_fuse(_pa(a_small, dt), _pa(x, dt), out.data_ptr(), B, T, H, W, Cc, h, w, dt, _stream()),
+    ld = a_small.stride(-2)
+    if (not a_small.is_cuda or DTYPE_CODES.get(a_small.dtype) != dt or a_small.shape != (B * T, h * w, Cc) or a_small.stride(-1) != 1
+            or a_small.stride(0) != h * w * ld or a_small.data_ptr() % 16):
+        raise ValueError(f"audio_fuse: a_small must be [B*T, h*w, C] rows of one pitch in x's storage type, got {tuple(a_small.shape)} "
+                         f"strides {a_small.stride()} {a_small.dtype}")
+    with _prof("K7", 0.0, _nb(x, out) + a_small.numel() * a_small.element_size()):
+        _lib.check(lib.diffsal_audio_fuse(a_small.data_ptr(), ld, _pa(x, dt), out.data_ptr(), B, T, H, W, Cc, h, w, dt, _stream()),
                    "audio_fuse")
     return out
 

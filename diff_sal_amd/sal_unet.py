@@ -326,6 +326,15 @@ class SalUNet(nn.Module):
                             ("fc2", blk.mlp.fc2)):
                 pk[f"s{i}.{nm}.w"] = self._gemm_w(lin.weight)
             pk[f"s{i}.redu.w"] = self._pack_conv(dec.redu_chan_up[i].proj[0].weight)  # [Co, C, kt, 1, 1]
+        if all(f"s{i}.align.w" in pk for i in range(self.num_stages)) and self.num_stages > 1:
+            pk["align_all.w"] = torch.cat([pk[f"s{i}.align.w"] for i in range(self.num_stages)], 0).contiguous()
+            pk["align_all.b"] = torch.cat([dec.mid_stages[i].blocks[0].align_conv.bias.detach().float()
+                                           for i in range(self.num_stages)], 0).contiguous()
+            offs, o = [], 0
+            for i in range(self.num_stages):
+                offs.append(o)
+                o += self.up_channels[i]
+            pk["align_all.offs"] = offs
         pk["mt.w"] = self._pack_conv(dec.mt_proj[0].weight)
         pk["mt.tapw"] = self._tap_weight(dec.mt_proj[0].weight)
         pk["mt.scale"], pk["mt.shift"] = self._bn_affine(dec.mt_proj[1])
@@ -381,7 +390,11 @@ class SalUNet(nn.Module):
         n9 = B * T
         k_src = None                       # None: the key branch reads the same normalised frames as q and v
         if audio_tok is not None:
-            a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias, tag="K7-align")  # [B*T, ha*wa, C]
+            if isinstance(audio_tok, tuple):     # (all stages' align products side by side, channel offsets): this stage's slice
+                a_all, offs = audio_tok
+                a_small = a_all[:, :, offs[i]:offs[i] + C]
+            else:
+                a_small = ops.linear(audio_tok, pk[f"s{i}.align.w"], blk.align_conv.bias, tag="K7-align")  # [B*T, ha*wa, C]
             k_src = ops.audio_fuse(a_small, x, audio_hw[0], audio_hw[1])  # [B,C,T,H,W], read back as tokens (Q5)
         xt = x.view(n9, H * W, C)
         gh, gw = (H - self.kernel_kv[i]) // self.kernel_kv[i] + 1, (W - self.kernel_kv[i]) // self.kernel_kv[i] + 1
@@ -519,6 +532,7 @@ class SalUNet(nn.Module):
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
+    merge_align = True   # the stages' audio align convolutions as one product (eval)
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
     # step (1720 -> 1779 steps/s; "s3" and "mt" lose), but the nine tap products are rounded to 16 bits before they are summed
     # and the worst bf16 fixture error moves from 2.2e-2 to 2.9e-2 against a 3e-2 bar.
@@ -615,6 +629,11 @@ class SalUNet(nn.Module):
                 raise RuntimeError(f"audio has {ap.shape[1]} frames but the decoder input has {frames[0].shape[1]}")
             audio_hw = (ap.shape[2], ap.shape[3])
             audio_tok = ap.view(B * ap.shape[1], audio_hw[0] * audio_hw[1], ap.shape[4])
+            if self.merge_align and "align_all.w" in pk:
+                # the four stages' align 1x1 convolutions (transformer.py:133-135) read the same 512-channel audio tokens:
+                # ONE product with their output channels side by side (N = 1440) instead of four with N = 768 .. 96
+                a_all = ops.linear(audio_tok, pk["align_all.w"], pk["align_all.b"], tag="K7-align")
+                audio_tok = (a_all, pk["align_all.offs"])
 
         xcur = frames[0]
         h0, w0 = xcur.shape[2:4]

@@ -351,7 +351,9 @@ int diffsal_resize_sum(const void* const* ins /*host array of device ptrs*/, con
  * R/.../transformer.py:133-146.  a_small: [B*T, h*w, C] tokens; x: NHWC frames [B,T,H,W,C];
  * out: contiguous [B,C,T,H,W] (the reference layout, which the caller then *reinterprets* as
  * [B*T, H*W, C] tokens -- quirk Q5).  up = H / h (nearest), 1 when no upsample. */
-int diffsal_audio_fuse(const void* a_small, const void* x, void* out, int B, int T, int H, int W, int C,
+int diffsal_audio_fuse(const void* a_small, int a_ld /* elements between a_small's rows (>= C): the four stages' align
+                       convolutions run as ONE product whose output rows hold all their channels side by side */,
+                       const void* x, void* out, int B, int T, int H, int W, int C,
                        int h, int w, int dtype, diffsal_stream_t stream);
 
 /* ---- K8: LayerNorm over C on tokens [M,C] ------------------------------------------------ */
