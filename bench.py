@@ -196,6 +196,38 @@ def plumbing_only(args, rank, world):
         dist.destroy_process_group()
 
 
+_REAL_STDOUT_FD = None
+
+
+def quiet_stdout() -> None:
+    """stdout carries ONE JSON line and nothing else: until `emit`, file descriptor 1 points at stderr, so that whatever a
+    library writes to the C stdout (RCCL prints a version banner through printf when a communicator is created, and libc
+    would flush it behind our line at exit) lands in the log instead."""
+    global _REAL_STDOUT_FD
+    if _REAL_STDOUT_FD is None:
+        sys.stdout.flush()
+        _REAL_STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(result) -> None:
+    """Flush everything that was written meanwhile (to stderr), give file descriptor 1 back and print the line."""
+    global _REAL_STDOUT_FD
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if _REAL_STDOUT_FD is not None:
+        os.dup2(_REAL_STDOUT_FD, 1)
+        os.close(_REAL_STDOUT_FD)
+        _REAL_STDOUT_FD = None
+    print(json.dumps(result), flush=True)
+    quiet_stdout()          # teardown chatter (communicator destruction) goes to the log as well
+
+
 class Config:
     """The decoder of R/cfgs/audio_visual.py:50-82 / R/cfgs/visual.py:33-70 (the only configuration the reference ships)."""
     img_size = (224, 384)
@@ -495,7 +527,7 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
                      "classified_ms": round(sum(e[0].elapsed_time(e[1]) for e in ev), 3), "operators_bracketed": len(ev)},
     }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if world > 1:
         import torch.distributed as dist
 
@@ -549,6 +581,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         return plumbing_only(args, rank, world)
+    quiet_stdout()        # a rank process: from here on only `emit` writes to the real stdout
     if world > 1:
         import torch.distributed as dist
 
@@ -939,7 +972,7 @@ def main():
                       f"{cdt:.1f} s; solver update excluded (negligible)",
         }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if world > 1:
         import torch.distributed as dist
 
