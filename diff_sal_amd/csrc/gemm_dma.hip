@@ -1,0 +1,356 @@
+// Plain [M, K] x [N, K]^T products in exact fp32 (1x1 convolutions, Linear layers, the tap products of UpEmbed / mt_proj) with
+// both operands staged by LDS-DMA -- the main loop owns no staging registers and issues no LDS writes.
+//
+//   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )        R/models/saliency_decoder/attention.py:97-111 (proj_q/k/v, proj),
+//                                                          common_block.py:125-147 (Mlp fc1 / fc2), transformer.py:150-157
+//
+// Why another kernel beside igemm_linear_kernel: that one stages through registers (global -> VGPR -> ds_write), and its
+// 64 x 64 tiles (the shape that fills the chip on the decoder's token counts) pull 16 B/clk/CU through the vector memory
+// path for every 4096 matrix cycles -- the matrix pipe of the token GEMMs is 0.59 busy (profiles/r03_pmc_mfma_busy_fp32.md).
+//
+//  * Tiles are 96 wide in both directions (96 x 96, 96 x 192): every channel count of the network is a multiple of 96 and
+//    the token counts are 3024 * 4^i, so the tile grid has no partly filled N tiles and M = 3024 x N = 768 is exactly 256
+//    tiles -- one per CU -- where 64 x 64 tiles leave the CUs 2.25 tiles each (the busiest a third over the average) and
+//    128 x 128 tiles fill 144 of 256 CUs.
+//  * A wave owns 48 x 48 (or 48 x 96) outputs as 16 x 16 blocks of v_mfma_f32_16x16x4_f32 (bit-for-bit an fmaf chain, the
+//    fp32 vector rate; 9 / 18 independent accumulators).
+//  * A K slice is 32 floats: one 128-byte run per row.  An LDS stage is [BM + BN rows][128 B] with the eight 16-byte slots of
+//    a row XOR-swizzled by (row >> 1) & 7, so that the sixteen lanes of a ds_read_b128 pass (16 consecutive rows, one slot)
+//    cover all 64 banks.  A DMA instruction (buffer_load_dwordx4 ... lds) fills 8 rows = 1 KiB in lane order; the swizzle is
+//    applied on the SOURCE address (the lane that fills physical slot p of row r fetches logical slot p ^ ((r >> 1) & 7)).
+//    Rows past M / N are cut by the buffer descriptor's range check (the descriptor is rebuilt per tile: base = the tile's
+//    first row, num_records = its valid rows), the DMA then writes zeros.
+//  * STAGES-deep ring, the DMA of slice g + STAGES - 1 is issued while slice g is multiplied; ONE barrier per slice, placed
+//    between the two halves of the slice's MFMAs (the fragments of the second half are already in registers), counted vmcnt.
+//  * Persistent: a workgroup walks a strided list of tiles and the DMA ring runs on into the next tile; epilogue (bias, BN
+//    affine, per-image vector, activation, residual) straight from the accumulators: a lane holds four consecutive channels
+//    of one output row (weights are the MFMA "A" operand), 16-byte stores.
+//
+// The summation order inside a 32-wide slice differs from igemm_kernel's (k sets {j, j+4, j+8, j+12} per MFMA instead of pairs
+// {j, j+4}), so results differ from that kernel by fp32 rounding (~1e-7 relative); both are exact-fp32 fmaf chains.
+#include <type_traits>
+
+#include "common.h"
+
+namespace diffsal {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct DmaGemmArgs {
+  const float* a;
+  const float* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* rowvec;
+  const float* residual;
+  float* out;
+  int M, N, K;
+  int act, rowvec_ld, rows_per_img;
+  int n_tiles_m, n_tiles_n, n_tiles;
+  int xcd_order;   // tiles walked so that one XCD owns whole M-tile rows (large launches, grid % 8 == 0)
+};
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rsrc` at voff + soff into LDS at lds_addr + 16 lane.  Inline assembly on
+// purpose: hipcc orders every later LDS read behind a DMA it knows about (s_waitcnt vmcnt(0) in front of the fragment reads at a
+// loop header, whatever object they read), which serialises the ring.  Here the compiler sees neither the LDS write nor the
+// vmcnt event; the kernel places its own counted waits.  (Its counted waits for ordinary loads stay safe: vmcnt retires in
+// order, so DMAs it does not know about only make such a wait stricter.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_piece(unsigned lds_addr, unsigned voff, i32x4 rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TMB, int TNB, int STAGES, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
+  constexpr int BM = 32 * TMB, BN = 32 * TNB;
+  constexpr int APW = BM / 32, BPW = BN / 32;          // 1 KiB DMA pieces (8 rows) per wave and slice
+  constexpr int PPW = APW + BPW;
+  constexpr int STAGE_F = (BM + BN) * 32;              // floats per stage
+  constexpr int P = STAGES - 1;                        // slices in flight ahead of the one being multiplied
+  constexpr int WAIT_N = (P - 2 > 0 ? P - 2 : 0) * PPW;
+  static_assert(STAGES >= 3 && WAIT_N < 64, "ring depth");
+  __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE_F];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int K = p.K, nkt = K >> 5;
+
+  // ---- tile walk (same scheme as igemm_linear_kernel): v = blockIdx.x + i * gridDim.x
+  int n_virtual = p.n_tiles;
+  if (p.xcd_order) {
+    const int x = blockIdx.x & 7;
+    n_virtual = 8 * p.n_tiles_n * (p.n_tiles_m > x ? (p.n_tiles_m - x + 7) >> 3 : 0);
+  }
+  auto tile_mn = [&](int v, int& tmi, int& tni) __attribute__((always_inline)) {
+    if (p.xcd_order) {
+      const int q = v >> 3, ml = q / p.n_tiles_n;
+      tni = q - ml * p.n_tiles_n;
+      tmi = ml * 8 + (v & 7);
+    } else {
+      tmi = v / p.n_tiles_n;
+      tni = v - tmi * p.n_tiles_n;
+    }
+  };
+  const int bid = blockIdx.x, gsz = gridDim.x;
+  const int my_tiles = n_virtual > bid ? (n_virtual - bid + gsz - 1) / gsz : 0;
+  const int total = my_tiles * nkt;
+  if (total == 0) return;
+
+  // ---- issue side: one per-lane byte offset serves every piece (pieces of a wave are 32 rows apart: the swizzle term
+  // ((row >> 1) & 7) = (4 wave + (lane >> 4)) & 7 does not depend on the piece)
+  unsigned voff[APW > BPW ? APW : BPW];
+  {
+    const int r0 = 8 * wave + (lane >> 3);
+    const int slot = (lane & 7) ^ ((r0 >> 1) & 7);
+#pragma unroll
+    for (int q = 0; q < (APW > BPW ? APW : BPW); ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K + slot * 4) * 4u;
+  }
+  int iss_v = bid, iss_kt = 0;
+  i32x4 rs_a, rs_b;
+  auto descriptors = [&](int v) __attribute__((always_inline)) {
+    int tmi, tni;
+    tile_mn(v, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+    // past the last tile: zero records, every lane is out of range (the DMA then writes zeros into a free stage and touches
+    // no memory) -- the ring keeps issuing so that the counted waits stay exact
+    const bool live = v < n_virtual;
+    const int rows_a = live ? min(BM, p.M - m0) : 0, rows_b = live ? min(BN, p.N - n0) : 0;
+    const unsigned long pa = reinterpret_cast<unsigned long>(p.a + static_cast<long>(m0) * K);
+    const unsigned long pb = reinterpret_cast<unsigned long>(p.w + static_cast<long>(n0) * K);
+    rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * 4, 0x00020000};
+    rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * 4, 0x00020000};
+  };
+  descriptors(iss_v);
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)smem)) + wave * 1024u;
+  auto issue_slice = [&](int stage) __attribute__((always_inline)) {
+    const unsigned st = lds_base + static_cast<unsigned>(stage * STAGE_F * 4);
+    const unsigned kofs = static_cast<unsigned>(iss_kt) * 128u;
+#pragma unroll
+    for (int q = 0; q < APW; ++q) dma_piece(st + q * 4096u, voff[q], rs_a, kofs);
+#pragma unroll
+    for (int q = 0; q < BPW; ++q) dma_piece(st + (BM * 32 + q * 1024) * 4u, voff[q], rs_b, kofs);
+    if (++iss_kt == nkt) {
+      iss_kt = 0;
+      iss_v += gsz;
+      descriptors(iss_v);
+    }
+  };
+
+  // ---- compute side: fragment addresses (floats inside a stage) for the two 16-wide halves of a slice
+  const int q4 = lane >> 4, r16 = lane & 15;
+  int a_off[TMB][2], b_off[TNB][2];
+#pragma unroll
+  for (int i = 0; i < TMB; ++i) {
+    const int row = wm * TMB * 16 + i * 16 + r16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_off[i][h] = row * 32 + (((q4 + 4 * h) ^ ((row >> 1) & 7)) << 2);
+  }
+#pragma unroll
+  for (int j = 0; j < TNB; ++j) {
+    const int row = wn * TNB * 16 + j * 16 + r16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) b_off[j][h] = BM * 32 + row * 32 + (((q4 + 4 * h) ^ ((row >> 1) & 7)) << 2);
+  }
+  f32x4v acc[TMB][TNB];
+#pragma unroll
+  for (int i = 0; i < TMB; ++i)
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  float4 fa[2][TMB], fb[2][TNB];
+  auto load_frags = [&](const float* st, int h, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TMB; ++i) fa[set][i] = ld4(st + a_off[i][h]);
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) fb[set][j] = ld4(st + b_off[j][h]);
+  };
+  auto do_mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < TMB; ++i) {
+        const float av = c == 0 ? fa[set][i].x : c == 1 ? fa[set][i].y : c == 2 ? fa[set][i].z : fa[set][i].w;
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) {
+          const float bv = c == 0 ? fb[set][j].x : c == 1 ? fb[set][j].y : c == 2 ? fb[set][j].z : fb[set][j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
+        }
+      }
+    }
+  };
+
+  int cmp_v = bid;
+  const float* __restrict__ resid = p.residual;
+  float* __restrict__ outp = p.out;
+  // Epilogue operands (per-channel vectors, residual quads) are requested at the start of the tile's LAST pass over the ring and
+  // wait in registers: requested in the epilogue they would be a dependent round trip with the matrix pipe idle, and -- vmcnt
+  // retires in order -- their wait would also drain the DMA ring.
+  float4 rres[TMB][TNB], rbias[TNB], rscale[TNB], rshift[TNB];
+  auto fetch_epilogue_operands = [&]() __attribute__((always_inline)) {
+    int tmi, tni;
+    tile_mn(cmp_v, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) {
+      const int n = n0 + wn * TNB * 16 + j * 16 + 4 * q4;
+      const int nc = n < p.N ? n : 0;
+      if (p.bias) rbias[j] = ld4(p.bias + nc);
+      if (p.scale) { rscale[j] = ld4(p.scale + nc); rshift[j] = ld4(p.shift + nc); }
+      if (resid) {
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) {
+          const int m = m0 + wm * TMB * 16 + i * 16 + r16;
+          const bool ok = m < p.M && n < p.N;
+          rres[i][j] = ld4(resid + (ok ? static_cast<long>(m) * p.N + n : 0));
+        }
+      }
+    }
+  };
+  auto touch = [](const float4& x) __attribute__((always_inline)) { asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); };
+  auto finish_tile = [&]() __attribute__((always_inline)) {
+    int tmi, tni;
+    tile_mn(cmp_v, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+    // an unconditional use of every prefetched register: hipcc then knows that no request is pending when the next tile's
+    // prefetch overwrites them (otherwise it waits vmcnt(0) in front of every one of those loads, draining the ring)
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) {
+      touch(rbias[j]); touch(rscale[j]); touch(rshift[j]);
+#pragma unroll
+      for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) {
+      const int n = n0 + wn * TNB * 16 + j * 16 + 4 * q4;
+      const bool n_ok = n < p.N;
+#pragma unroll
+      for (int i = 0; i < TMB; ++i) {
+        const int m = m0 + wm * TMB * 16 + i * 16 + r16;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (m >= p.M || !n_ok) continue;
+        const long o = static_cast<long>(m) * p.N + n;
+        if (p.bias) { v[0] += rbias[j].x; v[1] += rbias[j].y; v[2] += rbias[j].z; v[3] += rbias[j].w; }
+        if (p.scale) {
+          v[0] = v[0] * rscale[j].x + rshift[j].x; v[1] = v[1] * rscale[j].y + rshift[j].y;
+          v[2] = v[2] * rscale[j].z + rshift[j].z; v[3] = v[3] * rscale[j].w + rshift[j].w;
+        }
+        if (p.rowvec) {
+          const float4 t = ld4(p.rowvec + static_cast<long>(m / p.rows_per_img) * p.rowvec_ld + n);
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+        }
+        if (p.act == DIFFSAL_ACT_GELU_GRAD) {
+          const float4 t = rres[i][j];
+          v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
+        } else if (resid) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+        st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
+      }
+    }
+  };
+
+  // ---- prologue: P slices in flight; slice 0 must have landed before anyone reads it
+#pragma unroll
+  for (int s = 0; s < P; ++s) issue_slice(s);
+  wait_vmcnt<(P - 1) * PPW>();
+  __builtin_amdgcn_s_barrier();
+  load_frags(smem, 0, 0);
+
+  // one K slice: stage S is multiplied, stage S + 1 is read ahead, stage S - 1 (free after the barrier) takes the DMA of slice g + P
+  auto step = [&](auto idx) __attribute__((always_inline)) {
+    constexpr int S = decltype(idx)::value;
+    const float* cur = smem + S * STAGE_F;
+    const float* nxt = smem + ((S + 1) % STAGES) * STAGE_F;
+    load_frags(cur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // slice g + 1 (this wave's pieces) has landed; after the barrier every wave's pieces have, and nobody reads the stage of
+    // slice g - 1 any more
+    wait_vmcnt<WAIT_N>();
+    __builtin_amdgcn_s_barrier();
+    issue_slice((S + P) % STAGES);
+    load_frags(nxt, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    do_mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ring = [&](auto self, auto idx) __attribute__((always_inline)) {
+    constexpr int S = decltype(idx)::value;
+    if constexpr (S < STAGES) {
+      step(idx);
+      self(self, std::integral_constant<int, S + 1>{});
+    }
+  };
+  for (int t = 0; t < my_tiles; ++t) {          // the host guarantees nkt % STAGES == 0: a tile starts on stage 0
+    for (int kt = 0; kt < nkt; kt += STAGES) {
+      if (kt + STAGES >= nkt) fetch_epilogue_operands();
+      ring(ring, std::integral_constant<int, 0>{});
+    }
+    finish_tile();
+    cmp_v += gsz;
+  }
+}
+
+namespace {
+
+template <int TMB, int TNB, int STAGES, int OCC>
+int launch_dma(DmaGemmArgs& a, hipStream_t s) {
+  constexpr int BM = 32 * TMB, BN = 32 * TNB;
+  a.n_tiles_m = (a.M + BM - 1) / BM;
+  a.n_tiles_n = (a.N + BN - 1) / BN;
+  a.n_tiles = a.n_tiles_m * a.n_tiles_n;
+  const int slots = 256 * OCC;
+  const int grid = a.n_tiles < slots ? a.n_tiles : slots;
+  a.xcd_order = (tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC>), dim3(grid), dim3(256), 0, s, a);
+  return check_launch("diffsal_conv_igemm(dma)");
+}
+
+}  // namespace
+
+// Tile shapes of this kernel, in the order of TUNE_GEMM_DMA's value - 1.
+//   0: 96 x 96, 3 stages (72 KB), two workgroups per CU      1: 96 x 96, 6 stages (144 KB), one per CU
+//   2: 96 x 192, 4 stages (144 KB), one per CU               3: 96 x 192, 3 stages (108 KB), one per CU
+// Returns 1 if launched, 0 if the shape is not handled, < 0 on error.
+int try_gemm_dma(int cfg, const float* a, const float* w, const float* bias, const float* scale, const float* shift,
+                 const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M, int K, int N,
+                 int act, hipStream_t s) {
+  const int stages = cfg == 1 ? 6 : cfg == 2 ? 4 : 3;
+  if ((K / 32) % stages != 0) return 0;   // a tile must start on ring stage 0
+  if (K % 32 != 0 || N % 4 != 0 || M <= 0 || M >= (1L << 31) / (K > N ? K : N) / 4) return 0;   // 32-bit byte offsets
+  if (!aligned16(a) || !aligned16(w) || !aligned16(out) || (bias && !aligned16(bias)) || (scale && !(aligned16(scale) && aligned16(shift))) ||
+      (rowvec && !(aligned16(rowvec) && rowvec_ld % 4 == 0)) || (residual && !aligned16(residual)))
+    return 0;
+  DmaGemmArgs g{a, w, bias, scale, shift, rowvec, residual, out, static_cast<int>(M), N, K, act, rowvec_ld, rows_per_img, 0, 0, 0, 0};
+  int rc;
+  switch (cfg) {
+    case 0: rc = launch_dma<3, 3, 3, 2>(g, s); break;
+    case 1: rc = launch_dma<3, 3, 6, 1>(g, s); break;
+    case 2: rc = launch_dma<3, 6, 4, 1>(g, s); break;
+    case 3: rc = launch_dma<3, 6, 3, 1>(g, s); break;
+    default: return 0;
+  }
+  return rc == DIFFSAL_OK ? 1 : rc;
+}
+
+}  // namespace diffsal

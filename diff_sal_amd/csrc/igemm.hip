@@ -36,6 +36,11 @@ int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, co
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
                       int K, int N, int act, hipStream_t s);
 
+// gemm_dma.hip: plain fp32 products with LDS-DMA staging, 96-wide tiles
+int try_gemm_dma(int cfg, const float* a, const float* w, const float* bias, const float* scale, const float* shift,
+                 const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M, int K, int N,
+                 int act, hipStream_t s);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct IgemmArgs {
@@ -999,6 +1004,11 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
       d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) && !px &&
       d->act != DIFFSAL_ACT_GELU_GRAD) {
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
+    if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+  }
+  if (a.linear && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 && !px && tune(TUNE_GEMM_DMA) > 0) {
+    const int r = try_gemm_dma(tune(TUNE_GEMM_DMA) - 1, in, w, bias, scale, shift, rowvec, a.rowvec_ld, d->Ho * d->Wo, residual, out, M,
+                               a.K, d->Cout, d->act, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
   Plan pl = choose_plan(M, d->Cout, a.K, d->precision, a.linear != 0);

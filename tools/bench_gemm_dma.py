@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""A/B of the LDS-DMA GEMM (csrc/gemm_dma.hip) against the planner's kernel on the plain products of one fp32 step (B = 4):
+correctness against an fp64 product, then interleaved timing rounds in ONE process.  GPU only.
+usage: tools/bench_gemm_dma.py [filter] [--cfgs 1,2,3,4] [--rounds 5]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_sal_amd import _lib, ops  # noqa: E402
+
+# name, M, K, N, bias, act, residual
+SHAPES = [
+    ("s0.q      ", 3024, 768, 768, True, 0, False),
+    ("s0.proj   ", 3024, 768, 768, True, 0, True),
+    ("s0.fc1    ", 3024, 768, 1536, True, 2, False),
+    ("s0.fc2    ", 3024, 1536, 768, True, 0, True),
+    ("s1.tap    ", 3024, 768, 3456, False, 0, False),
+    ("s1.q      ", 12096, 384, 384, True, 0, False),
+    ("s1.proj   ", 12096, 384, 384, True, 0, True),
+    ("s1.fc1    ", 12096, 384, 768, True, 2, False),
+    ("s1.fc2    ", 12096, 768, 384, True, 0, True),
+    ("s2.tap    ", 12096, 384, 1728, False, 0, False),
+    ("s2.q      ", 48384, 192, 192, True, 0, False),
+    ("s2.proj   ", 48384, 192, 192, True, 0, True),
+    ("s2.fc1    ", 48384, 192, 384, True, 2, False),
+    ("s2.fc2    ", 48384, 384, 192, True, 0, True),
+    ("s3.tap    ", 48384, 192, 864, False, 0, False),
+    ("mt.tap    ", 28560, 768, 864, False, 0, False),
+    ("kv s0     ", 648, 768, 768, True, 0, False),
+    ("nin0      ", 21504, 96, 192, True, 0, False),
+    ("nin1      ", 5376, 192, 384, True, 0, False),
+    ("nin2      ", 1344, 384, 768, True, 0, False),
+    ("ragged    ", 3000, 288, 200, True, 1, True),
+]
+
+
+def run(x, w, b, act, res):
+    return ops.linear(x, w, b, act=act, residual=res)
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    cfgs = [1, 2, 3, 4]
+    rounds = 5
+    flt = ""
+    i = 0
+    while i < len(args):
+        if args[i] == "--cfgs":
+            cfgs = [int(c) for c in args[i + 1].split(",")]
+            i += 2
+        elif args[i] == "--rounds":
+            rounds = int(args[i + 1])
+            i += 2
+        else:
+            flt = args[i]
+            i += 1
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    print(f"{'shape':10s} {'M':>6s} {'K':>5s} {'N':>5s} | {'planner us (TF/s)':>20s} | " + " | ".join(f"dma cfg {c} us (TF/s) err" for c in cfgs))
+    for name, M, K, N, has_b, act, has_r in SHAPES:
+        if flt and flt not in name:
+            continue
+        x = torch.randn(M, K, device=dev, generator=g)
+        w = torch.randn(N, K, device=dev, generator=g) * (K ** -0.5)
+        b = torch.randn(N, device=dev, generator=g) if has_b else None
+        res = torch.randn(M, N, device=dev, generator=g) if has_r else None
+        ref = x.double() @ w.double().t()
+        if b is not None:
+            ref = ref + b.double()
+        if act == 1:
+            ref = torch.relu(ref)
+        elif act == 2:
+            ref = torch.nn.functional.gelu(ref)
+        if res is not None:
+            ref = ref + res.double()
+        scale = ref.abs().max().item()
+        variants = [0] + cfgs
+        errs, times = {}, {v: [] for v in variants}
+        for v in variants:
+            _lib.set_tuning("DIFFSAL_GEMM_DMA", v if v else None)
+            y = run(x, w, b, act, res)
+            torch.cuda.synchronize()
+            errs[v] = ((y.double() - ref).abs().max().item()) / scale
+        reps = 20
+        for _ in range(rounds):
+            for v in variants:
+                _lib.set_tuning("DIFFSAL_GEMM_DMA", v if v else None)
+                run(x, w, b, act, res)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run(x, w, b, act, res)
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) * 1e3 / reps)
+        _lib.set_tuning("DIFFSAL_GEMM_DMA", None)
+        fl = 2.0 * M * K * N
+        cells = []
+        for v in variants:
+            t = sorted(times[v])[len(times[v]) // 2]
+            cells.append(f"{t:7.1f} ({fl / t / 1e6:5.1f}) {errs[v]:.1e}")
+        print(f"{name:10s} {M:6d} {K:5d} {N:5d} | " + " | ".join(cells), flush=True)
+
+
+if __name__ == "__main__":
+    main()
