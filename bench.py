@@ -68,6 +68,76 @@ def class_table(events, mfma_peak_tflops):
     return rows
 
 
+def kernel_table(events, mfma_peak_tflops):
+    """The GEMM-family operator launches of ONE step grouped by the kernel the library launched for them
+    (diffsal_last_gemm_kernel(), recorded by ops at the call site): launches, HIP-event time, FLOPs actually issued, matrix-pipe
+    rate.  Sorted by time: the first row is the dominant kernel."""
+    agg = {}
+    for e0, e1, fl, cls, nb, *rest in events:
+        if cls not in GEMM_CLASSES:
+            continue
+        name = (rest[1] if len(rest) > 1 and rest[1] else f"({cls})").split(" [")[0]
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += fl
+        a[2] += e0.elapsed_time(e1)
+    rows = []
+    for name in sorted(agg, key=lambda k: -agg[k][2]):
+        n, fl, ms = agg[name]
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        rows.append({"name": name, "launches_per_step": n, "avg_us": round(ms * 1e3 / n, 2), "ms_per_step": round(ms, 4),
+                     "gflop_per_step": round(fl / 1e9, 2), "tflops": round(tf, 2), "frac": round(tf / mfma_peak_tflops, 4)})
+    return rows
+
+
+def profiled_kernel(name, precision, bid):
+    """rocprofv3 evidence for `name` from the newest profiles/rNN_{precision}_kernel_stats.csv / rNN_pmc_mfma_busy_{precision}.md of
+    THIS build (profiles/rNN_manifest.jsonl lists the build of every artefact; other builds are refused)."""
+    pdir = os.path.join(ROOT, "profiles")
+    out = {"profile_avg_us": None, "mfma_busy": None, "profile_source": None}
+    if not os.path.isdir(pdir) or bid is None:
+        return out
+    builds = {}
+    for mf in sorted(f for f in os.listdir(pdir) if f.endswith("_manifest.jsonl")):
+        for line in open(os.path.join(pdir, mf)):
+            try:
+                j = json.loads(line)
+                builds[j.get("file")] = j.get("build")
+            except Exception:  # noqa: BLE001
+                pass
+    key = name.split(" [")[0]
+    stats = sorted(f for f in os.listdir(pdir) if f.endswith(f"_{precision}_kernel_stats.csv"))
+    busy = sorted(f for f in os.listdir(pdir) if f.endswith(f"_pmc_mfma_busy_{precision}.md"))
+    notes = []
+    if stats:
+        f = stats[-1]
+        if builds.get(f) == bid:
+            import csv
+            for row in csv.DictReader(open(os.path.join(pdir, f))):
+                if key in row.get("Name", ""):
+                    out["profile_avg_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+                    break
+            notes.append(f"profiles/{f}")
+        else:
+            notes.append(f"profiles/{f} is from build {builds.get(f)}, this is {bid}: refused")
+    if busy:
+        f = busy[-1]
+        txt = open(os.path.join(pdir, f)).read()
+        if f"build {bid}" in txt.splitlines()[0]:
+            for line in txt.splitlines():
+                if line.startswith("| `") and key in line:
+                    try:
+                        out["mfma_busy"] = float(line.rstrip(" |").split("|")[-1])
+                    except ValueError:
+                        pass
+                    break
+            notes.append(f"profiles/{f}")
+        else:
+            notes.append(f"profiles/{f} is not from build {bid}: refused")
+    out["profile_source"] = "; ".join(notes) if notes else None
+    return out
+
+
 def median(v):
     v = sorted(v)
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
@@ -564,6 +634,8 @@ def main():
     ap.add_argument("--dump-launches", default=None,
                     help="write every operator launch of the profiled step (class, GFLOP, MB, us, TF/s, GB/s) to this JSON file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-trajectory", action="store_true",
+                    help="cpu_baseline without its one 50-NFE single-clip trajectory (~10-15 s of CPU time)")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the `train` object (BASELINE configs[3]: ~10 full-model AV training steps per rank, with the "
                          "gradient exchange report) that the default line carries at every N")
@@ -711,7 +783,7 @@ def main():
         rows = []
         for e0, e1, fl, cls, nb, *note in all_ev:
             us = e0.elapsed_time(e1) * 1e3
-            rows.append({"class": cls, "op": note[0] if note else "", "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3), "us": round(us, 2),
+            rows.append({"class": cls, "op": note[0] if note else "", "kernel": note[1] if len(note) > 1 else "", "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3), "us": round(us, 2),
                          "tflops": round(fl / us / 1e6, 2) if us > 0 else 0.0, "gbs": round(nb / us / 1e3, 1) if us > 0 else 0.0})
         json.dump({"precision": args.precision, "mode": args.mode, "batch": B, "launches": rows}, open(args.dump_launches, "w"), indent=0)
     peak_for_mode = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
@@ -767,32 +839,39 @@ def main():
                      "direct_graph_tflops": round(ref_flops / (ref_ms * 1e-3) / 1e12, 2) if ref_ms > 0 else None,
                      "note": "direct_graph_* = the reference's own graph on the same kernels (tap_conv off), one profiled step outside "
                              "the timed regions; *_equivalent prices its GEMM FLOPs at the time the shipped path needs for them"}
-    if args.precision == "fp32" and ref_graph is not None:
-        # `achieved` = ALGORITHMIC FLOPs (the reference graph's GEMM FLOPs, SURVEY 8d: K4+K5+K10+K12+K13+K14 = 149.44 GF per
-        # clip-step; measured here by running that graph once) / HIP-event time of the launches that implement those layers
-        # in the shipped step (GEMM family + tap gathers); the FLOPs actually executed stand beside it.
-        n_alg = n_launch + sum(1 for e in all_ev if e[3] in ("K12-tap", "K14-tap"))
-        alg_ms = ref_graph["ms_gemm_plus_tap_gathers"]
+    ktab = kernel_table(all_ev, peak_for_mode)
+    dominant = None
+    if ktab:
+        dominant = dict(ktab[0])
+        dominant["share_of_step_in_kernel"] = round(dominant["ms_per_step"] / max(common["step_ms_all_kernels"], 1e-9), 4)
+        dominant.update(profiled_kernel(dominant["name"], args.precision, bid))
+        dominant["note"] = ("launches / avg_us / tflops measured live with HIP events around the operator launches of one timed step (the library "
+                            "names the kernel it launched: diffsal_last_gemm_kernel); profile_avg_us / mfma_busy are read from the same-build "
+                            "rocprofv3 artefacts under profiles/ when they exist (SQ_VALU_MFMA_BUSY_CYCLES / all SIMD cycles)")
+    common["kernels"] = ktab
+    if args.precision == "fp32":
+        # roofline.achieved / frac = the matrix-pipe rate on the FLOPs the GEMM family actually ISSUES in one step (every
+        # implicit-GEMM, Winograd, DMA-GEMM and fused-block launch; HIP-event time of exactly those launches): a kernel figure,
+        # never above 1.  The reference graph's GEMM FLOPs priced at the shipped time (the contract's "algorithmic" figure; the
+        # shipped step issues ~half of them: tap GEMMs at the source resolution, Winograd F(2x2,3x3), composed conv_in) stand
+        # beside it as achieved_reference_graph / frac_reference_graph and may pass 1.
         roofline = {
-            "kernel": "diffsal::igemm_kernel / igemm_linear_kernel / wino_gemm_kernel / lin_stream_kernel / mlp_block_kernel / block_front_kernel (fp32 MFMA GEMM family: "
-                      "3x3 convs, token GEMMs, ReduceTemp, fused transformer-block halves) + tapsum_kernel (gathers of the restructured convolutions)",
-            "bound": "mfma", "achieved": ref_graph["tflops_equivalent"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ref_graph["frac_equivalent"], "traffic": None if traffic is None else traffic * n_launch / n_alg,
-            "executed_mfma_tflops": round(achieved, 2), "executed_frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "note": "achieved = algorithmic FLOPs of the reference graph / time of the launches implementing them; the shipped "
-                    "step executes fewer FLOPs (conv3x3(upsample(x)) runs as low-resolution tap GEMMs + a gather, exact; the ResnetBlock and two "
-                    "UpEmbed 3x3 convolutions run as Winograd F(2x2,3x3), 16 instead of 36 products per tile), "
-                    "executed_* is the matrix-pipe rate on the FLOPs actually issued -- the number to read as kernel quality; `frac` prices the "
-                    "reference graph's FLOPs and can therefore pass 1.0 (48 % of its products are never issued)",
-            "reference_graph": ref_graph, **common,
-            "launches_per_step": n_alg, "avg_launch_us": round(alg_ms * 1e3 / n_alg, 2),
-            "flops_per_launch": ref_graph["gemm_gflop_per_step"] * 1e9 / n_alg, "step_ms_in_kernel": alg_ms}
-    elif args.precision == "fp32":
-        roofline = {
-            "kernel": "diffsal::igemm_kernel / igemm_linear_kernel / wino_gemm_kernel / lin_stream_kernel / mlp_block_kernel (fp32 MFMA GEMM family: "
-                      "3x3 convs, token GEMMs, ReduceTemp, fused MLP)",
+            "kernel": "fp32 MFMA GEMM family of one step: diffsal::gemm_dma_kernel / igemm_kernel / igemm_linear_kernel / wino_gemm_kernel / "
+                      "lin_stream_kernel / mlp_block_kernel / block_front_kernel (3x3 convs, token GEMMs, tap GEMMs, ReduceTemp, fused "
+                      "transformer-block halves); per kernel: `kernels`, the largest: `dominant_kernel`",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **common}
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "executed_mfma_tflops": round(achieved, 2), "executed_frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "dominant_kernel": dominant,
+            "note": "achieved = FLOPs actually issued by the GEMM-family launches of one step / HIP-event time of exactly those launches "
+                    "(kernel quality; <= 1 by construction).  *_reference_graph = the reference graph's GEMM FLOPs (SURVEY 8d) priced at the "
+                    "time the shipped launches that implement those layers need (GEMM family + tap gathers): an end-to-end figure that can "
+                    "pass 1 because about half of the reference graph's products are never issued",
+            **common}
+        if ref_graph is not None:
+            roofline["achieved_reference_graph"] = ref_graph["tflops_equivalent"]
+            roofline["frac_reference_graph"] = ref_graph["frac_equivalent"]
+            roofline["reference_graph"] = ref_graph
     elif args.precision == "bf16x3":   # three bf16 MFMAs per fp32-accurate product: the instruction-level peak is the bf16 one
         roofline = {
             "kernel": "diffsal::igemm_kernel<..., bf16x3> (split-precision bf16 MFMA implicit GEMM, fp32 accumulate)",
@@ -806,7 +885,7 @@ def main():
             "kernel": f"diffsal::igemm16_kernel / igemm16_linear_kernel / conv16_halo_kernel / block16_kernel / block_front_kernel <{args.precision}> "
                       f"(native 16-bit MFMA GEMM family on {args.precision} storage, fp32 accumulate)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **common}
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "dominant_kernel": dominant, **common}
 
     DT_LABEL = {"fp32": "f32", "bf16x3": "f32 in/out, bf16x3 split-precision MFMA (NOT the headline configuration)",
                 "bf16": "bf16 storage, f32 accumulate (NOT the headline configuration; BASELINE configs[1] as written)",
@@ -969,8 +1048,37 @@ def main():
             "value": round(B * args.cpu_steps / cdt, 4), "unit": "denoise-steps/s", "cores": nthreads, "kind": "port",
             "sample": f"{args.cpu_steps} SalUNet evaluations at batch {B} (fp32, eval, torch CPU oracle, "
                       f"{nthreads} of {os.cpu_count()} host threads: more threads are slower), "
-                      f"{cdt:.1f} s; solver update excluded (negligible)",
+                      f"{cdt:.1f} s; solver update excluded (negligible).  Also (BASELINE.md section 3): `batch1` = the same at one clip "
+                      f"per evaluation, `dpm50_batch1` = ONE whole 50-NFE DPM-Solver trajectory of one clip (the oracle network under the "
+                      f"sampler's host arithmetic)",
         }
+        # BASELINE.md section 3's other two CPU points: single-clip evaluations, and one complete 50-NFE trajectory
+        n1 = max(1, min(16, nthreads))
+        torch.set_num_threads(n1)
+        x1, f1, a1 = xc[:1], [f[:1] for f in fc], None if ac is None else ac[:1]
+        with torch.no_grad():
+            c0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                orc.salunet_forward(sd, ocfg, x1, tcpu[:1], f1, a1)
+            c1 = time.perf_counter() - c0
+            result["cpu_baseline"]["batch1"] = {"value": round(args.cpu_steps / c1, 4), "unit": "denoise-steps/s", "cores": n1,
+                                                "sample": f"{args.cpu_steps} evaluations at batch 1, {c1:.1f} s"}
+            if not args.no_cpu_trajectory:
+                nfe = [0]
+
+                def cpu_net(x, t, f, a=None):
+                    nfe[0] += 1
+                    return orc.salunet_forward(sd, ocfg, x, t.to(torch.float32), f, a)
+
+                cpu_top = type("CpuTop", (), {"decoder_net": staticmethod(cpu_net)})()
+                cpu_sampler = DiffusionSampler(cpu_top, timesteps=NFE_PER_TRAJECTORY, sample_type="dpmsolver", skip_type="logSNR",
+                                               denoise=True, training_target="x0")
+                c0 = time.perf_counter()
+                cpu_sampler.sample_dpm_solver(x1, f1, a1)
+                c2 = time.perf_counter() - c0
+                result["cpu_baseline"]["dpm50_batch1"] = {
+                    "value": round(nfe[0] / c2, 4), "unit": "denoise-steps/s", "cores": n1, "nfe": nfe[0], "seconds": round(c2, 2),
+                    "sample": "one 50-NFE DPM-Solver trajectory (multistep-2, logSNR, denoise-to-zero) of one clip, host loop included"}
     if rank == 0:
         emit(result)
     if world > 1:

@@ -11,6 +11,8 @@
 namespace diffsal {
 
 void set_error(const char* fmt, ...);
+// which kernel (and tile plan) the GEMM-family entry points launched last on this thread: diffsal_last_gemm_kernel()
+void note_kernel(const char* fmt, ...);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

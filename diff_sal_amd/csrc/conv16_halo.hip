@@ -299,6 +299,7 @@ static int launch_halo(HaloArgs<T>& a, hipStream_t s) {
   DS_RAISE_DYNAMIC_LDS((conv16_halo_kernel<TW, NW, TN, T>), 160 * 1024);
   const long blocks = static_cast<long>(a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
   hipLaunchKernelGGL((conv16_halo_kernel<TW, NW, TN, T>), dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), lds, s, a);
+  note_kernel("conv16_halo_kernel<%d, %d, %d> [16x%d pixels x %d channels]", TW, NW, TN, TW, TN * 32);
   return check_launch("diffsal_conv_igemm(16-bit halo)");
 }
 

@@ -132,18 +132,24 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   };
   descriptors(iss_v);
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)smem)) + wave * 1024u;
-  auto issue_slice = [&](int stage) __attribute__((always_inline)) {
+  // piece q of the slice being issued: q < APW rows of A, else rows of W
+  auto issue_piece = [&](int stage, int q) __attribute__((always_inline)) {
     const unsigned st = lds_base + static_cast<unsigned>(stage * STAGE_F * 4);
     const unsigned kofs = static_cast<unsigned>(iss_kt) * 128u;
-#pragma unroll
-    for (int q = 0; q < APW; ++q) dma_piece(st + q * 4096u, voff[q], rs_a, kofs);
-#pragma unroll
-    for (int q = 0; q < BPW; ++q) dma_piece(st + (BM * 32 + q * 1024) * 4u, voff[q], rs_b, kofs);
+    if (q < APW) dma_piece(st + q * 4096u, voff[q], rs_a, kofs);
+    else dma_piece(st + (BM * 32 + (q - APW) * 1024) * 4u, voff[q - APW], rs_b, kofs);
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
     if (++iss_kt == nkt) {
       iss_kt = 0;
       iss_v += gsz;
       descriptors(iss_v);
     }
+  };
+  auto issue_slice = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) issue_piece(stage, q);
+    issue_advance();
   };
 
   // ---- compute side: fragment addresses (floats inside a stage) for the two 16-wide halves of a slice
@@ -168,25 +174,23 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
     for (int j = 0; j < TNB; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
   float4 fa[2][TMB], fb[2][TNB];
+  auto load_frag = [&](const float* st, int h, int set, int f) __attribute__((always_inline)) {   // f < TMB: A block f, else W block
+    if (f < TMB) fa[set][f] = ld4(st + a_off[f][h]);
+    else fb[set][f - TMB] = ld4(st + b_off[f - TMB][h]);
+  };
   auto load_frags = [&](const float* st, int h, int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TMB; ++i) fa[set][i] = ld4(st + a_off[i][h]);
-#pragma unroll
-    for (int j = 0; j < TNB; ++j) fb[set][j] = ld4(st + b_off[j][h]);
+    for (int f = 0; f < TMB + TNB; ++f) load_frag(st, h, set, f);
+  };
+  auto mfma_one = [&](int set, int idx) __attribute__((always_inline)) {   // idx = (c * TMB + i) * TNB + j
+    const int c = idx / (TMB * TNB), i = (idx / TNB) % TMB, j = idx % TNB;
+    const float av = c == 0 ? fa[set][i].x : c == 1 ? fa[set][i].y : c == 2 ? fa[set][i].z : fa[set][i].w;
+    const float bv = c == 0 ? fb[set][j].x : c == 1 ? fb[set][j].y : c == 2 ? fb[set][j].z : fb[set][j].w;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
   };
   auto do_mfmas = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int i = 0; i < TMB; ++i) {
-        const float av = c == 0 ? fa[set][i].x : c == 1 ? fa[set][i].y : c == 2 ? fa[set][i].z : fa[set][i].w;
-#pragma unroll
-        for (int j = 0; j < TNB; ++j) {
-          const float bv = c == 0 ? fb[set][j].x : c == 1 ? fb[set][j].y : c == 2 ? fb[set][j].z : fb[set][j].w;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
-        }
-      }
-    }
+    for (int idx = 0; idx < 4 * TMB * TNB; ++idx) mfma_one(set, idx);
   };
 
   int cmp_v = bid;
@@ -216,55 +220,70 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
       }
     }
   };
-  auto touch = [](const float4& x) __attribute__((always_inline)) { asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); };
-  auto finish_tile = [&]() __attribute__((always_inline)) {
+  // act_c: the activation as a compile-time constant (one straight-line copy of the loop per activation, chosen by ONE scalar
+  // branch per tile: with the choice inside the loop every 16 x 16 block re-tested it)
+  auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value;
     int tmi, tni;
     tile_mn(cmp_v, tmi, tni);
-    const int m0 = tmi * BM, n0 = tni * BN;
+    const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
+    const long o0 = static_cast<long>(mb) * p.N + nb;
+    float* __restrict__ ob = outp + o0;
+    const float* __restrict__ rvb = p.rowvec;
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) {
+      const bool n_ok = nb + j * 16 < p.N;
+#pragma unroll
+      for (int i = 0; i < TMB; ++i) {
+        const int m = mb + i * 16;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) { v[0] += rbias[j].x; v[1] += rbias[j].y; v[2] += rbias[j].z; v[3] += rbias[j].w; }
+        if (p.scale) {
+          v[0] = v[0] * rscale[j].x + rshift[j].x; v[1] = v[1] * rscale[j].y + rshift[j].y;
+          v[2] = v[2] * rscale[j].z + rshift[j].z; v[3] = v[3] * rscale[j].w + rshift[j].w;
+        }
+        if (rvb) {
+          const int mc = m < p.M ? m : p.M - 1;
+          const float4 t = ld4(rvb + static_cast<long>(mc / p.rows_per_img) * p.rowvec_ld + (n_ok ? nb + j * 16 : 0));
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if constexpr (ACT == DIFFSAL_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if constexpr (ACT == DIFFSAL_ACT_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if constexpr (ACT == DIFFSAL_ACT_SIGMOID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
+        }
+        if constexpr (ACT == DIFFSAL_ACT_GELU_GRAD) {
+          const float4 t = rres[i][j];
+          v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
+        } else {
+          if (resid) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+        }
+        if (m < p.M && n_ok) st4(ob + (static_cast<long>(i) * 16 * p.N + j * 16), make_float4(v[0], v[1], v[2], v[3]));
+      }
+    }
+  };
+  auto touch = [](const float4& x) __attribute__((always_inline)) { asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); };
+  auto finish_tile = [&]() __attribute__((always_inline)) {
     // an unconditional use of every prefetched register: hipcc then knows that no request is pending when the next tile's
-    // prefetch overwrites them (otherwise it waits vmcnt(0) in front of every one of those loads, draining the ring)
+    // prefetch overwrites them
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
       touch(rbias[j]); touch(rscale[j]); touch(rshift[j]);
 #pragma unroll
       for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
     }
-#pragma unroll
-    for (int j = 0; j < TNB; ++j) {
-      const int n = n0 + wn * TNB * 16 + j * 16 + 4 * q4;
-      const bool n_ok = n < p.N;
-#pragma unroll
-      for (int i = 0; i < TMB; ++i) {
-        const int m = m0 + wm * TMB * 16 + i * 16 + r16;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (m >= p.M || !n_ok) continue;
-        const long o = static_cast<long>(m) * p.N + n;
-        if (p.bias) { v[0] += rbias[j].x; v[1] += rbias[j].y; v[2] += rbias[j].z; v[3] += rbias[j].w; }
-        if (p.scale) {
-          v[0] = v[0] * rscale[j].x + rshift[j].x; v[1] = v[1] * rscale[j].y + rshift[j].y;
-          v[2] = v[2] * rscale[j].z + rshift[j].z; v[3] = v[3] * rscale[j].w + rshift[j].w;
-        }
-        if (p.rowvec) {
-          const float4 t = ld4(p.rowvec + static_cast<long>(m / p.rows_per_img) * p.rowvec_ld + n);
-          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-        }
-        if (p.act == DIFFSAL_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == DIFFSAL_ACT_GELU_ERF) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.act == DIFFSAL_ACT_SIGMOID) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
-        }
-        if (p.act == DIFFSAL_ACT_GELU_GRAD) {
-          const float4 t = rres[i][j];
-          v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
-        } else if (resid) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-        st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
-      }
+    switch (p.act) {
+      case DIFFSAL_ACT_RELU: epilogue(std::integral_constant<int, DIFFSAL_ACT_RELU>{}); break;
+      case DIFFSAL_ACT_GELU_ERF: epilogue(std::integral_constant<int, DIFFSAL_ACT_GELU_ERF>{}); break;
+      case DIFFSAL_ACT_SIGMOID: epilogue(std::integral_constant<int, DIFFSAL_ACT_SIGMOID>{}); break;
+      case DIFFSAL_ACT_GELU_GRAD: epilogue(std::integral_constant<int, DIFFSAL_ACT_GELU_GRAD>{}); break;
+      default: epilogue(std::integral_constant<int, DIFFSAL_ACT_NONE>{}); break;
     }
   };
 
@@ -288,10 +307,24 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
     // slice g - 1 any more
     wait_vmcnt<WAIT_N>();
     __builtin_amdgcn_s_barrier();
-    issue_slice((S + P) % STAGES);
-    load_frags(nxt, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    do_mfmas(1);
+    // second half of the slice: its MFMAs (operands already in registers) with the DMA pieces of slice g + P and the fragment
+    // reads of slice g + 1 slipped between them, one every GAP MFMAs -- a wave alone on its SIMD must not stop issuing MFMAs
+    // for the ~60 cycles a DMA instruction takes to issue
+    {
+      constexpr int NM = 4 * TMB * TNB, NX = PPW + TMB + TNB, GAP = NM / NX > 0 ? NM / NX : 1;
+#pragma unroll
+      for (int idx = 0; idx < NM; ++idx) {
+        mfma_one(1, idx);
+        if ((idx + 1) % GAP == 0 && (idx + 1) / GAP <= NX) {
+          const int x = (idx + 1) / GAP - 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (x < TMB + TNB) load_frag(nxt, 0, 0, x);        // reads first: the next step's first MFMAs wait for them
+          else issue_piece((S + P) % STAGES, x - TMB - TNB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      issue_advance();
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   auto ring = [&](auto self, auto idx) __attribute__((always_inline)) {
@@ -323,6 +356,7 @@ int launch_dma(DmaGemmArgs& a, hipStream_t s) {
   const int grid = a.n_tiles < slots ? a.n_tiles : slots;
   a.xcd_order = (tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
   hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC>), dim3(grid), dim3(256), 0, s, a);
+  note_kernel("gemm_dma_kernel<%d, %d, %d, %d> [%dx%d tile, %d stages]", TMB, TNB, STAGES, OCC, BM, BN, STAGES);
   return check_launch("diffsal_conv_igemm(dma)");
 }
 

@@ -895,12 +895,15 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
     const bool no_xcd = tune(TUNE_NO_XCD_ORDER) == 1;
     a.xcd_order = (!no_xcd && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm_linear_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, s, a);
+    note_kernel("igemm_linear_kernel<%d, %d, %d, %d> [%dx%d tile]", WM, WN, TM, TN, BM, BN);
     return check_launch("diffsal_conv_igemm(linear)");
   }
   if (precision == DIFFSAL_PREC_BF16X3)
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 1>), dim3(a.n_tiles, a.splits, nz), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, 0>), dim3(a.n_tiles, a.splits, nz), dim3(256), 0, s, a);
+  note_kernel("igemm_kernel<%d, %d, %d, %d, %d> [%dx%d tile, split-K %d%s]", WM, WN, TM, TN, precision == DIFFSAL_PREC_BF16X3 ? 1 : 0, BM, BN,
+              a.splits, a.pair ? ", pair" : "");
   int rc = check_launch("diffsal_conv_igemm");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);
@@ -1004,12 +1007,21 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
       d->Ho == d->H && d->Wo == d->W && !scale && !rowvec && aligned16(out) && (!residual || aligned16(residual)) && !px &&
       d->act != DIFFSAL_ACT_GELU_GRAD) {
     const int r = try_linear_stream(in, w, bias, residual, out, M, d->Cin, d->Cout, d->act, s);
+    if (r > 0) note_kernel("lin_stream_kernel [K=%d, N=%d]", d->Cin, d->Cout);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
-  if (a.linear && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 && !px && tune(TUNE_GEMM_DMA) > 0) {
-    const int r = try_gemm_dma(tune(TUNE_GEMM_DMA) - 1, in, w, bias, scale, shift, rowvec, a.rowvec_ld, d->Ho * d->Wo, residual, out, M,
-                               a.K, d->Cout, d->act, s);
-    if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+  // Plain products with K a multiple of 96 and enough 96 x 96 tiles to fill the chip: the LDS-DMA kernel (gemm_dma.hip).
+  // Measured (tools/bench_gemm_dma.py, B = 4 shapes): faster than the planner's choice from ~192 tiles on (M = 3024: 1.35x,
+  // M = 12096: 1.1-1.2x, M = 48384: 1.0-1.05x), slower below (M = 648 / 1344: split-K and 64 x 64 tiles fill the chip better).
+  // DIFFSAL_GEMM_DMA=0 switches it off, 1..4 force one of its tile configurations on every shape it accepts.
+  if (a.linear && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 && !px && tune(TUNE_GEMM_DMA) != 0 && tune(TUNE_IGEMM_CFG) < 0) {
+    const long tiles96 = ((M + 95) / 96) * ((d->Cout + 95) / 96);
+    const int forced = tune(TUNE_GEMM_DMA);
+    if (forced > 0 || (tiles96 >= 192 && a.K % 96 == 0)) {
+      const int r = try_gemm_dma(forced > 0 ? forced - 1 : 0, in, w, bias, scale, shift, rowvec, a.rowvec_ld, d->Ho * d->Wo, residual, out,
+                                 M, a.K, d->Cout, d->act, s);
+      if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+    }
   }
   Plan pl = choose_plan(M, d->Cout, a.K, d->precision, a.linear != 0);
   if (tune(TUNE_IGEMM_CFG) >= 0) {   // tuning aid: force a tile shape (no split-K)

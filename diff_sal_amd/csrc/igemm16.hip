@@ -666,9 +666,11 @@ static int launch16(Igemm16Args<T>& a, hipStream_t s) {
     const int grid = a.n_tiles < a.persist_wgs ? a.n_tiles : a.persist_wgs;
     a.xcd_order = (tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= a.persist_wgs && a.n_tiles_n > 1 && tiles_m >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm16_linear_kernel<WM, WN, TM, TN, T>), dim3(grid), dim3(256), 0, s, a);
+    note_kernel("igemm16_linear_kernel<%d, %d, %d, %d> [%dx%d tile]", WM, WN, TM, TN, BM, BN);
     return check_launch("diffsal_conv_igemm(16-bit linear)");
   }
   hipLaunchKernelGGL((igemm16_kernel<WM, WN, TM, TN, T>), dim3(a.n_tiles, a.splits, nz), dim3(256), 0, s, a);
+  note_kernel("igemm16_kernel<%d, %d, %d, %d> [%dx%d tile, split-K %d%s]", WM, WN, TM, TN, BM, BN, a.splits, a.pair ? ", pair" : "");
   int rc = check_launch("diffsal_conv_igemm(16-bit)");
   if (rc || a.splits == 1) return rc;
   const long total4 = static_cast<long>(a.M) * (a.Cout / 4);

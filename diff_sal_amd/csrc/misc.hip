@@ -15,6 +15,14 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 static const char* const kTuneNames[TUNE_COUNT] = {
     "DIFFSAL_NO_PERSIST", "DIFFSAL_NO_XCD_ORDER", "DIFFSAL_NO_HALO", "DIFFSAL_FORCE_HALO", "DIFFSAL_IGEMM_CFG",
     "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
@@ -658,8 +666,9 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 25; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 26; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
+extern "C" const char* diffsal_last_gemm_kernel(void) { return g_kernel; }
 
 extern "C" int diffsal_set_tuning(const char* name, int value) {
   DS_REQUIRE(name, DIFFSAL_E_ARG, "set_tuning: null name");

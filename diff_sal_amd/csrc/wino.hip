@@ -501,6 +501,7 @@ extern "C" int diffsal_conv_wino(const diffsal_conv_desc* d, const float* x, con
   const int n_blocks = pl.g.tile_blocks * pl.g.cout_blocks;
   const int grid_x = pl.n_full + (n_blocks - pl.n_full) * pl.tail_split;
   hipLaunchKernelGGL(wino_gemm_kernel, dim3(grid_x, pl.splits), dim3(256), 0, s, a);   // 128 KB of static LDS
+  note_kernel("wino_gemm_kernel [%s]", pl.splits > 1 ? "input channels split" : (pl.tail_split > 1 ? "tail pieces" : "whole blocks"));
   rc = check_launch("conv_wino(products)");
   if (rc) return rc;
   if (pl.tail_split > 1) {

@@ -31,10 +31,11 @@ _PROF_DEPTH = [0]      # brackets nest (an operator's finishing reduction inside
 
 
 class _prof:
-    __slots__ = ("cls", "flops", "nbytes", "e0", "note", "counted")
+    __slots__ = ("cls", "flops", "nbytes", "e0", "note", "counted", "kernel")
 
-    def __init__(self, cls, flops=0.0, nbytes=0.0, note=""):
+    def __init__(self, cls, flops=0.0, nbytes=0.0, note="", kernel=""):
         self.cls, self.flops, self.nbytes, self.e0, self.note, self.counted = cls, float(flops), float(nbytes), None, note, False
+        self.kernel = kernel      # which kernel ran (GEMM entry points: diffsal_last_gemm_kernel(), set by the call site)
 
     def __enter__(self):
         if PROFILE is not None:
@@ -51,7 +52,7 @@ class _prof:
         if self.e0 is not None and et is None and PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.append((self.e0, e1, self.flops, self.cls, self.nbytes, self.note))
+            PROFILE.append((self.e0, e1, self.flops, self.cls, self.nbytes, self.note, self.kernel))
         return False
 
 
@@ -506,16 +507,20 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         n_tiles = N * dd * dd * (((H + dd - 1) // dd + 1) // 2) * (((W + dd - 1) // dd + 1) // 2)
         # FLOPs actually issued: 16 products per 2x2 tile, input and output channel (the direct form has 36)
         with _prof(tag, 2.0 * n_tiles * 16 * Cin * Cout, _nb(x, wino, residual, out) + 2 * 16 * n_tiles * Cin * 4,
-                   f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw} winograd F(2x2,3x3)" if PROFILE is not None else ""):
+                   f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw} winograd F(2x2,3x3)" if PROFILE is not None else "") as pr:
             _lib.check(lib.diffsal_conv_wino(C.byref(d), _p(x), _p(wino), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out),
                                              _p(ws), ws_bytes, _stream()), "conv_wino")
+            if PROFILE is not None:
+                pr.kernel = lib.diffsal_last_gemm_kernel().decode()
         return out
     ws_bytes = lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32) if ws_bytes else None
     with _prof(tag, 2.0 * N * Ho * Wo * Cout * kh * kw * Cin, _nb(x, w_packed, residual, out),
-               f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw}" if PROFILE is not None else ""):
+               f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw}" if PROFILE is not None else "") as pr:
         _lib.check(lib.diffsal_conv_igemm(C.byref(d), _pa(x, dt), _pa(w_packed, dt), _p(bias), _p(scale), _p(shift), rv,
                                           _pa(residual, dt), _pa(out, dt), _p(ws), ws_bytes, _stream()), "conv_igemm")
+        if PROFILE is not None:
+            pr.kernel = lib.diffsal_last_gemm_kernel().decode()
     return out
 
 
@@ -550,9 +555,11 @@ def linear_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Optional[Ten
     ws_bytes = 2 * lib.diffsal_conv_igemm_ws_bytes(C.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=x0.device, dtype=torch.float32) if ws_bytes else None
     x0c, x1c = x0.contiguous(), x1.contiguous()
-    with _prof(tag, 4.0 * M * K * N, _nb(x0c, x1c, w0, w1, y0, y1), f"2 x (M={M} K={K} N={N}) 1x1 pair"):
+    with _prof(tag, 4.0 * M * K * N, _nb(x0c, x1c, w0, w1, y0, y1), f"2 x (M={M} K={K} N={N}) 1x1 pair") as pr:
         _lib.check(lib.diffsal_linear_pair(C.byref(d), _pa(x0c, dt), _pa(x1c, dt), _pa(w0, dt), _pa(w1, dt), _p(b0), _p(b1),
                                            y0.data_ptr(), y1.data_ptr(), _p(ws), ws_bytes, _stream()), "linear_pair")
+        if PROFILE is not None:
+            pr.kernel = lib.diffsal_last_gemm_kernel().decode()
     return y0, y1
 
 
@@ -801,7 +808,8 @@ def block_front(x: Tensor, k: Tensor, v: Tensor, norm1, w9: Tensor, norm_q, lin_
         raise RuntimeError("block_front: fp32 storage needs the output projection")
     M = N * H * W
     fl = 2.0 * M * Cc * Cc * (2 if with_p else 1) + 4.0 * M * Lk * Cc + 22.0 * M * Cc
-    with _prof("K10f", fl, _nb(x, out, k, v, lin_q[0]) + (_nb(lin_p[0]) if with_p else 0.0), f"block_front M={M} C={Cc}"):
+    with _prof("K10f", fl, _nb(x, out, k, v, lin_q[0]) + (_nb(lin_p[0]) if with_p else 0.0), f"block_front M={M} C={Cc}",
+               kernel=f"block_front_kernel<{'float' if with_p else '16-bit'}, {Cc}>"):
         _lib.check(lib.diffsal_block_front(_pa(x, dt), _pa(k, dt), _pa(v, dt), _p(norm1[0]), _p(norm1[1]), float(norm1[2]),
                                            _p(w9), _p(norm_q[0]), _p(norm_q[1]), float(norm_q[2]), _pa(lin_q[0], dt),
                                            _p(lin_q[1]), _pa(lin_p[0], dt) if with_p else None,
@@ -1641,7 +1649,7 @@ def mlp_block(x1: Tensor, norm2, fc1, fc2, norm_z=None, frames=None):
     hw, T, tk = frames if frames is not None else (M, 1, 1)
     gz, bz, ez = norm_z if norm_z is not None else (None, None, 0.0)
     hid = fc1[0].shape[0]
-    with _prof("K10", 4.0 * M * Cc * hid, _nb(x1, x2, z)):
+    with _prof("K10", 4.0 * M * Cc * hid, _nb(x1, x2, z), f"mlp_block M={M} C={Cc}", kernel="mlp_block_kernel"):
         _lib.check(lib.diffsal_mlp_block(_p(x1), _p(norm2[0]), _p(norm2[1]), float(norm2[2]), _p(fc1[0]), _p(fc1[1]), _p(fc2[0]),
                                          _p(fc2[1]), _p(x2), _p(z), _p(gz), _p(bz), float(ez), M, Cc, hid, hw, T, tk, _stream()),
                    "mlp_block")
@@ -1660,7 +1668,7 @@ def block16(o: Tensor, x: Tensor, proj, norm2, fc1, fc2, norm_z=None, frames=Non
     hw, T, tk = frames if frames is not None else (M, 1, 1)
     gz, bz, ez = norm_z if norm_z is not None else (None, None, 0.0)
     hid = fc1[0].shape[0]
-    with _prof("K10", 2.0 * M * Cc * (Cc + 2 * hid), _nb(o, x, x2, z)):
+    with _prof("K10", 2.0 * M * Cc * (Cc + 2 * hid), _nb(o, x, x2, z), f"block16 M={M} C={Cc}", kernel="block16_kernel"):
         _lib.check(lib.diffsal_block16(_pa(o, dt), _pa(x, dt), _pa(proj[0], dt), _p(proj[1]), _p(norm2[0]), _p(norm2[1]), float(norm2[2]),
                                        _pa(fc1[0], dt), _p(fc1[1]), _pa(fc2[0], dt), _p(fc2[1]), x2.data_ptr(),
                                        None if z is None else z.data_ptr(), _p(gz), _p(bz), float(ez), M, Cc, hid, hw, T, tk, dt,

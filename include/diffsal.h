@@ -44,6 +44,11 @@ enum { DIFFSAL_ACT_NONE = 0, DIFFSAL_ACT_RELU = 1, DIFFSAL_ACT_GELU_ERF = 2, DIF
 
 int diffsal_version(void);
 const char* diffsal_last_error(void);
+/* Name and tile plan of the kernel the last diffsal_conv_igemm / diffsal_linear_pair / diffsal_conv_wino call of THIS thread
+ * launched (e.g. "gemm_dma_kernel<96x96,3 stages>", "igemm_linear_kernel<64x64>", "igemm_kernel<128x96> split-K 2"): lets a
+ * profiler attribute HIP-event times to kernels without a tracing tool (bench.py's roofline.dominant_kernel).  Thread-local,
+ * never NULL; not part of the reference's surface. */
+const char* diffsal_last_gemm_kernel(void);
 
 /* Test / tuning switches (kernel-variant selection for bit-equality tests and tile sweeps; none changes results beyond
  * summation order).  The DIFFSAL_* environment variables of the same names are read ONCE when the library is loaded; afterwards

@@ -1,0 +1,135 @@
+"""The LDS-DMA plain-product kernel (csrc/gemm_dma.hip) against plain fp32 / fp64 PyTorch of the same operator, through the
+C ABI (diffsal_conv_igemm): every tile configuration, every epilogue term, ragged M / N (the buffer range check cuts the DMA),
+multi-tile persistent walks, the XCD tile order, and the planner's automatic choice.
+
+Tolerance 2e-5 of the output maximum (the kernel is an exact-fp32 fmaf chain; its k order inside a 32-wide slice differs from
+igemm_kernel's, so it is compared with the reference, not bit for bit with that kernel).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import salunet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = 2e-5
+
+
+def rel_err(got, ref):
+    ref = ref.double().cpu()
+    return (got.double().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+
+
+def rnd(name, *shape, scale=1.0):
+    return orc.synth_tensor(name, shape, scale)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diff_sal_amd import ops as o
+
+    assert torch.cuda.is_available()
+    return o
+
+
+def reference(x, w, b, act, r, scale=None, shift=None, rowvec=None, rows_per_img=1):
+    y = x.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if scale is not None:
+        y = y * scale.double() + shift.double()
+    if rowvec is not None:
+        y = y + rowvec.double().repeat_interleave(rows_per_img, dim=0)[: y.shape[0]]
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = F.gelu(y)
+    elif act == 3:
+        y = torch.sigmoid(y)
+    if r is not None:
+        y = y + r.double()
+    return y
+
+
+# cfg (DIFFSAL_GEMM_DMA value): 1 = 96x96 / 3 stages, 2 = 96x96 / 6 stages, 3 = 96x192 / 4 stages, 4 = 96x192 / 3 stages;
+# K / 32 must be a multiple of the stage count (otherwise the library falls back to the tiled kernel -- also a valid result)
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,K,N", [(3024, 768, 768), (1000, 384, 200), (96, 96, 96), (97, 192, 100), (5000, 1152, 388),
+                                   (50011, 192, 192)])
+def test_gemm_dma_every_tile_configuration(ops, tuning, cfg, M, K, N):
+    tuning.set("DIFFSAL_GEMM_DMA", cfg)
+    x, w = rnd("dx%d_%d" % (M, K), M, K).to(DEV), rnd("dw%d_%d" % (N, K), N, K, scale=K ** -0.5).to(DEV)
+    b, r = rnd("db%d" % N, N, scale=0.3).to(DEV), rnd("dr%d_%d" % (M, N), M, N).to(DEV)
+    for act, bias, res in ((0, None, None), (0, b, r), (2, b, None), (1, b, r), (3, None, r)):
+        y = ops.linear(x, w, bias, act=act, residual=res)
+        assert rel_err(y, reference(x, w, bias, act, res)) < TOL, (cfg, M, K, N, act)
+
+
+@pytest.mark.parametrize("cfg", [1, 4])
+def test_gemm_dma_affine_rowvec_epilogue(ops, tuning, cfg):
+    """BN affine (scale / shift) and the per-image vector (rowvec, rows_per_img = Ho * Wo) as the 1x1 convolutions use them."""
+    tuning.set("DIFFSAL_GEMM_DMA", cfg)
+    Nimg, H, W, Cin, Cout = 5, 9, 22, 288, 200
+    x = rnd("ax", Nimg, H, W, Cin).to(DEV)
+    w = rnd("aw", Cout, Cin, scale=Cin ** -0.5).to(DEV)
+    b, sc, sh = rnd("ab", Cout, scale=0.2).to(DEV), (1.0 + 0.3 * rnd("as", Cout)).to(DEV), rnd("ah", Cout, scale=0.2).to(DEV)
+    rv = rnd("av", Nimg, Cout, scale=0.5).to(DEV)
+    res = rnd("ar", Nimg, H, W, Cout).to(DEV)
+    y = ops.conv_igemm(x, w, bias=b, scale=sc, shift=sh, rowvec=rv, residual=res, act=ops.ACT_RELU)
+    ref = reference(x.reshape(-1, Cin), w, b, 1, res.reshape(-1, Cout), sc, sh, rv, H * W).reshape(Nimg, H, W, Cout)
+    assert rel_err(y, ref) < TOL
+
+
+def test_gemm_dma_zero_fill_past_the_last_row(ops, tuning):
+    """Rows past M / N never reach memory (range-checked DMA): NaN-poisoned neighbours of the operands must not leak, and
+    memory behind the output stays untouched."""
+    tuning.set("DIFFSAL_GEMM_DMA", 1)
+    M, K, N = 200, 96, 100
+    big_x = torch.full((M + 96, K), float("nan"), device=DEV)
+    big_w = torch.full((N + 96, K), float("nan"), device=DEV)
+    big_x[:M] = rnd("zx", M, K).to(DEV)
+    big_w[:N] = rnd("zw", N, K, scale=K ** -0.5).to(DEV)
+    out = torch.full((M + 8, N), 7.0, device=DEV)
+    from diff_sal_amd.ops import conv_igemm
+    y = conv_igemm(big_x[:M].reshape(1, 1, M, K), big_w[:N], out=out[:M].reshape(1, 1, M, N))
+    assert torch.isfinite(y).all()
+    assert rel_err(y.reshape(M, N), reference(big_x[:M], big_w[:N], None, 0, None)) < TOL
+    assert (out[M:] == 7.0).all()
+
+
+def test_gemm_dma_xcd_order_and_plain_order_agree(ops, tuning):
+    """Large launches walk the tiles XCD by XCD: every tile exactly once -- bit-equal with the plain order."""
+    tuning.set("DIFFSAL_GEMM_DMA", 1)
+    M, K, N = 70001, 96, 488
+    x, w, b = rnd("xx", M, K).to(DEV), rnd("xw", N, K, scale=K ** -0.5).to(DEV), rnd("xb", N, scale=0.1).to(DEV)
+    tuning.set("DIFFSAL_NO_XCD_ORDER", 1)
+    plain = ops.linear(x, w, b, act=ops.ACT_GELU)
+    tuning.set("DIFFSAL_NO_XCD_ORDER", 0)
+    xcd = ops.linear(x, w, b, act=ops.ACT_GELU)
+    assert torch.equal(plain, xcd)
+    assert rel_err(xcd, reference(x, w, b, 2, None)) < TOL
+
+
+def test_planner_picks_dma_kernel_for_token_gemms_and_results_agree(ops, tuning):
+    """Default planner (DMA kernel from ~192 tiles on, K % 96 == 0) against the tiled kernels (DIFFSAL_GEMM_DMA=0) on the
+    decoder's token-GEMM shapes: both within 2e-5 of fp64, and within 1e-6 of each other."""
+    for M, K, N in ((3024, 768, 768), (12096, 384, 768), (3024, 768, 3456)):
+        x, w, b = rnd("tx%d" % K, M, K).to(DEV), rnd("tw%d_%d" % (N, K), N, K, scale=K ** -0.5).to(DEV), rnd("tb%d" % N, N, scale=0.1).to(DEV)
+        r = rnd("tr%d_%d" % (M, N), M, N).to(DEV)
+        tuning.set("DIFFSAL_GEMM_DMA", 0)
+        tiled = ops.linear(x, w, b, residual=r)
+        tuning.set("DIFFSAL_GEMM_DMA", None)
+        auto = ops.linear(x, w, b, residual=r)
+        ref = reference(x, w, b, 0, r)
+        assert rel_err(tiled, ref) < TOL and rel_err(auto, ref) < TOL
+        assert rel_err(auto, tiled) < 2e-6
+
+
+def test_gemm_dma_is_deterministic(ops, tuning):
+    tuning.set("DIFFSAL_GEMM_DMA", 1)
+    x, w = rnd("ex", 12096, 384).to(DEV), rnd("ew", 384, 384, scale=0.05).to(DEV)
+    a = ops.linear(x, w)
+    for _ in range(5):
+        assert torch.equal(a, ops.linear(x, w))
