@@ -50,6 +50,12 @@ struct DmaGemmArgs {
   int act, rowvec_ld, rows_per_img;
   int n_tiles_m, n_tiles_n, n_tiles;
   int xcd_order;   // tiles walked so that one XCD owns whole M-tile rows (large launches, grid % 8 == 0)
+  // convolution mode (CONV): row m = (image, oy, ox) of a channels-last input; K slice kt = (32-channel chunk, tap), taps fastest
+  int H, W, Cin, Ho, Wo, KW, taps, stride_h, stride_w, pad_t, pad_l, dil_h, dil_w;
+  unsigned in_bytes;
+  // split-K: unit u = (split, tile); a unit covers K slices [split * kt_per_unit, ...) and leaves raw sums in partial[split]
+  int splits, kt_per_unit;
+  float* partial;
 };
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rsrc` at voff + soff into LDS at lds_addr + 16 lane.  Inline assembly on
@@ -70,7 +76,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TMB, int TNB, int STAGES, int OCC>
+template <int TMB, int TNB, int STAGES, int OCC, bool CONV>
 __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   constexpr int BM = 32 * TMB, BN = 32 * TNB;
   constexpr int APW = BM / 32, BPW = BN / 32;          // 1 KiB DMA pieces (8 rows) per wave and slice
@@ -83,10 +89,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int K = p.K, nkt = K >> 5;
+  const int K = p.K, nkt = p.kt_per_unit;       // K slices per unit (= K / 32 without split-K)
 
   // ---- tile walk (same scheme as igemm_linear_kernel): v = blockIdx.x + i * gridDim.x
-  int n_virtual = p.n_tiles;
+  int n_virtual = p.n_tiles * p.splits;         // xcd_order only without split-K
   if (p.xcd_order) {
     const int x = blockIdx.x & 7;
     n_virtual = 8 * p.n_tiles_n * (p.n_tiles_m > x ? (p.n_tiles_m - x + 7) >> 3 : 0);
@@ -97,49 +103,99 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
       tni = q - ml * p.n_tiles_n;
       tmi = ml * 8 + (v & 7);
     } else {
-      tmi = v / p.n_tiles_n;
-      tni = v - tmi * p.n_tiles_n;
+      const int t = p.splits > 1 ? v % p.n_tiles : v;
+      tmi = t / p.n_tiles_n;
+      tni = t - tmi * p.n_tiles_n;
     }
   };
+  auto split_of = [&](int v) __attribute__((always_inline)) { return p.splits > 1 ? v / p.n_tiles : 0; };
   const int bid = blockIdx.x, gsz = gridDim.x;
   const int my_tiles = n_virtual > bid ? (n_virtual - bid + gsz - 1) / gsz : 0;
   const int total = my_tiles * nkt;
   if (total == 0) return;
 
-  // ---- issue side: one per-lane byte offset serves every piece (pieces of a wave are 32 rows apart: the swizzle term
-  // ((row >> 1) & 7) = (4 wave + (lane >> 4)) & 7 does not depend on the piece)
-  unsigned voff[APW > BPW ? APW : BPW];
-  {
-    const int r0 = 8 * wave + (lane >> 3);
-    const int slot = (lane & 7) ^ ((r0 >> 1) & 7);
+  // ---- issue side.  Plain products: one per-lane byte offset serves every piece (pieces of a wave are 32 rows apart: the
+  // swizzle term ((row >> 1) & 7) = (4 wave + (lane >> 4)) & 7 does not depend on the piece); the descriptor of A is rebuilt
+  // per tile (base = first row, records = valid rows).  Convolutions: a row's pixel origin (a_pix) and the bit mask of its
+  // taps that lie inside the image (a_valid) are rebuilt per tile, the tap displacement is added per slice, and a tap outside
+  // the image -- or a row past M -- becomes offset 0xFFFFFFFF: out of range, the DMA writes zeros (the convolution's padding).
+  constexpr int VQ = APW > BPW ? APW : BPW;
+  unsigned voff[VQ];
+  const int r0 = 8 * wave + (lane >> 3);
+  const int slot = (lane & 7) ^ ((r0 >> 1) & 7);
 #pragma unroll
-    for (int q = 0; q < (APW > BPW ? APW : BPW); ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K + slot * 4) * 4u;
-  }
+  for (int q = 0; q < VQ; ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K + slot * 4) * 4u;
+  unsigned a_pix[APW], a_valid[APW];
   int iss_v = bid, iss_kt = 0;
+  int iss_tap = 0, iss_ky = 0, iss_kx = 0, iss_chunk = 0;   // CONV: position of the slice being issued
+  unsigned iss_kofs = 0;                                    // byte offset of the slice inside a weight row
   i32x4 rs_a, rs_b;
   auto descriptors = [&](int v) __attribute__((always_inline)) {
     int tmi, tni;
     tile_mn(v, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
-    // past the last tile: zero records, every lane is out of range (the DMA then writes zeros into a free stage and touches
+    // past the last unit: zero records, every lane is out of range (the DMA then writes zeros into a free stage and touches
     // no memory) -- the ring keeps issuing so that the counted waits stay exact
     const bool live = v < n_virtual;
-    const int rows_a = live ? min(BM, p.M - m0) : 0, rows_b = live ? min(BN, p.N - n0) : 0;
-    const unsigned long pa = reinterpret_cast<unsigned long>(p.a + static_cast<long>(m0) * K);
+    const int rows_b = live ? min(BN, p.N - n0) : 0;
     const unsigned long pb = reinterpret_cast<unsigned long>(p.w + static_cast<long>(n0) * K);
-    rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * 4, 0x00020000};
     rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * 4, 0x00020000};
+    const int kt0 = split_of(v) * nkt;
+    iss_kofs = static_cast<unsigned>(kt0) * 128u;
+    if constexpr (!CONV) {
+      const int rows_a = live ? min(BM, p.M - m0) : 0;
+      const unsigned long pa = reinterpret_cast<unsigned long>(p.a + static_cast<long>(m0) * K);
+      rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * 4, 0x00020000};
+    } else {
+      const unsigned long pa = reinterpret_cast<unsigned long>(p.a);
+      rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, static_cast<int>(live ? p.in_bytes : 0u), 0x00020000};
+      iss_chunk = kt0 / p.taps;
+      iss_tap = kt0 - iss_chunk * p.taps;
+      iss_ky = iss_tap / p.KW;
+      iss_kx = iss_tap - iss_ky * p.KW;
+      const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+      for (int q = 0; q < APW; ++q) {
+        const int m = m0 + r0 + 32 * q;
+        const int mc = m < p.M ? m : p.M - 1;
+        const int n = mc / HoWo, rem = mc - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride_h - p.pad_t, ix0 = ox * p.stride_w - p.pad_l;
+        a_pix[q] = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + slot * 4) * 4u;   // wraps for taps outside: masked
+        unsigned bits = 0;
+        if (m < p.M)
+          for (int t = 0; t < p.taps; ++t) {
+            const int ky = t / p.KW, kx = t - ky * p.KW;
+            const int iy = iy0 + ky * p.dil_h, ix = ix0 + kx * p.dil_w;
+            bits |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) ? (1u << t) : 0u;
+          }
+        a_valid[q] = bits;
+      }
+    }
   };
   descriptors(iss_v);
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)smem)) + wave * 1024u;
   // piece q of the slice being issued: q < APW rows of A, else rows of W
   auto issue_piece = [&](int stage, int q) __attribute__((always_inline)) {
     const unsigned st = lds_base + static_cast<unsigned>(stage * STAGE_F * 4);
-    const unsigned kofs = static_cast<unsigned>(iss_kt) * 128u;
-    if (q < APW) dma_piece(st + q * 4096u, voff[q], rs_a, kofs);
-    else dma_piece(st + (BM * 32 + (q - APW) * 1024) * 4u, voff[q - APW], rs_b, kofs);
+    if (q < APW) {
+      if constexpr (!CONV) {
+        dma_piece(st + q * 4096u, voff[q], rs_a, iss_kofs);
+      } else {
+        const unsigned delta = static_cast<unsigned>((iss_ky * p.dil_h * p.W + iss_kx * p.dil_w) * p.Cin + iss_chunk * 32) * 4u;
+        const unsigned oob = ((a_valid[q] >> iss_tap) & 1u) - 1u;      // 0 inside the image, else all ones
+        dma_piece(st + q * 4096u, (a_pix[q] + delta) | oob, rs_a, 0u);
+      }
+    } else {
+      dma_piece(st + (BM * 32 + (q - APW) * 1024) * 4u, voff[q - APW], rs_b, iss_kofs);
+    }
   };
   auto issue_advance = [&]() __attribute__((always_inline)) {
+    iss_kofs += 128u;
+    if constexpr (CONV) {
+      if (++iss_kx == p.KW) { iss_kx = 0; ++iss_ky; }
+      if (++iss_tap == p.taps) { iss_tap = 0; iss_ky = 0; iss_kx = 0; ++iss_chunk; }
+    }
     if (++iss_kt == nkt) {
       iss_kt = 0;
       iss_v += gsz;
@@ -269,7 +325,22 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
     }
   };
   auto touch = [](const float4& x) __attribute__((always_inline)) { asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); };
+  auto store_partial = [&]() __attribute__((always_inline)) {   // split-K: raw sums of this unit's K range
+    int tmi, tni;
+    tile_mn(cmp_v, tmi, tni);
+    const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
+    float* __restrict__ ob = p.partial + static_cast<long>(split_of(cmp_v)) * p.M * p.N + static_cast<long>(mb) * p.N + nb;
+#pragma unroll
+    for (int j = 0; j < TNB; ++j)
+#pragma unroll
+      for (int i = 0; i < TMB; ++i) {
+        const float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (mb + i * 16 < p.M && nb + j * 16 < p.N) st4(ob + (static_cast<long>(i) * 16 * p.N + j * 16), v);
+      }
+  };
   auto finish_tile = [&]() __attribute__((always_inline)) {
+    if (p.splits > 1) { store_partial(); return; }
     // an unconditional use of every prefetched register: hipcc then knows that no request is pending when the next tile's
     // prefetch overwrites them
 #pragma unroll
@@ -336,7 +407,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   };
   for (int t = 0; t < my_tiles; ++t) {          // the host guarantees nkt % STAGES == 0: a tile starts on stage 0
     for (int kt = 0; kt < nkt; kt += STAGES) {
-      if (kt + STAGES >= nkt) fetch_epilogue_operands();
+      if (kt + STAGES >= nkt && p.splits == 1) fetch_epilogue_operands();
       ring(ring, std::integral_constant<int, 0>{});
     }
     finish_tile();
@@ -344,45 +415,130 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   }
 }
 
+// Sum of the split-K slabs in a fixed order (deterministic) + the epilogue; float4 over N.
+__global__ __launch_bounds__(256) void gemm_dma_reduce_kernel(DmaGemmArgs p) {
+  const int n4 = p.N >> 2;
+  const long total = static_cast<long>(p.M) * n4, slab = static_cast<long>(p.M) * p.N;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int n = static_cast<int>(i % n4) * 4;
+    const long m = i / n4, o = m * p.N + n;
+    float4 a = ld4(p.partial + o);
+    for (int s = 1; s < p.splits; ++s) {
+      const float4 b = ld4(p.partial + s * slab + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = v[e];
+      if (p.bias) x += p.bias[n + e];
+      if (p.scale) x = x * p.scale[n + e] + p.shift[n + e];
+      if (p.rowvec) x += p.rowvec[(m / p.rows_per_img) * p.rowvec_ld + n + e];
+      if (p.act == DIFFSAL_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (p.act == DIFFSAL_ACT_GELU_ERF) x = gelu_erf(x);
+      else if (p.act == DIFFSAL_ACT_SIGMOID) x = sigmoidf_(x);
+      if (p.act == DIFFSAL_ACT_GELU_GRAD) x *= gelu_erf_grad(p.residual[o + e]);
+      else if (p.residual) x += p.residual[o + e];
+      v[e] = x;
+    }
+    st4(p.out + o, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
 namespace {
 
-template <int TMB, int TNB, int STAGES, int OCC>
-int launch_dma(DmaGemmArgs& a, hipStream_t s) {
-  constexpr int BM = 32 * TMB, BN = 32 * TNB;
-  a.n_tiles_m = (a.M + BM - 1) / BM;
-  a.n_tiles_n = (a.N + BN - 1) / BN;
-  a.n_tiles = a.n_tiles_m * a.n_tiles_n;
-  const int slots = 256 * OCC;
-  const int grid = a.n_tiles < slots ? a.n_tiles : slots;
-  a.xcd_order = (tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC>), dim3(grid), dim3(256), 0, s, a);
-  note_kernel("gemm_dma_kernel<%d, %d, %d, %d> [%dx%d tile, %d stages]", TMB, TNB, STAGES, OCC, BM, BN, STAGES);
-  return check_launch("diffsal_conv_igemm(dma)");
+// K split for a launch of `tiles` 96-wide tiles and kt K slices: units = tiles * S should fill 256 CUs (two workgroups each) without
+// a long last round; every unit needs a multiple of `stages` slices.  Cost model in units of one K slice on one CU:
+// rounds of 256 CUs x (slices per unit) + the slab round trip of a split (S + 1 passes over M x N at ~3 TB/s ~ slices).
+int choose_split(long tiles, int kt, int stages, long mn) {
+  int best = 1;
+  double best_t = 1e30;
+  for (int S = 1; S <= 32; ++S) {
+    if (kt % (S * stages) != 0) continue;
+    const int per = kt / S;
+    if (S > 1 && per < 2 * stages) break;
+    const long units = tiles * S;
+    const double rounds = static_cast<double>((units + 255) / 256);        // co-resident pairs share the matrix pipe
+    double t = rounds * per * 1.0e-6;                                      // ~1 us per slice per CU
+    t += 3.0e-6 + 1.2e-6;                                                  // fill / drain
+    if (S > 1) t += (S + 1.0) * mn * 4.0 / 3.0e12 + 4.0e-6;
+    if (t < best_t) { best_t = t; best = S; }
+  }
+  return best;
 }
+
+template <int TMB, int TNB, int STAGES, int OCC>
+int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
+  constexpr int BM = 32 * TMB, BN = 32 * TNB;
+  const int slots = 256 * OCC;
+  const int units = a.n_tiles * a.splits;
+  const int grid = units < slots ? units : slots;
+  a.xcd_order = (a.splits == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
+  if (conv) hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, false>), dim3(grid), dim3(256), 0, s, a);
+  note_kernel("gemm_dma_kernel<%d, %d, %d, %d, %s> [%dx%d tile, %d stages, split-K %d]", TMB, TNB, STAGES, OCC, conv ? "true" : "false", BM, BN,
+              STAGES, a.splits);
+  int rc = check_launch("diffsal_conv_igemm(dma)");
+  if (rc || a.splits == 1) return rc;
+  long g = (static_cast<long>(a.M) * (a.N / 4) + 255) / 256;
+  g = g > 2048 ? 2048 : g;
+  hipLaunchKernelGGL(gemm_dma_reduce_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a);
+  return check_launch("diffsal_conv_igemm(dma split-K sum)");
+}
+
+struct DmaCfg { int bm, bn, stages; };
+const DmaCfg kDmaCfgs[4] = {{96, 96, 3}, {96, 96, 6}, {96, 192, 4}, {96, 192, 3}};
 
 }  // namespace
 
 // Tile shapes of this kernel, in the order of TUNE_GEMM_DMA's value - 1.
 //   0: 96 x 96, 3 stages (72 KB), two workgroups per CU      1: 96 x 96, 6 stages (144 KB), one per CU
 //   2: 96 x 192, 4 stages (144 KB), one per CU               3: 96 x 192, 3 stages (108 KB), one per CU
-// Returns 1 if launched, 0 if the shape is not handled, < 0 on error.
-int try_gemm_dma(int cfg, const float* a, const float* w, const float* bias, const float* scale, const float* shift,
-                 const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M, int K, int N,
-                 int act, hipStream_t s) {
-  const int stages = cfg == 1 ? 6 : cfg == 2 ? 4 : 3;
-  if ((K / 32) % stages != 0) return 0;   // a tile must start on ring stage 0
-  if (K % 32 != 0 || N % 4 != 0 || M <= 0 || M >= (1L << 31) / (K > N ? K : N) / 4) return 0;   // 32-bit byte offsets
+// d: the convolution (NULL = a plain [M, K] x [N, K]^T product).  allow_split: split-K may be planned (needs the workspace of
+// gemm_dma_ws_bytes).  Returns 1 if launched, 0 if the shape is not handled here, < 0 on error.
+size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N) {
+  if (cfg < 0 || cfg > 3 || K % 32 != 0) return 0;
+  const DmaCfg& c = kDmaCfgs[cfg];
+  const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+  const int S = choose_split(tiles, K / 32, c.stages, M * N);
+  return S > 1 ? static_cast<size_t>(S) * M * N * sizeof(float) : 0;
+}
+
+int try_gemm_dma(int cfg, const diffsal_conv_desc* d, const float* a, const float* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M,
+                 int K, int N, int act, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (cfg < 0 || cfg > 3) return 0;
+  const DmaCfg& c = kDmaCfgs[cfg];
+  if (K % 32 != 0 || (K / 32) % c.stages != 0) return 0;   // a unit must start on ring stage 0
+  // 32-bit byte offsets: plain products address A rows relative to the tile (any M), the output / residual through 64-bit
+  // pointers; the weight matrix and (convolutions) the whole input must stay below 4 GiB, which validate() has checked
+  if (N % 4 != 0 || M <= 0 || M >= (1L << 31) || static_cast<long>(N) * K * 4 >= (1L << 32) - 16 || 96L * K * 4 >= (1L << 31)) return 0;
   if (!aligned16(a) || !aligned16(w) || !aligned16(out) || (bias && !aligned16(bias)) || (scale && !(aligned16(scale) && aligned16(shift))) ||
       (rowvec && !(aligned16(rowvec) && rowvec_ld % 4 == 0)) || (residual && !aligned16(residual)))
     return 0;
-  DmaGemmArgs g{a, w, bias, scale, shift, rowvec, residual, out, static_cast<int>(M), N, K, act, rowvec_ld, rows_per_img, 0, 0, 0, 0};
+  DmaGemmArgs g{};
+  g.a = a; g.w = w; g.bias = bias; g.scale = scale; g.shift = shift; g.rowvec = rowvec; g.residual = residual; g.out = out;
+  g.M = static_cast<int>(M); g.N = N; g.K = K; g.act = act; g.rowvec_ld = rowvec_ld; g.rows_per_img = rows_per_img;
+  g.n_tiles_m = static_cast<int>((M + c.bm - 1) / c.bm);
+  g.n_tiles_n = (N + c.bn - 1) / c.bn;
+  g.n_tiles = g.n_tiles_m * g.n_tiles_n;
+  const bool conv = d != nullptr;
+  if (conv) {
+    if (d->KH * d->KW > 32) return 0;
+    g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.KW = d->KW; g.taps = d->KH * d->KW;
+    g.stride_h = d->stride_h; g.stride_w = d->stride_w; g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.dil_h = d->dil_h; g.dil_w = d->dil_w;
+    g.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
+  }
+  g.splits = choose_split(g.n_tiles, K / 32, c.stages, M * N);
+  if (g.splits > 1 && (!ws || ws_bytes < static_cast<size_t>(g.splits) * M * N * sizeof(float) || !aligned16(ws))) g.splits = 1;
+  g.kt_per_unit = K / 32 / g.splits;
+  g.partial = g.splits > 1 ? static_cast<float*>(ws) : nullptr;
   int rc;
   switch (cfg) {
-    case 0: rc = launch_dma<3, 3, 3, 2>(g, s); break;
-    case 1: rc = launch_dma<3, 3, 6, 1>(g, s); break;
-    case 2: rc = launch_dma<3, 6, 4, 1>(g, s); break;
-    case 3: rc = launch_dma<3, 6, 3, 1>(g, s); break;
-    default: return 0;
+    case 0: rc = launch_dma<3, 3, 3, 2>(g, conv, s); break;
+    case 1: rc = launch_dma<3, 3, 6, 1>(g, conv, s); break;
+    case 2: rc = launch_dma<3, 6, 4, 1>(g, conv, s); break;
+    default: rc = launch_dma<3, 6, 3, 1>(g, conv, s); break;
   }
   return rc == DIFFSAL_OK ? 1 : rc;
 }

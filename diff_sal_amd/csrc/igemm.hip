@@ -36,10 +36,11 @@ int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, co
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
                       int K, int N, int act, hipStream_t s);
 
-// gemm_dma.hip: plain fp32 products with LDS-DMA staging, 96-wide tiles
-int try_gemm_dma(int cfg, const float* a, const float* w, const float* bias, const float* scale, const float* shift,
-                 const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M, int K, int N,
-                 int act, hipStream_t s);
+// gemm_dma.hip: fp32 products / convolutions with LDS-DMA staging, 96-wide tiles (d = NULL: plain product)
+int try_gemm_dma(int cfg, const diffsal_conv_desc* d, const float* a, const float* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M,
+                 int K, int N, int act, void* ws, size_t ws_bytes, hipStream_t s);
+size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -917,6 +918,33 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
 
 using namespace diffsal;
 
+// Which LDS-DMA tile configuration (gemm_dma.hip) takes this fp32 launch, -1: none.
+//  * plain products with K a multiple of 96 and enough 96 x 96 tiles to fill the chip.  Measured (tools/bench_gemm_dma.py, B = 4
+//    shapes): faster than the planner's choice from ~192 tiles on (M = 3024: 1.35x, M = 12096: 1.1-1.2x, M = 48384:
+//    1.0-1.05x), slower below (M = 648 / 1344: split-K and 64 x 64 tiles fill the chip better).  DIFFSAL_GEMM_DMA=0 switches it
+//    off, 1..4 force one of its tile configurations on every shape it accepts;
+//  * convolutions (taps displaced per K slice, padding by the DMA's range check).  Measured (tools/bench_conv_dma.py): the tiled
+//    kernel already runs the large convolutions at 0.74-0.80 of the matrix peak (~0.9 of what the chip's clock under this load
+//    allows), so the DMA form is within +-5 % of it; it wins where its tile grid fits better: many tiles with a short K
+//    (UpEmbed-2 of stage 3: 275 -> 265 us, ReduceTemp of stage 3: 143 -> 136) and M <= ~400 rows with a long K, where its K
+//    split fills the chip (Downsample 768: 61 -> 49 us, ReduceTemp of stage 0: 38 -> 35).  DIFFSAL_CONV_DMA=0 switches it
+//    off, 1..4 force a configuration.
+static int dma_route(const diffsal_conv_desc* d, bool linear, long M, int K, bool pair) {
+  if (d->precision != DIFFSAL_PREC_FP32 || d->w_format != 0 || d->dtype != DIFFSAL_F32 || pair || tune(TUNE_IGEMM_CFG) >= 0) return -1;
+  const long tiles96 = ((M + 95) / 96) * ((d->Cout + 95) / 96);
+  if (linear) {
+    const int forced = tune(TUNE_GEMM_DMA);
+    if (forced == 0) return -1;
+    if (forced > 0) return forced - 1;
+    return (tiles96 >= 192 && K % 96 == 0) ? 0 : -1;
+  }
+  const int forced = tune(TUNE_CONV_DMA);
+  if (forced == 0) return -1;
+  if (forced > 0) return forced - 1;
+  if (K % 96 != 0 || d->Cout % 4 != 0) return -1;
+  return ((tiles96 >= 1024 && K <= 1024) || (M <= 400 && K >= 3072)) ? 0 : -1;
+}
+
 static int validate(const diffsal_conv_desc* d) {
   DS_REQUIRE(d, DIFFSAL_E_ARG, "conv_igemm: null descriptor");
   DS_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, DIFFSAL_E_SHAPE, "conv_igemm: Cin=%d must be a multiple of 32", d->Cin);
@@ -946,8 +974,15 @@ extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (validate(d) != DIFFSAL_OK) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   if (d->dtype != DIFFSAL_F32) return igemm16_ws_bytes(d);
-  const Plan pl = choose_plan(M, d->Cout, d->KH * d->KW * d->Cin, d->precision, is_linear(d));
-  return pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
+  const int K = d->KH * d->KW * d->Cin;
+  const Plan pl = choose_plan(M, d->Cout, K, d->precision, is_linear(d));
+  size_t need = pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
+  const int r = dma_route(d, is_linear(d), M, K, false);
+  if (r >= 0) {
+    const size_t nd = gemm_dma_ws_bytes(r, M, K, d->Cout);
+    need = nd > need ? nd : need;
+  }
+  return need;
 }
 
 // second problem of a pair launch (same descriptor): diffsal_linear_pair
@@ -1010,17 +1045,12 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
     if (r > 0) note_kernel("lin_stream_kernel [K=%d, N=%d]", d->Cin, d->Cout);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
-  // Plain products with K a multiple of 96 and enough 96 x 96 tiles to fill the chip: the LDS-DMA kernel (gemm_dma.hip).
-  // Measured (tools/bench_gemm_dma.py, B = 4 shapes): faster than the planner's choice from ~192 tiles on (M = 3024: 1.35x,
-  // M = 12096: 1.1-1.2x, M = 48384: 1.0-1.05x), slower below (M = 648 / 1344: split-K and 64 x 64 tiles fill the chip better).
-  // DIFFSAL_GEMM_DMA=0 switches it off, 1..4 force one of its tile configurations on every shape it accepts.
-  if (a.linear && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 && !px && tune(TUNE_GEMM_DMA) != 0 && tune(TUNE_IGEMM_CFG) < 0) {
-    const long tiles96 = ((M + 95) / 96) * ((d->Cout + 95) / 96);
-    const int forced = tune(TUNE_GEMM_DMA);
-    if (forced > 0 || (tiles96 >= 192 && a.K % 96 == 0)) {
-      const int r = try_gemm_dma(forced > 0 ? forced - 1 : 0, in, w, bias, scale, shift, rowvec, a.rowvec_ld, d->Ho * d->Wo, residual, out,
-                                 M, a.K, d->Cout, d->act, s);
-      if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+  {
+    const int r = dma_route(d, a.linear != 0, M, a.K, px != nullptr);
+    if (r >= 0) {
+      const int rr = try_gemm_dma(r, a.linear ? nullptr : d, in, w, bias, scale, shift, rowvec, a.rowvec_ld, d->Ho * d->Wo, residual, out, M,
+                                  a.K, d->Cout, d->act, ws, ws_bytes, s);
+      if (rr != 0) return rr < 0 ? rr : DIFFSAL_OK;
     }
   }
   Plan pl = choose_plan(M, d->Cout, a.K, d->precision, a.linear != 0);

@@ -133,3 +133,68 @@ def test_gemm_dma_is_deterministic(ops, tuning):
     a = ops.linear(x, w)
     for _ in range(5):
         assert torch.equal(a, ops.linear(x, w))
+
+
+# ---- convolution mode (DIFFSAL_CONV_DMA): tap displacement per K slice, padding = out-of-range DMA lanes (zeros), split-K ----
+CONV_CASES = [
+    # N, H, W, Cin, Cout, kh, kw, stride, pad, dil, asym
+    (2, 14, 24, 96, 192, 3, 3, 1, 1, 1, False),     # ResnetBlock conv family, zero padding on all four sides
+    (2, 14, 24, 192, 192, 3, 3, 2, 0, 1, True),     # Downsample: pad (0,1,0,1), stride 2
+    (1, 30, 46, 96, 96, 3, 3, 4, 0, 1, True),       # Downsample4x4 (odd sizes exercise the bounds)
+    (3, 14, 24, 384, 192, 3, 3, 1, 2, 2, False),    # UpEmbed dilated conv
+    (5, 13, 19, 96, 100, 3, 3, 1, 1, 1, False),     # ragged rows / channels
+    (4, 7, 12, 768, 768, 3, 3, 1, 1, 1, False),     # few rows, long K: split-K units + the slab sum
+    (1, 1, 40, 96, 768, 1, 1, 1, 0, 1, False),      # a 1x1 routed through the convolution form when forced
+]
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dma_matches_conv2d(ops, tuning, cfg, case):
+    N, H, W, Cin, Cout, kh, kw, s, p, d, asym = case
+    tuning.set("DIFFSAL_CONV_DMA", cfg)
+    tuning.set("DIFFSAL_GEMM_DMA", cfg)
+    x = rnd("vx%d%d" % (Cin, Cout), N, Cin, H, W)
+    w = rnd("vw%d%d" % (Cin, Cout), Cout, Cin, kh, kw, scale=(Cin * kh * kw) ** -0.5)
+    b = rnd("vb", Cout, scale=0.1)
+    if asym:
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)).double(), w.double(), b.double(), stride=s)
+        kwargs = dict(stride=(s, s), pad=(0, 0), out_hw=ref.shape[-2:])
+    else:
+        ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d)
+        kwargs = dict(stride=(s, s), pad=(p, p), dil=(d, d))
+    res = rnd("vr", *ref.shape)
+    ref = torch.relu(ref) + res.double()
+    from diff_sal_amd.ops import pack_conv_weight
+    got = ops.conv_igemm(x.permute(0, 2, 3, 1).contiguous().to(DEV), pack_conv_weight(w.to(DEV)), kh=kh, kw=kw, bias=b.to(DEV),
+                         residual=res.permute(0, 2, 3, 1).contiguous().to(DEV), act=ops.ACT_RELU, **kwargs)
+    assert got.shape == ref.permute(0, 2, 3, 1).shape
+    assert rel_err(got, ref.permute(0, 2, 3, 1)) < TOL, case
+
+
+def test_conv_dma_reduce_temp_form(ops, tuning):
+    """ReduceTemp (R/models/saliency_decoder/common_block.py:150-173): Conv3d (5,1,1) stride 5 over 9 frames = a 5x1 stride-(5,1)
+    convolution of the [B, 9, HW, C] view; only frames 0-4 reach the output."""
+    tuning.set("DIFFSAL_CONV_DMA", 1)
+    B, T, HW, C, Co = 3, 9, 200, 96, 192
+    x = rnd("rx", B, T, HW, C).to(DEV)
+    w = rnd("rw", Co, C, 5, 1, scale=(5 * C) ** -0.5).to(DEV)
+    from diff_sal_amd.ops import pack_conv_weight
+    y = ops.conv_igemm(x, pack_conv_weight(w), kh=5, kw=1, stride=(5, 1), out_hw=(1, HW), act=ops.ACT_RELU)
+    ref = torch.relu(torch.einsum("bthc,octz->bho", x[:, :5].double(), w.double())).reshape(B, 1, HW, Co)
+    assert rel_err(y, ref) < TOL
+
+
+def test_conv_dma_planner_rule_agrees_with_tiled_kernel(ops, tuning):
+    """Shapes the planner routes to the DMA form by itself (many tiles x short K; few rows x long K) against the tiled kernel."""
+    from diff_sal_amd.ops import pack_conv_weight
+    for N, H, W, Cin, Cout, st in ((36, 56, 96, 96, 96, 1), (4, 14, 24, 768, 768, 2)):
+        x = torch.relu(rnd("px%d" % Cin, N, H, W, Cin)).to(DEV)
+        w = rnd("pw%d" % Cin, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(DEV)
+        kwargs = dict(kh=3, kw=3, stride=(st, st), pad=(2, 2) if st == 1 else (0, 0), dil=(2, 2) if st == 1 else (1, 1),
+                      out_hw=(H, W) if st == 1 else (H // 2, W // 2))
+        tuning.set("DIFFSAL_CONV_DMA", 0)
+        tiled = ops.conv_igemm(x, pack_conv_weight(w), **kwargs)
+        tuning.set("DIFFSAL_CONV_DMA", None)
+        auto = ops.conv_igemm(x, pack_conv_weight(w), **kwargs)
+        assert rel_err(auto, tiled) < 3e-6
