@@ -26,13 +26,14 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 SIGNATURES = {
     "diffsal_version": (c_i, []),
     "diffsal_last_error": (C.c_char_p, []),
     "diffsal_last_gemm_kernel": (C.c_char_p, []),
+    "diffsal_conv_igemm_group": (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_kv_prep_proj": (c_i, [c_f] * 14 + [c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_fl, c_i, c_i, c_f]),
     "diffsal_block_front": (c_i, [c_f, c_f, c_f, c_f, c_f, c_fl, c_f, c_f, c_f, c_fl, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i,
                                   c_i, c_i, c_fl, c_i, c_f]),

@@ -76,8 +76,32 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TMB, int TNB, int STAGES, int OCC, bool CONV>
-__global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
+// Grouped launch: up to four independent problems (own operands, shapes, K splits) share ONE persistent grid; unit v of the
+// launch belongs to problem idx = #(unit_end[j] <= v).  The host orders the problems by decreasing K slices per unit, so the
+// long units start first (the four ReduceTemp products of a step: 120 / 60 / 30 / 15 slices per tile).
+constexpr int kMaxGroup = 4;
+struct DmaGroupArgs {
+  int n, total;
+  int unit_end[kMaxGroup];
+  DmaGemmArgs prob[kMaxGroup];
+};
+
+// Field-by-field scalar selects (no address of the by-value kernel argument is taken: that would move it to scratch memory).
+__device__ __forceinline__ DmaGemmArgs pick_problem(const DmaGroupArgs& g, int idx) {
+  DmaGemmArgs r;
+#define DS_PICK(f) r.f = idx == 0 ? g.prob[0].f : idx == 1 ? g.prob[1].f : idx == 2 ? g.prob[2].f : g.prob[3].f
+  DS_PICK(a); DS_PICK(w); DS_PICK(bias); DS_PICK(scale); DS_PICK(shift); DS_PICK(rowvec); DS_PICK(residual); DS_PICK(out);
+  DS_PICK(M); DS_PICK(N); DS_PICK(K); DS_PICK(act); DS_PICK(rowvec_ld); DS_PICK(rows_per_img);
+  DS_PICK(n_tiles_m); DS_PICK(n_tiles_n); DS_PICK(n_tiles); DS_PICK(xcd_order);
+  DS_PICK(H); DS_PICK(W); DS_PICK(Cin); DS_PICK(Ho); DS_PICK(Wo); DS_PICK(KW); DS_PICK(taps); DS_PICK(stride_h); DS_PICK(stride_w);
+  DS_PICK(pad_t); DS_PICK(pad_l); DS_PICK(dil_h); DS_PICK(dil_w); DS_PICK(in_bytes); DS_PICK(splits); DS_PICK(kt_per_unit);
+  DS_PICK(partial);
+#undef DS_PICK
+  return r;
+}
+
+template <int TMB, int TNB, int STAGES, int OCC, bool CONV, bool GROUPED>
+__global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<GROUPED, DmaGroupArgs, DmaGemmArgs> g) {
   constexpr int BM = 32 * TMB, BN = 32 * TNB;
   constexpr int APW = BM / 32, BPW = BN / 32;          // 1 KiB DMA pieces (8 rows) per wave and slice
   constexpr int PPW = APW + BPW;
@@ -89,16 +113,34 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int K = p.K, nkt = p.kt_per_unit;       // K slices per unit (= K / 32 without split-K)
+  // pi: the problem of the unit being ISSUED (the DMA ring runs up to P slices ahead, into the next unit), pc: of the unit being
+  // multiplied.  One problem per launch: both are the kernel argument.
+  DmaGemmArgs pi, pc;
+  if constexpr (GROUPED) { pi = pick_problem(g, 0); pc = pi; } else { pi = g; pc = g; }
 
-  // ---- tile walk (same scheme as igemm_linear_kernel): v = blockIdx.x + i * gridDim.x
-  int n_virtual = p.n_tiles * p.splits;         // xcd_order only without split-K
-  if (p.xcd_order) {
-    const int x = blockIdx.x & 7;
-    n_virtual = 8 * p.n_tiles_n * (p.n_tiles_m > x ? (p.n_tiles_m - x + 7) >> 3 : 0);
+  // ---- unit walk (same scheme as igemm_linear_kernel): v = blockIdx.x + i * gridDim.x
+  int n_virtual;
+  if constexpr (GROUPED) {
+    n_virtual = g.total;
+  } else {
+    n_virtual = g.n_tiles * g.splits;         // xcd_order only without split-K
+    if (g.xcd_order) {
+      const int x = blockIdx.x & 7;
+      n_virtual = 8 * g.n_tiles_n * (g.n_tiles_m > x ? (g.n_tiles_m - x + 7) >> 3 : 0);
+    }
   }
-  auto tile_mn = [&](int v, int& tmi, int& tni) __attribute__((always_inline)) {
-    if (p.xcd_order) {
+  // problem of unit v and the unit's index inside it
+  auto locate = [&](int v, int& idx, int& lv) __attribute__((always_inline)) {
+    if constexpr (GROUPED) {
+      idx = (v >= g.unit_end[0]) + (v >= g.unit_end[1]) + (v >= g.unit_end[2]);
+      lv = v - (idx == 0 ? 0 : idx == 1 ? g.unit_end[0] : idx == 2 ? g.unit_end[1] : g.unit_end[2]);
+    } else {
+      idx = 0;
+      lv = v;
+    }
+  };
+  auto tile_mn = [&](const DmaGemmArgs& p, int v, int& tmi, int& tni) __attribute__((always_inline)) {
+    if (!GROUPED && p.xcd_order) {
       const int q = v >> 3, ml = q / p.n_tiles_n;
       tni = q - ml * p.n_tiles_n;
       tmi = ml * 8 + (v & 7);
@@ -108,11 +150,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
       tni = t - tmi * p.n_tiles_n;
     }
   };
-  auto split_of = [&](int v) __attribute__((always_inline)) { return p.splits > 1 ? v / p.n_tiles : 0; };
+  auto split_of = [&](const DmaGemmArgs& p, int v) __attribute__((always_inline)) { return p.splits > 1 ? v / p.n_tiles : 0; };
   const int bid = blockIdx.x, gsz = gridDim.x;
   const int my_tiles = n_virtual > bid ? (n_virtual - bid + gsz - 1) / gsz : 0;
-  const int total = my_tiles * nkt;
-  if (total == 0) return;
+  if (my_tiles == 0) return;
 
   // ---- issue side.  Plain products: one per-lane byte offset serves every piece (pieces of a wave are 32 rows apart: the
   // swizzle term ((row >> 1) & 7) = (4 wave + (lane >> 4)) & 7 does not depend on the piece); the descriptor of A is rebuilt
@@ -123,51 +164,59 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   unsigned voff[VQ];
   const int r0 = 8 * wave + (lane >> 3);
   const int slot = (lane & 7) ^ ((r0 >> 1) & 7);
-#pragma unroll
-  for (int q = 0; q < VQ; ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K + slot * 4) * 4u;
   unsigned a_pix[APW], a_valid[APW];
-  int iss_v = bid, iss_kt = 0;
+  int iss_v = bid, iss_kt = 0, iss_lv = 0;
   int iss_tap = 0, iss_ky = 0, iss_kx = 0, iss_chunk = 0;   // CONV: position of the slice being issued
   unsigned iss_kofs = 0;                                    // byte offset of the slice inside a weight row
   i32x4 rs_a, rs_b;
   auto descriptors = [&](int v) __attribute__((always_inline)) {
-    int tmi, tni;
-    tile_mn(v, tmi, tni);
-    const int m0 = tmi * BM, n0 = tni * BN;
     // past the last unit: zero records, every lane is out of range (the DMA then writes zeros into a free stage and touches
     // no memory) -- the ring keeps issuing so that the counted waits stay exact
     const bool live = v < n_virtual;
-    const int rows_b = live ? min(BN, p.N - n0) : 0;
-    const unsigned long pb = reinterpret_cast<unsigned long>(p.w + static_cast<long>(n0) * K);
+    if constexpr (GROUPED) {
+      int idx;
+      locate(live ? v : 0, idx, iss_lv);
+      pi = pick_problem(g, idx);
+    } else {
+      iss_lv = v;
+    }
+    const int K = pi.K;
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K + slot * 4) * 4u;
+    int tmi, tni;
+    tile_mn(pi, iss_lv, tmi, tni);
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const int rows_b = live ? min(BN, pi.N - n0) : 0;
+    const unsigned long pb = reinterpret_cast<unsigned long>(pi.w + static_cast<long>(n0) * K);
     rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * 4, 0x00020000};
-    const int kt0 = split_of(v) * nkt;
+    const int kt0 = split_of(pi, iss_lv) * pi.kt_per_unit;
     iss_kofs = static_cast<unsigned>(kt0) * 128u;
     if constexpr (!CONV) {
-      const int rows_a = live ? min(BM, p.M - m0) : 0;
-      const unsigned long pa = reinterpret_cast<unsigned long>(p.a + static_cast<long>(m0) * K);
+      const int rows_a = live ? min(BM, pi.M - m0) : 0;
+      const unsigned long pa = reinterpret_cast<unsigned long>(pi.a + static_cast<long>(m0) * K);
       rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * 4, 0x00020000};
     } else {
-      const unsigned long pa = reinterpret_cast<unsigned long>(p.a);
-      rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, static_cast<int>(live ? p.in_bytes : 0u), 0x00020000};
-      iss_chunk = kt0 / p.taps;
-      iss_tap = kt0 - iss_chunk * p.taps;
-      iss_ky = iss_tap / p.KW;
-      iss_kx = iss_tap - iss_ky * p.KW;
-      const int HoWo = p.Ho * p.Wo;
+      const unsigned long pa = reinterpret_cast<unsigned long>(pi.a);
+      rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, static_cast<int>(live ? pi.in_bytes : 0u), 0x00020000};
+      iss_chunk = kt0 / pi.taps;
+      iss_tap = kt0 - iss_chunk * pi.taps;
+      iss_ky = iss_tap / pi.KW;
+      iss_kx = iss_tap - iss_ky * pi.KW;
+      const int HoWo = pi.Ho * pi.Wo;
 #pragma unroll
       for (int q = 0; q < APW; ++q) {
         const int m = m0 + r0 + 32 * q;
-        const int mc = m < p.M ? m : p.M - 1;
+        const int mc = m < pi.M ? m : pi.M - 1;
         const int n = mc / HoWo, rem = mc - n * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int iy0 = oy * p.stride_h - p.pad_t, ix0 = ox * p.stride_w - p.pad_l;
-        a_pix[q] = static_cast<unsigned>(((n * p.H + iy0) * p.W + ix0) * p.Cin + slot * 4) * 4u;   // wraps for taps outside: masked
+        const int oy = rem / pi.Wo, ox = rem - oy * pi.Wo;
+        const int iy0 = oy * pi.stride_h - pi.pad_t, ix0 = ox * pi.stride_w - pi.pad_l;
+        a_pix[q] = static_cast<unsigned>(((n * pi.H + iy0) * pi.W + ix0) * pi.Cin + slot * 4) * 4u;   // wraps for taps outside: masked
         unsigned bits = 0;
-        if (m < p.M)
-          for (int t = 0; t < p.taps; ++t) {
-            const int ky = t / p.KW, kx = t - ky * p.KW;
-            const int iy = iy0 + ky * p.dil_h, ix = ix0 + kx * p.dil_w;
-            bits |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) ? (1u << t) : 0u;
+        if (m < pi.M)
+          for (int t = 0; t < pi.taps; ++t) {
+            const int ky = t / pi.KW, kx = t - ky * pi.KW;
+            const int iy = iy0 + ky * pi.dil_h, ix = ix0 + kx * pi.dil_w;
+            bits |= ((iy >= 0) & (iy < pi.H) & (ix >= 0) & (ix < pi.W)) ? (1u << t) : 0u;
           }
         a_valid[q] = bits;
       }
@@ -182,7 +231,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
       if constexpr (!CONV) {
         dma_piece(st + q * 4096u, voff[q], rs_a, iss_kofs);
       } else {
-        const unsigned delta = static_cast<unsigned>((iss_ky * p.dil_h * p.W + iss_kx * p.dil_w) * p.Cin + iss_chunk * 32) * 4u;
+        const unsigned delta = static_cast<unsigned>((iss_ky * pi.dil_h * pi.W + iss_kx * pi.dil_w) * pi.Cin + iss_chunk * 32) * 4u;
         const unsigned oob = ((a_valid[q] >> iss_tap) & 1u) - 1u;      // 0 inside the image, else all ones
         dma_piece(st + q * 4096u, (a_pix[q] + delta) | oob, rs_a, 0u);
       }
@@ -193,10 +242,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   auto issue_advance = [&]() __attribute__((always_inline)) {
     iss_kofs += 128u;
     if constexpr (CONV) {
-      if (++iss_kx == p.KW) { iss_kx = 0; ++iss_ky; }
-      if (++iss_tap == p.taps) { iss_tap = 0; iss_ky = 0; iss_kx = 0; ++iss_chunk; }
+      if (++iss_kx == pi.KW) { iss_kx = 0; ++iss_ky; }
+      if (++iss_tap == pi.taps) { iss_tap = 0; iss_ky = 0; iss_kx = 0; ++iss_chunk; }
     }
-    if (++iss_kt == nkt) {
+    if (++iss_kt == pi.kt_per_unit) {
       iss_kt = 0;
       iss_v += gsz;
       descriptors(iss_v);
@@ -249,29 +298,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
     for (int idx = 0; idx < 4 * TMB * TNB; ++idx) mfma_one(set, idx);
   };
 
-  int cmp_v = bid;
-  const float* __restrict__ resid = p.residual;
-  float* __restrict__ outp = p.out;
+  int cmp_v = bid, cmp_lv = bid;
   // Epilogue operands (per-channel vectors, residual quads) are requested at the start of the tile's LAST pass over the ring and
   // wait in registers: requested in the epilogue they would be a dependent round trip with the matrix pipe idle, and -- vmcnt
   // retires in order -- their wait would also drain the DMA ring.
   float4 rres[TMB][TNB], rbias[TNB], rscale[TNB], rshift[TNB];
   auto fetch_epilogue_operands = [&]() __attribute__((always_inline)) {
     int tmi, tni;
-    tile_mn(cmp_v, tmi, tni);
+    tile_mn(pc, cmp_lv, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
       const int n = n0 + wn * TNB * 16 + j * 16 + 4 * q4;
-      const int nc = n < p.N ? n : 0;
-      if (p.bias) rbias[j] = ld4(p.bias + nc);
-      if (p.scale) { rscale[j] = ld4(p.scale + nc); rshift[j] = ld4(p.shift + nc); }
-      if (resid) {
+      const int nc = n < pc.N ? n : 0;
+      if (pc.bias) rbias[j] = ld4(pc.bias + nc);
+      if (pc.scale) { rscale[j] = ld4(pc.scale + nc); rshift[j] = ld4(pc.shift + nc); }
+      if (pc.residual) {
 #pragma unroll
         for (int i = 0; i < TMB; ++i) {
           const int m = m0 + wm * TMB * 16 + i * 16 + r16;
-          const bool ok = m < p.M && n < p.N;
-          rres[i][j] = ld4(resid + (ok ? static_cast<long>(m) * p.N + n : 0));
+          const bool ok = m < pc.M && n < pc.N;
+          rres[i][j] = ld4(pc.residual + (ok ? static_cast<long>(m) * pc.N + n : 0));
         }
       }
     }
@@ -281,27 +328,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
   auto epilogue = [&](auto act_c) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_c)::value;
     int tmi, tni;
-    tile_mn(cmp_v, tmi, tni);
+    tile_mn(pc, cmp_lv, tmi, tni);
     const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
-    const long o0 = static_cast<long>(mb) * p.N + nb;
-    float* __restrict__ ob = outp + o0;
-    const float* __restrict__ rvb = p.rowvec;
+    const long o0 = static_cast<long>(mb) * pc.N + nb;
+    float* __restrict__ ob = pc.out + o0;
+    const float* __restrict__ rvb = pc.rowvec;
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
-      const bool n_ok = nb + j * 16 < p.N;
+      const bool n_ok = nb + j * 16 < pc.N;
 #pragma unroll
       for (int i = 0; i < TMB; ++i) {
         const int m = mb + i * 16;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) { v[0] += rbias[j].x; v[1] += rbias[j].y; v[2] += rbias[j].z; v[3] += rbias[j].w; }
-        if (p.scale) {
+        if (pc.bias) { v[0] += rbias[j].x; v[1] += rbias[j].y; v[2] += rbias[j].z; v[3] += rbias[j].w; }
+        if (pc.scale) {
           v[0] = v[0] * rscale[j].x + rshift[j].x; v[1] = v[1] * rscale[j].y + rshift[j].y;
           v[2] = v[2] * rscale[j].z + rshift[j].z; v[3] = v[3] * rscale[j].w + rshift[j].w;
         }
         if (rvb) {
-          const int mc = m < p.M ? m : p.M - 1;
-          const float4 t = ld4(rvb + static_cast<long>(mc / p.rows_per_img) * p.rowvec_ld + (n_ok ? nb + j * 16 : 0));
+          const int mc = m < pc.M ? m : pc.M - 1;
+          const float4 t = ld4(rvb + static_cast<long>(mc / pc.rows_per_img) * pc.rowvec_ld + (n_ok ? nb + j * 16 : 0));
           v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
         }
         if constexpr (ACT == DIFFSAL_ACT_RELU) {
@@ -318,29 +365,29 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
           const float4 t = rres[i][j];
           v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
         } else {
-          if (resid) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (pc.residual) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         }
-        if (m < p.M && n_ok) st4(ob + (static_cast<long>(i) * 16 * p.N + j * 16), make_float4(v[0], v[1], v[2], v[3]));
+        if (m < pc.M && n_ok) st4(ob + (static_cast<long>(i) * 16 * pc.N + j * 16), make_float4(v[0], v[1], v[2], v[3]));
       }
     }
   };
   auto touch = [](const float4& x) __attribute__((always_inline)) { asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); };
   auto store_partial = [&]() __attribute__((always_inline)) {   // split-K: raw sums of this unit's K range
     int tmi, tni;
-    tile_mn(cmp_v, tmi, tni);
+    tile_mn(pc, cmp_lv, tmi, tni);
     const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
-    float* __restrict__ ob = p.partial + static_cast<long>(split_of(cmp_v)) * p.M * p.N + static_cast<long>(mb) * p.N + nb;
+    float* __restrict__ ob = pc.partial + static_cast<long>(split_of(pc, cmp_lv)) * pc.M * pc.N + static_cast<long>(mb) * pc.N + nb;
 #pragma unroll
     for (int j = 0; j < TNB; ++j)
 #pragma unroll
       for (int i = 0; i < TMB; ++i) {
         const float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (mb + i * 16 < p.M && nb + j * 16 < p.N) st4(ob + (static_cast<long>(i) * 16 * p.N + j * 16), v);
+        if (mb + i * 16 < pc.M && nb + j * 16 < pc.N) st4(ob + (static_cast<long>(i) * 16 * pc.N + j * 16), v);
       }
   };
   auto finish_tile = [&]() __attribute__((always_inline)) {
-    if (p.splits > 1) { store_partial(); return; }
+    if (pc.splits > 1) { store_partial(); return; }
     // an unconditional use of every prefetched register: hipcc then knows that no request is pending when the next tile's
     // prefetch overwrites them
 #pragma unroll
@@ -349,7 +396,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
 #pragma unroll
       for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
     }
-    switch (p.act) {
+    switch (pc.act) {
       case DIFFSAL_ACT_RELU: epilogue(std::integral_constant<int, DIFFSAL_ACT_RELU>{}); break;
       case DIFFSAL_ACT_GELU_ERF: epilogue(std::integral_constant<int, DIFFSAL_ACT_GELU_ERF>{}); break;
       case DIFFSAL_ACT_SIGMOID: epilogue(std::integral_constant<int, DIFFSAL_ACT_SIGMOID>{}); break;
@@ -405,9 +452,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(DmaGemmArgs p) {
       self(self, std::integral_constant<int, S + 1>{});
     }
   };
-  for (int t = 0; t < my_tiles; ++t) {          // the host guarantees nkt % STAGES == 0: a tile starts on stage 0
+  for (int t = 0; t < my_tiles; ++t) {          // the host guarantees kt_per_unit % STAGES == 0: a unit starts on stage 0
+    if constexpr (GROUPED) {
+      int idx;
+      locate(cmp_v, idx, cmp_lv);
+      pc = pick_problem(g, idx);
+    } else {
+      cmp_lv = cmp_v;
+    }
+    const int nkt = pc.kt_per_unit;
     for (int kt = 0; kt < nkt; kt += STAGES) {
-      if (kt + STAGES >= nkt && p.splits == 1) fetch_epilogue_operands();
+      if (kt + STAGES >= nkt && pc.splits == 1) fetch_epilogue_operands();
       ring(ring, std::integral_constant<int, 0>{});
     }
     finish_tile();
@@ -474,10 +529,10 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   const int units = a.n_tiles * a.splits;
   const int grid = units < slots ? units : slots;
   a.xcd_order = (a.splits == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
-  if (conv) hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, true>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, false>), dim3(grid), dim3(256), 0, s, a);
-  note_kernel("gemm_dma_kernel<%d, %d, %d, %d, %s> [%dx%d tile, %d stages, split-K %d]", TMB, TNB, STAGES, OCC, conv ? "true" : "false", BM, BN,
-              STAGES, a.splits);
+  if (conv) hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
+  note_kernel("gemm_dma_kernel<%d, %d, %d, %d, %s, false> [%dx%d tile, %d stages, split-K %d]", TMB, TNB, STAGES, OCC, conv ? "true" : "false",
+              BM, BN, STAGES, a.splits);
   int rc = check_launch("diffsal_conv_igemm(dma)");
   if (rc || a.splits == 1) return rc;
   long g = (static_cast<long>(a.M) * (a.N / 4) + 255) / 256;
@@ -489,13 +544,41 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
 struct DmaCfg { int bm, bn, stages; };
 const DmaCfg kDmaCfgs[4] = {{96, 96, 3}, {96, 96, 6}, {96, 192, 4}, {96, 192, 3}};
 
+// fills the problem-independent part of the arguments; false: shape not handled by tile configuration c
+bool dma_fill(DmaGemmArgs& g, const DmaCfg& c, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias,
+              const float* scale, const float* shift, const float* rowvec, int rowvec_ld, const float* residual, float* out) {
+  const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
+  const int K = d->KH * d->KW * d->Cin, N = d->Cout;
+  if (K % 32 != 0 || (K / 32) % c.stages != 0) return false;   // a unit must start on ring stage 0
+  // 32-bit byte offsets: plain products address A rows relative to the tile (any M), the output / residual through 64-bit
+  // pointers; the weight matrix and (convolutions) the whole input must stay below 4 GiB, which validate() has checked
+  if (N % 4 != 0 || M <= 0 || M >= (1L << 31) || static_cast<long>(N) * K * 4 >= (1L << 32) - 16 || 96L * K * 4 >= (1L << 31)) return false;
+  if (!aligned16(a) || !aligned16(w) || !aligned16(out) || (bias && !aligned16(bias)) || (scale && !(aligned16(scale) && aligned16(shift))) ||
+      (rowvec && !(aligned16(rowvec) && rowvec_ld % 4 == 0)) || (residual && !aligned16(residual)) || d->KH * d->KW > 32)
+    return false;
+  g = DmaGemmArgs{};
+  g.a = a; g.w = w; g.bias = bias; g.scale = scale; g.shift = shift; g.rowvec = rowvec; g.residual = residual; g.out = out;
+  g.M = static_cast<int>(M); g.N = N; g.K = K; g.act = d->act; g.rowvec_ld = rowvec_ld; g.rows_per_img = d->Ho * d->Wo;
+  g.n_tiles_m = static_cast<int>((M + c.bm - 1) / c.bm);
+  g.n_tiles_n = (N + c.bn - 1) / c.bn;
+  g.n_tiles = g.n_tiles_m * g.n_tiles_n;
+  if (as_conv) {
+    g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.KW = d->KW; g.taps = d->KH * d->KW;
+    g.stride_h = d->stride_h; g.stride_w = d->stride_w; g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.dil_h = d->dil_h; g.dil_w = d->dil_w;
+    g.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
+  }
+  g.splits = 1;
+  g.kt_per_unit = K / 32;
+  return true;
+}
+
 }  // namespace
 
 // Tile shapes of this kernel, in the order of TUNE_GEMM_DMA's value - 1.
 //   0: 96 x 96, 3 stages (72 KB), two workgroups per CU      1: 96 x 96, 6 stages (144 KB), one per CU
 //   2: 96 x 192, 4 stages (144 KB), one per CU               3: 96 x 192, 3 stages (108 KB), one per CU
-// d: the convolution (NULL = a plain [M, K] x [N, K]^T product).  allow_split: split-K may be planned (needs the workspace of
-// gemm_dma_ws_bytes).  Returns 1 if launched, 0 if the shape is not handled here, < 0 on error.
+// as_conv: the convolution form (taps, padding); false = d is a plain [M, K] x [N, K]^T product.  Split-K is planned when the
+// workspace allows (gemm_dma_ws_bytes).  Returns 1 if launched, 0 if the shape is not handled here, < 0 on error.
 size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N) {
   if (cfg < 0 || cfg > 3 || K % 32 != 0) return 0;
   const DmaCfg& c = kDmaCfgs[cfg];
@@ -504,42 +587,62 @@ size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N) {
   return S > 1 ? static_cast<size_t>(S) * M * N * sizeof(float) : 0;
 }
 
-int try_gemm_dma(int cfg, const diffsal_conv_desc* d, const float* a, const float* w, const float* bias, const float* scale,
-                 const float* shift, const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M,
-                 int K, int N, int act, void* ws, size_t ws_bytes, hipStream_t s) {
+int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, int rowvec_ld, const float* residual, float* out, void* ws, size_t ws_bytes,
+                 hipStream_t s) {
   if (cfg < 0 || cfg > 3) return 0;
   const DmaCfg& c = kDmaCfgs[cfg];
-  if (K % 32 != 0 || (K / 32) % c.stages != 0) return 0;   // a unit must start on ring stage 0
-  // 32-bit byte offsets: plain products address A rows relative to the tile (any M), the output / residual through 64-bit
-  // pointers; the weight matrix and (convolutions) the whole input must stay below 4 GiB, which validate() has checked
-  if (N % 4 != 0 || M <= 0 || M >= (1L << 31) || static_cast<long>(N) * K * 4 >= (1L << 32) - 16 || 96L * K * 4 >= (1L << 31)) return 0;
-  if (!aligned16(a) || !aligned16(w) || !aligned16(out) || (bias && !aligned16(bias)) || (scale && !(aligned16(scale) && aligned16(shift))) ||
-      (rowvec && !(aligned16(rowvec) && rowvec_ld % 4 == 0)) || (residual && !aligned16(residual)))
-    return 0;
-  DmaGemmArgs g{};
-  g.a = a; g.w = w; g.bias = bias; g.scale = scale; g.shift = shift; g.rowvec = rowvec; g.residual = residual; g.out = out;
-  g.M = static_cast<int>(M); g.N = N; g.K = K; g.act = act; g.rowvec_ld = rowvec_ld; g.rows_per_img = rows_per_img;
-  g.n_tiles_m = static_cast<int>((M + c.bm - 1) / c.bm);
-  g.n_tiles_n = (N + c.bn - 1) / c.bn;
-  g.n_tiles = g.n_tiles_m * g.n_tiles_n;
-  const bool conv = d != nullptr;
-  if (conv) {
-    if (d->KH * d->KW > 32) return 0;
-    g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.KW = d->KW; g.taps = d->KH * d->KW;
-    g.stride_h = d->stride_h; g.stride_w = d->stride_w; g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.dil_h = d->dil_h; g.dil_w = d->dil_w;
-    g.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
-  }
-  g.splits = choose_split(g.n_tiles, K / 32, c.stages, M * N);
-  if (g.splits > 1 && (!ws || ws_bytes < static_cast<size_t>(g.splits) * M * N * sizeof(float) || !aligned16(ws))) g.splits = 1;
-  g.kt_per_unit = K / 32 / g.splits;
+  DmaGemmArgs g;
+  if (!dma_fill(g, c, d, as_conv, a, w, bias, scale, shift, rowvec, rowvec_ld, residual, out)) return 0;
+  const long MN = static_cast<long>(g.M) * g.N;
+  g.splits = choose_split(g.n_tiles, g.K / 32, c.stages, MN);
+  if (g.splits > 1 && (!ws || ws_bytes < static_cast<size_t>(g.splits) * MN * sizeof(float) || !aligned16(ws))) g.splits = 1;
+  g.kt_per_unit = g.K / 32 / g.splits;
   g.partial = g.splits > 1 ? static_cast<float*>(ws) : nullptr;
   int rc;
   switch (cfg) {
-    case 0: rc = launch_dma<3, 3, 3, 2>(g, conv, s); break;
-    case 1: rc = launch_dma<3, 3, 6, 1>(g, conv, s); break;
-    case 2: rc = launch_dma<3, 6, 4, 1>(g, conv, s); break;
-    default: rc = launch_dma<3, 6, 3, 1>(g, conv, s); break;
+    case 0: rc = launch_dma<3, 3, 3, 2>(g, as_conv, s); break;
+    case 1: rc = launch_dma<3, 3, 6, 1>(g, as_conv, s); break;
+    case 2: rc = launch_dma<3, 6, 4, 1>(g, as_conv, s); break;
+    default: rc = launch_dma<3, 6, 3, 1>(g, as_conv, s); break;
   }
+  return rc == DIFFSAL_OK ? 1 : rc;
+}
+
+// Up to four problems in ONE launch of the 96 x 96 / 3-stage kernel (convolution form: a plain product is its 1x1 case).
+// No split-K: every problem's units are whole tiles; the host sorts the problems by K slices per unit (longest first) and the
+// grid has one workgroup per unit, so the hardware dispatcher hands the next (shorter) unit to whichever CU frees up first.
+// Returns 1 if launched, 0 if some problem does not fit this kernel (the caller then launches them one by one).
+int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* const* a, const float* const* w, const float* const* bias,
+                       float* const* out, hipStream_t s) {
+  if (n < 1 || n > kMaxGroup) return 0;
+  const DmaCfg& c = kDmaCfgs[0];
+  DmaGemmArgs pr[kMaxGroup];
+  for (int i = 0; i < n; ++i)
+    if (!dma_fill(pr[i], c, d[i], true, a[i], w[i], bias ? bias[i] : nullptr, nullptr, nullptr, nullptr, 0, nullptr, out[i])) return 0;
+  int order[kMaxGroup];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (pr[order[j]].kt_per_unit > pr[order[i]].kt_per_unit) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  DmaGroupArgs g{};
+  g.n = n;
+  int units = 0;
+  for (int i = 0; i < kMaxGroup; ++i) {
+    if (i < n) {
+      g.prob[i] = pr[order[i]];
+      units += g.prob[i].n_tiles;
+    } else {
+      g.prob[i] = g.prob[n - 1];
+    }
+    g.unit_end[i] = i < n ? units : 0x7FFFFFFF;
+  }
+  g.total = units;
+  const int persist = tune(TUNE_GROUP_GRID);   // > 0: a persistent grid of that many workgroups walks the units with stride
+  const int grid = persist > 0 && units > persist ? persist : units;
+  hipLaunchKernelGGL((gemm_dma_kernel<3, 3, 3, 2, true, true>), dim3(grid), dim3(256), 0, s, g);
+  note_kernel("gemm_dma_kernel<3, 3, 3, 2, true, true> [96x96 tile, 3 stages, %d problems, %d units]", n, units);
+  const int rc = check_launch("diffsal_conv_igemm_group(dma)");
   return rc == DIFFSAL_OK ? 1 : rc;
 }
 

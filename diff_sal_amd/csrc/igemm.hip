@@ -36,10 +36,12 @@ int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, co
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
                       int K, int N, int act, hipStream_t s);
 
-// gemm_dma.hip: fp32 products / convolutions with LDS-DMA staging, 96-wide tiles (d = NULL: plain product)
-int try_gemm_dma(int cfg, const diffsal_conv_desc* d, const float* a, const float* w, const float* bias, const float* scale,
-                 const float* shift, const float* rowvec, int rowvec_ld, int rows_per_img, const float* residual, float* out, long M,
-                 int K, int N, int act, void* ws, size_t ws_bytes, hipStream_t s);
+// gemm_dma.hip: fp32 products / convolutions with LDS-DMA staging, 96-wide tiles
+int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, int rowvec_ld, const float* residual, float* out, void* ws, size_t ws_bytes,
+                 hipStream_t s);
+int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* const* a, const float* const* w, const float* const* bias,
+                       float* const* out, hipStream_t s);
 size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1048,8 +1050,7 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
   {
     const int r = dma_route(d, a.linear != 0, M, a.K, px != nullptr);
     if (r >= 0) {
-      const int rr = try_gemm_dma(r, a.linear ? nullptr : d, in, w, bias, scale, shift, rowvec, a.rowvec_ld, d->Ho * d->Wo, residual, out, M,
-                                  a.K, d->Cout, d->act, ws, ws_bytes, s);
+      const int rr = try_gemm_dma(r, d, !a.linear, in, w, bias, scale, shift, rowvec, a.rowvec_ld, residual, out, ws, ws_bytes, s);
       if (rr != 0) return rr < 0 ? rr : DIFFSAL_OK;
     }
   }
@@ -1094,6 +1095,34 @@ extern "C" int diffsal_conv_igemm(const diffsal_conv_desc* d, const void* in_v, 
                                   const float* rowvec, const void* residual_v, void* out_v, void* ws,
                                   size_t ws_bytes, diffsal_stream_t stream) {
   return conv_igemm_impl(d, in_v, w_v, bias, scale, shift, rowvec, residual_v, out_v, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int diffsal_conv_igemm_group(int n, const diffsal_conv_desc* const* descs, const void* const* in, const void* const* w,
+                                        const float* const* bias, void* const* out, void* ws, size_t ws_bytes, diffsal_stream_t stream) {
+  DS_REQUIRE(n >= 1 && n <= 4 && descs && in && w && out, DIFFSAL_E_ARG, "conv_igemm_group: 1..4 problems, non-null tables");
+  bool dma_ok = tune(TUNE_GEMM_DMA) != 0 && tune(TUNE_IGEMM_CFG) < 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate(descs[i]);
+    if (rc) return rc;
+    DS_REQUIRE(in[i] && w[i] && out[i], DIFFSAL_E_ARG, "conv_igemm_group: null operand of problem %d", i);
+    DS_REQUIRE(descs[i]->act >= DIFFSAL_ACT_NONE && descs[i]->act <= DIFFSAL_ACT_SIGMOID, DIFFSAL_E_ARG, "conv_igemm_group: act=%d", descs[i]->act);
+    dma_ok = dma_ok && descs[i]->dtype == DIFFSAL_F32 && descs[i]->precision == DIFFSAL_PREC_FP32 && descs[i]->w_format == 0;
+  }
+  if (dma_ok) {
+    const float* a_[4]; const float* w_[4]; const float* b_[4]; float* o_[4];
+    for (int i = 0; i < n; ++i) {
+      a_[i] = static_cast<const float*>(in[i]); w_[i] = static_cast<const float*>(w[i]);
+      b_[i] = bias ? bias[i] : nullptr; o_[i] = static_cast<float*>(out[i]);
+    }
+    const int r = try_gemm_dma_group(n, descs, a_, w_, b_, o_, static_cast<hipStream_t>(stream));
+    if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+  }
+  for (int i = 0; i < n; ++i) {     // some problem does not fit the grouped kernel: one launch each (same results)
+    const int rc = conv_igemm_impl(descs[i], in[i], w[i], bias ? bias[i] : nullptr, nullptr, nullptr, nullptr, nullptr, out[i], ws, ws_bytes,
+                                   stream, nullptr);
+    if (rc) return rc;
+  }
+  return DIFFSAL_OK;
 }
 
 extern "C" int diffsal_linear_pair(const diffsal_conv_desc* d, const void* in0, const void* in1, const void* w0, const void* w1,

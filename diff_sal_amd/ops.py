@@ -11,7 +11,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
-from typing import Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -522,6 +522,59 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         if PROFILE is not None:
             pr.kernel = lib.diffsal_last_gemm_kernel().decode()
     return out
+
+
+def conv_igemm_group(problems: Sequence[dict], tag: str = "gemm") -> List[Tensor]:
+    """Up to four independent convolutions / plain products in ONE launch (``diffsal_conv_igemm_group``).  Each problem is a dict
+    of ``conv_igemm`` keywords: ``x`` (NHWC), ``w`` (packed [Cout, kh*kw*Cin]) and optionally ``kh, kw, stride, pad, dil, out_hw,
+    bias, act, out``; epilogue = bias + activation only.  Returns the outputs in order."""
+    lib = _lib.load()
+    n = len(problems)
+    if not 1 <= n <= 4:
+        raise RuntimeError("conv_igemm_group: 1..4 problems")
+    descs, outs, keep = [], [], []
+    flops = nbytes = 0.0
+    ws_bytes = 0
+    notes = []
+    for pr in problems:
+        x, w = pr["x"], pr["w"]
+        kh, kw = pr.get("kh", 1), pr.get("kw", 1)
+        stride, pad, dil = pr.get("stride", (1, 1)), pr.get("pad", (0, 0)), pr.get("dil", (1, 1))
+        N, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        assert w.shape[1] == kh * kw * Cin, (w.shape, kh, kw, Cin)
+        if pr.get("out_hw") is None:
+            Ho = (H + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride[0] + 1
+            Wo = (W + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride[1] + 1
+        else:
+            Ho, Wo = pr["out_hw"]
+        dt = _dt(x)
+        out = pr.get("out")
+        if out is None:
+            out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+        d = ConvDesc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], pr.get("act", ACT_NONE),
+                     0, 0, _lib.PREC_FP32, dt)
+        descs.append(d)
+        outs.append(out)
+        ws_bytes = max(ws_bytes, lib.diffsal_conv_igemm_ws_bytes(C.byref(d)))
+        flops += 2.0 * N * Ho * Wo * Cout * kh * kw * Cin
+        nbytes += _nb(x, w, out)
+        notes.append(f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw}")
+    ws = torch.empty((ws_bytes // 4,), device=outs[0].device, dtype=torch.float32) if ws_bytes else None
+    PA = C.c_void_p * n
+    dp = (C.POINTER(ConvDesc) * n)(*[C.pointer(d) for d in descs])
+    xs = PA(*[_pa(pr["x"], _dt(pr["x"])) for pr in problems])
+    wsl = PA(*[_pa(pr["w"], _dt(pr["x"])) for pr in problems])
+    bs = PA(*[_p(pr.get("bias")) for pr in problems])
+    os_ = PA(*[_pa(o, _dt(o)) for o in outs])
+    keep.extend([dp, xs, wsl, bs, os_])
+    with _prof(tag, flops, nbytes, "group: " + " | ".join(notes) if PROFILE is not None else "") as pr_:
+        _lib.check(lib.diffsal_conv_igemm_group(n, C.cast(dp, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(wsl, C.c_void_p),
+                                                C.cast(bs, C.c_void_p), C.cast(os_, C.c_void_p), _p(ws), ws_bytes, _stream()),
+                   "conv_igemm_group")
+        if PROFILE is not None:
+            pr_.kernel = lib.diffsal_last_gemm_kernel().decode()
+    return outs
 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,

@@ -533,6 +533,7 @@ class SalUNet(nn.Module):
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     merge_align = True   # the stages' audio align convolutions as one product (eval)
+    group_reduce_temp = True   # fp32 tap path: the stages' ReduceTemp products in one grouped launch after the last stage
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
     # step (1720 -> 1779 steps/s; "s3" and "mt" lose), but the nine tap products are rounded to 16 bits before they are summed
     # and the worst bf16 fixture error moves from 2.2e-2 to 2.9e-2 against a 3e-2 bar.
@@ -638,7 +639,7 @@ class SalUNet(nn.Module):
         xcur = frames[0]
         h0, w0 = xcur.shape[2:4]
         th, tw = h0 * 2 ** (ns - 1) * 2, w0 * 2 ** (ns - 1) * 2
-        zs = []
+        zs, redu = [], []
         # tap path of mt_proj: the ReduceTemp outputs of all stages land in ONE row-concatenated matrix, so that the nine tap
         # mixings of the four scales are a single GEMM
         z_all, z_off, sizes = None, 0, []
@@ -686,9 +687,17 @@ class SalUNet(nn.Module):
                     raise RuntimeError(f"stage {i}: {H}x{W} tokens, expected {sizes[i]}")
                 z_out = z_all[z_off:z_off + Bn * H * W].view(Bn, 1, H * W, self.ori_embed_dim)
                 z_off += Bn * H * W
+            if z_out is not None and self.group_reduce_temp and cdt == torch.float32:
+                # ReduceTemp of every stage feeds nothing but mt_proj: the four products (M = 336 .. 21504 rows, K = 3840 .. 480)
+                # wait for the last stage and share ONE launch, longest K first -- each alone fills a fraction of the chip
+                redu.append(dict(x=z.view(Bn, T, H * W, C), w=pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU, out=z_out))
+                zs.append(z_out.view(Bn, H, W, self.ori_embed_dim))
+                continue
             z = ops.conv_igemm(z.view(Bn, T, H * W, C), pk[f"s{i}.redu.w"], kh=kt, kw=1, stride=(kt, 1), act=ACT_RELU,
                                out=z_out, tag="K13")
             zs.append(z.view(Bn, H, W, self.ori_embed_dim))
+        if redu:
+            ops.conv_igemm_group(redu, tag="K13")
         mt = dec.mt_proj
         if z_all is not None:
             y9 = ops.linear(z_all, pk["mt.tapw"], None, tag="K14")

@@ -175,6 +175,14 @@ size_t diffsal_conv_wino_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wino(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
                       const float* scale, const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
                       size_t ws_bytes, diffsal_stream_t stream);
+/* Up to four independent convolutions / plain products (own descriptor, operands and output; bias + activation epilogue
+ * only) in ONE launch: the four ReduceTemp products of a step (R/models/saliency_decoder/common_block.py:150-173,
+ * sal_unet.py:480-487) have 336 .. 21504 rows and 3840 .. 480 columns of K, each alone fills a fraction of the chip.  fp32
+ * problems that fit the LDS-DMA kernel (K a multiple of 96) share one grid, longest units first; anything else runs as n
+ * diffsal_conv_igemm calls (same results).  `ws` / `ws_bytes`: the largest diffsal_conv_igemm_ws_bytes of the problems. */
+int diffsal_conv_igemm_group(int n, const diffsal_conv_desc* const* descs, const void* const* in, const void* const* w,
+                             const float* const* bias, void* const* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
+
 /* Two plain products of ONE shape in one launch (grid z = 2): out_i [M,N] = in_i [M,K] x w_i [N,K]^T + bias_i.  The key and value
  * projections of a transformer block (attention.py:78-83: proj_k / proj_v on the 648 pooled tokens of a stage) are 8-26 us
  * launches at their latency floor; paired they are four launches per step instead of eight.  d: a 1x1 descriptor (KH = KW = 1,

@@ -198,3 +198,36 @@ def test_conv_dma_planner_rule_agrees_with_tiled_kernel(ops, tuning):
         tuning.set("DIFFSAL_CONV_DMA", None)
         auto = ops.conv_igemm(x, pack_conv_weight(w), **kwargs)
         assert rel_err(auto, tiled) < 3e-6
+
+
+def test_conv_igemm_group_equals_single_launches(ops, tuning):
+    """diffsal_conv_igemm_group: four ReduceTemp-shaped products (and a mix of plain products) in one launch == the same
+    problems one by one (within fp32 summation order), and a group with a problem the
+    grouped kernel cannot take (K not a multiple of 96) falls back to single launches."""
+    from diff_sal_amd.ops import pack_conv_weight
+    B, T = 2, 9
+    probs = []
+    for i, (HW, C) in enumerate(((40, 768), (170, 384), (650, 192), (2600, 96))):
+        x = rnd("gx%d" % i, B, T, HW, C).to(DEV)
+        w = pack_conv_weight(rnd("gw%d" % i, 768, C, 5, 1, scale=(5 * C) ** -0.5).to(DEV))
+        probs.append(dict(x=x, w=w, kh=5, kw=1, stride=(5, 1), out_hw=(1, HW), act=ops.ACT_RELU))
+    tuning.set("DIFFSAL_CONV_DMA", 1)
+    singles = [ops.conv_igemm(p["x"], p["w"], kh=5, kw=1, stride=(5, 1), out_hw=p["out_hw"], act=ops.ACT_RELU) for p in probs]
+    grouped = ops.conv_igemm_group(probs)
+    for s_, g_ in zip(singles, grouped):       # the single launches may split K (few rows, long K): same sums, other order
+        assert rel_err(g_, s_) < 3e-6
+    # plain products with biases, different shapes, written into caller-provided outputs
+    lin = []
+    for i, (M, K, N) in enumerate(((648, 768, 768), (648, 384, 384), (1000, 96, 200))):
+        x = rnd("hx%d" % i, 1, 1, M, K).to(DEV)
+        w = rnd("hw%d" % i, N, K, scale=K ** -0.5).to(DEV)
+        b = rnd("hb%d" % i, N, scale=0.2).to(DEV)
+        lin.append(dict(x=x, w=w, bias=b, out=torch.full((1, 1, M, N), 3.0, device=DEV)))
+    outs = ops.conv_igemm_group(lin)
+    for p, o in zip(lin, outs):
+        assert o.data_ptr() == p["out"].data_ptr()
+        assert rel_err(o.reshape(o.shape[2], -1), reference(p["x"].reshape(p["x"].shape[2], -1), p["w"], p["bias"], 0, None)) < TOL
+    # fallback: K = 160 is not a multiple of 96
+    odd = [dict(x=rnd("ox", 1, 1, 500, 160).to(DEV), w=rnd("ow", 64, 160, scale=0.1).to(DEV)), lin[1]]
+    outs = ops.conv_igemm_group(odd)
+    assert rel_err(outs[0].reshape(500, 64), reference(odd[0]["x"].reshape(500, 160), odd[0]["w"], None, 0, None)) < TOL
