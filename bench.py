@@ -620,9 +620,10 @@ def main():
     ap.add_argument("--train-scope", choices=["full", "decoder"], default="full",
                     help="--workload train: full = MViT + (VGGish, AudioAttnNet) + SalUNet inside the step, as the reference; "
                          "decoder = the denoiser alone on given features (round-1 measurement)")
-    ap.add_argument("--sampler-mode", choices=["eager", "graph", "f1"], default="eager",
-                    help="eager = headline; graph = whole trajectories replayed from a HIP graph; f1 = step-invariant "
-                         "shortcut of visual-only mode (1 evaluation per trajectory) -- both reported separately")
+    ap.add_argument("--sampler-mode", choices=["auto", "eager", "graph", "f1"], default="auto",
+                    help="auto = what DiffusionSampler does by default: eager from 3 clips per step on (the headline batch of 4), "
+                         "HIP-graph replay of whole trajectories at 1-2 clips; eager / graph force one; f1 = step-invariant "
+                         "shortcut of visual-only mode (1 evaluation per trajectory), reported separately")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16", "fp16"], default="fp32",
                     help="fp32 = headline (exact fp32 MFMA); bf16x3 = split-precision bf16 MFMA on fp32 tensors (~4e-6); "
                          "bf16 / fp16 = 16-bit STORAGE of activations + packed weights, native 16-bit MFMA, fp32 accumulate "
@@ -724,6 +725,11 @@ def main():
 
     net.forward_fused_update = counted_fused
 
+    if args.sampler_mode == "auto":
+        args.sampler_mode = "graph" if B <= 2 else "eager"
+        if args.sampler_mode == "graph" and args.steps % NFE_PER_TRAJECTORY != 0:      # whole trajectories only
+            args.steps = max(NFE_PER_TRAJECTORY, args.steps // NFE_PER_TRAJECTORY * NFE_PER_TRAJECTORY)
+    sampler.hip_graph = False
     special = args.sampler_mode != "eager"
     if special:
         assert args.steps % NFE_PER_TRAJECTORY == 0, "graph / f1 modes time whole 50-NFE trajectories"

@@ -505,7 +505,7 @@ namespace {
 // K split for a launch of `tiles` 96-wide tiles and kt K slices: units = tiles * S should fill 256 CUs (two workgroups each) without
 // a long last round; every unit needs a multiple of `stages` slices.  Cost model in units of one K slice on one CU:
 // rounds of 256 CUs x (slices per unit) + the slab round trip of a split (S + 1 passes over M x N at ~3 TB/s ~ slices).
-int choose_split(long tiles, int kt, int stages, long mn) {
+int choose_split(long tiles, int kt, int stages, long mn, double* t_out = nullptr) {
   int best = 1;
   double best_t = 1e30;
   for (int S = 1; S <= 32; ++S) {
@@ -514,11 +514,12 @@ int choose_split(long tiles, int kt, int stages, long mn) {
     if (S > 1 && per < 2 * stages) break;
     const long units = tiles * S;
     const double rounds = static_cast<double>((units + 255) / 256);        // co-resident pairs share the matrix pipe
-    double t = rounds * per * 1.0e-6;                                      // ~1 us per slice per CU
+    double t = rounds * per * 1.13e-6;                                     // one 96 x 96 x 32 slice on one CU
     t += 3.0e-6 + 1.2e-6;                                                  // fill / drain
     if (S > 1) t += (S + 1.0) * mn * 4.0 / 3.0e12 + 4.0e-6;
     if (t < best_t) { best_t = t; best = S; }
   }
+  if (t_out) *t_out = best_t;
   return best;
 }
 
@@ -585,6 +586,16 @@ size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N) {
   const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
   const int S = choose_split(tiles, K / 32, c.stages, M * N);
   return S > 1 ? static_cast<size_t>(S) * M * N * sizeof(float) : 0;
+}
+
+// the planner's time estimate (seconds) for this kernel on a plain M x K x N product, 1e30 if the shape is not handled
+double gemm_dma_estimate(int cfg, long M, int K, int N) {
+  if (cfg < 0 || cfg > 3 || K % 32 != 0 || (K / 32) % kDmaCfgs[cfg].stages != 0) return 1e30;
+  const DmaCfg& c = kDmaCfgs[cfg];
+  const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+  double t = 1e30;
+  choose_split(tiles, K / 32, c.stages, M * N, &t);
+  return c.bn == 96 ? t : 2.0 * t * 0.95;     // a 96 x 192 slice is twice the work
 }
 
 int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias, const float* scale,

@@ -43,6 +43,7 @@ int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const float*
 int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* const* a, const float* const* w, const float* const* bias,
                        float* const* out, hipStream_t s);
 size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N);
+double gemm_dma_estimate(int cfg, long M, int K, int N);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -835,7 +836,7 @@ static const TileCfg kCfgs[] = {{128, 192, 1, 0.95f}, {128, 128, 2, 0.95f}, {128
 constexpr int kNumCfgs = 6;  // (a 256x96 tile with 64x96 per wave and one wave per SIMD measured 5-20 % slower)
 constexpr int kCUs = 256;
 
-struct Plan { int cfg, splits; };
+struct Plan { int cfg, splits; double t; };   // t: the model's time estimate (seconds)
 
 // Pick tile shape and split-K factor with a small analytic model.  The 256 CUs each hold `occ`
 // workgroups; co-resident workgroups share the CU's matrix pipes, and every workgroup also has a
@@ -852,7 +853,7 @@ static Plan choose_plan(long M, int Cout, int K, int precision, bool linear = fa
   // the bf16x3 loop sustains ~2x the fp32 one on large tiles: split-K slabs and fixed latencies weigh twice as much
   const double mac_per_s_cu = (precision == DIFFSAL_PREC_BF16X3 ? 2.0 : 1.0) * 157.3e12 / 2.0 / kCUs;
   const int KT = K / BK;
-  Plan best{5, 1};
+  Plan best{5, 1, 1e30};
   double best_t = 1e30;
   for (int c = 0; c < kNumCfgs; ++c) {
     const TileCfg& t = kCfgs[c];
@@ -880,7 +881,7 @@ static Plan choose_plan(long M, int Cout, int K, int precision, bool linear = fa
       double tt = full * round_time(t.occ);
       if (rest > 0) tt += round_time(static_cast<double>((rest + kCUs - 1) / kCUs));
       if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6;
-      if (tt < best_t) { best_t = tt; best = Plan{c, S}; }
+      if (tt < best_t) { best_t = tt; best = Plan{c, S, tt}; }
     }
   }
   return best;
@@ -921,10 +922,10 @@ static int launch(IgemmArgs& a, hipStream_t s, int precision) {
 using namespace diffsal;
 
 // Which LDS-DMA tile configuration (gemm_dma.hip) takes this fp32 launch, -1: none.
-//  * plain products with K a multiple of 96 and enough 96 x 96 tiles to fill the chip.  Measured (tools/bench_gemm_dma.py, B = 4
-//    shapes): faster than the planner's choice from ~192 tiles on (M = 3024: 1.35x, M = 12096: 1.1-1.2x, M = 48384:
-//    1.0-1.05x), slower below (M = 648 / 1344: split-K and 64 x 64 tiles fill the chip better).  DIFFSAL_GEMM_DMA=0 switches it
-//    off, 1..4 force one of its tile configurations on every shape it accepts;
+//  * plain products with K a multiple of 96 whose tile grid (x K split) fills the chip.  Measured (tools/bench_gemm_dma.py, B = 4
+//    shapes): M = 3024: 1.35x, M = 12096: 1.1-1.2x, M = 48384: 1.0-1.05x against the tiled kernels; at one clip per step
+//    (M = 756 .. 12096) 1.1-1.4x with its K split, but 0.8x on M = 756 x N = 3456 (288 tiles on 256 CUs).
+//    DIFFSAL_GEMM_DMA=0 switches it off, 1..4 force one of its tile configurations on every shape it accepts;
 //  * convolutions (taps displaced per K slice, padding by the DMA's range check).  Measured (tools/bench_conv_dma.py): the tiled
 //    kernel already runs the large convolutions at 0.74-0.80 of the matrix peak (~0.9 of what the chip's clock under this load
 //    allows), so the DMA form is within +-5 % of it; it wins where its tile grid fits better: many tiles with a short K
@@ -938,7 +939,13 @@ static int dma_route(const diffsal_conv_desc* d, bool linear, long M, int K, boo
     const int forced = tune(TUNE_GEMM_DMA);
     if (forced == 0) return -1;
     if (forced > 0) return forced - 1;
-    return (tiles96 >= 192 && K % 96 == 0) ? 0 : -1;
+    if (K % 96 != 0 || d->Cout % 4 != 0) return -1;
+    // both kernels priced by their models; the DMA kernel's (rounds of 256 CUs x K slices x 1.13 us + fill + slab trip) tracks
+    // its measured times within ~10 %, the tiled planner's estimate is optimistic by 1.1-1.5x on these shapes (31 shapes of
+    // the B = 1 and B = 4 steps, tools/bench_gemm_dma.py): the DMA kernel takes the launch when its estimate is within 1.25x
+    const double t_dma = gemm_dma_estimate(0, M, K, d->Cout);
+    const double t_tiled = choose_plan(M, d->Cout, K, d->precision, true).t;
+    return t_dma <= 1.25 * t_tiled ? 0 : -1;
   }
   const int forced = tune(TUNE_CONV_DMA);
   if (forced == 0) return -1;

@@ -175,8 +175,47 @@ class GradReducer:
         self._work, self._armed = [], False
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """``torch.optim.Optimizer`` face of ``DiffusionTrainStep``'s flat Adam: ONE parameter group whose ``lr`` / ``betas`` /
+    ``eps`` / ``weight_decay`` are what the fused clip + Adam kernel reads at every step, so that the reference's scheduler
+    (``optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma)``, R/util/utils.py:116-123, stepped once per epoch at
+    R/diffusion_trainer.py:296) -- or any other ``torch.optim.lr_scheduler`` -- drives the learning rate unchanged.
+    ``step()`` runs the owner's ``optimizer_step()``; the moments live in the owner's flat buffers (``state_dict()`` /
+    ``load_state_dict()`` are the owner's: the ``torch.optim.Adam`` checkpoint format)."""
+
+    def __init__(self, owner: "DiffusionTrainStep", params, lr, betas, eps, weight_decay):
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._owner = owner
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError("FlatAdam.step: closures are not supported (the loss is computed by DiffusionTrainStep)")
+        self._owner.optimizer_step()
+
+    def zero_grad(self, set_to_none: bool = True):
+        self._owner.flat.zero_grad()
+
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):
+            raise RuntimeError("FlatAdam keeps ONE parameter group (one flat buffer, one set of hyper-parameters)")
+        super().add_param_group(param_group)
+
+    def state_dict(self):
+        return self._owner.state_dict()
+
+    def load_state_dict(self, sd):
+        self._owner.load_state_dict(sd)
+
+
 class DiffusionTrainStep:
-    """prepare_data -> forward -> MSE -> backward -> gradient mean -> clip -> Adam, for ``model``.
+    """prepare_data -> forward -> loss -> backward -> gradient mean -> clip -> Adam, for ``model``.
+
+    ``loss_fn(pred, x0) -> scalar tensor | dict with "total"`` replaces the built-in MSE (``mse_weight * sum_chw (pred - x0)^2``
+    averaged over the batch) -- pass ``loss_config=config`` to get the reference's ``get_lossv2(config, pred, x0)["total"]``
+    (R/diffusion_trainer.py:219, R/models/sal_losses.py:179-259: MSE or KL main term + weighted CC / SIM / NSS, every term with
+    its HIP gradient, ``diff_sal_amd.sal_losses``).  ``self.optimizer`` is a ``torch.optim.Optimizer`` (``FlatAdam``) for
+    learning-rate schedulers.
 
     ``model`` is a ``diff_sal_amd.SalUNet`` (called as ``model(x_t, t, feat_list, audio)``) or a
     ``VideoSaliencyModel`` (called as ``model({"img", "input", "audio"}, t)``, R/diffusion_trainer.py:212-218).
@@ -187,10 +226,19 @@ class DiffusionTrainStep:
                  beta_schedule: str = "cosine", beta_start: float = 1e-4, beta_end: float = 0.02,
                  num_diffusion_timesteps: int = 1000, gaussian_dequantization: bool = True,
                  bucket_mb: float = 32.0, process_group=None, broadcast_buffers: bool = True,
-                 store_clipped_grad: bool = False, exchange_single_rank: bool = False):
+                 store_clipped_grad: bool = False, exchange_single_rank: bool = False,
+                 loss_fn: Optional[Callable] = None, loss_config=None):
         self.model = model
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(beta1), float(beta2)), float(eps), float(weight_decay)
         self.grad_clip, self.mse_weight = float(grad_clip), float(mse_weight)
+        if loss_fn is not None and loss_config is not None:
+            raise ValueError("DiffusionTrainStep: give loss_fn or loss_config, not both")
+        if loss_config is not None:
+            from . import sal_losses
+
+            def loss_fn(pred, x0, _cfg=loss_config):            # R/diffusion_trainer.py:219
+                return sal_losses.get_lossv2(_cfg, pred, x0)
+        self.loss_fn = loss_fn
+        self.last_losses: Optional[Dict] = None      # the loss dictionary of the last step when loss_fn returns one
         self.gaussian_dequantization = bool(gaussian_dequantization)
         self.store_clipped_grad = bool(store_clipped_grad)
         betas = to_torch(get_beta_schedule(beta_schedule, beta_start=beta_start, beta_end=beta_end,
@@ -200,6 +248,7 @@ class DiffusionTrainStep:
         self.sqrt_one_minus_alphas_hat = torch.sqrt(1.0 - alphas_hat)
         self.num_timesteps = int(betas.shape[0])
         self.flat = FlatParams(model, int(bucket_mb * (1 << 20)))
+        self.optimizer = FlatAdam(self, self.flat.params, float(lr), (float(beta1), float(beta2)), float(eps), float(weight_decay))
         self.group = process_group
         self.reducer = GradReducer(self.flat, process_group, exchange_single_rank)
         self.world = self.reducer.world
@@ -207,6 +256,21 @@ class DiffusionTrainStep:
         self.step_count = 0
         self.last_norm: Optional[Tensor] = None
         self._rng = np.random  # the reference draws t0 from numpy's global generator (diffusion_trainer.py:111)
+
+    # hyper-parameters live in the optimizer face's single parameter group (what a scheduler rewrites)
+    def _hp(self, key):
+        return self.optimizer.param_groups[0][key]
+
+    lr = property(lambda self: float(self._hp("lr")), lambda self, v: self.optimizer.param_groups[0].__setitem__("lr", float(v)))
+    betas = property(lambda self: tuple(float(b) for b in self._hp("betas")),
+                     lambda self, v: self.optimizer.param_groups[0].__setitem__("betas", (float(v[0]), float(v[1]))))
+    eps = property(lambda self: float(self._hp("eps")), lambda self, v: self.optimizer.param_groups[0].__setitem__("eps", float(v)))
+    weight_decay = property(lambda self: float(self._hp("weight_decay")),
+                            lambda self, v: self.optimizer.param_groups[0].__setitem__("weight_decay", float(v)))
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
 
     # ---- R/diffusion_trainer.py:78-120 (training branch) ----
     def prepare_data(self, sal_maps: Tensor, *, t0: Optional[int] = None, noise: Optional[Tensor] = None,
@@ -247,7 +311,7 @@ class DiffusionTrainStep:
             off += b.numel()
 
     def loss_and_backward(self, x0: Tensor, x_t: Tensor, t: Tensor, cond: Dict) -> Tensor:
-        """Forward + MSE + backward + gradient exchange; leaves the rank-SUMMED gradient in ``flat.flat_g``."""
+        """Forward + loss + backward + gradient exchange; leaves the rank-SUMMED gradient in ``flat.flat_g``."""
         from . import autograd_ops as ag
 
         self.model.train()
@@ -259,7 +323,19 @@ class DiffusionTrainStep:
 
         with ops.batched_packs():        # every parameter's kernel layouts (forward, data-gradient) rebuilt by one launch
             pred = self._forward(x_t, t, cond)
-            loss = ag.mse_loss(pred, x0, self.mse_weight / x0.shape[0])
+            if self.loss_fn is None:
+                loss = ag.mse_loss(pred, x0, self.mse_weight / x0.shape[0])
+                self.last_losses = None
+            else:
+                out = self.loss_fn(pred, x0)
+                if isinstance(out, dict):
+                    self.last_losses = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+                    loss = out["total"]
+                else:
+                    self.last_losses, loss = None, out
+                if not torch.is_tensor(loss) or loss.dim() != 0 or not loss.requires_grad:
+                    raise RuntimeError("DiffusionTrainStep: loss_fn must return a scalar tensor (or a dict with 'total') that "
+                                       "carries a gradient to the prediction")
             loss.backward()
         self.reducer.finish()
         return loss.detach()

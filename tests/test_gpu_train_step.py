@@ -454,3 +454,58 @@ def test_fused_tape_nodes_leave_every_gradient_where_the_separate_nodes_put_it(m
     for k in g_f:
         den = g_s[k].abs().max().item() + 1e-12
         assert (g_f[k] - g_s[k]).abs().max().item() / den < 2e-5, k
+
+
+def test_train_step_with_the_reference_loss_dictionary_and_a_scheduler():
+    """DiffusionTrainStep(loss_config=...) trains on get_lossv2's total (R/diffusion_trainer.py:219: MSE main term + weighted
+    CC / NSS here), every term's gradient reaching the parameters: loss values equal the stand-alone losses of the same
+    prediction, the gradient equals autograd of (mse + cc + nss) assembled by hand from the same operators, the update differs
+    from the MSE-only step, and torch's MultiStepLR drives the flat Adam's learning rate."""
+    from diff_sal_amd import autograd_ops as ag
+    from diff_sal_amd import sal_losses
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    B = 2
+    x, feats, audio = orc.synth_inputs(cfg, B, True, tag="losshook")
+    sal = torch.sigmoid(x).to(DEV)
+    cond = {"feat_list": [f.to(DEV) for f in feats], "audio_feat": audio.to(DEV)}
+    lc = type("L", (), dict(loss_kl=False, loss_ce=False, loss_mse=True, mse_weight=1.0, loss_cc=True, cc_weight=-300.0,
+                            loss_sim=False, sim_weight=0.0, loss_nss=True, nss_weight=-100.0))()
+    config = type("C", (), {"loss": lc})()
+
+    def make(**kw):
+        net = build(cfg, sd)
+        net.dropout_p = 0.0
+        return net, DiffusionTrainStep(net, lr=1e-3, gaussian_dequantization=False, **kw)
+
+    noise = torch.randn(sal.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    net_a, ts_a = make(loss_config=config)
+    x0, x_t, t, _ = ts_a.prepare_data(sal, t0=321, noise=noise)
+    loss_a = ts_a.loss_and_backward(x0, x_t, t, cond)
+    d = ts_a.last_losses
+    assert set(d) == {"total", "main", "cc", "sim", "nss"}
+    assert abs(float(d["total"]) - float(d["main"] + d["cc"] + d["sim"] + d["nss"])) < 1e-5 * max(1.0, abs(float(d["total"])))
+    assert float(loss_a) == pytest.approx(float(d["total"]))
+    g_a = ts_a.flat.flat_g.clone()
+    # the same total assembled by hand on a second copy of the network
+    net_b, ts_b = make(loss_fn=lambda p, g: ag.mse_loss(p, g, 1.0 / p.shape[0]) - 300.0 * sal_losses.cc_s2(p, g) - 100.0 * sal_losses.nss2(p, g))
+    loss_b = ts_b.loss_and_backward(x0, x_t, t, cond)
+    assert float(loss_b) == pytest.approx(float(loss_a), rel=1e-5)
+    assert (ts_b.flat.flat_g - g_a).abs().max().item() <= 1e-5 * g_a.abs().max().item()
+    # MSE only: a different gradient
+    net_c, ts_c = make()
+    ts_c.loss_and_backward(x0, x_t, t, cond)
+    assert (ts_c.flat.flat_g - g_a).abs().max().item() > 1e-3 * g_a.abs().max().item()
+    # scheduler on the optimizer face: lr 1e-3 for two steps, then 1e-4
+    sched = torch.optim.lr_scheduler.MultiStepLR(ts_a.optimizer, milestones=[2], gamma=0.1)
+    before = ts_a.flat.flat_p.clone()
+    deltas = []
+    for _ in range(3):
+        ts_a.optimizer.step()
+        sched.step()
+        deltas.append((ts_a.flat.flat_p - before).abs().max().item())
+        before = ts_a.flat.flat_p.clone()
+    assert ts_a.lr == pytest.approx(1e-4) and ts_a.step_count == 3
+    assert deltas[2] < 0.2 * deltas[0]              # Adam's step size follows the learning rate

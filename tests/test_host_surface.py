@@ -206,3 +206,49 @@ def test_rel_table_plan_reproduces_interpolate_and_gather_and_its_transpose():
             for e in range(int(ptr[row]), int(ptr[row + 1])):
                 d[row] += cw[e] * flat[col[e]]
         assert torch.allclose(d, rel.grad, rtol=1e-4, atol=1e-4), (rel_len, q, k, (d - rel.grad).abs().max())
+
+
+def test_train_step_optimizer_face_drives_lr_through_torch_schedulers():
+    """R/util/utils.py:116-123 wraps Adam in MultiStepLR and R/diffusion_trainer.py:296 steps it once per epoch: the same
+    scheduler object must be able to drive DiffusionTrainStep's flat Adam (host logic only: no optimizer step runs here)."""
+    import warnings
+
+    import torch
+    from torch import nn
+
+    from diff_sal_amd.train_step import DiffusionTrainStep, FlatAdam
+
+    net = nn.Sequential(nn.Linear(8, 8), nn.Linear(8, 4))
+    ts = DiffusionTrainStep(net, lr=1e-4, weight_decay=0.0)
+    assert isinstance(ts.optimizer, FlatAdam) and isinstance(ts.optimizer, torch.optim.Optimizer)
+    assert len(ts.param_groups) == 1 and ts.param_groups[0]["lr"] == 1e-4
+    assert sum(p.numel() for p in ts.param_groups[0]["params"]) == sum(p.numel() for p in net.parameters())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # "lr_scheduler.step() before optimizer.step()": no HIP step on this host
+        sched = torch.optim.lr_scheduler.MultiStepLR(ts.optimizer, milestones=[2, 4], gamma=0.1)
+        lrs = []
+        for _ in range(5):
+            lrs.append(ts.lr)
+            sched.step()
+    assert lrs == pytest.approx([1e-4, 1e-4, 1e-5, 1e-5, 1e-6])
+    ts.lr = 3e-4                                   # the attribute and the group are one value
+    assert ts.param_groups[0]["lr"] == 3e-4
+    sd = ts.optimizer.state_dict()                 # torch.optim.Adam checkpoint format, from the owner
+    assert sd["param_groups"][0]["lr"] == 3e-4 and sd["state"] == {}
+    with pytest.raises(RuntimeError):
+        ts.optimizer.add_param_group({"params": [nn.Parameter(torch.zeros(3))]})
+
+
+def test_train_step_loss_hook_arguments():
+    import torch
+    from torch import nn
+
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    net = nn.Linear(4, 4)
+    with pytest.raises(ValueError):
+        DiffusionTrainStep(net, loss_fn=lambda p, g: (p - g).square().sum(), loss_config=object())
+    cfg = type("C", (), {"loss": type("L", (), dict(loss_kl=False, loss_ce=False, loss_mse=True, mse_weight=1.0, loss_cc=True, cc_weight=-0.1,
+                                                     loss_sim=False, sim_weight=0.0, loss_nss=False, nss_weight=0.0))()})()
+    ts = DiffusionTrainStep(nn.Linear(4, 4), loss_config=cfg)
+    assert callable(ts.loss_fn) and ts.last_losses is None

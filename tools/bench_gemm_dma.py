@@ -33,6 +33,20 @@ SHAPES = [
     ("nin1      ", 5376, 192, 384, True, 0, False),
     ("nin2      ", 1344, 384, 768, True, 0, False),
     ("ragged    ", 3000, 288, 200, True, 1, True),
+    # one clip per step (B = 1: 9 frames)
+    ("b1 s0.q   ", 756, 768, 768, True, 0, False),
+    ("b1 s0.fc1 ", 756, 768, 1536, True, 2, False),
+    ("b1 s0.fc2 ", 756, 1536, 768, True, 0, True),
+    ("b1 s1.tap ", 756, 768, 3456, False, 0, False),
+    ("b1 s1.q   ", 3024, 384, 384, True, 0, False),
+    ("b1 s1.fc1 ", 3024, 384, 768, True, 2, False),
+    ("b1 s1.fc2 ", 3024, 768, 384, True, 0, True),
+    ("b1 s2.tap ", 3024, 384, 1728, False, 0, False),
+    ("b1 s2.q   ", 12096, 192, 192, True, 0, False),
+    ("b1 s2.fc1 ", 12096, 192, 384, True, 2, False),
+    ("b1 s2.fc2 ", 12096, 384, 192, True, 0, True),
+    ("b1 s3.tap ", 12096, 192, 864, False, 0, False),
+    ("b1 mt.tap ", 7140, 768, 864, False, 0, False),
 ]
 
 
