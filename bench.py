@@ -356,6 +356,9 @@ class Top(torch.nn.Module):
         self.decoder_net, self.audio_net, self.visual_net = net, None, None
 
 
+EXCHANGE_MODE = "allreduce"     # --exchange: how the gradient buckets are summed over the ranks (train_step.GradReducer)
+
+
 def build_train_step(cfg, net, feats, audio, dev, rank, *, batch, av, full, exchange_single_rank=False):
     """The model, inputs and DiffusionTrainStep of BASELINE configs[3] on this rank's synthetic clips."""
     import numpy as np
@@ -385,10 +388,10 @@ def build_train_step(cfg, net, feats, audio, dev, rank, *, batch, av, full, exch
         cond = {"img": torch.randn((B, 3, 16, H, W), generator=g).to(dev)}
         if av:
             cond["audio"] = torch.randn((B, 1, 9, H // 2, W // 2), generator=g).to(dev)
-        ts = DiffusionTrainStep(model, exchange_single_rank=exchange_single_rank)
+        ts = DiffusionTrainStep(model, exchange_single_rank=exchange_single_rank, exchange=EXCHANGE_MODE)
     else:
         cond = {"feat_list": feats, "audio_feat": audio}
-        ts = DiffusionTrainStep(net, exchange_single_rank=exchange_single_rank)   # reference hyper-parameters: Adam 1e-4, clip 1.0, dropout 0.1
+        ts = DiffusionTrainStep(net, exchange_single_rank=exchange_single_rank, exchange=EXCHANGE_MODE)   # reference hyper-parameters: Adam 1e-4, clip 1.0, dropout 0.1
     ts._rng = np.random.RandomState(99)               # same timestep sequence on every rank / run
     return ts, sal, cond
 
@@ -442,6 +445,7 @@ def exchange_report(ts, sal, cond, steps, dev, world, ms_with):
     flat, red = ts.flat, ts.reducer
     rep = {"backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if _dist_on() else "none",
            "world": world, "collective_executed": bool(_dist_on() and red.exchange),
+           "mode": red.mode, "collectives_per_bucket": list(red.collectives),
            "bytes_per_step_per_rank": int(flat.numel * 4), "buckets_mb": [round(len(r) * 4 / 2 ** 20, 2) for r in flat.buckets]}
     chk = torch.stack([flat.flat_p.double().sum(), flat.flat_p.double().abs().sum()])
     lo, hi = chk.clone(), chk.clone()
@@ -635,6 +639,9 @@ def main():
     ap.add_argument("--dump-launches", default=None,
                     help="write every operator launch of the profiled step (class, GFLOP, MB, us, TF/s, GB/s) to this JSON file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["allreduce", "reduce_scatter"], default="allreduce",
+                    help="training legs: gradient buckets summed by one ring all-reduce each (default) or by reduce-scatter + "
+                         "all-gather (same result; for A/B on an xGMI node)")
     ap.add_argument("--no-cpu-trajectory", action="store_true",
                     help="cpu_baseline without its one 50-NFE single-clip trajectory (~10-15 s of CPU time)")
     ap.add_argument("--no-train-leg", action="store_true",
@@ -646,12 +653,17 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 is the fastest setting measured on the 256-core box)")
     args = ap.parse_args()
+    global EXCHANGE_MODE
+    EXCHANGE_MODE = args.exchange
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("DIFFSAL_BENCH_FAULT_RANK") == str(rank) and world > 1:
+        # test hook (tests/test_host_surface.py): this rank dies before the rendezvous; spawn_ranks must end its peers
+        sys.exit(3)
     if not torch.cuda.is_available():
         return plumbing_only(args, rank, world)
     quiet_stdout()        # a rank process: from here on only `emit` writes to the real stdout

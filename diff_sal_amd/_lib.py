@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 SIGNATURES = {
@@ -100,11 +100,11 @@ SIGNATURES = {
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "diffsal_cast": (c_i, [c_f, c_i, c_f, c_i, C.c_long, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
-    "diffsal_attention_general": (c_i, [c_f] * 8 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f, c_f]),
+    "diffsal_attention_general": (c_i, [c_f] * 8 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f, c_sz, c_f]),
     "diffsal_attention_general_tail_floats": (c_sz, [c_i] * 5),
     "diffsal_attention_general_bwd_splits": (c_i, [c_i] * 4),
     "diffsal_attention_general_bwd_qtail_floats": (c_sz, [c_i] * 6),
-    "diffsal_attention_general_bwd": (c_i, [c_f] * 16 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f]),
+    "diffsal_attention_general_bwd": (c_i, [c_f] * 12 + [c_sz] + [c_f] * 4 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f]),
     "diffsal_im2col3d": (c_i, [c_f, c_f] + [c_i] * 15 + [c_f]),
     "diffsal_pool3d_ln": (c_i, [c_f] * 5 + [c_i] * 9 + [C.c_long, C.c_long, c_fl, c_f]),
     "diffsal_maxpool_tokens": (c_i, [c_f, c_f] + [c_i] * 11 + [c_f]),

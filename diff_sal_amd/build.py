@@ -16,8 +16,22 @@ def _hipcc():
     return "hipcc"
 
 
+FLAGS_STAMP = os.path.join(CSRC, ".build_flags")
+
+
+def _flags_changed(extra):
+    """The objects / library on disk were built with another DIFFSAL_EXTRA_HIPCC_FLAGS set (e.g. -DDIFFSAL_DEV_STAMPS): a plain
+    build must not take an instrumented library for up to date (and vice versa)."""
+    try:
+        return open(FLAGS_STAMP).read() != " ".join(extra)
+    except OSError:
+        return bool(extra)
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    if _flags_changed(os.environ.get("DIFFSAL_EXTRA_HIPCC_FLAGS", "").split()):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [
@@ -51,11 +65,12 @@ def build_library(force=False, verbose=False):
         return LIB
     common = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "diffsal.h")]
     extra = os.environ.get("DIFFSAL_EXTRA_HIPCC_FLAGS", "").split()
+    force = force or _flags_changed(extra)
     objs, todo = [], []
     for s in SOURCES:
         src, o = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-        if force or extra or _stale(src, o, common):
+        if force or _stale(src, o, common):
             todo.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", src, "-o", o])
     running, failed, jobs = [], [], _jobs()
     while todo or running:
@@ -73,6 +88,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(" ".join(extra))
     return LIB
 
 

@@ -801,7 +801,7 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
                                          const float* v, const float* residual, float* out, float* lse, int B, int H, int Lq, int Lk,
                                          int D, int E, int DV, const long* q_strides, const long* k_strides,
                                          const long* v_strides, const long* r_strides, float scale, int skip_first,
-                                         float* tail_ws, diffsal_stream_t stream) {
+                                         float* tail_ws, size_t tail_ws_floats, diffsal_stream_t stream) {
   DS_REQUIRE(q && k && v && out && q_strides && k_strides && v_strides, DIFFSAL_E_ARG, "attention_general: null argument");
   DS_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && static_cast<long>(B) * H < 65536, DIFFSAL_E_SHAPE,
              "attention_general: bad shape B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
@@ -823,7 +823,12 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
   a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale; a.skip_first = skip_first;
   a.qb_bh = B * H;
   attention_tail_plan(B * H, Lq, Lk, &a.qb_x, &a.qb_full, &a.qb_split);
-  if (!tail_ws || !aligned16(tail_ws)) { a.qb_full = a.qb_x * a.qb_bh; a.qb_split = 1; }     // no scratch: every block whole
+  // no scratch, or less than this plan's pieces need (diffsal_attention_general_tail_floats): every block whole
+  if (!tail_ws || !aligned16(tail_ws) || tail_ws_floats < diffsal_attention_general_tail_floats(B, H, Lq, Lk, DV)) {
+    a.qb_full = a.qb_x * a.qb_bh;
+    a.qb_split = 1;
+    tail_ws = nullptr;
+  }
   a.o_slabs = tail_ws;
   a.l_slabs = tail_ws ? tail_ws + static_cast<long>(a.qb_split) * B * H * Lq * DV : nullptr;
   const int total = a.qb_x * a.qb_bh, n_tail = total - a.qb_full;
@@ -869,8 +874,8 @@ extern "C" size_t diffsal_attention_general_bwd_qtail_floats(int B, int H, int L
 
 extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra,
                                              const float* v, const float* residual, const float* out, const float* lse,
-                                             const float* dout, float* delta_ws, float* kv_part_ws, float* q_tail_ws, float* dq,
-                                             float* dq_extra,
+                                             const float* dout, float* delta_ws, float* kv_part_ws, float* q_tail_ws,
+                                             size_t q_tail_ws_floats, float* dq, float* dq_extra,
                                              float* dk, float* dv, int B, int H, int Lq, int Lk, int D, int E, int DV,
                                              const long* q_strides, const long* k_strides, const long* v_strides,
                                              const long* r_strides, float scale, int skip_first, diffsal_stream_t stream) {
@@ -893,7 +898,12 @@ extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extr
   a.kv_part = kv_part_ws;
   a.qb_bh = B * H;
   attention_tail_plan(B * H, Lq, Lk, &a.qb_x, &a.qb_full, &a.qb_split);
-  if (!q_tail_ws || !aligned16(q_tail_ws)) { a.qb_full = a.qb_x * a.qb_bh; a.qb_split = 1; }     // no scratch: every block whole
+  // no scratch, or less than this plan's pieces need (diffsal_attention_general_bwd_qtail_floats): every block whole
+  if (!q_tail_ws || !aligned16(q_tail_ws) || q_tail_ws_floats < diffsal_attention_general_bwd_qtail_floats(B, H, Lq, Lk, D, E)) {
+    a.qb_full = a.qb_x * a.qb_bh;
+    a.qb_split = 1;
+    q_tail_ws = nullptr;
+  }
   a.q_slabs = q_tail_ws;
   DS_REQUIRE(a.q_splits == 1 || (kv_part_ws && aligned16(kv_part_ws)), DIFFSAL_E_ARG,
              "attention_general_bwd: %d query splits need kv_part_ws of splits * B*H*Lk*(D+DV) floats", a.q_splits);

@@ -615,7 +615,10 @@ extern "C" int diffsal_block_front(const void* x, const void* k, const void* v, 
   DS_REQUIRE(static_cast<long>(N) * H * W * C < (1L << 31), DIFFSAL_E_SHAPE, "block_front: tensor too large for one launch");
   DS_REQUIRE(dtype == DIFFSAL_F32 || dtype == DIFFSAL_BF16 || dtype == DIFFSAL_F16, DIFFSAL_E_ARG, "block_front: dtype %d", dtype);
   DS_REQUIRE(dtype != DIFFSAL_F32 || (wp && bias_p), DIFFSAL_E_ARG, "block_front: fp32 storage needs the output projection");
-  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(g1) && aligned16(b1), DIFFSAL_E_ALIGN, "block_front: misaligned pointer");
+  DS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(g1) && aligned16(b1) && aligned16(k) && aligned16(v) && aligned16(w9) &&
+                 aligned16(gq) && aligned16(bq) && aligned16(wq) && aligned16(bias_q) && (!wp || aligned16(wp)) &&
+                 (!bias_p || aligned16(bias_p)),
+             DIFFSAL_E_ALIGN, "block_front: misaligned pointer (every operand is read in 16-byte pieces)");
   DS_REQUIRE(out != x, DIFFSAL_E_ARG, "block_front: in-place operation is not supported (neighbouring tiles read the halo)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_y = (H + FT_TH - 1) / FT_TH, tiles_x = (W + FT_TW - 1) / FT_TW;

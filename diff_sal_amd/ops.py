@@ -477,7 +477,9 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
 
     ``pad`` is (top, left); bottom/right padding is implied by ``out_hw`` (zero fill outside).  ``wino``: the same weight in
     Winograd form (``pack_wino_weight``); used instead of the direct kernel when the library's planner expects a gain
-    (``diffsal_conv_wino_supported``: fp32 3x3 stride-1, padding = dilation in {1, 2}, Cin and Cout >= 192)."""
+    (``diffsal_conv_wino_supported``: fp32 3x3 stride-1, padding = dilation in {1, 2}, Cin % 32 == 0, Cout >= 128, enough
+    workgroups and a transformed input of at most 160 MB -- both depend on the BATCH, so the same clip can take the Winograd
+    kernel in a large pass and the direct kernel alone: results then differ by the transforms' ~1e-6 relative rounding)."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
@@ -1327,7 +1329,7 @@ def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra:
         _lib.check(lib.diffsal_attention_general(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
             _p(out), _p(lse), B, H, Lq, Lk, D, E, DV, _bhl_strides(q), _bhl_strides(k), _bhl_strides(v),
-            None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _p(tail), _stream()),
+            None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _p(tail), nt, _stream()),
             "attention_general")
     return (out, lse) if want_lse else out
 
@@ -1352,7 +1354,7 @@ def attention_general_bwd(q, k, v, out, lse, dout, *, scale: float, q_extra=None
     with _prof("attn-bwd", flops, _nb(q, k, v, out, dout, dq, dk, dv)):
         _lib.check(lib.diffsal_attention_general_bwd(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
-            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(q_tail), _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk,
+            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(q_tail), nq, _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk,
             D, E, DV,
             _bhl_strides(q), _bhl_strides(k), _bhl_strides(v), None if residual is None else _bhl_strides(residual),
             float(scale), int(skip_first), _stream()), "attention_general_bwd")

@@ -121,22 +121,39 @@ class GradReducer:
     consumer).
 
     ``flat.zero_grad()`` then ``arm()`` before backward; when the last gradient of a bucket has been produced its
-    per-parameter hook gathers the bucket into the flat buffer (one kernel) and launches the bucket's all-reduce;
+    per-parameter hook gathers the bucket into the flat buffer (one kernel) and launches the bucket's exchange;
     ``finish()`` handles whatever is left (buckets holding parameters that received no gradient this step) and
-    waits for all of them."""
+    waits for all of them.
 
-    def __init__(self, flat: FlatParams, group=None, exchange_single_rank: bool = False):
-        self.flat, self.group = flat, group
+    Collectives are issued strictly in bucket order 0, 1, 2, ... on every rank: a bucket that completes while an earlier
+    one is still open waits for it.  Ranks whose graphs differ (a parameter that receives no gradient on ONE rank only --
+    its bucket closes in ``finish()`` there, in the middle of backward elsewhere) therefore still pair the same buffers in
+    the same order; an order taken from hook arrival would pair different buckets across ranks and hang RCCL.
+
+    ``exchange``: "allreduce" -- one ring all-reduce per bucket; "reduce_scatter" -- reduce-scatter of the bucket into
+    per-rank shards followed by an all-gather of the shards (same result; on xGMI's point-to-point links the two halves
+    can use all seven links of a GPU where a single ring is bound by one link per hop).  Buckets whose
+    length is not a multiple of the world size, and backends without reduce-scatter (gloo), use the all-reduce."""
+
+    def __init__(self, flat: FlatParams, group=None, exchange_single_rank: bool = False, exchange: str = "allreduce"):
+        if exchange not in ("allreduce", "reduce_scatter"):
+            raise ValueError(f"GradReducer: exchange={exchange!r} (allreduce or reduce_scatter)")
+        self.flat, self.group, self.mode = flat, group, exchange
         have_group = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if have_group else 1
+        self.rank = dist.get_rank(group) if have_group else 0
         # whether the collective is issued: always with more than one rank; with ONE rank only on request (the call path --
         # hook, bucket gather, asynchronous all_reduce, wait -- then runs unchanged, RCCL reducing over a single rank)
         self.exchange = self.world > 1 or (have_group and bool(exchange_single_rank))
+        self._native_rs = have_group and dist.get_backend(group) == "nccl"
         self._pending: List[int] = []
         self._launched: List[bool] = []
+        self._ready: List[bool] = []
+        self._next = 0
         self._work = []
         self._armed = False
         self.launch_order: List[int] = []
+        self.collectives: List[str] = []       # what was issued per bucket in the last step ("allreduce" / "reduce_scatter+all_gather")
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -147,8 +164,14 @@ class GradReducer:
             b = self.flat.bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:
-                self._launch(b)
+                self._ready[b] = True
+                self._drain()
         return hook
+
+    def _drain(self) -> None:
+        while self._next < len(self._ready) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, b: int) -> None:
         if self._launched[b]:
@@ -157,19 +180,35 @@ class GradReducer:
         r = self.flat.buckets[b]
         self.launch_order.append(b)
         self.flat.gather(self.flat.bucket_members[b])
-        if self.exchange:
-            self._work.append(dist.all_reduce(self.flat.flat_g[r.start:r.stop], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+        if not self.exchange:
+            return
+        buf = self.flat.flat_g[r.start:r.stop]
+        n = buf.numel()
+        if self.mode == "reduce_scatter" and n % self.world == 0:
+            self.collectives.append("reduce_scatter+all_gather")
+            shard = n // self.world
+            mine = buf[self.rank * shard:(self.rank + 1) * shard]
+            if self._native_rs:      # in place: the output is this rank's slice of the input (RCCL's in-place form)
+                self._work.append(dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._work.append(dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True))
+            else:                    # gloo has no reduce-scatter: same arithmetic through its all-reduce (bookkeeping tests)
+                self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.collectives.append("allreduce")
+            self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def arm(self) -> None:
         self._pending = list(self.flat.bucket_size)
         self._launched = [False] * len(self.flat.buckets)
-        self._work, self.launch_order = [], []
+        self._ready = [False] * len(self.flat.buckets)
+        self._next = 0
+        self._work, self.launch_order, self.collectives = [], [], []
         self._armed = True
 
     def finish(self) -> None:
-        for b in range(len(self.flat.buckets)):
-            self._launch(b)
+        for b in range(len(self.flat.buckets)):     # the rest, in bucket order
+            self._ready[b] = True
+        self._drain()
         for w in self._work:
             w.wait()
         self._work, self._armed = [], False
@@ -227,7 +266,7 @@ class DiffusionTrainStep:
                  num_diffusion_timesteps: int = 1000, gaussian_dequantization: bool = True,
                  bucket_mb: float = 32.0, process_group=None, broadcast_buffers: bool = True,
                  store_clipped_grad: bool = False, exchange_single_rank: bool = False,
-                 loss_fn: Optional[Callable] = None, loss_config=None):
+                 loss_fn: Optional[Callable] = None, loss_config=None, exchange: str = "allreduce"):
         self.model = model
         self.grad_clip, self.mse_weight = float(grad_clip), float(mse_weight)
         if loss_fn is not None and loss_config is not None:
@@ -250,7 +289,7 @@ class DiffusionTrainStep:
         self.flat = FlatParams(model, int(bucket_mb * (1 << 20)))
         self.optimizer = FlatAdam(self, self.flat.params, float(lr), (float(beta1), float(beta2)), float(eps), float(weight_decay))
         self.group = process_group
-        self.reducer = GradReducer(self.flat, process_group, exchange_single_rank)
+        self.reducer = GradReducer(self.flat, process_group, exchange_single_rank, exchange)
         self.world = self.reducer.world
         self.broadcast_buffers = bool(broadcast_buffers) and self.reducer.exchange
         self.step_count = 0

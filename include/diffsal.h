@@ -470,8 +470,8 @@ int diffsal_attention_general(const float* q, const float* q_extra, const float*
                               const float* residual, float* out, float* lse /*[B,H,Lq] row log-sum-exp, or NULL*/, int B,
                               int H, int Lq, int Lk, int D, int E, int DV, const long* q_strides /*host [3]*/,
                               const long* k_strides, const long* v_strides, const long* r_strides, float scale,
-                              int skip_first, float* tail_ws, diffsal_stream_t stream);
-/* tail_ws (optional): diffsal_attention_general_tail_floats(...) floats.  With it the blocks of the last, partly filled
+                              int skip_first, float* tail_ws, size_t tail_ws_floats, diffsal_stream_t stream);
+/* tail_ws (optional): tail_ws_floats >= diffsal_attention_general_tail_floats(...) floats (a smaller buffer is ignored).  With it the blocks of the last, partly filled
  * round of workgroups are cut into pieces over the keys and a finishing launch merges the pieces' outputs by their
  * log-sum-exps; without it (NULL, or the function returned 0) every block runs whole. */
 size_t diffsal_attention_general_tail_floats(int B, int H, int Lq, int Lk, int DV);
@@ -479,13 +479,14 @@ size_t diffsal_attention_general_tail_floats(int B, int H, int Lq, int Lk, int D
  * head-major tensors: dq [B,H,Lq,D] (includes the residual path's dO when `residual` was given), dq_extra [B,H,Lq,E]
  * (NULL iff E == 0), dk [B,H,Lk,D], dv [B,H,Lk,DV]; k_extra is a constant table and gets no gradient.  No atomics. */
 int diffsal_attention_general_bwd_splits(int B, int H, int Lq, int Lk); /* S; kv_part_ws needs S*B*H*Lk*(D+DV) floats if S > 1 */
-/* q_tail_ws (optional): diffsal_attention_general_bwd_qtail_floats(...) floats.  With it the dq kernel cuts the blocks of its
+/* q_tail_ws (optional): q_tail_ws_floats >= diffsal_attention_general_bwd_qtail_floats(...) floats (a smaller buffer is ignored).  With it the dq kernel cuts the blocks of its
  * last, partly filled round of workgroups into pieces over the keys and a finishing launch adds their partial rows (fixed
  * order); without it (NULL, or the function returned 0) every block runs whole. */
 size_t diffsal_attention_general_bwd_qtail_floats(int B, int H, int Lq, int Lk, int D, int E);
 int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
                                   const float* residual, const float* out, const float* lse, const float* dout,
-                                  float* delta_ws, float* kv_part_ws, float* q_tail_ws, float* dq, float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
+                                  float* delta_ws, float* kv_part_ws, float* q_tail_ws, size_t q_tail_ws_floats, float* dq,
+                                  float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
                                   int Lk, int D, int E, int DV, const long* q_strides, const long* k_strides,
                                   const long* v_strides, const long* r_strides, float scale, int skip_first,
                                   diffsal_stream_t stream);

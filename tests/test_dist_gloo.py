@@ -129,3 +129,79 @@ def test_two_rank_bucketed_gradient_allreduce():
         assert ret[r]["nb"] >= 3
         assert sorted(ret[r]["order"]) == list(range(ret[r]["nb"]))   # every bucket exchanged exactly once
     assert ret[0]["order"] == ret[1]["order"]                          # same collective order on every rank
+
+
+# ---- wider worlds, uneven buckets, rank-dependent graphs, both exchange modes ----
+class _Branchy(torch.nn.Module):
+    """Uneven parameter sizes (buckets of 1 .. 2 tensors at 512 B), and a branch that only some ranks execute."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(7, 300)        # 2100 + 300 parameters: a bucket of its own
+        self.side = torch.nn.Linear(300, 300)   # used on even ranks only
+        self.b = torch.nn.Linear(300, 5)
+        self.tiny = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(3)) for _ in range(6)])
+
+    def forward(self, x, use_side):
+        h = torch.tanh(self.a(x))
+        if use_side:
+            h = h + torch.tanh(self.side(h))
+        y = self.b(h)
+        return y + sum(t.sum() for t in self.tiny)
+
+
+def _branchy_worker(rank, world, port, mode, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from diff_sal_amd.train_step import FlatParams, GradReducer
+
+    dsd.init_from_env("gloo")
+    torch.manual_seed(11)
+    m = _Branchy()
+    flat = FlatParams(m, bucket_bytes=512)
+    red = GradReducer(flat, exchange=mode)
+    oks, orders = [], []
+    for it in range(2):
+        flat.zero_grad()
+        red.arm()
+        x = torch.randn(3, 7, generator=torch.Generator().manual_seed(50 * it + rank))
+        m(x, use_side=(rank % 2 == 0)).square().sum().backward()       # `side` gets no gradient on odd ranks
+        red.finish()
+        exp = torch.zeros_like(flat.flat_g)
+        for r in range(world):
+            torch.manual_seed(11)
+            m2 = _Branchy()
+            f2 = FlatParams(m2, bucket_bytes=512)
+            xr = torch.randn(3, 7, generator=torch.Generator().manual_seed(50 * it + r))
+            f2.zero_grad()
+            m2(xr, use_side=(r % 2 == 0)).square().sum().backward()
+            f2.gather(range(len(f2.params)))
+            exp += f2.flat_g
+        oks.append(bool(torch.allclose(flat.flat_g, exp, rtol=1e-5, atol=1e-5)))
+        orders.append(list(red.launch_order))
+    ret[rank] = dict(ok=oks, orders=orders, nb=len(flat.buckets), sizes=[len(b) for b in flat.buckets],
+                     members=[len(mm) for mm in flat.bucket_members], kinds=list(red.collectives))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(4, "allreduce"), (4, "reduce_scatter"), (8, "allreduce")])
+def test_many_rank_exchange_with_rank_dependent_graph(world, mode):
+    """4 and 8 gloo ranks; buckets of unequal membership; a layer that receives no gradient on the odd ranks (its bucket closes
+    in finish() there and during backward on the even ranks).  Every rank must issue the collectives in the same order --
+    bucket order -- or the exchange pairs different buffers; the summed gradient equals the sum of the per-rank gradients."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_branchy_worker, args=(world, port, mode, ret), nprocs=world, join=True)
+    nb = ret[0]["nb"]
+    assert nb >= 4 and len(set(ret[0]["members"])) >= 2                 # uneven membership
+    for r in range(world):
+        assert ret[r]["ok"] == [True, True], (r, ret[r])
+        assert ret[r]["orders"] == [list(range(nb))] * 2                 # strictly bucket order, on every rank, every step
+        assert len(ret[r]["kinds"]) == nb
+    if mode == "reduce_scatter":
+        # buckets whose length divides by the world take the reduce-scatter + all-gather path, the others the all-reduce
+        kinds = ret[0]["kinds"]
+        for k, n in zip(kinds, ret[0]["sizes"]):
+            assert k == ("reduce_scatter+all_gather" if n % world == 0 else "allreduce")
+        assert "reduce_scatter+all_gather" in kinds

@@ -252,3 +252,21 @@ def test_train_step_loss_hook_arguments():
                                                      loss_sim=False, sim_weight=0.0, loss_nss=False, nss_weight=0.0))()})()
     ts = DiffusionTrainStep(nn.Linear(4, 4), loss_config=cfg)
     assert callable(ts.loss_fn) and ts.last_losses is None
+
+
+def test_bench_ends_every_rank_when_one_dies():
+    """A rank that exits before the rendezvous leaves its peers waiting in init_process_group forever: spawn_ranks' watchdog
+    must notice the death, stop the others and return a failure code promptly (not after the job timeout)."""
+    import time
+
+    if torch.cuda.is_available():
+        pytest.skip("plumbing-only mode is for GPU-less hosts")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DIFFSAL_BENCH_FAULT_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--no-cpu-baseline", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert "rank failure" in r.stderr
+    assert time.time() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no result line from a broken job
