@@ -38,14 +38,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 struct DmaGemmArgs {
-  const float* a;
-  const float* w;
+  const void* a;          // storage type T of the launch (float, bf16, f16): activations, weights, residual, output
+  const void* w;
   const float* bias;
   const float* scale;
   const float* shift;
   const float* rowvec;
-  const float* residual;
-  float* out;
+  const void* residual;
+  void* out;
   int M, N, K;
   int act, rowvec_ld, rows_per_img;
   int n_tiles_m, n_tiles_n, n_tiles;
@@ -70,6 +70,17 @@ __device__ __forceinline__ void dma_piece(unsigned lds_addr, unsigned voff, i32x
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory", "m0");
 }
+
+typedef __bf16 dma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dma_f16x8 __attribute__((ext_vector_type(8)));
+// one 16 x 16 x 32 product of two 16-byte fragments (8 elements of k per lane), fp32 accumulation
+__device__ __forceinline__ f32x4v mma16(const float4& a, const float4& b, f32x4v c, const bf16_t*) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dma_bf16x8, a), __builtin_bit_cast(dma_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mma16(const float4& a, const float4& b, f32x4v c, const f16_t*) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dma_f16x8, a), __builtin_bit_cast(dma_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mma16(const float4&, const float4&, f32x4v c, const float*) { return c; }   // never called
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -100,8 +111,14 @@ __device__ __forceinline__ DmaGemmArgs pick_problem(const DmaGroupArgs& g, int i
   return r;
 }
 
-template <int TMB, int TNB, int STAGES, int OCC, bool CONV, bool GROUPED>
+// T: storage type.  fp32: a 128-byte K slice is 32 floats and every 16-byte fragment feeds four v_mfma_f32_16x16x4_f32; bf16 / f16:
+// 64 elements per slice, a fragment is the 8-element operand of ONE v_mfma_f32_16x16x32 (plain products only: the packed
+// convolution weights order K by 32-channel chunks).  Byte geometry -- rows, slots, swizzle, DMA pieces -- is the same.
+template <typename T, int TMB, int TNB, int STAGES, int OCC, bool CONV, bool GROUPED>
 __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<GROUPED, DmaGroupArgs, DmaGemmArgs> g) {
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int ESZ = sizeof(T);
+  static_assert(F32 || !CONV, "16-bit storage: plain products only");
   constexpr int BM = 32 * TMB, BN = 32 * TNB;
   constexpr int APW = BM / 32, BPW = BN / 32;          // 1 KiB DMA pieces (8 rows) per wave and slice
   constexpr int PPW = APW + BPW;
@@ -182,19 +199,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     }
     const int K = pi.K;
 #pragma unroll
-    for (int q = 0; q < VQ; ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K + slot * 4) * 4u;
+    for (int q = 0; q < VQ; ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K * ESZ + slot * 16);
     int tmi, tni;
     tile_mn(pi, iss_lv, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
     const int rows_b = live ? min(BN, pi.N - n0) : 0;
-    const unsigned long pb = reinterpret_cast<unsigned long>(pi.w + static_cast<long>(n0) * K);
-    rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * 4, 0x00020000};
+    const unsigned long pb = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.w) + static_cast<long>(n0) * K);
+    rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * ESZ, 0x00020000};
     const int kt0 = split_of(pi, iss_lv) * pi.kt_per_unit;
     iss_kofs = static_cast<unsigned>(kt0) * 128u;
     if constexpr (!CONV) {
       const int rows_a = live ? min(BM, pi.M - m0) : 0;
-      const unsigned long pa = reinterpret_cast<unsigned long>(pi.a + static_cast<long>(m0) * K);
-      rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * 4, 0x00020000};
+      const unsigned long pa = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.a) + static_cast<long>(m0) * K);
+      rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * ESZ, 0x00020000};
     } else {
       const unsigned long pa = reinterpret_cast<unsigned long>(pi.a);
       rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, static_cast<int>(live ? pi.in_bytes : 0u), 0x00020000};
@@ -287,15 +304,22 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
 #pragma unroll
     for (int f = 0; f < TMB + TNB; ++f) load_frag(st, h, set, f);
   };
-  auto mfma_one = [&](int set, int idx) __attribute__((always_inline)) {   // idx = (c * TMB + i) * TNB + j
+  // MFMA idx of a half slice.  fp32: idx = (c * TMB + i) * TNB + j, component c of the 16-byte fragments (four k per MFMA);
+  // 16-bit: idx = i * TNB + j, the whole fragment (eight k per lane, 32 per MFMA)
+  constexpr int NM = (F32 ? 4 : 1) * TMB * TNB;
+  auto mfma_one = [&](int set, int idx) __attribute__((always_inline)) {
     const int c = idx / (TMB * TNB), i = (idx / TNB) % TMB, j = idx % TNB;
-    const float av = c == 0 ? fa[set][i].x : c == 1 ? fa[set][i].y : c == 2 ? fa[set][i].z : fa[set][i].w;
-    const float bv = c == 0 ? fb[set][j].x : c == 1 ? fb[set][j].y : c == 2 ? fb[set][j].z : fb[set][j].w;
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
+    if constexpr (F32) {
+      const float av = c == 0 ? fa[set][i].x : c == 1 ? fa[set][i].y : c == 2 ? fa[set][i].z : fa[set][i].w;
+      const float bv = c == 0 ? fb[set][j].x : c == 1 ? fb[set][j].y : c == 2 ? fb[set][j].z : fb[set][j].w;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: rows = channels, cols = output rows
+    } else {
+      acc[i][j] = mma16(fb[set][j], fa[set][i], acc[i][j], static_cast<const T*>(nullptr));
+    }
   };
   auto do_mfmas = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int idx = 0; idx < 4 * TMB * TNB; ++idx) mfma_one(set, idx);
+    for (int idx = 0; idx < NM; ++idx) mfma_one(set, idx);
   };
 
   int cmp_v = bid, cmp_lv = bid;
@@ -318,7 +342,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
         for (int i = 0; i < TMB; ++i) {
           const int m = m0 + wm * TMB * 16 + i * 16 + r16;
           const bool ok = m < pc.M && n < pc.N;
-          rres[i][j] = ld4(pc.residual + (ok ? static_cast<long>(m) * pc.N + n : 0));
+          rres[i][j] = ld4(static_cast<const T*>(pc.residual) + (ok ? static_cast<long>(m) * pc.N + n : 0));
         }
       }
     }
@@ -331,7 +355,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     tile_mn(pc, cmp_lv, tmi, tni);
     const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
     const long o0 = static_cast<long>(mb) * pc.N + nb;
-    float* __restrict__ ob = pc.out + o0;
+    T* __restrict__ ob = static_cast<T*>(pc.out) + o0;
     const float* __restrict__ rvb = pc.rowvec;
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
@@ -426,17 +450,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     wait_vmcnt<WAIT_N>();
     __builtin_amdgcn_s_barrier();
     // second half of the slice: its MFMAs (operands already in registers) with the DMA pieces of slice g + P and the fragment
-    // reads of slice g + 1 slipped between them, one every GAP MFMAs -- a wave alone on its SIMD must not stop issuing MFMAs
+    // reads of slice g + 1 slipped between them at even distances -- a wave alone on its SIMD must not stop issuing MFMAs
     // for the ~60 cycles a DMA instruction takes to issue
     {
-      constexpr int NM = 4 * TMB * TNB, NX = PPW + TMB + TNB, GAP = NM / NX > 0 ? NM / NX : 1;
+      constexpr int NX = PPW + TMB + TNB;         // items to slip in: fragment reads first (the next step's first MFMAs wait for them)
 #pragma unroll
       for (int idx = 0; idx < NM; ++idx) {
         mfma_one(1, idx);
-        if ((idx + 1) % GAP == 0 && (idx + 1) / GAP <= NX) {
-          const int x = (idx + 1) / GAP - 1;
+#pragma unroll
+        for (int x = idx * NX / NM; x < (idx + 1) * NX / NM; ++x) {
           __builtin_amdgcn_sched_barrier(0);
-          if (x < TMB + TNB) load_frag(nxt, 0, 0, x);        // reads first: the next step's first MFMAs wait for them
+          if (x < TMB + TNB) load_frag(nxt, 0, 0, x);
           else issue_piece((S + P) % STAGES, x - TMB - TNB);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -471,7 +495,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
 }
 
 // Sum of the split-K slabs in a fixed order (deterministic) + the epilogue; float4 over N.
+template <typename T>
 __global__ __launch_bounds__(256) void gemm_dma_reduce_kernel(DmaGemmArgs p) {
+  const T* __restrict__ resid = static_cast<const T*>(p.residual);
+  T* __restrict__ outp = static_cast<T*>(p.out);
   const int n4 = p.N >> 2;
   const long total = static_cast<long>(p.M) * n4, slab = static_cast<long>(p.M) * p.N;
   for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
@@ -492,11 +519,16 @@ __global__ __launch_bounds__(256) void gemm_dma_reduce_kernel(DmaGemmArgs p) {
       if (p.act == DIFFSAL_ACT_RELU) x = fmaxf(x, 0.f);
       else if (p.act == DIFFSAL_ACT_GELU_ERF) x = gelu_erf(x);
       else if (p.act == DIFFSAL_ACT_SIGMOID) x = sigmoidf_(x);
-      if (p.act == DIFFSAL_ACT_GELU_GRAD) x *= gelu_erf_grad(p.residual[o + e]);
-      else if (p.residual) x += p.residual[o + e];
       v[e] = x;
     }
-    st4(p.out + o, make_float4(v[0], v[1], v[2], v[3]));
+    if (p.act == DIFFSAL_ACT_GELU_GRAD) {
+      const float4 t = ld4(resid + o);
+      v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
+    } else if (resid) {
+      const float4 t = ld4(resid + o);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    st4(outp + o, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
@@ -523,37 +555,46 @@ int choose_split(long tiles, int kt, int stages, long mn, double* t_out = nullpt
   return best;
 }
 
-template <int TMB, int TNB, int STAGES, int OCC>
+template <typename T, int TMB, int TNB, int STAGES, int OCC>
 int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   constexpr int BM = 32 * TMB, BN = 32 * TNB;
   const int slots = 256 * OCC;
   const int units = a.n_tiles * a.splits;
   const int grid = units < slots ? units : slots;
   a.xcd_order = (a.splits == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
-  if (conv) hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_dma_kernel<TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
-  note_kernel("gemm_dma_kernel<%d, %d, %d, %d, %s, false> [%dx%d tile, %d stages, split-K %d]", TMB, TNB, STAGES, OCC, conv ? "true" : "false",
-              BM, BN, STAGES, a.splits);
+  if constexpr (sizeof(T) == 4) {
+    if (conv) hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
+  }
+  note_kernel("gemm_dma_kernel<%s, %d, %d, %d, %d, %s, false> [%dx%d tile, %d stages, split-K %d]",
+              sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "__bf16" : "_Float16"), TMB, TNB, STAGES, OCC,
+              conv ? "true" : "false", BM, BN, STAGES, a.splits);
   int rc = check_launch("diffsal_conv_igemm(dma)");
   if (rc || a.splits == 1) return rc;
   long g = (static_cast<long>(a.M) * (a.N / 4) + 255) / 256;
   g = g > 2048 ? 2048 : g;
-  hipLaunchKernelGGL(gemm_dma_reduce_kernel, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gemm_dma_reduce_kernel<T>, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, a);
   return check_launch("diffsal_conv_igemm(dma split-K sum)");
 }
 
 struct DmaCfg { int bm, bn, stages; };
-const DmaCfg kDmaCfgs[4] = {{96, 96, 3}, {96, 96, 6}, {96, 192, 4}, {96, 192, 3}};
+constexpr int kNumDmaCfgs = 2;
+const DmaCfg kDmaCfgs[kNumDmaCfgs] = {{96, 96, 3}, {96, 96, 6}};
 
-// fills the problem-independent part of the arguments; false: shape not handled by tile configuration c
-bool dma_fill(DmaGemmArgs& g, const DmaCfg& c, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias,
-              const float* scale, const float* shift, const float* rowvec, int rowvec_ld, const float* residual, float* out) {
+// fills the problem-independent part of the arguments; false: shape not handled by tile configuration c.  esz: bytes per
+// element of the storage type (a K slice is 128 bytes of a row)
+bool dma_fill(DmaGemmArgs& g, const DmaCfg& c, const diffsal_conv_desc* d, bool as_conv, int esz, const void* a, const void* w,
+              const float* bias, const float* scale, const float* shift, const float* rowvec, int rowvec_ld, const void* residual, void* out) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const int K = d->KH * d->KW * d->Cin, N = d->Cout;
-  if (K % 32 != 0 || (K / 32) % c.stages != 0) return false;   // a unit must start on ring stage 0
+  const int epk = 128 / esz;                                       // elements per K slice
+  if (K % epk != 0 || (K / epk) % c.stages != 0) return false;     // a unit must start on ring stage 0
+  if (esz != 4 && as_conv) return false;
   // 32-bit byte offsets: plain products address A rows relative to the tile (any M), the output / residual through 64-bit
   // pointers; the weight matrix and (convolutions) the whole input must stay below 4 GiB, which validate() has checked
-  if (N % 4 != 0 || M <= 0 || M >= (1L << 31) || static_cast<long>(N) * K * 4 >= (1L << 32) - 16 || 96L * K * 4 >= (1L << 31)) return false;
+  if (N % 4 != 0 || M <= 0 || M >= (1L << 31) || static_cast<long>(N) * K * esz >= (1L << 32) - 16 || 96L * K * esz >= (1L << 31)) return false;
   if (!aligned16(a) || !aligned16(w) || !aligned16(out) || (bias && !aligned16(bias)) || (scale && !(aligned16(scale) && aligned16(shift))) ||
       (rowvec && !(aligned16(rowvec) && rowvec_ld % 4 == 0)) || (residual && !aligned16(residual)) || d->KH * d->KW > 32)
     return false;
@@ -569,58 +610,59 @@ bool dma_fill(DmaGemmArgs& g, const DmaCfg& c, const diffsal_conv_desc* d, bool 
     g.in_bytes = static_cast<unsigned>(static_cast<long>(d->N) * d->H * d->W * d->Cin * 4);
   }
   g.splits = 1;
-  g.kt_per_unit = K / 32;
+  g.kt_per_unit = K / epk;
   return true;
 }
 
 }  // namespace
 
-// Tile shapes of this kernel, in the order of TUNE_GEMM_DMA's value - 1.
+// Tile configurations of this kernel, in the order of DIFFSAL_GEMM_DMA's value - 1.
 //   0: 96 x 96, 3 stages (72 KB), two workgroups per CU      1: 96 x 96, 6 stages (144 KB), one per CU
-//   2: 96 x 192, 4 stages (144 KB), one per CU               3: 96 x 192, 3 stages (108 KB), one per CU
-// as_conv: the convolution form (taps, padding); false = d is a plain [M, K] x [N, K]^T product.  Split-K is planned when the
-// workspace allows (gemm_dma_ws_bytes).  Returns 1 if launched, 0 if the shape is not handled here, < 0 on error.
-size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N) {
-  if (cfg < 0 || cfg > 3 || K % 32 != 0) return 0;
+// (96 x 192 tiles were built and measured in round 4: 5-15 % slower on every shape of the step, removed.)
+// as_conv: the convolution form (taps, padding); false = d is a plain [M, K] x [N, K]^T product.  esz: 4 (fp32), 2 (dtype names
+// bf16 or f16; plain products only).  Split-K is planned when the workspace allows (gemm_dma_ws_bytes).  Returns 1 if launched,
+// 0 if the shape is not handled here, < 0 on error.
+size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N, int esz) {
+  if (cfg < 0 || cfg >= kNumDmaCfgs || K % (128 / esz) != 0) return 0;
   const DmaCfg& c = kDmaCfgs[cfg];
   const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
-  const int S = choose_split(tiles, K / 32, c.stages, M * N);
+  const int S = choose_split(tiles, K / (128 / esz), c.stages, M * N);
   return S > 1 ? static_cast<size_t>(S) * M * N * sizeof(float) : 0;
 }
 
-// the planner's time estimate (seconds) for this kernel on a plain M x K x N product, 1e30 if the shape is not handled
+// the planner's time estimate (seconds) for this kernel on a plain fp32 M x K x N product, 1e30 if the shape is not handled
 double gemm_dma_estimate(int cfg, long M, int K, int N) {
-  if (cfg < 0 || cfg > 3 || K % 32 != 0 || (K / 32) % kDmaCfgs[cfg].stages != 0) return 1e30;
+  if (cfg < 0 || cfg >= kNumDmaCfgs || K % 32 != 0 || (K / 32) % kDmaCfgs[cfg].stages != 0) return 1e30;
   const DmaCfg& c = kDmaCfgs[cfg];
   const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
   double t = 1e30;
   choose_split(tiles, K / 32, c.stages, M * N, &t);
-  return c.bn == 96 ? t : 2.0 * t * 0.95;     // a 96 x 192 slice is twice the work
+  return t;
 }
 
-int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias, const float* scale,
-                 const float* shift, const float* rowvec, int rowvec_ld, const float* residual, float* out, void* ws, size_t ws_bytes,
+int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* a, const void* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, int rowvec_ld, const void* residual, void* out, void* ws, size_t ws_bytes,
                  hipStream_t s) {
-  if (cfg < 0 || cfg > 3) return 0;
+  if (cfg < 0 || cfg >= kNumDmaCfgs) return 0;
   const DmaCfg& c = kDmaCfgs[cfg];
+  const int esz = d->dtype == DIFFSAL_F32 ? 4 : 2;
   DmaGemmArgs g;
-  if (!dma_fill(g, c, d, as_conv, a, w, bias, scale, shift, rowvec, rowvec_ld, residual, out)) return 0;
+  if (!dma_fill(g, c, d, as_conv, esz, a, w, bias, scale, shift, rowvec, rowvec_ld, residual, out)) return 0;
   const long MN = static_cast<long>(g.M) * g.N;
-  g.splits = choose_split(g.n_tiles, g.K / 32, c.stages, MN);
+  const int kt = g.kt_per_unit;
+  g.splits = choose_split(g.n_tiles, kt, c.stages, MN);
   if (g.splits > 1 && (!ws || ws_bytes < static_cast<size_t>(g.splits) * MN * sizeof(float) || !aligned16(ws))) g.splits = 1;
-  g.kt_per_unit = g.K / 32 / g.splits;
+  g.kt_per_unit = kt / g.splits;
   g.partial = g.splits > 1 ? static_cast<float*>(ws) : nullptr;
   int rc;
-  switch (cfg) {
-    case 0: rc = launch_dma<3, 3, 3, 2>(g, as_conv, s); break;
-    case 1: rc = launch_dma<3, 3, 6, 1>(g, as_conv, s); break;
-    case 2: rc = launch_dma<3, 6, 4, 1>(g, as_conv, s); break;
-    default: rc = launch_dma<3, 6, 3, 1>(g, as_conv, s); break;
-  }
+  if (d->dtype == DIFFSAL_F32) rc = cfg == 0 ? launch_dma<float, 3, 3, 3, 2>(g, as_conv, s) : launch_dma<float, 3, 3, 6, 1>(g, as_conv, s);
+  else if (cfg != 0) return 0;
+  else if (d->dtype == DIFFSAL_BF16) rc = launch_dma<bf16_t, 3, 3, 3, 2>(g, false, s);
+  else rc = launch_dma<f16_t, 3, 3, 3, 2>(g, false, s);
   return rc == DIFFSAL_OK ? 1 : rc;
 }
 
-// Up to four problems in ONE launch of the 96 x 96 / 3-stage kernel (convolution form: a plain product is its 1x1 case).
+// Up to four fp32 problems in ONE launch of the 96 x 96 / 3-stage kernel (convolution form: a plain product is its 1x1 case).
 // No split-K: every problem's units are whole tiles; the host sorts the problems by K slices per unit (longest first) and the
 // grid has one workgroup per unit, so the hardware dispatcher hands the next (shorter) unit to whichever CU frees up first.
 // Returns 1 if launched, 0 if some problem does not fit this kernel (the caller then launches them one by one).
@@ -630,7 +672,7 @@ int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* co
   const DmaCfg& c = kDmaCfgs[0];
   DmaGemmArgs pr[kMaxGroup];
   for (int i = 0; i < n; ++i)
-    if (!dma_fill(pr[i], c, d[i], true, a[i], w[i], bias ? bias[i] : nullptr, nullptr, nullptr, nullptr, 0, nullptr, out[i])) return 0;
+    if (!dma_fill(pr[i], c, d[i], true, 4, a[i], w[i], bias ? bias[i] : nullptr, nullptr, nullptr, nullptr, 0, nullptr, out[i])) return 0;
   int order[kMaxGroup];
   for (int i = 0; i < n; ++i) order[i] = i;
   for (int i = 0; i < n; ++i)
@@ -651,8 +693,8 @@ int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* co
   g.total = units;
   const int persist = tune(TUNE_GROUP_GRID);   // > 0: a persistent grid of that many workgroups walks the units with stride
   const int grid = persist > 0 && units > persist ? persist : units;
-  hipLaunchKernelGGL((gemm_dma_kernel<3, 3, 3, 2, true, true>), dim3(grid), dim3(256), 0, s, g);
-  note_kernel("gemm_dma_kernel<3, 3, 3, 2, true, true> [96x96 tile, 3 stages, %d problems, %d units]", n, units);
+  hipLaunchKernelGGL((gemm_dma_kernel<float, 3, 3, 3, 2, true, true>), dim3(grid), dim3(256), 0, s, g);
+  note_kernel("gemm_dma_kernel<float, 3, 3, 3, 2, true, true> [96x96 tile, 3 stages, %d problems, %d units]", n, units);
   const int rc = check_launch("diffsal_conv_igemm_group(dma)");
   return rc == DIFFSAL_OK ? 1 : rc;
 }

@@ -36,13 +36,13 @@ int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, co
 int try_linear_stream(const float* x, const float* w, const float* bias, const float* residual, float* out, long M,
                       int K, int N, int act, hipStream_t s);
 
-// gemm_dma.hip: fp32 products / convolutions with LDS-DMA staging, 96-wide tiles
-int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const float* a, const float* w, const float* bias, const float* scale,
-                 const float* shift, const float* rowvec, int rowvec_ld, const float* residual, float* out, void* ws, size_t ws_bytes,
+// gemm_dma.hip: products / convolutions with LDS-DMA staging, 96-wide tiles (fp32; plain products also on 16-bit storage)
+int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* a, const void* w, const float* bias, const float* scale,
+                 const float* shift, const float* rowvec, int rowvec_ld, const void* residual, void* out, void* ws, size_t ws_bytes,
                  hipStream_t s);
 int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* const* a, const float* const* w, const float* const* bias,
                        float* const* out, hipStream_t s);
-size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N);
+size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N, int esz);
 double gemm_dma_estimate(int cfg, long M, int K, int N);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -933,7 +933,20 @@ using namespace diffsal;
 //    split fills the chip (Downsample 768: 61 -> 49 us, ReduceTemp of stage 0: 38 -> 35).  DIFFSAL_CONV_DMA=0 switches it
 //    off, 1..4 force a configuration.
 static int dma_route(const diffsal_conv_desc* d, bool linear, long M, int K, bool pair) {
-  if (d->precision != DIFFSAL_PREC_FP32 || d->w_format != 0 || d->dtype != DIFFSAL_F32 || pair || tune(TUNE_IGEMM_CFG) >= 0) return -1;
+  if (d->precision != DIFFSAL_PREC_FP32 || d->w_format != 0 || pair) return -1;
+  if (d->dtype != DIFFSAL_F32) {
+    // 16-bit storage: plain products with K a multiple of 192 (three 64-element slices per ring pass).  Measured on the token
+    // GEMMs of a B = 4 step (tools/bench_gemm_dma.py, DMA_DTYPE=bf16): 12-19 us instead of 14-25 from ~192 tiles on (the
+    // 16-bit products are bound by operand delivery and launch latency, not by the matrix pipe: the DMA ring has no
+    // staging instructions to issue); below that the tiled kernel's small tiles win.  DIFFSAL_GEMM_DMA16=0 switches it off, 1
+    // forces it on every shape it accepts.
+    if (!linear || tune(TUNE_IGEMM16_CFG) >= 0 || K % 192 != 0 || d->Cout % 4 != 0) return -1;
+    const int forced = tune(TUNE_GEMM_DMA16);
+    if (forced == 0) return -1;
+    if (forced > 0) return 0;
+    return ((M + 95) / 96) * ((d->Cout + 95) / 96) >= 192 ? 0 : -1;
+  }
+  if (tune(TUNE_IGEMM_CFG) >= 0) return -1;
   const long tiles96 = ((M + 95) / 96) * ((d->Cout + 95) / 96);
   if (linear) {
     const int forced = tune(TUNE_GEMM_DMA);
@@ -982,13 +995,17 @@ static int validate(const diffsal_conv_desc* d) {
 extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (validate(d) != DIFFSAL_OK) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
-  if (d->dtype != DIFFSAL_F32) return igemm16_ws_bytes(d);
   const int K = d->KH * d->KW * d->Cin;
-  const Plan pl = choose_plan(M, d->Cout, K, d->precision, is_linear(d));
-  size_t need = pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
+  size_t need;
+  if (d->dtype != DIFFSAL_F32) {
+    need = igemm16_ws_bytes(d);
+  } else {
+    const Plan pl = choose_plan(M, d->Cout, K, d->precision, is_linear(d));
+    need = pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
+  }
   const int r = dma_route(d, is_linear(d), M, K, false);
   if (r >= 0) {
-    const size_t nd = gemm_dma_ws_bytes(r, M, K, d->Cout);
+    const size_t nd = gemm_dma_ws_bytes(r, M, K, d->Cout, d->dtype == DIFFSAL_F32 ? 4 : 2);
     need = nd > need ? nd : need;
   }
   return need;
@@ -1013,6 +1030,15 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
   DS_REQUIRE((d->act >= DIFFSAL_ACT_NONE && d->act <= DIFFSAL_ACT_SIGMOID) ||
                  (d->act == DIFFSAL_ACT_GELU_GRAD && d->dtype == DIFFSAL_F32 && residual_v && !px),
              DIFFSAL_E_ARG, "conv_igemm: act=%d (DIFFSAL_ACT_GELU_GRAD: fp32 only, the pre-activation goes in `residual`)", d->act);
+  if (d->dtype != DIFFSAL_F32) {
+    const long M16 = static_cast<long>(d->N) * d->Ho * d->Wo;
+    const int r16 = dma_route(d, is_linear(d), M16, d->KH * d->KW * d->Cin, px != nullptr);
+    if (r16 >= 0 && (!rowvec || d->rowvec_ld % 4 == 0)) {
+      const int rr = try_gemm_dma(r16, d, false, in_v, w_v, bias, scale, shift, rowvec, d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout, residual_v,
+                                  out_v, ws, ws_bytes, static_cast<hipStream_t>(stream));
+      if (rr != 0) return rr < 0 ? rr : DIFFSAL_OK;
+    }
+  }
   if (d->dtype != DIFFSAL_F32)
     return igemm16_launch(d, in_v, w_v, bias, scale, shift, rowvec, residual_v, out_v, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), px ? px->in2 : nullptr, px ? px->w2 : nullptr,

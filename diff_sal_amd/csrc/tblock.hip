@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   // phase A's global loads, issued one tile ahead: pass ps covers halo tokens ps * TPP + a_slot; returns the "inside the frame" bits
   constexpr int TPP = 256 / G;                                       // tokens per pass
   constexpr int NPASS = (FT_TOK + TPP - 1) / TPP;
-  raw_t pre[AHEAD ? NPASS : 2][3];
+  // NAH passes are fetched a tile ahead and wait in registers through phase D; the rest are fetched in phase A, two in flight
+  // (slots NAH, NAH + 1).  fp32: all of them ahead.  C = 192 on 16-bit storage: half -- with all twelve passes (72 registers)
+  // beside the six Q^T accumulators the kernel needed 512 registers and spilled 12-15 of them to scratch
+  constexpr int NAH = !AHEAD ? 0 : (F32 ? NPASS : NPASS / 2);
+  raw_t pre[NAH + (NAH < NPASS ? 2 : 0)][3];
   unsigned inside_mask = 0;
   auto fetch_pass = [&](int tile_, int ps, raw_t (&dst)[3]) -> bool {
     const int tx_ = tile_ % p.tiles_x, t2_ = tile_ / p.tiles_x;
@@ -190,10 +194,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   };
   auto fetch_tile = [&](int tile_) -> unsigned {
     unsigned mask = 0;
-    if constexpr (AHEAD) {
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) mask |= (fetch_pass(tile_, ps, pre[ps]) ? 1u : 0u) << ps;
-    }
+    for (int ps = 0; ps < NAH; ++ps) mask |= (fetch_pass(tile_, ps, pre[ps]) ? 1u : 0u) << ps;
     return mask;
   };
   if (AHEAD && static_cast<int>(blockIdx.x) < n_tiles) inside_mask = fetch_tile(blockIdx.x);
@@ -211,20 +213,22 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
     const int ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
     const int y0 = ty * FT_TH, x0 = tx * FT_TW;
-    if constexpr (!AHEAD) inside_mask = fetch_pass(tile, 0, pre[0]) ? 1u : 0u;
+    if constexpr (NAH < NPASS) {      // the first pass that was not fetched ahead (its mask bit replaces a stale one)
+      inside_mask = (inside_mask & ((1u << NAH) - 1u)) | ((fetch_pass(tile, NAH, pre[NAH + (NAH & 1)]) ? 1u : 0u) << NAH);
+    }
 
     // ---------------- phase A: halo tile (fetched while the previous tile was in phase D) -> LayerNorm_1 -> LDS; zeros outside
     // the frame are the convolution's padding
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int tok = ps * TPP + a_slot;
-      if constexpr (!AHEAD) {                                          // two passes in flight
-        if (ps + 1 < NPASS) inside_mask |= (fetch_pass(tile, ps + 1, pre[(ps + 1) & 1]) ? 1u : 0u) << (ps + 1);
+      if constexpr (NAH < NPASS) {                                     // two passes in flight
+        if (ps + 1 < NPASS && ps + 1 > NAH) inside_mask |= (fetch_pass(tile, ps + 1, pre[NAH + ((ps + 1) & 1)]) ? 1u : 0u) << (ps + 1);
       }
       const bool inside = (inside_mask >> ps) & 1u;
       float4 vv[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[AHEAD ? ps : (ps & 1)][i]);
+      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[ps < NAH ? ps : NAH + (ps & 1)][i]);
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += (vv[i].x + vv[i].y) + (vv[i].z + vv[i].w);

@@ -534,6 +534,11 @@ def conv_igemm_group(problems: Sequence[dict], tag: str = "gemm") -> List[Tensor
     n = len(problems)
     if not 1 <= n <= 4:
         raise RuntimeError("conv_igemm_group: 1..4 problems")
+    if get_gemm_precision() != "fp32" or any(getattr(pr["w"], "_diffsal_split", False) for pr in problems):
+        # split-precision mode (pre-split weights, per-call precision): the grouped entry point is exact-arithmetic only
+        return [conv_igemm(pr["x"], pr["w"], kh=pr.get("kh", 1), kw=pr.get("kw", 1), stride=pr.get("stride", (1, 1)),
+                           pad=pr.get("pad", (0, 0)), dil=pr.get("dil", (1, 1)), out_hw=pr.get("out_hw"), bias=pr.get("bias"),
+                           act=pr.get("act", ACT_NONE), out=pr.get("out"), tag=tag) for pr in problems]
     descs, outs, keep = [], [], []
     flops = nbytes = 0.0
     ws_bytes = 0

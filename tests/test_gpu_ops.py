@@ -103,6 +103,7 @@ def test_linear_pair_equals_two_launches(ops, M, K, N, tuning):
     """diffsal_linear_pair (key and value projections in one grid, z = 2) == the two single launches bit for bit (same tile
     plan, same split-K order), with and without bias, ragged M / N."""
     tuning.set("DIFFSAL_NO_PERSIST", 1)     # the single launches on the same one-tile kernel the pair uses
+    tuning.set("DIFFSAL_GEMM_DMA", 0)       # ... and not on the LDS-DMA kernel (same sums, another order)
     x0, x1 = rnd("p0x%d" % K, 2, M // 2, K).to(DEV), rnd("p1x%d" % K, 2, M // 2, K).to(DEV)
     w0, w1 = rnd("p0w%d" % N, N, K, scale=K ** -0.5).to(DEV), rnd("p1w%d" % N, N, K, scale=K ** -0.5).to(DEV)
     b0, b1 = rnd("p0b", N, scale=0.1).to(DEV), rnd("p1b", N, scale=0.1).to(DEV)

@@ -187,3 +187,22 @@ def test_fused_step_tail_is_bit_equal_to_the_plain_solver_loop(golden_dir, tiny)
     x0_ref = ops.resize_bilinear(s_low, 64, 128).view(2, 1, 64, 128)
     m_ref = ops.axpbypcz(xs, 1.7, x0_ref, -0.6)
     assert torch.equal(x0, x0_ref) and torch.equal(m, m_ref) and torch.equal(xn, ops.axpbypcz(xs, 0.9, m_ref, -0.3, mp, 0.2))
+
+
+def test_default_sampler_replays_small_batches_from_a_graph_and_matches_the_eager_loop():
+    """DiffusionSampler's default (hip_graph="auto"): one or two clips are replayed from a captured trajectory, three or more run
+    eagerly; both give the eager loop's result bit for bit, and repeated calls with new inputs reuse the capture."""
+    from diff_sal_amd.sampling import DiffusionSampler
+
+    cfg = CASES["tiny_av"][0]
+    sd = orc.synth_state_dict(orc.state_dict_template(cfg))
+    top = Top(build(cfg, sd))
+    auto = DiffusionSampler(top, timesteps=8, sample_type="dpmsolver")
+    eager = DiffusionSampler(top, timesteps=8, sample_type="dpmsolver", hip_graph=False)
+    assert auto.hip_graph == "auto" and eager.hip_graph is False
+    for B in (1, 2, 3):
+        for tag in ("a", "b"):
+            x, feats, audio = orc.synth_inputs(cfg, B, True, tag=f"auto{B}{tag}")
+            xd, fd, ad = x.to(DEV), [f.to(DEV) for f in feats], audio.to(DEV)
+            assert torch.equal(auto.sample_dpm_solver(xd, fd, ad), eager.sample_dpm_solver(xd, fd, ad))
+    assert len(auto._graphs) == 2 and not eager._graphs          # captured for B = 1 and B = 2 only

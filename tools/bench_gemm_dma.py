@@ -71,15 +71,17 @@ def main():
             flt = args[i]
             i += 1
     dev = "cuda"
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("DMA_DTYPE", ""), torch.float32)
+    key = "DIFFSAL_GEMM_DMA" if dt == torch.float32 else "DIFFSAL_GEMM_DMA16"
     g = torch.Generator(device=dev).manual_seed(5)
     print(f"{'shape':10s} {'M':>6s} {'K':>5s} {'N':>5s} | {'DMA off us (TF/s)':>20s} | " + " | ".join(f"dma cfg {c} us (TF/s) err" for c in cfgs))
     for name, M, K, N, has_b, act, has_r in SHAPES:
         if flt and flt not in name:
             continue
-        x = torch.randn(M, K, device=dev, generator=g)
-        w = torch.randn(N, K, device=dev, generator=g) * (K ** -0.5)
+        x = torch.randn(M, K, device=dev, generator=g).to(dt)
+        w = (torch.randn(N, K, device=dev, generator=g) * (K ** -0.5)).to(dt)
         b = torch.randn(N, device=dev, generator=g) if has_b else None
-        res = torch.randn(M, N, device=dev, generator=g) if has_r else None
+        res = torch.randn(M, N, device=dev, generator=g).to(dt) if has_r else None
         ref = x.double() @ w.double().t()
         if b is not None:
             ref = ref + b.double()
@@ -93,14 +95,14 @@ def main():
         variants = [0] + cfgs
         errs, times = {}, {v: [] for v in variants}
         for v in variants:
-            _lib.set_tuning("DIFFSAL_GEMM_DMA", v)
+            _lib.set_tuning(key, v)
             y = run(x, w, b, act, res)
             torch.cuda.synchronize()
             errs[v] = ((y.double() - ref).abs().max().item()) / scale
         reps = 20
         for _ in range(rounds):
             for v in variants:
-                _lib.set_tuning("DIFFSAL_GEMM_DMA", v)
+                _lib.set_tuning(key, v)
                 run(x, w, b, act, res)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -109,7 +111,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) * 1e3 / reps)
-        _lib.set_tuning("DIFFSAL_GEMM_DMA", None)
+        _lib.set_tuning(key, None)
         fl = 2.0 * M * K * N
         cells = []
         for v in variants:
