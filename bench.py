@@ -556,7 +556,7 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
         rows = []
         for e0, e1, fl, cls, nb, *note in ev:
             us = e0.elapsed_time(e1) * 1e3
-            rows.append({"class": cls, "op": note[0] if note else "", "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3),
+            rows.append({"class": cls, "op": note[0] if note else "", "kernel": note[1] if len(note) > 1 else "", "gflop": round(fl / 1e9, 4), "mbytes": round(nb / 1e6, 3),
                          "us": round(us, 2), "tflops": round(fl / us / 1e6, 2) if us > 0 else 0.0,
                          "gbs": round(nb / us / 1e3, 1) if us > 0 else 0.0})
         json.dump({"workload": "train", "mode": args.mode, "batch": B, "launches": rows}, open(args.dump_launches, "w"), indent=0)
