@@ -192,7 +192,11 @@ struct MlpBlockArgs {
   int hw, T, t_keep;                      // z is written for tokens whose frame (m / hw) % T < t_keep
 };
 
-__global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
+// Eight wavefronts per workgroup (two per SIMD) share the resident weights: while one wave of a SIMD is in its LayerNorm / GELU /
+// store phase (VALU: ~2000 instructions of erf-GELU per tile) the other issues MFMAs.  With four waves (one per SIMD, 346
+// registers each, the next tile prefetched into registers) the matrix pipe sat idle through every VALU phase: 0.55 busy.
+// The second resident wave also covers the tile loads, so the register prefetch is gone and a wave fits in 256 registers.
+__global__ __launch_bounds__(512) void mlp_block_kernel(MlpBlockArgs p) {
   constexpr int C = 96, HID = 192;
   constexpr int P1 = C + 4, P2 = HID + 4;           // LDS pitches (floats): conflict-free ds_read_b128 per 16-lane group
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -200,28 +204,28 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
   float* W2s = W1s + HID * P1;                       // [C][P2]
   float* vec = W2s + C * P2;                         // g2 | be2 | b2 | gz | bez (C each), b1 (HID)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < HID * (C / 4); i += 256) {
+  for (int i = tid; i < HID * (C / 4); i += 512) {
     const int n = i / (C / 4), c4 = (i - n * (C / 4)) * 4;
     st4(W1s + n * P1 + c4, ld4(p.w1 + n * C + c4));
   }
-  for (int i = tid; i < C * (HID / 4); i += 256) {
+  for (int i = tid; i < C * (HID / 4); i += 512) {
     const int c = i / (HID / 4), n4 = (i - c * (HID / 4)) * 4;
     st4(W2s + c * P2 + n4, ld4(p.w2 + c * HID + n4));
   }
-  for (int i = tid; i < C; i += 256) {
+  for (int i = tid; i < C; i += 512) {
     vec[i] = p.g2[i]; vec[C + i] = p.be2[i]; vec[2 * C + i] = p.b2[i];
     vec[3 * C + i] = p.z ? p.gz[i] : 0.f; vec[4 * C + i] = p.z ? p.bez[i] : 0.f;
   }
-  for (int i = tid; i < HID; i += 256) vec[5 * C + i] = p.b1[i];
+  for (int i = tid; i < HID; i += 512) vec[5 * C + i] = p.b1[i];
   __syncthreads();
 
   const int ml = lane & 31, hf = lane >> 5;
   const int n_tiles = (p.M + 31) / 32;
-  const int n_waves = gridDim.x * 4;
+  const int n_waves = gridDim.x * 8;
   const float* w1frag = W1s + ml * P1 + 4 * hf;      // + 32 t * P1 + 8 i : W1[n = 32t + ml][c = 8i + 4hf ..]
   const float* w2frag = W2s + ml * P2 + 4 * hf;      // + 32 u * P2 + 32 t + 8 g : W2[c = 32u + ml][n = 32t + 8g + 4hf ..]
 
-  float4 xa[12], xnext[12];
+  float4 xa[12];
   auto load_tile = [&](int tile, float4 (&dst)[12]) {
     int m = tile * 32 + ml;
     m = m < p.M ? m : p.M - 1;
@@ -245,10 +249,8 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
     rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
   };
 
-  int tile = blockIdx.x * 4 + wave;
-  if (tile < n_tiles) load_tile(tile, xa);
-  for (; tile < n_tiles; tile += n_waves) {
-    if (tile + n_waves < n_tiles) load_tile(tile + n_waves, xnext);  // lands during this tile's 576 MFMAs
+  for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += n_waves) {
+    load_tile(tile, xa);
     // ---- LayerNorm_2 in registers
     float mean, rstd;
     ln_rows(xa, mean, rstd, p.eps2);
@@ -277,6 +279,9 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
     for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) hid[t][r] = gelu_erf(hid[t][r]);
+    // x1 again for the residual (L2-resident: this wave read it a moment ago): its registers were given up during the first
+    // product so that two waves fit on a SIMD; the reload lands during the second product
+    load_tile(tile, xa);
     // ---- out^T = W2 hidden^T: 3 tiles of 32 channels; k pairs = (half 0's row, half 1's row) of each hidden register
     f32x16 o[3];
 #pragma unroll
@@ -319,8 +324,6 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(MlpBlockArgs p) {
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) xa[i] = xnext[i];
   }
 }
 
@@ -343,7 +346,7 @@ extern "C" int diffsal_mlp_block(const float* x1, const float* g2, const float* 
   DS_RAISE_DYNAMIC_LDS((mlp_block_kernel), 160 * 1024);
   const int n_tiles = static_cast<int>((M + 31) / 32);
   int grid = 256;
-  if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
-  hipLaunchKernelGGL(mlp_block_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  if (grid * 8 > n_tiles) grid = (n_tiles + 7) / 8;
+  hipLaunchKernelGGL(mlp_block_kernel, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
   return check_launch("mlp_block");
 }

@@ -1,10 +1,8 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4b
-timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_salunet.py tests/test_gpu_fullsize.py tests/test_gpu_train_ops.py -q -m gpu -k "tap or golden or full or fixture or salunet" > gpurun_out/r4b/t9.log 2>&1
-tail -n 4 gpurun_out/r4b/t9.log
+timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_salunet.py tests/test_gpu_fullsize.py -q -m gpu -k "mlp or block or golden or full" 2>&1 | tail -n 3
 timeout 900 python3 bench.py --no-cpu-baseline --no-alt-precision --no-encoders --no-train-leg --no-reference-graph 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])
-for c in d['roofline']['classes']:
-    if 'tap' in c['class'] or c['class'] in ('K3','K9','K11'): print(c['class'], c['launches'], c['ms'], c['gbs'])
+for k in d['roofline']['kernels']:
+    if 'mlp' in k['name'] or 'front' in k['name']: print(k)
 "

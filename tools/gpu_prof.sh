@@ -1,15 +1,15 @@
 cd $GRAFT_REPO_ROOT
-D=r3p
+D=r4p
 mkdir -p gpurun_out/$D
-bash tools/profile_round.sh $D r03 fp32 vis pmc > gpurun_out/$D/log_fp32.txt 2>&1
-bash tools/profile_round.sh $D r03 fp32 av > gpurun_out/$D/log_fp32_av.txt 2>&1
-bash tools/profile_round.sh $D r03 bf16 vis pmc > gpurun_out/$D/log_bf16.txt 2>&1
-bash tools/profile_round.sh $D r03 fp16 vis > gpurun_out/$D/log_fp16.txt 2>&1
-bash tools/profile_train.sh $D r03 > gpurun_out/$D/log_train.txt 2>&1
+bash tools/profile_round.sh $D r04 fp32 vis pmc > gpurun_out/$D/log_fp32.txt 2>&1
+bash tools/profile_round.sh $D r04 fp32 av > gpurun_out/$D/log_fp32_av.txt 2>&1
+bash tools/profile_round.sh $D r04 bf16 vis pmc > gpurun_out/$D/log_bf16.txt 2>&1
+bash tools/profile_round.sh $D r04 fp16 vis > gpurun_out/$D/log_fp16.txt 2>&1
+bash tools/profile_train.sh $D r04 > gpurun_out/$D/log_train.txt 2>&1
 cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 50 --warmup 10 > gpurun_out/$D/r03_bench.json 2> gpurun_out/$D/bench.err
-python3 bench.py --steps 50 --warmup 10 --mode av --no-cpu-baseline > gpurun_out/$D/r03_bench_av.json 2>> gpurun_out/$D/bench.err
-python3 bench.py --steps 50 --warmup 10 --precision bf16 --no-cpu-baseline --dump-launches gpurun_out/$D/r03_launches_bf16_unprofiled.json > gpurun_out/$D/r03_bench_bf16.json 2>> gpurun_out/$D/bench.err
-python3 bench.py --steps 20 --warmup 5 --precision fp16 --batch 64 --mode av --no-cpu-baseline --no-train-leg > gpurun_out/$D/r03_bench_fp16_b64_av.json 2>> gpurun_out/$D/bench.err
+python3 bench.py --steps 50 --warmup 10 > gpurun_out/$D/r04_bench.json 2> gpurun_out/$D/bench.err
+python3 bench.py --steps 50 --warmup 10 --mode av --no-cpu-baseline > gpurun_out/$D/r04_bench_av.json 2>> gpurun_out/$D/bench.err
+python3 bench.py --steps 50 --warmup 10 --precision bf16 --no-cpu-baseline --dump-launches gpurun_out/$D/r04_launches_bf16_unprofiled.json > gpurun_out/$D/r04_bench_bf16.json 2>> gpurun_out/$D/bench.err
+python3 bench.py --steps 20 --warmup 5 --precision fp16 --batch 64 --mode av --no-cpu-baseline --no-train-leg > gpurun_out/$D/r04_bench_fp16_b64_av.json 2>> gpurun_out/$D/bench.err
 rm -rf gpurun_out/$D/stats_* gpurun_out/$D/pmc_fetch_* gpurun_out/$D/pmc_write_* gpurun_out/$D/pmc_busy_*/
 ls gpurun_out/$D | head -60
