@@ -179,6 +179,172 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same tile product for PLAIN products (one tap: token GEMMs, 107 of the 124 weight gradients of a training step) with both
+// operands staged by LDS-DMA (buffer_load ... lds, as csrc/gemm_dma.hip): no staging registers, no ds_write pass, three stages
+// in flight and ONE barrier per 32-row step (placed between the two halves of the step's MFMAs) instead of a single stage
+// between two barriers.  A step's tiles are [32 rows][BCO] of dY and [32 rows][BKI] of X, row-linear (a ds_read_b32 of a half
+// wave covers 32 consecutive floats of one row: conflict-free on the unpadded pitch); a DMA piece is 1 KiB in lane order, the
+// lane's (row, column) fixed for the kernel.  Rows past the split's end, columns past Cout / K: offset 0xFFFFFFFF, the DMA
+// writes zeros.  Same accumulation order per output element as wgrad_kernel (rows in ascending order inside a split).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wgrad_dma_piece(unsigned lds_addr, unsigned voff, wg_i32x4 rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void wgrad_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CT, int WCO, int WK, int ST>
+__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgradArgs p) {
+  static_assert(WCO * WK == 4, "four waves");
+  constexpr int BM = 32, STAGES = 3, P = STAGES - 1;
+  constexpr int BCO = WCO * CT * 32, SL = WK * ST, BKI = SL * 32;
+  constexpr int A_F = BM * BCO, B_F = BM * BKI, STAGE_F = A_F + B_F;          // floats
+  constexpr int APW = A_F / 256 / 4, BPW = B_F / 256 / 4, PPW = APW + BPW;     // 1 KiB pieces per wave and step
+  static_assert(A_F % 1024 == 0 && B_F % 1024 == 0, "whole pieces per wave");
+  constexpr int WAIT_N = (P - 2 > 0 ? P - 2 : 0) * PPW;
+  __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE_F];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WK, wn = wave % WK;
+  const int co0 = blockIdx.x * BCO;
+  const int sl0 = blockIdx.y * SL;
+  const int n_slices = p.K / 32;
+  const int seg = blockIdx.z / p.splits, sp = blockIdx.z - seg * p.splits;
+  const int m_begin = seg * p.seg_rows + sp * BM;
+  const int m_end = min(p.M, (seg + 1) * p.seg_rows);
+  const int m_stride = p.splits * BM;
+  const int n_steps = m_begin < m_end ? (m_end - m_begin + m_stride - 1) / m_stride : 0;
+
+  const unsigned long pdy = reinterpret_cast<unsigned long>(p.dy), pin = reinterpret_cast<unsigned long>(p.in);
+  const wg_i32x4 rs_dy = {static_cast<int>(pdy), static_cast<int>(pdy >> 32) & 0xFFFF, static_cast<int>(p.dy_bytes), 0x00020000};
+  const wg_i32x4 rs_x = {static_cast<int>(pin), static_cast<int>(pin >> 32) & 0xFFFF, static_cast<int>(p.in_bytes), 0x00020000};
+  // this lane's slot in every piece it issues: (row of the step, byte offset inside the operand's row), ~0 when the column is
+  // outside the matrix
+  int a_row[APW], b_row[BPW];
+  unsigned a_col[APW], b_col[BPW];
+#pragma unroll
+  for (int q = 0; q < APW; ++q) {
+    const int idx = (wave + 4 * q) * 64 + lane;
+    a_row[q] = idx / (BCO / 4);
+    const int c = co0 + (idx - a_row[q] * (BCO / 4)) * 4;
+    a_col[q] = c < p.Cout ? static_cast<unsigned>(c) * 4u : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int q = 0; q < BPW; ++q) {
+    const int idx = (wave + 4 * q) * 64 + lane;
+    b_row[q] = idx / (BKI / 4);
+    const int k = sl0 * 32 + (idx - b_row[q] * (BKI / 4)) * 4;
+    b_col[q] = k < p.K ? static_cast<unsigned>(k) * 4u : 0xFFFFFFFFu;
+  }
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)smem)) + wave * 1024u;
+  int iss_step = 0;
+  auto issue_piece = [&](int stage, int q) __attribute__((always_inline)) {      // q < APW: dY, else X
+    const int mb = m_begin + iss_step * m_stride;
+    const unsigned st = lds_base + static_cast<unsigned>(stage * STAGE_F * 4);
+    if (q < APW) {
+      const int m = mb + a_row[q];
+      const unsigned off = (m < m_end && iss_step < n_steps) ? static_cast<unsigned>(m) * static_cast<unsigned>(p.Cout * 4) + a_col[q] : 0xFFFFFFFFu;
+      wgrad_dma_piece(st + q * 4096u, off | (a_col[q] == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u), rs_dy);
+    } else {
+      const int qb = q - APW;
+      const int m = mb + b_row[qb];
+      const unsigned off = (m < m_end && iss_step < n_steps) ? static_cast<unsigned>(m) * static_cast<unsigned>(p.K * 4) + b_col[qb] : 0xFFFFFFFFu;
+      wgrad_dma_piece(st + (A_F + qb * 1024) * 4u, off | (b_col[qb] == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u), rs_x);
+    }
+  };
+
+  f32x16 acc[CT][ST];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < ST; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_bias = p.dbias != nullptr && blockIdx.y == 0 && tid < BCO;
+  double bias_acc = 0.0;
+
+#pragma unroll
+  for (int s = 0; s < P; ++s) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) issue_piece(s, q);
+    ++iss_step;
+  }
+  wgrad_wait_vmcnt<(P - 1) * PPW>();
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0;
+  for (int t = 0; t < n_steps; ++t) {
+    const float* dYs = smem + stage * STAGE_F;
+    const float* Xs = dYs + A_F;
+    const int ist = stage == 0 ? STAGES - 1 : stage - 1;          // the stage freed by the previous step takes step t + P
+    if (do_bias) {
+      float s4 = 0.f;
+#pragma unroll
+      for (int r = 0; r < BM; ++r) s4 += dYs[r * BCO + tid];
+      bias_acc += static_cast<double>(s4);
+    }
+    // fragments of k-step ks + 1 are read before the MFMAs of k-step ks (one wave per SIMD: nobody else covers the LDS latency)
+    float fa[2][CT], fb[2][ST];
+    auto read_frags = [&](int ks, int set) __attribute__((always_inline)) {
+      const int mrow = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < CT; ++i) fa[set][i] = dYs[mrow * BCO + (wm * CT + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < ST; ++j) fb[set][j] = Xs[mrow * BKI + (wn * ST + j) * 32 + (lane & 31)];
+    };
+    auto mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < ST; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < BM / 4; ++ks) {
+      read_frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // step t + 1 (this wave's pieces) has landed; after the barrier every wave's have, and nobody reads stage `ist` any more
+    wgrad_wait_vmcnt<WAIT_N>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = BM / 4; ks < BM / 2; ++ks) {
+      if (ks + 1 < BM / 2) read_frags(ks + 1, (ks + 1) & 1);
+      const int h = ks - BM / 4;                                   // DMA pieces of step t + P between the second half's MFMAs
+#pragma unroll
+      for (int q = h * PPW / (BM / 4); q < (h + 1) * PPW / (BM / 4); ++q) issue_piece(ist, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++iss_step;
+    stage = stage + 1 == STAGES ? 0 : stage + 1;
+  }
+  if (do_bias && co0 + tid < p.Cout) {
+    p.dbias[static_cast<long>(blockIdx.z) * p.Cout + co0 + tid] = bias_acc;
+    if (p.dbias_out && gridDim.z == 1) p.dbias_out[co0 + tid] = static_cast<float>(bias_acc);
+  }
+  float* slab = p.slabs + static_cast<long>(blockIdx.z) * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < ST; ++j) {
+      const int sl = sl0 + wn * ST + j;
+      if (sl >= n_slices) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * CT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Cout) slab[static_cast<long>(co) * p.K + sl * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    }
+}
+
 // out[seg][i] = sum over the splits of one segment (deterministic: fixed association).  Workgroup = 16 float4 columns x
 // 16 split groups: group g adds splits g, g+16, ... in order, then the 16 group sums are added in order.  (One thread per
 // column walking all splits serially left 9 workgroups with 256-512 dependent steps each on the small token GEMMs.)
@@ -350,6 +516,10 @@ int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
   const dim3 grid((a.Cout + cf.bco - 1) / cf.bco, (a.K / 32 + cf.sl - 1) / cf.sl, segments * pl.splits);
   const long n = static_cast<long>(a.Cout) * a.K;
   if (pl.splits == 1) a.slabs = out;   // one split per segment: the tile goes straight to its destination
+  const bool plain = a.taps == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Ho == a.H && a.Wo == a.W;
+  if (plain && pl.cfg == 0 && tune(TUNE_WGRAD_DMA) != 0) {
+    hipLaunchKernelGGL((wgrad_dma_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a);
+  } else
   switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a); break;
     case 1: hipLaunchKernelGGL((wgrad_kernel<3, 1, 4, 2>), grid, dim3(256), 0, s, a); break;

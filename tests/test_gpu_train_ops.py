@@ -426,3 +426,23 @@ def test_adam_step_matches_torch_adam_with_clipping(ag, max_norm, world):
         assert (v.cpu() - st["exp_avg_sq"]).abs().max().item() <= 2e-6 * st["exp_avg_sq"].abs().max().item()
         # the update is ~lr * m / sqrt(v): compare the step taken, not the parameter (|p| ~ 1 hides it)
         assert (p.cpu() - ref_p.detach()).abs().max().item() <= 1e-4 * 1e-4 * step + 1.2e-7 * 4
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 160, 100), (70001, 96, 576), (3024, 768, 864), (333, 32, 4)])
+def test_wgrad_dma_kernel_equals_the_register_staged_kernel(M, K, N, tuning):
+    """Plain-product weight gradients on the 128 x 192 tile run on wgrad_dma_kernel (both operands by LDS-DMA, three stages, one
+    barrier per 32-row step): same rows in the same order through the same MFMA chains as wgrad_kernel -- bit-equal, including
+    the bias column sums; ragged M / K / N (rows past the split, columns past Cout / K are cut by the DMA's range check)."""
+    from diff_sal_amd import ops
+
+    tuning.set("DIFFSAL_WGRAD_CFG", 0)           # the tile shape that has the DMA variant
+    x = orc.synth_tensor("wdx%d" % M, (1, 1, M, K)).to(DEV)
+    dy = orc.synth_tensor("wdy%d" % M, (1, 1, M, N)).to(DEV)
+    tuning.set("DIFFSAL_WGRAD_DMA", 0)
+    dw0, db0 = ops.conv_wgrad(x, dy, want_bias=True)
+    tuning.set("DIFFSAL_WGRAD_DMA", 1)
+    dw1, db1 = ops.conv_wgrad(x, dy, want_bias=True)
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    ref = dy.reshape(M, N).double().t() @ x.reshape(M, K).double()
+    assert (dw1.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    assert (db1.double() - dy.reshape(M, N).double().sum(0)).abs().max().item() < 1e-4 * (dy.abs().sum(dim=(0, 1, 2)).max().item())

@@ -72,7 +72,7 @@ def main():
             i += 1
     dev = "cuda"
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(os.environ.get("DMA_DTYPE", ""), torch.float32)
-    key = "DIFFSAL_GEMM_DMA" if dt == torch.float32 else "DIFFSAL_GEMM_DMA16"
+    key = os.environ.get("DMA_KEY") or ("DIFFSAL_GEMM_DMA" if dt == torch.float32 else "DIFFSAL_GEMM_DMA16")
     g = torch.Generator(device=dev).manual_seed(5)
     print(f"{'shape':10s} {'M':>6s} {'K':>5s} {'N':>5s} | {'DMA off us (TF/s)':>20s} | " + " | ".join(f"dma cfg {c} us (TF/s) err" for c in cfgs))
     for name, M, K, N, has_b, act, has_r in SHAPES:
