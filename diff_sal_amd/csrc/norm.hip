@@ -600,9 +600,98 @@ extern "C" size_t diffsal_groupnorm_ws_bytes(int B, int groups) {
   return static_cast<size_t>(B) * GN_CHUNKS_MAX * groups * 2 * sizeof(double);
 }
 
+// GroupNorm (+ swish) of fp32 maps in ONE launch when an (image, group) slab fits the LDS: a 1024-thread workgroup per
+// (image, group) parks its HW x (C / groups) floats in LDS while it sums them (mean), reads them back for the centred second moment
+// (the two-pass form, as torch) and once more to normalise: x is read once and out written once, no statistics round trip
+// through memory and no second launch (K3: six GroupNorms per step were twelve launches of ~8 us, 0.8 TB/s).  A pixel's group
+// slice is VEC * U consecutive floats (3, 6, 12 or 24 at 32 groups and C = 96 .. 768); item i = (pixel i / U, piece i % U).
+// R/models/saliency_decoder/sal_unet.py:36-44 (Normalize + nonlinearity).
+template <int VEC, int U>
+__global__ __launch_bounds__(1024) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ out, int HW, int C,
+                                                       int groups, float eps, int swish) {
+  constexpr int CPG = VEC * U;
+  extern __shared__ __attribute__((aligned(16))) float gn_slab[];
+  __shared__ double red[16];
+  __shared__ float gb[2 * CPG];
+  const int tid = threadIdx.x, g = blockIdx.x, n = blockIdx.y;
+  const int items = HW * U;
+  const float* xs = x + static_cast<long>(n) * HW * C + g * CPG;
+  float* os = out + static_cast<long>(n) * HW * C + g * CPG;
+  if (tid < CPG) { gb[tid] = gamma[g * CPG + tid]; gb[CPG + tid] = beta[g * CPG + tid]; }
+  struct __attribute__((packed, aligned(VEC == 4 ? 16 : 4))) Piece { float v[VEC]; };   // C / groups = 12, 24: 16-byte aligned pieces
+  auto block_sum = [&](float v) -> double {        // fp32 inside a wavefront, fp64 across the 16 wavefronts, fixed order
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = static_cast<double>(v);
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+  };
+  float s = 0.f;
+#pragma unroll 4
+  for (int i = tid; i < items; i += 1024) {
+    const int pix = i / U, u = i - pix * U;
+    const Piece p = *reinterpret_cast<const Piece*>(xs + static_cast<long>(pix) * C + u * VEC);
+    *reinterpret_cast<Piece*>(gn_slab + i * VEC) = p;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += p.v[e];
+  }
+  const double cnt = static_cast<double>(HW) * CPG;
+  const float mean = static_cast<float>(block_sum(s) / cnt);
+  float q = 0.f;
+  for (int i = tid; i < items; i += 1024) {
+    const Piece p = *reinterpret_cast<const Piece*>(gn_slab + i * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const float d = p.v[e] - mean; q = fmaf(d, d, q); }
+  }
+  const float rstd = static_cast<float>(1.0 / sqrt(block_sum(q) / cnt + static_cast<double>(eps)));
+#pragma unroll 4
+  for (int i = tid; i < items; i += 1024) {
+    const int pix = i / U, u = i - pix * U;
+    Piece p = *reinterpret_cast<const Piece*>(gn_slab + i * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float y = (p.v[e] - mean) * rstd * gb[u * VEC + e] + gb[CPG + u * VEC + e];
+      p.v[e] = swish ? swishf(y) : y;
+    }
+    *reinterpret_cast<Piece*>(os + static_cast<long>(pix) * C + u * VEC) = p;
+  }
+}
+
+// 1 if launched, 0 if the shape does not fit (the caller runs the statistics + normalisation launches)
+static int try_gn_slab(const float* x, const float* gamma, const float* beta, float* out, int B, int HW, int C, int groups, float eps,
+                       int swish, hipStream_t s) {
+  if (tune(TUNE_GN_CHUNKS) > 0 || tune(TUNE_GN_APPLY_WGS) > 0 || tune(TUNE_NO_GN_SLAB) == 1) return 0;   // the two-launch path is being tuned / forced
+  const int cpg = C / groups;
+  const size_t lds = static_cast<size_t>(HW) * cpg * sizeof(float);
+  // fewer than 128 workgroups (one per CU, streaming its slab at a single CU's ~30 GB/s) lose to the two launches, which spread an
+  // image over up to 512 workgroups: measured equal at B = 4 (six GroupNorms of a step: 0.109 ms either way, 6 launches instead
+  // of 12), slower below
+  if (lds > 150 * 1024 || static_cast<long>(B) * groups < 128) return 0;
+#define GN_SLAB(VEC, U)                                                                                          \
+  do {                                                                                                           \
+    DS_RAISE_DYNAMIC_LDS((gn_slab_kernel<VEC, U>), 152 * 1024);                                                  \
+    hipLaunchKernelGGL((gn_slab_kernel<VEC, U>), dim3(groups, B), dim3(1024), lds, s, x, gamma, beta, out, HW, C, groups, eps, swish); \
+  } while (0)
+  if (cpg == 3) GN_SLAB(3, 1);
+  else if (cpg == 6) GN_SLAB(3, 2);
+  else if (cpg == 12) GN_SLAB(4, 3);
+  else if (cpg == 24) GN_SLAB(4, 6);
+  else return 0;
+#undef GN_SLAB
+  return check_launch("groupnorm_swish(slab)") == DIFFSAL_OK ? 1 : DIFFSAL_E_LAUNCH;
+}
+
 template <typename T>
 static int groupnorm_swish_t(const T* x, const float* gamma, const float* beta, T* out, int B, int HW, int C, int groups,
                              float eps, void* ws, hipStream_t s, int swish = 1) {
+  if constexpr (sizeof(T) == 4) {
+    const int r = try_gn_slab(reinterpret_cast<const float*>(x), gamma, beta, reinterpret_cast<float*>(out), B, HW, C, groups, eps, swish, s);
+    if (r != 0) return r < 0 ? r : DIFFSAL_OK;
+  }
   const int chunks = gn_chunks();
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(chunks, B), dim3(256), 2 * C * sizeof(double), s, x,
                      static_cast<double*>(ws), HW, C, groups);

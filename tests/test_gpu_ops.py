@@ -520,3 +520,18 @@ def test_tapsum_autograd_matches_conv_of_upsampled_sum(ops, case):
         assert rel_err(z.grad, nhwc(zr.grad)) < 1e-5
     assert rel_err(wd.grad, w.grad) < 1e-5
     assert rel_err(bd.grad, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,HW", [(4, 192, (56, 96)), (4, 96, (56, 96)), (2, 384, (28, 48)), (4, 768, (14, 24)), (1, 192, (9, 7))])
+def test_groupnorm_single_launch_slab_path_equals_the_two_launch_path(ops, tuning, B, C, HW):
+    """fp32 GroupNorm + swish: the LDS-resident one-launch kernel (a workgroup per image and group; up to 129 KB of slab at
+    192 channels x 56 x 96) against the statistics + normalisation launches and against torch; B * groups < 128 (the last two
+    cases) stays on the two-launch path by itself."""
+    x = (rnd("gs%d_%d" % (C, HW[0]), B, *HW, C) * 1.7 + 0.4).to(DEV)
+    g, b = (rnd("gsg", C, scale=0.2) + 1.0).to(DEV), rnd("gsb", C, scale=0.2).to(DEV)
+    one = ops.groupnorm_swish(x, g, b, 32, 1e-6)
+    tuning.set("DIFFSAL_NO_GN_SLAB", 1)
+    two = ops.groupnorm_swish(x, g, b, 32, 1e-6)
+    ref = F.silu(F.group_norm(x.permute(0, 3, 1, 2).double(), 32, g.double(), b.double(), 1e-6)).permute(0, 2, 3, 1)
+    assert rel_err(one, ref) < 2e-5 and rel_err(two, ref) < 2e-5
+    assert rel_err(one, two) < 3e-6
