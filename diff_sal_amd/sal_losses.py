@@ -5,6 +5,7 @@ reductions each.  ``saliency_metrics`` returns all four at once -- what the trai
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 from . import ops
 
@@ -64,11 +65,25 @@ def kldiv2(s_map, gt):
     return saliency_terms(s_map, gt)[3]
 
 
+def cross_entropy_loss(output, label, weights, batch_average=False, is_reduce=True):
+    """R/models/sal_losses.py:48-63: BCE with logits against label / 255, summed per clip, times ``weights`` (a scalar
+    ``ce_weight`` in get_kl_cc_sim_loss, or one weight per clip)."""
+    b = output.size(0)
+    loss = F.binary_cross_entropy_with_logits(output.reshape(b, -1), label.reshape(b, -1) / 255, reduction="none").sum(1)
+    loss = loss * weights
+    if is_reduce:
+        loss = torch.sum(loss)
+    if batch_average:
+        loss = loss / torch.sum(torch.as_tensor(weights))
+    return loss
+
+
 def get_kl_cc_sim_loss(config, pred_map, gt):
     """R/models/sal_losses.py:179-206: (main, cc, sim, nss) with the configuration's switches and weights.  The main term is KL
     (``loss_kl``), else the weighted MSE (``loss_mse``: the shipped configuration, R/cfgs/diffusion.yml:39-51); every enabled
-    term carries its gradient.  One metric launch set serves all four saliency terms.  ``loss_ce`` (binary cross-entropy with
-    logits on 0..255 labels, :48-60) is not built: no configuration of the reference enables it."""
+    term carries its gradient.  One metric launch set serves all four saliency terms.  ``loss_ce`` (:48-63: binary
+    cross-entropy with logits on labels / 255, summed over pixels and clips, times ``ce_weight``) is elementwise torch on the
+    device tensor -- no configuration of the reference enables it, so it has no kernel of its own."""
     from . import autograd_ops as ag
 
     lc = config.loss
@@ -79,7 +94,7 @@ def get_kl_cc_sim_loss(config, pred_map, gt):
     if getattr(lc, "loss_kl", False):
         main = lc.kl_weight * terms[3]
     elif getattr(lc, "loss_ce", False):
-        raise NotImplementedError("get_kl_cc_sim_loss: loss_ce is not built (no reference configuration enables it)")
+        main = cross_entropy_loss(pred_map, gt, lc.ce_weight)
     elif getattr(lc, "loss_mse", False):
         main = ag.mse_loss(pred_map, gt, float(lc.mse_weight) / pred_map.shape[0])
     else:

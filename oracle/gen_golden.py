@@ -560,6 +560,21 @@ def gen_loss_grads():
         d[f"{name}.cfg"] = np.array([lc[k] for k in ("kl_weight", "cc_weight", "sim_weight", "nss_weight", "mse_weight")])
         print(f"loss grads [{name}]:", {k: float(out[k]) for k in out}, "|grad| max", float(pred.grad.abs().max()))
     np.savez_compressed(os.path.join(GOLD, "sal_loss_grads.npz"), **d)
+    # third configuration, its own file: the loss_ce main term (cross_entropy_loss, :48-63: BCE with logits on labels / 255,
+    # summed over pixels and clips, times ce_weight) + CC.  The prediction is used as a logit map, as the reference does.
+    lc = dict(loss_kl=False, loss_ce=True, loss_mse=False, loss_cc=True, loss_sim=False, loss_nss=False,
+              kl_weight=1.0, cc_weight=-0.5, sim_weight=1.0, nss_weight=1.0, mse_weight=1.0, ce_weight=0.003)
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(**lc))
+    pred = (4.0 * base - 2.0).clone().requires_grad_(True)
+    gt255 = 255.0 * gt / gt.max()
+    out = ref.get_lossv2(cfg, pred, gt255)
+    out["total"].backward()
+    e = {k: np.array(float(out[k])) for k in ("total", "main", "cc")}
+    e["grad"] = pred.grad.numpy().copy()
+    e["pred"], e["gt"] = pred.detach().numpy(), gt255.numpy()
+    e["cfg"] = np.array([lc["ce_weight"], lc["cc_weight"]])
+    print("loss grads [ce]:", {k: float(out[k]) for k in out}, "|grad| max", float(pred.grad.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "sal_loss_ce.npz"), **e)
 
 
 def gen_legacy_denoising():

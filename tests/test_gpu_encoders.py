@@ -357,3 +357,28 @@ def test_training_loss_terms_and_gradients_match_reference(golden_dir, name):
     err = (pred.grad.cpu() - gref).abs().max().item() / gref.abs().max().item()
     print(f"loss gradient [{name}]: rel err {err:.2e}")
     assert err < 1e-4
+
+
+@pytest.mark.gpu
+def test_training_loss_ce_branch_matches_reference(golden_dir):
+    """get_lossv2 with loss_ce as its main term (cross_entropy_loss, R/models/sal_losses.py:48-63,187-188) + CC: values and
+    d total / d pred against the reference's autograd (tests/golden/sal_loss_ce.npz, oracle/gen_golden.py::gen_loss_grads)."""
+    import types
+
+    from diff_sal_amd import sal_losses as sl
+
+    g = np.load(f"{golden_dir}/sal_loss_ce.npz")
+    ce_w, cc_w = (float(v) for v in g["cfg"])
+    lc = dict(loss_kl=False, loss_ce=True, loss_mse=False, loss_cc=True, loss_sim=False, loss_nss=False,
+              kl_weight=1.0, cc_weight=cc_w, sim_weight=1.0, nss_weight=1.0, mse_weight=1.0, ce_weight=ce_w)
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(**lc))
+    pred = torch.from_numpy(g["pred"]).to(DEV).requires_grad_(True)
+    out = sl.get_lossv2(cfg, pred, torch.from_numpy(g["gt"]).to(DEV))
+    out["total"].backward()
+    for k in ("total", "main", "cc"):
+        ref = float(g[k])
+        assert abs(float(out[k]) - ref) <= 2e-5 * max(1.0, abs(ref)), (k, float(out[k]), ref)
+    gref = torch.from_numpy(g["grad"])
+    err = (pred.grad.cpu() - gref).abs().max().item() / gref.abs().max().item()
+    print(f"loss gradient [ce]: rel err {err:.2e}")
+    assert err < 1e-4

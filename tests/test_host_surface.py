@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 from torch import nn
@@ -270,3 +271,21 @@ def test_bench_ends_every_rank_when_one_dies():
     assert "rank failure" in r.stderr
     assert time.time() - t0 < 120
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no result line from a broken job
+
+
+def test_loss_ce_main_term_matches_reference_value(golden_dir):
+    """cross_entropy_loss (R/models/sal_losses.py:48-63) on the host: the main term of the loss_ce configuration against the
+    value the reference produced (tests/golden/sal_loss_ce.npz); needs no HIP library (no saliency term enabled)."""
+    import types
+
+    from diff_sal_amd import sal_losses as sl
+
+    g = np.load(f"{golden_dir}/sal_loss_ce.npz")
+    lc = dict(loss_kl=False, loss_ce=True, loss_mse=False, loss_cc=False, loss_sim=False, loss_nss=False, ce_weight=float(g["cfg"][0]))
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(**lc))
+    pred = torch.from_numpy(g["pred"]).requires_grad_(True)
+    main, cc, sim, nss = sl.get_kl_cc_sim_loss(cfg, pred, torch.from_numpy(g["gt"]))
+    assert abs(float(main) - float(g["main"])) <= 1e-5 * abs(float(g["main"]))
+    assert float(cc) == 0.0 and float(sim) == 0.0 and float(nss) == 0.0
+    main.backward()
+    assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0

@@ -11,5 +11,6 @@ python3 bench.py --steps 50 --warmup 10 > gpurun_out/$D/r04_bench.json 2> gpurun
 python3 bench.py --steps 50 --warmup 10 --mode av --no-cpu-baseline > gpurun_out/$D/r04_bench_av.json 2>> gpurun_out/$D/bench.err
 python3 bench.py --steps 50 --warmup 10 --precision bf16 --no-cpu-baseline --dump-launches gpurun_out/$D/r04_launches_bf16_unprofiled.json > gpurun_out/$D/r04_bench_bf16.json 2>> gpurun_out/$D/bench.err
 python3 bench.py --steps 20 --warmup 5 --precision fp16 --batch 64 --mode av --no-cpu-baseline --no-train-leg > gpurun_out/$D/r04_bench_fp16_b64_av.json 2>> gpurun_out/$D/bench.err
+bash tools/batch_sweep.sh gpurun_out/$D/r04_batch_sweep.jsonl
 rm -rf gpurun_out/$D/stats_* gpurun_out/$D/pmc_fetch_* gpurun_out/$D/pmc_write_* gpurun_out/$D/pmc_busy_*/
 ls gpurun_out/$D | head -60
