@@ -56,6 +56,10 @@ struct DmaGemmArgs {
   // split-K: unit u = (split, tile); a unit covers K slices [split * kt_per_unit, ...) and leaves raw sums in partial[split]
   int splits, kt_per_unit;
   float* partial;
+  // batched plain products (one launch, `batch` independent problems of ONE shape: the 36 position products of the F(4x4, 3x3)
+  // Winograd path): unit v = (batch index, tile), operands / output of problem b at a + b a_bs, w + b w_bs, out + b o_bs (elements)
+  int batch;
+  long a_bs, w_bs, o_bs;
 };
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rsrc` at voff + soff into LDS at lds_addr + 16 lane.  Inline assembly on
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   if constexpr (GROUPED) {
     n_virtual = g.total;
   } else {
-    n_virtual = g.n_tiles * g.splits;         // xcd_order only without split-K
+    n_virtual = g.n_tiles * g.splits * g.batch;         // xcd_order only without split-K and batch
     if (g.xcd_order) {
       const int x = blockIdx.x & 7;
       n_virtual = 8 * g.n_tiles_n * (g.n_tiles_m > x ? (g.n_tiles_m - x + 7) >> 3 : 0);
@@ -197,6 +201,15 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     } else {
       iss_lv = v;
     }
+    long ib_a = 0, ib_w = 0;       // batched: element offsets of the unit's problem
+    if constexpr (!GROUPED) {
+      if (g.batch > 1) {
+        const int per = g.n_tiles * g.splits, vv = live ? v : 0, ib = vv / per;
+        iss_lv = vv - ib * per;
+        ib_a = ib * g.a_bs;
+        ib_w = ib * g.w_bs;
+      }
+    }
     const int K = pi.K;
 #pragma unroll
     for (int q = 0; q < VQ; ++q) voff[q] = static_cast<unsigned>((r0 + 32 * q) * K * ESZ + slot * 16);
@@ -204,13 +217,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     tile_mn(pi, iss_lv, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
     const int rows_b = live ? min(BN, pi.N - n0) : 0;
-    const unsigned long pb = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.w) + static_cast<long>(n0) * K);
+    const unsigned long pb = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.w) + ib_w + static_cast<long>(n0) * K);
     rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * ESZ, 0x00020000};
     const int kt0 = split_of(pi, iss_lv) * pi.kt_per_unit;
     iss_kofs = static_cast<unsigned>(kt0) * 128u;
     if constexpr (!CONV) {
       const int rows_a = live ? min(BM, pi.M - m0) : 0;
-      const unsigned long pa = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.a) + static_cast<long>(m0) * K);
+      const unsigned long pa = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.a) + ib_a + static_cast<long>(m0) * K);
       rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * ESZ, 0x00020000};
     } else {
       const unsigned long pa = reinterpret_cast<unsigned long>(pi.a);
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   };
 
   int cmp_v = bid, cmp_lv = bid;
+  long cmp_ob = 0;                 // batched: element offset of the output of the unit being multiplied
   // Epilogue operands (per-channel vectors, residual quads) are requested at the start of the tile's LAST pass over the ring and
   // wait in registers: requested in the epilogue they would be a dependent round trip with the matrix pipe idle, and -- vmcnt
   // retires in order -- their wait would also drain the DMA ring.
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     tile_mn(pc, cmp_lv, tmi, tni);
     const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
     const long o0 = static_cast<long>(mb) * pc.N + nb;
-    T* __restrict__ ob = static_cast<T*>(pc.out) + o0;
+    T* __restrict__ ob = static_cast<T*>(pc.out) + cmp_ob + o0;
     const float* __restrict__ rvb = pc.rowvec;
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
@@ -483,6 +497,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
       pc = pick_problem(g, idx);
     } else {
       cmp_lv = cmp_v;
+      if (g.batch > 1) {
+        const int per = g.n_tiles * g.splits, ib = cmp_v / per;
+        cmp_lv = cmp_v - ib * per;
+        cmp_ob = ib * g.o_bs;
+      }
     }
     const int nkt = pc.kt_per_unit;
     for (int kt = 0; kt < nkt; kt += STAGES) {
@@ -559,9 +578,9 @@ template <typename T, int TMB, int TNB, int STAGES, int OCC>
 int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   constexpr int BM = 32 * TMB, BN = 32 * TNB;
   const int slots = 256 * OCC;
-  const int units = a.n_tiles * a.splits;
+  const int units = a.n_tiles * a.splits * a.batch;
   const int grid = units < slots ? units : slots;
-  a.xcd_order = (a.splits == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
+  a.xcd_order = (a.splits == 1 && a.batch == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
   if constexpr (sizeof(T) == 4) {
     if (conv) hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
@@ -611,6 +630,7 @@ bool dma_fill(DmaGemmArgs& g, const DmaCfg& c, const diffsal_conv_desc* d, bool 
   }
   g.splits = 1;
   g.kt_per_unit = K / epk;
+  g.batch = 1;
   return true;
 }
 
@@ -659,6 +679,24 @@ int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* 
   else if (cfg != 0) return 0;
   else if (d->dtype == DIFFSAL_BF16) rc = launch_dma<bf16_t, 3, 3, 3, 2>(g, false, s);
   else rc = launch_dma<f16_t, 3, 3, 3, 2>(g, false, s);
+  return rc == DIFFSAL_OK ? 1 : rc;
+}
+
+// `batch` plain fp32 products of one shape in ONE launch of the 96 x 96 / 3-stage kernel, no epilogue: out_b [M, N] = a_b [M, K] x
+// w_b [N, K]^T with the operands of problem b at a + b a_bs, w + b w_bs, out + b o_bs (elements).  Returns 1 if launched, 0 if the
+// shape is not handled (K % 96 != 0, N % 4 != 0, misaligned), < 0 on error.
+int gemm_dma_batched(const float* a, const float* w, float* out, long M, int K, int N, int batch, long a_bs, long w_bs, long o_bs,
+                     hipStream_t s) {
+  diffsal_conv_desc d{};
+  d.N = 1; d.H = 1; d.W = static_cast<int>(M); d.Ho = 1; d.Wo = static_cast<int>(M); d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1;
+  d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1;
+  d.dtype = DIFFSAL_F32;
+  if (M <= 0 || M >= (1L << 31) || batch < 1 || a_bs % 4 != 0 || w_bs % 4 != 0 || o_bs % 4 != 0) return 0;
+  DmaGemmArgs g;
+  if (!dma_fill(g, kDmaCfgs[0], &d, false, 4, a, w, nullptr, nullptr, nullptr, nullptr, 0, nullptr, out)) return 0;
+  g.batch = batch; g.a_bs = a_bs; g.w_bs = w_bs; g.o_bs = o_bs;
+  if (static_cast<long>(g.n_tiles) * batch >= (1L << 30)) return 0;
+  const int rc = launch_dma<float, 3, 3, 3, 2>(g, false, s);
   return rc == DIFFSAL_OK ? 1 : rc;
 }
 

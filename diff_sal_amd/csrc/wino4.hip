@@ -1,0 +1,323 @@
+// 3x3 stride-1 "same" convolutions (dilation d = padding, d in {1, 2}) of the fp32 denoiser as Winograd F(4x4, 3x3): 36
+// multiplications per 4x4 output tile, input channel and output channel instead of 144 -- the matrix pipe does 4x fewer MFMAs
+// than the direct convolution (F(2x2, 3x3) of csrc/wino.hip: 2.25x fewer).  Same layers as that file: ResnetBlock.conv1 / conv2
+// (R/models/saliency_decoder/sal_unet.py:104-142) and UpEmbed's second convolution (common_block.py:196-216).
+//
+//   Y = A^T [ sum_ci (G g G^T) o (B^T x B) ] A        per tile; o = element-wise over the 36 positions xi = (i, j)
+//
+// interpolation points 0, +-1, +-2, infinity (Lavin & Gray 2015, the standard F(4x4, 3x3) matrices).  The transforms multiply by
+// up to 8 and cancel: results differ from the direct fp32 convolution by ~1e-5 of the output maximum (F(2x2): ~1e-6), two
+// orders inside the 1e-3 parity bar; DIFFSAL_NO_WINOGRAD4=1 keeps F(2x2) / the direct kernel.
+//
+// Unlike wino.hip this path is NOT fused: a 36-position accumulator set for a 64 x 64 tile block is 590 KB, more than the 512 KB
+// of vector registers of a CU, and a block that fits (32 x 64) needs 12 TB/s of operand traffic to keep the matrix pipe busy.
+// The positions are 36 independent plain products [tiles, Cin] x [Cout, Cin]^T instead -- exactly what gemm_dma_kernel is built
+// for (96 x 96 tiles, LDS-DMA ring, 0.7-0.85 of the fp32 matrix peak) -- run as ONE batched launch between two streaming kernels:
+//
+//  1. wino4_input_kernel    V[xi][tile][ci] = B^T x B        2.25x the input bytes (F(2x2): 4x)
+//  2. gemm_dma_kernel       M[xi][tile][co] = V[xi] U[xi]^T   batch of 36, K = Cin; U = G g G^T [36][Cout][Cin] from the host
+//  3. wino4_output_kernel   Y = A^T M A + the usual epilogue (bias, BN affine, per-image vector, activation, residual)
+//
+// A dilated convolution is d*d undilated ones on the polyphase sub-grids: a tile is (image, py, px, ty, tx) and covers outputs
+// (py + d(4 ty + a), px + d(4 tx + b)), a, b in 0..3; its inputs are rows py + d(4 ty + i - 1), i in 0..5.
+#include "common.h"
+
+namespace diffsal {
+
+int gemm_dma_batched(const float* a, const float* w, float* out, long M, int K, int N, int batch, long a_bs, long w_bs, long o_bs,
+                     hipStream_t s);
+
+struct Wino4Geom {
+  int N, H, W, Cin, Cout, d;
+  int TY, TX;          // tiles per sub-grid
+  int n_tiles;         // N * d*d * TY * TX
+};
+
+__device__ __forceinline__ void wino4_tile_coords(const Wino4Geom& g, int t, int& n, int& y0, int& x0) {
+  const int per_class = g.TY * g.TX, per_img = g.d * g.d * per_class;
+  n = t / per_img;
+  const int r = t - n * per_img;
+  const int cls = r / per_class, rr = r - cls * per_class;
+  const int py = cls / g.d, px = cls - py * g.d;
+  const int ty = rr / g.TX, tx = rr - ty * g.TX;
+  y0 = py + g.d * 4 * ty;      // first output row of the tile; rows y0 + d a, a = 0..3; input rows y0 + d (i - 1), i = 0..5
+  x0 = px + g.d * 4 * tx;
+}
+
+// The transform kernels work on VT = float4 / float2 / float channels per lane: small layers (a few thousand tile x channel-quad
+// items) take the narrower types so that the launch still has enough lanes to hide its 36 dependent-free loads per lane.
+__device__ __forceinline__ float4 w4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 w4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// a + s b
+__device__ __forceinline__ float4 w4_fma(float s, float4 b, float4 a) {
+  return make_float4(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z), fmaf(s, b.w, a.w));
+}
+__device__ __forceinline__ float2 w4_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 w4_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 w4_fma(float s, float2 b, float2 a) { return make_float2(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y)); }
+__device__ __forceinline__ float w4_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float w4_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float w4_fma(float s, float b, float a) { return fmaf(s, b, a); }
+template <typename VT> __device__ __forceinline__ VT w4_zero();
+template <> __device__ __forceinline__ float4 w4_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float2 w4_zero<float2>() { return make_float2(0.f, 0.f); }
+template <> __device__ __forceinline__ float w4_zero<float>() { return 0.f; }
+template <typename VT> __device__ __forceinline__ VT w4_ld(const float* p) { return *reinterpret_cast<const VT*>(p); }
+template <typename VT> __device__ __forceinline__ void w4_st(float* p, VT v) { *reinterpret_cast<VT*>(p) = v; }
+template <typename VT> __device__ __forceinline__ float w4_get(const VT& v, int e);
+template <> __device__ __forceinline__ float w4_get<float4>(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+template <> __device__ __forceinline__ float w4_get<float2>(const float2& v, int e) { return e == 0 ? v.x : v.y; }
+template <> __device__ __forceinline__ float w4_get<float>(const float& v, int) { return v; }
+
+// B^T applied to six values (rows of B^T: [4 0 -5 0 1 0], [0 -4 -4 1 1 0], [0 4 -4 -1 1 0], [0 -2 -1 2 1 0], [0 2 -1 -2 1 0],
+// [0 4 0 -5 0 1])
+template <typename VT>
+__device__ __forceinline__ void w4_bt(const VT (&d)[6], VT (&t)[6]) {
+  t[0] = w4_fma(4.f, d[0], w4_fma(-5.f, d[2], d[4]));
+  const VT a = w4_fma(-4.f, d[2], d[4]), b = w4_fma(-4.f, d[1], d[3]);
+  t[1] = w4_add(a, b);
+  t[2] = w4_sub(a, b);
+  const VT c = w4_sub(d[4], d[2]), e = w4_sub(d[3], d[1]);
+  t[3] = w4_fma(2.f, e, c);
+  t[4] = w4_fma(-2.f, e, c);
+  t[5] = w4_fma(4.f, d[1], w4_fma(-5.f, d[3], d[5]));
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1. input transform.  item = (tile, channel quad), quads fastest: a wave reads 16-byte pieces of consecutive channels of one
+//    pixel (128-byte runs and longer) and writes, per position, consecutive channels of consecutive tiles (fully coalesced).
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename VT>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, Wino4Geom g) {
+  constexpr int VW = sizeof(VT) / 4;
+  const int q4n = g.Cin / VW;
+  const long items = static_cast<long>(g.n_tiles) * q4n;
+  const long pos_stride = static_cast<long>(g.n_tiles) * g.Cin;
+  for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
+    const int t = static_cast<int>(it / q4n);
+    const int q4 = static_cast<int>(it - static_cast<long>(t) * q4n);
+    int n, y0, x0;
+    wino4_tile_coords(g, t, n, y0, x0);
+    const float* base = x + static_cast<long>(n) * g.H * g.W * g.Cin + q4 * VW;
+    VT tt[6][6];
+    // columns first: tt[.][j] = B^T (column j of the 6 x 6 patch)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int xx = x0 + g.d * (j - 1);
+      const bool vx = xx >= 0 && xx < g.W;
+      VT dd[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int y = y0 + g.d * (i - 1);
+        const bool v = vx && y >= 0 && y < g.H;
+        const VT r = w4_ld<VT>(base + (v ? (static_cast<long>(y) * g.W + xx) : 0) * g.Cin);
+        dd[i] = v ? r : w4_zero<VT>();
+      }
+      VT c[6];
+      w4_bt(dd, c);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tt[i][j] = c[i];
+    }
+    float* dst = V + static_cast<long>(t) * g.Cin + q4 * VW;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {      // (.) B : rows
+      VT o[6];
+      w4_bt(tt[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) w4_st<VT>(dst + (i * 6 + j) * pos_stride, o[j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 3. output transform + epilogue.  item = (tile, channel quad), quads fastest.
+// ------------------------------------------------------------------------------------------------------------------------
+struct Wino4Out {
+  const float* M;
+  float* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* rowvec;
+  const float* residual;
+  int act, rowvec_ld;
+  Wino4Geom g;
+};
+
+__device__ __forceinline__ float w4_act(float x, int act) {
+  if (act == DIFFSAL_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == DIFFSAL_ACT_GELU_ERF) return gelu_erf(x);
+  if (act == DIFFSAL_ACT_SIGMOID) return sigmoidf_(x);
+  return x;
+}
+
+// A^T applied to six values (rows of A^T: [1 1 1 1 1 0], [0 1 -1 2 -2 0], [0 1 1 4 4 0], [0 1 -1 8 -8 1])
+template <typename VT>
+__device__ __forceinline__ void w4_at(const VT (&m)[6], VT (&y)[4]) {
+  const VT s12 = w4_add(m[1], m[2]), d12 = w4_sub(m[1], m[2]), s34 = w4_add(m[3], m[4]), d34 = w4_sub(m[3], m[4]);
+  y[0] = w4_add(w4_add(m[0], s12), s34);
+  y[1] = w4_fma(2.f, d34, d12);
+  y[2] = w4_fma(4.f, s34, s12);
+  y[3] = w4_add(w4_fma(8.f, d34, d12), m[5]);
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
+  constexpr int VW = sizeof(VT) / 4;
+  const Wino4Geom& g = p.g;
+  const int q4n = g.Cout / VW;
+  const long items = static_cast<long>(g.n_tiles) * q4n;
+  const long pos_stride = static_cast<long>(g.n_tiles) * g.Cout;
+  const long HW = static_cast<long>(g.H) * g.W;
+  for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
+    const int t = static_cast<int>(it / q4n);
+    const int co = static_cast<int>(it - static_cast<long>(t) * q4n) * VW;
+    int n, y0, x0;
+    wino4_tile_coords(g, t, n, y0, x0);
+    const float* src = p.M + static_cast<long>(t) * g.Cout + co;
+    VT s[4][6];                     // A^T M : columns j of M, rows a of the result
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      VT m[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m[i] = w4_ld<VT>(src + (i * 6 + j) * pos_stride);
+      VT y[4];
+      w4_at(m, y);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s[a][j] = y[a];
+    }
+    float bb[VW], ss[VW], hh[VW], rr[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      bb[e] = p.bias ? p.bias[co + e] : 0.f;
+      ss[e] = p.scale ? p.scale[co + e] : 1.f;
+      hh[e] = p.scale ? p.shift[co + e] : 0.f;
+      rr[e] = p.rowvec ? p.rowvec[static_cast<long>(n) * p.rowvec_ld + co + e] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = y0 + g.d * a;
+      VT y[4];
+      w4_at(s[a], y);                   // (.) A
+      if (oy >= g.H) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ox = x0 + g.d * b;
+        if (ox >= g.W) continue;
+        const long o = (static_cast<long>(n) * HW + static_cast<long>(oy) * g.W + ox) * g.Cout + co;
+        float v[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          float xv = w4_get<VT>(y[b], e) + bb[e];
+          if (p.scale) xv = xv * ss[e] + hh[e];
+          xv += rr[e];
+          v[e] = w4_act(xv, p.act);
+        }
+        if (p.residual) {
+          const VT rs = w4_ld<VT>(p.residual + o);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[e] += w4_get<VT>(rs, e);
+        }
+        VT ov;
+        if constexpr (VW == 4) ov = make_float4(v[0], v[1], v[2], v[3]);
+        else if constexpr (VW == 2) ov = make_float2(v[0], v[1]);
+        else ov = v[0];
+        w4_st<VT>(p.out + o, ov);
+      }
+    }
+  }
+}
+
+namespace {
+
+bool wino4_shape_ok(const diffsal_conv_desc* d) {
+  return d && d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
+         (d->dil_h == 1 || d->dil_h == 2) && d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H && d->Wo == d->W &&
+         d->Cin > 0 && d->Cin % 96 == 0 && d->Cout > 0 && d->Cout % 4 == 0 && d->N > 0 && d->H > 0 && d->W > 0 &&
+         d->dtype == DIFFSAL_F32 && d->precision == DIFFSAL_PREC_FP32;
+}
+
+Wino4Geom wino4_geom(const diffsal_conv_desc* d) {
+  Wino4Geom g{};
+  g.N = d->N; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Cout = d->Cout; g.d = d->dil_h;
+  g.TY = ((g.H + g.d - 1) / g.d + 3) / 4;
+  g.TX = ((g.W + g.d - 1) / g.d + 3) / 4;
+  g.n_tiles = g.N * g.d * g.d * g.TY * g.TX;
+  return g;
+}
+
+constexpr long kW4Lanes = 65536;       // lanes a transform launch should have before it takes wider pieces per lane
+
+size_t wino4_v_bytes(const Wino4Geom& g) { return 36ul * g.n_tiles * g.Cin * sizeof(float); }
+size_t wino4_m_bytes(const Wino4Geom& g) { return 36ul * g.n_tiles * g.Cout * sizeof(float); }
+
+}  // namespace
+}  // namespace diffsal
+
+using namespace diffsal;
+
+// 1 when diffsal_conv_wino4 accepts the descriptor AND the planner expects it to beat both the F(2x2) path and the direct kernel
+extern "C" int diffsal_conv_wino4_supported(const diffsal_conv_desc* d) {
+  if (!wino4_shape_ok(d) || tune(TUNE_NO_WINOGRAD) == 1 || tune(TUNE_NO_WINOGRAD4) == 1) return 0;
+  if (tune(TUNE_FORCE_WINOGRAD) == 1) return 1;
+  const Wino4Geom g = wino4_geom(d);
+  // the transformed input and the position products (36 x tiles x (Cin + Cout) floats) are written and read back once: they have
+  // to stay in the 256 MB Infinity Cache for the two streaming kernels to cost less than the products they save
+  return (wino4_v_bytes(g) + wino4_m_bytes(g) <= 400ul * 1000 * 1000 && d->Cout >= 96 && g.n_tiles >= 96) ? 1 : 0;
+}
+
+extern "C" size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d) {
+  if (!wino4_shape_ok(d)) return 0;
+  const Wino4Geom g = wino4_geom(d);
+  return wino4_v_bytes(g) + wino4_m_bytes(g);
+}
+
+// U: the transformed weight G g G^T as [36][Cout][Cin] fp32 (ops.pack_wino4_weight)
+extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
+                                  const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                                  size_t ws_bytes, diffsal_stream_t stream) {
+  DS_REQUIRE(d && x && U && out && ws, DIFFSAL_E_ARG, "conv_wino4: null argument");
+  DS_REQUIRE(wino4_shape_ok(d), DIFFSAL_E_SHAPE,
+             "conv_wino4: fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2}, Cin %% 96 == 0, Cout %% 4 == 0 only");
+  DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "conv_wino4: scale and shift come together");
+  const Wino4Geom g = wino4_geom(d);
+  const size_t vb = wino4_v_bytes(g), mb = wino4_m_bytes(g);
+  DS_REQUIRE(ws_bytes >= vb + mb, DIFFSAL_E_ARG, "conv_wino4: workspace of %zu bytes, need %zu", ws_bytes, vb + mb);
+  DS_REQUIRE(aligned16(x) && aligned16(U) && aligned16(out) && aligned16(ws) && (!bias || aligned16(bias)) &&
+                 (!scale || (aligned16(scale) && aligned16(shift))) && (!rowvec || aligned16(rowvec)) &&
+                 (!residual || aligned16(residual)) && (!rowvec || d->rowvec_ld % 4 == 0),
+             DIFFSAL_E_ALIGN, "conv_wino4: misaligned pointer");
+  DS_REQUIRE(static_cast<long>(d->N) * d->H * d->W * d->Cin < (1L << 31) && static_cast<long>(d->N) * d->H * d->W * d->Cout < (1L << 31),
+             DIFFSAL_E_SHAPE, "conv_wino4: tensor too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* V = static_cast<float*>(ws);
+  float* Mb = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
+  {
+    // lanes per item: wide pieces when there are plenty of items, else narrower ones (>= ~128 K lanes keep 256 CUs busy)
+    const long scalars = static_cast<long>(g.n_tiles) * g.Cin;
+    const int vw = scalars >= 4 * kW4Lanes ? 4 : (scalars >= 2 * kW4Lanes ? 2 : 1);
+    long gi = (scalars / vw + 255) / 256;
+    gi = gi > 16384 ? 16384 : gi;
+    if (vw == 4) hipLaunchKernelGGL(wino4_input_kernel<float4>, dim3(static_cast<unsigned>(gi)), dim3(256), 0, s, x, V, g);
+    else if (vw == 2) hipLaunchKernelGGL(wino4_input_kernel<float2>, dim3(static_cast<unsigned>(gi)), dim3(256), 0, s, x, V, g);
+    else hipLaunchKernelGGL(wino4_input_kernel<float>, dim3(static_cast<unsigned>(gi)), dim3(256), 0, s, x, V, g);
+    const int rc = check_launch("conv_wino4(input transform)");
+    if (rc) return rc;
+  }
+  const int r = gemm_dma_batched(V, U, Mb, g.n_tiles, g.Cin, g.Cout, 36, static_cast<long>(g.n_tiles) * g.Cin,
+                                 static_cast<long>(g.Cout) * g.Cin, static_cast<long>(g.n_tiles) * g.Cout, s);
+  if (r < 0) return r;
+  DS_REQUIRE(r == 1, DIFFSAL_E_SHAPE, "conv_wino4: the position products do not fit the batched GEMM kernel");
+  Wino4Out a{};
+  a.M = Mb; a.out = out; a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec; a.residual = residual;
+  a.act = d->act; a.rowvec_ld = d->rowvec_ld; a.g = g;
+  const long scalars = static_cast<long>(g.n_tiles) * g.Cout;
+  const int vw = scalars >= 4 * kW4Lanes ? 4 : (scalars >= 2 * kW4Lanes ? 2 : 1);
+  long go = (scalars / vw + 255) / 256;
+  go = go > 16384 ? 16384 : go;
+  if (vw == 4) hipLaunchKernelGGL(wino4_output_kernel<float4>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
+  else if (vw == 2) hipLaunchKernelGGL(wino4_output_kernel<float2>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(wino4_output_kernel<float>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
+  note_kernel("gemm_dma_kernel<float, 3, 3, 3, 2, false, false> [winograd F(4x4,3x3): 36 x (M=%d K=%d N=%d)]", g.n_tiles, g.Cin, g.Cout);
+  return check_launch("conv_wino4(output transform)");
+}

@@ -395,6 +395,26 @@ def pack_wino_weight(w: Tensor) -> Tensor:
     return U.view(16, cb, 64, Cin // 8, 8).permute(3, 1, 0, 2, 4).contiguous()
 
 
+def pack_wino4_weight(w: Tensor) -> Tensor:
+    """[Cout, Cin, 3, 3] -> the Winograd F(4x4, 3x3) weight U = G w G^T as [36][Cout][Cin] fp32 (position-major: the B operand of
+    the 36 position products of diffsal_conv_wino4); include/diffsal.h.  Computed in fp64, rounded once."""
+    w = w.detach().double()
+    Cout, Cin = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 3)
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], device=w.device, dtype=torch.float64)
+    return torch.einsum("ia,ocab,jb->ijoc", G, w, G).reshape(36, Cout, Cin).float().contiguous()
+
+
+class WinoWeights:
+    """The Winograd forms of one 3x3 weight: ``f2`` (pack_wino_weight) and ``f4`` (pack_wino4_weight); conv_igemm(wino=...) asks
+    the library per shape which of them -- if any -- to use."""
+
+    def __init__(self, w: Tensor):
+        self.f2 = pack_wino_weight(w) if w.shape[1] % 8 == 0 else None
+        self.f4 = pack_wino4_weight(w) if w.shape[1] % 96 == 0 else None
+
+
 @_classed("pack")
 def split_weight(w_packed: Tensor) -> Tensor:
     """bf16x3 mode only: pre-split a packed fp32 weight [Cout, K] into bf16 hi/lo halves per 32-k slice (same shape and
@@ -472,11 +492,12 @@ def pack_conv_weight_diff(w: Tensor) -> Tensor:
 def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=(1, 1), pad=(0, 0), dil=(1, 1),
                out_hw: Optional[Sequence[int]] = None, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
                shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               act: int = ACT_NONE, out: Optional[Tensor] = None, tag: str = "gemm", wino: Optional[Tensor] = None) -> Tensor:
+               act: int = ACT_NONE, out: Optional[Tensor] = None, tag: str = "gemm", wino=None) -> Tensor:
     """Implicit-GEMM conv on NHWC x [N,H,W,Cin] with packed weight [Cout, kh*kw*Cin] -> [N,Ho,Wo,Cout].
 
     ``pad`` is (top, left); bottom/right padding is implied by ``out_hw`` (zero fill outside).  ``wino``: the same weight in
-    Winograd form (``pack_wino_weight``); used instead of the direct kernel when the library's planner expects a gain
+    Winograd form (a ``pack_wino_weight`` tensor, or ``WinoWeights`` = F(2x2) and F(4x4) forms: F(4x4) where
+    ``diffsal_conv_wino4_supported`` says so, ~1e-5 relative rounding); used instead of the direct kernel when the library's planner expects a gain
     (``diffsal_conv_wino_supported``: fp32 3x3 stride-1, padding = dilation in {1, 2}, Cin % 32 == 0, Cout >= 128, enough
     workgroups and a transformed input of at most 160 MB -- both depend on the BATCH, so the same clip can take the Winograd
     kernel in a large pass and the direct kernel alone: results then differ by the transforms' ~1e-6 relative rounding)."""
@@ -502,6 +523,22 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         rv = rowvec.data_ptr()
     else:
         rv = None
+    wino4 = None
+    if isinstance(wino, WinoWeights):
+        wino, wino4 = wino.f2, wino.f4
+    if wino4 is not None and lib.diffsal_conv_wino4_supported(C.byref(d)):
+        ws_bytes = lib.diffsal_conv_wino4_ws_bytes(C.byref(d))
+        ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
+        dd = dil[0]
+        n_tiles = N * dd * dd * (((H + dd - 1) // dd + 3) // 4) * (((W + dd - 1) // dd + 3) // 4)
+        # FLOPs actually issued: 36 products per 4x4 tile, input and output channel (the direct form has 144)
+        with _prof(tag, 2.0 * n_tiles * 36 * Cin * Cout, _nb(x, wino4, residual, out) + 2 * 36 * n_tiles * (Cin + Cout) * 4,
+                   f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw} winograd F(4x4,3x3)" if PROFILE is not None else "") as pr:
+            _lib.check(lib.diffsal_conv_wino4(C.byref(d), _p(x), _p(wino4), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out),
+                                              _p(ws), ws_bytes, _stream()), "conv_wino4")
+            if PROFILE is not None:
+                pr.kernel = lib.diffsal_last_gemm_kernel().decode()
+        return out
     if wino is not None and lib.diffsal_conv_wino_supported(C.byref(d)):
         ws_bytes = lib.diffsal_conv_wino_ws_bytes(C.byref(d))
         ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)

@@ -251,7 +251,7 @@ class SalUNet(nn.Module):
         planner then decides per shape whether diffsal_conv_wino or the direct kernel runs (ops.conv_igemm(wino=...))."""
         if self.compute_dtype != torch.float32 or self._precision() != "fp32" or not self.winograd:
             return None
-        return ops.pack_wino_weight(w)
+        return ops.WinoWeights(w)
 
     def _tap_weight(self, w: Tensor) -> Tensor:
         """Conv2d 3x3 weight -> the [9*Cout, Cin] matrix of its nine 1x1 tap mixings (row = tap * Cout + co), in the storage /

@@ -175,6 +175,17 @@ size_t diffsal_conv_wino_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wino(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
                       const float* scale, const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
                       size_t ws_bytes, diffsal_stream_t stream);
+/* Winograd F(4x4, 3x3) form of the same operator (same layers and shape rules as diffsal_conv_wino, Cin % 96 == 0): 4x fewer
+ * multiplications than the direct convolution; transform rounding ~1e-5 of the output maximum.  `U` is G g G^T as
+ * [36][Cout][Cin] fp32 (ops.pack_wino4_weight).  Three launches: input transform, the 36 position products as one batched
+ * plain product, output transform + epilogue.  ws: diffsal_conv_wino4_ws_bytes(d) = 36 * tiles * (Cin + Cout) floats.
+ * diffsal_conv_wino4_supported: the shape qualifies and the planner expects a gain (DIFFSAL_NO_WINOGRAD4=1 /
+ * DIFFSAL_NO_WINOGRAD=1: never, DIFFSAL_FORCE_WINOGRAD=1: whenever the shape qualifies). */
+int diffsal_conv_wino4_supported(const diffsal_conv_desc* d /*host*/);
+size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d /*host*/);
+int diffsal_conv_wino4(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
+                       const float* scale, const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                       size_t ws_bytes, diffsal_stream_t stream);
 /* Up to four independent convolutions / plain products (own descriptor, operands and output; bias + activation epilogue
  * only) in ONE launch: the four ReduceTemp products of a step (R/models/saliency_decoder/common_block.py:150-173,
  * sal_unet.py:480-487) have 336 .. 21504 rows and 3840 .. 480 columns of K, each alone fills a fraction of the chip.  fp32

@@ -69,3 +69,64 @@ def test_winograd_conv_matches_direct_convolution(case, tuning):
     tuning.set("DIFFSAL_NO_WINOGRAD", 1)              # the switch wins over everything: the direct kernel, bit for bit
     off = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), wino=ops.pack_wino_weight(wd), **kw)
     assert torch.equal(off, direct)
+
+
+CASES4 = [
+    # N, H, W, Cin, Cout, d, epilogue            F(4x4, 3x3): Cin % 96 == 0
+    (2, 14, 24, 192, 192, 1, "bias"),                 # 14 rows: the last tile row is half empty
+    (2, 14, 24, 192, 192, 2, "bn_relu_res"),          # sub-grids of 7 x 12
+    (1, 7, 9, 96, 68, 2, "bias_rowvec"),              # odd everything, Cout not a multiple of 16
+    (3, 5, 6, 96, 100, 1, "none"),
+    (4, 28, 48, 192, 384, 1, "bias_res"),             # ResnetBlock of stage 1 at its real size
+    (4, 14, 24, 768, 768, 1, "bias_rowvec"),          # ResnetBlock of stage 2: deepest contraction
+    (36, 14, 24, 384, 384, 2, "bn_relu_res"),         # UpEmbed-2 of stage 1
+]
+
+
+@pytest.mark.parametrize("case", CASES4, ids=[f"{c[1]}x{c[2]}_{c[3]}to{c[4]}_d{c[5]}_{c[6]}" for c in CASES4])
+def test_winograd_f4_conv_matches_direct_convolution(case, tuning):
+    """F(4x4, 3x3) (csrc/wino4.hip: input transform, 36 batched position products on gemm_dma_kernel, output transform + epilogue)
+    against torch's fp32 convolution and the direct kernel.  Bar 1e-4 of the output maximum (measured ~1e-5: the transforms
+    multiply by up to 8 and cancel); DIFFSAL_NO_WINOGRAD4 falls back to F(2x2), DIFFSAL_NO_WINOGRAD to the direct kernel."""
+    from diff_sal_amd import ops
+
+    N, H, W, Cin, Cout, d, epi = case
+    tuning.set("DIFFSAL_FORCE_WINOGRAD", 1)
+    x = rnd("wx", N, H, W, Cin)
+    w = rnd("ww", Cout, Cin, 3, 3, scale=0.05)
+    bias = rnd("wb", Cout, scale=0.2) if "bias" in epi or "bn" in epi else None
+    scale = (rnd("ws", Cout, scale=0.1) + 1.0) if "bn" in epi else None
+    shift = rnd("wh", Cout, scale=0.1) if "bn" in epi else None
+    rowvec = rnd("wr", N, Cout + 4, scale=0.3)[:, :Cout] if "rowvec" in epi else None
+    res = rnd("wq", N, H, W, Cout) if "res" in epi else None
+    act = ops.ACT_RELU if "relu" in epi else ops.ACT_NONE
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None if bias is None else bias.double(), padding=d, dilation=d).permute(0, 2, 3, 1)
+    if scale is not None:
+        ref = ref * scale + shift
+    if rowvec is not None:
+        ref = ref + rowvec[:, None, None, :]
+    if act == ops.ACT_RELU:
+        ref = ref.relu()
+    if res is not None:
+        ref = ref + res
+    dv = lambda t: None if t is None else t.to(DEV)
+    wd = w.to(DEV)
+    kw = dict(kh=3, kw=3, pad=(d, d), dil=(d, d), bias=dv(bias), scale=dv(scale), shift=dv(shift), rowvec=dv(rowvec),
+              residual=dv(res), act=act)
+    ww = ops.WinoWeights(wd)
+    direct = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), **kw)
+    f4 = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), wino=ww, **kw)
+    tuning.set("DIFFSAL_NO_WINOGRAD4", 1)
+    f2 = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), wino=ww, **kw)
+    e4, e2, e0 = rel_err(f4, ref), rel_err(f2, ref), rel_err(direct, ref)
+    print(f"F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {e0:.2e}")
+    assert e0 < 2e-5 and e2 < 2e-5
+    assert e4 < 1e-4
+    assert not torch.equal(f4, f2) and not torch.equal(f4, direct), "the F(4x4) path did not run"
+    again = None
+    tuning.set("DIFFSAL_NO_WINOGRAD4", None)
+    again = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), wino=ww, **kw)
+    assert torch.equal(again, f4)                     # deterministic
+    tuning.set("DIFFSAL_NO_WINOGRAD", 1)
+    off = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), wino=ww, **kw)
+    assert torch.equal(off, direct)
