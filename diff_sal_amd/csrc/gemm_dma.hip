@@ -269,22 +269,29 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
       dma_piece(st + (BM * 32 + (q - APW) * 1024) * 4u, voff[q - APW], rs_b, iss_kofs);
     }
   };
-  auto issue_advance = [&]() __attribute__((always_inline)) {
+  // A unit is a multiple of STAGES slices and starts on ring stage 0, so the slice issued while stage S is multiplied (P ahead)
+  // is the LAST of its unit only for S == 0: the unit-boundary test and the descriptor rebuild behind it exist once in the ring
+  // (and not at all in the prologue: P < STAGES <= kt_per_unit), not once per stage -- a third of the code size for the
+  // convolution form, whose descriptor rebuild is long.
+  auto issue_advance = [&](auto may_end_unit) __attribute__((always_inline)) {
     iss_kofs += 128u;
     if constexpr (CONV) {
       if (++iss_kx == pi.KW) { iss_kx = 0; ++iss_ky; }
       if (++iss_tap == pi.taps) { iss_tap = 0; iss_ky = 0; iss_kx = 0; ++iss_chunk; }
     }
-    if (++iss_kt == pi.kt_per_unit) {
-      iss_kt = 0;
-      iss_v += gsz;
-      descriptors(iss_v);
+    ++iss_kt;
+    if constexpr (decltype(may_end_unit)::value) {
+      if (iss_kt == pi.kt_per_unit) {
+        iss_kt = 0;
+        iss_v += gsz;
+        descriptors(iss_v);
+      }
     }
   };
-  auto issue_slice = [&](int stage) __attribute__((always_inline)) {
+  auto issue_slice = [&](int stage) __attribute__((always_inline)) {      // prologue only
 #pragma unroll
     for (int q = 0; q < PPW; ++q) issue_piece(stage, q);
-    issue_advance();
+    issue_advance(std::false_type{});
   };
 
   // ---- compute side: fragment addresses (floats inside a stage) for the two 16-wide halves of a slice
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      issue_advance();
+      issue_advance(std::integral_constant<bool, S == 0>{});
     }
     __builtin_amdgcn_sched_barrier(0);
   };

@@ -318,6 +318,7 @@ extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, co
   if (vw == 4) hipLaunchKernelGGL(wino4_output_kernel<float4>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
   else if (vw == 2) hipLaunchKernelGGL(wino4_output_kernel<float2>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(wino4_output_kernel<float>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
-  note_kernel("gemm_dma_kernel<float, 3, 3, 3, 2, false, false> [winograd F(4x4,3x3): 36 x (M=%d K=%d N=%d)]", g.n_tiles, g.Cin, g.Cout);
+  note_kernel("wino4_input_kernel + 36 x gemm_dma_kernel<float, 3, 3, 3, 2, false, false> + wino4_output_kernel [F(4x4,3x3): 36 x (M=%d K=%d N=%d)]",
+              g.n_tiles, g.Cin, g.Cout);
   return check_launch("conv_wino4(output transform)");
 }

@@ -633,6 +633,21 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = AC
     return y.reshape(*lead, w.shape[0])
 
 
+def linear_group(xs: Sequence[Tensor], ws: Sequence[Tensor], biases: Sequence[Optional[Tensor]], tag: str = "K10") -> List[Tensor]:
+    """Up to four token GEMMs of ANY shapes in one launch (``conv_igemm_group``): x_i [..., K_i] @ w_i[N_i, K_i]^T + b_i.  fp32
+    storage, exact arithmetic (the caller checks)."""
+    probs, leads = [], []
+    for x, w, b in zip(xs, ws, biases):
+        lead = x.shape[:-1]
+        M = 1
+        for s_ in lead:
+            M *= s_
+        probs.append(dict(x=x.reshape(1, 1, M, x.shape[-1]), w=w, bias=b))
+        leads.append(lead)
+    outs = conv_igemm_group(probs, tag=tag)
+    return [o.reshape(*lead, w.shape[0]) for o, lead, w in zip(outs, leads, ws)]
+
+
 def linear_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Optional[Tensor], b1: Optional[Tensor],
                 tag: str = "K10") -> Tuple[Tensor, Tensor]:
     """Two token GEMMs of one shape in one launch: (x0 @ w0^T + b0, x1 @ w1^T + b1); x_i [..., K], w_i [N, K] (exact

@@ -457,11 +457,21 @@ class SalUNet(nn.Module):
                 kk, vv = ops.dwpool_ln_kv(k_src.view(n9, H, W, C), xn.view(n9, H, W, C), pk[f"s{i}.wk"], pk[f"s{i}.wv"],
                                           a.conv_proj_k.bn.weight, a.conv_proj_k.bn.bias, a.conv_proj_v.bn.weight,
                                           a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
-        q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
-        if self.pair_kv and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and (
+        if (self.group_qkv and self.compute_dtype == torch.float32 and ops.get_gemm_precision() == "fp32"
+                and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and C % 96 == 0
+                and -(-(q.numel() // C) // 96) * (C // 96) <= 256):
+            # the three projections of the block in ONE launch when the query product alone leaves workgroup slots free (<= 256
+            # tiles of 96 x 96: stage 0 at B = 4; the key / value products have 648 rows and would fill a quarter of the chip
+            # for the length of a whole K walk).  Measured at B = 4: stage 0 64 us against 40 + 36; stages 1 / 2, whose query
+            # products fill the chip, 60 / 65 us against 38 + 19 / 41 + 15 -- not grouped.
+            q, kk, vv = ops.linear_group((q, kk, vv), (pk[f"s{i}.q.w"], pk[f"s{i}.k.w"], pk[f"s{i}.v.w"]),
+                                         (a.proj_q.bias, a.proj_k.bias, a.proj_v.bias))
+        elif self.pair_kv and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and (
                 self.compute_dtype != torch.float32 or ops.get_gemm_precision() == "fp32"):
+            q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
             kk, vv = ops.linear_pair(kk, vv, pk[f"s{i}.k.w"], pk[f"s{i}.v.w"], a.proj_k.bias, a.proj_v.bias)   # one launch
         else:
+            q = ops.linear(q, pk[f"s{i}.q.w"], a.proj_q.bias)
             kk = ops.linear(kk, pk[f"s{i}.k.w"], a.proj_k.bias)
             vv = ops.linear(vv, pk[f"s{i}.v.w"], a.proj_v.bias)
         o = ops.attention(q, kk, vv, self.heads[i], float(C) ** -0.5)  # scale uses full C (Q6)
@@ -532,6 +542,7 @@ class SalUNet(nn.Module):
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
+    group_qkv = True  # fp32: query, key and value projections of a block in one grouped launch (ops.linear_group)
     merge_align = True   # the stages' audio align convolutions as one product (eval)
     group_reduce_temp = True   # fp32 tap path: the stages' ReduceTemp products in one grouped launch after the last stage
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
