@@ -60,7 +60,15 @@ struct DmaGemmArgs {
   // Winograd path): unit v = (batch index, tile), operands / output of problem b at a + b a_bs, w + b w_bs, out + b o_bs (elements)
   int batch;
   long a_bs, w_bs, o_bs;
+#ifdef DIFFSAL_DEV_STAMPS
+  unsigned long long* stamps;   // development build only: 32 time stamps per workgroup (diffsal_set_dma_stamps)
+#endif
 };
+
+#ifdef DIFFSAL_DEV_STAMPS
+static unsigned long long* g_dma_stamps = nullptr;
+static size_t g_dma_stamp_bytes = 0;
+#endif
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from the buffer `rsrc` at voff + soff into LDS at lds_addr + 16 lane.  Inline assembly on
 // purpose: hipcc orders every later LDS read behind a DMA it knows about (s_waitcnt vmcnt(0) in front of the fragment reads at a
@@ -175,6 +183,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   const int bid = blockIdx.x, gsz = gridDim.x;
   const int my_tiles = n_virtual > bid ? (n_virtual - bid + gsz - 1) / gsz : 0;
   if (my_tiles == 0) return;
+#ifdef DIFFSAL_DEV_STAMPS
+  auto stamp = [&](int k) {
+    if constexpr (!GROUPED) { if (g.stamps && tid == 0 && k < 32) g.stamps[blockIdx.x * 32 + k] = wall_clock64(); }
+  };
+#else
+  auto stamp = [](int) {};
+#endif
+  stamp(0);
 
   // ---- issue side.  Plain products: one per-lane byte offset serves every piece (pieces of a wave are 32 rows apart: the
   // swizzle term ((row >> 1) & 7) = (4 wave + (lane >> 4)) & 7 does not depend on the piece); the descriptor of A is rebuilt
@@ -431,16 +447,21 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
         if (mb + i * 16 < pc.M && nb + j * 16 < pc.N) st4(ob + (static_cast<long>(i) * 16 * pc.N + j * 16), v);
       }
   };
-  auto finish_tile = [&]() __attribute__((always_inline)) {
-    if (pc.splits > 1) { store_partial(); return; }
-    // an unconditional use of every prefetched register: hipcc then knows that no request is pending when the next tile's
-    // prefetch overwrites them
+  // An unconditional use of every prefetched register.  hipcc puts s_waitcnt vmcnt(0) in front of it -- it cannot know about the
+  // DMA ring, and vmcnt(0) drains the ring.  So the use sits right behind a mid-slice wait of the ring itself (the step AFTER the
+  // one the operands were requested in): that wait is vmcnt(0) already, the compiler's is then free, and from there on hipcc knows
+  // that nothing is pending -- the epilogue starts without a wait.  (In the epilogue itself the same wait cost 2-3 us per unit:
+  // the first slices of the next unit, just requested, had to land before the first store could be issued.)
+  auto touch_epilogue_operands = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
       touch(rbias[j]); touch(rscale[j]); touch(rshift[j]);
 #pragma unroll
       for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
     }
+  };
+  auto finish_tile = [&]() __attribute__((always_inline)) {
+    if (pc.splits > 1) { store_partial(); return; }
     switch (pc.act) {
       case DIFFSAL_ACT_RELU: epilogue(std::integral_constant<int, DIFFSAL_ACT_RELU>{}); break;
       case DIFFSAL_ACT_GELU_ERF: epilogue(std::integral_constant<int, DIFFSAL_ACT_GELU_ERF>{}); break;
@@ -458,8 +479,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   load_frags(smem, 0, 0);
 
   // one K slice: stage S is multiplied, stage S + 1 is read ahead, stage S - 1 (free after the barrier) takes the DMA of slice g + P
-  auto step = [&](auto idx) __attribute__((always_inline)) {
+  // LAST: the unit's last pass over the ring -- stage 0 requests the epilogue operands behind its barrier, stage 1 uses them
+  auto step = [&](auto idx, auto last_c) __attribute__((always_inline)) {
     constexpr int S = decltype(idx)::value;
+    constexpr bool LAST = decltype(last_c)::value;
     const float* cur = smem + S * STAGE_F;
     const float* nxt = smem + ((S + 1) % STAGES) * STAGE_F;
     load_frags(cur, 1, 1);
@@ -470,6 +493,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     // slice g - 1 any more
     wait_vmcnt<WAIT_N>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (LAST && S == 0) {
+      if (pc.splits == 1) fetch_epilogue_operands();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LAST && S == 1) {
+      touch_epilogue_operands();      // unconditional: on every path hipcc then knows that no request outlives the unit
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // second half of the slice: its MFMAs (operands already in registers) with the DMA pieces of slice g + P and the fragment
     // reads of slice g + 1 slipped between them at even distances -- a wave alone on its SIMD must not stop issuing MFMAs
     // for the ~60 cycles a DMA instruction takes to issue
@@ -490,11 +521,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto ring = [&](auto self, auto idx) __attribute__((always_inline)) {
+  auto ring = [&](auto self, auto idx, auto last_c) __attribute__((always_inline)) {
     constexpr int S = decltype(idx)::value;
     if constexpr (S < STAGES) {
-      step(idx);
-      self(self, std::integral_constant<int, S + 1>{});
+      step(idx, last_c);
+      self(self, std::integral_constant<int, S + 1>{}, last_c);
     }
   };
   for (int t = 0; t < my_tiles; ++t) {          // the host guarantees kt_per_unit % STAGES == 0: a unit starts on stage 0
@@ -511,11 +542,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
       }
     }
     const int nkt = pc.kt_per_unit;
-    for (int kt = 0; kt < nkt; kt += STAGES) {
-      if (kt + STAGES >= nkt && pc.splits == 1) fetch_epilogue_operands();
-      ring(ring, std::integral_constant<int, 0>{});
-    }
+    stamp(1 + 3 * t);
+    for (int kt = STAGES; kt < nkt; kt += STAGES) ring(ring, std::integral_constant<int, 0>{}, std::false_type{});
+    ring(ring, std::integral_constant<int, 0>{}, std::true_type{});
+    stamp(2 + 3 * t);
     finish_tile();
+    stamp(3 + 3 * t);
     cmp_v += gsz;
   }
 }
@@ -587,6 +619,9 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   const int slots = 256 * OCC;
   const int units = a.n_tiles * a.splits * a.batch;
   const int grid = units < slots ? units : slots;
+#ifdef DIFFSAL_DEV_STAMPS
+  a.stamps = (g_dma_stamps && static_cast<size_t>(grid) * 32 * 8 <= g_dma_stamp_bytes) ? g_dma_stamps : nullptr;
+#endif
   a.xcd_order = (a.splits == 1 && a.batch == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
   if constexpr (sizeof(T) == 4) {
     if (conv) hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
@@ -745,3 +780,14 @@ int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* co
 }
 
 }  // namespace diffsal
+
+#ifdef DIFFSAL_DEV_STAMPS
+// Development builds only (hipcc -DDIFFSAL_DEV_STAMPS; tools/probe_dma_stamps.py): a caller-owned device buffer receives 32 time
+// stamps per workgroup of every following single-problem launch of gemm_dma_kernel that fits in `bytes` (slot 0: kernel entry;
+// 1 + 3t, 2 + 3t, 3 + 3t: unit t starts, its K walk is done, its epilogue is done); (nullptr, 0) turns it off.
+extern "C" int diffsal_set_dma_stamps(void* device_buffer, size_t bytes) {
+  diffsal::g_dma_stamps = static_cast<unsigned long long*>(device_buffer);
+  diffsal::g_dma_stamp_bytes = device_buffer ? bytes : 0;
+  return DIFFSAL_OK;
+}
+#endif
