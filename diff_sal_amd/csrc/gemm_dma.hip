@@ -460,8 +460,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
       for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
     }
   };
+  // no epilogue operand at all (the position products of the Winograd path, the tap products of UpEmbed / mt_proj): the sums go
+  // out as they are -- ~60 instructions instead of the ~500 of the general epilogue, whose optional terms hipcc turns into selects
+  auto store_plain = [&]() __attribute__((always_inline)) {
+    int tmi, tni;
+    tile_mn(pc, cmp_lv, tmi, tni);
+    const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
+    float* __restrict__ ob = static_cast<float*>(pc.out) + cmp_ob + static_cast<long>(mb) * pc.N + nb;
+#pragma unroll
+    for (int j = 0; j < TNB; ++j)
+#pragma unroll
+      for (int i = 0; i < TMB; ++i) {
+        const float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (mb + i * 16 < pc.M && nb + j * 16 < pc.N) st4(ob + (static_cast<long>(i) * 16 * pc.N + j * 16), v);
+      }
+  };
   auto finish_tile = [&]() __attribute__((always_inline)) {
     if (pc.splits > 1) { store_partial(); return; }
+    if constexpr (F32) {
+      if (!pc.bias && !pc.scale && !pc.rowvec && !pc.residual && pc.act == DIFFSAL_ACT_NONE) { store_plain(); return; }
+    }
     switch (pc.act) {
       case DIFFSAL_ACT_RELU: epilogue(std::integral_constant<int, DIFFSAL_ACT_RELU>{}); break;
       case DIFFSAL_ACT_GELU_ERF: epilogue(std::integral_constant<int, DIFFSAL_ACT_GELU_ERF>{}); break;
