@@ -648,9 +648,9 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   } else {
     hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
   }
-  note_kernel("gemm_dma_kernel<%s, %d, %d, %d, %d, %s, false> [%dx%d tile, %d stages, split-K %d]",
+  note_kernel("gemm_dma_kernel<%s, %d, %d, %d, %d, %s, false> [%dx%d tile, %d stages, split-K %d, batch %d]",
               sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "__bf16" : "_Float16"), TMB, TNB, STAGES, OCC,
-              conv ? "true" : "false", BM, BN, STAGES, a.splits);
+              conv ? "true" : "false", BM, BN, STAGES, a.splits, a.batch);
   int rc = check_launch("diffsal_conv_igemm(dma)");
   if (rc || a.splits == 1) return rc;
   long g = (static_cast<long>(a.M) * (a.N / 4) + 255) / 256;

@@ -272,10 +272,12 @@ extern "C" size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d) {
   return wino4_v_bytes(g) + wino4_m_bytes(g);
 }
 
-// U: the transformed weight G g G^T as [36][Cout][Cin] fp32 (ops.pack_wino4_weight)
-extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
-                                  const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
-                                  size_t ws_bytes, diffsal_stream_t stream) {
+// U: the transformed weight G g G^T as [36][Cout][Cin] fp32 (ops.pack_wino4_weight).  stages: bit 0 input transform, bit 1 the
+// position products, bit 2 output transform + epilogue -- the three launches of the path, callable one by one (same arguments,
+// same workspace) so that a profiler can bracket each: diffsal_conv_wino4 is stages = 7.
+extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
+                                         const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                                         size_t ws_bytes, int stages, diffsal_stream_t stream) {
   DS_REQUIRE(d && x && U && out && ws, DIFFSAL_E_ARG, "conv_wino4: null argument");
   DS_REQUIRE(wino4_shape_ok(d), DIFFSAL_E_SHAPE,
              "conv_wino4: fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2}, Cin %% 96 == 0, Cout %% 4 == 0 only");
@@ -292,7 +294,8 @@ extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* V = static_cast<float*>(ws);
   float* Mb = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
-  {
+  DS_REQUIRE(stages >= 1 && stages <= 7, DIFFSAL_E_ARG, "conv_wino4: stages=%d", stages);
+  if (stages & 1) {
     // lanes per item: wide pieces when there are plenty of items, else narrower ones (>= ~128 K lanes keep 256 CUs busy)
     const long scalars = static_cast<long>(g.n_tiles) * g.Cin;
     const int vw = scalars >= 4 * kW4Lanes ? 4 : (scalars >= 2 * kW4Lanes ? 2 : 1);
@@ -304,10 +307,14 @@ extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, co
     const int rc = check_launch("conv_wino4(input transform)");
     if (rc) return rc;
   }
-  const int r = gemm_dma_batched(V, U, Mb, g.n_tiles, g.Cin, g.Cout, 36, static_cast<long>(g.n_tiles) * g.Cin,
-                                 static_cast<long>(g.Cout) * g.Cin, static_cast<long>(g.n_tiles) * g.Cout, s);
-  if (r < 0) return r;
-  DS_REQUIRE(r == 1, DIFFSAL_E_SHAPE, "conv_wino4: the position products do not fit the batched GEMM kernel");
+  if (stages & 2) {
+    const int r = gemm_dma_batched(V, U, Mb, g.n_tiles, g.Cin, g.Cout, 36, static_cast<long>(g.n_tiles) * g.Cin,
+                                   static_cast<long>(g.Cout) * g.Cin, static_cast<long>(g.n_tiles) * g.Cout, s);
+    if (r < 0) return r;
+    DS_REQUIRE(r == 1, DIFFSAL_E_SHAPE, "conv_wino4: the position products do not fit the batched GEMM kernel");
+    if (stages == 2) return DIFFSAL_OK;          // the kernel's own name stays (diffsal_last_gemm_kernel)
+  }
+  if (!(stages & 4)) return DIFFSAL_OK;
   Wino4Out a{};
   a.M = Mb; a.out = out; a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec; a.residual = residual;
   a.act = d->act; a.rowvec_ld = d->rowvec_ld; a.g = g;
@@ -318,7 +325,14 @@ extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, co
   if (vw == 4) hipLaunchKernelGGL(wino4_output_kernel<float4>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
   else if (vw == 2) hipLaunchKernelGGL(wino4_output_kernel<float2>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(wino4_output_kernel<float>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
-  note_kernel("wino4_input_kernel + 36 x gemm_dma_kernel<float, 3, 3, 3, 2, false, false> + wino4_output_kernel [F(4x4,3x3): 36 x (M=%d K=%d N=%d)]",
-              g.n_tiles, g.Cin, g.Cout);
+  if (stages == 7)
+    note_kernel("wino4_input_kernel + 36 x gemm_dma_kernel<float, 3, 3, 3, 2, false, false> + wino4_output_kernel [F(4x4,3x3): 36 x (M=%d K=%d N=%d)]",
+                g.n_tiles, g.Cin, g.Cout);
   return check_launch("conv_wino4(output transform)");
+}
+
+extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
+                                  const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                                  size_t ws_bytes, diffsal_stream_t stream) {
+  return diffsal_conv_wino4_stages(d, x, U, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, 7, stream);
 }

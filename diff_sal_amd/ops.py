@@ -531,13 +531,24 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
         dd = dil[0]
         n_tiles = N * dd * dd * (((H + dd - 1) // dd + 3) // 4) * (((W + dd - 1) // dd + 3) // 4)
-        # FLOPs actually issued: 36 products per 4x4 tile, input and output channel (the direct form has 144)
-        with _prof(tag, 2.0 * n_tiles * 36 * Cin * Cout, _nb(x, wino4, residual, out) + 2 * 36 * n_tiles * (Cin + Cout) * 4,
-                   f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw} winograd F(4x4,3x3)" if PROFILE is not None else "") as pr:
-            _lib.check(lib.diffsal_conv_wino4(C.byref(d), _p(x), _p(wino4), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out),
-                                              _p(ws), ws_bytes, _stream()), "conv_wino4")
-            if PROFILE is not None:
-                pr.kernel = lib.diffsal_last_gemm_kernel().decode()
+        args = (C.byref(d), _p(x), _p(wino4), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out), _p(ws), ws_bytes)
+        if PROFILE is None:
+            _lib.check(lib.diffsal_conv_wino4(*args, _stream()), "conv_wino4")
+            return out
+        # profiling: the three launches bracketed one by one -- the transforms are streaming kernels (class <tag>-xf, HBM-bound),
+        # the products a launch of the GEMM kernel.  FLOPs actually issued: 36 products per 4x4 tile, input and output channel
+        # (the direct form has 144)
+        note = f"M={N * Ho * Wo} K={kh * kw * Cin} N={Cout} {kh}x{kw} winograd F(4x4,3x3)"
+        vb, mb = 36 * n_tiles * Cin * 4, 36 * n_tiles * Cout * 4
+        with _prof(tag + "-xf", 0.0, _nb(x) + vb, note + ": input transform") as pr:
+            _lib.check(lib.diffsal_conv_wino4_stages(*args, 1, _stream()), "conv_wino4")
+            pr.kernel = "wino4_input_kernel"
+        with _prof(tag, 2.0 * n_tiles * 36 * Cin * Cout, vb + mb + _nb(wino4), note + f": 36 x (M={n_tiles} K={Cin} N={Cout})") as pr:
+            _lib.check(lib.diffsal_conv_wino4_stages(*args, 2, _stream()), "conv_wino4")
+            pr.kernel = lib.diffsal_last_gemm_kernel().decode()
+        with _prof(tag + "-xf", 0.0, mb + _nb(residual, out), note + ": output transform") as pr:
+            _lib.check(lib.diffsal_conv_wino4_stages(*args, 4, _stream()), "conv_wino4")
+            pr.kernel = "wino4_output_kernel"
         return out
     if wino is not None and lib.diffsal_conv_wino_supported(C.byref(d)):
         ws_bytes = lib.diffsal_conv_wino_ws_bytes(C.byref(d))

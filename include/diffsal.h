@@ -186,6 +186,12 @@ size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wino4(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
                        const float* scale, const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
                        size_t ws_bytes, diffsal_stream_t stream);
+/* The same with the three launches selectable (stages: bit 0 input transform, bit 1 position products, bit 2 output transform +
+ * epilogue; 7 = diffsal_conv_wino4): same arguments and workspace for every call of one convolution.  For profilers that bracket
+ * operator launches (bench.py attributes the transforms to the HBM-bound classes and the products to the GEMM kernel). */
+int diffsal_conv_wino4_stages(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
+                              const float* scale, const float* shift, const float* rowvec, const float* residual, float* out,
+                              void* ws, size_t ws_bytes, int stages, diffsal_stream_t stream);
 /* Up to four independent convolutions / plain products (own descriptor, operands and output; bias + activation epilogue
  * only) in ONE launch: the four ReduceTemp products of a step (R/models/saliency_decoder/common_block.py:150-173,
  * sal_unet.py:480-487) have 336 .. 21504 rows and 3840 .. 480 columns of K, each alone fills a fraction of the chip.  fp32
