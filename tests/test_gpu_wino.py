@@ -130,3 +130,28 @@ def test_winograd_f4_conv_matches_direct_convolution(case, tuning):
     tuning.set("DIFFSAL_NO_WINOGRAD", 1)
     off = ops.conv_igemm(x.to(DEV), ops.pack_conv_weight(wd), wino=ww, **kw)
     assert torch.equal(off, direct)
+
+
+def test_winograd_f4_staged_calls_equal_the_single_call(tuning):
+    """diffsal_conv_wino4_stages (input transform / position products / output transform as separate calls: what ops does
+    under bench.py's per-launch profiler) produces the bits of diffsal_conv_wino4."""
+    from diff_sal_amd import ops
+
+    tuning.set("DIFFSAL_FORCE_WINOGRAD", 1)
+    x = rnd("wx", 4, 28, 48, 192).to(DEV)
+    w = rnd("ww", 384, 192, 3, 3, scale=0.05).to(DEV)
+    b = rnd("wb", 384, scale=0.2).to(DEV)
+    res = rnd("wq", 4, 28, 48, 384).to(DEV)
+    ww, wp = ops.WinoWeights(w), ops.pack_conv_weight(w)
+    kw = dict(kh=3, kw=3, pad=(1, 1), dil=(1, 1), bias=b, residual=res, act=ops.ACT_RELU, wino=ww)
+    one = ops.conv_igemm(x, wp, **kw)
+    ops.PROFILE = []
+    try:
+        staged = ops.conv_igemm(x, wp, tag="K4", **kw)
+        classes = [e[3] for e in ops.PROFILE]
+        kernels = [e[6] if len(e) > 6 else None for e in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert torch.equal(one, staged)
+    assert classes == ["K4-xf", "K4", "K4-xf"], classes
+    assert kernels[0] == "wino4_input_kernel" and kernels[2] == "wino4_output_kernel" and "gemm_dma_kernel" in kernels[1] and "batch 36" in kernels[1]
