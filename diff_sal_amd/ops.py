@@ -500,7 +500,9 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
     ``diffsal_conv_wino4_supported`` says so, ~1e-5 relative rounding); used instead of the direct kernel when the library's planner expects a gain
     (``diffsal_conv_wino_supported``: fp32 3x3 stride-1, padding = dilation in {1, 2}, Cin % 32 == 0, Cout >= 128, enough
     workgroups and a transformed input of at most 160 MB -- both depend on the BATCH, so the same clip can take the Winograd
-    kernel in a large pass and the direct kernel alone: results then differ by the transforms' ~1e-6 relative rounding)."""
+    kernel in a large pass and the direct kernel alone: results then differ by the transforms' rounding, ~1e-6 relative for
+    F(2x2) and ~1e-5 for F(4x4); ``SalUNet.winograd = False`` / DIFFSAL_NO_WINOGRAD=1 pin the direct kernel for callers that need
+    chunked and whole-batch evaluation to agree bit for bit)."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
