@@ -1,12 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/w4
-timeout 3000 python -m pytest tests/test_gpu_salunet.py tests/test_gpu_fullsize.py tests/test_gpu_wino.py tests/test_gpu_gemm_dma.py tests/test_gpu_ops.py -x -q > gpurun_out/w4/t_part.log 2>&1
-tail -n 5 gpurun_out/w4/t_part.log
-timeout 600 python tools/bench_wino.py 4 2>&1 | grep -v amdgpu | cut -c1-60,150-260
-for i in 1 2; do
-timeout 600 python3 bench.py --batch 4 --steps 100 --no-cpu-baseline --no-alt-precision --no-encoders --no-train-leg --no-reference-graph --dump-launches gpurun_out/w4/launches.json 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('B=4', d['config']['sampler_mode'], d['value'], d['ms_per_step'])
-for c in d['roofline'].get('classes', [])[:6]: print(c['class'], c['launches'], c['ms'])
-"
-done
+export DIFFSAL_NO_REBUILD=1
+python tools/probe_dma_stamps.py wino 36 56 96 96 96 2 2>&1 | grep -v amdgpu | tail -4
+python tools/probe_dma_stamps.py wino 4 14 24 768 768 1 2>&1 | grep -v amdgpu | tail -4
