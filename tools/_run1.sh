@@ -1,4 +1,3 @@
+# scratch: the command of the last ad-hoc GPU call (see tools/_run_all.sh, tools/gpu_prof.sh for the full suite / evidence runs)
 cd $GRAFT_REPO_ROOT
-export DIFFSAL_NO_REBUILD=1
-python tools/probe_dma_stamps.py wino 36 56 96 96 96 2 2>&1 | grep -v amdgpu | tail -4
-python tools/probe_dma_stamps.py wino 4 14 24 768 768 1 2>&1 | grep -v amdgpu | tail -4
+timeout 900 python -m pytest tests/test_gpu_wino.py tests/test_gpu_gemm_dma.py -x -q 2>&1 | tail -3
