@@ -1,3 +1,9 @@
-# scratch: the command of the last ad-hoc GPU call (see tools/_run_all.sh, tools/gpu_prof.sh for the full suite / evidence runs)
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_wino.py tests/test_gpu_gemm_dma.py -x -q 2>&1 | tail -3
+export DIFFSAL_NO_REBUILD=1
+for r in 1 2 3; do for v in A B; do
+cp diff_sal_amd/lib$v.so diff_sal_amd/libdiffsal_hip.so
+timeout 600 python3 bench.py --batch 4 --steps 100 --no-cpu-baseline --no-alt-precision --no-encoders --no-train-leg --no-reference-graph 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$v', d['value'], d['ms_per_step'], [ (c['class'], c['ms']) for c in d['roofline'].get('classes', [])[:5]])
+"
+done; done
