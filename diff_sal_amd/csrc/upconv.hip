@@ -1,0 +1,220 @@
+// conv3x3_dilation2(bilinear_up2(z)) from a 3x3 convolution at the SOURCE resolution (UpEmbed's first convolution,
+// R/models/saliency_decoder/common_block.py:196-206: nn.Upsample(x2, bilinear, align_corners=False) -> Conv2d(3x3, padding 2,
+// dilation 2, no bias) -> BatchNorm2d -> ReLU).
+//
+// A shift by 2 output pixels is a shift by 1 source pixel, so away from the border the convolution commutes with the
+// interpolation.  Exactly (per axis, n source pixels, z zero outside [0, n)):
+//
+//   I0 f (2m) = 0.75 f[m] + 0.25 f[m-1],  I0 f (2m+1) = 0.75 f[m] + 0.25 f[m+1]        interpolation WITHOUT clamping
+//   up2(z) = I0 z + D z on [0, 2n), 0 outside;   D z = 0.25 z[0] (delta_0 - delta_-1) + 0.25 z[n-1] (delta_2n-1 - delta_2n)
+//
+//   conv(up2 z)(p) = I0_y I0_x c (p)  +  sum_taps w_tap [ D_y I0_x + I0_y D_x + D_y D_x ] z (p + 2 tap)
+//
+// with c = conv3x3(z) (dilation 1, zero padding) evaluated on the grid EXTENDED by one pixel (y in [-1, h], x in [-1, w]) -- the
+// F(4x4) Winograd path computes it (csrc/wino4.hip, extended-grid form) with 4x fewer products than the nine tap mixings of
+// csrc/tapsum.hip.  The correction terms are non-zero only for outputs p in {0, 1, 2} or {2n-3, 2n-2, 2n-1} along an axis and
+// involve z only through the nine tap products T = W_tap z of the BORDER rows and columns of z (a product with ~10 % of the rows).
+// This kernel: the interpolation of c, the corrections on the border ring, BatchNorm affine + activation.  Exact up to summation
+// order (tests: 1e-5 against F.interpolate + F.conv2d).
+#include "common.h"
+
+namespace diffsal {
+
+struct UpCommuteArgs {
+  const float* c;      // [N][h + 2][w + 2][C]: conv3x3(z) on the extended grid
+  const float* tb;     // [N][2 w + 2 h - 4][9][C]: tap products of the border pixels: top row, bottom row, then the left and the
+                       // right column WITHOUT their corner pixels (rows 1 .. h - 2)
+  const float* scale;  // BatchNorm affine (may be null)
+  const float* shift;
+  float* out;          // [N][2 h][2 w][C]
+  int N, h, w, C, act;
+};
+
+// (coefficient, 0 = first / 1 = last border line) of D at high-resolution index q along an axis of n source pixels; 0 if none
+__device__ __forceinline__ float upc_dcoef(int q, int n, int& which) {
+  which = q >= n ? 1 : 0;          // q in {2n-1, 2n} -> last line
+  if (q == 0 || q == 2 * n - 1) return 0.25f;
+  if (q == -1 || q == 2 * n) return -0.25f;
+  return 0.f;
+}
+
+// the two source indices and weights of I0 at high-resolution index q (zero-extended signal of n entries: the caller masks)
+__device__ __forceinline__ void upc_i0(int q, int& m0, int& m1) {
+  const int m = q >> 1;            // floor (q may be -1)
+  m0 = m;
+  m1 = (q & 1) ? m + 1 : m - 1;
+}
+
+__device__ __forceinline__ void upc_finish(const UpCommuteArgs& p, float (&v)[4], const float4& sc, const float4& sh, float* dst) {
+  v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+  if (p.act == DIFFSAL_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  st4(dst, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+// Interior: item = (source pixel (y, x), channel quad): the 3 x 3 neighbourhood of c around it gives the 2 x 2 output pixels
+// (2y + sy, 2x + sx) (nine 16-byte loads for four outputs); outputs on the border ring are left to the ring kernel.  One
+// workgroup row = one source row of one image; 32-bit index arithmetic.
+__global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs p) {
+  const int c4n = p.C >> 2;
+  const int H2 = 2 * p.h, W2 = 2 * p.w;
+  const int row_items = p.w * c4n;
+  const int n = blockIdx.y / p.h, y = blockIdx.y - n * p.h;
+  const long crow = static_cast<long>(p.w + 2) * p.C;
+  const float* cimg = p.c + static_cast<long>(n) * (p.h + 2) * crow;
+  float* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < row_items; it += gridDim.x * 256) {
+    const int x = it / c4n, co = (it - x * c4n) * 4;
+    float4 cc[3][3];                 // c on rows y - 1 .. y + 1, columns x - 1 .. x + 1 (extended grid: + 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) cc[a][b] = ld4(cimg + (y + a) * crow + static_cast<long>(x + b) * p.C + co);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) { sc = ld4(p.scale + co); sh = ld4(p.shift + co); }
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        const int py = 2 * y + sy, px = 2 * x + sx;
+        if (py < 3 || py >= H2 - 3 || px < 3 || px >= W2 - 3) continue;
+        // I0: the near sample (weight 0.75) is the centre, the far one (0.25) the neighbour on the side of the parity
+        const int ya = sy ? 2 : 0, xa = sx ? 2 : 0;
+        const float4 a00 = cc[1][1], a01 = cc[1][xa], a10 = cc[ya][1], a11 = cc[ya][xa];
+        float v[4];
+        v[0] = 0.75f * (0.75f * a00.x + 0.25f * a01.x) + 0.25f * (0.75f * a10.x + 0.25f * a11.x);
+        v[1] = 0.75f * (0.75f * a00.y + 0.25f * a01.y) + 0.25f * (0.75f * a10.y + 0.25f * a11.y);
+        v[2] = 0.75f * (0.75f * a00.z + 0.25f * a01.z) + 0.25f * (0.75f * a10.z + 0.25f * a11.z);
+        v[3] = 0.75f * (0.75f * a00.w + 0.25f * a01.w) + 0.25f * (0.75f * a10.w + 0.25f * a11.w);
+        upc_finish(p, v, sc, sh, oimg + (static_cast<long>(py) * W2 + px) * p.C + co);
+      }
+  }
+}
+
+// Border ring: item = (ring pixel, channel quad); ring pixel r of an image: the six full rows first (0, 1, 2, H2-3, H2-2, H2-1),
+// then six columns of each remaining row.
+__global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArgs p) {
+  const int c4n = p.C >> 2;
+  const int H2 = 2 * p.h, W2 = 2 * p.w;
+  const int nb = 2 * p.w + 2 * p.h - 4;
+  const int full = H2 < 6 ? H2 : 6;                              // rows that are ring over their whole width
+  const int colw = W2 < 6 ? W2 : 6;
+  const int per_img = full * W2 + (H2 - full) * colw;
+  const long crow = static_cast<long>(p.w + 2) * p.C;
+  const int n = blockIdx.y;
+  const float* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
+  const float* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
+  float* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < per_img * c4n; it += gridDim.x * 256) {
+    const int r = it / c4n, co = (it - r * c4n) * 4;
+    int py, px;
+    if (r < full * W2) {
+      const int k = r / W2;
+      px = r - k * W2;
+      py = H2 < 6 ? k : (k < 3 ? k : H2 - 6 + k);
+    } else {
+      const int q = r - full * W2, k = q / colw, j = q - k * colw;
+      py = 3 + k;
+      px = W2 < 6 ? j : (j < 3 ? j : W2 - 6 + j);
+    }
+    int y0, y1, x0, x1;
+    upc_i0(py, y0, y1);
+    upc_i0(px, x0, x1);
+    const float4 a00 = ld4(cb + (y0 + 1) * crow + static_cast<long>(x0 + 1) * p.C + co);
+    const float4 a01 = ld4(cb + (y0 + 1) * crow + static_cast<long>(x1 + 1) * p.C + co);
+    const float4 a10 = ld4(cb + (y1 + 1) * crow + static_cast<long>(x0 + 1) * p.C + co);
+    const float4 a11 = ld4(cb + (y1 + 1) * crow + static_cast<long>(x1 + 1) * p.C + co);
+    float v[4];
+    v[0] = 0.75f * (0.75f * a00.x + 0.25f * a01.x) + 0.25f * (0.75f * a10.x + 0.25f * a11.x);
+    v[1] = 0.75f * (0.75f * a00.y + 0.25f * a01.y) + 0.25f * (0.75f * a10.y + 0.25f * a11.y);
+    v[2] = 0.75f * (0.75f * a00.z + 0.25f * a01.z) + 0.25f * (0.75f * a10.z + 0.25f * a11.z);
+    v[3] = 0.75f * (0.75f * a00.w + 0.25f * a01.w) + 0.25f * (0.75f * a10.w + 0.25f * a11.w);
+    auto tap_at = [&](int line_idx, int tap) { return ld4(tbn + (static_cast<long>(line_idx) * 9 + tap) * p.C + co); };
+    // pixel (row m, border column wx) in the list: the corners live in the row lists
+    auto col_line = [&](int wx, int m) {
+      const int xc = wx ? p.w - 1 : 0;
+      return m == 0 ? xc : (m == p.h - 1 ? p.w + xc : 2 * p.w + wx * (p.h - 2) + (m - 1));
+    };
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int qy = py + 2 * (ky - 1);
+      int wy;
+      const float cy = upc_dcoef(qy, p.h, wy);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int qx = px + 2 * (kx - 1);
+        int wx;
+        const float cx = upc_dcoef(qx, p.w, wx);
+        const int tap = ky * 3 + kx;
+        if (cy != 0.f) {          // D_y I0_x: border ROW wy (top / bottom), interpolated along x at qx
+          int m0, m1;
+          upc_i0(qx, m0, m1);
+          if (m0 >= 0 && m0 < p.w) {
+            const float4 t = tap_at(wy * p.w + m0, tap);
+            const float f = cy * 0.75f;
+            v[0] += f * t.x; v[1] += f * t.y; v[2] += f * t.z; v[3] += f * t.w;
+          }
+          if (m1 >= 0 && m1 < p.w) {
+            const float4 t = tap_at(wy * p.w + m1, tap);
+            const float f = cy * 0.25f;
+            v[0] += f * t.x; v[1] += f * t.y; v[2] += f * t.z; v[3] += f * t.w;
+          }
+        }
+        if (cx != 0.f) {          // I0_y D_x: border COLUMN wx (left / right), interpolated along y at qy
+          int m0, m1;
+          upc_i0(qy, m0, m1);
+          if (m0 >= 0 && m0 < p.h) {
+            const float4 t = tap_at(col_line(wx, m0), tap);
+            const float f = cx * 0.75f;
+            v[0] += f * t.x; v[1] += f * t.y; v[2] += f * t.z; v[3] += f * t.w;
+          }
+          if (m1 >= 0 && m1 < p.h) {
+            const float4 t = tap_at(col_line(wx, m1), tap);
+            const float f = cx * 0.25f;
+            v[0] += f * t.x; v[1] += f * t.y; v[2] += f * t.z; v[3] += f * t.w;
+          }
+        }
+        if (cy != 0.f && cx != 0.f) {   // D_y D_x: the corner pixel (row wy, column wx), taken from the row list
+          const float4 t = tap_at(wy * p.w + (wx ? p.w - 1 : 0), tap);
+          const float f = cy * cx;
+          v[0] += f * t.x; v[1] += f * t.y; v[2] += f * t.z; v[3] += f * t.w;
+        }
+      }
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) { sc = ld4(p.scale + co); sh = ld4(p.shift + co); }
+    upc_finish(p, v, sc, sh, oimg + (static_cast<long>(py) * W2 + px) * p.C + co);
+  }
+}
+
+}  // namespace diffsal
+
+using namespace diffsal;
+
+extern "C" int diffsal_up2_conv_commute(const float* c_ext, const float* tap_border, const float* scale, const float* shift, float* out,
+                                        int N, int h, int w, int C, int act, diffsal_stream_t stream) {
+  DS_REQUIRE(c_ext && tap_border && out, DIFFSAL_E_ARG, "up2_conv_commute: null argument");
+  DS_REQUIRE(N > 0 && h >= 2 && w >= 2 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "up2_conv_commute: N=%d h=%d w=%d C=%d", N, h, w, C);
+  DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "up2_conv_commute: scale and shift come together");
+  DS_REQUIRE(act == DIFFSAL_ACT_NONE || act == DIFFSAL_ACT_RELU, DIFFSAL_E_ARG, "up2_conv_commute: act=%d", act);
+  DS_REQUIRE(aligned16(c_ext) && aligned16(tap_border) && aligned16(out) && (!scale || (aligned16(scale) && aligned16(shift))),
+             DIFFSAL_E_ALIGN, "up2_conv_commute: misaligned pointer");
+  DS_REQUIRE(static_cast<long>(N) * 4 * h * w * C < (1L << 40), DIFFSAL_E_SHAPE, "up2_conv_commute: tensor too large");
+  UpCommuteArgs a{c_ext, tap_border, scale, shift, out, N, h, w, C, act};
+  DS_REQUIRE(static_cast<long>(N) * h < 65536 && static_cast<long>(w) * (C / 4) < (1L << 30), DIFFSAL_E_SHAPE, "up2_conv_commute: N * h >= 65536");
+  const int row_items = w * (C / 4);
+  int gx = (row_items + 255) / 256;
+  gx = gx > 64 ? 64 : gx;
+  hipLaunchKernelGGL(up2_conv_commute_kernel, dim3(gx, N * h), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const int rc = check_launch("up2_conv_commute(interior)");
+  if (rc) return rc;
+  const int H2 = 2 * h, W2 = 2 * w, full = H2 < 6 ? H2 : 6, colw = W2 < 6 ? W2 : 6;
+  const long ring_items = (static_cast<long>(full) * W2 + static_cast<long>(H2 - full) * colw) * (C / 4);
+  DS_REQUIRE(ring_items < (1L << 30) && N < 65536, DIFFSAL_E_SHAPE, "up2_conv_commute: ring too large");
+  int gr = static_cast<int>((ring_items + 255) / 256);
+  gr = gr > 1024 ? 1024 : gr;
+  hipLaunchKernelGGL(up2_conv_commute_ring_kernel, dim3(gr, N), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("up2_conv_commute");
+}

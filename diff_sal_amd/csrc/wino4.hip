@@ -31,6 +31,9 @@ struct Wino4Geom {
   int N, H, W, Cin, Cout, d;
   int TY, TX;          // tiles per sub-grid
   int n_tiles;         // N * d*d * TY * TX
+  // extended-grid form (d == 1, padding 2): outputs on (H + 2) x (W + 2), output (oy, ox) = the convolution centred on input
+  // (oy - 1, ox - 1) -- the convolution evaluated one pixel beyond the map on every side (diffsal_up2_conv_commute needs it)
+  int e, HO, WO;
 };
 
 __device__ __forceinline__ void wino4_tile_coords(const Wino4Geom& g, int t, int& n, int& y0, int& x0) {
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     const int q4 = static_cast<int>(it - static_cast<long>(t) * q4n);
     int n, y0, x0;
     wino4_tile_coords(g, t, n, y0, x0);
+    y0 -= g.e; x0 -= g.e;
     const float* base = x + static_cast<long>(n) * g.H * g.W * g.Cin + q4 * VW;
     VT tt[6][6];
     // columns first: tt[.][j] = B^T (column j of the 6 x 6 patch)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
   const int q4n = g.Cout / VW;
   const long items = static_cast<long>(g.n_tiles) * q4n;
   const long pos_stride = static_cast<long>(g.n_tiles) * g.Cout;
-  const long HW = static_cast<long>(g.H) * g.W;
+  const long HW = static_cast<long>(g.HO) * g.WO;
   for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
     const int t = static_cast<int>(it / q4n);
     const int co = static_cast<int>(it - static_cast<long>(t) * q4n) * VW;
@@ -199,12 +203,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
       const int oy = y0 + g.d * a;
       VT y[4];
       w4_at(s[a], y);                   // (.) A
-      if (oy >= g.H) continue;
+      if (oy >= g.HO) continue;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int ox = x0 + g.d * b;
-        if (ox >= g.W) continue;
-        const long o = (static_cast<long>(n) * HW + static_cast<long>(oy) * g.W + ox) * g.Cout + co;
+        if (ox >= g.WO) continue;
+        const long o = (static_cast<long>(n) * HW + static_cast<long>(oy) * g.WO + ox) * g.Cout + co;
         float v[VW];
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
@@ -231,8 +235,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
 namespace {
 
 bool wino4_shape_ok(const diffsal_conv_desc* d) {
-  return d && d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
-         (d->dil_h == 1 || d->dil_h == 2) && d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H && d->Wo == d->W &&
+  if (!d) return false;
+  const bool same = d->pad_t == d->dil_h && d->pad_l == d->dil_w && d->Ho == d->H && d->Wo == d->W;
+  const bool ext = d->dil_h == 1 && d->pad_t == 2 && d->pad_l == 2 && d->Ho == d->H + 2 && d->Wo == d->W + 2;
+  return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == d->dil_w &&
+         (d->dil_h == 1 || d->dil_h == 2) && (same || ext) &&
          d->Cin > 0 && d->Cin % 96 == 0 && d->Cout > 0 && d->Cout % 4 == 0 && d->N > 0 && d->H > 0 && d->W > 0 &&
          d->dtype == DIFFSAL_F32 && d->precision == DIFFSAL_PREC_FP32;
 }
@@ -240,8 +247,10 @@ bool wino4_shape_ok(const diffsal_conv_desc* d) {
 Wino4Geom wino4_geom(const diffsal_conv_desc* d) {
   Wino4Geom g{};
   g.N = d->N; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Cout = d->Cout; g.d = d->dil_h;
-  g.TY = ((g.H + g.d - 1) / g.d + 3) / 4;
-  g.TX = ((g.W + g.d - 1) / g.d + 3) / 4;
+  g.e = d->Ho == d->H + 2 ? 1 : 0;
+  g.HO = d->Ho; g.WO = d->Wo;
+  g.TY = ((g.HO + g.d - 1) / g.d + 3) / 4;
+  g.TX = ((g.WO + g.d - 1) / g.d + 3) / 4;
   g.n_tiles = g.N * g.d * g.d * g.TY * g.TX;
   return g;
 }
@@ -280,7 +289,8 @@ extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float
                                          size_t ws_bytes, int stages, diffsal_stream_t stream) {
   DS_REQUIRE(d && x && U && out && ws, DIFFSAL_E_ARG, "conv_wino4: null argument");
   DS_REQUIRE(wino4_shape_ok(d), DIFFSAL_E_SHAPE,
-             "conv_wino4: fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2}, Cin %% 96 == 0, Cout %% 4 == 0 only");
+             "conv_wino4: fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2} (or dilation 1, padding 2, output (H + 2) x "
+             "(W + 2)), Cin %% 96 == 0, Cout %% 4 == 0 only");
   DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "conv_wino4: scale and shift come together");
   const Wino4Geom g = wino4_geom(d);
   const size_t vb = wino4_v_bytes(g), mb = wino4_m_bytes(g);
@@ -289,7 +299,7 @@ extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float
                  (!scale || (aligned16(scale) && aligned16(shift))) && (!rowvec || aligned16(rowvec)) &&
                  (!residual || aligned16(residual)) && (!rowvec || d->rowvec_ld % 4 == 0),
              DIFFSAL_E_ALIGN, "conv_wino4: misaligned pointer");
-  DS_REQUIRE(static_cast<long>(d->N) * d->H * d->W * d->Cin < (1L << 31) && static_cast<long>(d->N) * d->H * d->W * d->Cout < (1L << 31),
+  DS_REQUIRE(static_cast<long>(d->N) * d->H * d->W * d->Cin < (1L << 31) && static_cast<long>(d->N) * d->Ho * d->Wo * d->Cout < (1L << 31),
              DIFFSAL_E_SHAPE, "conv_wino4: tensor too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* V = static_cast<float*>(ws);

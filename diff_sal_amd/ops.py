@@ -532,7 +532,7 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
         ws_bytes = lib.diffsal_conv_wino4_ws_bytes(C.byref(d))
         ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
         dd = dil[0]
-        n_tiles = N * dd * dd * (((H + dd - 1) // dd + 3) // 4) * (((W + dd - 1) // dd + 3) // 4)
+        n_tiles = N * dd * dd * (((Ho + dd - 1) // dd + 3) // 4) * (((Wo + dd - 1) // dd + 3) // 4)
         args = (C.byref(d), _p(x), _p(wino4), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out), _p(ws), ws_bytes)
         if PROFILE is None:
             _lib.check(lib.diffsal_conv_wino4(*args, _stream()), "conv_wino4")
@@ -573,6 +573,43 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
                                           _pa(residual, dt), _pa(out, dt), _p(ws), ws_bytes, _stream()), "conv_igemm")
         if PROFILE is not None:
             pr.kernel = lib.diffsal_last_gemm_kernel().decode()
+    return out
+
+
+_BORDER_IDX: dict = {}
+
+
+def _border_index(h: int, w: int, device) -> Tensor:
+    """Flat pixel indices (y * w + x) of the border lines of an h x w map in the order diffsal_up2_conv_commute reads them: top row,
+    bottom row, left column, right column (the columns without their corner pixels)."""
+    key = (h, w, str(device))
+    idx = _BORDER_IDX.get(key)
+    if idx is None:
+        xs, ys = torch.arange(w), torch.arange(h)
+        ys = ys[1:h - 1]                                   # the corners are in the row lists
+        idx = torch.cat([xs, (h - 1) * w + xs, ys * w, ys * w + (w - 1)]).to(device)
+        _BORDER_IDX[key] = idx
+    return idx
+
+
+def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                   act: int = ACT_NONE, tag: str = "K12") -> Tensor:
+    """act(BN(conv3x3(dilation 2, padding 2)(bilinear_up2(z)))) for z [N,h,w,Cin] fp32 -> [N,2h,2w,Cout]: the convolution runs at the
+    SOURCE resolution on the grid extended by one pixel (F(4x4) Winograd where ``wino`` qualifies, else the direct kernel), the
+    nine tap products only on the border pixels, and one kernel interpolates and corrects the 3-pixel border ring
+    (``diffsal_up2_conv_commute``, csrc/upconv.hip).  ``w_packed``: pack_conv_weight(w); ``tapw``: the [9*Cout, Cin] tap matrix (row =
+    tap * Cout + co).  Exact up to summation order."""
+    lib = _lib.load()
+    N, h, w, Cin = z.shape
+    Cout = w_packed.shape[0]
+    c_ext = conv_igemm(z, w_packed, kh=3, kw=3, pad=(2, 2), dil=(1, 1), out_hw=(h + 2, w + 2), tag=tag, wino=wino)
+    zb = z.reshape(N, h * w, Cin).index_select(1, _border_index(h, w, z.device))
+    tb = linear(zb, tapw, None, tag=tag)                                   # [N, 2w + 2h - 4, 9 * Cout]
+    out = torch.empty((N, 2 * h, 2 * w, Cout), device=z.device, dtype=z.dtype)
+    with _prof(tag + "-tap", 0.0, _nb(c_ext, tb, out), f"up2 commute {h}x{w} C={Cout}" if PROFILE is not None else "") as pr:
+        _lib.check(lib.diffsal_up2_conv_commute(_p(c_ext), _p(tb), _p(scale), _p(shift), _p(out), N, h, w, Cout, act, _stream()),
+                   "up2_conv_commute")
+        pr.kernel = "up2_conv_commute_kernel"
     return out
 
 

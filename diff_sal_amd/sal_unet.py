@@ -310,6 +310,7 @@ class SalUNet(nn.Module):
                 pe = st.patch_embed[0].proj
                 pk[f"s{i}.pe1.w"] = self._pack_conv(pe[1].weight)
                 pk[f"s{i}.pe1.tapw"] = self._tap_weight(pe[1].weight)
+                pk[f"s{i}.pe1.wino"] = self._pack_wino(pe[1].weight)
                 pk[f"s{i}.pe1.scale"], pk[f"s{i}.pe1.shift"] = self._bn_affine(pe[2])
                 pk[f"s{i}.pe2.w"] = self._pack_conv(pe[4].weight)
                 pk[f"s{i}.pe2.wino"] = self._pack_wino(pe[4].weight)
@@ -542,6 +543,7 @@ class SalUNet(nn.Module):
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
+    up_commute = True  # fp32: UpEmbed's first convolution at the source resolution where the map is >= 12 x 12 (ops.up2_conv3x3_d2)
     group_qkv = True  # fp32: query, key and value projections of a block in one grouped launch (ops.linear_group)
     merge_align = True   # the stages' audio align convolutions as one product (eval)
     group_reduce_temp = True   # fp32 tap path: the stages' ReduceTemp products in one grouped launch after the last stage
@@ -668,7 +670,13 @@ class SalUNet(nn.Module):
             if self.dilation[i] != 0:
                 Bn, T, h, w, Cp = xcur.shape
                 d = self.dilation[i]
-                if self._use_tap_conv(taps, f"s{i}") and d in (1, 2) and h >= 2 and w >= 2:
+                if (self.up_commute and d == 2 and self._use_tap_conv(taps, f"s{i}") and pk[f"s{i}.pe1.wino"] is not None
+                        and h >= 12 and w >= 12 and f"s{i}.pe1.w" in pk):
+                    # the convolution at the source resolution (F(4x4)) + interpolation + border-ring corrections: where the
+                    # interior is most of the map (stages 2 and 3 at 224 x 384)
+                    u = ops.up2_conv3x3_d2(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.w"], pk[f"s{i}.pe1.wino"], pk[f"s{i}.pe1.tapw"],
+                                           scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
+                elif self._use_tap_conv(taps, f"s{i}") and d in (1, 2) and h >= 2 and w >= 2:
                     y9 = ops.linear(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.tapw"], None, tag="K12")
                     u = ops.tapsum([y9], 2 * h, 2 * w, C, dil=d, scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"],
                                    act=ACT_RELU, tag="K12-tap")

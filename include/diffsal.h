@@ -192,6 +192,15 @@ int diffsal_conv_wino4(const diffsal_conv_desc* d /*host*/, const float* x, cons
 int diffsal_conv_wino4_stages(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
                               const float* scale, const float* shift, const float* rowvec, const float* residual, float* out,
                               void* ws, size_t ws_bytes, int stages, diffsal_stream_t stream);
+/* conv3x3(dilation 2, padding 2)(bilinear_up2(z)) -> BN affine -> activation (UpEmbed's first convolution,
+ * R/models/saliency_decoder/common_block.py:196-206) from c_ext = conv3x3(z) (dilation 1, zero padding) evaluated at the SOURCE
+ * resolution on the grid extended by one pixel on every side ([N][h + 2][w + 2][C]: diffsal_conv_wino4 / diffsal_conv_igemm with
+ * padding 2 and output (h + 2) x (w + 2)) and tap_border = the nine tap products W_tap z of the border pixels of z
+ * ([N][2 w + 2 h - 4][9][C]: top row, bottom row, left column and right column without their corners; tap = 3 ky + kx).  A shift by two output pixels is a shift by
+ * one source pixel: the result is the unclamped interpolation of c_ext plus corrections on a 3-pixel border ring (csrc/upconv.hip);
+ * exact up to summation order.  out: [N][2 h][2 w][C] fp32.  act: DIFFSAL_ACT_NONE or DIFFSAL_ACT_RELU. */
+int diffsal_up2_conv_commute(const float* c_ext, const float* tap_border, const float* scale, const float* shift, float* out,
+                             int N, int h, int w, int C, int act, diffsal_stream_t stream);
 /* Up to four independent convolutions / plain products (own descriptor, operands and output; bias + activation epilogue
  * only) in ONE launch: the four ReduceTemp products of a step (R/models/saliency_decoder/common_block.py:150-173,
  * sal_unet.py:480-487) have 336 .. 21504 rows and 3840 .. 480 columns of K, each alone fills a fraction of the chip.  fp32
