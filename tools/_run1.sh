@@ -1,11 +1,14 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/w4
-timeout 900 python -m pytest tests/test_gpu_upconv.py -x -q -s 2>&1 | grep -v amdgpu | tail -25
-timeout 3000 python -m pytest tests/test_gpu_salunet.py tests/test_gpu_fullsize.py tests/test_gpu_wino.py tests/test_gpu_sampling.py -x -q > gpurun_out/w4/t_part.log 2>&1
-tail -n 5 gpurun_out/w4/t_part.log
-for i in 1 2; do
-timeout 600 python3 bench.py --batch 4 --steps 100 --no-cpu-baseline --no-alt-precision --no-encoders --no-train-leg --no-reference-graph --dump-launches gpurun_out/w4/launches.json 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('B=4', d['config']['sampler_mode'], d['value'], d['ms_per_step'], [ (c['class'], c['launches'], c['ms']) for c in d['roofline'].get('classes', [])[:9]])
-"
-done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/w4/st -- python3 $GRAFT_REPO_ROOT/bench.py --batch 4 --steps 50 --repeats 1 --no-cpu-baseline --no-alt-precision --no-encoders --no-train-leg --no-reference-graph > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/w4/st/**/*kernel_stats.csv',recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+for r in rows[:40]:
+    n=r['Name']
+    if any(k in n for k in ('up2','index','gather','wino4','Index','copy')): print(f"{n[:100]:100s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:7.1f} us")
+PY
+rm -rf gpurun_out/w4/st
