@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 
 SIGNATURES = {
@@ -124,7 +124,7 @@ SIGNATURES = {
     "diffsal_conv_wino4_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wino4": (c_i, [C.POINTER(ConvDesc)] + [c_f] * 9 + [c_sz, c_f]),
     "diffsal_conv_wino4_stages": (c_i, [C.POINTER(ConvDesc)] + [c_f] * 9 + [c_sz, c_i, c_f]),
-    "diffsal_up2_conv_commute": (c_i, [c_f] * 5 + [c_i] * 5 + [c_f]),
+    "diffsal_up2_conv_commute": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
     "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),
     "diffsal_qkv_pool_bwd_weight_chunks": (c_i, []),

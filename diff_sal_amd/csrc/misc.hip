@@ -666,7 +666,7 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 31; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 32; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 extern "C" const char* diffsal_last_gemm_kernel(void) { return g_kernel; }
 

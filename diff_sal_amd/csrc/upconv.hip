@@ -20,13 +20,15 @@
 
 namespace diffsal {
 
+// T: storage type of c, the tap products and the output (fp32, or bf16 / f16 storage with fp32 arithmetic in between)
+template <typename T>
 struct UpCommuteArgs {
-  const float* c;      // [N][h + 2][w + 2][C]: conv3x3(z) on the extended grid
-  const float* tb;     // [N][2 w + 2 h - 4][9][C]: tap products of the border pixels: top row, bottom row, then the left and the
+  const T* c;          // [N][h + 2][w + 2][C]: conv3x3(z) on the extended grid
+  const T* tb;     // [N][2 w + 2 h - 4][9][C]: tap products of the border pixels: top row, bottom row, then the left and the
                        // right column WITHOUT their corner pixels (rows 1 .. h - 2)
   const float* scale;  // BatchNorm affine (may be null)
   const float* shift;
-  float* out;          // [N][2 h][2 w][C]
+  T* out;              // [N][2 h][2 w][C]
   int N, h, w, C, act;
 };
 
@@ -45,7 +47,8 @@ __device__ __forceinline__ void upc_i0(int q, int& m0, int& m1) {
   m1 = (q & 1) ? m + 1 : m - 1;
 }
 
-__device__ __forceinline__ void upc_finish(const UpCommuteArgs& p, float (&v)[4], const float4& sc, const float4& sh, float* dst) {
+template <typename T>
+__device__ __forceinline__ void upc_finish(const UpCommuteArgs<T>& p, float (&v)[4], const float4& sc, const float4& sh, T* dst) {
   v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
   if (p.act == DIFFSAL_ACT_RELU) {
 #pragma unroll
@@ -57,14 +60,15 @@ __device__ __forceinline__ void upc_finish(const UpCommuteArgs& p, float (&v)[4]
 // Interior: item = (source pixel (y, x), channel quad): the 3 x 3 neighbourhood of c around it gives the 2 x 2 output pixels
 // (2y + sy, 2x + sx) (nine 16-byte loads for four outputs); outputs on the border ring are left to the ring kernel.  One
 // workgroup row = one source row of one image; 32-bit index arithmetic.
-__global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs p) {
+template <typename T>
+__global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs<T> p) {
   const int c4n = p.C >> 2;
   const int H2 = 2 * p.h, W2 = 2 * p.w;
   const int row_items = p.w * c4n;
   const int n = blockIdx.y / p.h, y = blockIdx.y - n * p.h;
   const long crow = static_cast<long>(p.w + 2) * p.C;
-  const float* cimg = p.c + static_cast<long>(n) * (p.h + 2) * crow;
-  float* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
+  const T* cimg = p.c + static_cast<long>(n) * (p.h + 2) * crow;
+  T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
   for (int it = blockIdx.x * 256 + threadIdx.x; it < row_items; it += gridDim.x * 256) {
     const int x = it / c4n, co = (it - x * c4n) * 4;
     float4 cc[3][3];                 // c on rows y - 1 .. y + 1, columns x - 1 .. x + 1 (extended grid: + 1)
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs p) 
 
 // Border ring: item = (ring pixel, channel quad); ring pixel r of an image: the six full rows first (0, 1, 2, H2-3, H2-2, H2-1),
 // then six columns of each remaining row.
-__global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArgs p) {
+template <typename T>
+__global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArgs<T> p) {
   const int c4n = p.C >> 2;
   const int H2 = 2 * p.h, W2 = 2 * p.w;
   const int nb = 2 * p.w + 2 * p.h - 4;
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArg
   const int per_img = full * W2 + (H2 - full) * colw;
   const long crow = static_cast<long>(p.w + 2) * p.C;
   const int n = blockIdx.y;
-  const float* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
-  const float* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
-  float* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
+  const T* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
+  const T* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
+  T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
   for (int it = blockIdx.x * 256 + threadIdx.x; it < per_img * c4n; it += gridDim.x * 256) {
     const int r = it / c4n, co = (it - r * c4n) * 4;
     int py, px;
@@ -193,28 +198,41 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArg
 
 using namespace diffsal;
 
-extern "C" int diffsal_up2_conv_commute(const float* c_ext, const float* tap_border, const float* scale, const float* shift, float* out,
-                                        int N, int h, int w, int C, int act, diffsal_stream_t stream) {
+namespace {
+template <typename T>
+int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out, int N, int h, int w, int C,
+                  int act, hipStream_t s) {
+  UpCommuteArgs<T> a{static_cast<const T*>(c_ext), static_cast<const T*>(tap_border), scale, shift, static_cast<T*>(out), N, h, w, C, act};
+  const int row_items = w * (C / 4);
+  int gx = (row_items + 255) / 256;
+  gx = gx > 64 ? 64 : gx;
+  hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, N * h), dim3(256), 0, s, a);
+  const int rc = check_launch("up2_conv_commute(interior)");
+  if (rc) return rc;
+  const int H2 = 2 * h, W2 = 2 * w, full = H2 < 6 ? H2 : 6, colw = W2 < 6 ? W2 : 6;
+  const long ring_items = (static_cast<long>(full) * W2 + static_cast<long>(H2 - full) * colw) * (C / 4);
+  int gr = static_cast<int>((ring_items + 255) / 256);
+  gr = gr > 1024 ? 1024 : gr;
+  hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N), dim3(256), 0, s, a);
+  return check_launch("up2_conv_commute");
+}
+}  // namespace
+
+extern "C" int diffsal_up2_conv_commute(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
+                                        int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(c_ext && tap_border && out, DIFFSAL_E_ARG, "up2_conv_commute: null argument");
   DS_REQUIRE(N > 0 && h >= 2 && w >= 2 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "up2_conv_commute: N=%d h=%d w=%d C=%d", N, h, w, C);
   DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "up2_conv_commute: scale and shift come together");
   DS_REQUIRE(act == DIFFSAL_ACT_NONE || act == DIFFSAL_ACT_RELU, DIFFSAL_E_ARG, "up2_conv_commute: act=%d", act);
   DS_REQUIRE(aligned16(c_ext) && aligned16(tap_border) && aligned16(out) && (!scale || (aligned16(scale) && aligned16(shift))),
              DIFFSAL_E_ALIGN, "up2_conv_commute: misaligned pointer");
-  DS_REQUIRE(static_cast<long>(N) * 4 * h * w * C < (1L << 40), DIFFSAL_E_SHAPE, "up2_conv_commute: tensor too large");
-  UpCommuteArgs a{c_ext, tap_border, scale, shift, out, N, h, w, C, act};
-  DS_REQUIRE(static_cast<long>(N) * h < 65536 && static_cast<long>(w) * (C / 4) < (1L << 30), DIFFSAL_E_SHAPE, "up2_conv_commute: N * h >= 65536");
-  const int row_items = w * (C / 4);
-  int gx = (row_items + 255) / 256;
-  gx = gx > 64 ? 64 : gx;
-  hipLaunchKernelGGL(up2_conv_commute_kernel, dim3(gx, N * h), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  const int rc = check_launch("up2_conv_commute(interior)");
-  if (rc) return rc;
-  const int H2 = 2 * h, W2 = 2 * w, full = H2 < 6 ? H2 : 6, colw = W2 < 6 ? W2 : 6;
-  const long ring_items = (static_cast<long>(full) * W2 + static_cast<long>(H2 - full) * colw) * (C / 4);
-  DS_REQUIRE(ring_items < (1L << 30) && N < 65536, DIFFSAL_E_SHAPE, "up2_conv_commute: ring too large");
-  int gr = static_cast<int>((ring_items + 255) / 256);
-  gr = gr > 1024 ? 1024 : gr;
-  hipLaunchKernelGGL(up2_conv_commute_ring_kernel, dim3(gr, N), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  return check_launch("up2_conv_commute");
+  DS_REQUIRE(static_cast<long>(N) * h < 65536 && static_cast<long>(w) * (C / 4) < (1L << 30) && N < 65536, DIFFSAL_E_SHAPE,
+             "up2_conv_commute: N * h >= 65536");
+  const long ring_bound = (6L * 2 * w + 2L * h * 6) * (C / 4);
+  DS_REQUIRE(ring_bound < (1L << 30), DIFFSAL_E_SHAPE, "up2_conv_commute: ring too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(T) return up2_commute_t<T>(c_ext, tap_border, scale, shift, out, N, h, w, C, act, s)
+  DS_DTYPE_DISPATCH(dtype, "up2_conv_commute", CALL);
+#undef CALL
+  return DIFFSAL_OK;
 }

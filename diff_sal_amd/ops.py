@@ -594,8 +594,9 @@ def _border_index(h: int, w: int, device) -> Tensor:
 
 def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
                    act: int = ACT_NONE, tag: str = "K12") -> Tensor:
-    """act(BN(conv3x3(dilation 2, padding 2)(bilinear_up2(z)))) for z [N,h,w,Cin] fp32 -> [N,2h,2w,Cout]: the convolution runs at the
-    SOURCE resolution on the grid extended by one pixel (F(4x4) Winograd where ``wino`` qualifies, else the direct kernel), the
+    """act(BN(conv3x3(dilation 2, padding 2)(bilinear_up2(z)))) for z [N,h,w,Cin] (fp32, or bf16 / fp16 storage) -> [N,2h,2w,Cout]:
+    the convolution runs at the SOURCE resolution on the grid extended by one pixel (F(4x4) Winograd where ``wino`` qualifies -- fp32
+    only --, else the direct kernel of the storage type), the
     nine tap products only on the border pixels, and one kernel interpolates and corrects the 3-pixel border ring
     (``diffsal_up2_conv_commute``, csrc/upconv.hip).  ``w_packed``: pack_conv_weight(w); ``tapw``: the [9*Cout, Cin] tap matrix (row =
     tap * Cout + co).  Exact up to summation order."""
@@ -607,8 +608,9 @@ def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Op
     tb = linear(zb, tapw, None, tag=tag)                                   # [N, 2w + 2h - 4, 9 * Cout]
     out = torch.empty((N, 2 * h, 2 * w, Cout), device=z.device, dtype=z.dtype)
     with _prof(tag + "-tap", 0.0, _nb(c_ext, tb, out), f"up2 commute {h}x{w} C={Cout}" if PROFILE is not None else "") as pr:
-        _lib.check(lib.diffsal_up2_conv_commute(_p(c_ext), _p(tb), _p(scale), _p(shift), _p(out), N, h, w, Cout, act, _stream()),
-                   "up2_conv_commute")
+        dt = _dt(z)
+        _lib.check(lib.diffsal_up2_conv_commute(_pa(c_ext, dt), _pa(tb, dt), _p(scale), _p(shift), _pa(out, dt), N, h, w, Cout, act, dt,
+                                                _stream()), "up2_conv_commute")
         pr.kernel = "up2_conv_commute_kernel"
     return out
 

@@ -543,7 +543,8 @@ class SalUNet(nn.Module):
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
-    up_commute = True  # fp32: UpEmbed's first convolution at the source resolution where the map is >= 12 x 12 (ops.up2_conv3x3_d2)
+    up_commute = True  # UpEmbed's first convolution at the source resolution (ops.up2_conv3x3_d2): fp32 where the map is >= 12 x 12,
+    up_commute16 = True  # 16-bit storage on every stage
     group_qkv = True  # fp32: query, key and value projections of a block in one grouped launch (ops.linear_group)
     merge_align = True   # the stages' audio align convolutions as one product (eval)
     group_reduce_temp = True   # fp32 tap path: the stages' ReduceTemp products in one grouped launch after the last stage
@@ -670,10 +671,13 @@ class SalUNet(nn.Module):
             if self.dilation[i] != 0:
                 Bn, T, h, w, Cp = xcur.shape
                 d = self.dilation[i]
-                if (self.up_commute and d == 2 and self._use_tap_conv(taps, f"s{i}") and pk[f"s{i}.pe1.wino"] is not None
-                        and h >= 12 and w >= 12 and f"s{i}.pe1.w" in pk):
-                    # the convolution at the source resolution (F(4x4)) + interpolation + border-ring corrections: where the
-                    # interior is most of the map (stages 2 and 3 at 224 x 384)
+                f32c = (self._use_tap_conv(taps, f"s{i}") and self.compute_dtype == torch.float32 and pk[f"s{i}.pe1.wino"] is not None
+                        and h >= 12 and w >= 12)
+                lowc = self.compute_dtype != torch.float32 and self.up_commute16 and taps is None and h >= 2 and w >= 2
+                if self.up_commute and d == 2 and (f32c or lowc):
+                    # the convolution at the source resolution + interpolation + border-ring corrections.  fp32: F(4x4) there, and only
+                    # where the interior is most of the map (stages 2 and 3 at 224 x 384; the alternative is the tap path).  16-bit
+                    # storage: every stage (the alternative is the convolution on the up-sampled map: 4x the products)
                     u = ops.up2_conv3x3_d2(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.w"], pk[f"s{i}.pe1.wino"], pk[f"s{i}.pe1.tapw"],
                                            scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
                 elif self._use_tap_conv(taps, f"s{i}") and d in (1, 2) and h >= 2 and w >= 2:

@@ -198,9 +198,10 @@ int diffsal_conv_wino4_stages(const diffsal_conv_desc* d /*host*/, const float* 
  * padding 2 and output (h + 2) x (w + 2)) and tap_border = the nine tap products W_tap z of the border pixels of z
  * ([N][2 w + 2 h - 4][9][C]: top row, bottom row, left column and right column without their corners; tap = 3 ky + kx).  A shift by two output pixels is a shift by
  * one source pixel: the result is the unclamped interpolation of c_ext plus corrections on a 3-pixel border ring (csrc/upconv.hip);
- * exact up to summation order.  out: [N][2 h][2 w][C] fp32.  act: DIFFSAL_ACT_NONE or DIFFSAL_ACT_RELU. */
-int diffsal_up2_conv_commute(const float* c_ext, const float* tap_border, const float* scale, const float* shift, float* out,
-                             int N, int h, int w, int C, int act, diffsal_stream_t stream);
+ * exact up to summation order.  c_ext, tap_border and out ([N][2 h][2 w][C]) are in the storage type `dtype` (fp32 arithmetic in
+ * between); act: DIFFSAL_ACT_NONE or DIFFSAL_ACT_RELU. */
+int diffsal_up2_conv_commute(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
+                             int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream);
 /* Up to four independent convolutions / plain products (own descriptor, operands and output; bias + activation epilogue
  * only) in ONE launch: the four ReduceTemp products of a step (R/models/saliency_decoder/common_block.py:150-173,
  * sal_unet.py:480-487) have 336 .. 21504 rows and 3840 .. 480 columns of K, each alone fills a fraction of the chip.  fp32

@@ -62,3 +62,34 @@ def test_up2_conv_commute_matches_interpolate_then_conv(case, tuning):
     err_d = (got_d.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
     print(f"commuted, direct kernel {err_d:.2e}")
     assert err_d < 2e-5
+
+
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 7, 12, 768, 384), (4, 14, 24, 384, 192), (4, 28, 48, 192, 96)], ids=["s1", "s2", "s3"])
+def test_up2_conv_commute_16bit_storage(dname, shape, tuning):
+    """The same construction on bf16 / fp16 storage (direct 16-bit convolution on the extended grid, tap products and the result in
+    the storage type, fp32 arithmetic in the interpolation / ring kernels) against fp64 on the ROUNDED inputs, next to the path it
+    replaces there (up-sample, then the dilated convolution on the up-sampled map).  Bar: 3x the one-rounding operator bar of
+    tests/test_gpu_lowp.py (c, the tap products and the result are each rounded once)."""
+    from diff_sal_amd import ops
+
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dname]
+    bar = 3 * {"bf16": 6e-3, "fp16": 8e-4}[dname]
+    N, h, w, Cin, Cout = shape
+    z = rnd("uz", N, h, w, Cin).to(dt)
+    wt = rnd("uw", Cout, Cin, 3, 3, scale=0.05).to(dt)
+    scale = rnd("us", Cout, scale=0.1) + 1.0
+    shift = rnd("uh", Cout, scale=0.1)
+    up = F.interpolate(z.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = (F.conv2d(up, wt.double(), None, padding=2, dilation=2).permute(0, 2, 3, 1) * scale + shift).relu()
+    wd = wt.to(DEV)
+    wp = ops.cast(ops.pack_conv_weight(wd.float()), dt)
+    tapw = wd.permute(2, 3, 0, 1).reshape(9 * Cout, Cin).contiguous()
+    got = ops.up2_conv3x3_d2(z.to(DEV), wp, None, tapw, scale=scale.to(DEV), shift=shift.to(DEV), act=ops.ACT_RELU)
+    assert got.dtype == dt
+    err = (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    u = ops.resize_bilinear(z.to(DEV), 2 * h, 2 * w)
+    old = ops.conv_igemm(u, wp, kh=3, kw=3, pad=(2, 2), dil=(2, 2), scale=scale.to(DEV), shift=shift.to(DEV), act=ops.ACT_RELU)
+    err_old = (old.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"{dname}: commuted {err:.2e}  up-sample + convolution {err_old:.2e}  (bar {bar:.1e})")
+    assert err < bar
