@@ -649,6 +649,8 @@ def main():
                          "gradient exchange report) that the default line carries at every N")
     ap.add_argument("--train-leg-steps", type=int, default=10)
     ap.add_argument("--no-encoders", action="store_true", help="skip the end-to-end (encoders + 50 steps) leg")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B aid: set a SalUNet switch (fuse_resblock=0, up_commute=0, ...) on the benchmarked network; recorded in config")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 is the fastest setting measured on the 256-core box)")
@@ -687,6 +689,12 @@ def main():
         net.gemm_precision = "bf16x3" if mode == "bf16x3" else "fp32"
 
     set_precision(args.precision)
+    for kv in args.set:
+        name, _, val = kv.partition("=")
+        if not hasattr(net, name):
+            raise SystemExit(f"--set {kv}: SalUNet has no switch {name!r}")
+        cur = getattr(net, name)
+        setattr(net, name, (val not in ("0", "false", "False", "")) if isinstance(cur, bool) else type(cur)(val))
     if args.tap16 is not None:
         net.tap_conv16 = tuple(x for x in args.tap16.split(",") if x)
 
@@ -939,6 +947,7 @@ def main():
             "step": "one SalUNet evaluation + DPM-Solver update on one batch",
             "sampler_mode": args.sampler_mode + ("" if not special else " (NOT the headline configuration)"),
             "gflop_per_clip_step": 151.61 if not av else 152.73,
+            **({"switches (A/B run, NOT the shipped defaults)": list(args.set)} if args.set else {}),
         },
         "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
         "build": bid,

@@ -24,9 +24,16 @@ class ConvDesc(C.Structure):
         "dil_h", "dil_w", "act", "rowvec_ld", "w_format", "precision", "dtype")]
 
 
+class Wino4Ext(C.Structure):
+    """struct diffsal_wino4_ext (include/diffsal.h): optional extras of diffsal_conv_wino4_ex."""
+
+    _fields_ = [("in_ab", C.c_void_p), ("side_a", C.c_void_p), ("side_w", C.c_void_p), ("side_out", C.c_void_p),
+                ("out_stats", C.c_void_p), ("side_rows", C.c_longlong), ("in_swish", C.c_int), ("out_groups", C.c_int)]
+
+
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 
 SIGNATURES = {
@@ -124,6 +131,11 @@ SIGNATURES = {
     "diffsal_conv_wino4_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wino4": (c_i, [C.POINTER(ConvDesc)] + [c_f] * 9 + [c_sz, c_f]),
     "diffsal_conv_wino4_stages": (c_i, [C.POINTER(ConvDesc)] + [c_f] * 9 + [c_sz, c_i, c_f]),
+    "diffsal_conv_wino4_ex": (c_i, [C.POINTER(ConvDesc)] + [c_f] * 9 + [c_sz, C.POINTER(Wino4Ext), c_i, c_f]),
+    "diffsal_conv_wino4_stats_bytes": (c_sz, [C.POINTER(ConvDesc), c_i]),
+    "diffsal_conv_wino4_side_supported": (c_i, [C.POINTER(ConvDesc), C.c_long]),
+    "diffsal_gn_affine": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_i, c_f]),
+    "diffsal_gn_affine_wino4": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_i, c_fl, c_f, c_f]),
     "diffsal_up2_conv_commute": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
     "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),

@@ -41,7 +41,7 @@ constexpr int kWave = 64;  // CDNA wavefront
 enum TuneKey {
   TUNE_NO_PERSIST = 0, TUNE_NO_XCD_ORDER, TUNE_NO_HALO, TUNE_FORCE_HALO, TUNE_IGEMM_CFG, TUNE_IGEMM16_CFG, TUNE_PLAN_DEBUG,
   TUNE_WGRAD_CFG, TUNE_WGRAD_SPLITS, TUNE_WGRAD_VERBOSE, TUNE_NO_FUSED_BLOCK, TUNE_NO_WINOGRAD, TUNE_FORCE_WINOGRAD, TUNE_GN_CHUNKS,
-  TUNE_GN_APPLY_WGS, TUNE_GEMM_DMA, TUNE_CONV_DMA, TUNE_GROUP_GRID, TUNE_GEMM_DMA16, TUNE_WGRAD_DMA, TUNE_NO_GN_SLAB, TUNE_NO_WINOGRAD4, TUNE_COUNT
+  TUNE_GN_APPLY_WGS, TUNE_GEMM_DMA, TUNE_CONV_DMA, TUNE_GROUP_GRID, TUNE_GEMM_DMA16, TUNE_WGRAD_DMA, TUNE_NO_GN_SLAB, TUNE_NO_WINOGRAD4, TUNE_BATCH_TILE, TUNE_NO_TAPSUM_HEAD4, TUNE_COUNT
 };
 int tune(int key);
 
@@ -86,6 +86,12 @@ __device__ __forceinline__ float group_max(float v) {
 
 __device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// x sigmoid(x) on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each, five instructions instead of the ~30 of
+// libm's expf + an IEEE division): for kernels that evaluate it per LOADED element (the F(4x4) input transform reads every
+// pixel 2.25 times).  exp2 of a large positive argument overflows to +inf, rcp(+inf) = 0: the limit x -> -inf is exact.
+__device__ __forceinline__ float swishf_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp, one v_rcp, six FMAs -- a third of the
 // instructions of libm's erff; the difference is far below the fp32 noise of the surrounding GEMMs.
 __device__ __forceinline__ float erf_as(float x) {

@@ -60,6 +60,14 @@ struct DmaGemmArgs {
   // Winograd path): unit v = (batch index, tile), operands / output of problem b at a + b a_bs, w + b w_bs, out + b o_bs (elements)
   int batch;
   long a_bs, w_bs, o_bs;
+  // a second run of `batch2` problems of the SAME shape appended to the batch: operands a2 + i a2_bs, ONE weight matrix w2, output
+  // out2 + i o2_bs (a plain product whose rows are cut into batch2 pieces of M rows: the ResnetBlock's 1x1 shortcut rides in the
+  // launch of its first convolution's position products, R/models/saliency_decoder/sal_unet.py:123-142)
+  int batch2;
+  const void* a2;
+  const void* w2;
+  void* out2;
+  long a2_bs, o2_bs;
 #ifdef DIFFSAL_DEV_STAMPS
   unsigned long long* stamps;   // development build only: 32 time stamps per workgroup (diffsal_set_dma_stamps)
 #endif
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   if constexpr (GROUPED) {
     n_virtual = g.total;
   } else {
-    n_virtual = g.n_tiles * g.splits * g.batch;         // xcd_order only without split-K and batch
+    n_virtual = g.n_tiles * g.splits * (g.batch + g.batch2);         // xcd_order only without split-K and batch
     if (g.xcd_order) {
       const int x = blockIdx.x & 7;
       n_virtual = 8 * g.n_tiles_n * (g.n_tiles_m > x ? (g.n_tiles_m - x + 7) >> 3 : 0);
@@ -218,12 +226,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
       iss_lv = v;
     }
     long ib_a = 0, ib_w = 0;       // batched: element offsets of the unit's problem
+    const void* base_a = pi.a;
+    const void* base_w = pi.w;
     if constexpr (!GROUPED) {
-      if (g.batch > 1) {
+      if (g.batch + g.batch2 > 1) {
         const int per = g.n_tiles * g.splits, vv = live ? v : 0, ib = vv / per;
         iss_lv = vv - ib * per;
-        ib_a = ib * g.a_bs;
-        ib_w = ib * g.w_bs;
+        if (ib < g.batch) {
+          ib_a = ib * g.a_bs;
+          ib_w = ib * g.w_bs;
+        } else {
+          ib_a = (ib - g.batch) * g.a2_bs;
+          base_a = g.a2;
+          base_w = g.w2;
+        }
       }
     }
     const int K = pi.K;
@@ -233,13 +249,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     tile_mn(pi, iss_lv, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
     const int rows_b = live ? min(BN, pi.N - n0) : 0;
-    const unsigned long pb = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.w) + ib_w + static_cast<long>(n0) * K);
+    const unsigned long pb = reinterpret_cast<unsigned long>(static_cast<const T*>(base_w) + ib_w + static_cast<long>(n0) * K);
     rs_b = i32x4{static_cast<int>(pb), static_cast<int>(pb >> 32) & 0xFFFF, rows_b * K * ESZ, 0x00020000};
     const int kt0 = split_of(pi, iss_lv) * pi.kt_per_unit;
     iss_kofs = static_cast<unsigned>(kt0) * 128u;
     if constexpr (!CONV) {
       const int rows_a = live ? min(BM, pi.M - m0) : 0;
-      const unsigned long pa = reinterpret_cast<unsigned long>(static_cast<const T*>(pi.a) + ib_a + static_cast<long>(m0) * K);
+      const unsigned long pa = reinterpret_cast<unsigned long>(static_cast<const T*>(base_a) + ib_a + static_cast<long>(m0) * K);
       rs_a = i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * K * ESZ, 0x00020000};
     } else {
       const unsigned long pa = reinterpret_cast<unsigned long>(pi.a);
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
 
   int cmp_v = bid, cmp_lv = bid;
   long cmp_ob = 0;                 // batched: element offset of the output of the unit being multiplied
+  void* cmp_out = pc.out;          // and its base (the appended run of a batched launch writes to out2)
   // Epilogue operands (per-channel vectors, residual quads) are requested at the start of the tile's LAST pass over the ring and
   // wait in registers: requested in the epilogue they would be a dependent round trip with the matrix pipe idle, and -- vmcnt
   // retires in order -- their wait would also drain the DMA ring.
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     tile_mn(pc, cmp_lv, tmi, tni);
     const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
     const long o0 = static_cast<long>(mb) * pc.N + nb;
-    T* __restrict__ ob = static_cast<T*>(pc.out) + cmp_ob + o0;
+    T* __restrict__ ob = static_cast<T*>(cmp_out) + cmp_ob + o0;
     const float* __restrict__ rvb = pc.rowvec;
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     int tmi, tni;
     tile_mn(pc, cmp_lv, tmi, tni);
     const int mb = tmi * BM + wm * TMB * 16 + r16, nb = tni * BN + wn * TNB * 16 + 4 * q4;
-    float* __restrict__ ob = static_cast<float*>(pc.out) + cmp_ob + static_cast<long>(mb) * pc.N + nb;
+    float* __restrict__ ob = static_cast<float*>(cmp_out) + cmp_ob + static_cast<long>(mb) * pc.N + nb;
 #pragma unroll
     for (int j = 0; j < TNB; ++j)
 #pragma unroll
@@ -552,12 +569,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
       int idx;
       locate(cmp_v, idx, cmp_lv);
       pc = pick_problem(g, idx);
+      cmp_out = pc.out;
     } else {
       cmp_lv = cmp_v;
-      if (g.batch > 1) {
+      if (g.batch + g.batch2 > 1) {
         const int per = g.n_tiles * g.splits, ib = cmp_v / per;
         cmp_lv = cmp_v - ib * per;
-        cmp_ob = ib * g.o_bs;
+        if (ib < g.batch) {
+          cmp_ob = ib * g.o_bs;
+          cmp_out = g.out;
+        } else {
+          cmp_ob = (ib - g.batch) * g.o2_bs;
+          cmp_out = g.out2;
+        }
       }
     }
     const int nkt = pc.kt_per_unit;
@@ -636,12 +660,12 @@ template <typename T, int TMB, int TNB, int STAGES, int OCC>
 int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   constexpr int BM = 32 * TMB, BN = 32 * TNB;
   const int slots = 256 * OCC;
-  const int units = a.n_tiles * a.splits * a.batch;
+  const int units = a.n_tiles * a.splits * (a.batch + a.batch2);
   const int grid = units < slots ? units : slots;
 #ifdef DIFFSAL_DEV_STAMPS
   a.stamps = (g_dma_stamps && static_cast<size_t>(grid) * 32 * 8 <= g_dma_stamp_bytes) ? g_dma_stamps : nullptr;
 #endif
-  a.xcd_order = (a.splits == 1 && a.batch == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
+  a.xcd_order = (a.splits == 1 && a.batch == 1 && a.batch2 == 0 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
   if constexpr (sizeof(T) == 4) {
     if (conv) hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);
@@ -650,7 +674,7 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
   }
   note_kernel("gemm_dma_kernel<%s, %d, %d, %d, %d, %s, false> [%dx%d tile, %d stages, split-K %d, batch %d]",
               sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "__bf16" : "_Float16"), TMB, TNB, STAGES, OCC,
-              conv ? "true" : "false", BM, BN, STAGES, a.splits, a.batch);
+              conv ? "true" : "false", BM, BN, STAGES, a.splits, a.batch + a.batch2);
   int rc = check_launch("diffsal_conv_igemm(dma)");
   if (rc || a.splits == 1) return rc;
   long g = (static_cast<long>(a.M) * (a.N / 4) + 255) / 256;
@@ -660,8 +684,8 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
 }
 
 struct DmaCfg { int bm, bn, stages; };
-constexpr int kNumDmaCfgs = 2;
-const DmaCfg kDmaCfgs[kNumDmaCfgs] = {{96, 96, 3}, {96, 96, 6}};
+constexpr int kNumDmaCfgs = 2;                 // selectable through DIFFSAL_GEMM_DMA; entry 2: the wide tile of batched launches
+const DmaCfg kDmaCfgs[kNumDmaCfgs + 1] = {{96, 96, 3}, {96, 96, 6}, {96, 128, 3}};
 
 // fills the problem-independent part of the arguments; false: shape not handled by tile configuration c.  esz: bytes per
 // element of the storage type (a K slice is 128 bytes of a row)
@@ -746,18 +770,39 @@ int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* 
 // `batch` plain fp32 products of one shape in ONE launch of the 96 x 96 / 3-stage kernel, no epilogue: out_b [M, N] = a_b [M, K] x
 // w_b [N, K]^T with the operands of problem b at a + b a_bs, w + b w_bs, out + b o_bs (elements).  Returns 1 if launched, 0 if the
 // shape is not handled (K % 96 != 0, N % 4 != 0, misaligned), < 0 on error.
+// side_rows > 0: the plain product side_out [side_rows, N] = side_a [side_rows, K] x side_w [N, K]^T shares the launch as
+// side_rows / M further problems of the same shape (side_rows % M == 0, else 0 is returned and nothing is launched).
 int gemm_dma_batched(const float* a, const float* w, float* out, long M, int K, int N, int batch, long a_bs, long w_bs, long o_bs,
-                     hipStream_t s) {
+                     hipStream_t s, const float* side_a, const float* side_w, float* side_out, long side_rows) {
   diffsal_conv_desc d{};
   d.N = 1; d.H = 1; d.W = static_cast<int>(M); d.Ho = 1; d.Wo = static_cast<int>(M); d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1;
   d.stride_h = d.stride_w = d.dil_h = d.dil_w = 1;
   d.dtype = DIFFSAL_F32;
   if (M <= 0 || M >= (1L << 31) || batch < 1 || a_bs % 4 != 0 || w_bs % 4 != 0 || o_bs % 4 != 0) return 0;
+  const long nb2 = side_rows > 0 ? side_rows / M : 0;
+  if (side_rows > 0 && (side_rows % M != 0 || !side_a || !side_w || !side_out || !aligned16(side_a) || !aligned16(side_w) ||
+                        !aligned16(side_out) || nb2 > 4096))
+    return 0;
+  // Tile shape.  96 x 96 at two workgroups per CU is the default; 96 x 128 at one per CU (a third fewer, a third longer units)
+  // where that shortens the busiest CU's share: the launch's units spread over 256 CUs in whole units, so 288 units of 96 x 96
+  // (36 positions x 8 tiles of N = 768) put two on 32 CUs while 216 units of 96 x 128 are one round.  Cost in K slices of a
+  // 96 x 96 unit on one CU; the wider tile is taken when it wins by 10 % (it has no co-resident workgroup to cover its
+  // epilogues).  DIFFSAL_BATCH_TILE = 0 / 1 forces 96 x 96 / 96 x 128 (shape permitting).
+  const long tm = (M + 95) / 96, nbt = batch + nb2;
+  const long u96 = tm * ((N + 95) / 96) * nbt, u128 = tm * ((N + 127) / 128) * nbt;
+  const double t96 = static_cast<double>((u96 + 255) / 256), t128 = static_cast<double>((u128 + 255) / 256) * (4.0 / 3.0);
+  const int force = tune(TUNE_BATCH_TILE);
+  const bool wide = N % 128 == 0 && (force == 1 || (force != 0 && t128 * 1.1 < t96));
   DmaGemmArgs g;
-  if (!dma_fill(g, kDmaCfgs[0], &d, false, 4, a, w, nullptr, nullptr, nullptr, nullptr, 0, nullptr, out)) return 0;
+  if (!dma_fill(g, kDmaCfgs[wide ? 2 : 0], &d, false, 4, a, w, nullptr, nullptr, nullptr, nullptr, 0, nullptr, out)) return 0;
   g.batch = batch; g.a_bs = a_bs; g.w_bs = w_bs; g.o_bs = o_bs;
-  if (static_cast<long>(g.n_tiles) * batch >= (1L << 30)) return 0;
-  const int rc = launch_dma<float, 3, 3, 3, 2>(g, false, s);
+  if (side_rows > 0) {
+    g.batch2 = static_cast<int>(nb2);
+    g.a2 = side_a; g.w2 = side_w; g.out2 = side_out;
+    g.a2_bs = M * K; g.o2_bs = M * N;
+  }
+  if (static_cast<long>(g.n_tiles) * (batch + g.batch2) >= (1L << 30)) return 0;
+  const int rc = wide ? launch_dma<float, 3, 4, 3, 1>(g, false, s) : launch_dma<float, 3, 3, 3, 2>(g, false, s);
   return rc == DIFFSAL_OK ? 1 : rc;
 }
 

@@ -724,6 +724,60 @@ extern "C" int diffsal_groupnorm_swish(const void* x, const float* gamma, const 
   return DIFFSAL_OK;
 }
 
+// GroupNorm statistics -> affine form ab [B][2][C] (scale row, shift row): same chunk sums and fp64 finish as gn_apply_kernel's
+// prologue, one workgroup per image.
+namespace diffsal {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ ab, int HW, int C,
+                                                          int groups, float eps, int GN_CHUNKS) {
+  // grid (B, ceil(groups / 4)): a wavefront per group, lane k takes chunks k, k + 64, ...: one round trip to memory
+  const int b = blockIdx.x, g = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= groups) return;
+  const int cpg = C / groups;
+  double s = 0, q = 0;
+  for (int k = lane; k < GN_CHUNKS; k += 64) {
+    const double* o = ws + ((static_cast<long>(b) * GN_CHUNKS + k) * groups + g) * 2;
+    s += o[0]; q += o[1];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  const double n = static_cast<double>(HW) * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  var = var < 0 ? 0 : var;
+  const float mf = static_cast<float>(mean), rf = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    const float sc = rf * gamma[c];
+    ab[static_cast<long>(b) * 2 * C + c] = sc;
+    ab[static_cast<long>(b) * 2 * C + C + c] = beta[c] - mf * sc;
+  }
+}
+}  // namespace diffsal
+
+extern "C" int diffsal_gn_affine(const void* x, const float* gamma, const float* beta, float* ab, int B, int HW, int C, int groups,
+                                 float eps, void* ws, size_t ws_bytes, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(x && gamma && beta && ab && ws, DIFFSAL_E_ARG, "gn_affine: null argument");
+  DS_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 1024, DIFFSAL_E_SHAPE,
+             "gn_affine: bad shape B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
+  DS_REQUIRE(ws_bytes >= diffsal_groupnorm_ws_bytes(B, groups), DIFFSAL_E_ARG, "gn_affine: workspace too small");
+  DS_REQUIRE(aligned16(x) && aligned16(ab) && aligned16(ws), DIFFSAL_E_ALIGN, "gn_affine: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int chunks = gn_chunks();
+#define CALL(T)                                                                                                                  \
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(chunks, B), dim3(256), 2 * C * sizeof(double), s, static_cast<const T*>(x),       \
+                     static_cast<double*>(ws), HW, C, groups)
+  DS_DTYPE_DISPATCH(dtype, "gn_affine", CALL);
+#undef CALL
+  int rc = check_launch("gn_affine(stats)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, (groups + 3) / 4), dim3(256), 0, s, static_cast<const double*>(ws), gamma, beta,
+                     ab, HW, C, groups, eps, chunks);
+  return check_launch("gn_affine(finish)");
+}
+
 // GroupNorm with the activation optional: act = 0 plain affine GroupNorm (AttnBlock.norm of the legacy UNet,
 // R/models/diffusion_decoder/diffusion.py:145,173), act = 1 the K3 form above.
 extern "C" int diffsal_groupnorm(const void* x, const float* gamma, const float* beta, void* out, int B, int HW, int C,

@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs<T> 
   const int c4n = p.C >> 2;
   const int H2 = 2 * p.h, W2 = 2 * p.w;
   const int row_items = p.w * c4n;
-  const int n = blockIdx.y / p.h, y = blockIdx.y - n * p.h;
   const long crow = static_cast<long>(p.w + 2) * p.C;
+  // rows (image, source row) in a grid-stride loop: N * h may exceed the 65535 workgroups of grid dimension y
+  for (long row = blockIdx.y; row < static_cast<long>(p.N) * p.h; row += gridDim.y) {
+  const int n = static_cast<int>(row / p.h), y = static_cast<int>(row - static_cast<long>(n) * p.h);
   const T* cimg = p.c + static_cast<long>(n) * (p.h + 2) * crow;
   T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
   for (int it = blockIdx.x * 256 + threadIdx.x; it < row_items; it += gridDim.x * 256) {
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs<T> 
         upc_finish(p, v, sc, sh, oimg + (static_cast<long>(py) * W2 + px) * p.C + co);
       }
   }
+  }
 }
 
 // Border ring: item = (ring pixel, channel quad); ring pixel r of an image: the six full rows first (0, 1, 2, H2-3, H2-2, H2-1),
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArg
   const int colw = W2 < 6 ? W2 : 6;
   const int per_img = full * W2 + (H2 - full) * colw;
   const long crow = static_cast<long>(p.w + 2) * p.C;
-  const int n = blockIdx.y;
+  for (int n = blockIdx.y; n < p.N; n += gridDim.y) {
   const T* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
   const T* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
   T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArg
     if (p.scale) { sc = ld4(p.scale + co); sh = ld4(p.shift + co); }
     upc_finish(p, v, sc, sh, oimg + (static_cast<long>(py) * W2 + px) * p.C + co);
   }
+  }
 }
 
 }  // namespace diffsal
@@ -206,14 +210,15 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
   const int row_items = w * (C / 4);
   int gx = (row_items + 255) / 256;
   gx = gx > 64 ? 64 : gx;
-  hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, N * h), dim3(256), 0, s, a);
+  const long rows = static_cast<long>(N) * h;
+  hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
   const int rc = check_launch("up2_conv_commute(interior)");
   if (rc) return rc;
   const int H2 = 2 * h, W2 = 2 * w, full = H2 < 6 ? H2 : 6, colw = W2 < 6 ? W2 : 6;
   const long ring_items = (static_cast<long>(full) * W2 + static_cast<long>(H2 - full) * colw) * (C / 4);
   int gr = static_cast<int>((ring_items + 255) / 256);
   gr = gr > 1024 ? 1024 : gr;
-  hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N < 65535 ? N : 65535), dim3(256), 0, s, a);
   return check_launch("up2_conv_commute");
 }
 }  // namespace
@@ -226,8 +231,8 @@ extern "C" int diffsal_up2_conv_commute(const void* c_ext, const void* tap_borde
   DS_REQUIRE(act == DIFFSAL_ACT_NONE || act == DIFFSAL_ACT_RELU, DIFFSAL_E_ARG, "up2_conv_commute: act=%d", act);
   DS_REQUIRE(aligned16(c_ext) && aligned16(tap_border) && aligned16(out) && (!scale || (aligned16(scale) && aligned16(shift))),
              DIFFSAL_E_ALIGN, "up2_conv_commute: misaligned pointer");
-  DS_REQUIRE(static_cast<long>(N) * h < 65536 && static_cast<long>(w) * (C / 4) < (1L << 30) && N < 65536, DIFFSAL_E_SHAPE,
-             "up2_conv_commute: N * h >= 65536");
+  DS_REQUIRE(static_cast<long>(w) * (C / 4) < (1L << 30) && static_cast<long>(N) * h < (1L << 31), DIFFSAL_E_SHAPE,
+             "up2_conv_commute: row too long");
   const long ring_bound = (6L * 2 * w + 2L * h * 6) * (C / 4);
   DS_REQUIRE(ring_bound < (1L << 30), DIFFSAL_E_SHAPE, "up2_conv_commute: ring too large");
   hipStream_t s = static_cast<hipStream_t>(stream);

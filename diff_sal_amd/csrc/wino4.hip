@@ -25,7 +25,7 @@
 namespace diffsal {
 
 int gemm_dma_batched(const float* a, const float* w, float* out, long M, int K, int N, int batch, long a_bs, long w_bs, long o_bs,
-                     hipStream_t s);
+                     hipStream_t s, const float* side_a, const float* side_w, float* side_out, long side_rows);
 
 struct Wino4Geom {
   int N, H, W, Cin, Cout, d;
@@ -90,8 +90,26 @@ __device__ __forceinline__ void w4_bt(const VT (&d)[6], VT (&t)[6]) {
 // 1. input transform.  item = (tile, channel quad), quads fastest: a wave reads 16-byte pieces of consecutive channels of one
 //    pixel (128-byte runs and longer) and writes, per position, consecutive channels of consecutive tiles (fully coalesced).
 // ------------------------------------------------------------------------------------------------------------------------
-template <typename VT>
-__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, Wino4Geom g) {
+// y = a x + b per channel, then (swish) y sigmoid(y): GroupNorm's affine form + the ResnetBlock's nonlinearity applied as the
+// transform loads its input (R/models/saliency_decoder/sal_unet.py:36-44, 125, 133)
+__device__ __forceinline__ float w4_gn1(float x, float a, float b, int swish) {
+  const float y = fmaf(a, x, b);
+  return swish ? swishf_fast(y) : y;
+}
+__device__ __forceinline__ float4 w4_gn(float4 x, float4 a, float4 b, int sw) {
+  return make_float4(w4_gn1(x.x, a.x, b.x, sw), w4_gn1(x.y, a.y, b.y, sw), w4_gn1(x.z, a.z, b.z, sw), w4_gn1(x.w, a.w, b.w, sw));
+}
+__device__ __forceinline__ float2 w4_gn(float2 x, float2 a, float2 b, int sw) {
+  return make_float2(w4_gn1(x.x, a.x, b.x, sw), w4_gn1(x.y, a.y, b.y, sw));
+}
+__device__ __forceinline__ float w4_gn(float x, float a, float b, int sw) { return w4_gn1(x, a, b, sw); }
+
+// GN: the input is read through a per-(image, channel) affine map ab [N][2][Cin] (scale row, shift row: diffsal_gn_affine) and
+// an optional swish -- GroupNorm + nonlinearity without a normalised tensor in memory; the convolution's zero padding applies
+// to the NORMALISED map, so taps outside the image stay exactly zero.
+template <typename VT, bool GN>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, Wino4Geom g,
+                                                          const float* __restrict__ ab, int swish) {
   constexpr int VW = sizeof(VT) / 4;
   const int q4n = g.Cin / VW;
   const long items = static_cast<long>(g.n_tiles) * q4n;
@@ -103,6 +121,11 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     wino4_tile_coords(g, t, n, y0, x0);
     y0 -= g.e; x0 -= g.e;
     const float* base = x + static_cast<long>(n) * g.H * g.W * g.Cin + q4 * VW;
+    VT ga = w4_zero<VT>(), gb = w4_zero<VT>();
+    if constexpr (GN) {
+      ga = w4_ld<VT>(ab + static_cast<long>(n) * 2 * g.Cin + q4 * VW);
+      gb = w4_ld<VT>(ab + static_cast<long>(n) * 2 * g.Cin + g.Cin + q4 * VW);
+    }
     VT tt[6][6];
     // columns first: tt[.][j] = B^T (column j of the 6 x 6 patch)
 #pragma unroll
@@ -114,7 +137,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       for (int i = 0; i < 6; ++i) {
         const int y = y0 + g.d * (i - 1);
         const bool v = vx && y >= 0 && y < g.H;
-        const VT r = w4_ld<VT>(base + (v ? (static_cast<long>(y) * g.W + xx) : 0) * g.Cin);
+        VT r = w4_ld<VT>(base + (v ? (static_cast<long>(y) * g.W + xx) : 0) * g.Cin);
+        if constexpr (GN) r = w4_gn(r, ga, gb, swish);
         dd[i] = v ? r : w4_zero<VT>();
       }
       VT c[6];
@@ -146,6 +170,12 @@ struct Wino4Out {
   const float* residual;
   int act, rowvec_ld;
   Wino4Geom g;
+  // STATS: per-(image, group) sum and sum of squares of the RESULT (after the epilogue) for the GroupNorm that follows
+  // (ResnetBlock.norm2 on conv1's output, sal_unet.py:131-133): every workgroup leaves the sums of its 256 items in
+  // stats[blockIdx.x][2 images][groups][2] (fp64; the items of a workgroup touch at most two images), diffsal_gn_affine_wino4
+  // adds them up in a fixed order
+  double* stats;
+  int groups, tiles_per_img;
 };
 
 __device__ __forceinline__ float w4_act(float x, int act) {
@@ -165,7 +195,8 @@ __device__ __forceinline__ void w4_at(const VT (&m)[6], VT (&y)[4]) {
   y[3] = w4_add(w4_fma(8.f, d34, d12), m[5]);
 }
 
-template <typename VT>
+constexpr int kW4StatGroups = 64;
+template <typename VT, bool STATS>
 __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
   constexpr int VW = sizeof(VT) / 4;
   const Wino4Geom& g = p.g;
@@ -173,6 +204,13 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
   const long items = static_cast<long>(g.n_tiles) * q4n;
   const long pos_stride = static_cast<long>(g.n_tiles) * g.Cout;
   const long HW = static_cast<long>(g.HO) * g.WO;
+  __shared__ double st_sh[STATS ? 2 * kW4StatGroups * 2 : 1];
+  int n_first = 0;
+  if constexpr (STATS) {          // one pass per workgroup (grid = ceil(items / 256)): its statistics slot is blockIdx.x
+    for (int i = threadIdx.x; i < 2 * kW4StatGroups * 2; i += 256) st_sh[i] = 0.0;
+    __syncthreads();
+    n_first = static_cast<int>((static_cast<long>(blockIdx.x) * 256) / q4n) / p.tiles_per_img;
+  }
   for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
     const int t = static_cast<int>(it / q4n);
     const int co = static_cast<int>(it - static_cast<long>(t) * q4n) * VW;
@@ -191,6 +229,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
       for (int a = 0; a < 4; ++a) s[a][j] = y[a];
     }
     float bb[VW], ss[VW], hh[VW], rr[VW];
+    float ssum[VW], ssq[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
       bb[e] = p.bias ? p.bias[co + e] : 0.f;
@@ -222,6 +263,10 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
 #pragma unroll
           for (int e = 0; e < VW; ++e) v[e] += w4_get<VT>(rs, e);
         }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) { ssum[e] += v[e]; ssq[e] = fmaf(v[e], v[e], ssq[e]); }
+        }
         VT ov;
         if constexpr (VW == 4) ov = make_float4(v[0], v[1], v[2], v[3]);
         else if constexpr (VW == 2) ov = make_float2(v[0], v[1]);
@@ -229,6 +274,57 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
         w4_st<VT>(p.out + o, ov);
       }
     }
+    if constexpr (STATS) {
+      const int cpg = g.Cout / p.groups;
+      double* slot = st_sh + (n - n_first) * (kW4StatGroups * 2);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        const int grp = (co + e) / cpg;
+        atomicAdd(slot + grp * 2, static_cast<double>(ssum[e]));
+        atomicAdd(slot + grp * 2 + 1, static_cast<double>(ssq[e]));
+      }
+    }
+  }
+  if constexpr (STATS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * p.groups * 2; i += 256) {
+      const int img = i / (p.groups * 2), r = i - img * (p.groups * 2);
+      p.stats[(static_cast<long>(blockIdx.x) * 2 + img) * (p.groups * 2) + r] = st_sh[img * (kW4StatGroups * 2) + r];
+    }
+  }
+}
+
+// ab [N][2][C] from the workgroup sums wino4_output_kernel<.., true> left: the workgroups whose 256 items touch image n are
+// w in [n ipi / 256, ((n + 1) ipi - 1) / 256] (ipi = items per image), slot = n - (first image of w).  One workgroup per image;
+// 8 lanes per group take every 8th partial, combined in a fixed order, fp64 mean / variance (E[x^2] - mean^2, as gn_apply_kernel).
+__global__ __launch_bounds__(256) void wino4_gn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ ab, int C,
+                                                                int groups, long ipi, int q4n, int tiles_per_img, double count, float eps) {
+  // grid (N, ceil(groups / 4)): a wavefront per group, its 64 lanes take every 64th workgroup sum (one round trip instead of a
+  // chain of dependent ones), butterfly in a fixed order
+  const int n = blockIdx.x, grp = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (grp >= groups) return;
+  const long w_lo = (n * ipi) / 256, w_hi = ((n + 1) * ipi - 1) / 256;
+  double s = 0, q = 0;
+  for (long w = w_lo + lane; w <= w_hi; w += 64) {
+    const int nf = static_cast<int>((w * 256) / q4n) / tiles_per_img;
+    const double* o = stats + ((w * 2 + (n - nf)) * groups + grp) * 2;
+    s += o[0]; q += o[1];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  var = var < 0 ? 0 : var;
+  const float mf = static_cast<float>(mean), rf = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  const int cpg = C / groups;
+  for (int c = grp * cpg + lane; c < (grp + 1) * cpg; c += 64) {
+    const float sc = rf * gamma[c];
+    ab[static_cast<long>(n) * 2 * C + c] = sc;
+    ab[static_cast<long>(n) * 2 * C + C + c] = beta[c] - mf * sc;
   }
 }
 
@@ -281,12 +377,48 @@ extern "C" size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d) {
   return wino4_v_bytes(g) + wino4_m_bytes(g);
 }
 
+
+namespace {
+// channels per lane of the transform kernels for `scalars` = tiles x channels: wide pieces when there are plenty of items, else
+// narrower ones (>= ~128 K lanes keep 256 CUs busy)
+int wino4_vw(long scalars) { return scalars >= 4 * kW4Lanes ? 4 : (scalars >= 2 * kW4Lanes ? 2 : 1); }
+
+// statistics of the output: a workgroup's 256 items must touch at most two images
+bool wino4_stats_ok(const Wino4Geom& g, int groups) {
+  if (groups <= 0 || groups > kW4StatGroups || g.Cout % groups != 0 || g.e != 0) return false;
+  const int vw = wino4_vw(static_cast<long>(g.n_tiles) * g.Cout);
+  const long ipi = static_cast<long>(g.n_tiles / g.N) * (g.Cout / vw);
+  return ipi >= 256;
+}
+long wino4_out_wgs(const Wino4Geom& g) {
+  const int vw = wino4_vw(static_cast<long>(g.n_tiles) * g.Cout);
+  return (static_cast<long>(g.n_tiles) * (g.Cout / vw) + 255) / 256;
+}
+}  // namespace
+
+/* bytes of the `out_stats` buffer of diffsal_conv_wino4_ex for this convolution and group count; 0: not available for the shape */
+extern "C" size_t diffsal_conv_wino4_stats_bytes(const diffsal_conv_desc* d, int groups) {
+  if (!wino4_shape_ok(d)) return 0;
+  const Wino4Geom g = wino4_geom(d);
+  if (!wino4_stats_ok(g, groups)) return 0;
+  return static_cast<size_t>(wino4_out_wgs(g)) * 2 * groups * 2 * sizeof(double);
+}
+
+/* 1 if a plain product with `side_rows` rows can share the launch of this convolution's position products */
+extern "C" int diffsal_conv_wino4_side_supported(const diffsal_conv_desc* d, long side_rows) {
+  if (!wino4_shape_ok(d) || side_rows <= 0) return 0;
+  const Wino4Geom g = wino4_geom(d);
+  return (side_rows % g.n_tiles == 0 && side_rows / g.n_tiles <= 4096) ? 1 : 0;
+}
+
 // U: the transformed weight G g G^T as [36][Cout][Cin] fp32 (ops.pack_wino4_weight).  stages: bit 0 input transform, bit 1 the
 // position products, bit 2 output transform + epilogue -- the three launches of the path, callable one by one (same arguments,
-// same workspace) so that a profiler can bracket each: diffsal_conv_wino4 is stages = 7.
-extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
-                                         const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
-                                         size_t ws_bytes, int stages, diffsal_stream_t stream) {
+// same workspace) so that a profiler can bracket each: diffsal_conv_wino4 is stages = 7.  ext (may be NULL): GroupNorm affine +
+// swish applied to the input as it is transformed, a plain product riding in the launch of the position products, statistics
+// of the result for the next GroupNorm (include/diffsal.h).
+extern "C" int diffsal_conv_wino4_ex(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
+                                     const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                                     size_t ws_bytes, const diffsal_wino4_ext* ext, int stages, diffsal_stream_t stream) {
   DS_REQUIRE(d && x && U && out && ws, DIFFSAL_E_ARG, "conv_wino4: null argument");
   DS_REQUIRE(wino4_shape_ok(d), DIFFSAL_E_SHAPE,
              "conv_wino4: fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2} (or dilation 1, padding 2, output (H + 2) x "
@@ -301,25 +433,39 @@ extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float
              DIFFSAL_E_ALIGN, "conv_wino4: misaligned pointer");
   DS_REQUIRE(static_cast<long>(d->N) * d->H * d->W * d->Cin < (1L << 31) && static_cast<long>(d->N) * d->Ho * d->Wo * d->Cout < (1L << 31),
              DIFFSAL_E_SHAPE, "conv_wino4: tensor too large");
+  diffsal_wino4_ext e{};
+  if (ext) e = *ext;
+  DS_REQUIRE(!e.in_ab || aligned16(e.in_ab), DIFFSAL_E_ALIGN, "conv_wino4: misaligned in_ab");
+  DS_REQUIRE(e.side_rows == 0 || (e.side_a && e.side_w && e.side_out && diffsal_conv_wino4_side_supported(d, e.side_rows)), DIFFSAL_E_ARG,
+             "conv_wino4: side product of %lld rows does not fit (rows must be a multiple of the %d tiles)", e.side_rows, g.n_tiles);
+  DS_REQUIRE(!e.out_stats || (wino4_stats_ok(g, e.out_groups) && aligned16(e.out_stats)), DIFFSAL_E_ARG,
+             "conv_wino4: output statistics not available for this shape (groups=%d)", e.out_groups);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* V = static_cast<float*>(ws);
   float* Mb = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
   DS_REQUIRE(stages >= 1 && stages <= 7, DIFFSAL_E_ARG, "conv_wino4: stages=%d", stages);
   if (stages & 1) {
-    // lanes per item: wide pieces when there are plenty of items, else narrower ones (>= ~128 K lanes keep 256 CUs busy)
     const long scalars = static_cast<long>(g.n_tiles) * g.Cin;
-    const int vw = scalars >= 4 * kW4Lanes ? 4 : (scalars >= 2 * kW4Lanes ? 2 : 1);
+    const int vw = wino4_vw(scalars);
     long gi = (scalars / vw + 255) / 256;
     gi = gi > 16384 ? 16384 : gi;
-    if (vw == 4) hipLaunchKernelGGL(wino4_input_kernel<float4>, dim3(static_cast<unsigned>(gi)), dim3(256), 0, s, x, V, g);
-    else if (vw == 2) hipLaunchKernelGGL(wino4_input_kernel<float2>, dim3(static_cast<unsigned>(gi)), dim3(256), 0, s, x, V, g);
-    else hipLaunchKernelGGL(wino4_input_kernel<float>, dim3(static_cast<unsigned>(gi)), dim3(256), 0, s, x, V, g);
+    const dim3 gd(static_cast<unsigned>(gi));
+#define W4_IN(VT)                                                                                                   \
+  do {                                                                                                              \
+    if (e.in_ab) hipLaunchKernelGGL((wino4_input_kernel<VT, true>), gd, dim3(256), 0, s, x, V, g, e.in_ab, e.in_swish); \
+    else hipLaunchKernelGGL((wino4_input_kernel<VT, false>), gd, dim3(256), 0, s, x, V, g, nullptr, 0);             \
+  } while (0)
+    if (vw == 4) W4_IN(float4);
+    else if (vw == 2) W4_IN(float2);
+    else W4_IN(float);
+#undef W4_IN
     const int rc = check_launch("conv_wino4(input transform)");
     if (rc) return rc;
   }
   if (stages & 2) {
     const int r = gemm_dma_batched(V, U, Mb, g.n_tiles, g.Cin, g.Cout, 36, static_cast<long>(g.n_tiles) * g.Cin,
-                                   static_cast<long>(g.Cout) * g.Cin, static_cast<long>(g.n_tiles) * g.Cout, s);
+                                   static_cast<long>(g.Cout) * g.Cin, static_cast<long>(g.n_tiles) * g.Cout, s, e.side_a, e.side_w,
+                                   e.side_out, e.side_rows);
     if (r < 0) return r;
     DS_REQUIRE(r == 1, DIFFSAL_E_SHAPE, "conv_wino4: the position products do not fit the batched GEMM kernel");
     if (stages == 2) return DIFFSAL_OK;          // the kernel's own name stays (diffsal_last_gemm_kernel)
@@ -328,21 +474,51 @@ extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float
   Wino4Out a{};
   a.M = Mb; a.out = out; a.bias = bias; a.scale = scale; a.shift = shift; a.rowvec = rowvec; a.residual = residual;
   a.act = d->act; a.rowvec_ld = d->rowvec_ld; a.g = g;
+  a.stats = e.out_stats; a.groups = e.out_groups; a.tiles_per_img = g.n_tiles / g.N;
   const long scalars = static_cast<long>(g.n_tiles) * g.Cout;
-  const int vw = scalars >= 4 * kW4Lanes ? 4 : (scalars >= 2 * kW4Lanes ? 2 : 1);
+  const int vw = wino4_vw(scalars);
   long go = (scalars / vw + 255) / 256;
-  go = go > 16384 ? 16384 : go;
-  if (vw == 4) hipLaunchKernelGGL(wino4_output_kernel<float4>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
-  else if (vw == 2) hipLaunchKernelGGL(wino4_output_kernel<float2>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(wino4_output_kernel<float>, dim3(static_cast<unsigned>(go)), dim3(256), 0, s, a);
+  if (!a.stats) go = go > 16384 ? 16384 : go;    // with statistics: one pass per workgroup, its slot is blockIdx.x
+  const dim3 gd(static_cast<unsigned>(go));
+#define W4_OUT(VT)                                                                                   \
+  do {                                                                                               \
+    if (a.stats) hipLaunchKernelGGL((wino4_output_kernel<VT, true>), gd, dim3(256), 0, s, a);        \
+    else hipLaunchKernelGGL((wino4_output_kernel<VT, false>), gd, dim3(256), 0, s, a);               \
+  } while (0)
+  if (vw == 4) W4_OUT(float4);
+  else if (vw == 2) W4_OUT(float2);
+  else W4_OUT(float);
+#undef W4_OUT
   if (stages == 7)
     note_kernel("wino4_input_kernel + 36 x gemm_dma_kernel<float, 3, 3, 3, 2, false, false> + wino4_output_kernel [F(4x4,3x3): 36 x (M=%d K=%d N=%d)]",
                 g.n_tiles, g.Cin, g.Cout);
   return check_launch("conv_wino4(output transform)");
 }
 
+/* ab [N][2][Cout] (scale row, shift row) of GroupNorm(groups, eps; gamma, beta) over the OUTPUT of the convolution `d`, from the
+ * workgroup sums diffsal_conv_wino4_ex left in `stats` (ext.out_stats, same d and groups). */
+extern "C" int diffsal_gn_affine_wino4(const diffsal_conv_desc* d, const double* stats, const float* gamma, const float* beta, int groups,
+                                       float eps, float* ab, diffsal_stream_t stream) {
+  DS_REQUIRE(d && stats && gamma && beta && ab, DIFFSAL_E_ARG, "gn_affine_wino4: null argument");
+  DS_REQUIRE(wino4_shape_ok(d), DIFFSAL_E_SHAPE, "gn_affine_wino4: not a convolution of the F(4x4) path");
+  const Wino4Geom g = wino4_geom(d);
+  DS_REQUIRE(wino4_stats_ok(g, groups), DIFFSAL_E_SHAPE, "gn_affine_wino4: statistics not available for this shape (groups=%d)", groups);
+  const int vw = wino4_vw(static_cast<long>(g.n_tiles) * g.Cout);
+  const int q4n = g.Cout / vw, tpi = g.n_tiles / g.N;
+  const double count = static_cast<double>(g.HO) * g.WO * (g.Cout / groups);
+  hipLaunchKernelGGL(wino4_gn_finalize_kernel, dim3(g.N, (groups + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), stats, gamma, beta, ab, g.Cout,
+                     groups, static_cast<long>(tpi) * q4n, q4n, tpi, count, eps);
+  return check_launch("gn_affine_wino4");
+}
+
+extern "C" int diffsal_conv_wino4_stages(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
+                                         const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
+                                         size_t ws_bytes, int stages, diffsal_stream_t stream) {
+  return diffsal_conv_wino4_ex(d, x, U, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, nullptr, stages, stream);
+}
+
 extern "C" int diffsal_conv_wino4(const diffsal_conv_desc* d, const float* x, const float* U, const float* bias, const float* scale,
                                   const float* shift, const float* rowvec, const float* residual, float* out, void* ws,
                                   size_t ws_bytes, diffsal_stream_t stream) {
-  return diffsal_conv_wino4_stages(d, x, U, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, 7, stream);
+  return diffsal_conv_wino4_ex(d, x, U, bias, scale, shift, rowvec, residual, out, ws, ws_bytes, nullptr, 7, stream);
 }

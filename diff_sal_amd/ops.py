@@ -259,6 +259,117 @@ def groupnorm_swish(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, ep
     return out
 
 
+def gn_affine(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
+    """GroupNorm(groups, eps) of NHWC x [B,H,W,C] in AFFINE form: ab [B,2,C] fp32 with norm(x)[b,..,c] = ab[b,0,c] x + ab[b,1,c]
+    (statistics only: one read of x, nothing written back; the consumer applies it as it loads x -- ``conv3x3_wino4_ex(gn_ab=...)``,
+    R/models/saliency_decoder/sal_unet.py:41-44)."""
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    ab = torch.empty((B, 2, Cc), device=x.device, dtype=torch.float32)
+    nbytes = lib.diffsal_groupnorm_ws_bytes(B, groups)
+    ws = torch.empty((nbytes // 8,), device=x.device, dtype=torch.float64)
+    dt = _dt(x)
+    with _prof("K3", 0.0, _nb(x)):
+        _lib.check(lib.diffsal_gn_affine(_pa(x, dt), _p(gamma), _p(beta), _p(ab), B, H * W, Cc, groups, eps, ws.data_ptr(), nbytes, dt,
+                                         _stream()), "gn_affine")
+    return ab
+
+
+def _wino4_desc(x: Tensor, Cout: int, act: int, rowvec: Optional[Tensor]):
+    N, H, W, Cin = x.shape
+    d = ConvDesc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 1, 1, act, rowvec.shape[-1] if rowvec is not None else 0, 0,
+                 _lib.PREC_FP32, _lib.F32)
+    if rowvec is not None:
+        assert rowvec.stride(-1) == 1 and rowvec.dtype == torch.float32 and rowvec.is_cuda
+        d.rowvec_ld = rowvec.stride(0)
+    return d
+
+
+def resblock_wino4_plan(x: Tensor, Cout: int, groups: int = 32) -> Optional[dict]:
+    """None unless BOTH 3x3 convolutions of a ResnetBlock on NHWC x [N,H,W,Cin] (Cin -> Cout, Cout -> Cout, padding 1) take the
+    F(4x4, 3x3) path (``diffsal_conv_wino4_supported``: fp32, Cin % 96 == 0, enough tiles ...); else what the extended entry point
+    offers for this shape: ``side`` -- the 1x1 shortcut can share the launch of conv1's position products --, ``stats`` -- conv1's
+    output transform can emit norm2's statistics."""
+    if x.dtype != torch.float32 or get_gemm_precision() != "fp32":
+        return None
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    d1 = _wino4_desc(x, Cout, ACT_NONE, None)
+    d2 = ConvDesc(N, H, W, Cout, H, W, Cout, 3, 3, 1, 1, 1, 1, 1, 1, ACT_NONE, 0, 0, _lib.PREC_FP32, _lib.F32)
+    if Cout % 96 != 0 or not lib.diffsal_conv_wino4_supported(C.byref(d1)) or not lib.diffsal_conv_wino4_supported(C.byref(d2)):
+        return None
+    return dict(side=bool(lib.diffsal_conv_wino4_side_supported(C.byref(d1), N * H * W)),
+                stats=lib.diffsal_conv_wino4_stats_bytes(C.byref(d1), groups) > 0)
+
+
+def conv3x3_wino4_ex(x: Tensor, wino4: Tensor, *, bias: Optional[Tensor] = None, rowvec: Optional[Tensor] = None,
+                     residual: Optional[Tensor] = None, act: int = ACT_NONE, gn_ab: Optional[Tensor] = None, gn_swish: bool = True,
+                     side=None, stats_groups: int = 0, tag: str = "K4"):
+    """3x3 / padding 1 convolution of NHWC fp32 x on the F(4x4, 3x3) path with the ResnetBlock extras of ``diffsal_conv_wino4_ex``:
+    ``gn_ab`` [N,2,Cin] (``gn_affine``): the input is normalised (+ swish) as the input transform loads it; ``side = (a, w)``: the
+    plain product a [N,H,W,K] x w [Cout, K]^T (the 1x1 shortcut, no bias) computed by the launch of the position products;
+    ``stats_groups`` > 0: per-(image, group) sums of the result for the next GroupNorm.  Returns (out, side_out or None, stats or
+    None) -- stats is the opaque buffer ``gn_affine_from_stats`` takes."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout = wino4.shape[1]
+    d = _wino4_desc(x, Cout, act, rowvec)
+    out = torch.empty((N, H, W, Cout), device=x.device, dtype=torch.float32)
+    ws_bytes = lib.diffsal_conv_wino4_ws_bytes(C.byref(d))
+    ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
+    ext = _lib.Wino4Ext()
+    side_out = stats = None
+    if gn_ab is not None:
+        assert gn_ab.shape == (N, 2, Cin) and gn_ab.dtype == torch.float32 and gn_ab.is_contiguous()
+        ext.in_ab, ext.in_swish = gn_ab.data_ptr(), 1 if gn_swish else 0
+    if side is not None:
+        sa, sw = side
+        assert sa.dtype == torch.float32 and sa.is_contiguous() and sa.shape[-1] == Cin and sw.shape == (Cout, Cin)
+        rows = sa.numel() // Cin
+        side_out = torch.empty(tuple(sa.shape[:-1]) + (Cout,), device=x.device, dtype=torch.float32)
+        ext.side_a, ext.side_w, ext.side_out, ext.side_rows = sa.data_ptr(), sw.data_ptr(), side_out.data_ptr(), rows
+    if stats_groups > 0:
+        sb = lib.diffsal_conv_wino4_stats_bytes(C.byref(d), stats_groups)
+        if sb == 0:
+            raise RuntimeError("conv3x3_wino4_ex: output statistics are not available for this shape (resblock_wino4_plan)")
+        stats = torch.empty((sb // 8,), device=x.device, dtype=torch.float64)
+        ext.out_stats, ext.out_groups = stats.data_ptr(), stats_groups
+    rv = rowvec.data_ptr() if rowvec is not None else None
+    args = (C.byref(d), _p(x), _p(wino4), _p(bias), None, None, rv, _p(residual), _p(out), _p(ws), ws_bytes, C.byref(ext))
+    dd = 1
+    n_tiles = N * ((H + 3) // 4) * ((W + 3) // 4)
+    if PROFILE is None:
+        _lib.check(lib.diffsal_conv_wino4_ex(*args, 7, _stream()), "conv_wino4_ex")
+    else:
+        note = f"M={N * H * W} K={9 * Cin} N={Cout} 3x3 winograd F(4x4,3x3)"
+        vb, mb = 36 * n_tiles * Cin * 4, 36 * n_tiles * Cout * 4
+        nside = 0 if side is None else side[0].numel() // Cin
+        with _prof(tag + "-xf", 0.0, _nb(x) + vb, note + (": input transform (GroupNorm + swish on load)" if gn_ab is not None else ": input transform")) as pr:
+            _lib.check(lib.diffsal_conv_wino4_ex(*args, 1, _stream()), "conv_wino4_ex")
+            pr.kernel = "wino4_input_kernel"
+        with _prof(tag, 2.0 * (n_tiles * 36 + nside) * Cin * Cout, vb + mb + _nb(wino4) + (0 if side is None else _nb(side[0], side_out)),
+                   note + f": 36 x (M={n_tiles} K={Cin} N={Cout})" + (f" + 1x1 shortcut M={nside}" if nside else "")) as pr:
+            _lib.check(lib.diffsal_conv_wino4_ex(*args, 2, _stream()), "conv_wino4_ex")
+            pr.kernel = lib.diffsal_last_gemm_kernel().decode()
+        with _prof(tag + "-xf", 0.0, mb + _nb(residual, out), note + ": output transform" + (" (+ GroupNorm sums)" if stats is not None else "")) as pr:
+            _lib.check(lib.diffsal_conv_wino4_ex(*args, 4, _stream()), "conv_wino4_ex")
+            pr.kernel = "wino4_output_kernel"
+    if stats is not None:
+        stats = (stats, d, stats_groups)
+    return out, side_out, stats
+
+
+def gn_affine_from_stats(stats, gamma: Tensor, beta: Tensor, eps: float = 1e-6) -> Tensor:
+    """ab [N,2,C] of GroupNorm over the output of the convolution whose ``conv3x3_wino4_ex(stats_groups=...)`` call returned ``stats``."""
+    lib = _lib.load()
+    buf, d, groups = stats
+    ab = torch.empty((d.N, 2, d.Cout), device=buf.device, dtype=torch.float32)
+    with _prof("K3", 0.0, _nb(buf)):
+        _lib.check(lib.diffsal_gn_affine_wino4(C.byref(d), buf.data_ptr(), _p(gamma), _p(beta), groups, eps, _p(ab), _stream()),
+                   "gn_affine_wino4")
+    return ab
+
+
 def _as_conv4(w: Tensor) -> Tensor:
     """Conv3d weights [Cout, Cin, KT, 1, 1] and Linear weights [N, K] as [Cout, Cin, taps, 1] views."""
     if w.dim() == 5:

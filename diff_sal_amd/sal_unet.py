@@ -299,6 +299,8 @@ class SalUNet(nn.Module):
             pk[f"res{i}.conv2.wino"] = self._pack_wino(rb.conv2.weight)
             if hasattr(rb, "nin_shortcut"):
                 pk[f"res{i}.nin.w"] = self._pack_conv(rb.nin_shortcut.weight)
+                # fused block: the shortcut product rides in conv1's launch without its bias, which conv2's epilogue adds
+                pk[f"res{i}.bias2"] = (rb.conv2.bias.detach() + rb.nin_shortcut.bias.detach()).contiguous()
             pk[f"res{i}.down.w"] = self._pack_conv(dn.conv.weight)
             tw.append(rb.temb_proj.weight.detach())
             tb.append(rb.temb_proj.bias.detach())
@@ -364,6 +366,39 @@ class SalUNet(nn.Module):
         for i, blk in enumerate(self.res_encoder):
             rb, dn = blk[0], blk[1]
             co = rb.conv1.out_channels
+            w1, w2 = pk[f"res{i}.conv1.wino"], pk[f"res{i}.conv2.wino"]
+            plan = None
+            if self.fuse_resblock and w1 is not None and w2 is not None and w1.f4 is not None and w2.f4 is not None:
+                plan = ops.resblock_wino4_plan(f, co, 32)
+            if plan is not None:
+                # both convolutions on the F(4x4) path: GroupNorm + swish are applied as the input transforms load their tensors
+                # (statistics only: the normalised maps never exist), the 1x1 shortcut is computed by the launch of conv1's
+                # position products, and conv1's output transform leaves norm2's statistics
+                ab1 = ops.gn_affine(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
+                has_nin = hasattr(rb, "nin_shortcut")
+                side = (f, pk[f"res{i}.nin.w"]) if has_nin and plan["side"] else None
+                h, sc, st = ops.conv3x3_wino4_ex(f, w1.f4, bias=rb.conv1.bias, rowvec=tproj[:, off:off + co], gn_ab=ab1, side=side,
+                                                 stats_groups=32 if plan["stats"] else 0)
+                off += co
+                if st is not None:
+                    ab2 = ops.gn_affine_from_stats(st, rb.norm2.weight, rb.norm2.bias, rb.norm2.eps)
+                else:
+                    ab2 = ops.gn_affine(h, rb.norm2.weight, rb.norm2.bias, 32, rb.norm2.eps)
+                bias2 = rb.conv2.bias
+                if not has_nin:
+                    sc = f
+                elif sc is None:
+                    sc = ops.conv_igemm(f, pk[f"res{i}.nin.w"], bias=rb.nin_shortcut.bias, tag="K4")
+                else:
+                    bias2 = pk[f"res{i}.bias2"]
+                f, _, _ = ops.conv3x3_wino4_ex(h, w2.f4, bias=bias2, residual=sc, gn_ab=ab2)
+                if taps is not None:
+                    taps[f"res{i}"] = f
+                hh, ww = f.shape[1:3]
+                f = ops.conv_igemm(f, pk[f"res{i}.down.w"], kh=3, kw=3, stride=(2, 2),
+                                   out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1), bias=dn.conv.bias, tag="K5")
+                outs.append(f)
+                continue
             h = ops.groupnorm_swish(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
             h = ops.conv_igemm(h, pk[f"res{i}.conv1.w"], kh=3, kw=3, pad=(1, 1), bias=rb.conv1.bias,
                                rowvec=tproj[:, off:off + co], tag="K4", wino=pk[f"res{i}.conv1.wino"])
@@ -539,6 +574,10 @@ class SalUNet(nn.Module):
     # fp32 3x3 stride-1 convolutions (ResnetBlock conv1 / conv2, UpEmbed's second convolution) as Winograd F(2x2, 3x3) where the
     # library's planner expects a gain (csrc/wino.hip; ~1e-6 relative transform rounding).  Off: always the direct kernel
     winograd = True
+    # ResnetBlocks whose two convolutions take the F(4x4) path: GroupNorm + swish folded into the input transforms, the 1x1
+    # shortcut inside conv1's batched launch, norm2's statistics from conv1's output transform (ops.conv3x3_wino4_ex).  Off: the
+    # per-operator launches
+    fuse_resblock = True
     _freq_tables: dict = {}       # (device, half) -> timestep-embedding frequencies on the device (constant)
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch

@@ -153,7 +153,12 @@ class DiffusionSampler:
             return False
         if self.hip_graph == "auto":
             net = self.model.decoder_net
-            # only our own denoiser in eval mode is known to be capturable (no host sync, no allocation outside the pool)
+            from . import ops
+            # only our own denoiser in eval mode is known to be capturable (no host sync, no allocation outside the pool); a
+            # stochastic trajectory (DDIM with eta > 0) stays eager so that a seeded run draws the numbers the eager loop draws;
+            # per-launch profiling events cannot be recorded inside a capture
+            if ops.PROFILE is not None or (self.sample_type != "dpmsolver" and self.eta != 0.0):
+                return False
             return x.size(0) <= self.graph_batch_max and hasattr(net, "forward_fused_update") and not getattr(net, "training", False)
         return bool(self.hip_graph)
 
@@ -176,14 +181,35 @@ class DiffusionSampler:
         if ent is not None and ent[0] != state:
             ent = None              # stale: drop it (frees its private pool) and capture again
             del self._graphs[key]
+        if ent is not None and ent[1] is None:
+            return fn(x, img, audio_cond)          # this signature failed to capture once: eager from then on
         if ent is None:
             sx, simg = x.clone(), [f.clone() for f in img]
             sa = None if audio_cond is None else audio_cond.clone()
-            fn(sx, simg, sa)  # warm-up outside capture: library load, weight packing, allocator pools
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = fn(sx, simg, sa)
+            # the warm-up (library load, weight packing, allocator pools) must not move the caller's random stream
+            dev = x.device
+            rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+            try:
+                fn(sx, simg, sa)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                # thread_local: a HIP call from another thread of the process (pin-memory thread, collective watchdog) must
+                # not invalidate this capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = fn(sx, simg, sa)
+            except Exception as e:  # noqa: BLE001 -- any capture failure: remember it, run the loop eagerly
+                if self.hip_graph != "auto":
+                    raise
+                import warnings
+                warnings.warn(f"diff_sal_amd: HIP-graph capture of {fn.__name__} failed ({type(e).__name__}: {e}); "
+                              "this input signature runs eagerly from now on")
+                torch.cuda.synchronize()
+                self._graphs[key] = (state, None, None, None, None, None)
+                torch.set_rng_state(rng_cpu)
+                torch.cuda.set_rng_state(rng_dev, dev)
+                return fn(x, img, audio_cond)
+            torch.set_rng_state(rng_cpu)
+            torch.cuda.set_rng_state(rng_dev, dev)
             ent = (state, g, sx, simg, sa, out)
             self._graphs[key] = ent
         _, g, sx, simg, sa, out = ent
@@ -258,15 +284,28 @@ class DiffusionSampler:
         rows, last = self._fused_plan(steps)
         n = x.shape[0]
         m_prev = None
-        for t_net, ex, e0, A, c0, c1, two in rows:
-            # network time exactly as model_wrapper computes it: fp32 tensor arithmetic on the host, then a device fill
-            t_in = torch.full((n,), t_net, dtype=torch.float32, device=x.device)
-            m, x = net.forward_fused_update(x, t_in, img, audio_cond, ex=ex, e0=e0, A=A, c0=c0, c1=c1,
+        # network times exactly as model_wrapper computes them (fp32 arithmetic on the host), as ONE device table per (plan,
+        # batch, device) instead of a fill launch per step: row s is the [n] time vector of evaluation s
+        tkey = (id(rows), n, str(x.device))
+        t_all = self._t_tables.get(tkey) if hasattr(self, "_t_tables") else None
+        if t_all is None or t_all[0] is not rows:
+            vals = [r[0] for r in rows] + [last[0]]
+            if torch.cuda.is_current_stream_capturing():       # no host-to-device copy inside a capture: fills instead
+                tt = torch.stack([torch.full((n,), v, dtype=torch.float32, device=x.device) for v in vals])
+            else:
+                tt = torch.tensor(vals, dtype=torch.float32).view(-1, 1).expand(-1, n).contiguous().to(x.device)
+                if not hasattr(self, "_t_tables"):
+                    self._t_tables = {}
+                self._t_tables[tkey] = (rows, tt)
+            t_all = (rows, tt)
+        t_tab = t_all[1]
+        for s_, (t_net, ex, e0, A, c0, c1, two) in enumerate(rows):
+            m, x = net.forward_fused_update(x, t_tab[s_], img, audio_cond, ex=ex, e0=e0, A=A, c0=c0, c1=c1,
                                             m_prev=m_prev if two else None)
             m_prev = m
         if self.denoise:                                  # denoise_to_zero_fn: data prediction at t_0 (sampler.py:542)
             t_net, alpha, sigma = last
-            t_in = torch.full((n,), t_net, dtype=torch.float32, device=x.device)
+            t_in = t_tab[len(rows)]
             noise = _lincomb(x, 1.0 / sigma, net(x, t_in, img, audio_cond), -alpha / sigma)
             x = _lincomb(x, 1.0 / alpha, noise, -sigma / alpha)
         return x

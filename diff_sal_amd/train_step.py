@@ -133,7 +133,18 @@ class GradReducer:
     ``exchange``: "allreduce" -- one ring all-reduce per bucket; "reduce_scatter" -- reduce-scatter of the bucket into
     per-rank shards followed by an all-gather of the shards (same result; on xGMI's point-to-point links the two halves
     can use all seven links of a GPU where a single ring is bound by one link per hop).  Buckets whose
-    length is not a multiple of the world size, and backends without reduce-scatter (gloo), use the all-reduce."""
+    length is not a multiple of the world size, and backends without reduce-scatter (gloo), use the all-reduce.
+
+    Parameters without a gradient.  A bucket holding a parameter that never receives a gradient (audio-branch weights in
+    visual-only training, an unused head) would stay open until ``finish()`` -- and, the order being fixed, so would every
+    later bucket: the whole exchange serialised behind backward.  ``static_unused`` (default on; the assumption of DDP
+    without ``find_unused_parameters``, R/model.py:15): the set of parameters that received no gradient on ANY rank in the
+    first step (one small MAX all-reduce of the "fired" flags, issued by every rank at the end of its first step) is taken
+    as final; ``arm()`` counts those parameters as done, so their buckets close with the last gradient that does arrive.
+    If such a parameter later produces a gradient after its bucket was exchanged, ``finish()`` raises (the gradient would
+    be missing from the sum); ``reset_unused()`` re-learns the set, ``static_unused = False`` turns the prediction off."""
+
+    static_unused = True
 
     def __init__(self, flat: FlatParams, group=None, exchange_single_rank: bool = False, exchange: str = "allreduce"):
         if exchange not in ("allreduce", "reduce_scatter"):
@@ -152,6 +163,9 @@ class GradReducer:
         self._next = 0
         self._work = []
         self._armed = False
+        self._fired: List[bool] = []           # per parameter: its gradient hook ran this step
+        self._unused = None                    # None: not learnt yet; else the set of parameters without a gradient on any rank
+        self._late: List[int] = []
         self.launch_order: List[int] = []
         self.collectives: List[str] = []       # what was issued per bucket in the last step ("allreduce" / "reduce_scatter+all_gather")
         for i, p in enumerate(flat.params):
@@ -162,6 +176,11 @@ class GradReducer:
             if not self._armed:
                 return
             b = self.flat.bucket_of[i]
+            self._fired[i] = True
+            if self._unused is not None and i in self._unused:      # predicted to stay without a gradient, and got one
+                if self._launched[b]:
+                    self._late.append(i)
+                return
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._ready[b] = True
@@ -203,7 +222,26 @@ class GradReducer:
         self._ready = [False] * len(self.flat.buckets)
         self._next = 0
         self._work, self.launch_order, self.collectives = [], [], []
+        self._fired = [False] * len(self.flat.params)
+        self._late = []
+        if self._unused:
+            for i in self._unused:
+                b = self.flat.bucket_of[i]
+                self._pending[b] -= 1
+                if self._pending[b] == 0:
+                    self._ready[b] = True      # launched by the first drain (first hook, or finish())
         self._armed = True
+
+    def reset_unused(self) -> None:
+        """Forget which parameters were found to receive no gradient; the next step learns the set again (call it on EVERY
+        rank when the training graph changes, e.g. audio conditioning switched on)."""
+        self._unused = None
+
+    def _learn_unused(self) -> None:
+        fired = torch.tensor([1.0 if f else 0.0 for f in self._fired], dtype=torch.float32, device=self.flat.flat_g.device)
+        if self.world > 1:
+            dist.all_reduce(fired, op=dist.ReduceOp.MAX, group=self.group)
+        self._unused = {i for i, f in enumerate(fired.tolist()) if f == 0.0}
 
     def finish(self) -> None:
         for b in range(len(self.flat.buckets)):     # the rest, in bucket order
@@ -212,6 +250,14 @@ class GradReducer:
         for w in self._work:
             w.wait()
         self._work, self._armed = [], False
+        if self._late:
+            late, self._late = self._late, []
+            raise RuntimeError(
+                f"GradReducer: {len(late)} parameter(s) that received no gradient in the first step (flat indices {late[:8]}...) "
+                "produced one now, after their bucket had been exchanged -- the sum over ranks misses it.  Call "
+                "reducer.reset_unused() on every rank when the training graph changes, or set GradReducer.static_unused = False")
+        if self.static_unused and self._unused is None:
+            self._learn_unused()
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -401,7 +447,7 @@ class DiffusionTrainStep:
         """One training step on this rank's clips; returns the (detached, device-resident) loss."""
         x0, x_t, t, _ = self.prepare_data(sal_maps, t0=t0, noise=noise, dequant_noise=dequant_noise)
         loss = self.loss_and_backward(x0, x_t, t, cond)
-        self.optimizer_step()
+        self.optimizer.step()          # the torch.optim.Optimizer face: step hooks and lr_scheduler bookkeeping see the step
         return loss
 
     # ---- checkpoint surface of torch.optim.Adam (R/diffusion_trainer.py:187-193, 263-268: "optim_dict") ----
@@ -429,6 +475,9 @@ class DiffusionTrainStep:
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": [i for i, _, _ in idx]}
+        for k, v in self.optimizer.param_groups[0].items():     # whatever else lives in the group (a scheduler's initial_lr)
+            if k != "params" and k not in group:
+                group[k] = v
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd: Dict) -> None:
@@ -473,3 +522,7 @@ class DiffusionTrainStep:
         self.betas = tuple(float(b) for b in g0.get("betas", self.betas))
         self.eps = float(g0.get("eps", self.eps))
         self.weight_decay = float(g0.get("weight_decay", self.weight_decay))
+        for k, v in g0.items():
+            if k not in ("params", "lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "foreach", "capturable",
+                         "differentiable", "fused"):
+                self.optimizer.param_groups[0][k] = v

@@ -192,6 +192,41 @@ int diffsal_conv_wino4(const diffsal_conv_desc* d /*host*/, const float* x, cons
 int diffsal_conv_wino4_stages(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
                               const float* scale, const float* shift, const float* rowvec, const float* residual, float* out,
                               void* ws, size_t ws_bytes, int stages, diffsal_stream_t stream);
+/* Extensions of the F(4x4) path for a ResnetBlock (R/models/saliency_decoder/sal_unet.py:123-142: h = conv1(swish(norm1(x))) +
+ * temb; out = nin_shortcut(x) + conv2(swish(norm2(h)))), all optional (zero / NULL = off):
+ *   in_ab, in_swish   the input is read through y = a[n][c] x + b[n][c] (ab = [N][2][Cin]: scale row then shift row per image:
+ *                     GroupNorm in affine form, diffsal_gn_affine / diffsal_gn_affine_wino4) and, if in_swish, y sigmoid(y), as the
+ *                     input transform loads it: no normalised tensor in memory.  The zero padding applies to the normalised map.
+ *   side_*            side_out [side_rows, Cout] = side_a [side_rows, Cin] x side_w [Cout, Cin]^T (no epilogue) computed by the SAME
+ *                     launch as the 36 position products, as side_rows / tiles further problems of their shape (the block's 1x1
+ *                     shortcut; diffsal_conv_wino4_side_supported: side_rows must be a multiple of the tile count).
+ *   out_stats, out_groups   the output transform leaves per-(image, group) sums / sums of squares of the RESULT in out_stats
+ *                     (diffsal_conv_wino4_stats_bytes bytes; 0 = not available for the shape) for diffsal_gn_affine_wino4:
+ *                     the GroupNorm that follows needs no statistics pass. */
+typedef struct diffsal_wino4_ext {
+  const float* in_ab;
+  const float* side_a;
+  const float* side_w;
+  float* side_out;
+  double* out_stats;
+  long long side_rows;
+  int in_swish;
+  int out_groups;
+} diffsal_wino4_ext;
+size_t diffsal_conv_wino4_stats_bytes(const diffsal_conv_desc* d /*host*/, int groups);
+int diffsal_conv_wino4_side_supported(const diffsal_conv_desc* d /*host*/, long side_rows);
+int diffsal_conv_wino4_ex(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
+                          const float* scale, const float* shift, const float* rowvec, const float* residual, float* out,
+                          void* ws, size_t ws_bytes, const diffsal_wino4_ext* ext /*host, may be NULL*/, int stages,
+                          diffsal_stream_t stream);
+/* GroupNorm(groups, eps; gamma, beta) in affine form: ab [B][2][C] with y = ab[b][0][c] x + ab[b][1][c] (statistics in fp64).
+ * diffsal_gn_affine: from the tensor x [B, HW, C] (one statistics launch + a finishing launch; ws as diffsal_groupnorm_swish);
+ * diffsal_gn_affine_wino4: from the sums a diffsal_conv_wino4_ex call left in ext.out_stats (same d, same groups).
+ * R/models/saliency_decoder/sal_unet.py:41-44. */
+int diffsal_gn_affine(const void* x, const float* gamma, const float* beta, float* ab, int B, int HW, int C, int groups,
+                      float eps, void* ws, size_t ws_bytes, int dtype, diffsal_stream_t stream);
+int diffsal_gn_affine_wino4(const diffsal_conv_desc* d /*host*/, const double* stats, const float* gamma, const float* beta,
+                            int groups, float eps, float* ab, diffsal_stream_t stream);
 /* conv3x3(dilation 2, padding 2)(bilinear_up2(z)) -> BN affine -> activation (UpEmbed's first convolution,
  * R/models/saliency_decoder/common_block.py:196-206) from c_ext = conv3x3(z) (dilation 1, zero padding) evaluated at the SOURCE
  * resolution on the grid extended by one pixel on every side ([N][h + 2][w + 2][C]: diffsal_conv_wino4 / diffsal_conv_igemm with

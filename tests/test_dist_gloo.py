@@ -205,3 +205,80 @@ def test_many_rank_exchange_with_rank_dependent_graph(world, mode):
         for k, n in zip(kinds, ret[0]["sizes"]):
             assert k == ("reduce_scatter+all_gather" if n % world == 0 else "allreduce")
         assert "reduce_scatter+all_gather" in kinds
+
+
+# ---- parameters that never receive a gradient must not serialise the exchange behind backward ----
+def test_unused_parameters_are_learnt_in_the_first_step_and_no_longer_hold_buckets_open():
+    from diff_sal_amd.train_step import FlatParams, GradReducer
+
+    m = _toy_trainable()
+    flat = FlatParams(m, bucket_bytes=1024)
+    red = GradReducer(flat)
+    nb = len(flat.buckets)
+    launched_before_finish = []
+    for it in range(3):
+        flat.zero_grad()
+        red.arm()
+        m(torch.randn(4, 6, generator=torch.Generator().manual_seed(it))).square().sum().backward()
+        launched_before_finish.append(len(red.launch_order))
+        red.finish()
+        assert red.launch_order == list(range(nb))                   # bucket order, every bucket once
+    unused = {i for i, p in enumerate(flat.params) if any(p is q for q in m.unused.parameters())}
+    assert red._unused == unused and len(unused) == 2
+    # step 1: the bucket holding `unused` (and every later one) waits for finish(); afterwards nothing does
+    assert launched_before_finish[0] < nb
+    assert launched_before_finish[1] == nb and launched_before_finish[2] == nb
+
+
+def test_a_gradient_for_a_parameter_learnt_as_unused_is_refused_loudly():
+    from diff_sal_amd.train_step import FlatParams, GradReducer
+
+    torch.manual_seed(11)
+    m = _Branchy()
+    flat = FlatParams(m, bucket_bytes=512)
+    red = GradReducer(flat)
+    x = torch.randn(3, 7)
+
+    def one(use_side):
+        flat.zero_grad()
+        red.arm()
+        m(x, use_side=use_side).square().sum().backward()
+        red.finish()
+
+    one(False)                                   # `side` learnt as unused
+    assert len(red._unused) == 2
+    with pytest.raises(RuntimeError, match="reset_unused"):
+        one(True)                                # its bucket went out before its gradient arrived
+    red.reset_unused()
+    one(True)                                    # re-learnt: fine, and the gradient is in the flat buffer
+    assert red._unused == set()
+    o = flat.offsets[[i for i, p in enumerate(flat.params) if p is m.side.weight][0]]
+    assert flat.flat_g[o:o + m.side.weight.numel()].abs().sum() > 0
+    red.static_unused = False
+    red.reset_unused()
+    one(False)
+    assert red._unused is None                   # prediction off: nothing learnt
+
+
+def test_train_step_goes_through_the_optimizer_face_and_keeps_scheduler_keys():
+    """MultiStepLR must see optimizer.step() before scheduler.step() (no warning), and its `initial_lr` survives a checkpoint."""
+    import warnings
+
+    from diff_sal_amd.train_step import FlatAdam
+
+    class _Owner:
+        def __init__(self):
+            self.n = 0
+
+        def optimizer_step(self):
+            self.n += 1
+
+    own = _Owner()
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = FlatAdam(own, [p], 1e-4, (0.9, 0.999), 1e-8, 0.0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        opt.step()
+        sched.step()
+    assert own.n == 1 and abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12 and opt.param_groups[0]["initial_lr"] == 1e-4

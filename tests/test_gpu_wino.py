@@ -155,3 +155,93 @@ def test_winograd_f4_staged_calls_equal_the_single_call(tuning):
     assert torch.equal(one, staged)
     assert classes == ["K4-xf", "K4", "K4-xf"], classes
     assert kernels[0] == "wino4_input_kernel" and kernels[2] == "wino4_output_kernel" and "gemm_dma_kernel" in kernels[1] and "batch 36" in kernels[1]
+
+
+# ---- ResnetBlock extras of the F(4x4) path (diffsal_conv_wino4_ex): GroupNorm + swish on load, the 1x1 shortcut inside the
+# launch of the position products, statistics of the result for the next GroupNorm ----
+def _gn_ab_ref(x_nhwc, gamma, beta, groups, eps):
+    """GroupNorm in affine form from fp64 statistics: ab [N,2,C]."""
+    N, H, W, Cc = x_nhwc.shape
+    xg = x_nhwc.double().reshape(N, H * W, groups, Cc // groups)
+    mean = xg.mean(dim=(1, 3))
+    var = xg.var(dim=(1, 3), unbiased=False)
+    rstd = (var + eps).rsqrt()
+    a = rstd.repeat_interleave(Cc // groups, dim=1) * gamma.double()
+    b = beta.double() - mean.repeat_interleave(Cc // groups, dim=1) * a
+    return torch.stack([a, b], dim=1).float()
+
+
+@pytest.mark.parametrize("shape", [(4, 56, 96, 96), (4, 14, 24, 768), (2, 9, 7, 192), (3, 28, 48, 384)])
+def test_gn_affine_matches_group_norm(shape):
+    from diff_sal_amd import ops
+
+    N, H, W, Cc = shape
+    x = rnd("gax", *shape) * 1.7 + 0.4
+    gamma, beta = rnd("gag", Cc, scale=0.3) + 1.0, rnd("gab", Cc, scale=0.2)
+    ab = ops.gn_affine(x.to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-6).cpu()
+    ref = _gn_ab_ref(x, gamma, beta, 32, 1e-6)
+    assert tuple(ab.shape) == (N, 2, Cc)
+    assert (ab - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    y = x * ab[:, 0][:, None, None, :] + ab[:, 1][:, None, None, :]
+    yr = F.group_norm(x.permute(0, 3, 1, 2), 32, gamma, beta, 1e-6).permute(0, 2, 3, 1)
+    assert rel_err(y, yr) < 2e-6
+
+
+RES_CASES = [
+    # N, H, W, Cin, Cout          the three ResnetBlocks of the noise encoder at B = 4 and a ragged one
+    (4, 56, 96, 96, 192),
+    (4, 28, 48, 192, 384),
+    (4, 14, 24, 384, 768),        # 14 rows: half-empty last tile row; 1344 shortcut rows = 14 x 96 tiles
+    (2, 12, 20, 96, 96),          # no shortcut (Cin == Cout); statistics over few workgroups
+]
+
+
+@pytest.mark.parametrize("case", RES_CASES, ids=[f"{c[1]}x{c[2]}_{c[3]}to{c[4]}" for c in RES_CASES])
+def test_resblock_extras_of_the_f4_path(case, tuning):
+    """h = conv1(swish(GN(x))) + temb (+ norm2 statistics, + the shortcut product in the same launch); out = conv2(swish(GN(h))) + sc."""
+    from diff_sal_amd import ops
+
+    N, H, W, Cin, Cout = case
+    tuning.set("DIFFSAL_FORCE_WINOGRAD", 1)
+    x = rnd("rx", N, H, W, Cin) * 1.3 + 0.2
+    w1, w2 = rnd("rw1", Cout, Cin, 3, 3, scale=0.05), rnd("rw2", Cout, Cout, 3, 3, scale=0.04)
+    b1, b2 = rnd("rb1", Cout, scale=0.2), rnd("rb2", Cout, scale=0.2)
+    g1, be1 = rnd("rg1", Cin, scale=0.3) + 1.0, rnd("re1", Cin, scale=0.2)
+    g2, be2 = rnd("rg2", Cout, scale=0.3) + 1.0, rnd("re2", Cout, scale=0.2)
+    temb = rnd("rt", N, Cout + 8, scale=0.3)[:, 4:4 + Cout]
+    wn = rnd("rwn", Cout, Cin, scale=0.1) if Cin != Cout else None
+    # fp64 reference of the block (R/models/saliency_decoder/sal_unet.py:123-142, eval mode)
+    xd = x.double().permute(0, 3, 1, 2)
+    h_ref = F.conv2d(F.silu(F.group_norm(xd, 32, g1.double(), be1.double(), 1e-6)), w1.double(), b1.double(), padding=1) + \
+        temb.double()[:, :, None, None]
+    sc_ref = xd if wn is None else F.conv2d(xd, wn.double()[:, :, None, None])
+    out_ref = F.conv2d(F.silu(F.group_norm(h_ref, 32, g2.double(), be2.double(), 1e-6)), w2.double(), b2.double(), padding=1) + sc_ref
+    h_ref, sc_ref, out_ref = (t.permute(0, 2, 3, 1).float() for t in (h_ref, sc_ref, out_ref))
+
+    xg = x.to(DEV)
+    plan = ops.resblock_wino4_plan(xg, Cout, 32)
+    assert plan is not None and plan["stats"]
+    assert plan["side"] == ((N * H * W) % (N * ((H + 3) // 4) * ((W + 3) // 4)) == 0)
+    u1, u2 = ops.pack_wino4_weight(w1.to(DEV)), ops.pack_wino4_weight(w2.to(DEV))
+    ab1 = ops.gn_affine(xg, g1.to(DEV), be1.to(DEV), 32, 1e-6)
+    side = (xg, wn.to(DEV)) if wn is not None and plan["side"] else None
+    h, sc, st = ops.conv3x3_wino4_ex(xg, u1, bias=b1.to(DEV), rowvec=temb.to(DEV), gn_ab=ab1, side=side, stats_groups=32)
+    assert rel_err(h, h_ref) < 5e-5
+    if side is not None:
+        assert rel_err(sc, sc_ref) < 2e-6
+        # the shortcut product is bit-equal to the stand-alone plain product on the same kernel
+        tuning.set("DIFFSAL_GEMM_DMA", 1)
+        alone = ops.linear(xg.view(N * H * W, Cin), wn.to(DEV), None)
+        assert torch.equal(sc.view(N * H * W, Cout), alone)
+    ab2 = ops.gn_affine_from_stats(st, g2.to(DEV), be2.to(DEV), 1e-6)
+    ab2_pass = ops.gn_affine(h, g2.to(DEV), be2.to(DEV), 32, 1e-6)               # the statistics pass over the same tensor
+    assert (ab2 - ab2_pass).abs().max().item() < 2e-6 * ab2_pass.abs().max().item()
+    assert (ab2.cpu() - _gn_ab_ref(h_ref, g2, be2, 32, 1e-6)).abs().max().item() < 1e-4 * ab2_pass.abs().max().item()
+    resid = sc if sc is not None else (xg if wn is None else ops.linear(xg.view(N * H * W, Cin), wn.to(DEV), None).view(N, H, W, Cout))
+    out, _, _ = ops.conv3x3_wino4_ex(h, u2, bias=b2.to(DEV), residual=resid, gn_ab=ab2)
+    assert rel_err(out, out_ref) < 1e-4
+    # against the per-operator launches (GroupNorm kernel, plain F(4x4) convolutions): same arithmetic up to rounding order
+    hn = ops.groupnorm_swish(xg, g1.to(DEV), be1.to(DEV), 32, 1e-6)
+    h_un = ops.conv_igemm(hn, ops.pack_conv_weight(w1.to(DEV)), kh=3, kw=3, pad=(1, 1), bias=b1.to(DEV), rowvec=temb.to(DEV),
+                          wino=ops.WinoWeights(w1.to(DEV)))
+    assert rel_err(h, h_un.cpu()) < 2e-5
