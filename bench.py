@@ -199,6 +199,7 @@ def plumbing_train_leg(world):
     """CPU-only host: the gradient-exchange half of the `train` object on host tensors over gloo -- the same FlatParams /
     GradReducer code the GPU step uses (bucket hooks, asynchronous all_reduce, wait), a MIN / MAX checksum comparison of the
     replicas -- with every timing field null (there is no CPU training step to time)."""
+    import numpy as np
     import torch.distributed as dist
 
     from diff_sal_amd.train_step import FlatParams, GradReducer
@@ -206,13 +207,17 @@ def plumbing_train_leg(world):
     torch.manual_seed(5)
     m = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Tanh(), torch.nn.Linear(96, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
     flat = FlatParams(m, bucket_bytes=4 << 10)
-    red = GradReducer(flat, None, exchange_single_rank=True)
+    red = GradReducer(flat, None, exchange_single_rank=True, exchange=EXCHANGE_MODE)
     rank = dist.get_rank() if dist.is_initialized() else 0
     x = torch.randn(16, 64, generator=torch.Generator().manual_seed(100 + rank))
-    for _ in range(2):
+    # the reference draws ONE timestep per rank-batch from an unseeded generator (R/diffusion_trainer.py:111): every rank trains
+    # at its own t0, the replicas must still end up identical (the gradient exchange is the only coupling)
+    rng = np.random.RandomState(1000 + rank)
+    for _ in range(3):
+        t0 = int(rng.randint(0, 1000))
         flat.zero_grad()
         red.arm()
-        m(x).square().mean().backward()
+        (m(x) * (1.0 + t0 / 1000.0)).square().mean().backward()
         red.finish()
         flat.flat_p.add_(flat.flat_g, alpha=-0.1 / max(world, 1))
     chk = torch.stack([flat.flat_p.double().sum(), flat.flat_p.double().abs().sum()])
@@ -226,6 +231,7 @@ def plumbing_train_leg(world):
                          "collective_executed": bool(dist.is_initialized() and red.exchange),
                          "bytes_per_step_per_rank": int(flat.numel * 4),
                          "buckets_mb": [round(len(r) * 4 / 2 ** 20, 4) for r in flat.buckets],
+                         "mode": red.mode, "steps": 3, "rank_dependent_t0": True,
                          "launch_order": list(red.launch_order), "replicas_identical": bool(torch.equal(lo, hi)),
                          "allreduce_ms_per_bucket": None, "ms_per_step_without_exchange": None, "exposed_ms": None,
                          "overlap_frac": None}}
@@ -251,9 +257,16 @@ def plumbing_only(args, rank, world):
         ranks = dist.get_world_size()
         dist.barrier()
     train = None
-    if args.workload == "sample" and not args.no_train_leg:
+    if args.workload == "train" or not args.no_train_leg:
         train = plumbing_train_leg(world)
-    if rank == 0:
+    if rank == 0 and args.workload == "train":
+        print(json.dumps({"metric": "training samples/sec (diffusion train step of the denoiser: fwd + MSE + bwd + all-reduce + clip + Adam)",
+                          "value": None, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": train["what"]}, "exchange": train["exchange"],
+                          "rccl_ranks": ranks, "backend": "gloo", "devices": ["cpu"] * world, "max_over_ranks_s": round(el, 4)}),
+              flush=True)
+    elif rank == 0:
         print(json.dumps({"metric": "denoise-steps/sec (batch x NFE / wall time), 16x224x384 clip, 50-step DPM-Solver",
                           "train": train,
                           "value": None, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
@@ -396,6 +409,21 @@ def build_train_step(cfg, net, feats, audio, dev, rank, *, batch, av, full, exch
     return ts, sal, cond
 
 
+def rank_table(own_seconds, units_per_rank, dev, world, unit):
+    """Every rank's own rate over the timed region (its clock stops at its own device synchronize, before the closing barrier):
+    the spread tells a straggling GPU from a uniformly slow job; `value` of the line stays units of all ranks / MAX time."""
+    rates = [units_per_rank / own_seconds]
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([own_seconds], device=dev, dtype=torch.float64)
+        out = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(out, tt)
+        rates = [units_per_rank / float(o.item()) for o in out]
+    return {"unit": unit + " per rank", "per_rank": [round(r, 3) for r in rates], "min": round(min(rates), 3), "max": round(max(rates), 3),
+            "spread": round(max(rates) / min(rates) - 1.0, 4)}
+
+
 def _dist_on():
     import torch.distributed as dist
 
@@ -424,6 +452,7 @@ def timed_train_region(ts, sal, cond, steps, dev, profile_last=False):
         ev, ops.PROFILE = ops.PROFILE, None
     timed_train_region.host_issue_s = time.perf_counter() - t0      # the host has queued every launch of the region by now
     torch.cuda.synchronize()
+    timed_train_region.own_s = time.perf_counter() - t0             # this rank's own clock (before the closing barrier)
     if _dist_on():
         dist.barrier()
     torch.cuda.synchronize()
@@ -489,7 +518,57 @@ def exchange_report(ts, sal, cond, steps, dev, world, ms_with):
     rep["ms_per_step_without_exchange"] = round(ms_without, 4)
     rep["exposed_ms"] = round(exposed, 4)
     rep["overlap_frac"] = round(max(0.0, min(1.0, 1.0 - exposed / total)), 4) if total > 0 else None
+    # weak-scaling efficiency of the step against the same step without its one collective (the N = 1 figure on this node)
+    rep["efficiency_vs_no_exchange"] = round(ms_without / ms_with, 4) if ms_with > 0 else None
+    rep["modes"] = exchange_modes(ts, sal, cond, steps, dev, world, ms_without)
     return rep
+
+
+def exchange_modes(ts, sal, cond, steps, dev, world, ms_without):
+    """The same step under BOTH exchange forms in one invocation -- ring all-reduce per bucket, and reduce-scatter + all-gather
+    (all seven xGMI links of a GPU instead of one per ring hop) -- so that one scaling run A/Bs them: step time, the collectives'
+    blocking time measured alone, bus bandwidth (2 (w - 1) / w of the payload per rank for either form), exposed time and overlap."""
+    import torch.distributed as dist
+
+    flat, red = ts.flat, ts.reducer
+    out = {}
+    keep = red.mode
+    gbytes = flat.numel * 4 / 1e9
+    try:
+        for mode in ("allreduce", "reduce_scatter"):
+            red.mode = mode
+            ts.step(sal, cond)
+            el, _, _ = timed_train_region(ts, sal, cond, steps, dev)
+            ms = el / steps * 1e3
+            scratch = torch.zeros_like(flat.flat_g)
+            tot = 0.0
+            for r in flat.buckets:
+                v = scratch[r.start:r.stop]
+                n = v.numel()
+                ts_ = []
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    if mode == "reduce_scatter" and n % world == 0 and red._native_rs:
+                        mine = v[red.rank * (n // world):(red.rank + 1) * (n // world)]
+                        dist.reduce_scatter_tensor(mine, v, op=dist.ReduceOp.SUM, group=ts.group)
+                        dist.all_gather_into_tensor(v, mine, group=ts.group)
+                    else:
+                        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ts.group)
+                    torch.cuda.synchronize()
+                    ts_.append((time.perf_counter() - t0) * 1e3)
+                tot += median(ts_[1:])
+            exposed = max(0.0, ms - ms_without)
+            out[mode] = {"ms_per_step": round(ms, 4), "collectives_ms_total": round(tot, 4),
+                         "bus_gbs": round(gbytes * 2 * (world - 1) / max(world, 1) / (tot * 1e-3), 2) if tot > 0 and world > 1 else None,
+                         "exposed_ms": round(exposed, 4),
+                         "overlap_frac": round(max(0.0, min(1.0, 1.0 - exposed / tot)), 4) if tot > 0 else None,
+                         "collectives_per_bucket": sorted(set(red.collectives))}
+    finally:
+        red.mode = keep
+    return out
 
 
 def train_leg(cfg, dev, rank, world, *, steps=10, warmup=3, batch=4):
@@ -522,6 +601,7 @@ def train_leg(cfg, dev, rank, world, *, steps=10, warmup=3, batch=4):
         for _ in range(max(warmup, 1)):
             ts.step(sal, cond)
         el, loss, _ = timed_train_region(ts, sal, cond, steps, dev)
+        ranks_tab = rank_table(timed_train_region.own_s, batch * steps, dev, world, "samples/s")
         ms = el / steps * 1e3
         out = {"what": "BASELINE configs[3]: audio-visual training step of the WHOLE model (MViTv2-S fwd+bwd, frozen VGGish, "
                        "AudioAttnNet fwd+bwd, SalUNet fwd+bwd; MSE, one bucketed gradient all-reduce, clip 1.0, Adam), "
@@ -529,6 +609,7 @@ def train_leg(cfg, dev, rank, world, *, steps=10, warmup=3, batch=4):
                "value": round(world * batch * steps / el, 3), "unit": "samples/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": round(ms, 4), "scaling": "weak", "batch_per_gpu": batch,
                "trainable_params": ts.flat.live_numel, "grad_buckets": len(ts.flat.buckets), "final_loss": float(loss.item())}
+        out["ranks"] = ranks_tab
         out["exchange"] = exchange_report(ts, sal, cond, steps, dev, world, ms)
         if note:
             out["note"] = note
@@ -548,6 +629,8 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
     regions, ev, host_issue = [], [], []
     for rep_i in range(args.repeats):      # each region: exactly K steps between barrier + synchronize; MAX over ranks
         el, loss, e = timed_train_region(ts, sal, cond, args.steps, dev, profile_last=rep_i == args.repeats - 1)
+        if rep_i == 0:
+            ranks_tab = rank_table(timed_train_region.own_s, B * args.steps, dev, world, "samples/s")
         ev = e or ev
         regions.append(el)
         host_issue.append(timed_train_region.host_issue_s)
@@ -585,6 +668,7 @@ def bench_train(args, net, cfg, feats, audio, dev, rank, world):
                    "batch_per_gpu": B, "trainable_params": ts.flat.live_numel, "grad_buckets": len(ts.flat.buckets),
                    "exchange": "RCCL all-reduce of the flat fp32 gradient, bucketed, overlapped with backward",
                    "final_loss": float(loss.item())},
+        "ranks": ranks_tab,
         "exchange": exchange_report(ts, sal, cond, args.steps, dev, world, elapsed / args.steps * 1e3),
         "repeats": args.repeats, "ms_per_step_all_regions": [round(r / args.steps * 1e3, 4) for r in regions],
         # host time to QUEUE a step's launches (Python + autograd tape + ~1 800 launches): when it reaches ms_per_step the step is
@@ -649,6 +733,8 @@ def main():
                          "gradient exchange report) that the default line carries at every N")
     ap.add_argument("--train-leg-steps", type=int, default=10)
     ap.add_argument("--no-encoders", action="store_true", help="skip the end-to-end (encoders + 50 steps) leg")
+    ap.add_argument("--no-solo-leg", action="store_true",
+                    help="N > 1: skip rank 0's solo timing of the same steps (the N = 1 reference of `scaling_efficiency`)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B aid: set a SalUNet switch (fuse_resblock=0, up_commute=0, ...) on the benchmarked network; recorded in config")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -783,6 +869,7 @@ def main():
         t0 = time.perf_counter()
         run_steps(args.steps, profile_last=profile_last)
         torch.cuda.synchronize()
+        state["own_s"] = time.perf_counter() - t0       # this rank's own clock (before the closing barrier)
         barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -795,7 +882,24 @@ def main():
         return el
 
     run_steps(max(args.warmup, 1))
-    regions = [timed_region(i == args.repeats - 1) for i in range(args.repeats)]
+    # N > 1: rank 0 first times the same K steps ALONE (its peers wait at the barrier, their GPUs idle): the N = 1 value of this very
+    # run configuration, against which the line reports its own weak-scaling efficiency (the driver computes its own from the
+    # per-N lines; this one needs no second invocation)
+    solo = None
+    if world > 1 and not args.no_solo_leg:
+        torch.cuda.synchronize()
+        barrier()
+        if rank == 0:
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            solo = time.perf_counter() - t0
+        barrier()
+    regions = []
+    for i in range(args.repeats):
+        regions.append(timed_region(i == args.repeats - 1))
+        if i == 0:
+            ranks_tab = rank_table(state["own_s"], B * args.steps, dev, world, "denoise-steps/s")
     elapsed = median(regions)
 
     # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
@@ -950,6 +1054,11 @@ def main():
             **({"switches (A/B run, NOT the shipped defaults)": list(args.set)} if args.set else {}),
         },
         "rccl_ranks": ranks_seen, "backend": "nccl (RCCL)" if world > 1 else "none (single rank)", "devices": devices,
+        "ranks": ranks_tab,
+        **({"solo_rank0": {"what": "rank 0 alone, same configuration and K steps, the other GPUs idle (N = 1 reference of this run)",
+                           "value": round(B * args.steps / solo, 3), "ms_per_step": round(solo / args.steps * 1e3, 4)},
+            "scaling_efficiency": round((world * B * args.steps / elapsed) / (world * B * args.steps / solo), 4)}
+           if solo is not None else {}),
         "build": bid,
         "roofline": roofline,
     }

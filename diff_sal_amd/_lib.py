@@ -33,7 +33,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 
 SIGNATURES = {
@@ -136,6 +136,7 @@ SIGNATURES = {
     "diffsal_conv_wino4_side_supported": (c_i, [C.POINTER(ConvDesc), C.c_long]),
     "diffsal_gn_affine": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_i, c_f]),
     "diffsal_gn_affine_wino4": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_i, c_fl, c_f, c_f]),
+    "diffsal_border_gather": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_up2_conv_commute": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
     "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),

@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   if constexpr (GROUPED) {
     n_virtual = g.total;
   } else {
-    n_virtual = g.n_tiles * g.splits * (g.batch + g.batch2);         // xcd_order only without split-K and batch
+    n_virtual = g.n_tiles * g.splits * (g.batch + g.batch2);         // xcd_order only without split-K
     if (g.xcd_order) {
-      const int x = blockIdx.x & 7;
-      n_virtual = 8 * g.n_tiles_n * (g.n_tiles_m > x ? (g.n_tiles_m - x + 7) >> 3 : 0);
+      // rows = (problem of the batch, M tile): an XCD owns whole rows, so that a row's A block is fetched into ONE L2
+      const int x = blockIdx.x & 7, rows = g.n_tiles_m * (g.batch + g.batch2);
+      n_virtual = 8 * g.n_tiles_n * (rows > x ? (rows - x + 7) >> 3 : 0);
     }
   }
   // problem of unit v and the unit's index inside it
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     }
   };
   auto tile_mn = [&](const DmaGemmArgs& p, int v, int& tmi, int& tni) __attribute__((always_inline)) {
-    if (!GROUPED && p.xcd_order) {
+    if (!GROUPED && p.xcd_order && p.batch + p.batch2 == 1) {
       const int q = v >> 3, ml = q / p.n_tiles_n;
       tni = q - ml * p.n_tiles_n;
       tmi = ml * 8 + (v & 7);
@@ -230,8 +231,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     const void* base_w = pi.w;
     if constexpr (!GROUPED) {
       if (g.batch + g.batch2 > 1) {
-        const int per = g.n_tiles * g.splits, vv = live ? v : 0, ib = vv / per;
-        iss_lv = vv - ib * per;
+        const int per = g.n_tiles * g.splits, vv = live ? v : 0;
+        int ib;
+        if (g.xcd_order) {           // v = 8 (row-of-eight ml, N tile) + XCD: row = ml * 8 + XCD = ib * n_tiles_m + M tile
+          const int q = vv >> 3, ml = q / g.n_tiles_n, row = ml * 8 + (vv & 7);
+          ib = row / g.n_tiles_m;
+          iss_lv = (row - ib * g.n_tiles_m) * g.n_tiles_n + (q - ml * g.n_tiles_n);
+        } else {
+          ib = vv / per;
+          iss_lv = vv - ib * per;
+        }
         if (ib < g.batch) {
           ib_a = ib * g.a_bs;
           ib_w = ib * g.w_bs;
@@ -573,8 +582,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     } else {
       cmp_lv = cmp_v;
       if (g.batch + g.batch2 > 1) {
-        const int per = g.n_tiles * g.splits, ib = cmp_v / per;
-        cmp_lv = cmp_v - ib * per;
+        const int per = g.n_tiles * g.splits;
+        int ib;
+        if (g.xcd_order) {
+          const int q = cmp_v >> 3, ml = q / g.n_tiles_n, row = ml * 8 + (cmp_v & 7);
+          ib = row / g.n_tiles_m;
+          cmp_lv = (row - ib * g.n_tiles_m) * g.n_tiles_n + (q - ml * g.n_tiles_n);
+        } else {
+          ib = cmp_v / per;
+          cmp_lv = cmp_v - ib * per;
+        }
         if (ib < g.batch) {
           cmp_ob = ib * g.o_bs;
           cmp_out = g.out;
@@ -665,7 +682,13 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
 #ifdef DIFFSAL_DEV_STAMPS
   a.stamps = (g_dma_stamps && static_cast<size_t>(grid) * 32 * 8 <= g_dma_stamp_bytes) ? g_dma_stamps : nullptr;
 #endif
-  a.xcd_order = (a.splits == 1 && a.batch == 1 && a.batch2 == 0 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles >= slots && a.n_tiles_n > 1 && a.n_tiles_m >= 16) ? 1 : 0;
+  // XCD-aware unit order (one XCD owns whole rows of N tiles) on plain products that fill the chip.  The same order over the
+  // (position, M tile) rows of a BATCHED launch is implemented (DIFFSAL_BATCH_XCD=1) but off: measured on one box, alternating,
+  // 3.58 against 3.50 ms per step -- an XCD then owns 4 or 5 of the 36 positions and the launch ends on the XCDs with 5.
+  const long rows_total = static_cast<long>(a.n_tiles_m) * (a.batch + a.batch2);
+  const bool batched = a.batch + a.batch2 > 1;
+  a.xcd_order = (a.splits == 1 && tune(TUNE_NO_XCD_ORDER) != 1 && grid % 8 == 0 && a.n_tiles_n > 1 &&
+                 (batched ? (tune(TUNE_BATCH_XCD) == 1 && units >= 128 && rows_total >= 16) : (a.n_tiles >= slots && a.n_tiles_m >= 16))) ? 1 : 0;
   if constexpr (sizeof(T) == 4) {
     if (conv) hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, true, false>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_dma_kernel<T, TMB, TNB, STAGES, OCC, false, false>), dim3(grid), dim3(256), 0, s, a);

@@ -169,192 +169,6 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// mt_proj form (R/models/saliency_decoder/sal_unet.py:480-489, :407: dilation 1, sources at power-of-two factors, head folded):
-// the same gather with the interpolation set-up hoisted out of the tap loop and the arithmetic cut to what the geometry needs.
-//
-// A 4 x 4 output patch whose origin is a multiple of 4, shifted by the nine taps, touches the 6 x 6 target positions
-// (Y0 - 1 + j, X0 - 1 + i), j, i = 0..5.  Per source and axis those six positions read 4 (factor 2) or 3 (factor >= 4)
-// consecutive source lines; their line pair and interpolation weight depend on the source only -- tapsum_kernel recomputes
-// them for each of the 36 (tap, source) pairs (eight bilin_coord + ~25 readfirstlane + two 4 x 4 weight tables per pair:
-// about as many instructions as the FMAs it then issues).  Here they are wave-uniform scalars computed once per source:
-//   factor 2 / 4: the line pair of position j is a compile-time pattern (j / 2 resp. j / 3 -- the patch origin is a multiple
-//     of 4), so horizontal and vertical passes are two-tap: 64 / 56 FMAs per channel and tap (tapsum_kernel: 128 / 96);
-//   factor >= 8:  three-line weight vectors (one of them zero): 84 FMAs.
-// Weights are those of bilin_coord (align_corners = False, source index clamped); a position outside the image has weight 0
-// (the convolution's zero padding).  CPL channels per lane: 3 when C = 96, so that the 32 lanes of an image's half-wave are all
-// busy (4 channels per lane leave 8 idle).  Same patch / image-pair / XCD order as tapsum_kernel; results differ from it by
-// summation order only.
-// ------------------------------------------------------------------------------------------------
-template <int CPL> struct TapVec { float v[CPL]; };
-template <int CPL>
-__device__ __forceinline__ TapVec<CPL> tap_ld(const float* p) {
-  TapVec<CPL> r;
-  if constexpr (CPL == 4) { const float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
-  else {
-#pragma unroll
-    for (int e = 0; e < CPL; ++e) r.v[e] = p[e];
-  }
-  return r;
-}
-
-// One axis of one source: NL source lines from `first` on (indices clamped into [0, n)), and for the six positions
-// P0 - 1 + j the weights on those lines (all zero for a position outside [0, L)).  F = 2, 4: wa[j], wb[j] on the pair
-// (j / (6 / (NL - 1)), + 1); F = 0: w3[j][0..2].
-template <int F>
-struct TapAxis {
-  static constexpr int NL = F == 2 ? 4 : 3;
-  int idx[NL];
-  float wa[6], wb[6], w3[6][3];
-};
-template <int F>
-__device__ __forceinline__ void tap_axis(int P0, int L, int n, float scale, TapAxis<F>& ax) {
-  const int f = L / n;
-  int first = 0;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int p = P0 - 1 + j;
-    const bool valid = p >= 0 && p < L;
-    int i0, i1;
-    float l1;
-    bilin_coord(valid ? p : 0, scale, n, i0, i1, l1);
-    // lower line of the position's pair BEFORE clamping: floor((p + 0.5) / f - 0.5); -1 where bilin_coord clamps the coordinate
-    // at 0 (then the whole weight belongs to line 0 = the pair's upper line).  Past the last line the pair is (n - 1, n) and
-    // bilin_coord's weights (1 - l1, l1) both land on the clamped index n - 1.
-    const int num = 2 * p + 1 - f;
-    const int lower = num >= 0 ? num / (2 * f) : -1;
-    if (j == 0) first = lower;
-    float a = 1.f - l1, b = l1;
-    if (lower < 0) { a = 0.f; b = 1.f; }
-    if (!valid) { a = 0.f; b = 0.f; }
-    ax.wa[j] = uni_f(a);
-    ax.wb[j] = uni_f(b);
-    if constexpr (F == 0) {
-      const int r = lower - first;                     // 0 or 1: six positions span less than one line at factor >= 8
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ax.w3[j][k] = uni_f((k == r ? a : 0.f) + (k == r + 1 ? b : 0.f));
-    }
-  }
-  first = uni_i(first);
-#pragma unroll
-  for (int k = 0; k < TapAxis<F>::NL; ++k) ax.idx[k] = uni_i(min(max(first + k, 0), n - 1));
-}
-
-// the nine taps of one source: acc[d][e] += sum_tap bilerp(Y[..., tap * C + c]; (Y0 + d + ky - 1, X0 + e + kx - 1))
-template <int CPL, int F>
-__device__ __forceinline__ void tap9_source(const float* __restrict__ img, int h, int w, long P, int C, int Y0, int X0, int H, int W,
-                                            float sy, float sx, float (&acc)[4][4][CPL]) {
-  constexpr int NL = TapAxis<F>::NL;
-  constexpr int PER = F == 2 ? 2 : 3;                  // positions per line pair (F = 2, 4)
-  TapAxis<F> ay, axx;
-  tap_axis<F>(Y0, H, h, sy, ay);
-  tap_axis<F>(X0, W, w, sx, axx);
-  long off[NL][NL];
-#pragma unroll
-  for (int r = 0; r < NL; ++r)
-#pragma unroll
-    for (int c = 0; c < NL; ++c) off[r][c] = (static_cast<long>(ay.idx[r]) * w + axx.idx[c]) * P;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const float* tp = img + (ky * 3 + kx) * C;
-      TapVec<CPL> V[NL][NL];
-#pragma unroll
-      for (int r = 0; r < NL; ++r)
-#pragma unroll
-        for (int c = 0; c < NL; ++c) V[r][c] = tap_ld<CPL>(tp + off[r][c]);
-      float Hh[NL][4][CPL];
-#pragma unroll
-      for (int r = 0; r < NL; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int j = e + kx;
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) {
-            if constexpr (F != 0) {
-              const int c0 = j / PER;
-              Hh[r][e][q] = fmaf(axx.wb[j], V[r][c0 + 1].v[q], axx.wa[j] * V[r][c0].v[q]);
-            } else {
-              Hh[r][e][q] = fmaf(axx.w3[j][2], V[r][2].v[q], fmaf(axx.w3[j][1], V[r][1].v[q], axx.w3[j][0] * V[r][0].v[q]));
-            }
-          }
-        }
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int j = d + ky;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) {
-            if constexpr (F != 0) {
-              const int r0 = j / PER;
-              acc[d][e][q] = fmaf(ay.wb[j], Hh[r0 + 1][e][q], fmaf(ay.wa[j], Hh[r0][e][q], acc[d][e][q]));
-            } else {
-              acc[d][e][q] = fmaf(ay.w3[j][2], Hh[2][e][q], fmaf(ay.w3[j][1], Hh[1][e][q], fmaf(ay.w3[j][0], Hh[0][e][q], acc[d][e][q])));
-            }
-          }
-      }
-    }
-}
-
-template <int CPL>
-__global__ __launch_bounds__(256) void tapsum_head4_kernel(TapSumArgs a, int w_patches, long n_items) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-  const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u;       // XCD-aware order, as tapsum_kernel
-  const unsigned vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
-  const long item = static_cast<long>(vb) * 4 + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  long t = item;
-  const int h_patches = (a.H + 3) >> 2;
-  const int px = static_cast<int>(t % w_patches); t /= w_patches;
-  const int py = static_cast<int>(t % h_patches);
-  const int pair = static_cast<int>(t / h_patches);
-  const int Y0 = uni_i(py * 4), X0 = uni_i(px * 4);
-  const int n = pair * 2 + half, c = l32 * CPL;
-  const int nc = n < a.N ? n : a.N - 1, cc = c < a.C ? c : a.C - CPL;   // dead lanes walk valid memory and contribute nothing
-  const long P = 9L * a.C;
-  float acc[4][4][CPL];
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) acc[d][e][q] = 0.f;
-#pragma unroll 1
-  for (int s = 0; s < a.n_in; ++s) {
-    const int hs = a.h[s], ws = a.w[s];
-    const int f = a.H / hs;
-    const float* img = static_cast<const float*>(a.in[s]) + static_cast<long>(nc) * hs * ws * P + cc;
-    if (f == 2) tap9_source<CPL, 2>(img, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], acc);
-    else if (f == 4) tap9_source<CPL, 4>(img, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], acc);
-    else tap9_source<CPL, 0>(img, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], acc);
-  }
-  float bi[CPL], sc[CPL], sh[CPL], hw[CPL];
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) {
-    bi[q] = a.bias ? a.bias[cc + q] : 0.f;
-    sc[q] = a.scale ? a.scale[cc + q] : 1.f;
-    sh[q] = a.scale ? a.shift[cc + q] : 0.f;
-    hw[q] = c < a.C ? a.head_w[c + q] : 0.f;          // lanes beyond C contribute nothing to the pixel's dot product
-  }
-#pragma unroll
-  for (int d = 0; d < 4; ++d)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        float v = (acc[d][e][q] + bi[q]) * sc[q] + sh[q];
-        if (a.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
-        t2 = fmaf(v, hw[q], t2);
-      }
-      t2 = group_sum<32>(t2);
-      if (l32 == 0 && n < a.N && Y0 + d < a.H && X0 + e < a.W)
-        a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t2 + a.head_b[0]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Adjoint of tapsum with respect to one source's tap products (training): dY[n, iy, ix, tap, :] =
 //   sum_{Y, X} wy(Y -> iy) wx(X -> ix) dU[n, Y - dil (ky-1), X - dil (kx-1), :]   (terms outside the image drop out),
 // gather form, deterministic.  Separable like the plain resize adjoint (backward.hip): a row pass makes the three
@@ -426,18 +240,6 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
   a.head_w = head_w; a.head_b = head_b; a.head_out = head_out;
   DS_REQUIRE((!out || aligned16(out)) && (!bias || aligned16(bias)) && (!scale || (aligned16(scale) && aligned16(shift))), DIFFSAL_E_ALIGN,
              "tapsum: misaligned pointer");
-  // mt_proj form: head folded, dilation 1, fp32, every source at a factor 2 .. 64 (six positions span < 1 source line from 8 on)
-  bool head4 = head_out && dil == 1 && dtype == DIFFSAL_F32 && tune(TUNE_NO_TAPSUM_HEAD4) != 1 && H % 4 == 0 && W % 4 == 0;
-  for (int i = 0; i < n_src && head4; ++i) head4 = H / hs[i] >= 2 && H / hs[i] <= 64;
-  if (head4) {
-    const long n_items = static_cast<long>((N + 1) / 2) * (H / 4) * (W / 4);
-    const unsigned grid = static_cast<unsigned>((n_items + 3) / 4);
-    if (C % 3 == 0 && C / 3 <= 32 && C / 3 > 24)
-      hipLaunchKernelGGL((tapsum_head4_kernel<3>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, W / 4, n_items);
-    else
-      hipLaunchKernelGGL((tapsum_head4_kernel<4>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, W / 4, n_items);
-    return check_launch("tapsum(head)");
-  }
   const int slabs = (C + 127) / 128;
   const long n_items = static_cast<long>((N + 1) / 2) * ((H + 3) / 4) * ((W + 3) / 4) * slabs;
   DS_REQUIRE((n_items + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "tapsum: output too large");

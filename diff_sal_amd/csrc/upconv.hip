@@ -198,9 +198,44 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArg
   }
 }
 
+// The border pixels of z [N][h][w][C] in the order diffsal_up2_conv_commute reads their tap products: top row, bottom row, then the
+// left and the right column without their corner pixels -> zb [N][2 w + 2 h - 4][C].  16-byte pieces, one per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void border_gather_kernel(const T* __restrict__ z, T* __restrict__ zb, int N, int h, int w, int C) {
+  constexpr int EPP = 16 / sizeof(T);                 // elements per piece
+  const int ppx = C / EPP, nb = 2 * w + 2 * h - 4;
+  const long total = static_cast<long>(N) * nb * ppx;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * 256) {
+    const int q = static_cast<int>(i % ppx);
+    const long r = i / ppx;
+    const int b = static_cast<int>(r % nb), n = static_cast<int>(r / nb);
+    int y, x;
+    if (b < w) { y = 0; x = b; }
+    else if (b < 2 * w) { y = h - 1; x = b - w; }
+    else if (b < 2 * w + h - 2) { y = b - 2 * w + 1; x = 0; }
+    else { y = b - 2 * w - (h - 2) + 1; x = w - 1; }
+    const float4 v = *reinterpret_cast<const float4*>(z + ((static_cast<long>(n) * h + y) * w + x) * C + q * EPP);
+    *reinterpret_cast<float4*>(zb + r * C + q * EPP) = v;
+  }
+}
+
 }  // namespace diffsal
 
 using namespace diffsal;
+
+extern "C" int diffsal_border_gather(const void* z, void* zb, int N, int h, int w, int C, int dtype, diffsal_stream_t stream) {
+  DS_REQUIRE(z && zb, DIFFSAL_E_ARG, "border_gather: null argument");
+  DS_REQUIRE(N > 0 && h >= 2 && w >= 2 && C > 0 && C % 8 == 0, DIFFSAL_E_SHAPE, "border_gather: N=%d h=%d w=%d C=%d", N, h, w, C);
+  DS_REQUIRE(aligned16(z) && aligned16(zb), DIFFSAL_E_ALIGN, "border_gather: misaligned pointer");
+  const long pieces = static_cast<long>(N) * (2 * w + 2 * h - 4) * (C / (dtype == DIFFSAL_F32 ? 4 : 8));
+  long g = (pieces + 255) / 256;
+  g = g > 4096 ? 4096 : g;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(T) hipLaunchKernelGGL(border_gather_kernel<T>, dim3(static_cast<unsigned>(g)), dim3(256), 0, s, static_cast<const T*>(z), static_cast<T*>(zb), N, h, w, C)
+  DS_DTYPE_DISPATCH(dtype, "border_gather", CALL);
+#undef CALL
+  return check_launch("border_gather");
+}
 
 namespace {
 template <typename T>

@@ -687,22 +687,6 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
     return out
 
 
-_BORDER_IDX: dict = {}
-
-
-def _border_index(h: int, w: int, device) -> Tensor:
-    """Flat pixel indices (y * w + x) of the border lines of an h x w map in the order diffsal_up2_conv_commute reads them: top row,
-    bottom row, left column, right column (the columns without their corner pixels)."""
-    key = (h, w, str(device))
-    idx = _BORDER_IDX.get(key)
-    if idx is None:
-        xs, ys = torch.arange(w), torch.arange(h)
-        ys = ys[1:h - 1]                                   # the corners are in the row lists
-        idx = torch.cat([xs, (h - 1) * w + xs, ys * w, ys * w + (w - 1)]).to(device)
-        _BORDER_IDX[key] = idx
-    return idx
-
-
 def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
                    act: int = ACT_NONE, tag: str = "K12") -> Tensor:
     """act(BN(conv3x3(dilation 2, padding 2)(bilinear_up2(z)))) for z [N,h,w,Cin] (fp32, or bf16 / fp16 storage) -> [N,2h,2w,Cout]:
@@ -715,7 +699,10 @@ def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Op
     N, h, w, Cin = z.shape
     Cout = w_packed.shape[0]
     c_ext = conv_igemm(z, w_packed, kh=3, kw=3, pad=(2, 2), dil=(1, 1), out_hw=(h + 2, w + 2), tag=tag, wino=wino)
-    zb = z.reshape(N, h * w, Cin).index_select(1, _border_index(h, w, z.device))
+    z = z.contiguous()
+    zb = torch.empty((N, 2 * w + 2 * h - 4, Cin), device=z.device, dtype=z.dtype)
+    dt = _dt(z)
+    _lib.check(lib.diffsal_border_gather(_pa(z, dt), _pa(zb, dt), N, h, w, Cin, dt, _stream()), "border_gather")
     tb = linear(zb, tapw, None, tag=tag)                                   # [N, 2w + 2h - 4, 9 * Cout]
     out = torch.empty((N, 2 * h, 2 * w, Cout), device=z.device, dtype=z.dtype)
     with _prof(tag + "-tap", 0.0, _nb(c_ext, tb, out), f"up2 commute {h}x{w} C={Cout}" if PROFILE is not None else "") as pr:

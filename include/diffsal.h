@@ -227,6 +227,9 @@ int diffsal_gn_affine(const void* x, const float* gamma, const float* beta, floa
                       float eps, void* ws, size_t ws_bytes, int dtype, diffsal_stream_t stream);
 int diffsal_gn_affine_wino4(const diffsal_conv_desc* d /*host*/, const double* stats, const float* gamma, const float* beta,
                             int groups, float eps, float* ab, diffsal_stream_t stream);
+/* zb [N][2 w + 2 h - 4][C] = the border pixels of z [N][h][w][C] in the order diffsal_up2_conv_commute reads their tap products
+ * (top row, bottom row, left column, right column; the columns without their corner pixels).  C % 8 == 0. */
+int diffsal_border_gather(const void* z, void* zb, int N, int h, int w, int C, int dtype, diffsal_stream_t stream);
 /* conv3x3(dilation 2, padding 2)(bilinear_up2(z)) -> BN affine -> activation (UpEmbed's first convolution,
  * R/models/saliency_decoder/common_block.py:196-206) from c_ext = conv3x3(z) (dilation 1, zero padding) evaluated at the SOURCE
  * resolution on the grid extended by one pixel on every side ([N][h + 2][w + 2][C]: diffsal_conv_wino4 / diffsal_conv_igemm with

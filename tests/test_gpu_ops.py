@@ -476,11 +476,13 @@ def test_tapsum_equals_conv_of_upsampled_sum(ops, case):
     assert rel_err(got, nhwc(ref)) < 1e-5
 
 
-@pytest.mark.parametrize("N,Cout,H,W", [(4, 96, 16, 32), (3, 32, 20, 24), (1, 128, 8, 16)])
-def test_tapsum_with_folded_head(ops, N, Cout, H, W):
+@pytest.mark.parametrize("N,Cout,H,W,factors", [(4, 96, 16, 32, (2, 4)), (3, 32, 20, 24, (2, 4)), (1, 128, 8, 16, (2, 4)),
+                                                (2, 96, 32, 64, (16, 8, 4, 2)),      # mt_proj's four scales
+                                                (3, 96, 64, 64, (32, 16, 8))])        # 2-line sources, odd batch
+def test_tapsum_with_folded_head(ops, N, Cout, H, W, factors):
     """MLPHead (1x1 to one channel + sigmoid, common_block.py:111-122) in the gather's epilogue == tapsum then head_sigmoid,
     for even / odd batches (the second image of a lane pair may be missing) and channel counts below the 128-lane slab."""
-    Cin, factors = 64, (2, 4)
+    Cin = 64
     zs = [rnd("hz%d" % f, N, Cin, H // f, W // f) for f in factors]
     w = rnd("hw", Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
     b, sc, sh = rnd("hb", Cout, scale=0.1), 1.0 + rnd("hsc", Cout, scale=0.1), rnd("hsh", Cout, scale=0.1)

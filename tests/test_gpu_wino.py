@@ -245,3 +245,25 @@ def test_resblock_extras_of_the_f4_path(case, tuning):
     h_un = ops.conv_igemm(hn, ops.pack_conv_weight(w1.to(DEV)), kh=3, kw=3, pad=(1, 1), bias=b1.to(DEV), rowvec=temb.to(DEV),
                           wino=ops.WinoWeights(w1.to(DEV)))
     assert rel_err(h, h_un.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(4, 28, 48, 192, 384), (36, 14, 24, 384, 384), (4, 14, 24, 384, 768)], ids=str)
+def test_batched_position_products_xcd_order_is_bit_identical(case, tuning):
+    """The XCD-aware unit order of the batched launch (an XCD owns whole (position, M tile) rows) changes which workgroup computes a
+    unit, not the unit's arithmetic: results equal the plain order bit for bit, with and without the appended shortcut product."""
+    from diff_sal_amd import ops
+
+    N, H, W, Cin, Cout = case
+    tuning.set("DIFFSAL_FORCE_WINOGRAD", 1)
+    x = rnd("xx", N, H, W, Cin).to(DEV)
+    u = ops.pack_wino4_weight(rnd("xw", Cout, Cin, 3, 3, scale=0.05).to(DEV))
+    wn = rnd("xn", Cout, Cin, scale=0.1).to(DEV)
+    plan = ops.resblock_wino4_plan(x, Cout, 32)
+    side = (x, wn) if plan is not None and plan["side"] else None
+    tuning.set("DIFFSAL_BATCH_XCD", 1)              # off by default (measured slower): the order is still kept correct
+    a, sa, _ = ops.conv3x3_wino4_ex(x, u, side=side)
+    tuning.set("DIFFSAL_BATCH_XCD", None)
+    b, sb, _ = ops.conv3x3_wino4_ex(x, u, side=side)
+    assert torch.equal(a, b)
+    if side is not None:
+        assert torch.equal(sa, sb)

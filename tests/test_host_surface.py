@@ -155,6 +155,24 @@ def test_bench_spawns_its_own_ranks():
         assert r.returncode == 0 and json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 2
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
+def test_bench_train_plumbing_at_eight_ranks_keeps_the_replicas_identical(mode):
+    """`bench.py --workload train --gpus 8` on a GPU-less host: eight gloo ranks run three optimizer steps of the exchange
+    plumbing, each rank at its OWN timestep per step (the reference draws t0 per rank-batch from an unseeded generator,
+    R/diffusion_trainer.py:111) -- the replicas must stay bit-identical, in either exchange form."""
+    if torch.cuda.is_available():
+        pytest.skip("plumbing-only mode is for GPU-less hosts")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "train", "--steps", "3", "--warmup", "1",
+                        "--exchange", mode], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    ex = j["exchange"]
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["unit"] == "samples/s" and j["value"] is None
+    assert ex["world"] == 8 and ex["steps"] == 3 and ex["rank_dependent_t0"] and ex["mode"] == mode
+    assert ex["collective_executed"] and ex["replicas_identical"] is True
+
+
 def test_step_invariant_shortcut_checks_its_precondition():
     from diff_sal_amd.sampling import DiffusionSampler
 

@@ -32,6 +32,6 @@ bad = 0
 for i, b in enumerate(priv):
     if b:
         bad += 1
-        nm = subprocess.run([f"{LLVM}/llvm-cxxfilt", kern[i]], capture_output=True, text=True).stdout.strip() if i < len(kern) else "?"
+        nm = subprocess.run(["c++filt", kern[i]], capture_output=True, text=True).stdout.strip() if i < len(kern) else "?"
         print(f"  scratch {b:6d} B  spilled vgprs {spill[i] if i < len(spill) else '?':>4}  {nm[:150]}")
 print(f"{bad} kernels with scratch")
