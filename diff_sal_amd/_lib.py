@@ -33,7 +33,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 
 SIGNATURES = {
@@ -136,6 +136,7 @@ SIGNATURES = {
     "diffsal_conv_wino4_side_supported": (c_i, [C.POINTER(ConvDesc), C.c_long]),
     "diffsal_gn_affine": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f, c_sz, c_i, c_f]),
     "diffsal_gn_affine_wino4": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_i, c_fl, c_f, c_f]),
+    "diffsal_workspace_bytes": (c_sz, [c_i, C.POINTER(ConvDesc), C.POINTER(C.c_long), c_i]),
     "diffsal_border_gather": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_up2_conv_commute": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
@@ -162,6 +163,16 @@ SIGNATURES = {
     "diffsal_grad_norm": (c_i, [c_f, C.c_long, c_fl, c_f, c_f, c_f]),
     "diffsal_adam_step": (c_i, [c_f] * 4 + [C.c_long] + [C.c_double] * 5 + [c_i, c_fl, c_f, c_fl, c_i, c_f]),
 }
+
+(WS_GROUPNORM, WS_CONV_IGEMM, WS_CONV_WINO, WS_CONV_WINO4, WS_CONV_WINO4_STATS, WS_CONV_WGRAD, WS_WGRAD_SEGMENTED, WS_TAPSUM_BWD,
+ WS_SALIENCY_METRICS, WS_ATTENTION_TAIL, WS_ATTENTION_BWD_QTAIL) = range(11)      # enum DIFFSAL_WS_* of include/diffsal.h
+
+
+def workspace_bytes(op: int, desc=None, dims=()):
+    """``diffsal_workspace_bytes``: scratch bytes of operator ``op`` (WS_*) for a descriptor and / or a tuple of integers."""
+    arr = (C.c_long * len(dims))(*[int(v) for v in dims]) if dims else None
+    return load().diffsal_workspace_bytes(op, C.byref(desc) if desc is not None else None, arr, len(dims))
+
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 ACT_GELU_GRAD = 5      # training only: product * gelu'(residual) (include/diffsal.h)

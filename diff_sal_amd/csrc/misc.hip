@@ -27,7 +27,7 @@ static const char* const kTuneNames[TUNE_COUNT] = {
     "DIFFSAL_NO_PERSIST", "DIFFSAL_NO_XCD_ORDER", "DIFFSAL_NO_HALO", "DIFFSAL_FORCE_HALO", "DIFFSAL_IGEMM_CFG",
     "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
     "DIFFSAL_NO_FUSED_BLOCK", "DIFFSAL_NO_WINOGRAD", "DIFFSAL_FORCE_WINOGRAD", "DIFFSAL_GN_CHUNKS", "DIFFSAL_GN_APPLY_WGS",
-    "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD"};
+    "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD", "DIFFSAL_NO_TAPSUM_ROWS"};
 static int g_tune[TUNE_COUNT];
 static const bool g_tune_init = [] {
   for (int k = 0; k < TUNE_COUNT; ++k) {
@@ -666,7 +666,28 @@ static int ew_grid(long total_threads) {
 
 using namespace diffsal;
 
-extern "C" int diffsal_version(void) { return 34; }  // = _lib.ABI_VERSION
+extern "C" size_t diffsal_workspace_bytes(int op, const diffsal_conv_desc* d, const long* dims, int n_dims) {
+  auto D = [&](int i) { return static_cast<int>(dims[i]); };
+  const bool have = dims != nullptr;
+  switch (op) {
+    case DIFFSAL_WS_GROUPNORM: return have && n_dims == 2 ? diffsal_groupnorm_ws_bytes(D(0), D(1)) : 0;
+    case DIFFSAL_WS_CONV_IGEMM: return d ? diffsal_conv_igemm_ws_bytes(d) : 0;
+    case DIFFSAL_WS_CONV_WINO: return d ? diffsal_conv_wino_ws_bytes(d) : 0;
+    case DIFFSAL_WS_CONV_WINO4: return d ? diffsal_conv_wino4_ws_bytes(d) : 0;
+    case DIFFSAL_WS_CONV_WINO4_STATS: return d && have && n_dims == 1 ? diffsal_conv_wino4_stats_bytes(d, D(0)) : 0;
+    case DIFFSAL_WS_CONV_WGRAD: return d ? diffsal_conv_wgrad_ws_bytes(d) : 0;
+    case DIFFSAL_WS_WGRAD_SEGMENTED: return have && n_dims == 4 ? diffsal_wgrad_segmented_ws_bytes(D(0), D(1), D(2), D(3)) : 0;
+    case DIFFSAL_WS_TAPSUM_BWD: return have && n_dims == 4 ? static_cast<size_t>(diffsal_tapsum_bwd_ws_bytes(D(0), D(1), D(2), D(3))) : 0;
+    case DIFFSAL_WS_SALIENCY_METRICS: return have && n_dims == 1 ? diffsal_saliency_metrics_ws_bytes(D(0)) : 0;
+    case DIFFSAL_WS_ATTENTION_TAIL:
+      return have && n_dims == 5 ? sizeof(float) * diffsal_attention_general_tail_floats(D(0), D(1), D(2), D(3), D(4)) : 0;
+    case DIFFSAL_WS_ATTENTION_BWD_QTAIL:
+      return have && n_dims == 6 ? sizeof(float) * diffsal_attention_general_bwd_qtail_floats(D(0), D(1), D(2), D(3), D(4), D(5)) : 0;
+    default: return 0;
+  }
+}
+
+extern "C" int diffsal_version(void) { return 35; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 extern "C" const char* diffsal_last_gemm_kernel(void) { return g_kernel; }
 

@@ -606,9 +606,10 @@ extern "C" size_t diffsal_groupnorm_ws_bytes(int B, int groups) {
 // through memory and no second launch (K3: six GroupNorms per step were twelve launches of ~8 us, 0.8 TB/s).  A pixel's group
 // slice is VEC * U consecutive floats (3, 6, 12 or 24 at 32 groups and C = 96 .. 768); item i = (pixel i / U, piece i % U).
 // R/models/saliency_decoder/sal_unet.py:36-44 (Normalize + nonlinearity).
-template <int VEC, int U>
-__global__ __launch_bounds__(1024) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ out, int HW, int C,
+// T: storage type of x / out (fp32, or bf16 / f16: the slab in LDS and all arithmetic stay fp32, one rounding on the way out)
+template <typename T, int VEC, int U>
+__global__ __launch_bounds__(1024) void gn_slab_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ out, int HW, int C,
                                                        int groups, float eps, int swish) {
   constexpr int CPG = VEC * U;
   extern __shared__ __attribute__((aligned(16))) float gn_slab[];
@@ -616,10 +617,11 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const float* __restrict__
   __shared__ float gb[2 * CPG];
   const int tid = threadIdx.x, g = blockIdx.x, n = blockIdx.y;
   const int items = HW * U;
-  const float* xs = x + static_cast<long>(n) * HW * C + g * CPG;
-  float* os = out + static_cast<long>(n) * HW * C + g * CPG;
+  const T* xs = x + static_cast<long>(n) * HW * C + g * CPG;
+  T* os = out + static_cast<long>(n) * HW * C + g * CPG;
   if (tid < CPG) { gb[tid] = gamma[g * CPG + tid]; gb[CPG + tid] = beta[g * CPG + tid]; }
   struct __attribute__((packed, aligned(VEC == 4 ? 16 : 4))) Piece { float v[VEC]; };   // C / groups = 12, 24: 16-byte aligned pieces
+  struct __attribute__((packed, aligned(VEC == 4 ? 4 * sizeof(T) : sizeof(T)))) PieceT { T v[VEC]; };   // the same piece in memory
   auto block_sum = [&](float v) -> double {        // fp32 inside a wavefront, fp64 across the 16 wavefronts, fixed order
     v = group_sum<64>(v);
     __syncthreads();
@@ -634,7 +636,10 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const float* __restrict__
 #pragma unroll 4
   for (int i = tid; i < items; i += 1024) {
     const int pix = i / U, u = i - pix * U;
-    const Piece p = *reinterpret_cast<const Piece*>(xs + static_cast<long>(pix) * C + u * VEC);
+    const PieceT pt = *reinterpret_cast<const PieceT*>(xs + static_cast<long>(pix) * C + u * VEC);
+    Piece p;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) p.v[e] = static_cast<float>(pt.v[e]);
     *reinterpret_cast<Piece*>(gn_slab + i * VEC) = p;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s += p.v[e];
@@ -657,12 +662,16 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const float* __restrict__
       const float y = (p.v[e] - mean) * rstd * gb[u * VEC + e] + gb[CPG + u * VEC + e];
       p.v[e] = swish ? swishf(y) : y;
     }
-    *reinterpret_cast<Piece*>(os + static_cast<long>(pix) * C + u * VEC) = p;
+    PieceT po;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) po.v[e] = static_cast<T>(p.v[e]);
+    *reinterpret_cast<PieceT*>(os + static_cast<long>(pix) * C + u * VEC) = po;
   }
 }
 
 // 1 if launched, 0 if the shape does not fit (the caller runs the statistics + normalisation launches)
-static int try_gn_slab(const float* x, const float* gamma, const float* beta, float* out, int B, int HW, int C, int groups, float eps,
+template <typename T>
+static int try_gn_slab(const T* x, const float* gamma, const float* beta, T* out, int B, int HW, int C, int groups, float eps,
                        int swish, hipStream_t s) {
   if (tune(TUNE_GN_CHUNKS) > 0 || tune(TUNE_GN_APPLY_WGS) > 0 || tune(TUNE_NO_GN_SLAB) == 1) return 0;   // the two-launch path is being tuned / forced
   const int cpg = C / groups;
@@ -673,8 +682,8 @@ static int try_gn_slab(const float* x, const float* gamma, const float* beta, fl
   if (lds > 150 * 1024 || static_cast<long>(B) * groups < 128) return 0;
 #define GN_SLAB(VEC, U)                                                                                          \
   do {                                                                                                           \
-    DS_RAISE_DYNAMIC_LDS((gn_slab_kernel<VEC, U>), 152 * 1024);                                                  \
-    hipLaunchKernelGGL((gn_slab_kernel<VEC, U>), dim3(groups, B), dim3(1024), lds, s, x, gamma, beta, out, HW, C, groups, eps, swish); \
+    DS_RAISE_DYNAMIC_LDS((gn_slab_kernel<T, VEC, U>), 152 * 1024);                                               \
+    hipLaunchKernelGGL((gn_slab_kernel<T, VEC, U>), dim3(groups, B), dim3(1024), lds, s, x, gamma, beta, out, HW, C, groups, eps, swish); \
   } while (0)
   if (cpg == 3) GN_SLAB(3, 1);
   else if (cpg == 6) GN_SLAB(3, 2);
@@ -688,8 +697,8 @@ static int try_gn_slab(const float* x, const float* gamma, const float* beta, fl
 template <typename T>
 static int groupnorm_swish_t(const T* x, const float* gamma, const float* beta, T* out, int B, int HW, int C, int groups,
                              float eps, void* ws, hipStream_t s, int swish = 1) {
-  if constexpr (sizeof(T) == 4) {
-    const int r = try_gn_slab(reinterpret_cast<const float*>(x), gamma, beta, reinterpret_cast<float*>(out), B, HW, C, groups, eps, swish, s);
+  {
+    const int r = try_gn_slab<T>(x, gamma, beta, out, B, HW, C, groups, eps, swish, s);
     if (r != 0) return r < 0 ? r : DIFFSAL_OK;
   }
   const int chunks = gn_chunks();

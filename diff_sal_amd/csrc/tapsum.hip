@@ -169,6 +169,208 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// mt_proj form (R/models/saliency_decoder/sal_unet.py:480-489, :407: dilation 1, every source at a power-of-two factor, MLPHead
+// folded): the same gather, reorganised so that it is no longer bound by vector-instruction issue.
+//
+// A 4 x 4 output patch whose origin is a multiple of 4, shifted by the nine taps, touches the 6 x 6 target positions
+// (Y0 - 1 + j, X0 - 1 + i), j, i = 0..5; per source and axis they read NL = 4 (factor 2) or 3 (factor >= 4) consecutive source
+// lines.  tapsum_kernel recomputes coordinates and two 4 x 4 weight tables for each of the 36 (tap, source) pairs and then
+// interpolates densely: ~35 K instructions per wavefront, vector-issue bound at 134 us.  Here, per source:
+//   * the six positions of an axis are set up ONCE (weights of bilin_coord: align_corners = False, index clamped; a position
+//     outside the image has weight 0 -- the convolution's zero padding);
+//   * the sum runs over (ky, source line r):  G[e] = sum_kx sum_c wx[e + kx][c] Y[ky, kx][r][c]  (the horizontal pass of the
+//     three taps of a kernel row TOGETHER), then acc[d][e] += wy[d + ky][r] G[e]: the vertical pass is paid once per kernel row,
+//     not once per tap -- 360-480 FMAs per channel, patch and source where the per-tap separable form needs 864-1152;
+//   * factor 2 / 4: the column pair of position i is the compile-time pattern i / 2, i / 3 (two-tap horizontal pass);
+//   * (ky, r) are RUNTIME loops (the vertical weights come from a 24-entry table in LDS, written once per source), the loads
+//     of the next (ky, r) are issued before the current one is summed: ~5 K instructions per wavefront at ~150 registers.
+//     (A fully unrolled per-tap version was built first: hipcc gave it 300-400 registers whatever the ring depth, one
+//     wavefront per SIMD, and it was no faster than tapsum_kernel -- profiles/NOTES.md.)
+// CPL channels per lane: 3 when C = 96 (all 32 lanes of an image's half-wave busy), else 4.
+// ------------------------------------------------------------------------------------------------
+template <int CPL> struct TapVec { float v[CPL]; };
+// uniform base (scalar registers) + this lane's 32-bit byte offset: addressed by the hardware as saddr + voffset
+template <int CPL>
+__device__ __forceinline__ TapVec<CPL> tap_ld(const char* ubase, unsigned lane_byte) {
+  TapVec<CPL> r;
+  const char* p = ubase + static_cast<unsigned long>(lane_byte);
+  if constexpr (CPL == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+  else {
+    struct __attribute__((packed, aligned(4))) Piece { float v[CPL]; };      // one 12-byte load
+    const Piece t = *reinterpret_cast<const Piece*>(p);
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) r.v[e] = t.v[e];
+  }
+  return r;
+}
+
+// position p of an axis of L target / n source samples (factor f = L / n): the pair's lower line BEFORE clamping and the weights
+// (a on it, b on the next); a = b = 0 outside [0, L)
+__device__ __forceinline__ void tap_pos(int p, int L, int n, float scale, int& lower, float& a, float& b) {
+  const int f = L / n;
+  const bool valid = p >= 0 && p < L;
+  int i0, i1;
+  float l1;
+  bilin_coord(valid ? p : 0, scale, n, i0, i1, l1);
+  const int num = 2 * p + 1 - f;                    // floor((p + 0.5) / f - 0.5), -1 where bilin_coord clamps the coordinate at 0
+  lower = num >= 0 ? num / (2 * f) : -1;
+  a = 1.f - l1;
+  b = l1;
+  if (lower < 0) { a = 0.f; b = 1.f; }              // both lines of the pair clamp to line 0: its whole weight
+  if (!valid) { a = 0.f; b = 0.f; }
+}
+
+template <int CPL, int F>
+__device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, unsigned lane_byte, int h, int w, int P, int C, int Y0,
+                                                int X0, int H, int W, float sy, float sx, float* __restrict__ wtab,
+                                                float (&acc)[4][4][CPL]) {
+  constexpr int NL = F == 2 ? 4 : 3;
+  constexpr int PER = F == 2 ? 2 : 3;
+  const int lane = threadIdx.x & 63;
+  // ---- x axis: six positions, weights in registers (every lane computes the same values)
+  float wxa[6], wxb[6];
+  int xr[6], first_x = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int lower;
+    tap_pos(X0 - 1 + i, W, w, sx, lower, wxa[i], wxb[i]);
+    if (i == 0) first_x = lower;
+    xr[i] = lower - first_x;                        // F = 2, 4: i / PER by construction; F = 0: 0 or 1
+  }
+  first_x = uni_i(first_x);
+  unsigned coff[NL];
+#pragma unroll
+  for (int c = 0; c < NL; ++c) coff[c] = static_cast<unsigned>(uni_i(min(max(first_x + c, 0), w - 1)) * P * 4);
+  // ---- y axis: dense weights wtab[j * 4 + r] of line r (0 .. NL-1) for position j, one entry per lane
+  int first_y;
+  {
+    float a0, b0;
+    tap_pos(Y0 - 1, H, h, sy, first_y, a0, b0);
+    first_y = uni_i(first_y);
+    if (lane < 24) {
+      const int j = lane >> 2, r = lane & 3;
+      int lower;
+      float a, b;
+      tap_pos(Y0 - 1 + j, H, h, sy, lower, a, b);
+      wtab[lane] = (lower - first_y == r ? a : 0.f) + (lower - first_y + 1 == r ? b : 0.f);
+    }
+  }
+  // ---- (ky, r) items; item it = ky * NL + r.  V[kx][c]: the NL vectors of source line r in tap (ky, kx)
+  constexpr int NIT = 3 * NL;
+  auto fetch = [&](TapVec<CPL> (&V)[3][NL], int it) __attribute__((always_inline)) {
+    const int ky = it / NL, r = it - ky * NL;
+    const int row = min(max(first_y + r, 0), h - 1);
+    const unsigned roff = static_cast<unsigned>(uni_i(row * w) * P * 4 + ky * 3 * C * 4);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int c = 0; c < NL; ++c) V[kx][c] = tap_ld<CPL>(src + (roff + coff[c] + static_cast<unsigned>(kx * C * 4)), lane_byte);
+  };
+  auto sum = [&](const TapVec<CPL> (&V)[3][NL], int it) __attribute__((always_inline)) {
+    const int ky = it / NL, r = it - ky * NL;
+    float wv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) wv[d] = wtab[(d + ky) * 4 + r];
+    float G[4][CPL];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) G[e][q] = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = e + kx;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          if constexpr (F != 0) {
+            G[e][q] = fmaf(wxb[i], V[kx][i / PER + 1].v[q], fmaf(wxa[i], V[kx][i / PER].v[q], G[e][q]));
+          } else {          // factor >= 8: the pair of position i starts at column xr[i] in {0, 1}: dense three-column weights
+            const float w0 = xr[i] == 0 ? wxa[i] : 0.f, w1 = xr[i] == 0 ? wxb[i] : wxa[i], w2 = xr[i] == 0 ? 0.f : wxb[i];
+            G[e][q] = fmaf(w2, V[kx][2].v[q], fmaf(w1, V[kx][1].v[q], fmaf(w0, V[kx][0].v[q], G[e][q])));
+          }
+        }
+      }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc[d][e][q] = fmaf(wv[d], G[e][q], acc[d][e][q]);
+  };
+  TapVec<CPL> Va[3][NL], Vb[3][NL];
+  fetch(Va, 0);
+#pragma unroll 1
+  for (int it = 0; it < NIT; it += 2) {            // two items per trip: the register sets swap roles without copies
+    if (it + 1 < NIT) fetch(Vb, it + 1);
+    sum(Va, it);
+    if (it + 1 < NIT) {
+      if (it + 2 < NIT) fetch(Va, it + 2);
+      sum(Vb, it + 1);
+    }
+  }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void tapsum_head_rows_kernel(TapSumArgs a, int w_patches, long n_items) {
+  __shared__ float wtab_all[4][32];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u;       // XCD-aware order, as tapsum_kernel
+  const unsigned vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+  const long item = static_cast<long>(vb) * 4 + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  float* wtab = wtab_all[threadIdx.x >> 6];
+  long t = item;
+  const int h_patches = a.H >> 2;
+  const int px = static_cast<int>(t % w_patches); t /= w_patches;
+  const int py = static_cast<int>(t % h_patches);
+  const int pair = static_cast<int>(t / h_patches);
+  const int Y0 = uni_i(py * 4), X0 = uni_i(px * 4);
+  const int n = pair * 2 + half, c = l32 * CPL;
+  const int nc = n < a.N ? n : a.N - 1, cc = c < a.C ? c : a.C - CPL;   // dead lanes walk valid memory and contribute nothing
+  const int P = 9 * a.C;
+  float acc[4][4][CPL];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) acc[d][e][q] = 0.f;
+#pragma unroll 1
+  for (int s = 0; s < a.n_in; ++s) {
+    const int hs = a.h[s], ws = a.w[s];
+    const int f = a.H / hs;
+    const char* src = static_cast<const char*>(a.in[s]);
+    const unsigned lane_byte = static_cast<unsigned>((static_cast<long>(nc) * hs * ws * P + cc) * 4);     // < 4 GiB: checked by the host
+    if (f == 2) tap_source_rows<CPL, 2>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
+    else if (f == 4) tap_source_rows<CPL, 4>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
+    else tap_source_rows<CPL, 0>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
+  }
+  float bi[CPL], sc[CPL], sh[CPL], hw[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    bi[q] = a.bias ? a.bias[cc + q] : 0.f;
+    sc[q] = a.scale ? a.scale[cc + q] : 1.f;
+    sh[q] = a.scale ? a.shift[cc + q] : 0.f;
+    hw[q] = c < a.C ? a.head_w[c + q] : 0.f;          // lanes beyond C contribute nothing to the pixel's dot product
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        float v = (acc[d][e][q] + bi[q]) * sc[q] + sh[q];
+        if (a.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
+        t2 = fmaf(v, hw[q], t2);
+      }
+      t2 = group_sum<32>(t2);
+      if (l32 == 0 && n < a.N) a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t2 + a.head_b[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adjoint of tapsum with respect to one source's tap products (training): dY[n, iy, ix, tap, :] =
 //   sum_{Y, X} wy(Y -> iy) wx(X -> ix) dU[n, Y - dil (ky-1), X - dil (kx-1), :]   (terms outside the image drop out),
 // gather form, deterministic.  Separable like the plain resize adjoint (backward.hip): a row pass makes the three
@@ -240,6 +442,19 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
   a.head_w = head_w; a.head_b = head_b; a.head_out = head_out;
   DS_REQUIRE((!out || aligned16(out)) && (!bias || aligned16(bias)) && (!scale || (aligned16(scale) && aligned16(shift))), DIFFSAL_E_ALIGN,
              "tapsum: misaligned pointer");
+  // mt_proj form: head folded, dilation 1, fp32, H and W multiples of 4, every source at a factor 2 .. 64
+  bool rows = head_out && dil == 1 && dtype == DIFFSAL_F32 && tune(TUNE_NO_TAPSUM_ROWS) != 1 && H % 4 == 0 && W % 4 == 0;
+  for (int i = 0; i < n_src && rows; ++i)
+    rows = H / hs[i] >= 2 && H / hs[i] <= 64 && static_cast<long>(N) * hs[i] * ws[i] * 9 * C * 4 < (1L << 32) - (1L << 20);
+  if (rows) {
+    const long n_items = static_cast<long>((N + 1) / 2) * (H / 4) * (W / 4);
+    const unsigned grid = static_cast<unsigned>((n_items + 3) / 4);
+    if (C % 3 == 0 && C / 3 <= 32 && C / 3 > 24)
+      hipLaunchKernelGGL((tapsum_head_rows_kernel<3>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, W / 4, n_items);
+    else
+      hipLaunchKernelGGL((tapsum_head_rows_kernel<4>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, W / 4, n_items);
+    return check_launch("tapsum(head)");
+  }
   const int slabs = (C + 127) / 128;
   const long n_items = static_cast<long>((N + 1) / 2) * ((H + 3) / 4) * ((W + 3) / 4) * slabs;
   DS_REQUIRE((n_items + 3) / 4 < (1L << 31), DIFFSAL_E_SHAPE, "tapsum: output too large");

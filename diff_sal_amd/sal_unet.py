@@ -262,7 +262,7 @@ class SalUNet(nn.Module):
     def _use_tap_conv(self, taps, which: str) -> bool:
         # fp32 storage: the 3x3 convolutions are bound by the matrix rate, so 3-4x fewer FLOPs is 3x less time -- every use.
         # 16-bit storage: only the uses listed in tap_conv16 (where GEMM + gather beat up-sampling + convolution).
-        if not self.tap_conv or taps is not None:
+        if not self.tap_conv or (taps is not None and self.taps_reference_forms):
             return False
         return self.compute_dtype == torch.float32 or which in self.tap_conv16
 
@@ -578,6 +578,10 @@ class SalUNet(nn.Module):
     # shortcut inside conv1's batched launch, norm2's statistics from conv1's output transform (ops.conv3x3_wino4_ex).  Off: the
     # per-operator launches
     fuse_resblock = True
+    # forward(..., taps=dict): intermediate tensors are recorded while the SHIPPED forms run (tap / source-resolution forms of
+    # UpEmbed's first convolution and mt_proj, fused ResnetBlocks); only the 4-scale sum `multi_scale` does not exist there.  True:
+    # the reference's operator order (bilinear up-sampling, then the 3x3 convolutions) with every tap, `multi_scale` included
+    taps_reference_forms = False
     _freq_tables: dict = {}       # (device, half) -> timestep-embedding frequencies on the device (constant)
     fold_head = True        # tap path of mt_proj: MLPHead's 96 -> 1 dot product + sigmoid in the gather's epilogue
     merge_qkv_prep = True   # query (dw 3x3 + LN) and pooled key / value (dw k x k + LN) branches of a block in one launch
@@ -712,7 +716,8 @@ class SalUNet(nn.Module):
                 d = self.dilation[i]
                 f32c = (self._use_tap_conv(taps, f"s{i}") and self.compute_dtype == torch.float32 and pk[f"s{i}.pe1.wino"] is not None
                         and h >= 12 and w >= 12)
-                lowc = self.compute_dtype != torch.float32 and self.up_commute16 and taps is None and h >= 2 and w >= 2
+                lowc = (self.compute_dtype != torch.float32 and self.up_commute16 and not (taps is not None and self.taps_reference_forms)
+                        and h >= 2 and w >= 2)
                 if self.up_commute and d == 2 and (f32c or lowc):
                     # the convolution at the source resolution + interpolation + border-ring corrections.  fp32: F(4x4) there, and only
                     # where the interior is most of the map (stages 2 and 3 at 224 x 384; the alternative is the tap path).  16-bit

@@ -384,16 +384,35 @@ class DiffusionTrainStep:
         data["input"] = x_t
         return self.model(data, t)
 
-    def _sync_buffers(self) -> None:
-        bufs = [b for b in self.model.buffers() if b.dtype.is_floating_point]
-        if not bufs:
+    def _flatten_buffers(self) -> None:
+        """Floating-point buffers (BatchNorm running statistics) become views into ONE flat tensor, once: the per-step broadcast
+        of rank 0's buffers (DDP's ``broadcast_buffers=True``, R/model.py:15) is then a single collective on that tensor -- no
+        gather before it and no copy kernel per buffer after it (the denoiser + encoders hold ~100 such buffers; the copies were
+        most of the exchange's exposed time at one rank).  Kernels that update running statistics write through the views."""
+        bufs = [b for b in self.model.buffers() if b.dtype == torch.float32 and b.numel() > 0]
+        self._flat_buffers = None
+        if not bufs or any(b.device != bufs[0].device for b in bufs):
             return
-        flat = torch.cat([b.reshape(-1) for b in bufs])
-        dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        off = 0
+        off, offs = 0, []
         for b in bufs:
-            b.copy_(flat[off:off + b.numel()].view(b.shape))
-            off += b.numel()
+            offs.append(off)
+            off += _aligned(b.numel())
+        flat = torch.zeros(off, device=bufs[0].device, dtype=torch.float32)
+        for b, o in zip(bufs, offs):
+            view = flat[o:o + b.numel()].view(b.shape)
+            view.copy_(b)
+            b.data = view
+        self._flat_buffers = flat
+
+    def _sync_buffers(self) -> None:
+        if getattr(self, "_flat_buffers", "unset") == "unset":
+            self._flatten_buffers()
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        if self._flat_buffers is not None:
+            dist.broadcast(self._flat_buffers, src=src, group=self.group)
+        others = [b for b in self.model.buffers() if b.dtype.is_floating_point and b.dtype != torch.float32 and b.numel() > 0]
+        for b in others:           # none in the reference's model; kept exact for foreign modules
+            dist.broadcast(b, src=src, group=self.group)
 
     def loss_and_backward(self, x0: Tensor, x_t: Tensor, t: Tensor, cond: Dict) -> Tensor:
         """Forward + loss + backward + gradient exchange; leaves the rank-SUMMED gradient in ``flat.flat_g``."""

@@ -155,6 +155,26 @@ enum { DIFFSAL_PREC_FP32 = 0, DIFFSAL_PREC_BF16X3 = 1 };
  * normalisation, softmax and all accumulations stay fp32; parameters of norms, biases and the timestep path stay fp32. */
 enum { DIFFSAL_F32 = 0, DIFFSAL_BF16 = 1, DIFFSAL_F16 = 2 };
 
+/* ---- scratch sizes, one entry point --------------------------------------------------------------------------
+ * Bytes of caller-provided scratch the operator `op` needs for a shape: `d` for the operators described by a diffsal_conv_desc,
+ * `dims` (n_dims integers, in the order of the typed function's arguments) for the others; 0 = the operator needs none for this
+ * shape, or op / argument count unknown.  The typed functions below (diffsal_*_ws_bytes, ..._floats) are the same numbers with
+ * named arguments; the library never allocates, a workspace is whatever the caller's allocator hands over. */
+enum {
+  DIFFSAL_WS_GROUPNORM = 0,      /* dims = {B, groups}                 diffsal_groupnorm_ws_bytes (also diffsal_gn_affine) */
+  DIFFSAL_WS_CONV_IGEMM = 1,     /* d                                  diffsal_conv_igemm_ws_bytes */
+  DIFFSAL_WS_CONV_WINO = 2,      /* d                                  diffsal_conv_wino_ws_bytes */
+  DIFFSAL_WS_CONV_WINO4 = 3,     /* d                                  diffsal_conv_wino4_ws_bytes */
+  DIFFSAL_WS_CONV_WINO4_STATS = 4, /* d, dims = {groups}               diffsal_conv_wino4_stats_bytes */
+  DIFFSAL_WS_CONV_WGRAD = 5,     /* d                                  diffsal_conv_wgrad_ws_bytes */
+  DIFFSAL_WS_WGRAD_SEGMENTED = 6, /* dims = {segments, seg_rows, K, Cout}  diffsal_wgrad_segmented_ws_bytes */
+  DIFFSAL_WS_TAPSUM_BWD = 7,     /* dims = {N, W, C, h}                diffsal_tapsum_bwd_ws_bytes */
+  DIFFSAL_WS_SALIENCY_METRICS = 8, /* dims = {B}                       diffsal_saliency_metrics_ws_bytes */
+  DIFFSAL_WS_ATTENTION_TAIL = 9, /* dims = {B, H, Lq, Lk, DV}          4 x diffsal_attention_general_tail_floats */
+  DIFFSAL_WS_ATTENTION_BWD_QTAIL = 10 /* dims = {B, H, Lq, Lk, D, E}   4 x diffsal_attention_general_bwd_qtail_floats */
+};
+size_t diffsal_workspace_bytes(int op, const diffsal_conv_desc* d /*host, may be NULL*/, const long* dims /*host*/, int n_dims);
+
 /* Bytes of scratch the call below needs for this shape (0 unless the planner picks split-K, which it does
  * when the M x Cout grid alone cannot fill the 256 CUs). */
 size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d /*host*/);

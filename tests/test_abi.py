@@ -65,3 +65,22 @@ def test_integration_md_binding_matches_the_header():
 
 def test_abi_version_guard():
     assert _lib.load().diffsal_version() == _lib.ABI_VERSION
+
+
+def test_workspace_bytes_is_the_typed_functions_behind_one_entry_point():
+    """SURVEY 8b names ONE `diffsal_workspace_bytes(op, dims...)`: it must return what the typed *_ws_bytes functions return
+    (host arithmetic only: no GPU needed), and 0 for an unknown operator or a wrong argument count."""
+    lib = _lib.load()
+    d = _lib.ConvDesc(4, 28, 48, 384, 28, 48, 384, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0)
+    ref = ctypes.byref(d)
+    assert _lib.workspace_bytes(_lib.WS_GROUPNORM, dims=(4, 32)) == lib.diffsal_groupnorm_ws_bytes(4, 32) > 0
+    assert _lib.workspace_bytes(_lib.WS_CONV_IGEMM, d) == lib.diffsal_conv_igemm_ws_bytes(ref)
+    assert _lib.workspace_bytes(_lib.WS_CONV_WINO, d) == lib.diffsal_conv_wino_ws_bytes(ref) > 0
+    assert _lib.workspace_bytes(_lib.WS_CONV_WINO4, d) == lib.diffsal_conv_wino4_ws_bytes(ref) == 36 * 4 * 7 * 12 * (384 + 384) * 4
+    assert _lib.workspace_bytes(_lib.WS_CONV_WINO4_STATS, d, (32,)) == lib.diffsal_conv_wino4_stats_bytes(ref, 32) > 0
+    assert _lib.workspace_bytes(_lib.WS_CONV_WGRAD, d) == lib.diffsal_conv_wgrad_ws_bytes(ref)
+    assert _lib.workspace_bytes(_lib.WS_WGRAD_SEGMENTED, dims=(36, 336, 192, 18)) == lib.diffsal_wgrad_segmented_ws_bytes(36, 336, 192, 18)
+    assert _lib.workspace_bytes(_lib.WS_TAPSUM_BWD, dims=(36, 96, 96, 28)) == lib.diffsal_tapsum_bwd_ws_bytes(36, 96, 96, 28) > 0
+    assert _lib.workspace_bytes(_lib.WS_SALIENCY_METRICS, dims=(4,)) == lib.diffsal_saliency_metrics_ws_bytes(4) > 0
+    assert _lib.workspace_bytes(_lib.WS_ATTENTION_TAIL, dims=(4, 4, 2352, 296, 96)) == 4 * lib.diffsal_attention_general_tail_floats(4, 4, 2352, 296, 96)
+    assert _lib.workspace_bytes(99, d) == 0 and _lib.workspace_bytes(_lib.WS_GROUPNORM, dims=(4,)) == 0
