@@ -27,7 +27,7 @@ static const char* const kTuneNames[TUNE_COUNT] = {
     "DIFFSAL_NO_PERSIST", "DIFFSAL_NO_XCD_ORDER", "DIFFSAL_NO_HALO", "DIFFSAL_FORCE_HALO", "DIFFSAL_IGEMM_CFG",
     "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
     "DIFFSAL_NO_FUSED_BLOCK", "DIFFSAL_NO_WINOGRAD", "DIFFSAL_FORCE_WINOGRAD", "DIFFSAL_GN_CHUNKS", "DIFFSAL_GN_APPLY_WGS",
-    "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD", "DIFFSAL_NO_TAPSUM_ROWS"};
+    "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD", "DIFFSAL_NO_TAPSUM_ROWS", "DIFFSAL_TAPSUM_ROWS_FORM"};
 static int g_tune[TUNE_COUNT];
 static const bool g_tune_init = [] {
   for (int k = 0; k < TUNE_COUNT; ++k) {

@@ -17,6 +17,8 @@
 // interpolation weights, so every weight stays a wave-uniform scalar) and a 128-channel slab, 4 channels per lane.  Per tap and
 // source the patch needs at most 4 (factor <= 2) or 3 (factor >= 4) source rows / columns, consumed a row at a time as in
 // resize_sum_kernel (misc.hip).  Exact up to summation order; fp32 arithmetic on fp32 / bf16 / fp16 storage.
+#include <type_traits>
+
 #include "common.h"
 
 namespace diffsal {
@@ -233,9 +235,12 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     int lower;
-    tap_pos(X0 - 1 + i, W, w, sx, lower, wxa[i], wxb[i]);
+    float a, b;
+    tap_pos(X0 - 1 + i, W, w, sx, lower, a, b);
+    wxa[i] = uni_f(a);                              // wave-uniform: scalar registers
+    wxb[i] = uni_f(b);
     if (i == 0) first_x = lower;
-    xr[i] = lower - first_x;                        // F = 2, 4: i / PER by construction; F = 0: 0 or 1
+    xr[i] = uni_i(lower - first_x);                 // F = 2, 4: i / PER by construction; F = 0: 0 or 1
   }
   first_x = uni_i(first_x);
   unsigned coff[NL];
@@ -255,16 +260,20 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
       wtab[lane] = (lower - first_y == r ? a : 0.f) + (lower - first_y + 1 == r ? b : 0.f);
     }
   }
-  // ---- (ky, r) items; item it = ky * NL + r.  V[kx][c]: the NL vectors of source line r in tap (ky, kx)
+  // ---- (ky, r) items; item it = ky * NL + r.  V[kx][c]: the NL vectors of source line r in tap (ky, kx).  The loads of item
+  // it + 1 are issued before item it is summed (two register sets, two items per trip so that the sets swap roles without copies).
+  // Measured: a ring of three sets at sub-step (kx) granularity -- a third of the registers, two wavefronts per SIMD instead of
+  // one -- is SLOWER (99 against 87 us): what the gather needs is loads in flight, and a whole item ahead is 9-12 of them.
   constexpr int NIT = 3 * NL;
   auto fetch = [&](TapVec<CPL> (&V)[3][NL], int it) __attribute__((always_inline)) {
     const int ky = it / NL, r = it - ky * NL;
     const int row = min(max(first_y + r, 0), h - 1);
-    const unsigned roff = static_cast<unsigned>(uni_i(row * w) * P * 4 + ky * 3 * C * 4);
+    const int roff = row * w * P * 4 + ky * 3 * C * 4;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int c = 0; c < NL; ++c) V[kx][c] = tap_ld<CPL>(src + (roff + coff[c] + static_cast<unsigned>(kx * C * 4)), lane_byte);
+      for (int c = 0; c < NL; ++c)      // the offset IS uniform; inside the runtime loop hipcc no longer proves it: say so
+        V[kx][c] = tap_ld<CPL>(src + static_cast<unsigned>(uni_i(roff + static_cast<int>(coff[c]) + kx * C * 4)), lane_byte);
   };
   auto sum = [&](const TapVec<CPL> (&V)[3][NL], int it) __attribute__((always_inline)) {
     const int ky = it / NL, r = it - ky * NL;
@@ -298,23 +307,35 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
 #pragma unroll
         for (int q = 0; q < CPL; ++q) acc[d][e][q] = fmaf(wv[d], G[e][q], acc[d][e][q]);
   };
+  // (Deeper rings were tried with the items unrolled so that the set indices are static: hipcc then allocates 256-512 registers
+  // and spills, scheduling barriers or not.  Two sets in a runtime loop is what it compiles well.)
   TapVec<CPL> Va[3][NL], Vb[3][NL];
   fetch(Va, 0);
+  constexpr int PAIRS = (NIT - 1) / 2;             // trips with both fetches unconditional (no phi copies of the register sets)
 #pragma unroll 1
-  for (int it = 0; it < NIT; it += 2) {            // two items per trip: the register sets swap roles without copies
-    if (it + 1 < NIT) fetch(Vb, it + 1);
+  for (int it = 0; it < 2 * PAIRS; it += 2) {
+    fetch(Vb, it + 1);
     sum(Va, it);
-    if (it + 1 < NIT) {
-      if (it + 2 < NIT) fetch(Va, it + 2);
-      sum(Vb, it + 1);
-    }
+    fetch(Va, it + 2);
+    sum(Vb, it + 1);
+  }
+  if constexpr (NIT % 2 == 1) {
+    sum(Va, NIT - 1);
+  } else {
+    fetch(Vb, NIT - 1);
+    sum(Va, NIT - 2);
+    sum(Vb, NIT - 1);
   }
 }
 
-template <int CPL>
-__global__ __launch_bounds__(256) void tapsum_head_rows_kernel(TapSumArgs a, int w_patches, long n_items) {
+// IMGS images per wavefront (64 / IMGS lanes each, CPL channels per lane): 2 x 32 lanes x 3 channels for C = 96 keeps every lane
+// busy; 1 x 64 lanes x 2 channels (48 live lanes at C = 96) makes twice as many, lighter wavefronts -- more of them resident per
+// SIMD, more loads in flight (the launch is latency-bound: ~2.6 wavefronts per SIMD in the 2-image form)
+template <int CPL, int IMGS>
+__global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kernel(TapSumArgs a, int w_patches, long n_items) {
+  constexpr int LPI = 64 / IMGS;
   __shared__ float wtab_all[4][32];
-  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const int lane = threadIdx.x & 63, sub = lane / LPI, li = lane % LPI;
   const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u;       // XCD-aware order, as tapsum_kernel
   const unsigned vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
   const long item = static_cast<long>(vb) * 4 + (threadIdx.x >> 6);
@@ -324,9 +345,9 @@ __global__ __launch_bounds__(256) void tapsum_head_rows_kernel(TapSumArgs a, int
   const int h_patches = a.H >> 2;
   const int px = static_cast<int>(t % w_patches); t /= w_patches;
   const int py = static_cast<int>(t % h_patches);
-  const int pair = static_cast<int>(t / h_patches);
+  const int grp = static_cast<int>(t / h_patches);
   const int Y0 = uni_i(py * 4), X0 = uni_i(px * 4);
-  const int n = pair * 2 + half, c = l32 * CPL;
+  const int n = grp * IMGS + sub, c = li * CPL;
   const int nc = n < a.N ? n : a.N - 1, cc = c < a.C ? c : a.C - CPL;   // dead lanes walk valid memory and contribute nothing
   const int P = 9 * a.C;
   float acc[4][4][CPL];
@@ -365,8 +386,8 @@ __global__ __launch_bounds__(256) void tapsum_head_rows_kernel(TapSumArgs a, int
         if (a.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
         t2 = fmaf(v, hw[q], t2);
       }
-      t2 = group_sum<32>(t2);
-      if (l32 == 0 && n < a.N) a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t2 + a.head_b[0]);
+      t2 = group_sum<LPI>(t2);
+      if (li == 0 && n < a.N) a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t2 + a.head_b[0]);
     }
 }
 
@@ -447,12 +468,20 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
   for (int i = 0; i < n_src && rows; ++i)
     rows = H / hs[i] >= 2 && H / hs[i] <= 64 && static_cast<long>(N) * hs[i] * ws[i] * 9 * C * 4 < (1L << 32) - (1L << 20);
   if (rows) {
-    const long n_items = static_cast<long>((N + 1) / 2) * (H / 4) * (W / 4);
-    const unsigned grid = static_cast<unsigned>((n_items + 3) / 4);
-    if (C % 3 == 0 && C / 3 <= 32 && C / 3 > 24)
-      hipLaunchKernelGGL((tapsum_head_rows_kernel<3>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, W / 4, n_items);
+    // lane mapping: two images per wavefront (3 or 4 channels per lane: the default), or DIFFSAL_TAPSUM_ROWS_FORM = 2: one image (2
+    // channels per lane, C <= 128: twice the wavefronts at 177 instead of 272 registers).  Measured equal (87-92 us, same box):
+    // neither form is bound by resident wavefronts
+    const int form = tune(TUNE_TAPSUM_ROWS_FORM) == 2 ? 2 : 1;
+    const int imgs = form == 1 ? 2 : 1;
+    const long n_items = static_cast<long>((N + imgs - 1) / imgs) * (H / 4) * (W / 4);
+    const dim3 grid(static_cast<unsigned>((n_items + 3) / 4));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (form == 2 && C % 2 == 0)
+      hipLaunchKernelGGL((tapsum_head_rows_kernel<2, 1>), grid, dim3(256), 0, st, a, W / 4, n_items);
+    else if (C % 3 == 0 && C / 3 <= 32 && C / 3 > 24)
+      hipLaunchKernelGGL((tapsum_head_rows_kernel<3, 2>), grid, dim3(256), 0, st, a, W / 4, n_items);
     else
-      hipLaunchKernelGGL((tapsum_head_rows_kernel<4>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, W / 4, n_items);
+      hipLaunchKernelGGL((tapsum_head_rows_kernel<4, 2>), grid, dim3(256), 0, st, a, W / 4, n_items);
     return check_launch("tapsum(head)");
   }
   const int slabs = (C + 127) / 128;
