@@ -28,12 +28,13 @@ class Wino4Ext(C.Structure):
     """struct diffsal_wino4_ext (include/diffsal.h): optional extras of diffsal_conv_wino4_ex."""
 
     _fields_ = [("in_ab", C.c_void_p), ("side_a", C.c_void_p), ("side_w", C.c_void_p), ("side_out", C.c_void_p),
-                ("out_stats", C.c_void_p), ("side_rows", C.c_longlong), ("in_swish", C.c_int), ("out_groups", C.c_int)]
+                ("out_stats", C.c_void_p), ("up2_c", C.c_void_p), ("up2_scale", C.c_void_p), ("up2_shift", C.c_void_p),
+                ("side_rows", C.c_longlong), ("in_swish", C.c_int), ("out_groups", C.c_int), ("up2_act", C.c_int), ("reserved", C.c_int)]
 
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 
 SIGNATURES = {
@@ -139,6 +140,7 @@ SIGNATURES = {
     "diffsal_workspace_bytes": (c_sz, [c_i, C.POINTER(ConvDesc), C.POINTER(C.c_long), c_i]),
     "diffsal_border_gather": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_up2_conv_commute": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
+    "diffsal_up2_conv_commute_ring": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
     "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),
     "diffsal_qkv_pool_bwd_weight_chunks": (c_i, []),

@@ -679,7 +679,9 @@ static int try_gn_slab(const T* x, const float* gamma, const float* beta, T* out
   // fewer than 128 workgroups (one per CU, streaming its slab at a single CU's ~30 GB/s) lose to the two launches, which spread an
   // image over up to 512 workgroups: measured equal at B = 4 (six GroupNorms of a step: 0.109 ms either way, 6 launches instead
   // of 12), slower below
-  if (lds > 150 * 1024 || static_cast<long>(B) * groups < 128) return 0;
+  // ... and more than ~1000 slabs lose to them as well (16-bit storage, 64 clips: 21.55 against 20.95 ms per step, same box): past
+  // that the two launches' whole-row coalesced passes win over 2048 workgroups reading 6-48-byte pieces
+  if (lds > 150 * 1024 || static_cast<long>(B) * groups < 128 || static_cast<long>(B) * groups > 1024) return 0;
 #define GN_SLAB(VEC, U)                                                                                          \
   do {                                                                                                           \
     DS_RAISE_DYNAMIC_LDS((gn_slab_kernel<T, VEC, U>), 152 * 1024);                                               \

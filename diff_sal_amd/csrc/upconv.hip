@@ -240,15 +240,17 @@ extern "C" int diffsal_border_gather(const void* z, void* zb, int N, int h, int 
 namespace {
 template <typename T>
 int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out, int N, int h, int w, int C,
-                  int act, hipStream_t s) {
+                  int act, hipStream_t s, bool ring_only) {
   UpCommuteArgs<T> a{static_cast<const T*>(c_ext), static_cast<const T*>(tap_border), scale, shift, static_cast<T*>(out), N, h, w, C, act};
-  const int row_items = w * (C / 4);
-  int gx = (row_items + 255) / 256;
-  gx = gx > 64 ? 64 : gx;
-  const long rows = static_cast<long>(N) * h;
-  hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
-  const int rc = check_launch("up2_conv_commute(interior)");
-  if (rc) return rc;
+  if (!ring_only) {
+    const int row_items = w * (C / 4);
+    int gx = (row_items + 255) / 256;
+    gx = gx > 64 ? 64 : gx;
+    const long rows = static_cast<long>(N) * h;
+    hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
+    const int rc = check_launch("up2_conv_commute(interior)");
+    if (rc) return rc;
+  }
   const int H2 = 2 * h, W2 = 2 * w, full = H2 < 6 ? H2 : 6, colw = W2 < 6 ? W2 : 6;
   const long ring_items = (static_cast<long>(full) * W2 + static_cast<long>(H2 - full) * colw) * (C / 4);
   int gr = static_cast<int>((ring_items + 255) / 256);
@@ -258,8 +260,8 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
 }
 }  // namespace
 
-extern "C" int diffsal_up2_conv_commute(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
-                                        int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream) {
+static int up2_commute_impl(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
+                            int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream, bool ring_only) {
   DS_REQUIRE(c_ext && tap_border && out, DIFFSAL_E_ARG, "up2_conv_commute: null argument");
   DS_REQUIRE(N > 0 && h >= 2 && w >= 2 && C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "up2_conv_commute: N=%d h=%d w=%d C=%d", N, h, w, C);
   DS_REQUIRE((scale == nullptr) == (shift == nullptr), DIFFSAL_E_ARG, "up2_conv_commute: scale and shift come together");
@@ -271,8 +273,20 @@ extern "C" int diffsal_up2_conv_commute(const void* c_ext, const void* tap_borde
   const long ring_bound = (6L * 2 * w + 2L * h * 6) * (C / 4);
   DS_REQUIRE(ring_bound < (1L << 30), DIFFSAL_E_SHAPE, "up2_conv_commute: ring too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(T) return up2_commute_t<T>(c_ext, tap_border, scale, shift, out, N, h, w, C, act, s)
+#define CALL(T) return up2_commute_t<T>(c_ext, tap_border, scale, shift, out, N, h, w, C, act, s, ring_only)
   DS_DTYPE_DISPATCH(dtype, "up2_conv_commute", CALL);
 #undef CALL
   return DIFFSAL_OK;
+}
+
+extern "C" int diffsal_up2_conv_commute(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
+                                        int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream) {
+  return up2_commute_impl(c_ext, tap_border, scale, shift, out, N, h, w, C, act, dtype, stream, false);
+}
+
+/* Only the 3-pixel border ring of `out` is written (the pixels whose value needs the tap products): for a consumer that forms the
+ * interior itself from c_ext -- diffsal_conv_wino4_ex with ext.up2_c (the interior never exists in memory). */
+extern "C" int diffsal_up2_conv_commute_ring(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
+                                             int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream) {
+  return up2_commute_impl(c_ext, tap_border, scale, shift, out, N, h, w, C, act, dtype, stream, true);
 }

@@ -72,6 +72,18 @@ template <> __device__ __forceinline__ float w4_get<float4>(const float4& v, int
 template <> __device__ __forceinline__ float w4_get<float2>(const float2& v, int e) { return e == 0 ? v.x : v.y; }
 template <> __device__ __forceinline__ float w4_get<float>(const float& v, int) { return v; }
 
+// the interpolation / epilogue expressions of up2_conv_commute_kernel (csrc/upconv.hip), per component
+__device__ __forceinline__ float w4_lerp1(float a, float b) { return 0.75f * a + 0.25f * b; }
+__device__ __forceinline__ float4 w4_lerp(float4 a, float4 b) { return make_float4(w4_lerp1(a.x, b.x), w4_lerp1(a.y, b.y), w4_lerp1(a.z, b.z), w4_lerp1(a.w, b.w)); }
+__device__ __forceinline__ float2 w4_lerp(float2 a, float2 b) { return make_float2(w4_lerp1(a.x, b.x), w4_lerp1(a.y, b.y)); }
+__device__ __forceinline__ float w4_lerp(float a, float b) { return w4_lerp1(a, b); }
+__device__ __forceinline__ float4 w4_affine(float4 v, float4 s, float4 h) { return make_float4(v.x * s.x + h.x, v.y * s.y + h.y, v.z * s.z + h.z, v.w * s.w + h.w); }
+__device__ __forceinline__ float2 w4_affine(float2 v, float2 s, float2 h) { return make_float2(v.x * s.x + h.x, v.y * s.y + h.y); }
+__device__ __forceinline__ float w4_affine(float v, float s, float h) { return v * s + h; }
+__device__ __forceinline__ float4 w4_relu(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
+__device__ __forceinline__ float2 w4_relu(float2 v) { return make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)); }
+__device__ __forceinline__ float w4_relu(float v) { return fmaxf(v, 0.f); }
+
 // B^T applied to six values (rows of B^T: [4 0 -5 0 1 0], [0 -4 -4 1 1 0], [0 4 -4 -1 1 0], [0 -2 -1 2 1 0], [0 2 -1 -2 1 0],
 // [0 4 0 -5 0 1])
 template <typename VT>
@@ -149,6 +161,91 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     float* dst = V + static_cast<long>(t) * g.Cin + q4 * VW;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {      // (.) B : rows
+      VT o[6];
+      w4_bt(tt[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) w4_st<VT>(dst + (i * 6 + j) * pos_stride, o[j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1b. input transform of UpEmbed's SECOND convolution (dilation 2) reading the source-resolution result of the FIRST one:
+//     u1 = act(BN(I0_y I0_x c)) is formed from c = conv3x3(z) on the extended source grid [N][h + 2][w + 2][C] as the patch is
+//     gathered (the arithmetic of up2_conv_commute_kernel, expression for expression; equal up to FMA contraction), so the interior of u1
+//     -- 74 MB at stage 3 -- is neither written nor read back; the 3-pixel border ring, whose values need the tap products, is
+//     read from `u1` where diffsal_up2_conv_commute_ring left it.  R/models/saliency_decoder/common_block.py:196-216.
+//     Per patch column: the 7 source rows of the two source columns (14 loads), horizontal then vertical interpolation.
+// ------------------------------------------------------------------------------------------------------------------------
+struct Wino4Up2 {
+  const float* c;        // [N][h + 2][w + 2][C]
+  const float* u1;       // [N][2h][2w][C]: ring pixels valid
+  const float* scale;    // BatchNorm affine of the first convolution (may be null)
+  const float* shift;
+  int h, w, act;
+};
+
+template <typename VT>
+__global__ __launch_bounds__(256) void wino4_input_up2_kernel(Wino4Up2 u, float* __restrict__ V, Wino4Geom g) {
+  constexpr int VW = sizeof(VT) / 4;
+  const int q4n = g.Cin / VW;
+  const long items = static_cast<long>(g.n_tiles) * q4n;
+  const long pos_stride = static_cast<long>(g.n_tiles) * g.Cin;
+  const int H2 = g.H, W2 = g.W;                       // = 2 h, 2 w
+  const long crow = static_cast<long>(u.w + 2) * g.Cin;
+  for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
+    const int t = static_cast<int>(it / q4n);
+    const int q4 = static_cast<int>(it - static_cast<long>(t) * q4n);
+    int n, y0, x0;
+    wino4_tile_coords(g, t, n, y0, x0);
+    const float* cimg = u.c + static_cast<long>(n) * (u.h + 2) * crow + q4 * VW;
+    const float* uimg = u.u1 + static_cast<long>(n) * H2 * W2 * g.Cin + q4 * VW;
+    VT sc, sh;
+    if (u.scale) { sc = w4_ld<VT>(u.scale + q4 * VW); sh = w4_ld<VT>(u.shift + q4 * VW); }
+    // rows of the patch: y = y0 + 2 (i - 1), one parity; source row m_i = y >> 1, far row m_i + 1 (odd y) or m_i - 1 (even y).
+    // The seven source rows involved: r = 0..6 <-> source row mb + r, mb = (first patch row >> 1) - (even parity ? 1 : 0)
+    const int yf = y0 - 2, sy = yf & 1;
+    const int mb = (yf >> 1) - (sy ? 0 : 1);          // >> on a negative yf: arithmetic shift = floor, as the rows outside are masked anyway
+    VT tt[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int xx = x0 + 2 * (j - 1);
+      const bool vx = xx >= 0 && xx < W2;
+      const int sx = xx & 1, nx = xx >> 1;
+      const int xc = nx + 1, xf_ = (sx ? nx + 1 : nx - 1) + 1;      // centre / far column on the extended grid (+ 1)
+      const bool ringx = xx < 3 || xx >= W2 - 3;
+      VT hrow[7];
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        const int cr = mb + r + 1;                   // row on the extended grid
+        const bool ok = vx && cr >= 0 && cr < u.h + 2;
+        const float* rp = cimg + (ok ? static_cast<long>(cr) * crow : 0);
+        const VT a0 = w4_ld<VT>(rp + (ok ? static_cast<long>(xc) * g.Cin : 0)), a1 = w4_ld<VT>(rp + (ok ? static_cast<long>(xf_) * g.Cin : 0));
+        hrow[r] = w4_lerp(a0, a1);                    // 0.75 a0 + 0.25 a1, the expression of up2_conv_commute_kernel
+      }
+      VT dd[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int y = yf + 2 * i;
+        const bool v = vx && y >= 0 && y < H2;
+        const bool ring = ringx || y < 3 || y >= H2 - 3;
+        // centre row m = y >> 1 <-> r = (y >> 1) - mb; far row: + 1 (odd) / - 1 (even)
+        // (selects, not hrow[runtime index]: that would put the array in scratch)
+        const VT hc = sy ? hrow[i] : hrow[i + 1], hf = sy ? hrow[i + 1] : hrow[i];
+        VT val = w4_lerp(hc, hf);
+        if (u.scale) val = w4_affine(val, sc, sh);
+        if (u.act == DIFFSAL_ACT_RELU) val = w4_relu(val);
+        if (v && ring) val = w4_ld<VT>(uimg + (static_cast<long>(y) * W2 + xx) * g.Cin);
+        dd[i] = v ? val : w4_zero<VT>();
+      }
+      VT cc[6];
+      w4_bt(dd, cc);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tt[i][j] = cc[i];
+    }
+    float* dst = V + static_cast<long>(t) * g.Cin + q4 * VW;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
       VT o[6];
       w4_bt(tt[i], o);
 #pragma unroll
@@ -436,6 +533,10 @@ extern "C" int diffsal_conv_wino4_ex(const diffsal_conv_desc* d, const float* x,
   diffsal_wino4_ext e{};
   if (ext) e = *ext;
   DS_REQUIRE(!e.in_ab || aligned16(e.in_ab), DIFFSAL_E_ALIGN, "conv_wino4: misaligned in_ab");
+  DS_REQUIRE(!e.up2_c || (!e.in_ab && g.d == 2 && g.e == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.H >= 4 && g.W >= 4 && aligned16(e.up2_c) &&
+                          (e.up2_scale == nullptr) == (e.up2_shift == nullptr) && (!e.up2_scale || (aligned16(e.up2_scale) && aligned16(e.up2_shift))) &&
+                          (e.up2_act == DIFFSAL_ACT_NONE || e.up2_act == DIFFSAL_ACT_RELU)),
+             DIFFSAL_E_ARG, "conv_wino4: up2 input needs dilation 2, even H and W >= 4, no in_ab, act NONE / RELU");
   DS_REQUIRE(e.side_rows == 0 || (e.side_a && e.side_w && e.side_out && diffsal_conv_wino4_side_supported(d, e.side_rows)), DIFFSAL_E_ARG,
              "conv_wino4: side product of %lld rows does not fit (rows must be a multiple of the %d tiles)", e.side_rows, g.n_tiles);
   DS_REQUIRE(!e.out_stats || (wino4_stats_ok(g, e.out_groups) && aligned16(e.out_stats)), DIFFSAL_E_ARG,
@@ -450,9 +551,11 @@ extern "C" int diffsal_conv_wino4_ex(const diffsal_conv_desc* d, const float* x,
     long gi = (scalars / vw + 255) / 256;
     gi = gi > 16384 ? 16384 : gi;
     const dim3 gd(static_cast<unsigned>(gi));
+    const Wino4Up2 up{e.up2_c, x, e.up2_scale, e.up2_shift, g.H / 2, g.W / 2, e.up2_act};
 #define W4_IN(VT)                                                                                                   \
   do {                                                                                                              \
-    if (e.in_ab) hipLaunchKernelGGL((wino4_input_kernel<VT, true>), gd, dim3(256), 0, s, x, V, g, e.in_ab, e.in_swish); \
+    if (e.up2_c) hipLaunchKernelGGL((wino4_input_up2_kernel<VT>), gd, dim3(256), 0, s, up, V, g);                   \
+    else if (e.in_ab) hipLaunchKernelGGL((wino4_input_kernel<VT, true>), gd, dim3(256), 0, s, x, V, g, e.in_ab, e.in_swish); \
     else hipLaunchKernelGGL((wino4_input_kernel<VT, false>), gd, dim3(256), 0, s, x, V, g, nullptr, 0);             \
   } while (0)
     if (vw == 4) W4_IN(float4);

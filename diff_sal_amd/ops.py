@@ -275,9 +275,9 @@ def gn_affine(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 32, eps: flo
     return ab
 
 
-def _wino4_desc(x: Tensor, Cout: int, act: int, rowvec: Optional[Tensor]):
+def _wino4_desc(x: Tensor, Cout: int, act: int, rowvec: Optional[Tensor], dil: int = 1):
     N, H, W, Cin = x.shape
-    d = ConvDesc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 1, 1, act, rowvec.shape[-1] if rowvec is not None else 0, 0,
+    d = ConvDesc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, dil, dil, dil, dil, act, rowvec.shape[-1] if rowvec is not None else 0, 0,
                  _lib.PREC_FP32, _lib.F32)
     if rowvec is not None:
         assert rowvec.stride(-1) == 1 and rowvec.dtype == torch.float32 and rowvec.is_cuda
@@ -302,18 +302,31 @@ def resblock_wino4_plan(x: Tensor, Cout: int, groups: int = 32) -> Optional[dict
                 stats=lib.diffsal_conv_wino4_stats_bytes(C.byref(d1), groups) > 0)
 
 
-def conv3x3_wino4_ex(x: Tensor, wino4: Tensor, *, bias: Optional[Tensor] = None, rowvec: Optional[Tensor] = None,
+def wino4_supported(x: Tensor, Cout: int, dil: int = 1) -> bool:
+    """The planner takes the F(4x4, 3x3) path for a 3x3 / padding = dilation convolution of NHWC fp32 x to Cout channels."""
+    if x.dtype != torch.float32 or get_gemm_precision() != "fp32":
+        return False
+    d = _wino4_desc(x, Cout, ACT_NONE, None, dil)
+    return bool(_lib.load().diffsal_conv_wino4_supported(C.byref(d)))
+
+
+def conv3x3_wino4_ex(x: Tensor, wino4: Tensor, *, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,
+                     shift: Optional[Tensor] = None, rowvec: Optional[Tensor] = None,
                      residual: Optional[Tensor] = None, act: int = ACT_NONE, gn_ab: Optional[Tensor] = None, gn_swish: bool = True,
-                     side=None, stats_groups: int = 0, tag: str = "K4"):
+                     side=None, stats_groups: int = 0, dil: int = 1, up2=None, tag: str = "K4"):
     """3x3 / padding 1 convolution of NHWC fp32 x on the F(4x4, 3x3) path with the ResnetBlock extras of ``diffsal_conv_wino4_ex``:
     ``gn_ab`` [N,2,Cin] (``gn_affine``): the input is normalised (+ swish) as the input transform loads it; ``side = (a, w)``: the
     plain product a [N,H,W,K] x w [Cout, K]^T (the 1x1 shortcut, no bias) computed by the launch of the position products;
     ``stats_groups`` > 0: per-(image, group) sums of the result for the next GroupNorm.  Returns (out, side_out or None, stats or
-    None) -- stats is the opaque buffer ``gn_affine_from_stats`` takes."""
+    None) -- stats is the opaque buffer ``gn_affine_from_stats`` takes.
+
+    ``dil`` 1 or 2 (padding = dilation); ``scale`` / ``shift``: BatchNorm affine of the epilogue.  ``up2 = (c_ext, scale1, shift1,
+    act1)``: x is the [N,H,W,Cin] buffer of which ``up2_conv3x3_d2(..., ring_only=True)`` wrote only the border ring; the input
+    transform forms the interior act1(BN1(interpolation of c_ext)) itself (dilation 2 only)."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout = wino4.shape[1]
-    d = _wino4_desc(x, Cout, act, rowvec)
+    d = _wino4_desc(x, Cout, act, rowvec, dil)
     out = torch.empty((N, H, W, Cout), device=x.device, dtype=torch.float32)
     ws_bytes = lib.diffsal_conv_wino4_ws_bytes(C.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32)
@@ -328,6 +341,11 @@ def conv3x3_wino4_ex(x: Tensor, wino4: Tensor, *, bias: Optional[Tensor] = None,
         rows = sa.numel() // Cin
         side_out = torch.empty(tuple(sa.shape[:-1]) + (Cout,), device=x.device, dtype=torch.float32)
         ext.side_a, ext.side_w, ext.side_out, ext.side_rows = sa.data_ptr(), sw.data_ptr(), side_out.data_ptr(), rows
+    if up2 is not None:
+        c_ext, s1, h1, a1 = up2
+        assert dil == 2 and gn_ab is None and c_ext.dtype == torch.float32 and c_ext.is_contiguous()
+        assert tuple(c_ext.shape) == (N, H // 2 + 2, W // 2 + 2, Cin), (c_ext.shape, x.shape)
+        ext.up2_c, ext.up2_scale, ext.up2_shift, ext.up2_act = c_ext.data_ptr(), _p(s1), _p(h1), a1
     if stats_groups > 0:
         sb = lib.diffsal_conv_wino4_stats_bytes(C.byref(d), stats_groups)
         if sb == 0:
@@ -335,16 +353,18 @@ def conv3x3_wino4_ex(x: Tensor, wino4: Tensor, *, bias: Optional[Tensor] = None,
         stats = torch.empty((sb // 8,), device=x.device, dtype=torch.float64)
         ext.out_stats, ext.out_groups = stats.data_ptr(), stats_groups
     rv = rowvec.data_ptr() if rowvec is not None else None
-    args = (C.byref(d), _p(x), _p(wino4), _p(bias), None, None, rv, _p(residual), _p(out), _p(ws), ws_bytes, C.byref(ext))
-    dd = 1
-    n_tiles = N * ((H + 3) // 4) * ((W + 3) // 4)
+    args = (C.byref(d), _p(x), _p(wino4), _p(bias), _p(scale), _p(shift), rv, _p(residual), _p(out), _p(ws), ws_bytes, C.byref(ext))
+    n_tiles = N * dil * dil * (((H + dil - 1) // dil + 3) // 4) * (((W + dil - 1) // dil + 3) // 4)
     if PROFILE is None:
         _lib.check(lib.diffsal_conv_wino4_ex(*args, 7, _stream()), "conv_wino4_ex")
     else:
         note = f"M={N * H * W} K={9 * Cin} N={Cout} 3x3 winograd F(4x4,3x3)"
         vb, mb = 36 * n_tiles * Cin * 4, 36 * n_tiles * Cout * 4
         nside = 0 if side is None else side[0].numel() // Cin
-        with _prof(tag + "-xf", 0.0, _nb(x) + vb, note + (": input transform (GroupNorm + swish on load)" if gn_ab is not None else ": input transform")) as pr:
+        xin = _nb(x) if up2 is None else _nb(up2[0])
+        with _prof(tag + "-xf", 0.0, xin + vb, note + (": input transform (GroupNorm + swish on load)" if gn_ab is not None else
+                                                        ": input transform (interpolation of the source-resolution convolution on load)" if up2 is not None
+                                                        else ": input transform")) as pr:
             _lib.check(lib.diffsal_conv_wino4_ex(*args, 1, _stream()), "conv_wino4_ex")
             pr.kernel = "wino4_input_kernel"
         with _prof(tag, 2.0 * (n_tiles * 36 + nside) * Cin * Cout, vb + mb + _nb(wino4) + (0 if side is None else _nb(side[0], side_out)),
@@ -688,13 +708,17 @@ def conv_igemm(x: Tensor, w_packed: Tensor, *, kh: int = 1, kw: int = 1, stride=
 
 
 def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
-                   act: int = ACT_NONE, tag: str = "K12") -> Tensor:
+                   act: int = ACT_NONE, tag: str = "K12", ring_only: bool = False):
     """act(BN(conv3x3(dilation 2, padding 2)(bilinear_up2(z)))) for z [N,h,w,Cin] (fp32, or bf16 / fp16 storage) -> [N,2h,2w,Cout]:
     the convolution runs at the SOURCE resolution on the grid extended by one pixel (F(4x4) Winograd where ``wino`` qualifies -- fp32
     only --, else the direct kernel of the storage type), the
     nine tap products only on the border pixels, and one kernel interpolates and corrects the 3-pixel border ring
     (``diffsal_up2_conv_commute``, csrc/upconv.hip).  ``w_packed``: pack_conv_weight(w); ``tapw``: the [9*Cout, Cin] tap matrix (row =
-    tap * Cout + co).  Exact up to summation order."""
+    tap * Cout + co).  Exact up to summation order.
+
+    ``ring_only``: returns ``(out, c_ext)`` with only the 3-pixel border ring of ``out`` written (``diffsal_up2_conv_commute_ring``): the
+    consumer forms the interior from ``c_ext`` itself -- ``conv3x3_wino4_ex(up2=(c_ext, scale, shift, act))``, UpEmbed's second
+    convolution reading the first one's source-resolution result."""
     lib = _lib.load()
     N, h, w, Cin = z.shape
     Cout = w_packed.shape[0]
@@ -705,12 +729,13 @@ def up2_conv3x3_d2(z: Tensor, w_packed: Tensor, wino, tapw: Tensor, *, scale: Op
     _lib.check(lib.diffsal_border_gather(_pa(z, dt), _pa(zb, dt), N, h, w, Cin, dt, _stream()), "border_gather")
     tb = linear(zb, tapw, None, tag=tag)                                   # [N, 2w + 2h - 4, 9 * Cout]
     out = torch.empty((N, 2 * h, 2 * w, Cout), device=z.device, dtype=z.dtype)
-    with _prof(tag + "-tap", 0.0, _nb(c_ext, tb, out), f"up2 commute {h}x{w} C={Cout}" if PROFILE is not None else "") as pr:
+    with _prof(tag + "-tap", 0.0, _nb(c_ext, tb) + (0 if ring_only else _nb(out)),
+               f"up2 commute {h}x{w} C={Cout}" + (" (border ring only)" if ring_only else "") if PROFILE is not None else "") as pr:
         dt = _dt(z)
-        _lib.check(lib.diffsal_up2_conv_commute(_pa(c_ext, dt), _pa(tb, dt), _p(scale), _p(shift), _pa(out, dt), N, h, w, Cout, act, dt,
-                                                _stream()), "up2_conv_commute")
-        pr.kernel = "up2_conv_commute_kernel"
-    return out
+        fn = lib.diffsal_up2_conv_commute_ring if ring_only else lib.diffsal_up2_conv_commute
+        _lib.check(fn(_pa(c_ext, dt), _pa(tb, dt), _p(scale), _p(shift), _pa(out, dt), N, h, w, Cout, act, dt, _stream()), "up2_conv_commute")
+        pr.kernel = "up2_conv_commute_ring_kernel" if ring_only else "up2_conv_commute_kernel"
+    return (out, c_ext) if ring_only else out
 
 
 def conv_igemm_group(problems: Sequence[dict], tag: str = "gemm") -> List[Tensor]:

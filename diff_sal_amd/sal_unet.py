@@ -495,7 +495,7 @@ class SalUNet(nn.Module):
                                           a.conv_proj_v.bn.bias, self.kernel_kv[i], a.conv_proj_k.bn.eps)
         if (self.group_qkv and self.compute_dtype == torch.float32 and ops.get_gemm_precision() == "fp32"
                 and not getattr(pk[f"s{i}.k.w"], "_diffsal_split", False) and C % 96 == 0
-                and -(-(q.numel() // C) // 96) * (C // 96) <= 256):
+                and (self.group_qkv_all or -(-(q.numel() // C) // 96) * (C // 96) <= 256)):
             # the three projections of the block in ONE launch when the query product alone leaves workgroup slots free (<= 256
             # tiles of 96 x 96: stage 0 at B = 4; the key / value products have 648 rows and would fill a quarter of the chip
             # for the length of a whole K walk).  Measured at B = 4: stage 0 64 us against 40 + 36; stages 1 / 2, whose query
@@ -588,7 +588,11 @@ class SalUNet(nn.Module):
     pair_kv = True    # key and value projections of a block in one launch (ops.linear_pair)
     up_commute = True  # UpEmbed's first convolution at the source resolution (ops.up2_conv3x3_d2): fp32 where the map is >= 12 x 12,
     up_commute16 = True  # 16-bit storage on every stage
+    # fp32, where both UpEmbed convolutions take the F(4x4) path: the second one's input transform interpolates the first one's
+    # source-resolution result itself (ops.conv3x3_wino4_ex(up2=...)); the first one's output exists only on its 3-pixel border ring
+    fuse_up_pe2 = True
     group_qkv = True  # fp32: query, key and value projections of a block in one grouped launch (ops.linear_group)
+    group_qkv_all = False  # ... at every stage, not only where the query product alone leaves workgroup slots free (A/B aid)
     merge_align = True   # the stages' audio align convolutions as one product (eval)
     group_reduce_temp = True   # fp32 tap path: the stages' ReduceTemp products in one grouped launch after the last stage
     # uses of the tap form on 16-bit storage, from {"s1", "s2", "s3", "mt"}.  Off by default: ("s1", "s2") is +3.4 % on the bf16
@@ -718,12 +722,23 @@ class SalUNet(nn.Module):
                         and h >= 12 and w >= 12)
                 lowc = (self.compute_dtype != torch.float32 and self.up_commute16 and not (taps is not None and self.taps_reference_forms)
                         and h >= 2 and w >= 2)
+                fuse_up = None
                 if self.up_commute and d == 2 and (f32c or lowc):
                     # the convolution at the source resolution + interpolation + border-ring corrections.  fp32: F(4x4) there, and only
                     # where the interior is most of the map (stages 2 and 3 at 224 x 384; the alternative is the tap path).  16-bit
                     # storage: every stage (the alternative is the convolution on the up-sampled map: 4x the products)
-                    u = ops.up2_conv3x3_d2(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.w"], pk[f"s{i}.pe1.wino"], pk[f"s{i}.pe1.tapw"],
-                                           scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
+                    w2 = pk[f"s{i}.pe2.wino"]
+                    if (f32c and self.fuse_up_pe2 and w2 is not None and w2.f4 is not None
+                            and ops.wino4_supported(torch.empty((Bn * T, 2 * h, 2 * w, C), device="meta"), C, 2)):
+                        # ... and UpEmbed's second convolution forms the interpolated interior itself as its input transform gathers
+                        # it: only the border ring of the first convolution's output is ever written
+                        u, c_ext = ops.up2_conv3x3_d2(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.w"], pk[f"s{i}.pe1.wino"], pk[f"s{i}.pe1.tapw"],
+                                                      scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12",
+                                                      ring_only=True)
+                        fuse_up = (c_ext, pk[f"s{i}.pe1.scale"], pk[f"s{i}.pe1.shift"], ACT_RELU)
+                    else:
+                        u = ops.up2_conv3x3_d2(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.w"], pk[f"s{i}.pe1.wino"], pk[f"s{i}.pe1.tapw"],
+                                               scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
                 elif self._use_tap_conv(taps, f"s{i}") and d in (1, 2) and h >= 2 and w >= 2:
                     y9 = ops.linear(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.tapw"], None, tag="K12")
                     u = ops.tapsum([y9], 2 * h, 2 * w, C, dil=d, scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"],
@@ -733,10 +748,15 @@ class SalUNet(nn.Module):
                     u = ops.conv_igemm(u, pk[f"s{i}.pe1.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
                                        scale=pk[f"s{i}.pe1.scale"], shift=pk[f"s{i}.pe1.shift"], act=ACT_RELU, tag="K12")
                 skip = frames[i] if i in (1, 2) else None  # transformer.py:265-270
-                u = ops.conv_igemm(u, pk[f"s{i}.pe2.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
-                                   scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU, tag="K12",
-                                   residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C),
-                                   wino=pk[f"s{i}.pe2.wino"])
+                if fuse_up is not None:
+                    u, _, _ = ops.conv3x3_wino4_ex(u, pk[f"s{i}.pe2.wino"].f4, scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"],
+                                                   act=ACT_RELU, residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C),
+                                                   dil=2, up2=fuse_up, tag="K12")
+                else:
+                    u = ops.conv_igemm(u, pk[f"s{i}.pe2.w"], kh=3, kw=3, pad=(d, d), dil=(d, d),
+                                       scale=pk[f"s{i}.pe2.scale"], shift=pk[f"s{i}.pe2.shift"], act=ACT_RELU, tag="K12",
+                                       residual=None if skip is None else skip.view(Bn * T, 2 * h, 2 * w, C),
+                                       wino=pk[f"s{i}.pe2.wino"])
                 xcur = u.view(Bn, T, 2 * h, 2 * w, C)
             kt = self.temporal_list[i]
             if (xcur.shape[1] - kt) // kt + 1 != 1:

@@ -229,10 +229,20 @@ typedef struct diffsal_wino4_ext {
   const float* side_w;
   float* side_out;
   double* out_stats;
+  const float* up2_c;       /* see below */
+  const float* up2_scale;
+  const float* up2_shift;
   long long side_rows;
   int in_swish;
   int out_groups;
+  int up2_act;
+  int reserved;
 } diffsal_wino4_ext;
+/*   up2_c, up2_scale, up2_shift, up2_act   UpEmbed's second convolution (dilation 2) fed from the SOURCE-resolution result of the
+ *                     first one (R/.../common_block.py:196-216): up2_c = conv3x3(z) on the extended grid [N][H/2 + 2][W/2 + 2][Cin]
+ *                     (what diffsal_up2_conv_commute takes as c_ext); the input transform forms act(BN(interpolation of up2_c)) itself
+ *                     -- the arithmetic of diffsal_up2_conv_commute's interior -- and reads from `x` only the 3-pixel border ring, which
+ *                     diffsal_up2_conv_commute_ring must have written there.  dil = 2, H and W even, fp32; excludes in_ab. */
 size_t diffsal_conv_wino4_stats_bytes(const diffsal_conv_desc* d /*host*/, int groups);
 int diffsal_conv_wino4_side_supported(const diffsal_conv_desc* d /*host*/, long side_rows);
 int diffsal_conv_wino4_ex(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
@@ -259,6 +269,9 @@ int diffsal_border_gather(const void* z, void* zb, int N, int h, int w, int C, i
  * exact up to summation order.  c_ext, tap_border and out ([N][2 h][2 w][C]) are in the storage type `dtype` (fp32 arithmetic in
  * between); act: DIFFSAL_ACT_NONE or DIFFSAL_ACT_RELU. */
 int diffsal_up2_conv_commute(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
+                             int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream);
+/* the same, writing ONLY the 3-pixel border ring of `out` (for diffsal_conv_wino4_ex with ext.up2_c) */
+int diffsal_up2_conv_commute_ring(const void* c_ext, const void* tap_border, const float* scale, const float* shift, void* out,
                              int N, int h, int w, int C, int act, int dtype, diffsal_stream_t stream);
 /* Up to four independent convolutions / plain products (own descriptor, operands and output; bias + activation epilogue
  * only) in ONE launch: the four ReduceTemp products of a step (R/models/saliency_decoder/common_block.py:150-173,
