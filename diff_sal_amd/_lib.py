@@ -34,7 +34,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 
 SIGNATURES = {
@@ -65,6 +65,7 @@ SIGNATURES = {
     "diffsal_sigmoid_gate": (c_i, [c_f, c_f, c_f, C.c_long, c_f]),
     "diffsal_conv_igemm_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    "diffsal_linear_f32out": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f]),
     "diffsal_linear_pair": (c_i, [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     "diffsal_conv_wgrad_ws_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "diffsal_conv_wgrad_splits": (c_i, [C.POINTER(ConvDesc)]),

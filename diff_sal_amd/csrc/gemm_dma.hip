@@ -63,6 +63,7 @@ struct DmaGemmArgs {
   // a second run of `batch2` problems of the SAME shape appended to the batch: operands a2 + i a2_bs, ONE weight matrix w2, output
   // out2 + i o2_bs (a plain product whose rows are cut into batch2 pieces of M rows: the ResnetBlock's 1x1 shortcut rides in the
   // launch of its first convolution's position products, R/models/saliency_decoder/sal_unet.py:123-142)
+  int out_f32;     // 16-bit storage launches: the output (and nothing else) is fp32 -- sums leave without a rounding to 16 bits
   int batch2;
   const void* a2;
   const void* w2;
@@ -454,7 +455,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
         } else {
           if (pc.residual) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         }
-        if (m < pc.M && n_ok) st4(ob + (static_cast<long>(i) * 16 * pc.N + j * 16), make_float4(v[0], v[1], v[2], v[3]));
+        if (m < pc.M && n_ok) {
+          if (!F32 && pc.out_f32)
+            st4(static_cast<float*>(cmp_out) + cmp_ob + o0 + (static_cast<long>(i) * 16 * pc.N + j * 16), make_float4(v[0], v[1], v[2], v[3]));
+          else
+            st4(ob + (static_cast<long>(i) * 16 * pc.N + j * 16), make_float4(v[0], v[1], v[2], v[3]));
+        }
       }
     }
   };
@@ -770,7 +776,7 @@ double gemm_dma_estimate(int cfg, long M, int K, int N) {
 
 int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* a, const void* w, const float* bias, const float* scale,
                  const float* shift, const float* rowvec, int rowvec_ld, const void* residual, void* out, void* ws, size_t ws_bytes,
-                 hipStream_t s) {
+                 hipStream_t s, bool out_f32) {
   if (cfg < 0 || cfg >= kNumDmaCfgs) return 0;
   const DmaCfg& c = kDmaCfgs[cfg];
   const int esz = d->dtype == DIFFSAL_F32 ? 4 : 2;
@@ -782,6 +788,11 @@ int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* 
   if (g.splits > 1 && (!ws || ws_bytes < static_cast<size_t>(g.splits) * MN * sizeof(float) || !aligned16(ws))) g.splits = 1;
   g.kt_per_unit = kt / g.splits;
   g.partial = g.splits > 1 ? static_cast<float*>(ws) : nullptr;
+  if (out_f32) {
+    if (esz == 4 || residual) return 0;         // 16-bit storage only; a residual would be read in the storage type
+    g.out_f32 = 1;
+    if (g.splits > 1) { g.splits = 1; g.kt_per_unit = kt; g.partial = nullptr; }     // the slab sum writes the storage type
+  }
   int rc;
   if (d->dtype == DIFFSAL_F32) rc = cfg == 0 ? launch_dma<float, 3, 3, 3, 2>(g, as_conv, s) : launch_dma<float, 3, 3, 6, 1>(g, as_conv, s);
   else if (cfg != 0) return 0;

@@ -39,7 +39,7 @@ int try_linear_stream(const float* x, const float* w, const float* bias, const f
 // gemm_dma.hip: products / convolutions with LDS-DMA staging, 96-wide tiles (fp32; plain products also on 16-bit storage)
 int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* a, const void* w, const float* bias, const float* scale,
                  const float* shift, const float* rowvec, int rowvec_ld, const void* residual, void* out, void* ws, size_t ws_bytes,
-                 hipStream_t s);
+                 hipStream_t s, bool out_f32 = false);
 int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* const* a, const float* const* w, const float* const* bias,
                        float* const* out, hipStream_t s);
 size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N, int esz);
@@ -1155,6 +1155,26 @@ extern "C" int diffsal_conv_igemm_group(int n, const diffsal_conv_desc* const* d
                                    stream, nullptr);
     if (rc) return rc;
   }
+  return DIFFSAL_OK;
+}
+
+/* 16-bit storage in, fp32 out: out [M, N] (fp32) = act(in [M, K] x w [N, K]^T + bias) for a plain product described by d (KH = KW = 1,
+ * dtype bf16 / f16): the sums leave the matrix cores without a rounding to the storage type -- for consumers that add many of them
+ * (the nine tap products of mt_proj under the 4-scale interpolation, R/models/saliency_decoder/sal_unet.py:480-489).  Runs on
+ * gemm_dma_kernel only: K % 192 == 0, N % 4 == 0; DIFFSAL_E_SHAPE otherwise. */
+extern "C" int diffsal_linear_f32out(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, float* out,
+                                     diffsal_stream_t stream) {
+  DS_REQUIRE(d && in && w && out, DIFFSAL_E_ARG, "linear_f32out: null argument");
+  int rc = validate(d);
+  if (rc) return rc;
+  DS_REQUIRE(is_linear(d) && d->dtype != DIFFSAL_F32 && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 &&
+                 d->act >= DIFFSAL_ACT_NONE && d->act <= DIFFSAL_ACT_SIGMOID,
+             DIFFSAL_E_ARG, "linear_f32out: a plain product on bf16 / f16 storage");
+  DS_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && (!bias || aligned16(bias)), DIFFSAL_E_ALIGN, "linear_f32out: misaligned pointer");
+  const int rr = try_gemm_dma(0, d, false, in, w, bias, nullptr, nullptr, nullptr, d->Cout, nullptr, out, nullptr, 0,
+                              static_cast<hipStream_t>(stream), true);
+  if (rr < 0) return rr;
+  DS_REQUIRE(rr == 1, DIFFSAL_E_SHAPE, "linear_f32out: K=%d must be a multiple of 192 and N=%d of 4", d->KH * d->KW * d->Cin, d->Cout);
   return DIFFSAL_OK;
 }
 

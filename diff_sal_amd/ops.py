@@ -797,12 +797,27 @@ def conv_igemm_group(problems: Sequence[dict], tag: str = "gemm") -> List[Tensor
 
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, *, act: int = ACT_NONE,
-           residual: Optional[Tensor] = None, tag: str = "K10") -> Tensor:
-    """Token GEMM: x [..., K] @ w[N, K]^T (+bias, act, +residual) through the same MFMA kernel."""
+           residual: Optional[Tensor] = None, tag: str = "K10", out_f32: bool = False) -> Tensor:
+    """Token GEMM: x [..., K] @ w[N, K]^T (+bias, act, +residual) through the same MFMA kernel.  ``out_f32`` (16-bit storage
+    only, no residual, K % 192 == 0): the result is fp32 -- the sums are not rounded to the storage type (``diffsal_linear_f32out``)."""
     lead = x.shape[:-1]
     M = 1
     for s in lead:
         M *= s
+    if out_f32:
+        if x.dtype == torch.float32 or residual is not None:
+            raise RuntimeError("linear(out_f32=True): 16-bit storage in, no residual")
+        lib = _lib.load()
+        K, N = x.shape[-1], w.shape[0]
+        dt = _dt(x)
+        d = ConvDesc(1, 1, M, K, 1, M, N, 1, 1, 1, 1, 0, 0, 1, 1, act, 0, 0, _lib.PREC_FP32, dt)
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        xc = x.reshape(M, K)
+        with _prof(tag, 2.0 * M * N * K, _nb(xc, w, out), f"M={M} K={K} N={N} 1x1 (fp32 out)" if PROFILE is not None else "") as pr:
+            _lib.check(lib.diffsal_linear_f32out(C.byref(d), _pa(xc, dt), _pa(w, dt), _p(bias), _p(out), _stream()), "linear_f32out")
+            if PROFILE is not None:
+                pr.kernel = lib.diffsal_last_gemm_kernel().decode()
+        return out.reshape(*lead, N)
     y = conv_igemm(x.reshape(1, 1, M, x.shape[-1]), w, bias=bias, act=act, tag=tag,
                    residual=None if residual is None else residual.reshape(1, 1, M, w.shape[0]))
     return y.reshape(*lead, w.shape[0])

@@ -264,6 +264,9 @@ class SalUNet(nn.Module):
         # 16-bit storage: only the uses listed in tap_conv16 (where GEMM + gather beat up-sampling + convolution).
         if not self.tap_conv or (taps is not None and self.taps_reference_forms):
             return False
+        if (which == "mt" and self.compute_dtype != torch.float32 and self.mt_tap16_f32 and self.fold_head
+                and self.ori_embed_dim % 192 == 0):       # diffsal_linear_f32out: K a multiple of 192
+            return True
         return self.compute_dtype == torch.float32 or which in self.tap_conv16
 
     def _gemm_w(self, w: Tensor) -> Tensor:
@@ -599,6 +602,10 @@ class SalUNet(nn.Module):
     # step (1720 -> 1779 steps/s; "s3" and "mt" lose), but the nine tap products are rounded to 16 bits before they are summed
     # and the worst bf16 fixture error moves from 2.2e-2 to 2.9e-2 against a 3e-2 bar.
     tap_conv16 = ()
+    # mt_proj on 16-bit storage as the tap form with fp32 tap products (no rounding before the nine interpolated products are summed,
+    # so the accuracy reason against tap_conv16 = ("mt",) does not apply) + the fp32 head gather: instead of the 4-scale sum, the
+    # 768 -> 96 convolution on it and the head kernel
+    mt_tap16_f32 = True
 
     def forward(self, x: Tensor, t: Tensor, feat_list: Sequence[Tensor], audio_feat_list: Optional[Tensor] = None,
                 taps: Optional[dict] = None) -> Tensor:
@@ -787,7 +794,10 @@ class SalUNet(nn.Module):
             ops.conv_igemm_group(redu, tag="K13")
         mt = dec.mt_proj
         if z_all is not None:
-            y9 = ops.linear(z_all, pk["mt.tapw"], None, tag="K14")
+            # 16-bit storage: the tap products leave the matrix cores in fp32 and the gather adds them in fp32 (ops.linear(out_f32)):
+            # nothing of mt_proj is rounded to 16 bits -- the 4-scale sum [B,112,192,768] (2.1 GB at 64 clips) does not exist either
+            f32_taps = cdt != torch.float32 and self.mt_tap16_f32 and "mt" not in self.tap_conv16 and self.ori_embed_dim % 192 == 0
+            y9 = ops.linear(z_all, pk["mt.tapw"], None, tag="K14", out_f32=f32_taps)
             ys, off = [], 0
             for z_ in zs:
                 m_ = z_.shape[0] * z_.shape[1] * z_.shape[2]

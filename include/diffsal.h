@@ -182,6 +182,12 @@ int diffsal_conv_igemm(const diffsal_conv_desc* d /*host*/, const void* in, cons
                        const float* bias, const float* scale, const float* shift, const float* rowvec,
                        const void* residual, void* out, void* ws, size_t ws_bytes, diffsal_stream_t stream);
 
+/* 16-bit storage in, fp32 out (plain products: KH = KW = 1, d->dtype bf16 / f16): out [M, Cout] fp32 = act(in x w^T + bias), the sums
+ * leave without a rounding to the storage type -- for consumers that add many products (the nine interpolated tap products of
+ * mt_proj, R/models/saliency_decoder/sal_unet.py:480-489).  K % 192 == 0, Cout % 4 == 0. */
+int diffsal_linear_f32out(const diffsal_conv_desc* d /*host*/, const void* in, const void* w, const float* bias, float* out,
+                          diffsal_stream_t stream);
+
 /* Winograd F(2x2, 3x3) form of the same operator for fp32 3x3 stride-1 convolutions with padding = dilation in {1, 2},
  * Cin % 32 == 0, Cout % 4 == 0 (ResnetBlock.conv1 / conv2, R/models/saliency_decoder/sal_unet.py:104-142; UpEmbed's second
  * convolution, common_block.py:196-216): 2.25x fewer multiplications; the result differs from the direct convolution by
