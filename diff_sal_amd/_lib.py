@@ -226,9 +226,13 @@ def check(rc, what=""):
         raise RuntimeError(f"libdiffsal_hip {what} failed (code {rc}): {msg}")
 
 
+TUNING_EPOCH = [0]      # bumped by set_tuning: host-side caches of the library's planner answers key on it
+
+
 def set_tuning(name: str, value) -> None:
     """Set a test / tuning switch of the library (include/diffsal.h: diffsal_set_tuning); None or a negative value unsets it."""
     check(load().diffsal_set_tuning(name.encode(), -1 if value is None else int(value)), "set_tuning")
+    TUNING_EPOCH[0] += 1
 
 
 def get_tuning(name: str) -> int:

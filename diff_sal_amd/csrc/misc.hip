@@ -452,6 +452,27 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ 
   // pass 3: out[b, c, t, y, :] = a * s, x fastest across lanes
   // flat over (channel, frame, x) with x fastest across lanes; the index split uses reciprocal multiplies (i < 2^23, exact
   // after the integer fix-up) instead of three integer divisions per 4-byte store
+  if ((W & 3) == 0) {
+    // four consecutive x per lane: one 16-byte (fp32) / 8-byte (16-bit) store instead of four 4 / 2-byte ones -- the pass writes the
+    // whole [B,C,T,H,W] tensor (74 MB at stage 3) and was bound by store instructions, not bytes
+    const int W4 = W >> 2, total4 = 32 * T * W4;
+    const float inv_w4 = 1.0f / static_cast<float>(W4), inv_t4 = 1.0f / static_cast<float>(T);
+    for (int i = threadIdx.x; i < total4; i += 256) {
+      int iw = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_w4);
+      int x4 = i - iw * W4;
+      if (x4 < 0) { --iw; x4 += W4; } else if (x4 >= W4) { ++iw; x4 -= W4; }
+      int cc = static_cast<int>((static_cast<float>(iw) + 0.5f) * inv_t4);
+      int t = iw - cc * T;
+      if (t < 0) { --cc; t += T; } else if (t >= T) { ++cc; t -= T; }
+      const int cg = cs * 32 + cc, xx = x4 * 4;
+      const TT* arow = a_small + ((static_cast<long>(b) * T + t) * h * w + ys * w) * a_ld + cg;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = static_cast<float>(arow[static_cast<long>((xx + e) / up) * a_ld]) * sh[cc * WP + xx + e];
+      st4(out + (((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    return;
+  }
   const int total = 32 * T * W;
   const float inv_w = 1.0f / static_cast<float>(W), inv_t = 1.0f / static_cast<float>(T);
   for (int i = threadIdx.x; i < total; i += 256) {

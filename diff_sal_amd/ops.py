@@ -292,6 +292,22 @@ def resblock_wino4_plan(x: Tensor, Cout: int, groups: int = 32) -> Optional[dict
     output transform can emit norm2's statistics."""
     if x.dtype != torch.float32 or get_gemm_precision() != "fp32":
         return None
+    key = ("res", tuple(x.shape), Cout, groups, _tuning_epoch())
+    if key in _PLAN_CACHE:
+        return _PLAN_CACHE[key]
+    plan = _resblock_wino4_plan(x, Cout, groups)
+    _PLAN_CACHE[key] = plan
+    return plan
+
+
+_PLAN_CACHE: dict = {}      # shape -> planner answers (they depend on the shape and the library's tuning switches only)
+
+
+def _tuning_epoch() -> int:
+    return _lib.TUNING_EPOCH[0]
+
+
+def _resblock_wino4_plan(x: Tensor, Cout: int, groups: int):
     lib = _lib.load()
     N, H, W, Cin = x.shape
     d1 = _wino4_desc(x, Cout, ACT_NONE, None)
@@ -306,8 +322,11 @@ def wino4_supported(x: Tensor, Cout: int, dil: int = 1) -> bool:
     """The planner takes the F(4x4, 3x3) path for a 3x3 / padding = dilation convolution of NHWC fp32 x to Cout channels."""
     if x.dtype != torch.float32 or get_gemm_precision() != "fp32":
         return False
-    d = _wino4_desc(x, Cout, ACT_NONE, None, dil)
-    return bool(_lib.load().diffsal_conv_wino4_supported(C.byref(d)))
+    key = ("w4", tuple(x.shape), Cout, dil, _tuning_epoch())
+    if key not in _PLAN_CACHE:
+        d = _wino4_desc(x, Cout, ACT_NONE, None, dil)
+        _PLAN_CACHE[key] = bool(_lib.load().diffsal_conv_wino4_supported(C.byref(d)))
+    return _PLAN_CACHE[key]
 
 
 def conv3x3_wino4_ex(x: Tensor, wino4: Tensor, *, bias: Optional[Tensor] = None, scale: Optional[Tensor] = None,

@@ -83,6 +83,14 @@ class _ParamTree:
                        norm2=nn.LayerNorm(c), align_conv=nn.Conv2d(512, c, 1))
 
 
+class _ShapeOnly:
+    """What ops.wino4_supported reads of a tensor (shape, fp32): the planner is asked about a map that does not exist yet."""
+    dtype = torch.float32
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
 class SalUNet(nn.Module):
     """See module docstring.  Keyword names follow R/models/saliency_decoder/sal_unet.py:147-179."""
 
@@ -736,7 +744,7 @@ class SalUNet(nn.Module):
                     # storage: every stage (the alternative is the convolution on the up-sampled map: 4x the products)
                     w2 = pk[f"s{i}.pe2.wino"]
                     if (f32c and self.fuse_up_pe2 and w2 is not None and w2.f4 is not None
-                            and ops.wino4_supported(torch.empty((Bn * T, 2 * h, 2 * w, C), device="meta"), C, 2)):
+                            and ops.wino4_supported(_ShapeOnly((Bn * T, 2 * h, 2 * w, C)), C, 2)):
                         # ... and UpEmbed's second convolution forms the interpolated interior itself as its input transform gathers
                         # it: only the border ring of the first convolution's output is ever written
                         u, c_ext = ops.up2_conv3x3_d2(xcur.view(Bn * T, h, w, Cp), pk[f"s{i}.pe1.w"], pk[f"s{i}.pe1.wino"], pk[f"s{i}.pe1.tapw"],
