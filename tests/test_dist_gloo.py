@@ -282,3 +282,39 @@ def test_train_step_goes_through_the_optimizer_face_and_keeps_scheduler_keys():
         opt.step()
         sched.step()
     assert own.n == 1 and abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12 and opt.param_groups[0]["initial_lr"] == 1e-4
+
+
+def test_batchnorm_buffers_become_views_of_one_flat_tensor_for_the_broadcast():
+    """DDP's broadcast_buffers (R/model.py:15) as ONE collective: the floating-point buffers are views of a flat tensor (no gather,
+    no per-buffer copy back); in-place running-statistics updates go through the views; a buffer replaced behind the step's back
+    (module.to(...), re-registration) is noticed and the flat tensor rebuilt."""
+    import torch.distributed as dist
+
+    from diff_sal_amd.train_step import DiffusionTrainStep
+
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+        created = True
+    try:
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1), torch.nn.BatchNorm2d(2))
+        ts = DiffusionTrainStep(m, exchange_single_rank=True)
+        assert ts.broadcast_buffers
+        m[1].running_mean.fill_(0.25)
+        ts._sync_buffers()
+        flat = ts._flat_buffers
+        floats = [b for b in m.buffers() if b.dtype == torch.float32]
+        assert flat is not None and len(floats) == 4
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        assert all(lo <= b.data_ptr() < hi for b in floats)                         # views, not copies
+        assert torch.all(m[1].running_mean == 0.25)                                  # values survived the move
+        m[3].running_var.mul_(3.0)                                                   # a kernel's in-place update ...
+        assert float(flat.sum()) == float(sum(b.sum() for b in floats))              # ... is seen by the flat tensor
+        m[1].running_mean = torch.full((4,), 0.5)                                    # replaced behind the step's back
+        ts._sync_buffers()
+        assert ts._flat_buffers is not flat                                          # rebuilt
+        assert m[1].running_mean.data_ptr() >= ts._flat_buffers.data_ptr() and torch.all(m[1].running_mean == 0.5)
+    finally:
+        if created:
+            dist.destroy_process_group()
