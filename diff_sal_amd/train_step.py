@@ -390,7 +390,7 @@ class DiffusionTrainStep:
         gather before it and no copy kernel per buffer after it (the denoiser + encoders hold ~100 such buffers; the copies were
         most of the exchange's exposed time at one rank).  Kernels that update running statistics write through the views."""
         bufs = [b for b in self.model.buffers() if b.dtype == torch.float32 and b.numel() > 0]
-        self._flat_buffers, self._flat_buffer_probe = None, None
+        self._flat_buffers = None
         if not bufs or any(b.device != bufs[0].device for b in bufs):
             return
         off, offs = 0, []
@@ -403,12 +403,13 @@ class DiffusionTrainStep:
             view.copy_(b)
             b.data = view
         self._flat_buffers = flat
-        self._flat_buffer_probe = (bufs[0], offs[0])
 
     def _sync_buffers(self) -> None:
-        probe = getattr(self, "_flat_buffer_probe", None)
-        stale = (probe is not None and self._flat_buffers is not None
-                 and probe[0].data_ptr() != self._flat_buffers.data_ptr() + 4 * probe[1])     # module.to(...) / a re-registered buffer
+        stale = False
+        if getattr(self, "_flat_buffers", None) is not None:       # module.to(...) / a re-registered buffer: the views are gone
+            lo = self._flat_buffers.data_ptr()
+            hi = lo + 4 * self._flat_buffers.numel()
+            stale = any(not (lo <= b.data_ptr() < hi) for b in self.model.buffers() if b.dtype == torch.float32 and b.numel() > 0)
         if getattr(self, "_flat_buffers", "unset") == "unset" or stale:
             self._flatten_buffers()
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
