@@ -309,22 +309,43 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
   };
   // (Deeper rings were tried with the items unrolled so that the set indices are static: hipcc then allocates 256-512 registers
   // and spills, scheduling barriers or not.  Two sets in a runtime loop is what it compiles well.)
-  TapVec<CPL> Va[3][NL], Vb[3][NL];
-  fetch(Va, 0);
-  constexpr int PAIRS = (NIT - 1) / 2;             // trips with both fetches unconditional (no phi copies of the register sets)
+  if constexpr (CPL <= 2) {
+    // light form (2 channels per lane): THREE register sets, the loads of items it + 1 and it + 2 in flight while item it is
+    // summed; NIT = 9 or 12 is a multiple of 3, so three items per trip keep the sets' roles fixed
+    TapVec<CPL> Va[3][NL], Vb[3][NL], Vc[3][NL];
+    fetch(Va, 0);
+    fetch(Vb, 1);
 #pragma unroll 1
-  for (int it = 0; it < 2 * PAIRS; it += 2) {
-    fetch(Vb, it + 1);
-    sum(Va, it);
-    fetch(Va, it + 2);
-    sum(Vb, it + 1);
-  }
-  if constexpr (NIT % 2 == 1) {
-    sum(Va, NIT - 1);
+    for (int it = 0; it < NIT - 3; it += 3) {
+      fetch(Vc, it + 2);
+      sum(Va, it);
+      fetch(Va, it + 3);
+      sum(Vb, it + 1);
+      fetch(Vb, it + 4);
+      sum(Vc, it + 2);
+    }
+    fetch(Vc, NIT - 1);
+    sum(Va, NIT - 3);
+    sum(Vb, NIT - 2);
+    sum(Vc, NIT - 1);
   } else {
-    fetch(Vb, NIT - 1);
-    sum(Va, NIT - 2);
-    sum(Vb, NIT - 1);
+    TapVec<CPL> Va[3][NL], Vb[3][NL];
+    fetch(Va, 0);
+    constexpr int PAIRS = (NIT - 1) / 2;             // trips with both fetches unconditional (no phi copies of the register sets)
+#pragma unroll 1
+    for (int it = 0; it < 2 * PAIRS; it += 2) {
+      fetch(Vb, it + 1);
+      sum(Va, it);
+      fetch(Va, it + 2);
+      sum(Vb, it + 1);
+    }
+    if constexpr (NIT % 2 == 1) {
+      sum(Va, NIT - 1);
+    } else {
+      fetch(Vb, NIT - 1);
+      sum(Va, NIT - 2);
+      sum(Vb, NIT - 1);
+    }
   }
 }
 
@@ -341,11 +362,22 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
   const long item = static_cast<long>(vb) * 4 + (threadIdx.x >> 6);
   if (item >= n_items) return;
   float* wtab = wtab_all[threadIdx.x >> 6];
-  long t = item;
   const int h_patches = a.H >> 2;
-  const int px = static_cast<int>(t % w_patches); t /= w_patches;
-  const int py = static_cast<int>(t % h_patches);
-  const int grp = static_cast<int>(t / h_patches);
+  int px, py, grp;
+  if (((w_patches | h_patches) & 1) == 0) {
+    // the four wavefronts of a workgroup take a 2 x 2 block of patches (not four in a row): their source windows overlap in rows
+    // AND columns, and they run on one CU -- one L1
+    const long blk = item >> 2;
+    const int wv = static_cast<int>(item & 3), wb = w_patches >> 1, hb = h_patches >> 1;
+    px = static_cast<int>(blk % wb) * 2 + (wv & 1);
+    py = static_cast<int>((blk / wb) % hb) * 2 + (wv >> 1);
+    grp = static_cast<int>(blk / (static_cast<long>(wb) * hb));
+  } else {
+    long t = item;
+    px = static_cast<int>(t % w_patches); t /= w_patches;
+    py = static_cast<int>(t % h_patches);
+    grp = static_cast<int>(t / h_patches);
+  }
   const int Y0 = uni_i(py * 4), X0 = uni_i(px * 4);
   const int n = grp * IMGS + sub, c = li * CPL;
   const int nc = n < a.N ? n : a.N - 1, cc = c < a.C ? c : a.C - CPL;   // dead lanes walk valid memory and contribute nothing
