@@ -563,7 +563,8 @@ class SalUNet(nn.Module):
                 h, w = 2 * h, 2 * w
             per_clip.append(T * h * w * self.up_channels[i] * 2)           # tokens and the MLP hidden layer
             tok += h * w
-        per_clip.append(tok * 9 * self.down_channel if tap_form else 4 * h * w * self.ori_embed_dim)   # mt_proj taps / 4-scale sum
+        # mt_proj taps / 4-scale sum; on 16-bit storage the tap products are fp32 (mt_tap16_f32): counted as two elements each
+        per_clip.append(tok * 9 * self.down_channel * (2 if es == 2 else 1) if tap_form else 4 * h * w * self.ori_embed_dim)
         worst = max(per_clip)
         by_bytes = ((1 << 32) - (1 << 24)) // (worst * es)
         by_count = ((1 << 31) - (1 << 24)) // worst
