@@ -560,9 +560,9 @@ class WinoWeights:
     """The Winograd forms of one 3x3 weight: ``f2`` (pack_wino_weight) and ``f4`` (pack_wino4_weight); conv_igemm(wino=...) asks
     the library per shape which of them -- if any -- to use."""
 
-    def __init__(self, w: Tensor):
-        self.f2 = pack_wino_weight(w) if w.shape[1] % 8 == 0 else None
-        self.f4 = pack_wino4_weight(w) if w.shape[1] % 96 == 0 else None
+    def __init__(self, w: Tensor, f2: bool = True, f4: bool = True):
+        self.f2 = pack_wino_weight(w) if f2 and w.shape[1] % 8 == 0 else None
+        self.f4 = pack_wino4_weight(w) if f4 and w.shape[1] % 96 == 0 else None
 
 
 @_classed("pack")

@@ -254,12 +254,13 @@ class SalUNet(nn.Module):
             return ops.cast(wp, self.compute_dtype)
         return ops.split_weight(wp) if self._precision() == "bf16x3" else wp
 
-    def _pack_wino(self, w: Tensor):
-        """Winograd F(2x2, 3x3) form of a 3x3 weight for the exact-fp32 path (ops.pack_wino_weight), else None: the library's
-        planner then decides per shape whether diffsal_conv_wino or the direct kernel runs (ops.conv_igemm(wino=...))."""
+    def _pack_wino(self, w: Tensor, f2: bool = True):
+        """Winograd forms of a 3x3 weight for the exact-fp32 path (F(2x2): ops.pack_wino_weight, F(4x4): ops.pack_wino4_weight), else
+        None: the library's planner then decides per shape which of them -- if any -- runs (ops.conv_igemm(wino=...)).  ``f2=False``:
+        only the F(4x4) form (a layer that can only use that one does not keep 16/9 of its weight bytes for nothing)."""
         if self.compute_dtype != torch.float32 or self._precision() != "fp32" or not self.winograd:
             return None
-        return ops.WinoWeights(w)
+        return ops.WinoWeights(w, f2=f2)
 
     def _tap_weight(self, w: Tensor) -> Tensor:
         """Conv2d 3x3 weight -> the [9*Cout, Cin] matrix of its nine 1x1 tap mixings (row = tap * Cout + co), in the storage /
@@ -323,7 +324,10 @@ class SalUNet(nn.Module):
                 pe = st.patch_embed[0].proj
                 pk[f"s{i}.pe1.w"] = self._pack_conv(pe[1].weight)
                 pk[f"s{i}.pe1.tapw"] = self._tap_weight(pe[1].weight)
-                pk[f"s{i}.pe1.wino"] = self._pack_wino(pe[1].weight)
+                # UpEmbed's first convolution uses a Winograd form only at the source resolution (extended grid: F(4x4) only) and only
+                # where the source map is at least 12 x 12 (_forward_eval): stage i reads a map of img / 32 * 2^(i-1)
+                hs, ws_ = (self.img_size[0] // 32) << (i - 1), (self.img_size[1] // 32) << (i - 1)
+                pk[f"s{i}.pe1.wino"] = self._pack_wino(pe[1].weight, f2=False) if min(hs, ws_) >= 12 else None
                 pk[f"s{i}.pe1.scale"], pk[f"s{i}.pe1.shift"] = self._bn_affine(pe[2])
                 pk[f"s{i}.pe2.w"] = self._pack_conv(pe[4].weight)
                 pk[f"s{i}.pe2.wino"] = self._pack_wino(pe[4].weight)
