@@ -34,7 +34,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 
 SIGNATURES = {
@@ -113,7 +113,8 @@ SIGNATURES = {
     "diffsal_attention_general_tail_floats": (c_sz, [c_i] * 5),
     "diffsal_attention_general_bwd_splits": (c_i, [c_i] * 4),
     "diffsal_attention_general_bwd_qtail_floats": (c_sz, [c_i] * 6),
-    "diffsal_attention_general_bwd": (c_i, [c_f] * 12 + [c_sz] + [c_f] * 4 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f]),
+    "diffsal_attention_general_bwd_ds_floats": (c_sz, [c_i] * 4),
+    "diffsal_attention_general_bwd": (c_i, [c_f] * 12 + [c_sz] + [c_f, c_sz] + [c_f] * 4 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f]),
     "diffsal_im2col3d": (c_i, [c_f, c_f] + [c_i] * 15 + [c_f]),
     "diffsal_pool3d_ln": (c_i, [c_f] * 5 + [c_i] * 9 + [C.c_long, C.c_long, c_fl, c_f]),
     "diffsal_maxpool_tokens": (c_i, [c_f, c_f] + [c_i] * 11 + [c_f]),
@@ -168,7 +169,7 @@ SIGNATURES = {
 }
 
 (WS_GROUPNORM, WS_CONV_IGEMM, WS_CONV_WINO, WS_CONV_WINO4, WS_CONV_WINO4_STATS, WS_CONV_WGRAD, WS_WGRAD_SEGMENTED, WS_TAPSUM_BWD,
- WS_SALIENCY_METRICS, WS_ATTENTION_TAIL, WS_ATTENTION_BWD_QTAIL) = range(11)      # enum DIFFSAL_WS_* of include/diffsal.h
+ WS_SALIENCY_METRICS, WS_ATTENTION_TAIL, WS_ATTENTION_BWD_QTAIL, WS_ATTENTION_BWD_DS) = range(12)      # enum DIFFSAL_WS_* of include/diffsal.h
 
 
 def workspace_bytes(op: int, desc=None, dims=()):

@@ -309,6 +309,11 @@ struct AttnBwdArgs {
   // adds them up): the last, partly filled round of workgroups (one per CU) fills the chip instead of a third of it.
   int qb_x, qb_full, qb_split, qb_bh;
   float* q_slabs;        // [qb_split][B*H*Lq][D + E]
+  // dS form: the dk / dv kernel leaves dS [B*H][Lq][Lkp] (Lkp = Lk rounded up to 32, zeros past Lk) and the dq kernel is the
+  // one product dS K' left over -- 4 + 1 tile products per (query, key) tile pair instead of 4 + 3 (288 GB of HBM: the 0.5 GB
+  // of the largest MViT layer is written and read once at a quarter of the memory rate while the matrix pipe works)
+  float* ds;
+  int Lkp;
   long q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, r_sb, r_sh, r_sl;
   int H, Lq, Lk;
   float scale;
@@ -544,7 +549,123 @@ __global__ __launch_bounds__(256) void attention_bwd_q_kernel(AttnBwdArgs p) {
     }
 }
 
+// dq kernel of the dS form: dQ'^T += K'^T dS^T with dS read back from the dk / dv kernel's buffer -- the last third of
+// attention_bwd_q_kernel (same tiles, same tail mode, same lane ownership: the sums run in the same order, so dq is
+// bit-identical to the recomputing kernel's given the same dS).
 template <int D, int E, int DV>
+__global__ __launch_bounds__(256, 2) void attention_bwd_q_ds_kernel(AttnBwdArgs p) {
+  constexpr int DQ = D + E;
+  constexpr int NQT = (DQ + 31) / 32;
+  constexpr int KP = NQT * 32 + 4;
+  __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int blk = blockIdx.x, piece = -1;
+  if (blk >= p.qb_full) {
+    const int t = blk - p.qb_full;
+    blk = p.qb_full + t / p.qb_split;
+    piece = t - (blk - p.qb_full) * p.qb_split;
+  }
+  const int bh = blk / p.qb_x, b = bh / p.H, h = bh - b * p.H;
+  const int ql = lane & 31, hf = lane >> 5;
+  const int qi = (blk - bh * p.qb_x) * 128 + wave * 32 + ql;
+  const int qc = qi < p.Lq ? qi : p.Lq - 1;
+
+  f32x16 acc[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* kb = p.k + b * p.k_sb + h * p.k_sh;
+  const float* dsrow = p.ds + (static_cast<long>(bh) * p.Lq + qc) * p.Lkp + hf * 4;
+  const int all_tiles = (p.Lk + 31) / 32;
+  const int per_piece = (all_tiles + p.qb_split - 1) / p.qb_split;
+  const int t_begin = piece < 0 ? 0 : piece * per_piece;
+  const int n_tiles = piece < 0 ? all_tiles : min(all_tiles, t_begin + per_piece);
+  constexpr int KC4 = NQT * 8;
+  constexpr int KF4 = 32 * KC4;
+  constexpr int KPT = (KF4 + 255) / 256;
+  float4 kreg[KPT], dreg[4];
+  auto fetch = [&](int tile) {
+    const int key0 = tile * 32;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
+      const int key = key0 + (row < 32 ? row : 31);
+      const long kc = key < p.Lk ? key : p.Lk - 1;
+      const float* src = kb + kc * p.k_sl + (c4 < D ? c4 : 0);
+      if constexpr (E > 0) src = (c4 < D || c4 >= DQ) ? src : p.k_extra + kc * E + (c4 - D);
+      kreg[i] = ld4(src);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dreg[g] = ld4(dsrow + key0 + 8 * g);     // keys hf*4 + 8 g + (0..3) of this lane's query
+  };
+  auto park = [&](int tile) {
+    const int key0 = tile * 32;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / KC4, c4 = (idx - row * KC4) * 4;
+      if (idx < KF4) st4(&Ks[row * KP + c4], keep_or_zero(kreg[i], key0 + row < p.Lk && c4 < DQ));
+    }
+  };
+  fetch(t_begin);
+  park(t_begin);
+  __syncthreads();
+  for (int tile = t_begin; tile < n_tiles; ++tile) {
+    float s[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { s[4 * g + 0] = dreg[g].x; s[4 * g + 1] = dreg[g].y; s[4 * g + 2] = dreg[g].z; s[4 * g + 3] = dreg[g].w; }
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+    mfma_groups_scalar_f32<NQT, 16>(
+        [&](int t, int r) { return &Ks[(hf * 4 + (r & 3) + 8 * (r >> 2)) * KP + t * 32 + ql]; },
+        [&](int t, const float (&a)[16]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], s[r], acc[t], 0, 0, 0);
+        });
+    __syncthreads();
+    if (tile + 1 < n_tiles) {
+      park(tile + 1);
+      __syncthreads();
+    }
+  }
+  if (qi >= p.Lq) return;
+  if (piece >= 0) {
+    float* sl = p.q_slabs + ((static_cast<long>(piece) * gridDimBH(p) + bh) * p.Lq + qi) * DQ;
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 32 * t + 4 * hf + 8 * g;
+        if (c >= DQ) continue;
+        const float sc = c < D ? p.scale : 1.0f;
+        st4(sl + c, make_float4(acc[t][4 * g + 0] * sc, acc[t][4 * g + 1] * sc, acc[t][4 * g + 2] * sc, acc[t][4 * g + 3] * sc));
+      }
+    return;
+  }
+  float* dqr = p.dq + (static_cast<long>(bh) * p.Lq + qi) * D;
+  float* der = E ? p.dq_extra + (static_cast<long>(bh) * p.Lq + qi) * E : nullptr;
+  const bool add_res = p.residual && !(p.skip_first && qi == 0);
+  const float* gres = p.dout + (static_cast<long>(b) * p.Lq + qi) * (static_cast<long>(p.H) * DV) + h * DV;
+#pragma unroll
+  for (int t = 0; t < NQT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * t + 4 * hf + 8 * g;
+      float4 v4 = make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+      if (c < D) {
+        v4.x *= p.scale; v4.y *= p.scale; v4.z *= p.scale; v4.w *= p.scale;
+        if (add_res) { const float4 r4 = ld4(gres + c); v4.x += r4.x; v4.y += r4.y; v4.z += r4.z; v4.w += r4.w; }
+        st4(dqr + c, v4);
+      } else if (c < DQ) {
+        st4(der + (c - D), v4);
+      }
+    }
+}
+
+
+template <int D, int E, int DV, bool WRITE_DS>
 __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
   constexpr int DQ = D + E;
   constexpr int HQ = DQ / 2, HV = DV / 2;
@@ -669,6 +790,18 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
       s[r] = pr;                                                 // P
       dp[r] = pr * (dp[r] - Ds[qrow_i]);                         // dS
     }
+    if constexpr (WRITE_DS) {                                    // dS[query][this lane's key]: 32 lanes = 128 contiguous bytes per row
+      if (ki < p.Lkp) {
+        const int qbase = tile * 32 + hf * 4;
+        float* dst = p.ds + (static_cast<long>(bh) * p.Lq + qbase) * p.Lkp + ki;
+        const bool key_ok = ki < p.Lk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dq_row = (r & 3) + 8 * (r >> 2);
+          if (qbase + dq_row < p.Lq) dst[static_cast<long>(dq_row) * p.Lkp] = key_ok ? dp[r] : 0.f;
+        }
+      }
+    }
     // dV^T += dO^T P and dK^T += (scale q)^T dS : A = dO / Q'[query row of (r, hf)][32 t + (lane & 31)], scalars read ahead
     mfma_groups_scalar_f32<2 * (NVT + NKT), 8>(                // group = (output tile, half of the 16 query rows)
         [&](int gg, int j) {
@@ -728,15 +861,35 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_sum_kernel(const float* 
 }
 
 template <int D, int E, int DV>
+static int launch_attention_bwd_kv(AttnBwdArgs& a, int B, hipStream_t s) {
+  const dim3 grid((a.Lk + 127) / 128, B * a.H, a.q_splits);
+  if (a.ds) hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV, false>), grid, dim3(256), 0, s, a);
+  int rc = check_launch("attention_general_bwd(dk, dv)");
+  if (rc || a.q_splits == 1) return rc;
+  const long n_dk = static_cast<long>(B) * a.H * a.Lk * D, n_dv = static_cast<long>(B) * a.H * a.Lk * DV;
+  long g = ((n_dk + n_dv) / 4 + 255) / 256;
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(attention_bwd_kv_sum_kernel, dim3(static_cast<int>(g)), dim3(256), 0, s, a.kv_part, a.dk, a.dv, n_dk, n_dv,
+                     a.q_splits);
+  return check_launch("attention_general_bwd(sum)");
+}
+
+template <int D, int E, int DV>
 static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
   const long rows = static_cast<long>(B) * a.H * a.Lq;
   hipLaunchKernelGGL((attention_bwd_delta_kernel<DV>), dim3(static_cast<unsigned>((rows + 31) / 32)), dim3(256), 0, s, a, rows);
   int rc = check_launch("attention_general_bwd(delta)");
   if (rc) return rc;
+  if (a.ds) {                // dS form: dk / dv first (it writes dS), then dq = dS K'
+    rc = launch_attention_bwd_kv<D, E, DV>(a, B, s);
+    if (rc) return rc;
+  }
   {
     const int total = a.qb_x * a.qb_bh;
     const int grid = a.qb_full + (total - a.qb_full) * a.qb_split;
-    hipLaunchKernelGGL((attention_bwd_q_kernel<D, E, DV>), dim3(grid), dim3(256), 0, s, a);
+    if (a.ds) hipLaunchKernelGGL((attention_bwd_q_ds_kernel<D, E, DV>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attention_bwd_q_kernel<D, E, DV>), dim3(grid), dim3(256), 0, s, a);
     rc = check_launch("attention_general_bwd(dq)");
     if (rc) return rc;
     if (a.qb_split > 1) {
@@ -749,15 +902,7 @@ static int launch_attention_bwd(AttnBwdArgs& a, int B, hipStream_t s) {
       if (rc) return rc;
     }
   }
-  hipLaunchKernelGGL((attention_bwd_kv_kernel<D, E, DV>), dim3((a.Lk + 127) / 128, B * a.H, a.q_splits), dim3(256), 0, s, a);
-  rc = check_launch("attention_general_bwd(dk, dv)");
-  if (rc || a.q_splits == 1) return rc;
-  const long n_dk = static_cast<long>(B) * a.H * a.Lk * D, n_dv = static_cast<long>(B) * a.H * a.Lk * DV;
-  long g = ((n_dk + n_dv) / 4 + 255) / 256;
-  g = g > 4096 ? 4096 : g;
-  hipLaunchKernelGGL(attention_bwd_kv_sum_kernel, dim3(static_cast<int>(g)), dim3(256), 0, s, a.kv_part, a.dk, a.dv, n_dk, n_dv,
-                     a.q_splits);
-  return check_launch("attention_general_bwd(sum)");
+  return a.ds ? 0 : launch_attention_bwd_kv<D, E, DV>(a, B, s);
 }
 
 }  // namespace diffsal
@@ -872,10 +1017,16 @@ extern "C" size_t diffsal_attention_general_bwd_qtail_floats(int B, int H, int L
   return sp > 1 ? static_cast<size_t>(sp) * B * H * Lq * (D + E) : 0;
 }
 
+// floats of the dS buffer of the backward's dS form: [B*H][Lq][Lk rounded up to 32]
+extern "C" size_t diffsal_attention_general_bwd_ds_floats(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  return static_cast<size_t>(B) * H * Lq * ((Lk + 31) / 32 * 32);
+}
+
 extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra,
                                              const float* v, const float* residual, const float* out, const float* lse,
                                              const float* dout, float* delta_ws, float* kv_part_ws, float* q_tail_ws,
-                                             size_t q_tail_ws_floats, float* dq, float* dq_extra,
+                                             size_t q_tail_ws_floats, float* ds_ws, size_t ds_ws_floats, float* dq, float* dq_extra,
                                              float* dk, float* dv, int B, int H, int Lq, int Lk, int D, int E, int DV,
                                              const long* q_strides, const long* k_strides, const long* v_strides,
                                              const long* r_strides, float scale, int skip_first, diffsal_stream_t stream) {
@@ -905,6 +1056,10 @@ extern "C" int diffsal_attention_general_bwd(const float* q, const float* q_extr
     q_tail_ws = nullptr;
   }
   a.q_slabs = q_tail_ws;
+  // dS form when the caller brings the buffer (NULL or a smaller one: the recomputing dq kernel)
+  a.ds = ds_ws && aligned16(ds_ws) && ds_ws_floats >= diffsal_attention_general_bwd_ds_floats(B, H, Lq, Lk) && tune(TUNE_NO_ATTN_BWD_DS) <= 0
+             ? ds_ws : nullptr;
+  a.Lkp = (Lk + 31) / 32 * 32;
   DS_REQUIRE(a.q_splits == 1 || (kv_part_ws && aligned16(kv_part_ws)), DIFFSAL_E_ARG,
              "attention_general_bwd: %d query splits need kv_part_ws of splits * B*H*Lk*(D+DV) floats", a.q_splits);
   DS_REQUIRE((static_cast<long>(B) * H * Lk * D) % 4 == 0, DIFFSAL_E_SHAPE, "attention_general_bwd: dk size");

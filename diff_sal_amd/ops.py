@@ -1600,8 +1600,11 @@ def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra:
     return (out, lse) if want_lse else out
 
 
+ATTN_BWD_DS = True      # dS form of the backward (include/diffsal.h): the dq kernel reads dS instead of recomputing S and dP
+
+
 def attention_general_bwd(q, k, v, out, lse, dout, *, scale: float, q_extra=None, k_extra=None, residual=None,
-                          skip_first: bool = False):
+                          skip_first: bool = False, ds_form: Optional[bool] = None):
     """-> (dq [B,H,Lq,D], dq_extra [B,H,Lq,E] or None, dk [B,H,Lk,D], dv [B,H,Lk,DV]); dq includes the residual path."""
     lib = _lib.load()
     B, H, Lq, D = q.shape
@@ -1616,11 +1619,13 @@ def attention_general_bwd(q, k, v, out, lse, dout, *, scale: float, q_extra=None
     kv_part = torch.empty((splits, B * H * Lk * (D + DV)), device=dev) if splits > 1 else None
     nq = lib.diffsal_attention_general_bwd_qtail_floats(B, H, Lq, Lk, D, E)      # dq kernel: pieces of its last partial round
     q_tail = torch.empty((nq,), device=dev) if nq else None
+    nds = lib.diffsal_attention_general_bwd_ds_floats(B, H, Lq, Lk) if (ATTN_BWD_DS if ds_form is None else ds_form) else 0
+    ds = torch.empty((nds,), device=dev) if nds else None
     flops = 2.0 * B * H * Lq * Lk * (2 * (D + E) + 2 * DV + D + E + DV)
     with _prof("attn-bwd", flops, _nb(q, k, v, out, dout, dq, dk, dv)):
         _lib.check(lib.diffsal_attention_general_bwd(
             q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
-            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(q_tail), nq, _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk,
+            _p(out), _p(lse), _p(dout.contiguous()), _p(delta), _p(kv_part), _p(q_tail), nq, _p(ds), nds, _p(dq), _p(dqe), _p(dk), _p(dv), B, H, Lq, Lk,
             D, E, DV,
             _bhl_strides(q), _bhl_strides(k), _bhl_strides(v), None if residual is None else _bhl_strides(residual),
             float(scale), int(skip_first), _stream()), "attention_general_bwd")

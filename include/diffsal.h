@@ -171,7 +171,8 @@ enum {
   DIFFSAL_WS_TAPSUM_BWD = 7,     /* dims = {N, W, C, h}                diffsal_tapsum_bwd_ws_bytes */
   DIFFSAL_WS_SALIENCY_METRICS = 8, /* dims = {B}                       diffsal_saliency_metrics_ws_bytes */
   DIFFSAL_WS_ATTENTION_TAIL = 9, /* dims = {B, H, Lq, Lk, DV}          4 x diffsal_attention_general_tail_floats */
-  DIFFSAL_WS_ATTENTION_BWD_QTAIL = 10 /* dims = {B, H, Lq, Lk, D, E}   4 x diffsal_attention_general_bwd_qtail_floats */
+  DIFFSAL_WS_ATTENTION_BWD_QTAIL = 10, /* dims = {B, H, Lq, Lk, D, E}  4 x diffsal_attention_general_bwd_qtail_floats */
+  DIFFSAL_WS_ATTENTION_BWD_DS = 11     /* dims = {B, H, Lq, Lk}        4 x diffsal_attention_general_bwd_ds_floats */
 };
 size_t diffsal_workspace_bytes(int op, const diffsal_conv_desc* d /*host, may be NULL*/, const long* dims /*host*/, int n_dims);
 
@@ -587,10 +588,14 @@ int diffsal_attention_general_bwd_splits(int B, int H, int Lq, int Lk); /* S; kv
  * last, partly filled round of workgroups into pieces over the keys and a finishing launch adds their partial rows (fixed
  * order); without it (NULL, or the function returned 0) every block runs whole. */
 size_t diffsal_attention_general_bwd_qtail_floats(int B, int H, int Lq, int Lk, int D, int E);
+/* ds_ws (optional): ds_ws_floats >= diffsal_attention_general_bwd_ds_floats(...) floats (NULL or a smaller buffer: ignored).  With it the dk / dv kernel leaves
+ * dS [B*H][Lq][Lk rounded up to 32] there and dq is the one product dS K' (five tile products per query / key tile pair instead of seven: the recomputation of
+ * S and dP in the dq kernel is traded for one write and one read of dS); same sums in the same order, dq bit-identical to the recomputing form. */
+size_t diffsal_attention_general_bwd_ds_floats(int B, int H, int Lq, int Lk);
 int diffsal_attention_general_bwd(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
                                   const float* residual, const float* out, const float* lse, const float* dout,
-                                  float* delta_ws, float* kv_part_ws, float* q_tail_ws, size_t q_tail_ws_floats, float* dq,
-                                  float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
+                                  float* delta_ws, float* kv_part_ws, float* q_tail_ws, size_t q_tail_ws_floats, float* ds_ws,
+                                  size_t ds_ws_floats, float* dq, float* dq_extra, float* dk, float* dv, int B, int H, int Lq,
                                   int Lk, int D, int E, int DV, const long* q_strides, const long* k_strides,
                                   const long* v_strides, const long* r_strides, float scale, int skip_first,
                                   diffsal_stream_t stream);

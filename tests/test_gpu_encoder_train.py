@@ -57,6 +57,31 @@ def test_attention_general_backward(shape):
         close(a.grad, b.grad, 5e-5, n)
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 150, 70, 64, 0), (1, 2, 121, 31, 96, 48), (1, 16, 2689, 673, 96, 32), (2, 1, 1000, 97, 96, 32)])
+def test_attention_backward_ds_form_is_bit_identical(shape):
+    """The dS form (dk / dv kernel leaves dS, the dq kernel is the one product dS K') against the recomputing dq kernel: the same
+    sums in the same order -> identical bits in every output, with and without the dq kernel's tail mode."""
+    from diff_sal_amd import ops
+
+    B, H, Lq, Lk, D, E = shape
+    q, k, v = (rnd(n, B, H, L, D).to(DEV) for n, L in (("bq", Lq), ("bk", Lk), ("bv", Lk)))
+    qe = rnd("bqe", B, H, Lq, E, scale=0.3).to(DEV) if E else None
+    ke = None
+    if E:
+        ke = torch.zeros(Lk, E)
+        ke[torch.arange(1, Lk), torch.randint(0, E, (Lk - 1,), generator=torch.Generator().manual_seed(1))] = 1.0
+        ke = ke.to(DEV)
+    G = rnd("bg", B, Lq, H * D).to(DEV)
+    kw = dict(scale=D ** -0.5, q_extra=qe, k_extra=ke, residual=q if E else None, skip_first=bool(E))
+    out, lse = ops.attention_general(q, k, v, want_lse=True, **kw)
+    a = ops.attention_general_bwd(q, k, v, out, lse, G, ds_form=False, **kw)
+    b = ops.attention_general_bwd(q, k, v, out, lse, G, ds_form=True, **kw)
+    for x, y, n in zip(a, b, ("dq", "dq_extra", "dk", "dv")):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert torch.equal(x, y), n
+
+
 def test_pool_maxpool_relpos_backward():
     from diff_sal_amd import encoder_autograd as eg
 
