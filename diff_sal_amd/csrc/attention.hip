@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_q_ds_kernel(AttnBwdArgs 
   constexpr int DQ = D + E;
   constexpr int NQT = (DQ + 31) / 32;
   constexpr int KP = NQT * 32 + 4;
-  __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
+  __shared__ __attribute__((aligned(16))) float Ks2[2][32 * KP];   // two stages, one barrier per key tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int blk = blockIdx.x, piece = -1;
   if (blk >= p.qb_full) {
@@ -601,7 +601,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_q_ds_kernel(AttnBwdArgs 
 #pragma unroll
     for (int g = 0; g < 4; ++g) dreg[g] = ld4(dsrow + key0 + 8 * g);     // keys hf*4 + 8 g + (0..3) of this lane's query
   };
-  auto park = [&](int tile) {
+  auto park = [&](int tile, int st) {
+    float* Ks = Ks2[st];
     const int key0 = tile * 32;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -611,9 +612,11 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_q_ds_kernel(AttnBwdArgs 
     }
   };
   fetch(t_begin);
-  park(t_begin);
+  park(t_begin, 0);
   __syncthreads();
   for (int tile = t_begin; tile < n_tiles; ++tile) {
+    const int cur = (tile - t_begin) & 1;
+    const float* Ks = Ks2[cur];
     float s[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { s[4 * g + 0] = dreg[g].x; s[4 * g + 1] = dreg[g].y; s[4 * g + 2] = dreg[g].z; s[4 * g + 3] = dreg[g].w; }
@@ -624,11 +627,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_q_ds_kernel(AttnBwdArgs 
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], s[r], acc[t], 0, 0, 0);
         });
+    if (tile + 1 < n_tiles) park(tile + 1, cur ^ 1);
     __syncthreads();
-    if (tile + 1 < n_tiles) {
-      park(tile + 1);
-      __syncthreads();
-    }
   }
   if (qi >= p.Lq) return;
   if (piece >= 0) {
@@ -672,9 +672,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
   constexpr int NKT = D / 32, NVT = DV / 32;
   constexpr int QP = DQ + 4, GP = DV + 4;
   static_assert(D % 32 == 0, "dK tiles");
-  __shared__ __attribute__((aligned(16))) float Qs[32 * QP];    // [q*scale | q_extra] of the current query tile
-  __shared__ __attribute__((aligned(16))) float Gs[32 * GP];    // dO of the current query tile
-  __shared__ float Ls[32], Ds[32];                               // lse, delta
+  // two stages: the next query tile is parked between the two halves of this tile's MFMAs (its loads were issued at the top of
+  // the iteration) -- one barrier per tile and no wait for memory behind it
+  __shared__ __attribute__((aligned(16))) float Qs2[2][32 * QP];   // [q*scale | q_extra] of a query tile
+  __shared__ __attribute__((aligned(16))) float Gs2[2][32 * GP];   // its dO
+  __shared__ float Ls2[2][32], Ds2[2][32];                          // lse, delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int kl = lane & 31, hf = lane >> 5;
@@ -745,7 +747,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
       dreg = p.delta[static_cast<long>(bh) * p.Lq + qcl];
     }
   };
-  auto park = [&](int tile) {
+  auto park = [&](int tile, int st) {
+    float* Qs = Qs2[st]; float* Gs = Gs2[st]; float* Ls = Ls2[st]; float* Ds = Ds2[st];
     const int q0 = tile * 32;
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
@@ -769,9 +772,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
     }
   };
   fetch(tile_lo);
-  park(tile_lo);
+  park(tile_lo, 0);
   __syncthreads();
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int cur = (tile - tile_lo) & 1;
+    const float* Qs = Qs2[cur]; const float* Gs = Gs2[cur]; const float* Ls = Ls2[cur]; const float* Ds = Ds2[cur];
     if (tile + 1 < tile_hi) fetch(tile + 1);
     // S = Q' K'^T (rows = queries, column = this lane's key):  A = Q'[query = lane & 31][hf*HQ + j], B = kf[j]
     f32x16 s, dp;
@@ -802,6 +807,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
         }
       }
     }
+    if (tile + 1 < tile_hi) park(tile + 1, cur ^ 1);             // nobody reads that stage before the barrier below
     // dV^T += dO^T P and dK^T += (scale q)^T dS : A = dO / Q'[query row of (r, hf)][32 t + (lane & 31)], scalars read ahead
     mfma_groups_scalar_f32<2 * (NVT + NKT), 8>(                // group = (output tile, half of the 16 query rows)
         [&](int gg, int j) {
@@ -820,10 +826,6 @@ __global__ __launch_bounds__(256) void attention_bwd_kv_kernel(AttnBwdArgs p) {
           }
         });
     __syncthreads();
-    if (tile + 1 < tile_hi) {
-      park(tile + 1);
-      __syncthreads();
-    }
   }
   if (ki >= p.Lk) return;
   float* dkr = p.dk + (static_cast<long>(bh) * p.Lk + ki) * D;
