@@ -620,7 +620,7 @@ struct TileCfg16 { int bm, bn, occ; float eff; };
 // delivered through L1 at ~27 B/clk/CU the two-resident 128x96 / 128x128 tiles win almost everywhere; the 256-row
 // tiles (one resident workgroup, two stages of prefetch) do not cover the load latency yet and lose 30-40 %.
 static const TileCfg16 kCfgs16[] = {{128, 192, 1, 0.62f}, {128, 128, 2, 0.70f}, {128, 96, 2, 0.75f}, {64, 128, 2, 0.55f},
-                                    {128, 64, 2, 0.55f},  {64, 64, 4, 0.55f},   {256, 96, 1, 0.50f},  {256, 128, 1, 0.50f}};
+                                    {128, 64, 2, 0.55f},  {64, 64, 4, 0.40f},   {256, 96, 1, 0.50f},  {256, 128, 1, 0.50f}};
 constexpr int kNumCfgs16 = 8;
 constexpr int kCUs16 = 256;
 
@@ -646,9 +646,15 @@ static Plan16 choose_plan16(long M, int Cout, int K) {
       const int st_per = (NST + S - 1) / S;
       const double t_mfma = static_cast<double>(t.bm) * t.bn * (st_per * STK) / (mac_per_s_cu * t.eff);
       const double resident = static_cast<double>(wgs < slots ? (wgs + kCUs16 - 1) / kCUs16 : t.occ);
-      const double round = resident * t_mfma > t_mfma + t_fixed ? resident * t_mfma : t_mfma + t_fixed;
+      // a lone workgroup on a CU is bound by the latency of a stage (load -> LDS -> MFMA: 0.35 us + 0.1 us per 64 x 64 of tile), not
+      // by the matrix rate: long-K products with few tiles (res2's convolutions, UpEmbed-1's extended-grid convolution, K = 6912)
+      // take the K split.  Constants fitted to the sweep of every (tile, split) on the step's 23 convolution shapes
+      // (tools/tune_igemm16.py, TUNE_SPLITS=0,1,2): regret 69 -> 28 us per step; 53 -> 39 us, 75 -> 52 us on the two named above
+      const double t_stage = 0.35e-6 + 0.1e-6 * (t.bm * t.bn / 4096.0);
+      const double t_alone = (t_mfma > st_per * t_stage ? t_mfma : st_per * t_stage) + t_fixed;
+      const double round = resident * t_mfma > t_alone ? resident * t_mfma : t_alone;
       double tt = rounds * round;
-      if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6;
+      if (S > 1) tt += (S + 1.0) * M * Cout * 4.0 / 3.0e12 + 4.0e-6 + 0.5e-6 * S;
       if (tt < best_t) { best_t = tt; best = Plan16{c, S}; }
     }
   }
@@ -690,9 +696,13 @@ int conv16_halo_launch(const diffsal_conv_desc* d, const void* in, const void* w
 static Plan16 plan_for(const diffsal_conv_desc* d) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   Plan16 pl = choose_plan16(M, d->Cout, d->KH * d->KW * d->Cin);
-  if (tune(TUNE_IGEMM16_CFG) >= 0) {  // tuning aid: force a tile shape (no split-K)
-    pl.cfg = tune(TUNE_IGEMM16_CFG) % kNumCfgs16;
+  if (tune(TUNE_IGEMM16_CFG) >= 0) {  // tuning aid: force a tile shape (value % 8) and 2^(value / 8) K splits
+    const int v = tune(TUNE_IGEMM16_CFG);
+    pl.cfg = v % kNumCfgs16;
     pl.splits = 1;
+    const int NST = (d->KH * d->KW * d->Cin / SUBK + 1) / 2;
+    for (int e = 0; e < v / kNumCfgs16 && e < 4; ++e)
+      if (NST / (pl.splits * 2) >= 4 && d->Cout % 4 == 0) pl.splits *= 2;
   }
   if (conv16_halo_applies(d)) pl.splits = 1;   // halo-eligible shapes report no workspace; keep the pointer-alignment fallback valid
   return pl;
