@@ -34,7 +34,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 
 SIGNATURES = {
@@ -145,7 +145,7 @@ SIGNATURES = {
     "diffsal_up2_conv_commute_ring": (c_i, [c_f] * 5 + [c_i] * 6 + [c_f]),
     "diffsal_rel_tables": (c_i, [c_f] * 5 + [c_i, c_f]),
     "diffsal_rel_tables_bwd": (c_i, [c_f] * 6 + [c_i, c_f]),
-    "diffsal_qkv_pool_bwd_weight_chunks": (c_i, []),
+    "diffsal_qkv_pool_bwd_weight_chunks": (c_i, [c_i] * 5 + [C.POINTER(c_i)]),
     "diffsal_qkv_pool_bwd_weight": (c_i, [c_f] * 3 + [c_i] * 6 + [c_f] * 2 + [c_i, c_f]),
     "diffsal_relpos_project_bwd_chunks": (c_i, []),
     "diffsal_relpos_project_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] + [c_i] * 9 + [c_f]),

@@ -58,6 +58,9 @@ struct QkvPoolArgs {
   int blocks[2];           // workgroups per tensor
   int iters;               // 32-token passes per workgroup
   int w_channel_major;     // 1: filters (and their gradients) in the parameter's own [96][27] layout instead of tap-major [27][96]
+  // run forms (below): per tensor the run length (0: the token-per-lane-group form above handles it), its workgroups and the
+  // passes per workgroup
+  int run_R[3], run_blocks[3], run_iters;
 };
 
 // the 27 x 96 filter of one tensor -> LDS as [tap][channel quad] (+ a 28th all-zero row), from either memory layout
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_data_kernel(QkvPoolArgs p) {
     if (blk >= p.blocks[1]) { blk -= p.blocks[1]; which = 2; }
   }
   const int g = which ? 1 : 0;
+  if (p.run_R[which]) return;                  // this tensor goes through the run form
   stage_filter(w_s, p.w27[which], p.w_channel_major);
   __syncthreads();
   const int gl = threadIdx.x & 7, gr = threadIdx.x >> 3;
@@ -264,13 +268,171 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_data_kernel(QkvPoolArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Run forms of the two gradient kernels (fp32, temporal stride 1, equal spatial strides 1 or 2, row length a
+// multiple of 4).  The token-per-lane-group forms issue one 16-byte load per (token, tap, 4 channels): 27 x 24 requests per
+// stride-1 token, and the texture addresser (64 B / clk / CU) is what bounds them (64 us for the 43 k tokens x 3 tensors of a
+// stage-3 block: 8 % of the memory rate).  Here a thread owns a RUN of R consecutive tokens of one row and 4 channels: a kernel
+// row's inputs are loaded once for the whole run ((R - 1) s + 3 loads for 3 R taps; R = 8, s = 1: 11.25 loads per token instead
+// of 27) and a token's 24 channel quads sit in consecutive lanes (384 contiguous bytes).  Tap order and fmaf chains per output
+// are those of the forms above: the data gradient is bit-identical to them; the filter gradient (thread = (token lane, kernel
+// plane, quad) as above, a run per step) sums its outputs in another order.  The forward stays on the token form: it runs at
+// 3 TB/s there and the run form measured the same or slower (tools/bench_pool.py).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int RUNS = 10;                       // data gradient: runs per 256-thread pass (240 threads = 10 runs x 24 channel quads)
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int R, int S>
+__device__ __forceinline__ void pool_bwd_data_runs(const QkvPoolArgs& p, const float4* w_s, int which, int blk) {
+  constexpr int NC = S == 1 ? R + 2 : R / 2 + 1;
+  const int g = which ? 1 : 0;
+  const int quad = threadIdx.x % PQ, rl = threadIdx.x / PQ;
+  if (rl >= RUNS) return;
+  const int T = p.T, H = p.H, W = p.W, To = p.To[g], Ho = p.Ho[g], Wo = p.Wo[g], heads = p.heads;
+  const int N = 1 + T * H * W, Lo = To * Ho * Wo, rpr = W / R;
+  const int n_video = p.B * heads * T * H * rpr, n_runs = n_video + p.B * heads;
+  const float* __restrict__ dy = p.dy[which];
+  for (int pass = 0; pass < p.run_iters; ++pass) {
+    const int run = (blk * p.run_iters + pass) * RUNS + rl;
+    if (run >= n_runs) return;
+    if (run >= n_video) {
+      const int bh = run - n_video, b = bh / heads, head = bh - b * heads;
+      st4(p.dqkv + (static_cast<long>(b) * N * 3 + which) * heads * PD + head * PD + quad * 4,
+          ld4(dy + static_cast<long>(bh) * (Lo + 1) * PD + quad * 4));
+      continue;
+    }
+    int r = run;
+    const int j = r % rpr; r /= rpr;
+    const int iy = r % H; r /= H;
+    const int it = r % T;
+    const int bh = r / T, b = bh / heads, head = bh - b * heads;
+    const float* dyb = dy + static_cast<long>(bh) * (Lo + 1) * PD + quad * 4;
+    const int ix0 = j * R, nx_base = S == 1 ? ix0 - 1 : ix0 / 2;
+    float4 acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = zero4();
+#pragma unroll 1
+    for (int kt = 0; kt < 3; ++kt) {
+      const int nt = it + 1 - kt;
+      if (nt < 0 || nt >= To) continue;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int d = iy + 1 - ky;
+        if (d < 0 || (S == 2 && (d & 1))) continue;
+        const int ny = S == 1 ? d : d >> 1;
+        if (ny >= Ho) continue;
+        const float* rowp = dyb + static_cast<long>(1 + (nt * Ho + ny) * Wo) * PD;
+        float4 seg[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int nx = nx_base + c;
+          seg[c] = ld4((nx >= 0 && nx < Wo) ? rowp + nx * PD : dyb);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int nx = nx_base + c;
+          if (!(nx >= 0 && nx < Wo)) seg[c] = zero4();
+        }
+        const float4* wr = w_s + (kt * 3 + ky) * 3 * PQ + quad;
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            constexpr int dummy = 0; (void)dummy;
+            const int e = i + 1 - kx;                                  // output column x stride = input column + 1 - kx
+            if (S == 1) acc[i] = fma4(seg[e + 1], wr[kx * PQ], acc[i]);
+            else if (e >= 0 && (e & 1) == 0) acc[i] = fma4(seg[e >> 1], wr[kx * PQ], acc[i]);
+          }
+      }
+    }
+    float* dst = p.dqkv + ((static_cast<long>(b) * N + 1 + (it * H + iy) * W + ix0) * 3 + which) * heads * PD + head * PD + quad * 4;
+#pragma unroll
+    for (int i = 0; i < R; ++i) st4(dst + static_cast<long>(i) * 3 * heads * PD, acc[i]);
+  }
+}
+
+template <int R, int S>
+__device__ __forceinline__ void pool_bwd_weight_runs(const QkvPoolArgs& p, int which, float4 (&acc)[9], int kt, int tl, int quad, int lo,
+                                                     int hi) {
+  constexpr int NC = (R - 1) * S + 3;
+  const int g = which ? 1 : 0;
+  const int T = p.T, H = p.H, W = p.W, To = p.To[g], Ho = p.Ho[g], Wo = p.Wo[g], heads = p.heads;
+  const int Lo = To * Ho * Wo, rpr = Wo / R;
+  const int tok_stride = 3 * heads * PD;
+  const long clip_stride = static_cast<long>(1 + T * H * W) * tok_stride;
+  const float* __restrict__ qkv = static_cast<const float*>(p.qkv);
+  const float* __restrict__ dy = p.dy[which];
+  for (int run = lo + tl; run < hi; run += 3) {
+    int r = run;
+    const int j = r % rpr; r /= rpr;
+    const int ho = r % Ho; r /= Ho;
+    const int to = r % To;
+    const int bh = r / To, b = bh / heads, head = bh - b * heads;
+    const int it = to - 1 + kt;
+    if (it < 0 || it >= T) continue;
+    const float* base = qkv + b * clip_stride + (which * heads + head) * PD + quad * 4;
+    const int wo0 = j * R, x0 = wo0 * S - 1, y0 = ho * S - 1;
+    const float* dyp = dy + (static_cast<long>(bh) * (Lo + 1) + 1 + (to * Ho + ho) * Wo + wo0) * PD + quad * 4;
+    float4 gy[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) gy[i] = ld4(dyp + i * PD);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y0 + ky;
+      if (iy < 0 || iy >= H) continue;
+      const float* rowp = base + static_cast<long>(1 + (it * H + iy) * W) * tok_stride;
+      float4 seg[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ix = x0 + c;
+        seg[c] = ld4((ix >= 0 && ix < W) ? rowp + ix * tok_stride : base);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ix = x0 + c;
+        if (!(ix >= 0 && ix < W)) seg[c] = zero4();
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[ky * 3 + kx] = fma4(seg[i * S + kx], gy[i], acc[ky * 3 + kx]);
+    }
+  }
+}
+
+__device__ __forceinline__ int run_which(const QkvPoolArgs& p, int& blk) {
+  int which = 0;
+  if (blk >= p.run_blocks[0]) {
+    blk -= p.run_blocks[0]; which = 1;
+    if (blk >= p.run_blocks[1]) { blk -= p.run_blocks[1]; which = 2; }
+  }
+  return which;
+}
+
+__global__ __launch_bounds__(256) void qkv_pool_bwd_data_runs_kernel(QkvPoolArgs p) {
+  __shared__ float4 w_s[28 * PQ];
+  int blk = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int which = run_which(p, blk), g = which ? 1 : 0;
+  stage_filter(w_s, p.w27[which], p.w_channel_major);
+  __syncthreads();
+  const int R = p.run_R[which], S = p.sh[g];
+  if (S == 1 && R == 8) pool_bwd_data_runs<8, 1>(p, w_s, which, blk);
+  else if (S == 1) pool_bwd_data_runs<4, 1>(p, w_s, which, blk);
+  else if (R == 8) pool_bwd_data_runs<8, 2>(p, w_s, which, blk);
+  else pool_bwd_data_runs<4, 2>(p, w_s, which, blk);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // filter gradient of the three poolings in one launch: dw_x[tap][c] = sum over output tokens of dy_x[out][c] * in_x[tap of out][c].
 // blockIdx.y = tensor, blockIdx.x = chunk of its output tokens; thread = (token lane 0..2, kernel plane kt, channel quad), nine
 // taps each; the three token lanes are combined in a fixed order in LDS (double) and the chunk sums go to part[x][chunk][27*96]
 // for diffsal_reduce_partials(segs = 3).  Same products and per-thread order as pool3d_bwd_weight_kernel; 512 chunks per
 // tensor instead of 1024 per launch (a quarter of the partial-sum traffic for the three tensors).
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int QKV_WCHUNKS = 512;
+// chunks of output tokens per tensor (gridDim.x): 512, or 170 (two workgroups per CU over the three tensors, a third of the
+// partial-sum traffic) when the query tensor has <= 6000 runs -- a thread then still walks <= 12 of them; measured per stage in
+// tools/bench_pool.py (stage 3: 47 -> 42 us, stage 4: 44 -> 36 us; stage 1 / 2 lose with 170)
+static int qkv_wchunks(long q_runs) { return q_runs > 6000 ? 512 : 170; }
 
 __global__ __launch_bounds__(256) void qkv_pool_bwd_weight_kernel(QkvPoolArgs p, double* __restrict__ part) {
   __shared__ double shw[27 * PD];
@@ -284,15 +446,23 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_weight_kernel(QkvPoolArgs p,
   const int rows = p.B * heads * Lo;                                   // video tokens of the output
   const int tok_stride = 3 * heads * PD;
   const long clip_stride = static_cast<long>(1 + T * H * W) * tok_stride;
-  const int lo = static_cast<int>(static_cast<long>(rows) * blockIdx.x / QKV_WCHUNKS);
-  const int hi = static_cast<int>(static_cast<long>(rows) * (blockIdx.x + 1) / QKV_WCHUNKS);
+  const int lo = static_cast<int>(static_cast<long>(rows) * blockIdx.x / gridDim.x);
+  const int hi = static_cast<int>(static_cast<long>(rows) * (blockIdx.x + 1) / gridDim.x);
   const float inv_lo = 1.0f / static_cast<float>(Lo), inv_heads = 1.0f / static_cast<float>(heads);
   const float inv_wo = 1.0f / static_cast<float>(Wo), inv_ho = 1.0f / static_cast<float>(Ho);
   const float* __restrict__ dy = p.dy[which];
   float4 acc[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
+  if (live && p.run_R[which]) {                  // run form: a run of R outputs of one row per step, its inputs loaded once per kernel row
+    const int R = p.run_R[which];
+    const int n_video = p.B * heads * To * Ho * (Wo / R);
+    const int rlo = static_cast<int>(static_cast<long>(n_video) * blockIdx.x / gridDim.x);
+    const int rhi = static_cast<int>(static_cast<long>(n_video) * (blockIdx.x + 1) / gridDim.x);
+    if (sh == 1 && R == 8) pool_bwd_weight_runs<8, 1>(p, which, acc, kt, tl, c / 4, rlo, rhi);
+    else if (sh == 1) pool_bwd_weight_runs<4, 1>(p, which, acc, kt, tl, c / 4, rlo, rhi);
+    else pool_bwd_weight_runs<4, 2>(p, which, acc, kt, tl, c / 4, rlo, rhi);
+  } else if (live) {
     for (int r = lo + tl; r < hi; r += TL) {
       const int bh = div_fast_(r, Lo, inv_lo);
       const int l = r - bh * Lo;
@@ -340,7 +510,7 @@ __global__ __launch_bounds__(256) void qkv_pool_bwd_weight_kernel(QkvPoolArgs p,
     }
     __syncthreads();
   }
-  double* o = part + (static_cast<long>(which) * QKV_WCHUNKS + blockIdx.x) * 27 * PD;
+  double* o = part + (static_cast<long>(which) * gridDim.x + blockIdx.x) * 27 * PD;
   for (int i = threadIdx.x; i < 27 * PD; i += 256) {
     const int tap = i / PD, ch = i - tap * PD;
     o[p.w_channel_major ? ch * 27 + tap : i] = shw[i];
@@ -523,6 +693,36 @@ static int fill_geometry(QkvPoolArgs& a, int B, int heads, int T, int H, int W, 
   return DIFFSAL_OK;
 }
 
+// Run-form plan of one launch: axis_len(g) = the row length the runs walk (outputs for the forward / filter gradient, inputs
+// for the data gradient); r8_s2: run length 8 at stride 2 (data gradient only).  -> number of run-form workgroups.
+static unsigned plan_runs(QkvPoolArgs& a, bool allowed, bool data, long* total_runs) {
+  long total = 0;
+  long n_runs[3] = {0, 0, 0};
+  for (int x = 0; x < 3; ++x) {
+    const int g = x ? 1 : 0;
+    a.run_R[x] = 0;
+    if (!allowed || a.st[g] != 1 || a.sh[g] != a.sw[g] || a.sh[g] > 2) continue;
+    const int len = data ? a.W : a.Wo[g];
+    int R = 0;
+    if (len % 8 == 0 && (a.sh[g] == 1 || data)) R = 8;
+    else if (len % 4 == 0) R = 4;
+    if (!R) continue;
+    a.run_R[x] = R;
+    n_runs[x] = static_cast<long>(a.B) * a.heads * (data ? static_cast<long>(a.T) * a.H : static_cast<long>(a.To[g]) * a.Ho[g]) * (len / R) +
+                static_cast<long>(a.B) * a.heads;
+    total += n_runs[x];
+  }
+  const long per = total / (RUNS * 2048L);
+  a.run_iters = per < 1 ? 1 : (per > 8 ? 8 : static_cast<int>(per));
+  unsigned grid = 0;
+  for (int x = 0; x < 3; ++x) {
+    a.run_blocks[x] = static_cast<int>((n_runs[x] + static_cast<long>(RUNS) * a.run_iters - 1) / (static_cast<long>(RUNS) * a.run_iters));
+    grid += static_cast<unsigned>(a.run_blocks[x]);
+  }
+  if (total_runs) *total_runs = total;
+  return grid;
+}
+
 extern "C" int diffsal_qkv_pool(const void* qkv, const float* const* w27, const float* const* gamma, const float* const* beta,
                                 const float* eps, float* const* out, int B, int heads, int D, int T, int H, int W,
                                 const int* stride_q, const int* stride_kv, int dtype, int w_channel_major,
@@ -593,12 +793,23 @@ extern "C" int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* co
   a.rows[0] = a.rows[1] = static_cast<int>(rows);
   a.iters = passes_for(3 * rows);
   a.blocks[0] = a.blocks[1] = (a.rows[0] + PROWS * a.iters - 1) / (PROWS * a.iters);
+  const unsigned run_grid = plan_runs(a, tune(TUNE_NO_POOL_RUNS) <= 0, true, nullptr);
+  if (run_grid) {
+    hipLaunchKernelGGL(qkv_pool_bwd_data_runs_kernel, dim3(run_grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    rc = check_launch("qkv_pool_bwd_data(runs)");
+    if (rc || (a.run_R[0] && a.run_R[1] && a.run_R[2])) return rc;
+  }
   hipLaunchKernelGGL(qkv_pool_bwd_data_kernel, dim3(static_cast<unsigned>(3 * a.blocks[0])), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("qkv_pool_bwd_data");
 }
 
-extern "C" int diffsal_qkv_pool_bwd_weight_chunks(void) { return QKV_WCHUNKS; }
+extern "C" int diffsal_qkv_pool_bwd_weight_chunks(int B, int heads, int T, int H, int W, const int* stride_q) {
+  if (!stride_q || stride_q[0] < 1 || stride_q[1] < 1 || stride_q[2] < 1) return 512;
+  const int Wo = (W - 1) / stride_q[2] + 1;
+  const int R = (stride_q[2] == 1 && Wo % 8 == 0) ? 8 : 4;
+  return qkv_wchunks(static_cast<long>(B) * heads * ((T - 1) / stride_q[0] + 1) * ((H - 1) / stride_q[1] + 1) * Wo / R);
+}
 
 extern "C" int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const* dy, double* part, int B, int heads, int D, int T,
                                            int H, int W, const int* stride_q, const int* stride_kv, int w_channel_major,
@@ -619,7 +830,9 @@ extern "C" int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const*
   DS_REQUIRE(static_cast<long>(B) * heads * a.To[0] * a.Ho[0] * a.Wo[0] < (1L << 23), DIFFSAL_E_SHAPE,
              "qkv_pool_bwd_weight: too many output tokens (the index arithmetic covers < 2^23)");
   DS_REQUIRE(static_cast<long>(1 + T * H * W) * 3 * heads * PD < (1L << 31), DIFFSAL_E_SHAPE, "qkv_pool_bwd_weight: clip too large");
-  hipLaunchKernelGGL(qkv_pool_bwd_weight_kernel, dim3(QKV_WCHUNKS, 3), dim3(256), 0, static_cast<hipStream_t>(stream), a, part);
+  plan_runs(a, tune(TUNE_NO_POOL_RUNS) <= 0, false, nullptr);
+  const int chunks = diffsal_qkv_pool_bwd_weight_chunks(B, heads, T, H, W, stride_q);
+  hipLaunchKernelGGL(qkv_pool_bwd_weight_kernel, dim3(chunks, 3), dim3(256), 0, static_cast<hipStream_t>(stream), a, part);
   return check_launch("qkv_pool_bwd_weight");
 }
 

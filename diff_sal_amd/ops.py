@@ -1727,9 +1727,9 @@ def qkv_pool_bwd_weight(qkv: Tensor, dys, size, stride_q, stride_kv, channel_maj
     B, N, _, heads, D = qkv.shape
     T, H, W = size
     dys = [_cont(d) for d in dys]
-    chunks = lib.diffsal_qkv_pool_bwd_weight_chunks()
-    part = torch.empty((3, chunks, 27 * D), device=qkv.device, dtype=torch.float64)
     sq, skv = (C.c_int * 3)(*stride_q), (C.c_int * 3)(*stride_kv)
+    chunks = lib.diffsal_qkv_pool_bwd_weight_chunks(B, heads, T, H, W, sq)
+    part = torch.empty((3, chunks, 27 * D), device=qkv.device, dtype=torch.float64)
     with _prof("pool-bwd", 54.0 * sum(d.numel() for d in dys), sum(d.numel() for d in dys) * 8):
         _lib.check(lib.diffsal_qkv_pool_bwd_weight(_p(qkv), _ptr3(dys), part.data_ptr(), B, heads, D, T, H, W, sq, skv,
                                                    int(channel_major), _stream()), "qkv_pool_bwd_weight")

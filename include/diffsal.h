@@ -656,8 +656,8 @@ int diffsal_qkv_pool_bwd_data(const float* const* dy, const float* const* w27, f
                               int H, int W, const int* stride_q, const int* stride_kv, int w_channel_major,
                               diffsal_stream_t stream);
 /* qkv_pool_bwd_weight: the three filter gradients in one launch: part[3][chunks][27*96] doubles (chunks =
- * diffsal_qkv_pool_bwd_weight_chunks()), finished by diffsal_reduce_partials(part, out, 3, chunks, 27*96, 0). */
-int diffsal_qkv_pool_bwd_weight_chunks(void);
+ * diffsal_qkv_pool_bwd_weight_chunks(B, heads, T, H, W, stride_q): 512, or 170 on small stages), finished by diffsal_reduce_partials(part, out, 3, chunks, 27*96, 0). */
+int diffsal_qkv_pool_bwd_weight_chunks(int B, int heads, int T, int H, int W, const int* stride_q);
 int diffsal_qkv_pool_bwd_weight(const float* qkv, const float* const* dy, double* part, int B, int heads, int D, int T, int H,
                                 int W, const int* stride_q, const int* stride_kv, int w_channel_major /* layout of each [27*96] row */,
                                 diffsal_stream_t stream);

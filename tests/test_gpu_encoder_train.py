@@ -82,6 +82,57 @@ def test_attention_backward_ds_form_is_bit_identical(shape):
             assert torch.equal(x, y), n
 
 
+RUN_CASES = [
+    # size (T, H, W), stride_q, stride_kv        row lengths a multiple of 4: the run forms of csrc/mvit_pool.hip take the tensors they can
+    ((3, 6, 8), (1, 1, 1), (1, 2, 2)),           # q: runs of 8, stride 1; k, v: stride 2 (forward / filter gradient runs of 4, data gradient runs of 8)
+    ((2, 4, 12), (1, 2, 2), (1, 4, 4)),          # q: stride 2, runs of 4 (6 outputs per row: not a multiple of 4 -> forward stays on the token form); k, v: token form
+    ((2, 8, 16), (1, 2, 2), (1, 1, 1)),          # q: stride 2 with 8 outputs per row; k, v: stride 1, runs of 8
+    ((3, 5, 12), (1, 1, 1), (1, 1, 1)),          # runs of 4 at stride 1, odd height
+]
+
+
+@pytest.mark.parametrize("case", RUN_CASES, ids=[f"{c[0][1]}x{c[0][2]}_q{c[1][1]}_kv{c[2][1]}" for c in RUN_CASES])
+def test_pool_run_forms(case, tuning):
+    """Run forms of the three pooling kernels (a thread owns a run of consecutive tokens of one row): against autograd of the same
+    depthwise convolutions, and against the token-per-lane-group forms -- forward and data gradient bit for bit (same taps, same fmaf
+    chains), the filter gradient to summation order."""
+    from diff_sal_amd import ops
+
+    size, sq, skv = case
+    B, heads, D = 2, 2, 96
+    N = 1 + size[0] * size[1] * size[2]
+    qkv = rnd("rq", B, N, 3, heads, D).requires_grad_(True)
+    ws = [rnd(f"rw{i}", D, 1, 3, 3, 3, scale=0.2).requires_grad_(True) for i in range(3)]
+    strides = (sq, skv, skv)
+    refs = []
+    for i in range(3):
+        x = qkv[:, :, i].permute(0, 2, 1, 3)
+        t = x[:, :, 1:].reshape(B * heads, *size, D).permute(0, 4, 1, 2, 3)
+        t = F.conv3d(t, ws[i], None, stride=strides[i], padding=1, groups=D)
+        refs.append(torch.cat([x[:, :, :1], t.reshape(B, heads, D, -1).transpose(2, 3)], 2))
+    Gs = [rnd(f"rg{i}", *r.shape) for i, r in enumerate(refs)]
+    sum((r * g).sum() for r, g in zip(refs, Gs)).backward()
+    qd = qkv.detach().to(DEV)
+    wd = [w.detach().reshape(D, 27).t().contiguous().to(DEV) for w in ws]
+    gd = [g.to(DEV) for g in Gs]
+    res = {}
+    for form in ("runs", "tokens"):
+        tuning.set("DIFFSAL_NO_POOL_RUNS", 1 if form == "tokens" else None)
+        outs = ops.qkv_pool(qd, wd, size, sq, skv)[:3]
+        dqkv = ops.qkv_pool_bwd_data(gd, wd, qd.shape, size, sq, skv)
+        dws = ops.qkv_pool_bwd_weight(qd, gd, size, sq, skv)
+        res[form] = (outs, dqkv, dws)
+    for o, r in zip(res["runs"][0], refs):
+        close(o, r, 2e-5, "pool fwd")
+    close(res["runs"][1], qkv.grad, 5e-5, "dqkv")
+    for i in range(3):
+        close(res["runs"][2][i], ws[i].grad.reshape(D, 27).t(), 5e-5, f"dw{i}")
+    for a, b in zip(res["runs"][0], res["tokens"][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res["runs"][1], res["tokens"][1])
+    close(res["runs"][2], res["tokens"][2], 2e-6, "dw runs vs tokens")
+
+
 def test_pool_maxpool_relpos_backward():
     from diff_sal_amd import encoder_autograd as eg
 
