@@ -477,15 +477,20 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments, bool one_tap
     if (only < 0 && ((c == 3 && Cout > 48) || (c == 2 && Cout > 64))) continue;
     const long tiles = ((Cout + cf.bco - 1) / cf.bco) * ((K / 32 + cf.sl - 1) / cf.sl) * segments;
     const double step_cycles = 16.0 * cf.mfma_per_kstep * 64.0;
-    for (int r = 1; r <= 8; ++r) {
-      long sp = r * 512L / tiles;
+    // the LDS-DMA form of the 128 x 192 tile (plain products) holds three 40 KB stages: ONE workgroup per CU, 256 at once -- planned
+    // in rounds of 256 (the rounds of 512 of the register-staged kernels gave it twice the splits it can run at once: two rounds of
+    // half the length and twice the slab traffic)
+    const bool dma = c == 0 && one_tap && tune(TUNE_WGRAD_DMA) != 0;
+    const long slots = dma ? 256 : 512;
+    for (int r = 1; r <= (dma ? 16 : 8); ++r) {
+      long sp = r * slots / tiles;
       sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
       sp = sp > 512 ? 512 : sp;
       const long wgs = tiles * sp;
-      const long rounds = (wgs + 511) / 512;
+      const long rounds = (wgs + slots - 1) / slots;
       const long rps = ((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM;
       const double steps = static_cast<double>(rps) / 32.0 + 4.0;   // in 32-row steps
-      const double occ = wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0);
+      const double occ = dma ? 1.0 : (wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0));
       double t = rounds * occ * steps * step_cycles;
       if (sp > 1) t += 2.0 * sp * segments * Cout * static_cast<double>(K) * 4.0 / 1250.0;
       if (one_tap) {
