@@ -34,7 +34,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 
 SIGNATURES = {
@@ -109,7 +109,7 @@ SIGNATURES = {
     "diffsal_head_sigmoid": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "diffsal_cast": (c_i, [c_f, c_i, c_f, c_i, C.c_long, c_f]),
     "diffsal_axpbypcz": (c_i, [c_f, c_f, c_f, c_fl, c_fl, c_fl, c_f, c_sz, c_f]),
-    "diffsal_attention_general": (c_i, [c_f] * 8 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f, c_sz, c_f]),
+    "diffsal_attention_general": (c_i, [c_f] * 4 + [c_f] + [c_f] * 4 + [c_i] * 7 + [C.POINTER(C.c_long)] * 4 + [c_fl, c_i, c_f, c_sz, c_f]),
     "diffsal_attention_general_tail_floats": (c_sz, [c_i] * 5),
     "diffsal_attention_general_bwd_splits": (c_i, [c_i] * 4),
     "diffsal_attention_general_bwd_qtail_floats": (c_sz, [c_i] * 6),

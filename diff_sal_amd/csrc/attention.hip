@@ -38,6 +38,13 @@ struct AttnArgs {
   const float* q_extra;  // [B,H,Lq,E] contiguous, or null when E == 0
   const float* k;
   const float* k_extra;  // [Lk,E] contiguous (shared), or null
+  // slot form of a ONE-HOT k_extra (MViT's decomposed relative-position bias: a key has one column per axis): k_slots[key][0..2] =
+  // the columns that are 1 (E = none: the class token), [3] unused.  The bias  q_extra . k_extra[key]  is then the sum of (at most)
+  // three gathered q_extra values, added to S on the vector unit from LDS, and the E / D extra MFMAs of the contraction form (a fifth
+  // of the forward's at E = 48) are not issued: forward 565 -> 515 us on MViT's first stage.  Forward only: in the dk / dv kernel
+  // (one wavefront per SIMD) the gathers cost what the 24 MFMAs saved, and a dq kernel that sums dS per column by LDS adds ran 4x slower
+  // (ds_add_f32 retires lane by lane) -- both measured and removed (profiles/NOTES.md).
+  const int* k_slots;
   const float* v;
   const float* residual; // same indexing as q, or null
   float* out;            // [B, Lq, H*DV]
@@ -57,16 +64,19 @@ struct AttnArgs {
   float* l_slabs;        // [qb_split][B*H][Lq]
 };
 
-template <int D, int E, int DV>
+template <int D, int E, int DV, bool SL = false>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
-  constexpr int DQ = D + E;             // contraction length of QK^T
-  static_assert(DQ % 8 == 0 && DV % 32 == 0 && D % 4 == 0 && E % 4 == 0, "shape");
+  constexpr int DQ = SL ? D : D + E;    // contraction length of QK^T (slot form: the bias is gathered, not contracted)
+  static_assert(DQ % 8 == 0 && DV % 32 == 0 && D % 4 == 0 && E % 8 == 0 && (!SL || E > 0), "shape");
   constexpr int HQ = DQ / 2;            // per lane half
   constexpr int KP = DQ + 4;            // LDS pitches (floats)
   constexpr int VP = DV + 4;
   constexpr int NT = DV / 32;
   __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
   __shared__ __attribute__((aligned(16))) float Vs[32 * VP];
+  // slot form: this wavefront's q_extra transposed [column][query] (+ an all-zero column E) and the key tile's slots
+  __shared__ float QeT[SL ? 4 : 1][SL ? (E + 1) * 32 : 1];
+  __shared__ int4 Ss[SL ? 32 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int blk = blockIdx.x, piece = -1;
@@ -92,8 +102,20 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
     for (int j4 = 0; j4 < HQ / 4; ++j4) {
       const int e0 = hf * HQ + j4 * 4;   // D, HQ multiples of 4: a float4 piece never straddles q / q_extra
       const float* src = qr + (e0 < D ? e0 : 0);
-      if constexpr (E > 0) src = e0 < D ? src : qe + (e0 - D);
+      if constexpr (E > 0 && !SL) src = e0 < D ? src : qe + (e0 - D);
       raw[j4] = ld4(src);
+    }
+    if constexpr (SL) {                  // this lane's half of its query's q_extra row -> QeT[column][query]
+      float4 re[E / 8];
+#pragma unroll
+      for (int j4 = 0; j4 < E / 8; ++j4) re[j4] = ld4(qe + hf * (E / 2) + j4 * 4);
+      float* qt = &QeT[wave][0];
+#pragma unroll
+      for (int j4 = 0; j4 < E / 8; ++j4) {
+        const int c = hf * (E / 2) + j4 * 4;
+        qt[(c + 0) * 32 + ql] = re[j4].x; qt[(c + 1) * 32 + ql] = re[j4].y; qt[(c + 2) * 32 + ql] = re[j4].z; qt[(c + 3) * 32 + ql] = re[j4].w;
+      }
+      if (hf == 0) qt[E * 32 + ql] = 0.f;
     }
 #pragma unroll
     for (int j4 = 0; j4 < HQ / 4; ++j4) {
@@ -118,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
   constexpr int KF4 = 32 * DQ / 4, VF4 = 32 * DV / 4;          // float4 pieces per tile
   constexpr int KPT = (KF4 + 255) / 256, VPT = (VF4 + 255) / 256;
   float4 kreg[KPT], vreg[VPT];
+  int4 sreg = make_int4(E, E, E, E);
   auto fetch = [&](int tile) {
     const int key0 = tile * 32;
 #pragma unroll
@@ -127,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
       const int key = key0 + (row < 32 ? row : 31);              // pieces past the tile read a valid row (never parked)
       const long kc = key < p.Lk ? key : p.Lk - 1;
       const float* src = kb + kc * p.k_sl + (c4 < D ? c4 : 0);
-      if constexpr (E > 0) src = c4 < D ? src : p.k_extra + kc * E + (c4 - D);
+      if constexpr (E > 0 && !SL) src = c4 < D ? src : p.k_extra + kc * E + (c4 - D);
       kreg[i] = ld4(src);
     }
 #pragma unroll
@@ -137,6 +160,12 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
       const int key = key0 + (row < 32 ? row : 31);
       const long kc = key < p.Lk ? key : p.Lk - 1;
       vreg[i] = ld4(vb + kc * p.v_sl + c4);
+    }
+    if constexpr (SL) {
+      if (tid < 32) {
+        const int key = key0 + tid;
+        sreg = *reinterpret_cast<const int4*>(p.k_slots + 4L * (key < p.Lk ? key : p.Lk - 1));
+      }
     }
   };
   auto park = [&](int tile) {
@@ -153,6 +182,9 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
       const int row = idx / (DV / 4), c4 = (idx - row * (DV / 4)) * 4;
       if (idx < VF4) st4(&Vs[row * VP + c4], keep_or_zero(vreg[i], key0 + row < p.Lk));
     }
+    if constexpr (SL) {
+      if (tid < 32) Ss[tid] = key0 + tid < p.Lk ? sreg : make_int4(E, E, E, E);
+    }
   };
 
   fetch(t_begin);
@@ -167,6 +199,14 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs p) {
     const float* krow = &Ks[ql * KP + hf * HQ];
     mfma_groups_f32<HQ / 4>([&](int j4) { return krow + j4 * 4; },
                             [&](int j4, float4 a) { DS_MFMA4(s, a, qf[j4 * 4 + 0], qf[j4 * 4 + 1], qf[j4 * 4 + 2], qf[j4 * 4 + 3]); });
+    if constexpr (SL) {              // + q_extra[query][the key's columns]
+      const float* qt = &QeT[wave][ql];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int4 sl = Ss[hf * 4 + (r & 3) + 8 * (r >> 2)];
+        s[r] += (qt[sl.x * 32] + qt[sl.y * 32]) + qt[sl.z * 32];
+      }
+    }
     // ---- online softmax for this lane's query over its 16 keys (+ the partner half's 16)
     const int key_base = tile * 32 + hf * 4;
     float mx = -3.0e38f;
@@ -944,7 +984,7 @@ extern "C" size_t diffsal_attention_general_tail_floats(int B, int H, int Lq, in
   return sp > 1 ? static_cast<size_t>(sp) * B * H * Lq * (DV + 1) : 0;
 }
 
-extern "C" int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra,
+extern "C" int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra, const int* k_slots,
                                          const float* v, const float* residual, float* out, float* lse, int B, int H, int Lq, int Lk,
                                          int D, int E, int DV, const long* q_strides, const long* k_strides,
                                          const long* v_strides, const long* r_strides, float scale, int skip_first,
@@ -963,6 +1003,7 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
                DIFFSAL_E_ALIGN, "attention_general: strides must be multiples of 4 elements");
   AttnArgs a;
   a.q = q; a.q_extra = q_extra; a.k = k; a.k_extra = k_extra; a.v = v; a.residual = residual; a.out = out; a.lse = lse;
+  a.k_slots = (k_slots && E > 0 && aligned16(k_slots) && tune(TUNE_NO_ATTN_SLOTS) <= 0) ? k_slots : nullptr;
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
@@ -981,7 +1022,9 @@ extern "C" int diffsal_attention_general(const float* q, const float* q_extra, c
   const int total = a.qb_x * a.qb_bh, n_tail = total - a.qb_full;
   const dim3 grid(static_cast<unsigned>(a.qb_full + n_tail * a.qb_split));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (D == 96 && E == 48 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 48, 96>), grid, dim3(256), 0, s, a);
+  if (D == 96 && E == 48 && DV == 96 && a.k_slots) hipLaunchKernelGGL((attention_fwd_kernel<96, 48, 96, true>), grid, dim3(256), 0, s, a);
+  else if (D == 96 && E == 32 && DV == 96 && a.k_slots) hipLaunchKernelGGL((attention_fwd_kernel<96, 32, 96, true>), grid, dim3(256), 0, s, a);
+  else if (D == 96 && E == 48 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 48, 96>), grid, dim3(256), 0, s, a);
   else if (D == 96 && E == 32 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 32, 96>), grid, dim3(256), 0, s, a);
   else if (D == 96 && E == 0 && DV == 96) hipLaunchKernelGGL((attention_fwd_kernel<96, 0, 96>), grid, dim3(256), 0, s, a);
   else if (D == 64 && E == 0 && DV == 64) hipLaunchKernelGGL((attention_fwd_kernel<64, 0, 64>), grid, dim3(256), 0, s, a);

@@ -1577,9 +1577,18 @@ def _bhl_strides(t: Tensor):
     return (C.c_long * 3)(t.stride(0), t.stride(1), t.stride(2))
 
 
+def _k_slots(k_extra, k_slots):
+    """The slot form of a one-hot k_extra (include/diffsal.h): given explicitly, or carried by the table (``relpos_onehot``)."""
+    if k_slots is None and k_extra is not None:
+        k_slots = getattr(k_extra, "slots", None)
+    if k_slots is not None and (k_slots.dtype != torch.int32 or k_slots.shape != (k_extra.shape[0], 4) or not k_slots.is_contiguous()):
+        raise ValueError("k_slots must be a contiguous int32 [Lk, 4] tensor")
+    return k_slots
+
+
 def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra: Optional[Tensor] = None,
                       k_extra: Optional[Tensor] = None, residual: Optional[Tensor] = None, skip_first: bool = False,
-                      want_lse: bool = False):
+                      want_lse: bool = False, k_slots: Optional[Tensor] = None):
     """softmax(scale q k^T + q_extra k_extra^T) v (+ residual) for [B,H,L,D] views -> [B, Lq, H*DV] (include/diffsal.h);
     with want_lse also the row log-sum-exp [B,H,Lq] the backward needs."""
     lib = _lib.load()
@@ -1591,9 +1600,10 @@ def attention_general(q: Tensor, k: Tensor, v: Tensor, *, scale: float, q_extra:
     nt = lib.diffsal_attention_general_tail_floats(B, H, Lq, Lk, DV)      # pieces of the last, partly filled round of workgroups
     tail = torch.empty((nt,), device=q.device, dtype=torch.float32) if nt else None
     flops = 2.0 * B * H * Lq * Lk * (D + E + DV)
+    k_slots = _k_slots(k_extra, k_slots)
     with _prof("attn", flops, _nb(q, k, v, out)):
         _lib.check(lib.diffsal_attention_general(
-            q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), v.data_ptr(), None if residual is None else residual.data_ptr(),
+            q.data_ptr(), _p(q_extra), k.data_ptr(), _p(k_extra), (None if k_slots is None else k_slots.data_ptr()), v.data_ptr(), None if residual is None else residual.data_ptr(),
             _p(out), _p(lse), B, H, Lq, Lk, D, E, DV, _bhl_strides(q), _bhl_strides(k), _bhl_strides(v),
             None if residual is None else _bhl_strides(residual), float(scale), int(skip_first), _p(tail), nt, _stream()),
             "attention_general")
@@ -1796,6 +1806,12 @@ def relpos_onehot(k_size, E: int, device) -> Tensor:
     oh[1 + l, l // (kh * kw)] = 1.0
     oh[1 + l, 8 + (l // kw) % kh] = 1.0
     oh[1 + l, w0 + l % kw] = 1.0
+    # the same table in slot form (include/diffsal.h, k_slots): the three columns of a key, E = none (the class token)
+    slots = torch.full((1 + kt * kh * kw, 4), E, device=device, dtype=torch.int32)
+    slots[1:, 0] = (l // (kh * kw)).int()
+    slots[1:, 1] = (8 + (l // kw) % kh).int()
+    slots[1:, 2] = (w0 + l % kw).int()
+    oh.slots = slots
     return oh
 
 

@@ -568,11 +568,15 @@ int diffsal_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long 
  * q / k / v / residual are addressed through (batch, head, row) element strides, so slices of a fused qkv GEMM output
  * are read in place; q_extra [B,H,Lq,E] and k_extra [Lk,E] are contiguous and carry an additive attention bias as E
  * extra contraction columns (MViT: E = 48 or 32, see diffsal_relpos_project; otherwise E = 0 and both are NULL).
+ * k_slots (optional, E > 0): the slot form of a ONE-HOT k_extra -- k_slots[t][0..2] = the columns of row t that are 1 (E = none, e.g. the
+ * class token; [3] unused), 16-byte aligned.  With it the bias is three gathered q_extra values per (query, key) added on the vector unit
+ * and the E extra contraction columns are not multiplied (a fifth fewer matrix instructions at E = 48); k_extra must still describe the
+ * same matrix (the backward contracts with it).  The result differs from the contraction form by summation order only.
  * Built (D, E, DV): (96,48,96), (96,32,96), (96,0,96), (64,0,64), (32,0,32).  Replaces
  *   R/models/mvit.py:587-605 (MultiScaleAttention: attn = (q*scale) k^T, add_decomposed_rel_pos, softmax, attn v, + q),
  *   R/models/audio_attention.py:50-58 (dots, softmax, out). */
-int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra, const float* v,
-                              const float* residual, float* out, float* lse /*[B,H,Lq] row log-sum-exp, or NULL*/, int B,
+int diffsal_attention_general(const float* q, const float* q_extra, const float* k, const float* k_extra,
+                              const int* k_slots /*[Lk][4] or NULL*/, const float* v, const float* residual, float* out, float* lse /*[B,H,Lq] row log-sum-exp, or NULL*/, int B,
                               int H, int Lq, int Lk, int D, int E, int DV, const long* q_strides /*host [3]*/,
                               const long* k_strides, const long* v_strides, const long* r_strides, float scale,
                               int skip_first, float* tail_ws, size_t tail_ws_floats, diffsal_stream_t stream);

@@ -133,6 +133,40 @@ def test_pool_run_forms(case, tuning):
     close(res["runs"][2], res["tokens"][2], 2e-6, "dw runs vs tokens")
 
 
+@pytest.mark.parametrize("case", [(2, 2, (2, 6, 10), (2, 3, 5)), (1, 4, (8, 14, 24), (8, 7, 12)), (1, 1, (4, 28, 48), (4, 7, 12)), (2, 3, (2, 5, 7), (2, 5, 20))])
+def test_attention_slot_form(case, tuning):
+    """MViT's relative-position bias in slot form (k_slots: the three one-hot columns of a key; the forward adds three gathered q_extra
+    values per (query, key) on the vector unit) against the contraction form (E extra columns of QK^T on the matrix pipe): output and
+    log-sum-exp to summation order, and the gradients computed from either forward's log-sum-exp."""
+    from diff_sal_amd import ops
+
+    B, H, q_size, k_size = case
+    D = 96
+    E = ops.relpos_columns(k_size)
+    Lq, Lk = 1 + q_size[0] * q_size[1] * q_size[2], 1 + k_size[0] * k_size[1] * k_size[2]
+    q, k, v = (rnd(n, B, H, L, D).to(DEV) for n, L in (("sq", Lq), ("sk", Lk), ("sv", Lk)))
+    qe = rnd("sqe", B, H, Lq, E, scale=0.3).to(DEV)
+    oh = ops.relpos_onehot(k_size, E, DEV)
+    assert oh.slots.shape == (Lk, 4) and int(oh.slots[0, 0]) == E
+    # the slot table describes the one-hot table
+    dense = torch.zeros(Lk, E + 1, device=DEV)
+    dense.scatter_(1, oh.slots[:, :3].long(), 1.0)
+    assert torch.equal(dense[:, :E], oh)
+    G = rnd("sg", B, Lq, H * D).to(DEV)
+    kw = dict(scale=D ** -0.5, q_extra=qe, k_extra=oh, residual=q, skip_first=True)
+    res = {}
+    for form in ("slots", "contraction"):
+        tuning.set("DIFFSAL_NO_ATTN_SLOTS", 1 if form == "contraction" else None)
+        out, lse = ops.attention_general(q, k, v, want_lse=True, **kw)
+        grads = [ops.attention_general_bwd(q, k, v, out, lse, G, ds_form=f, **kw) for f in (True, False)]
+        res[form] = (out, lse, grads)
+    close(res["slots"][0], res["contraction"][0], 2e-6, "out")
+    close(res["slots"][1], res["contraction"][1], 2e-6, "lse")
+    for f in (0, 1):
+        for a, b, n in zip(res["slots"][2][f], res["contraction"][2][f], ("dq", "dq_extra", "dk", "dv")):
+            close(a, b, 5e-6, f"{n} (ds_form={not f})")
+
+
 def test_pool_maxpool_relpos_backward():
     from diff_sal_amd import encoder_autograd as eg
 

@@ -436,6 +436,7 @@ def test_wgrad_dma_kernel_equals_the_register_staged_kernel(M, K, N, tuning):
     from diff_sal_amd import ops
 
     tuning.set("DIFFSAL_WGRAD_CFG", 0)           # the tile shape that has the DMA variant
+    tuning.set("DIFFSAL_WGRAD_SPLITS", 5)        # one split of M for both (the two kernels are planned in rounds of 256 / 512 workgroups)
     x = orc.synth_tensor("wdx%d" % M, (1, 1, M, K)).to(DEV)
     dy = orc.synth_tensor("wdy%d" % M, (1, 1, M, N)).to(DEV)
     tuning.set("DIFFSAL_WGRAD_DMA", 0)

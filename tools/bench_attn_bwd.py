@@ -30,8 +30,7 @@ for H, Lq, Lk, E in SHAPES:
     D = 96
     q, k, v = (torch.randn(B, H, L, D, device="cuda") for L in (Lq, Lk, Lk))
     qe = torch.randn(B, H, Lq, E, device="cuda") * 0.3
-    ke = torch.zeros(Lk, E, device="cuda")
-    ke[torch.arange(1, Lk), torch.randint(0, E, (Lk - 1,))] = 1.0
+    ke = ops.relpos_onehot((8, 7, 12), E, "cuda")          # carries its slot form (DIFFSAL_NO_ATTN_SLOTS=1: contraction form)
     G = torch.randn(B, Lq, H * D, device="cuda")
     kw = dict(scale=D ** -0.5, q_extra=qe, k_extra=ke, residual=q, skip_first=True)
     out, lse = ops.attention_general(q, k, v, want_lse=True, **kw)
