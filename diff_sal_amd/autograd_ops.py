@@ -152,6 +152,32 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class LayerNorm3Fn(torch.autograd.Function):
+    """Three LayerNorms of one width as one node: one forward launch, one backward launch + one reduction (MViT's norm_q / norm_k /
+    norm_v on the pooled tensors: the key / value tensors are a few hundred tokens per head)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, x2, g0, b0, g1, b1, g2, b2, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(x0, x1, x2, g0, g1, g2)
+        return tuple(ops.layernorm_multi((x0, x1, x2), (g0, g1, g2), (b0, b1, b2), eps))
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        x0, x1, x2, g0, g1, g2 = ctx.saved_tensors
+        xs, ds = (x0, x1, x2), [d0, d1, d2]
+        ds = [torch.zeros_like(x) if d is None else d for x, d in zip(xs, ds)]
+        dxs, dgs, dbs = ops.layernorm_bwd_multi(xs, ds, (g0, g1, g2), ctx.eps)
+        return dxs[0], dxs[1], dxs[2], dgs[0], dbs[0], dgs[1], dbs[1], dgs[2], dbs[2], None
+
+
+def layernorm3(xs, norms):
+    """LayerNorm of three tensors by three nn.LayerNorm modules of one width -> three outputs."""
+    (n0, n1, n2) = norms
+    return LayerNorm3Fn.apply(xs[0], xs[1], xs[2], n0.weight, n0.bias, n1.weight, n1.bias, n2.weight, n2.bias,
+                              (float(n0.eps), float(n1.eps), float(n2.eps)))
+
+
 class LayerNormForkFn(torch.autograd.Function):
     """(x, LayerNorm(x)) for a pre-norm residual block: x goes on over the residual connection, the normalised copy into the
     branch.  One node for both uses of x, so its backward is ONE kernel, dx = LN'(d_branch) + d_residual, where the tape

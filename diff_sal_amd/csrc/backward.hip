@@ -274,12 +274,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
 
 // LayerNorm backward over C (rows in registers, statistics recomputed): dx, and per-block partial dgamma / dbeta.
 template <int G, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            const float* __restrict__ gamma, const float* __restrict__ add,
-                                                            float* __restrict__ dx, double* __restrict__ part, int M, int C,
-                                                            float eps) {
+__device__ __forceinline__ void layernorm_bwd_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ gamma, const float* __restrict__ add,
+                                                   float* __restrict__ dx, double* __restrict__ part, int M, int C, float eps,
+                                                   double* shd) {
   constexpr int ROWS = 256 / G;
-  extern __shared__ double shd[];  // [2][C]
   const int gl = threadIdx.x % G, gr = threadIdx.x / G;
   float4 dg[NV], db[NV];
 #pragma unroll
@@ -358,6 +357,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) part[static_cast<long>(blockIdx.x) * 2 * C + i] = shd[i];
+}
+
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ add,
+                                                            float* __restrict__ dx, double* __restrict__ part, int M, int C,
+                                                            float eps) {
+  extern __shared__ double shd[];  // [2][C]
+  layernorm_bwd_body<G, NV>(x, dy, gamma, add, dx, part, M, C, eps, shd);
+}
+
+// up to three tensors of one width (blockIdx.y; see LnMulti in norm.hip): part[t][gridDim.x][2][C]; a workgroup without rows
+// leaves zeros
+struct LnBwdMulti {
+  const float* x[3]; const float* dy[3]; const float* gamma[3]; float* dx[3];
+  double* part;
+  int M[3];
+  float eps[3];
+};
+
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_multi_kernel(LnBwdMulti p, int C) {
+  extern __shared__ double shd[];  // [2][C]
+  const int t = blockIdx.y;
+  layernorm_bwd_body<G, NV>(p.x[t], p.dy[t], p.gamma[t], nullptr, p.dx[t], p.part + static_cast<long>(t) * gridDim.x * 2 * C, p.M[t], C,
+                            p.eps[t], shd);
 }
 
 // y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter-based hash of (seed, element index): the same call
@@ -1038,6 +1063,28 @@ extern "C" int diffsal_layernorm_bwd(const float* x, const float* dy, const floa
   DS_ROW_DISPATCH_B(C, CALL);
 #undef CALL
   return check_launch("layernorm_bwd");
+}
+
+extern "C" int diffsal_layernorm_bwd_multi(const float* const* x, const float* const* dy, const float* const* gamma, float* const* dx,
+                                           double* part, const int* M, int n, int C, const float* eps, diffsal_stream_t stream) {
+  DS_REQUIRE(x && dy && gamma && dx && part && M && eps && n >= 1 && n <= 3, DIFFSAL_E_ARG,
+             "layernorm_bwd_multi: null argument or n=%d not in 1..3", n);
+  DS_REQUIRE(C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm_bwd_multi: bad width C=%d", C);
+  LnBwdMulti a{};
+  int most = 0;
+  for (int t = 0; t < n; ++t) {
+    DS_REQUIRE(x[t] && dy[t] && gamma[t] && dx[t] && M[t] > 0, DIFFSAL_E_ARG, "layernorm_bwd_multi: null tensor %d", t);
+    a.x[t] = x[t]; a.dy[t] = dy[t]; a.gamma[t] = gamma[t]; a.dx[t] = dx[t]; a.M[t] = M[t]; a.eps[t] = eps[t];
+    most = M[t] > most ? M[t] : most;
+  }
+  a.part = part;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int blocks = diffsal_layernorm_bwd_blocks(most, C);      // part [n][blocks][2][C]
+#define CALL(G, NV) \
+  hipLaunchKernelGGL((layernorm_bwd_multi_kernel<G, NV>), dim3(blocks, n), dim3(256), 2 * C * sizeof(double), s, a, C)
+  DS_ROW_DISPATCH_B(C, CALL);
+#undef CALL
+  return check_launch("layernorm_bwd_multi");
 }
 
 extern "C" int diffsal_dropout(const float* x, float* out, size_t n, float p, uint64_t seed, diffsal_stream_t stream) {

@@ -232,6 +232,35 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// Up to three LayerNorms of one width in one launch (blockIdx.y = tensor): MViT's norm_q / norm_k / norm_v on the pooled tensors
+// (R/models/mvit.py:562-570) -- the key / value tensors are 673 tokens per head, launches of their own cost more than their work.
+struct LnMulti {
+  const float* x[3]; const float* gamma[3]; const float* beta[3]; float* out[3];
+  const float* dy[3]; double* part;      // backward
+  int M[3];
+  float eps[3];
+};
+
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_multi_kernel(LnMulti p, int C) {
+  constexpr int ROWS = 256 / G;
+  const int t = blockIdx.y;
+  const int gl = threadIdx.x % G;
+  const int gr = threadIdx.x / G;
+  const float* __restrict__ x = p.x[t];
+  float* __restrict__ out = p.out[t];
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < p.M[t]; row += static_cast<long>(gridDim.x) * ROWS) {
+    const float* xr = x + row * C;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (gl + i * G) * 4;
+      v[i] = c < C ? ld4(xr + c) : make_float4(0, 0, 0, 0);
+    }
+    ln_rows_finish<G, NV, float>(v, gl, C, p.gamma[t], p.beta[t], p.eps[t], out + row * C);
+  }
+}
+
 // depthwise 3x3 (pad 1, stride 1) + LayerNorm.  R/.../attention.py:36-47,94 (quirk Q8: centre slice)
 // PRELN: the input is the block's un-normalised frames and every loaded token goes through the block's LayerNorm (pg, pb,
 // peps) first -- see ln_rows_inplace.  Validity and trip counts are uniform within a lane group, so the group reductions
@@ -817,6 +846,26 @@ static int layernorm_t(const T* x, const float* gamma, const float* beta, T* out
   DS_ROW_DISPATCH(C, CALL);
 #undef CALL
   return check_launch("layernorm");
+}
+
+extern "C" int diffsal_layernorm_multi(const float* const* x, const float* const* gamma, const float* const* beta, float* const* out,
+                                       const int* M, int n, int C, const float* eps, diffsal_stream_t stream) {
+  DS_REQUIRE(x && gamma && beta && out && M && eps && n >= 1 && n <= 3, DIFFSAL_E_ARG, "layernorm_multi: null argument or n=%d not in 1..3", n);
+  DS_REQUIRE(C > 0 && C % 4 == 0, DIFFSAL_E_SHAPE, "layernorm_multi: bad width C=%d", C);
+  LnMulti a{};
+  int most = 0;
+  for (int t = 0; t < n; ++t) {
+    DS_REQUIRE(x[t] && gamma[t] && beta[t] && out[t] && M[t] > 0, DIFFSAL_E_ARG, "layernorm_multi: null tensor %d", t);
+    DS_REQUIRE(aligned16(x[t]) && aligned16(out[t]) && aligned16(gamma[t]) && aligned16(beta[t]), DIFFSAL_E_ALIGN,
+               "layernorm_multi: misaligned pointer");
+    a.x[t] = x[t]; a.gamma[t] = gamma[t]; a.beta[t] = beta[t]; a.out[t] = out[t]; a.M[t] = M[t]; a.eps[t] = eps[t];
+    most = M[t] > most ? M[t] : most;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(G, NV) hipLaunchKernelGGL((layernorm_multi_kernel<G, NV>), dim3(row_grid(most, 256 / G), n), dim3(256), 0, s, a, C)
+  DS_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return check_launch("layernorm_multi");
 }
 
 extern "C" int diffsal_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,

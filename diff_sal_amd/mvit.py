@@ -274,9 +274,7 @@ class MViT(nn.Module):
         pq, pk_, pv = eg.qkv_pool(qkv, w27[0], w27[1], w27[2], size, blk.stride_q, blk.stride_kv)
         q_size = tuple((s - 1) // st + 1 for s, st in zip(size, blk.stride_q))
         k_size = tuple((s - 1) // st + 1 for s, st in zip(size, blk.stride_kv))
-        q = ag.layernorm(pq, a.norm_q.weight, a.norm_q.bias, a.norm_q.eps)
-        k = ag.layernorm(pk_, a.norm_k.weight, a.norm_k.bias, a.norm_k.eps)
-        v = ag.layernorm(pv, a.norm_v.weight, a.norm_v.bias, a.norm_v.eps)
+        q, k, v = ag.layernorm3((pq, pk_, pv), (a.norm_q, a.norm_k, a.norm_v))
         # relative-position tables: parameter preprocessing (linear resample + gather) stays on the tape so that the
         # table gradients of relpos_project flow back to rel_pos_t / rel_pos_h / rel_pos_w
         plans = tuple(self._rel_plan(r.shape[0], qs, ks, x.device)

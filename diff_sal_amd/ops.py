@@ -1319,6 +1319,40 @@ def norm_bwd_apply(x, dy, y, mu, rs, gamma, beta, k1, k2, k3, seg_rows: int, mod
 
 
 @_classed("K8-bwd")
+@_classed("K8")
+def layernorm_multi(xs, gammas, betas, epss):
+    """LayerNorm of up to three fp32 tensors of one width in one launch (include/diffsal.h) -> list of outputs."""
+    lib = _lib.load()
+    n, Cc = len(xs), xs[0].shape[-1]
+    xs = [_cont(x) for x in xs]
+    outs = [torch.empty_like(x) for x in xs]
+    M = (C.c_int * n)(*[x.numel() // Cc for x in xs])
+    eps = (C.c_float * n)(*[float(e) for e in epss])
+    ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.diffsal_layernorm_multi(ptrs(xs), ptrs([_cont(g) for g in gammas]), ptrs([_cont(b) for b in betas]), ptrs(outs), M, n, Cc,
+                                           eps, _stream()), "layernorm_multi")
+    return outs
+
+
+@_classed("K8-bwd")
+def layernorm_bwd_multi(xs, dys, gammas, epss):
+    """-> (dxs, dgammas, dbetas) of ``layernorm_multi``: one launch + one reduction."""
+    lib = _lib.load()
+    n, Cc = len(xs), xs[0].shape[-1]
+    xs, dys = [_cont(x) for x in xs], [_cont(d) for d in dys]
+    rows = [x.numel() // Cc for x in xs]
+    blocks = lib.diffsal_layernorm_bwd_blocks(max(rows), Cc)
+    part = torch.empty((n, blocks, 2, Cc), device=xs[0].device, dtype=torch.float64)
+    dxs = [torch.empty_like(x) for x in xs]
+    M = (C.c_int * n)(*rows)
+    eps = (C.c_float * n)(*[float(e) for e in epss])
+    ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.diffsal_layernorm_bwd_multi(ptrs(xs), ptrs(dys), ptrs([_cont(g) for g in gammas]), ptrs(dxs), part.data_ptr(), M, n, Cc,
+                                               eps, _stream()), "layernorm_bwd_multi")
+    s_ = reduce_partials(part, n, blocks, 2 * Cc).view(n, 2, Cc)
+    return dxs, [s_[t, 0] for t in range(n)], [s_[t, 1] for t in range(n)]
+
+
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5, add: Optional[Tensor] = None):
     """-> (dx (+ add), dgamma, dbeta)."""
     lib = _lib.load()

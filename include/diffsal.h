@@ -395,6 +395,13 @@ int diffsal_norm_bwd_apply(const float* x, const float* dy, const float* y, cons
  * branch, so the tape needs no separate accumulation pass) and per-block partial (dgamma, dbeta) -> part[blocks][2][C],
  * blocks = diffsal_layernorm_bwd_blocks() */
 int diffsal_layernorm_bwd_blocks(int M, int C);
+/* n <= 3 tensors of one width in ONE launch (MViT's norm_q / norm_k / norm_v on the pooled tensors, R/models/mvit.py:562-570): host arrays of
+ * n device pointers / row counts / eps; backward: part [n][blocks][2][C] with blocks = diffsal_layernorm_bwd_blocks(max M, C), finished by
+ * diffsal_reduce_partials(part, out, n, blocks, 2*C, 0) -> [n][dgamma | dbeta]. */
+int diffsal_layernorm_multi(const float* const* x, const float* const* gamma, const float* const* beta, float* const* out, const int* M,
+                            int n, int C, const float* eps, diffsal_stream_t stream);
+int diffsal_layernorm_bwd_multi(const float* const* x, const float* const* dy, const float* const* gamma, float* const* dx, double* part,
+                                const int* M, int n, int C, const float* eps, diffsal_stream_t stream);
 int diffsal_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* add, float* dx, double* part, int M, int C,
                           float eps, diffsal_stream_t stream);
 /* out = x * keep / (1-p), keep from a counter-based hash of (seed, index); same call = its own backward.

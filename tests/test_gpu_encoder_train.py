@@ -167,6 +167,45 @@ def test_attention_slot_form(case, tuning):
             close(a, b, 5e-6, f"{n} (ds_form={not f})")
 
 
+def test_layernorm_of_three_tensors_is_the_three_layernorms():
+    """ops.layernorm_multi / layernorm_bwd_multi (one launch for norm_q / norm_k / norm_v of an MViT block) against the single-tensor
+    kernels: outputs and dx bit for bit (same rows through the same code), dgamma / dbeta to the partial-sum partition."""
+    from diff_sal_amd import autograd_ops as ag
+    from diff_sal_amd import ops
+
+    C = 96
+    xs = [rnd(f"lx{i}", 2, 2, L, C).to(DEV) for i, L in enumerate((1 + 2 * 9 * 11, 34, 34))]
+    gs = [(rnd(f"lg{i}", C, scale=0.2) + 1.0).to(DEV) for i in range(3)]
+    bs = [rnd(f"lb{i}", C, scale=0.2).to(DEV) for i in range(3)]
+    dys = [rnd(f"ld{i}", *x.shape).to(DEV) for i, x in enumerate(xs)]
+    eps = (1e-6, 1e-6, 1e-5)
+    outs = ops.layernorm_multi(xs, gs, bs, eps)
+    dxs, dgs, dbs = ops.layernorm_bwd_multi(xs, dys, gs, eps)
+    for i in range(3):
+        assert torch.equal(outs[i], ops.layernorm(xs[i], gs[i], bs[i], eps[i]))
+        dx, dg, db = ops.layernorm_bwd(xs[i], dys[i], gs[i], eps[i])
+        assert torch.equal(dxs[i], dx)
+        close(dgs[i], dg, 2e-6, "dgamma")
+        close(dbs[i], db, 2e-6, "dbeta")
+    # the autograd node against torch
+    norms = [torch.nn.LayerNorm(C, eps=e).to(DEV) for e in eps]
+    for n, g, b in zip(norms, gs, bs):
+        n.weight.data.copy_(g)
+        n.bias.data.copy_(b)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    sum((n(x) * d).sum() for n, x, d in zip(norms, xr, dys)).backward()
+    ref = [(x.grad.clone(), n.weight.grad.clone(), n.bias.grad.clone()) for x, n in zip(xr, norms)]
+    for n in norms:
+        n.weight.grad = n.bias.grad = None
+    xd = [x.clone().requires_grad_(True) for x in xs]
+    ys = ag.layernorm3(xd, norms)
+    sum((y * d).sum() for y, d in zip(ys, dys)).backward()
+    for x, n, (rx, rg, rb) in zip(xd, norms, ref):
+        close(x.grad, rx, 2e-5, "dx vs torch")
+        close(n.weight.grad, rg, 2e-5, "dgamma vs torch")
+        close(n.bias.grad, rb, 2e-5, "dbeta vs torch")
+
+
 def test_pool_maxpool_relpos_backward():
     from diff_sal_amd import encoder_autograd as eg
 
