@@ -992,6 +992,19 @@ static int validate(const diffsal_conv_desc* d) {
   return DIFFSAL_OK;
 }
 
+// the planner's choice, or the tuning aid's: DIFFSAL_IGEMM_CFG = tile shape (value % 8) and 2^(value / 8) K splits
+static Plan plan_or_forced(long M, int Cout, int K, int precision, bool linear) {
+  Plan pl = choose_plan(M, Cout, K, precision, linear);
+  const int v = tune(TUNE_IGEMM_CFG);
+  if (v >= 0) {
+    pl.cfg = (v % 8) % kNumCfgs;
+    pl.splits = 1;
+    for (int e = 0; e < v / 8 && e < 4; ++e)
+      if (K / BK / (pl.splits * 2) >= 4 && Cout % 4 == 0) pl.splits *= 2;
+  }
+  return pl;
+}
+
 extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (validate(d) != DIFFSAL_OK) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
@@ -1000,7 +1013,7 @@ extern "C" size_t diffsal_conv_igemm_ws_bytes(const diffsal_conv_desc* d) {
   if (d->dtype != DIFFSAL_F32) {
     need = igemm16_ws_bytes(d);
   } else {
-    const Plan pl = choose_plan(M, d->Cout, K, d->precision, is_linear(d));
+    const Plan pl = plan_or_forced(M, d->Cout, K, d->precision, is_linear(d));
     need = pl.splits > 1 ? static_cast<size_t>(pl.splits) * M * d->Cout * sizeof(float) : 0;
   }
   const int r = dma_route(d, is_linear(d), M, K, false);
@@ -1087,11 +1100,7 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
       if (rr != 0) return rr < 0 ? rr : DIFFSAL_OK;
     }
   }
-  Plan pl = choose_plan(M, d->Cout, a.K, d->precision, a.linear != 0);
-  if (tune(TUNE_IGEMM_CFG) >= 0) {   // tuning aid: force a tile shape (no split-K)
-    pl.cfg = tune(TUNE_IGEMM_CFG) % kNumCfgs;
-    pl.splits = 1;
-  }
+  const Plan pl = plan_or_forced(M, d->Cout, a.K, d->precision, a.linear != 0);
   if (tune(TUNE_PLAN_DEBUG) == 1) {   // tuning aid: which tile shape / split the planner chose
     fprintf(stderr, "[diffsal plan] M=%ld K=%d N=%d linear=%d -> %dx%d splits=%d\n", M, a.K, d->Cout, a.linear,
                              kCfgs[pl.cfg].bm, kCfgs[pl.cfg].bn, pl.splits);

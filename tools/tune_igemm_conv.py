@@ -10,12 +10,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diff_sal_amd import _lib, ops  # noqa: E402
 from tools.tune_igemm16 import timed  # noqa: E402
 
+SPLITS = [int(v) for v in os.environ.get("TUNE_SPLITS", "0").split(",")]     # log2 of the forced K splits (value / 8 of DIFFSAL_IGEMM_CFG)
 CFG = ["128x192", "128x128", "128x96", "64x128", "128x64", "64x64"]
 # (images, H, W, Cin, Cout, kh, kw, dil, stride)
 SHAPES = [(4, 56, 96, 96, 192, 3, 3, 1, 1), (4, 56, 96, 192, 192, 3, 3, 1, 1), (4, 56, 96, 192, 192, 3, 3, 1, 2),
           (4, 28, 48, 192, 384, 3, 3, 1, 1), (4, 28, 48, 384, 384, 3, 3, 1, 1), (4, 28, 48, 384, 384, 3, 3, 1, 2),
           (4, 14, 24, 384, 768, 3, 3, 1, 1), (4, 14, 24, 768, 768, 3, 3, 1, 1), (4, 14, 24, 768, 768, 3, 3, 1, 2),
           (36, 14, 24, 384, 384, 3, 3, 2, 1), (36, 28, 48, 192, 192, 3, 3, 2, 1), (36, 56, 96, 96, 96, 3, 3, 2, 1)]
+if os.environ.get("TUNE_ONLY_STRIDED"):
+    SHAPES = [s_ for s_ in SHAPES if s_[8] == 2]
 
 
 def main():
@@ -33,8 +36,9 @@ def main():
         for c, cn in enumerate(CFG):
             if (c == 0 and co < 161) or (c in (1, 3) and co < 97):
                 continue
-            _lib.set_tuning("DIFFSAL_IGEMM_CFG", c)
-            line += f" {cn} {timed(f):6.1f}"
+            for sp in SPLITS:
+                _lib.set_tuning("DIFFSAL_IGEMM_CFG", c + 8 * sp)
+                line += f" {cn}{'/' + str(1 << sp) if sp else ''} {timed(f):6.1f}"
         _lib.set_tuning("DIFFSAL_IGEMM_CFG", None)
         print(line, flush=True)
 
