@@ -47,6 +47,18 @@ SHAPES = [
     ("b1 s2.fc2 ", 12096, 384, 192, True, 0, True),
     ("b1 s3.tap ", 12096, 192, 864, False, 0, False),
     ("b1 mt.tap ", 7140, 768, 864, False, 0, False),
+    # MViTv2-S token GEMMs of a training step (4 clips): stage 3 (11 blocks), stages 2 / 1 / 4
+    ("mv3.qkv   ", 10756, 384, 1152, True, 0, False),
+    ("mv3.proj  ", 10756, 384, 384, True, 0, True),
+    ("mv3.fc1   ", 10756, 384, 1536, True, 0, False),
+    ("mv3.fc2   ", 10756, 1536, 384, True, 0, True),
+    ("mv2.qkv   ", 43012, 192, 576, True, 0, False),
+    ("mv2.fc1   ", 43012, 192, 768, True, 0, False),
+    ("mv2.fc2   ", 43012, 768, 192, True, 0, True),
+    ("mv1.fc1   ", 172036, 96, 384, True, 0, False),
+    ("mv1.fc2   ", 172036, 384, 96, True, 0, True),
+    ("mv4.fc1   ", 2692, 768, 3072, True, 0, False),
+    ("mv4.fc2   ", 2692, 3072, 768, True, 0, True),
 ]
 
 
