@@ -34,7 +34,7 @@ class Wino4Ext(C.Structure):
 
 # must equal diffsal_version() of the loaded binary: bumped whenever a signature or struct in include/diffsal.h changes,
 # so that a stale libdiffsal_hip.so is rejected instead of being called with the wrong argument lists
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 
 SIGNATURES = {
@@ -78,6 +78,7 @@ SIGNATURES = {
     "diffsal_affine_act": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "diffsal_norm_bwd_apply": (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_f]),
     "diffsal_layernorm_bwd_blocks": (c_i, [c_i, c_i]),
+    "diffsal_wino4_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
     "diffsal_layernorm_multi": (c_i, [c_f] * 4 + [C.POINTER(c_i), c_i, c_i, C.POINTER(c_fl), c_f]),
     "diffsal_layernorm_bwd_multi": (c_i, [c_f] * 5 + [C.POINTER(c_i), c_i, c_i, C.POINTER(c_fl), c_f]),
     "diffsal_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f]),

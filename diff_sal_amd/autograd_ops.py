@@ -51,8 +51,17 @@ class ConvFn(torch.autograd.Function):
         if in_gelu and ((kh, kw) != (1, 1) or stride != (1, 1)):
             raise NotImplementedError("training path: the GELU in front of a layer is folded into 1x1 stride-1 products only")
         xin = ops.gelu(x) if in_gelu else x
-        y = ops.conv_igemm(xin, w_packed, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, out_hw=out_hw, bias=bias,
-                           rowvec=rowvec, residual=residual, act=act)
+        # 3x3 stride-1 padding = dilation convolutions with the parameter at hand (w_raw): F(4x4, 3x3) where the planner takes it
+        # (a quarter of the products; the weight transform runs on the device, the weights change every step)
+        w_raw = meta[8] if len(meta) > 8 else None
+        ctx.wino = bool(WINO4_TRAIN and w_raw is not None and (kh, kw) == (3, 3) and stride == (1, 1) and pad == dil and dil[0] == dil[1]
+                        and dil[0] in (1, 2) and not in_gelu and ops.wino4_supported(xin, w_raw.shape[0], dil[0]))
+        if ctx.wino:
+            y = ops.conv3x3_wino4_ex(xin, ops.wino4_weight(w_raw), bias=bias, rowvec=rowvec, residual=residual, act=act, dil=dil[0],
+                                     tag="gemm")[0]
+        else:
+            y = ops.conv_igemm(xin, w_packed, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil, out_hw=out_hw, bias=bias,
+                               rowvec=rowvec, residual=residual, act=act)
         ctx.meta = meta
         ctx.has = (bias is not None, rowvec is not None, residual is not None)
         ctx.save_for_backward(xin, w_dgrad if w_dgrad is not None else x.new_empty(0), y if act == ACT_RELU else x.new_empty(0),
@@ -79,9 +88,15 @@ class ConvFn(torch.autograd.Function):
         drv = ops.colsum(g, Ho * Wo) if (has_rv and ctx.needs_input_grad[3]) else None
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         dx = None
-        if ctx.needs_input_grad[0]:
+        w_raw = ctx.meta[8] if len(ctx.meta) > 8 else None
+        if ctx.needs_input_grad[0] and ctx.wino and ops.wino4_supported(g, x.shape[-1], dil[0]):
+            # dX = conv(dY, flipped w^T), same padding = dilation: the F(4x4) path with the flipped kernel's transform
+            dx = ops.conv3x3_wino4_ex(g, ops.wino4_weight(w_raw, dgrad=True), dil=dil[0], tag="gemm")[0]
+        elif ctx.needs_input_grad[0]:
             if w_dgrad.numel() == 0:
-                raise RuntimeError("ConvFn: input needs a gradient but no dgrad weight was supplied")
+                if w_raw is None:
+                    raise RuntimeError("ConvFn: input needs a gradient but no dgrad weight was supplied")
+                w_dgrad = dgrad_weight(w_raw, stride)
             H, W = x.shape[1:3]
             if stride == (1, 1):
                 # flipped-kernel convolution over dY with padding dil*(k-1) - pad
@@ -109,10 +124,16 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, drv, dres, None, None
 
 
+# F(4x4, 3x3) for the training-mode 3x3 convolutions (forward and data gradient) that pass their parameter (DIFFSAL_NO_WINO4_TRAIN=1: off)
+WINO4_TRAIN = _os.environ.get("DIFFSAL_NO_WINO4_TRAIN", "0") != "1"
+
+
 def conv(x, w_packed, *, kh=1, kw=1, stride=(1, 1), pad=(0, 0), dil=(1, 1), out_hw=None, bias=None, rowvec=None,
-         residual=None, act=ACT_NONE, w_dgrad=None, in_gelu=False):
+         residual=None, act=ACT_NONE, w_dgrad=None, in_gelu=False, w_raw=None):
+    """w_raw: the parameter itself [Cout, Cin, KH, KW] (constant here; its gradient flows through w_packed): lets the node pick the
+    F(4x4) path for 3x3 stride-1 convolutions and build the data-gradient weight it needs in the backward (w_dgrad may then be None)."""
     return ConvFn.apply(x, w_packed, bias, rowvec, residual, w_dgrad,
-                        (kh, kw, tuple(stride), tuple(pad), tuple(dil), out_hw, act, bool(in_gelu)))
+                        (kh, kw, tuple(stride), tuple(pad), tuple(dil), out_hw, act, bool(in_gelu), None if w_raw is None else w_raw.detach()))
 
 
 def linear(x, w, bias=None, *, residual=None, act=ACT_NONE, in_gelu=False):

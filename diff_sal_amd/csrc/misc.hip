@@ -711,7 +711,7 @@ extern "C" size_t diffsal_workspace_bytes(int op, const diffsal_conv_desc* d, co
   }
 }
 
-extern "C" int diffsal_version(void) { return 41; }  // = _lib.ABI_VERSION
+extern "C" int diffsal_version(void) { return 42; }  // = _lib.ABI_VERSION
 extern "C" const char* diffsal_last_error(void) { return g_err; }
 extern "C" const char* diffsal_last_gemm_kernel(void) { return g_kernel; }
 

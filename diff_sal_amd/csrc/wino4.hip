@@ -454,9 +454,48 @@ size_t wino4_v_bytes(const Wino4Geom& g) { return 36ul * g.n_tiles * g.Cin * siz
 size_t wino4_m_bytes(const Wino4Geom& g) { return 36ul * g.n_tiles * g.Cout * sizeof(float); }
 
 }  // namespace
+// U = G g G^T of every (output, input) channel pair on the device (training: the weights change every step; inference packs U once on
+// the host in fp64, ops.pack_wino4_weight).  w [Cout][Cin][3][3] (the parameter's layout).  dgrad = 0: U [36][Cout][Cin] -- the forward
+// convolution; dgrad = 1: U [36][Cin][Cout] of the flipped kernel g'[a][b] = g[2-a][2-b] -- the data gradient dX = conv(dY, w^T flipped).
+// The fastest thread index is the output's last dimension (coalesced stores; the nine-float reads are strided either way).
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int dgrad) {
+  const long n = static_cast<long>(Cout) * Cin;
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int inner = dgrad ? Cout : Cin;
+  const int o = static_cast<int>(i / inner), c = static_cast<int>(i - static_cast<long>(o) * inner);     // output row / column of U's [.][.]
+  const int co = dgrad ? c : o, ci = dgrad ? o : c;
+  const float* gp = w + (static_cast<long>(co) * Cin + ci) * 9;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) g[a][b] = dgrad ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
+  constexpr float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                             {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+  float t[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) t[r][b] = G[r][0] * g[0][b] + G[r][1] * g[1][b] + G[r][2] * g[2][b];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) U[(r * 6 + q) * n + i] = t[r][0] * G[q][0] + t[r][1] * G[q][1] + t[r][2] * G[q][2];
+}
+
 }  // namespace diffsal
 
 using namespace diffsal;
+
+extern "C" int diffsal_wino4_weight(const float* w, float* U, int Cout, int Cin, int dgrad, diffsal_stream_t stream) {
+  DS_REQUIRE(w && U, DIFFSAL_E_ARG, "wino4_weight: null argument");
+  DS_REQUIRE(Cout > 0 && Cin > 0 && static_cast<long>(Cout) * Cin < (1L << 31), DIFFSAL_E_SHAPE, "wino4_weight: bad shape %d x %d", Cout, Cin);
+  const long n = static_cast<long>(Cout) * Cin;
+  hipLaunchKernelGGL(wino4_weight_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, U,
+                     Cout, Cin, dgrad ? 1 : 0);
+  return check_launch("wino4_weight");
+}
 
 // 1 when diffsal_conv_wino4 accepts the descriptor AND the planner expects it to beat both the F(2x2) path and the direct kernel
 extern "C" int diffsal_conv_wino4_supported(const diffsal_conv_desc* d) {

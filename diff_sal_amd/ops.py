@@ -556,6 +556,19 @@ def pack_wino4_weight(w: Tensor) -> Tensor:
     return torch.einsum("ia,ocab,jb->ijoc", G, w, G).reshape(36, Cout, Cin).float().contiguous()
 
 
+@_classed("pack")
+def wino4_weight(w: Tensor, dgrad: bool = False) -> Tensor:
+    """The F(4x4, 3x3) weight U = G w G^T computed on the device in fp32 (training; ``pack_wino4_weight`` is the fp64 host form of
+    inference): [36, Cout, Cin], or with ``dgrad`` [36, Cin, Cout] of the flipped kernel (the data-gradient convolution)."""
+    lib = _lib.load()
+    w = w.detach()
+    Cout, Cin = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 3) and w.dtype == torch.float32
+    U = torch.empty((36, Cin, Cout) if dgrad else (36, Cout, Cin), device=w.device, dtype=torch.float32)
+    _lib.check(lib.diffsal_wino4_weight(_p(w.contiguous()), _p(U), Cout, Cin, int(dgrad), _stream()), "wino4_weight")
+    return U
+
+
 class WinoWeights:
     """The Winograd forms of one 3x3 weight: ``f2`` (pack_wino_weight) and ``f4`` (pack_wino4_weight); conv_igemm(wino=...) asks
     the library per shape which of them -- if any -- to use."""

@@ -894,15 +894,14 @@ class SalUNet(nn.Module):
             co = rb.conv1.out_channels
             h = ag.groupnorm_swish(f, rb.norm1.weight, rb.norm1.bias, 32, rb.norm1.eps)
             h = ag.conv(h, pw(rb.conv1.weight), kh=3, kw=3, pad=(1, 1), bias=rb.conv1.bias,
-                        rowvec=tproj[:, off:off + co], w_dgrad=dgw(rb.conv1.weight))
+                        rowvec=tproj[:, off:off + co], w_raw=rb.conv1.weight)
             off += co
             h = ag.groupnorm_swish(h, rb.norm2.weight, rb.norm2.bias, 32, rb.norm2.eps)
             h = ag.dropout(h, self.dropout_p, dropout_seed + 7919 * i)
             sc = f
             if hasattr(rb, "nin_shortcut"):
                 sc = ag.conv(f, pw(rb.nin_shortcut.weight), bias=rb.nin_shortcut.bias, w_dgrad=dgw(rb.nin_shortcut.weight))
-            f = ag.conv(h, pw(rb.conv2.weight), kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc,
-                        w_dgrad=dgw(rb.conv2.weight))
+            f = ag.conv(h, pw(rb.conv2.weight), kh=3, kw=3, pad=(1, 1), bias=rb.conv2.bias, residual=sc, w_raw=rb.conv2.weight)
             hh, ww = f.shape[1:3]
             f = ag.conv(f, pw(dn.conv.weight), kh=3, kw=3, stride=(2, 2), out_hw=((hh - 2) // 2 + 1, (ww - 2) // 2 + 1),
                         bias=dn.conv.bias, w_dgrad=dgw(dn.conv.weight, (2, 2)))
@@ -940,9 +939,9 @@ class SalUNet(nn.Module):
                     u = ag.tapsum(y9, [(h, w)], Bn * T, 2 * h, 2 * w, C, dil=d)
                 else:
                     u = ag.resize_bilinear(xcur.view(Bn * T, h, w, Cp), 2 * h, 2 * w)
-                    u = ag.conv(u, pw(pe[1].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[1].weight))
+                    u = ag.conv(u, pw(pe[1].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_raw=pe[1].weight)
                 u = ag.batchnorm_relu_train(u, pe[2])
-                u = ag.conv(u, pw(pe[4].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_dgrad=dgw(pe[4].weight))
+                u = ag.conv(u, pw(pe[4].weight), kh=3, kw=3, pad=(d, d), dil=(d, d), w_raw=pe[4].weight)
                 u = ag.batchnorm_relu_train(u, pe[5])
                 if i in (1, 2):
                     u = ag.add(u, frames[i].view(Bn * T, 2 * h, 2 * w, C))
@@ -994,7 +993,7 @@ class SalUNet(nn.Module):
             y = ag.tapsum(y9, [z.shape[1:3] for z in zs], B, th, tw_, mt[0].weight.shape[0], dil=1, bias=mt[0].bias)
         else:
             acc = ag.resize_sum(zs, th, tw_)
-            y = ag.conv(acc, pw(mt[0].weight), kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, w_dgrad=dgw(mt[0].weight))
+            y = ag.conv(acc, pw(mt[0].weight), kh=3, kw=3, pad=(1, 1), bias=mt[0].bias, w_raw=mt[0].weight)
         y = ag.batchnorm_relu_train(y, mt[1])
         s_ = ag.head_sigmoid(y, self.logits.linear_pred.weight.reshape(-1), self.logits.linear_pred.bias)
         out = ag.resize_bilinear(s_, self.img_size[0], self.img_size[1])

@@ -209,6 +209,10 @@ int diffsal_conv_wino(const diffsal_conv_desc* d /*host*/, const float* x, const
  * diffsal_conv_wino4_supported: the shape qualifies and the planner expects a gain (DIFFSAL_NO_WINOGRAD4=1 /
  * DIFFSAL_NO_WINOGRAD=1: never, DIFFSAL_FORCE_WINOGRAD=1: whenever the shape qualifies). */
 int diffsal_conv_wino4_supported(const diffsal_conv_desc* d /*host*/);
+/* U = G g G^T on the device, fp32 (training: the weights change every step).  w [Cout][Cin][3][3]; dgrad = 0 -> U [36][Cout][Cin] (the forward
+ * convolution); dgrad = 1 -> U [36][Cin][Cout] of the flipped kernel: the data gradient dX = conv(dY, .) of a stride-1, padding = dilation
+ * convolution runs on the same F(4x4) path with it. */
+int diffsal_wino4_weight(const float* w, float* U, int Cout, int Cin, int dgrad, diffsal_stream_t stream);
 size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d /*host*/);
 int diffsal_conv_wino4(const diffsal_conv_desc* d /*host*/, const float* x, const float* U, const float* bias,
                        const float* scale, const float* shift, const float* rowvec, const float* residual, float* out, void* ws,

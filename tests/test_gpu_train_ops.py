@@ -428,6 +428,45 @@ def test_adam_step_matches_torch_adam_with_clipping(ag, max_norm, world):
         assert (p.cpu() - ref_p.detach()).abs().max().item() <= 1e-4 * 1e-4 * step + 1.2e-7 * 4
 
 
+@pytest.mark.parametrize("case", [(4, 28, 48, 192, 384, 1, True), (36, 14, 24, 384, 384, 2, False), (4, 56, 96, 96, 192, 1, True)])
+def test_training_convolution_on_the_winograd_path(case):
+    """ConvFn with the parameter at hand (w_raw) runs its forward and its data gradient on the F(4x4, 3x3) path with the weight transform
+    computed on the device: against the direct convolution of the same node (forward, dx, dw, dbias, drowvec) and the device transform
+    against the fp64 host transform."""
+    from diff_sal_amd import autograd_ops as ag
+    from diff_sal_amd import ops
+
+    N, H, W, Cin, Cout, dil, extras = case
+    w = orc.synth_tensor("tw%d" % Cout, (Cout, Cin, 3, 3), 0.05).to(DEV)
+    U_host = ops.pack_wino4_weight(w)
+    assert (ops.wino4_weight(w) - U_host).abs().max().item() <= 2e-6 * U_host.abs().max().item()
+    wt = w.flip(2, 3).transpose(0, 1).contiguous()                  # the data gradient's convolution weight [Cin, Cout, 3, 3]
+    Ud_host = ops.pack_wino4_weight(wt)
+    assert (ops.wino4_weight(w, dgrad=True) - Ud_host).abs().max().item() <= 2e-6 * Ud_host.abs().max().item()
+    x0 = orc.synth_tensor("tx%d" % Cin, (N, H, W, Cin)).to(DEV)
+    assert ops.wino4_supported(x0, Cout, dil)
+    bias = orc.synth_tensor("tb", (Cout,), 0.1).to(DEV) if extras else None
+    rv0 = orc.synth_tensor("trv", (N, Cout), 0.1).to(DEV) if extras else None
+    G = orc.synth_tensor("tg%d" % Cout, (N, H, W, Cout)).to(DEV)
+    res = {}
+    for form in ("wino", "direct"):
+        ag.WINO4_TRAIN = form == "wino"
+        try:
+            x = x0.clone().requires_grad_(True)
+            wl = w.clone().requires_grad_(True)
+            b = bias.clone().requires_grad_(True) if extras else None
+            rv = rv0.clone().requires_grad_(True) if extras else None
+            y = ag.conv(x, ops.pack_conv_weight_diff(wl), kh=3, kw=3, pad=(dil, dil), dil=(dil, dil), bias=b, rowvec=rv, w_raw=wl)
+            (y * G).sum().backward()
+            res[form] = (y.detach(), x.grad, wl.grad) + ((b.grad, rv.grad) if extras else ())
+        finally:
+            ag.WINO4_TRAIN = True
+    for a, b_, n in zip(res["wino"], res["direct"], ("y", "dx", "dw", "dbias", "drowvec")):
+        e = (a - b_).abs().max().item() / b_.abs().max().item()
+        print(f"{n}: winograd vs direct {e:.2e}")
+        assert e < (1e-4 if n in ("y", "dx") else 1e-6), n          # dw / dbias / drowvec come from the same kernels on the same operands
+
+
 @pytest.mark.parametrize("M,K,N", [(5000, 160, 100), (70001, 96, 576), (3024, 768, 864), (333, 32, 4)])
 def test_wgrad_dma_kernel_equals_the_register_staged_kernel(M, K, N, tuning):
     """Plain-product weight gradients on the 128 x 192 tile run on wgrad_dma_kernel (both operands by LDS-DMA, three stages, one
