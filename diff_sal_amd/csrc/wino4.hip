@@ -503,8 +503,11 @@ extern "C" int diffsal_conv_wino4_supported(const diffsal_conv_desc* d) {
   if (tune(TUNE_FORCE_WINOGRAD) == 1) return 1;
   const Wino4Geom g = wino4_geom(d);
   // the transformed input and the position products (36 x tiles x (Cin + Cout) floats) are written and read back once: they have
-  // to stay in the 256 MB Infinity Cache for the two streaming kernels to cost less than the products they save
-  return (wino4_v_bytes(g) + wino4_m_bytes(g) <= 400ul * 1000 * 1000 && d->Cout >= 96 && g.n_tiles >= 96) ? 1 : 0;
+  // to stay in the 256 MB Infinity Cache for the two streaming kernels to cost less than the products they save.  From 24 tiles
+  // (one 14 x 24 map): alone such a convolution was slower than F(2x2) (round 4: 0.71-0.83x, hence a bar of 96 tiles), but the
+  // fused ResnetBlock rides on this path (GroupNorm in the input transform, shortcut in the batched launch, statistics from the
+  // output transform: three launches fewer per block) -- measured per step: B = 1 582 -> 602 steps/s, B = 2 877 -> 888
+  return (wino4_v_bytes(g) + wino4_m_bytes(g) <= 400ul * 1000 * 1000 && d->Cout >= 96 && g.n_tiles >= 24) ? 1 : 0;
 }
 
 extern "C" size_t diffsal_conv_wino4_ws_bytes(const diffsal_conv_desc* d) {

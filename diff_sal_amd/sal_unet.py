@@ -804,6 +804,18 @@ class SalUNet(nn.Module):
                                out=z_out, tag="K13")
             zs.append(z.view(Bn, H, W, self.ori_embed_dim))
         if redu:
+            # a grouped launch has no K split: its makespan is at least the longest unit's K walk (stage 0: 120 slices).  At one clip that
+            # is 2.4x the launch's work per CU -- such a product runs on its own (the planner splits its K), the rest stays grouped
+            def _units(pr):
+                n, t, hw, c = pr["x"].shape
+                return -(-n * hw // 96) * -(-pr["w"].shape[0] // 96), pr["kh"] * c // 32
+            while len(redu) > 1:
+                work = sum(u * k for u, k in map(_units, redu)) / 256.0
+                j = max(range(len(redu)), key=lambda q: _units(redu[q])[1])
+                if _units(redu[j])[1] <= 1.5 * work:
+                    break
+                pr = redu.pop(j)
+                ops.conv_igemm(pr["x"], pr["w"], kh=pr["kh"], kw=pr["kw"], stride=pr["stride"], act=pr["act"], out=pr["out"], tag="K13")
             ops.conv_igemm_group(redu, tag="K13")
         mt = dec.mt_proj
         if z_all is not None:
