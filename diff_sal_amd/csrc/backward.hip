@@ -1074,6 +1074,8 @@ extern "C" int diffsal_layernorm_bwd_multi(const float* const* x, const float* c
   int most = 0;
   for (int t = 0; t < n; ++t) {
     DS_REQUIRE(x[t] && dy[t] && gamma[t] && dx[t] && M[t] > 0, DIFFSAL_E_ARG, "layernorm_bwd_multi: null tensor %d", t);
+    DS_REQUIRE(aligned16(x[t]) && aligned16(dy[t]) && aligned16(gamma[t]) && aligned16(dx[t]), DIFFSAL_E_ALIGN,
+               "layernorm_bwd_multi: misaligned tensor %d", t);
     a.x[t] = x[t]; a.dy[t] = dy[t]; a.gamma[t] = gamma[t]; a.dx[t] = dx[t]; a.M[t] = M[t]; a.eps[t] = eps[t];
     most = M[t] > most ? M[t] : most;
   }

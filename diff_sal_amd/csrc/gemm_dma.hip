@@ -390,8 +390,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   // Epilogue operands (per-channel vectors, residual quads) are requested at the start of the tile's LAST pass over the ring and
   // wait in registers: requested in the epilogue they would be a dependent round trip with the matrix pipe idle, and -- vmcnt
   // retires in order -- their wait would also drain the DMA ring.
-  float4 rres[TMB][TNB], rbias[TNB], rscale[TNB], rshift[TNB];
+  // (the residual quads only while they fit: 9 of them on the 96 x 96 tile; the 192 x 192 tile of 16-bit storage would hold 36 --
+  // 144 registers -- and reads them in its epilogue instead)
+  constexpr bool PRE_RES = TMB * TNB <= 12;
+  float4 rres[PRE_RES ? TMB : 1][PRE_RES ? TNB : 1], rbias[PRE_RES ? TNB : 1], rscale[PRE_RES ? TNB : 1], rshift[PRE_RES ? TNB : 1];
   auto fetch_epilogue_operands = [&]() __attribute__((always_inline)) {
+    if constexpr (!PRE_RES) return;
     int tmi, tni;
     tile_mn(pc, cmp_lv, tmi, tni);
     const int m0 = tmi * BM, n0 = tni * BN;
@@ -399,14 +403,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
     for (int j = 0; j < TNB; ++j) {
       const int n = n0 + wn * TNB * 16 + j * 16 + 4 * q4;
       const int nc = n < pc.N ? n : 0;
-      if (pc.bias) rbias[j] = ld4(pc.bias + nc);
-      if (pc.scale) { rscale[j] = ld4(pc.scale + nc); rshift[j] = ld4(pc.shift + nc); }
-      if (pc.residual) {
+      if constexpr (PRE_RES) {
+        if (pc.bias) rbias[j] = ld4(pc.bias + nc);
+        if (pc.scale) { rscale[j] = ld4(pc.scale + nc); rshift[j] = ld4(pc.shift + nc); }
+        if (pc.residual) {
 #pragma unroll
-        for (int i = 0; i < TMB; ++i) {
-          const int m = m0 + wm * TMB * 16 + i * 16 + r16;
-          const bool ok = m < pc.M && n < pc.N;
-          rres[i][j] = ld4(static_cast<const T*>(pc.residual) + (ok ? static_cast<long>(m) * pc.N + n : 0));
+          for (int i = 0; i < TMB; ++i) {
+            const int m = m0 + wm * TMB * 16 + i * 16 + r16;
+            const bool ok = m < pc.M && n < pc.N;
+            rres[i][j] = ld4(static_cast<const T*>(pc.residual) + (ok ? static_cast<long>(m) * pc.N + n : 0));
+          }
         }
       }
     }
@@ -424,15 +430,23 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
       const bool n_ok = nb + j * 16 < pc.N;
+      float4 qb, qs, qh;
+      if constexpr (PRE_RES) {
+        qb = rbias[j]; qs = rscale[j]; qh = rshift[j];
+      } else {
+        const int nc = n_ok ? nb + j * 16 : 0;
+        if (pc.bias) qb = ld4(pc.bias + nc);
+        if (pc.scale) { qs = ld4(pc.scale + nc); qh = ld4(pc.shift + nc); }
+      }
 #pragma unroll
       for (int i = 0; i < TMB; ++i) {
         const int m = mb + i * 16;
         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
         acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (pc.bias) { v[0] += rbias[j].x; v[1] += rbias[j].y; v[2] += rbias[j].z; v[3] += rbias[j].w; }
+        if (pc.bias) { v[0] += qb.x; v[1] += qb.y; v[2] += qb.z; v[3] += qb.w; }
         if (pc.scale) {
-          v[0] = v[0] * rscale[j].x + rshift[j].x; v[1] = v[1] * rscale[j].y + rshift[j].y;
-          v[2] = v[2] * rscale[j].z + rshift[j].z; v[3] = v[3] * rscale[j].w + rshift[j].w;
+          v[0] = v[0] * qs.x + qh.x; v[1] = v[1] * qs.y + qh.y;
+          v[2] = v[2] * qs.z + qh.z; v[3] = v[3] * qs.w + qh.w;
         }
         if (rvb) {
           const int mc = m < pc.M ? m : pc.M - 1;
@@ -449,11 +463,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = sigmoidf_(v[e]);
         }
+        float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PRE_RES) {
+          rq = rres[i][j];
+        } else {
+          if (pc.residual && m < pc.M && n_ok) rq = ld4(static_cast<const T*>(pc.residual) + o0 + (static_cast<long>(i) * 16 * pc.N + j * 16));
+        }
         if constexpr (ACT == DIFFSAL_ACT_GELU_GRAD) {
-          const float4 t = rres[i][j];
+          const float4 t = rq;
           v[0] *= gelu_erf_grad(t.x); v[1] *= gelu_erf_grad(t.y); v[2] *= gelu_erf_grad(t.z); v[3] *= gelu_erf_grad(t.w);
         } else {
-          if (pc.residual) { const float4 t = rres[i][j]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (pc.residual) { const float4 t = rq; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         }
         if (m < pc.M && n_ok) {
           if (!F32 && pc.out_f32)
@@ -485,11 +505,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_dma_kernel(std::conditional_t<G
   // that nothing is pending -- the epilogue starts without a wait.  (In the epilogue itself the same wait cost 2-3 us per unit:
   // the first slices of the next unit, just requested, had to land before the first store could be issued.)
   auto touch_epilogue_operands = [&]() __attribute__((always_inline)) {
+    if constexpr (PRE_RES) {
 #pragma unroll
-    for (int j = 0; j < TNB; ++j) {
-      touch(rbias[j]); touch(rscale[j]); touch(rshift[j]);
+      for (int j = 0; j < TNB; ++j) {
+        touch(rbias[j]); touch(rscale[j]); touch(rshift[j]);
 #pragma unroll
-      for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
+        for (int i = 0; i < TMB; ++i) touch(rres[i][j]);
+      }
     }
   };
   // no epilogue operand at all (the position products of the Winograd path, the tap products of UpEmbed / mt_proj): the sums go
@@ -714,7 +736,7 @@ int launch_dma(DmaGemmArgs& a, bool conv, hipStream_t s) {
 
 struct DmaCfg { int bm, bn, stages; };
 constexpr int kNumDmaCfgs = 2;                 // selectable through DIFFSAL_GEMM_DMA; entry 2: the wide tile of batched launches
-const DmaCfg kDmaCfgs[kNumDmaCfgs + 1] = {{96, 96, 3}, {96, 96, 6}, {96, 128, 3}};
+const DmaCfg kDmaCfgs[kNumDmaCfgs + 2] = {{96, 96, 3}, {96, 96, 6}, {96, 128, 3}, {192, 192, 3}};   // entry 3: 16-bit storage, large products
 
 // fills the problem-independent part of the arguments; false: shape not handled by tile configuration c.  esz: bytes per
 // element of the storage type (a K slice is 128 bytes of a row)
@@ -777,14 +799,15 @@ double gemm_dma_estimate(int cfg, long M, int K, int N) {
 int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* a, const void* w, const float* bias, const float* scale,
                  const float* shift, const float* rowvec, int rowvec_ld, const void* residual, void* out, void* ws, size_t ws_bytes,
                  hipStream_t s, bool out_f32) {
-  if (cfg < 0 || cfg >= kNumDmaCfgs) return 0;
-  const DmaCfg& c = kDmaCfgs[cfg];
   const int esz = d->dtype == DIFFSAL_F32 ? 4 : 2;
+  const bool big16 = cfg == 3 && esz == 2;     // 192 x 192 tiles, one workgroup per CU: twice the flops per staged byte
+  if (cfg < 0 || (cfg >= kNumDmaCfgs && !big16)) return 0;
+  const DmaCfg& c = kDmaCfgs[cfg];
   DmaGemmArgs g;
   if (!dma_fill(g, c, d, as_conv, esz, a, w, bias, scale, shift, rowvec, rowvec_ld, residual, out)) return 0;
   const long MN = static_cast<long>(g.M) * g.N;
   const int kt = g.kt_per_unit;
-  g.splits = choose_split(g.n_tiles, kt, c.stages, MN);
+  g.splits = big16 ? 1 : choose_split(g.n_tiles, kt, c.stages, MN);
   if (g.splits > 1 && (!ws || ws_bytes < static_cast<size_t>(g.splits) * MN * sizeof(float) || !aligned16(ws))) g.splits = 1;
   g.kt_per_unit = kt / g.splits;
   g.partial = g.splits > 1 ? static_cast<float*>(ws) : nullptr;
@@ -795,6 +818,7 @@ int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* 
   }
   int rc;
   if (d->dtype == DIFFSAL_F32) rc = cfg == 0 ? launch_dma<float, 3, 3, 3, 2>(g, as_conv, s) : launch_dma<float, 3, 3, 6, 1>(g, as_conv, s);
+  else if (big16) rc = d->dtype == DIFFSAL_BF16 ? launch_dma<bf16_t, 6, 6, 3, 1>(g, false, s) : launch_dma<f16_t, 6, 6, 3, 1>(g, false, s);
   else if (cfg != 0) return 0;
   else if (d->dtype == DIFFSAL_BF16) rc = launch_dma<bf16_t, 3, 3, 3, 2>(g, false, s);
   else rc = launch_dma<f16_t, 3, 3, 3, 2>(g, false, s);

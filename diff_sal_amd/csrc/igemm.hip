@@ -943,7 +943,7 @@ static int dma_route(const diffsal_conv_desc* d, bool linear, long M, int K, boo
     if (!linear || tune(TUNE_IGEMM16_CFG) >= 0 || K % 192 != 0 || d->Cout % 4 != 0) return -1;
     const int forced = tune(TUNE_GEMM_DMA16);
     if (forced == 0) return -1;
-    if (forced > 0) return 0;
+    if (forced > 0) return forced == 2 ? 3 : 0;
     return ((M + 95) / 96) * ((d->Cout + 95) / 96) >= 192 ? 0 : -1;
   }
   if (tune(TUNE_IGEMM_CFG) >= 0) return -1;

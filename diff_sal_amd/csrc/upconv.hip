@@ -225,7 +225,9 @@ using namespace diffsal;
 
 extern "C" int diffsal_border_gather(const void* z, void* zb, int N, int h, int w, int C, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(z && zb, DIFFSAL_E_ARG, "border_gather: null argument");
-  DS_REQUIRE(N > 0 && h >= 2 && w >= 2 && C > 0 && C % 8 == 0, DIFFSAL_E_SHAPE, "border_gather: N=%d h=%d w=%d C=%d", N, h, w, C);
+  // a piece is 16 bytes: four fp32 or eight 16-bit channels
+  DS_REQUIRE(N > 0 && h >= 2 && w >= 2 && C > 0 && C % (dtype == DIFFSAL_F32 ? 4 : 8) == 0, DIFFSAL_E_SHAPE,
+             "border_gather: N=%d h=%d w=%d C=%d", N, h, w, C);
   DS_REQUIRE(aligned16(z) && aligned16(zb), DIFFSAL_E_ALIGN, "border_gather: misaligned pointer");
   const long pieces = static_cast<long>(N) * (2 * w + 2 * h - 4) * (C / (dtype == DIFFSAL_F32 ? 4 : 8));
   long g = (pieces + 255) / 256;

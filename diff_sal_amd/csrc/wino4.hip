@@ -301,11 +301,13 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
   const long items = static_cast<long>(g.n_tiles) * q4n;
   const long pos_stride = static_cast<long>(g.n_tiles) * g.Cout;
   const long HW = static_cast<long>(g.HO) * g.WO;
-  __shared__ double st_sh[STATS ? 2 * kW4StatGroups * 2 : 1];
+  // STATS: every thread leaves the per-channel sums of its item in LDS; the workgroup's (image, group) sums are then added
+  // up in a FIXED order (tile, channel) -- no atomics, the statistics are bit-reproducible from run to run
+  __shared__ float2 st_sh[STATS ? 256 * VW : 1];
   int n_first = 0;
   if constexpr (STATS) {          // one pass per workgroup (grid = ceil(items / 256)): its statistics slot is blockIdx.x
-    for (int i = threadIdx.x; i < 2 * kW4StatGroups * 2; i += 256) st_sh[i] = 0.0;
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VW; ++e) st_sh[threadIdx.x * VW + e] = make_float2(0.f, 0.f);    // threads past the last item
     n_first = static_cast<int>((static_cast<long>(blockIdx.x) * 256) / q4n) / p.tiles_per_img;
   }
   for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
@@ -372,21 +374,33 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(Wino4Out p) {
       }
     }
     if constexpr (STATS) {
-      const int cpg = g.Cout / p.groups;
-      double* slot = st_sh + (n - n_first) * (kW4StatGroups * 2);
 #pragma unroll
-      for (int e = 0; e < VW; ++e) {
-        const int grp = (co + e) / cpg;
-        atomicAdd(slot + grp * 2, static_cast<double>(ssum[e]));
-        atomicAdd(slot + grp * 2 + 1, static_cast<double>(ssq[e]));
-      }
+      for (int e = 0; e < VW; ++e) st_sh[threadIdx.x * VW + e] = make_float2(ssum[e], ssq[e]);
     }
   }
   if constexpr (STATS) {
     __syncthreads();
+    // thread i = (image slot, group, sum | sum of squares): the workgroup's tiles of that image in order, the group's channels in
+    // order.  Item of (tile t, channel c) = t q4n + c / VW, element c % VW; this workgroup holds items [base, base + 256)
+    const int cpg = g.Cout / p.groups;
+    const long base = static_cast<long>(blockIdx.x) * 256;
+    const int t_lo = static_cast<int>(base / q4n);
+    const long last = base + 255 < items - 1 ? base + 255 : items - 1;
+    const int t_hi = static_cast<int>(last / q4n);
     for (int i = threadIdx.x; i < 2 * p.groups * 2; i += 256) {
       const int img = i / (p.groups * 2), r = i - img * (p.groups * 2);
-      p.stats[(static_cast<long>(blockIdx.x) * 2 + img) * (p.groups * 2) + r] = st_sh[img * (kW4StatGroups * 2) + r];
+      const int grp = r >> 1, which = r & 1;
+      double acc = 0.0;
+      for (int t = t_lo; t <= t_hi; ++t) {
+        if (t / p.tiles_per_img != n_first + img) continue;
+        for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) {
+          const long item = static_cast<long>(t) * q4n + c / VW;
+          if (item < base || item > last) continue;
+          const float2 v = st_sh[static_cast<int>(item - base) * VW + (c % VW)];
+          acc += static_cast<double>(which ? v.y : v.x);
+        }
+      }
+      p.stats[(static_cast<long>(blockIdx.x) * 2 + img) * (p.groups * 2) + r] = acc;
     }
   }
 }

@@ -1331,7 +1331,6 @@ def norm_bwd_apply(x, dy, y, mu, rs, gamma, beta, k1, k2, k3, seg_rows: int, mod
     return dx
 
 
-@_classed("K8-bwd")
 @_classed("K8")
 def layernorm_multi(xs, gammas, betas, epss):
     """LayerNorm of up to three fp32 tensors of one width in one launch (include/diffsal.h) -> list of outputs."""
@@ -1366,6 +1365,7 @@ def layernorm_bwd_multi(xs, dys, gammas, epss):
     return dxs, [s_[t, 0] for t in range(n)], [s_[t, 1] for t in range(n)]
 
 
+@_classed("K8-bwd")
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float = 1e-5, add: Optional[Tensor] = None):
     """-> (dx (+ add), dgamma, dbeta)."""
     lib = _lib.load()

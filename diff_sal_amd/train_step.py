@@ -135,14 +135,21 @@ class GradReducer:
     can use all seven links of a GPU where a single ring is bound by one link per hop).  Buckets whose
     length is not a multiple of the world size, and backends without reduce-scatter (gloo), use the all-reduce.
 
-    Parameters without a gradient.  A bucket holding a parameter that never receives a gradient (audio-branch weights in
+    Parameters without a gradient.  The reference wraps the model in ``DistributedDataParallel(...,
+    find_unused_parameters=True)`` (R/model.py:15): the set of parameters that receive no gradient may change from step to
+    step and from rank to rank.  Here a bucket holding a parameter that never receives a gradient (audio-branch weights in
     visual-only training, an unused head) would stay open until ``finish()`` -- and, the order being fixed, so would every
-    later bucket: the whole exchange serialised behind backward.  ``static_unused`` (default on; the assumption of DDP
-    without ``find_unused_parameters``, R/model.py:15): the set of parameters that received no gradient on ANY rank in the
-    first step (one small MAX all-reduce of the "fired" flags, issued by every rank at the end of its first step) is taken
-    as final; ``arm()`` counts those parameters as done, so their buckets close with the last gradient that does arrive.
-    If such a parameter later produces a gradient after its bucket was exchanged, ``finish()`` raises (the gradient would
-    be missing from the sum); ``reset_unused()`` re-learns the set, ``static_unused = False`` turns the prediction off."""
+    later bucket: the whole exchange serialised behind backward.  ``static_unused`` (default on) PREDICTS the set: the
+    parameters that received no gradient on ANY rank in the first step (one small MAX all-reduce of the "fired" flags, issued
+    by every rank at the end of its first step) are counted as done by ``arm()``, so their buckets close with the last
+    gradient that does arrive.  The prediction is verified every step and a wrong one is repaired, on every rank together:
+    a gradient that does arrive for such a parameter (on any rank, before or after its bucket went out) is kept out of the
+    bucket; ``finish()`` MAX-reduces the per-parameter "fired" flags of the predicted set over the ranks (host data, a
+    gloo side group: no device synchronisation), and the flagged parameters' gradients are summed over the ranks by one
+    extra all-reduce each and leave the predicted set (``relearned`` lists them).  The result is the same sum DDP's
+    ``find_unused_parameters=True`` produces, whatever the arrival order.  ``reset_unused()`` re-learns the set from
+    scratch, ``static_unused = False`` turns the prediction off (every bucket with a gradient-less parameter then waits
+    for ``finish()``)."""
 
     static_unused = True
 
@@ -165,7 +172,8 @@ class GradReducer:
         self._armed = False
         self._fired: List[bool] = []           # per parameter: its gradient hook ran this step
         self._unused = None                    # None: not learnt yet; else the set of parameters without a gradient on any rank
-        self._late: List[int] = []
+        self._side = None                      # gloo group for the per-step check of the prediction (host flags)
+        self.relearned: List[int] = []         # parameters that left the predicted set in the last step
         self.launch_order: List[int] = []
         self.collectives: List[str] = []       # what was issued per bucket in the last step ("allreduce" / "reduce_scatter+all_gather")
         for i, p in enumerate(flat.params):
@@ -177,9 +185,7 @@ class GradReducer:
                 return
             b = self.flat.bucket_of[i]
             self._fired[i] = True
-            if self._unused is not None and i in self._unused:      # predicted to stay without a gradient, and got one
-                if self._launched[b]:
-                    self._late.append(i)
+            if self._unused and i in self._unused:      # predicted to stay without a gradient, and got one: finish() repairs
                 return
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -198,7 +204,10 @@ class GradReducer:
         self._launched[b] = True
         r = self.flat.buckets[b]
         self.launch_order.append(b)
-        self.flat.gather(self.flat.bucket_members[b])
+        members = self.flat.bucket_members[b]
+        if self._unused:       # a surprise gradient stays out of the bucket on every rank (finish() exchanges it on its own)
+            members = [i for i in members if i not in self._unused]
+        self.flat.gather(members)
         if not self.exchange:
             return
         buf = self.flat.flat_g[r.start:r.stop]
@@ -223,7 +232,7 @@ class GradReducer:
         self._next = 0
         self._work, self.launch_order, self.collectives = [], [], []
         self._fired = [False] * len(self.flat.params)
-        self._late = []
+        self.relearned = []
         if self._unused:
             for i in self._unused:
                 b = self.flat.bucket_of[i]
@@ -242,6 +251,36 @@ class GradReducer:
         if self.world > 1:
             dist.all_reduce(fired, op=dist.ReduceOp.MAX, group=self.group)
         self._unused = {i for i, f in enumerate(fired.tolist()) if f == 0.0}
+        if self._unused and self.world > 1 and self._side is None:
+            # every rank holds the same set, so every rank comes here together.  The per-step check reduces HOST flags: over
+            # the group itself when it is a gloo group, else over a gloo twin of it
+            if dist.get_backend(self.group) == "gloo":
+                self._side = self.group if self.group is not None else dist.group.WORLD
+            else:
+                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
+                try:
+                    self._side = dist.new_group(ranks=ranks, backend="gloo", use_local_synchronization=True)
+                except TypeError:       # older torch: every process of the default group must make the call
+                    self._side = dist.new_group(ranks=ranks, backend="gloo")
+
+    def _verify_unused(self) -> None:
+        """The prediction against this step's facts, on every rank together; parameters it got wrong are exchanged now."""
+        order = sorted(self._unused)
+        flags = torch.tensor([1 if self._fired[i] else 0 for i in order], dtype=torch.int32)
+        if self.world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._side)
+        late = [i for i, f in zip(order, flags.tolist()) if f]
+        if not late:
+            return
+        for i in late:
+            p, slot = self.flat.params[i], self.flat.grad_view(i)
+            if p.grad is not None and p.grad.data_ptr() != slot.data_ptr():
+                slot.copy_(p.grad)                       # else: no gradient on this rank, the slot is still zero
+            p.grad = slot
+            if self.exchange:
+                dist.all_reduce(slot, op=dist.ReduceOp.SUM, group=self.group)
+            self._unused.discard(i)
+        self.relearned = late
 
     def finish(self) -> None:
         for b in range(len(self.flat.buckets)):     # the rest, in bucket order
@@ -250,12 +289,8 @@ class GradReducer:
         for w in self._work:
             w.wait()
         self._work, self._armed = [], False
-        if self._late:
-            late, self._late = self._late, []
-            raise RuntimeError(
-                f"GradReducer: {len(late)} parameter(s) that received no gradient in the first step (flat indices {late[:8]}...) "
-                "produced one now, after their bucket had been exchanged -- the sum over ranks misses it.  Call "
-                "reducer.reset_unused() on every rank when the training graph changes, or set GradReducer.static_unused = False")
+        if self._unused:
+            self._verify_unused()
         if self.static_unused and self._unused is None:
             self._learn_unused()
 

@@ -87,8 +87,12 @@ def main():
     key = os.environ.get("DMA_KEY") or ("DIFFSAL_GEMM_DMA" if dt == torch.float32 else "DIFFSAL_GEMM_DMA16")
     g = torch.Generator(device=dev).manual_seed(5)
     print(f"{'shape':10s} {'M':>6s} {'K':>5s} {'N':>5s} | {'DMA off us (TF/s)':>20s} | " + " | ".join(f"dma cfg {c} us (TF/s) err" for c in cfgs))
+    mscale = int(os.environ.get("DMA_MSCALE", "1"))      # 16: the shapes of a 64-clip pass (BASELINE configs[4])
     for name, M, K, N, has_b, act, has_r in SHAPES:
         if flt and flt not in name:
+            continue
+        M *= mscale
+        if M * max(K, N) * 8 > 6e9:
             continue
         x = torch.randn(M, K, device=dev, generator=g).to(dt)
         w = (torch.randn(N, K, device=dev, generator=g) * (K ** -0.5)).to(dt)
@@ -129,7 +133,7 @@ def main():
         for v in variants:
             t = sorted(times[v])[len(times[v]) // 2]
             cells.append(f"{t:7.1f} ({fl / t / 1e6:5.1f}) {errs[v]:.1e}")
-        print(f"{name:10s} {M:6d} {K:5d} {N:5d} | " + " | ".join(cells), flush=True)
+        print(f"{name:10s} {M:7d} {K:5d} {N:5d} | " + " | ".join(cells), flush=True)
 
 
 if __name__ == "__main__":
