@@ -42,7 +42,7 @@ enum TuneKey {
   TUNE_NO_PERSIST = 0, TUNE_NO_XCD_ORDER, TUNE_NO_HALO, TUNE_FORCE_HALO, TUNE_IGEMM_CFG, TUNE_IGEMM16_CFG, TUNE_PLAN_DEBUG,
   TUNE_WGRAD_CFG, TUNE_WGRAD_SPLITS, TUNE_WGRAD_VERBOSE, TUNE_NO_FUSED_BLOCK, TUNE_NO_WINOGRAD, TUNE_FORCE_WINOGRAD, TUNE_GN_CHUNKS,
   TUNE_GN_APPLY_WGS, TUNE_GEMM_DMA, TUNE_CONV_DMA, TUNE_GROUP_GRID, TUNE_GEMM_DMA16, TUNE_WGRAD_DMA, TUNE_NO_GN_SLAB, TUNE_NO_WINOGRAD4, TUNE_BATCH_TILE, TUNE_BATCH_XCD, TUNE_NO_TAPSUM_ROWS, TUNE_TAPSUM_ROWS_FORM,
-  TUNE_NO_ATTN_BWD_DS, TUNE_NO_POOL_RUNS, TUNE_NO_ATTN_SLOTS, TUNE_COUNT
+  TUNE_NO_ATTN_BWD_DS, TUNE_NO_POOL_RUNS, TUNE_NO_ATTN_SLOTS, TUNE_NO_STREAM16, TUNE_COUNT
 };
 int tune(int key);
 
@@ -191,6 +191,39 @@ __device__ __forceinline__ void st4(f16_t* p, float4 v) {
   const f32x4_t f = {v.x, v.y, v.z, v.w};
   *reinterpret_cast<f16x4_t*>(p) = __builtin_convertvector(f, f16x4_t);
 }
+// 8 elements = one 16-byte access of 16-bit storage: what the HBM-bound kernels on 16-bit storage move per lane (the 4-element
+// accessors above are 8-byte accesses: half the bytes in flight per instruction, and a 32-channel slab is only half a 128-byte line)
+struct f8v { float v[8]; };
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f8v ld8(const bf16_t* p) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  f8v r;
+  r.v[0] = __builtin_bit_cast(float, u.x << 16); r.v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+  r.v[2] = __builtin_bit_cast(float, u.y << 16); r.v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+  r.v[4] = __builtin_bit_cast(float, u.z << 16); r.v[5] = __builtin_bit_cast(float, u.z & 0xFFFF0000u);
+  r.v[6] = __builtin_bit_cast(float, u.w << 16); r.v[7] = __builtin_bit_cast(float, u.w & 0xFFFF0000u);
+  return r;
+}
+__device__ __forceinline__ f8v ld8(const f16_t* p) {
+  const f16x8_t h = *reinterpret_cast<const f16x8_t*>(p);
+  const f32x8_t f = __builtin_convertvector(h, f32x8_t);
+  f8v r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r.v[e] = f[e];
+  return r;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const f8v& x) {
+  const f32x8_t f = {x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7]};
+  *reinterpret_cast<bf16x8_t*>(p) = __builtin_convertvector(f, bf16x8_t);
+}
+__device__ __forceinline__ void st8(f16_t* p, const f8v& x) {
+  const f32x8_t f = {x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7]};
+  *reinterpret_cast<f16x8_t*>(p) = __builtin_convertvector(f, f16x8_t);
+}
+__device__ __forceinline__ float to_f32(bf16_t x) { return static_cast<float>(x); }
+__device__ __forceinline__ float to_f32(f16_t x) { return static_cast<float>(x); }
 // 4-element accesses of T need 4 * sizeof(T) alignment
 template <typename T> inline bool aligned_vec4(const T* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
 

@@ -28,7 +28,7 @@ static const char* const kTuneNames[TUNE_COUNT] = {
     "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
     "DIFFSAL_NO_FUSED_BLOCK", "DIFFSAL_NO_WINOGRAD", "DIFFSAL_FORCE_WINOGRAD", "DIFFSAL_GN_CHUNKS", "DIFFSAL_GN_APPLY_WGS",
     "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD", "DIFFSAL_NO_TAPSUM_ROWS", "DIFFSAL_TAPSUM_ROWS_FORM",
-    "DIFFSAL_NO_ATTN_BWD_DS", "DIFFSAL_NO_POOL_RUNS", "DIFFSAL_NO_ATTN_SLOTS"};
+    "DIFFSAL_NO_ATTN_BWD_DS", "DIFFSAL_NO_POOL_RUNS", "DIFFSAL_NO_ATTN_SLOTS", "DIFFSAL_NO_STREAM16"};
 static int g_tune[TUNE_COUNT];
 static const bool g_tune_init = [] {
   for (int k = 0; k < TUNE_COUNT; ++k) {
@@ -486,6 +486,158 @@ __global__ __launch_bounds__(256) void audio_fuse_kernel(const TT* __restrict__ 
     const int cg = cs * 32 + cc;
     const float av = static_cast<float>(a_small[((static_cast<long>(b) * T + t) * h * w + ys * w + xx / up) * a_ld + cg]);
     out[(((static_cast<long>(b) * C + cg) * T + t) * H + y) * W + xx] = static_cast<TT>(av * sh[cc * WP + xx]);
+  }
+}
+
+// K7 on 16-bit storage.  The form above moves 8 bytes per lane and a 32-channel slab is 64 bytes of a pixel -- half a 128-byte
+// line per request, the other half fetched again by the neighbouring slab's workgroup (1.4-1.7 TB/s at 64 clips).  Here:
+//  * a workgroup owns (clip, R rows, CS channels), CS * 2 bytes a multiple of 128 (CS = 64) or the whole pixel (C = 96), and every
+//    global access is 16 bytes per lane (8 channels of x / a_small, 8 consecutive x of the [B,C,T,H,W] result);
+//  * pass 3 (out = a * s, written W-contiguous) needs a_small channel-major: frame t's slab [rows of the audio map][w][CS] is staged
+//    in LDS (two buffers, one barrier per frame, the next frame's piece in registers meanwhile) instead of 2-byte strided loads;
+//  * R rows per workgroup so that a (c, t) run of the result is R * W * 2 >= 192 bytes where the map is narrow.
+// Arithmetic and summation order are those of audio_fuse_kernel: results are bit-identical.
+// n / d for 0 <= n, n d < 2^20, with magic = 2^20 / d + 1 (host): one multiply and one shift instead of a ~25-instruction division
+__device__ __forceinline__ int div_magic(int n, unsigned magic) { return static_cast<int>((static_cast<unsigned>(n) * magic) >> 20); }
+inline unsigned make_magic(int d) { return (1u << 20) / static_cast<unsigned>(d) + 1u; }
+
+struct AudioFuse16Args {
+  int T, H, W, C, h, w, a_ld, R, RS;
+  unsigned mW, mR, mXG;           // div_magic constants of W, R, W / XV
+};
+
+// CS: channels per workgroup, XV: consecutive x per store, UPS: log2 of the up-sampling factor of the audio map
+template <typename TT, int CS, int XV, int UPS>
+__global__ __launch_bounds__(256) void audio_fuse16_kernel(const TT* __restrict__ a_small, const TT* __restrict__ x,
+                                                           TT* __restrict__ out, AudioFuse16Args g) {
+  extern __shared__ float sh[];          // s[CS][R W + 1] | a_t[2][RS w][CS + 2] (16-bit)
+  constexpr int OCT = CS / 8, AP = CS + 2;          // AP: pixel pitch of the staged audio slab, an odd number of dwords
+  constexpr int KMAX = 6;                           // pass-3 items per thread (host-checked)
+  const int T = g.T, H = g.H, W = g.W, C = g.C, h = g.h, w = g.w, a_ld = g.a_ld, R = g.R, RS = g.RS;
+  const int RW = R * W, RP = RW + 1;
+  TT* a_sh = reinterpret_cast<TT*>(sh + CS * RP);
+  const int cslabs = C / CS, rblocks = H / R;
+  int bid = blockIdx.x;
+  const int cs = bid % cslabs; bid /= cslabs;
+  const int yb = bid % rblocks;
+  const int b = bid / rblocks;
+  const int y0 = yb * R, c0 = cs * CS;
+  const int ys0 = y0 >> UPS;
+  // ---- pass 1: m[c][r, x] = mean_t a * x; an item = (pixel of the R x W block, channel octet), octets fastest across lanes
+  for (int i = threadIdx.x; i < RW * OCT; i += 256) {
+    const int p = i / OCT, o = i - p * OCT;
+    const int r = div_magic(p, g.mW), xx = p - r * W;
+    const int ys = (y0 + r) >> UPS, xs = xx >> UPS;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const TT* ap = a_small + (static_cast<long>(b) * T * h * w + ys * w + xs) * a_ld + c0 + o * 8;
+    const TT* xp = x + ((static_cast<long>(b) * T * H + (y0 + r)) * W + xx) * C + c0 + o * 8;
+    const long a_fs = static_cast<long>(h) * w * a_ld, x_fs = static_cast<long>(H) * W * C;
+#pragma unroll 3
+    for (int t = 0; t < T; ++t) {
+      const f8v av = ld8(ap + t * a_fs);
+      const f8v xv = ld8(xp + t * x_fs);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = fmaf(av.v[e], xv.v[e], s[e]);
+    }
+    const float ft = static_cast<float>(T);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[(o * 8 + e) * RP + p] = s[e] / ft;
+  }
+  __syncthreads();
+  // ---- pass 2: softmax over x for each (channel, row): 8 lanes per softmax row
+  for (int row = threadIdx.x >> 3; row < CS * R; row += 32) {
+    const int c = div_magic(row, g.mR), r = row - c * R, l8 = threadIdx.x & 7;
+    float* sr = sh + c * RP + r * W;
+    float mx = -3.0e38f;
+    for (int xx = l8; xx < W; xx += 8) mx = fmaxf(mx, sr[xx]);
+    mx = group_max<8>(mx);
+    float sum = 0.f;
+    for (int xx = l8; xx < W; xx += 8) {
+      const float e = expf(sr[xx] - mx);
+      sr[xx] = e;
+      sum += e;
+    }
+    sum = group_sum<8>(sum);
+    const float inv = 1.0f / sum;
+    for (int xx = l8; xx < W; xx += 8) sr[xx] *= inv;
+  }
+  // ---- pass 3: out[b, c, t, y0 + r, x] = a * s, one frame at a time.  A thread keeps its items (channel, row, XV consecutive x)
+  // for every frame: their softmax weights stay in registers, per frame an item costs its audio reads, XV products and one store
+  const int apix = RS * w;                     // audio pixels under the block (rows ys0 .. ys0 + RS - 1, clamped)
+  const int n_chunk = apix * OCT;              // 16-byte pieces of a frame's slab
+  uint4 stage[3];                              // at most 768 pieces per frame (host-checked)
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < n_chunk) {
+        const int px = i / OCT, o = i - px * OCT;
+        const int ry = px / w, rx = px - ry * w;
+        const int ys = min(ys0 + ry, h - 1);
+        stage[k] = *reinterpret_cast<const uint4*>(a_small + ((static_cast<long>(b) * T + t) * h * w + ys * w + rx) * a_ld + c0 + o * 8);
+      }
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < n_chunk) {
+        const int px = i / OCT, o = i - px * OCT;
+        unsigned* d = reinterpret_cast<unsigned*>(a_sh + (buf * apix + px) * AP + o * 8);
+        d[0] = stage[k].x; d[1] = stage[k].y; d[2] = stage[k].z; d[3] = stage[k].w;
+      }
+    }
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();                             // also orders pass 2's writes before the reads below
+  const int xg = W / XV, items = CS * R * xg;
+  float sw[KMAX][XV];
+  int a_of[KMAX];
+  long o_of[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int i = threadIdx.x + k * 256;
+    a_of[k] = -1;
+    o_of[k] = 0;
+    if (i < items) {
+      const int cr = div_magic(i, g.mXG), gq = i - cr * xg;
+      const int c = div_magic(cr, g.mR), r = cr - c * R;
+      const int xx = gq * XV;
+#pragma unroll
+      for (int e = 0; e < XV; ++e) sw[k][e] = sh[c * RP + r * W + xx + e];
+      a_of[k] = ((((y0 + r) >> UPS) - ys0) * w + (xx >> UPS)) * AP + c;
+      o_of[k] = ((static_cast<long>(b) * C + c0 + c) * T * H + y0 + r) * W + xx;
+    }
+  }
+  const long o_fs = static_cast<long>(H) * W;
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) fetch(t + 1);
+    const TT* at = a_sh + (t & 1) * apix * AP;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (a_of[k] < 0) continue;
+      const TT* ar = at + a_of[k];
+      TT* op = out + o_of[k] + t * o_fs;
+      if constexpr (XV == 8) {
+        f8v v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = to_f32(ar[(e >> UPS) * AP]) * sw[k][e];
+        st8(op, v);
+      } else {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = to_f32(ar[(e >> UPS) * AP]) * sw[k][e];
+        st4(op, make_float4(v[0], v[1], v[2], v[3]));
+      }
+    }
+    if (t + 1 < T) {
+      park((t + 1) & 1);
+      __syncthreads();
+    }
   }
 }
 
@@ -1080,6 +1232,41 @@ extern "C" int diffsal_audio_fuse(const void* a_small, int a_ld, const void* x, 
                "audio_fuse: audio map %dx%d does not upsample to %dx%d by an integer factor", h, w, H, W);
   } else {
     DS_REQUIRE(h == H && w == W, DIFFSAL_E_SHAPE, "audio_fuse: audio map %dx%d incompatible with %dx%d", h, w, H, W);
+  }
+  const int ups = up == 1 ? 0 : up == 2 ? 1 : up == 4 ? 2 : up == 8 ? 3 : -1;
+  if (dtype != DIFFSAL_F32 && tune(TUNE_NO_STREAM16) != 1 && (C % 64 == 0 || C == 96) && W % 4 == 0 && aligned16(out) && a_ld % 8 == 0 && ups >= 0) {
+    // 16-bit storage: 16-byte accesses, whole 128-byte lines per slab, R rows per workgroup (audio_fuse16_kernel)
+    const int CS = C % 64 == 0 ? 64 : 96;
+    const int XV = W % 8 == 0 ? 8 : 4;
+    int R = H;
+    for (int r = 1; r <= H; ++r)
+      if (H % r == 0 && r * W >= 96) { R = r; break; }
+    const int RS = R % up == 0 ? R / up : (up % R == 0 ? 1 : (R - 1) / up + 2);     // audio rows under a block of R rows
+    const size_t lds16 = static_cast<size_t>(CS) * (R * W + 1) * sizeof(float) + static_cast<size_t>(2) * RS * w * (CS + 2) * 2;
+    const long items = static_cast<long>(CS) * R * (W / XV);
+    if (lds16 <= 64 * 1024 && RS * w * (CS / 8) <= 768 && items <= 6 * 256 && static_cast<long>(R) * W * W < (1 << 20) && items * (W / XV) < (1 << 20)) {
+      const int grid = B * (H / R) * (C / CS);
+      hipStream_t s = static_cast<hipStream_t>(stream);
+      AudioFuse16Args g{T, H, W, C, h, w, a_ld, R, RS, make_magic(W), make_magic(R), make_magic(W / XV)};
+#define CALL16(TT, CSV, XVV, UPSV)                                                                                      \
+  hipLaunchKernelGGL((audio_fuse16_kernel<TT, CSV, XVV, UPSV>), dim3(grid), dim3(256), lds16, s, static_cast<const TT*>(a_small), \
+                     static_cast<const TT*>(x), static_cast<TT*>(out), g)
+#define CALL16_U(TT, CSV, XVV)                                                                             \
+  do {                                                                                                     \
+    if (ups == 0) CALL16(TT, CSV, XVV, 0); else if (ups == 1) CALL16(TT, CSV, XVV, 1);                     \
+    else if (ups == 2) CALL16(TT, CSV, XVV, 2); else CALL16(TT, CSV, XVV, 3);                              \
+  } while (0)
+#define CALL16_T(TT)                                                                                       \
+  do {                                                                                                     \
+    if (CS == 64) { if (XV == 8) CALL16_U(TT, 64, 8); else CALL16_U(TT, 64, 4); }                          \
+    else { if (XV == 8) CALL16_U(TT, 96, 8); else CALL16_U(TT, 96, 4); }                                   \
+  } while (0)
+      if (dtype == DIFFSAL_BF16) CALL16_T(bf16_t); else CALL16_T(f16_t);
+#undef CALL16_T
+#undef CALL16_U
+#undef CALL16
+      return check_launch("audio_fuse(16-bit)");
+    }
   }
   const size_t lds = static_cast<size_t>(32) * (W + 1) * sizeof(float);
 #define CALL(TT)                                                                                                     \

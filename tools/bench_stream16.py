@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Old (8-byte) against new (16-byte) forms of the HBM-bound kernels on 16-bit storage at the shapes of a 64-clip pass.
+usage: tools/bench_stream16.py [filter] [--batch 64] [--dtype fp16]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_sal_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+STAGES = [(7, 12, 768), (14, 24, 384), (28, 48, 192), (56, 96, 96)]
+
+
+def timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def ab(name, fn, nbytes):
+    cells = []
+    for old in (1, None):
+        _lib.set_tuning("DIFFSAL_NO_STREAM16", old)
+        t = timeit(fn)
+        cells.append(f"{t:8.1f} us {nbytes / t / 1e6:6.2f} TB/s")
+    _lib.set_tuning("DIFFSAL_NO_STREAM16", None)
+    print(f"{name:34s} | old {cells[0]} | new {cells[1]}", flush=True)
+
+
+def main():
+    args = sys.argv[1:]
+    B, dt, flt = 64, torch.float16, ""
+    i = 0
+    while i < len(args):
+        if args[i] == "--batch":
+            B = int(args[i + 1]); i += 2
+        elif args[i] == "--dtype":
+            dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[args[i + 1]]; i += 2
+        else:
+            flt = args[i]; i += 1
+    T = 9
+    g = torch.Generator(device=DEV).manual_seed(3)
+    es = 2
+    for si, (H, W, C) in enumerate(STAGES):
+        x = torch.randn(B, T, H, W, C, device=DEV, generator=g).to(dt)
+        if not flt or "fuse" in flt:
+            a_all = torch.randn(B * T, 84, 1440, device=DEV, generator=g).to(dt)
+            off = [0, 768, 1152, 1344][si]
+            a_small = a_all[:, :, off:off + C]
+            ab(f"K7 audio_fuse s{si} {H}x{W}x{C}", lambda: ops.audio_fuse(a_small, x, 7, 12), 2 * x.numel() * es + a_small.numel() * es)
+        for name, fn, nb in EXTRA:
+            if not flt or name.split()[0].lower() in flt:
+                fn(si, B, T, H, W, C, x, dt, g)
+        del x
+
+
+EXTRA = []
+
+if __name__ == "__main__":
+    main()
