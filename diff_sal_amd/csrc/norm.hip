@@ -607,6 +607,257 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(QkvPrepArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K9 on 16-bit storage, 16-byte form (qkv_prep16_kernel).  The kernels above give a lane four channels: 8-byte accesses on
+// 16-bit storage, one LayerNorm lane group per 4 G channels, the nine fp32 weight vectors of the depthwise filter re-read
+// from L1 for every token (1.3-2.2 TB/s at 64 clips).  Here a token of C = 24 G channels is held by G lanes as THREE octets
+// per lane (channel of octet i, element e: (gl + i G) 8 + e): every access of the token tensors is 16 bytes, a 64-lane
+// wavefront holds 64 / G tokens, the per-channel constants (depthwise filter, LayerNorm affine) sit in LDS in lane order
+// (conflict-free 16-byte reads), and the pooled branch adds its 64 / G position lanes up inside the wavefront (DPP row shifts +
+// permlane swaps that keep the lane-in-group) before a [2][4][C] hand-off through LDS.  Same formulas as the forms above
+// (two-pass LayerNorm, fmaf accumulation in tap / position order); the order of the additions inside a LayerNorm sum and of
+// the pooled positions differs, so results agree to fp32 rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) {      // lane l <- lane l - N inside its row of 16, 0 where there is none
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xF, 0xF, true));
+}
+// sum over the 64 / G lane groups of a wavefront of the values with the same lane-in-group; valid in the LAST G lanes
+template <int G>
+__device__ __forceinline__ float sum_over_groups(float v) {
+  if constexpr (G <= 4) v += dpp_row_shr<4>(v);
+  if constexpr (G <= 8) v += dpp_row_shr<8>(v);
+  if constexpr (G <= 16) v += lane_xor16(v);
+  v += lane_xor32(v);
+  return v;
+}
+
+// per-channel fp32 vector -> LDS in lane order: dst[((i * 2 + hf) * G + gl) * 4 + e] = src[(gl + i G) 8 + hf 4 + e]
+template <int G>
+__device__ __forceinline__ void lane_order_fill(float* __restrict__ dst, const float* __restrict__ src, int C) {
+  for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
+    const int oct = c4 >> 1, hf = c4 & 1, i = oct / G, gl = oct - i * G;
+    st4(dst + ((i * 2 + hf) * G + gl) * 4, ld4(src + c4 * 4));
+  }
+}
+struct LaneVec { float v[24]; };
+template <int G>
+__device__ __forceinline__ LaneVec lane_order_read(const float* __restrict__ src, int gl) {
+  LaneVec r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const float4 t = ld4(src + ((i * 2 + hf) * G + gl) * 4);
+      r.v[i * 8 + hf * 4 + 0] = t.x; r.v[i * 8 + hf * 4 + 1] = t.y; r.v[i * 8 + hf * 4 + 2] = t.z; r.v[i * 8 + hf * 4 + 3] = t.w;
+    }
+  return r;
+}
+
+// two-pass LayerNorm of a token held as 24 values per lane by G lanes
+template <int G>
+__device__ __forceinline__ void ln24_stats(const float (&v)[24], int C, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 24; ++j) s += v[j];
+  s = group_sum<G>(s);
+  mean = s / static_cast<float>(C);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 24; ++j) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+  q = group_sum<G>(q);
+  rstd = 1.0f / sqrtf(q / static_cast<float>(C) + eps);
+}
+
+template <typename T, int G>
+__device__ __forceinline__ void load24(const T* __restrict__ p, int gl, float (&v)[24]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const f8v t = ld8(p + (gl + i * G) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i * 8 + e] = t.v[e];
+  }
+}
+template <typename T, int G>
+__device__ __forceinline__ void store24(T* __restrict__ p, int gl, const float (&v)[24]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f8v t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.v[e] = v[i * 8 + e];
+    st8(p + (gl + i * G) * 8, t);
+  }
+}
+
+template <typename T, int G, bool PRELN>
+__global__ __launch_bounds__(256, 3) void qkv_prep16_kernel(QkvPrepArgs a) {
+  extern __shared__ float sh16[];
+  constexpr int TPB = 256 / G;                  // tokens (query branch) / window positions (pooled branch) per pass
+  const int C = a.C, gl = threadIdx.x % G, gr = threadIdx.x / G;
+  if (static_cast<int>(blockIdx.x) < a.nq) {
+    // ---- query branch: depthwise 3x3 (pad 1) + LayerNorm on every token (attention.py:36-47,94)
+    float* wl = sh16;                            // [9][C] filter, then gamma, beta, each in lane order
+    for (int t = 0; t < 9; ++t) lane_order_fill<G>(wl + t * C, a.w9 + t * C, C);
+    lane_order_fill<G>(wl + 9 * C, a.gq, C);
+    lane_order_fill<G>(wl + 10 * C, a.bq, C);
+    __syncthreads();
+    const T* __restrict__ x = static_cast<const T*>(a.xq);
+    T* __restrict__ out = static_cast<T*>(a.oq);
+    const int H = a.H, W = a.W;
+    const int M = a.N * H * W;
+    for (int row = blockIdx.x * TPB + gr; row < M; row += a.nq * TPB) {
+      const int xw = row % W, yh = (row / W) % H;
+      float acc[24];
+#pragma unroll
+      for (int j = 0; j < 24; ++j) acc[j] = 0.f;
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky)         // (one kernel row per trip: unrolled over all nine taps hipcc hoists 27 + 54 loads and spills)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tap = ky * 3 + kx;
+        const int iy = yh + ky - 1, ix = xw + kx - 1;
+        // a padding tap reads the centre pixel and enters with weight 0 (no branch: lane groups of one wavefront differ here, and
+        // the divergent form measured 30 % slower)
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const T* xr = x + static_cast<long>(ok ? row + (ky - 1) * W + (kx - 1) : row) * C;
+        const float m = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const f8v t = ld8(xr + (gl + i * G) * 8);
+          float4 w0 = ld4(wl + tap * C + ((i * 2 + 0) * G + gl) * 4), w1 = ld4(wl + tap * C + ((i * 2 + 1) * G + gl) * 4);
+          w0.x *= m; w0.y *= m; w0.z *= m; w0.w *= m; w1.x *= m; w1.y *= m; w1.z *= m; w1.w *= m;
+          acc[i * 8 + 0] = fmaf(t.v[0], w0.x, acc[i * 8 + 0]); acc[i * 8 + 1] = fmaf(t.v[1], w0.y, acc[i * 8 + 1]);
+          acc[i * 8 + 2] = fmaf(t.v[2], w0.z, acc[i * 8 + 2]); acc[i * 8 + 3] = fmaf(t.v[3], w0.w, acc[i * 8 + 3]);
+          acc[i * 8 + 4] = fmaf(t.v[4], w1.x, acc[i * 8 + 4]); acc[i * 8 + 5] = fmaf(t.v[5], w1.y, acc[i * 8 + 5]);
+          acc[i * 8 + 6] = fmaf(t.v[6], w1.z, acc[i * 8 + 6]); acc[i * 8 + 7] = fmaf(t.v[7], w1.w, acc[i * 8 + 7]);
+        }
+      }
+      float mean, rstd;
+      ln24_stats<G>(acc, C, a.eps, mean, rstd);
+      const LaneVec g = lane_order_read<G>(wl + 9 * C, gl), b = lane_order_read<G>(wl + 10 * C, gl);
+#pragma unroll
+      for (int j = 0; j < 24; ++j) acc[j] = (acc[j] - mean) * rstd * g.v[j] + b.v[j];
+      store24<T, G>(out + static_cast<long>(row) * C, gl, acc);
+    }
+    return;
+  }
+  // ---- pooled key / value branch: depthwise k x k stride k + LayerNorm, one workgroup per pooled token (attention.py:49-76,88-95)
+  float* pre = sh16;                             // [2][C] the block's LayerNorm affine (PRELN), lane order
+  float* part = sh16 + 2 * C;                    // [2][4][C] per-wavefront sums
+  if constexpr (PRELN) {
+    lane_order_fill<G>(pre, a.pg, C);
+    lane_order_fill<G>(pre + C, a.pb, C);
+    __syncthreads();
+  }
+  const T* __restrict__ xk = static_cast<const T*>(a.xk);
+  const T* __restrict__ xv = static_cast<const T*>(a.xv);
+  const int tok = blockIdx.x - a.nq;
+  const int k = a.k, gh = a.gh, gw = a.gw, H = a.H, W = a.W;
+  const int n = tok / (gh * gw), cell = tok - n * gh * gw;
+  const int gy = cell / gw, gx = cell - gy * gw;
+  const bool same = (xk == xv) && (!PRELN || a.ln_k != 0);
+  float ak[24], av[24];
+#pragma unroll
+  for (int j = 0; j < 24; ++j) { ak[j] = 0.f; av[j] = 0.f; }
+  const long img = static_cast<long>(n) * H * W;
+#pragma unroll 1
+  for (int pos = gr; pos < k * k; pos += TPB) {
+    const int dy = pos / k, dx = pos - dy * k;
+    const long off = (img + static_cast<long>(gy * k + dy) * W + (gx * k + dx)) * C;
+    float tk[24], tv[24];
+    load24<T, G>(xk + off, gl, tk);
+    if (!same) load24<T, G>(xv + off, gl, tv);
+    if constexpr (PRELN) {
+      // the block's first LayerNorm on the loaded token, rounded through the storage type as the stand-alone launch stores it
+      float mean, rstd;
+      if (a.ln_k) {
+        ln24_stats<G>(tk, C, a.peps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float4 g4 = ld4(pre + ((i * 2 + hf) * G + gl) * 4), b4 = ld4(pre + C + ((i * 2 + hf) * G + gl) * 4);
+            const int j = i * 8 + hf * 4;
+            tk[j] = static_cast<float>(static_cast<T>((tk[j] - mean) * rstd * g4.x + b4.x));
+            tk[j + 1] = static_cast<float>(static_cast<T>((tk[j + 1] - mean) * rstd * g4.y + b4.y));
+            tk[j + 2] = static_cast<float>(static_cast<T>((tk[j + 2] - mean) * rstd * g4.z + b4.z));
+            tk[j + 3] = static_cast<float>(static_cast<T>((tk[j + 3] - mean) * rstd * g4.w + b4.w));
+          }
+      }
+      if (!same) {
+        ln24_stats<G>(tv, C, a.peps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float4 g4 = ld4(pre + ((i * 2 + hf) * G + gl) * 4), b4 = ld4(pre + C + ((i * 2 + hf) * G + gl) * 4);
+            const int j = i * 8 + hf * 4;
+            tv[j] = static_cast<float>(static_cast<T>((tv[j] - mean) * rstd * g4.x + b4.x));
+            tv[j + 1] = static_cast<float>(static_cast<T>((tv[j + 1] - mean) * rstd * g4.y + b4.y));
+            tv[j + 2] = static_cast<float>(static_cast<T>((tv[j + 2] - mean) * rstd * g4.z + b4.z));
+            tv[j + 3] = static_cast<float>(static_cast<T>((tv[j + 3] - mean) * rstd * g4.w + b4.w));
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int c = (gl + i * G) * 8 + hf * 4, j = i * 8 + hf * 4;
+        const float4 p1 = ld4(a.wk + static_cast<long>(pos) * C + c), p2 = ld4(a.wv + static_cast<long>(pos) * C + c);
+        ak[j] = fmaf(tk[j], p1.x, ak[j]); ak[j + 1] = fmaf(tk[j + 1], p1.y, ak[j + 1]);
+        ak[j + 2] = fmaf(tk[j + 2], p1.z, ak[j + 2]); ak[j + 3] = fmaf(tk[j + 3], p1.w, ak[j + 3]);
+        av[j] = fmaf(same ? tk[j] : tv[j], p2.x, av[j]); av[j + 1] = fmaf(same ? tk[j + 1] : tv[j + 1], p2.y, av[j + 1]);
+        av[j + 2] = fmaf(same ? tk[j + 2] : tv[j + 2], p2.z, av[j + 2]); av[j + 3] = fmaf(same ? tk[j + 3] : tv[j + 3], p2.w, av[j + 3]);
+      }
+  }
+  // position lanes of a wavefront, then the four wavefronts (fixed order)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 24; ++j) { ak[j] = sum_over_groups<G>(ak[j]); av[j] = sum_over_groups<G>(av[j]); }
+  if (lane >= 64 - G) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int c = (gl + i * G) * 8 + hf * 4, j = i * 8 + hf * 4;
+        st4(part + (0 * 4 + wave) * C + c, make_float4(ak[j], ak[j + 1], ak[j + 2], ak[j + 3]));
+        st4(part + (1 * 4 + wave) * C + c, make_float4(av[j], av[j + 1], av[j + 2], av[j + 3]));
+      }
+  }
+  __syncthreads();
+  if (gr < 2) {                                  // lane group 0 finishes K, lane group 1 V
+    float v[24];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int c = (gl + i * G) * 8 + hf * 4, j = i * 8 + hf * 4;
+        float4 t = ld4(part + (gr * 4 + 0) * C + c);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float4 u = ld4(part + (gr * 4 + w) * C + c);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+      }
+    float mean, rstd;
+    ln24_stats<G>(v, C, a.eps, mean, rstd);
+    const float* gm = gr == 0 ? a.gk : a.gv;
+    const float* bt = gr == 0 ? a.bk : a.bv;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int c = (gl + i * G) * 8 + hf * 4, j = i * 8 + hf * 4;
+        const float4 g4 = ld4(gm + c), b4 = ld4(bt + c);
+        v[j] = (v[j] - mean) * rstd * g4.x + b4.x; v[j + 1] = (v[j + 1] - mean) * rstd * g4.y + b4.y;
+        v[j + 2] = (v[j + 2] - mean) * rstd * g4.z + b4.z; v[j + 3] = (v[j + 3] - mean) * rstd * g4.w + b4.w;
+      }
+    store24<T, G>((gr == 0 ? static_cast<T*>(a.ok) : static_cast<T*>(a.ov)) + static_cast<long>(tok) * C, gl, v);
+  }
+}
+
 // Dispatch on C: lane-group width G = min(64, pow2 >= C/4), NV = ceil(C/4/G).
 #define DS_ROW_DISPATCH(C, CALL)                                  \
   do {                                                            \
@@ -949,6 +1200,26 @@ extern "C" int diffsal_dwpool_ln_kv(const void* xk, const void* xv, const float*
 template <typename T>
 static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
   const int nkv = a.N * a.gh * a.gw;
+  if constexpr (sizeof(T) == 2) {
+    // 16-bit storage, the decoder's widths: the 16-byte form (qkv_prep16_kernel); its query branch has no folded LayerNorm (that
+    // combination -- SalUNet.fold_norm1 -- is measured slower and off: it keeps the form above)
+    const int G = a.C / 24;
+    const long rows = static_cast<long>(a.N) * a.H * a.W;
+    if (tune(TUNE_NO_STREAM16) != 1 && a.C % 24 == 0 && (G == 4 || G == 8 || G == 16 || G == 32) && !a.pwk && !(a.oq && a.pg) && rows < (1L << 31) &&
+        aligned16(a.pg ? a.pg : a.gk)) {
+      a.nq = a.oq ? row_grid(rows, 256 / G) : 0;
+      if (a.nq > 2048) a.nq = 2048;              // each workgroup stages the filter in LDS: a few passes per workgroup
+      const size_t lds = static_cast<size_t>(a.C) * sizeof(float) * (a.oq ? 11 : 10);
+#define CALL16(GV)                                                                                                       \
+  do {                                                                                                                   \
+    if (a.pg) hipLaunchKernelGGL((qkv_prep16_kernel<T, GV, true>), dim3(a.nq + nkv), dim3(256), lds, s, a);                 \
+    else hipLaunchKernelGGL((qkv_prep16_kernel<T, GV, false>), dim3(a.nq + nkv), dim3(256), lds, s, a);                     \
+  } while (0)
+      if (G == 4) CALL16(4); else if (G == 8) CALL16(8); else if (G == 16) CALL16(16); else CALL16(32);
+#undef CALL16
+      return check_launch("qkv_prep(16-bit)");
+    }
+  }
   const bool strip = a.C <= 256 && a.W >= 16;
   const size_t lds_of = 2 * a.C * sizeof(float);     // x (256 / G) position lanes
 #define CALL(G, NV)                                                                                                  \

@@ -100,6 +100,53 @@ __global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs<T> 
   }
 }
 
+// The interior kernel on 16-bit storage with 16-byte accesses: item = (source pixel, channel OCTET) -- nine 16-byte loads, four
+// 16-byte stores (the form above moves 8 bytes per lane there: 1.5-1.8 TB/s at 64 clips).  Same arithmetic per element.
+template <typename T>
+__global__ __launch_bounds__(256) void up2_conv_commute16_kernel(UpCommuteArgs<T> p) {
+  const int c8n = p.C >> 3;
+  const int H2 = 2 * p.h, W2 = 2 * p.w;
+  const int row_items = p.w * c8n;
+  const long crow = static_cast<long>(p.w + 2) * p.C;
+  for (long row = blockIdx.y; row < static_cast<long>(p.N) * p.h; row += gridDim.y) {
+    const int n = static_cast<int>(row / p.h), y = static_cast<int>(row - static_cast<long>(n) * p.h);
+    const T* cimg = p.c + static_cast<long>(n) * (p.h + 2) * crow;
+    T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < row_items; it += gridDim.x * 256) {
+      const int x = it / c8n, co = (it - x * c8n) * 8;
+      f8v cc[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) cc[a][b] = ld8(cimg + (y + a) * crow + static_cast<long>(x + b) * p.C + co);
+      float sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+      if (p.scale) {
+        const float4 s0 = ld4(p.scale + co), s1 = ld4(p.scale + co + 4), h0 = ld4(p.shift + co), h1 = ld4(p.shift + co + 4);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      }
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const int py = 2 * y + sy, px = 2 * x + sx;
+          if (py < 3 || py >= H2 - 3 || px < 3 || px >= W2 - 3) continue;
+          const int ya = sy ? 2 : 0, xa = sx ? 2 : 0;
+          f8v v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = 0.75f * (0.75f * cc[1][1].v[e] + 0.25f * cc[1][xa].v[e]) + 0.25f * (0.75f * cc[ya][1].v[e] + 0.25f * cc[ya][xa].v[e]);
+            t = t * sc[e] + sh[e];
+            v.v[e] = p.act == DIFFSAL_ACT_RELU ? fmaxf(t, 0.f) : t;
+          }
+          st8(oimg + (static_cast<long>(py) * W2 + px) * p.C + co, v);
+        }
+    }
+  }
+}
+
 // Border ring: item = (ring pixel, channel quad); ring pixel r of an image: the six full rows first (0, 1, 2, H2-3, H2-2, H2-1),
 // then six columns of each remaining row.
 template <typename T>
@@ -219,6 +266,98 @@ __global__ __launch_bounds__(256) void border_gather_kernel(const T* __restrict_
   }
 }
 
+// The ring kernel on 16-bit storage: ONE ring pixel per workgroup (blockIdx.x), so the pixel decode, the tap loop and every
+// "does this tap touch the border" test are uniform -- scalar instructions and scalar branches instead of per-lane arithmetic in
+// front of an 8-byte access (the form above: 170-215 us per stage at 64 clips, most of the K12-tap class); a thread is (image,
+// channel octet): 16-byte accesses, 256 / (C / 8) images per workgroup.  Same terms in the same order per element.
+template <typename T>
+__global__ __launch_bounds__(256) void up2_conv_commute_ring16_kernel(UpCommuteArgs<T> p) {
+  const int c8n = p.C >> 3;
+  const int ipw = 256 / c8n;                                     // images per workgroup
+  const int H2 = 2 * p.h, W2 = 2 * p.w;
+  const int nb = 2 * p.w + 2 * p.h - 4;
+  const int full = H2 < 6 ? H2 : 6;
+  const int colw = W2 < 6 ? W2 : 6;
+  const long crow = static_cast<long>(p.w + 2) * p.C;
+  const int r = blockIdx.x;
+  int py, px;
+  if (r < full * W2) {
+    const int k = r / W2;
+    px = r - k * W2;
+    py = H2 < 6 ? k : (k < 3 ? k : H2 - 6 + k);
+  } else {
+    const int q = r - full * W2, k = q / colw, j = q - k * colw;
+    py = 3 + k;
+    px = W2 < 6 ? j : (j < 3 ? j : W2 - 6 + j);
+  }
+  const int sub = threadIdx.x / c8n, co = (threadIdx.x - sub * c8n) * 8;
+  if (sub >= ipw) return;
+  int y0, y1, x0, x1;
+  upc_i0(py, y0, y1);
+  upc_i0(px, x0, x1);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+  if (p.scale) {
+    const float4 s0 = ld4(p.scale + co), s1 = ld4(p.scale + co + 4), h0 = ld4(p.shift + co), h1 = ld4(p.shift + co + 4);
+    sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+    sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+  }
+  for (int n = blockIdx.y * ipw + sub; n < p.N; n += gridDim.y * ipw) {
+    const T* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
+    const T* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
+    const f8v a00 = ld8(cb + (y0 + 1) * crow + static_cast<long>(x0 + 1) * p.C + co);
+    const f8v a01 = ld8(cb + (y0 + 1) * crow + static_cast<long>(x1 + 1) * p.C + co);
+    const f8v a10 = ld8(cb + (y1 + 1) * crow + static_cast<long>(x0 + 1) * p.C + co);
+    const f8v a11 = ld8(cb + (y1 + 1) * crow + static_cast<long>(x1 + 1) * p.C + co);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.75f * (0.75f * a00.v[e] + 0.25f * a01.v[e]) + 0.25f * (0.75f * a10.v[e] + 0.25f * a11.v[e]);
+    auto add_tap = [&](int line_idx, int tap, float f) {
+      const f8v t = ld8(tbn + (static_cast<long>(line_idx) * 9 + tap) * p.C + co);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f * t.v[e];
+    };
+    auto col_line = [&](int wx, int m) {
+      const int xc = wx ? p.w - 1 : 0;
+      return m == 0 ? xc : (m == p.h - 1 ? p.w + xc : 2 * p.w + wx * (p.h - 2) + (m - 1));
+    };
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int qy = py + 2 * (ky - 1);
+      int wy;
+      const float cy = upc_dcoef(qy, p.h, wy);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int qx = px + 2 * (kx - 1);
+        int wx;
+        const float cx = upc_dcoef(qx, p.w, wx);
+        const int tap = ky * 3 + kx;
+        if (cy != 0.f) {
+          int m0, m1;
+          upc_i0(qx, m0, m1);
+          if (m0 >= 0 && m0 < p.w) add_tap(wy * p.w + m0, tap, cy * 0.75f);
+          if (m1 >= 0 && m1 < p.w) add_tap(wy * p.w + m1, tap, cy * 0.25f);
+        }
+        if (cx != 0.f) {
+          int m0, m1;
+          upc_i0(qy, m0, m1);
+          if (m0 >= 0 && m0 < p.h) add_tap(col_line(wx, m0), tap, cx * 0.75f);
+          if (m1 >= 0 && m1 < p.h) add_tap(col_line(wx, m1), tap, cx * 0.25f);
+        }
+        if (cy != 0.f && cx != 0.f) add_tap(wy * p.w + (wx ? p.w - 1 : 0), tap, cy * cx);
+      }
+    }
+    f8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[e] * sc[e] + sh[e];
+      o.v[e] = p.act == DIFFSAL_ACT_RELU ? fmaxf(t, 0.f) : t;
+    }
+    st8(p.out + (static_cast<long>(n) * H2 * W2 + static_cast<long>(py) * W2 + px) * p.C + co, o);
+  }
+}
+
 }  // namespace diffsal
 
 using namespace diffsal;
@@ -249,7 +388,17 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
     int gx = (row_items + 255) / 256;
     gx = gx > 64 ? 64 : gx;
     const long rows = static_cast<long>(N) * h;
-    hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
+    if constexpr (sizeof(T) == 2) {
+      if (C % 8 == 0 && tune(TUNE_NO_STREAM16) != 1) {
+        int g8 = (w * (C / 8) + 255) / 256;
+        g8 = g8 > 64 ? 64 : g8;
+        hipLaunchKernelGGL(up2_conv_commute16_kernel<T>, dim3(g8, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
+      } else {
+        hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
+      }
+    } else {
+      hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
+    }
     const int rc = check_launch("up2_conv_commute(interior)");
     if (rc) return rc;
   }
@@ -257,6 +406,15 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
   const long ring_items = (static_cast<long>(full) * W2 + static_cast<long>(H2 - full) * colw) * (C / 4);
   int gr = static_cast<int>((ring_items + 255) / 256);
   gr = gr > 1024 ? 1024 : gr;
+  if constexpr (sizeof(T) == 2) {
+    if (C % 8 == 0 && C / 8 <= 256 && tune(TUNE_NO_STREAM16) != 1) {
+      const int per_img = full * W2 + (H2 - full) * colw, ipw = 256 / (C / 8);
+      int gy = (N + ipw - 1) / ipw;
+      gy = gy > 4096 ? 4096 : gy;
+      hipLaunchKernelGGL(up2_conv_commute_ring16_kernel<T>, dim3(per_img, gy), dim3(256), 0, s, a);
+      return check_launch("up2_conv_commute(ring, 16-bit)");
+    }
+  }
   hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N < 65535 ? N : 65535), dim3(256), 0, s, a);
   return check_launch("up2_conv_commute");
 }

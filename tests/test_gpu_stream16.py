@@ -70,3 +70,88 @@ def test_audio_fuse_16_byte_form(ops, dname, H, W, C, h, w):
     m = torch.softmax((a_up * x.float()).mean(1), dim=2)
     ref = (a_up * m[:, None]).permute(0, 4, 1, 2, 3)
     assert rel_err(got, ref) < OP_RTOL[dname]
+
+
+def _ln(x, g, b, eps):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+# (H, W, C, k): the four decoder stages (k = kernel_kv: 18 pooled keys per frame) and a ragged one
+PREP_CASES = [(7, 12, 768, 2), (14, 24, 384, 4), (28, 48, 192, 8), (56, 96, 96, 16), (9, 10, 96, 3)]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("H,W,C,k", PREP_CASES)
+@pytest.mark.parametrize("mode", ["qkv", "kv_preln_vis", "kv_preln_av"])
+def test_qkv_prep_16_byte_form(ops, dname, H, W, C, k, mode):
+    """K9 (R/models/saliency_decoder/attention.py:36-76,88-95; the block's norm, transformer.py:150): depthwise 3x3 + LayerNorm on
+    every token, depthwise k x k stride-k pooling + LayerNorm of key / value; the pooled branch alone with the block's first
+    LayerNorm applied as the tokens are loaded (the form behind block_front)."""
+    dt = DTYPES[dname]
+    N = 3
+    tol = OP_RTOL[dname]
+    x = rnd("p16x", N, H, W, C).to(dt)
+    xk = rnd("p16k", N, H, W, C).to(dt)
+    w9 = rnd("p16w9", 9, C, scale=0.3)
+    wk, wv = rnd("p16wk", k * k, C, scale=1.0 / k), rnd("p16wv", k * k, C, scale=1.0 / k)
+    gq, bq = 1 + rnd("p16gq", C, scale=0.1), rnd("p16bq", C, scale=0.1)
+    gk, bk = 1 + rnd("p16gk", C, scale=0.1), rnd("p16bk", C, scale=0.1)
+    gv, bv = 1 + rnd("p16gv", C, scale=0.1), rnd("p16bv", C, scale=0.1)
+    pg, pb = 1 + rnd("p16pg", C, scale=0.1), rnd("p16pb", C, scale=0.1)
+    d = lambda t: t.to(DEV)
+    gh, gw = (H - k) // k + 1, (W - k) // k + 1
+
+    def pooled(src, w, g, b):          # [N,H,W,C] fp32 -> [N, gh*gw, C]
+        win = src[:, :gh * k, :gw * k].reshape(N, gh, k, gw, k, C).permute(0, 1, 3, 2, 4, 5).reshape(N, gh * gw, k * k, C)
+        return _ln((win * w).sum(2), g, b, 1e-5)
+
+    if mode == "qkv":
+        def run():
+            return ops.qkv_prep(d(x), d(w9), d(gq), d(bq), d(xk), d(x), d(wk), d(wv), d(gk), d(bk), d(gv), d(bv), k, 1e-5)
+        got = run()
+        with old_forms():
+            old = run()
+        xf = x.float().permute(0, 3, 1, 2)
+        qc = torch.nn.functional.conv2d(xf, w9.t().reshape(C, 1, 3, 3), padding=1, groups=C).permute(0, 2, 3, 1)
+        ref = (_ln(qc, gq, bq, 1e-5).reshape(N, H * W, C), pooled(xk.float(), wk, gk, bk), pooled(x.float(), wv, gv, bv))
+    else:
+        av = mode == "kv_preln_av"
+        src_k = xk if av else x
+
+        def run():
+            return ops.kv_prep(d(src_k), d(x), d(wk), d(wv), d(gk), d(bk), d(gv), d(bv), k, 1e-5, pre_ln=(d(pg), d(pb), 1e-6, not av))
+        got = run()
+        with old_forms():
+            old = run()
+        xn = _ln(x.float(), pg, pb, 1e-6).to(dt).float()
+        ref = (pooled(src_k.float() if av else xn, wk, gk, bk), pooled(xn, wv, gv, bv))
+    for g_, o_, r_ in zip(got, old, ref):
+        assert g_.dtype == dt and g_.shape == o_.shape == r_.shape
+        assert rel_err(g_, o_.float()) < tol           # the 8-byte form: same formulas, another summation order, one rounding
+        assert rel_err(g_, r_) < 2 * tol               # pre-LN rounds the normalised tokens to the storage type first
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("h,w,C", [(7, 12, 384), (14, 24, 192), (28, 48, 96), (5, 9, 40)])
+def test_up2_commute_interior_16_byte_form(ops, dname, h, w, C):
+    """K12 (R/models/saliency_decoder/common_block.py:196-206), the interpolation kernel of the source-resolution form: 8 channels per
+    item instead of 4, the same arithmetic per element -> identical bits."""
+    from diff_sal_amd import _lib
+
+    dt = DTYPES[dname]
+    N = 3
+    lib = _lib.load()
+    c_ext = rnd("c16c", N, h + 2, w + 2, C).to(DEV).to(dt)
+    tb = rnd("c16t", N, 2 * w + 2 * h - 4, 9 * C).to(DEV).to(dt)
+    scale, shift = (1 + rnd("c16s", C, scale=0.1)).to(DEV), rnd("c16h", C, scale=0.1).to(DEV)
+    code = ops.DTYPE_CODES[dt]
+
+    def run():
+        out = torch.zeros((N, 2 * h, 2 * w, C), device=DEV, dtype=dt)
+        _lib.check(lib.diffsal_up2_conv_commute(c_ext.data_ptr(), tb.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                                                N, h, w, C, 1, code, torch.cuda.current_stream().cuda_stream), "up2_conv_commute")
+        return out
+    got = run()
+    with old_forms():
+        old = run()
+    assert torch.equal(got, old)

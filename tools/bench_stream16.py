@@ -56,9 +56,39 @@ def main():
             off = [0, 768, 1152, 1344][si]
             a_small = a_all[:, :, off:off + C]
             ab(f"K7 audio_fuse s{si} {H}x{W}x{C}", lambda: ops.audio_fuse(a_small, x, 7, 12), 2 * x.numel() * es + a_small.numel() * es)
-        for name, fn, nb in EXTRA:
-            if not flt or name.split()[0].lower() in flt:
-                fn(si, B, T, H, W, C, x, dt, g)
+        if not flt or "prep" in flt:
+            k = [2, 4, 8, 16][si]
+            N = B * T
+            xn = x.view(N, H, W, C)
+            xk = torch.randn(N, H, W, C, device=DEV, generator=g).to(dt)
+            f = lambda *s_: torch.randn(*s_, device=DEV, generator=g)
+            w9, wk, wv = f(9, C), f(k * k, C), f(k * k, C)
+            gs = [f(C) for _ in range(8)]
+            if si < 2:
+                ab(f"K9 qkv_prep s{si}", lambda: ops.qkv_prep(xn, w9, gs[0], gs[1], xk, xn, wk, wv, gs[2], gs[3], gs[4], gs[5], k, 1e-5),
+                   4 * xn.numel() * es)
+            else:
+                ab(f"K9 kv_prep(preln) s{si}", lambda: ops.kv_prep(xk, xn, wk, wv, gs[2], gs[3], gs[4], gs[5], k, 1e-5, pre_ln=(gs[6], gs[7], 1e-6, False)),
+                   2 * xn.numel() * es)
+            del xk
+        if (not flt or "commute" in flt) and si < 3:
+            # UpEmbed conv1 of the NEXT stage at this stage's resolution: source h x w, Cout = C / 2
+            Co = C // 2
+            N = B * T
+            lib = _lib.load()
+            c_ext = torch.randn(N, H + 2, W + 2, Co, device=DEV, generator=g).to(dt)
+            tb = torch.randn(N, 2 * W + 2 * H - 4, 9 * Co, device=DEV, generator=g).to(dt)
+            sc, sh = torch.randn(Co, device=DEV, generator=g), torch.randn(Co, device=DEV, generator=g)
+            out = torch.empty(N, 2 * H, 2 * W, Co, device=DEV, dtype=dt)
+            code = ops.DTYPE_CODES[dt]
+            st = torch.cuda.current_stream().cuda_stream
+            ab(f"K12-tap commute {H}x{W} C={Co}", lambda: _lib.check(lib.diffsal_up2_conv_commute(
+                c_ext.data_ptr(), tb.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr(), N, H, W, Co, 1, code, st), "c"),
+               (c_ext.numel() + out.numel()) * es)
+            ab(f"K12-tap   ring only {H}x{W} C={Co}", lambda: _lib.check(lib.diffsal_up2_conv_commute_ring(
+                c_ext.data_ptr(), tb.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr(), N, H, W, Co, 1, code, st), "c"),
+               (c_ext.numel() + out.numel()) * es)
+            del c_ext, tb, out
         del x
 
 
