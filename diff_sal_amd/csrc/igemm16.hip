@@ -693,6 +693,12 @@ int conv16_halo_pointers_ok(const diffsal_conv_desc* d, const float* bias, const
 int conv16_halo_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                        const float* shift, const float* rowvec, const void* residual, void* out, hipStream_t s);
 
+// conv16_dma.hip: the same convolutions (any padding) with an LDS-DMA halo patch, two workgroups per CU
+int conv16_dma_applies(const diffsal_conv_desc* d, const float* bias, const float* scale, const float* shift, const float* rowvec,
+                       const void* residual, const void* out);
+int conv16_dma_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
+                      const float* shift, const float* rowvec, const void* residual, void* out, hipStream_t s);
+
 static Plan16 plan_for(const diffsal_conv_desc* d) {
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   Plan16 pl = choose_plan16(M, d->Cout, d->KH * d->KW * d->Cin);
@@ -774,6 +780,8 @@ static int run16(const diffsal_conv_desc* d, const void* in, const void* w, cons
 int igemm16_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,
                    const float* shift, const float* rowvec, const void* residual, void* out, void* ws, size_t ws_bytes,
                    hipStream_t s, const void* in2, const void* w2, const float* bias2, void* out2) {
+  if (!in2 && conv16_dma_applies(d, bias, scale, shift, rowvec, residual, out))
+    return conv16_dma_launch(d, in, w, bias, scale, shift, rowvec, residual, out, s);
   if (!in2 && conv16_halo_applies(d) && conv16_halo_pointers_ok(d, bias, scale, shift, rowvec, residual, out))
     return conv16_halo_launch(d, in, w, bias, scale, shift, rowvec, residual, out, s);
   if (d->dtype == DIFFSAL_BF16)

@@ -155,3 +155,72 @@ def test_up2_commute_interior_16_byte_form(ops, dname, h, w, C):
     with old_forms():
         old = run()
     assert torch.equal(got, old)
+
+
+# N, H, W, Cin, Cout, pad, dil, epilogue
+CONV_DMA_CASES = [
+    (2, 56, 96, 96, 96, 2, 2, "bn_relu_res"),     # stage-3 UpEmbed conv2: 8 x 32 tiles, one N tile
+    (3, 28, 48, 192, 192, 2, 2, "bn_relu_res"),   # stage 2: 16 x 16 tiles, two N tiles
+    (2, 14, 24, 384, 192, 2, 1, "bn_relu"),       # UpEmbed conv1 at the source resolution on the extended grid (out 16 x 26)
+    (2, 56, 96, 96, 192, 1, 1, "bias_rowvec"),    # ResnetBlock conv1
+    (2, 9, 17, 32, 72, 1, 1, "bias"),             # ragged: partial tiles in both directions, Cout < 96 and not a multiple of 32
+    (1, 20, 36, 768, 96, 1, 1, "none"),           # 24 chunks
+]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("case", CONV_DMA_CASES)
+def test_conv16_dma_halo_kernel(ops, dname, case):
+    """csrc/conv16_dma.hip (R/models/saliency_decoder/common_block.py:196-216, sal_unet.py:104-142 on 16-bit storage): forced on
+    shapes of a few tiles, against the generic 16-bit implicit-GEMM kernel -- same accumulation order, identical bits -- and
+    against F.conv2d on the rounded operands."""
+    import torch.nn.functional as F
+
+    from diff_sal_amd import _lib
+
+    dt = DTYPES[dname]
+    N, H, W, Cin, Cout, pad, dil, epi = case
+    x = rnd("cdx%d" % Cin, N, Cin, H, W).to(dt)
+    w = rnd("cdw%d%d" % (Cin, Cout), Cout, Cin, 3, 3, scale=1.0 / (3 * Cin ** 0.5)).to(dt)
+    Ho, Wo = H + 2 * pad - 2 * dil, W + 2 * pad - 2 * dil
+    bias = rnd("cdb", Cout, scale=0.1) if "bias" in epi else None
+    scale = (1 + rnd("cds", Cout, scale=0.2)) if "bn" in epi else None
+    shift = rnd("cdh", Cout, scale=0.1) if "bn" in epi else None
+    rowvec = rnd("cdr", N, Cout, scale=0.5) if "rowvec" in epi else None
+    res = rnd("cdres", N, Cout, Ho, Wo).to(dt) if "res" in epi else None
+    act = 1 if "relu" in epi else 0
+    dv = lambda t: None if t is None else t.to(DEV)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = ops.cast(ops.pack_conv_weight(w.float().to(DEV)), dt)
+    rn = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+    def run():
+        return ops.conv_igemm(xn, wp, kh=3, kw=3, pad=(pad, pad), dil=(dil, dil), out_hw=(Ho, Wo), bias=dv(bias), scale=dv(scale),
+                              shift=dv(shift), rowvec=dv(rowvec), residual=rn, act=act)
+    _lib.set_tuning("DIFFSAL_FORCE_HALO", 2)
+    try:
+        got = run()
+        name = _lib.load().diffsal_last_gemm_kernel().decode()
+    finally:
+        _lib.set_tuning("DIFFSAL_FORCE_HALO", None)
+    assert "conv16_dma_kernel" in name
+    # the generic kernel on one fixed tile shape WITHOUT a K split (its split sums the K ranges in another order)
+    _lib.set_tuning("DIFFSAL_NO_HALO", 1)
+    _lib.set_tuning("DIFFSAL_IGEMM16_CFG", 0)
+    try:
+        old = run()
+        assert "igemm16_kernel" in _lib.load().diffsal_last_gemm_kernel().decode()
+    finally:
+        _lib.set_tuning("DIFFSAL_NO_HALO", None)
+        _lib.set_tuning("DIFFSAL_IGEMM16_CFG", None)
+    assert torch.equal(got, old)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=pad, dilation=dil)
+    if scale is not None:
+        ref = ref * scale[None, :, None, None] + shift[None, :, None, None]
+    if rowvec is not None:
+        ref = ref + rowvec[:, :, None, None]
+    if act:
+        ref = F.relu(ref)
+    if res is not None:
+        ref = ref + res.float()
+    assert rel_err(got, ref.permute(0, 2, 3, 1)) < OP_RTOL[dname]
