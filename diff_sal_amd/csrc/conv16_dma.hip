@@ -225,6 +225,20 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   const float* rv_row = p.rowvec ? p.rowvec + static_cast<long>(img) * p.rowvec_ld : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    // the residual octets of this row tile are requested before the sums are parked (a round trip under the LDS traffic)
+    uint4 rraw[6];
+    if (resid) {
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int item = it * 64 + lane;
+        const int px = item / 12, oc = item - px * 12;
+        const int n = n0 + oc * 8;
+        const int gy = y0 + (wave * TM + i) * RPM + px / TW, gx = x0 + px % TW;
+        rraw[it] = (gy < p.Ho && gx < p.Wo && n < p.Cout)
+                       ? *reinterpret_cast<const uint4*>(resid + ((static_cast<long>(img) * p.Ho + gy) * p.Wo + gx) * p.Cout + n)
+                       : make_uint4(0, 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
       }
       const long o = ((static_cast<long>(img) * p.Ho + gy) * p.Wo + gx) * p.Cout + n;
       if (resid) {
-        const f8v t = ld8(resid + o);
+        const f8v t = ld8(reinterpret_cast<const T*>(&rraw[it]));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += t.v[e];
       }

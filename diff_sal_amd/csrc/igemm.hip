@@ -43,6 +43,9 @@ int try_gemm_dma(int cfg, const diffsal_conv_desc* d, bool as_conv, const void* 
 int try_gemm_dma_group(int n, const diffsal_conv_desc* const* d, const float* const* a, const float* const* w, const float* const* bias,
                        float* const* out, hipStream_t s);
 size_t gemm_dma_ws_bytes(int cfg, long M, int K, int N, int esz);
+// gemm16_dma.hip: 16-bit plain products on 256 x 96 tiles, two workgroups per CU
+int try_gemm16_dma2(const diffsal_conv_desc* d, const void* a, const void* w, const float* bias, const float* scale, const float* shift,
+                    const float* rowvec, int rowvec_ld, const void* residual, void* out, hipStream_t s, bool out_f32);
 double gemm_dma_estimate(int cfg, long M, int K, int N);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1043,6 +1046,12 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
   DS_REQUIRE((d->act >= DIFFSAL_ACT_NONE && d->act <= DIFFSAL_ACT_SIGMOID) ||
                  (d->act == DIFFSAL_ACT_GELU_GRAD && d->dtype == DIFFSAL_F32 && residual_v && !px),
              DIFFSAL_E_ARG, "conv_igemm: act=%d (DIFFSAL_ACT_GELU_GRAD: fp32 only, the pre-activation goes in `residual`)", d->act);
+  if (d->dtype != DIFFSAL_F32 && is_linear(d) && !px && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 &&
+      d->act != DIFFSAL_ACT_GELU_GRAD) {
+    const int rr = try_gemm16_dma2(d, in_v, w_v, bias, scale, shift, rowvec, d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout, residual_v, out_v,
+                                   static_cast<hipStream_t>(stream), false);
+    if (rr != 0) return rr < 0 ? rr : DIFFSAL_OK;
+  }
   if (d->dtype != DIFFSAL_F32) {
     const long M16 = static_cast<long>(d->N) * d->Ho * d->Wo;
     const int r16 = dma_route(d, is_linear(d), M16, d->KH * d->KW * d->Cin, px != nullptr);
@@ -1180,8 +1189,10 @@ extern "C" int diffsal_linear_f32out(const diffsal_conv_desc* d, const void* in,
                  d->act >= DIFFSAL_ACT_NONE && d->act <= DIFFSAL_ACT_SIGMOID,
              DIFFSAL_E_ARG, "linear_f32out: a plain product on bf16 / f16 storage");
   DS_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && (!bias || aligned16(bias)), DIFFSAL_E_ALIGN, "linear_f32out: misaligned pointer");
-  const int rr = try_gemm_dma(0, d, false, in, w, bias, nullptr, nullptr, nullptr, d->Cout, nullptr, out, nullptr, 0,
-                              static_cast<hipStream_t>(stream), true);
+  int rr = try_gemm16_dma2(d, in, w, bias, nullptr, nullptr, nullptr, d->Cout, nullptr, out, static_cast<hipStream_t>(stream), true);
+  if (rr == 0)
+    rr = try_gemm_dma(0, d, false, in, w, bias, nullptr, nullptr, nullptr, d->Cout, nullptr, out, nullptr, 0,
+                      static_cast<hipStream_t>(stream), true);
   if (rr < 0) return rr;
   DS_REQUIRE(rr == 1, DIFFSAL_E_SHAPE, "linear_f32out: K=%d must be a multiple of 192 and N=%d of 4", d->KH * d->KW * d->Cin, d->Cout);
   return DIFFSAL_OK;

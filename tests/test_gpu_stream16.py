@@ -224,3 +224,61 @@ def test_conv16_dma_halo_kernel(ops, dname, case):
     if res is not None:
         ref = ref + res.float()
     assert rel_err(got, ref.permute(0, 2, 3, 1)) < OP_RTOL[dname]
+
+
+# M, K, N, epilogue
+GEMM2_CASES = [
+    (3024, 768, 768, "bias"),
+    (3024, 768, 1536, "bias_gelu"),
+    (1000, 1536, 768, "bias_res"),        # partial last row tile
+    (5000, 192, 200, "bias_relu_res"),    # N neither a multiple of 96 nor of 32
+    (700, 96, 864, "none"),               # three K chunks
+    (2000, 768, 864, "f32out"),           # mt_proj's tap products: fp32 out
+]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("case", GEMM2_CASES)
+def test_gemm16_dma2_plain_products(ops, dname, case):
+    """csrc/gemm16_dma.hip (R/models/saliency_decoder/attention.py:97-111, common_block.py:125-147 on 16-bit storage), forced on
+    small shapes: identical bits to the generic 16-bit kernel without a K split (same MFMA, same K order); fp64 reference."""
+    from diff_sal_amd import _lib
+
+    dt = DTYPES[dname]
+    M, K, N, epi = case
+    x = rnd("g2x%d" % K, M, K).to(DEV).to(dt)
+    w = rnd("g2w%d%d" % (K, N), N, K, scale=K ** -0.5).to(DEV).to(dt)
+    b = rnd("g2b", N, scale=0.1).to(DEV) if "bias" in epi else None
+    res = rnd("g2r", M, N).to(DEV).to(dt) if "res" in epi else None
+    act = 2 if "gelu" in epi else (1 if "relu" in epi else 0)
+    f32 = epi == "f32out"
+
+    def run():
+        return ops.linear(x, w, b, act=act, residual=res, out_f32=f32) if f32 else ops.linear(x, w, b, act=act, residual=res)
+    _lib.set_tuning("DIFFSAL_GEMM_DMA16", 3)
+    try:
+        got = run()
+        name = _lib.load().diffsal_last_gemm_kernel().decode()
+    finally:
+        _lib.set_tuning("DIFFSAL_GEMM_DMA16", None)
+    assert "gemm16_dma2_kernel" in name
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    assert got.dtype == (torch.float32 if f32 else dt)
+    assert rel_err(got, ref) < (1e-5 if f32 else OP_RTOL[dname])
+    if not f32:
+        _lib.set_tuning("DIFFSAL_GEMM_DMA16", 0)
+        _lib.set_tuning("DIFFSAL_IGEMM16_CFG", 0)
+        try:
+            old = run()
+        finally:
+            _lib.set_tuning("DIFFSAL_GEMM_DMA16", None)
+            _lib.set_tuning("DIFFSAL_IGEMM16_CFG", None)
+        assert torch.equal(got, old)

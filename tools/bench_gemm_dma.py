@@ -68,7 +68,7 @@ def run(x, w, b, act, res):
 
 def main():
     args = [a for a in sys.argv[1:]]
-    cfgs = [1, 2, 3, 4]
+    cfgs = [1, 2, 3, 4]     # 16-bit (DMA_DTYPE): 1 / 2 = gemm_dma.hip 96 x 96 / 192 x 192, 3 = gemm16_dma.hip (two workgroups per CU)
     rounds = 5
     flt = ""
     i = 0
