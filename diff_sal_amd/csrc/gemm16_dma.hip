@@ -48,6 +48,10 @@ struct GdArgs {
   int M, N, K;
   int act, rowvec_ld, rows_per_img, out_f32;
   int tiles_m, tiles_n;
+  // row form (ReduceTemp, R/models/saliency_decoder/sal_unet.py:300-318: a (kt, 1) kernel with stride (kt, 1) over [B, T, HW, C] that
+  // leaves ONE frame): taps > 1: output row m = (image m / Wrow, position m % Wrow) reads input rows (image, t, position), t < taps;
+  // K is ordered (32-channel chunk, tap, channel) as pack_conv_weight leaves it.  taps == 1: the plain product (Hrow = 1)
+  int taps, Wrow, Hrow, Cin;
 };
 
 // inline assembly on purpose (see gemm_dma.hip): the compiler must know neither the LDS write nor the vmcnt event
@@ -88,16 +92,24 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
 
   // ---- issue side: A instruction q (q < 4) of a wavefront covers rows (q * 4 + wave) * 16 + (lane >> 2), W instruction q (q < 2) rows
   // (q * 4 + wave) * 16 + (lane >> 2) of the N tile; physical slot lane & 3 receives logical slot (lane & 3) ^ ((row >> 2) & 3)
-  const unsigned long pa = reinterpret_cast<unsigned long>(p.a + static_cast<long>(m0) * p.K);
+  // byte offset of output row m's first input row
+  auto row_off = [&](int m) __attribute__((always_inline)) -> long {
+    const int n = m / p.Wrow, pos = m - n * p.Wrow;
+    return (static_cast<long>(n) * p.Hrow * p.Wrow + pos) * p.Cin * 2;
+  };
+  const long base_off = row_off(m0);
+  const long total_b = static_cast<long>((p.M + p.Wrow - 1) / p.Wrow) * p.Hrow * p.Wrow * p.Cin * 2;
+  const unsigned long pa = reinterpret_cast<unsigned long>(p.a) + static_cast<unsigned long>(base_off);
   const int rows_a = min(BM, p.M - m0), rows_w = min(BN, p.N - n0);
-  const gd_i32x4 rs_a = gd_i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, rows_a * p.K * 2, 0x00020000};
+  const long rec_a = total_b - base_off;
+  const gd_i32x4 rs_a = gd_i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, static_cast<int>(rec_a < 0x7FFFFFFFL ? rec_a : 0x7FFFFFFFL), 0x00020000};
   const unsigned long pw = reinterpret_cast<unsigned long>(p.w + static_cast<long>(n0) * p.K);
   const gd_i32x4 rs_w = gd_i32x4{static_cast<int>(pw), static_cast<int>(pw >> 32) & 0xFFFF, rows_w * p.K * 2, 0x00020000};
   unsigned a_voff[4], w_voff[2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = (q * 4 + wave) * 16 + (lane >> 2), ls = (lane & 3) ^ ((row >> 2) & 3);
-    a_voff[q] = row < rows_a ? static_cast<unsigned>((row * p.K + ls * 8) * 2) : DEAD;
+    a_voff[q] = row < rows_a ? static_cast<unsigned>(row_off(m0 + row) - base_off + ls * 16) : DEAD;
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -105,11 +117,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
     w_voff[q] = row < rows_w ? static_cast<unsigned>((row * p.K + ls * 8) * 2) : DEAD;
   }
   const bool w_live1 = (4 + wave) * 16 < BN;
+  const unsigned tap_stride = static_cast<unsigned>(p.Wrow) * p.Cin * 2u;
   auto issue = [&](int g) __attribute__((always_inline)) {             // K chunk g -> slot g % 3
     const bool live = g < G;
     const unsigned dst = lds0 + (g % 3) * kGdSlot, soff = static_cast<unsigned>(g) * 64u;
+    const int ch = g / p.taps, tap = g - ch * p.taps;
+    const unsigned soff_a = static_cast<unsigned>(tap) * tap_stride + static_cast<unsigned>(ch) * 64u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gd_dma(live ? dst + (q * 4 + wave) * 1024 : lds_scratch, live ? a_voff[q] : DEAD, rs_a, soff);
+    for (int q = 0; q < 4; ++q) gd_dma(live ? dst + (q * 4 + wave) * 1024 : lds_scratch, live ? a_voff[q] : DEAD, rs_a, soff_a);
     gd_dma(live ? dst + BM * 64 + wave * 1024 : lds_scratch, live ? w_voff[0] : DEAD, rs_w, soff);
     gd_dma(live && w_live1 ? dst + BM * 64 + (4 + wave) * 1024 : lds_scratch, live && w_live1 ? w_voff[1] : DEAD, rs_w, soff);
   };
@@ -247,8 +262,14 @@ int try_gemm16_dma2(const diffsal_conv_desc* d, const void* a, const void* w, co
   if (forced == 0 || forced == 1 || forced == 2) return 0;
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const int K = d->KH * d->KW * d->Cin, N = d->Cout;
-  if (d->KH != 1 || d->KW != 1 || d->stride_h != 1 || d->stride_w != 1 || d->dtype == DIFFSAL_F32) return 0;
-  if (K % 32 != 0 || K < 64 || N % 8 != 0 || M <= 0 || M >= (1L << 31) || 256L * K * 2 >= (1L << 31) || 96L * K * 2 >= (1L << 31)) return 0;
+  if (d->dtype == DIFFSAL_F32 || d->KW != 1 || d->stride_w != 1 || d->pad_t != 0 || d->pad_l != 0 || d->dil_h != 1 || d->Wo != d->W) return 0;
+  const bool plain = d->KH == 1 && d->stride_h == 1 && d->Ho == d->H;
+  const bool rowform = d->KH > 1 && d->Ho == 1 && d->KH <= d->H;           // one output frame: the stride does not matter
+  if (!plain && !rowform) return 0;
+  const long in_bytes = static_cast<long>(d->N) * d->H * d->W * d->Cin * 2;
+  if (K % 32 != 0 || d->Cin % 32 != 0 || K < 64 || N % 8 != 0 || M <= 0 || M >= (1L << 31) || 256L * K * 2 >= (1L << 31) || 96L * K * 2 >= (1L << 31) ||
+      (rowform && (static_cast<long>(d->H) * d->W * d->Cin * 2 * 2 >= (1L << 31) || in_bytes >= (1L << 40))))
+    return 0;
   if (!aligned16(a) || !aligned16(w) || !aligned16(out) || !aligned16(bias) || !aligned16(scale) || !aligned16(shift) || !aligned16(rowvec) ||
       !aligned16(residual) || (rowvec && rowvec_ld % 4 != 0) || ((scale == nullptr) != (shift == nullptr)))
     return 0;
@@ -261,7 +282,8 @@ int try_gemm16_dma2(const diffsal_conv_desc* d, const void* a, const void* w, co
 #define GD_LAUNCH(T)                                                                                                        \
   do {                                                                                                                      \
     GdArgs<T> g{static_cast<const T*>(a), static_cast<const T*>(w), bias, scale, shift, rowvec, static_cast<const T*>(residual), out, \
-                static_cast<int>(M), N, K, d->act, rowvec_ld, d->Ho * d->Wo, out_f32 ? 1 : 0, static_cast<int>((M + 255) / 256), (N + 95) / 96}; \
+                static_cast<int>(M), N, K, d->act, rowvec_ld, d->Ho * d->Wo, out_f32 ? 1 : 0, static_cast<int>((M + 255) / 256), (N + 95) / 96, \
+                rowform ? d->KH : 1, rowform ? d->W : static_cast<int>(M), rowform ? d->H : 1, d->Cin};                        \
     DS_RAISE_DYNAMIC_LDS((gemm16_dma2_kernel<T>), 160 * 1024);                                                              \
     hipLaunchKernelGGL((gemm16_dma2_kernel<T>), dim3(static_cast<unsigned>(tiles)), dim3(256), lds, s, g);                   \
   } while (0)

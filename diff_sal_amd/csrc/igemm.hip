@@ -1046,8 +1046,8 @@ static int conv_igemm_impl(const diffsal_conv_desc* d, const void* in_v, const v
   DS_REQUIRE((d->act >= DIFFSAL_ACT_NONE && d->act <= DIFFSAL_ACT_SIGMOID) ||
                  (d->act == DIFFSAL_ACT_GELU_GRAD && d->dtype == DIFFSAL_F32 && residual_v && !px),
              DIFFSAL_E_ARG, "conv_igemm: act=%d (DIFFSAL_ACT_GELU_GRAD: fp32 only, the pre-activation goes in `residual`)", d->act);
-  if (d->dtype != DIFFSAL_F32 && is_linear(d) && !px && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 &&
-      d->act != DIFFSAL_ACT_GELU_GRAD) {
+  if (d->dtype != DIFFSAL_F32 && !px && d->precision == DIFFSAL_PREC_FP32 && d->w_format == 0 && d->act != DIFFSAL_ACT_GELU_GRAD) {
+    // plain products and ReduceTemp's row form
     const int rr = try_gemm16_dma2(d, in_v, w_v, bias, scale, shift, rowvec, d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout, residual_v, out_v,
                                    static_cast<hipStream_t>(stream), false);
     if (rr != 0) return rr < 0 ? rr : DIFFSAL_OK;

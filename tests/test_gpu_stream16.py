@@ -282,3 +282,36 @@ def test_gemm16_dma2_plain_products(ops, dname, case):
             _lib.set_tuning("DIFFSAL_GEMM_DMA16", None)
             _lib.set_tuning("DIFFSAL_IGEMM16_CFG", None)
         assert torch.equal(got, old)
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("Bn,T,HW,C,kt,Co", [(3, 9, 84, 768, 5, 768), (2, 9, 336, 96, 5, 768), (2, 5, 100, 64, 5, 200)])
+def test_gemm16_dma2_reduce_temp_row_form(ops, dname, Bn, T, HW, C, kt, Co):
+    """ReduceTemp (R/models/saliency_decoder/sal_unet.py:300-318) on 16-bit storage through csrc/gemm16_dma.hip's row form: a (kt, 1)
+    kernel over the frame axis that leaves one frame, K ordered (chunk, tap, channel) as the packed weight is."""
+    from diff_sal_amd import _lib
+
+    dt = DTYPES[dname]
+    x = rnd("rt%d" % C, Bn, T, HW, C).to(DEV).to(dt)
+    w = rnd("rtw%d" % C, Co, C, kt, 1, scale=(kt * C) ** -0.5).to(DEV)
+    wp = ops.cast(ops.pack_conv_weight(w), dt)
+
+    def run():
+        return ops.conv_igemm(x, wp, kh=kt, kw=1, stride=(kt, 1), act=1)
+    _lib.set_tuning("DIFFSAL_GEMM_DMA16", 3)
+    try:
+        got = run()
+        assert "gemm16_dma2_kernel" in _lib.load().diffsal_last_gemm_kernel().decode()
+    finally:
+        _lib.set_tuning("DIFFSAL_GEMM_DMA16", None)
+    _lib.set_tuning("DIFFSAL_GEMM_DMA16", 0)
+    _lib.set_tuning("DIFFSAL_IGEMM16_CFG", 0)
+    try:
+        old = run()
+    finally:
+        _lib.set_tuning("DIFFSAL_GEMM_DMA16", None)
+        _lib.set_tuning("DIFFSAL_IGEMM16_CFG", None)
+    assert got.shape == old.shape == (Bn, 1, HW, Co)
+    assert torch.equal(got, old)
+    ref = torch.relu(torch.einsum("bthc,octu->bho", x[:, :kt].double(), wp.new_tensor(w.to(dt).double().cpu().numpy(), dtype=torch.float64)))
+    assert rel_err(got.view(Bn, HW, Co), ref) < OP_RTOL[dname]
