@@ -8,7 +8,7 @@
 // overlap.  This kernel is built so that they do:
 //
 //  * a workgroup is 4 wavefronts and 256 output pixels (8 x 32 or 16 x 16) x 96 output channels; its LDS -- two patch buffers of
-//    one 32-channel chunk, a three-slot ring of single-tap weight slices, 74 KB -- leaves room for a SECOND workgroup on the CU:
+//    one 32-channel chunk, a four-slot ring of single-tap weight slices, 80 KB -- leaves room for a SECOND workgroup on the CU:
 //    one's prologue, barriers and epilogue run under the other's matrix work;
 //  * patch and weights go memory -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write); a pixel / weight
 //    row is 64 bytes with its four 16-byte slots XOR-swizzled by (index >> 2) & 3 -- applied on the SOURCE address -- so that the
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((cd_lds_ptr_t)cd_smem));
   constexpr int PATCH_CAP = kCdPatchIss * kCdWaves * 1024;           // 28672
   constexpr int SLOT_B = kCdSlotRows * kCdRowB;                      // 8192
-  const unsigned lds_w = lds0 + 2 * PATCH_CAP, lds_scratch = lds_w + 3 * SLOT_B;
+  // dead DMA instructions write zeros into the last KiB of patch buffer 0's 28 KiB, which no patch reaches (host-checked)
+  const unsigned lds_w = lds0 + 2 * PATCH_CAP, lds_scratch = lds0 + PATCH_CAP - 1024;
   const int n_chunks = p.Cin >> 5;
   const int G = 9 * n_chunks;
 
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
     const bool live = c < n_chunks && (q * kCdWaves + wave) * 1024 < patch_bytes + 1024;
     cd_dma(live ? dst : lds_scratch, live ? a_voff[q] : DEAD, rs_a, static_cast<unsigned>(c) * 64u);
   };
-  auto issue_weights = [&](int g) __attribute__((always_inline)) {       // the slice of step g (chunk g / 9, tap g % 9) -> slot g % 3
+  auto issue_weights = [&](int g) __attribute__((always_inline)) {       // the slice of step g (chunk g / 9, tap g % 9) -> slot g % 4
     const bool live = g < G;
-    const unsigned dst = lds_w + (g % 3) * SLOT_B;
+    const unsigned dst = lds_w + (g & 3) * SLOT_B;
     const unsigned soff = static_cast<unsigned>(g) * 64u;      // [Cin / 32][9][32] inside a weight row: step g is 64 bytes further
     cd_dma(live ? dst + wave * 1024 : lds_scratch, live ? w_voff[0] : DEAD, rs_w, soff);
     cd_dma(live && w_live1 ? dst + (kCdWaves + wave) * 1024 : lds_scratch, live && w_live1 ? w_voff[1] : DEAD, rs_w, soff);
@@ -181,17 +182,16 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap, ++g) {
       // everything this wavefront issued up to step g - 2 has landed (first step: all but weight slice 1); after the barrier
-      // everybody's has, and nobody reads slot (g + 2) % 3 or the other patch buffer any more
-      // ... and this wavefront's LDS reads of step g - 1 have RETURNED: hipcc sinks that step's last MFMAs (and the lgkmcnt waits in
-      // front of them) below this barrier, and a read still queued in a busy LDS could otherwise meet the DMA that another
-      // wavefront issues into the same slot right behind the barrier (seen as rare wrong tiles with every CU loaded)
-      if (g == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      // everybody's has.  What is issued now lands in buffers last read TWO steps ago -- weight slot (g + 2) % 4, and the other patch
+      // buffer from tap 1 on -- so that a fragment read of step g - 1 that is still queued in a busy LDS (hipcc sinks that step's
+      // last MFMAs and their lgkmcnt waits below this barrier) cannot meet a DMA: with a three-slot ring and lookahead 2 that
+      // happened -- rare wrong tiles with every CU loaded -- and the cure there, lgkmcnt(0) in front of the barrier, cost 5 %
+      if (g == 0) cd_wait_vmcnt<2>(); else cd_wait_vmcnt<3>();
       __builtin_amdgcn_s_barrier();
       issue_weights(g + 2);
-      if (tap < kCdPatchIss) issue_patch(chunk + 1, tap);
+      if (tap >= 1 && tap <= kCdPatchIss) issue_patch(chunk + 1, tap - 1);
       else cd_dma(lds_scratch, DEAD, rs_a, 0u);
-      const unsigned char* Bb = cd_smem + 2 * PATCH_CAP + (g % 3) * SLOT_B;
+      const unsigned char* Bb = cd_smem + 2 * PATCH_CAP + (g & 3) * SLOT_B;
       const int ky = tap / 3, kx = tap - ky * 3;
       const int toff = ky * d * PW + kx * d;
       vec fa[2][TM], fb[2][TN];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
     }
   }
   // every DMA (the dead ones of the last steps included) has landed before the LDS is reused
-  cd_wait_vmcnt<0>();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (and this wavefront's last fragment reads have returned: the staging below reuses the patch buffers)
   __builtin_amdgcn_s_barrier();
 
   // ---- epilogue through LDS.  A lane holds, for pixel lp of row tile i, channels (r & 3) + 8 (r >> 2) + 4 kh of every 32-channel
@@ -299,7 +299,7 @@ static int launch_cd(CdArgs<T>& a, hipStream_t s) {
   a.tiles_x = (a.Wo + TW - 1) / TW;
   a.tiles_y = (a.Ho + TH - 1) / TH;
   a.tiles_n = (a.Cout + 95) / 96;
-  const size_t lds = 2 * kCdPatchIss * kCdWaves * 1024 + 3 * kCdSlotRows * kCdRowB + 1024 ;       // 76800: two per CU
+  const size_t lds = 2 * kCdPatchIss * kCdWaves * 1024 + 4 * kCdSlotRows * kCdRowB;       // 81920: exactly two per CU
   DS_RAISE_DYNAMIC_LDS((conv16_dma_kernel<TW, T>), 160 * 1024);
   const long blocks = static_cast<long>(a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
   hipLaunchKernelGGL((conv16_dma_kernel<TW, T>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
@@ -332,7 +332,7 @@ int conv16_dma_applies(const diffsal_conv_desc* d, const float* bias, const floa
     return 0;
   const bool wide = cd_wide(d);
   const int th = wide ? 8 : 16, tw = wide ? 32 : 16;
-  if ((th + 2 * d->dil_h) * (tw + 2 * d->dil_w) * kCdRowB > kCdPatchIss * kCdWaves * 1024) return 0;
+  if ((th + 2 * d->dil_h) * (tw + 2 * d->dil_w) * kCdRowB > kCdPatchIss * kCdWaves * 1024 - 1024) return 0;    // + the scratch KiB
   // Measured against what the planner took before (tools/bench_conv16.py, 4 .. 64 clips): ahead wherever the tiles are not mostly
   // padding (the 9 x 14 extended grid of a 7 x 12 map fills 0.49 of a tile: the generic kernel's flattened rows win) and the
   // launch is not a handful of workgroups with a long K walk (14 x 24 maps of the noise encoder at 4 clips, K = 6912: the generic
