@@ -88,6 +88,48 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
   }
 }
 
+// K1 for many clips (17 .. 64 per call): a LANE is a clip.  The forms above walk the clips one after the other (64-lane butterfly per
+// clip and output feature: 60-90 us per launch at 64 clips for 6 MFLOP); here a wavefront owns one output feature, its 64 lanes the
+// clips, the weight row is wave-uniform (scalar loads) and f(in) sits in LDS transposed [K][65]: one pass over K.
+// Same products; the sum over k runs in k order in one lane instead of 64 partial sums and a butterfly: fp32 rounding differs.
+template <bool EMB>
+__global__ __launch_bounds__(256) void dense_lanes_kernel(const void* __restrict__ t, int t_is_f32, const float* __restrict__ freq,
+                                                          const float* __restrict__ in, int B, int K, int swish_in, int swish_out,
+                                                          const float* __restrict__ w, const float* __restrict__ bias, int N,
+                                                          float* __restrict__ out) {
+  extern __shared__ float sh[];  // f(in)^T [K][65]
+  if constexpr (EMB) {           // in = the sinusoidal embedding of t (sal_unet.py:15-33), K = ch
+    const int half = K / 2;
+    for (int i = threadIdx.x; i < 64 * half; i += 256) {
+      const int j = i >> 6, b = i & 63;
+      float sv = 0.f, cv = 0.f;
+      if (b < B) {
+        const float tv = t_is_f32 ? static_cast<const float*>(t)[b] : static_cast<float>(static_cast<const long long*>(t)[b]);
+        const float a = tv * freq[j];
+        sv = sinf(a); cv = cosf(a);
+      }
+      sh[j * 65 + b] = sv;
+      sh[(half + j) * 65 + b] = cv;
+    }
+    if ((K & 1) && threadIdx.x < 64) sh[(K - 1) * 65 + threadIdx.x] = 0.f;
+  } else {
+    for (int i = threadIdx.x; i < B * K; i += 256) {
+      const int b = i / K, k = i - b * K;
+      const float v = in[i];
+      sh[k * 65 + b] = swish_in ? swishf(v) : v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (n >= N) return;
+  const float* wr = w + static_cast<long>(n) * K;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(wr[k], sh[k * 65 + lane], s);
+  s += bias ? bias[n] : 0.f;
+  if (lane < B) out[static_cast<long>(lane) * N + n] = swish_out ? swishf(s) : s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: conv_in 1 -> C, 3x3, pad 1; NCHW (C=1) in, NHWC out.  R/.../sal_unet.py:240,292
 // A thread owns 4 output channels (its 36 weights stay in registers) and walks over pixels; the
@@ -888,10 +930,21 @@ extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, cons
                                 const float* b0, const float* w1, const float* b1, float* hidden_ws, float* temb_out,
                                 diffsal_stream_t stream) {
   DS_REQUIRE(t && freq && w0 && b0 && w1 && b1 && hidden_ws && temb_out, DIFFSAL_E_ARG, "temb_mlp: null argument");
-  DS_REQUIRE(B > 0 && ch >= 4 && ch <= 1024 && static_cast<long>(B) * ch * 16 <= 64 * 1024, DIFFSAL_E_SHAPE,
-             "temb_mlp: bad shape B=%d ch=%d", B, ch);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tc = 4 * ch;
+  if (B > 16 && B <= 64 && static_cast<size_t>(tc) * 65 * sizeof(float) <= 160 * 1024 && ch >= 4) {     // a lane per clip
+    const size_t l0 = static_cast<size_t>(ch) * 65 * sizeof(float), l1 = static_cast<size_t>(tc) * 65 * sizeof(float);
+    DS_RAISE_DYNAMIC_LDS((dense_lanes_kernel<false>), 160 * 1024);
+    hipLaunchKernelGGL((dense_lanes_kernel<true>), dim3((tc + 3) / 4), dim3(256), l0, s, t, t_is_f32, freq, static_cast<const float*>(nullptr),
+                       B, ch, 0, 1, w0, b0, tc, hidden_ws);
+    int rc = check_launch("temb_mlp(dense0)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((dense_lanes_kernel<false>), dim3((tc + 3) / 4), dim3(256), l1, s, static_cast<const void*>(nullptr), 0,
+                       static_cast<const float*>(nullptr), hidden_ws, B, tc, 0, 0, w1, b1, tc, temb_out);
+    return check_launch("temb_mlp(dense1)");
+  }
+  DS_REQUIRE(B > 0 && ch >= 4 && ch <= 1024 && static_cast<long>(B) * ch * 16 <= 64 * 1024, DIFFSAL_E_SHAPE,
+             "temb_mlp: bad shape B=%d ch=%d", B, ch);
   hipLaunchKernelGGL(temb_dense0_kernel, dim3((tc + 3) / 4), dim3(256), static_cast<size_t>(B) * ch * sizeof(float), s,
                      t, t_is_f32, B, ch, freq, w0, b0, hidden_ws);
   int rc = check_launch("temb_mlp(dense0)");
@@ -904,6 +957,13 @@ extern "C" int diffsal_temb_mlp(const void* t, int t_is_f32, int B, int ch, cons
 extern "C" int diffsal_dense_small(const float* in, int B, int K, int swish_in, const float* w, const float* bias,
                                    int N, float* out, diffsal_stream_t stream) {
   DS_REQUIRE(in && w && out, DIFFSAL_E_ARG, "dense_small: null argument");
+  if (B > 16 && B <= 64 && K > 0 && N > 0 && static_cast<size_t>(K) * 65 * sizeof(float) <= 160 * 1024) {     // a lane per clip
+    DS_RAISE_DYNAMIC_LDS((dense_lanes_kernel<false>), 160 * 1024);
+    hipLaunchKernelGGL((dense_lanes_kernel<false>), dim3((N + 3) / 4), dim3(256), static_cast<size_t>(K) * 65 * sizeof(float),
+                       static_cast<hipStream_t>(stream), static_cast<const void*>(nullptr), 0, static_cast<const float*>(nullptr), in, B, K,
+                       swish_in, 0, w, bias, N, out);
+    return check_launch("dense_small");
+  }
   DS_REQUIRE(B > 0 && K > 0 && N > 0 && static_cast<long>(B) * K * 4 <= 64 * 1024, DIFFSAL_E_SHAPE,
              "dense_small: bad shape B=%d K=%d N=%d", B, K, N);
   hipLaunchKernelGGL(dense_small_kernel, dim3((N + 3) / 4), dim3(256), static_cast<size_t>(B) * K * sizeof(float),

@@ -179,7 +179,8 @@ def temb_mlp(t: Tensor, freq: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Te
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("t must be a contiguous GPU tensor")
     out = torch.empty((2, B, 4 * ch), device=t.device, dtype=torch.float32)  # [0] = hidden scratch, [1] = temb
-    rows = max(1, (64 * 1024) // (16 * ch))       # the kernels keep a [rows, 4 ch] operand in 64 KiB of LDS: larger batches in slices
+    # the kernels keep a [rows, 4 ch] operand in 64 KiB of LDS: larger batches in slices (17 clips and more: a lane per clip, 64 a call)
+    rows = 64 if B > 16 else max(1, (64 * 1024) // (16 * ch))
     with _prof("K1", 2.0 * B * (ch * 4 * ch + 16 * ch * ch), _nb(w0, w1)):
         for s in range(0, B, rows):
             n = min(rows, B - s)
@@ -194,7 +195,7 @@ def dense_small(x: Tensor, w: Tensor, bias: Optional[Tensor], swish_in: bool) ->
     B, K = x.shape
     N = w.shape[0]
     out = torch.empty((B, N), device=x.device, dtype=torch.float32)
-    rows = max(1, (64 * 1024) // (4 * K))         # [rows, K] operand in 64 KiB of LDS: larger batches in slices
+    rows = 64 if B > 16 else max(1, (64 * 1024) // (4 * K))         # [rows, K] operand in 64 KiB of LDS: larger batches in slices
     with _prof("K1", 2.0 * B * K * N, _nb(w, x, out)):
         for s in range(0, B, rows):
             n = min(rows, B - s)

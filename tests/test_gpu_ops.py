@@ -196,6 +196,21 @@ def test_temb_mlp(ops, tdtype):
     assert rel_err(ops.dense_small(got, w.to(DEV), b.to(DEV), True), F.linear(orc.swish(ref), w, b)) < 2e-5
 
 
+@pytest.mark.parametrize("B", [17, 64, 100])
+def test_temb_mlp_many_clips_lane_per_clip_form(ops, B):
+    """K1 at 17+ clips per call (BASELINE configs[4]: 64 clips per GPU): a lane per clip, one pass over K (csrc/misc.hip::dense_lanes_kernel);
+    fractional and integer timesteps, every clip its own."""
+    sd = orc.synth_state_dict(orc.state_dict_template(orc.SalUNetConfig()))
+    t = (torch.arange(B, dtype=torch.float32) * 9.73 + 0.46) % 1000.0
+    ref = orc.temb_mlp(sd, t, 96)
+    freq = torch.exp(torch.arange(48, dtype=torch.float32) * -(math.log(10000) / 47))
+    got = ops.temb_mlp(t.to(DEV), freq.to(DEV), *[sd[k].to(DEV) for k in (
+        "temb.dense.0.weight", "temb.dense.0.bias", "temb.dense.1.weight", "temb.dense.1.bias")])
+    assert got.shape == (B, 384) and rel_err(got, ref) < 2e-5
+    w, b = rnd("tpw", 1344, 384, scale=0.05), rnd("tpb", 1344, scale=0.1)
+    assert rel_err(ops.dense_small(got, w.to(DEV), b.to(DEV), True), F.linear(orc.swish(ref), w, b)) < 2e-5
+
+
 def test_conv_in_and_skip(ops):
     x, w, b = rnd("cix", 2, 1, 24, 40), rnd("ciw", 96, 1, 3, 3, scale=0.3), rnd("cib", 96, scale=0.1)
     ref = nhwc(F.conv2d(x, w, b, padding=1))
