@@ -775,6 +775,116 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
   }
 }
 
+// K11 on 16-bit storage, 16-byte form.  The kernel above gives a (query, head) G lanes of float4 pieces -- 8-byte accesses -- and a
+// workgroup 4 * 64 / G queries: at the coarse stages (head dim 384 / 192, G = 16) that is 16 queries per 55 KB of staged K / V
+// (0.8-1.4 TB/s at 64 clips).  Here a workgroup owns ALL queries of one (image, head): K and V of the head go to LDS once, as fp32 in
+// lane order (conflict-free 16-byte reads); a query's head slice is three octets per lane on G = d / 24 lanes (16-byte loads and
+// stores); a lane group carries TWO queries per pass so that every K / V read from LDS feeds two dot products.
+// Same formulas as attention_kernel (scores * scale, max, exp, normalise, P V), another summation order inside the dot products.
+template <typename T, int G, int LK>
+__global__ __launch_bounds__(256, 2) void attention16_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                             T* __restrict__ o, int Lq, int Lk, int C, int heads, float scale) {
+  extern __shared__ float sh[];  // Kl[Lk][d] | Vl[Lk][d], a row in lane order: [(i * 2 + hf) * G + gl][4] = channels (gl + i G) 8 + hf 4 ..
+  constexpr int QPP = 256 / G;     // lane groups per workgroup
+  const int d = C / heads;
+  float* Kl = sh;
+  float* Vl = sh + Lk * d;
+  const int n = blockIdx.x / heads, hd = blockIdx.x - n * heads;
+  const int cb = hd * d;
+  for (int it = threadIdx.x; it < Lk * (d >> 3); it += 256) {
+    const int t = it / (d >> 3), oc = it - t * (d >> 3);
+    const int i = oc / G, gl = oc - i * G;
+    const f8v kv = ld8(k + (static_cast<long>(n) * Lk + t) * C + cb + oc * 8);
+    const f8v vv = ld8(v + (static_cast<long>(n) * Lk + t) * C + cb + oc * 8);
+    float* kd = Kl + t * d + ((i * 2) * G + gl) * 4;
+    float* vd = Vl + t * d + ((i * 2) * G + gl) * 4;
+    st4(kd, make_float4(kv.v[0], kv.v[1], kv.v[2], kv.v[3])); st4(kd + G * 4, make_float4(kv.v[4], kv.v[5], kv.v[6], kv.v[7]));
+    st4(vd, make_float4(vv.v[0], vv.v[1], vv.v[2], vv.v[3])); st4(vd + G * 4, make_float4(vv.v[4], vv.v[5], vv.v[6], vv.v[7]));
+  }
+  __syncthreads();
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  // the queries of the NEXT pass are requested (raw 16-byte pieces) before this pass is computed: a pass is a dependent chain of
+  // LDS reads and FMAs behind its loads, and a workgroup makes only a handful of passes
+  uint4 nraw[6];
+  auto fetch = [&](int l0) __attribute__((always_inline)) {
+    const int l1 = l0 + QPP < Lq ? l0 + QPP : l0;
+    const T* q0 = q + (static_cast<long>(n) * Lq + l0) * C + cb;
+    const T* q1 = q + (static_cast<long>(n) * Lq + l1) * C + cb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      nraw[i] = *reinterpret_cast<const uint4*>(q0 + (gl + i * G) * 8);
+      nraw[3 + i] = *reinterpret_cast<const uint4*>(q1 + (gl + i * G) * 8);
+    }
+  };
+  if (gr < Lq) fetch(gr);
+  for (int l0 = gr; l0 < Lq; l0 += 2 * QPP) {            // trip count uniform within a lane group
+    const int l1 = l0 + QPP;
+    const bool two = l1 < Lq;
+    float qa[24], qb[24];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const f8v a = ld8(reinterpret_cast<const T*>(&nraw[i])), b = ld8(reinterpret_cast<const T*>(&nraw[3 + i]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qa[i * 8 + e] = a.v[e]; qb[i * 8 + e] = b.v[e]; }
+    }
+    if (l0 + 2 * QPP < Lq) fetch(l0 + 2 * QPP);
+    float sa[LK], sb[LK];
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      sa[t] = 0.f; sb[t] = 0.f;
+      if (t < Lk) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const float4 kk = ld4(Kl + t * d + (p * G + gl) * 4);
+          sa[t] = fmaf(qa[p * 4 + 0], kk.x, fmaf(qa[p * 4 + 1], kk.y, fmaf(qa[p * 4 + 2], kk.z, fmaf(qa[p * 4 + 3], kk.w, sa[t]))));
+          sb[t] = fmaf(qb[p * 4 + 0], kk.x, fmaf(qb[p * 4 + 1], kk.y, fmaf(qb[p * 4 + 2], kk.z, fmaf(qb[p * 4 + 3], kk.w, sb[t]))));
+        }
+      }
+    }
+    float ma = -3.0e38f, mb = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) {
+        sa[t] = group_sum<G>(sa[t]) * scale; ma = fmaxf(ma, sa[t]);
+        sb[t] = group_sum<G>(sb[t]) * scale; mb = fmaxf(mb, sb[t]);
+      }
+    }
+    float suma = 0.f, sumb = 0.f;
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) { sa[t] = expf(sa[t] - ma); suma += sa[t]; sb[t] = expf(sb[t] - mb); sumb += sb[t]; }
+    }
+    const float ia = 1.0f / suma, ib = 1.0f / sumb;
+    float oa[24], ob[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) { oa[j] = 0.f; ob[j] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < LK; ++t) {
+      if (t < Lk) {
+        const float pa = sa[t] * ia, pb = sb[t] * ib;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const float4 vv = ld4(Vl + t * d + (p * G + gl) * 4);
+          oa[p * 4 + 0] = fmaf(pa, vv.x, oa[p * 4 + 0]); oa[p * 4 + 1] = fmaf(pa, vv.y, oa[p * 4 + 1]);
+          oa[p * 4 + 2] = fmaf(pa, vv.z, oa[p * 4 + 2]); oa[p * 4 + 3] = fmaf(pa, vv.w, oa[p * 4 + 3]);
+          ob[p * 4 + 0] = fmaf(pb, vv.x, ob[p * 4 + 0]); ob[p * 4 + 1] = fmaf(pb, vv.y, ob[p * 4 + 1]);
+          ob[p * 4 + 2] = fmaf(pb, vv.z, ob[p * 4 + 2]); ob[p * 4 + 3] = fmaf(pb, vv.w, ob[p * 4 + 3]);
+        }
+      }
+    }
+    T* o0 = o + (static_cast<long>(n) * Lq + l0) * C + cb;
+    T* o1 = o + (static_cast<long>(n) * Lq + l1) * C + cb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f8v a, b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a.v[e] = oa[i * 8 + e]; b.v[e] = ob[i * 8 + e]; }
+      st8(o0 + (gl + i * G) * 8, a);
+      if (two) st8(o1 + (gl + i * G) * 8, b);
+    }
+  }
+}
+
 // K14 tail: per-pixel dot with w[C] + sigmoid; G lanes per pixel.
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -1384,6 +1494,24 @@ extern "C" int diffsal_attention(const void* q, const void* k, const void* v, vo
   DS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), DIFFSAL_E_ALIGN,
              "attention: misaligned pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    // 16-bit storage, head dims 48 .. 384, up to 18 keys: the 16-byte form, one workgroup per (image, head)
+    const int d = C / heads, G = d / 24;
+    const size_t lds16 = static_cast<size_t>(2) * Lk * d * sizeof(float);
+    if (dtype != DIFFSAL_F32 && tune(TUNE_NO_STREAM16) != 1 && d % 24 == 0 && (G == 2 || G == 4 || G == 8 || G == 16) && Lk <= 18 && C % 8 == 0 &&
+        lds16 <= 64 * 1024) {
+      const dim3 grid(static_cast<unsigned>(N * heads));
+#define CALL16(TT, GV) \
+  hipLaunchKernelGGL((attention16_kernel<TT, GV, 18>), grid, dim3(256), lds16, s, static_cast<const TT*>(q), static_cast<const TT*>(k), \
+                     static_cast<const TT*>(v), static_cast<TT*>(o), Lq, Lk, C, heads, scale)
+#define CALL16_G(TT) \
+  do { if (G == 2) CALL16(TT, 2); else if (G == 4) CALL16(TT, 4); else if (G == 8) CALL16(TT, 8); else CALL16(TT, 16); } while (0)
+      if (dtype == DIFFSAL_BF16) CALL16_G(bf16_t); else CALL16_G(f16_t);
+#undef CALL16_G
+#undef CALL16
+      return check_launch("attention(16-bit)");
+    }
+  }
 #define CALL(T) \
   attention_t<T>(static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v), static_cast<T*>(o), N, Lq, Lk, C, heads, scale, s)
   DS_DTYPE_DISPATCH(dtype, "attention", CALL);

@@ -315,3 +315,24 @@ def test_gemm16_dma2_reduce_temp_row_form(ops, dname, Bn, T, HW, C, kt, Co):
     assert torch.equal(got, old)
     ref = torch.relu(torch.einsum("bthc,octu->bho", x[:, :kt].double(), wp.new_tensor(w.to(dt).double().cpu().numpy(), dtype=torch.float64)))
     assert rel_err(got.view(Bn, HW, Co), ref) < OP_RTOL[dname]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("n,Lq,Lk,C,heads", [(3, 84, 18, 768, 2), (2, 336, 18, 384, 2), (2, 100, 18, 192, 2), (2, 77, 5, 96, 2), (1, 33, 18, 384, 4)])
+def test_attention_16_byte_form(ops, dname, n, Lq, Lk, C, heads):
+    """K11 (R/models/saliency_decoder/attention.py:97-108; scale C^-1/2 of the FULL width, quirk Q6): one workgroup per (image, head),
+    K / V in LDS once, two queries per lane group."""
+    import torch.nn.functional as F
+
+    dt = DTYPES[dname]
+    q, k, v = (rnd(nm, n, L, C).to(DEV).to(dt) for nm, L in (("a16q", Lq), ("a16k", Lk), ("a16v", Lk)))
+    scale = C ** -0.5
+    got = ops.attention(q, k, v, heads, scale)
+    with old_forms():
+        old = ops.attention(q, k, v, heads, scale)
+    d = C // heads
+    qh, kh, vh = (t.float().reshape(n, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = (F.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).transpose(1, 2).reshape(n, Lq, C)
+    assert got.dtype == dt and got.shape == ref.shape
+    assert rel_err(got, ref) < OP_RTOL[dname]
+    assert rel_err(got, old.float()) < OP_RTOL[dname]

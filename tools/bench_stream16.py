@@ -71,6 +71,12 @@ def main():
                 ab(f"K9 kv_prep(preln) s{si}", lambda: ops.kv_prep(xk, xn, wk, wv, gs[2], gs[3], gs[4], gs[5], k, 1e-5, pre_ln=(gs[6], gs[7], 1e-6, False)),
                    2 * xn.numel() * es)
             del xk
+        if (not flt or "attn" in flt) and si < 2:
+            N = B * T
+            qq = x.view(N, H * W, C)
+            kk = torch.randn(N, 18, C, device=DEV, generator=g).to(dt)
+            vv = torch.randn(N, 18, C, device=DEV, generator=g).to(dt)
+            ab(f"K11 attention s{si} Lq={H * W} C={C}", lambda: ops.attention(qq, kk, vv, 2, C ** -0.5), 2 * qq.numel() * es + 4 * kk.numel() * es)
         if (not flt or "commute" in flt) and si < 3:
             # UpEmbed conv1 of the NEXT stage at this stage's resolution: source h x w, Cout = C / 2
             Co = C // 2
