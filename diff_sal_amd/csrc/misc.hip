@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q,
 // Same formulas as attention_kernel (scores * scale, max, exp, normalise, P V), another summation order inside the dot products.
 template <typename T, int G, int LK>
 __global__ __launch_bounds__(256, 2) void attention16_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                             T* __restrict__ o, int Lq, int Lk, int C, int heads, float scale) {
+                                                             T* __restrict__ o, int Lq, int Lk, int C, int heads, float scale, int q_chunk) {
   extern __shared__ float sh[];  // Kl[Lk][d] | Vl[Lk][d], a row in lane order: [(i * 2 + hf) * G + gl][4] = channels (gl + i G) 8 + hf 4 ..
   constexpr int QPP = 256 / G;     // lane groups per workgroup
   const int d = C / heads;
@@ -802,12 +802,15 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const T* __restrict
     st4(vd, make_float4(vv.v[0], vv.v[1], vv.v[2], vv.v[3])); st4(vd + G * 4, make_float4(vv.v[4], vv.v[5], vv.v[6], vv.v[7]));
   }
   __syncthreads();
-  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  const int gl = threadIdx.x % G;
+  // blockIdx.y: a chunk of q_chunk queries (few images: the (image, head) pairs alone would leave most CUs idle)
+  const int q_lo = blockIdx.y * q_chunk, q_hi = min(Lq, q_lo + q_chunk);
+  const int gr = q_lo + threadIdx.x / G;
   // the queries of the NEXT pass are requested (raw 16-byte pieces) before this pass is computed: a pass is a dependent chain of
   // LDS reads and FMAs behind its loads, and a workgroup makes only a handful of passes
   uint4 nraw[6];
   auto fetch = [&](int l0) __attribute__((always_inline)) {
-    const int l1 = l0 + QPP < Lq ? l0 + QPP : l0;
+    const int l1 = l0 + QPP < q_hi ? l0 + QPP : l0;
     const T* q0 = q + (static_cast<long>(n) * Lq + l0) * C + cb;
     const T* q1 = q + (static_cast<long>(n) * Lq + l1) * C + cb;
 #pragma unroll
@@ -816,10 +819,10 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const T* __restrict
       nraw[3 + i] = *reinterpret_cast<const uint4*>(q1 + (gl + i * G) * 8);
     }
   };
-  if (gr < Lq) fetch(gr);
-  for (int l0 = gr; l0 < Lq; l0 += 2 * QPP) {            // trip count uniform within a lane group
+  if (gr < q_hi) fetch(gr);
+  for (int l0 = gr; l0 < q_hi; l0 += 2 * QPP) {          // trip count uniform within a lane group
     const int l1 = l0 + QPP;
-    const bool two = l1 < Lq;
+    const bool two = l1 < q_hi;
     float qa[24], qb[24];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) { qa[i * 8 + e] = a.v[e]; qb[i * 8 + e] = b.v[e]; }
     }
-    if (l0 + 2 * QPP < Lq) fetch(l0 + 2 * QPP);
+    if (l0 + 2 * QPP < q_hi) fetch(l0 + 2 * QPP);
     float sa[LK], sb[LK];
 #pragma unroll
     for (int t = 0; t < LK; ++t) {
@@ -1500,10 +1503,15 @@ extern "C" int diffsal_attention(const void* q, const void* k, const void* v, vo
     const size_t lds16 = static_cast<size_t>(2) * Lk * d * sizeof(float);
     if (dtype != DIFFSAL_F32 && tune(TUNE_NO_STREAM16) != 1 && d % 24 == 0 && (G == 2 || G == 4 || G == 8 || G == 16) && Lk <= 18 && C % 8 == 0 &&
         lds16 <= 64 * 1024) {
-      const dim3 grid(static_cast<unsigned>(N * heads));
+      // query chunks: whole passes of 2 * 256 / G queries, as many as it takes to put ~2 workgroups on every CU
+      const int pass_q = 2 * 256 / G, passes = (Lq + pass_q - 1) / pass_q;
+      int chunks = (512 + N * heads - 1) / (N * heads);
+      chunks = chunks < 1 ? 1 : (chunks > passes ? passes : chunks);
+      const int q_chunk = (passes + chunks - 1) / chunks * pass_q;
+      const dim3 grid(static_cast<unsigned>(N * heads), static_cast<unsigned>((Lq + q_chunk - 1) / q_chunk));
 #define CALL16(TT, GV) \
   hipLaunchKernelGGL((attention16_kernel<TT, GV, 18>), grid, dim3(256), lds16, s, static_cast<const TT*>(q), static_cast<const TT*>(k), \
-                     static_cast<const TT*>(v), static_cast<TT*>(o), Lq, Lk, C, heads, scale)
+                     static_cast<const TT*>(v), static_cast<TT*>(o), Lq, Lk, C, heads, scale, q_chunk)
 #define CALL16_G(TT) \
   do { if (G == 2) CALL16(TT, 2); else if (G == 4) CALL16(TT, 4); else if (G == 8) CALL16(TT, 8); else CALL16(TT, 16); } while (0)
       if (dtype == DIFFSAL_BF16) CALL16_G(bf16_t); else CALL16_G(f16_t);

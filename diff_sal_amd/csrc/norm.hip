@@ -689,6 +689,34 @@ __device__ __forceinline__ void store24(T* __restrict__ p, int gl, const float (
   }
 }
 
+// K8 on 16-bit storage with 16-byte accesses: a token of C = 24 G channels on G lanes, three octets per lane (layernorm_kernel
+// above moves 8 bytes per lane there).  Two-pass statistics in registers as everywhere; the sums run in another order.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void layernorm16_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ out, int M, int C, float eps) {
+  constexpr int ROWS = 256 / G;
+  const int gl = threadIdx.x % G, gr = threadIdx.x / G;
+  float g[24], b[24];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int c = (gl + i * G) * 8 + hf * 4, j = i * 8 + hf * 4;
+      const float4 g4 = ld4(gamma + c), b4 = ld4(beta + c);
+      g[j] = g4.x; g[j + 1] = g4.y; g[j + 2] = g4.z; g[j + 3] = g4.w;
+      b[j] = b4.x; b[j + 1] = b4.y; b[j + 2] = b4.z; b[j + 3] = b4.w;
+    }
+  for (long row = static_cast<long>(blockIdx.x) * ROWS + gr; row < M; row += static_cast<long>(gridDim.x) * ROWS) {
+    float v[24];
+    load24<T, G>(x + row * C, gl, v);
+    float mean, rstd;
+    ln24_stats<G>(v, C, eps, mean, rstd);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) v[j] = (v[j] - mean) * rstd * g[j] + b[j];
+    store24<T, G>(out + row * C, gl, v);
+  }
+}
+
 template <typename T, int G, bool PRELN>
 __global__ __launch_bounds__(256, 3) void qkv_prep16_kernel(QkvPrepArgs a) {
   extern __shared__ float sh16[];
@@ -1092,6 +1120,17 @@ static int row_grid(long rows, int rows_per_block) {
 
 template <typename T>
 static int layernorm_t(const T* x, const float* gamma, const float* beta, T* out, int M, int C, float eps, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    const int G = C / 24;
+    if (tune(TUNE_NO_STREAM16) != 1 && C % 24 == 0 && (G == 4 || G == 8 || G == 16 || G == 32)) {
+      int grid = row_grid(M, 256 / G);
+      grid = grid > 4096 ? 4096 : grid;            // each workgroup keeps gamma / beta in registers: a few rows per lane group
+#define CALL16(GV) hipLaunchKernelGGL((layernorm16_kernel<T, GV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, out, M, C, eps)
+      if (G == 4) CALL16(4); else if (G == 8) CALL16(8); else if (G == 16) CALL16(16); else CALL16(32);
+#undef CALL16
+      return check_launch("layernorm(16-bit)");
+    }
+  }
 #define CALL(G, NV) \
   hipLaunchKernelGGL((layernorm_kernel<G, NV, T>), dim3(row_grid(M, 256 / G)), dim3(256), 0, s, x, gamma, beta, out, M, C, eps)
   DS_ROW_DISPATCH(C, CALL);

@@ -422,11 +422,11 @@ def test_qkv_prep_folded_layernorm_16bit(ops, dname, C, H, W, k):
     b = [rnd("fb%d" % i, C, scale=0.2).to(DEV) for i in range(4)]
     from diff_sal_amd import _lib
 
-    normed = ops.layernorm(raw, g[3], b[3], 1e-5)
     # the folded QUERY branch exists in the 4-channel-per-lane form only (SalUNet.fold_norm1, off by default); the 16-byte form of
     # the unfolded launch (csrc/norm.hip::qkv_prep16_kernel) adds in another order and has its own tests (tests/test_gpu_stream16.py)
     _lib.set_tuning("DIFFSAL_NO_STREAM16", 1)
     try:
+        normed = ops.layernorm(raw, g[3], b[3], 1e-5)
         for ln_k in (True, False):
             ref = ops.qkv_prep(normed, w9, g[0], b[0], normed if ln_k else xa, normed, wk, wv, g[1], b[1], g[2], b[2], k)
             got = ops.qkv_prep(raw, w9, g[0], b[0], raw if ln_k else xa, raw, wk, wv, g[1], b[1], g[2], b[2], k,

@@ -336,3 +336,17 @@ def test_attention_16_byte_form(ops, dname, n, Lq, Lk, C, heads):
     assert got.dtype == dt and got.shape == ref.shape
     assert rel_err(got, ref) < OP_RTOL[dname]
     assert rel_err(got, old.float()) < OP_RTOL[dname]
+
+
+@pytest.mark.parametrize("dname", list(DTYPES))
+@pytest.mark.parametrize("M,C", [(3024, 768), (1000, 384), (777, 192), (5000, 96)])
+def test_layernorm_16_byte_form(ops, dname, M, C):
+    """K8 (R/models/saliency_decoder/transformer.py:110,121): three octets per lane."""
+    dt = DTYPES[dname]
+    x = (rnd("ln16x%d" % C, M, C) * 2 + 0.3).to(DEV).to(dt)
+    g, b = (1 + rnd("ln16g", C, scale=0.1)).to(DEV), rnd("ln16b", C, scale=0.1).to(DEV)
+    got = ops.layernorm(x, g, b, 1e-6)
+    with old_forms():
+        old = ops.layernorm(x, g, b, 1e-6)
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), g, b, 1e-6)
+    assert rel_err(got, ref) < OP_RTOL[dname] and rel_err(got, old.float()) < OP_RTOL[dname]

@@ -71,6 +71,9 @@ def main():
                 ab(f"K9 kv_prep(preln) s{si}", lambda: ops.kv_prep(xk, xn, wk, wv, gs[2], gs[3], gs[4], gs[5], k, 1e-5, pre_ln=(gs[6], gs[7], 1e-6, False)),
                    2 * xn.numel() * es)
             del xk
+        if not flt or "ln" in flt:
+            gam, bet = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
+            ab(f"K8 layernorm s{si} C={C}", lambda: ops.layernorm(x, gam, bet, 1e-6), 2 * x.numel() * es)
         if (not flt or "attn" in flt) and si < 2:
             N = B * T
             qq = x.view(N, H * W, C)
