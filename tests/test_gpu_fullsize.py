@@ -106,8 +106,9 @@ def test_dpm_solver_50_nfe_full_size_trajectory(golden_dir, dname):
 
 
 def test_winograd_layers_are_active_at_batch4_and_agree_with_the_direct_kernels(golden_dir):
-    """configs[1]'s real shape: the eight layers the library's planner moves to Winograd F(2x2, 3x3) (six ResnetBlock convolutions,
-    UpEmbed-2 of stages 1 and 2) change the output by transform rounding only -- and they do run (the outputs are not bit-equal)."""
+    """configs[1]'s real shape: the layers the library's planner moves to Winograd -- F(4x4, 3x3) on the six ResnetBlock convolutions,
+    the source-resolution UpEmbed convolutions and UpEmbed-2 of stages 1 - 3 (F(2x2) only where DIFFSAL_NO_WINOGRAD4 asks for it)
+    -- change the output by transform rounding only, and they do run (the outputs are not bit-equal)."""
     cfg, sd, x, t, feats, g = _b4(golden_dir)
     net = build(cfg, sd)
     args = (x.to(DEV), t.to(DEV), [f.to(DEV) for f in feats], None)
