@@ -926,7 +926,8 @@ def main():
         bid = source_id()
     except Exception:  # noqa: BLE001
         bid = None
-    suf = args.precision + ("_av" if av else "")
+    # artefact suffix as tools/profile_round.sh writes it: precision [_b<batch> when not the headline batch of 4] [_av]
+    suf = args.precision + (f"_b{B}" if B != 4 else "") + ("_av" if av else "")
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_hbm_traffic_{suf}.json")) \
         if os.path.isdir(os.path.join(ROOT, "profiles")) else []
     if cands:
@@ -975,7 +976,7 @@ def main():
     if ktab:
         dominant = dict(ktab[0])
         dominant["share_of_step_in_kernel"] = round(dominant["ms_per_step"] / max(common["step_ms_all_kernels"], 1e-9), 4)
-        dominant.update(profiled_kernel(dominant["name"], args.precision, bid))
+        dominant.update(profiled_kernel(dominant["name"], suf, bid))
         dominant["note"] = ("launches / avg_us / tflops measured live with HIP events around the operator launches of one timed step (the library "
                             "names the kernel it launched: diffsal_last_gemm_kernel); profile_avg_us / mfma_busy are read from the same-build "
                             "rocprofv3 artefacts under profiles/ when they exist (SQ_VALU_MFMA_BUSY_CYCLES / all SIMD cycles)")
@@ -1013,7 +1014,7 @@ def main():
             **common}
     else:
         roofline = {
-            "kernel": f"diffsal::igemm16_kernel / igemm16_linear_kernel / conv16_halo_kernel / block16_kernel / block_front_kernel <{args.precision}> "
+            "kernel": f"diffsal::conv16_dma_kernel / gemm16_dma2_kernel / gemm_dma_kernel / igemm16_kernel / block16_kernel / block_front_kernel <{args.precision}> "
                       f"(native 16-bit MFMA GEMM family on {args.precision} storage, fp32 accumulate)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "dominant_kernel": dominant, **common}

@@ -36,7 +36,7 @@ def main():
     fam = (["igemm_kernel", "igemm_linear_kernel", "splitk_reduce_kernel", "lin_stream_kernel", "mlp_block_kernel", "tapsum_kernel",
             "block_front_kernel", "wino_gemm_kernel", "wino_input_kernel", "wino_reduce_kernel", "gemm_dma_kernel",
             "gemm_dma_reduce_kernel"] if prec == "fp32" else
-           ["igemm16_kernel", "igemm16_linear_kernel", "splitk16_reduce_kernel", "conv16_halo_kernel", "block16_kernel",
+           ["igemm16_kernel", "igemm16_linear_kernel", "splitk16_reduce_kernel", "conv16_halo_kernel", "conv16_dma_kernel", "gemm16_dma2_kernel", "block16_kernel",
             "block_front_kernel", "gemm_dma_kernel", "gemm_dma_reduce_kernel"])
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     steps = sum(n for k, (_, n) in fe.items() if "conv_in" in k)    # one conv_in (or fused conv_in_s4) launch per denoising step
