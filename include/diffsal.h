@@ -54,7 +54,10 @@ const char* diffsal_last_gemm_kernel(void);
  * summation order).  The DIFFSAL_* environment variables of the same names are read ONCE when the library is loaded; afterwards
  * only this call changes a switch (value < 0 = unset).  Names: DIFFSAL_NO_PERSIST, DIFFSAL_NO_XCD_ORDER, DIFFSAL_NO_HALO,
  * DIFFSAL_FORCE_HALO, DIFFSAL_IGEMM_CFG, DIFFSAL_IGEMM16_CFG, DIFFSAL_PLAN_DEBUG, DIFFSAL_WGRAD_CFG, DIFFSAL_WGRAD_SPLITS,
- * DIFFSAL_WGRAD_VERBOSE, DIFFSAL_NO_FUSED_BLOCK.  Not part of the reference's surface (it has no such knobs). */
+ * DIFFSAL_WGRAD_VERBOSE, DIFFSAL_NO_FUSED_BLOCK, ... (the full list: kTuneNames in csrc/misc.hip); round 6:
+ * DIFFSAL_NO_STREAM16 = 1 routes 16-bit storage back to the 8-byte forms of the HBM-bound kernels and to the kernels the planner took before
+ * conv16_dma / gemm16_dma2; DIFFSAL_FORCE_HALO = 2 and DIFFSAL_GEMM_DMA16 = 3 take those two on every shape they can run.
+ * Not part of the reference's surface (it has no such knobs). */
 int diffsal_set_tuning(const char* name, int value);
 int diffsal_get_tuning(const char* name);   /* current value, -1 if unset or unknown */
 
