@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
       // buffer from tap 1 on -- so that a fragment read of step g - 1 that is still queued in a busy LDS (hipcc sinks that step's
       // last MFMAs and their lgkmcnt waits below this barrier) cannot meet a DMA: with a three-slot ring and lookahead 2 that
       // happened -- rare wrong tiles with every CU loaded -- and the cure there, lgkmcnt(0) in front of the barrier, cost 5 %
-      if (g == 0) cd_wait_vmcnt<2>(); else cd_wait_vmcnt<3>();
+      // lgkmcnt(10): at most the ten fragment reads of step g - 1 are still on their way -- those of step g - 2, whose buffers the DMAs
+      // below overwrite, have returned whatever the compiler did with that step's MFMAs (LDS operations return in order)
+      if (g == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(10)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       issue_weights(g + 2);
       if (tap >= 1 && tap <= kCdPatchIss) issue_patch(chunk + 1, tap - 1);
