@@ -345,6 +345,144 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(WgradArgs p) {
     }
 }
 
+// Two stages (80 KB: TWO workgroups per CU, one's DMA issue, barriers and slab stores under the other's matrix work) instead of three:
+// one barrier per 32-row step at the step boundary, the next step's pieces issued between this step's MFMAs (a step is 4096 matrix
+// cycles: ample cover for the DMA latency).  Same products and order as wgrad_dma_kernel.
+template <int CT, int WCO, int WK, int ST>
+__global__ __launch_bounds__(256, 2) void wgrad_dma2_kernel(WgradArgs p) {
+  static_assert(WCO * WK == 4, "four waves");
+  constexpr int BM = 32, STAGES = 2;
+  constexpr int BCO = WCO * CT * 32, SL = WK * ST, BKI = SL * 32;
+  constexpr int A_F = BM * BCO, B_F = BM * BKI, STAGE_F = A_F + B_F;          // floats
+  constexpr int APW = A_F / 256 / 4, BPW = B_F / 256 / 4, PPW = APW + BPW;     // 1 KiB pieces per wave and step
+  static_assert(A_F % 1024 == 0 && B_F % 1024 == 0, "whole pieces per wave");
+  __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE_F];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WK, wn = wave % WK;
+  const int co0 = blockIdx.x * BCO;
+  const int sl0 = blockIdx.y * SL;
+  const int n_slices = p.K / 32;
+  const int seg = blockIdx.z / p.splits, sp = blockIdx.z - seg * p.splits;
+  const int m_begin = seg * p.seg_rows + sp * BM;
+  const int m_end = min(p.M, (seg + 1) * p.seg_rows);
+  const int m_stride = p.splits * BM;
+  const int n_steps = m_begin < m_end ? (m_end - m_begin + m_stride - 1) / m_stride : 0;
+
+  const unsigned long pdy = reinterpret_cast<unsigned long>(p.dy), pin = reinterpret_cast<unsigned long>(p.in);
+  const wg_i32x4 rs_dy = {static_cast<int>(pdy), static_cast<int>(pdy >> 32) & 0xFFFF, static_cast<int>(p.dy_bytes), 0x00020000};
+  const wg_i32x4 rs_x = {static_cast<int>(pin), static_cast<int>(pin >> 32) & 0xFFFF, static_cast<int>(p.in_bytes), 0x00020000};
+  // this lane's slot in every piece it issues: (row of the step, byte offset inside the operand's row), ~0 when the column is
+  // outside the matrix
+  int a_row[APW], b_row[BPW];
+  unsigned a_col[APW], b_col[BPW];
+#pragma unroll
+  for (int q = 0; q < APW; ++q) {
+    const int idx = (wave + 4 * q) * 64 + lane;
+    a_row[q] = idx / (BCO / 4);
+    const int c = co0 + (idx - a_row[q] * (BCO / 4)) * 4;
+    a_col[q] = c < p.Cout ? static_cast<unsigned>(c) * 4u : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int q = 0; q < BPW; ++q) {
+    const int idx = (wave + 4 * q) * 64 + lane;
+    b_row[q] = idx / (BKI / 4);
+    const int k = sl0 * 32 + (idx - b_row[q] * (BKI / 4)) * 4;
+    b_col[q] = k < p.K ? static_cast<unsigned>(k) * 4u : 0xFFFFFFFFu;
+  }
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)smem)) + wave * 1024u;
+  int iss_step = 0;
+  auto issue_piece = [&](int stage, int q) __attribute__((always_inline)) {      // q < APW: dY, else X
+    const int mb = m_begin + iss_step * m_stride;
+    const unsigned st = lds_base + static_cast<unsigned>(stage * STAGE_F * 4);
+    if (q < APW) {
+      const int m = mb + a_row[q];
+      const unsigned off = (m < m_end && iss_step < n_steps) ? static_cast<unsigned>(m) * static_cast<unsigned>(p.Cout * 4) + a_col[q] : 0xFFFFFFFFu;
+      wgrad_dma_piece(st + q * 4096u, off | (a_col[q] == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u), rs_dy);
+    } else {
+      const int qb = q - APW;
+      const int m = mb + b_row[qb];
+      const unsigned off = (m < m_end && iss_step < n_steps) ? static_cast<unsigned>(m) * static_cast<unsigned>(p.K * 4) + b_col[qb] : 0xFFFFFFFFu;
+      wgrad_dma_piece(st + (A_F + qb * 1024) * 4u, off | (b_col[qb] == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u), rs_x);
+    }
+  };
+
+  f32x16 acc[CT][ST];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < ST; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_bias = p.dbias != nullptr && blockIdx.y == 0 && tid < BCO;
+  double bias_acc = 0.0;
+
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) issue_piece(0, q);
+  ++iss_step;
+  wgrad_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < n_steps; ++t) {
+    const int stage = t & 1, ist = stage ^ 1;
+    const float* dYs = smem + stage * STAGE_F;
+    const float* Xs = dYs + A_F;
+    if (do_bias) {
+      float s4 = 0.f;
+#pragma unroll
+      for (int r = 0; r < BM; ++r) s4 += dYs[r * BCO + tid];
+      bias_acc += static_cast<double>(s4);
+    }
+    float fa[2][CT], fb[2][ST];
+    auto read_frags = [&](int ks, int set) __attribute__((always_inline)) {
+      const int mrow = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < CT; ++i) fa[set][i] = dYs[mrow * BCO + (wm * CT + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < ST; ++j) fb[set][j] = Xs[mrow * BKI + (wn * ST + j) * 32 + (lane & 31)];
+    };
+    auto mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < ST; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    // the other stage is free (everybody passed the barrier that ended step t - 1): the pieces of step t + 1 go out between this step's
+    // MFMAs and have the whole step to land
+    read_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < BM / 2; ++ks) {
+      if (ks + 1 < BM / 2) read_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+      for (int q = ks * PPW / (BM / 2); q < (ks + 1) * PPW / (BM / 2); ++q) issue_piece(ist, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++iss_step;
+    // this wavefront's pieces of step t + 1 have landed and its reads of this stage have returned; after the barrier everybody's
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (do_bias && co0 + tid < p.Cout) {
+    p.dbias[static_cast<long>(blockIdx.z) * p.Cout + co0 + tid] = bias_acc;
+    if (p.dbias_out && gridDim.z == 1) p.dbias_out[co0 + tid] = static_cast<float>(bias_acc);
+  }
+  float* slab = p.slabs + static_cast<long>(blockIdx.z) * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int j = 0; j < ST; ++j) {
+      const int sl = sl0 + wn * ST + j;
+      if (sl >= n_slices) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * CT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Cout) slab[static_cast<long>(co) * p.K + sl * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    }
+}
+
 // out[seg][i] = sum over the splits of one segment (deterministic: fixed association).  Workgroup = 16 float4 columns x
 // 16 split groups: group g adds splits g, g+16, ... in order, then the 16 group sums are added in order.  (One thread per
 // column walking all splits serially left 9 workgroups with 256-512 dependent steps each on the small token GEMMs.)
@@ -481,7 +619,8 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments, bool one_tap
     // in rounds of 256 (the rounds of 512 of the register-staged kernels gave it twice the splits it can run at once: two rounds of
     // half the length and twice the slab traffic)
     const bool dma = c == 0 && one_tap && tune(TUNE_WGRAD_DMA) != 0;
-    const long slots = dma ? 256 : 512;
+    const bool dma2 = dma && tune(TUNE_WGRAD_DMA) != 1;     // the two-stage form (default): two workgroups per CU; DIFFSAL_WGRAD_DMA=1: the three-stage form
+    const long slots = (dma && !dma2) ? 256 : 512;
     for (int r = 1; r <= (dma ? 16 : 8); ++r) {
       long sp = r * slots / tiles;
       sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
@@ -490,7 +629,7 @@ WgradPlan wgrad_plan(int Cout, long K, long seg_rows, int segments, bool one_tap
       const long rounds = (wgs + slots - 1) / slots;
       const long rps = ((seg_rows + sp - 1) / sp + WG_BM - 1) / WG_BM * WG_BM;
       const double steps = static_cast<double>(rps) / 32.0 + 4.0;   // in 32-row steps
-      const double occ = dma ? 1.0 : (wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0));
+      const double occ = (dma && !dma2) ? 1.0 : (wgs >= 512 ? 2.0 : (wgs > 256 ? 2.0 * wgs / 512.0 : 1.0));
       double t = rounds * occ * steps * step_cycles;
       if (sp > 1) t += 2.0 * sp * segments * Cout * static_cast<double>(K) * 4.0 / 1250.0;
       if (one_tap) {
@@ -523,7 +662,8 @@ int wgrad_launch(WgradArgs a, int segments, float* out, hipStream_t s) {
   if (pl.splits == 1) a.slabs = out;   // one split per segment: the tile goes straight to its destination
   const bool plain = a.taps == 1 && a.stride_h == 1 && a.stride_w == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Ho == a.H && a.Wo == a.W;
   if (plain && pl.cfg == 0 && tune(TUNE_WGRAD_DMA) != 0) {
-    hipLaunchKernelGGL((wgrad_dma_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a);
+    if (tune(TUNE_WGRAD_DMA) != 1) hipLaunchKernelGGL((wgrad_dma2_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_dma_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a);
   } else
   switch (pl.cfg) {
     case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 3>), grid, dim3(256), 0, s, a); break;

@@ -480,9 +480,12 @@ def test_wgrad_dma_kernel_equals_the_register_staged_kernel(M, K, N, tuning):
     dy = orc.synth_tensor("wdy%d" % M, (1, 1, M, N)).to(DEV)
     tuning.set("DIFFSAL_WGRAD_DMA", 0)
     dw0, db0 = ops.conv_wgrad(x, dy, want_bias=True)
-    tuning.set("DIFFSAL_WGRAD_DMA", 1)
+    tuning.set("DIFFSAL_WGRAD_DMA", 1)           # the three-stage form, one workgroup per CU
     dw1, db1 = ops.conv_wgrad(x, dy, want_bias=True)
     assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    tuning.set("DIFFSAL_WGRAD_DMA", 2)           # the two-stage form, two workgroups per CU (round 6; what an unset switch takes)
+    dw2, db2 = ops.conv_wgrad(x, dy, want_bias=True)
+    assert torch.equal(dw0, dw2) and torch.equal(db0, db2)
     ref = dy.reshape(M, N).double().t() @ x.reshape(M, K).double()
     assert (dw1.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
     assert (db1.double() - dy.reshape(M, N).double().sum(0)).abs().max().item() < 1e-4 * (dy.abs().sum(dim=(0, 1, 2)).max().item())

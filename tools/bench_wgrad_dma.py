@@ -20,14 +20,14 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(2)
     print(f"{'M':>7s} {'K':>5s} {'N':>5s} | wgrad_kernel us (TF/s) err | wgrad_dma us (TF/s) err")
-    tot = [0.0, 0.0]
+    tot = [0.0, 0.0, 0.0]
     for M, K, N in SHAPES:
         x = torch.randn(1, 1, M, K, device=dev, generator=g)
         dy = torch.randn(1, 1, M, N, device=dev, generator=g)
         ref = (dy.reshape(M, N).double().t() @ x.reshape(M, K).double())
         scale = ref.abs().max().item()
         res = []
-        for v in (0, 1):
+        for v in (0, 1, 2):
             _lib.set_tuning("DIFFSAL_WGRAD_DMA", v)
             out = ops.conv_wgrad(x, dy)
             dw = out[0] if isinstance(out, (tuple, list)) else out
@@ -48,6 +48,7 @@ def main():
         fl = 2.0 * M * K * N
         tot[0] += res[0][0]
         tot[1] += res[1][0]
+        tot[2] += res[2][0]
         print(f"{M:7d} {K:5d} {N:5d} | " + " | ".join(f"{t:8.1f} ({fl / t / 1e6:5.1f}) {e:.1e}" for t, e in res), flush=True)
     print("sum", tot)
 
