@@ -103,16 +103,22 @@ __global__ __launch_bounds__(256) void up2_conv_commute_kernel(UpCommuteArgs<T> 
 // The interior kernel on 16-bit storage with 16-byte accesses: item = (source pixel, channel OCTET) -- nine 16-byte loads, four
 // 16-byte stores (the form above moves 8 bytes per lane there: 1.5-1.8 TB/s at 64 clips).  Same arithmetic per element.
 template <typename T>
-__global__ __launch_bounds__(256) void up2_conv_commute16_kernel(UpCommuteArgs<T> p) {
+__global__ __launch_bounds__(256) void up2_conv_commute16_kernel(UpCommuteArgs<T> p, int gx, int rows_per_xcd) {
   const int c8n = p.C >> 3;
   const int H2 = 2 * p.h, W2 = 2 * p.w;
   const int row_items = p.w * c8n;
   const long crow = static_cast<long>(p.w + 2) * p.C;
-  for (long row = blockIdx.y; row < static_cast<long>(p.N) * p.h; row += gridDim.y) {
+  // 1-D grid, XCD-aware: workgroup b = 8 slot + xcd takes piece slot % gx of source row xcd * rows_per_xcd + slot / gx -- an XCD owns a
+  // contiguous run of (image, source row) rows, so the three rows of c an output row reads are fetched into ONE L2
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bx = slot % gx;
+  {
+    const long row = static_cast<long>(xcd) * rows_per_xcd + slot / gx;
+    if (slot / gx >= rows_per_xcd || row >= static_cast<long>(p.N) * p.h) return;
     const int n = static_cast<int>(row / p.h), y = static_cast<int>(row - static_cast<long>(n) * p.h);
     const T* cimg = p.c + static_cast<long>(n) * (p.h + 2) * crow;
     T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
-    for (int it = blockIdx.x * 256 + threadIdx.x; it < row_items; it += gridDim.x * 256) {
+    for (int it = bx * 256 + threadIdx.x; it < row_items; it += gx * 256) {
       const int x = it / c8n, co = (it - x * c8n) * 8;
       f8v cc[3][3];
 #pragma unroll
@@ -279,7 +285,13 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring16_kernel(UpCommuteA
   const int full = H2 < 6 ? H2 : 6;
   const int colw = W2 < 6 ? W2 : 6;
   const long crow = static_cast<long>(p.w + 2) * p.C;
-  const int r = blockIdx.x;
+  // 1-D grid, XCD-aware: workgroups are dealt round-robin over the eight XCDs, so workgroup b = 8 slot + xcd takes ring pixel
+  // slot % per_img of image group (slot / per_img) * 8 + xcd -- ALL ring pixels of an image group run on one XCD, whose L2 then holds
+  // that group's tap products and c once (with the pixels spread over the XCDs every L2 fetched every image's 235 KB again)
+  const int per_img_ = full * W2 + (H2 - full) * colw;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int r = slot % per_img_;
+  const int img_group = (slot / per_img_) * 8 + xcd;
   int py, px;
   if (r < full * W2) {
     const int k = r / W2;
@@ -303,7 +315,9 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring16_kernel(UpCommuteA
     sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
     sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
   }
-  for (int n = blockIdx.y * ipw + sub; n < p.N; n += gridDim.y * ipw) {
+  {
+    const int n = img_group * ipw + sub;
+    if (n >= p.N) return;
     const T* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
     const T* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
     const f8v a00 = ld8(cb + (y0 + 1) * crow + static_cast<long>(x0 + 1) * p.C + co);
@@ -392,7 +406,8 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
       if (C % 8 == 0 && tune(TUNE_NO_STREAM16) != 1) {
         int g8 = (w * (C / 8) + 255) / 256;
         g8 = g8 > 64 ? 64 : g8;
-        hipLaunchKernelGGL(up2_conv_commute16_kernel<T>, dim3(g8, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
+        const long rpx = (rows + 7) / 8;                          // rows per XCD
+        hipLaunchKernelGGL(up2_conv_commute16_kernel<T>, dim3(static_cast<unsigned>(8 * rpx * g8)), dim3(256), 0, s, a, g8, static_cast<int>(rpx));
       } else {
         hipLaunchKernelGGL(up2_conv_commute_kernel<T>, dim3(gx, static_cast<unsigned>(rows < 65535 ? rows : 65535)), dim3(256), 0, s, a);
       }
@@ -409,9 +424,11 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
   if constexpr (sizeof(T) == 2) {
     if (C % 8 == 0 && C / 8 <= 256 && tune(TUNE_NO_STREAM16) != 1) {
       const int per_img = full * W2 + (H2 - full) * colw, ipw = 256 / (C / 8);
-      int gy = (N + ipw - 1) / ipw;
-      gy = gy > 4096 ? 4096 : gy;
-      hipLaunchKernelGGL(up2_conv_commute_ring16_kernel<T>, dim3(per_img, gy), dim3(256), 0, s, a);
+      const long groups8 = ((N + ipw - 1) / ipw + 7) / 8 * 8;          // image groups, a multiple of the XCD count
+      if (groups8 * per_img < (1L << 31))
+        hipLaunchKernelGGL(up2_conv_commute_ring16_kernel<T>, dim3(static_cast<unsigned>(groups8 * per_img)), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N < 65535 ? N : 65535), dim3(256), 0, s, a);
       return check_launch("up2_conv_commute(ring, 16-bit)");
     }
   }
