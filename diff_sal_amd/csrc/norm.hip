@@ -733,7 +733,13 @@ __global__ __launch_bounds__(256, 3) void qkv_prep16_kernel(QkvPrepArgs a) {
     T* __restrict__ out = static_cast<T*>(a.oq);
     const int H = a.H, W = a.W;
     const int M = a.N * H * W;
-    for (int row = blockIdx.x * TPB + gr; row < M; row += a.nq * TPB) {
+    // XCD-aware walk (a.nq is a multiple of 8; workgroups are dealt round-robin over the XCDs): XCD x owns a contiguous range of token
+    // chunks, so the rows above and below a token -- W tokens away -- are fetched into the same L2 instead of into three
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = a.nq >> 3;
+    const int n_chunk = (M + TPB - 1) / TPB, cpx = (n_chunk + 7) >> 3;
+    for (int chunk = slot; chunk < cpx; chunk += wpx) {
+      const int row = (xcd * cpx + chunk) * TPB + gr;
+      if (row >= M) continue;
       const int xw = row % W, yh = (row / W) % H;
       float acc[24];
 #pragma unroll
@@ -1248,6 +1254,7 @@ static int qkv_prep_t(QkvPrepArgs a, hipStream_t s) {
         aligned16(a.pg ? a.pg : a.gk)) {
       a.nq = a.oq ? row_grid(rows, 256 / G) : 0;
       if (a.nq > 2048) a.nq = 2048;              // each workgroup stages the filter in LDS: a few passes per workgroup
+      a.nq = (a.nq + 7) / 8 * 8;                 // XCD-aware walk of the query branch
       const size_t lds = static_cast<size_t>(a.C) * sizeof(float) * (a.oq ? 11 : 10);
 #define CALL16(GV)                                                                                                       \
   do {                                                                                                                   \

@@ -198,7 +198,12 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
     for (int ps = 0; ps < NAH; ++ps) mask |= (fetch_pass(tile_, ps, pre[ps]) ? 1u : 0u) << ps;
     return mask;
   };
-  if (AHEAD && static_cast<int>(blockIdx.x) < n_tiles) inside_mask = fetch_tile(blockIdx.x);
+  // XCD-aware tile walk: workgroups are dealt round-robin over the eight XCDs, so virtual tile v = 8 s + xcd is tile xcd * (n_tiles / 8)
+  // + s -- an XCD owns a contiguous run of tiles and the halo rows two neighbouring tiles share are fetched into ONE L2 (a bijection
+  // when both counts are multiples of 8, else the identity)
+  const bool xcd_walk = (n_tiles & 7) == 0 && (gridDim.x & 7) == 0;
+  auto tile_of = [&](int v) { return xcd_walk ? (v & 7) * (n_tiles >> 3) + (v >> 3) : v; };
+  if (AHEAD && static_cast<int>(blockIdx.x) < n_tiles) inside_mask = fetch_tile(tile_of(blockIdx.x));
 
 #ifdef DIFFSAL_DEV_STAMPS
   int stamp_it = 0;
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
 #else
   auto stamp = [](int) {};
 #endif
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int vt = blockIdx.x; vt < n_tiles; vt += gridDim.x) {
+    const int tile = tile_of(vt);
     stamp(0);
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
     const int ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
     __syncthreads();
     stamp(3);
     // the next tile's halo pieces: in flight during phase D
-    if (AHEAD && tile + static_cast<int>(gridDim.x) < n_tiles) inside_mask = fetch_tile(tile + gridDim.x);
+    if (AHEAD && vt + static_cast<int>(gridDim.x) < n_tiles) inside_mask = fetch_tile(tile_of(vt + gridDim.x));
 
     // ---------------- phase D (per wave, transposed): Q^T = Wq q_in^T + bq
     f32x16 qt[NU];
