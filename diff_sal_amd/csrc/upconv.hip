@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void up2_conv_commute16_kernel(UpCommuteArgs<T
 // Border ring: item = (ring pixel, channel quad); ring pixel r of an image: the six full rows first (0, 1, 2, H2-3, H2-2, H2-1),
 // then six columns of each remaining row.
 template <typename T>
-__global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArgs<T> p) {
+__global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArgs<T> p, int gx) {
   const int c4n = p.C >> 2;
   const int H2 = 2 * p.h, W2 = 2 * p.w;
   const int nb = 2 * p.w + 2 * p.h - 4;
@@ -164,11 +164,19 @@ __global__ __launch_bounds__(256) void up2_conv_commute_ring_kernel(UpCommuteArg
   const int colw = W2 < 6 ? W2 : 6;
   const int per_img = full * W2 + (H2 - full) * colw;
   const long crow = static_cast<long>(p.w + 2) * p.C;
-  for (int n = blockIdx.y; n < p.N; n += gridDim.y) {
+  // 1-D grid, XCD-aware (round 6): workgroup b = 8 slot + xcd takes piece slot % gx of image (slot / gx) * 8 + xcd: the gx workgroups of an
+  // image run on ONE XCD, whose L2 holds that image's tap products once
+  const bool walk_ = gx > 0;              // gx < 0: image = blockIdx.x / |gx| in dispatch order (DIFFSAL_NO_XCD_ORDER=1)
+  gx = gx > 0 ? gx : -gx;
+  const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
+  const int bx_ = walk_ ? slot_ % gx : static_cast<int>(blockIdx.x) % gx;
+  {
+  const int n = walk_ ? (slot_ / gx) * 8 + xcd_ : static_cast<int>(blockIdx.x) / gx;
+  if (n >= p.N) return;
   const T* cb = p.c + static_cast<long>(n) * (p.h + 2) * crow;
   const T* tbn = p.tb + static_cast<long>(n) * nb * 9 * p.C;
   T* oimg = p.out + static_cast<long>(n) * H2 * W2 * p.C;
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < per_img * c4n; it += gridDim.x * 256) {
+  for (int it = bx_ * 256 + threadIdx.x; it < per_img * c4n; it += gx * 256) {
     const int r = it / c4n, co = (it - r * c4n) * 4;
     int py, px;
     if (r < full * W2) {
@@ -428,11 +436,11 @@ int up2_commute_t(const void* c_ext, const void* tap_border, const float* scale,
       if (groups8 * per_img < (1L << 31))
         hipLaunchKernelGGL(up2_conv_commute_ring16_kernel<T>, dim3(static_cast<unsigned>(groups8 * per_img)), dim3(256), 0, s, a);
       else
-        hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N < 65535 ? N : 65535), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(static_cast<unsigned>(static_cast<long>(gr) * ((N + 7) / 8 * 8))), dim3(256), 0, s, a, tune(TUNE_NO_XCD_ORDER) == 1 ? -gr : gr);
       return check_launch("up2_conv_commute(ring, 16-bit)");
     }
   }
-  hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(gr, N < 65535 ? N : 65535), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(up2_conv_commute_ring_kernel<T>, dim3(static_cast<unsigned>(static_cast<long>(gr) * ((N + 7) / 8 * 8))), dim3(256), 0, s, a, tune(TUNE_NO_XCD_ORDER) == 1 ? -gr : gr);
   return check_launch("up2_conv_commute");
 }
 }  // namespace

@@ -34,6 +34,7 @@ struct Wino4Geom {
   // extended-grid form (d == 1, padding 2): outputs on (H + 2) x (W + 2), output (oy, ox) = the convolution centred on input
   // (oy - 1, ox - 1) -- the convolution evaluated one pixel beyond the map on every side (diffsal_up2_conv_commute needs it)
   int e, HO, WO;
+  int xcd_walk;        // input transforms: XCD-aware workgroup order (DIFFSAL_NO_XCD_ORDER=1: dispatch order)
 };
 
 __device__ __forceinline__ void wino4_tile_coords(const Wino4Geom& g, int t, int& n, int& y0, int& x0) {
@@ -119,6 +120,15 @@ __device__ __forceinline__ float w4_gn(float x, float a, float b, int sw) { retu
 // GN: the input is read through a per-(image, channel) affine map ab [N][2][Cin] (scale row, shift row: diffsal_gn_affine) and
 // an optional swish -- GroupNorm + nonlinearity without a normalised tensor in memory; the convolution's zero padding applies
 // to the NORMALISED map, so taps outside the image stay exactly zero.
+// XCD-aware workgroup index (round 6): workgroups are dealt round-robin over the eight XCDs; give XCD x the contiguous run of virtual
+// indices that starts at its share, so that the tiles whose 6 x 6 input windows overlap are transformed on ONE XCD and the shared input
+// columns / rows come out of its L2 (a bijection of [0, gridDim.x) for any grid size)
+__device__ __forceinline__ unsigned w4_xcd_block() {
+  const unsigned nwg = gridDim.x, bid = blockIdx.x;
+  const unsigned xcd = bid & 7u, slot = bid >> 3, q = nwg >> 3, r = nwg & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 template <typename VT, bool GN>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, Wino4Geom g,
                                                           const float* __restrict__ ab, int swish) {
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   const int q4n = g.Cin / VW;
   const long items = static_cast<long>(g.n_tiles) * q4n;
   const long pos_stride = static_cast<long>(g.n_tiles) * g.Cin;
-  for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
+  for (long it = static_cast<long>(g.xcd_walk ? w4_xcd_block() : blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
     const int t = static_cast<int>(it / q4n);
     const int q4 = static_cast<int>(it - static_cast<long>(t) * q4n);
     int n, y0, x0;
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256) void wino4_input_up2_kernel(Wino4Up2 u, float*
   const long pos_stride = static_cast<long>(g.n_tiles) * g.Cin;
   const int H2 = g.H, W2 = g.W;                       // = 2 h, 2 w
   const long crow = static_cast<long>(u.w + 2) * g.Cin;
-  for (long it = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
+  for (long it = static_cast<long>(g.xcd_walk ? w4_xcd_block() : blockIdx.x) * 256 + threadIdx.x; it < items; it += static_cast<long>(gridDim.x) * 256) {
     const int t = static_cast<int>(it / q4n);
     const int q4 = static_cast<int>(it - static_cast<long>(t) * q4n);
     int n, y0, x0;
@@ -455,6 +465,7 @@ Wino4Geom wino4_geom(const diffsal_conv_desc* d) {
   Wino4Geom g{};
   g.N = d->N; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Cout = d->Cout; g.d = d->dil_h;
   g.e = d->Ho == d->H + 2 ? 1 : 0;
+  g.xcd_walk = tune(TUNE_NO_XCD_ORDER) == 1 ? 0 : 1;
   g.HO = d->Ho; g.WO = d->Wo;
   g.TY = ((g.HO + g.d - 1) / g.d + 3) / 4;
   g.TX = ((g.WO + g.d - 1) / g.d + 3) / 4;
