@@ -15,7 +15,8 @@ if not hasattr(lib, "diffsal_set_front_stamps"):
     sys.exit("this libdiffsal_hip.so was built without -DDIFFSAL_DEV_STAMPS")
 lib.diffsal_set_front_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 Lk, heads = 18, 2
-for dt, (N, H, W, C) in ((torch.float32, (36, 56, 96, 96)), (torch.bfloat16, (36, 56, 96, 96)), (torch.bfloat16, (36, 28, 48, 192))):
+NB = int(os.environ.get("FRONT_N", "36"))      # images: 36 = 4 clips, 576 = 64 clips
+for dt, (N, H, W, C) in ((torch.float32, (36, 56, 96, 96)), (torch.bfloat16, (NB, 56, 96, 96)), (torch.bfloat16, (NB, 28, 48, 192))):
     r = lambda *s, sc=1.0: torch.randn(*s, device="cuda") * sc
     x, k, v = r(N, H, W, C).to(dt), r(N, Lk, C).to(dt), r(N, Lk, C).to(dt)
     g1, b1, gq, bq, w9 = r(C, sc=0.1) + 1, r(C, sc=0.1), r(C, sc=0.1) + 1, r(C, sc=0.1), r(9, C, sc=0.4)
