@@ -106,6 +106,12 @@ def profiled_kernel(name, precision, bid):
             except Exception:  # noqa: BLE001
                 pass
     key = name.split(" [")[0]
+    # rocprofv3 leaves kernels with _Float16 / __bf16 template arguments mangled: match those on the base name + the type's mangling
+    base = key.split("<")[0]
+    tag = "DF16_" if "_Float16" in key else ("DF16b" if "__bf16" in key else None)
+
+    def matches(text):
+        return key in text or (tag is not None and f"{len(base)}{base}I" in text and tag in text)
     stats = sorted(f for f in os.listdir(pdir) if f.endswith(f"_{precision}_kernel_stats.csv"))
     busy = sorted(f for f in os.listdir(pdir) if f.endswith(f"_pmc_mfma_busy_{precision}.md"))
     notes = []
@@ -114,7 +120,7 @@ def profiled_kernel(name, precision, bid):
         if builds.get(f) == bid:
             import csv
             for row in csv.DictReader(open(os.path.join(pdir, f))):
-                if key in row.get("Name", ""):
+                if matches(row.get("Name", "")):
                     out["profile_avg_us"] = round(float(row["AverageNs"]) / 1e3, 2)
                     break
             notes.append(f"profiles/{f}")
@@ -125,7 +131,7 @@ def profiled_kernel(name, precision, bid):
         txt = open(os.path.join(pdir, f)).read()
         if f"build {bid}" in txt.splitlines()[0]:
             for line in txt.splitlines():
-                if line.startswith("| `") and key in line:
+                if line.startswith("| `") and matches(line):
                     try:
                         out["mfma_busy"] = float(line.rstrip(" |").split("|")[-1])
                     except ValueError:
