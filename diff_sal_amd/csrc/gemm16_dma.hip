@@ -67,12 +67,20 @@ __device__ __forceinline__ void gd_wait_vmcnt() {
 }
 
 
-constexpr int kGdSlot = (256 + 96) * 64 + 0;    // bytes of a ring slot: 256 rows of A, 96 rows of W, one 32-element K chunk
-
-template <typename T>
+// Two tile shapes, four wavefronts each, a wavefront = TM x 3 accumulators of 32 x 32:
+//   <2, 1>  256 x 96: the wavefronts stacked along M (64 rows x 96 columns each);
+//   <3, 2>  192 x 192: the wavefronts 2 x 2 (96 x 96 each).  Per MFMA a wavefront reads (1 / TM + 1 / 3) KiB of fragments from LDS:
+//           0.83 against 0.67 -- at one MFMA per 8 cycles and CU that is 81 % of the LDS's 128 bytes per cycle against 65 %, before the
+//           DMA's own LDS writes -- and a tile's L2 -> LDS bytes per flop are 1 / 256 + 1 / 96 against 2 / 192 (-27 %).
+// A ring slot holds BM rows of A and BN rows of W, one 32-element K chunk (64 bytes) each; (BM + BN) / 16 <= 24 DMA instructions per step,
+// six per wavefront in both shapes.
+template <typename T, int TM, int WN>
 __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
   typedef typename GdMma<T>::vec vec;
-  constexpr int TM = 2, TN = 3, BM = 256, BN = 96;
+  constexpr int TN = 3, WM = 4 / WN, BM = WM * TM * 32, BN = WN * 96;
+  constexpr int kGdSlot = (BM + BN) * 64;
+  constexpr int NA = BM / 64;                     // DMA instruction q of a wavefront: q < NA rows of A, else rows of W
+  static_assert(BM % 64 == 0 && (BM + BN) / 16 <= 24, "six DMA instructions per wavefront and step");
   constexpr unsigned DEAD = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char gd_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
   }
   const int tn = b % p.tiles_n, tm = b / p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((gd_lds_ptr_t)gd_smem));
   const unsigned lds_scratch = lds0 + 3 * kGdSlot;
   const int G = p.K >> 5;
@@ -105,18 +114,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
   const gd_i32x4 rs_a = gd_i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, static_cast<int>(rec_a < 0x7FFFFFFFL ? rec_a : 0x7FFFFFFFL), 0x00020000};
   const unsigned long pw = reinterpret_cast<unsigned long>(p.w + static_cast<long>(n0) * p.K);
   const gd_i32x4 rs_w = gd_i32x4{static_cast<int>(pw), static_cast<int>(pw >> 32) & 0xFFFF, rows_w * p.K * 2, 0x00020000};
-  unsigned a_voff[4], w_voff[2];
+  unsigned a_voff[NA], w_voff[6 - NA];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NA; ++q) {
     const int row = (q * 4 + wave) * 16 + (lane >> 2), ls = (lane & 3) ^ ((row >> 2) & 3);
     a_voff[q] = row < rows_a ? static_cast<unsigned>(row_off(m0 + row) - base_off + ls * 16) : DEAD;
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < 6 - NA; ++q) {
     const int row = (q * 4 + wave) * 16 + (lane >> 2), ls = (lane & 3) ^ ((row >> 2) & 3);
-    w_voff[q] = row < rows_w ? static_cast<unsigned>((row * p.K + ls * 8) * 2) : DEAD;
+    w_voff[q] = row < rows_w ? static_cast<unsigned>((row * p.K + ls * 8) * 2) : DEAD;     // rows past BN (256 x 96: q = 1, waves 2, 3): past rows_w
   }
-  const bool w_live1 = (4 + wave) * 16 < BN;
   const unsigned tap_stride = static_cast<unsigned>(p.Wrow) * p.Cin * 2u;
   auto issue = [&](int g) __attribute__((always_inline)) {             // K chunk g -> slot g % 3
     const bool live = g < G;
@@ -124,9 +132,12 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
     const int ch = g / p.taps, tap = g - ch * p.taps;
     const unsigned soff_a = static_cast<unsigned>(tap) * tap_stride + static_cast<unsigned>(ch) * 64u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gd_dma(live ? dst + (q * 4 + wave) * 1024 : lds_scratch, live ? a_voff[q] : DEAD, rs_a, soff_a);
-    gd_dma(live ? dst + BM * 64 + wave * 1024 : lds_scratch, live ? w_voff[0] : DEAD, rs_w, soff);
-    gd_dma(live && w_live1 ? dst + BM * 64 + (4 + wave) * 1024 : lds_scratch, live && w_live1 ? w_voff[1] : DEAD, rs_w, soff);
+    for (int q = 0; q < NA; ++q) gd_dma(live ? dst + (q * 4 + wave) * 1024 : lds_scratch, live ? a_voff[q] : DEAD, rs_a, soff_a);
+#pragma unroll
+    for (int q = 0; q < 6 - NA; ++q) {
+      const bool in_tile = (q * 4 + wave) * 16 < BN;      // 256 x 96: the second W instruction of wavefronts 2, 3 has no rows
+      gd_dma(live && in_tile ? dst + BM * 64 + (q * 4 + wave) * 1024 : lds_scratch, live && in_tile ? w_voff[q] : DEAD, rs_w, soff);
+    }
   };
 
   // ---- fragment addressing: lane -> row lp of its 32-row MFMA tile, k half kh; logical slot of (kk, kh) = 2 kk + kh
@@ -134,13 +145,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
   int a_off[TM][2], b_off[TN][2];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int row = wave * 64 + i * 32 + lp;
+    const int row = wm * (TM * 32) + i * 32 + lp;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = row * 64 + (((kk * 2 + kh) ^ ((row >> 2) & 3)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int row = j * 32 + lp;
+    const int row = wn * 96 + j * 32 + lp;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = BM * 64 + row * 64 + (((kk * 2 + kh) ^ ((row >> 2) & 3)) << 4);
   }
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
       for (int it = 0; it < 6; ++it) {
         const int item = it * 64 + lane;
         const int rr = item / 12, oc = item - rr * 12;
-        const int n = n0 + oc * 8, m = m0 + wave * 64 + i * 32 + rr;
+        const int n = n0 + wn * 96 + oc * 8, m = m0 + wm * (TM * 32) + i * 32 + rr;
         rraw[it] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint4*>(resid + static_cast<long>(m) * p.N + n) : make_uint4(0, 0, 0, 0);
       }
     }
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma2_kernel(GdArgs<T> p) {
     for (int it = 0; it < 6; ++it) {
       const int item = it * 64 + lane;            // 32 rows x 12 octets
       const int rr = item / 12, oc = item - rr * 12;
-      const int n = n0 + oc * 8, m = m0 + wave * 64 + i * 32 + rr;
+      const int n = n0 + wn * 96 + oc * 8, m = m0 + wm * (TM * 32) + i * 32 + rr;
       const float4 s0 = ld4(stage + rr * 100 + oc * 8), s1 = ld4(stage + rr * 100 + oc * 8 + 4);
       if (m >= p.M || n >= p.N) continue;
       float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -259,7 +270,7 @@ int try_gemm16_dma2(const diffsal_conv_desc* d, const void* a, const void* w, co
                     const float* rowvec, int rowvec_ld, const void* residual, void* out, hipStream_t s, bool out_f32) {
   if (tune(TUNE_NO_STREAM16) == 1 || tune(TUNE_IGEMM16_CFG) >= 0) return 0;
   const int forced = tune(TUNE_GEMM_DMA16);         // 0: off, 3: on every shape it can run (tests); 1 / 2 force gemm_dma.hip's tiles
-  if (forced == 0 || forced == 1 || forced == 2) return 0;
+  if (forced == 0 || forced == 1 || forced == 2) return 0;     // 3 / 4: this kernel's 256 x 96 / 192 x 192 tile on every shape it can run
   const long M = static_cast<long>(d->N) * d->Ho * d->Wo;
   const int K = d->KH * d->KW * d->Cin, N = d->Cout;
   if (d->dtype == DIFFSAL_F32 || d->KW != 1 || d->stride_w != 1 || d->pad_t != 0 || d->pad_l != 0 || d->dil_h != 1 || d->Wo != d->W) return 0;
@@ -275,21 +286,32 @@ int try_gemm16_dma2(const diffsal_conv_desc* d, const void* a, const void* w, co
     return 0;
   if (out_f32 && residual) return 0;
   const long tiles = ((M + 255) / 256) * ((N + 95) / 96);
-  // two workgroups per CU: from a chip's worth of tiles on; below that gemm_dma.hip's 96 x 96 tiles (and their K split) fill it better
-  if (forced != 3 && tiles < 512) return 0;
   if (tiles >= (1L << 31)) return 0;
-  const size_t lds = 3 * kGdSlot + 1024;
-#define GD_LAUNCH(T)                                                                                                        \
+  // 192 x 192 tiles (DIFFSAL_GEMM_DMA16 = 4 forces them, 3 the 256 x 96 ones): from 400 tiles on (measured at 4 .. 64 clips: faster than
+  // both the 256 x 96 tiles and gemm_dma.hip's 96 x 96 ones from ~500 tiles, slower at ~250), unless a quarter of the last tile column
+  // lies past N
+  const long tiles_sq = ((M + 191) / 192) * ((N + 191) / 192);
+  const bool square = forced == 4 || (forced != 3 && tiles_sq >= 400 && ((N + 191) / 192) * 192 - N <= N / 4);
+  // 256 x 96: from a chip's worth of tiles (two workgroups per CU) on; below that gemm_dma.hip's 96 x 96 tiles (and their K split) fill
+  // the chip better
+  if (!square && forced != 3 && tiles < 512) return 0;
+  const int bm = square ? 192 : 256, bn = square ? 192 : 96;
+  const size_t lds = 3 * static_cast<size_t>(bm + bn) * 64 + 1024;
+#define GD_LAUNCH(T, TM_, WN_)                                                                                              \
   do {                                                                                                                      \
     GdArgs<T> g{static_cast<const T*>(a), static_cast<const T*>(w), bias, scale, shift, rowvec, static_cast<const T*>(residual), out, \
-                static_cast<int>(M), N, K, d->act, rowvec_ld, d->Ho * d->Wo, out_f32 ? 1 : 0, static_cast<int>((M + 255) / 256), (N + 95) / 96, \
+                static_cast<int>(M), N, K, d->act, rowvec_ld, d->Ho * d->Wo, out_f32 ? 1 : 0, static_cast<int>((M + bm - 1) / bm), (N + bn - 1) / bn, \
                 rowform ? d->KH : 1, rowform ? d->W : static_cast<int>(M), rowform ? d->H : 1, d->Cin};                        \
-    DS_RAISE_DYNAMIC_LDS((gemm16_dma2_kernel<T>), 160 * 1024);                                                              \
-    hipLaunchKernelGGL((gemm16_dma2_kernel<T>), dim3(static_cast<unsigned>(tiles)), dim3(256), lds, s, g);                   \
+    DS_RAISE_DYNAMIC_LDS((gemm16_dma2_kernel<T, TM_, WN_>), 160 * 1024);                                                    \
+    hipLaunchKernelGGL((gemm16_dma2_kernel<T, TM_, WN_>), dim3(static_cast<unsigned>(g.tiles_m) * g.tiles_n), dim3(256), lds, s, g); \
   } while (0)
-  if (d->dtype == DIFFSAL_BF16) GD_LAUNCH(__bf16); else GD_LAUNCH(_Float16);
+  if (square) {
+    if (d->dtype == DIFFSAL_BF16) GD_LAUNCH(__bf16, 3, 2); else GD_LAUNCH(_Float16, 3, 2);
+  } else {
+    if (d->dtype == DIFFSAL_BF16) GD_LAUNCH(__bf16, 2, 1); else GD_LAUNCH(_Float16, 2, 1);
+  }
 #undef GD_LAUNCH
-  note_kernel("gemm16_dma2_kernel<%s> [256x96 tile, LDS-DMA, 2 workgroups per CU]", d->dtype == DIFFSAL_BF16 ? "__bf16" : "_Float16");
+  note_kernel("gemm16_dma2_kernel<%s> [%dx%d tile, LDS-DMA, 2 workgroups per CU]", d->dtype == DIFFSAL_BF16 ? "__bf16" : "_Float16", bm, bn);
   const int rc = check_launch("diffsal_conv_igemm(16-bit DMA, 2 per CU)");
   return rc == DIFFSAL_OK ? 1 : rc;
 }

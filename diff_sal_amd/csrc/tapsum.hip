@@ -222,12 +222,23 @@ __device__ __forceinline__ void tap_pos(int p, int L, int n, float scale, int& l
   if (!valid) { a = 0.f; b = 0.f; }
 }
 
-template <int CPL, int F>
+// PS: the patch is PS rows x 4 columns of output pixels (PS = 4 or 8; origin a multiple of (PS, 4)): PS + 2 positions and
+// NLY = PS / F + 2 source lines (3 from factor 8 on) on the y axis, 6 positions and NL = 4 / F + 2 columns on the x axis.  The tall
+// patch reads (8 / F + 2)(4 / F + 2) source pixels per source where two 4 x 4 patches read 2 (4 / F + 2)^2: 24 against 32 at factor 2,
+// 12 against 18 at factor 4, 9 against 18 beyond -- the kernel's requests to the L2 were 8x the tap products' bytes (12.8 GB at 64
+// clips: ~10 TB/s, what the L2s deliver), now 5x.  (An 8 x 8 patch -- 3.3x -- needs 192 accumulators and two sets of 54 staging
+// registers: hipcc spills 217-306 of them.)  Same sums in the same order: the extra lines of a position carry weight 0.
+// SX: the two 32-lane halves of the wavefront hold two horizontally adjacent patches of ONE image instead of the same patch of two
+// images: the x-axis weights and column offsets become per-lane values, and the halves' column windows overlap (columns 2, 3 of the left
+// half are columns 0, 1 of the right one at factor 2) in loads issued back to back by one wavefront -- one fetch from the L2.
+template <int CPL, int F, int PS, bool SX>
 __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, unsigned lane_byte, int h, int w, int P, int C, int Y0,
                                                 int X0, int H, int W, float sy, float sx, float* __restrict__ wtab,
-                                                float (&acc)[4][4][CPL]) {
-  constexpr int NL = F == 2 ? 4 : 3;
-  constexpr int PER = F == 2 ? 2 : 3;
+                                                float (&acc)[PS][4][CPL]) {
+  constexpr int NPY = PS + 2;                                  // positions on the y axis
+  constexpr int NL = F == 2 ? 4 : 3;                           // source columns
+  constexpr int NLY = F == 2 ? PS / 2 + 2 : (F == 4 ? PS / 4 + 2 : 3);      // source lines
+  constexpr int NLP = PS == 4 ? 4 : 6;                         // pitch of the vertical weight table
   const int lane = threadIdx.x & 63;
   // ---- x axis: six positions, weights in registers (every lane computes the same values)
   float wxa[6], wxb[6];
@@ -237,23 +248,26 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
     int lower;
     float a, b;
     tap_pos(X0 - 1 + i, W, w, sx, lower, a, b);
-    wxa[i] = uni_f(a);                              // wave-uniform: scalar registers
-    wxb[i] = uni_f(b);
+    wxa[i] = SX ? a : uni_f(a);                     // !SX: wave-uniform, scalar registers
+    wxb[i] = SX ? b : uni_f(b);
     if (i == 0) first_x = lower;
-    xr[i] = uni_i(lower - first_x);                 // F = 2, 4: i / PER by construction; F = 0: 0 or 1
+    xr[i] = SX ? lower - first_x : uni_i(lower - first_x);     // F = 2, 4: (2 i - 1 + F) / (2 F) by construction; F = 0: 0 or 1
   }
-  first_x = uni_i(first_x);
-  unsigned coff[NL];
+  if constexpr (!SX) first_x = uni_i(first_x);
+  unsigned coff[NL];               // !SX: uniform column offset (added to the scalar base); SX: this lane's byte offset, column included
 #pragma unroll
-  for (int c = 0; c < NL; ++c) coff[c] = static_cast<unsigned>(uni_i(min(max(first_x + c, 0), w - 1)) * P * 4);
+  for (int c = 0; c < NL; ++c) {
+    const int col = min(max(first_x + c, 0), w - 1);
+    coff[c] = SX ? lane_byte + static_cast<unsigned>(col * P * 4) : static_cast<unsigned>(uni_i(col) * P * 4);
+  }
   // ---- y axis: dense weights wtab[j * 4 + r] of line r (0 .. NL-1) for position j, one entry per lane
   int first_y;
   {
     float a0, b0;
     tap_pos(Y0 - 1, H, h, sy, first_y, a0, b0);
     first_y = uni_i(first_y);
-    if (lane < 24) {
-      const int j = lane >> 2, r = lane & 3;
+    if (lane < NPY * NLP) {
+      const int j = lane / NLP, r = lane - j * NLP;
       int lower;
       float a, b;
       tap_pos(Y0 - 1 + j, H, h, sy, lower, a, b);
@@ -264,22 +278,24 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
   // it + 1 are issued before item it is summed (two register sets, two items per trip so that the sets swap roles without copies).
   // Measured: a ring of three sets at sub-step (kx) granularity -- a third of the registers, two wavefronts per SIMD instead of
   // one -- is SLOWER (99 against 87 us): what the gather needs is loads in flight, and a whole item ahead is 9-12 of them.
-  constexpr int NIT = 3 * NL;
+  constexpr int NIT = 3 * NLY;
   auto fetch = [&](TapVec<CPL> (&V)[3][NL], int it) __attribute__((always_inline)) {
-    const int ky = it / NL, r = it - ky * NL;
+    const int ky = it / NLY, r = it - ky * NLY;
     const int row = min(max(first_y + r, 0), h - 1);
     const int roff = row * w * P * 4 + ky * 3 * C * 4;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int c = 0; c < NL; ++c)      // the offset IS uniform; inside the runtime loop hipcc no longer proves it: say so
-        V[kx][c] = tap_ld<CPL>(src + static_cast<unsigned>(uni_i(roff + static_cast<int>(coff[c]) + kx * C * 4)), lane_byte);
+      for (int c = 0; c < NL; ++c) {    // the offset IS uniform; inside the runtime loop hipcc no longer proves it: say so
+        if constexpr (SX) V[kx][c] = tap_ld<CPL>(src + static_cast<unsigned>(uni_i(roff + kx * C * 4)), coff[c]);
+        else V[kx][c] = tap_ld<CPL>(src + static_cast<unsigned>(uni_i(roff + static_cast<int>(coff[c]) + kx * C * 4)), lane_byte);
+      }
   };
   auto sum = [&](const TapVec<CPL> (&V)[3][NL], int it) __attribute__((always_inline)) {
-    const int ky = it / NL, r = it - ky * NL;
-    float wv[4];
+    const int ky = it / NLY, r = it - ky * NLY;
+    float wv[PS];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) wv[d] = wtab[(d + ky) * 4 + r];
+    for (int d = 0; d < PS; ++d) wv[d] = wtab[(d + ky) * NLP + r];
     float G[4][CPL];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -293,7 +309,9 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
           if constexpr (F != 0) {
-            G[e][q] = fmaf(wxb[i], V[kx][i / PER + 1].v[q], fmaf(wxa[i], V[kx][i / PER].v[q], G[e][q]));
+            constexpr int F2 = F != 0 ? 2 * F : 1;
+            const int col = (2 * i - 1 + F) / F2;           // the pair's lower column, relative to the first position's
+            G[e][q] = fmaf(wxb[i], V[kx][col + 1].v[q], fmaf(wxa[i], V[kx][col].v[q], G[e][q]));
           } else {          // factor >= 8: the pair of position i starts at column xr[i] in {0, 1}: dense three-column weights
             const float w0 = xr[i] == 0 ? wxa[i] : 0.f, w1 = xr[i] == 0 ? wxb[i] : wxa[i], w2 = xr[i] == 0 ? 0.f : wxb[i];
             G[e][q] = fmaf(w2, V[kx][2].v[q], fmaf(w1, V[kx][1].v[q], fmaf(w0, V[kx][0].v[q], G[e][q])));
@@ -301,7 +319,7 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
         }
       }
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < PS; ++d)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -352,17 +370,18 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
 // IMGS images per wavefront (64 / IMGS lanes each, CPL channels per lane): 2 x 32 lanes x 3 channels for C = 96 keeps every lane
 // busy; 1 x 64 lanes x 2 channels (48 live lanes at C = 96) makes twice as many, lighter wavefronts -- more of them resident per
 // SIMD, more loads in flight (the launch is latency-bound: ~2.6 wavefronts per SIMD in the 2-image form)
-template <int CPL, int IMGS>
+template <int CPL, int IMGS, int PS, bool SX = false>
 __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kernel(TapSumArgs a, int w_patches, long n_items) {
+  static_assert(!SX || IMGS == 2, "SX: the two halves of a wavefront are two patches of one image");
   constexpr int LPI = 64 / IMGS;
-  __shared__ float wtab_all[4][32];
+  __shared__ float wtab_all[4][64];
   const int lane = threadIdx.x & 63, sub = lane / LPI, li = lane % LPI;
   const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u;       // XCD-aware order, as tapsum_kernel
   const unsigned vb = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
   const long item = static_cast<long>(vb) * 4 + (threadIdx.x >> 6);
   if (item >= n_items) return;
   float* wtab = wtab_all[threadIdx.x >> 6];
-  const int h_patches = a.H >> 2;
+  const int h_patches = a.H / PS;
   int px, py, grp;
   if (((w_patches | h_patches) & 1) == 0) {
     // the four wavefronts of a workgroup take a 2 x 2 block of patches (not four in a row): their source windows overlap in rows
@@ -378,13 +397,13 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
     py = static_cast<int>(t % h_patches);
     grp = static_cast<int>(t / h_patches);
   }
-  const int Y0 = uni_i(py * 4), X0 = uni_i(px * 4);
-  const int n = grp * IMGS + sub, c = li * CPL;
+  const int Y0 = uni_i(py * PS), X0 = SX ? (px * 2 + sub) * 4 : uni_i(px * 4);     // SX: w_patches counts 8-pixel patch pairs
+  const int n = SX ? grp : grp * IMGS + sub, c = li * CPL;
   const int nc = n < a.N ? n : a.N - 1, cc = c < a.C ? c : a.C - CPL;   // dead lanes walk valid memory and contribute nothing
   const int P = 9 * a.C;
-  float acc[4][4][CPL];
+  float acc[PS][4][CPL];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < PS; ++d)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -395,9 +414,9 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
     const int f = a.H / hs;
     const char* src = static_cast<const char*>(a.in[s]);
     const unsigned lane_byte = static_cast<unsigned>((static_cast<long>(nc) * hs * ws * P + cc) * 4);     // < 4 GiB: checked by the host
-    if (f == 2) tap_source_rows<CPL, 2>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
-    else if (f == 4) tap_source_rows<CPL, 4>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
-    else tap_source_rows<CPL, 0>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
+    if (f == 2) tap_source_rows<CPL, 2, PS, SX>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
+    else if (f == 4) tap_source_rows<CPL, 4, PS, SX>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
+    else tap_source_rows<CPL, 0, PS, SX>(src, lane_byte, hs, ws, P, a.C, Y0, X0, a.H, a.W, a.sy[s], a.sx[s], wtab, acc);
   }
   float bi[CPL], sc[CPL], sh[CPL], hw[CPL];
 #pragma unroll
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
     hw[q] = c < a.C ? a.head_w[c + q] : 0.f;          // lanes beyond C contribute nothing to the pixel's dot product
   }
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < PS; ++d)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float t2 = 0.f;
@@ -500,20 +519,28 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
   for (int i = 0; i < n_src && rows; ++i)
     rows = H / hs[i] >= 2 && H / hs[i] <= 64 && static_cast<long>(N) * hs[i] * ws[i] * 9 * C * 4 < (1L << 32) - (1L << 20);
   if (rows) {
-    // lane mapping: two images per wavefront (3 or 4 channels per lane: the default), or DIFFSAL_TAPSUM_ROWS_FORM = 2: one image (2
-    // channels per lane, C <= 128: twice the wavefronts at 177 instead of 272 registers).  Measured equal (87-92 us, same box):
-    // neither form is bound by resident wavefronts
-    const int form = tune(TUNE_TAPSUM_ROWS_FORM) == 2 ? 2 : 1;
-    const int imgs = form == 1 ? 2 : 1;
-    const long n_items = static_cast<long>((N + imgs - 1) / imgs) * (H / 4) * (W / 4);
+    // lane mapping (DIFFSAL_TAPSUM_ROWS_FORM): unset -- an 8 x 4 patch per 32-lane half, 3 or 4 channels per lane, the halves of a
+    // wavefront two adjacent patches of one image (H, W multiples of 8), else = 3: the same patch of two images (H a multiple of 8), else
+    // = 1: 4 x 4 patches of two images; = 2: one image per wavefront (2 channels per lane, C <= 128, 4 x 4: twice the wavefronts at 177
+    // instead of 272 registers: measured equal at 4 clips, slower at 64)
+    const int form = tune(TUNE_TAPSUM_ROWS_FORM);
+    const bool tall = form != 1 && form != 2 && H % 8 == 0;
+    const bool sx = tall && form != 3 && W % 8 == 0;
+    const int imgs = form == 2 || sx ? 1 : 2;
+    const int ps = tall ? 8 : 4, pw = sx ? 8 : 4;
+    const long n_items = static_cast<long>((N + imgs - 1) / imgs) * (H / ps) * (W / pw);
     const dim3 grid(static_cast<unsigned>((n_items + 3) / 4));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (form == 2 && C % 2 == 0)
-      hipLaunchKernelGGL((tapsum_head_rows_kernel<2, 1>), grid, dim3(256), 0, st, a, W / 4, n_items);
-    else if (C % 3 == 0 && C / 3 <= 32 && C / 3 > 24)
-      hipLaunchKernelGGL((tapsum_head_rows_kernel<3, 2>), grid, dim3(256), 0, st, a, W / 4, n_items);
-    else
-      hipLaunchKernelGGL((tapsum_head_rows_kernel<4, 2>), grid, dim3(256), 0, st, a, W / 4, n_items);
+    const bool three = C % 3 == 0 && C / 3 <= 32 && C / 3 > 24;
+#define TS_HEAD(...) hipLaunchKernelGGL((tapsum_head_rows_kernel<__VA_ARGS__>), grid, dim3(256), 0, st, a, W / pw, n_items)
+    if (form == 2 && C % 2 == 0) TS_HEAD(2, 1, 4);
+    else if (sx && three) TS_HEAD(3, 2, 8, true);
+    else if (sx) TS_HEAD(4, 2, 8, true);
+    else if (tall && three) TS_HEAD(3, 2, 8);
+    else if (tall) TS_HEAD(4, 2, 8);
+    else if (three) TS_HEAD(3, 2, 4);
+    else TS_HEAD(4, 2, 4);
+#undef TS_HEAD
     return check_launch("tapsum(head)");
   }
   const int slabs = (C + 127) / 128;

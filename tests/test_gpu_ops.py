@@ -494,6 +494,7 @@ def test_tapsum_equals_conv_of_upsampled_sum(ops, case):
 @pytest.mark.parametrize("N,Cout,H,W,factors", [(4, 96, 16, 32, (2, 4)), (3, 32, 20, 24, (2, 4)), (1, 128, 8, 16, (2, 4)),
                                                 (2, 96, 32, 64, (16, 8, 4, 2)),      # mt_proj's four scales
                                                 (3, 96, 64, 64, (32, 16, 8)),         # 2-line sources, odd batch
+                                                (3, 96, 24, 40, (2, 4)),              # H, W multiples of 8: 3 x 5 patch pairs
                                                 (1, 60, 16, 16, (2, 8))])             # 4 channels per lane, 15 live lanes
 def test_tapsum_with_folded_head(ops, tuning, N, Cout, H, W, factors):
     """MLPHead (1x1 to one channel + sigmoid, common_block.py:111-122) in the gather's epilogue == tapsum then head_sigmoid,
@@ -514,6 +515,12 @@ def test_tapsum_with_folded_head(ops, tuning, N, Cout, H, W, factors):
     ref = F.relu(F.conv2d(up, w, b, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
     ref = torch.sigmoid((ref * hw_.cpu()[None, :, None, None]).sum(1) + hb_.cpu())
     assert (one.cpu()[..., 0] - ref).abs().max().item() < 1e-5
+    # the lane mappings of the row-streamed kernel (8 x 4 patches, two of one image or one of two images per wavefront; 4 x 4 patches)
+    # sum the same terms in the same order
+    for form in (1, 3):
+        tuning.set("DIFFSAL_TAPSUM_ROWS_FORM", form)
+        assert torch.equal(one, ops.tapsum(ys, H, W, Cout, head=(hw_, hb_), **kw))
+    tuning.set("DIFFSAL_TAPSUM_ROWS_FORM", None)
     # H, W multiples of 4: the row-streamed head kernel ran; the general gather gives the same map up to summation order
     tuning.set("DIFFSAL_NO_TAPSUM_ROWS", 1)
     gen = ops.tapsum(ys, H, W, Cout, head=(hw_, hb_), **kw)

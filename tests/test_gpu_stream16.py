@@ -237,9 +237,10 @@ GEMM2_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [3, 4], ids=["256x96", "192x192"])
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("case", GEMM2_CASES)
-def test_gemm16_dma2_plain_products(ops, dname, case):
+def test_gemm16_dma2_plain_products(ops, dname, case, tile):
     """csrc/gemm16_dma.hip (R/models/saliency_decoder/attention.py:97-111, common_block.py:125-147 on 16-bit storage), forced on
     small shapes: identical bits to the generic 16-bit kernel without a K split (same MFMA, same K order); fp64 reference."""
     from diff_sal_amd import _lib
@@ -255,13 +256,13 @@ def test_gemm16_dma2_plain_products(ops, dname, case):
 
     def run():
         return ops.linear(x, w, b, act=act, residual=res, out_f32=f32) if f32 else ops.linear(x, w, b, act=act, residual=res)
-    _lib.set_tuning("DIFFSAL_GEMM_DMA16", 3)
+    _lib.set_tuning("DIFFSAL_GEMM_DMA16", tile)
     try:
         got = run()
         name = _lib.load().diffsal_last_gemm_kernel().decode()
     finally:
         _lib.set_tuning("DIFFSAL_GEMM_DMA16", None)
-    assert "gemm16_dma2_kernel" in name
+    assert "gemm16_dma2_kernel" in name and ("192x192" in name) == (tile == 4)
     ref = x.double() @ w.double().t()
     if b is not None:
         ref = ref + b.double()
@@ -286,7 +287,8 @@ def test_gemm16_dma2_plain_products(ops, dname, case):
 
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("Bn,T,HW,C,kt,Co", [(3, 9, 84, 768, 5, 768), (2, 9, 336, 96, 5, 768), (2, 5, 100, 64, 5, 200)])
-def test_gemm16_dma2_reduce_temp_row_form(ops, dname, Bn, T, HW, C, kt, Co):
+@pytest.mark.parametrize("tile", [3, 4], ids=["256x96", "192x192"])
+def test_gemm16_dma2_reduce_temp_row_form(ops, dname, Bn, T, HW, C, kt, Co, tile):
     """ReduceTemp (R/models/saliency_decoder/sal_unet.py:300-318) on 16-bit storage through csrc/gemm16_dma.hip's row form: a (kt, 1)
     kernel over the frame axis that leaves one frame, K ordered (chunk, tap, channel) as the packed weight is."""
     from diff_sal_amd import _lib
@@ -298,7 +300,7 @@ def test_gemm16_dma2_reduce_temp_row_form(ops, dname, Bn, T, HW, C, kt, Co):
 
     def run():
         return ops.conv_igemm(x, wp, kh=kt, kw=1, stride=(kt, 1), act=1)
-    _lib.set_tuning("DIFFSAL_GEMM_DMA16", 3)
+    _lib.set_tuning("DIFFSAL_GEMM_DMA16", tile)
     try:
         got = run()
         assert "gemm16_dma2_kernel" in _lib.load().diffsal_last_gemm_kernel().decode()

@@ -68,7 +68,9 @@ def run(x, w, b, act, res):
 
 def main():
     args = [a for a in sys.argv[1:]]
-    cfgs = [1, 2, 3, 4]     # 16-bit (DMA_DTYPE): 1 / 2 = gemm_dma.hip 96 x 96 / 192 x 192, 3 = gemm16_dma.hip (two workgroups per CU)
+    # 16-bit (DMA_DTYPE): 1 / 2 = gemm_dma.hip 96 x 96 / 192 x 192, 3 / 4 = gemm16_dma.hip 256 x 96 / 192 x 192 (two workgroups per CU);
+    # -1 = the library's own choice (key unset)
+    cfgs = [1, 2, 3, 4]
     rounds = 5
     flt = ""
     i = 0
@@ -111,14 +113,14 @@ def main():
         variants = [0] + cfgs
         errs, times = {}, {v: [] for v in variants}
         for v in variants:
-            _lib.set_tuning(key, v)
+            _lib.set_tuning(key, None if v < 0 else v)
             y = run(x, w, b, act, res)
             torch.cuda.synchronize()
             errs[v] = ((y.double() - ref).abs().max().item()) / scale
         reps = 20
         for _ in range(rounds):
             for v in variants:
-                _lib.set_tuning(key, v)
+                _lib.set_tuning(key, None if v < 0 else v)
                 run(x, w, b, act, res)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
