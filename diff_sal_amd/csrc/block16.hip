@@ -67,8 +67,14 @@ __device__ __forceinline__ int perm32(int q) {
   return 16 * j + 4 * h + (e < 4 ? e : e + 4);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
+// NW wavefronts per workgroup (one workgroup per CU: the weights are staged once).  NW = 8 -- two wavefronts per SIMD, 256 registers
+// each, no next-tile prefetch registers: the chain of a tile is MFMA -> LayerNorm / GELU on the VALU -> MFMA, and a single wavefront per
+// SIMD leaves the matrix pipe idle through the ~100 erf-GELUs per lane (and the VALU idle through the MFMAs and the loads); the second
+// wavefront fills both.
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void block16_kernel(Block16Args<T> p) {
+  constexpr int NT = NW * 64;
+  constexpr bool PREFETCH = NW == 4;
   typedef typename Blk16<T>::vec vec;
   constexpr int C = 96, HID = 192;
   constexpr int P1 = C + 8, P2 = HID + 8;          // LDS row pitches in elements: 208 B and 400 B = odd multiples of 16 B
@@ -78,25 +84,25 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
   T* W2s = W1s + HID * P1;                         // [C][P2]   columns permuted per 32-block
   float* vecs = reinterpret_cast<float*>(W2s + C * P2);   // bp | g2 | be2 | b2 | gz | bez (C each) | b1 (HID)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < C * C; i += 256) { const int r = i / C, c = i - r * C; Wps[r * P1 + c] = p.wp[i]; }
-  for (int i = tid; i < HID * C; i += 256) {
+  for (int i = tid; i < C * C; i += NT) { const int r = i / C, c = i - r * C; Wps[r * P1 + c] = p.wp[i]; }
+  for (int i = tid; i < HID * C; i += NT) {
     const int r = i / C, q = i - r * C;
     W1s[r * P1 + q] = p.w1[r * C + (q & ~31) + perm32(q & 31)];
   }
-  for (int i = tid; i < C * HID; i += 256) {
+  for (int i = tid; i < C * HID; i += NT) {
     const int r = i / HID, q = i - r * HID;
     W2s[r * P2 + q] = p.w2[r * HID + (q & ~31) + perm32(q & 31)];
   }
-  for (int i = tid; i < C; i += 256) {
+  for (int i = tid; i < C; i += NT) {
     vecs[i] = p.bp[i]; vecs[C + i] = p.g2[i]; vecs[2 * C + i] = p.be2[i]; vecs[3 * C + i] = p.b2[i];
     vecs[4 * C + i] = p.z ? p.gz[i] : 0.f; vecs[5 * C + i] = p.z ? p.bez[i] : 0.f;
   }
-  for (int i = tid; i < HID; i += 256) vecs[6 * C + i] = p.b1[i];
+  for (int i = tid; i < HID; i += NT) vecs[6 * C + i] = p.b1[i];
   __syncthreads();
 
   const int ml = lane & 31, hf = lane >> 5;
   const int n_tiles = (p.M + 31) / 32;
-  const int n_waves = gridDim.x * 4;
+  const int n_waves = gridDim.x * NW;
   const T* wpf = Wps + ml * P1 + 8 * hf;           // + 32u*P1 + 16 s      : Wp[c = 32u + ml][k = 16s + 8hf ..]
   const T* w1f = W1s + ml * P1 + 8 * hf;           // + 32t*P1 + 32u + 16j : W1[n = 32t + ml][perm block u, step j]
   const T* w2f = W2s + ml * P2 + 8 * hf;           // + 32u*P2 + 32t + 16j : W2[c = 32u + ml][perm block t, step j]
@@ -139,10 +145,14 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
   // channel of accumulator register r of row tile u for this lane
   auto chan = [&](int u, int r) { return 32 * u + 4 * hf + (r & 3) + 8 * (r >> 2); };
 
-  int tile = blockIdx.x * 4 + wave;
-  if (tile < n_tiles) load_tile(tile, oa, xa);
+  int tile = blockIdx.x * NW + wave;
+  if (PREFETCH && tile < n_tiles) load_tile(tile, oa, xa);
   for (; tile < n_tiles; tile += n_waves) {
-    if (tile + n_waves < n_tiles) load_tile(tile + n_waves, onext, xnext);
+    if constexpr (PREFETCH) {
+      if (tile + n_waves < n_tiles) load_tile(tile + n_waves, onext, xnext);
+    } else {
+      load_tile(tile, oa, xa);
+    }
     // ---- x1^T = Wp o^T + bp + x^T
     f32x16 x1[3];
 #pragma unroll
@@ -167,14 +177,19 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
     // ---- LayerNorm_2 (fp32 statistics over the 96 channels of this lane's token: 48 here + 48 in the partner lane)
     float mean, rstd;
     ln_stats(x1, mean, rstd, p.eps2);
-    f32x16 xn[3];
+    // the normalised activations go straight into the packed B operands of fc1 (24 registers instead of 48 fp32 ones)
+    vec xb[3][2];
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < 3; ++u) {
+      f32x16 xn;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = chan(u, r);
-        xn[u][r] = (x1[u][r] - mean) * rstd * vecs[C + c] + vecs[2 * C + c];
+        xn[r] = (x1[u][r] - mean) * rstd * vecs[C + c] + vecs[2 * C + c];
       }
+      xb[u][0] = b_from(xn, 0);
+      xb[u][1] = b_from(xn, 1);
+    }
     // ---- hidden^T = gelu(W1 xn^T + b1): 6 row tiles, 6 k-steps (3 channel blocks x 2)
     f32x16 hid[6];
 #pragma unroll
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const vec b = b_from(xn[u], j);
+        const vec b = xb[u][j];
 #pragma unroll
         for (int t = 0; t < 6; ++t)
           hid[t] = Blk16<T>::mma(*reinterpret_cast<const vec*>(w1f + 32 * t * P1 + 32 * u + 16 * j), b, hid[t]);
@@ -240,21 +255,32 @@ __global__ __launch_bounds__(256, 1) void block16_kernel(Block16Args<T> p) {
           }
       }
     }
+    if constexpr (PREFETCH) {
 #pragma unroll
-    for (int s = 0; s < 6; ++s) oa[s] = onext[s];
+      for (int s = 0; s < 6; ++s) oa[s] = onext[s];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) xa[i] = xnext[i];
+      for (int i = 0; i < 12; ++i) xa[i] = xnext[i];
+    }
   }
 }
 
 template <typename T>
 static int launch_block16(const Block16Args<T>& a, hipStream_t s) {
   const size_t lds = (static_cast<size_t>(96) * 104 + 192 * 104 + 96 * 200) * sizeof(T) + (6 * 96 + 192) * sizeof(float);
-  DS_RAISE_DYNAMIC_LDS((block16_kernel<T>), 160 * 1024);
   const int n_tiles = (a.M + 31) / 32;
+  // eight wavefronts per workgroup from two tiles per wavefront on (DIFFSAL_BLOCK16_WAVES = 4 / 8 forces)
+  const int forced = tune(TUNE_BLOCK16_WAVES);
+  const bool eight = forced == 8 || (forced != 4 && n_tiles >= 256 * 8 * 2);
   int grid = 256;
-  if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
-  hipLaunchKernelGGL((block16_kernel<T>), dim3(grid), dim3(256), lds, s, a);
+  if (eight) {
+    DS_RAISE_DYNAMIC_LDS((block16_kernel<T, 8>), 160 * 1024);
+    if (grid * 8 > n_tiles) grid = (n_tiles + 7) / 8;
+    hipLaunchKernelGGL((block16_kernel<T, 8>), dim3(grid), dim3(512), lds, s, a);
+  } else {
+    DS_RAISE_DYNAMIC_LDS((block16_kernel<T, 4>), 160 * 1024);
+    if (grid * 4 > n_tiles) grid = (n_tiles + 3) / 4;
+    hipLaunchKernelGGL((block16_kernel<T, 4>), dim3(grid), dim3(256), lds, s, a);
+  }
   return check_launch("block16");
 }
 

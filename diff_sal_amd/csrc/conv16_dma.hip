@@ -72,16 +72,36 @@ __device__ __forceinline__ void cd_wait_vmcnt() {
 
 constexpr int kCdWaves = 4;
 constexpr int kCdRowB = 64;                     // bytes per staged pixel / weight row (one 32-channel chunk)
-constexpr int kCdPatchIss = 7;                  // patch DMA instructions per wavefront and chunk (28 KiB >= the largest patch)
-constexpr int kCdSlotRows = 96;                 // weight rows of a ring slot (the N tile)
 
-// TW: tile width in pixels (32: 8 x 32 tile, a wavefront owns two image rows; 16: 16 x 16 tile, four image rows)
-template <int TW, typename T>
+// Two tile shapes (the LDS of both is exactly 80 KB), four wavefronts, a wavefront = TM x 3 accumulators of 32 x 32:
+//   WN = 1: 256 pixels (8 x 32 or 16 x 16) x 96 channels, the wavefronts stacked over the pixels (64 pixels x 96 channels each); two
+//           28 KB patch buffers, a FOUR-slot ring of 6 KB weight slices;
+//   WN = 2: 192 pixels (8 x 24) x 192 channels, the wavefronts 2 x 2 (96 pixels x 96 channels each): per MFMA a wavefront reads
+//           (1 / 3 + 1 / 3) KiB of fragments from LDS instead of (1 / 2 + 1 / 3) -- with the DMA's own writes the LDS was as busy as the
+//           matrix pipe (49 KB per 384 matrix cycles and workgroup at 128 B per cycle), which is what held these convolutions at 0.55 of
+//           the pipe; now 62 KB per 576 -- and the 8 x 24 tile wastes 12.5 % of a 28 x 48 or 14 x 24 map where 8 x 32 wasted 34 %.
+//           Two 22 KB patch buffers, a THREE-slot ring of 12 KB weight slices.
+template <int WN> struct CdShape {
+  static constexpr int TM = WN == 1 ? 2 : 3;
+  static constexpr int PIX = (kCdWaves / WN) * TM * 32;              // 256 / 192
+  static constexpr int BN = WN * 96;
+  static constexpr int PATCH_ISS = WN == 1 ? 7 : 6;                  // patch DMA instructions per wavefront and chunk
+  static constexpr int PATCH_CAP = WN == 1 ? 28672 : 22528;          // bytes of a patch buffer; its last KiB takes the dead DMAs
+  static constexpr int SLOTS = WN == 1 ? 4 : 3;
+  static constexpr int SLOT_B = BN * kCdRowB;
+  static constexpr int W_ISS = (BN / 16 + kCdWaves - 1) / kCdWaves;  // weight DMA instructions per wavefront and step: 2 / 3
+  static constexpr int LDS = 2 * PATCH_CAP + SLOTS * SLOT_B;         // 81920 both
+};
+
+// TW: tile width in pixels (WN = 1: 32 -- 8 x 32 tile -- or 16 -- 16 x 16; WN = 2: 24 -- 8 x 24)
+template <int TW, int WN, typename T>
 __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   typedef typename CdMma<T>::vec vec;
-  constexpr int TH = 256 / TW;
-  constexpr int RPM = 32 / TW;                     // image rows per 32-pixel MFMA tile
-  constexpr int TM = 2, TN = 3, BN = 96;
+  typedef CdShape<WN> S;
+  constexpr int TM = S::TM, TN = 3, BN = S::BN;
+  constexpr int TH = S::PIX / TW;
+  constexpr int kCdPatchIss = S::PATCH_ISS;
+  static_assert(S::PIX % TW == 0 && S::LDS <= 81920, "tile");
   constexpr unsigned DEAD = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char cd_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -98,14 +118,15 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   const int ty = b % p.tiles_y;
   const int img = b / p.tiles_y;
   const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int d = p.dil;
   const int PH = TH + 2 * d, PW = TW + 2 * d;
   const int patch_bytes = PH * PW * kCdRowB;       // <= 27648
   // LDS: [patch 0][patch 1][weight slot 0..2][scratch KiB]
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((cd_lds_ptr_t)cd_smem));
-  constexpr int PATCH_CAP = kCdPatchIss * kCdWaves * 1024;           // 28672
-  constexpr int SLOT_B = kCdSlotRows * kCdRowB;                      // 8192
-  // dead DMA instructions write zeros into the last KiB of patch buffer 0's 28 KiB, which no patch reaches (host-checked)
+  constexpr int PATCH_CAP = S::PATCH_CAP;
+  constexpr int SLOT_B = S::SLOT_B;
+  // dead DMA instructions write zeros into the last KiB of patch buffer 0, which no patch reaches (host-checked)
   const unsigned lds_w = lds0 + 2 * PATCH_CAP, lds_scratch = lds0 + PATCH_CAP - 1024;
   const int n_chunks = p.Cin >> 5;
   const int G = 9 * n_chunks;
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   const cd_i32x4 rs_a = cd_i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, p.H * p.W * p.Cin * 2, 0x00020000};
   const unsigned long pw = reinterpret_cast<unsigned long>(p.w);
   const cd_i32x4 rs_w = cd_i32x4{static_cast<int>(pw), static_cast<int>(pw >> 32) & 0xFFFF, p.Cout * p.K * 2, 0x00020000};
-  unsigned a_voff[kCdPatchIss], w_voff[2];
+  unsigned a_voff[kCdPatchIss], w_voff[S::W_ISS];
 #pragma unroll
   for (int q = 0; q < kCdPatchIss; ++q) {
     const int idx = (q * kCdWaves + wave) * 64 + lane;
@@ -129,35 +150,40 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
     a_voff[q] = ok ? static_cast<unsigned>(((gy * p.W + gx) * p.Cin + ls * 8) * 2) : DEAD;
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < S::W_ISS; ++q) {
     const int row = (q * kCdWaves + wave) * 16 + (lane >> 2), ls = (lane & 3) ^ ((row >> 2) & 3);
     const bool ok = row < BN && n0 + row < p.Cout;
     w_voff[q] = ok ? static_cast<unsigned>(((n0 + row) * p.K + ls * 8) * 2) : DEAD;
   }
-  const bool w_live1 = (kCdWaves + wave) * 16 < BN;          // the second weight instruction of waves 2 and 3 covers rows >= 96: scratch
   // patch instruction q of chunk c -> buffer c & 1 (instructions past the patch write zeros into their own KiB of the 28 KiB buffer)
   auto issue_patch = [&](int c, int q) __attribute__((always_inline)) {
     const unsigned dst = lds0 + (c & 1) * PATCH_CAP + (q * kCdWaves + wave) * 1024;
-    const bool live = c < n_chunks && (q * kCdWaves + wave) * 1024 < patch_bytes + 1024;
+    const bool live = c < n_chunks && (q * kCdWaves + wave) * 1024 < patch_bytes + 1024 && (q * kCdWaves + wave) * 1024 < PATCH_CAP;
     cd_dma(live ? dst : lds_scratch, live ? a_voff[q] : DEAD, rs_a, static_cast<unsigned>(c) * 64u);
   };
-  auto issue_weights = [&](int g) __attribute__((always_inline)) {       // the slice of step g (chunk g / 9, tap g % 9) -> slot g % 4
+  auto issue_weights = [&](int g) __attribute__((always_inline)) {       // the slice of step g (chunk g / 9, tap g % 9) -> slot g % SLOTS
     const bool live = g < G;
-    const unsigned dst = lds_w + (g & 3) * SLOT_B;
+    const unsigned dst = lds_w + (g % S::SLOTS) * SLOT_B;
     const unsigned soff = static_cast<unsigned>(g) * 64u;      // [Cin / 32][9][32] inside a weight row: step g is 64 bytes further
-    cd_dma(live ? dst + wave * 1024 : lds_scratch, live ? w_voff[0] : DEAD, rs_w, soff);
-    cd_dma(live && w_live1 ? dst + (kCdWaves + wave) * 1024 : lds_scratch, live && w_live1 ? w_voff[1] : DEAD, rs_w, soff);
+#pragma unroll
+    for (int q = 0; q < S::W_ISS; ++q) {
+      const bool in_tile = (q * kCdWaves + wave) * 16 < BN;    // 96 rows: the second instruction of wavefronts 2, 3 has none (scratch)
+      cd_dma(live && in_tile ? dst + (q * kCdWaves + wave) * 1024 : lds_scratch, live && in_tile ? w_voff[q] : DEAD, rs_w, soff);
+    }
   };
 
   // ---- fragment addressing: lane -> pixel lp of its MFMA row tile, k half kh; logical slot of (kk, kh) = 2 kk + kh
   const int lp = lane & 31, kh = lane >> 5;
   int a_pix[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a_pix[i] = ((wave * TM + i) * RPM + lp / TW) * PW + lp % TW;
+  for (int i = 0; i < TM; ++i) {
+    const int t = (wm * TM + i) * 32 + lp;         // pixel of the workgroup's tile, row-major over TH x TW
+    a_pix[i] = (t / TW) * PW + t % TW;
+  }
   int b_off[TN][2];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int row = j * 32 + lp;
+    const int row = wn * 96 + j * 32 + lp;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = row * kCdRowB + (((kk * 2 + kh) ^ ((row >> 2) & 3)) << 4);
   }
@@ -188,15 +214,29 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
       // happened -- rare wrong tiles with every CU loaded -- and the cure there, lgkmcnt(0) in front of the barrier, cost 5 %
       // lgkmcnt(10): at most the ten fragment reads of step g - 1 are still on their way -- those of step g - 2, whose buffers the DMAs
       // below overwrite, have returned whatever the compiler did with that step's MFMAs (LDS operations return in order)
-      if (g == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(10)" ::: "memory");
+      if constexpr (WN == 1) {
+        if (g == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(10)" ::: "memory");
+      } else {
+        // three weight slots: what is issued below lands in the slot read in step g - 1, so every fragment read of that step has to
+        // have returned before the barrier (lgkmcnt(0)); four DMA instructions per wavefront and step (three weight rows, one patch)
+        if (g == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
       issue_weights(g + 2);
-      if (tap >= 1 && tap <= kCdPatchIss) issue_patch(chunk + 1, tap - 1);
+      constexpr int P0 = WN == 1 ? 1 : 0;          // first tap that refills the other patch buffer (WN = 1: reuse distance of two steps)
+      if (tap >= P0 && tap < P0 + kCdPatchIss) issue_patch(chunk + 1, tap - P0);
       else cd_dma(lds_scratch, DEAD, rs_a, 0u);
-      const unsigned char* Bb = cd_smem + 2 * PATCH_CAP + (g & 3) * SLOT_B;
+      const unsigned char* Bb = cd_smem + 2 * PATCH_CAP + (g % S::SLOTS) * SLOT_B;
       const int ky = tap / 3, kx = tap - ky * 3;
       const int toff = ky * d * PW + kx * d;
+      if constexpr (WN == 2) {
+        // keep the per-tap fragment addresses from being hoisted out of the chunk loop (9 taps x 3 row tiles x 2 halves of them: the
+        // kernel spilled); recomputed per step they cost a few VALU instructions under the MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(a_pix[i]));
+      }
       vec fa[2][TM], fb[2][TN];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -235,8 +275,9 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
       for (int it = 0; it < 6; ++it) {
         const int item = it * 64 + lane;
         const int px = item / 12, oc = item - px * 12;
-        const int n = n0 + oc * 8;
-        const int gy = y0 + (wave * TM + i) * RPM + px / TW, gx = x0 + px % TW;
+        const int n = n0 + wn * 96 + oc * 8;
+        const int t = (wm * TM + i) * 32 + px;
+        const int gy = y0 + t / TW, gx = x0 + t % TW;
         rraw[it] = (gy < p.Ho && gx < p.Wo && n < p.Cout)
                        ? *reinterpret_cast<const uint4*>(resid + ((static_cast<long>(img) * p.Ho + gy) * p.Wo + gx) * p.Cout + n)
                        : make_uint4(0, 0, 0, 0);
@@ -252,9 +293,9 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
     for (int it = 0; it < 6; ++it) {
       const int item = it * 64 + lane;            // 32 pixels x 12 octets
       const int px = item / 12, oc = item - px * 12;
-      const int n = n0 + oc * 8;
-      const int mt = wave * TM + i;
-      const int gy = y0 + mt * RPM + px / TW, gx = x0 + px % TW;
+      const int n = n0 + wn * 96 + oc * 8;
+      const int t = (wm * TM + i) * 32 + px;
+      const int gy = y0 + t / TW, gx = x0 + t % TW;
       const float4 s0 = ld4(stage + px * 100 + oc * 8), s1 = ld4(stage + px * 100 + oc * 8 + 4);
       if (gy >= p.Ho || gx >= p.Wo || n >= p.Cout) continue;
       float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -296,25 +337,51 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   }
 }
 
-template <int TW, typename T>
+template <int TW, int WN, typename T>
 static int launch_cd(CdArgs<T>& a, hipStream_t s) {
-  constexpr int TH = 256 / TW;
+  typedef CdShape<WN> S;
+  constexpr int TH = S::PIX / TW;
   a.tiles_x = (a.Wo + TW - 1) / TW;
   a.tiles_y = (a.Ho + TH - 1) / TH;
-  a.tiles_n = (a.Cout + 95) / 96;
-  const size_t lds = 2 * kCdPatchIss * kCdWaves * 1024 + 4 * kCdSlotRows * kCdRowB;       // 81920: exactly two per CU
-  DS_RAISE_DYNAMIC_LDS((conv16_dma_kernel<TW, T>), 160 * 1024);
+  a.tiles_n = (a.Cout + S::BN - 1) / S::BN;
+  const size_t lds = S::LDS;                       // 81920: exactly two per CU
+  DS_RAISE_DYNAMIC_LDS((conv16_dma_kernel<TW, WN, T>), 160 * 1024);
   const long blocks = static_cast<long>(a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
-  hipLaunchKernelGGL((conv16_dma_kernel<TW, T>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
-  note_kernel("conv16_dma_kernel<%d> [%dx%d pixels x 96 channels, LDS-DMA halo, 2 workgroups per CU]", TW, TH, TW);
+  hipLaunchKernelGGL((conv16_dma_kernel<TW, WN, T>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
+  note_kernel("conv16_dma_kernel<%d> [%dx%d pixels x %d channels, LDS-DMA halo, 2 workgroups per CU]", TW, TH, TW, S::BN);
   return check_launch("diffsal_conv_igemm(16-bit DMA halo)");
 }
 
-static bool cd_wide(const diffsal_conv_desc* d) {
-  // 8 x 32 tiles where the width fills them; 16 x 16 where 32 would be mostly padding (14 x 24, 28 x 48 maps)
-  const int w32 = (d->Wo + 31) / 32 * 32, w16 = (d->Wo + 15) / 16 * 16;
-  const int h8 = (d->Ho + 7) / 8 * 8, h16 = (d->Ho + 15) / 16 * 16;
-  return static_cast<long>(w32) * h8 <= static_cast<long>(w16) * h16;
+// the tile of a descriptor: 0 = none, 1 = 8 x 32 x 96, 2 = 16 x 16 x 96, 3 = 8 x 24 x 192
+struct CdPlan { int tile; long blocks; double used; };
+
+static CdPlan cd_plan(const diffsal_conv_desc* d) {
+  auto fill = [&](int th, int tw, int bn, int cap) {
+    CdPlan r{0, 0, 0.0};
+    if ((th + 2 * d->dil_h) * (tw + 2 * d->dil_w) * kCdRowB > cap - 1024) return r;     // the patch + the scratch KiB
+    const long ty = (d->Ho + th - 1) / th, tx = (d->Wo + tw - 1) / tw;
+    r.tile = 1;
+    r.blocks = static_cast<long>(d->N) * ty * tx * ((d->Cout + bn - 1) / bn);
+    r.used = static_cast<double>(d->Ho) * d->Wo / static_cast<double>(ty * th * tx * tw);
+    return r;
+  };
+  // 256-pixel tiles: 8 x 32 where the width fills them; 16 x 16 where 32 would be mostly padding (14 x 24, 28 x 48 maps)
+  const CdPlan w32 = fill(8, 32, 96, CdShape<1>::PATCH_CAP), w16 = fill(16, 16, 96, CdShape<1>::PATCH_CAP);
+  CdPlan best{0, 0, 0.0};
+  if (w32.tile && (!w16.tile || w32.used >= w16.used)) { best = w32; best.tile = 1; }
+  else if (w16.tile) { best = w16; best.tile = 2; }
+  // 192 pixels x 192 channels (DIFFSAL_CONV16_TILE: 0 never, 1 wherever it can run): where its 8 x 24 tiles cover the map better (28 x 48
+  // at dilation 2, 14 x 24: 0.875 against 0.66 -- measured +22-24 %; on maps both cover fully the two shapes are within 3 % of each
+  // other either way: these convolutions run at ~1 PF/s with the chip's clock held down, and fewer LDS reads per MFMA do not change
+  // that), at most a third of the last channel tile empty, the chip still filled twice
+  const int forced = tune(TUNE_CONV16_TILE);
+  CdPlan sq = fill(8, 24, 192, CdShape<2>::PATCH_CAP);
+  if (sq.tile && forced != 0) {
+    const int waste = (d->Cout + 191) / 192 * 192 - d->Cout;
+    const bool ok = forced == 1 || !best.tile || (waste * 3 <= d->Cout && sq.blocks >= 512 && sq.used >= best.used + 0.05);
+    if (ok) { sq.tile = 3; return sq; }
+  }
+  return best;
 }
 
 // 1 if this kernel handles the descriptor (16-bit storage assumed)
@@ -333,17 +400,13 @@ int conv16_dma_applies(const diffsal_conv_desc* d, const float* bias, const floa
   if (!aligned16(out) || !aligned16(residual) || !aligned16(bias) || !aligned16(scale) || !aligned16(shift) || !aligned16(rowvec) ||
       (rowvec && ld % 4 != 0))
     return 0;
-  const bool wide = cd_wide(d);
-  const int th = wide ? 8 : 16, tw = wide ? 32 : 16;
-  if ((th + 2 * d->dil_h) * (tw + 2 * d->dil_w) * kCdRowB > kCdPatchIss * kCdWaves * 1024 - 1024) return 0;    // + the scratch KiB
+  const CdPlan pl = cd_plan(d);
+  if (!pl.tile) return 0;
   // Measured against what the planner took before (tools/bench_conv16.py, 4 .. 64 clips): ahead wherever the tiles are not mostly
   // padding (the 9 x 14 extended grid of a 7 x 12 map fills 0.49 of a tile: the generic kernel's flattened rows win) and the
   // launch is not a handful of workgroups with a long K walk (14 x 24 maps of the noise encoder at 4 clips, K = 6912: the generic
   // kernel splits K over the idle CUs)
-  const long ty = (d->Ho + th - 1) / th, tx = (d->Wo + tw - 1) / tw;
-  const long blocks = static_cast<long>(d->N) * ty * tx * ((d->Cout + 95) / 96);
-  const double used = static_cast<double>(d->Ho) * d->Wo / static_cast<double>(ty * th * tx * tw);
-  return force || (used >= 0.6 && blocks >= 96 && (blocks >= 512 || 9 * d->Cin <= 3456));
+  return force || (pl.used >= 0.6 && pl.blocks >= 96 && (pl.blocks >= 512 || 9 * d->Cin <= 3456));
 }
 
 template <typename T>
@@ -355,7 +418,11 @@ static int run_cd(const diffsal_conv_desc* d, const void* in, const void* w, con
   a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.Cin = d->Cin; a.Cout = d->Cout; a.K = 9 * d->Cin;
   a.dil = d->dil_h; a.pad = d->pad_t; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
-  return cd_wide(d) ? launch_cd<32, T>(a, s) : launch_cd<16, T>(a, s);
+  switch (cd_plan(d).tile) {
+    case 1: return launch_cd<32, 1, T>(a, s);
+    case 2: return launch_cd<16, 1, T>(a, s);
+    default: return launch_cd<24, 2, T>(a, s);
+  }
 }
 
 int conv16_dma_launch(const diffsal_conv_desc* d, const void* in, const void* w, const float* bias, const float* scale,

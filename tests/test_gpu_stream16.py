@@ -168,9 +168,10 @@ CONV_DMA_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [0, 1], ids=["256x96", "192x192"])
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("case", CONV_DMA_CASES)
-def test_conv16_dma_halo_kernel(ops, dname, case):
+def test_conv16_dma_halo_kernel(ops, dname, case, tile):
     """csrc/conv16_dma.hip (R/models/saliency_decoder/common_block.py:196-216, sal_unet.py:104-142 on 16-bit storage): forced on
     shapes of a few tiles, against the generic 16-bit implicit-GEMM kernel -- same accumulation order, identical bits -- and
     against F.conv2d on the rounded operands."""
@@ -198,12 +199,14 @@ def test_conv16_dma_halo_kernel(ops, dname, case):
         return ops.conv_igemm(xn, wp, kh=3, kw=3, pad=(pad, pad), dil=(dil, dil), out_hw=(Ho, Wo), bias=dv(bias), scale=dv(scale),
                               shift=dv(shift), rowvec=dv(rowvec), residual=rn, act=act)
     _lib.set_tuning("DIFFSAL_FORCE_HALO", 2)
+    _lib.set_tuning("DIFFSAL_CONV16_TILE", tile)
     try:
         got = run()
         name = _lib.load().diffsal_last_gemm_kernel().decode()
     finally:
         _lib.set_tuning("DIFFSAL_FORCE_HALO", None)
-    assert "conv16_dma_kernel" in name
+        _lib.set_tuning("DIFFSAL_CONV16_TILE", None)
+    assert "conv16_dma_kernel" in name and ("x 192 channels" in name) == (tile == 1)
     # the generic kernel on one fixed tile shape WITHOUT a K split (its split sums the K ranges in another order)
     _lib.set_tuning("DIFFSAL_NO_HALO", 1)
     _lib.set_tuning("DIFFSAL_IGEMM16_CFG", 0)
