@@ -289,9 +289,10 @@ int try_gemm16_dma2(const diffsal_conv_desc* d, const void* a, const void* w, co
   if (tiles >= (1L << 31)) return 0;
   // 192 x 192 tiles (DIFFSAL_GEMM_DMA16 = 4 forces them, 3 the 256 x 96 ones): from 400 tiles on (measured at 4 .. 64 clips: faster than
   // both the 256 x 96 tiles and gemm_dma.hip's 96 x 96 ones from ~500 tiles, slower at ~250), unless a quarter of the last tile column
-  // lies past N
+  // lies past N -- or any of it on a short K walk (N = 864, K = 192: 70 -> 78 us; K = 768: 1006 -> 885)
   const long tiles_sq = ((M + 191) / 192) * ((N + 191) / 192);
-  const bool square = forced == 4 || (forced != 3 && tiles_sq >= 400 && ((N + 191) / 192) * 192 - N <= N / 4);
+  const int n_waste = ((N + 191) / 192) * 192 - N;
+  const bool square = forced == 4 || (forced != 3 && tiles_sq >= 400 && (n_waste == 0 || (n_waste <= N / 4 && K >= 384)));
   // 256 x 96: from a chip's worth of tiles (two workgroups per CU) on; below that gemm_dma.hip's 96 x 96 tiles (and their K split) fill
   // the chip better
   if (!square && forced != 3 && tiles < 512) return 0;

@@ -27,6 +27,7 @@ struct TapSumArgs {
   const void* in[4];   // Y_i: [N, h_i, w_i, 9 * C] (tap-major channel blocks), storage type of the launch
   int h[4], w[4];
   float sy[4], sx[4];
+  int lf[4];           // log2 of the factor H / h (head kernels: every factor is a power of two)
   int n_in;
   const float* bias;   // per output channel, any of the three may be null
   const float* scale;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void tapsum_kernel(TapSumArgs a, T* __restrict
 // CPL channels per lane: 3 when C = 96 (all 32 lanes of an image's half-wave busy), else 4.
 // ------------------------------------------------------------------------------------------------
 template <int CPL> struct TapVec { float v[CPL]; };
+
 // uniform base (scalar registers) + this lane's 32-bit byte offset: addressed by the hardware as saddr + voffset
 template <int CPL>
 __device__ __forceinline__ TapVec<CPL> tap_ld(const char* ubase, unsigned lane_byte) {
@@ -371,7 +373,7 @@ __device__ __forceinline__ void tap_source_rows(const char* __restrict__ src, un
 // busy; 1 x 64 lanes x 2 channels (48 live lanes at C = 96) makes twice as many, lighter wavefronts -- more of them resident per
 // SIMD, more loads in flight (the launch is latency-bound: ~2.6 wavefronts per SIMD in the 2-image form)
 template <int CPL, int IMGS, int PS, bool SX = false>
-__global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kernel(TapSumArgs a, int w_patches, long n_items) {
+__global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kernel(TapSumArgs a, int w_patches, long n_items, int row_map) {
   static_assert(!SX || IMGS == 2, "SX: the two halves of a wavefront are two patches of one image");
   constexpr int LPI = 64 / IMGS;
   __shared__ float wtab_all[4][64];
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
   float* wtab = wtab_all[threadIdx.x >> 6];
   const int h_patches = a.H / PS;
   int px, py, grp;
-  if (((w_patches | h_patches) & 1) == 0) {
+  if (!row_map && ((w_patches | h_patches) & 1) == 0) {
     // the four wavefronts of a workgroup take a 2 x 2 block of patches (not four in a row): their source windows overlap in rows
     // AND columns, and they run on one CU -- one L1
     const long blk = item >> 2;
@@ -426,6 +428,8 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
     sh[q] = a.scale ? a.shift[cc + q] : 0.f;
     hw[q] = c < a.C ? a.head_w[c + q] : 0.f;          // lanes beyond C contribute nothing to the pixel's dot product
   }
+  float hb = a.head_b[0];                             // read once and pinned (see tapsum_head_lds_kernel)
+  asm volatile("" : "+v"(hb));
 #pragma unroll
   for (int d = 0; d < PS; ++d)
 #pragma unroll
@@ -438,7 +442,264 @@ __global__ __launch_bounds__(256, IMGS == 1 ? 2 : 1) void tapsum_head_rows_kerne
         t2 = fmaf(v, hw[q], t2);
       }
       t2 = group_sum<LPI>(t2);
-      if (li == 0 && n < a.N) a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t2 + a.head_b[0]);
+      if (li == 0 && n < a.N) a.head_out[(static_cast<long>(n) * a.H + Y0 + d) * a.W + X0 + e] = sigmoidf_(t2 + hb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mt_proj form, source lines staged in LDS by the whole workgroup.
+//
+// tapsum_head_rows_kernel is one wavefront per SIMD (400 registers) that waits a full memory latency for every (ky, line) item, and
+// its patches re-read their neighbours' source pixels from the L2: at 64 clips 5x the tap products' bytes at the ~10 TB/s the L2s
+// deliver -- both limits at once.  Here a workgroup (4 wavefronts, 2 x 2, a wavefront = two adjacent 8 x 4 patches as above) owns a
+// 16 x 16 block of one image and walks the flattened (source, ky, line) items of the BLOCK's window -- 16 / f + 2 lines of 16 / f + 2
+// source pixels x 3 taps x C fp32 (11.5 KB at factor 2) -- through a six-slot LDS ring filled by LDS-DMA four items ahead (three
+// 1 KiB instructions per wavefront and item, the 1152 contiguous bytes of a pixel's three kx taps as 72 pieces; lanes past the window
+// re-read its last column): every source pixel of the window crosses the L2 -> CU path once per block (1.9x the tap products' bytes
+// instead of 5x), the latency is covered by the ring instead of by registers, and at 170 registers two workgroups share a CU.  A
+// wavefront multiplies the lines of an item that its own 8 rows touch (6 of 10 at factor 2) and skips the others -- they carried
+// weight 0 in the row-streamed kernel: same sums, same order, same bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTlSlot = 12288, kTlDepth = 6;
+typedef int tl_i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* tl_lds_ptr_t;
+
+__device__ __forceinline__ void tl_dma(unsigned lds_addr, unsigned voff, tl_i32x4 rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+
+// one (ky, line) item of this wavefront: slot = the staged line (pixel-major: [column][3 kx][C] fp32), rl = the line's index among the
+// wavefront's own lines, col0 = this lane half's first column in the block's window, ncb = the window's columns
+template <int CPL, int F>
+__device__ __forceinline__ void tl_item(const float* __restrict__ slot, int ky, int rl, int col0, int ncb, int C, int li,
+                                        const float* __restrict__ wtab, const float (&wxa)[6], const float (&wxb)[6], const int (&xr)[6],
+                                        float (&acc)[8][4][CPL]) {
+  constexpr int NL = F == 2 ? 4 : 3;
+  float wv[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) wv[d] = wtab[(d + ky) * 6 + rl];
+  float G[4][CPL];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) G[e][q] = 0.f;
+  int cidx[NL];
+#pragma unroll
+  for (int c = 0; c < NL; ++c) cidx[c] = min(col0 + c, ncb - 1) * 3 * C + li * CPL;   // a column past the window carries weight 0
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    float V[NL][CPL];
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) V[c][q] = slot[cidx[c] + kx * C + q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = e + kx;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        if constexpr (F != 0) {
+          constexpr int F2 = F != 0 ? 2 * F : 1;
+          const int col = (2 * i - 1 + F) / F2;
+          G[e][q] = fmaf(wxb[i], V[col + 1][q], fmaf(wxa[i], V[col][q], G[e][q]));
+        } else {
+          const float w0 = xr[i] == 0 ? wxa[i] : 0.f, w1 = xr[i] == 0 ? wxb[i] : wxa[i], w2 = xr[i] == 0 ? 0.f : wxb[i];
+          G[e][q] = fmaf(w2, V[2][q], fmaf(w1, V[1][q], fmaf(w0, V[0][q], G[e][q])));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) acc[d][e][q] = fmaf(wv[d], G[e][q], acc[d][e][q]);
+}
+
+// tap_pos for a power-of-two factor 2^lf (no integer division)
+__device__ __forceinline__ void tap_pos2(int p, int L, int n, float scale, int lf, int& lower, float& a, float& b) {
+  const bool valid = p >= 0 && p < L;
+  int i0, i1;
+  float l1;
+  bilin_coord(valid ? p : 0, scale, n, i0, i1, l1);
+  const int num = 2 * p + 1 - (1 << lf);
+  lower = num >= 0 ? num >> (lf + 1) : -1;
+  a = 1.f - l1;
+  b = l1;
+  if (lower < 0) { a = 0.f; b = 1.f; }
+  if (!valid) { a = 0.f; b = 0.f; }
+}
+
+// the DMA side's position: which item of which source goes out next (the ring runs on across sources: while the last items of a source
+// are multiplied, the first items of the next one are already on their way)
+struct TlIssue {
+  unsigned voff[3];     // this lane's three pieces of a line: byte offset of (window column, piece)
+  tl_i32x4 rsrc;        // the source's image n
+  int s, bfy, hs, ws, nlb, iky, ir, slot;
+  bool done;            // the source's last item has gone out
+};
+
+template <int C>
+__device__ __forceinline__ void tl_issue_setup(const TapSumArgs& a, TlIssue& st, int s, int n, int BY, int BX) {
+  constexpr int P = 9 * C, PPC = 3 * C / 4;
+  const int tid = threadIdx.x;
+  st.s = s;
+  st.hs = a.h[s]; st.ws = a.w[s];
+  st.nlb = max(16 >> a.lf[s], 1) + 2;                          // lines and columns of the block's window
+  int lo; float aa, bb;
+  tap_pos2(BY - 1, a.H, st.hs, a.sy[s], a.lf[s], lo, aa, bb);
+  st.bfy = uni_i(lo);
+  tap_pos2(BX - 1, a.W, st.ws, a.sx[s], a.lf[s], lo, aa, bb);
+  const int bfx = uni_i(lo);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int pc = q * 256 + tid;
+    const int ci = pc / PPC, j = pc - ci * PPC;
+    const int col = min(max(bfx + min(ci, st.nlb - 1), 0), st.ws - 1);
+    st.voff[q] = static_cast<unsigned>(col * P * 4 + j * 16);
+  }
+  const unsigned long base = reinterpret_cast<unsigned long>(a.in[s]) + static_cast<unsigned long>(n) * st.hs * st.ws * P * 4ul;
+  st.rsrc = tl_i32x4{static_cast<int>(base), static_cast<int>(base >> 32) & 0xFFFF, st.hs * st.ws * P * 4, 0x00020000};
+  st.iky = 0; st.ir = 0; st.done = false;
+}
+
+// one item (three DMA instructions per wavefront) into the ring's next slot; past a source's last item: that item again (into a free slot)
+template <int C>
+__device__ __forceinline__ void tl_issue_one(TlIssue& st, unsigned lds0, int wave) {
+  constexpr int P = 9 * C;
+  const int line = min(max(st.bfy + st.ir, 0), st.hs - 1);
+  const unsigned soff = static_cast<unsigned>(line * st.ws * P * 4 + st.iky * 3 * C * 4);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) tl_dma(lds0 + st.slot * kTlSlot + (q * 4 + wave) * 1024, st.voff[q], st.rsrc, soff);
+  st.slot = st.slot + 1 == kTlDepth ? 0 : st.slot + 1;
+  const bool wrap = st.ir + 1 == st.nlb, last = wrap && st.iky == 2;
+  st.done = st.done || last;
+  st.ir = last ? st.ir : (wrap ? 0 : st.ir + 1);
+  st.iky = wrap && !last ? st.iky + 1 : st.iky;
+}
+
+// the items of one source (F: its factor class -- column pattern, lines per wavefront): wait, barrier, issue five items ahead, multiply
+template <int CPL, int F, int C>
+__device__ __forceinline__ void tl_source(const TapSumArgs& a, int s, int n, int BY, int BX, int Y0, int X0, unsigned lds0,
+                                          const unsigned char* __restrict__ smem, float* __restrict__ wtab, TlIssue& is, int& sl,
+                                          float (&acc)[8][4][CPL]) {
+  constexpr int NLYW = F == 2 ? 6 : (F == 4 ? 4 : 3);
+  const int lane = threadIdx.x & 63, wave = uni_i(threadIdx.x >> 6), li = lane & 31;
+  const int hs = a.h[s], ws = a.w[s], lf = a.lf[s];
+  const int nlb = max(16 >> lf, 1) + 2;
+  const int n_it = 3 * nlb;
+  // ---- window origin, this lane half's x weights, this wavefront's y weights
+  float wxa[6], wxb[6];
+  int xr[6], first_x = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int lower; float aa, bb;
+    tap_pos2(X0 - 1 + i, a.W, ws, a.sx[s], lf, lower, aa, bb);
+    wxa[i] = aa; wxb[i] = bb;
+    if (i == 0) first_x = lower;
+    xr[i] = lower - first_x;
+  }
+  int lo, first_yw; float aa, bb;
+  tap_pos2(BX - 1, a.W, ws, a.sx[s], lf, lo, aa, bb);
+  const int col0 = first_x - uni_i(lo);
+  tap_pos2(Y0 - 1, a.H, hs, a.sy[s], lf, first_yw, aa, bb);
+  first_yw = uni_i(first_yw);
+  tap_pos2(BY - 1, a.H, hs, a.sy[s], lf, lo, aa, bb);
+  const int lw = first_yw - uni_i(lo);
+  if (lane < 60) {                                 // (the table is this wavefront's own: its reads of the previous source's are behind it)
+    const int j = lane / 6, r = lane - j * 6;
+    int lower;
+    tap_pos2(Y0 - 1 + j, a.H, hs, a.sy[s], lf, lower, aa, bb);
+    wtab[lane] = (lower - first_yw == r ? aa : 0.f) + (lower - first_yw + 1 == r ? bb : 0.f);
+  }
+  int cky = 0, cr = 0;
+#pragma unroll 1
+  for (int it = 0; it < n_it; ++it) {
+    // this wavefront's pieces of item `it` have landed (three per item: those of the four items after it may be in flight) and its LDS
+    // reads of the item before have returned; after the barrier everybody's have, and that item's slot takes the item five ahead
+    asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    tl_issue_one<C>(is, lds0, wave);
+    if (is.done && is.s + 1 < a.n_in) tl_issue_setup<C>(a, is, is.s + 1, n, BY, BX);     // (no vector memory operation in there)
+    const int rl = cr - lw;
+    if (rl >= 0 && rl < NLYW)
+      tl_item<CPL, F>(reinterpret_cast<const float*>(smem + sl * kTlSlot), cky, rl, col0, nlb, C, li, wtab, wxa, wxb, xr, acc);
+    sl = sl + 1 == kTlDepth ? 0 : sl + 1;
+    if (++cr == nlb) { cr = 0; ++cky; }
+  }
+}
+
+template <int CPL, int C>
+__global__ __launch_bounds__(256, 2) void tapsum_head_lds_kernel(TapSumArgs a, int bw, int bh) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
+  float* wtab = reinterpret_cast<float*>(tl_smem + kTlDepth * kTlSlot) + (threadIdx.x >> 6) * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni_i(tid >> 6), sub = lane >> 5, li = lane & 31;
+  const unsigned nb = gridDim.x, xq = nb >> 3, xrm = nb & 7u, xcd = blockIdx.x & 7u;       // XCD-aware order: an image's blocks on one XCD
+  const unsigned vb = xcd * xq + (xcd < xrm ? xcd : xrm) + (blockIdx.x >> 3);
+  const int bx = static_cast<int>(vb % bw), by = static_cast<int>((vb / bw) % bh), n = static_cast<int>(vb / (static_cast<unsigned>(bw) * bh));
+  const int BY = by * 16, BX = bx * 16;
+  const int Y0 = BY + (wave >> 1) * 8;                         // wave-uniform
+  const int X0 = BX + ((wave & 1) * 2 + sub) * 4;              // per lane half
+  const int c0 = li * CPL;
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((tl_lds_ptr_t)tl_smem));
+  float acc[8][4][CPL];
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) acc[d][e][q] = 0.f;
+  TlIssue is;
+  is.slot = 0;
+  tl_issue_setup<C>(a, is, 0, n, BY, BX);
+#pragma unroll 1
+  for (int d = 0; d < kTlDepth - 1; ++d) {
+    tl_issue_one<C>(is, lds0, wave);
+    if (is.done && is.s + 1 < a.n_in) tl_issue_setup<C>(a, is, is.s + 1, n, BY, BX);
+  }
+  // the sources come coarsest first (host-checked): factor >= 8, then 4, then 2 -- three loops in a row, one instantiation each (as the
+  // arms of one branch inside a single loop they cost hipcc 354 registers instead of 254: the 96 accumulators meet in a three-way join)
+  int s = 0, sl = 0;
+#pragma unroll 1
+  for (; s < a.n_in && a.lf[s] >= 3; ++s) tl_source<CPL, 0, C>(a, s, n, BY, BX, Y0, X0, lds0, tl_smem, wtab, is, sl, acc);
+#pragma unroll 1
+  for (; s < a.n_in && a.lf[s] == 2; ++s) tl_source<CPL, 4, C>(a, s, n, BY, BX, Y0, X0, lds0, tl_smem, wtab, is, sl, acc);
+#pragma unroll 1
+  for (; s < a.n_in && a.lf[s] == 1; ++s) tl_source<CPL, 2, C>(a, s, n, BY, BX, Y0, X0, lds0, tl_smem, wtab, is, sl, acc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the repeated last items
+
+  const int cc = c0 < C ? c0 : C - CPL;
+  float bi[CPL], sc[CPL], sh[CPL], hw[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    bi[q] = a.bias ? a.bias[cc + q] : 0.f;
+    sc[q] = a.scale ? a.scale[cc + q] : 1.f;
+    sh[q] = a.scale ? a.shift[cc + q] : 0.f;
+    hw[q] = c0 < C ? a.head_w[c0 + q] : 0.f;
+  }
+  // the head's bias, read ONCE and pinned: left to itself hipcc re-reads it from memory before every pixel's sigmoid (the stores in between
+  // might alias it) -- 32 exposed memory latencies per wavefront
+  float hb = a.head_b[0];
+  asm volatile("" : "+v"(hb));
+  float* __restrict__ hout = a.head_out + (static_cast<long>(n) * a.H + Y0) * a.W + X0;
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        float v = (acc[d][e][q] + bi[q]) * sc[q] + sh[q];
+        if (a.act == DIFFSAL_ACT_RELU) v = fmaxf(v, 0.f);
+        t2 = fmaf(v, hw[q], t2);
+      }
+      t2 = group_sum<32>(t2);
+      if (li == 0) hout[d * a.W + e] = sigmoidf_(t2 + hb);
+      __builtin_amdgcn_sched_barrier(0);       // one pixel at a time: interleaved, the 32 reductions need ~100 registers more than the loops
     }
 }
 
@@ -502,6 +763,8 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
     a.w[i] = i < n_src ? ws[i] : 1;
     a.sy[i] = static_cast<float>(a.h[i]) / static_cast<float>(H);
     a.sx[i] = static_cast<float>(a.w[i]) / static_cast<float>(W);
+    a.lf[i] = 0;
+    while ((a.h[i] << (a.lf[i] + 1)) <= H) ++a.lf[i];
     if (i < n_src) {
       DS_REQUIRE(srcs[i] && aligned16(srcs[i]) && hs[i] > 0 && ws[i] > 0, DIFFSAL_E_ARG, "tapsum: bad source %d", i);
       const int f = H / hs[i];
@@ -519,6 +782,21 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
   for (int i = 0; i < n_src && rows; ++i)
     rows = H / hs[i] >= 2 && H / hs[i] <= 64 && static_cast<long>(N) * hs[i] * ws[i] * 9 * C * 4 < (1L << 32) - (1L << 20);
   if (rows) {
+    // DIFFSAL_TAPSUM_ROWS_FORM unset: the LDS-staged kernel where it applies (C = 96: three channels per lane; H and W multiples of 16;
+    // a source image below 2 GiB; sources coarsest first); 1 .. 4: the row-streamed kernel's lane mappings
+    {
+      bool lds_ok = tune(TUNE_TAPSUM_ROWS_FORM) < 0 && H % 16 == 0 && W % 16 == 0 && C == 96;     // 10 columns x 72 pieces <= 768 per item
+      for (int i = 0; i < n_src && lds_ok; ++i)      // coarsest first: the kernel walks the factor classes >= 8, 4, 2 in that order
+        lds_ok = static_cast<long>(hs[i]) * ws[i] * 9 * C * 4 < (1L << 31) && (i == 0 || hs[i] >= hs[i - 1]);
+      if (lds_ok) {
+        const long blocks = static_cast<long>(N) * (H / 16) * (W / 16);
+        DS_REQUIRE(blocks < (1L << 31), DIFFSAL_E_SHAPE, "tapsum: output too large");
+        const size_t lds = kTlDepth * kTlSlot + 4 * 64 * sizeof(float);
+        DS_RAISE_DYNAMIC_LDS((tapsum_head_lds_kernel<3, 96>), 160 * 1024);
+        hipLaunchKernelGGL((tapsum_head_lds_kernel<3, 96>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, static_cast<hipStream_t>(stream), a, W / 16, H / 16);
+        return check_launch("tapsum(head, LDS-staged)");
+      }
+    }
     // lane mapping (DIFFSAL_TAPSUM_ROWS_FORM): unset -- an 8 x 4 patch per 32-lane half, 3 or 4 channels per lane, the halves of a
     // wavefront two adjacent patches of one image (H, W multiples of 8), else = 3: the same patch of two images (H a multiple of 8), else
     // = 1: 4 x 4 patches of two images; = 2: one image per wavefront (2 channels per lane, C <= 128, 4 x 4: twice the wavefronts at 177
@@ -526,13 +804,14 @@ static int tapsum_impl(const void* const* srcs, const int* hs, const int* ws, in
     const int form = tune(TUNE_TAPSUM_ROWS_FORM);
     const bool tall = form != 1 && form != 2 && H % 8 == 0;
     const bool sx = tall && form != 3 && W % 8 == 0;
+    const int row_map = form == 4 ? 1 : 0;
     const int imgs = form == 2 || sx ? 1 : 2;
     const int ps = tall ? 8 : 4, pw = sx ? 8 : 4;
     const long n_items = static_cast<long>((N + imgs - 1) / imgs) * (H / ps) * (W / pw);
     const dim3 grid(static_cast<unsigned>((n_items + 3) / 4));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool three = C % 3 == 0 && C / 3 <= 32 && C / 3 > 24;
-#define TS_HEAD(...) hipLaunchKernelGGL((tapsum_head_rows_kernel<__VA_ARGS__>), grid, dim3(256), 0, st, a, W / pw, n_items)
+#define TS_HEAD(...) hipLaunchKernelGGL((tapsum_head_rows_kernel<__VA_ARGS__>), grid, dim3(256), 0, st, a, W / pw, n_items, row_map)
     if (form == 2 && C % 2 == 0) TS_HEAD(2, 1, 4);
     else if (sx && three) TS_HEAD(3, 2, 8, true);
     else if (sx) TS_HEAD(4, 2, 8, true);

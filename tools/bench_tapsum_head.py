@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diff_sal_amd import _lib, ops  # noqa: E402
 
 
-FORMS = (1, 3, None)
+FORMS = (1, 3, 4, None)
 
 
 def main():
