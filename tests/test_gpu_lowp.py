@@ -323,6 +323,17 @@ def test_block16_fused_kernel(ops, dname, M, with_z):
     x2, z = ops.block16(dq_(o), dq_(x), (dq_(wp), d(bp)), (d(g2), d(be2), 1e-5), (dq_(w1), d(b1)), (dq_(w2), d(b2)),
                         (d(gz), d(bz), 1e-5) if with_z else None, (hw, T, keep))
     assert x2.dtype == dt
+    # four or eight wavefronts per workgroup (DIFFSAL_BLOCK16_WAVES; eight from 4096 tiles on): the same arithmetic per token
+    from diff_sal_amd import _lib
+    kept_rows = ((torch.arange(M, device=DEV) // hw) % T) < keep
+    for nw in (4, 8):
+        _lib.set_tuning("DIFFSAL_BLOCK16_WAVES", nw)
+        try:
+            x2w, zw = ops.block16(dq_(o), dq_(x), (dq_(wp), d(bp)), (d(g2), d(be2), 1e-5), (dq_(w1), d(b1)), (dq_(w2), d(b2)),
+                                  (d(gz), d(bz), 1e-5) if with_z else None, (hw, T, keep))
+        finally:
+            _lib.set_tuning("DIFFSAL_BLOCK16_WAVES", None)
+        assert torch.equal(x2w, x2) and (not with_z or torch.equal(zw[kept_rows], z[kept_rows]))
     # three chained GEMMs with 16-bit operands: the normalised activations and the hidden layer are rounded to the storage
     # type before they are multiplied (2-3 roundings along the path instead of 1)
     assert rel_err(x2, ref_x2) < 3 * OP_RTOL[dname]
