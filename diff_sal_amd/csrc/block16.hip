@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 1) void block16_kernel(Block16Args<T> p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float d = v[u][r] - mean; q = fmaf(d, d, q); }
     q += lane_xor32(q);
-    rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    rstd = 1.0f / sqrtf(fmaf(q, 1.0f / C, eps));       // (explicit FMAs here and below: the two instantiations of this kernel round alike)
   };
   // channel of accumulator register r of row tile u for this lane
   auto chan = [&](int u, int r) { return 32 * u + 4 * hf + (r & 3) + 8 * (r >> 2); };
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, 1) void block16_kernel(Block16Args<T> p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = chan(u, r);
-        xn[r] = (x1[u][r] - mean) * rstd * vecs[C + c] + vecs[2 * C + c];
+        xn[r] = fmaf((x1[u][r] - mean) * rstd, vecs[C + c], vecs[2 * C + c]);
       }
       xb[u][0] = b_from(xn, 0);
       xb[u][1] = b_from(xn, 1);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NW * 64, 1) void block16_kernel(Block16Args<T> p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int c = 32 * u + 8 * g + 4 * hf + e;
-              v4[e] = (y[u][4 * g + e] - mz) * rz * vecs[4 * C + c] + vecs[5 * C + c];
+              v4[e] = fmaf((y[u][4 * g + e] - mz) * rz, vecs[4 * C + c], vecs[5 * C + c]);
             }
             st4(dz + 32 * u + 8 * g, make_float4(v4[0], v4[1], v4[2], v4[3]));
           }

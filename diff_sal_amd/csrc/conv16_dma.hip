@@ -93,15 +93,19 @@ template <int WN> struct CdShape {
   static constexpr int LDS = 2 * PATCH_CAP + SLOTS * SLOT_B;         // 81920 both
 };
 
-// TW: tile width in pixels (WN = 1: 32 -- 8 x 32 tile -- or 16 -- 16 x 16; WN = 2: 24 -- 8 x 24)
+// TW: tile width in pixels (WN = 1: 32 -- 8 x 32 tile -- or 16 -- 16 x 16; WN = 2: 24 -- 8 x 24).  TW = 0 (WN = 1): maps of at most 128
+// output pixels (the 9 x 14 extended grid of a 7 x 12 map: a 256-pixel tile of one image would be half padding) -- a tile is TWO WHOLE
+// IMAGES, 128 tile rows each, the patch buffer holds both padded images
 template <int TW, int WN, typename T>
 __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   typedef typename CdMma<T>::vec vec;
   typedef CdShape<WN> S;
   constexpr int TM = S::TM, TN = 3, BN = S::BN;
-  constexpr int TH = S::PIX / TW;
+  constexpr bool MI = TW == 0;
+  constexpr int TWX = MI ? 1 : TW;
+  constexpr int TH = S::PIX / TWX;
   constexpr int kCdPatchIss = S::PATCH_ISS;
-  static_assert(S::PIX % TW == 0 && S::LDS <= 81920, "tile");
+  static_assert(S::PIX % TWX == 0 && S::LDS <= 81920 && (!MI || WN == 1), "tile");
   constexpr unsigned DEAD = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char cd_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,12 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   const int tn = b % p.tiles_n; b /= p.tiles_n;
   const int tx = b % p.tiles_x; b /= p.tiles_x;
   const int ty = b % p.tiles_y;
-  const int img = b / p.tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+  const int img = MI ? (b / p.tiles_y) * 2 : b / p.tiles_y;        // MI: the first of the tile's two images (tiles_x = tiles_y = 1)
+  const int y0 = MI ? 0 : ty * TH, x0 = MI ? 0 : tx * TW, n0 = tn * BN;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int d = p.dil;
-  const int PH = TH + 2 * d, PW = TW + 2 * d;
-  const int patch_bytes = PH * PW * kCdRowB;       // <= 27648
+  const int PH = (MI ? p.Ho : TH) + 2 * d, PW = (MI ? p.Wo : TW) + 2 * d;
+  const int PP = PH * PW, OP = p.Ho * p.Wo;        // MI: pixels of a padded image / of an output map
+  const int patch_bytes = (MI ? 2 : 1) * PP * kCdRowB;       // <= 27648
   // LDS: [patch 0][patch 1][weight slot 0..2][scratch KiB]
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((cd_lds_ptr_t)cd_smem));
   constexpr int PATCH_CAP = S::PATCH_CAP;
@@ -136,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   // (q * 4 + wave) * 16 + (lane >> 2).
   const T* in_img = p.in + static_cast<long>(img) * p.H * p.W * p.Cin;
   const unsigned long pa = reinterpret_cast<unsigned long>(in_img);
-  const cd_i32x4 rs_a = cd_i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, p.H * p.W * p.Cin * 2, 0x00020000};
+  const int a_records = __builtin_amdgcn_readfirstlane((MI && img + 1 < p.N ? 2 : 1) * p.H * p.W * p.Cin * 2);
+  const cd_i32x4 rs_a = cd_i32x4{static_cast<int>(pa), static_cast<int>(pa >> 32) & 0xFFFF, a_records, 0x00020000};
   const unsigned long pw = reinterpret_cast<unsigned long>(p.w);
   const cd_i32x4 rs_w = cd_i32x4{static_cast<int>(pw), static_cast<int>(pw >> 32) & 0xFFFF, p.Cout * p.K * 2, 0x00020000};
   unsigned a_voff[kCdPatchIss], w_voff[S::W_ISS];
@@ -144,10 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   for (int q = 0; q < kCdPatchIss; ++q) {
     const int idx = (q * kCdWaves + wave) * 64 + lane;
     const int pix = idx >> 2, ls = (idx & 3) ^ ((pix >> 2) & 3);
-    const int pr = pix / PW, pc = pix - pr * PW;
+    const int pj = MI ? pix / PP : 0, pl = pix - pj * PP;             // MI: image of the tile, pixel of its padded map
+    const int pr = pl / PW, pc = pl - pr * PW;
     const int gy = y0 - p.pad + pr, gx = x0 - p.pad + pc;
-    const bool ok = pix < PH * PW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    a_voff[q] = ok ? static_cast<unsigned>(((gy * p.W + gx) * p.Cin + ls * 8) * 2) : DEAD;
+    const bool ok = pix < (MI ? 2 : 1) * PP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;        // (an image past N: past the descriptor's range)
+    a_voff[q] = ok ? static_cast<unsigned>((((pj * p.H + gy) * p.W + gx) * p.Cin + ls * 8) * 2) : DEAD;
   }
 #pragma unroll
   for (int q = 0; q < S::W_ISS; ++q) {
@@ -178,7 +185,12 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int t = (wm * TM + i) * 32 + lp;         // pixel of the workgroup's tile, row-major over TH x TW
-    a_pix[i] = (t / TW) * PW + t % TW;
+    if constexpr (MI) {                            // tile row = (image t / 128, pixel t % 128 of its map; rows past the map multiply pixel 0)
+      const int tj = t >> 7, tl = (t & 127) < OP ? (t & 127) : 0;
+      a_pix[i] = tj * PP + (tl / p.Wo) * PW + tl % p.Wo;
+    } else {
+      a_pix[i] = (t / TWX) * PW + t % TWX;
+    }
   }
   int b_off[TN][2];
 #pragma unroll
@@ -277,9 +289,10 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
         const int px = item / 12, oc = item - px * 12;
         const int n = n0 + wn * 96 + oc * 8;
         const int t = (wm * TM + i) * 32 + px;
-        const int gy = y0 + t / TW, gx = x0 + t % TW;
-        rraw[it] = (gy < p.Ho && gx < p.Wo && n < p.Cout)
-                       ? *reinterpret_cast<const uint4*>(resid + ((static_cast<long>(img) * p.Ho + gy) * p.Wo + gx) * p.Cout + n)
+        const int ti = MI ? img + (t >> 7) : img, tl = MI ? (t & 127) : 0;
+        const int gy = MI ? tl / p.Wo : y0 + t / TWX, gx = MI ? tl % p.Wo : x0 + t % TWX;
+        rraw[it] = (gy < p.Ho && gx < p.Wo && n < p.Cout && ti < p.N)
+                       ? *reinterpret_cast<const uint4*>(resid + ((static_cast<long>(ti) * p.Ho + gy) * p.Wo + gx) * p.Cout + n)
                        : make_uint4(0, 0, 0, 0);
       }
     }
@@ -295,9 +308,10 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
       const int px = item / 12, oc = item - px * 12;
       const int n = n0 + wn * 96 + oc * 8;
       const int t = (wm * TM + i) * 32 + px;
-      const int gy = y0 + t / TW, gx = x0 + t % TW;
+      const int ti = MI ? img + (t >> 7) : img, tl = MI ? (t & 127) : 0;
+      const int gy = MI ? tl / p.Wo : y0 + t / TWX, gx = MI ? tl % p.Wo : x0 + t % TWX;
       const float4 s0 = ld4(stage + px * 100 + oc * 8), s1 = ld4(stage + px * 100 + oc * 8 + 4);
-      if (gy >= p.Ho || gx >= p.Wo || n >= p.Cout) continue;
+      if (gy >= p.Ho || gx >= p.Wo || n >= p.Cout || ti >= p.N) continue;
       float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
       if (p.bias) {
         const float4 t0 = ld4(p.bias + n), t1 = ld4(p.bias + n + 4);
@@ -310,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
         v[4] = v[4] * c1.x + h1.x; v[5] = v[5] * c1.y + h1.y; v[6] = v[6] * c1.z + h1.z; v[7] = v[7] * c1.w + h1.w;
       }
       if (rv_row) {
-        const float4 t0 = ld4(rv_row + n), t1 = ld4(rv_row + n + 4);
+        const float* rv = MI ? rv_row + static_cast<long>(ti - img) * p.rowvec_ld : rv_row;
+        const float4 t0 = ld4(rv + n), t1 = ld4(rv + n + 4);
         v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
       }
       if (p.act == DIFFSAL_ACT_RELU) {
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = sigmoidf_(v[e]);
       }
-      const long o = ((static_cast<long>(img) * p.Ho + gy) * p.Wo + gx) * p.Cout + n;
+      const long o = ((static_cast<long>(ti) * p.Ho + gy) * p.Wo + gx) * p.Cout + n;
       if (resid) {
         const f8v t = ld8(reinterpret_cast<const T*>(&rraw[it]));
 #pragma unroll
@@ -340,19 +355,22 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
 template <int TW, int WN, typename T>
 static int launch_cd(CdArgs<T>& a, hipStream_t s) {
   typedef CdShape<WN> S;
-  constexpr int TH = S::PIX / TW;
-  a.tiles_x = (a.Wo + TW - 1) / TW;
-  a.tiles_y = (a.Ho + TH - 1) / TH;
+  constexpr bool MI = TW == 0;
+  constexpr int TWX = MI ? 1 : TW;
+  constexpr int TH = S::PIX / TWX;
+  a.tiles_x = MI ? 1 : (a.Wo + TWX - 1) / TWX;
+  a.tiles_y = MI ? 1 : (a.Ho + TH - 1) / TH;
   a.tiles_n = (a.Cout + S::BN - 1) / S::BN;
   const size_t lds = S::LDS;                       // 81920: exactly two per CU
   DS_RAISE_DYNAMIC_LDS((conv16_dma_kernel<TW, WN, T>), 160 * 1024);
-  const long blocks = static_cast<long>(a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
+  const long blocks = static_cast<long>(MI ? (a.N + 1) / 2 : a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
   hipLaunchKernelGGL((conv16_dma_kernel<TW, WN, T>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
-  note_kernel("conv16_dma_kernel<%d> [%dx%d pixels x %d channels, LDS-DMA halo, 2 workgroups per CU]", TW, TH, TW, S::BN);
+  if (MI) note_kernel("conv16_dma_kernel<0> [2 images of %dx%d pixels x %d channels, LDS-DMA halo, 2 workgroups per CU]", a.Ho, a.Wo, S::BN);
+  else note_kernel("conv16_dma_kernel<%d> [%dx%d pixels x %d channels, LDS-DMA halo, 2 workgroups per CU]", TW, TH, TW, S::BN);
   return check_launch("diffsal_conv_igemm(16-bit DMA halo)");
 }
 
-// the tile of a descriptor: 0 = none, 1 = 8 x 32 x 96, 2 = 16 x 16 x 96, 3 = 8 x 24 x 192
+// the tile of a descriptor: 0 = none, 1 = 8 x 32 x 96, 2 = 16 x 16 x 96, 3 = 8 x 24 x 192, 4 = two whole images x 96
 struct CdPlan { int tile; long blocks; double used; };
 
 static CdPlan cd_plan(const diffsal_conv_desc* d) {
@@ -370,6 +388,16 @@ static CdPlan cd_plan(const diffsal_conv_desc* d) {
   CdPlan best{0, 0, 0.0};
   if (w32.tile && (!w16.tile || w32.used >= w16.used)) { best = w32; best.tile = 1; }
   else if (w16.tile) { best = w16; best.tile = 2; }
+  // small maps: two whole images per 256-pixel tile, when that covers them better and both padded images fit the patch buffer
+  if (d->Ho * d->Wo <= 128 && 2 * (d->Ho + 2 * d->dil_h) * (d->Wo + 2 * d->dil_w) * kCdRowB <= CdShape<1>::PATCH_CAP - 1024 &&
+      static_cast<long>(d->H) * d->W * d->Cin * 2 * 2 < (1L << 31)) {
+    const double used = d->Ho * d->Wo / 128.0;
+    if (used > best.used + 0.05) {
+      best.tile = 4;
+      best.blocks = static_cast<long>((d->N + 1) / 2) * ((d->Cout + 95) / 96);
+      best.used = used;
+    }
+  }
   // 192 pixels x 192 channels (DIFFSAL_CONV16_TILE: 0 never, 1 wherever it can run): where its 8 x 24 tiles cover the map better (28 x 48
   // at dilation 2, 14 x 24: 0.875 against 0.66 -- measured +22-24 %; on maps both cover fully the two shapes are within 3 % of each
   // other either way: these convolutions run at ~1 PF/s with the chip's clock held down, and fewer LDS reads per MFMA do not change
@@ -421,6 +449,7 @@ static int run_cd(const diffsal_conv_desc* d, const void* in, const void* w, con
   switch (cd_plan(d).tile) {
     case 1: return launch_cd<32, 1, T>(a, s);
     case 2: return launch_cd<16, 1, T>(a, s);
+    case 4: return launch_cd<0, 1, T>(a, s);
     default: return launch_cd<24, 2, T>(a, s);
   }
 }

@@ -165,6 +165,8 @@ CONV_DMA_CASES = [
     (2, 56, 96, 96, 192, 1, 1, "bias_rowvec"),    # ResnetBlock conv1
     (2, 9, 17, 32, 72, 1, 1, "bias"),             # ragged: partial tiles in both directions, Cout < 96 and not a multiple of 32
     (1, 20, 36, 768, 96, 1, 1, "none"),           # 24 chunks
+    (5, 7, 12, 64, 96, 2, 1, "bn_relu_res"),      # 9 x 14 extended grid: two whole images per tile, odd image count
+    (4, 6, 10, 32, 200, 1, 1, "bias_rowvec"),     # 60-pixel maps, a per-image vector, a partial N tile
 ]
 
 
@@ -207,6 +209,7 @@ def test_conv16_dma_halo_kernel(ops, dname, case, tile):
         _lib.set_tuning("DIFFSAL_FORCE_HALO", None)
         _lib.set_tuning("DIFFSAL_CONV16_TILE", None)
     assert "conv16_dma_kernel" in name and ("x 192 channels" in name) == (tile == 1)
+    assert ("2 images" in name) == (tile == 0 and Ho * Wo <= 128)
     # the generic kernel on one fixed tile shape WITHOUT a K split (its split sums the K ranges in another order)
     _lib.set_tuning("DIFFSAL_NO_HALO", 1)
     _lib.set_tuning("DIFFSAL_IGEMM16_CFG", 0)
