@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
   // (slots NAH, NAH + 1).  fp32: all of them ahead.  C = 192 on 16-bit storage: half -- with all twelve passes (72 registers)
   // beside the six Q^T accumulators the kernel needed 512 registers and spilled 12-15 of them to scratch
   constexpr int NAH = !AHEAD ? 0 : (F32 ? NPASS : NPASS / 2);
-  raw_t pre[NAH + (NAH < NPASS ? 2 : 0)][3];
+  // round 6: the passes that are not fetched ahead are ALL requested at the top of phase A (one slot each: 6 registers per pass on
+  // 16-bit storage, free there -- the accumulators of phase D do not exist yet).  With two in flight phase A was six (twelve at
+  // C = 192: six) exposed memory latencies in a row, 5.6 of a tile's 16 us
+  constexpr int NFL = NAH < NPASS ? NPASS - NAH : 0;
+  raw_t pre[NAH + NFL][3];
   unsigned inside_mask = 0;
   auto fetch_pass = [&](int tile_, int ps, raw_t (&dst)[3]) -> bool {
     const int tx_ = tile_ % p.tiles_x, t2_ = tile_ / p.tiles_x;
@@ -219,8 +223,10 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
     const int ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
     const int y0 = ty * FT_TH, x0 = tx * FT_TW;
-    if constexpr (NAH < NPASS) {      // the first pass that was not fetched ahead (its mask bit replaces a stale one)
-      inside_mask = (inside_mask & ((1u << NAH) - 1u)) | ((fetch_pass(tile, NAH, pre[NAH + (NAH & 1)]) ? 1u : 0u) << NAH);
+    if constexpr (NAH < NPASS) {      // the passes that were not fetched ahead (their mask bits replace stale ones)
+      inside_mask &= (1u << NAH) - 1u;
+#pragma unroll
+      for (int ps = NAH; ps < NPASS; ++ps) inside_mask |= (fetch_pass(tile, ps, pre[ps]) ? 1u : 0u) << ps;
     }
 
     // ---------------- phase A: halo tile (fetched while the previous tile was in phase D) -> LayerNorm_1 -> LDS; zeros outside
@@ -228,13 +234,10 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 4 || C > 96) ? 1 : 2)) void blo
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int tok = ps * TPP + a_slot;
-      if constexpr (NAH < NPASS) {                                     // two passes in flight
-        if (ps + 1 < NPASS && ps + 1 > NAH) inside_mask |= (fetch_pass(tile, ps + 1, pre[NAH + ((ps + 1) & 1)]) ? 1u : 0u) << (ps + 1);
-      }
       const bool inside = (inside_mask >> ps) & 1u;
       float4 vv[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[ps < NAH ? ps : NAH + (ps & 1)][i]);
+      for (int i = 0; i < 3; ++i) vv[i] = raw_to_f4(pre[ps][i]);
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += (vv[i].x + vv[i].y) + (vv[i].z + vv[i].w);

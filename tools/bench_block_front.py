@@ -24,8 +24,10 @@ def timed(fn, n=20):
 
 def main():
     Lk, heads = 18, 2
+    scale = int(os.environ.get("FRONT_SCALE", "1"))       # 16: the 64-clip pass
     for dt, (N, H, W, C) in ((torch.float32, (36, 56, 96, 96)), (torch.bfloat16, (36, 56, 96, 96)), (torch.float16, (36, 56, 96, 96)),
                              (torch.bfloat16, (36, 28, 48, 192)), (torch.float16, (36, 28, 48, 192))):
+        N *= scale
         g = torch.Generator(device="cuda").manual_seed(0)
         r = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc
         x = r(N, H, W, C).to(dt)
