@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffsal_hip.so")
-SOURCES = ["igemm.hip", "igemm16.hip", "lin_stream.hip", "wgrad.hip", "backward.hip", "optim.hip", "pack.hip", "norm.hip", "misc.hip", "metrics.hip", "attention.hip", "mvit.hip", "mvit_pool.hip", "block16.hip", "conv16_halo.hip", "conv16_dma.hip", "gemm16_dma.hip", "tapsum.hip", "tblock.hip", "wino.hip", "gemm_dma.hip", "wino4.hip", "upconv.hip"]
+SOURCES = ["igemm.hip", "igemm16.hip", "lin_stream.hip", "wgrad.hip", "backward.hip", "optim.hip", "pack.hip", "norm.hip", "misc.hip", "metrics.hip", "attention.hip", "mvit.hip", "mvit_pool.hip", "block16.hip", "conv16_halo.hip", "conv16_dma.hip", "gemm16_dma.hip", "attn16_mfma.hip", "tapsum.hip", "tblock.hip", "wino.hip", "gemm_dma.hip", "wino4.hip", "upconv.hip"]
 
 
 def _hipcc():

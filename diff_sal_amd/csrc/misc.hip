@@ -28,7 +28,7 @@ static const char* const kTuneNames[TUNE_COUNT] = {
     "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
     "DIFFSAL_NO_FUSED_BLOCK", "DIFFSAL_NO_WINOGRAD", "DIFFSAL_FORCE_WINOGRAD", "DIFFSAL_GN_CHUNKS", "DIFFSAL_GN_APPLY_WGS",
     "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD", "DIFFSAL_NO_TAPSUM_ROWS", "DIFFSAL_TAPSUM_ROWS_FORM",
-    "DIFFSAL_NO_ATTN_BWD_DS", "DIFFSAL_NO_POOL_RUNS", "DIFFSAL_NO_ATTN_SLOTS", "DIFFSAL_NO_STREAM16", "DIFFSAL_CONV16_TILE", "DIFFSAL_BLOCK16_WAVES"};
+    "DIFFSAL_NO_ATTN_BWD_DS", "DIFFSAL_NO_POOL_RUNS", "DIFFSAL_NO_ATTN_SLOTS", "DIFFSAL_NO_STREAM16", "DIFFSAL_CONV16_TILE", "DIFFSAL_BLOCK16_WAVES", "DIFFSAL_NO_ATTN16_MFMA"};
 static int g_tune[TUNE_COUNT];
 static const bool g_tune_init = [] {
   for (int k = 0; k < TUNE_COUNT; ++k) {
@@ -1485,6 +1485,10 @@ static void attention_t(const T* q, const T* k, const T* v, T* o, int N, int Lq,
   else launch_attention_g<32, T>(G, q, k, v, o, N, Lq, Lk, C, heads, scale, s);
 }
 
+namespace diffsal {
+int try_attention16_mfma(const void* q, const void* k, const void* v, void* o, int N, int Lq, int Lk, int C, int heads, float scale,
+                         int dtype, hipStream_t s);
+}
 extern "C" int diffsal_attention(const void* q, const void* k, const void* v, void* o, int N, int Lq, int Lk,
                                  int C, int heads, float scale, int dtype, diffsal_stream_t stream) {
   DS_REQUIRE(q && k && v && o, DIFFSAL_E_ARG, "attention: null argument");
@@ -1497,6 +1501,11 @@ extern "C" int diffsal_attention(const void* q, const void* k, const void* v, vo
   DS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), DIFFSAL_E_ALIGN,
              "attention: misaligned pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    // 16-bit storage, head dim 192 / 384 (stages 1 / 0): the matrix-core form (csrc/attn16_mfma.hip)
+    const int rc = diffsal::try_attention16_mfma(q, k, v, o, N, Lq, Lk, C, heads, scale, dtype, s);
+    if (rc != 0) return rc < 0 ? rc : DIFFSAL_OK;
+  }
   {
     // 16-bit storage, head dims 48 .. 384, up to 18 keys: the 16-byte form, one workgroup per (image, head)
     const int d = C / heads, G = d / 24;

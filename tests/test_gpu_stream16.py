@@ -326,10 +326,12 @@ def test_gemm16_dma2_reduce_temp_row_form(ops, dname, Bn, T, HW, C, kt, Co, tile
 
 
 @pytest.mark.parametrize("dname", list(DTYPES))
-@pytest.mark.parametrize("n,Lq,Lk,C,heads", [(3, 84, 18, 768, 2), (2, 336, 18, 384, 2), (2, 100, 18, 192, 2), (2, 77, 5, 96, 2), (1, 33, 18, 384, 4)])
+@pytest.mark.parametrize("n,Lq,Lk,C,heads", [(3, 84, 18, 768, 2), (2, 336, 18, 384, 2), (2, 100, 18, 192, 2), (2, 77, 5, 96, 2), (1, 33, 18, 384, 4),
+                                                 (2, 130, 5, 384, 2), (1, 40, 32, 768, 2)])      # matrix-core form: Lk <= 16, Lk = 32
 def test_attention_16_byte_form(ops, dname, n, Lq, Lk, C, heads):
     """K11 (R/models/saliency_decoder/attention.py:97-108; scale C^-1/2 of the FULL width, quirk Q6): one workgroup per (image, head),
-    K / V in LDS once, two queries per lane group."""
+    K / V in LDS once, two queries per lane group; head dims 192 / 384 on the matrix cores (csrc/attn16_mfma.hip: the probabilities
+    enter the second product as a 16-bit hi + lo pair)."""
     import torch.nn.functional as F
 
     dt = DTYPES[dname]
