@@ -42,7 +42,7 @@ enum TuneKey {
   TUNE_NO_PERSIST = 0, TUNE_NO_XCD_ORDER, TUNE_NO_HALO, TUNE_FORCE_HALO, TUNE_IGEMM_CFG, TUNE_IGEMM16_CFG, TUNE_PLAN_DEBUG,
   TUNE_WGRAD_CFG, TUNE_WGRAD_SPLITS, TUNE_WGRAD_VERBOSE, TUNE_NO_FUSED_BLOCK, TUNE_NO_WINOGRAD, TUNE_FORCE_WINOGRAD, TUNE_GN_CHUNKS,
   TUNE_GN_APPLY_WGS, TUNE_GEMM_DMA, TUNE_CONV_DMA, TUNE_GROUP_GRID, TUNE_GEMM_DMA16, TUNE_WGRAD_DMA, TUNE_NO_GN_SLAB, TUNE_NO_WINOGRAD4, TUNE_BATCH_TILE, TUNE_BATCH_XCD, TUNE_NO_TAPSUM_ROWS, TUNE_TAPSUM_ROWS_FORM,
-  TUNE_NO_ATTN_BWD_DS, TUNE_NO_POOL_RUNS, TUNE_NO_ATTN_SLOTS, TUNE_NO_STREAM16, TUNE_CONV16_TILE, TUNE_BLOCK16_WAVES, TUNE_NO_ATTN16_MFMA, TUNE_COUNT
+  TUNE_NO_ATTN_BWD_DS, TUNE_NO_POOL_RUNS, TUNE_NO_ATTN_SLOTS, TUNE_NO_STREAM16, TUNE_CONV16_TILE, TUNE_BLOCK16_WAVES, TUNE_NO_ATTN16_MFMA, TUNE_CONV16_HALF, TUNE_COUNT
 };
 int tune(int key);
 

@@ -96,14 +96,19 @@ template <int WN> struct CdShape {
 // TW: tile width in pixels (WN = 1: 32 -- 8 x 32 tile -- or 16 -- 16 x 16; WN = 2: 24 -- 8 x 24).  TW = 0 (WN = 1): maps of at most 128
 // output pixels (the 9 x 14 extended grid of a 7 x 12 map: a 256-pixel tile of one image would be half padding) -- a tile is TWO WHOLE
 // IMAGES, 128 tile rows each, the patch buffer holds both padded images
-template <int TW, int WN, typename T>
+// HALF (WN = 1 only): a 128-pixel tile (8 x 16 or 4 x 32; a wavefront = 32 pixels x 96 channels) for launches whose 256-pixel tiles would
+// leave most CUs without a workgroup (B <= 4 maps: 96-170 workgroups).  A CU that has a workgroup is already 0.6 busy on the matrix pipe
+// there (a step of 12 MFMAs per SIMD takes 0.29 us; eight wavefronts per workgroup or a deeper DMA queue change nothing: measured) --
+// what is idle is the other CUs, so the tiles are halved and twice as many CUs work.
+template <int TW, int WN, typename T, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   typedef typename CdMma<T>::vec vec;
   typedef CdShape<WN> S;
-  constexpr int TM = S::TM, TN = 3, BN = S::BN;
+  static_assert(!HALF || (WN == 1 && TW != 0), "half tiles: 128 pixels x 96 channels");
+  constexpr int TM = HALF ? 1 : S::TM, TN = 3, BN = S::BN;
   constexpr bool MI = TW == 0;
   constexpr int TWX = MI ? 1 : TW;
-  constexpr int TH = S::PIX / TWX;
+  constexpr int TH = (HALF ? S::PIX / 2 : S::PIX) / TWX;
   constexpr int kCdPatchIss = S::PATCH_ISS;
   static_assert(S::PIX % TWX == 0 && S::LDS <= 81920 && (!MI || WN == 1), "tile");
   constexpr unsigned DEAD = 0x80000000u;
@@ -352,19 +357,19 @@ __global__ __launch_bounds__(256, 2) void conv16_dma_kernel(CdArgs<T> p) {
   }
 }
 
-template <int TW, int WN, typename T>
+template <int TW, int WN, typename T, bool HALF = false>
 static int launch_cd(CdArgs<T>& a, hipStream_t s) {
   typedef CdShape<WN> S;
   constexpr bool MI = TW == 0;
   constexpr int TWX = MI ? 1 : TW;
-  constexpr int TH = S::PIX / TWX;
+  constexpr int TH = (HALF ? S::PIX / 2 : S::PIX) / TWX;
   a.tiles_x = MI ? 1 : (a.Wo + TWX - 1) / TWX;
   a.tiles_y = MI ? 1 : (a.Ho + TH - 1) / TH;
   a.tiles_n = (a.Cout + S::BN - 1) / S::BN;
   const size_t lds = S::LDS;                       // 81920: exactly two per CU
-  DS_RAISE_DYNAMIC_LDS((conv16_dma_kernel<TW, WN, T>), 160 * 1024);
+  DS_RAISE_DYNAMIC_LDS((conv16_dma_kernel<TW, WN, T, HALF>), 160 * 1024);
   const long blocks = static_cast<long>(MI ? (a.N + 1) / 2 : a.N) * a.tiles_y * a.tiles_x * a.tiles_n;
-  hipLaunchKernelGGL((conv16_dma_kernel<TW, WN, T>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv16_dma_kernel<TW, WN, T, HALF>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
   if (MI) note_kernel("conv16_dma_kernel<0> [2 images of %dx%d pixels x %d channels, LDS-DMA halo, 2 workgroups per CU]", a.Ho, a.Wo, S::BN);
   else note_kernel("conv16_dma_kernel<%d> [%dx%d pixels x %d channels, LDS-DMA halo, 2 workgroups per CU]", TW, TH, TW, S::BN);
   return check_launch("diffsal_conv_igemm(16-bit DMA halo)");
@@ -446,9 +451,13 @@ static int run_cd(const diffsal_conv_desc* d, const void* in, const void* w, con
   a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.Cin = d->Cin; a.Cout = d->Cout; a.K = 9 * d->Cin;
   a.dil = d->dil_h; a.pad = d->pad_t; a.act = d->act;
   a.rowvec_ld = d->rowvec_ld > 0 ? d->rowvec_ld : d->Cout;
-  switch (cd_plan(d).tile) {
-    case 1: return launch_cd<32, 1, T>(a, s);
-    case 2: return launch_cd<16, 1, T>(a, s);
+  const CdPlan pl = cd_plan(d);
+  // fewer workgroups than CUs on the 256-pixel tiles: 128-pixel tiles (DIFFSAL_CONV16_HALF = 0 / 1: never / on every 8 x 32, 16 x 16 shape)
+  const int fh = tune(TUNE_CONV16_HALF);
+  const bool half = fh == 1 || (fh != 0 && pl.blocks < 224);
+  switch (pl.tile) {
+    case 1: return half ? launch_cd<32, 1, T, true>(a, s) : launch_cd<32, 1, T>(a, s);
+    case 2: return half ? launch_cd<16, 1, T, true>(a, s) : launch_cd<16, 1, T>(a, s);
     case 4: return launch_cd<0, 1, T>(a, s);
     default: return launch_cd<24, 2, T>(a, s);
   }

@@ -28,7 +28,7 @@ static const char* const kTuneNames[TUNE_COUNT] = {
     "DIFFSAL_IGEMM16_CFG", "DIFFSAL_PLAN_DEBUG", "DIFFSAL_WGRAD_CFG", "DIFFSAL_WGRAD_SPLITS", "DIFFSAL_WGRAD_VERBOSE",
     "DIFFSAL_NO_FUSED_BLOCK", "DIFFSAL_NO_WINOGRAD", "DIFFSAL_FORCE_WINOGRAD", "DIFFSAL_GN_CHUNKS", "DIFFSAL_GN_APPLY_WGS",
     "DIFFSAL_GEMM_DMA", "DIFFSAL_CONV_DMA", "DIFFSAL_GROUP_GRID", "DIFFSAL_GEMM_DMA16", "DIFFSAL_WGRAD_DMA", "DIFFSAL_NO_GN_SLAB", "DIFFSAL_NO_WINOGRAD4", "DIFFSAL_BATCH_TILE", "DIFFSAL_BATCH_XCD", "DIFFSAL_NO_TAPSUM_ROWS", "DIFFSAL_TAPSUM_ROWS_FORM",
-    "DIFFSAL_NO_ATTN_BWD_DS", "DIFFSAL_NO_POOL_RUNS", "DIFFSAL_NO_ATTN_SLOTS", "DIFFSAL_NO_STREAM16", "DIFFSAL_CONV16_TILE", "DIFFSAL_BLOCK16_WAVES", "DIFFSAL_NO_ATTN16_MFMA"};
+    "DIFFSAL_NO_ATTN_BWD_DS", "DIFFSAL_NO_POOL_RUNS", "DIFFSAL_NO_ATTN_SLOTS", "DIFFSAL_NO_STREAM16", "DIFFSAL_CONV16_TILE", "DIFFSAL_BLOCK16_WAVES", "DIFFSAL_NO_ATTN16_MFMA", "DIFFSAL_CONV16_HALF"};
 static int g_tune[TUNE_COUNT];
 static const bool g_tune_init = [] {
   for (int k = 0; k < TUNE_COUNT; ++k) {

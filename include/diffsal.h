@@ -57,7 +57,7 @@ const char* diffsal_last_gemm_kernel(void);
  * DIFFSAL_WGRAD_VERBOSE, DIFFSAL_NO_FUSED_BLOCK, ... (the full list: kTuneNames in csrc/misc.hip); round 6:
  * DIFFSAL_NO_STREAM16 = 1 routes 16-bit storage back to the 8-byte forms of the HBM-bound kernels and to the kernels the planner took before
  * conv16_dma / gemm16_dma2; DIFFSAL_FORCE_HALO = 2 and DIFFSAL_GEMM_DMA16 = 3 / 4 take those two (gemm16_dma2 with its 256 x 96 / 192 x 192
- * tile) on every shape they can run; DIFFSAL_CONV16_TILE = 0 / 1 keeps conv16_dma off / on its 8 x 24 x 192-channel tile;
+ * tile) on every shape they can run; DIFFSAL_CONV16_TILE = 0 / 1 keeps conv16_dma off / on its 8 x 24 x 192-channel tile, DIFFSAL_CONV16_HALF = 0 / 1 off / on its 128-pixel tiles;
  * DIFFSAL_BLOCK16_WAVES = 4 / 8 fixes the wavefronts per workgroup of the fused C = 96 block; DIFFSAL_TAPSUM_ROWS_FORM = 1 .. 4 takes the
  * row-streamed head gather (and its lane mapping) instead of the LDS-staged one; DIFFSAL_NO_ATTN16_MFMA = 1 keeps the 16-bit attention core
  * of head dims 192 / 384 off the matrix cores.

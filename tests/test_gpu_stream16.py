@@ -170,10 +170,10 @@ CONV_DMA_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1], ids=["256x96", "192x192"])
+@pytest.mark.parametrize("tile,waves", [(0, 0), (0, 1), (1, 0)], ids=["256x96", "128x96", "192x192"])
 @pytest.mark.parametrize("dname", list(DTYPES))
 @pytest.mark.parametrize("case", CONV_DMA_CASES)
-def test_conv16_dma_halo_kernel(ops, dname, case, tile):
+def test_conv16_dma_halo_kernel(ops, dname, case, tile, waves):
     """csrc/conv16_dma.hip (R/models/saliency_decoder/common_block.py:196-216, sal_unet.py:104-142 on 16-bit storage): forced on
     shapes of a few tiles, against the generic 16-bit implicit-GEMM kernel -- same accumulation order, identical bits -- and
     against F.conv2d on the rounded operands."""
@@ -202,14 +202,18 @@ def test_conv16_dma_halo_kernel(ops, dname, case, tile):
                               shift=dv(shift), rowvec=dv(rowvec), residual=rn, act=act)
     _lib.set_tuning("DIFFSAL_FORCE_HALO", 2)
     _lib.set_tuning("DIFFSAL_CONV16_TILE", tile)
+    _lib.set_tuning("DIFFSAL_CONV16_HALF", waves)
     try:
         got = run()
         name = _lib.load().diffsal_last_gemm_kernel().decode()
     finally:
         _lib.set_tuning("DIFFSAL_FORCE_HALO", None)
         _lib.set_tuning("DIFFSAL_CONV16_TILE", None)
+        _lib.set_tuning("DIFFSAL_CONV16_HALF", None)
     assert "conv16_dma_kernel" in name and ("x 192 channels" in name) == (tile == 1)
     assert ("2 images" in name) == (tile == 0 and Ho * Wo <= 128)
+    if "2 images" not in name and tile == 0:
+        assert (("4x32 pixels" in name) or ("8x16 pixels" in name)) == (waves == 1)
     # the generic kernel on one fixed tile shape WITHOUT a K split (its split sums the K ranges in another order)
     _lib.set_tuning("DIFFSAL_NO_HALO", 1)
     _lib.set_tuning("DIFFSAL_IGEMM16_CFG", 0)

@@ -50,9 +50,10 @@ def main():
         res = torch.randn(N, Ho, Wo, Cout, device=DEV, generator=g).to(dt) if has_res else None
         fl = 2.0 * N * Ho * Wo * 9 * Cin * Cout
         cells, outs = [], []
-        for old, tile in ((1, None), (None, 0), (None, 1), (None, None)):
+        for old, tile, waves in ((1, None, None), (None, 0, 0), (None, 0, 1), (None, None, None)):
             _lib.set_tuning("DIFFSAL_NO_STREAM16", old)
             _lib.set_tuning("DIFFSAL_CONV16_TILE", tile)
+            _lib.set_tuning("DIFFSAL_CONV16_HALF", waves)
             _lib.set_tuning("DIFFSAL_FORCE_HALO", 2 if (old is None and os.environ.get("CD_FORCE")) else None)
             run = lambda: ops.conv_igemm(x, wp, kh=3, kw=3, pad=(pad, pad), dil=(dil, dil), out_hw=(Ho, Wo), scale=sc, shift=sh, residual=res, act=1)
             outs.append(run())
@@ -73,6 +74,7 @@ def main():
         _lib.set_tuning("DIFFSAL_NO_STREAM16", None)
         _lib.set_tuning("DIFFSAL_FORCE_HALO", None)
         _lib.set_tuning("DIFFSAL_CONV16_TILE", None)
+        _lib.set_tuning("DIFFSAL_CONV16_HALF", None)
         print(f"{name} M={N * Ho * Wo:8d} K={9 * Cin:5d} N={Cout:4d} | " + " | ".join(cells) + f" | same bits: {all(torch.equal(outs[0], o) for o in outs[1:])}", flush=True)
 
 
